@@ -1,0 +1,204 @@
+// TEST INFRASTRUCTURE -- not part of the product path.
+//
+// Driver that links the *unmodified* reference decoder (datemoon/ASR-decoder,
+// compiled from the sources where they lie under /root/reference by
+// oracle/Makefile into oracle/_ref/libref_decoder.so) behind a tiny C ABI so
+// that tests and tools can (1) validate oracle/wfst_oracle.c bit for bit and
+// (2) emit the golden vectors under tests/golden/.
+//
+// Only the code in this file is ours; everything it calls is the reference:
+//   Fst::ReadFst                     src/newfst/optimize-fst.h:208-280
+//   OnlineLatticeDecoderMempool      src/my-decoder/online-decoder-mempool-base.h:77
+//   InitDecoding/AdvanceDecoding/FinalizeDecoding/GetBestPath
+//                                    src/my-decoder/online-decoder-base-inl.h:41,631,830,1072
+//   LatticeToVector                  src/newfst/lattice-functions.cc:179-217
+// The decodable below plays the role of Kaldi's DecodableMatrixScaledMapped
+// (kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:107) with the scale pre-applied:
+// LogLikelihood(f, tid) = M[f][tid2pdf[tid]].
+//
+// Never shipped, never imported by the product; `oracle/_ref/` is git-ignored.
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "src/my-decoder/online-decoder-mempool-base.h"
+#include "src/newfst/lattice-functions.h"
+
+using namespace datemoon;
+
+namespace {
+
+class MatrixDecodable : public DecodableInterface {
+ public:
+  MatrixDecodable(const float *m, int T, int stride, const int *tid2pdf, int n_tid)
+      : m_(m), T_(T), stride_(stride), map_(tid2pdf), n_tid_(n_tid), ready_(T) {}
+  float LogLikelihood(int frame, int index) override {
+    int col = map_ ? map_[index] : index;
+    return m_[(size_t)frame * stride_ + col];
+  }
+  bool IsLastFrame(int frame) const override { return frame == T_ - 1; }
+  int NumFramesReady() const override { return ready_; }
+  int NumIndices() const override { return n_tid_; }
+  void SetReady(int r) { ready_ = r; }
+
+ private:
+  const float *m_;
+  int T_, stride_;
+  const int *map_;
+  int n_tid_, ready_;
+};
+
+// Probe subclass: reads protected members, changes no behaviour.
+class ProbeDecoder : public OnlineLatticeDecoderMempool {
+ public:
+  ProbeDecoder(Fst *g, const LatticeFasterDecoderConfig &c) : OnlineLatticeDecoderMempool(g, c) {}
+  int CountFrontier(float *best) const {
+    int n = 0;
+    float b = FLOAT_INF;
+    for (const Elem *e = _toks.GetList(); e != NULL; e = e->tail) {
+      ++n;
+      if (e->val->_tot_cost < b) b = e->val->_tot_cost;
+    }
+    *best = b;
+    return n;
+  }
+  int DumpFrontier(int *states, float *costs, int max_n) const {
+    int n = 0;
+    for (const Elem *e = _toks.GetList(); e != NULL; e = e->tail) {
+      if (n < max_n) {
+        states[n] = e->key;
+        costs[n] = e->val->_tot_cost;
+      }
+      ++n;
+    }
+    return n;
+  }
+  int NumToks() const { return _num_toks; }
+  int NumLinks() const { return _num_links; }
+};
+
+}  // namespace
+
+extern "C" {
+
+struct RefConfig {
+  float beam;
+  int max_active;
+  int min_active;
+  float lattice_beam;
+  int prune_interval;
+  float beam_delta;
+  float hash_ratio;
+  float prune_scale;
+};
+
+void *ref_graph_load(const char *path) {
+  Fst *g = new Fst();
+  if (!g->ReadFst(path)) {
+    delete g;
+    return NULL;
+  }
+  return g;
+}
+
+void ref_graph_free(void *g) { delete static_cast<Fst *>(g); }
+
+void ref_graph_info(void *gp, int *start, int *n_states, int *n_arcs) {
+  Fst *g = static_cast<Fst *>(gp);
+  *start = g->Start();
+  *n_states = g->TotState();
+  *n_arcs = g->TotArc();
+}
+
+// Decode one utterance with the reference decoder.
+//   chunk <= 0 : one AdvanceDecoding call over all T frames (offline CLI shape,
+//                kaldi-hclg-my-decoder.cc:97-109)
+//   chunk  > 0 : NumFramesReady grows by `chunk` per call (streaming shape,
+//                kaldi-online-nnet3-my-decoder.cc:32-46)
+// frame_ntoks/frame_best (nullable, T+1 entries) are filled only when
+// chunk == 1 (frontier after InitDecoding at [0], after frame f at [f+1]).
+// dump_frame >= 0 with chunk == 1 dumps that frontier (index as above) into
+// dump_states/dump_costs (max dump_cap), count into *dump_n.
+// Returns 1 if GetBestPath succeeded, 0 otherwise.
+int ref_decode(void *gp, const RefConfig *rc, const float *loglikes, int T, int stride,
+               const int *tid2pdf, int n_tid, int chunk, int do_finalize, int use_final_probs,
+               int *path_ilabel, int *path_olabel, float *path_graph, float *path_ac,
+               int max_path, int *n_path, float *tot_score, float *lm_score, int *words,
+               int max_words, int *n_words, int *tids, int max_tids, int *n_tids,
+               int *frame_ntoks, float *frame_best, int dump_frame, int *dump_states,
+               float *dump_costs, int dump_cap, int *dump_n, int *num_toks_end,
+               int *num_links_end) {
+  Fst *g = static_cast<Fst *>(gp);
+  LatticeFasterDecoderConfig cfg;
+  cfg._beam = rc->beam;
+  cfg._max_active = rc->max_active;
+  cfg._min_active = rc->min_active;
+  cfg._lattice_beam = rc->lattice_beam;
+  cfg._prune_interval = rc->prune_interval;
+  cfg._beam_delta = rc->beam_delta;
+  cfg._hash_ratio = rc->hash_ratio;
+  cfg._prune_scale = rc->prune_scale;
+
+  ProbeDecoder dec(g, cfg);
+  MatrixDecodable decodable(loglikes, T, stride, tid2pdf, n_tid);
+
+  dec.InitDecoding();
+  if (chunk == 1 && frame_ntoks) frame_ntoks[0] = dec.CountFrontier(&frame_best[0]);
+  if (chunk == 1 && dump_frame == 0 && dump_n)
+    *dump_n = dec.DumpFrontier(dump_states, dump_costs, dump_cap);
+  if (chunk <= 0) {
+    dec.AdvanceDecoding(&decodable);
+  } else {
+    for (int r = 0; r < T;) {
+      r = (r + chunk < T) ? r + chunk : T;
+      decodable.SetReady(r);
+      dec.AdvanceDecoding(&decodable);
+      if (chunk == 1 && frame_ntoks) frame_ntoks[r] = dec.CountFrontier(&frame_best[r]);
+      if (chunk == 1 && dump_frame == r && dump_n)
+        *dump_n = dec.DumpFrontier(dump_states, dump_costs, dump_cap);
+    }
+  }
+  if (do_finalize) dec.FinalizeDecoding();
+  if (num_toks_end) *num_toks_end = dec.NumToks();
+  if (num_links_end) *num_links_end = dec.NumLinks();
+
+  *n_path = 0;
+  *n_words = 0;
+  *n_tids = 0;
+  *tot_score = 0;
+  *lm_score = 0;
+  Lattice best_path;
+  if (!dec.GetBestPath(&best_path, use_final_probs != 0)) return 0;
+
+  // Hop-by-hop dump in forward order (same walk as LatticeToVector).
+  {
+    StateId s = best_path.Start();
+    LatticeState *cur = best_path.GetState(s);
+    int n = 0;
+    while (!cur->IsFinal()) {
+      LatticeArc *arc = cur->GetArc(0);
+      if (n < max_path) {
+        path_ilabel[n] = arc->_input;
+        path_olabel[n] = arc->_output;
+        path_graph[n] = arc->_w.Value1();
+        path_ac[n] = arc->_w.Value2();
+      }
+      ++n;
+      cur = best_path.GetState(arc->_to);
+    }
+    *n_path = n;
+  }
+  std::vector<int> w, p;
+  float tot = 0, lm = 0;
+  if (!LatticeToVector(best_path, w, p, tot, lm)) return 0;
+  *tot_score = tot;
+  *lm_score = lm;
+  *n_words = (int)w.size();
+  *n_tids = (int)p.size();
+  for (int i = 0; i < (int)w.size() && i < max_words; ++i) words[i] = w[i];
+  for (int i = 0; i < (int)p.size() && i < max_tids; ++i) tids[i] = p[i];
+  return 1;
+}
+
+}  // extern "C"

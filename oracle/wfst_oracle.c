@@ -1,0 +1,651 @@
+/*
+ * TEST INFRASTRUCTURE -- CPU oracle for the WFST token-passing hot path.
+ *
+ * A plain-C restatement of the reference algorithm (datemoon/ASR-decoder,
+ * class OnlineLatticeDecoderMempool).  It is the checker for the HIP path: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product never calls it and has no CPU fallback.
+ *
+ * Parity status: PINNED.  The reference has no golden vectors for this path
+ * (SURVEY.md section 4), so the oracle is pinned against the reference decoder
+ * itself, compiled unmodified into oracle/_ref/libref_decoder.so
+ * (oracle/Makefile, oracle/ref_driver.cc): tests/test_oracle_vs_reference.py
+ * requires bit-identical words, transition-ids, per-hop costs and scores, and
+ * tests/golden/ holds reference-generated vectors (tests/golden/make_golden.py)
+ * that this file must reproduce where the reference tree is absent.
+ *
+ * Every function cites the reference lines it follows; paths are relative to
+ * /root/reference/src.  Float arithmetic is single precision, left to right,
+ * no contraction (reference: -O2 -msse2, configure.ac:12-13).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FLOAT_INF (1.0f / 0.0f)
+
+/* ---- graph: newfst/arc.h:17-26, newfst/optimize-fst.h:13-48,226-280 ---- */
+typedef struct { int ilabel, olabel; float w; int to; } Arc;
+typedef struct { unsigned num_arcs, niepsilons, noepsilons; } StateInfo;
+typedef struct {
+  int start, final_state, n_states, n_arcs;
+  StateInfo *si;
+  int64_t *off; /* arc offset of each state (prefix sum of num_arcs) */
+  Arc *arcs;
+} Graph;
+
+/* ---- config: my-decoder/lattice-faster-decoder-conf.h:21-44 ---- */
+typedef struct {
+  float beam; int max_active; int min_active; float lattice_beam;
+  int prune_interval; float beam_delta; float hash_ratio; float prune_scale;
+} Config;
+
+/* ---- tokens and links: my-decoder/online-decoder-base.h:28-84 ---- */
+struct Token;
+typedef struct Link {
+  struct Token *next_tok; int ilabel, olabel; float graph_cost, acoustic_cost;
+  struct Link *next;
+} Link;
+typedef struct Token {
+  float tot_cost, extra_cost; Link *links; struct Token *next; struct Token *backpointer;
+  int is_final; /* stands for membership in _final_costs (value is always 0) */
+  int tie;      /* audit only: an equal-cost rival arrived after this cost was set */
+} Token;
+typedef struct { Token *toks; int must_prune_forward_links, must_prune_tokens; } TokenList;
+
+/* ---- HashList<StateId, Token*>: util/hash-list.h:13-105, hash-list-inl.h:15-173 ---- */
+typedef struct Elem { int key; Token *val; struct Elem *tail; } Elem;
+typedef struct { size_t prev_bucket; Elem *last_elem; } Bucket;
+#define NOBUCKET ((size_t)-1)
+typedef struct {
+  Elem *list_head; size_t bucket_list_tail; size_t hash_size;
+  Bucket *buckets; size_t n_buckets; Elem *freed_head;
+  Elem **blocks; size_t n_blocks, cap_blocks;
+} HashList;
+
+/* simple block pools standing in for MemPool<T> (util/mem-pool.h:17-65); allocation
+ * order has no effect on results */
+typedef struct PoolBlock { struct PoolBlock *next; } PoolBlock;
+typedef struct { void *free_head; PoolBlock *blocks; size_t elem_size; } Pool;
+
+typedef struct {
+  const Graph *g; Config cfg; HashList toks;
+  TokenList *active; int n_active, cap_active;
+  const Elem **queue; size_t n_queue, cap_queue;
+  float *tmp; size_t n_tmp, cap_tmp;
+  Pool tok_pool, link_pool;
+  int num_toks, num_links, warned, finalized, any_final;
+  float final_relative_cost, final_best_cost;
+  int num_frames_decoded;
+  /* decodable (DecodableMatrixScaledMapped with the scale pre-applied) */
+  const float *ll; int T, stride; const int *tid2pdf; int frames_ready;
+  /* work counters for the roofline's algorithmic bytes */
+  int64_t cnt_N, cnt_E, cnt_Z, cnt_tok_created, cnt_link_created;
+} Decoder;
+
+static void *pool_new(Pool *p) {
+  if (!p->free_head) {
+    size_t n = 1024, i;
+    char *blk = (char *)malloc(sizeof(PoolBlock) + n * p->elem_size);
+    ((PoolBlock *)blk)->next = p->blocks; p->blocks = (PoolBlock *)blk;
+    char *base = blk + sizeof(PoolBlock);
+    for (i = 0; i < n; ++i) { *(void **)(base + i * p->elem_size) = p->free_head; p->free_head = base + i * p->elem_size; }
+  }
+  void *r = p->free_head; p->free_head = *(void **)r; return r;
+}
+static void pool_del(Pool *p, void *e) { *(void **)e = p->free_head; p->free_head = e; }
+static void pool_destroy(Pool *p) { while (p->blocks) { PoolBlock *n = p->blocks->next; free(p->blocks); p->blocks = n; } p->free_head = NULL; }
+
+/* ---- HashList ---- */
+static void hl_set_size(HashList *h, size_t size) { /* hash-list-inl.h:15-23 */
+  h->hash_size = size;
+  if (size > h->n_buckets) {
+    h->buckets = (Bucket *)realloc(h->buckets, size * sizeof(Bucket));
+    for (size_t i = h->n_buckets; i < size; ++i) { h->buckets[i].prev_bucket = 0; h->buckets[i].last_elem = NULL; }
+    h->n_buckets = size;
+  }
+}
+static Elem *hl_clear(HashList *h) { /* hash-list-inl.h:25-38 */
+  for (size_t b = h->bucket_list_tail; b != NOBUCKET; b = h->buckets[b].prev_bucket) h->buckets[b].last_elem = NULL;
+  h->bucket_list_tail = NOBUCKET;
+  Elem *ans = h->list_head; h->list_head = NULL; return ans;
+}
+static void hl_delete(HashList *h, Elem *e) { e->tail = h->freed_head; h->freed_head = e; } /* :46-51 */
+static void hl_delete_elems(HashList *h) { /* :53-61 */
+  for (Elem *e = hl_clear(h), *t; e; e = t) { t = e->tail; hl_delete(h, e); }
+}
+static Elem *hl_new(HashList *h) { /* :86-104 */
+  if (!h->freed_head) {
+    size_t n = 1024;
+    Elem *tmp = (Elem *)malloc(n * sizeof(Elem));
+    for (size_t i = 0; i + 1 < n; ++i) tmp[i].tail = tmp + i + 1;
+    tmp[n - 1].tail = NULL; h->freed_head = tmp;
+    if (h->n_blocks == h->cap_blocks) { h->cap_blocks = h->cap_blocks ? 2 * h->cap_blocks : 16; h->blocks = (Elem **)realloc(h->blocks, h->cap_blocks * sizeof(Elem *)); }
+    h->blocks[h->n_blocks++] = tmp;
+  }
+  Elem *a = h->freed_head; h->freed_head = a->tail; return a;
+}
+static Elem *hl_insert(HashList *h, int key, Token *val) { /* hash-list-inl.h:128-173 */
+  size_t index = (size_t)key % h->hash_size;
+  Bucket *b = &h->buckets[index];
+  if (b->last_elem) {
+    Elem *head = (b->prev_bucket == NOBUCKET) ? h->list_head : h->buckets[b->prev_bucket].last_elem->tail;
+    Elem *tail = b->last_elem->tail;
+    for (Elem *e = head; e != tail; e = e->tail) if (e->key == key) return e;
+  }
+  Elem *elem = hl_new(h); elem->key = key; elem->val = val;
+  if (!b->last_elem) {
+    if (h->bucket_list_tail == NOBUCKET) h->list_head = elem;
+    else h->buckets[h->bucket_list_tail].last_elem->tail = elem;
+    elem->tail = NULL; b->last_elem = elem; b->prev_bucket = h->bucket_list_tail; h->bucket_list_tail = index;
+  } else {
+    elem->tail = b->last_elem->tail; b->last_elem->tail = elem; b->last_elem = elem;
+  }
+  return elem;
+}
+
+/* ---- token / link allocation: online-decoder-mempool-base.h:33-74 ---- */
+static Token *new_token(Decoder *d, float tot, float extra, Link *links, Token *next, Token *bp) {
+  Token *t = (Token *)pool_new(&d->tok_pool);
+  t->tot_cost = tot; t->extra_cost = extra; t->links = links; t->next = next; t->backpointer = bp; t->is_final = 0; t->tie = 0;
+  d->num_toks++; d->cnt_tok_created++; return t;
+}
+static Link *new_link(Decoder *d, Token *nt, int il, int ol, float gc, float ac, Link *next) {
+  Link *l = (Link *)pool_new(&d->link_pool);
+  l->next_tok = nt; l->ilabel = il; l->olabel = ol; l->graph_cost = gc; l->acoustic_cost = ac; l->next = next;
+  d->num_links++; d->cnt_link_created++; return l;
+}
+static void delete_token(Decoder *d, Token *t) { pool_del(&d->tok_pool, t); d->num_toks--; }
+static void delete_link(Decoder *d, Link *l) { pool_del(&d->link_pool, l); d->num_links--; }
+static void delete_forward_links(Decoder *d, Token *tok) { /* base-inl.h:8-19 */
+  Link *l = tok->links, *m;
+  while (l) { m = l->next; delete_link(d, l); l = m; }
+  tok->links = NULL;
+}
+
+static inline float loglike(const Decoder *d, int frame, int index) {
+  int col = d->tid2pdf ? d->tid2pdf[index] : index;
+  return d->ll[(size_t)frame * d->stride + col];
+}
+
+static void active_resize(Decoder *d, int n) {
+  if (n > d->cap_active) { d->cap_active = n * 2 + 16; d->active = (TokenList *)realloc(d->active, d->cap_active * sizeof(TokenList)); }
+  for (int i = d->n_active; i < n; ++i) { d->active[i].toks = NULL; d->active[i].must_prune_forward_links = 1; d->active[i].must_prune_tokens = 1; }
+  d->n_active = n;
+}
+
+static void clear_active_tokens(Decoder *d) { /* base-inl.h:69-85 */
+  for (int i = 0; i < d->n_active; ++i)
+    for (Token *tok = d->active[i].toks; tok;) { delete_forward_links(d, tok); Token *n = tok->next; delete_token(d, tok); tok = n; }
+  d->n_active = 0;
+}
+
+/* FindOrAddToken: base-inl.h:88-136 */
+static Elem *find_or_add_token(Decoder *d, int state, int frame_plus_one, float tot_cost, Token *bp, int *changed) {
+  Token **toks = &d->active[frame_plus_one].toks;
+  Elem *e = hl_insert(&d->toks, state, NULL);
+  if (e->val == NULL) {
+    Token *nt = new_token(d, tot_cost, 0.0f, NULL, *toks, bp);
+    *toks = nt; e->val = nt;
+    if (changed) *changed = 1;
+  } else {
+    Token *tok = e->val;
+    if (tok->tot_cost > tot_cost) { tok->tot_cost = tot_cost; tok->backpointer = bp; tok->tie = 0; if (changed) *changed = 1; }
+    else { if (tok->tot_cost == tot_cost) tok->tie = 1; if (changed) *changed = 0; }
+  }
+  return e;
+}
+
+/* k-th smallest (0-based) of a[0,n): the only observable of std::nth_element */
+static float kth_smallest(float *a, int64_t n, int64_t k) {
+  int64_t lo = 0, hi = n - 1;
+  while (lo < hi) {
+    float p = a[lo + (hi - lo) / 2];
+    int64_t i = lo, j = hi;
+    while (i <= j) {
+      while (a[i] < p) ++i;
+      while (a[j] > p) --j;
+      if (i <= j) { float t = a[i]; a[i] = a[j]; a[j] = t; ++i; --j; }
+    }
+    if (k <= j) hi = j;
+    else if (k >= i) lo = i;
+    else return a[k];
+  }
+  return a[k];
+}
+
+/* GetCutoff: base-inl.h:138-234 */
+static float get_cutoff(Decoder *d, Elem *list_head, size_t *tok_count, float *adaptive_beam, Elem **best_elem) {
+  float best_weight = FLOAT_INF;
+  size_t count = 0;
+  const Config *c = &d->cfg;
+  if (c->max_active == 2147483647 && c->min_active == 0) {
+    for (Elem *e = list_head; e; e = e->tail, ++count) {
+      float w = e->val->tot_cost;
+      if (w < best_weight) { best_weight = w; if (best_elem) *best_elem = e; }
+    }
+    if (tok_count) *tok_count = count;
+    if (adaptive_beam) *adaptive_beam = c->beam;
+    return best_weight + c->beam;
+  }
+  d->n_tmp = 0;
+  for (Elem *e = list_head; e; e = e->tail, ++count) {
+    float w = e->val->tot_cost;
+    if (d->n_tmp == d->cap_tmp) { d->cap_tmp = d->cap_tmp ? 2 * d->cap_tmp : 4096; d->tmp = (float *)realloc(d->tmp, d->cap_tmp * sizeof(float)); }
+    d->tmp[d->n_tmp++] = w;
+    if (w < best_weight) { best_weight = w; if (best_elem) *best_elem = e; }
+  }
+  if (tok_count) *tok_count = count;
+  float beam_cutoff = best_weight + c->beam;
+  float min_active_cutoff = FLOAT_INF, max_active_cutoff = FLOAT_INF;
+  if (d->n_tmp > (size_t)c->max_active) max_active_cutoff = kth_smallest(d->tmp, (int64_t)d->n_tmp, (int64_t)c->max_active);
+  if (max_active_cutoff < beam_cutoff) {
+    if (adaptive_beam) *adaptive_beam = max_active_cutoff - best_weight + c->beam_delta;
+    return max_active_cutoff;
+  }
+  if (d->n_tmp > (size_t)c->min_active) {
+    if (c->min_active == 0) min_active_cutoff = best_weight;
+    else /* the k-th smallest of the whole array equals the reference's nth_element over its
+            (already partitioned) prefix [0, max_active) */
+      min_active_cutoff = kth_smallest(d->tmp, (int64_t)d->n_tmp, (int64_t)c->min_active);
+  }
+  if (min_active_cutoff > beam_cutoff) {
+    if (adaptive_beam) *adaptive_beam = min_active_cutoff - best_weight + c->beam_delta;
+    return min_active_cutoff;
+  }
+  if (adaptive_beam) *adaptive_beam = c->beam;
+  return beam_cutoff;
+}
+
+static void possibly_resize_hash(Decoder *d, size_t num_toks) { /* base-inl.h:236-244 */
+  size_t new_sz = (size_t)((float)num_toks * d->cfg.hash_ratio);
+  if (new_sz > d->toks.hash_size) hl_set_size(&d->toks, new_sz);
+}
+
+static void queue_push(Decoder *d, const Elem *e) {
+  if (d->n_queue == d->cap_queue) { d->cap_queue = d->cap_queue ? 2 * d->cap_queue : 1024; d->queue = (const Elem **)realloc(d->queue, d->cap_queue * sizeof(Elem *)); }
+  d->queue[d->n_queue++] = e;
+}
+
+/* ProcessNonemitting: base-inl.h:353-431 */
+static void process_nonemitting(Decoder *d, float cutoff) {
+  const Graph *g = d->g;
+  int frame = d->n_active - 1;
+  if (d->toks.list_head == NULL && !d->warned) d->warned = 1;
+  for (const Elem *e = d->toks.list_head; e; e = e->tail)
+    if (g->si[e->key].niepsilons != 0) queue_push(d, e);
+  while (d->n_queue) {
+    const Elem *elem = d->queue[--d->n_queue];
+    int state = elem->key; Token *tok = elem->val;
+    float cur_cost = tok->tot_cost;
+    if (cur_cost >= cutoff) continue;
+    delete_forward_links(d, tok);
+    const Arc *arcs = g->arcs + g->off[state];
+    unsigned n = g->si[state].num_arcs;
+    for (unsigned i = 0; i < n; ++i) {
+      const Arc *arc = &arcs[i];
+      if (arc->ilabel == 0) {
+        d->cnt_Z++;
+        float graph_cost = arc->w;
+        float tot_cost = cur_cost + graph_cost;
+        if (tot_cost < cutoff) {
+          int changed = 0;
+          Elem *nt = find_or_add_token(d, arc->to, frame, tot_cost, tok, &changed);
+          tok->links = new_link(d, nt->val, 0, arc->olabel, graph_cost, 0, tok->links);
+          if (changed && g->si[arc->to].niepsilons != 0) queue_push(d, nt);
+        }
+      }
+    }
+  }
+}
+
+/* ProcessEmitting: base-inl.h:246-351 */
+static float process_emitting(Decoder *d) {
+  const Graph *g = d->g;
+  int nnetframe = d->num_frames_decoded;
+  int frame = d->n_active - 1;
+  active_resize(d, d->n_active + 1);
+  Elem *final_toks = hl_clear(&d->toks);
+  Elem *best_elem = NULL; float adaptive_beam; size_t tok_cnt = 0;
+  float cur_cutoff = get_cutoff(d, final_toks, &tok_cnt, &adaptive_beam, &best_elem);
+  possibly_resize_hash(d, tok_cnt);
+  float next_cutoff = FLOAT_INF;
+  if (best_elem) {
+    int state = best_elem->key; Token *tok = best_elem->val;
+    const Arc *arcs = g->arcs + g->off[state]; unsigned n = g->si[state].num_arcs;
+    for (unsigned i = 0; i < n; ++i) {
+      const Arc *arc = &arcs[i];
+      if (arc->ilabel != 0) {
+        float tot_score = tok->tot_cost + arc->w - loglike(d, nnetframe, arc->ilabel);
+        if (tot_score + adaptive_beam < next_cutoff) next_cutoff = tot_score + adaptive_beam;
+      }
+    }
+  }
+  for (Elem *e = final_toks, *e_tail; e; e = e_tail) {
+    int state = e->key; Token *tok = e->val;
+    if (tok->tot_cost <= cur_cutoff) {
+      d->cnt_N++;
+      const Arc *arcs = g->arcs + g->off[state]; unsigned n = g->si[state].num_arcs;
+      for (unsigned i = 0; i < n; ++i) {
+        const Arc *arc = &arcs[i];
+        if (arc->ilabel != 0) {
+          d->cnt_E++;
+          float ac_cost = -loglike(d, nnetframe, arc->ilabel);
+          float graph_cost = arc->w;
+          float cur_cost = tok->tot_cost;
+          float tot_cost = cur_cost + ac_cost + graph_cost;
+          if (tot_cost >= next_cutoff) continue;
+          else if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
+          Elem *nt = find_or_add_token(d, arc->to, frame + 1, tot_cost, tok, NULL);
+          tok->links = new_link(d, nt->val, arc->ilabel, arc->olabel, graph_cost, ac_cost, tok->links);
+        }
+      }
+    }
+    e_tail = e->tail;
+    hl_delete(&d->toks, e);
+  }
+  d->num_frames_decoded++;
+  return next_cutoff;
+}
+
+/* PruneForwardLinks: base-inl.h:482-572 */
+static void prune_forward_links(Decoder *d, int fpo, int *extra_costs_changed, int *links_pruned, float delta) {
+  *extra_costs_changed = 0; *links_pruned = 0;
+  if (d->active[fpo].toks == NULL && !d->warned) d->warned = 1;
+  int changed = 1;
+  while (changed) {
+    changed = 0;
+    for (Token *tok = d->active[fpo].toks; tok; tok = tok->next) {
+      Link *link, *prev_link = NULL;
+      float tok_extra_cost = FLOAT_INF;
+      for (link = tok->links; link;) {
+        Token *nt = link->next_tok;
+        float link_extra_cost = nt->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - nt->tot_cost);
+        if (link_extra_cost > d->cfg.lattice_beam) {
+          Link *nl = link->next;
+          if (prev_link) prev_link->next = nl; else tok->links = nl;
+          delete_link(d, link); link = nl; *links_pruned = 1;
+        } else {
+          if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;
+          if (link_extra_cost < tok_extra_cost) tok_extra_cost = link_extra_cost;
+          prev_link = link; link = link->next;
+        }
+      }
+      if (fabsf(tok_extra_cost - tok->extra_cost) > delta) changed = 1;
+      tok->extra_cost = tok_extra_cost;
+    }
+    if (changed) *extra_costs_changed = 1;
+  }
+}
+
+/* PruneTokensForFrame: base-inl.h:578-607 */
+static void prune_tokens_for_frame(Decoder *d, int fpo) {
+  Token **toks = &d->active[fpo].toks;
+  Token *tok, *next_tok, *prev_tok = NULL;
+  for (tok = *toks; tok; tok = next_tok) {
+    next_tok = tok->next;
+    if (tok->extra_cost == FLOAT_INF) {
+      if (prev_tok) prev_tok->next = tok->next; else *toks = tok->next;
+      delete_token(d, tok);
+    } else prev_tok = tok;
+  }
+}
+
+/* PruneActiveTokens: base-inl.h:438-480 */
+static void prune_active_tokens(Decoder *d, float delta) {
+  int cur = d->n_active - 1;
+  for (int f = cur - 1; f >= 0; f--) {
+    if (d->active[f].must_prune_forward_links) {
+      int links_pruned = 0, extra_costs_changed = 0;
+      prune_forward_links(d, f, &extra_costs_changed, &links_pruned, delta);
+      if (extra_costs_changed && f > 0) d->active[f - 1].must_prune_forward_links = 1;
+      if (links_pruned) d->active[f].must_prune_tokens = 1;
+      d->active[f].must_prune_forward_links = 0;
+    }
+    if (f + 1 < cur && d->active[f + 1].must_prune_tokens) {
+      prune_tokens_for_frame(d, f + 1);
+      d->active[f + 1].must_prune_tokens = 0;
+    }
+  }
+}
+
+/* ComputeFinalCosts: base-inl.h:670-720.  mark != 0 fills the final-cost set. */
+static void compute_final_costs(Decoder *d, int mark, int *any_final, float *final_relative_cost, float *final_best_cost) {
+  float best_cost = FLOAT_INF, best_cost_with_final = FLOAT_INF;
+  int any = 0;
+  for (const Elem *e = d->toks.list_head; e; e = e->tail) {
+    Token *tok = e->val;
+    int fst_final = (e->key == d->g->final_state);
+    if (tok->tot_cost < best_cost) best_cost = tok->tot_cost;
+    if (mark) tok->is_final = 0;
+    if (mark && fst_final) { tok->is_final = 1; any = 1; if (tok->tot_cost < best_cost_with_final) best_cost_with_final = tok->tot_cost; }
+  }
+  if (any_final) *any_final = any;
+  if (final_relative_cost) {
+    if (best_cost == FLOAT_INF && best_cost_with_final == FLOAT_INF) *final_relative_cost = FLOAT_INF;
+    else *final_relative_cost = best_cost_with_final - best_cost;
+  }
+  if (final_best_cost) *final_best_cost = (best_cost_with_final != FLOAT_INF) ? best_cost_with_final : best_cost;
+}
+
+/* PruneForwardLinksFinal: base-inl.h:725-824 */
+static void prune_forward_links_final(Decoder *d) {
+  int fpo = d->n_active - 1;
+  compute_final_costs(d, 1, &d->any_final, &d->final_relative_cost, &d->final_best_cost);
+  d->finalized = 1;
+  hl_delete_elems(&d->toks);
+  int changed = 1; float delta = 1.0e-5f;
+  while (changed) {
+    changed = 0;
+    for (Token *tok = d->active[fpo].toks; tok; tok = tok->next) {
+      Link *link, *prev_link = NULL;
+      float final_cost = !d->any_final ? 0.0f : (tok->is_final ? 0.0f : FLOAT_INF);
+      float tok_extra_cost = tok->tot_cost + final_cost - d->final_best_cost;
+      for (link = tok->links; link;) {
+        Token *nt = link->next_tok;
+        float link_extra_cost = nt->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - nt->tot_cost);
+        if (link_extra_cost > d->cfg.lattice_beam) {
+          Link *nl = link->next;
+          if (prev_link) prev_link->next = nl; else tok->links = nl;
+          delete_link(d, link); link = nl;
+        } else {
+          if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;
+          if (link_extra_cost < tok_extra_cost) tok_extra_cost = link_extra_cost;
+          prev_link = link; link = link->next;
+        }
+      }
+      if (tok_extra_cost > d->cfg.lattice_beam) tok_extra_cost = FLOAT_INF;
+      if (fabsf(tok->extra_cost - tok_extra_cost) > delta) changed = 1;
+      tok->extra_cost = tok_extra_cost;
+    }
+  }
+}
+
+/* FinalizeDecoding: base-inl.h:829-847 */
+static void finalize_decoding(Decoder *d) {
+  int final_fpo = d->n_active - 1;
+  prune_forward_links_final(d);
+  for (int f = final_fpo - 1; f >= 0; --f) {
+    int b1, b2;
+    prune_forward_links(d, f, &b1, &b2, 0.0f);
+    prune_tokens_for_frame(d, f + 1);
+  }
+  prune_tokens_for_frame(d, 0);
+}
+
+/* InitDecoding: base-inl.h:40-67 */
+static void init_decoding(Decoder *d) {
+  clear_active_tokens(d);
+  hl_delete_elems(&d->toks);
+  d->n_queue = 0; d->n_tmp = 0; d->warned = 0; d->finalized = 0; d->any_final = 0;
+  active_resize(d, 1);
+  Token *start_tok = new_token(d, 0.0f, 0.0f, NULL, NULL, NULL);
+  d->active[0].toks = start_tok;
+  hl_insert(&d->toks, d->g->start, start_tok);
+  d->num_frames_decoded = 0; /* set before the closure: it is not read there */
+  process_nonemitting(d, d->cfg.beam);
+  d->num_frames_decoded = 0;
+}
+
+/* AdvanceDecoding: base-inl.h:630-668 */
+static void advance_decoding(Decoder *d, int max_num_frames) {
+  int target = d->frames_ready;
+  if (max_num_frames >= 0 && d->num_frames_decoded + max_num_frames < target) target = d->num_frames_decoded + max_num_frames;
+  while (d->num_frames_decoded < target) {
+    if ((d->n_active - 1) % d->cfg.prune_interval == 0) prune_active_tokens(d, d->cfg.lattice_beam * d->cfg.prune_scale);
+    float cutoff = process_emitting(d);
+    process_nonemitting(d, cutoff);
+  }
+}
+
+/* ---- graph loading ---- */
+static void graph_index(Graph *g) {
+  g->off = (int64_t *)malloc(((size_t)g->n_states + 1) * sizeof(int64_t));
+  int64_t o = 0;
+  for (int i = 0; i < g->n_states; ++i) { g->off[i] = o; o += g->si[i].num_arcs; }
+  g->off[g->n_states] = o;
+}
+
+void *oracle_graph_load(const char *path) { /* Fst::ReadFst, newfst/optimize-fst.h:226-280 */
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return NULL;
+  int hdr[6];
+  if (fread(hdr, sizeof(int), 6, fp) != 6) { fclose(fp); return NULL; }
+  Graph *g = (Graph *)calloc(1, sizeof(Graph));
+  g->start = hdr[0]; g->final_state = hdr[1]; g->n_states = hdr[2]; g->n_arcs = hdr[3];
+  g->si = (StateInfo *)malloc((size_t)g->n_states * sizeof(StateInfo));
+  g->arcs = (Arc *)malloc((size_t)g->n_arcs * sizeof(Arc) + 16);
+  int ok = fread(g->si, sizeof(StateInfo), g->n_states, fp) == (size_t)g->n_states &&
+           fread(g->arcs, sizeof(Arc), g->n_arcs, fp) == (size_t)g->n_arcs;
+  fclose(fp);
+  if (ok) { graph_index(g); if (g->off[g->n_states] != g->n_arcs) ok = 0; }
+  if (!ok) { free(g->si); free(g->arcs); free(g->off); free(g); return NULL; }
+  return g;
+}
+
+void oracle_graph_free(void *gp) {
+  Graph *g = (Graph *)gp; if (!g) return;
+  free(g->si); free(g->arcs); free(g->off); free(g);
+}
+
+/* Decode one utterance.  Same argument list and meaning as ref_decode() in
+ * oracle/ref_driver.cc; `extra` (nullable, 8 x int64) receives
+ * {N, E, Z, tokens created, links created, tie hops on best path, quirk hops, 0}. */
+int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, int stride,
+                     const int *tid2pdf, int n_tid, int chunk, int do_finalize, int use_final_probs,
+                     int *path_ilabel, int *path_olabel, float *path_graph, float *path_ac,
+                     int max_path, int *n_path, float *tot_score, float *lm_score, int *words,
+                     int max_words, int *n_words, int *tids, int max_tids, int *n_tids,
+                     int *frame_ntoks, float *frame_best, int dump_frame, int *dump_states,
+                     float *dump_costs, int dump_cap, int *dump_n, int *num_toks_end,
+                     int *num_links_end, int64_t *extra) {
+  (void)n_tid;
+  Decoder D; memset(&D, 0, sizeof(D));
+  Decoder *d = &D;
+  d->g = (const Graph *)gp; d->cfg = *rc;
+  d->toks.bucket_list_tail = NOBUCKET;
+  d->tok_pool.elem_size = sizeof(Token); d->link_pool.elem_size = sizeof(Link);
+  d->ll = loglikes; d->T = T; d->stride = stride; d->tid2pdf = tid2pdf; d->frames_ready = T;
+  /* ctor: base-inl.h:27 (the reference would ask for ~68 GB with max_active=INT_MAX; the
+   * oracle caps the *initial* size there, which the reference cannot run at all) */
+  {
+    float fs = (float)rc->max_active * rc->hash_ratio;
+    size_t sz = fs > 1.0e9f ? (size_t)1000 : (size_t)fs;
+    hl_set_size(&d->toks, sz);
+  }
+#define FRONTIER_STATS(idx) do { if (chunk == 1 && frame_ntoks) { int n_ = 0; float b_ = FLOAT_INF; \
+    for (const Elem *e_ = d->toks.list_head; e_; e_ = e_->tail) { ++n_; if (e_->val->tot_cost < b_) b_ = e_->val->tot_cost; } \
+    frame_ntoks[idx] = n_; frame_best[idx] = b_; } \
+    if (chunk == 1 && dump_frame == (idx) && dump_n) { int n_ = 0; \
+    for (const Elem *e_ = d->toks.list_head; e_; e_ = e_->tail) { if (n_ < dump_cap) { dump_states[n_] = e_->key; dump_costs[n_] = e_->val->tot_cost; } ++n_; } \
+    *dump_n = n_; } } while (0)
+
+  init_decoding(d);
+  FRONTIER_STATS(0);
+  if (chunk <= 0) { advance_decoding(d, -1); }
+  else {
+    for (int r = 0; r < T;) {
+      r = (r + chunk < T) ? r + chunk : T;
+      d->frames_ready = r;
+      advance_decoding(d, -1);
+      FRONTIER_STATS(r);
+    }
+  }
+  if (do_finalize) finalize_decoding(d);
+  if (num_toks_end) *num_toks_end = d->num_toks;
+  if (num_links_end) *num_links_end = d->num_links;
+
+  *n_path = 0; *n_words = 0; *n_tids = 0; *tot_score = 0; *lm_score = 0;
+  int ok = 0;
+  int64_t tie_hops = 0, quirk_hops = 0;
+  /* BestPathEnd: base-inl.h:1096-1158 */
+  if (d->n_active - 1 > 0) {
+    int any_final = d->any_final;
+    if (!d->finalized && use_final_probs) compute_final_costs(d, 1, &any_final, NULL, NULL);
+    float best_cost = FLOAT_INF; Token *best_tok = NULL;
+    for (Token *tok = d->active[d->n_active - 1].toks; tok; tok = tok->next) {
+      float cost = tok->tot_cost;
+      if (use_final_probs && any_final) { if (!tok->is_final) cost = FLOAT_INF; }
+      if (cost < best_cost) { best_cost = cost; best_tok = tok; }
+    }
+    if (best_tok) {
+      /* GetBestPath + TraceBackBestPath: base-inl.h:1071-1094,1160-1200.  Hops come out last
+       * to first; the lattice is walked start->final by LatticeToVector, i.e. reversed. */
+      int cap = 1024, n = 0;
+      int *hi = (int *)malloc(cap * sizeof(int)), *ho = (int *)malloc(cap * sizeof(int));
+      float *hg = (float *)malloc(cap * sizeof(float)), *ha = (float *)malloc(cap * sizeof(float));
+      for (Token *tok = best_tok; tok;) {
+        int il = 0, ol = 0; float gc = 0.0f, ac = 0.0f;
+        if (tok->tie) tie_hops++;
+        if (tok->backpointer) {
+          Link *link;
+          for (link = tok->backpointer->links; link; link = link->next)
+            if (link->next_tok == tok) { il = link->ilabel; ol = link->olabel; gc = link->graph_cost; ac = link->acoustic_cost; break; }
+          if (link && (tok->backpointer->tot_cost + ac) + gc != tok->tot_cost) quirk_hops++;
+        }
+        if (n == cap) { cap *= 2; hi = (int *)realloc(hi, cap * sizeof(int)); ho = (int *)realloc(ho, cap * sizeof(int)); hg = (float *)realloc(hg, cap * sizeof(float)); ha = (float *)realloc(ha, cap * sizeof(float)); }
+        hi[n] = il; ho[n] = ol; hg[n] = gc; ha[n] = ac; ++n;
+        tok = tok->backpointer;
+      }
+      /* LatticeToVector: newfst/lattice-functions.cc:179-217 */
+      float tot = 0, lm = 0; int nw = 0, nt = 0;
+      for (int k = n - 1, j = 0; k >= 0; --k, ++j) {
+        if (j < max_path) { path_ilabel[j] = hi[k]; path_olabel[j] = ho[k]; path_graph[j] = hg[k]; path_ac[j] = ha[k]; }
+        if (hi[k] != 0) { if (nt < max_tids) tids[nt] = hi[k]; nt++; }
+        if (ho[k] != 0) { if (nw < max_words) words[nw] = ho[k]; nw++; }
+        lm += hg[k];
+        tot += hg[k] + ha[k];
+      }
+      *n_path = n; *n_words = nw; *n_tids = nt; *tot_score = tot; *lm_score = lm;
+      free(hi); free(ho); free(hg); free(ha);
+      ok = 1;
+    }
+  }
+  if (extra) { extra[0] = d->cnt_N; extra[1] = d->cnt_E; extra[2] = d->cnt_Z; extra[3] = d->cnt_tok_created; extra[4] = d->cnt_link_created; extra[5] = tie_hops; extra[6] = quirk_hops; extra[7] = 0; }
+
+  /* teardown */
+  clear_active_tokens(d);
+  hl_delete_elems(&d->toks);
+  for (size_t i = 0; i < d->toks.n_blocks; ++i) free(d->toks.blocks[i]);
+  free(d->toks.blocks); free(d->toks.buckets);
+  pool_destroy(&d->tok_pool); pool_destroy(&d->link_pool);
+  free(d->active); free(d->queue); free(d->tmp);
+  return ok;
+}
+
+int oracle_decode(void *gp, const Config *rc, const float *loglikes, int T, int stride,
+                  const int *tid2pdf, int n_tid, int chunk, int do_finalize, int use_final_probs,
+                  int *path_ilabel, int *path_olabel, float *path_graph, float *path_ac,
+                  int max_path, int *n_path, float *tot_score, float *lm_score, int *words,
+                  int max_words, int *n_words, int *tids, int max_tids, int *n_tids,
+                  int *frame_ntoks, float *frame_best, int dump_frame, int *dump_states,
+                  float *dump_costs, int dump_cap, int *dump_n, int *num_toks_end,
+                  int *num_links_end) {
+  return oracle_decode_ex(gp, rc, loglikes, T, stride, tid2pdf, n_tid, chunk, do_finalize,
+                          use_final_probs, path_ilabel, path_olabel, path_graph, path_ac, max_path,
+                          n_path, tot_score, lm_score, words, max_words, n_words, tids, max_tids,
+                          n_tids, frame_ntoks, frame_best, dump_frame, dump_states, dump_costs,
+                          dump_cap, dump_n, num_toks_end, num_links_end, NULL);
+}

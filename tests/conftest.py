@@ -1,0 +1,38 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("asr-decoder_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import pyoracle
+
+    pyoracle.build_oracle()
+    return pyoracle.OracleDecoder()
+
+
+@pytest.fixture(scope="session")
+def refdec():
+    import pyoracle
+
+    if os.path.isdir("/root/reference/src"):
+        pyoracle.build_ref()
+    if not os.path.exists(pyoracle.REF_SO):
+        pytest.skip("oracle/_ref/libref_decoder.so not built (reference tree absent)")
+    return pyoracle.RefDecoder()
