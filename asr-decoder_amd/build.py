@@ -1,0 +1,40 @@
+"""Build libwfstdec.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU.  The result is asr-decoder_amd/lib/libwfstdec.so; it is
+git-ignored (history stays source-only) but travels with the repo snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRCS = [os.path.join(HERE, "csrc", "wfst_kernels.hip"), os.path.join(HERE, "csrc", "wfst_capi.cc")]
+HDRS = [os.path.join(HERE, "csrc", "wfst_device.h"), os.path.join(HERE, "..", "include", "wfst_decoder.h")]
+LIB = os.path.join(HERE, "lib", "libwfstdec.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: the search must round like the reference (no FMA; configure.ac:12-13)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(p) <= t for p in SRCS + HDRS + [os.path.abspath(__file__)])
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + SRCS
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

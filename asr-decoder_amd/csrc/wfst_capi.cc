@@ -1,0 +1,720 @@
+// C ABI (include/wfst_decoder.h) of the MI355X-native batched WFST decoder: graph upload,
+// per-batch device state, the frame loop that enqueues the HIP kernels.  Host C++; compiled by
+// hipcc together with wfst_kernels.hip into libwfstdec.so.  No CPU decoding path exists here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wfst_decoder.h"
+#include "wfst_device.h"
+
+using namespace wfst;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(WFST_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+}  // namespace
+
+struct wfst_graph {
+  int device = 0;
+  int32_t start = 0, final_state = 0, n_states = 0, n_arcs = 0;
+  int32_t max_col = 0;  // largest log-likelihood column any arc reads
+  std::vector<int32_t> ilabel_host;  // original ilabels (re-mapped when tid2pdf changes)
+  DevBuf<uint2> state_info;
+  DevBuf<int4> arcs;
+  DevBuf<int32_t> arc_ilabel, arc_src;
+  GraphDev view() const {
+    GraphDev g;
+    g.state_info = state_info.p;
+    g.arcs = arcs.p;
+    g.arc_ilabel = arc_ilabel.p;
+    g.arc_src = arc_src.p;
+    g.start = start;
+    g.final_state = final_state;
+    g.n_states = n_states;
+    g.n_arcs = n_arcs;
+    return g;
+  }
+  ~wfst_graph() {
+    state_info.release();
+    arcs.release();
+    arc_ilabel.release();
+    arc_src.release();
+  }
+};
+
+struct wfst_decoder {
+  const wfst_graph *graph = nullptr;
+  int device = 0;
+  wfst_config cfg;
+  int32_t n_channels = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  DecoderDev D;
+  DevBuf<ChanCtl> ctl;
+  DevBuf<int4> tok;
+  DevBuf<int32_t> frame_off, keys, toki, occ, front_slot, worklist, target, chan_list;
+  DevBuf<float> cutoff_hist;
+  DevBuf<unsigned long long> vals;
+  DevBuf<const float *> ll_base;
+  // host mirrors (the frame loop is deterministic, so the host knows these without a read-back)
+  std::vector<int32_t> h_decoded, h_target, h_state;  // state: 0 = never inited, 1 = decoding, 2 = finalized
+  std::vector<const float *> h_ll_base;
+  // pinned staging
+  int32_t *p_target = nullptr, *p_chan = nullptr;
+  const float **p_ll = nullptr;
+  ChanCtl *p_ctl = nullptr;
+  // best-path output buffers (device), grown on demand
+  DevBuf<int32_t> bp_il, bp_ol, bp_n;
+  DevBuf<float> bp_g, bp_ac;
+  // host-fed log-likelihood history (advance_host)
+  std::vector<float *> hist_dev;
+  std::vector<size_t> hist_rows_cap;
+  std::vector<int32_t> hist_rows;
+  int32_t hist_stride = 0;
+  int tiles_per_channel = 16;
+
+  ~wfst_decoder() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (float *p : hist_dev)
+      if (p) (void)hipFree(p);
+    if (p_target) (void)hipHostFree(p_target);
+    if (p_chan) (void)hipHostFree(p_chan);
+    if (p_ll) (void)hipHostFree((void *)p_ll);
+    if (p_ctl) (void)hipHostFree(p_ctl);
+    ctl.release(); tok.release(); frame_off.release(); keys.release(); toki.release(); occ.release();
+    front_slot.release(); worklist.release(); target.release(); chan_list.release(); cutoff_hist.release();
+    vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_g.release();
+    bp_ac.release();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+extern "C" {
+
+void wfst_config_default(wfst_config *c) {  // lattice-faster-decoder-conf.h:35-44
+  c->beam = 16.0f;
+  c->max_active = 2147483647;
+  c->min_active = 200;
+  c->lattice_beam = 10.0f;
+  c->prune_interval = 25;
+  c->beam_delta = 0.5f;
+  c->hash_ratio = 2.0f;
+  c->prune_scale = 0.1f;
+}
+
+const char *wfst_last_error(void) { return g_err.c_str(); }
+
+int wfst_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+/* ---------------------------------------------------------------- graph */
+
+static int upload_arcs(wfst_graph *g, const wfst_state_info *states, const wfst_arc *arcs,
+                       const int32_t *tid2pdf, int32_t n_tid) {
+  const int32_t S = g->n_states, A = g->n_arcs;
+  std::vector<int4> h_arcs((size_t)A);
+  int32_t max_col = 0;
+  for (int32_t a = 0; a < A; ++a) {
+    const int32_t il = g->ilabel_host[a];
+    int32_t col = -1;
+    if (il != 0) {
+      if (tid2pdf) {
+        if (il < 0 || il > n_tid) return fail(WFST_E_ARG, "arc ilabel outside tid2pdf range");
+        col = tid2pdf[il];
+      } else {
+        col = il;
+      }
+      if (col < 0) return fail(WFST_E_ARG, "negative log-likelihood column");
+      max_col = std::max(max_col, col);
+    }
+    int4 v;
+    v.x = col;
+    if (arcs) {
+      v.y = arcs[a].olabel;
+      memcpy(&v.z, &arcs[a].weight, 4);
+      v.w = arcs[a].nextstate;
+      h_arcs[a] = v;
+    } else {
+      h_arcs[a].x = col;  // only the column changes (set_tid2pdf)
+    }
+  }
+  (void)S;
+  (void)states;
+  if (arcs) {
+    HIP_TRY(hipMemcpy(g->arcs.p, h_arcs.data(), (size_t)A * sizeof(int4), hipMemcpyHostToDevice));
+  } else {
+    // read-modify-write of column x only
+    std::vector<int4> cur((size_t)A);
+    HIP_TRY(hipMemcpy(cur.data(), g->arcs.p, (size_t)A * sizeof(int4), hipMemcpyDeviceToHost));
+    for (int32_t a = 0; a < A; ++a) cur[a].x = h_arcs[a].x;
+    HIP_TRY(hipMemcpy(g->arcs.p, cur.data(), (size_t)A * sizeof(int4), hipMemcpyHostToDevice));
+  }
+  g->max_col = max_col;
+  return WFST_OK;
+}
+
+int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states, int32_t n_arcs,
+                           const wfst_state_info *states, const wfst_arc *arcs, int device,
+                           wfst_graph **out) {
+  if (!out) return fail(WFST_E_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_states <= 0 || n_arcs < 0 || !states || (n_arcs > 0 && !arcs))
+    return fail(WFST_E_ARG, "empty graph or NULL arrays");
+  if (start < 0 || start >= n_states) return fail(WFST_E_ARG, "start state out of range");
+  int ndev = wfst_device_count();
+  if (ndev <= 0) return fail(WFST_E_DEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(WFST_E_ARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+
+  std::vector<uint2> h_si((size_t)n_states);
+  std::vector<int32_t> h_src((size_t)n_arcs);
+  std::vector<int32_t> h_il((size_t)n_arcs);
+  int64_t off = 0;
+  for (int32_t s = 0; s < n_states; ++s) {
+    const uint32_t na = states[s].num_arcs, ne = states[s].niepsilons;
+    if (ne > na || off + na > n_arcs) return fail(WFST_E_FORMAT, "state arc counts inconsistent with total_arcs");
+    if (ne > kEpsMask) return fail(WFST_E_FORMAT, "state with more than 4095 input-epsilon arcs");
+    if (na - ne >= (1u << (32 - kEpsBits))) return fail(WFST_E_FORMAT, "state with 2^20 or more emitting arcs");
+    for (uint32_t i = 0; i < na; ++i) {
+      const wfst_arc &a = arcs[off + i];
+      if ((i < ne) != (a.ilabel == 0))
+        return fail(WFST_E_FORMAT, "input-epsilon arcs must precede a state's other arcs (reference flat format)");
+      if (a.nextstate < 0 || a.nextstate >= n_states) return fail(WFST_E_FORMAT, "arc nextstate out of range");
+      h_src[off + i] = (int32_t)((uint32_t)s | (i < ne ? 0x80000000u : 0u));
+      h_il[off + i] = a.ilabel;
+    }
+    h_si[s] = make_uint2((uint32_t)off, ((na - ne) << kEpsBits) | ne);
+    off += na;
+  }
+  if (off != n_arcs) return fail(WFST_E_FORMAT, "sum of num_arcs != total_arcs");
+
+  wfst_graph *g = new wfst_graph();
+  g->device = device;
+  g->start = start;
+  g->final_state = final_state;
+  g->n_states = n_states;
+  g->n_arcs = n_arcs;
+  g->ilabel_host.swap(h_il);
+  hipError_t e;
+  if ((e = g->state_info.alloc(n_states)) != hipSuccess || (e = g->arcs.alloc(n_arcs)) != hipSuccess ||
+      (e = g->arc_ilabel.alloc(n_arcs)) != hipSuccess || (e = g->arc_src.alloc(n_arcs)) != hipSuccess) {
+    delete g;
+    return fail(WFST_E_DEVICE, std::string("hipMalloc(graph): ") + hipGetErrorString(e));
+  }
+  int rc = WFST_OK;
+  if (hipMemcpy(g->state_info.p, h_si.data(), h_si.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(g->arc_src.p, h_src.data(), h_src.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(g->arc_ilabel.p, g->ilabel_host.data(), g->ilabel_host.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(WFST_E_DEVICE, "hipMemcpy(graph) failed");
+  if (rc == WFST_OK) rc = upload_arcs(g, states, arcs, nullptr, 0);
+  if (rc != WFST_OK) {
+    delete g;
+    return rc;
+  }
+  *out = g;
+  return WFST_OK;
+}
+
+int wfst_graph_load(const char *path, int device, wfst_graph **out) {
+  if (!path || !out) return fail(WFST_E_ARG, "NULL argument");
+  *out = nullptr;
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return fail(WFST_E_IO, std::string("cannot open ") + path);
+  int32_t hdr[6];
+  if (fread(hdr, 4, 6, fp) != 6) {
+    fclose(fp);
+    return fail(WFST_E_IO, "truncated header");
+  }
+  const int32_t S = hdr[2], A = hdr[3];
+  if (S <= 0 || A < 0) {
+    fclose(fp);
+    return fail(WFST_E_IO, "bad header");
+  }
+  std::vector<wfst_state_info> si((size_t)S);
+  std::vector<wfst_arc> arcs((size_t)A);
+  bool ok = fread(si.data(), sizeof(wfst_state_info), S, fp) == (size_t)S &&
+            fread(arcs.data(), sizeof(wfst_arc), A, fp) == (size_t)A;
+  fclose(fp);
+  if (!ok) return fail(WFST_E_IO, "truncated graph file");
+  return wfst_graph_from_arrays(hdr[0], hdr[1], S, A, si.data(), arcs.data(), device, out);
+}
+
+int wfst_graph_set_tid2pdf(wfst_graph *g, const int32_t *tid2pdf, int32_t n_tid) {
+  if (!g) return fail(WFST_E_ARG, "NULL graph");
+  HIP_TRY(hipSetDevice(g->device));
+  return upload_arcs(g, nullptr, nullptr, tid2pdf, n_tid);
+}
+
+int wfst_graph_info(const wfst_graph *g, int32_t *start, int32_t *final_state, int32_t *n_states,
+                    int32_t *n_arcs, int64_t *device_bytes) {
+  if (!g) return fail(WFST_E_ARG, "NULL graph");
+  if (start) *start = g->start;
+  if (final_state) *final_state = g->final_state;
+  if (n_states) *n_states = g->n_states;
+  if (n_arcs) *n_arcs = g->n_arcs;
+  if (device_bytes)
+    *device_bytes = (int64_t)(g->state_info.bytes() + g->arcs.bytes() + g->arc_ilabel.bytes() + g->arc_src.bytes());
+  return WFST_OK;
+}
+
+void wfst_graph_free(wfst_graph *g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  delete g;
+}
+
+/* -------------------------------------------------------------- decoder */
+
+static int check_config(const wfst_config *c) {  // LatticeFasterDecoderConfig::Check, conf.h:62-67
+  if (!(c->beam > 0.0f && c->max_active > 1 && c->lattice_beam > 0.0f && c->prune_interval > 0 &&
+        c->beam_delta > 0.0f && c->hash_ratio >= 1.0f && c->prune_scale > 0.0f && c->prune_scale < 1.0f))
+    return fail(WFST_E_ARG, "invalid decoder config (LatticeFasterDecoderConfig::Check)");
+  if (c->min_active < 0) return fail(WFST_E_ARG, "min_active < 0");
+  return WFST_OK;
+}
+
+int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
+                        const wfst_limits *limits, void *hip_stream, wfst_decoder **out) {
+  if (!out) return fail(WFST_E_ARG, "out is NULL");
+  *out = nullptr;
+  if (!g || !cfg || n_channels <= 0) return fail(WFST_E_ARG, "NULL graph/config or n_channels <= 0");
+  int rc = check_config(cfg);
+  if (rc != WFST_OK) return rc;
+  HIP_TRY(hipSetDevice(g->device));
+  wfst_limits L = {0, 0, 0};
+  if (limits) L = *limits;
+  if (L.max_frames <= 0) L.max_frames = 4096;
+  if (L.max_tokens_per_frame <= 0) L.max_tokens_per_frame = 32768;
+  if (L.arena_tokens <= 0) L.arena_tokens = 4194304;
+  if (L.arena_tokens > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "arena_tokens must fit int32");
+  int log2cap = 4;
+  while ((1ll << log2cap) < 2ll * L.max_tokens_per_frame) ++log2cap;
+  if (log2cap > 30) return fail(WFST_E_ARG, "max_tokens_per_frame too large");
+
+  wfst_decoder *d = new wfst_decoder();
+  d->graph = g;
+  d->device = g->device;
+  d->cfg = *cfg;
+  d->n_channels = n_channels;
+  if (hip_stream) {
+    d->stream = (hipStream_t)hip_stream;
+  } else {
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete d;
+      return fail(WFST_E_DEVICE, "hipStreamCreate failed");
+    }
+    d->own_stream = true;
+  }
+  const size_t B = (size_t)n_channels, cap = (size_t)1 << log2cap;
+  const size_t fo = (size_t)L.max_frames + 2;
+  hipError_t e = hipSuccess;
+  auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  A(d->ctl.alloc(B));
+  A(d->tok.alloc(B * (size_t)L.arena_tokens));
+  A(d->frame_off.alloc(B * fo));
+  A(d->cutoff_hist.alloc(B * fo));
+  A(d->keys.alloc(B * 2 * cap));
+  A(d->vals.alloc(B * 2 * cap));
+  A(d->toki.alloc(B * 2 * cap));
+  A(d->occ.alloc(B * 2 * cap));
+  A(d->front_slot.alloc(B * (size_t)L.max_tokens_per_frame));
+  A(d->worklist.alloc(B * 2 * (size_t)L.max_tokens_per_frame));
+  A(d->target.alloc(B));
+  A(d->chan_list.alloc(B));
+  A(d->ll_base.alloc(B));
+  A(hipHostMalloc((void **)&d->p_target, B * 4));
+  A(hipHostMalloc((void **)&d->p_chan, B * 4));
+  A(hipHostMalloc((void **)&d->p_ll, B * sizeof(float *)));
+  A(hipHostMalloc((void **)&d->p_ctl, B * sizeof(ChanCtl)));
+  if (e == hipSuccess) A(hipMemsetAsync(d->ctl.p, 0, d->ctl.bytes(), d->stream));
+  if (e == hipSuccess) A(hipMemsetAsync(d->target.p, 0, d->target.bytes(), d->stream));
+  if (e == hipSuccess) A(hipMemsetAsync(d->ll_base.p, 0, d->ll_base.bytes(), d->stream));
+  if (e == hipSuccess) A(hipStreamSynchronize(d->stream));
+  if (e != hipSuccess) {
+    delete d;
+    return fail(WFST_E_DEVICE, std::string("decoder allocation failed: ") + hipGetErrorString(e));
+  }
+  DecoderDev &D = d->D;
+  D.g = g->view();
+  D.ctl = d->ctl.p;
+  D.tok = d->tok.p;
+  D.frame_off = d->frame_off.p;
+  D.cutoff_hist = d->cutoff_hist.p;
+  D.keys = d->keys.p;
+  D.vals = d->vals.p;
+  D.toki = d->toki.p;
+  D.occ = d->occ.p;
+  D.front_slot = d->front_slot.p;
+  D.worklist = d->worklist.p;
+  D.ll_base = d->ll_base.p;
+  D.n_channels = n_channels;
+  D.stride = 0;
+  D.cap = (int32_t)cap;
+  D.log2cap = log2cap;
+  D.max_tok = L.max_tokens_per_frame;
+  D.wl_cap = L.max_tokens_per_frame;
+  D.max_frames = L.max_frames;
+  D.arena_cap = L.arena_tokens;
+  D.beam = cfg->beam;
+  D.lattice_beam = cfg->lattice_beam;
+  D.beam_delta = cfg->beam_delta;
+  D.max_active = cfg->max_active;
+  D.min_active = cfg->min_active;
+  D.prune_interval = cfg->prune_interval;
+  d->h_decoded.assign(B, 0);
+  d->h_target.assign(B, 0);
+  d->h_state.assign(B, 0);
+  d->h_ll_base.assign(B, nullptr);
+  d->hist_dev.assign(B, nullptr);
+  d->hist_rows_cap.assign(B, 0);
+  d->hist_rows.assign(B, 0);
+  const char *tp = getenv("WFST_TILES_PER_CHANNEL");
+  if (tp && atoi(tp) > 0) d->tiles_per_channel = atoi(tp);
+  *out = d;
+  return WFST_OK;
+}
+
+void wfst_decoder_free(wfst_decoder *d) { delete d; }
+
+// Resolve a channel list: returns the device pointer to use (nullptr = all channels) and count.
+static int stage_channels(wfst_decoder *d, const int32_t *channels, int32_t n, const int32_t **dev, int32_t *cnt) {
+  if (!channels) {
+    *dev = nullptr;
+    *cnt = d->n_channels;
+    return WFST_OK;
+  }
+  if (n <= 0 || n > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
+  std::vector<char> seen((size_t)d->n_channels, 0);
+  for (int i = 0; i < n; ++i) {
+    if (channels[i] < 0 || channels[i] >= d->n_channels) return fail(WFST_E_ARG, "channel index out of range");
+    if (seen[channels[i]]) return fail(WFST_E_ARG, "duplicate channel in list");
+    seen[channels[i]] = 1;
+  }
+  HIP_TRY(hipStreamSynchronize(d->stream));  // staging buffer reuse
+  memcpy(d->p_chan, channels, (size_t)n * 4);
+  HIP_TRY(hipMemcpyAsync(d->chan_list.p, d->p_chan, (size_t)n * 4, hipMemcpyHostToDevice, d->stream));
+  *dev = d->chan_list.p;
+  *cnt = n;
+  return WFST_OK;
+}
+
+int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  HIP_TRY(hipSetDevice(d->device));
+  const int32_t *dev;
+  int32_t cnt;
+  int rc = stage_channels(d, channels, n, &dev, &cnt);
+  if (rc != WFST_OK) return rc;
+  launch_init(d->D, dev, cnt, d->stream);
+  HIP_TRY(hipGetLastError());
+  for (int i = 0; i < cnt; ++i) {
+    const int c = channels ? channels[i] : i;
+    d->h_decoded[c] = 0;
+    d->h_target[c] = 0;
+    d->h_state[c] = 1;
+    d->h_ll_base[c] = nullptr;
+    d->hist_rows[c] = 0;
+  }
+  return WFST_OK;
+}
+
+static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, const float *const *loglikes,
+                          const int32_t *n_frames_ready, int32_t stride, int32_t max_num_frames) {
+  if (!loglikes || !n_frames_ready) return fail(WFST_E_ARG, "NULL loglikes / n_frames_ready");
+  const int32_t cnt = channels ? n : d->n_channels;
+  if (cnt <= 0 || cnt > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
+  if (stride <= d->graph->max_col)
+    return fail(WFST_E_ARG, "stride too small: the graph reads log-likelihood column " + std::to_string(d->graph->max_col));
+  if (d->D.stride != 0 && d->D.stride != stride) {
+    // a different row stride only matters for channels still holding frames; keep it simple
+    for (int c = 0; c < d->n_channels; ++c)
+      if (d->h_state[c] != 0 && d->h_decoded[c] > 0 && d->h_ll_base[c] != nullptr) {
+        bool listed = false;
+        for (int i = 0; i < cnt; ++i) listed |= ((channels ? channels[i] : i) == c);
+        if (!listed) return fail(WFST_E_ARG, "all live channels of a decoder must use one stride");
+      }
+  }
+  int steps = 0;
+  for (int i = 0; i < cnt; ++i) {
+    const int c = channels ? channels[i] : i;
+    if (c < 0 || c >= d->n_channels) return fail(WFST_E_ARG, "channel index out of range");
+    if (d->h_state[c] == 0) return fail(WFST_E_STATE, "AdvanceDecoding before InitDecoding");
+    if (d->h_state[c] == 2) return fail(WFST_E_STATE, "AdvanceDecoding after FinalizeDecoding");
+    if (n_frames_ready[i] < d->h_decoded[c]) return fail(WFST_E_ARG, "NumFramesReady decreased");  // base-inl.h:641
+    if (!loglikes[i] && n_frames_ready[i] > 0) return fail(WFST_E_ARG, "NULL log-likelihood matrix");
+    int target = n_frames_ready[i];
+    if (max_num_frames >= 0) target = std::min(target, d->h_decoded[c] + max_num_frames);  // base-inl.h:643-648
+    if (target > d->D.max_frames) return fail(WFST_E_CAPACITY, "utterance longer than wfst_limits.max_frames");
+    steps = std::max(steps, target - d->h_decoded[c]);
+  }
+  if (steps == 0) return WFST_OK;
+  HIP_TRY(hipStreamSynchronize(d->stream));  // pinned staging reuse
+  for (int i = 0; i < cnt; ++i) {
+    const int c = channels ? channels[i] : i;
+    int target = n_frames_ready[i];
+    if (max_num_frames >= 0) target = std::min(target, d->h_decoded[c] + max_num_frames);
+    d->h_target[c] = target;
+    d->h_ll_base[c] = loglikes[i];
+  }
+  for (int c = 0; c < d->n_channels; ++c) {
+    d->p_target[c] = d->h_target[c];
+    d->p_ll[c] = d->h_ll_base[c];
+  }
+  HIP_TRY(hipMemcpyAsync(d->target.p, d->p_target, (size_t)d->n_channels * 4, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipMemcpyAsync((void *)d->ll_base.p, (const void *)d->p_ll, (size_t)d->n_channels * sizeof(float *),
+                         hipMemcpyHostToDevice, d->stream));
+  d->D.stride = stride;
+  for (int s = 0; s < steps; ++s) {
+    launch_boundary(d->D, d->target.p, s > 0, 1, d->stream);
+    launch_expand(d->D, d->tiles_per_channel, d->stream);
+  }
+  launch_boundary(d->D, d->target.p, 1, 0, d->stream);
+  HIP_TRY(hipGetLastError());
+  for (int c = 0; c < d->n_channels; ++c) d->h_decoded[c] = std::max(d->h_decoded[c], d->h_target[c]);
+  return WFST_OK;
+}
+
+int wfst_decoder_advance(wfst_decoder *d, const int32_t *channels, int32_t n, const float *const *loglikes,
+                         const int32_t *n_frames_ready, int32_t stride, int32_t max_num_frames) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  HIP_TRY(hipSetDevice(d->device));
+  return advance_device(d, channels, n, loglikes, n_frames_ready, stride, max_num_frames);
+}
+
+int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t n,
+                              const float *const *loglikes_host, const int32_t *n_frames_ready,
+                              int32_t stride, int32_t max_num_frames) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  if (!loglikes_host || !n_frames_ready) return fail(WFST_E_ARG, "NULL loglikes / n_frames_ready");
+  HIP_TRY(hipSetDevice(d->device));
+  const int32_t cnt = channels ? n : d->n_channels;
+  if (cnt <= 0 || cnt > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
+  if (d->hist_stride != 0 && d->hist_stride != stride) {
+    for (int c = 0; c < d->n_channels; ++c)
+      if (d->hist_rows[c] > 0) return fail(WFST_E_ARG, "stride changed while channels hold frames");
+  }
+  d->hist_stride = stride;
+  std::vector<const float *> dev_ptrs((size_t)cnt);
+  for (int i = 0; i < cnt; ++i) {
+    const int c = channels ? channels[i] : i;
+    if (c < 0 || c >= d->n_channels) return fail(WFST_E_ARG, "channel index out of range");
+    const int32_t have = d->hist_rows[c], want = n_frames_ready[i];
+    if (want < have) return fail(WFST_E_ARG, "NumFramesReady decreased");
+    if ((size_t)want > d->hist_rows_cap[c]) {
+      size_t ncap = std::max<size_t>((size_t)want, std::max<size_t>(d->hist_rows_cap[c] * 2, 256));
+      float *np = nullptr;
+      HIP_TRY(hipMalloc((void **)&np, ncap * (size_t)stride * 4));
+      if (have > 0) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        HIP_TRY(hipMemcpy(np, d->hist_dev[c], (size_t)have * stride * 4, hipMemcpyDeviceToDevice));
+      }
+      if (d->hist_dev[c]) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        HIP_TRY(hipFree(d->hist_dev[c]));
+      }
+      d->hist_dev[c] = np;
+      d->hist_rows_cap[c] = ncap;
+    }
+    if (want > have) {
+      if (!loglikes_host[i]) return fail(WFST_E_ARG, "NULL log-likelihood matrix");
+      HIP_TRY(hipMemcpyAsync(d->hist_dev[c] + (size_t)have * stride, loglikes_host[i] + (size_t)have * stride,
+                             (size_t)(want - have) * stride * 4, hipMemcpyHostToDevice, d->stream));
+      d->hist_rows[c] = want;
+    }
+    dev_ptrs[i] = d->hist_dev[c];
+  }
+  // pageable host memory: the copies above must have consumed the caller's buffers on return
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return advance_device(d, channels, n, dev_ptrs.data(), n_frames_ready, stride, max_num_frames);
+}
+
+int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  HIP_TRY(hipSetDevice(d->device));
+  const int32_t *dev;
+  int32_t cnt;
+  int rc = stage_channels(d, channels, n, &dev, &cnt);
+  if (rc != WFST_OK) return rc;
+  for (int i = 0; i < cnt; ++i) {
+    const int c = channels ? channels[i] : i;
+    if (d->h_state[c] == 0) return fail(WFST_E_STATE, "FinalizeDecoding before InitDecoding");
+  }
+  launch_set_finalized(d->D, dev, cnt, d->stream);
+  HIP_TRY(hipGetLastError());
+  for (int i = 0; i < cnt; ++i) d->h_state[channels ? channels[i] : i] = 2;
+  return WFST_OK;
+}
+
+static int read_ctl(wfst_decoder *d) {
+  HIP_TRY(hipMemcpyAsync(d->p_ctl, d->ctl.p, d->ctl.bytes(), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return WFST_OK;
+}
+
+static int check_ctl_errors(wfst_decoder *d) {
+  for (int c = 0; c < d->n_channels; ++c) {
+    const int e = d->p_ctl[c].error;
+    if (e) {
+      std::string m = "channel " + std::to_string(c) + " exceeded a device capacity:";
+      if (e & kErrTableFull) m += " hash table (max_tokens_per_frame)";
+      if (e & kErrArenaFull) m += " token arena (arena_tokens)";
+      if (e & kErrFrontierFull) m += " frontier (max_tokens_per_frame)";
+      if (e & kErrWorklistFull) m += " epsilon worklist (max_tokens_per_frame)";
+      if (e & kErrFramesFull) m += " frames (max_frames)";
+      return fail(WFST_E_CAPACITY, m);
+    }
+  }
+  return WFST_OK;
+}
+
+int wfst_decoder_sync(wfst_decoder *d) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  HIP_TRY(hipSetDevice(d->device));
+  int rc = read_ctl(d);
+  if (rc != WFST_OK) return rc;
+  return check_ctl_errors(d);
+}
+
+int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t channel) {
+  if (!d || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad decoder/channel");
+  return d->h_decoded[channel];
+}
+
+int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs,
+                               int32_t cap, int32_t *ilabel, int32_t *olabel, float *graph_cost,
+                               float *acoustic_cost, int32_t *n_hops) {
+  if (!d || !ilabel || !olabel || !graph_cost || !acoustic_cost || !n_hops || cap <= 0)
+    return fail(WFST_E_ARG, "NULL output or cap <= 0");
+  HIP_TRY(hipSetDevice(d->device));
+  const int32_t *dev;
+  int32_t cnt;
+  int rc = stage_channels(d, channels, n, &dev, &cnt);
+  if (rc != WFST_OK) return rc;
+  for (int i = 0; i < cnt; ++i) {
+    const int c = channels ? channels[i] : i;
+    if (d->h_state[c] == 0) return fail(WFST_E_STATE, "GetBestPath before InitDecoding");
+    if (d->h_state[c] == 2 && !use_final_probs)  // base-inl.h:1100-1102 (LOG_ERR)
+      return fail(WFST_E_STATE, "You cannot call FinalizeDecoding() and then GetBestPath with use_final_probs == false");
+  }
+  const size_t need = (size_t)cnt * (size_t)cap;
+  if (d->bp_il.n < need) {
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(d->bp_il.alloc(need));
+    HIP_TRY(d->bp_ol.alloc(need));
+    HIP_TRY(d->bp_g.alloc(need));
+    HIP_TRY(d->bp_ac.alloc(need));
+  }
+  if (d->bp_n.n < (size_t)cnt) HIP_TRY(d->bp_n.alloc((size_t)d->n_channels));
+  launch_best_path(d->D, dev, cnt, use_final_probs ? 1 : 0, cap, d->bp_il.p, d->bp_ol.p, d->bp_g.p, d->bp_ac.p,
+                   d->bp_n.p, d->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(n_hops, d->bp_n.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(ilabel, d->bp_il.p, need * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(olabel, d->bp_ol.p, need * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(graph_cost, d->bp_g.p, need * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(acoustic_cost, d->bp_ac.p, need * 4, hipMemcpyDeviceToHost, d->stream));
+  rc = read_ctl(d);
+  if (rc != WFST_OK) return rc;
+  rc = check_ctl_errors(d);
+  if (rc != WFST_OK) return rc;
+  for (int i = 0; i < cnt; ++i)
+    if (n_hops[i] > cap) return fail(WFST_E_CAPACITY, "best path longer than cap hops; n_hops holds the needed size");
+  return WFST_OK;
+}
+
+int wfst_lattice_to_vector(const int32_t *ilabel, const int32_t *olabel, const float *graph_cost,
+                           const float *acoustic_cost, int32_t n_hops, int32_t *words, int32_t max_words,
+                           int32_t *n_words, int32_t *tids, int32_t max_tids, int32_t *n_tids,
+                           float *tot_score, float *lm_score) {
+  // newfst/lattice-functions.cc:179-217; n_hops == 0 is its `Start() == kNoStateId` -> false
+  if (n_hops < 0 || !n_words || !n_tids || !tot_score || !lm_score) return fail(WFST_E_ARG, "bad argument");
+  float tot = 0, lm = 0;
+  int nw = 0, nt = 0;
+  for (int k = 0; k < n_hops; ++k) {
+    if (ilabel[k] != 0) { if (tids && nt < max_tids) tids[nt] = ilabel[k]; ++nt; }
+    if (olabel[k] != 0) { if (words && nw < max_words) words[nw] = olabel[k]; ++nw; }
+    lm += graph_cost[k];
+    tot += graph_cost[k] + acoustic_cost[k];
+  }
+  *n_words = nw;
+  *n_tids = nt;
+  *tot_score = tot;
+  *lm_score = lm;
+  return WFST_OK;
+}
+
+int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]) {
+  if (!d || !stats || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(d->device));
+  int rc = read_ctl(d);
+  if (rc != WFST_OK) return rc;
+  const ChanCtl &c = d->p_ctl[channel];
+  stats[0] = c.n_decoded;
+  stats[1] = (int64_t)c.cnt_N;
+  stats[2] = (int64_t)c.cnt_E;
+  stats[3] = (int64_t)c.cnt_Z;
+  stats[4] = (int64_t)c.cnt_tok;
+  stats[5] = c.peak_tokens;
+  stats[6] = (int64_t)c.cnt_slots;
+  stats[7] = 0;
+  return WFST_OK;
+}
+
+int wfst_decoder_get_frontier(wfst_decoder *d, int32_t channel, int32_t cap, int32_t *states, float *costs) {
+  if (!d || channel < 0 || channel >= d->n_channels || cap < 0) return fail(WFST_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(d->device));
+  int rc = read_ctl(d);
+  if (rc != WFST_OK) return rc;
+  const ChanCtl &c = d->p_ctl[channel];
+  const int n = c.front_count, k = std::min(n, cap);
+  if (k > 0) {
+    std::vector<int4> t((size_t)k);
+    HIP_TRY(hipMemcpy(t.data(), d->tok.p + (size_t)channel * (size_t)d->D.arena_cap + c.front_begin,
+                      (size_t)k * sizeof(int4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < k; ++i) {
+      states[i] = t[i].x;
+      memcpy(&costs[i], &t[i].y, 4);
+    }
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+"""ctypes binding of the C ABI in include/wfst_decoder.h (libwfstdec.so).
+
+Thin plumbing for tests, bench.py and the smoke entry: numpy in, numpy out; device matrices
+are passed as raw device pointers (e.g. ``torch.Tensor.data_ptr()``).  There is no CPU
+fallback: if the HIP library is missing or no MI355X is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libwfstdec.so")
+
+WFST_OK = 0
+ERR_NAMES = {-1: "WFST_E_ARG", -2: "WFST_E_IO", -3: "WFST_E_DEVICE", -4: "WFST_E_CAPACITY",
+             -5: "WFST_E_STATE", -6: "WFST_E_FORMAT"}
+
+# every symbol include/wfst_decoder.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "wfst_config_default", "wfst_last_error", "wfst_device_count", "wfst_graph_load",
+    "wfst_graph_from_arrays", "wfst_graph_set_tid2pdf", "wfst_graph_info", "wfst_graph_free",
+    "wfst_decoder_create", "wfst_decoder_free", "wfst_decoder_init", "wfst_decoder_advance",
+    "wfst_decoder_advance_host", "wfst_decoder_finalize", "wfst_decoder_sync",
+    "wfst_decoder_num_frames_decoded", "wfst_decoder_get_best_path", "wfst_lattice_to_vector",
+    "wfst_decoder_get_stats", "wfst_decoder_get_frontier",
+]
+
+
+class WfstError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "WFST_E_?"), code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    """wfst_config == LatticeFasterDecoderConfig (reference
+    src/my-decoder/lattice-faster-decoder-conf.h:21-44), reference defaults."""
+
+    _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
+                ("lattice_beam", C.c_float), ("prune_interval", C.c_int32), ("beam_delta", C.c_float),
+                ("hash_ratio", C.c_float), ("prune_scale", C.c_float)]
+
+    def __init__(self, beam=16.0, max_active=2147483647, min_active=200, lattice_beam=10.0,
+                 prune_interval=25, beam_delta=0.5, hash_ratio=2.0, prune_scale=0.1):
+        super().__init__(beam, max_active, min_active, lattice_beam, prune_interval, beam_delta,
+                         hash_ratio, prune_scale)
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_frames", C.c_int32), ("max_tokens_per_frame", C.c_int32), ("arena_tokens", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libwfstdec.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.wfst_last_error.restype = C.c_char_p
+        L.wfst_decoder_get_frontier.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != WFST_OK:
+        raise WfstError(rc, lib().wfst_last_error().decode())
+
+
+def _i32(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f32(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def device_count():
+    return int(lib().wfst_device_count())
+
+
+class Graph:
+    """HCLG resident in HBM (replaces the reference's ``Fst``)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @staticmethod
+    def load(path, device=0):
+        h = C.c_void_p()
+        _check(lib().wfst_graph_load(path.encode(), int(device), C.byref(h)))
+        return Graph(h)
+
+    @staticmethod
+    def from_arrays(start, final_state, state_info, arcs, device=0):
+        si = np.ascontiguousarray(state_info)
+        ar = np.ascontiguousarray(arcs)
+        assert si.dtype.itemsize == 12 and ar.dtype.itemsize == 16
+        h = C.c_void_p()
+        _check(lib().wfst_graph_from_arrays(int(start), int(final_state), int(si.shape[0]), int(ar.shape[0]),
+                                            si.ctypes.data_as(C.c_void_p), ar.ctypes.data_as(C.c_void_p),
+                                            int(device), C.byref(h)))
+        return Graph(h)
+
+    def set_tid2pdf(self, tid2pdf):
+        m = np.ascontiguousarray(tid2pdf, dtype=np.int32)
+        _check(lib().wfst_graph_set_tid2pdf(self.h, _i32(m), int(m.shape[0] - 1)))
+
+    def info(self):
+        s, f, ns, na = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        b = C.c_int64()
+        _check(lib().wfst_graph_info(self.h, C.byref(s), C.byref(f), C.byref(ns), C.byref(na), C.byref(b)))
+        return dict(start=s.value, final_state=f.value, n_states=ns.value, n_arcs=na.value, device_bytes=b.value)
+
+    def free(self):
+        if self.h:
+            lib().wfst_graph_free(self.h)
+            self.h = None
+
+
+class BatchDecoder:
+    """A batch of decoding channels (one channel == one reference decoder object)."""
+
+    def __init__(self, graph, cfg, n_channels, max_frames=0, max_tokens_per_frame=0, arena_tokens=0, stream=None):
+        self.graph = graph
+        self.n = int(n_channels)
+        lim = Limits(int(max_frames), int(max_tokens_per_frame), int(arena_tokens))
+        h = C.c_void_p()
+        _check(lib().wfst_decoder_create(graph.h, C.byref(cfg), self.n, C.byref(lim),
+                                         C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+
+    def free(self):
+        if self.h:
+            lib().wfst_decoder_free(self.h)
+            self.h = None
+
+    def _chan(self, channels):
+        if channels is None:
+            return None, 0
+        ch = np.ascontiguousarray(channels, dtype=np.int32)
+        return ch, int(ch.shape[0])
+
+    def init(self, channels=None):
+        ch, n = self._chan(channels)
+        _check(lib().wfst_decoder_init(self.h, _i32(ch), n))
+
+    def advance(self, ll_ptrs, n_frames_ready, stride, channels=None, max_num_frames=-1):
+        """ll_ptrs: device addresses (ints) of row 0 of each listed channel's matrix."""
+        ch, n = self._chan(channels)
+        cnt = n if ch is not None else self.n
+        ptrs = (C.c_void_p * cnt)(*[int(p) for p in ll_ptrs])
+        nr = np.ascontiguousarray(n_frames_ready, dtype=np.int32)
+        assert nr.shape[0] == cnt
+        _check(lib().wfst_decoder_advance(self.h, _i32(ch), n, ptrs, _i32(nr), int(stride), int(max_num_frames)))
+
+    def advance_host(self, mats, n_frames_ready, channels=None, max_num_frames=-1):
+        """mats: list of C-contiguous float32 [frames][stride] numpy arrays (host)."""
+        ch, n = self._chan(channels)
+        cnt = n if ch is not None else self.n
+        mats = [np.ascontiguousarray(m, dtype=np.float32) for m in mats]
+        stride = int(mats[0].shape[1])
+        assert all(m.shape[1] == stride for m in mats)
+        ptrs = (C.c_void_p * cnt)(*[m.ctypes.data for m in mats])
+        nr = np.ascontiguousarray(n_frames_ready, dtype=np.int32)
+        _check(lib().wfst_decoder_advance_host(self.h, _i32(ch), n, ptrs, _i32(nr), stride, int(max_num_frames)))
+
+    def finalize(self, channels=None):
+        ch, n = self._chan(channels)
+        _check(lib().wfst_decoder_finalize(self.h, _i32(ch), n))
+
+    def sync(self):
+        _check(lib().wfst_decoder_sync(self.h))
+
+    def num_frames_decoded(self, channel):
+        return int(lib().wfst_decoder_num_frames_decoded(self.h, int(channel)))
+
+    def best_paths(self, channels=None, use_final_probs=True, cap=2048):
+        """Returns one dict per listed channel: ok, ilabel, olabel, graph, ac, words, tids,
+        tot_score, lm_score (LatticeToVector applied to the hop list)."""
+        ch, n = self._chan(channels)
+        cnt = n if ch is not None else self.n
+        il = np.zeros((cnt, cap), np.int32)
+        ol = np.zeros((cnt, cap), np.int32)
+        g = np.zeros((cnt, cap), np.float32)
+        ac = np.zeros((cnt, cap), np.float32)
+        nh = np.zeros(cnt, np.int32)
+        _check(lib().wfst_decoder_get_best_path(self.h, _i32(ch), n, int(bool(use_final_probs)), int(cap),
+                                                _i32(il), _i32(ol), _f32(g), _f32(ac), _i32(nh)))
+        out = []
+        for i in range(cnt):
+            k = int(nh[i])
+            words = np.zeros(max(k, 1), np.int32)
+            tids = np.zeros(max(k, 1), np.int32)
+            nw, nt = C.c_int32(), C.c_int32()
+            tot, lm = C.c_float(), C.c_float()
+            _check(lib().wfst_lattice_to_vector(_i32(il[i]), _i32(ol[i]), _f32(g[i]), _f32(ac[i]), k,
+                                                _i32(words), k, C.byref(nw), _i32(tids), k, C.byref(nt),
+                                                C.byref(tot), C.byref(lm)))
+            out.append(dict(ok=k > 0, ilabel=il[i, :k].copy(), olabel=ol[i, :k].copy(), graph=g[i, :k].copy(),
+                            ac=ac[i, :k].copy(), words=words[: nw.value].copy(), tids=tids[: nt.value].copy(),
+                            tot_score=float(tot.value), lm_score=float(lm.value)))
+        return out
+
+    def stats(self, channel):
+        s = (C.c_int64 * 8)()
+        _check(lib().wfst_decoder_get_stats(self.h, int(channel), s))
+        return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], slots=s[6])
+
+    def frontier(self, channel, cap=1 << 20):
+        st = np.zeros(cap, np.int32)
+        co = np.zeros(cap, np.float32)
+        n = lib().wfst_decoder_get_frontier(self.h, int(channel), int(cap), _i32(st), _f32(co))
+        if n < 0:
+            _check(n)
+        k = min(n, cap)
+        return st[:k].copy(), co[:k].copy()

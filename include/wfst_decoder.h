@@ -1,0 +1,170 @@
+/*
+ * wfst_decoder.h -- C ABI of the MI355X-native batched WFST token-passing decoder.
+ *
+ * This is the drop-in boundary for ONE path of datemoon/ASR-decoder: the frame-synchronous
+ * token-passing search of src/my-decoder (ProcessEmitting / ProcessNonemitting / beam pruning
+ * over the flat HCLG of src/newfst), precomputed log-likelihoods in, best path out.
+ * Plain pointers and sizes only; no C++ or torch types.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference's src/).
+ *
+ * Threading: one wfst_decoder per host thread (like one reference decoder object per worker
+ * thread, v2-asr/v2-asr-work-thread.h:66); a wfst_graph is immutable after creation and may be
+ * shared by any number of decoders on the same device (like the shared read-only Fst,
+ * kaldi-nnet3/kaldi-online-nnet3-my-decoder.h:121).
+ *
+ * Errors: every function returning int returns WFST_OK (0) or a negative WFST_E_* code;
+ * wfst_last_error() gives the message of the calling thread's last failure.  There is no CPU
+ * fallback: without a usable HIP device every call that needs one fails with WFST_E_DEVICE.
+ */
+#ifndef WFST_DECODER_H_
+#define WFST_DECODER_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFST_OK 0
+#define WFST_E_ARG (-1)      /* bad argument                                              */
+#define WFST_E_IO (-2)       /* graph file unreadable / truncated                         */
+#define WFST_E_DEVICE (-3)   /* HIP error (no device, out of memory, launch failure)      */
+#define WFST_E_CAPACITY (-4) /* a per-channel limit of wfst_limits was exceeded on device */
+#define WFST_E_STATE (-5)    /* call sequence violated (e.g. advance before init)         */
+#define WFST_E_FORMAT (-6)   /* graph violates a layout limit (see wfst_graph_from_arrays) */
+
+typedef struct wfst_graph wfst_graph;     /* HCLG resident in HBM; replaces `Fst` (newfst/optimize-fst.h:53-307) */
+typedef struct wfst_decoder wfst_decoder; /* a batch of decoding channels; one channel replaces one
+                                             OnlineLatticeDecoderMempool (my-decoder/online-decoder-mempool-base.h:77) */
+
+/* Field-for-field LatticeFasterDecoderConfig (my-decoder/lattice-faster-decoder-conf.h:21-44);
+ * wfst_config_default() fills the reference defaults (conf.h:35-44).  hash_ratio and prune_scale
+ * are accepted for compatibility: the device hash is sized by wfst_limits, and best-path decoding
+ * keeps no forward-link lists to back-prune (prune_interval and lattice_beam still decide which
+ * of several parallel arcs GetBestPath reports, exactly as in the reference). */
+typedef struct wfst_config {
+  float beam;
+  int32_t max_active;
+  int32_t min_active;
+  float lattice_beam;
+  int32_t prune_interval;
+  float beam_delta;
+  float hash_ratio;
+  float prune_scale;
+} wfst_config;
+
+/* Per-channel device capacities (0 = default).  Exceeding one makes the affected call return
+ * WFST_E_CAPACITY; nothing is silently dropped. */
+typedef struct wfst_limits {
+  int32_t max_frames;           /* frames per utterance                     (default 4096)    */
+  int32_t max_tokens_per_frame; /* distinct states reached in one frame     (default 32768)   */
+  int64_t arena_tokens;         /* tokens kept per utterance for traceback  (default 4194304) */
+} wfst_limits;
+
+/* Original on-disk / in-memory graph records of the reference format. */
+typedef struct wfst_arc { int32_t ilabel, olabel; float weight; int32_t nextstate; } wfst_arc;   /* StdArc, newfst/arc.h:17-26 */
+typedef struct wfst_state_info { uint32_t num_arcs, niepsilons, noepsilons; } wfst_state_info;   /* Fst::StateInfo, newfst/optimize-fst.h:220-225 */
+
+void wfst_config_default(wfst_config *cfg);
+const char *wfst_last_error(void);
+int wfst_device_count(void);
+
+/* ---- graph ------------------------------------------------------------------------------- */
+
+/* Fst::ReadFst(const char*) (newfst/optimize-fst.h:208-280): reads the flat format
+ * {start, final_state, total_states, total_arcs, total_niepsilons, total_noepsilons} int32,
+ * StateInfo x S, StdArc x A and uploads it as CSR to `device`. */
+int wfst_graph_load(const char *path, int device, wfst_graph **out);
+
+/* Same from host arrays (what Fst holds after ReadFst or after Fst(ConstFst),
+ * newfst/optimize-fst.h:82-134).  Requirements, checked: every state's input-epsilon arcs precede
+ * its other arcs (the reference format guarantees it, fst_format_convert_tool/read_fst.c:110-135);
+ * <= 4095 input-epsilon arcs and < 2^20 emitting arcs per state (WFST_E_FORMAT otherwise). */
+int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states, int32_t n_arcs,
+                           const wfst_state_info *states, const wfst_arc *arcs, int device,
+                           wfst_graph **out);
+
+/* Optional transition-id -> pdf map (Kaldi DecodableMatrixScaledMapped as used by
+ * kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:107; hmm/transition-model.h:52-61):
+ * LogLikelihood(f, ilabel) = loglikes[f][tid2pdf[ilabel]].  tid2pdf has n_tid+1 entries, entry 0
+ * unused.  Without a map, column = ilabel (a matrix with NumIndices()+1 columns). */
+int wfst_graph_set_tid2pdf(wfst_graph *g, const int32_t *tid2pdf, int32_t n_tid);
+
+int wfst_graph_info(const wfst_graph *g, int32_t *start, int32_t *final_state, int32_t *n_states,
+                    int32_t *n_arcs, int64_t *device_bytes);
+void wfst_graph_free(wfst_graph *g);
+
+/* ---- decoder ----------------------------------------------------------------------------- */
+
+/* Decoder(Fst*, const LatticeFasterDecoderConfig&) (my-decoder/online-decoder-base.h:95,
+ * base-inl.h:22-30) for n_channels independent utterance slots.  `hip_stream` is a hipStream_t
+ * (NULL = a stream owned by the decoder); all work is enqueued on it. */
+int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
+                        const wfst_limits *limits, void *hip_stream, wfst_decoder **out);
+void wfst_decoder_free(wfst_decoder *d);
+
+/* InitDecoding() (base-inl.h:40-67) for the listed channels (channels == NULL: all). */
+int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n);
+
+/* AdvanceDecoding(decodable, max_num_frames) (base-inl.h:630-668) for the listed channels at
+ * once.  For channel channels[i]: loglikes[i] is a DEVICE pointer to row 0 of the utterance's
+ * row-major float32 matrix [frames][stride] of already-scaled log-likelihoods (what
+ * LogLikelihood(frame, index) returns, itf/decodable-itf.h:71), n_frames_ready[i] is
+ * NumFramesReady(); rows [0, n_frames_ready[i]) must stay valid and unchanged until the
+ * channel's next wfst_decoder_init (GetBestPath reads acoustic costs back from them).
+ * max_num_frames < 0: decode everything ready.  Returns after the work is ENQUEUED on the stream;
+ * use wfst_decoder_sync or any result getter to wait. */
+int wfst_decoder_advance(wfst_decoder *d, const int32_t *channels, int32_t n,
+                         const float *const *loglikes, const int32_t *n_frames_ready,
+                         int32_t stride, int32_t max_num_frames);
+
+/* Same with HOST matrices: rows [NumFramesDecoded, n_frames_ready) are copied into a device
+ * history buffer owned by the channel (the shape a DecodableInterface-pulling caller needs). */
+int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t n,
+                              const float *const *loglikes_host, const int32_t *n_frames_ready,
+                              int32_t stride, int32_t max_num_frames);
+
+/* FinalizeDecoding() (base-inl.h:829-847): marks the channels finalized (afterwards advance is an
+ * error and get_best_path requires use_final_probs != 0, as in the reference). */
+int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n);
+
+/* Blocks until everything enqueued so far has run; returns WFST_E_CAPACITY / WFST_E_DEVICE if a
+ * channel hit a limit or the device faulted. */
+int wfst_decoder_sync(wfst_decoder *d);
+
+/* NumFramesDecoded() (my-decoder/online-decoder-base.h:139). */
+int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t channel);
+
+/* GetBestPath(Lattice*, use_final_probs) (base-inl.h:1071-1094) for every listed channel at once.
+ * The linear best-path lattice is returned hop by hop in start->final order, exactly the arcs the
+ * reference's Lattice holds (first hop is the (0,0,One) arc of the root token): for channel
+ * channels[i], hops are written to ilabel/olabel/graph_cost/acoustic_cost + i*cap, their number
+ * to n_hops[i] (0 = the reference's `return false`: no frames decoded or no surviving token).
+ * If a path is longer than cap, n_hops[i] is the needed size and WFST_E_CAPACITY is returned. */
+int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t n,
+                               int32_t use_final_probs, int32_t cap, int32_t *ilabel,
+                               int32_t *olabel, float *graph_cost, float *acoustic_cost,
+                               int32_t *n_hops);
+
+/* LatticeToVector (newfst/lattice-functions.cc:179-217) on one hop list: nonzero olabels ->
+ * words, nonzero ilabels -> transition-ids, lm = sum graph, tot = sum (graph + acoustic), float
+ * accumulation in forward order.  Host-only helper; returns the counts through n_words/n_tids. */
+int wfst_lattice_to_vector(const int32_t *ilabel, const int32_t *olabel, const float *graph_cost,
+                           const float *acoustic_cost, int32_t n_hops, int32_t *words,
+                           int32_t max_words, int32_t *n_words, int32_t *tids, int32_t max_tids,
+                           int32_t *n_tids, float *tot_score, float *lm_score);
+
+/* Per-channel work counters since the last init: {frames, N tokens expanded, E emitting arcs
+ * traversed, Z epsilon arcs traversed, tokens kept, peak tokens per frame, hash slots touched,
+ * reserved}.  N and E follow the definitions of the reference loop (base-inl.h:311-347). */
+int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]);
+
+/* Frontier of a channel after the last decoded frame (states and costs, unordered); for tests.
+ * Returns the number of tokens (may exceed cap; only cap are written). */
+int wfst_decoder_get_frontier(wfst_decoder *d, int32_t channel, int32_t cap, int32_t *states,
+                              float *costs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFST_DECODER_H_ */

@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol include/wfst_decoder.h
+declares, and refuses to run without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = importlib.import_module("asr-decoder_amd")
+    p.build.build()
+    return p
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "wfst_decoder.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wfst_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(pkg):
+    assert declared_functions() == sorted(pkg.wfstdec.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = ctypes.CDLL(pkg.wfstdec.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+
+
+def test_config_default_matches_reference_defaults(pkg):
+    # lattice-faster-decoder-conf.h:35-44
+    c = pkg.wfstdec.Config(0, 0, 0, 0, 0, 0, 0, 0)
+    pkg.wfstdec.lib().wfst_config_default(ctypes.byref(c))
+    assert (c.beam, c.max_active, c.min_active, c.lattice_beam, c.prune_interval) == (16.0, 2147483647, 200, 10.0, 25)
+    assert (c.beam_delta, c.hash_ratio) == (0.5, 2.0) and abs(c.prune_scale - 0.1) < 1e-7
+
+
+def test_lattice_to_vector_is_host_only(pkg):
+    import numpy as np
+
+    il = np.array([0, 5, 0, 7], np.int32)
+    ol = np.array([0, 0, 9, 3], np.int32)
+    g = np.array([0, 0.5, 0.25, 1.0], np.float32)
+    a = np.array([0, 2.0, 0, 1.5], np.float32)
+    words = np.zeros(4, np.int32)
+    tids = np.zeros(4, np.int32)
+    nw, nt = ctypes.c_int32(), ctypes.c_int32()
+    tot, lm = ctypes.c_float(), ctypes.c_float()
+    f = lambda x, t: x.ctypes.data_as(ctypes.POINTER(t))
+    rc = pkg.wfstdec.lib().wfst_lattice_to_vector(f(il, ctypes.c_int32), f(ol, ctypes.c_int32), f(g, ctypes.c_float),
+                                                  f(a, ctypes.c_float), 4, f(words, ctypes.c_int32), 4, ctypes.byref(nw),
+                                                  f(tids, ctypes.c_int32), 4, ctypes.byref(nt), ctypes.byref(tot), ctypes.byref(lm))
+    assert rc == 0 and list(words[: nw.value]) == [9, 3] and list(tids[: nt.value]) == [5, 7]
+    assert tot.value == 5.25 and lm.value == 1.75
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    if pkg.wfstdec.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    s = pkg.synth.make_hclg_like(50, seed=1, n_tid=20, n_words=5)
+    with pytest.raises(pkg.wfstdec.WfstError) as ei:
+        pkg.wfstdec.Graph.from_arrays(s.start, s.final_state, s.state_info, s.arcs)
+    assert ei.value.code == -3
