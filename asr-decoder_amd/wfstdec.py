@@ -64,6 +64,15 @@ def lib():
             raise FileNotFoundError(
                 "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  If
+        # this library were dlopen'ed first it would bind /opt/rocm's copy and torch would then
+        # bring up a second runtime ("No HIP GPUs are available").  Loading torch first lets the
+        # loader satisfy our DT_NEEDED libamdhip64.so.7 with the copy already in the process.
+        if os.environ.get("WFST_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.wfst_last_error.restype = C.c_char_p
         L.wfst_decoder_get_frontier.restype = C.c_int
