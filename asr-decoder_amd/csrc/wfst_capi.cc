@@ -106,12 +106,26 @@ struct wfst_decoder {
   std::vector<int32_t> hist_rows;
   int32_t hist_stride = 0;
   int tiles_per_channel = 16;
+  // optional kernel timing (wfst_decoder_set_profiling)
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<int, int>> ev_pairs[2];  // [kernel class] -> (start, stop) event indices
+  size_t ev_used = 0;
+  int ev_get() {
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return -1;
+      ev_pool.push_back(e);
+    }
+    return (int)ev_used++;
+  }
 
   ~wfst_decoder() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (float *p : hist_dev)
       if (p) (void)hipFree(p);
+    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     if (p_target) (void)hipHostFree(p_target);
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
@@ -502,11 +516,18 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   HIP_TRY(hipMemcpyAsync((void *)d->ll_base.p, (const void *)d->p_ll, (size_t)d->n_channels * sizeof(float *),
                          hipMemcpyHostToDevice, d->stream));
   d->D.stride = stride;
+  auto timed = [&](int cls, auto &&launch) {
+    if (!d->profiling) { launch(); return; }
+    const int a = d->ev_get(), b = d->ev_get();
+    if (a >= 0 && b >= 0) (void)hipEventRecord(d->ev_pool[a], d->stream);
+    launch();
+    if (a >= 0 && b >= 0) { (void)hipEventRecord(d->ev_pool[b], d->stream); d->ev_pairs[cls].push_back({a, b}); }
+  };
   for (int s = 0; s < steps; ++s) {
-    launch_boundary(d->D, d->target.p, s > 0, 1, d->stream);
-    launch_expand(d->D, d->tiles_per_channel, d->stream);
+    timed(1, [&] { launch_boundary(d->D, d->target.p, s > 0, 1, d->stream); });
+    timed(0, [&] { launch_expand(d->D, d->tiles_per_channel, d->stream); });
   }
-  launch_boundary(d->D, d->target.p, 1, 0, d->stream);
+  timed(1, [&] { launch_boundary(d->D, d->target.p, 1, 0, d->stream); });
   HIP_TRY(hipGetLastError());
   for (int c = 0; c < d->n_channels; ++c) d->h_decoded[c] = std::max(d->h_decoded[c], d->h_target[c]);
   return WFST_OK;
@@ -678,6 +699,34 @@ int wfst_lattice_to_vector(const int32_t *ilabel, const int32_t *olabel, const f
   *n_tids = nt;
   *tot_score = tot;
   *lm_score = lm;
+  return WFST_OK;
+}
+
+int wfst_decoder_set_profiling(wfst_decoder *d, int32_t enable) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  d->profiling = enable != 0;
+  d->ev_used = 0;
+  d->ev_pairs[0].clear();
+  d->ev_pairs[1].clear();
+  return WFST_OK;
+}
+
+int wfst_decoder_get_profile(wfst_decoder *d, double ms[2], int64_t launches[2]) {
+  if (!d || !ms || !launches) return fail(WFST_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  for (int k = 0; k < 2; ++k) {
+    double tot = 0;
+    for (auto &pr : d->ev_pairs[k]) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, d->ev_pool[pr.first], d->ev_pool[pr.second]));
+      tot += t;
+    }
+    ms[k] = tot;
+    launches[k] = (int64_t)d->ev_pairs[k].size();
+  }
   return WFST_OK;
 }
 

@@ -25,7 +25,8 @@ SYMBOLS = [
     "wfst_decoder_create", "wfst_decoder_free", "wfst_decoder_init", "wfst_decoder_advance",
     "wfst_decoder_advance_host", "wfst_decoder_finalize", "wfst_decoder_sync",
     "wfst_decoder_num_frames_decoded", "wfst_decoder_get_best_path", "wfst_lattice_to_vector",
-    "wfst_decoder_get_stats", "wfst_decoder_get_frontier",
+    "wfst_decoder_get_stats", "wfst_decoder_get_frontier", "wfst_decoder_set_profiling",
+    "wfst_decoder_get_profile",
 ]
 
 
@@ -224,6 +225,15 @@ class BatchDecoder:
         s = (C.c_int64 * 8)()
         _check(lib().wfst_decoder_get_stats(self.h, int(channel), s))
         return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], slots=s[6])
+
+    def set_profiling(self, on):
+        _check(lib().wfst_decoder_set_profiling(self.h, int(bool(on))))
+
+    def profile(self):
+        ms = (C.c_double * 2)()
+        n = (C.c_int64 * 2)()
+        _check(lib().wfst_decoder_get_profile(self.h, ms, n))
+        return dict(expand_ms=ms[0], expand_launches=n[0], boundary_ms=ms[1], boundary_launches=n[1])
 
     def frontier(self, channel, cap=1 << 20):
         st = np.zeros(cap, np.int32)

@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s decoded by the MI355X WFST token-passing decoder.
+
+Workload = BASELINE.json configs[1] ("1xMI355X, batch=128 utterances, ~10M-arc HCLG, beam=13,
+precomputed nnet3 log-likelihoods"), generated as SURVEY.md section 8(d) prescribes: synthetic
+"hclg-like" graph (2.85M states / ~10.1M arcs, seed 7), float32[300][3000] log-likelihoods per
+utterance (seed = global utterance index), beam 13 with the reference service's max-active 7000 /
+min-active 200.  One "step" = one pass of the hot path over one batch: InitDecoding ->
+AdvanceDecoding(all frames) -> FinalizeDecoding -> GetBestPath + LatticeToVector for every
+utterance (reference call sequence kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:97-129).
+Log-likelihoods are resident in HBM before the timed region starts.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: utterances shard embarrassingly (128 per GPU, graph replicated, weak scaling); the only
+collective is one RCCL all_gather of the padded word-id results per step.
+Rank 0 prints ONE JSON line (metric, roofline, cpu_baseline).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=128, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--states", type=int, default=2850000)
+    ap.add_argument("--pdfs", type=int, default=3000)
+    ap.add_argument("--beam", type=float, default=13.0)
+    ap.add_argument("--max-active", type=int, default=7000)
+    ap.add_argument("--min-active", type=int, default=200)
+    ap.add_argument("--mu", type=float, default=-2.0)
+    ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances timed on the host cores (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(sample, host cores)")
+    ap.add_argument("--graph-cache", default="/tmp/wfst_bench_graph_%d.bin")
+    return ap.parse_args()
+
+
+def make_utts(synth, g, m, first, count, T, P, mu, sigma):
+    out = np.empty((count, T, P), np.float32)
+    for i in range(count):
+        out[i] = synth.make_loglikes(g, T, P, m, seed=first + i, mu=mu, sigma=sigma)[0]
+    return out
+
+
+def cpu_baseline(graph_path, cd, mats, m, n_threads):
+    """Time the CPU decoder on a bounded sample: the UNMODIFIED reference (oracle/_ref, kind
+    "reference") when its prebuilt library is present, else our C restatement (kind "port").
+    One decoder object per thread over one shared read-only graph -- the reference service's
+    threading model (v2-asrbin/v2-asr-service.cc:95-105)."""
+    import pyoracle
+
+    kind = "reference" if os.path.exists(pyoracle.REF_SO) else "port"
+    if kind == "reference":
+        dec = pyoracle.RefDecoder()
+    else:
+        pyoracle.build_oracle()
+        dec = pyoracle.OracleDecoder()
+    h = dec.load_graph(graph_path)
+    cfg = pyoracle.Config(**cd)
+    results = [None] * len(mats)
+    nxt = [0]
+    lock = threading.Lock()
+
+    def work():
+        while True:
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= len(mats):
+                return
+            results[i] = dec.decode(h, cfg, mats[i], m)
+
+    # silence the reference's LOG_COM chatter on stderr during the timed part
+    saved = os.dup(2)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 2)
+    try:
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work) for _ in range(n_threads)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        dt = time.perf_counter() - t0
+    finally:
+        os.dup2(saved, 2)
+        os.close(saved)
+        os.close(devnull)
+    dec.free_graph(h)
+    frames = sum(int(x.shape[0]) for x in mats)
+    return kind, frames / dt, dt, results
+
+
+def oracle_counts(graph_path, cd, mats, m):
+    """N/E/Z work counts of the CPU restatement (algorithmic bytes come from the
+    CPU restatement's counts, not from GPU-side expansion)."""
+    import ctypes as C
+
+    import pyoracle
+
+    pyoracle.build_oracle()
+    orc = pyoracle.OracleDecoder()
+    f = orc.lib.oracle_decode_ex
+    f.restype = C.c_int
+    h = orc.load_graph(graph_path)
+    tot = np.zeros(8, np.int64)
+    cfg = pyoracle.Config(**cd)
+    lock = threading.Lock()
+    idx = [0]
+
+    def work():
+        while True:
+            with lock:
+                i = idx[0]
+                idx[0] += 1
+            if i >= len(mats):
+                return
+            ll = np.ascontiguousarray(mats[i], np.float32)
+            T, stride = ll.shape
+            mp = 4 * T + 64
+            ib = [np.zeros(mp, np.int32) for _ in range(4)]
+            fb = [np.zeros(mp, np.float32) for _ in range(2)]
+            n = [C.c_int(0) for _ in range(6)]
+            sc = [C.c_float(0), C.c_float(0)]
+            ex = np.zeros(8, np.int64)
+            ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+            fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+            f(C.c_void_p(h), C.byref(cfg), fp(ll), T, stride, ip(m), int(m.shape[0] - 1), 0, 1, 1,
+              ip(ib[0]), ip(ib[1]), fp(fb[0]), fp(fb[1]), mp, C.byref(n[0]), C.byref(sc[0]), C.byref(sc[1]),
+              ip(ib[2]), mp, C.byref(n[1]), ip(ib[3]), mp, C.byref(n[2]), None, None, -1, None, None, 0, None,
+              C.byref(n[3]), C.byref(n[4]), ex.ctypes.data_as(C.POINTER(C.c_int64)))
+            with lock:
+                tot[:] += ex
+
+    th = [threading.Thread(target=work) for _ in range(min(len(mats), os.cpu_count() or 1))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    orc.free_graph(h)
+    return dict(N=int(tot[0]), E=int(tot[1]), Z=int(tot[2]), ties_on_best_path=int(tot[5]))
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    pkg = importlib.import_module("asr-decoder_amd")
+    synth, wfstdec = pkg.synth, pkg.wfstdec
+    pkg.build.build()
+
+    B, T, P = a.batch, a.frames, a.pdfs
+    n_tid = 2 * P
+    m = synth.default_tid2pdf(n_tid)
+    cd = dict(beam=a.beam, max_active=a.max_active, min_active=a.min_active, lattice_beam=7.0,
+              prune_interval=25, beam_delta=0.5)
+
+    # ---- inputs (untimed) -------------------------------------------------------------------
+    t0 = time.time()
+    gpath = (a.graph_cache % a.states) + (".r%d" % rank if world > 1 else "")
+    if os.path.exists(gpath):
+        g = synth.Graph.read(gpath)
+    else:
+        g = synth.make_hclg_like(a.states, seed=7, n_tid=n_tid)
+        g.write(gpath)
+    log("[rank %d] graph: %d states, %d arcs (%.1fs)" % (rank, g.n_states, g.n_arcs, time.time() - t0))
+    t0 = time.time()
+    mats = make_utts(synth, g, m, rank * B, B, T, P, a.mu, a.sigma)
+    ll_dev = torch.from_numpy(mats).to(dev)  # [B][T][P] resident in HBM
+    log("[rank %d] log-likelihoods: %d x [%d x %d] (%.1fs)" % (rank, B, T, P, time.time() - t0))
+
+    graph = wfstdec.Graph.from_arrays(g.start, g.final_state, g.state_info, g.arcs, device=local_rank)
+    graph.set_tid2pdf(m)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    dec = wfstdec.BatchDecoder(graph, wfstdec.Config(**cd), B, max_frames=T + 2, max_tokens_per_frame=32768,
+                               arena_tokens=int(T * 14000), stream=stream)
+    ptrs = [ll_dev[i].data_ptr() for i in range(B)]
+    ready = [T] * B
+    Lmax = 64
+
+    def step():
+        dec.init()
+        dec.advance(ptrs, ready, P)
+        dec.finalize()
+        res = dec.best_paths(cap=2 * T + 64)
+        if world > 1:  # gather final results on every rank (rank 0 is the consumer)
+            w = torch.zeros((B, Lmax + 3), dtype=torch.float32, device=dev)
+            host = np.zeros((B, Lmax + 3), np.float32)
+            for i, r in enumerate(res):
+                k = min(len(r["words"]), Lmax)
+                host[i, 0] = k
+                host[i, 1] = r["tot_score"]
+                host[i, 2] = r["lm_score"]
+                host[i, 3:3 + k] = r["words"][:k]
+            w.copy_(torch.from_numpy(host))
+            out = [torch.empty_like(w) for _ in range(world)]
+            dist.all_gather(out, w)
+        return res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        res = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    frames_total = world * B * T * a.steps
+    value = frames_total / dt
+
+    # ---- roofline pass: one more step with HIP events around every kernel launch -----------
+    gstats = [dec.stats(c) for c in range(B)]
+    dec.set_profiling(True)
+    step()
+    prof = dec.profile()
+    dec.set_profiling(False)
+
+    out = {
+        "metric": "frames/sec decoded (RTFx = value/100) at fixed beam, best-path parity with the reference CPU decoder",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded hclg-like graph + planted-path log-likelihoods, SURVEY.md 8(d))",
+        "config": {
+            "workload": "BASELINE configs[1]: batch=%d utterances/GPU x %d frames, %d-arc HCLG, beam=%g, "
+                        "max_active=%d, min_active=%d, %d pdfs" % (B, T, g.n_arcs, a.beam, a.max_active, a.min_active, P),
+            "global_batch": world * B, "frames_per_utt": T, "parallelism": "utterance-sharded x%d (graph replicated)" % world,
+            "rtfx": value / 100.0,
+        },
+    }
+    if rank == 0:
+        N = sum(s["N"] for s in gstats)
+        E = sum(s["E"] for s in gstats)
+        Z = sum(s["Z"] for s in gstats)
+        toks = sum(s["tokens"] for s in gstats)
+        out["config"]["mean_active_tokens_per_frame"] = toks / float(B * (T + 1))
+        out["config"]["mean_expanded_tokens_per_frame"] = N / float(B * T)
+        # ---- CPU baseline + live parity on a bounded sample ---------------------------------
+        scale = 1.0
+        if a.cpu_sample > 0:
+            ns = min(a.cpu_sample, B)
+            nth = a.cpu_threads or min(ns, os.cpu_count() or 1)
+            sample = [mats[i] for i in range(ns)]
+            kind, fps, cdt, cres = cpu_baseline(gpath, cd, sample, m, nth)
+            exact = 0
+            for i in range(ns):
+                o, r = cres[i], res[i]
+                if (np.array_equal(o.words, r["words"]) and np.array_equal(o.tids, r["tids"]) and
+                        np.float32(o.tot_score).tobytes() == np.float32(r["tot_score"]).tobytes()):
+                    exact += 1
+            out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": nth, "kind": kind,
+                                   "sample": "%d of the %d utterances of rank 0 (%d frames), %.1fs wall on %d host threads, "
+                                             "one decoder object per thread over one shared graph" % (ns, B, ns * T, cdt, nth),
+                                   "host_cpus": os.cpu_count()}
+            out["config"]["parity"] = "%d/%d sampled utterances bit-exact (words, transition-ids, tot_score) vs the %s CPU decoder" % (
+                exact, ns, "reference" if kind == "reference" else "oracle")
+            oc = oracle_counts(gpath, cd, sample, m)
+            gs = {k: sum(gstats[i][k] for i in range(ns)) for k in ("N", "E", "Z")}
+            out["config"]["work_counts_sample"] = {"oracle": oc, "gpu": gs}
+            # algorithmic bytes from the CPU restatement's counts, scaled from the sample to the batch
+            # by the GPU's own (identically defined) N+E counters
+            if gs["N"] + gs["E"] > 0:
+                scale = (oc["N"] + oc["E"]) / float(gs["N"] + gs["E"])
+        # expand kernel: per emitting arc 16 B arc + 4 B log-like + 8 B hash min-update = 28 B,
+        # per expanded token 8 B {state,cost} + 8 B arc-range = 16 B (the token's 8 B arena write and
+        # the 24 B per epsilon arc belong to the boundary kernel).  DESIGN.md "Roofline accounting".
+        exp_bytes = scale * (28.0 * E + 16.0 * N)
+        bnd_bytes = scale * (8.0 * N) + 24.0 * Z
+        dom = "expand" if prof["expand_ms"] >= prof["boundary_ms"] else "boundary"
+        k_ms, k_n, k_bytes = ((prof["expand_ms"], prof["expand_launches"], exp_bytes) if dom == "expand"
+                              else (prof["boundary_ms"], prof["boundary_launches"], bnd_bytes))
+        per_launch_bytes = k_bytes / max(k_n, 1)
+        avg_ms = k_ms / max(k_n, 1)
+        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(dom + "_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
+                           "expand_ms_per_step": prof["expand_ms"], "boundary_ms_per_step": prof["boundary_ms"],
+                           "measured": "hipEvent pairs around every launch on the decoder's stream, one extra step after the timed region"}
+        print(json.dumps(out), flush=True)
+    dec.free()
+    graph.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
