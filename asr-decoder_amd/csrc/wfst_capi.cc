@@ -14,6 +14,7 @@
 #include "wfst_device.h"
 
 using namespace wfst;
+namespace wfst { int insert_kernel_set_lds(int bytes); }
 
 namespace {
 
@@ -55,13 +56,16 @@ struct wfst_graph {
   std::vector<int32_t> ilabel_host;  // original ilabels (re-mapped when tid2pdf changes)
   DevBuf<uint2> state_info;
   DevBuf<int4> arcs;
-  DevBuf<int32_t> arc_ilabel, arc_src;
+  DevBuf<int32_t> arc_ilabel, arc_olabel, arc_src;
+  uint32_t start_flags = 0;
   GraphDev view() const {
     GraphDev g;
     g.state_info = state_info.p;
     g.arcs = arcs.p;
     g.arc_ilabel = arc_ilabel.p;
+    g.arc_olabel = arc_olabel.p;
     g.arc_src = arc_src.p;
+    g.start_flags = start_flags;
     g.start = start;
     g.final_state = final_state;
     g.n_states = n_states;
@@ -72,6 +76,7 @@ struct wfst_graph {
     state_info.release();
     arcs.release();
     arc_ilabel.release();
+    arc_olabel.release();
     arc_src.release();
   }
 };
@@ -86,9 +91,10 @@ struct wfst_decoder {
   DecoderDev D;
   DevBuf<ChanCtl> ctl;
   DevBuf<int4> tok;
-  DevBuf<int32_t> frame_off, keys, toki, occ, front_slot, worklist, target, chan_list;
+  DevBuf<int32_t> frame_off, bucket_cnt, eps_keys, eps_toki, eps_occ_list, worklist, target, chan_list;
+  DevBuf<int4> bucket;
   DevBuf<float> cutoff_hist;
-  DevBuf<unsigned long long> vals;
+  DevBuf<unsigned long long> eps_vals;
   DevBuf<const float *> ll_base;
   // host mirrors (the frame loop is deterministic, so the host knows these without a read-back)
   std::vector<int32_t> h_decoded, h_target, h_state;  // state: 0 = never inited, 1 = decoding, 2 = finalized
@@ -109,7 +115,7 @@ struct wfst_decoder {
   // optional kernel timing (wfst_decoder_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
-  std::vector<std::pair<int, int>> ev_pairs[2];  // [kernel class] -> (start, stop) event indices
+  std::vector<std::pair<int, int>> ev_pairs[3];  // [kernel class] -> (start, stop) event indices
   size_t ev_used = 0;
   int ev_get() {
     if (ev_used == ev_pool.size()) {
@@ -130,9 +136,9 @@ struct wfst_decoder {
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
-    ctl.release(); tok.release(); frame_off.release(); keys.release(); toki.release(); occ.release();
-    front_slot.release(); worklist.release(); target.release(); chan_list.release(); cutoff_hist.release();
-    vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_g.release();
+    ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); eps_keys.release();
+    eps_toki.release(); eps_occ_list.release(); worklist.release(); target.release(); chan_list.release();
+    bucket.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_g.release();
     bp_ac.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -162,7 +168,7 @@ int wfst_device_count(void) {
 /* ---------------------------------------------------------------- graph */
 
 static int upload_arcs(wfst_graph *g, const wfst_state_info *states, const wfst_arc *arcs,
-                       const int32_t *tid2pdf, int32_t n_tid) {
+                       const int32_t *tid2pdf, int32_t n_tid, const std::vector<uint32_t> *state_flags = nullptr) {
   const int32_t S = g->n_states, A = g->n_arcs;
   std::vector<int4> h_arcs((size_t)A);
   int32_t max_col = 0;
@@ -182,7 +188,7 @@ static int upload_arcs(wfst_graph *g, const wfst_state_info *states, const wfst_
     int4 v;
     v.x = col;
     if (arcs) {
-      v.y = arcs[a].olabel;
+      v.y = (int32_t)(*state_flags)[arcs[a].nextstate];
       memcpy(&v.z, &arcs[a].weight, 4);
       v.w = arcs[a].nextstate;
       h_arcs[a] = v;
@@ -220,7 +226,9 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
 
   std::vector<uint2> h_si((size_t)n_states);
   std::vector<int32_t> h_src((size_t)n_arcs);
-  std::vector<int32_t> h_il((size_t)n_arcs);
+  std::vector<int32_t> h_il((size_t)n_arcs), h_ol((size_t)n_arcs);
+  std::vector<uint32_t> h_flags((size_t)n_states, 0u);
+  if ((uint32_t)n_arcs >= kNoArc) return fail(WFST_E_FORMAT, "graphs of 2^30 arcs or more are not supported");
   int64_t off = 0;
   for (int32_t s = 0; s < n_states; ++s) {
     const uint32_t na = states[s].num_arcs, ne = states[s].niepsilons;
@@ -234,7 +242,10 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
       if (a.nextstate < 0 || a.nextstate >= n_states) return fail(WFST_E_FORMAT, "arc nextstate out of range");
       h_src[off + i] = (int32_t)((uint32_t)s | (i < ne ? 0x80000000u : 0u));
       h_il[off + i] = a.ilabel;
+      h_ol[off + i] = a.olabel;
+      if (i < ne) h_flags[a.nextstate] |= kFlagEpsTarget;
     }
+    if (ne) h_flags[s] |= kFlagOutEps;
     h_si[s] = make_uint2((uint32_t)off, ((na - ne) << kEpsBits) | ne);
     off += na;
   }
@@ -247,18 +258,21 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
   g->n_states = n_states;
   g->n_arcs = n_arcs;
   g->ilabel_host.swap(h_il);
+  g->start_flags = h_flags[start];
   hipError_t e;
   if ((e = g->state_info.alloc(n_states)) != hipSuccess || (e = g->arcs.alloc(n_arcs)) != hipSuccess ||
-      (e = g->arc_ilabel.alloc(n_arcs)) != hipSuccess || (e = g->arc_src.alloc(n_arcs)) != hipSuccess) {
+      (e = g->arc_ilabel.alloc(n_arcs)) != hipSuccess || (e = g->arc_olabel.alloc(n_arcs)) != hipSuccess ||
+      (e = g->arc_src.alloc(n_arcs)) != hipSuccess) {
     delete g;
     return fail(WFST_E_DEVICE, std::string("hipMalloc(graph): ") + hipGetErrorString(e));
   }
   int rc = WFST_OK;
   if (hipMemcpy(g->state_info.p, h_si.data(), h_si.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(g->arc_src.p, h_src.data(), h_src.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(g->arc_olabel.p, h_ol.data(), h_ol.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(g->arc_ilabel.p, g->ilabel_host.data(), g->ilabel_host.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(WFST_E_DEVICE, "hipMemcpy(graph) failed");
-  if (rc == WFST_OK) rc = upload_arcs(g, states, arcs, nullptr, 0);
+  if (rc == WFST_OK) rc = upload_arcs(g, states, arcs, nullptr, 0, &h_flags);
   if (rc != WFST_OK) {
     delete g;
     return rc;
@@ -305,7 +319,8 @@ int wfst_graph_info(const wfst_graph *g, int32_t *start, int32_t *final_state, i
   if (n_states) *n_states = g->n_states;
   if (n_arcs) *n_arcs = g->n_arcs;
   if (device_bytes)
-    *device_bytes = (int64_t)(g->state_info.bytes() + g->arcs.bytes() + g->arc_ilabel.bytes() + g->arc_src.bytes());
+    *device_bytes = (int64_t)(g->state_info.bytes() + g->arcs.bytes() + g->arc_ilabel.bytes() +
+                              g->arc_olabel.bytes() + g->arc_src.bytes());
   return WFST_OK;
 }
 
@@ -339,9 +354,17 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   if (L.max_tokens_per_frame <= 0) L.max_tokens_per_frame = 32768;
   if (L.arena_tokens <= 0) L.arena_tokens = 4194304;
   if (L.arena_tokens > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "arena_tokens must fit int32");
-  int log2cap = 4;
-  while ((1ll << log2cap) < 2ll * L.max_tokens_per_frame) ++log2cap;
-  if (log2cap > 30) return fail(WFST_E_ARG, "max_tokens_per_frame too large");
+  // hash partitions: each insert workgroup owns an LDS table of lds_slots entries at <= 50 % load
+  const int64_t M = L.max_tokens_per_frame;
+  int lds_slots = 4096, log2lds = 12;
+  if (2 * M > 64ll * lds_slots) { lds_slots = 8192; log2lds = 13; }
+  if (2 * M > 64ll * lds_slots) return fail(WFST_E_ARG, "max_tokens_per_frame too large (limit 262144)");
+  int log2part = 0;
+  while ((int64_t)lds_slots << log2part < 2 * M) ++log2part;
+  const int n_part = 1 << log2part;
+  const int64_t bucket_cap = std::max<int64_t>(2048, 8 * M / n_part);
+  int log2ecap = 6;
+  while ((1ll << log2ecap) < 2 * M) ++log2ecap;
 
   wfst_decoder *d = new wfst_decoder();
   d->graph = g;
@@ -357,7 +380,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
     }
     d->own_stream = true;
   }
-  const size_t B = (size_t)n_channels, cap = (size_t)1 << log2cap;
+  const size_t B = (size_t)n_channels, ecap = (size_t)1 << log2ecap;
   const size_t fo = (size_t)L.max_frames + 2;
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -365,11 +388,12 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   A(d->tok.alloc(B * (size_t)L.arena_tokens));
   A(d->frame_off.alloc(B * fo));
   A(d->cutoff_hist.alloc(B * fo));
-  A(d->keys.alloc(B * 2 * cap));
-  A(d->vals.alloc(B * 2 * cap));
-  A(d->toki.alloc(B * 2 * cap));
-  A(d->occ.alloc(B * 2 * cap));
-  A(d->front_slot.alloc(B * (size_t)L.max_tokens_per_frame));
+  A(d->bucket.alloc(B * (size_t)n_part * (size_t)bucket_cap));
+  A(d->bucket_cnt.alloc(B * (size_t)n_part));
+  A(d->eps_keys.alloc(B * ecap));
+  A(d->eps_vals.alloc(B * ecap));
+  A(d->eps_toki.alloc(B * ecap));
+  A(d->eps_occ_list.alloc(B * ecap));
   A(d->worklist.alloc(B * 2 * (size_t)L.max_tokens_per_frame));
   A(d->target.alloc(B));
   A(d->chan_list.alloc(B));
@@ -379,6 +403,10 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   A(hipHostMalloc((void **)&d->p_ll, B * sizeof(float *)));
   A(hipHostMalloc((void **)&d->p_ctl, B * sizeof(ChanCtl)));
   if (e == hipSuccess) A(hipMemsetAsync(d->ctl.p, 0, d->ctl.bytes(), d->stream));
+  if (e == hipSuccess) A(hipMemsetAsync(d->bucket_cnt.p, 0, d->bucket_cnt.bytes(), d->stream));
+  if (e == hipSuccess) A(hipMemsetAsync(d->eps_keys.p, 0xFF, d->eps_keys.bytes(), d->stream));
+  if (e == hipSuccess) A(hipMemsetAsync(d->eps_vals.p, 0xFF, d->eps_vals.bytes(), d->stream));
+  if (e == hipSuccess && lds_slots * 12 > 65536) A((hipError_t)insert_kernel_set_lds(lds_slots * 12));
   if (e == hipSuccess) A(hipMemsetAsync(d->target.p, 0, d->target.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->ll_base.p, 0, d->ll_base.bytes(), d->stream));
   if (e == hipSuccess) A(hipStreamSynchronize(d->stream));
@@ -392,17 +420,23 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.tok = d->tok.p;
   D.frame_off = d->frame_off.p;
   D.cutoff_hist = d->cutoff_hist.p;
-  D.keys = d->keys.p;
-  D.vals = d->vals.p;
-  D.toki = d->toki.p;
-  D.occ = d->occ.p;
-  D.front_slot = d->front_slot.p;
+  D.bucket = d->bucket.p;
+  D.bucket_cnt = d->bucket_cnt.p;
+  D.eps_keys = d->eps_keys.p;
+  D.eps_vals = d->eps_vals.p;
+  D.eps_toki = d->eps_toki.p;
+  D.eps_occ_list = d->eps_occ_list.p;
   D.worklist = d->worklist.p;
   D.ll_base = d->ll_base.p;
   D.n_channels = n_channels;
   D.stride = 0;
-  D.cap = (int32_t)cap;
-  D.log2cap = log2cap;
+  D.n_part = n_part;
+  D.log2part = log2part;
+  D.lds_slots = lds_slots;
+  D.log2lds = log2lds;
+  D.bucket_cap = (int32_t)bucket_cap;
+  D.ecap = (int32_t)ecap;
+  D.log2ecap = log2ecap;
   D.max_tok = L.max_tokens_per_frame;
   D.wl_cap = L.max_tokens_per_frame;
   D.max_frames = L.max_frames;
@@ -523,11 +557,12 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     launch();
     if (a >= 0 && b >= 0) { (void)hipEventRecord(d->ev_pool[b], d->stream); d->ev_pairs[cls].push_back({a, b}); }
   };
+  timed(2, [&] { launch_closure(d->D, d->target.p, 1, d->stream); });  // GetCutoff + seed only
   for (int s = 0; s < steps; ++s) {
-    timed(1, [&] { launch_boundary(d->D, d->target.p, s > 0, 1, d->stream); });
     timed(0, [&] { launch_expand(d->D, d->tiles_per_channel, d->stream); });
+    timed(1, [&] { launch_insert(d->D, d->stream); });
+    timed(2, [&] { launch_closure(d->D, d->target.p, s + 1 < steps, d->stream); });
   }
-  timed(1, [&] { launch_boundary(d->D, d->target.p, 1, 0, d->stream); });
   HIP_TRY(hipGetLastError());
   for (int c = 0; c < d->n_channels; ++c) d->h_decoded[c] = std::max(d->h_decoded[c], d->h_target[c]);
   return WFST_OK;
@@ -620,6 +655,7 @@ static int check_ctl_errors(wfst_decoder *d) {
       if (e & kErrFrontierFull) m += " frontier (max_tokens_per_frame)";
       if (e & kErrWorklistFull) m += " epsilon worklist (max_tokens_per_frame)";
       if (e & kErrFramesFull) m += " frames (max_frames)";
+      if (e & kErrBucketFull) m += " candidate bucket (max_tokens_per_frame)";
       return fail(WFST_E_CAPACITY, m);
     }
   }
@@ -708,16 +744,15 @@ int wfst_decoder_set_profiling(wfst_decoder *d, int32_t enable) {
   HIP_TRY(hipStreamSynchronize(d->stream));
   d->profiling = enable != 0;
   d->ev_used = 0;
-  d->ev_pairs[0].clear();
-  d->ev_pairs[1].clear();
+  for (auto &v : d->ev_pairs) v.clear();
   return WFST_OK;
 }
 
-int wfst_decoder_get_profile(wfst_decoder *d, double ms[2], int64_t launches[2]) {
+int wfst_decoder_get_profile(wfst_decoder *d, double ms[3], int64_t launches[3]) {
   if (!d || !ms || !launches) return fail(WFST_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(d->device));
   HIP_TRY(hipStreamSynchronize(d->stream));
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     double tot = 0;
     for (auto &pr : d->ev_pairs[k]) {
       float t = 0;
@@ -742,7 +777,7 @@ int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]) {
   stats[3] = (int64_t)c.cnt_Z;
   stats[4] = (int64_t)c.cnt_tok;
   stats[5] = c.peak_tokens;
-  stats[6] = (int64_t)c.cnt_slots;
+  stats[6] = (int64_t)c.cnt_rec;
   stats[7] = 0;
   return WFST_OK;
 }

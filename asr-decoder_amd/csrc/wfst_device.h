@@ -15,78 +15,92 @@ namespace wfst {
 // ---- graph in HBM: CSR -------------------------------------------------------------------
 // state_info[s] = {arc_begin, (n_emit << 12) | n_eps}: one 8-byte load gives both arc ranges of
 //   a state: epsilon arcs [arc_begin, arc_begin+n_eps), emitting arcs the n_emit after them.
-// arcs[a]       = {ll_col, olabel, weight bits, nextstate}: 16-byte AoS, one dwordx4 per lane.
-//   ll_col is the log-likelihood column of the arc's ilabel (tid2pdf applied at upload), -1 for
-//   an input-epsilon arc.
-// arc_ilabel[a] = original ilabel (transition-id) for output.
-// arc_src[a]    = source state of arc a (resolves a winning arc to its source token).
+// arcs[a]       = {ll_col, next_flags, weight bits, nextstate}: 16-byte AoS, one dwordx4 per lane.
+//   ll_col      log-likelihood column of the arc's ilabel (tid2pdf applied at upload), -1 for an
+//               input-epsilon arc;
+//   next_flags  kFlagOutEps / kFlagEpsTarget of NEXTSTATE (so a new token knows, without touching
+//               state_info, whether the epsilon closure has to look at it).
+// arc_ilabel[a], arc_olabel[a] = labels for output (cold: traceback only).
+// arc_src[a]    = source state of arc a, bit 31 set for an input-epsilon arc.
 struct GraphDev {
   const uint2 *state_info;
   const int4 *arcs;
   const int32_t *arc_ilabel;
+  const int32_t *arc_olabel;
   const int32_t *arc_src;
   int32_t start, final_state, n_states, n_arcs;
+  uint32_t start_flags;
 };
 
 constexpr int kEpsBits = 12;
 constexpr uint32_t kEpsMask = (1u << kEpsBits) - 1;
+constexpr uint32_t kFlagOutEps = 0x80000000u;     // state has outgoing input-epsilon arcs
+constexpr uint32_t kFlagEpsTarget = 0x40000000u;  // some input-epsilon arc enters the state
+constexpr uint32_t kFlagMask = kFlagOutEps | kFlagEpsTarget;
+constexpr uint32_t kArcMask = ~kFlagMask;          // arc indices are < 2^30
+constexpr uint32_t kNoArc = kArcMask;              // "no arc" (root token), flags kept beside it
 constexpr int32_t kEmptyKey = -1;
 constexpr unsigned long long kEmptyVal = ~0ull;
-constexpr uint32_t kNoArc = 0xFFFFFFFFu;
 
 // error bits (ChanCtl::error)
 constexpr int kErrTableFull = 1, kErrArenaFull = 2, kErrFrontierFull = 4, kErrWorklistFull = 8,
-              kErrFramesFull = 16;
+              kErrFramesFull = 16, kErrBucketFull = 32;
 
 // ---- per-channel control block (one 128-byte line each) ----------------------------------
 struct __attribute__((aligned(128))) ChanCtl {
   int32_t n_decoded;     // NumFramesDecoded()
-  int32_t target;        // decode frames while n_decoded < target (set per advance call)
   int32_t front_begin;   // arena index of the current frontier's first token
   int32_t front_count;   // tokens in the current frontier
-  int32_t cur_tab;       // hash table (0/1) holding the current frontier's states
   int32_t active;        // this frame step processes the channel
   uint32_t bound;        // orderable next_cutoff, tightened during expansion (atomicMin)
   float cur_cutoff;      // GetCutoff() result for the frame being expanded
   float adaptive_beam;
-  int32_t n_occ[2];      // occupied-slot list length per hash table
+  int32_t new_count;     // tokens of the frame being built (atomicAdd by the insert workgroups)
+  unsigned long long best_next;  // min (orderable cost << 32 | arena index) over the new frame
+  int32_t eps_occ;       // occupied slots of the epsilon table
+  int32_t wl_n;          // epsilon-closure seeds queued by the insert workgroups
   int32_t error;         // sticky kErr* bits
   int32_t finalized;
   int32_t peak_tokens;
-  int32_t pad0[2];
-  unsigned long long cnt_N, cnt_E, cnt_Z, cnt_tok, cnt_slots;  // work counters since init
+  int32_t pad0;
+  unsigned long long cnt_N, cnt_E, cnt_Z, cnt_tok, cnt_rec;  // work counters since init
   unsigned long long pad1[3];
 };
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
 
 // ---- decoder (batch of channels) ---------------------------------------------------------
-// Per channel c (all slabs are [n_channels][...] and 128-byte aligned per channel):
-//   tok[c][arena_cap]        int4 {state, cost bits, prev token (arena index, -1 root), arc}
-//   frame_off[c][max_frames+2]  arena offset of each frame's frontier (frame f = tokens
-//                               [frame_off[f], frame_off[f+1]))
-//   cutoff_hist[c][max_frames+2] cutoff used by the epsilon closure of frame f ([0] = beam)
-//   keys/vals/toki[c][2][cap]   open-addressed next-state hash, ping-pong per frame:
-//                               key = state, val = (orderable cost << 32 | arc), toki = arena index
-//   occ[c][2][cap]              slots occupied in each table (cleared by walking this list)
-//   front_slot[c][max_tok]      hash slot of each token of the frontier being built
-//   worklist[c][2][wl_cap]      epsilon-closure frontiers (double buffered)
+// Per channel c:
+//   tok[c][arena_cap]           int4 {state, cost bits, prev token (arena index, -1 root),
+//                               winning arc | flags of the state}; frame f = tokens
+//                               [frame_off[f], frame_off[f+1]); the newest frame is the frontier
+//   frame_off[c][max_frames+2], cutoff_hist[c][max_frames+2] (cutoff of frame f's closure)
+//   bucket[c][P][bucket_cap]    int4 candidate records {nextstate, cost bits, source token,
+//                               arc | flags(nextstate)}, partition = top bits of hash(nextstate)
+//   bucket_cnt[c][P]
+//   eps table (global, small working set): eps_keys/vals/toki[c][ecap], eps_occ_list[c][ecap]:
+//                               only tokens whose state has or receives epsilon arcs
+//   worklist[c][2][wl_cap]      epsilon-closure frontiers (slots of the eps table)
 struct DecoderDev {
   GraphDev g;
   ChanCtl *ctl;
   int4 *tok;
   int32_t *frame_off;
   float *cutoff_hist;
-  int32_t *keys;
-  unsigned long long *vals;
-  int32_t *toki;
-  int32_t *occ;
-  int32_t *front_slot;
+  int4 *bucket;
+  int32_t *bucket_cnt;
+  int32_t *eps_keys;
+  unsigned long long *eps_vals;
+  int32_t *eps_toki;
+  int32_t *eps_occ_list;
   int32_t *worklist;
   const float *const *ll_base;  // [n_channels] device pointers to row 0 of each utterance matrix
   int32_t n_channels;
   int32_t stride;               // floats per log-likelihood row
-  int32_t cap, log2cap;         // hash slots per table (power of two)
-  int32_t max_tok;              // frontier capacity
+  int32_t n_part, log2part;     // hash partitions per channel (power of two, <= 64)
+  int32_t lds_slots, log2lds;   // LDS hash slots per partition workgroup (4096 or 8192)
+  int32_t bucket_cap;           // records per bucket
+  int32_t ecap, log2ecap;       // epsilon-table slots (power of two)
+  int32_t max_tok;              // tokens per frame
   int32_t wl_cap;
   int32_t max_frames;
   int64_t arena_cap;
@@ -97,10 +111,11 @@ struct DecoderDev {
 
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
-void launch_boundary(const DecoderDev &D, const int32_t *target_dev, int do_finalize, int do_prep,
-                     hipStream_t s);
-void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
+void launch_prep(const DecoderDev &D, const int32_t *target_dev, hipStream_t s);
 void launch_expand(const DecoderDev &D, int tiles_per_channel, hipStream_t s);
+void launch_insert(const DecoderDev &D, hipStream_t s);
+void launch_closure(const DecoderDev &D, const int32_t *target_dev, int do_prep, hipStream_t s);
+void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_best_path(const DecoderDev &D, const int32_t *chan_list_dev, int n, int use_final,
                       int cap, int32_t *ilabel, int32_t *olabel, float *graph, float *ac,
                       int32_t *n_hops, hipStream_t s);

@@ -1,24 +1,28 @@
 // HIP kernels of the batched WFST token-passing decoder, written for gfx950 (MI355X, wave64).
 //
 // One frame of the reference's hot loop (AdvanceDecoding, my-decoder/online-decoder-base-inl.h:
-// 649-667) for ALL channels of a batch is two launches:
+// 649-667) for ALL channels of a batch is three launches:
 //
-//   boundary_kernel  one 1024-thread workgroup per channel.
-//       finalize part  = tail of ProcessEmitting + ProcessNonemitting (base-inl.h:353-431):
-//                        collect the slots the expansion created, drop tokens that lost against
-//                        the final next_cutoff, run the epsilon closure to its fixpoint inside
-//                        the kernel, append the frame's tokens to the arena, clear the old table.
-//       prep part      = GetCutoff (base-inl.h:138-234, exact k-th smallest by LDS radix select)
-//                        + the best-token seeding of next_cutoff (base-inl.h:282-300).
-//   expand_kernel    load-balanced ProcessEmitting inner loop (base-inl.h:311-347): a workgroup
-//                    takes 256 frontier tokens, scans their emitting out-degrees in LDS and maps
-//                    one lane to one arc, so low-degree HCLG states (2-3 arcs) fill wavefronts;
-//                    survivors go into the channel's open-addressed next-state hash with a
-//                    64-bit atomicMin of (orderable cost << 32 | arc).
+//   expand_kernel   ProcessEmitting's inner loop (base-inl.h:311-347), load balanced: a workgroup
+//                   takes 256 frontier tokens, scans their emitting out-degrees in LDS and maps
+//                   one lane to one arc, so low-degree HCLG states (2-3 arcs) still fill
+//                   wavefronts.  Survivors of the (evolving) next_cutoff are counting-sorted in LDS
+//                   by hash partition of their next state and appended, coalesced, to that
+//                   partition's bucket in HBM: one global atomic per partition per 1024 candidates
+//                   instead of two per candidate (scattered atomics run at ~26 G/s on MI355X at
+//                   any scope, half the rate of plain random gathers: tools/ubench_atomics.hip).
+//   insert_kernel   FindOrAddToken (base-inl.h:88-136) as insert-or-min in an LDS hash table, one
+//                   workgroup per (channel, partition): ds_cmpst on the key, ds_min_u64 on
+//                   (orderable cost << 32 | arc); the winner of each state writes the 16-byte
+//                   token (state, cost, backpointer, arc) straight into the arena.
+//   closure_kernel  ProcessNonemitting to its fixpoint inside the kernel (base-inl.h:353-431) on
+//                   a small global table that only holds states with epsilon arcs in or out, then
+//                   GetCutoff (base-inl.h:138-234; exact k-th smallest by LDS radix select) and the
+//                   best-token seeding of next_cutoff (base-inl.h:282-300) for the next frame.
 //
 // Float arithmetic follows the reference's operation order exactly (compiled with
 // -ffp-contract=off): tot = (cur + (-loglike)) + graph; seed = (cur + graph) - loglike.
-// There is no MFMA here: the path is irregular graph traversal, HBM/L2-latency bound.
+// There is no MFMA here: the path is irregular graph traversal, bound by HBM/L2 request rate.
 #include "wfst_device.h"
 
 namespace wfst {
@@ -60,13 +64,16 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 __device__ __forceinline__ int lane_rank(u64 mask) {  // active lanes below this one
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
-__device__ __forceinline__ uint32_t hash_state(int32_t s, int log2cap) {
-  return ((uint32_t)s * 2654435761u) >> (32 - log2cap);
+__device__ __forceinline__ uint32_t hash32(int32_t s) { return (uint32_t)s * 2654435761u; }
+// partition = top log2part bits of the hash, LDS slot = the next log2lds bits
+__device__ __forceinline__ int part_of(uint32_t h, int log2part) { return log2part ? (int)(h >> (32 - log2part)) : 0; }
+__device__ __forceinline__ uint32_t lds_slot_of(uint32_t h, int log2part, int log2lds) {
+  return (h >> (32 - log2part - log2lds)) & ((1u << log2lds) - 1u);
 }
 
-// Open-addressed insert (linear probing).  Returns the slot of `state`, -1 if the table is full.
-__device__ __forceinline__ int find_or_insert(int32_t *keys, int cap, int log2cap, int32_t state, bool *created) {
-  uint32_t slot = hash_state(state, log2cap);
+// ---- global epsilon table (open addressing, linear probing) ------------------------------
+__device__ __forceinline__ int eps_find_or_insert(int32_t *keys, int cap, int log2cap, int32_t state, bool *created) {
+  uint32_t slot = hash32(state) >> (32 - log2cap);
   const uint32_t mask = (uint32_t)cap - 1;
   *created = false;
   for (int p = 0; p < cap; ++p) {
@@ -81,12 +88,11 @@ __device__ __forceinline__ int find_or_insert(int32_t *keys, int cap, int log2ca
   }
   return -1;
 }
-template <bool kAgent>
-__device__ __forceinline__ int find_slot(const int32_t *keys, int cap, int log2cap, int32_t state) {
-  uint32_t slot = hash_state(state, log2cap);
+__device__ __forceinline__ int eps_find(const int32_t *keys, int cap, int log2cap, int32_t state) {
+  uint32_t slot = hash32(state) >> (32 - log2cap);
   const uint32_t mask = (uint32_t)cap - 1;
   for (int p = 0; p < cap; ++p) {
-    int32_t k = kAgent ? ld_agent(&keys[slot]) : keys[slot];
+    int32_t k = ld_agent(&keys[slot]);
     if (k == state) return (int)slot;
     if (k == kEmptyKey) return -1;
     slot = (slot + 1) & mask;
@@ -95,12 +101,13 @@ __device__ __forceinline__ int find_slot(const int32_t *keys, int cap, int log2c
 }
 
 // =========================================================================================
-// expand_kernel: ProcessEmitting's inner loop (base-inl.h:311-347), load balanced.
-//   grid (n_channels, tiles_per_channel), 256 threads.  blockIdx.x = channel, so with
-//   n_channels % 8 == 0 all workgroups of a channel share an XCD (speed only: its hash table and
-//   log-likelihood row then stay in one L2).
+// expand_kernel: grid (n_channels, tiles_per_channel), 256 threads.  blockIdx.x = channel, so
+// with n_channels % 8 == 0 the workgroups of a channel share an XCD (speed only: its buckets
+// and log-likelihood row stay in one L2).
 // =========================================================================================
 constexpr int kExpandThreads = 256;
+constexpr int kCandPerThread = 4;
+constexpr int kChunk = kExpandThreads * kCandPerThread;  // candidates per counting-sort round
 
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D) {
   const int c = blockIdx.x;
@@ -108,22 +115,23 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D) {
   if (!ctl->active) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = ctl->front_count;
-  const int4 *tok = D.tok + (size_t)c * D.arena_cap + ctl->front_begin;
-  const int tabT = ctl->cur_tab ^ 1;
-  const size_t tab_off = ((size_t)c * 2 + tabT) * (size_t)D.cap;
-  int32_t *keys = D.keys + tab_off;
-  u64 *vals = D.vals + tab_off;
-  int32_t *occ = D.occ + tab_off;
+  const int fbegin = ctl->front_begin;
+  const int4 *tok = D.tok + (size_t)c * D.arena_cap + fbegin;
   const float cutoff = ctl->cur_cutoff, ab = ctl->adaptive_beam;
   const float *llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
   const float kInf = __builtin_huge_valf();
+  const int P = D.n_part, log2part = D.log2part, bcap = D.bucket_cap;
+  int4 *bucket = D.bucket + (size_t)c * P * bcap;
+  int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
 
   __shared__ int s_base[kExpandThreads + 1];
   __shared__ int s_arcbeg[kExpandThreads];
   __shared__ float s_cost[kExpandThreads];
   __shared__ int s_wsum[kExpandThreads / 64];
+  __shared__ int s_cnt[64], s_lbase[65], s_gbase[64];
+  __shared__ int4 s_rec[kChunk];
 
-  u64 nN = 0, nE = 0;
+  u64 nN = 0, nE = 0, nR = 0;
   for (int tile = blockIdx.y; tile * kExpandThreads < n; tile += gridDim.y) {
     const int i = tile * kExpandThreads + tid;
     int deg = 0, arcbeg = 0;
@@ -158,92 +166,268 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D) {
     }
     s_base[tid] = wbase + incl - deg;
     if (tid == 0) s_base[kExpandThreads] = total;
+    if (tid < 64) s_cnt[tid] = 0;
     __syncthreads();
 
     float bound = o2f(ld_agent(&ctl->bound));
-    for (int j0 = 0; j0 < total; j0 += kExpandThreads) {
-      const int j = j0 + tid;
-      const bool valid = j < total;
-      float tot = kInf;
-      int a = 0;
-      int32_t nextstate = 0;
-      if (valid) {
-        int lo = 0, hi = kExpandThreads;  // s_base[lo] <= j < s_base[hi]
-        while (hi - lo > 1) {
-          int mid = (lo + hi) >> 1;
-          if (s_base[mid] <= j) lo = mid; else hi = mid;
+    const int tok0 = fbegin + tile * kExpandThreads;  // arena index of the tile's first token
+    for (int j0 = 0; j0 < total; j0 += kChunk) {
+      int4 rec[kCandPerThread];
+      float tot[kCandPerThread];
+      float tmin = kInf;
+#pragma unroll
+      for (int k = 0; k < kCandPerThread; ++k) {
+        const int j = j0 + k * kExpandThreads + tid;
+        tot[k] = kInf;
+        if (j < total) {
+          int lo = 0, hi = kExpandThreads;  // s_base[lo] <= j < s_base[hi]
+          while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (s_base[mid] <= j) lo = mid; else hi = mid;
+          }
+          const int a = s_arcbeg[lo] + (j - s_base[lo]);
+          const int4 arc = D.g.arcs[a];
+          const float ac_cost = -llrow[arc.x];                         // base-inl.h:326
+          tot[k] = (s_cost[lo] + ac_cost) + __int_as_float(arc.z);      // base-inl.h:329
+          rec[k] = make_int4(arc.w, __float_as_int(tot[k]), tok0 + lo, (int)((uint32_t)a | (uint32_t)arc.y));
+          tmin = fminf(tmin, tot[k]);
         }
-        a = s_arcbeg[lo] + (j - s_base[lo]);
-        const int4 arc = D.g.arcs[a];
-        const float ac_cost = -llrow[arc.x];                      // base-inl.h:326
-        tot = (s_cost[lo] + ac_cost) + __int_as_float(arc.z);     // base-inl.h:329
-        nextstate = arc.w;
       }
       // base-inl.h:330-333: tighten next_cutoff by the best candidate seen (wave-aggregated)
-      const float cand = wave_min_f(tot) + ab;
+      const float cand = wave_min_f(tmin) + ab;
       if (cand < bound) {
         uint32_t old = 0;
         if (lane == 0) old = atomicMin(&ctl->bound, f2o(cand));
         old = __shfl(old, 0, 64);
         bound = fminf(o2f(old), cand);
       }
-      if (valid && tot < bound) {
-        // FindOrAddToken (base-inl.h:88-136) as insert-or-min on (cost, arc)
-        const u64 packed = ((u64)f2o(tot) << 32) | (uint32_t)a;
-        bool created;
-        const int slot = find_or_insert(keys, D.cap, D.log2cap, nextstate, &created);
-        if (slot < 0) {
-          atomicOr(&ctl->error, kErrTableFull);
-        } else if (created) {
-          const int pos = atomicAdd(&ctl->n_occ[tabT], 1);
-          occ[pos] = slot;
-          atomicMin(&vals[slot], packed);
-        } else if (packed < ld_agent(&vals[slot])) {
-          atomicMin(&vals[slot], packed);
+      // counting sort of the survivors by hash partition, in LDS
+      int part[kCandPerThread], rank[kCandPerThread];
+#pragma unroll
+      for (int k = 0; k < kCandPerThread; ++k) {
+        part[k] = -1;
+        if (tot[k] < bound) {
+          part[k] = part_of(hash32(rec[k].x), log2part);
+          rank[k] = atomicAdd(&s_cnt[part[k]], 1);
         }
       }
+      __syncthreads();
+      if (tid < 64) {
+        const int cnt = tid < P ? s_cnt[tid] : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          int v = __shfl_up(inc, off, 64);
+          if (lane >= off) inc += v;
+        }
+        s_lbase[tid] = inc - cnt;
+        if (tid == 63) s_lbase[64] = inc;
+        int g = 0;
+        if (cnt) {
+          g = atomicAdd(&bucket_cnt[tid], cnt);
+          if (g + cnt > bcap) atomicOr(&ctl->error, kErrBucketFull);
+        }
+        s_gbase[tid] = g;
+        s_cnt[tid] = 0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kCandPerThread; ++k)
+        if (part[k] >= 0) s_rec[s_lbase[part[k]] + rank[k]] = rec[k];
+      __syncthreads();
+      const int npass = s_lbase[64];
+      nR += (tid == 0) ? (u64)npass : 0;
+      for (int q = tid; q < npass; q += kExpandThreads) {
+        const int4 r = s_rec[q];
+        const int p = part_of(hash32(r.x), log2part);
+        const int gi = s_gbase[p] + (q - s_lbase[p]);
+        if (gi < bcap) bucket[(size_t)p * bcap + gi] = r;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   nN = wave_sum_u64(nN);
   nE = wave_sum_u64(nE);
-  if (lane == 0 && (nN | nE)) {
+  if (lane == 0 && (nN | nE | nR)) {
     atomicAdd(&ctl->cnt_N, nN);
     atomicAdd(&ctl->cnt_E, nE);
+    if (nR) atomicAdd(&ctl->cnt_rec, nR);
   }
 }
 
 // =========================================================================================
-// boundary_kernel and its pieces.  One 1024-thread workgroup per channel.
+// insert_kernel: grid (n_channels, n_part), 256 threads, dynamic LDS = lds_slots * 12 bytes.
+// =========================================================================================
+constexpr int kInsertThreads = 256;
+
+__global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int c = blockIdx.x, p = blockIdx.y;
+  ChanCtl *ctl = D.ctl + c;
+  if (!ctl->active) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int SL = D.lds_slots;
+  u64 *vals = reinterpret_cast<u64 *>(smem);
+  int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)SL * 8);
+  __shared__ int s_nstates, s_gpos, s_wpos, s_ok;
+  __shared__ u64 s_best[kInsertThreads / 64];
+
+  const int P = D.n_part;
+  int32_t *cntp = D.bucket_cnt + (size_t)c * P + p;
+  int n = *cntp;
+  if (n > D.bucket_cap) n = D.bucket_cap;
+  if (n == 0) return;
+  const int4 *bucket = D.bucket + ((size_t)c * P + p) * D.bucket_cap;
+  const float cutoff = o2f(ctl->bound);  // FINAL next_cutoff of this frame
+  const uint32_t mask = (uint32_t)SL - 1;
+
+  for (int i = tid; i < SL; i += kInsertThreads) { keys[i] = kEmptyKey; vals[i] = kEmptyVal; }
+  if (tid == 0) { s_nstates = 0; s_wpos = 0; s_ok = 1; }
+  __syncthreads();
+
+  // pass 1: insert-or-min.  Candidates that lost against the final cutoff are dropped here: the
+  // reference keeps those order-dependent extras (base-inl.h:330) but never expands them.
+  for (int i = tid; i < n; i += kInsertThreads) {
+    const int4 r = bucket[i];
+    if (!(__int_as_float(r.y) < cutoff)) continue;
+    uint32_t slot = lds_slot_of(hash32(r.x), D.log2part, D.log2lds);
+    bool found = false;
+    for (int q = 0; q < SL; ++q) {
+      int32_t k = keys[slot];
+      if (k == kEmptyKey) {
+        k = atomicCAS(&keys[slot], kEmptyKey, r.x);
+        if (k == kEmptyKey) { atomicAdd(&s_nstates, 1); found = true; break; }
+      }
+      if (k == r.x) { found = true; break; }
+      slot = (slot + 1) & mask;
+    }
+    if (found) atomicMin(&vals[slot], ((u64)f2o(__int_as_float(r.y)) << 32) | (uint32_t)r.w);
+    else atomicOr(&ctl->error, kErrTableFull);
+  }
+  __syncthreads();
+  const int ns = s_nstates;
+  const int base = ctl->front_begin + ctl->front_count;
+  if (tid == 0) {
+    int g = atomicAdd(&ctl->new_count, ns);
+    s_gpos = g;
+    if (g + ns > D.max_tok) { atomicOr(&ctl->error, kErrFrontierFull); s_ok = 0; }
+    if ((int64_t)base + g + ns > D.arena_cap) { atomicOr(&ctl->error, kErrArenaFull); s_ok = 0; }
+    *cntp = 0;  // bucket consumed
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  const int gpos = s_gpos;
+  int4 *tok = D.tok + (size_t)c * D.arena_cap;
+  int32_t *ekeys = D.eps_keys + (size_t)c * D.ecap;
+  u64 *evals = D.eps_vals + (size_t)c * D.ecap;
+  int32_t *etoki = D.eps_toki + (size_t)c * D.ecap;
+  int32_t *eocc = D.eps_occ_list + (size_t)c * D.ecap;
+  int32_t *wl = D.worklist + (size_t)c * 2 * D.wl_cap;
+
+  // pass 2: the record that won its state writes the token
+  u64 best = ~0ull;
+  for (int i0 = 0; i0 < n; i0 += kInsertThreads) {
+    const int i = i0 + tid;
+    bool winner = false;
+    int4 r = make_int4(0, 0, 0, 0);
+    u64 packed = 0;
+    if (i < n) {
+      r = bucket[i];
+      if (__int_as_float(r.y) < cutoff) {
+        packed = ((u64)f2o(__int_as_float(r.y)) << 32) | (uint32_t)r.w;
+        uint32_t slot = lds_slot_of(hash32(r.x), D.log2part, D.log2lds);
+        for (int q = 0; q < SL; ++q) {
+          const int32_t k = keys[slot];
+          if (k == r.x) { winner = vals[slot] == packed; break; }
+          if (k == kEmptyKey) break;
+          slot = (slot + 1) & mask;
+        }
+      }
+    }
+    const u64 wm = __ballot(winner);
+    int wb = 0;
+    if (lane == 0 && wm) wb = atomicAdd(&s_wpos, __popcll(wm));
+    wb = __shfl(wb, 0, 64);
+    int idx = 0;
+    const uint32_t flags = (uint32_t)r.w & kFlagMask;
+    if (winner) {
+      idx = base + gpos + wb + lane_rank(wm);
+      tok[idx] = r;  // {state, cost, source token, arc | flags}
+      const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
+      best = b < best ? b : best;
+    }
+    // states with epsilon arcs in or out must be findable by the closure
+    const bool fl = winner && flags;
+    const u64 fm = __ballot(fl);
+    if (fm) {
+      int ob = 0;
+      if (lane == 0) ob = atomicAdd(&ctl->eps_occ, __popcll(fm));
+      ob = __shfl(ob, 0, 64);
+      int es = -1;
+      if (fl) {
+        bool created;
+        es = eps_find_or_insert(ekeys, D.ecap, D.log2ecap, r.x, &created);
+        if (es < 0) atomicOr(&ctl->error, kErrTableFull);
+        else {
+          evals[es] = packed;
+          etoki[es] = idx;
+          const int op = ob + lane_rank(fm);
+          if (op < D.ecap) eocc[op] = es;
+        }
+      }
+      const bool seed = fl && es >= 0 && (flags & kFlagOutEps);
+      const u64 sm = __ballot(seed);
+      if (sm) {
+        int sb = 0;
+        if (lane == 0) sb = atomicAdd(&ctl->wl_n, __popcll(sm));
+        sb = __shfl(sb, 0, 64);
+        if (seed) {
+          const int wp = sb + lane_rank(sm);
+          if (wp < D.wl_cap) wl[wp] = es; else atomicOr(&ctl->error, kErrWorklistFull);
+        }
+      }
+    }
+  }
+  best = wave_min_u64(best);
+  if (lane == 0) s_best[wave] = best;
+  __syncthreads();
+  if (tid == 0) {
+    u64 b = s_best[0];
+    for (int w = 1; w < kInsertThreads / 64; ++w) b = s_best[w] < b ? s_best[w] : b;
+    if (b != ~0ull) atomicMin(&ctl->best_next, b);
+  }
+}
+
+// =========================================================================================
+// closure_kernel and its pieces.  One 1024-thread workgroup per channel.
 // =========================================================================================
 constexpr int kBT = 1024;
 constexpr int kBW = kBT / 64;
 
 struct BoundaryShared {
-  int nfront;
+  int nnew;       // tokens of the frame being built (continues ChanCtl::new_count)
   int wl_n[2];
   int err;
+  int occ;        // occupied slots of the epsilon table (continues ChanCtl::eps_occ)
   float redf[kBW];
   u64 red64[kBW];
+  u64 best;
   uint32_t hist[256];
   uint32_t sel_prefix, sel_k;
   int active;
 };
 
-// ProcessNonemitting to its fixpoint (base-inl.h:383-430) on table `tabB`, then commit the
-// frontier: arena records with resolved backpointers.  On entry sh.nfront tokens are listed in
-// front_slot (with toki assigned) and sh.wl_n[0] of them (those with epsilon arcs) in
-// worklist[0]; sh.wl_n[1] == 0.  Returns the number of frontier tokens written.
-__device__ int closure_and_commit(const DecoderDev &D, int c, ChanCtl *ctl, BoundaryShared &sh,
-                                  int tabB, int tabA, int base, float cutoff, u64 *nZ_out) {
+// ProcessNonemitting to its fixpoint (base-inl.h:383-430) on the channel's epsilon table, then
+// rewrite the arena records of the tokens an epsilon arc created or improved.  On entry
+// sh.wl_n[0] seeds are in worklist[0], sh.wl_n[1] == 0, sh.nnew / sh.occ continue the counters.
+__device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, u64 *nZ_out) {
   const int tid = threadIdx.x;
-  const size_t offB = ((size_t)c * 2 + tabB) * (size_t)D.cap;
-  int32_t *keysB = D.keys + offB;
-  u64 *valsB = D.vals + offB;
-  int32_t *tokiB = D.toki + offB;
-  int32_t *occB = D.occ + offB;
-  int32_t *front_slot = D.front_slot + (size_t)c * D.max_tok;
+  int32_t *keys = D.eps_keys + (size_t)c * D.ecap;
+  u64 *vals = D.eps_vals + (size_t)c * D.ecap;
+  int32_t *toki = D.eps_toki + (size_t)c * D.ecap;
+  int32_t *occ = D.eps_occ_list + (size_t)c * D.ecap;
   int32_t *wl = D.worklist + (size_t)c * 2 * D.wl_cap;
+  int4 *tok = D.tok + (size_t)c * D.arena_cap;
   u64 nZ = 0;
 
   int cur = 0;
@@ -255,9 +439,9 @@ __device__ int closure_and_commit(const DecoderDev &D, int c, ChanCtl *ctl, Boun
     int32_t *wl_nxt = wl + (size_t)(cur ^ 1) * D.wl_cap;
     for (int i = tid; i < nw; i += kBT) {
       const int S = wl_cur[i];
-      const float cost = o2f((uint32_t)(ld_agent(&valsB[S]) >> 32));
+      const float cost = o2f((uint32_t)(ld_agent(&vals[S]) >> 32));
       if (!(cost < cutoff)) continue;  // base-inl.h:391
-      const int32_t state = ld_agent(&keysB[S]);
+      const int32_t state = ld_agent(&keys[S]);
       const uint2 si = D.g.state_info[state];
       const int neps = (int)(si.y & kEpsMask);
       for (int e = 0; e < neps; ++e) {
@@ -267,23 +451,22 @@ __device__ int closure_and_commit(const DecoderDev &D, int c, ChanCtl *ctl, Boun
         const float tot = cost + __int_as_float(arc.z);  // base-inl.h:414
         if (!(tot < cutoff)) continue;                    // base-inl.h:415
         const uint32_t otot = f2o(tot);
-        const u64 packed = ((u64)otot << 32) | (uint32_t)a;
+        const u64 packed = ((u64)otot << 32) | ((uint32_t)a | (uint32_t)arc.y);
         bool created;
-        const int ds = find_or_insert(keysB, D.cap, D.log2cap, arc.w, &created);
+        const int ds = eps_find_or_insert(keys, D.ecap, D.log2ecap, arc.w, &created);
         if (ds < 0) { atomicOr(&sh.err, kErrTableFull); continue; }
         if (created) {
-          const int pos = atomicAdd(&ctl->n_occ[tabB], 1);
-          occB[pos] = ds;
+          const int op = atomicAdd(&sh.occ, 1);
+          if (op < D.ecap) occ[op] = ds;
         }
-        const u64 old = atomicMin(&valsB[ds], packed);
+        const u64 old = atomicMin(&vals[ds], packed);
         if (packed < old) {
-          const bool was_in = o2f((uint32_t)(old >> 32)) < cutoff;
-          if (!was_in) {  // newly created token (or one that had lost against the cutoff)
-            const int fpos = atomicAdd(&sh.nfront, 1);
-            if (fpos < D.max_tok) { front_slot[fpos] = ds; tokiB[ds] = base + fpos; }
+          if (old == kEmptyVal) {  // a state no emitting arc reached: new token
+            const int np = atomicAdd(&sh.nnew, 1);
+            atomicExch(&toki[ds], base + np);
           }
           // base-inl.h:425: re-queue when the cost changed and the state has epsilon arcs
-          if (otot < (uint32_t)(old >> 32) && (D.g.state_info[arc.w].y & kEpsMask)) {
+          if (otot < (uint32_t)(old >> 32) && ((uint32_t)arc.y & kFlagOutEps)) {
             const int wp = atomicAdd(&sh.wl_n[cur ^ 1], 1);
             if (wp < D.wl_cap) wl_nxt[wp] = ds; else atomicOr(&sh.err, kErrWorklistFull);
           }
@@ -298,104 +481,61 @@ __device__ int closure_and_commit(const DecoderDev &D, int c, ChanCtl *ctl, Boun
     cur ^= 1;
   }
   __syncthreads();
-  int nf = sh.nfront;
-  if (nf > D.max_tok) { if (tid == 0) atomicOr(&sh.err, kErrFrontierFull); nf = D.max_tok; }
-  if ((int64_t)base + nf > D.arena_cap) { if (tid == 0) atomicOr(&sh.err, kErrArenaFull); nf = 0; }
-
-  // commit: one 16-byte record per token; backpointer = token of the winning arc's source state
-  int4 *tok = D.tok + (size_t)c * D.arena_cap;
-  const int32_t *keysA = tabA >= 0 ? D.keys + ((size_t)c * 2 + tabA) * (size_t)D.cap : nullptr;
-  const int32_t *tokiA = tabA >= 0 ? D.toki + ((size_t)c * 2 + tabA) * (size_t)D.cap : nullptr;
-  for (int pos = tid; pos < nf; pos += kBT) {
-    const int slot = front_slot[pos];
-    const u64 v = ld_agent(&valsB[slot]);
-    const int32_t state = ld_agent(&keysB[slot]);
-    const uint32_t arc = (uint32_t)v;
-    int prev = -1;
-    if (arc != kNoArc) {
+  int nocc = sh.occ;
+  if (nocc > D.ecap) nocc = D.ecap;
+  const bool fits = sh.nnew <= D.max_tok && (int64_t)base + sh.nnew <= D.arena_cap;
+  if (!fits && tid == 0) atomicOr(&sh.err, sh.nnew > D.max_tok ? kErrFrontierFull : kErrArenaFull);
+  // tokens whose winning arc is an epsilon arc: (re)write their arena record; clear the table
+  u64 best = ~0ull;
+  for (int i = tid; i < nocc; i += kBT) {
+    const int s = occ[i];
+    const u64 v = ld_agent(&vals[s]);
+    const uint32_t arc = (uint32_t)v & kArcMask;
+    if (arc != kNoArc && fits) {
       const int32_t srci = D.g.arc_src[arc];
-      const int32_t src = srci & 0x7FFFFFFF;
-      int ss;
-      if (srci < 0) {  // epsilon arc: source token lives on this frame
-        ss = find_slot<true>(keysB, D.cap, D.log2cap, src);
-        prev = ss >= 0 ? ld_agent(&tokiB[ss]) : -2;
-      } else {
-        ss = keysA ? find_slot<false>(keysA, D.cap, D.log2cap, src) : -1;
-        prev = ss >= 0 ? tokiA[ss] : -2;
+      if (srci < 0) {
+        const int32_t state = ld_agent(&keys[s]);
+        const int idx = ld_agent(&toki[s]);
+        const int ss = eps_find(keys, D.ecap, D.log2ecap, srci & 0x7FFFFFFF);
+        const int prev = ss >= 0 ? ld_agent(&toki[ss]) : -2;
+        tok[idx] = make_int4(state, __float_as_int(o2f((uint32_t)(v >> 32))), prev, (int)(uint32_t)v);
+        const u64 b = (v & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
+        best = b < best ? b : best;
       }
     }
-    tok[base + pos] = make_int4(state, __float_as_int(o2f((uint32_t)(v >> 32))), prev, (int)arc);
+  }
+  best = wave_min_u64(best);
+  if ((tid & 63) == 0) sh.red64[tid >> 6] = best;
+  __syncthreads();  // every lookup above is done before the table is cleared
+  for (int i = tid; i < nocc; i += kBT) {
+    const int s = occ[i];
+    keys[s] = kEmptyKey;
+    vals[s] = kEmptyVal;
+  }
+  if (tid == 0) {
+    u64 b = sh.red64[0];
+    for (int w = 1; w < kBW; ++w) b = sh.red64[w] < b ? sh.red64[w] : b;
+    sh.best = b;
   }
   *nZ_out = nZ;
-  return nf;
+  __syncthreads();
 }
 
 __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, BoundaryShared &sh) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int f = ctl->n_decoded;
-  const int tabA = ctl->cur_tab, tabB = tabA ^ 1;
   const float cutoff = o2f(ctl->bound);
   const int base = ctl->front_begin + ctl->front_count;
-  const int n_occB = ctl->n_occ[tabB];
-  const size_t offB = ((size_t)c * 2 + tabB) * (size_t)D.cap;
-  const int32_t *keysB = D.keys + offB;
-  const u64 *valsB = D.vals + offB;
-  int32_t *tokiB = D.toki + offB;
-  const int32_t *occB = D.occ + offB;
-  int32_t *front_slot = D.front_slot + (size_t)c * D.max_tok;
-  int32_t *wl0 = D.worklist + (size_t)c * 2 * D.wl_cap;
-
-  if (tid == 0) { sh.nfront = 0; sh.wl_n[0] = 0; sh.wl_n[1] = 0; sh.err = 0; }
-  __syncthreads();
-  // keep what the expansion created and that beats the FINAL next_cutoff (a subset of the
-  // reference's tokens: its order-dependent extras, base-inl.h:330, are never expanded)
-  for (int i0 = 0; i0 < n_occB; i0 += kBT) {
-    const int i = i0 + tid;
-    bool keep = false;
-    int slot = 0;
-    if (i < n_occB) {
-      slot = occB[i];
-      keep = o2f((uint32_t)(valsB[slot] >> 32)) < cutoff;
-    }
-    const u64 m = __ballot(keep);
-    int wbase = 0;
-    if (lane == 0 && m) wbase = atomicAdd(&sh.nfront, __popcll(m));
-    wbase = __shfl(wbase, 0, 64);
-    bool has_eps = false;
-    if (keep) {
-      const int pos = wbase + lane_rank(m);
-      if (pos < D.max_tok) { front_slot[pos] = slot; tokiB[slot] = base + pos; }
-      has_eps = (D.g.state_info[keysB[slot]].y & kEpsMask) != 0;  // base-inl.h:376-381
-    }
-    const u64 me = __ballot(has_eps);
-    int ebase = 0;
-    if (lane == 0 && me) ebase = atomicAdd(&sh.wl_n[0], __popcll(me));
-    ebase = __shfl(ebase, 0, 64);
-    if (has_eps) {
-      const int wp = ebase + lane_rank(me);
-      if (wp < D.wl_cap) wl0[wp] = slot; else atomicOr(&sh.err, kErrWorklistFull);
-    }
+  if (tid == 0) {
+    sh.nnew = ctl->new_count;
+    sh.occ = ctl->eps_occ;
+    sh.wl_n[0] = ctl->wl_n < D.wl_cap ? ctl->wl_n : D.wl_cap;
+    sh.wl_n[1] = 0;
+    sh.err = 0;
   }
   __syncthreads();
-  if (tid == 0 && sh.wl_n[0] > D.wl_cap) sh.wl_n[0] = D.wl_cap;
-
   u64 nZ = 0;
-  const int nf = closure_and_commit(D, c, ctl, sh, tabB, tabA, base, cutoff, &nZ);
-
-  // clear the table of the frame just expanded by walking its occupied-slot list
-  __syncthreads();
-  {
-    const size_t offA = ((size_t)c * 2 + tabA) * (size_t)D.cap;
-    int32_t *keysA = D.keys + offA;
-    u64 *valsA = D.vals + offA;
-    const int32_t *occA = D.occ + offA;
-    const int nA = ctl->n_occ[tabA];
-    for (int i = tid; i < nA; i += kBT) {
-      const int s = occA[i];
-      keysA[s] = kEmptyKey;
-      valsA[s] = kEmptyVal;
-    }
-  }
+  epsilon_closure(D, c, sh, base, cutoff, &nZ);
   nZ = wave_sum_u64(nZ);
   if (lane == 0) sh.red64[tid >> 6] = nZ;
   __syncthreads();
@@ -403,20 +543,23 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
     u64 z = 0;
     for (int w = 0; w < kBW; ++w) z += sh.red64[w];
     int err = sh.err;
+    int nf = sh.nnew;
+    if (nf > D.max_tok || (int64_t)base + nf > D.arena_cap) nf = 0;
+    if (ctl->error | err) nf = 0;  // a channel that hit a limit stops producing tokens
     if (f + 2 > D.max_frames + 1) err |= kErrFramesFull;
     else {
       D.frame_off[(size_t)c * (D.max_frames + 2) + f + 2] = base + nf;
       D.cutoff_hist[(size_t)c * (D.max_frames + 2) + f + 1] = cutoff;
     }
+    if (sh.best < ctl->best_next) ctl->best_next = sh.best;
     ctl->cnt_Z += z;
     ctl->cnt_tok += (u64)nf;
-    ctl->cnt_slots += (u64)ctl->n_occ[tabB];
     if (nf > ctl->peak_tokens) ctl->peak_tokens = nf;
-    ctl->n_occ[tabA] = 0;
     ctl->front_begin = base;
     ctl->front_count = nf;
-    ctl->cur_tab = tabB;
     ctl->n_decoded = f + 1;
+    ctl->eps_occ = 0;
+    ctl->wl_n = 0;
     ctl->active = 0;
     if (err) ctl->error |= err;
   }
@@ -467,22 +610,10 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
   __syncthreads();
   if (!sh.active) return;
   const int n = ctl->front_count;
-  const int4 *tok = D.tok + (size_t)c * D.arena_cap + ctl->front_begin;
-
-  // best token (GetCutoff's running minimum; ties -> lowest index)
-  u64 best = ~0ull;
-  for (int i = tid; i < n; i += kBT) {
-    const u64 v = ((u64)f2o(__int_as_float(tok[i].y)) << 32) | (uint32_t)i;
-    best = v < best ? v : best;
-  }
-  best = wave_min_u64(best);
-  if (lane == 0) sh.red64[wave] = best;
-  __syncthreads();
-  best = sh.red64[0];
-  for (int w = 1; w < kBW; ++w) best = sh.red64[w] < best ? sh.red64[w] : best;
-  __syncthreads();
+  const int4 *tokc = D.tok + (size_t)c * D.arena_cap;
+  const int4 *tok = tokc + ctl->front_begin;
+  const u64 best = ctl->best_next;  // min (cost, arena index) over the frontier
   const float best_w = n > 0 ? o2f((uint32_t)(best >> 32)) : kInf;
-  const int best_i = (int)(uint32_t)best;
 
   // GetCutoff, base-inl.h:138-234
   float cutoff, ab;
@@ -514,7 +645,7 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
   // seed next_cutoff from the best token's emitting arcs, base-inl.h:282-300
   float seed = kInf;
   if (n > 0) {
-    const int4 bt = tok[best_i];
+    const int4 bt = tokc[(uint32_t)best];
     const uint2 si = D.g.state_info[bt.x];
     const int deg = (int)(si.y >> kEpsBits), ab0 = (int)(si.x + (si.y & kEpsMask));
     const float *llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
@@ -535,15 +666,17 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
     ctl->cur_cutoff = cutoff;
     ctl->adaptive_beam = ab;
     ctl->bound = f2o(s < kInf ? next_cutoff : kInf);
+    ctl->new_count = 0;
+    ctl->best_next = ~0ull;
     ctl->active = 1;
   }
 }
 
-__global__ __launch_bounds__(kBT) void boundary_kernel(DecoderDev D, const int32_t *target, int do_finalize, int do_prep) {
+__global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_t *target, int do_prep) {
   __shared__ BoundaryShared sh;
   const int c = blockIdx.x;
   ChanCtl *ctl = D.ctl + c;
-  if (do_finalize && ctl->active) finalize_frame(D, c, ctl, sh);
+  if (ctl->active) finalize_frame(D, c, ctl, sh);
   __syncthreads();
   if (do_prep) prep_frame(D, c, ctl, target, sh);
 }
@@ -551,47 +684,50 @@ __global__ __launch_bounds__(kBT) void boundary_kernel(DecoderDev D, const int32
 // =========================================================================================
 // init: InitDecoding (base-inl.h:40-67)
 // =========================================================================================
-__global__ __launch_bounds__(256) void clear_tables_kernel(DecoderDev D, const int32_t *chans) {
-  const int c = chans ? chans[blockIdx.x] : blockIdx.x;
-  const size_t off = (size_t)c * 2 * (size_t)D.cap;
-  const size_t n = (size_t)2 * D.cap;
-  for (size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.y * blockDim.x) {
-    D.keys[off + i] = kEmptyKey;
-    D.vals[off + i] = kEmptyVal;
-  }
-}
-
 __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *chans) {
   __shared__ BoundaryShared sh;
   const int c = chans ? chans[blockIdx.x] : blockIdx.x;
   const int tid = threadIdx.x;
   ChanCtl *ctl = D.ctl + c;
+  int32_t *keys = D.eps_keys + (size_t)c * D.ecap;
+  u64 *vals = D.eps_vals + (size_t)c * D.ecap;
+  // the epsilon table is left empty by every closure; after an error it may not be
+  if (ctl->error || ctl->eps_occ || ctl->active) {
+    for (int i = tid; i < D.ecap; i += kBT) { keys[i] = kEmptyKey; vals[i] = kEmptyVal; }
+  }
+  for (int i = tid; i < D.n_part; i += kBT) D.bucket_cnt[(size_t)c * D.n_part + i] = 0;
+  __syncthreads();
   if (tid == 0) {
     ChanCtl z;
     memset(&z, 0, sizeof(z));
+    z.best_next = ~0ull;
     *ctl = z;
-    sh.err = 0; sh.wl_n[0] = 0; sh.wl_n[1] = 0; sh.nfront = 1;
-    const size_t off0 = (size_t)c * 2 * (size_t)D.cap;
-    bool created;
-    const int slot = find_or_insert(D.keys + off0, D.cap, D.log2cap, D.g.start, &created);
-    D.vals[off0 + slot] = ((u64)f2o(0.0f) << 32) | kNoArc;
-    D.occ[off0] = slot;
-    ctl->n_occ[0] = 1;
-    D.front_slot[(size_t)c * D.max_tok] = slot;
-    D.toki[off0 + slot] = 0;
-    if (D.g.state_info[D.g.start].y & kEpsMask) { D.worklist[(size_t)c * 2 * D.wl_cap] = slot; sh.wl_n[0] = 1; }
+    sh.err = 0; sh.wl_n[0] = 0; sh.wl_n[1] = 0; sh.nnew = 1; sh.occ = 0; sh.best = ~0ull;
+    const uint32_t fl = D.g.start_flags;
+    D.tok[(size_t)c * D.arena_cap] = make_int4(D.g.start, __float_as_int(0.0f), -1, (int)(kNoArc | fl));
+    if (fl) {
+      bool created;
+      const int es = eps_find_or_insert(keys, D.ecap, D.log2ecap, D.g.start, &created);
+      vals[es] = ((u64)f2o(0.0f) << 32) | (kNoArc | fl);
+      D.eps_toki[(size_t)c * D.ecap + es] = 0;
+      D.eps_occ_list[(size_t)c * D.ecap] = es;
+      sh.occ = 1;
+      if (fl & kFlagOutEps) { D.worklist[(size_t)c * 2 * D.wl_cap] = es; sh.wl_n[0] = 1; }
+    }
   }
   __syncthreads();
   u64 nZ = 0;
-  const int nf = closure_and_commit(D, c, ctl, sh, 0, -1, 0, D.beam, &nZ);  // ProcessNonemitting(_config._beam)
-  __syncthreads();
+  epsilon_closure(D, c, sh, 0, D.beam, &nZ);  // ProcessNonemitting(_config._beam)
   if (tid == 0) {
+    int nf = sh.nnew;
+    if (sh.err || nf > D.max_tok || nf > D.arena_cap) nf = 0;
     D.frame_off[(size_t)c * (D.max_frames + 2) + 0] = 0;
     D.frame_off[(size_t)c * (D.max_frames + 2) + 1] = nf;
     D.cutoff_hist[(size_t)c * (D.max_frames + 2) + 0] = D.beam;
+    const u64 root = ((u64)f2o(0.0f) << 32) | 0u;
+    ctl->best_next = sh.best < root ? sh.best : root;
     ctl->front_begin = 0;
     ctl->front_count = nf;
-    ctl->cur_tab = 0;
     ctl->cnt_tok = (u64)nf;
     ctl->peak_tokens = nf;
     if (sh.err) ctl->error |= sh.err;
@@ -649,7 +785,7 @@ __global__ __launch_bounds__(64) void best_path_kernel(DecoderDev D, const int32
     } else {
       const int4 P = tok[prev];
       const float cb = __int_as_float(P.y), ct = __int_as_float(T.y);
-      const int warc = T.w;
+      const int warc = (int)((uint32_t)T.w & kArcMask);
       const bool eps = D.g.arcs[warc].x < 0;
       const int fbp = eps ? fr : fr - 1;
       const uint2 si = D.g.state_info[P.x];
@@ -673,7 +809,7 @@ __global__ __launch_bounds__(64) void best_path_kernel(DecoderDev D, const int32
       }
       const int4 C = D.g.arcs[chosen];
       il[pos] = D.g.arc_ilabel[chosen];
-      ol[pos] = C.y;
+      ol[pos] = D.g.arc_olabel[chosen];
       og[pos] = __int_as_float(C.z);
       oa[pos] = eps ? 0.f : -llrow[C.x];
       if (!eps) --fr;
@@ -691,14 +827,17 @@ static __global__ void set_finalized_kernel(DecoderDev D, const int32_t *chans, 
 }
 
 void launch_init(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
-  hipLaunchKernelGGL(clear_tables_kernel, dim3(n, 16), dim3(256), 0, s, D, chans);
   hipLaunchKernelGGL(init_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
-}
-void launch_boundary(const DecoderDev &D, const int32_t *target, int do_finalize, int do_prep, hipStream_t s) {
-  hipLaunchKernelGGL(boundary_kernel, dim3(D.n_channels), dim3(kBT), 0, s, D, target, do_finalize, do_prep);
 }
 void launch_expand(const DecoderDev &D, int tiles_per_channel, hipStream_t s) {
   hipLaunchKernelGGL(expand_kernel, dim3(D.n_channels, tiles_per_channel), dim3(kExpandThreads), 0, s, D);
+}
+void launch_insert(const DecoderDev &D, hipStream_t s) {
+  const size_t lds = (size_t)D.lds_slots * 12;
+  hipLaunchKernelGGL(insert_kernel, dim3(D.n_channels, D.n_part), dim3(kInsertThreads), lds, s, D);
+}
+void launch_closure(const DecoderDev &D, const int32_t *target, int do_prep, hipStream_t s) {
+  hipLaunchKernelGGL(closure_kernel, dim3(D.n_channels), dim3(kBT), 0, s, D, target, do_prep);
 }
 void launch_set_finalized(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(set_finalized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, D, chans, n);
@@ -707,6 +846,9 @@ void launch_best_path(const DecoderDev &D, const int32_t *chans, int n, int use_
                       int32_t *olabel, float *graph, float *ac, int32_t *n_hops, hipStream_t s) {
   hipLaunchKernelGGL(best_path_kernel, dim3(n), dim3(64), 0, s, D, chans, use_final, cap, ilabel, olabel, graph, ac,
                      n_hops);
+}
+int insert_kernel_set_lds(int bytes) {
+  return (int)hipFuncSetAttribute((const void *)insert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 }  // namespace wfst

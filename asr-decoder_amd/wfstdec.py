@@ -224,16 +224,17 @@ class BatchDecoder:
     def stats(self, channel):
         s = (C.c_int64 * 8)()
         _check(lib().wfst_decoder_get_stats(self.h, int(channel), s))
-        return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], slots=s[6])
+        return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], records=s[6])
 
     def set_profiling(self, on):
         _check(lib().wfst_decoder_set_profiling(self.h, int(bool(on))))
 
     def profile(self):
-        ms = (C.c_double * 2)()
-        n = (C.c_int64 * 2)()
+        ms = (C.c_double * 3)()
+        n = (C.c_int64 * 3)()
         _check(lib().wfst_decoder_get_profile(self.h, ms, n))
-        return dict(expand_ms=ms[0], expand_launches=n[0], boundary_ms=ms[1], boundary_launches=n[1])
+        return dict(expand_ms=ms[0], expand_launches=n[0], insert_ms=ms[1], insert_launches=n[1],
+                    closure_ms=ms[2], closure_launches=n[2])
 
     def frontier(self, channel, cap=1 << 20):
         st = np.zeros(cap, np.int32)

@@ -49,9 +49,12 @@ def parse():
     ap.add_argument("--states", type=int, default=2850000)
     ap.add_argument("--pdfs", type=int, default=3000)
     ap.add_argument("--beam", type=float, default=13.0)
-    ap.add_argument("--max-active", type=int, default=7000)
-    ap.add_argument("--min-active", type=int, default=200)
-    ap.add_argument("--mu", type=float, default=-2.0)
+    ap.add_argument("--max-active", type=int, default=1000000, help="1000000 never binds (beam-only pruning: the bit-exact parity regime); 7000 = the reference service's operating point")
+    ap.add_argument("--min-active", type=int, default=0)
+    ap.add_argument("--workload", choices=["multi", "single"], default="multi",
+                    help="multi: many live hypotheses (synth.make_loglikes_multi); single: one planted path (SURVEY 8(d))")
+    ap.add_argument("--paths", type=int, default=352)
+    ap.add_argument("--mu", type=float, default=None, help="noise mean (default -4.0 multi, -2.0 single)")
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances timed on the host cores (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(sample, host cores)")
@@ -59,10 +62,14 @@ def parse():
     return ap.parse_args()
 
 
-def make_utts(synth, g, m, first, count, T, P, mu, sigma):
+def make_utts(synth, g, m, first, count, T, P, a):
     out = np.empty((count, T, P), np.float32)
     for i in range(count):
-        out[i] = synth.make_loglikes(g, T, P, m, seed=first + i, mu=mu, sigma=sigma)[0]
+        if a.workload == "multi":
+            out[i] = synth.make_loglikes_multi(g, T, P, m, seed=first + i, n_paths=a.paths, mu=a.mu, sigma=a.sigma,
+                                               jitter=0.5, ac_lo=0.5)[0]
+        else:
+            out[i] = synth.make_loglikes(g, T, P, m, seed=first + i, mu=a.mu, sigma=a.sigma)[0]
     return out
 
 
@@ -163,6 +170,8 @@ def oracle_counts(graph_path, cd, mats, m):
 
 def main():
     a = parse()
+    if a.mu is None:
+        a.mu = -4.0 if a.workload == "multi" else -2.0
     import torch
     import torch.distributed as dist
 
@@ -199,15 +208,15 @@ def main():
         g.write(gpath)
     log("[rank %d] graph: %d states, %d arcs (%.1fs)" % (rank, g.n_states, g.n_arcs, time.time() - t0))
     t0 = time.time()
-    mats = make_utts(synth, g, m, rank * B, B, T, P, a.mu, a.sigma)
+    mats = make_utts(synth, g, m, rank * B, B, T, P, a)
     ll_dev = torch.from_numpy(mats).to(dev)  # [B][T][P] resident in HBM
     log("[rank %d] log-likelihoods: %d x [%d x %d] (%.1fs)" % (rank, B, T, P, time.time() - t0))
 
     graph = wfstdec.Graph.from_arrays(g.start, g.final_state, g.state_info, g.arcs, device=local_rank)
     graph.set_tid2pdf(m)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    dec = wfstdec.BatchDecoder(graph, wfstdec.Config(**cd), B, max_frames=T + 2, max_tokens_per_frame=32768,
-                               arena_tokens=int(T * 14000), stream=stream)
+    dec = wfstdec.BatchDecoder(graph, wfstdec.Config(**cd), B, max_frames=T + 2, max_tokens_per_frame=65536,
+                               arena_tokens=int(T * 24000), stream=stream)
     ptrs = [ll_dev[i].data_ptr() for i in range(B)]
     ready = [T] * B
     Lmax = 64
@@ -262,7 +271,8 @@ def main():
         "metric": "frames/sec decoded (RTFx = value/100) at fixed beam, best-path parity with the reference CPU decoder",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded hclg-like graph + planted-path log-likelihoods, SURVEY.md 8(d))",
+        "dtype": "f32", "data": "synthetic (seeded hclg-like graph + %s log-likelihoods, SURVEY.md 8(d))" % (
+            "%d-live-hypotheses" % a.paths if a.workload == "multi" else "single-planted-path"),
         "config": {
             "workload": "BASELINE configs[1]: batch=%d utterances/GPU x %d frames, %d-arc HCLG, beam=%g, "
                         "max_active=%d, min_active=%d, %d pdfs" % (B, T, g.n_arcs, a.beam, a.max_active, a.min_active, P),
@@ -303,17 +313,17 @@ def main():
             # by the GPU's own (identically defined) N+E counters
             if gs["N"] + gs["E"] > 0:
                 scale = (oc["N"] + oc["E"]) / float(gs["N"] + gs["E"])
-        # expand kernel: per emitting arc 16 B arc + 4 B log-like + 8 B hash min-update = 28 B,
-        # per expanded token 8 B {state,cost} + 8 B arc-range = 16 B (the token's 8 B arena write and
-        # the 24 B per epsilon arc belong to the boundary kernel).  DESIGN.md "Roofline accounting".
-        exp_bytes = scale * (28.0 * E + 16.0 * N)
-        bnd_bytes = scale * (8.0 * N) + 24.0 * Z
-        dom = "expand" if prof["expand_ms"] >= prof["boundary_ms"] else "boundary"
-        k_ms, k_n, k_bytes = ((prof["expand_ms"], prof["expand_launches"], exp_bytes) if dom == "expand"
-                              else (prof["boundary_ms"], prof["boundary_launches"], bnd_bytes))
+        # Algorithmic bytes: 28 B per traversed emitting arc (16 B arc + 4 B log-like
+        # + 8 B hash min-update), 24 B per expanded token (8 B {state,cost} + 8 B arc range + 8 B
+        # backpointer/arena write), 24 B per traversed epsilon arc.  Per kernel (DESIGN.md "Roofline
+        # accounting"): expand = 20 E + 16 N, insert = 8 E + 8 N, closure = 24 Z.
+        kb = {"expand": scale * (20.0 * E + 16.0 * N), "insert": scale * (8.0 * E + 8.0 * N), "closure": 24.0 * Z}
+        dom = max(("expand", "insert", "closure"), key=lambda k: prof[k + "_ms"])
+        k_ms, k_n, k_bytes = prof[dom + "_ms"], prof[dom + "_launches"], kb[dom]
         per_launch_bytes = k_bytes / max(k_n, 1)
         avg_ms = k_ms / max(k_n, 1)
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        all_ms = prof["expand_ms"] + prof["insert_ms"] + prof["closure_ms"]
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):
@@ -324,7 +334,8 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
-                           "expand_ms_per_step": prof["expand_ms"], "boundary_ms_per_step": prof["boundary_ms"],
+                           "kernel_ms_per_step": {k: prof[k + "_ms"] for k in ("expand", "insert", "closure")},
+                           "all_kernels_achieved_GBs": (sum(kb.values()) / (all_ms * 1e-3) / 1e9) if all_ms > 0 else 0.0,
                            "measured": "hipEvent pairs around every launch on the decoder's stream, one extra step after the timed region"}
         print(json.dumps(out), flush=True)
     dec.free()

@@ -155,17 +155,18 @@ int wfst_lattice_to_vector(const int32_t *ilabel, const int32_t *olabel, const f
                            int32_t *n_tids, float *tot_score, float *lm_score);
 
 /* Per-channel work counters since the last init: {frames, N tokens expanded, E emitting arcs
- * traversed, Z epsilon arcs traversed, tokens kept, peak tokens per frame, hash slots touched,
- * reserved}.  N and E follow the definitions of the reference loop (base-inl.h:311-347). */
+ * traversed, Z epsilon arcs traversed, tokens kept, peak tokens per frame, candidate records
+ * bucketed, reserved}.  N and E follow the definitions of the reference loop (base-inl.h:311-347). */
 int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]);
 
 /* Kernel timing for the roofline report: while enabled, every expand / boundary launch of
  * wfst_decoder_advance is bracketed by HIP events recorded on the decoder's own stream.
  * wfst_decoder_get_profile waits for the stream and returns, since the last enable:
- * ms[0], launches[0] = expand kernel (ProcessEmitting inner loop); ms[1], launches[1] = boundary
- * kernel (cutoff + epsilon closure + token commit).  Leave it off in production runs. */
+ * [0] expand kernel (ProcessEmitting inner loop -> candidate buckets), [1] insert kernel
+ * (FindOrAddToken in LDS hash tables -> tokens), [2] closure kernel (ProcessNonemitting fixpoint +
+ * GetCutoff + next_cutoff seed).  Leave it off in production runs. */
 int wfst_decoder_set_profiling(wfst_decoder *d, int32_t enable);
-int wfst_decoder_get_profile(wfst_decoder *d, double ms[2], int64_t launches[2]);
+int wfst_decoder_get_profile(wfst_decoder *d, double ms[3], int64_t launches[3]);
 
 /* Frontier of a channel after the last decoded frame (states and costs, unordered); for tests.
  * Returns the number of tokens (may exceed cap; only cap are written). */
