@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -91,8 +92,8 @@ struct wfst_decoder {
   DecoderDev D;
   DevBuf<ChanCtl> ctl;
   DevBuf<int4> tok;
-  DevBuf<int32_t> frame_off, bucket_cnt, eps_keys, eps_toki, eps_occ_list, worklist, target, chan_list;
-  DevBuf<int4> bucket;
+  DevBuf<int32_t> frame_off, bucket_cnt, eps_keys, eps_toki, eps_occ_list, target, chan_list;
+  DevBuf<int4> bucket, worklist;
   DevBuf<float> cutoff_hist;
   DevBuf<unsigned long long> eps_vals;
   DevBuf<const float *> ll_base;
@@ -104,7 +105,7 @@ struct wfst_decoder {
   const float **p_ll = nullptr;
   ChanCtl *p_ctl = nullptr;
   // best-path output buffers (device), grown on demand
-  DevBuf<int32_t> bp_il, bp_ol, bp_n;
+  DevBuf<int32_t> bp_il, bp_ol, bp_n, bp_chain;
   DevBuf<float> bp_g, bp_ac;
   // host-fed log-likelihood history (advance_host)
   std::vector<float *> hist_dev;
@@ -112,6 +113,9 @@ struct wfst_decoder {
   std::vector<int32_t> hist_rows;
   int32_t hist_stride = 0;
   int tiles_per_channel = 16;
+  // the frame loop of one advance call, captured once per (frames, stride) and replayed
+  bool use_graph = true;
+  std::map<std::pair<int, int>, hipGraphExec_t> graphs;
   // optional kernel timing (wfst_decoder_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -132,13 +136,14 @@ struct wfst_decoder {
     for (float *p : hist_dev)
       if (p) (void)hipFree(p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
     if (p_target) (void)hipHostFree(p_target);
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); eps_keys.release();
     eps_toki.release(); eps_occ_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_g.release();
+    bucket.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
     bp_ac.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -354,13 +359,13 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   if (L.max_tokens_per_frame <= 0) L.max_tokens_per_frame = 32768;
   if (L.arena_tokens <= 0) L.arena_tokens = 4194304;
   if (L.arena_tokens > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "arena_tokens must fit int32");
-  // hash partitions: each insert workgroup owns an LDS table of lds_slots entries at <= 50 % load
+  // hash partitions per channel: each insert workgroup owns an LDS table of lds_slots entries;
+  // a bucket too full for it is handled in sub-passes, so these are speed knobs, not limits
   const int64_t M = L.max_tokens_per_frame;
-  int lds_slots = 4096, log2lds = 12;
-  if (2 * M > 64ll * lds_slots) { lds_slots = 8192; log2lds = 13; }
-  if (2 * M > 64ll * lds_slots) return fail(WFST_E_ARG, "max_tokens_per_frame too large (limit 262144)");
-  int log2part = 0;
-  while ((int64_t)lds_slots << log2part < 2 * M) ++log2part;
+  int lds_slots = 4096, log2lds = 12, log2part = 4;
+  if (const char *e = getenv("WFST_LOG2_PARTS")) log2part = std::max(0, std::min(6, atoi(e)));
+  if (const char *e = getenv("WFST_LDS_SLOTS")) { if (atoi(e) == 8192) { lds_slots = 8192; log2lds = 13; } }
+  while (log2part > 0 && (int64_t)lds_slots << (log2part - 1) >= 4 * M) --log2part;  // tiny limits: fewer parts
   const int n_part = 1 << log2part;
   const int64_t bucket_cap = std::max<int64_t>(2048, 8 * M / n_part);
   int log2ecap = 6;
@@ -454,6 +459,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   d->hist_dev.assign(B, nullptr);
   d->hist_rows_cap.assign(B, 0);
   d->hist_rows.assign(B, 0);
+  if (const char *ng = getenv("WFST_NO_GRAPH")) d->use_graph = atoi(ng) == 0;
   const char *tp = getenv("WFST_TILES_PER_CHANNEL");
   if (tp && atoi(tp) > 0) d->tiles_per_channel = atoi(tp);
   *out = d;
@@ -557,11 +563,36 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     launch();
     if (a >= 0 && b >= 0) { (void)hipEventRecord(d->ev_pool[b], d->stream); d->ev_pairs[cls].push_back({a, b}); }
   };
-  timed(2, [&] { launch_closure(d->D, d->target.p, 1, d->stream); });  // GetCutoff + seed only
-  for (int s = 0; s < steps; ++s) {
-    timed(0, [&] { launch_expand(d->D, d->tiles_per_channel, d->stream); });
-    timed(1, [&] { launch_insert(d->D, d->stream); });
-    timed(2, [&] { launch_closure(d->D, d->target.p, s + 1 < steps, d->stream); });
+  auto enqueue = [&] {
+    timed(2, [&] { launch_closure(d->D, d->target.p, 1, d->stream); });  // GetCutoff + seed only
+    for (int s = 0; s < steps; ++s) {
+      timed(0, [&] { launch_expand(d->D, d->tiles_per_channel, d->stream); });
+      timed(1, [&] { launch_insert(d->D, d->stream); });
+      timed(2, [&] { launch_closure(d->D, d->target.p, s + 1 < steps, d->stream); });
+    }
+  };
+  if (d->use_graph && !d->profiling && steps >= 4) {
+    // launch-bound inner loop -> hipGraph: per-frame state lives in ChanCtl on the device, so the
+    // captured kernels and their arguments are identical for every call with the same frame count
+    const auto key = std::make_pair(steps, (int)stride);
+    auto it = d->graphs.find(key);
+    if (it == d->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      HIP_TRY(hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal));
+      enqueue();
+      HIP_TRY(hipStreamEndCapture(d->stream, &graph));
+      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      HIP_TRY(hipGraphDestroy(graph));
+      if (d->graphs.size() >= 64) {  // bounded cache
+        for (auto &kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
+        d->graphs.clear();
+      }
+      it = d->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(hipGraphLaunch(it->second, d->stream));
+  } else {
+    enqueue();
   }
   HIP_TRY(hipGetLastError());
   for (int c = 0; c < d->n_channels; ++c) d->h_decoded[c] = std::max(d->h_decoded[c], d->h_target[c]);
@@ -696,12 +727,13 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
     HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(d->bp_il.alloc(need));
     HIP_TRY(d->bp_ol.alloc(need));
+    HIP_TRY(d->bp_chain.alloc(need));
     HIP_TRY(d->bp_g.alloc(need));
     HIP_TRY(d->bp_ac.alloc(need));
   }
   if (d->bp_n.n < (size_t)cnt) HIP_TRY(d->bp_n.alloc((size_t)d->n_channels));
   launch_best_path(d->D, dev, cnt, use_final_probs ? 1 : 0, cap, d->bp_il.p, d->bp_ol.p, d->bp_g.p, d->bp_ac.p,
-                   d->bp_n.p, d->stream);
+                   d->bp_n.p, d->bp_chain.p, d->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(n_hops, d->bp_n.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipMemcpyAsync(ilabel, d->bp_il.p, need * 4, hipMemcpyDeviceToHost, d->stream));

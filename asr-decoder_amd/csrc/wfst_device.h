@@ -57,8 +57,8 @@ struct __attribute__((aligned(128))) ChanCtl {
   float adaptive_beam;
   int32_t new_count;     // tokens of the frame being built (atomicAdd by the insert workgroups)
   unsigned long long best_next;  // min (orderable cost << 32 | arena index) over the new frame
-  int32_t eps_occ;       // occupied slots of the epsilon table
-  int32_t wl_n;          // epsilon-closure seeds queued by the insert workgroups
+  int32_t eps_occ;       // occupied slots of the epsilon table   } one 8-byte word: the insert
+  int32_t wl_n;          // epsilon-closure seeds queued          } workgroups bump both at once
   int32_t error;         // sticky kErr* bits
   int32_t finalized;
   int32_t peak_tokens;
@@ -92,7 +92,7 @@ struct DecoderDev {
   unsigned long long *eps_vals;
   int32_t *eps_toki;
   int32_t *eps_occ_list;
-  int32_t *worklist;
+  int4 *worklist;               // {eps-table slot, state, cost bits, 0}
   const float *const *ll_base;  // [n_channels] device pointers to row 0 of each utterance matrix
   int32_t n_channels;
   int32_t stride;               // floats per log-likelihood row
@@ -111,14 +111,13 @@ struct DecoderDev {
 
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
-void launch_prep(const DecoderDev &D, const int32_t *target_dev, hipStream_t s);
 void launch_expand(const DecoderDev &D, int tiles_per_channel, hipStream_t s);
 void launch_insert(const DecoderDev &D, hipStream_t s);
 void launch_closure(const DecoderDev &D, const int32_t *target_dev, int do_prep, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_best_path(const DecoderDev &D, const int32_t *chan_list_dev, int n, int use_final,
                       int cap, int32_t *ilabel, int32_t *olabel, float *graph, float *ac,
-                      int32_t *n_hops, hipStream_t s);
+                      int32_t *n_hops, int32_t *chain_scratch, hipStream_t s);
 
 }  // namespace wfst
 #endif

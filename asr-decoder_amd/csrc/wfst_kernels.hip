@@ -257,8 +257,11 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D) {
 
 // =========================================================================================
 // insert_kernel: grid (n_channels, n_part), 256 threads, dynamic LDS = lds_slots * 12 bytes.
+// A bucket whose records could overfill the LDS table is processed in 2^k sub-passes, each
+// taking the states of one sub-hash class (records >= distinct states, so the test is safe).
 // =========================================================================================
 constexpr int kInsertThreads = 256;
+constexpr int kInsertUnroll = 4;
 
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -280,114 +283,136 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D) {
   const int4 *bucket = D.bucket + ((size_t)c * P + p) * D.bucket_cap;
   const float cutoff = o2f(ctl->bound);  // FINAL next_cutoff of this frame
   const uint32_t mask = (uint32_t)SL - 1;
-
-  for (int i = tid; i < SL; i += kInsertThreads) { keys[i] = kEmptyKey; vals[i] = kEmptyVal; }
-  if (tid == 0) { s_nstates = 0; s_wpos = 0; s_ok = 1; }
-  __syncthreads();
-
-  // pass 1: insert-or-min.  Candidates that lost against the final cutoff are dropped here: the
-  // reference keeps those order-dependent extras (base-inl.h:330) but never expands them.
-  for (int i = tid; i < n; i += kInsertThreads) {
-    const int4 r = bucket[i];
-    if (!(__int_as_float(r.y) < cutoff)) continue;
-    uint32_t slot = lds_slot_of(hash32(r.x), D.log2part, D.log2lds);
-    bool found = false;
-    for (int q = 0; q < SL; ++q) {
-      int32_t k = keys[slot];
-      if (k == kEmptyKey) {
-        k = atomicCAS(&keys[slot], kEmptyKey, r.x);
-        if (k == kEmptyKey) { atomicAdd(&s_nstates, 1); found = true; break; }
-      }
-      if (k == r.x) { found = true; break; }
-      slot = (slot + 1) & mask;
-    }
-    if (found) atomicMin(&vals[slot], ((u64)f2o(__int_as_float(r.y)) << 32) | (uint32_t)r.w);
-    else atomicOr(&ctl->error, kErrTableFull);
-  }
-  __syncthreads();
-  const int ns = s_nstates;
   const int base = ctl->front_begin + ctl->front_count;
-  if (tid == 0) {
-    int g = atomicAdd(&ctl->new_count, ns);
-    s_gpos = g;
-    if (g + ns > D.max_tok) { atomicOr(&ctl->error, kErrFrontierFull); s_ok = 0; }
-    if ((int64_t)base + g + ns > D.arena_cap) { atomicOr(&ctl->error, kErrArenaFull); s_ok = 0; }
-    *cntp = 0;  // bucket consumed
-  }
-  __syncthreads();
-  if (!s_ok) return;
-  const int gpos = s_gpos;
   int4 *tok = D.tok + (size_t)c * D.arena_cap;
   int32_t *ekeys = D.eps_keys + (size_t)c * D.ecap;
   u64 *evals = D.eps_vals + (size_t)c * D.ecap;
   int32_t *etoki = D.eps_toki + (size_t)c * D.ecap;
   int32_t *eocc = D.eps_occ_list + (size_t)c * D.ecap;
-  int32_t *wl = D.worklist + (size_t)c * 2 * D.wl_cap;
+  int4 *wl = D.worklist + (size_t)c * 2 * D.wl_cap;
+  u64 *occ_wl = reinterpret_cast<u64 *>(&ctl->eps_occ);  // {eps_occ, wl_n} bumped by one atomic
 
-  // pass 2: the record that won its state writes the token
+  int log2sub = 0;
+  while (n > ((SL * 3) >> 2) << log2sub) ++log2sub;
+  const int sub_shift = 32 - D.log2part - D.log2lds - log2sub;
+  if (sub_shift < 0) { if (tid == 0) { atomicOr(&ctl->error, kErrTableFull); *cntp = 0; } return; }
+
   u64 best = ~0ull;
-  for (int i0 = 0; i0 < n; i0 += kInsertThreads) {
-    const int i = i0 + tid;
-    bool winner = false;
-    int4 r = make_int4(0, 0, 0, 0);
-    u64 packed = 0;
-    if (i < n) {
-      r = bucket[i];
-      if (__int_as_float(r.y) < cutoff) {
-        packed = ((u64)f2o(__int_as_float(r.y)) << 32) | (uint32_t)r.w;
-        uint32_t slot = lds_slot_of(hash32(r.x), D.log2part, D.log2lds);
+  for (int sub = 0; sub < (1 << log2sub); ++sub) {
+    __syncthreads();
+    for (int i = tid; i < SL; i += kInsertThreads) { keys[i] = kEmptyKey; vals[i] = kEmptyVal; }
+    if (tid == 0) { s_nstates = 0; s_wpos = 0; s_ok = 1; }
+    __syncthreads();
+
+    // pass 1: insert-or-min.  Candidates that lost against the final cutoff are dropped here: the
+    // reference keeps those order-dependent extras (base-inl.h:330) but never expands them.
+    for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
+      int4 r[kInsertUnroll];
+#pragma unroll
+      for (int k = 0; k < kInsertUnroll; ++k) {
+        const int i = i0 + k * kInsertThreads + tid;
+        r[k] = i < n ? bucket[i] : make_int4(0, 0x7F800000, 0, 0);  // cost +inf: never below a cutoff
+      }
+#pragma unroll
+      for (int k = 0; k < kInsertUnroll; ++k) {
+        if (!(__int_as_float(r[k].y) < cutoff)) continue;
+        const uint32_t h = hash32(r[k].x);
+        if (log2sub && (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) != sub) continue;
+        uint32_t slot = lds_slot_of(h, D.log2part, D.log2lds);
+        bool found = false;
         for (int q = 0; q < SL; ++q) {
-          const int32_t k = keys[slot];
-          if (k == r.x) { winner = vals[slot] == packed; break; }
-          if (k == kEmptyKey) break;
+          int32_t kk = keys[slot];
+          if (kk == kEmptyKey) {
+            kk = atomicCAS(&keys[slot], kEmptyKey, r[k].x);
+            if (kk == kEmptyKey) { atomicAdd(&s_nstates, 1); found = true; break; }
+          }
+          if (kk == r[k].x) { found = true; break; }
           slot = (slot + 1) & mask;
         }
+        if (found) atomicMin(&vals[slot], ((u64)f2o(__int_as_float(r[k].y)) << 32) | (uint32_t)r[k].w);
+        else atomicOr(&ctl->error, kErrTableFull);
       }
     }
-    const u64 wm = __ballot(winner);
-    int wb = 0;
-    if (lane == 0 && wm) wb = atomicAdd(&s_wpos, __popcll(wm));
-    wb = __shfl(wb, 0, 64);
-    int idx = 0;
-    const uint32_t flags = (uint32_t)r.w & kFlagMask;
-    if (winner) {
-      idx = base + gpos + wb + lane_rank(wm);
-      tok[idx] = r;  // {state, cost, source token, arc | flags}
-      const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
-      best = b < best ? b : best;
+    __syncthreads();
+    const int ns = s_nstates;
+    if (tid == 0) {
+      int g = atomicAdd(&ctl->new_count, ns);
+      s_gpos = g;
+      if (g + ns > D.max_tok) { atomicOr(&ctl->error, kErrFrontierFull); s_ok = 0; }
+      if ((int64_t)base + g + ns > D.arena_cap) { atomicOr(&ctl->error, kErrArenaFull); s_ok = 0; }
     }
-    // states with epsilon arcs in or out must be findable by the closure
-    const bool fl = winner && flags;
-    const u64 fm = __ballot(fl);
-    if (fm) {
-      int ob = 0;
-      if (lane == 0) ob = atomicAdd(&ctl->eps_occ, __popcll(fm));
-      ob = __shfl(ob, 0, 64);
-      int es = -1;
-      if (fl) {
-        bool created;
-        es = eps_find_or_insert(ekeys, D.ecap, D.log2ecap, r.x, &created);
-        if (es < 0) atomicOr(&ctl->error, kErrTableFull);
-        else {
-          evals[es] = packed;
-          etoki[es] = idx;
-          const int op = ob + lane_rank(fm);
-          if (op < D.ecap) eocc[op] = es;
+    __syncthreads();
+    if (!s_ok) break;
+    const int gpos = s_gpos;
+
+    // pass 2: the record that won its state writes the token
+    for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
+      int4 r[kInsertUnroll];
+#pragma unroll
+      for (int k = 0; k < kInsertUnroll; ++k) {
+        const int i = i0 + k * kInsertThreads + tid;
+        r[k] = i < n ? bucket[i] : make_int4(0, 0x7F800000, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < kInsertUnroll; ++k) {
+        bool winner = false;
+        u64 packed = 0;
+        if (__int_as_float(r[k].y) < cutoff) {
+          const uint32_t h = hash32(r[k].x);
+          if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
+            packed = ((u64)f2o(__int_as_float(r[k].y)) << 32) | (uint32_t)r[k].w;
+            uint32_t slot = lds_slot_of(h, D.log2part, D.log2lds);
+            for (int q = 0; q < SL; ++q) {
+              const int32_t kk = keys[slot];
+              if (kk == r[k].x) { winner = vals[slot] == packed; break; }
+              if (kk == kEmptyKey) break;
+              slot = (slot + 1) & mask;
+            }
+          }
         }
-      }
-      const bool seed = fl && es >= 0 && (flags & kFlagOutEps);
-      const u64 sm = __ballot(seed);
-      if (sm) {
-        int sb = 0;
-        if (lane == 0) sb = atomicAdd(&ctl->wl_n, __popcll(sm));
-        sb = __shfl(sb, 0, 64);
-        if (seed) {
-          const int wp = sb + lane_rank(sm);
-          if (wp < D.wl_cap) wl[wp] = es; else atomicOr(&ctl->error, kErrWorklistFull);
+        const u64 wm = __ballot(winner);
+        if (!wm) continue;
+        int wb = 0;
+        if (lane == 0) wb = atomicAdd(&s_wpos, __popcll(wm));
+        wb = __shfl(wb, 0, 64);
+        int idx = 0;
+        const uint32_t flags = (uint32_t)r[k].w & kFlagMask;
+        if (winner) {
+          idx = base + gpos + wb + lane_rank(wm);
+          tok[idx] = r[k];  // {state, cost, source token, arc | flags}
+          const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
+          best = b < best ? b : best;
+        }
+        // states with epsilon arcs in or out must be findable by the closure
+        const bool fl = winner && flags;
+        const u64 fm = __ballot(fl);
+        if (!fm) continue;
+        const bool seed = fl && (flags & kFlagOutEps);
+        const u64 sm = __ballot(seed);
+        u64 ob = 0;
+        if (lane == 0) ob = atomicAdd(occ_wl, (u64)__popcll(fm) | ((u64)__popcll(sm) << 32));
+        ob = __shfl(ob, 0, 64);
+        if (fl) {
+          bool created;
+          const int es = eps_find_or_insert(ekeys, D.ecap, D.log2ecap, r[k].x, &created);
+          const int op = (int)(uint32_t)ob + lane_rank(fm);
+          if (es < 0 || op >= D.ecap) atomicOr(&ctl->error, kErrTableFull);
+          else {
+            evals[es] = packed;
+            etoki[es] = idx;
+            eocc[op] = es;
+            if (seed) {
+              const int wp = (int)(ob >> 32) + lane_rank(sm);
+              if (wp < D.wl_cap) wl[wp] = make_int4(es, r[k].x, r[k].y, 0);
+              else atomicOr(&ctl->error, kErrWorklistFull);
+            }
+          }
         }
       }
     }
   }
+  __syncthreads();
+  if (tid == 0) *cntp = 0;  // bucket consumed
   best = wave_min_u64(best);
   if (lane == 0) s_best[wave] = best;
   __syncthreads();
@@ -426,7 +451,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
   u64 *vals = D.eps_vals + (size_t)c * D.ecap;
   int32_t *toki = D.eps_toki + (size_t)c * D.ecap;
   int32_t *occ = D.eps_occ_list + (size_t)c * D.ecap;
-  int32_t *wl = D.worklist + (size_t)c * 2 * D.wl_cap;
+  int4 *wl = D.worklist + (size_t)c * 2 * D.wl_cap;
   int4 *tok = D.tok + (size_t)c * D.arena_cap;
   u64 nZ = 0;
 
@@ -435,13 +460,15 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
     __syncthreads();
     const int nw = sh.wl_n[cur];
     if (nw == 0) break;
-    int32_t *wl_cur = wl + (size_t)cur * D.wl_cap;
-    int32_t *wl_nxt = wl + (size_t)(cur ^ 1) * D.wl_cap;
+    const int4 *wl_cur = wl + (size_t)cur * D.wl_cap;
+    int4 *wl_nxt = wl + (size_t)(cur ^ 1) * D.wl_cap;
     for (int i = tid; i < nw; i += kBT) {
-      const int S = wl_cur[i];
-      const float cost = o2f((uint32_t)(ld_agent(&vals[S]) >> 32));
+      // entry = {table slot, state, cost when queued}; a later improvement of the same token
+      // queues another entry, so a stale cost only repeats work the atomicMin below rejects
+      const int4 ent = wl_cur[i];
+      const float cost = __int_as_float(ent.z);
       if (!(cost < cutoff)) continue;  // base-inl.h:391
-      const int32_t state = ld_agent(&keys[S]);
+      const int32_t state = ent.y;
       const uint2 si = D.g.state_info[state];
       const int neps = (int)(si.y & kEpsMask);
       for (int e = 0; e < neps; ++e) {
@@ -468,7 +495,8 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
           // base-inl.h:425: re-queue when the cost changed and the state has epsilon arcs
           if (otot < (uint32_t)(old >> 32) && ((uint32_t)arc.y & kFlagOutEps)) {
             const int wp = atomicAdd(&sh.wl_n[cur ^ 1], 1);
-            if (wp < D.wl_cap) wl_nxt[wp] = ds; else atomicOr(&sh.err, kErrWorklistFull);
+            if (wp < D.wl_cap) wl_nxt[wp] = make_int4(ds, arc.w, __float_as_int(tot), 0);
+            else atomicOr(&sh.err, kErrWorklistFull);
           }
         }
       }
@@ -712,7 +740,7 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
       D.eps_toki[(size_t)c * D.ecap + es] = 0;
       D.eps_occ_list[(size_t)c * D.ecap] = es;
       sh.occ = 1;
-      if (fl & kFlagOutEps) { D.worklist[(size_t)c * 2 * D.wl_cap] = es; sh.wl_n[0] = 1; }
+      if (fl & kFlagOutEps) { D.worklist[(size_t)c * 2 * D.wl_cap] = make_int4(es, D.g.start, __float_as_int(0.0f), 0); sh.wl_n[0] = 1; }
     }
   }
   __syncthreads();
@@ -735,25 +763,31 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
 }
 
 // =========================================================================================
-// best path: BestPathEnd + TraceBackBestPath + GetBestPath (base-inl.h:1071-1200), one wave per
-// channel.  Hops are written in start->final order; hop 0 is the root token's (0,0,One) arc.
+// best path: BestPathEnd + TraceBackBestPath + GetBestPath (base-inl.h:1071-1200), one 256-thread
+// workgroup per channel.  Lane 0 walks the backpointer chain once (one dependent load per hop)
+// and records the token indices; all lanes then resolve the hops in parallel.  Hops are written
+// in start->final order; hop 0 is the root token's (0,0,One) arc.
 // =========================================================================================
-__global__ __launch_bounds__(64) void best_path_kernel(DecoderDev D, const int32_t *chans, int use_final, int cap,
-                                                       int32_t *o_il, int32_t *o_ol, float *o_g, float *o_ac,
-                                                       int32_t *n_hops) {
+constexpr int kBpThreads = 256;
+
+__global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, const int32_t *chans, int use_final, int cap,
+                                                               int32_t *o_il, int32_t *o_ol, float *o_g, float *o_ac,
+                                                               int32_t *n_hops, int32_t *chain) {
   const int bi = blockIdx.x;
   const int c = chans ? chans[bi] : bi;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const ChanCtl *ctl = D.ctl + c;
   const int n = ctl->front_count, nd = ctl->n_decoded;
   if (nd <= 0 || n == 0) {  // base-inl.h:1104-1108 / 1148-1154: no path
-    if (lane == 0) n_hops[bi] = 0;
+    if (tid == 0) n_hops[bi] = 0;
     return;
   }
+  __shared__ u64 s_all[kBpThreads / 64], s_fin[kBpThreads / 64];
+  __shared__ int s_len;
   const int4 *tok = D.tok + (size_t)c * D.arena_cap;
   const int fb = ctl->front_begin;
   u64 best_all = ~0ull, best_fin = ~0ull;
-  for (int i = lane; i < n; i += 64) {
+  for (int i = tid; i < n; i += kBpThreads) {
     const int4 t = tok[fb + i];
     const u64 v = ((u64)f2o(__int_as_float(t.y)) << 32) | (uint32_t)(fb + i);
     best_all = v < best_all ? v : best_all;
@@ -761,60 +795,78 @@ __global__ __launch_bounds__(64) void best_path_kernel(DecoderDev D, const int32
   }
   best_all = wave_min_u64(best_all);
   best_fin = wave_min_u64(best_fin);
-  if (lane != 0) return;
-  const u64 best = (use_final && best_fin != ~0ull) ? best_fin : best_all;
-  const int best_t = (int)(uint32_t)best;
-
-  int len = 0;
-  for (int t = best_t; t >= 0; t = tok[t].z) ++len;
-  n_hops[bi] = len;
+  if (lane == 0) { s_all[wave] = best_all; s_fin[wave] = best_fin; }
+  __syncthreads();
+  int32_t *ch = chain + (size_t)bi * cap;
+  if (tid == 0) {
+    for (int w = 1; w < kBpThreads / 64; ++w) {
+      best_all = s_all[w] < best_all ? s_all[w] : best_all;
+      best_fin = s_fin[w] < best_fin ? s_fin[w] : best_fin;
+    }
+    const u64 best = (use_final && best_fin != ~0ull) ? best_fin : best_all;
+    int len = 0;
+    for (int t = (int)(uint32_t)best; t >= 0; t = tok[t].z) {
+      if (len < cap) ch[cap - 1 - len] = t;  // last hop first, packed against the end
+      ++len;
+    }
+    n_hops[bi] = len;
+    s_len = len;
+  }
+  __syncthreads();
+  const int len = s_len;
   if (len > cap) return;
   int32_t *il = o_il + (size_t)bi * cap, *ol = o_ol + (size_t)bi * cap;
   float *og = o_g + (size_t)bi * cap, *oa = o_ac + (size_t)bi * cap;
   const float *cut = D.cutoff_hist + (size_t)c * (D.max_frames + 2);
+  const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
   const float *ll = D.ll_base[c];
   // forward links of frame f have met PruneForwardLinks iff a PruneActiveTokens pass started at
   // NumFramesDecoded() = m >= f+1 (base-inl.h:660-661, 445-476) or FinalizeDecoding ran
   const int m_last = ((nd - 1) / D.prune_interval) * D.prune_interval;
-  int pos = len - 1, fr = nd;
-  for (int t = best_t; t >= 0; --pos) {
+  for (int pos = tid; pos < len; pos += kBpThreads) {
+    const int t = ch[cap - len + pos];
     const int4 T = tok[t];
     const int prev = T.z;
     if (prev < 0) {  // base-inl.h:1193-1198
       il[pos] = 0; ol[pos] = 0; og[pos] = 0.f; oa[pos] = 0.f;
-    } else {
-      const int4 P = tok[prev];
-      const float cb = __int_as_float(P.y), ct = __int_as_float(T.y);
-      const int warc = (int)((uint32_t)T.w & kArcMask);
-      const bool eps = D.g.arcs[warc].x < 0;
-      const int fbp = eps ? fr : fr - 1;
-      const uint2 si = D.g.state_info[P.x];
-      const int ne = (int)(si.y & kEpsMask);
-      const int hi = eps ? (int)si.x + ne : (int)si.x + ne + (int)(si.y >> kEpsBits);
-      const bool pruned_once = ctl->finalized || m_last >= fbp + 1;
-      const float *llrow = ll + (size_t)(eps ? 0 : fbp) * D.stride;
-      int chosen = warc;
-      // TraceBackBestPath takes the FIRST link bp->tok; links are prepended in arc order
-      // (base-inl.h:340-341, 1169-1186), so a surviving parallel arc of higher index shadows the
-      // winning one.
-      for (int a = hi - 1; a > warc; --a) {
-        const int4 B = D.g.arcs[a];
-        if (B.w != T.x) continue;
-        const float alt_ac = eps ? 0.f : -llrow[B.x];
-        const float alt_tot = eps ? cb + __int_as_float(B.z) : (cb + alt_ac) + __int_as_float(B.z);
-        if (!(alt_tot < cut[fr])) continue;  // link never created
-        if (pruned_once && (0.0f + (alt_tot - ct)) > D.lattice_beam) continue;  // base-inl.h:524-532
-        chosen = a;
-        break;
-      }
-      const int4 C = D.g.arcs[chosen];
-      il[pos] = D.g.arc_ilabel[chosen];
-      ol[pos] = D.g.arc_olabel[chosen];
-      og[pos] = __int_as_float(C.z);
-      oa[pos] = eps ? 0.f : -llrow[C.x];
-      if (!eps) --fr;
+      continue;
     }
-    t = prev;
+    // frame of t: the f with frame_off[f] <= t < frame_off[f+1]
+    int lo = 0, hi = nd + 1;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (foff[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int fr = lo;
+    const int4 Pt = tok[prev];
+    const float cb = __int_as_float(Pt.y), ct = __int_as_float(T.y);
+    const int warc = (int)((uint32_t)T.w & kArcMask);
+    const bool eps = prev >= foff[fr];  // backpointer on the same frame <=> epsilon hop
+    const int fbp = eps ? fr : fr - 1;
+    const uint2 si = D.g.state_info[Pt.x];
+    const int ne = (int)(si.y & kEpsMask);
+    const int ahi = eps ? (int)si.x + ne : (int)si.x + ne + (int)(si.y >> kEpsBits);
+    const bool pruned_once = ctl->finalized || m_last >= fbp + 1;
+    const float *llrow = ll + (size_t)(eps ? 0 : fbp) * D.stride;
+    int chosen = warc;
+    // TraceBackBestPath takes the FIRST link bp->tok; links are prepended in arc order
+    // (base-inl.h:340-341, 1169-1186), so a surviving parallel arc of higher index shadows the
+    // winning one.
+    for (int a = ahi - 1; a > warc; --a) {
+      const int4 B = D.g.arcs[a];
+      if (B.w != T.x) continue;
+      const float alt_ac = eps ? 0.f : -llrow[B.x];
+      const float alt_tot = eps ? cb + __int_as_float(B.z) : (cb + alt_ac) + __int_as_float(B.z);
+      if (!(alt_tot < cut[fr])) continue;  // link never created
+      if (pruned_once && (0.0f + (alt_tot - ct)) > D.lattice_beam) continue;  // base-inl.h:524-532
+      chosen = a;
+      break;
+    }
+    const int4 C = D.g.arcs[chosen];
+    il[pos] = D.g.arc_ilabel[chosen];
+    ol[pos] = D.g.arc_olabel[chosen];
+    og[pos] = __int_as_float(C.z);
+    oa[pos] = eps ? 0.f : -llrow[C.x];
   }
 }
 
@@ -843,9 +895,9 @@ void launch_set_finalized(const DecoderDev &D, const int32_t *chans, int n, hipS
   hipLaunchKernelGGL(set_finalized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, D, chans, n);
 }
 void launch_best_path(const DecoderDev &D, const int32_t *chans, int n, int use_final, int cap, int32_t *ilabel,
-                      int32_t *olabel, float *graph, float *ac, int32_t *n_hops, hipStream_t s) {
-  hipLaunchKernelGGL(best_path_kernel, dim3(n), dim3(64), 0, s, D, chans, use_final, cap, ilabel, olabel, graph, ac,
-                     n_hops);
+                      int32_t *olabel, float *graph, float *ac, int32_t *n_hops, int32_t *chain, hipStream_t s) {
+  hipLaunchKernelGGL(best_path_kernel, dim3(n), dim3(kBpThreads), 0, s, D, chans, use_final, cap, ilabel, olabel, graph,
+                     ac, n_hops, chain);
 }
 int insert_kernel_set_lds(int bytes) {
   return (int)hipFuncSetAttribute((const void *)insert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--min-active", type=int, default=0)
     ap.add_argument("--workload", choices=["multi", "single"], default="multi",
                     help="multi: many live hypotheses (synth.make_loglikes_multi); single: one planted path (SURVEY 8(d))")
-    ap.add_argument("--paths", type=int, default=352)
+    ap.add_argument("--paths", type=int, default=272)
     ap.add_argument("--mu", type=float, default=None, help="noise mean (default -4.0 multi, -2.0 single)")
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances timed on the host cores (0 = skip)")
@@ -215,8 +215,8 @@ def main():
     graph = wfstdec.Graph.from_arrays(g.start, g.final_state, g.state_info, g.arcs, device=local_rank)
     graph.set_tid2pdf(m)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    dec = wfstdec.BatchDecoder(graph, wfstdec.Config(**cd), B, max_frames=T + 2, max_tokens_per_frame=65536,
-                               arena_tokens=int(T * 24000), stream=stream)
+    dec = wfstdec.BatchDecoder(graph, wfstdec.Config(**cd), B, max_frames=T + 2, max_tokens_per_frame=131072,
+                               arena_tokens=int(T * 20000), stream=stream)
     ptrs = [ll_dev[i].data_ptr() for i in range(B)]
     ready = [T] * B
     Lmax = 64
