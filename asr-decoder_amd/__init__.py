@@ -8,6 +8,6 @@ package only holds the build script, the ctypes binding used by tests and bench.
 synthetic input generator.  Import with ``importlib.import_module("asr-decoder_amd")``.
 """
 from . import build as _build  # noqa: F401
-from . import synth, wfstdec  # noqa: F401
+from . import shard, synth, wfstdec  # noqa: F401
 
-__all__ = ["synth", "wfstdec"]
+__all__ = ["shard", "synth", "wfstdec"]

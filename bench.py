@@ -189,7 +189,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     pkg = importlib.import_module("asr-decoder_amd")
-    synth, wfstdec = pkg.synth, pkg.wfstdec
+    synth, wfstdec, shard = pkg.synth, pkg.wfstdec, pkg.shard
     pkg.build.build()
 
     B, T, P = a.batch, a.frames, a.pdfs
@@ -226,18 +226,8 @@ def main():
         dec.advance(ptrs, ready, P)
         dec.finalize()
         res = dec.best_paths(cap=2 * T + 64)
-        if world > 1:  # gather final results on every rank (rank 0 is the consumer)
-            w = torch.zeros((B, Lmax + 3), dtype=torch.float32, device=dev)
-            host = np.zeros((B, Lmax + 3), np.float32)
-            for i, r in enumerate(res):
-                k = min(len(r["words"]), Lmax)
-                host[i, 0] = k
-                host[i, 1] = r["tot_score"]
-                host[i, 2] = r["lm_score"]
-                host[i, 3:3 + k] = r["words"][:k]
-            w.copy_(torch.from_numpy(host))
-            out = [torch.empty_like(w) for _ in range(world)]
-            dist.all_gather(out, w)
+        if world > 1:  # the path's only collective: gather the final results (RCCL all_gather)
+            shard.gather_results(shard.pack_results(res, Lmax), device=dev)
         return res
 
     def fence():

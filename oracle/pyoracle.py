@@ -161,5 +161,31 @@ class RefDecoder(_Base):
 
 
 class OracleDecoder(_Base):
+    """Adds the audit counters of oracle_decode_ex to Result.extra: N/E/Z work counts,
+    ``ties`` = best-path tokens that saw an exact-cost rival (reference tie-break is arrival
+    order), ``quirk_hops`` = hops where the reported arc is not the arg-min one."""
+
     PREFIX = "oracle"
     SO = ORACLE_SO
+
+    def __init__(self):
+        super().__init__()
+        self._decode_plain = self._decode
+        ex = self.lib.oracle_decode_ex
+        ex.restype = C.c_int
+        import threading
+
+        self._tls = threading.local()
+
+        def call(*args):
+            self._tls.extra = np.zeros(8, np.int64)
+            return ex(*args, self._tls.extra.ctypes.data_as(C.POINTER(C.c_int64)))
+
+        self._decode = call
+
+    def decode(self, *a, **kw):
+        r = super().decode(*a, **kw)
+        e = self._tls.extra
+        r.extra = dict(N=int(e[0]), E=int(e[1]), Z=int(e[2]), tokens_created=int(e[3]), links_created=int(e[4]),
+                       ties=int(e[5]), quirk_hops=int(e[6]))
+        return r

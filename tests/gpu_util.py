@@ -41,7 +41,7 @@ def decode_batch(graph, cd, mats, chunk=0, finalize=True, use_final_probs=True, 
     B = len(mats)
     own = dec is None
     if own:
-        dec = wfstdec.BatchDecoder(graph, gpu_config(cd), B, **(limits or dict(max_frames=512, max_tokens_per_frame=16384, arena_tokens=1 << 20)))
+        dec = wfstdec.BatchDecoder(graph, gpu_config(cd), B, **(limits or dict(max_frames=512, max_tokens_per_frame=32768, arena_tokens=1 << 22)))
     T = [int(m.shape[0]) for m in mats]
     stride = int(mats[0].shape[1])
     dev = None if host_feed else upload(mats)

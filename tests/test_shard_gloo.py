@@ -1,0 +1,67 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py -- contiguous utterance shards per rank and
+ONE all_gather of the packed results -- delivers every utterance's result to rank 0 in global
+order.  (On GPUs the same code runs on the nccl == RCCL backend.)"""
+import importlib
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_result(u):
+    rng = np.random.default_rng(u)
+    n = int(rng.integers(0, 20))
+    return dict(words=rng.integers(1, 50000, size=n).astype(np.int32), tot_score=float(np.float32(100.0 + u / 7.0)),
+                lm_score=float(np.float32(u / 3.0)))
+
+
+def _worker(rank, world, port, per_rank, lmax, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = importlib.import_module("asr-decoder_amd.shard")
+    mine = [_fake_result(u) for u in shard.shard_range(rank, world, per_rank)]
+    allp = shard.gather_results(shard.pack_results(mine, lmax))
+    dist.barrier()
+    if rank == 0:
+        q.put(allp)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_over_gloo():
+    world, per_rank, lmax = 2, 5, 16
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, lmax, q)) for r in range(world)]
+    [p.start() for p in procs]
+    allp = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    shard = importlib.import_module("asr-decoder_amd.shard")
+    got = shard.unpack_results(allp)
+    assert len(got) == world * per_rank
+    for u, r in enumerate(got):
+        e = _fake_result(u)
+        assert r["n_words"] == len(e["words"])
+        assert np.array_equal(r["words"], e["words"][:lmax])
+        assert np.float32(r["tot_score"]) == np.float32(e["tot_score"]) and np.float32(r["lm_score"]) == np.float32(e["lm_score"])
+
+
+def test_shard_ranges_partition_the_batch():
+    shard = importlib.import_module("asr-decoder_amd.shard")
+    seen = []
+    for r in range(8):
+        seen += list(shard.shard_range(r, 8, 128))
+    assert seen == list(range(1024))
