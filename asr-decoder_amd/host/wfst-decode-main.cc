@@ -1,0 +1,160 @@
+// wfst-decode: offline batch decode of precomputed log-likelihood matrices on an MI355X.
+// Same job and call sequence as the reference CLI kaldi-nnet3bin/kaldi-hclg-my-decoder.cc
+// (graph + decoder config + per-utterance matrices -> word ids, scores, real-time factor), with
+// plain files instead of Kaldi tables:
+//
+//   wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] CONFIG GRAPH LOGLIKES [WORDS_OUT]
+//
+//   CONFIG    text file of --beam=.. --max-active=.. lines (reference option names)
+//   GRAPH     flat graph in the reference format (Fst::ReadFst)
+//   LOGLIKES  binary: repeated { int32 key_len, key bytes, int32 frames, int32 cols,
+//             float32[frames*cols] }, cols = pdfs (with --tid2pdf) or NumIndices()+1
+//   tid2pdf   binary int32 array, entry 0 unused
+//
+// Output lines "key word-ids..." like the reference's words_writer (:126-129); the log at the end
+// prints the reference's "real-time factor assuming 100 frames/sec" (:189-192).
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+
+#include "wfst-host.h"
+
+using namespace datemoon;
+
+namespace {
+struct Utt {
+  std::string key;
+  int frames, cols;
+  std::vector<float> m;
+};
+bool ReadUtt(std::ifstream &in, Utt *u) {
+  int32_t kl;
+  if (!in.read((char *)&kl, 4)) return false;
+  u->key.resize(kl);
+  in.read(&u->key[0], kl);
+  in.read((char *)&u->frames, 4);
+  in.read((char *)&u->cols, 4);
+  u->m.resize((size_t)u->frames * u->cols);
+  in.read((char *)u->m.data(), u->m.size() * 4);
+  return (bool)in;
+}
+// DecodableInterface over a host matrix: the shape every reference caller has.
+class HostMatrixDecodable : public MatrixDecodable {
+ public:
+  explicit HostMatrixDecodable(const Utt &u) : _u(u) {}
+  float LogLikelihood(int f, int i) override { return _u.m[(size_t)f * _u.cols + i]; }
+  bool IsLastFrame(int f) const override { return f == _u.frames - 1; }
+  int NumFramesReady() const override { return _u.frames; }
+  int NumIndices() const override { return _u.cols - 1; }
+  const float *HostRows() const override { return _u.m.data(); }
+  int Stride() const override { return _u.cols; }
+
+ private:
+  const Utt &_u;
+};
+}  // namespace
+
+int main(int argc, char **argv) {
+  try {
+    std::string tid2pdf_file;
+    int batch = 128;
+    bool single = false;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i) {
+      std::string a = argv[i];
+      if (a.compare(0, 10, "--tid2pdf=") == 0) tid2pdf_file = a.substr(10);
+      else if (a.compare(0, 8, "--batch=") == 0) batch = atoi(a.c_str() + 8);
+      else if (a == "--single-stream") single = true;
+      else pos.push_back(a);
+    }
+    if (pos.size() < 3) {
+      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
+      return 1;
+    }
+    LatticeFasterDecoderConfig opt;
+    opt.ReadConfigFile(pos[0]);
+    Fst fst;
+    if (!fst.ReadFst(pos[1].c_str())) return 1;
+    if (!tid2pdf_file.empty()) {
+      std::ifstream t(tid2pdf_file.c_str(), std::ios::binary | std::ios::ate);
+      if (!t) { std::cerr << "cannot open " << tid2pdf_file << "\n"; return 1; }
+      std::vector<int32_t> m((size_t)t.tellg() / 4);
+      t.seekg(0);
+      t.read((char *)m.data(), m.size() * 4);
+      fst.SetTid2Pdf(m);
+    }
+    std::ifstream in(pos[2].c_str(), std::ios::binary);
+    if (!in) { std::cerr << "cannot open " << pos[2] << "\n"; return 1; }
+    std::ofstream fout;
+    if (pos.size() > 3) fout.open(pos[3].c_str());
+    std::ostream &out = pos.size() > 3 ? (std::ostream &)fout : std::cout;
+
+    std::vector<Utt> utts;
+    for (Utt u; ReadUtt(in, &u);) utts.push_back(u);
+    int num_success = 0, num_fail = 0;
+    long long frame_count = 0;
+    double tot_like = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto emit = [&](const Utt &u, Lattice &best, bool ok) {
+      std::vector<int> words, phones;
+      float tot = 0, lm = 0;
+      if (!ok || !LatticeToVector(best, words, phones, tot, lm)) {
+        std::cerr << "WARNING Did not successfully decode utterance " << u.key << ", len = " << u.frames << "\n";
+        ++num_fail;
+        return;
+      }
+      out << u.key;
+      for (int w : words) out << ' ' << w;
+      out << '\n';
+      std::cerr << "LOG " << u.key << " tot_score " << tot << " lm_score " << lm << " over " << u.frames << " frames.\n";
+      tot_like += -tot;
+      frame_count += u.frames;
+      ++num_success;
+    };
+    if (single) {  // the reference's shape: one decoder object, one utterance at a time
+      GpuLatticeDecoder decode(&fst, opt);
+      for (const Utt &u : utts) {
+        HostMatrixDecodable decodable(u);
+        decode.InitDecoding();
+        decode.AdvanceDecoding(&decodable);
+        decode.FinalizeDecoding();
+        Lattice best;
+        bool ok = decode.GetBestPath(&best);
+        emit(u, best, ok);
+      }
+    } else {  // the MI355X shape: `batch` utterances per pass
+      GpuBatchDecoder decode(&fst, opt, batch);
+      for (size_t b0 = 0; b0 < utts.size(); b0 += batch) {
+        const int n = (int)std::min<size_t>(batch, utts.size() - b0);
+        std::vector<int> ch(n), ready(n);
+        std::vector<const float *> rows(n);
+        int stride = utts[b0].cols;
+        for (int i = 0; i < n; ++i) {
+          ch[i] = i;
+          ready[i] = utts[b0 + i].frames;
+          rows[i] = utts[b0 + i].m.data();
+          if (utts[b0 + i].cols != stride) throw std::runtime_error("all matrices of a batch must have the same width");
+        }
+        decode.InitDecoding(ch);
+        decode.AdvanceDecodingHost(ch, rows, ready, stride);
+        decode.FinalizeDecoding(ch);
+        std::vector<Lattice> best;
+        std::vector<bool> ok;
+        decode.GetBestPaths(ch, &best, &ok);
+        for (int i = 0; i < n; ++i) emit(utts[b0 + i], best[i], ok[i]);
+      }
+    }
+    double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cerr << "LOG Time taken " << elapsed << "s: real-time factor assuming 100 frames/sec is "
+              << (frame_count ? elapsed * 100.0 / frame_count : 0.0) << "\n";
+    std::cerr << "LOG Done " << num_success << " utterances, failed for " << num_fail << "\n";
+    std::cerr << "LOG Overall log-likelihood per frame is " << (frame_count ? tot_like / frame_count : 0.0) << " over "
+              << frame_count << " frames.\n";
+    return num_success != 0 ? 0 : 1;
+  } catch (const std::exception &e) {
+    std::cerr << "ERROR " << e.what() << "\n";
+    return 2;
+  }
+}

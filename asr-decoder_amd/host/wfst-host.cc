@@ -1,0 +1,276 @@
+// Implementation of wfst-host.h: thin C++ over the C ABI.  No decoding happens on the host.
+#include "wfst-host.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+namespace datemoon {
+
+namespace {
+[[noreturn]] void Fatal(const std::string &what) { throw std::runtime_error(what + ": " + wfst_last_error()); }
+void Warn(const std::string &msg) { std::cerr << "WARNING (wfst) " << msg << std::endl; }
+
+// hop list (start->final order) -> the linear Lattice the reference's GetBestPath builds
+// (base-inl.h:1080-1091): last state = start, state 0 = final.
+void HopsToLattice(const int32_t *il, const int32_t *ol, const float *g, const float *ac, int n, Lattice *ofst) {
+  ofst->DeleteStates();
+  StateId state = ofst->AddState();
+  ofst->SetFinal(state);
+  for (int k = n - 1; k >= 0; --k) {
+    StateId ns = ofst->AddState();
+    ofst->AddArc(ns, LatticeArc(il[k], ol[k], state, LatticeWeight(g[k], ac[k])));
+    state = ns;
+  }
+  ofst->SetStart(state);
+}
+}  // namespace
+
+// ---- config -------------------------------------------------------------------------------
+void LatticeFasterDecoderConfig::ReadConfigFile(const std::string &path) {
+  std::ifstream in(path.c_str());
+  if (!in) throw std::runtime_error("cannot open config file " + path);
+  std::string line;
+  while (std::getline(in, line)) {
+    size_t h = line.find('#');
+    if (h != std::string::npos) line.erase(h);
+    size_t b = line.find_first_not_of(" \t\r\n");
+    if (b == std::string::npos) continue;
+    line = line.substr(b, line.find_last_not_of(" \t\r\n") - b + 1);
+    if (line.compare(0, 2, "--") != 0) throw std::runtime_error("bad config line: " + line);
+    size_t eq = line.find('=');
+    if (eq == std::string::npos) throw std::runtime_error("bad config line (no '='): " + line);
+    std::string name = line.substr(2, eq - 2), val = line.substr(eq + 1);
+    std::replace(name.begin(), name.end(), '_', '-');
+    if (name == "beam") _beam = (float)atof(val.c_str());
+    else if (name == "max-active") _max_active = atoi(val.c_str());
+    else if (name == "min-active") _min_active = atoi(val.c_str());
+    else if (name == "lattice-beam") _lattice_beam = (float)atof(val.c_str());
+    else if (name == "prune-interval") _prune_interval = atoi(val.c_str());
+    else if (name == "beam-delta") _beam_delta = (float)atof(val.c_str());
+    else if (name == "hash-ratio") _hash_ratio = (float)atof(val.c_str());
+    else if (name == "determinize-lattice") _determinize_lattice = (val == "true" || val == "1");
+    else throw std::runtime_error("unknown decoder option --" + name);
+  }
+}
+
+void LatticeFasterDecoderConfig::Check() const {
+  if (!(_beam > 0.0 && _max_active > 1 && _lattice_beam > 0.0 && _prune_interval > 0 && _beam_delta > 0.0 &&
+        _hash_ratio >= 1.0 && _prune_scale > 0.0 && _prune_scale < 1.0))
+    throw std::runtime_error("LatticeFasterDecoderConfig::Check failed");
+}
+
+wfst_config LatticeFasterDecoderConfig::ToC() const {
+  wfst_config c;
+  c.beam = _beam;
+  c.max_active = _max_active;
+  c.min_active = _min_active;
+  c.lattice_beam = _lattice_beam;
+  c.prune_interval = _prune_interval;
+  c.beam_delta = _beam_delta;
+  c.hash_ratio = _hash_ratio;
+  c.prune_scale = _prune_scale;
+  return c;
+}
+
+// ---- graph ----------------------------------------------------------------------------------
+Fst::~Fst() { wfst_graph_free(_graph); }
+
+bool Fst::ReadFst(const char *file, int device) {
+  wfst_graph_free(_graph);
+  _graph = nullptr;
+  if (wfst_graph_load(file, device, &_graph) != WFST_OK) {
+    std::cerr << "ReadFst " << file << " failed: " << wfst_last_error() << std::endl;
+    return false;
+  }
+  wfst_graph_info(_graph, &_start, &_final, &_states, &_arcs, nullptr);
+  return true;
+}
+
+void Fst::SetTid2Pdf(const std::vector<int32_t> &m) {
+  if (!_graph) throw std::runtime_error("SetTid2Pdf before ReadFst");
+  if (wfst_graph_set_tid2pdf(_graph, m.data(), (int32_t)m.size() - 1) != WFST_OK) Fatal("wfst_graph_set_tid2pdf");
+}
+
+// ---- LatticeToVector --------------------------------------------------------------------------
+bool LatticeToVector(Lattice &best_path, std::vector<int> &words, std::vector<int> &phones, float &tot, float &lm) {
+  if (best_path.Start() == kNoStateId) return false;
+  tot = 0;
+  lm = 0;
+  LatticeState *cur = best_path.GetState(best_path.Start());
+  while (!cur->IsFinal()) {
+    LatticeArc *arc = cur->GetArc(0);
+    if (arc->_input != 0) phones.push_back(arc->_input);
+    if (arc->_output != 0) words.push_back(arc->_output);
+    lm += arc->_w.Value1();
+    tot += arc->_w.Value1() + arc->_w.Value2();
+    cur = best_path.GetState(arc->_to);
+  }
+  return true;
+}
+
+// ---- single-stream decoder --------------------------------------------------------------------
+GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, const wfst_limits *limits)
+    : _dec(nullptr), _stride(0), _rows_ready(0), _inited(false) {
+  config.Check();
+  wfst_config c = config.ToC();
+  if (wfst_decoder_create(graph->Handle(), &c, 1, limits, nullptr, &_dec) != WFST_OK) Fatal("wfst_decoder_create");
+}
+GpuLatticeDecoder::~GpuLatticeDecoder() { wfst_decoder_free(_dec); }
+
+void GpuLatticeDecoder::InitDecoding() {
+  if (wfst_decoder_init(_dec, nullptr, 0) != WFST_OK) Fatal("InitDecoding");
+  _rows.clear();
+  _rows_ready = 0;
+  _stride = 0;
+  _inited = true;
+}
+
+void GpuLatticeDecoder::Pull(AmInterface *d) {
+  const int ready = d->NumFramesReady();
+  const int stride = d->NumIndices() + 1;
+  if (_stride == 0) _stride = stride;
+  if (stride != _stride) throw std::runtime_error("decodable changed NumIndices() within an utterance");
+  if (ready <= _rows_ready) return;
+  _rows.resize((size_t)ready * _stride);
+  if (MatrixDecodable *m = dynamic_cast<MatrixDecodable *>(d)) {
+    if (m->Stride() != _stride) throw std::runtime_error("MatrixDecodable::Stride() != NumIndices()+1");
+    memcpy(&_rows[(size_t)_rows_ready * _stride], m->HostRows() + (size_t)_rows_ready * _stride,
+           (size_t)(ready - _rows_ready) * _stride * sizeof(float));
+  } else {
+    for (int f = _rows_ready; f < ready; ++f) {
+      float *row = &_rows[(size_t)f * _stride];
+      row[0] = 0.0f;
+      for (int i = 1; i < _stride; ++i) row[i] = d->LogLikelihood(f, i);
+    }
+  }
+  _rows_ready = ready;
+}
+
+void GpuLatticeDecoder::AdvanceDecoding(AmInterface *decodable, int32 max_num_frames) {
+  if (!_inited) throw std::runtime_error("You must call InitDecoding() before AdvanceDecoding");
+  Pull(decodable);
+  const float *rows = _rows.data();
+  int32_t ready = _rows_ready;
+  if (ready == 0) return;
+  if (wfst_decoder_advance_host(_dec, nullptr, 0, &rows, &ready, _stride, max_num_frames) != WFST_OK)
+    Fatal("AdvanceDecoding");
+}
+
+BaseFloat GpuLatticeDecoder::ProcessEmitting(AmInterface *decodable) {
+  AdvanceDecoding(decodable, 1);
+  return 0.0f;
+}
+
+void GpuLatticeDecoder::FinalizeDecoding() {
+  if (wfst_decoder_finalize(_dec, nullptr, 0) != WFST_OK) Fatal("FinalizeDecoding");
+}
+
+int32 GpuLatticeDecoder::NumFramesDecoded() const { return wfst_decoder_num_frames_decoded(_dec, 0); }
+
+bool GpuLatticeDecoder::Decode(AmInterface *decodable) {
+  InitDecoding();
+  AdvanceDecoding(decodable);
+  FinalizeDecoding();
+  Lattice tmp;
+  return GetBestPath(&tmp, true);
+}
+
+bool GpuLatticeDecoder::GetBestPath(Lattice *ofst, bool use_final_probs) {
+  ofst->DeleteStates();
+  int cap = 4 * std::max(1, NumFramesDecoded()) + 64;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    std::vector<int32_t> il(cap), ol(cap);
+    std::vector<float> g(cap), ac(cap);
+    int32_t n = 0;
+    int rc = wfst_decoder_get_best_path(_dec, nullptr, 0, use_final_probs ? 1 : 0, cap, il.data(), ol.data(), g.data(),
+                                        ac.data(), &n);
+    if (rc == WFST_E_CAPACITY && n > cap) { cap = n; continue; }
+    if (rc == WFST_E_STATE) throw std::runtime_error(wfst_last_error());  // reference: LOG_ERR
+    if (rc != WFST_OK) Fatal("GetBestPath");
+    if (n == 0) { Warn("No final token found."); return false; }
+    HopsToLattice(il.data(), ol.data(), g.data(), ac.data(), n, ofst);
+    return true;
+  }
+  return false;
+}
+
+bool GpuLatticeDecoder::GetRawLattice(Lattice *ofst, bool) {
+  ofst->DeleteStates();
+  Warn("GetRawLattice: the state-level lattice is not produced by the best-path device decoder");
+  return false;
+}
+
+// ---- batch decoder ------------------------------------------------------------------------------
+GpuBatchDecoder::GpuBatchDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, int n_channels,
+                                 const wfst_limits *limits, void *hip_stream)
+    : _dec(nullptr), _n(n_channels) {
+  config.Check();
+  wfst_config c = config.ToC();
+  if (wfst_decoder_create(graph->Handle(), &c, n_channels, limits, hip_stream, &_dec) != WFST_OK)
+    Fatal("wfst_decoder_create");
+}
+GpuBatchDecoder::~GpuBatchDecoder() { wfst_decoder_free(_dec); }
+
+void GpuBatchDecoder::InitDecoding(const std::vector<int> &ch) {
+  if (wfst_decoder_init(_dec, ch.empty() ? nullptr : ch.data(), (int)ch.size()) != WFST_OK) Fatal("InitDecoding");
+}
+void GpuBatchDecoder::AdvanceDecoding(const std::vector<int> &ch, const std::vector<const float *> &ll,
+                                      const std::vector<int> &ready, int stride, int max_num_frames) {
+  if (wfst_decoder_advance(_dec, ch.empty() ? nullptr : ch.data(), (int)ch.size(), ll.data(), ready.data(), stride,
+                           max_num_frames) != WFST_OK)
+    Fatal("AdvanceDecoding");
+}
+void GpuBatchDecoder::AdvanceDecodingHost(const std::vector<int> &ch, const std::vector<const float *> &ll,
+                                          const std::vector<int> &ready, int stride, int max_num_frames) {
+  if (wfst_decoder_advance_host(_dec, ch.empty() ? nullptr : ch.data(), (int)ch.size(), ll.data(), ready.data(),
+                                stride, max_num_frames) != WFST_OK)
+    Fatal("AdvanceDecoding");
+}
+void GpuBatchDecoder::FinalizeDecoding(const std::vector<int> &ch) {
+  if (wfst_decoder_finalize(_dec, ch.empty() ? nullptr : ch.data(), (int)ch.size()) != WFST_OK)
+    Fatal("FinalizeDecoding");
+}
+int GpuBatchDecoder::NumFramesDecoded(int channel) const { return wfst_decoder_num_frames_decoded(_dec, channel); }
+
+void GpuBatchDecoder::GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts,
+                                   std::vector<bool> *ok, bool use_final_probs) {
+  const int cnt = channels.empty() ? _n : (int)channels.size();
+  int maxf = 1;
+  for (int i = 0; i < cnt; ++i) maxf = std::max(maxf, NumFramesDecoded(channels.empty() ? i : channels[i]));
+  int cap = 4 * maxf + 64;
+  ofsts->assign(cnt, Lattice());
+  ok->assign(cnt, false);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    std::vector<int32_t> il((size_t)cnt * cap), ol((size_t)cnt * cap), n(cnt);
+    std::vector<float> g((size_t)cnt * cap), ac((size_t)cnt * cap);
+    int rc = wfst_decoder_get_best_path(_dec, channels.empty() ? nullptr : channels.data(), (int)channels.size(),
+                                        use_final_probs ? 1 : 0, cap, il.data(), ol.data(), g.data(), ac.data(), n.data());
+    if (rc == WFST_E_CAPACITY && *std::max_element(n.begin(), n.end()) > cap) {
+      cap = *std::max_element(n.begin(), n.end());
+      continue;
+    }
+    if (rc == WFST_E_STATE) throw std::runtime_error(wfst_last_error());
+    if (rc != WFST_OK) Fatal("GetBestPath");
+    for (int i = 0; i < cnt; ++i) {
+      if (n[i] == 0) continue;
+      HopsToLattice(&il[(size_t)i * cap], &ol[(size_t)i * cap], &g[(size_t)i * cap], &ac[(size_t)i * cap], n[i],
+                    &(*ofsts)[i]);
+      (*ok)[i] = true;
+    }
+    return;
+  }
+}
+
+bool GpuBatchDecoder::GetBestPath(int channel, Lattice *ofst, bool use_final_probs) {
+  std::vector<Lattice> l;
+  std::vector<bool> ok;
+  GetBestPaths(std::vector<int>(1, channel), &l, &ok, use_final_probs);
+  *ofst = l[0];
+  return ok[0];
+}
+
+}  // namespace datemoon

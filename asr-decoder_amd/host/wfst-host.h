@@ -1,0 +1,216 @@
+// C++ host mirror of the reference's interface for the token-passing path, over the C ABI of
+// include/wfst_decoder.h.  Same names, argument meaning and error behaviour as the reference so
+// that a caller written against datemoon/ASR-decoder compiles against this header instead:
+//
+//   DecodableInterface / AmInterface     src/itf/decodable-itf.h:65-104
+//   DecoderItf                            src/my-decoder/decoder-itf.h:10-25
+//   LatticeFasterDecoderConfig            src/my-decoder/lattice-faster-decoder-conf.h:8-68
+//   Fst (ReadFst/Start/IsFinal/TotState)  src/newfst/optimize-fst.h:53-307
+//   Lattice / LatticeArc / LatticeWeight  src/newfst/lattice-fst.h:15-346, src/newfst/weigth.h:192-262
+//   LatticeToVector                       src/newfst/lattice-functions.cc:179-217
+//
+// GpuLatticeDecoder is the drop-in for OnlineLatticeDecoderMempool (one utterance stream,
+// decodable pulled through LogLikelihood()); GpuBatchDecoder is the batch shape the MI355X wants
+// (many channels per call, matrices already in HBM).  Nothing here decodes on the CPU.
+#ifndef WFST_HOST_H_
+#define WFST_HOST_H_
+
+#include <cstdint>
+#include <cstdio>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/wfst_decoder.h"
+
+namespace datemoon {
+
+typedef float BaseFloat;
+typedef int int32;
+typedef int StateId;
+typedef int Label;
+const int kNoStateId = -1;
+
+// ---- boundary A: what the decoder calls ---------------------------------------------------
+class DecodableInterface {
+ public:
+  virtual float LogLikelihood(int frame, int index) = 0;  // already scaled; the decoder negates it
+  virtual bool IsLastFrame(int frame) const = 0;
+  virtual int NumFramesReady() const = 0;
+  virtual int NumIndices() const = 0;  // indices are 1-based: 1..NumIndices()
+  virtual ~DecodableInterface() {}
+};
+typedef DecodableInterface AmInterface;
+
+// Optional fast path: a decodable that can hand over its rows in one piece (no per-element
+// virtual calls).  Row f must hold LogLikelihood(f, i) at column i, i in [0, NumIndices()].
+class MatrixDecodable : public DecodableInterface {
+ public:
+  virtual const float *HostRows() const = 0;  // row-major [NumFramesReady()][Stride()]
+  virtual int Stride() const = 0;
+};
+
+// ---- config ---------------------------------------------------------------------------------
+struct LatticeFasterDecoderConfig {
+  float _beam;
+  int _max_active;
+  int _min_active;
+  float _lattice_beam;
+  int _prune_interval;
+  bool _determinize_lattice;
+  float _beam_delta;
+  float _hash_ratio;
+  float _prune_scale;
+  LatticeFasterDecoderConfig()
+      : _beam(16.0f), _max_active(std::numeric_limits<int>::max()), _min_active(200), _lattice_beam(10.0f),
+        _prune_interval(25), _determinize_lattice(true), _beam_delta(0.5f), _hash_ratio(2.0f), _prune_scale(0.1f) {}
+  // "--name=value" lines (beam, max-active, min-active, lattice-beam, prune-interval, beam-delta,
+  // hash-ratio), the option names the reference registers (conf.h:46-61).  Unknown names throw.
+  void ReadConfigFile(const std::string &path);
+  void Check() const;  // same conditions as the reference's asserts (conf.h:62-67); throws
+  wfst_config ToC() const;
+};
+
+// ---- graph ----------------------------------------------------------------------------------
+class Fst {
+ public:
+  Fst() : _graph(nullptr) {}
+  ~Fst();
+  bool ReadFst(const char *file, int device = 0);  // false (with a message on stderr) on failure
+  bool Init(const char *file, const char *) { return ReadFst(file); }
+  void SetTid2Pdf(const std::vector<int32_t> &tid2pdf);  // entry 0 unused
+  StateId Start() const { return _start; }
+  bool IsFinal(StateId id) const { return id == _final; }
+  StateId TotState() const { return _states; }
+  int TotArc() const { return _arcs; }
+  const wfst_graph *Handle() const { return _graph; }
+
+ private:
+  Fst(const Fst &);
+  Fst &operator=(const Fst &);
+  wfst_graph *_graph;
+  int32_t _start = 0, _final = 0, _states = 0, _arcs = 0;
+};
+
+// ---- lattice (linear best path is all this path produces) ---------------------------------------
+struct LatticeWeight {
+  float _value1, _value2;  // graph cost, acoustic cost
+  LatticeWeight() : _value1(0), _value2(0) {}
+  LatticeWeight(float a, float b) : _value1(a), _value2(b) {}
+  float Value1() const { return _value1; }
+  float Value2() const { return _value2; }
+  static LatticeWeight One() { return LatticeWeight(0.0f, 0.0f); }
+};
+struct LatticeArc {
+  Label _input, _output;
+  LatticeWeight _w;
+  StateId _to;
+  LatticeArc() : _input(0), _output(0), _to(0) {}
+  LatticeArc(Label i, Label o, StateId to, LatticeWeight w) : _input(i), _output(o), _w(w), _to(to) {}
+};
+class LatticeState {
+ public:
+  LatticeState() : _final(false) {}
+  bool IsFinal() const { return _final; }
+  void SetFinal() { _final = true; }
+  void AddArc(const LatticeArc &a) { _arcs.push_back(a); }
+  LatticeArc *GetArc(unsigned i) { return i < _arcs.size() ? &_arcs[i] : nullptr; }
+  unsigned GetArcSize() const { return (unsigned)_arcs.size(); }
+
+ private:
+  std::vector<LatticeArc> _arcs;
+  bool _final;
+};
+class Lattice {
+ public:
+  Lattice() : _start(kNoStateId) {}
+  void DeleteStates() { _states.clear(); _start = kNoStateId; }
+  StateId AddState() { _states.push_back(LatticeState()); return (StateId)_states.size() - 1; }
+  void SetStart(StateId s) { _start = s; }
+  void SetFinal(StateId s) { _states[s].SetFinal(); }
+  void AddArc(StateId s, const LatticeArc &a) { _states[s].AddArc(a); }
+  StateId Start() const { return _start; }
+  StateId NumStates() const { return (StateId)_states.size(); }
+  LatticeState *GetState(StateId s) { return &_states[s]; }
+
+ private:
+  std::vector<LatticeState> _states;
+  StateId _start;
+};
+
+bool LatticeToVector(Lattice &best_path, std::vector<int> &best_words_arr, std::vector<int> &best_phones_arr,
+                     float &best_tot_score, float &best_lm_score);
+
+// ---- boundary B: what callers use -------------------------------------------------------------
+class DecoderItf {
+ public:
+  virtual ~DecoderItf() {}
+  virtual void InitDecoding() = 0;
+  virtual void AdvanceDecoding(AmInterface *decodable, int32 max_num_frames = -1) = 0;
+  virtual void FinalizeDecoding() = 0;
+  virtual int32 NumFramesDecoded() const = 0;
+  virtual BaseFloat ProcessEmitting(AmInterface *decodable) = 0;
+  virtual void ProcessNonemitting(BaseFloat cost_cutoff) = 0;
+  virtual bool Decode(AmInterface *decodable) = 0;
+  virtual bool GetBestPath(Lattice *ofst, bool use_final_probs = true) = 0;
+  virtual bool GetRawLattice(Lattice *ofst, bool use_final_probs = true) = 0;
+};
+
+// One utterance stream on channel 0 of a private 1-channel device decoder.  Scores are pulled
+// through LogLikelihood(f, i) for the frames that became ready since the last call (or taken in
+// one piece from a MatrixDecodable) and shipped to the GPU; the search runs there.
+// Fatal conditions throw std::runtime_error (the reference's LOG_ERR does, util/log-message.cc:
+// 122-145); soft ones print a warning and return false, as in the reference.
+class GpuLatticeDecoder : public DecoderItf {
+ public:
+  GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, const wfst_limits *limits = nullptr);
+  ~GpuLatticeDecoder() override;
+  void InitDecoding() override;
+  void AdvanceDecoding(AmInterface *decodable, int32 max_num_frames = -1) override;
+  void FinalizeDecoding() override;
+  int32 NumFramesDecoded() const override;
+  // The device frame step fuses ProcessEmitting and ProcessNonemitting: ProcessEmitting decodes
+  // exactly one frame (emitting arcs + epsilon closure) and returns the cutoff it used for the
+  // closure; ProcessNonemitting is then a no-op.
+  BaseFloat ProcessEmitting(AmInterface *decodable) override;
+  void ProcessNonemitting(BaseFloat) override {}
+  // InitDecoding + all ready frames + FinalizeDecoding.  (The reference's Decode() reads one frame
+  // past the end, base-inl.h:615; that landmine is not reproduced.)
+  bool Decode(AmInterface *decodable) override;
+  bool GetBestPath(Lattice *ofst, bool use_final_probs = true) override;
+  bool GetRawLattice(Lattice *ofst, bool use_final_probs = true) override;  // not on this path yet: false
+
+ private:
+  void Pull(AmInterface *decodable);
+  wfst_decoder *_dec;
+  std::vector<float> _rows;  // host history [frames][stride]
+  int _stride, _rows_ready;
+  bool _inited;
+};
+
+// Batch shape: n_channels utterances per call, device-resident matrices.
+class GpuBatchDecoder {
+ public:
+  GpuBatchDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, int n_channels,
+                  const wfst_limits *limits = nullptr, void *hip_stream = nullptr);
+  ~GpuBatchDecoder();
+  void InitDecoding(const std::vector<int> &channels = std::vector<int>());
+  void AdvanceDecoding(const std::vector<int> &channels, const std::vector<const float *> &device_loglikes,
+                       const std::vector<int> &num_frames_ready, int stride, int max_num_frames = -1);
+  void AdvanceDecodingHost(const std::vector<int> &channels, const std::vector<const float *> &host_loglikes,
+                           const std::vector<int> &num_frames_ready, int stride, int max_num_frames = -1);
+  void FinalizeDecoding(const std::vector<int> &channels = std::vector<int>());
+  int NumFramesDecoded(int channel) const;
+  bool GetBestPath(int channel, Lattice *ofst, bool use_final_probs = true);
+  void GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
+                    bool use_final_probs = true);
+  wfst_decoder *Handle() { return _dec; }
+
+ private:
+  wfst_decoder *_dec;
+  int _n;
+};
+
+}  // namespace datemoon
+#endif

@@ -67,3 +67,16 @@ def test_no_gpu_means_loud_failure(pkg):
     with pytest.raises(pkg.wfstdec.WfstError) as ei:
         pkg.wfstdec.Graph.from_arrays(s.start, s.final_state, s.state_info, s.arcs)
     assert ei.value.code == -3
+
+
+def test_host_mirror_builds_and_cli_prints_usage(pkg):
+    import subprocess
+
+    host = os.path.join(ROOT, "asr-decoder_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host])
+    p = subprocess.run([os.path.join(host, "wfst-decode")], capture_output=True, text=True)
+    assert p.returncode == 1 and "usage: wfst-decode" in p.stderr
+    hdr = open(os.path.join(host, "wfst-host.h")).read()
+    for name in ("class DecoderItf", "class DecodableInterface", "struct LatticeFasterDecoderConfig", "class Fst",
+                 "class Lattice", "bool LatticeToVector", "class GpuLatticeDecoder : public DecoderItf"):
+        assert name in hdr

@@ -1,0 +1,50 @@
+"""-m gpu: the C++ host mirror (asr-decoder_amd/host: DecoderItf / DecodableInterface / Fst /
+Lattice / LatticeToVector over the C ABI) through its CLI, wfst-decode, which has the call
+sequence of the reference CLI kaldi-hclg-my-decoder.cc:97-129.  Both shapes -- one GpuLatticeDecoder
+pulling a DecodableInterface (--single-stream) and the batch decoder -- must print the oracle's words
+and scores."""
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyoracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "asr-decoder_amd", "host", "wfst-decode")
+
+
+@pytest.mark.parametrize("mode", ["batch", "single"])
+def test_cli_matches_oracle(mode, synth, oracle, tmp_path):
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m = synth.default_tid2pdf(600)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=12\n--max-active=1000000\n--min-active=0\n--lattice-beam=6 # comment\n")
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=6.0)
+    mats = [synth.make_loglikes(g, T, 300, m, seed=300 + i, mu=-2.2)[0] for i, T in enumerate([80, 45, 120, 7, 64])]
+    with open(tmp_path / "ll.bin", "wb") as f:
+        for i, x in enumerate(mats):
+            key = ("utt%03d" % i).encode()
+            f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
+    args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--batch=4"]
+    if mode == "single":
+        args.append("--single-stream")
+    p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    words = {l.split()[0]: [int(w) for w in l.split()[1:]] for l in p.stdout.strip().splitlines()}
+    scores = {mm.group(1): (float(mm.group(2)), float(mm.group(3))) for mm in re.finditer(r"LOG (utt\d+) tot_score (\S+) lm_score (\S+)", p.stderr)}
+    assert "real-time factor assuming 100 frames/sec" in p.stderr
+    h = oracle.load_graph(gpath)
+    for i, x in enumerate(mats):
+        o = oracle.decode(h, pyoracle.Config(**cd), x, m)
+        k = "utt%03d" % i
+        assert words[k] == o.words.tolist(), k
+        assert abs(scores[k][0] - o.tot_score) <= 1e-4 * max(1.0, abs(o.tot_score))  # printed with 6 digits
+    oracle.free_graph(h)
