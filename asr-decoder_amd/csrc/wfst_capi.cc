@@ -94,6 +94,10 @@ struct wfst_decoder {
   DevBuf<int4> tok;
   DevBuf<int32_t> frame_off, bucket_cnt, eps_keys, eps_toki, eps_occ_list, target, chan_list;
   DevBuf<int4> bucket, worklist;
+  DevBuf<FrameCtl> fctl;
+  DevBuf<int32_t> tile_chan;
+  std::vector<int> gpar;  // step parity per group (persists across advance calls)
+  int expand_wgs = 2048;
   DevBuf<float> cutoff_hist;
   DevBuf<unsigned long long> eps_vals;
   DevBuf<const float *> ll_base;
@@ -113,9 +117,13 @@ struct wfst_decoder {
   std::vector<int32_t> hist_rows;
   int32_t hist_stride = 0;
   int tiles_per_channel = 16;
-  // the frame loop of one advance call, captured once per (frames, stride) and replayed
+  // the frame loop of one advance call, captured once per (frames per group, stride) and replayed
   bool use_graph = true;
-  std::map<std::pair<int, int>, hipGraphExec_t> graphs;
+  std::map<std::vector<int>, hipGraphExec_t> graphs;
+  // channel groups: each runs its frame loop on its own stream (fork/join around the main stream)
+  int n_groups = 1;
+  std::vector<hipStream_t> gstreams;
+  std::vector<hipEvent_t> gevents;  // [0] fork, [1..] join per group
   // optional kernel timing (wfst_decoder_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -137,13 +145,15 @@ struct wfst_decoder {
       if (p) (void)hipFree(p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    for (hipStream_t st : gstreams) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : gevents) (void)hipEventDestroy(ev);
     if (p_target) (void)hipHostFree(p_target);
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); eps_keys.release();
     eps_toki.release(); eps_occ_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
+    bucket.release(); fctl.release(); tile_chan.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
     bp_ac.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -362,9 +372,9 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   // hash partitions per channel: each insert workgroup owns an LDS table of lds_slots entries;
   // a bucket too full for it is handled in sub-passes, so these are speed knobs, not limits
   const int64_t M = L.max_tokens_per_frame;
-  int lds_slots = 4096, log2lds = 12, log2part = 4;
+  int lds_slots = 1024, log2lds = 10, log2part = 6;
   if (const char *e = getenv("WFST_LOG2_PARTS")) log2part = std::max(0, std::min(6, atoi(e)));
-  if (const char *e = getenv("WFST_LDS_SLOTS")) { if (atoi(e) == 8192) { lds_slots = 8192; log2lds = 13; } }
+  if (const char *e = getenv("WFST_LOG2_LDS_SLOTS")) { log2lds = std::max(8, std::min(13, atoi(e))); lds_slots = 1 << log2lds; }
   while (log2part > 0 && (int64_t)lds_slots << (log2part - 1) >= 4 * M) --log2part;  // tiny limits: fewer parts
   const int n_part = 1 << log2part;
   const int64_t bucket_cap = std::max<int64_t>(2048, 8 * M / n_part);
@@ -400,6 +410,9 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   A(d->eps_toki.alloc(B * ecap));
   A(d->eps_occ_list.alloc(B * ecap));
   A(d->worklist.alloc(B * 2 * (size_t)L.max_tokens_per_frame));
+  const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 256 + 2);
+  A(d->fctl.alloc(8));
+  A(d->tile_chan.alloc(8 * tile_cap));
   A(d->target.alloc(B));
   A(d->chan_list.alloc(B));
   A(d->ll_base.alloc(B));
@@ -409,9 +422,11 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   A(hipHostMalloc((void **)&d->p_ctl, B * sizeof(ChanCtl)));
   if (e == hipSuccess) A(hipMemsetAsync(d->ctl.p, 0, d->ctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->bucket_cnt.p, 0, d->bucket_cnt.bytes(), d->stream));
+  if (e == hipSuccess) A(hipMemsetAsync(d->fctl.p, 0, d->fctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->eps_keys.p, 0xFF, d->eps_keys.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->eps_vals.p, 0xFF, d->eps_vals.bytes(), d->stream));
   if (e == hipSuccess && lds_slots * 12 > 65536) A((hipError_t)insert_kernel_set_lds(lds_slots * 12));
+
   if (e == hipSuccess) A(hipMemsetAsync(d->target.p, 0, d->target.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->ll_base.p, 0, d->ll_base.bytes(), d->stream));
   if (e == hipSuccess) A(hipStreamSynchronize(d->stream));
@@ -432,6 +447,9 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.eps_toki = d->eps_toki.p;
   D.eps_occ_list = d->eps_occ_list.p;
   D.worklist = d->worklist.p;
+  D.fctl = d->fctl.p;
+  D.tile_chan = d->tile_chan.p;
+  D.tile_cap = (int32_t)tile_cap;
   D.ll_base = d->ll_base.p;
   D.n_channels = n_channels;
   D.stride = 0;
@@ -452,6 +470,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.max_active = cfg->max_active;
   D.min_active = cfg->min_active;
   D.prune_interval = cfg->prune_interval;
+  D.dbg = getenv("WFST_DBG") ? atoi(getenv("WFST_DBG")) : 0;
   d->h_decoded.assign(B, 0);
   d->h_target.assign(B, 0);
   d->h_state.assign(B, 0);
@@ -460,8 +479,18 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   d->hist_rows_cap.assign(B, 0);
   d->hist_rows.assign(B, 0);
   if (const char *ng = getenv("WFST_NO_GRAPH")) d->use_graph = atoi(ng) == 0;
-  const char *tp = getenv("WFST_TILES_PER_CHANNEL");
-  if (tp && atoi(tp) > 0) d->tiles_per_channel = atoi(tp);
+  d->n_groups = 1;
+  if (const char *gs = getenv("WFST_GROUPS")) d->n_groups = std::max(1, std::min(atoi(gs), std::min(8, n_channels)));
+  if (d->n_groups > 1) {
+    d->gstreams.resize(d->n_groups);
+    d->gevents.resize(d->n_groups + 1);
+    hipError_t ge = hipSuccess;
+    for (auto &st : d->gstreams) if (ge == hipSuccess) ge = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    for (auto &ev : d->gevents) if (ge == hipSuccess) ge = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (ge != hipSuccess) { delete d; return fail(WFST_E_DEVICE, "stream/event creation failed"); }
+  }
+  if (const char *tp = getenv("WFST_EXPAND_WGS")) { if (atoi(tp) > 0) d->expand_wgs = atoi(tp); }
+  d->gpar.assign(8, 0);
   *out = d;
   return WFST_OK;
 }
@@ -556,32 +585,58 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   HIP_TRY(hipMemcpyAsync((void *)d->ll_base.p, (const void *)d->p_ll, (size_t)d->n_channels * sizeof(float *),
                          hipMemcpyHostToDevice, d->stream));
   d->D.stride = stride;
-  auto timed = [&](int cls, auto &&launch) {
+  // frames to decode per channel group
+  const int G = d->n_groups, per = (d->n_channels + G - 1) / G;
+  std::vector<int> gsteps(G, 0);
+  for (int c = 0; c < d->n_channels; ++c)
+    gsteps[c / per] = std::max(gsteps[c / per], d->h_target[c] - d->h_decoded[c]);
+  auto timed = [&](int cls, hipStream_t st, auto &&launch) {
     if (!d->profiling) { launch(); return; }
     const int a = d->ev_get(), b = d->ev_get();
-    if (a >= 0 && b >= 0) (void)hipEventRecord(d->ev_pool[a], d->stream);
+    if (a >= 0 && b >= 0) (void)hipEventRecord(d->ev_pool[a], st);
     launch();
-    if (a >= 0 && b >= 0) { (void)hipEventRecord(d->ev_pool[b], d->stream); d->ev_pairs[cls].push_back({a, b}); }
+    if (a >= 0 && b >= 0) { (void)hipEventRecord(d->ev_pool[b], st); d->ev_pairs[cls].push_back({a, b}); }
   };
-  auto enqueue = [&] {
-    timed(2, [&] { launch_closure(d->D, d->target.p, 1, d->stream); });  // GetCutoff + seed only
-    for (int s = 0; s < steps; ++s) {
-      timed(0, [&] { launch_expand(d->D, d->tiles_per_channel, d->stream); });
-      timed(1, [&] { launch_insert(d->D, d->stream); });
-      timed(2, [&] { launch_closure(d->D, d->target.p, s + 1 < steps, d->stream); });
+  const std::vector<int> gpar0(d->gpar);  // parity each group starts this call with
+  auto enqueue = [&]() -> hipError_t {
+    hipError_t err = hipSuccess;
+    auto E = [&](hipError_t r) { if (err == hipSuccess) err = r; };
+    if (G > 1) E(hipEventRecord(d->gevents[0], d->stream));
+    for (int g = 0; g < G; ++g) {
+      const int off = g * per, cnt = std::min(per, d->n_channels - off);
+      if (cnt <= 0 || gsteps[g] == 0) continue;
+      hipStream_t st = G > 1 ? d->gstreams[g] : d->stream;
+      if (G > 1) E(hipStreamWaitEvent(st, d->gevents[0], 0));
+      int par = gpar0[g];
+      timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });  // GetCutoff + seed only
+      for (int s = 0; s < gsteps[g]; ++s) {
+        timed(0, st, [&] { launch_expand(d->D, g, par, d->expand_wgs, st); });
+        timed(1, st, [&] { launch_insert(d->D, off, cnt, g, par, st); });
+        timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, s + 1 < gsteps[g], g, par ^ 1, st); });
+        par ^= 1;
+      }
+      if (G > 1) {
+        E(hipEventRecord(d->gevents[1 + g], st));
+        E(hipStreamWaitEvent(d->stream, d->gevents[1 + g], 0));
+      }
     }
+    return err;
   };
   if (d->use_graph && !d->profiling && steps >= 4) {
     // launch-bound inner loop -> hipGraph: per-frame state lives in ChanCtl on the device, so the
-    // captured kernels and their arguments are identical for every call with the same frame count
-    const auto key = std::make_pair(steps, (int)stride);
+    // captured kernels and their arguments are identical for every call with the same frame counts
+    std::vector<int> key(gsteps);
+    key.push_back((int)stride);
+    for (int g = 0; g < G; ++g) key.push_back(gpar0[g]);
     auto it = d->graphs.find(key);
     if (it == d->graphs.end()) {
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
       HIP_TRY(hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal));
-      enqueue();
-      HIP_TRY(hipStreamEndCapture(d->stream, &graph));
+      hipError_t ce = enqueue();
+      hipError_t ee = hipStreamEndCapture(d->stream, &graph);
+      HIP_TRY(ce);
+      HIP_TRY(ee);
       HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       HIP_TRY(hipGraphDestroy(graph));
       if (d->graphs.size() >= 64) {  // bounded cache
@@ -592,9 +647,10 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     }
     HIP_TRY(hipGraphLaunch(it->second, d->stream));
   } else {
-    enqueue();
+    HIP_TRY(enqueue());
   }
   HIP_TRY(hipGetLastError());
+  for (int g = 0; g < G; ++g) d->gpar[g] = gpar0[g] ^ (gsteps[g] & 1);
   for (int c = 0; c < d->n_channels; ++c) d->h_decoded[c] = std::max(d->h_decoded[c], d->h_target[c]);
   return WFST_OK;
 }

@@ -62,11 +62,18 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t error;         // sticky kErr* bits
   int32_t finalized;
   int32_t peak_tokens;
-  int32_t pad0;
+  int32_t tile_start;    // first entry of this channel's tiles in tile_chan[] for the coming frame
   unsigned long long cnt_N, cnt_E, cnt_Z, cnt_tok, cnt_rec;  // work counters since init
   unsigned long long pad1[3];
 };
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
+
+// per channel-group frame counters, double buffered by step parity
+struct FrameCtl {
+  int32_t total_tiles[2];  // tiles published by prep_frame for the step of that parity
+  int32_t ticket[2];       // dynamic tile dispenser of expand_kernel
+  int32_t pad[12];
+};
 
 // ---- decoder (batch of channels) ---------------------------------------------------------
 // Per channel c:
@@ -92,14 +99,17 @@ struct DecoderDev {
   unsigned long long *eps_vals;
   int32_t *eps_toki;
   int32_t *eps_occ_list;
-  int4 *worklist;               // {eps-table slot, state, cost bits, 0}
+  int4 *worklist;               // [c][2][wl_cap] {eps-table slot, state, cost bits, 0}
+  FrameCtl *fctl;               // [n_groups]
+  int32_t *tile_chan;           // [n_groups][tile_cap] channel of each 256-token tile of the coming frame
+  int32_t tile_cap;
   const float *const *ll_base;  // [n_channels] device pointers to row 0 of each utterance matrix
   int32_t n_channels;
   int32_t stride;               // floats per log-likelihood row
   int32_t n_part, log2part;     // hash partitions per channel (power of two, <= 64)
   int32_t lds_slots, log2lds;   // LDS hash slots per partition workgroup (4096 or 8192)
   int32_t bucket_cap;           // records per bucket
-  int32_t ecap, log2ecap;       // epsilon-table slots (power of two)
+  int32_t ecap, log2ecap;       // global (fallback) epsilon-table slots (power of two)
   int32_t max_tok;              // tokens per frame
   int32_t wl_cap;
   int32_t max_frames;
@@ -107,13 +117,15 @@ struct DecoderDev {
   // config (LatticeFasterDecoderConfig)
   float beam, lattice_beam, beam_delta;
   int32_t max_active, min_active, prune_interval;
+  int32_t dbg;  // WFST_DBG ablation bits (timing experiments only; results are wrong when set)
 };
 
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
-void launch_expand(const DecoderDev &D, int tiles_per_channel, hipStream_t s);
-void launch_insert(const DecoderDev &D, hipStream_t s);
-void launch_closure(const DecoderDev &D, const int32_t *target_dev, int do_prep, hipStream_t s);
+void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s);
+void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, hipStream_t s);
+void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int do_prep,
+                    int group, int par, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_best_path(const DecoderDev &D, const int32_t *chan_list_dev, int n, int use_final,
                       int cap, int32_t *ilabel, int32_t *olabel, float *graph, float *ac,

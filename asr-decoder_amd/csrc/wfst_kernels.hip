@@ -109,20 +109,17 @@ constexpr int kExpandThreads = 256;
 constexpr int kCandPerThread = 4;
 constexpr int kChunk = kExpandThreads * kCandPerThread;  // candidates per counting-sort round
 
-__global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D) {
-  const int c = blockIdx.x;
-  ChanCtl *ctl = D.ctl + c;
-  if (!ctl->active) return;
+// Work unit = one tile of 256 frontier tokens of one channel.  prep_frame lists the tiles of all
+// active channels in tile_chan[]; workgroup w takes tile w, then further tiles from a ticket
+// counter, so a channel with 8x the tokens simply owns 8x the tiles (per-frame token counts are
+// heavy-tailed across a batch; a fixed share of workgroups per channel made every frame wait for
+// the heaviest one).
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, int group, int par) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = ctl->front_count;
-  const int fbegin = ctl->front_begin;
-  const int4 *tok = D.tok + (size_t)c * D.arena_cap + fbegin;
-  const float cutoff = ctl->cur_cutoff, ab = ctl->adaptive_beam;
-  const float *llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
+  FrameCtl *fc = D.fctl + group;
+  const int total_tiles = fc->total_tiles[par];
   const float kInf = __builtin_huge_valf();
   const int P = D.n_part, log2part = D.log2part, bcap = D.bucket_cap;
-  int4 *bucket = D.bucket + (size_t)c * P * bcap;
-  int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
 
   __shared__ int s_base[kExpandThreads + 1];
   __shared__ int s_arcbeg[kExpandThreads];
@@ -130,9 +127,22 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D) {
   __shared__ int s_wsum[kExpandThreads / 64];
   __shared__ int s_cnt[64], s_lbase[65], s_gbase[64];
   __shared__ int4 s_rec[kChunk];
+  __shared__ int s_ticket;
 
-  u64 nN = 0, nE = 0, nR = 0;
-  for (int tile = blockIdx.y; tile * kExpandThreads < n; tile += gridDim.y) {
+  const int32_t *tile_chan = D.tile_chan + (size_t)group * D.tile_cap;
+  for (int t = blockIdx.x; t < total_tiles;) {
+    const int c = tile_chan[t];
+    ChanCtl *ctl = D.ctl + c;
+    const int tile = t - ctl->tile_start;
+    const int n = ctl->front_count;
+    const int fbegin = ctl->front_begin;
+    const int4 *tok = D.tok + (size_t)c * D.arena_cap + fbegin;
+    const float cutoff = ctl->cur_cutoff, ab = ctl->adaptive_beam;
+    const float *llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
+    int4 *bucket = D.bucket + (size_t)c * P * bcap;
+    int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
+    u64 nN = 0, nE = 0, nR = 0;
+    {
     const int i = tile * kExpandThreads + tid;
     int deg = 0, arcbeg = 0;
     float cost = 0.f;
@@ -245,13 +255,19 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D) {
       }
       __syncthreads();
     }
-  }
-  nN = wave_sum_u64(nN);
-  nE = wave_sum_u64(nE);
-  if (lane == 0 && (nN | nE | nR)) {
-    atomicAdd(&ctl->cnt_N, nN);
-    atomicAdd(&ctl->cnt_E, nE);
-    if (nR) atomicAdd(&ctl->cnt_rec, nR);
+    }
+    nN = wave_sum_u64(nN);
+    nE = wave_sum_u64(nE);
+    if (lane == 0 && (nN | nE | nR)) {
+      atomicAdd(&ctl->cnt_N, nN);
+      atomicAdd(&ctl->cnt_E, nE);
+      if (nR) atomicAdd(&ctl->cnt_rec, nR);
+    }
+    // next tile: the first gridDim.x tiles are taken statically, the rest by ticket
+    if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(&fc->ticket[par], 1);
+    __syncthreads();
+    t = s_ticket;
+    __syncthreads();
   }
 }
 
@@ -263,15 +279,19 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D) {
 constexpr int kInsertThreads = 256;
 constexpr int kInsertUnroll = 4;
 
-__global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D) {
+__global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, int chan_off, int group, int par) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int c = blockIdx.x, p = blockIdx.y;
+  const int c = blockIdx.x + chan_off, p = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && p == 0 && tid == 0) {  // the tile list of the previous frame is consumed
+    D.fctl[group].total_tiles[par ^ 1] = 0;
+    D.fctl[group].ticket[par ^ 1] = 0;
+  }
   ChanCtl *ctl = D.ctl + c;
   if (!ctl->active) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int SL = D.lds_slots;
+  const int SLmax = D.lds_slots;
   u64 *vals = reinterpret_cast<u64 *>(smem);
-  int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)SL * 8);
+  int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)SLmax * 8);
   __shared__ int s_nstates, s_gpos, s_wpos, s_ok;
   __shared__ u64 s_best[kInsertThreads / 64];
 
@@ -282,6 +302,11 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D) {
   if (n == 0) return;
   const int4 *bucket = D.bucket + ((size_t)c * P + p) * D.bucket_cap;
   const float cutoff = o2f(ctl->bound);  // FINAL next_cutoff of this frame
+  // table sized to the load: the smallest power of two >= 4 n (records >= distinct states),
+  // so light partitions pay for clearing a few hundred slots, not the whole 48 KB
+  int log2sl = 6;
+  while ((1 << log2sl) < 4 * n && log2sl < D.log2lds) ++log2sl;
+  const int SL = 1 << log2sl;
   const uint32_t mask = (uint32_t)SL - 1;
   const int base = ctl->front_begin + ctl->front_count;
   int4 *tok = D.tok + (size_t)c * D.arena_cap;
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D) {
 
   int log2sub = 0;
   while (n > ((SL * 3) >> 2) << log2sub) ++log2sub;
-  const int sub_shift = 32 - D.log2part - D.log2lds - log2sub;
+  const int sub_shift = 32 - D.log2part - log2sl - log2sub;
   if (sub_shift < 0) { if (tid == 0) { atomicOr(&ctl->error, kErrTableFull); *cntp = 0; } return; }
 
   u64 best = ~0ull;
@@ -315,10 +340,10 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D) {
       }
 #pragma unroll
       for (int k = 0; k < kInsertUnroll; ++k) {
-        if (!(__int_as_float(r[k].y) < cutoff)) continue;
+        if (!(__int_as_float(r[k].y) < cutoff) || (D.dbg & 4)) continue;
         const uint32_t h = hash32(r[k].x);
         if (log2sub && (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) != sub) continue;
-        uint32_t slot = lds_slot_of(h, D.log2part, D.log2lds);
+        uint32_t slot = lds_slot_of(h, D.log2part, log2sl);
         bool found = false;
         for (int q = 0; q < SL; ++q) {
           int32_t kk = keys[slot];
@@ -346,6 +371,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D) {
     const int gpos = s_gpos;
 
     // pass 2: the record that won its state writes the token
+    if (D.dbg & 1) continue;
     for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
       int4 r[kInsertUnroll];
 #pragma unroll
@@ -361,7 +387,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D) {
           const uint32_t h = hash32(r[k].x);
           if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
             packed = ((u64)f2o(__int_as_float(r[k].y)) << 32) | (uint32_t)r[k].w;
-            uint32_t slot = lds_slot_of(h, D.log2part, D.log2lds);
+            uint32_t slot = lds_slot_of(h, D.log2part, log2sl);
             for (int q = 0; q < SL; ++q) {
               const int32_t kk = keys[slot];
               if (kk == r[k].x) { winner = vals[slot] == packed; break; }
@@ -626,7 +652,8 @@ __device__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh)
   return o2f(sh.sel_prefix);
 }
 
-__device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32_t *target, BoundaryShared &sh) {
+__device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32_t *target, BoundaryShared &sh,
+                           int group, int par) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float kInf = __builtin_huge_valf();
   if (tid == 0) {
@@ -697,16 +724,30 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
     ctl->new_count = 0;
     ctl->best_next = ~0ull;
     ctl->active = 1;
+    // publish this channel's tiles for the expansion (any disjoint range will do)
+    const int ntiles = (n + kExpandThreads - 1) / kExpandThreads;
+    sh.active = 0;
+    if (ntiles > 0) {
+      const int start = atomicAdd(&D.fctl[group].total_tiles[par], ntiles);
+      ctl->tile_start = start;
+      if (start + ntiles <= D.tile_cap) { sh.sel_k = (uint32_t)start; sh.active = ntiles; }
+      else ctl->error |= kErrFrontierFull;
+    }
   }
+  __syncthreads();
+  const int ntl = sh.active;
+  int32_t *tile_chan = D.tile_chan + (size_t)group * D.tile_cap + sh.sel_k;
+  for (int i = tid; i < ntl; i += kBT) tile_chan[i] = c;
 }
 
-__global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_t *target, int do_prep) {
+__global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_t *target, int do_prep, int chan_off,
+                                                      int group, int par) {
   __shared__ BoundaryShared sh;
-  const int c = blockIdx.x;
+  const int c = blockIdx.x + chan_off;
   ChanCtl *ctl = D.ctl + c;
   if (ctl->active) finalize_frame(D, c, ctl, sh);
   __syncthreads();
-  if (do_prep) prep_frame(D, c, ctl, target, sh);
+  if (do_prep) prep_frame(D, c, ctl, target, sh, group, par);  // par: parity of the step it prepares
 }
 
 // =========================================================================================
@@ -881,15 +922,19 @@ static __global__ void set_finalized_kernel(DecoderDev D, const int32_t *chans, 
 void launch_init(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(init_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
 }
-void launch_expand(const DecoderDev &D, int tiles_per_channel, hipStream_t s) {
-  hipLaunchKernelGGL(expand_kernel, dim3(D.n_channels, tiles_per_channel), dim3(kExpandThreads), 0, s, D);
+// chan_off / chan_cnt: the channel group a launch covers (groups run on their own streams so that
+// one group's latency-bound closure overlaps another group's expand / insert)
+void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s) {
+  hipLaunchKernelGGL(expand_kernel, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
 }
-void launch_insert(const DecoderDev &D, hipStream_t s) {
+void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, hipStream_t s) {
   const size_t lds = (size_t)D.lds_slots * 12;
-  hipLaunchKernelGGL(insert_kernel, dim3(D.n_channels, D.n_part), dim3(kInsertThreads), lds, s, D);
+  hipLaunchKernelGGL(insert_kernel, dim3(chan_cnt, D.n_part), dim3(kInsertThreads), lds, s, D, chan_off, group, par);
 }
-void launch_closure(const DecoderDev &D, const int32_t *target, int do_prep, hipStream_t s) {
-  hipLaunchKernelGGL(closure_kernel, dim3(D.n_channels), dim3(kBT), 0, s, D, target, do_prep);
+void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int do_prep, int group, int par,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(closure_kernel, dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off,
+                     group, par);
 }
 void launch_set_finalized(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(set_finalized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, D, chans, n);
@@ -902,5 +947,4 @@ void launch_best_path(const DecoderDev &D, const int32_t *chans, int n, int use_
 int insert_kernel_set_lds(int bytes) {
   return (int)hipFuncSetAttribute((const void *)insert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
-
 }  // namespace wfst

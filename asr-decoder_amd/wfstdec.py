@@ -206,19 +206,25 @@ class BatchDecoder:
         nh = np.zeros(cnt, np.int32)
         _check(lib().wfst_decoder_get_best_path(self.h, _i32(ch), n, int(bool(use_final_probs)), int(cap),
                                                 _i32(il), _i32(ol), _f32(g), _f32(ac), _i32(nh)))
+        # LatticeToVector (newfst/lattice-functions.cc:179-217) for all channels at once: the float32
+        # running sums tot += (g + a), lm += g in forward order are exactly np.cumsum in float32
+        # (strictly sequential accumulation); the C entry point wfst_lattice_to_vector does the same
+        # per utterance and tests/test_capi_symbols.py holds the two against each other.
+        pos = np.arange(cap)[None, :] < nh[:, None]
+        x = np.where(pos, g + ac, np.float32(0)).astype(np.float32)
+        tot = np.cumsum(x, axis=1, dtype=np.float32)
+        lm = np.cumsum(np.where(pos, g, np.float32(0)).astype(np.float32), axis=1, dtype=np.float32)
+        last = np.maximum(nh - 1, 0)
+        rows = np.arange(cnt)
+        tot_s, lm_s = tot[rows, last], lm[rows, last]
+        wmask = pos & (ol != 0)
+        tmask = pos & (il != 0)
         out = []
         for i in range(cnt):
             k = int(nh[i])
-            words = np.zeros(max(k, 1), np.int32)
-            tids = np.zeros(max(k, 1), np.int32)
-            nw, nt = C.c_int32(), C.c_int32()
-            tot, lm = C.c_float(), C.c_float()
-            _check(lib().wfst_lattice_to_vector(_i32(il[i]), _i32(ol[i]), _f32(g[i]), _f32(ac[i]), k,
-                                                _i32(words), k, C.byref(nw), _i32(tids), k, C.byref(nt),
-                                                C.byref(tot), C.byref(lm)))
-            out.append(dict(ok=k > 0, ilabel=il[i, :k].copy(), olabel=ol[i, :k].copy(), graph=g[i, :k].copy(),
-                            ac=ac[i, :k].copy(), words=words[: nw.value].copy(), tids=tids[: nt.value].copy(),
-                            tot_score=float(tot.value), lm_score=float(lm.value)))
+            out.append(dict(ok=k > 0, ilabel=il[i, :k], olabel=ol[i, :k], graph=g[i, :k], ac=ac[i, :k],
+                            words=ol[i][wmask[i]], tids=il[i][tmask[i]],
+                            tot_score=float(tot_s[i]) if k else 0.0, lm_score=float(lm_s[i]) if k else 0.0))
         return out
 
     def stats(self, channel):

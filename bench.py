@@ -221,11 +221,24 @@ def main():
     ready = [T] * B
     Lmax = 64
 
+    tb = {"init": 0.0, "advance_enqueue": 0.0, "finalize": 0.0, "sync": 0.0, "best_paths": 0.0, "n": 0}
+
     def step():
+        t0 = time.perf_counter()
         dec.init()
+        t1 = time.perf_counter()
         dec.advance(ptrs, ready, P)
+        t2 = time.perf_counter()
         dec.finalize()
+        t3 = time.perf_counter()
+        if os.environ.get("WFST_BENCH_BREAKDOWN"):
+            dec.sync()
+        t4 = time.perf_counter()
         res = dec.best_paths(cap=2 * T + 64)
+        t5 = time.perf_counter()
+        for k, v in zip(("init", "advance_enqueue", "finalize", "sync", "best_paths"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+            tb[k] += v
+        tb["n"] += 1
         if world > 1:  # the path's only collective: gather the final results (RCCL all_gather)
             shard.gather_results(shard.pack_results(res, Lmax), device=dev)
         return res
@@ -249,6 +262,8 @@ def main():
         dt = float(tt.item())
     frames_total = world * B * T * a.steps
     value = frames_total / dt
+    if os.environ.get("WFST_BENCH_BREAKDOWN"):
+        log("[rank %d] host-side ms per step: %s" % (rank, {k: round(1000.0 * v / max(tb["n"], 1), 2) for k, v in tb.items() if k != "n"}))
 
     # ---- roofline pass: one more step with HIP events around every kernel launch -----------
     gstats = [dec.stats(c) for c in range(B)]

@@ -80,3 +80,29 @@ def test_host_mirror_builds_and_cli_prints_usage(pkg):
     for name in ("class DecoderItf", "class DecodableInterface", "struct LatticeFasterDecoderConfig", "class Fst",
                  "class Lattice", "bool LatticeToVector", "class GpuLatticeDecoder : public DecoderItf"):
         assert name in hdr
+
+
+def test_vectorised_lattice_to_vector_equals_c_entry_point(pkg):
+    """wfstdec.BatchDecoder.best_paths sums scores with numpy cumsum; it must be bit-identical to
+    the sequential float32 accumulation of wfst_lattice_to_vector (the reference's LatticeToVector)."""
+    import numpy as np
+
+    rng = np.random.default_rng(3)
+    n = 700
+    g = rng.uniform(0, 4, n).astype(np.float32)
+    a = rng.uniform(0, 9, n).astype(np.float32)
+    il = rng.integers(0, 3, n).astype(np.int32)
+    ol = rng.integers(0, 2, n).astype(np.int32)
+    words = np.zeros(n, np.int32)
+    tids = np.zeros(n, np.int32)
+    nw, nt = ctypes.c_int32(), ctypes.c_int32()
+    tot, lm = ctypes.c_float(), ctypes.c_float()
+    f = lambda x, t: x.ctypes.data_as(ctypes.POINTER(t))
+    pkg.wfstdec.lib().wfst_lattice_to_vector(f(il, ctypes.c_int32), f(ol, ctypes.c_int32), f(g, ctypes.c_float), f(a, ctypes.c_float),
+                                             n, f(words, ctypes.c_int32), n, ctypes.byref(nw), f(tids, ctypes.c_int32), n,
+                                             ctypes.byref(nt), ctypes.byref(tot), ctypes.byref(lm))
+    t2 = np.cumsum((g + a).astype(np.float32), dtype=np.float32)[-1]
+    l2 = np.cumsum(g, dtype=np.float32)[-1]
+    assert np.float32(tot.value).tobytes() == np.float32(t2).tobytes()
+    assert np.float32(lm.value).tobytes() == np.float32(l2).tobytes()
+    assert list(words[: nw.value]) == list(ol[ol != 0]) and list(tids[: nt.value]) == list(il[il != 0])
