@@ -57,8 +57,9 @@ struct wfst_graph {
   std::vector<int32_t> ilabel_host;  // original ilabels (re-mapped when tid2pdf changes)
   DevBuf<uint2> state_info;
   DevBuf<int4> arcs;
-  DevBuf<int32_t> arc_ilabel, arc_olabel, arc_src;
-  uint32_t start_flags = 0;
+  DevBuf<int32_t> arc_ilabel, arc_olabel, arc_src, eps_target_state;
+  uint32_t start_eps = 0;
+  int32_t n_eps_targets = 0;
   GraphDev view() const {
     GraphDev g;
     g.state_info = state_info.p;
@@ -66,7 +67,9 @@ struct wfst_graph {
     g.arc_ilabel = arc_ilabel.p;
     g.arc_olabel = arc_olabel.p;
     g.arc_src = arc_src.p;
-    g.start_flags = start_flags;
+    g.eps_target_state = eps_target_state.p;
+    g.start_eps = start_eps;
+    g.n_eps_targets = n_eps_targets;
     g.start = start;
     g.final_state = final_state;
     g.n_states = n_states;
@@ -79,6 +82,7 @@ struct wfst_graph {
     arc_ilabel.release();
     arc_olabel.release();
     arc_src.release();
+    eps_target_state.release();
   }
 };
 
@@ -92,9 +96,10 @@ struct wfst_decoder {
   DecoderDev D;
   DevBuf<ChanCtl> ctl;
   DevBuf<int4> tok;
-  DevBuf<int32_t> frame_off, bucket_cnt, eps_keys, eps_toki, eps_occ_list, target, chan_list;
+  DevBuf<int32_t> frame_off, bucket_cnt, eps_toki, eps_occ_list, eps_won_list, target, chan_list;
   DevBuf<int4> bucket, worklist;
   DevBuf<FrameCtl> fctl;
+  DevBuf<unsigned long long> dbg_t;
   DevBuf<int32_t> tile_chan;
   std::vector<int> gpar;  // step parity per group (persists across advance calls)
   int expand_wgs = 2048;
@@ -151,9 +156,9 @@ struct wfst_decoder {
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
-    ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); eps_keys.release();
-    eps_toki.release(); eps_occ_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); fctl.release(); tile_chan.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
+    ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
+    eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
+    bucket.release(); fctl.release(); dbg_t.release(); tile_chan.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
     bp_ac.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -244,6 +249,7 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
   std::vector<int32_t> h_il((size_t)n_arcs), h_ol((size_t)n_arcs);
   std::vector<uint32_t> h_flags((size_t)n_states, 0u);
   if ((uint32_t)n_arcs >= kNoArc) return fail(WFST_E_FORMAT, "graphs of 2^30 arcs or more are not supported");
+  std::vector<uint8_t> is_target((size_t)n_states, 0);
   int64_t off = 0;
   for (int32_t s = 0; s < n_states; ++s) {
     const uint32_t na = states[s].num_arcs, ne = states[s].niepsilons;
@@ -258,13 +264,21 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
       h_src[off + i] = (int32_t)((uint32_t)s | (i < ne ? 0x80000000u : 0u));
       h_il[off + i] = a.ilabel;
       h_ol[off + i] = a.olabel;
-      if (i < ne) h_flags[a.nextstate] |= kFlagEpsTarget;
+      if (i < ne) is_target[a.nextstate] = 1;
     }
     if (ne) h_flags[s] |= kFlagOutEps;
     h_si[s] = make_uint2((uint32_t)off, ((na - ne) << kEpsBits) | ne);
     off += na;
   }
   if (off != n_arcs) return fail(WFST_E_FORMAT, "sum of num_arcs != total_arcs");
+  // next_eps word per state: bit 31 = has outgoing epsilon arcs, bits 30..0 = 1 + ordinal among
+  // the epsilon-target states (the index of the state's slot in every channel's epsilon table)
+  std::vector<int32_t> h_targets;
+  for (int32_t st = 0; st < n_states; ++st)
+    if (is_target[st]) {
+      h_targets.push_back(st);
+      h_flags[st] |= (uint32_t)h_targets.size();
+    }
 
   wfst_graph *g = new wfst_graph();
   g->device = device;
@@ -273,11 +287,12 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
   g->n_states = n_states;
   g->n_arcs = n_arcs;
   g->ilabel_host.swap(h_il);
-  g->start_flags = h_flags[start];
+  g->start_eps = h_flags[start];
+  g->n_eps_targets = (int32_t)h_targets.size();
   hipError_t e;
   if ((e = g->state_info.alloc(n_states)) != hipSuccess || (e = g->arcs.alloc(n_arcs)) != hipSuccess ||
       (e = g->arc_ilabel.alloc(n_arcs)) != hipSuccess || (e = g->arc_olabel.alloc(n_arcs)) != hipSuccess ||
-      (e = g->arc_src.alloc(n_arcs)) != hipSuccess) {
+      (e = g->arc_src.alloc(n_arcs)) != hipSuccess || (e = g->eps_target_state.alloc(h_targets.size())) != hipSuccess) {
     delete g;
     return fail(WFST_E_DEVICE, std::string("hipMalloc(graph): ") + hipGetErrorString(e));
   }
@@ -285,6 +300,7 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
   if (hipMemcpy(g->state_info.p, h_si.data(), h_si.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(g->arc_src.p, h_src.data(), h_src.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(g->arc_olabel.p, h_ol.data(), h_ol.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      (!h_targets.empty() && hipMemcpy(g->eps_target_state.p, h_targets.data(), h_targets.size() * 4, hipMemcpyHostToDevice) != hipSuccess) ||
       hipMemcpy(g->arc_ilabel.p, g->ilabel_host.data(), g->ilabel_host.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(WFST_E_DEVICE, "hipMemcpy(graph) failed");
   if (rc == WFST_OK) rc = upload_arcs(g, states, arcs, nullptr, 0, &h_flags);
@@ -335,7 +351,7 @@ int wfst_graph_info(const wfst_graph *g, int32_t *start, int32_t *final_state, i
   if (n_arcs) *n_arcs = g->n_arcs;
   if (device_bytes)
     *device_bytes = (int64_t)(g->state_info.bytes() + g->arcs.bytes() + g->arc_ilabel.bytes() +
-                              g->arc_olabel.bytes() + g->arc_src.bytes());
+                              g->arc_olabel.bytes() + g->arc_src.bytes() + g->eps_target_state.bytes());
   return WFST_OK;
 }
 
@@ -378,8 +394,6 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   while (log2part > 0 && (int64_t)lds_slots << (log2part - 1) >= 4 * M) --log2part;  // tiny limits: fewer parts
   const int n_part = 1 << log2part;
   const int64_t bucket_cap = std::max<int64_t>(2048, 8 * M / n_part);
-  int log2ecap = 6;
-  while ((1ll << log2ecap) < 2 * M) ++log2ecap;
 
   wfst_decoder *d = new wfst_decoder();
   d->graph = g;
@@ -395,7 +409,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
     }
     d->own_stream = true;
   }
-  const size_t B = (size_t)n_channels, ecap = (size_t)1 << log2ecap;
+  const size_t B = (size_t)n_channels, ecap = (size_t)std::max(1, g->n_eps_targets);
   const size_t fo = (size_t)L.max_frames + 2;
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -405,13 +419,14 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   A(d->cutoff_hist.alloc(B * fo));
   A(d->bucket.alloc(B * (size_t)n_part * (size_t)bucket_cap));
   A(d->bucket_cnt.alloc(B * (size_t)n_part));
-  A(d->eps_keys.alloc(B * ecap));
   A(d->eps_vals.alloc(B * ecap));
   A(d->eps_toki.alloc(B * ecap));
-  A(d->eps_occ_list.alloc(B * ecap));
+  A(d->eps_occ_list.alloc(B * (size_t)L.max_tokens_per_frame));
+  A(d->eps_won_list.alloc(B * (size_t)L.max_tokens_per_frame));
   A(d->worklist.alloc(B * 2 * (size_t)L.max_tokens_per_frame));
   const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 256 + 2);
   A(d->fctl.alloc(8));
+  A(d->dbg_t.alloc(64));
   A(d->tile_chan.alloc(8 * tile_cap));
   A(d->target.alloc(B));
   A(d->chan_list.alloc(B));
@@ -423,7 +438,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   if (e == hipSuccess) A(hipMemsetAsync(d->ctl.p, 0, d->ctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->bucket_cnt.p, 0, d->bucket_cnt.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->fctl.p, 0, d->fctl.bytes(), d->stream));
-  if (e == hipSuccess) A(hipMemsetAsync(d->eps_keys.p, 0xFF, d->eps_keys.bytes(), d->stream));
+  if (e == hipSuccess) A(hipMemsetAsync(d->dbg_t.p, 0, d->dbg_t.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->eps_vals.p, 0xFF, d->eps_vals.bytes(), d->stream));
   if (e == hipSuccess && lds_slots * 12 > 65536) A((hipError_t)insert_kernel_set_lds(lds_slots * 12));
 
@@ -442,12 +457,13 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.cutoff_hist = d->cutoff_hist.p;
   D.bucket = d->bucket.p;
   D.bucket_cnt = d->bucket_cnt.p;
-  D.eps_keys = d->eps_keys.p;
   D.eps_vals = d->eps_vals.p;
   D.eps_toki = d->eps_toki.p;
   D.eps_occ_list = d->eps_occ_list.p;
+  D.eps_won_list = d->eps_won_list.p;
   D.worklist = d->worklist.p;
   D.fctl = d->fctl.p;
+  D.dbg_t = d->dbg_t.p;
   D.tile_chan = d->tile_chan.p;
   D.tile_cap = (int32_t)tile_cap;
   D.ll_base = d->ll_base.p;
@@ -459,7 +475,6 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.log2lds = log2lds;
   D.bucket_cap = (int32_t)bucket_cap;
   D.ecap = (int32_t)ecap;
-  D.log2ecap = log2ecap;
   D.max_tok = L.max_tokens_per_frame;
   D.wl_cap = L.max_tokens_per_frame;
   D.max_frames = L.max_frames;
@@ -495,7 +510,23 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   return WFST_OK;
 }
 
-void wfst_decoder_free(wfst_decoder *d) { delete d; }
+void wfst_decoder_free(wfst_decoder *d) {
+  if (d && (d->D.dbg & 96)) {  // debug phase timers (100 MHz ticks)
+    unsigned long long t[64];
+    (void)hipSetDevice(d->device);
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(t, d->dbg_t.p, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
+      const char *names[] = {"closure:setup", "closure:rounds", "closure:commit", "closure:clear", "closure:finalize", "closure:prep",
+                             "insert:init", "insert:pass1", "insert:alloc", "insert:pass2", "insert:tail"};
+      for (int k = 0; k < 11; ++k)
+        if (t[3 * k + 2])
+          fprintf(stderr, "[wfst dbg] %-18s n=%llu mean=%.2f us max=%.2f us\n", names[k], t[3 * k + 2],
+                  0.01 * t[3 * k] / t[3 * k + 2], 0.01 * t[3 * k + 1]);
+      fprintf(stderr, "[wfst dbg] closure rounds total=%llu launches*chan=%llu max_seeds=%llu\n", t[40], t[41], t[42]);
+    }
+  }
+  delete d;
+}
 
 // Resolve a channel list: returns the device pointer to use (nullptr = all channels) and count.
 static int stage_channels(wfst_decoder *d, const int32_t *channels, int32_t n, const int32_t **dev, int32_t *cnt) {

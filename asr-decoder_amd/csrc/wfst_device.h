@@ -15,11 +15,13 @@ namespace wfst {
 // ---- graph in HBM: CSR -------------------------------------------------------------------
 // state_info[s] = {arc_begin, (n_emit << 12) | n_eps}: one 8-byte load gives both arc ranges of
 //   a state: epsilon arcs [arc_begin, arc_begin+n_eps), emitting arcs the n_emit after them.
-// arcs[a]       = {ll_col, next_flags, weight bits, nextstate}: 16-byte AoS, one dwordx4 per lane.
+// arcs[a]       = {ll_col, next_eps, weight bits, nextstate}: 16-byte AoS, one dwordx4 per lane.
 //   ll_col      log-likelihood column of the arc's ilabel (tid2pdf applied at upload), -1 for an
 //               input-epsilon arc;
-//   next_flags  kFlagOutEps / kFlagEpsTarget of NEXTSTATE (so a new token knows, without touching
-//               state_info, whether the epsilon closure has to look at it).
+//   next_eps    what the epsilon closure needs to know about NEXTSTATE without touching
+//               state_info: bit 31 = it has outgoing epsilon arcs; bits 30..0 = 1 + its ordinal
+//               among the graph's epsilon-TARGET states (0 = no epsilon arc enters it).
+// eps_target_state[k] = state id of epsilon-target ordinal k (n_eps_targets of them).
 // arc_ilabel[a], arc_olabel[a] = labels for output (cold: traceback only).
 // arc_src[a]    = source state of arc a, bit 31 set for an input-epsilon arc.
 struct GraphDev {
@@ -28,8 +30,10 @@ struct GraphDev {
   const int32_t *arc_ilabel;
   const int32_t *arc_olabel;
   const int32_t *arc_src;
+  const int32_t *eps_target_state;
   int32_t start, final_state, n_states, n_arcs;
-  uint32_t start_flags;
+  uint32_t start_eps;   // next_eps word of the start state
+  int32_t n_eps_targets;
 };
 
 constexpr int kEpsBits = 12;
@@ -37,9 +41,15 @@ constexpr uint32_t kEpsMask = (1u << kEpsBits) - 1;
 constexpr uint32_t kFlagOutEps = 0x80000000u;     // state has outgoing input-epsilon arcs
 constexpr uint32_t kFlagEpsTarget = 0x40000000u;  // some input-epsilon arc enters the state
 constexpr uint32_t kFlagMask = kFlagOutEps | kFlagEpsTarget;
+constexpr uint32_t kEpsWon = 0x80000000u;         // in a packed eps-table value: won by an epsilon arc
+// token/record flag bits from an arc's next_eps word
+__host__ __device__ inline uint32_t flags_of(uint32_t next_eps) {
+  return (next_eps & kFlagOutEps) | ((next_eps & 0x7FFFFFFFu) ? kFlagEpsTarget : 0u);
+}
 constexpr uint32_t kArcMask = ~kFlagMask;          // arc indices are < 2^30
 constexpr uint32_t kNoArc = kArcMask;              // "no arc" (root token), flags kept beside it
 constexpr int32_t kEmptyKey = -1;
+constexpr int32_t kPrevUnresolved = -3;  // token won by an epsilon arc: backpointer found at traceback
 constexpr unsigned long long kEmptyVal = ~0ull;
 
 // error bits (ChanCtl::error)
@@ -84,8 +94,9 @@ struct FrameCtl {
 //   bucket[c][P][bucket_cap]    int4 candidate records {nextstate, cost bits, source token,
 //                               arc | flags(nextstate)}, partition = top bits of hash(nextstate)
 //   bucket_cnt[c][P]
-//   eps table (global, small working set): eps_keys/vals/toki[c][ecap], eps_occ_list[c][ecap]:
-//                               only tokens whose state has or receives epsilon arcs
+//   eps table, direct mapped: eps_vals[c][K] (orderable cost << 32 | kEpsWon? | arc) and
+//                               eps_toki[c][K] indexed by the epsilon-target ordinal of a state,
+//                               eps_occ_list[c][...] = ordinals touched this frame (for clearing)
 //   worklist[c][2][wl_cap]      epsilon-closure frontiers (slots of the eps table)
 struct DecoderDev {
   GraphDev g;
@@ -95,10 +106,10 @@ struct DecoderDev {
   float *cutoff_hist;
   int4 *bucket;
   int32_t *bucket_cnt;
-  int32_t *eps_keys;
   unsigned long long *eps_vals;
   int32_t *eps_toki;
-  int32_t *eps_occ_list;
+  int32_t *eps_occ_list;        // [c][wl_cap] ordinals touched this frame
+  int32_t *eps_won_list;        // [c][wl_cap] ordinals whose token an epsilon arc won this frame
   int4 *worklist;               // [c][2][wl_cap] {eps-table slot, state, cost bits, 0}
   FrameCtl *fctl;               // [n_groups]
   int32_t *tile_chan;           // [n_groups][tile_cap] channel of each 256-token tile of the coming frame
@@ -109,7 +120,7 @@ struct DecoderDev {
   int32_t n_part, log2part;     // hash partitions per channel (power of two, <= 64)
   int32_t lds_slots, log2lds;   // LDS hash slots per partition workgroup (4096 or 8192)
   int32_t bucket_cap;           // records per bucket
-  int32_t ecap, log2ecap;       // global (fallback) epsilon-table slots (power of two)
+  int32_t ecap;                 // = n_eps_targets (entries of eps_vals / eps_toki per channel)
   int32_t max_tok;              // tokens per frame
   int32_t wl_cap;
   int32_t max_frames;
@@ -117,6 +128,7 @@ struct DecoderDev {
   // config (LatticeFasterDecoderConfig)
   float beam, lattice_beam, beam_delta;
   int32_t max_active, min_active, prune_interval;
+  unsigned long long *dbg_t;  // [64] phase timers (WFST_DBG & 32): sums, maxima, counts
   int32_t dbg;  // WFST_DBG ablation bits (timing experiments only; results are wrong when set)
 };
 

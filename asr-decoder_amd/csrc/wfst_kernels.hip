@@ -71,33 +71,15 @@ __device__ __forceinline__ uint32_t lds_slot_of(uint32_t h, int log2part, int lo
   return (h >> (32 - log2part - log2lds)) & ((1u << log2lds) - 1u);
 }
 
-// ---- global epsilon table (open addressing, linear probing) ------------------------------
-__device__ __forceinline__ int eps_find_or_insert(int32_t *keys, int cap, int log2cap, int32_t state, bool *created) {
-  uint32_t slot = hash32(state) >> (32 - log2cap);
-  const uint32_t mask = (uint32_t)cap - 1;
-  *created = false;
-  for (int p = 0; p < cap; ++p) {
-    int32_t k = ld_agent(&keys[slot]);
-    if (k == state) return (int)slot;
-    if (k == kEmptyKey) {
-      int32_t old = atomicCAS(&keys[slot], kEmptyKey, state);
-      if (old == kEmptyKey) { *created = true; return (int)slot; }
-      if (old == state) return (int)slot;
-    }
-    slot = (slot + 1) & mask;
-  }
-  return -1;
-}
-__device__ __forceinline__ int eps_find(const int32_t *keys, int cap, int log2cap, int32_t state) {
-  uint32_t slot = hash32(state) >> (32 - log2cap);
-  const uint32_t mask = (uint32_t)cap - 1;
-  for (int p = 0; p < cap; ++p) {
-    int32_t k = ld_agent(&keys[slot]);
-    if (k == state) return (int)slot;
-    if (k == kEmptyKey) return -1;
-    slot = (slot + 1) & mask;
-  }
-  return -1;
+// debug phase timers (WFST_DBG & 32): slot k accumulates {sum, max, count} of 100 MHz ticks
+__device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned long long &t_prev) {
+  if (!(D.dbg & (k >= 6 ? 64 : 32))) return;
+  const unsigned long long now = wall_clock64();
+  const unsigned long long dt = now - t_prev;
+  atomicAdd(&D.dbg_t[3 * k], dt);
+  atomicMax(&D.dbg_t[3 * k + 1], dt);
+  atomicAdd(&D.dbg_t[3 * k + 2], 1ull);
+  t_prev = now;
 }
 
 // =========================================================================================
@@ -199,7 +181,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
           const int4 arc = D.g.arcs[a];
           const float ac_cost = -llrow[arc.x];                         // base-inl.h:326
           tot[k] = (s_cost[lo] + ac_cost) + __int_as_float(arc.z);      // base-inl.h:329
-          rec[k] = make_int4(arc.w, __float_as_int(tot[k]), tok0 + lo, (int)((uint32_t)a | (uint32_t)arc.y));
+          rec[k] = make_int4(arc.w, __float_as_int(tot[k]), tok0 + lo, (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
           tmin = fminf(tmin, tot[k]);
         }
       }
@@ -310,10 +292,9 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   const uint32_t mask = (uint32_t)SL - 1;
   const int base = ctl->front_begin + ctl->front_count;
   int4 *tok = D.tok + (size_t)c * D.arena_cap;
-  int32_t *ekeys = D.eps_keys + (size_t)c * D.ecap;
   u64 *evals = D.eps_vals + (size_t)c * D.ecap;
   int32_t *etoki = D.eps_toki + (size_t)c * D.ecap;
-  int32_t *eocc = D.eps_occ_list + (size_t)c * D.ecap;
+  int32_t *eocc = D.eps_occ_list + (size_t)c * D.wl_cap;
   int4 *wl = D.worklist + (size_t)c * 2 * D.wl_cap;
   u64 *occ_wl = reinterpret_cast<u64 *>(&ctl->eps_occ);  // {eps_occ, wl_n} bumped by one atomic
 
@@ -323,11 +304,13 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   if (sub_shift < 0) { if (tid == 0) { atomicOr(&ctl->error, kErrTableFull); *cntp = 0; } return; }
 
   u64 best = ~0ull;
+  unsigned long long tq = wall_clock64();
   for (int sub = 0; sub < (1 << log2sub); ++sub) {
     __syncthreads();
     for (int i = tid; i < SL; i += kInsertThreads) { keys[i] = kEmptyKey; vals[i] = kEmptyVal; }
     if (tid == 0) { s_nstates = 0; s_wpos = 0; s_ok = 1; }
     __syncthreads();
+    if (tid == 0) dbg_phase(D, 6, tq);
 
     // pass 1: insert-or-min.  Candidates that lost against the final cutoff are dropped here: the
     // reference keeps those order-dependent extras (base-inl.h:330) but never expands them.
@@ -359,6 +342,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
       }
     }
     __syncthreads();
+    if (tid == 0) dbg_phase(D, 7, tq);
     const int ns = s_nstates;
     if (tid == 0) {
       int g = atomicAdd(&ctl->new_count, ns);
@@ -368,6 +352,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
     }
     __syncthreads();
     if (!s_ok) break;
+    if (tid == 0) dbg_phase(D, 8, tq);
     const int gpos = s_gpos;
 
     // pass 2: the record that won its state writes the token
@@ -409,35 +394,36 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
           const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
           best = b < best ? b : best;
         }
-        // states with epsilon arcs in or out must be findable by the closure
-        const bool fl = winner && flags;
-        const u64 fm = __ballot(fl);
-        if (!fm) continue;
-        const bool seed = fl && (flags & kFlagOutEps);
-        const u64 sm = __ballot(seed);
+        // a token on an epsilon-TARGET state registers itself in the channel's direct-mapped
+        // epsilon table (so an epsilon arc arriving later meets its cost); a token with epsilon
+        // arcs OUT seeds the closure worklist
+        const bool tgt = winner && (flags & kFlagEpsTarget);
+        const bool seed = winner && (flags & kFlagOutEps);
+        const u64 tm = __ballot(tgt), sm = __ballot(seed);
+        if (!(tm | sm)) continue;
         u64 ob = 0;
-        if (lane == 0) ob = atomicAdd(occ_wl, (u64)__popcll(fm) | ((u64)__popcll(sm) << 32));
+        if (lane == 0) ob = atomicAdd(occ_wl, (u64)__popcll(tm) | ((u64)__popcll(sm) << 32));
         ob = __shfl(ob, 0, 64);
-        if (fl) {
-          bool created;
-          const int es = eps_find_or_insert(ekeys, D.ecap, D.log2ecap, r[k].x, &created);
-          const int op = (int)(uint32_t)ob + lane_rank(fm);
-          if (es < 0 || op >= D.ecap) atomicOr(&ctl->error, kErrTableFull);
-          else {
-            evals[es] = packed;
-            etoki[es] = idx;
-            eocc[op] = es;
-            if (seed) {
-              const int wp = (int)(ob >> 32) + lane_rank(sm);
-              if (wp < D.wl_cap) wl[wp] = make_int4(es, r[k].x, r[k].y, 0);
-              else atomicOr(&ctl->error, kErrWorklistFull);
-            }
-          }
+        if (tgt) {
+          const uint32_t arc = (uint32_t)r[k].w & kArcMask;
+          const int ord = (int)((uint32_t)D.g.arcs[arc].y & 0x7FFFFFFFu) - 1;
+          const int op = (int)(uint32_t)ob + lane_rank(tm);
+          if (op < D.wl_cap) {
+            evals[ord] = (packed & 0xFFFFFFFF00000000ull) | arc;
+            etoki[ord] = idx;
+            eocc[op] = ord;
+          } else atomicOr(&ctl->error, kErrWorklistFull);
+        }
+        if (seed) {
+          const int wp = (int)(ob >> 32) + lane_rank(sm);
+          if (wp < D.wl_cap) wl[wp] = make_int4(0, r[k].x, r[k].y, 0);
+          else atomicOr(&ctl->error, kErrWorklistFull);
         }
       }
     }
   }
   __syncthreads();
+  if (tid == 0) dbg_phase(D, 9, tq);
   if (tid == 0) *cntp = 0;  // bucket consumed
   best = wave_min_u64(best);
   if (lane == 0) s_best[wave] = best;
@@ -446,6 +432,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
     u64 b = s_best[0];
     for (int w = 1; w < kInsertThreads / 64; ++w) b = s_best[w] < b ? s_best[w] : b;
     if (b != ~0ull) atomicMin(&ctl->best_next, b);
+    dbg_phase(D, 10, tq);
   }
 }
 
@@ -454,12 +441,14 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
 // =========================================================================================
 constexpr int kBT = 1024;
 constexpr int kBW = kBT / 64;
+constexpr int kClosureUnroll = 4;
 
 struct BoundaryShared {
   int nnew;       // tokens of the frame being built (continues ChanCtl::new_count)
   int wl_n[2];
   int err;
-  int occ;        // occupied slots of the epsilon table (continues ChanCtl::eps_occ)
+  int occ;        // epsilon-table entries touched this frame (continues ChanCtl::eps_occ)
+  int nwon;       // tokens won by an epsilon arc this frame
   float redf[kBW];
   u64 red64[kBW];
   u64 best;
@@ -468,61 +457,84 @@ struct BoundaryShared {
   int active;
 };
 
-// ProcessNonemitting to its fixpoint (base-inl.h:383-430) on the channel's epsilon table, then
-// rewrite the arena records of the tokens an epsilon arc created or improved.  On entry
+// ProcessNonemitting to its fixpoint (base-inl.h:383-430) on the channel's direct-mapped epsilon
+// table, then write the arena records of the tokens an epsilon arc created or improved.  On entry
 // sh.wl_n[0] seeds are in worklist[0], sh.wl_n[1] == 0, sh.nnew / sh.occ continue the counters.
 __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, u64 *nZ_out) {
   const int tid = threadIdx.x;
-  int32_t *keys = D.eps_keys + (size_t)c * D.ecap;
   u64 *vals = D.eps_vals + (size_t)c * D.ecap;
   int32_t *toki = D.eps_toki + (size_t)c * D.ecap;
-  int32_t *occ = D.eps_occ_list + (size_t)c * D.ecap;
+  int32_t *occ = D.eps_occ_list + (size_t)c * D.wl_cap;
+  int32_t *won = D.eps_won_list + (size_t)c * D.wl_cap;
   int4 *wl = D.worklist + (size_t)c * 2 * D.wl_cap;
   int4 *tok = D.tok + (size_t)c * D.arena_cap;
   u64 nZ = 0;
+  unsigned long long tq = wall_clock64();
+  if (tid == 0 && (D.dbg & 32)) { atomicAdd(&D.dbg_t[41], 1ull); atomicMax(&D.dbg_t[42], (unsigned long long)sh.wl_n[0]); }
+  if (tid == 0) sh.nwon = 0;
 
   int cur = 0;
   for (;;) {
     __syncthreads();
     const int nw = sh.wl_n[cur];
     if (nw == 0) break;
+    if (tid == 0 && (D.dbg & 32)) atomicAdd(&D.dbg_t[40], 1ull);
     const int4 *wl_cur = wl + (size_t)cur * D.wl_cap;
     int4 *wl_nxt = wl + (size_t)(cur ^ 1) * D.wl_cap;
-    for (int i = tid; i < nw; i += kBT) {
-      // entry = {table slot, state, cost when queued}; a later improvement of the same token
-      // queues another entry, so a stale cost only repeats work the atomicMin below rejects
-      const int4 ent = wl_cur[i];
-      const float cost = __int_as_float(ent.z);
-      if (!(cost < cutoff)) continue;  // base-inl.h:391
-      const int32_t state = ent.y;
-      const uint2 si = D.g.state_info[state];
-      const int neps = (int)(si.y & kEpsMask);
-      for (int e = 0; e < neps; ++e) {
-        const int a = (int)si.x + e;
-        const int4 arc = D.g.arcs[a];
-        nZ++;
-        const float tot = cost + __int_as_float(arc.z);  // base-inl.h:414
-        if (!(tot < cutoff)) continue;                    // base-inl.h:415
-        const uint32_t otot = f2o(tot);
-        const u64 packed = ((u64)otot << 32) | ((uint32_t)a | (uint32_t)arc.y);
-        bool created;
-        const int ds = eps_find_or_insert(keys, D.ecap, D.log2ecap, arc.w, &created);
-        if (ds < 0) { atomicOr(&sh.err, kErrTableFull); continue; }
-        if (created) {
-          const int op = atomicAdd(&sh.occ, 1);
-          if (op < D.ecap) occ[op] = ds;
-        }
-        const u64 old = atomicMin(&vals[ds], packed);
-        if (packed < old) {
-          if (old == kEmptyVal) {  // a state no emitting arc reached: new token
-            const int np = atomicAdd(&sh.nnew, 1);
-            atomicExch(&toki[ds], base + np);
-          }
-          // base-inl.h:425: re-queue when the cost changed and the state has epsilon arcs
-          if (otot < (uint32_t)(old >> 32) && ((uint32_t)arc.y & kFlagOutEps)) {
-            const int wp = atomicAdd(&sh.wl_n[cur ^ 1], 1);
-            if (wp < D.wl_cap) wl_nxt[wp] = make_int4(ds, arc.w, __float_as_int(tot), 0);
-            else atomicOr(&sh.err, kErrWorklistFull);
+    // four worklist entries per thread in flight (independent load chains issued together)
+    for (int i0 = 0; i0 < nw; i0 += kBT * kClosureUnroll) {
+      int4 ent[kClosureUnroll];
+      uint2 si[kClosureUnroll];
+      int4 arc0[kClosureUnroll];
+      bool live[kClosureUnroll];
+#pragma unroll
+      for (int k = 0; k < kClosureUnroll; ++k) {
+        const int i = i0 + k * kBT + tid;
+        live[k] = i < nw;
+        ent[k] = live[k] ? wl_cur[i] : make_int4(0, 0, 0x7F800000, 0);
+        // entry = {-, state, cost when queued}; a later improvement of the same token queues
+        // another entry, so a stale cost only repeats work the atomicMin below rejects
+        live[k] = live[k] && (__int_as_float(ent[k].z) < cutoff);  // base-inl.h:391
+      }
+#pragma unroll
+      for (int k = 0; k < kClosureUnroll; ++k) si[k] = live[k] ? D.g.state_info[ent[k].y] : make_uint2(0, 0);
+#pragma unroll
+      for (int k = 0; k < kClosureUnroll; ++k)
+        arc0[k] = (live[k] && (si[k].y & kEpsMask)) ? D.g.arcs[si[k].x] : make_int4(0, 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < kClosureUnroll; ++k) {
+        if (!live[k]) continue;
+        const float cost = __int_as_float(ent[k].z);
+        const int neps = (int)(si[k].y & kEpsMask);
+        for (int e = 0; e < neps; ++e) {
+          const int a = (int)si[k].x + e;
+          const int4 arc = e == 0 ? arc0[k] : D.g.arcs[a];
+          nZ++;
+          const float tot = cost + __int_as_float(arc.z);  // base-inl.h:414
+          if (!(tot < cutoff)) continue;                    // base-inl.h:415
+          const uint32_t otot = f2o(tot);
+          const int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;  // nextstate is an epsilon target
+          // FindOrAddToken (base-inl.h:88-136): one atomicMin on the state's own slot.  kEpsWon in
+          // the low word makes an emitting arc win an exact cost tie, as the reference's
+          // first-arrival rule does (emitting arcs are processed before the closure).
+          const u64 packed = ((u64)otot << 32) | kEpsWon | (uint32_t)a;
+          const u64 old = atomicMin(&vals[ord], packed);
+          if (packed < old) {
+            if (old == kEmptyVal) {  // a state no emitting arc reached: new token
+              toki[ord] = base + atomicAdd(&sh.nnew, 1);
+              const int op = atomicAdd(&sh.occ, 1);
+              if (op < D.wl_cap) occ[op] = ord; else atomicOr(&sh.err, kErrWorklistFull);
+            }
+            if (old == kEmptyVal || !((uint32_t)old & kEpsWon)) {  // first epsilon win of this token
+              const int wn = atomicAdd(&sh.nwon, 1);
+              if (wn < D.wl_cap) won[wn] = ord; else atomicOr(&sh.err, kErrWorklistFull);
+            }
+            // base-inl.h:425: re-queue when the cost changed and the state has epsilon arcs
+            if (otot < (uint32_t)(old >> 32) && ((uint32_t)arc.y & kFlagOutEps)) {
+              const int wp = atomicAdd(&sh.wl_n[cur ^ 1], 1);
+              if (wp < D.wl_cap) wl_nxt[wp] = make_int4(0, arc.w, __float_as_int(tot), 0);
+              else atomicOr(&sh.err, kErrWorklistFull);
+            }
           }
         }
       }
@@ -535,37 +547,38 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
     cur ^= 1;
   }
   __syncthreads();
-  int nocc = sh.occ;
-  if (nocc > D.ecap) nocc = D.ecap;
+  if (tid == 0) dbg_phase(D, 1, tq);
+  const int nocc = min(sh.occ, D.wl_cap), nwon = min(sh.nwon, D.wl_cap);
   const bool fits = sh.nnew <= D.max_tok && (int64_t)base + sh.nnew <= D.arena_cap;
   if (!fits && tid == 0) atomicOr(&sh.err, sh.nnew > D.max_tok ? kErrFrontierFull : kErrArenaFull);
-  // tokens whose winning arc is an epsilon arc: (re)write their arena record; clear the table
+  // Tokens won by an epsilon arc get their record here.  Their backpointer (the token of the arc's
+  // source state, on this same frame) is left as kPrevUnresolved: the traceback finds it by
+  // scanning the frame for that state -- a few epsilon hops per utterance instead of a dependent
+  // lookup chain per token on every frame's critical path.
   u64 best = ~0ull;
-  for (int i = tid; i < nocc; i += kBT) {
-    const int s = occ[i];
-    const u64 v = ld_agent(&vals[s]);
-    const uint32_t arc = (uint32_t)v & kArcMask;
-    if (arc != kNoArc && fits) {
-      const int32_t srci = D.g.arc_src[arc];
-      if (srci < 0) {
-        const int32_t state = ld_agent(&keys[s]);
-        const int idx = ld_agent(&toki[s]);
-        const int ss = eps_find(keys, D.ecap, D.log2ecap, srci & 0x7FFFFFFF);
-        const int prev = ss >= 0 ? ld_agent(&toki[ss]) : -2;
-        tok[idx] = make_int4(state, __float_as_int(o2f((uint32_t)(v >> 32))), prev, (int)(uint32_t)v);
-        const u64 b = (v & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
-        best = b < best ? b : best;
-      }
+  for (int i0 = 0; fits && i0 < nwon; i0 += kBT * kClosureUnroll) {
+    int od[kClosureUnroll];
+#pragma unroll
+    for (int k = 0; k < kClosureUnroll; ++k) {
+      const int i = i0 + k * kBT + tid;
+      od[k] = i < nwon ? won[i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < kClosureUnroll; ++k) {
+      if (od[k] < 0) continue;
+      const u64 v = ld_agent(&vals[od[k]]);
+      const int idx = ld_agent(&toki[od[k]]);
+      const int32_t state = D.g.eps_target_state[od[k]];
+      tok[idx] = make_int4(state, __float_as_int(o2f((uint32_t)(v >> 32))), kPrevUnresolved, (int)((uint32_t)v & kArcMask));
+      const u64 b = (v & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
+      best = b < best ? b : best;
     }
   }
   best = wave_min_u64(best);
   if ((tid & 63) == 0) sh.red64[tid >> 6] = best;
-  __syncthreads();  // every lookup above is done before the table is cleared
-  for (int i = tid; i < nocc; i += kBT) {
-    const int s = occ[i];
-    keys[s] = kEmptyKey;
-    vals[s] = kEmptyVal;
-  }
+  __syncthreads();  // every read of the table above is done before it is cleared
+  if (tid == 0) dbg_phase(D, 2, tq);
+  for (int i = tid; i < nocc; i += kBT) vals[occ[i]] = kEmptyVal;
   if (tid == 0) {
     u64 b = sh.red64[0];
     for (int w = 1; w < kBW; ++w) b = sh.red64[w] < b ? sh.red64[w] : b;
@@ -573,23 +586,27 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
   }
   *nZ_out = nZ;
   __syncthreads();
+  if (tid == 0) dbg_phase(D, 3, tq);
 }
 
 __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, BoundaryShared &sh) {
   const int tid = threadIdx.x, lane = tid & 63;
+  unsigned long long tq = wall_clock64();
   const int f = ctl->n_decoded;
   const float cutoff = o2f(ctl->bound);
   const int base = ctl->front_begin + ctl->front_count;
   if (tid == 0) {
     sh.nnew = ctl->new_count;
-    sh.occ = ctl->eps_occ;
+    sh.occ = ctl->eps_occ < D.wl_cap ? ctl->eps_occ : D.wl_cap;
     sh.wl_n[0] = ctl->wl_n < D.wl_cap ? ctl->wl_n : D.wl_cap;
     sh.wl_n[1] = 0;
     sh.err = 0;
   }
   __syncthreads();
+  if (tid == 0) dbg_phase(D, 0, tq);
   u64 nZ = 0;
   epsilon_closure(D, c, sh, base, cutoff, &nZ);
+  tq = wall_clock64();
   nZ = wave_sum_u64(nZ);
   if (lane == 0) sh.red64[tid >> 6] = nZ;
   __syncthreads();
@@ -616,6 +633,7 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
     ctl->wl_n = 0;
     ctl->active = 0;
     if (err) ctl->error |= err;
+    dbg_phase(D, 4, tq);
   }
   __syncthreads();
 }
@@ -656,6 +674,7 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
                            int group, int par) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float kInf = __builtin_huge_valf();
+  unsigned long long tq = wall_clock64();
   if (tid == 0) {
     int act = (ctl->n_decoded < target[c]) && ctl->error == 0 && !ctl->finalized;
     if (act && ctl->n_decoded >= D.max_frames) { ctl->error |= kErrFramesFull; act = 0; }
@@ -738,6 +757,7 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
   const int ntl = sh.active;
   int32_t *tile_chan = D.tile_chan + (size_t)group * D.tile_cap + sh.sel_k;
   for (int i = tid; i < ntl; i += kBT) tile_chan[i] = c;
+  if (tid == 0) dbg_phase(D, 5, tq);
 }
 
 __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_t *target, int do_prep, int chan_off,
@@ -758,11 +778,10 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
   const int c = chans ? chans[blockIdx.x] : blockIdx.x;
   const int tid = threadIdx.x;
   ChanCtl *ctl = D.ctl + c;
-  int32_t *keys = D.eps_keys + (size_t)c * D.ecap;
   u64 *vals = D.eps_vals + (size_t)c * D.ecap;
-  // the epsilon table is left empty by every closure; after an error it may not be
+  // every closure leaves the epsilon table empty; after an error it may not be
   if (ctl->error || ctl->eps_occ || ctl->active) {
-    for (int i = tid; i < D.ecap; i += kBT) { keys[i] = kEmptyKey; vals[i] = kEmptyVal; }
+    for (int i = tid; i < D.ecap; i += kBT) vals[i] = kEmptyVal;
   }
   for (int i = tid; i < D.n_part; i += kBT) D.bucket_cnt[(size_t)c * D.n_part + i] = 0;
   __syncthreads();
@@ -772,17 +791,16 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
     z.best_next = ~0ull;
     *ctl = z;
     sh.err = 0; sh.wl_n[0] = 0; sh.wl_n[1] = 0; sh.nnew = 1; sh.occ = 0; sh.best = ~0ull;
-    const uint32_t fl = D.g.start_flags;
+    const uint32_t ne = D.g.start_eps, fl = flags_of(ne);
     D.tok[(size_t)c * D.arena_cap] = make_int4(D.g.start, __float_as_int(0.0f), -1, (int)(kNoArc | fl));
-    if (fl) {
-      bool created;
-      const int es = eps_find_or_insert(keys, D.ecap, D.log2ecap, D.g.start, &created);
-      vals[es] = ((u64)f2o(0.0f) << 32) | (kNoArc | fl);
-      D.eps_toki[(size_t)c * D.ecap + es] = 0;
-      D.eps_occ_list[(size_t)c * D.ecap] = es;
+    if (fl & kFlagEpsTarget) {
+      const int ord = (int)(ne & 0x7FFFFFFFu) - 1;
+      vals[ord] = ((u64)f2o(0.0f) << 32) | kNoArc;
+      D.eps_toki[(size_t)c * D.ecap + ord] = 0;
+      D.eps_occ_list[(size_t)c * D.wl_cap] = ord;
       sh.occ = 1;
-      if (fl & kFlagOutEps) { D.worklist[(size_t)c * 2 * D.wl_cap] = make_int4(es, D.g.start, __float_as_int(0.0f), 0); sh.wl_n[0] = 1; }
     }
+    if (fl & kFlagOutEps) { D.worklist[(size_t)c * 2 * D.wl_cap] = make_int4(0, D.g.start, __float_as_int(0.0f), 0); sh.wl_n[0] = 1; }
   }
   __syncthreads();
   u64 nZ = 0;
@@ -839,27 +857,59 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   if (lane == 0) { s_all[wave] = best_all; s_fin[wave] = best_fin; }
   __syncthreads();
   int32_t *ch = chain + (size_t)bi * cap;
+  const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
+  __shared__ int s_t, s_need, s_lo, s_hi, s_found;
   if (tid == 0) {
     for (int w = 1; w < kBpThreads / 64; ++w) {
       best_all = s_all[w] < best_all ? s_all[w] : best_all;
       best_fin = s_fin[w] < best_fin ? s_fin[w] : best_fin;
     }
     const u64 best = (use_final && best_fin != ~0ull) ? best_fin : best_all;
-    int len = 0;
-    for (int t = (int)(uint32_t)best; t >= 0; t = tok[t].z) {
-      if (len < cap) ch[cap - 1 - len] = t;  // last hop first, packed against the end
-      ++len;
-    }
-    n_hops[bi] = len;
-    s_len = len;
+    s_t = (int)(uint32_t)best;
+    s_len = 0;
   }
+  // Walk the backpointer chain (last hop first, packed against the end of ch[]).  One thread
+  // follows resolved backpointers; a token won by an epsilon arc carries kPrevUnresolved and the
+  // whole workgroup scans its frame for the token of the arc's source state.
+  for (;;) {
+    __syncthreads();
+    const int t = s_t;
+    if (t < 0) break;
+    if (tid == 0) {
+      const int4 T = tok[t];
+      if (s_len < cap) ch[cap - 1 - s_len] = t;
+      ++s_len;
+      s_need = -1;
+      if (T.z == kPrevUnresolved) {
+        int lo = 0, hi = nd + 1;  // frame of t: frame_off[f] <= t < frame_off[f+1]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (foff[mid] <= t) lo = mid; else hi = mid;
+        }
+        s_lo = foff[lo];
+        s_hi = foff[lo + 1];
+        s_need = D.g.arc_src[(uint32_t)T.w & kArcMask] & 0x7FFFFFFF;
+        s_found = -1;
+      } else {
+        s_t = T.z;
+      }
+    }
+    __syncthreads();
+    if (s_need >= 0) {
+      const int need = s_need;
+      for (int i = s_lo + tid; i < s_hi; i += kBpThreads)
+        if (tok[i].x == need) s_found = i;
+      __syncthreads();
+      if (tid == 0) s_t = s_found;  // -1 (never expected) ends the walk
+    }
+  }
+  if (tid == 0) n_hops[bi] = s_len;
   __syncthreads();
   const int len = s_len;
   if (len > cap) return;
   int32_t *il = o_il + (size_t)bi * cap, *ol = o_ol + (size_t)bi * cap;
   float *og = o_g + (size_t)bi * cap, *oa = o_ac + (size_t)bi * cap;
   const float *cut = D.cutoff_hist + (size_t)c * (D.max_frames + 2);
-  const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
   const float *ll = D.ll_base[c];
   // forward links of frame f have met PruneForwardLinks iff a PruneActiveTokens pass started at
   // NumFramesDecoded() = m >= f+1 (base-inl.h:660-661, 445-476) or FinalizeDecoding ran
@@ -867,7 +917,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   for (int pos = tid; pos < len; pos += kBpThreads) {
     const int t = ch[cap - len + pos];
     const int4 T = tok[t];
-    const int prev = T.z;
+    const int prev = pos > 0 ? ch[cap - len + pos - 1] : -1;  // the chain itself holds the resolved backpointers
     if (prev < 0) {  // base-inl.h:1193-1198
       il[pos] = 0; ol[pos] = 0; og[pos] = 0.f; oa[pos] = 0.f;
       continue;
