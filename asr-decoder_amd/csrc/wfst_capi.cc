@@ -100,7 +100,8 @@ struct wfst_decoder {
   DevBuf<int4> bucket, worklist;
   DevBuf<FrameCtl> fctl;
   DevBuf<unsigned long long> dbg_t;
-  DevBuf<int32_t> tile_chan;
+  DevBuf<int32_t> tile_chan, items;
+  int insert_wgs = 768;
   std::vector<int> gpar;  // step parity per group (persists across advance calls)
   int expand_wgs = 2048;
   DevBuf<float> cutoff_hist;
@@ -158,7 +159,7 @@ struct wfst_decoder {
     if (p_ctl) (void)hipHostFree(p_ctl);
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); fctl.release(); dbg_t.release(); tile_chan.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
+    bucket.release(); fctl.release(); dbg_t.release(); items.release(); tile_chan.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
     bp_ac.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -388,7 +389,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   // hash partitions per channel: each insert workgroup owns an LDS table of lds_slots entries;
   // a bucket too full for it is handled in sub-passes, so these are speed knobs, not limits
   const int64_t M = L.max_tokens_per_frame;
-  int lds_slots = 1024, log2lds = 10, log2part = 6;
+  int lds_slots = 4096, log2lds = 12, log2part = 6;
   if (const char *e = getenv("WFST_LOG2_PARTS")) log2part = std::max(0, std::min(6, atoi(e)));
   if (const char *e = getenv("WFST_LOG2_LDS_SLOTS")) { log2lds = std::max(8, std::min(13, atoi(e))); lds_slots = 1 << log2lds; }
   while (log2part > 0 && (int64_t)lds_slots << (log2part - 1) >= 4 * M) --log2part;  // tiny limits: fewer parts
@@ -428,6 +429,8 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   A(d->fctl.alloc(8));
   A(d->dbg_t.alloc(64));
   A(d->tile_chan.alloc(8 * tile_cap));
+  const size_t item_cap = B * (size_t)n_part;
+  A(d->items.alloc(8 * item_cap));
   A(d->target.alloc(B));
   A(d->chan_list.alloc(B));
   A(d->ll_base.alloc(B));
@@ -466,6 +469,8 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.dbg_t = d->dbg_t.p;
   D.tile_chan = d->tile_chan.p;
   D.tile_cap = (int32_t)tile_cap;
+  D.items = d->items.p;
+  D.item_cap = (int32_t)item_cap;
   D.ll_base = d->ll_base.p;
   D.n_channels = n_channels;
   D.stride = 0;
@@ -474,6 +479,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.lds_slots = lds_slots;
   D.log2lds = log2lds;
   D.bucket_cap = (int32_t)bucket_cap;
+  D.joint_max = getenv("WFST_JOINT_MAX") ? atoi(getenv("WFST_JOINT_MAX")) : 1536;
   D.ecap = (int32_t)ecap;
   D.max_tok = L.max_tokens_per_frame;
   D.wl_cap = L.max_tokens_per_frame;
@@ -505,6 +511,8 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
     if (ge != hipSuccess) { delete d; return fail(WFST_E_DEVICE, "stream/event creation failed"); }
   }
   if (const char *tp = getenv("WFST_EXPAND_WGS")) { if (atoi(tp) > 0) d->expand_wgs = atoi(tp); }
+  if (const char *tp = getenv("WFST_INSERT_WGS")) { if (atoi(tp) > 0) d->insert_wgs = atoi(tp); }
+  if (n_channels > 65535) { delete d; return fail(WFST_E_ARG, "at most 65535 channels per decoder"); }
   d->gpar.assign(8, 0);
   *out = d;
   return WFST_OK;
@@ -642,7 +650,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
       timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });  // GetCutoff + seed only
       for (int s = 0; s < gsteps[g]; ++s) {
         timed(0, st, [&] { launch_expand(d->D, g, par, d->expand_wgs, st); });
-        timed(1, st, [&] { launch_insert(d->D, off, cnt, g, par, st); });
+        timed(1, st, [&] { launch_insert(d->D, off, cnt, g, par, d->insert_wgs, st); });
         timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, s + 1 < gsteps[g], g, par ^ 1, st); });
         par ^= 1;
       }

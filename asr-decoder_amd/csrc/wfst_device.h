@@ -82,7 +82,9 @@ static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
 struct FrameCtl {
   int32_t total_tiles[2];  // tiles published by prep_frame for the step of that parity
   int32_t ticket[2];       // dynamic tile dispenser of expand_kernel
-  int32_t pad[12];
+  int32_t n_items[2];      // insert work items listed by plan_kernel
+  int32_t item_ticket[2];  // dynamic item dispenser of insert_kernel
+  int32_t pad[8];
 };
 
 // ---- decoder (batch of channels) ---------------------------------------------------------
@@ -114,12 +116,15 @@ struct DecoderDev {
   FrameCtl *fctl;               // [n_groups]
   int32_t *tile_chan;           // [n_groups][tile_cap] channel of each 256-token tile of the coming frame
   int32_t tile_cap;
+  int32_t *items;               // [n_groups][item_cap] channel << 16 | first partition << 8 | group size
+  int32_t item_cap;
   const float *const *ll_base;  // [n_channels] device pointers to row 0 of each utterance matrix
   int32_t n_channels;
   int32_t stride;               // floats per log-likelihood row
   int32_t n_part, log2part;     // hash partitions per channel (power of two, <= 64)
   int32_t lds_slots, log2lds;   // LDS hash slots per partition workgroup (4096 or 8192)
   int32_t bucket_cap;           // records per bucket
+  int32_t joint_max;            // insert: most records a group of partitions may hold to share one workgroup
   int32_t ecap;                 // = n_eps_targets (entries of eps_vals / eps_toki per channel)
   int32_t max_tok;              // tokens per frame
   int32_t wl_cap;
@@ -135,7 +140,8 @@ struct DecoderDev {
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s);
-void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, hipStream_t s);
+void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups,
+                   hipStream_t s);  // plan + insert
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int do_prep,
                     int group, int par, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);

@@ -74,6 +74,7 @@ __device__ __forceinline__ uint32_t lds_slot_of(uint32_t h, int log2part, int lo
 // debug phase timers (WFST_DBG & 32): slot k accumulates {sum, max, count} of 100 MHz ticks
 __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned long long &t_prev) {
   if (!(D.dbg & (k >= 6 ? 64 : 32))) return;
+  if (k >= 6 && (blockIdx.y & 31) != 0) return;  // sample 1/32 of the insert workgroups
   const unsigned long long now = wall_clock64();
   const unsigned long long dt = now - t_prev;
   atomicAdd(&D.dbg_t[3 * k], dt);
@@ -258,34 +259,109 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
 // A bucket whose records could overfill the LDS table is processed in 2^k sub-passes, each
 // taking the states of one sub-hash class (records >= distinct states, so the test is safe).
 // =========================================================================================
-constexpr int kInsertThreads = 256;
+constexpr int kInsertThreads = 512;
 constexpr int kInsertUnroll = 4;
 
-__global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, int chan_off, int group, int par) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int c = blockIdx.x + chan_off, p = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x == 0 && p == 0 && tid == 0) {  // the tile list of the previous frame is consumed
-    D.fctl[group].total_tiles[par ^ 1] = 0;
-    D.fctl[group].ticket[par ^ 1] = 0;
+// Which buckets share a workgroup?  Partitions of a light channel hold a few dozen records each;
+// the largest aligned group of 64 / 16 / 4 partitions whose records fit ONE pass of a small LDS
+// table becomes one work item, so a light channel costs 1-4 items while a heavy channel keeps all
+// of its partitions separate.  Returns the group of partition p: {first partition, size, records}.
+__device__ __forceinline__ void partition_group(int P, int joint_max, int p, int ps /*inclusive prefix of counts, per lane*/,
+                                                int cnt_p, int *g0, int *G, int *n) {
+  *G = 1; *g0 = p; *n = cnt_p;
+  for (int cand = P; cand >= 4; cand >>= 2) {
+    const int s0 = p & ~(cand - 1);
+    const int tot = __shfl(ps, s0 + cand - 1, 64) - (s0 ? __shfl(ps, s0 - 1, 64) : 0);
+    if (tot <= joint_max) { *G = cand; *g0 = s0; *n = tot; return; }
   }
-  ChanCtl *ctl = D.ctl + c;
-  if (!ctl->active) return;
+}
+
+// plan_kernel: one wave per channel lists the insert work items of the frame: item =
+// channel << 16 | first partition << 8 | group size.  grid ceil(chan_cnt / 4) x 256.
+__global__ __launch_bounds__(256) void plan_kernel(DecoderDev D, int chan_off, int chan_cnt, int group, int par) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  FrameCtl *fc = D.fctl + group;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // lists of the previous step are consumed
+    fc->total_tiles[par ^ 1] = 0;
+    fc->ticket[par ^ 1] = 0;
+    fc->n_items[par ^ 1] = 0;
+    fc->item_ticket[par ^ 1] = 0;
+  }
+  const int ci = blockIdx.x * 4 + wave;
+  if (ci >= chan_cnt) return;
+  const int c = chan_off + ci;
+  if (!D.ctl[c].active) return;
+  const int P = D.n_part;
+  const int32_t *cnts = D.bucket_cnt + (size_t)c * P;
+  const int cnt = (lane < P) ? min(cnts[lane], D.bucket_cap) : 0;
+  int ps = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int v = __shfl_up(ps, off, 64);
+    if (lane >= off) ps += v;
+  }
+  int g0, G, n;
+  partition_group(P, min(D.joint_max, (D.lds_slots * 3) >> 2), lane < P ? lane : 0, ps, cnt, &g0, &G, &n);
+  const bool leader = lane < P && g0 == lane && n > 0;
+  const u64 m = __ballot(leader);
+  if (!m) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&fc->n_items[par], __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (leader) {
+    const int idx = base + lane_rank(m);
+    if (idx < D.item_cap) D.items[(size_t)group * D.item_cap + idx] = (c << 16) | (g0 << 8) | G;
+  }
+}
+
+// insert_kernel: a fixed grid of workgroups pulls the planned items (first gridDim.x statically,
+// then by ticket); 256 threads, dynamic LDS = lds_slots * 12 bytes.
+__global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, int group, int par) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int SLmax = D.lds_slots;
   u64 *vals = reinterpret_cast<u64 *>(smem);
   int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)SLmax * 8);
-  __shared__ int s_nstates, s_gpos, s_wpos, s_ok;
-  __shared__ u64 s_best[kInsertThreads / 64];
-
+  // one struct, a multiple of 16 bytes, so the dynamic LDS region behind it stays 16-byte aligned
+  // (64-bit LDS atomics on a misaligned table are replayed: cdna_hip_programming.md Guideline 17)
+  struct __attribute__((aligned(16))) InsertShared {
+    int nstates, gpos, wpos, ok, item, pad[3];
+    u64 best[kInsertThreads / 64];
+    int pref[68];  // record offsets of the buckets of the current item
+  };
+  static_assert(sizeof(InsertShared) % 16 == 0, "keep the dynamic LDS base aligned");
+  __shared__ InsertShared ish;
+  int &s_nstates = ish.nstates, &s_gpos = ish.gpos, &s_wpos = ish.wpos, &s_ok = ish.ok, &s_item = ish.item;
+  u64 *s_best = ish.best;
+  int *s_pref = ish.pref;
+  FrameCtl *fc = D.fctl + group;
+  const int n_items = min(fc->n_items[par], D.item_cap);
   const int P = D.n_part;
-  int32_t *cntp = D.bucket_cnt + (size_t)c * P + p;
-  int n = *cntp;
-  if (n > D.bucket_cap) n = D.bucket_cap;
-  if (n == 0) return;
-  const int4 *bucket = D.bucket + ((size_t)c * P + p) * D.bucket_cap;
+
+  for (int it = blockIdx.x; it < n_items;) {
+  const int item = D.items[(size_t)group * D.item_cap + it];
+  const int c = item >> 16, g0 = (item >> 8) & 0xFF, G = item & 0xFF;
+  ChanCtl *ctl = D.ctl + c;
+  int n = 0;
+  {
+    const int32_t *cnts = D.bucket_cnt + (size_t)c * P;
+    const int cnt = (lane < G) ? min(cnts[g0 + lane], D.bucket_cap) : 0;  // every wave computes the same
+    int ps = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int v = __shfl_up(ps, off, 64);
+      if (lane >= off) ps += v;
+    }
+    n = __shfl(ps, 63, 64);
+    if (wave == 0 && lane < G) s_pref[lane + 1] = ps;
+    if (tid == 0) s_pref[0] = 0;
+  }
+  int log2g = 0;
+  while ((1 << log2g) < G) ++log2g;
+  const int log2grp = D.log2part - log2g;  // hash bits that select this group of partitions
+  const int4 *bucket0 = D.bucket + ((size_t)c * P + g0) * D.bucket_cap;
   const float cutoff = o2f(ctl->bound);  // FINAL next_cutoff of this frame
-  // table sized to the load: the smallest power of two >= 4 n (records >= distinct states),
-  // so light partitions pay for clearing a few hundred slots, not the whole 48 KB
+  // table sized to the load: the smallest power of two >= 4 n (records >= distinct states)
   int log2sl = 6;
   while ((1 << log2sl) < 4 * n && log2sl < D.log2lds) ++log2sl;
   const int SL = 1 << log2sl;
@@ -298,14 +374,30 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   int4 *wl = D.worklist + (size_t)c * 2 * D.wl_cap;
   u64 *occ_wl = reinterpret_cast<u64 *>(&ctl->eps_occ);  // {eps_occ, wl_n} bumped by one atomic
 
+  // a single bucket too big for the table is processed in 2^k sub-passes by hash class
   int log2sub = 0;
   while (n > ((SL * 3) >> 2) << log2sub) ++log2sub;
-  const int sub_shift = 32 - D.log2part - log2sl - log2sub;
-  if (sub_shift < 0) { if (tid == 0) { atomicOr(&ctl->error, kErrTableFull); *cntp = 0; } return; }
+  const int sub_shift = 32 - log2grp - log2sl - log2sub;
+  if (sub_shift < 0 && tid == 0) atomicOr(&ctl->error, kErrTableFull);
+  __syncthreads();
+  // logical record i of the group -> (bucket, offset)
+  auto load_rec = [&](int i) -> int4 {
+    if (i >= n) return make_int4(0, 0x7F800000, 0, 0);  // cost +inf: never below a cutoff
+    int b = 0;
+    if (G > 1) {
+      int lo = 0, hi = G;  // s_pref[lo] <= i < s_pref[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_pref[mid] <= i) lo = mid; else hi = mid;
+      }
+      b = lo;
+    }
+    return bucket0[(size_t)b * D.bucket_cap + (i - s_pref[b])];
+  };
 
   u64 best = ~0ull;
   unsigned long long tq = wall_clock64();
-  for (int sub = 0; sub < (1 << log2sub); ++sub) {
+  for (int sub = 0; sub_shift >= 0 && sub < (1 << log2sub); ++sub) {
     __syncthreads();
     for (int i = tid; i < SL; i += kInsertThreads) { keys[i] = kEmptyKey; vals[i] = kEmptyVal; }
     if (tid == 0) { s_nstates = 0; s_wpos = 0; s_ok = 1; }
@@ -317,16 +409,13 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
     for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
       int4 r[kInsertUnroll];
 #pragma unroll
-      for (int k = 0; k < kInsertUnroll; ++k) {
-        const int i = i0 + k * kInsertThreads + tid;
-        r[k] = i < n ? bucket[i] : make_int4(0, 0x7F800000, 0, 0);  // cost +inf: never below a cutoff
-      }
+      for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid);
 #pragma unroll
       for (int k = 0; k < kInsertUnroll; ++k) {
-        if (!(__int_as_float(r[k].y) < cutoff) || (D.dbg & 4)) continue;
+        if (!(__int_as_float(r[k].y) < cutoff)) continue;
         const uint32_t h = hash32(r[k].x);
         if (log2sub && (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) != sub) continue;
-        uint32_t slot = lds_slot_of(h, D.log2part, log2sl);
+        uint32_t slot = lds_slot_of(h, log2grp, log2sl);
         bool found = false;
         for (int q = 0; q < SL; ++q) {
           int32_t kk = keys[slot];
@@ -356,14 +445,10 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
     const int gpos = s_gpos;
 
     // pass 2: the record that won its state writes the token
-    if (D.dbg & 1) continue;
     for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
       int4 r[kInsertUnroll];
 #pragma unroll
-      for (int k = 0; k < kInsertUnroll; ++k) {
-        const int i = i0 + k * kInsertThreads + tid;
-        r[k] = i < n ? bucket[i] : make_int4(0, 0x7F800000, 0, 0);
-      }
+      for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid);
 #pragma unroll
       for (int k = 0; k < kInsertUnroll; ++k) {
         bool winner = false;
@@ -372,7 +457,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
           const uint32_t h = hash32(r[k].x);
           if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
             packed = ((u64)f2o(__int_as_float(r[k].y)) << 32) | (uint32_t)r[k].w;
-            uint32_t slot = lds_slot_of(h, D.log2part, log2sl);
+            uint32_t slot = lds_slot_of(h, log2grp, log2sl);
             for (int q = 0; q < SL; ++q) {
               const int32_t kk = keys[slot];
               if (kk == r[k].x) { winner = vals[slot] == packed; break; }
@@ -424,7 +509,6 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   }
   __syncthreads();
   if (tid == 0) dbg_phase(D, 9, tq);
-  if (tid == 0) *cntp = 0;  // bucket consumed
   best = wave_min_u64(best);
   if (lane == 0) s_best[wave] = best;
   __syncthreads();
@@ -433,6 +517,11 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
     for (int w = 1; w < kInsertThreads / 64; ++w) b = s_best[w] < b ? s_best[w] : b;
     if (b != ~0ull) atomicMin(&ctl->best_next, b);
     dbg_phase(D, 10, tq);
+    s_item = (int)gridDim.x + atomicAdd(&fc->item_ticket[par], 1);
+  }
+  __syncthreads();
+  it = s_item;
+  __syncthreads();
   }
 }
 
@@ -602,6 +691,9 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
     sh.wl_n[1] = 0;
     sh.err = 0;
   }
+  // the insert workgroups read all bucket counters of the channel to form their groups, so the
+  // counters stay untouched during that launch and are reset here
+  for (int i = tid; i < D.n_part; i += kBT) D.bucket_cnt[(size_t)c * D.n_part + i] = 0;
   __syncthreads();
   if (tid == 0) dbg_phase(D, 0, tq);
   u64 nZ = 0;
@@ -977,9 +1069,10 @@ void launch_init(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s) {
   hipLaunchKernelGGL(expand_kernel, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
 }
-void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, hipStream_t s) {
+void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups, hipStream_t s) {
   const size_t lds = (size_t)D.lds_slots * 12;
-  hipLaunchKernelGGL(insert_kernel, dim3(chan_cnt, D.n_part), dim3(kInsertThreads), lds, s, D, chan_off, group, par);
+  hipLaunchKernelGGL(plan_kernel, dim3((chan_cnt + 3) / 4), dim3(256), 0, s, D, chan_off, chan_cnt, group, par);
+  hipLaunchKernelGGL(insert_kernel, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
 }
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int do_prep, int group, int par,
                     hipStream_t s) {
