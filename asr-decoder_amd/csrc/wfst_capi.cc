@@ -16,6 +16,7 @@
 
 using namespace wfst;
 namespace wfst { int insert_kernel_set_lds(int bytes); }
+static const int32_t kHeaderLabel = -2;  // ilabel_host marker of a header slot
 
 namespace {
 
@@ -55,14 +56,14 @@ struct wfst_graph {
   int32_t start = 0, final_state = 0, n_states = 0, n_arcs = 0;
   int32_t max_col = 0;  // largest log-likelihood column any arc reads
   std::vector<int32_t> ilabel_host;  // original ilabels (re-mapped when tid2pdf changes)
-  DevBuf<uint2> state_info;
-  DevBuf<int4> arcs;
+  DevBuf<int4> arcs;  // interleaved rows: header + arcs per state
+  std::vector<int32_t> pos_host;  // row position of each original state id (sorted)
+  int32_t orig_start = 0, orig_final = 0;
   DevBuf<int32_t> arc_ilabel, arc_olabel, arc_src, eps_target_state;
   uint32_t start_eps = 0;
   int32_t n_eps_targets = 0;
   GraphDev view() const {
     GraphDev g;
-    g.state_info = state_info.p;
     g.arcs = arcs.p;
     g.arc_ilabel = arc_ilabel.p;
     g.arc_olabel = arc_olabel.p;
@@ -77,7 +78,6 @@ struct wfst_graph {
     return g;
   }
   ~wfst_graph() {
-    state_info.release();
     arcs.release();
     arc_ilabel.release();
     arc_olabel.release();
@@ -188,13 +188,24 @@ int wfst_device_count(void) {
 
 /* ---------------------------------------------------------------- graph */
 
-static int upload_arcs(wfst_graph *g, const wfst_state_info *states, const wfst_arc *arcs,
-                       const int32_t *tid2pdf, int32_t n_tid, const std::vector<uint32_t> *state_flags = nullptr) {
-  const int32_t S = g->n_states, A = g->n_arcs;
-  std::vector<int4> h_arcs((size_t)A);
+// Device row layout ("ext" index space): state s owns the slots [pos(s), pos(s) + 1 + num_arcs(s))
+// of ONE int4 array, pos(s) = arc_begin(s) + s.  Slot pos(s) is the state's header
+// {(n_emit << 12) | n_eps, original state id, own next_eps word, 0}; its arcs follow, epsilon arcs
+// first.  A state is identified on the device by pos(s), so finding a token's arcs is ONE gather
+// whose cache lines also hold the arcs themselves.  Labels and sources live in cold arrays with
+// the same indexing.
+static int upload_columns(wfst_graph *g, const int32_t *tid2pdf, int32_t n_tid, std::vector<int4> *ext) {
+  const int64_t N = (int64_t)g->ilabel_host.size();
   int32_t max_col = 0;
-  for (int32_t a = 0; a < A; ++a) {
+  std::vector<int4> cur;
+  if (!ext) {  // set_tid2pdf: read-modify-write of the column word only
+    cur.resize((size_t)N);
+    HIP_TRY(hipMemcpy(cur.data(), g->arcs.p, (size_t)N * sizeof(int4), hipMemcpyDeviceToHost));
+    ext = &cur;
+  }
+  for (int64_t a = 0; a < N; ++a) {
     const int32_t il = g->ilabel_host[a];
+    if (il == kHeaderLabel) continue;
     int32_t col = -1;
     if (il != 0) {
       if (tid2pdf) {
@@ -206,28 +217,9 @@ static int upload_arcs(wfst_graph *g, const wfst_state_info *states, const wfst_
       if (col < 0) return fail(WFST_E_ARG, "negative log-likelihood column");
       max_col = std::max(max_col, col);
     }
-    int4 v;
-    v.x = col;
-    if (arcs) {
-      v.y = (int32_t)(*state_flags)[arcs[a].nextstate];
-      memcpy(&v.z, &arcs[a].weight, 4);
-      v.w = arcs[a].nextstate;
-      h_arcs[a] = v;
-    } else {
-      h_arcs[a].x = col;  // only the column changes (set_tid2pdf)
-    }
+    (*ext)[a].x = col;
   }
-  (void)S;
-  (void)states;
-  if (arcs) {
-    HIP_TRY(hipMemcpy(g->arcs.p, h_arcs.data(), (size_t)A * sizeof(int4), hipMemcpyHostToDevice));
-  } else {
-    // read-modify-write of column x only
-    std::vector<int4> cur((size_t)A);
-    HIP_TRY(hipMemcpy(cur.data(), g->arcs.p, (size_t)A * sizeof(int4), hipMemcpyDeviceToHost));
-    for (int32_t a = 0; a < A; ++a) cur[a].x = h_arcs[a].x;
-    HIP_TRY(hipMemcpy(g->arcs.p, cur.data(), (size_t)A * sizeof(int4), hipMemcpyHostToDevice));
-  }
+  HIP_TRY(hipMemcpy(g->arcs.p, ext->data(), (size_t)N * sizeof(int4), hipMemcpyHostToDevice));
   g->max_col = max_col;
   return WFST_OK;
 }
@@ -244,12 +236,11 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
   if (ndev <= 0) return fail(WFST_E_DEVICE, "no HIP device available (this library has no CPU path)");
   if (device < 0 || device >= ndev) return fail(WFST_E_ARG, "device index out of range");
   HIP_TRY(hipSetDevice(device));
+  const int64_t N = (int64_t)n_arcs + n_states;
+  if (N >= (int64_t)kNoArc) return fail(WFST_E_FORMAT, "graphs with states + arcs >= 2^30 are not supported");
 
-  std::vector<uint2> h_si((size_t)n_states);
-  std::vector<int32_t> h_src((size_t)n_arcs);
-  std::vector<int32_t> h_il((size_t)n_arcs), h_ol((size_t)n_arcs);
-  std::vector<uint32_t> h_flags((size_t)n_states, 0u);
-  if ((uint32_t)n_arcs >= kNoArc) return fail(WFST_E_FORMAT, "graphs of 2^30 arcs or more are not supported");
+  // pass 1: validate, positions, epsilon targets
+  std::vector<int32_t> pos((size_t)n_states);
   std::vector<uint8_t> is_target((size_t)n_states, 0);
   int64_t off = 0;
   for (int32_t s = 0; s < n_states; ++s) {
@@ -257,54 +248,82 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
     if (ne > na || off + na > n_arcs) return fail(WFST_E_FORMAT, "state arc counts inconsistent with total_arcs");
     if (ne > kEpsMask) return fail(WFST_E_FORMAT, "state with more than 4095 input-epsilon arcs");
     if (na - ne >= (1u << (32 - kEpsBits))) return fail(WFST_E_FORMAT, "state with 2^20 or more emitting arcs");
+    pos[s] = (int32_t)(off + s);
     for (uint32_t i = 0; i < na; ++i) {
       const wfst_arc &a = arcs[off + i];
       if ((i < ne) != (a.ilabel == 0))
         return fail(WFST_E_FORMAT, "input-epsilon arcs must precede a state's other arcs (reference flat format)");
       if (a.nextstate < 0 || a.nextstate >= n_states) return fail(WFST_E_FORMAT, "arc nextstate out of range");
-      h_src[off + i] = (int32_t)((uint32_t)s | (i < ne ? 0x80000000u : 0u));
-      h_il[off + i] = a.ilabel;
-      h_ol[off + i] = a.olabel;
       if (i < ne) is_target[a.nextstate] = 1;
     }
-    if (ne) h_flags[s] |= kFlagOutEps;
-    h_si[s] = make_uint2((uint32_t)off, ((na - ne) << kEpsBits) | ne);
     off += na;
   }
   if (off != n_arcs) return fail(WFST_E_FORMAT, "sum of num_arcs != total_arcs");
   // next_eps word per state: bit 31 = has outgoing epsilon arcs, bits 30..0 = 1 + ordinal among
   // the epsilon-target states (the index of the state's slot in every channel's epsilon table)
+  std::vector<uint32_t> next_eps((size_t)n_states, 0u);
   std::vector<int32_t> h_targets;
-  for (int32_t st = 0; st < n_states; ++st)
+  for (int32_t st = 0; st < n_states; ++st) {
+    if (states[st].niepsilons) next_eps[st] |= kFlagOutEps;
     if (is_target[st]) {
-      h_targets.push_back(st);
-      h_flags[st] |= (uint32_t)h_targets.size();
+      h_targets.push_back(pos[st]);
+      next_eps[st] |= (uint32_t)h_targets.size();
     }
+  }
+  // pass 2: rows
+  std::vector<int4> ext((size_t)N);
+  std::vector<int32_t> h_src((size_t)N, 0), h_il((size_t)N, kHeaderLabel), h_ol((size_t)N, 0);
+  off = 0;
+  for (int32_t s = 0; s < n_states; ++s) {
+    const uint32_t na = states[s].num_arcs, ne = states[s].niepsilons;
+    int4 h;
+    h.x = (int32_t)(((na - ne) << kEpsBits) | ne);
+    h.y = s;
+    h.z = (int32_t)next_eps[s];
+    h.w = 0;
+    ext[(size_t)pos[s]] = h;
+    for (uint32_t i = 0; i < na; ++i) {
+      const wfst_arc &a = arcs[off + i];
+      const size_t q = (size_t)pos[s] + 1 + i;
+      int4 v;
+      v.x = -1;
+      v.y = (int32_t)next_eps[a.nextstate];
+      memcpy(&v.z, &a.weight, 4);
+      v.w = pos[a.nextstate];
+      ext[q] = v;
+      h_src[q] = (int32_t)((uint32_t)pos[s] | (i < ne ? 0x80000000u : 0u));
+      h_il[q] = a.ilabel;
+      h_ol[q] = a.olabel;
+    }
+    off += na;
+  }
 
   wfst_graph *g = new wfst_graph();
   g->device = device;
-  g->start = start;
-  g->final_state = final_state;
+  g->start = pos[start];
+  g->final_state = (final_state >= 0 && final_state < n_states) ? pos[final_state] : -1;
+  g->orig_start = start;
+  g->orig_final = final_state;
   g->n_states = n_states;
   g->n_arcs = n_arcs;
   g->ilabel_host.swap(h_il);
-  g->start_eps = h_flags[start];
+  g->pos_host.swap(pos);
+  g->start_eps = next_eps[start];
   g->n_eps_targets = (int32_t)h_targets.size();
   hipError_t e;
-  if ((e = g->state_info.alloc(n_states)) != hipSuccess || (e = g->arcs.alloc(n_arcs)) != hipSuccess ||
-      (e = g->arc_ilabel.alloc(n_arcs)) != hipSuccess || (e = g->arc_olabel.alloc(n_arcs)) != hipSuccess ||
-      (e = g->arc_src.alloc(n_arcs)) != hipSuccess || (e = g->eps_target_state.alloc(h_targets.size())) != hipSuccess) {
+  if ((e = g->arcs.alloc((size_t)N)) != hipSuccess || (e = g->arc_ilabel.alloc((size_t)N)) != hipSuccess ||
+      (e = g->arc_olabel.alloc((size_t)N)) != hipSuccess || (e = g->arc_src.alloc((size_t)N)) != hipSuccess ||
+      (e = g->eps_target_state.alloc(h_targets.size())) != hipSuccess) {
     delete g;
     return fail(WFST_E_DEVICE, std::string("hipMalloc(graph): ") + hipGetErrorString(e));
   }
   int rc = WFST_OK;
-  if (hipMemcpy(g->state_info.p, h_si.data(), h_si.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(g->arc_src.p, h_src.data(), h_src.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+  if (hipMemcpy(g->arc_src.p, h_src.data(), h_src.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(g->arc_olabel.p, h_ol.data(), h_ol.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       (!h_targets.empty() && hipMemcpy(g->eps_target_state.p, h_targets.data(), h_targets.size() * 4, hipMemcpyHostToDevice) != hipSuccess) ||
       hipMemcpy(g->arc_ilabel.p, g->ilabel_host.data(), g->ilabel_host.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(WFST_E_DEVICE, "hipMemcpy(graph) failed");
-  if (rc == WFST_OK) rc = upload_arcs(g, states, arcs, nullptr, 0, &h_flags);
+  if (rc == WFST_OK) rc = upload_columns(g, nullptr, 0, &ext);
   if (rc != WFST_OK) {
     delete g;
     return rc;
@@ -340,18 +359,18 @@ int wfst_graph_load(const char *path, int device, wfst_graph **out) {
 int wfst_graph_set_tid2pdf(wfst_graph *g, const int32_t *tid2pdf, int32_t n_tid) {
   if (!g) return fail(WFST_E_ARG, "NULL graph");
   HIP_TRY(hipSetDevice(g->device));
-  return upload_arcs(g, nullptr, nullptr, tid2pdf, n_tid);
+  return upload_columns(g, tid2pdf, n_tid, nullptr);
 }
 
 int wfst_graph_info(const wfst_graph *g, int32_t *start, int32_t *final_state, int32_t *n_states,
                     int32_t *n_arcs, int64_t *device_bytes) {
   if (!g) return fail(WFST_E_ARG, "NULL graph");
-  if (start) *start = g->start;
-  if (final_state) *final_state = g->final_state;
+  if (start) *start = g->orig_start;
+  if (final_state) *final_state = g->orig_final;
   if (n_states) *n_states = g->n_states;
   if (n_arcs) *n_arcs = g->n_arcs;
   if (device_bytes)
-    *device_bytes = (int64_t)(g->state_info.bytes() + g->arcs.bytes() + g->arc_ilabel.bytes() +
+    *device_bytes = (int64_t)(g->arcs.bytes() + g->arc_ilabel.bytes() +
                               g->arc_olabel.bytes() + g->arc_src.bytes() + g->eps_target_state.bytes());
   return WFST_OK;
 }
@@ -519,14 +538,16 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
 }
 
 void wfst_decoder_free(wfst_decoder *d) {
-  if (d && (d->D.dbg & 96)) {  // debug phase timers (100 MHz ticks)
+  if (d && (d->D.dbg & 224)) {  // debug phase timers (100 MHz ticks)
     unsigned long long t[64];
     (void)hipSetDevice(d->device);
     (void)hipDeviceSynchronize();
     if (hipMemcpy(t, d->dbg_t.p, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
       const char *names[] = {"closure:setup", "closure:rounds", "closure:commit", "closure:clear", "closure:finalize", "closure:prep",
-                             "insert:init", "insert:pass1", "insert:alloc", "insert:pass2", "insert:tail"};
-      for (int k = 0; k < 11; ++k)
+                             "insert:init", "insert:pass1", "insert:alloc", "insert:pass2", "insert:tail",
+                             "expand:tile-load+scan", "expand:candidates", "expand:bound+count", "expand:bucket-atomics",
+                             "expand:write", "expand:stats+ticket"};
+      for (int k = 0; k < 17; ++k)
         if (t[3 * k + 2])
           fprintf(stderr, "[wfst dbg] %-18s n=%llu mean=%.2f us max=%.2f us\n", names[k], t[3 * k + 2],
                   0.01 * t[3 * k] / t[3 * k + 2], 0.01 * t[3 * k + 1]);
@@ -920,8 +941,9 @@ int wfst_decoder_get_frontier(wfst_decoder *d, int32_t channel, int32_t cap, int
     std::vector<int4> t((size_t)k);
     HIP_TRY(hipMemcpy(t.data(), d->tok.p + (size_t)channel * (size_t)d->D.arena_cap + c.front_begin,
                       (size_t)k * sizeof(int4), hipMemcpyDeviceToHost));
+    const std::vector<int32_t> &pos = d->graph->pos_host;
     for (int i = 0; i < k; ++i) {
-      states[i] = t[i].x;
+      states[i] = (int32_t)(std::lower_bound(pos.begin(), pos.end(), t[i].x) - pos.begin());  // row -> state id
       memcpy(&costs[i], &t[i].y, 4);
     }
   }

@@ -12,21 +12,21 @@
 
 namespace wfst {
 
-// ---- graph in HBM: CSR -------------------------------------------------------------------
-// state_info[s] = {arc_begin, (n_emit << 12) | n_eps}: one 8-byte load gives both arc ranges of
-//   a state: epsilon arcs [arc_begin, arc_begin+n_eps), emitting arcs the n_emit after them.
-// arcs[a]       = {ll_col, next_eps, weight bits, nextstate}: 16-byte AoS, one dwordx4 per lane.
-//   ll_col      log-likelihood column of the arc's ilabel (tid2pdf applied at upload), -1 for an
-//               input-epsilon arc;
-//   next_eps    what the epsilon closure needs to know about NEXTSTATE without touching
-//               state_info: bit 31 = it has outgoing epsilon arcs; bits 30..0 = 1 + its ordinal
-//               among the graph's epsilon-TARGET states (0 = no epsilon arc enters it).
-// eps_target_state[k] = state id of epsilon-target ordinal k (n_eps_targets of them).
-// arc_ilabel[a], arc_olabel[a] = labels for output (cold: traceback only).
-// arc_src[a]    = source state of arc a, bit 31 set for an input-epsilon arc.
+// ---- graph in HBM: CSR with the row header in front of the row ---------------------------
+// rows[]: ONE int4 array in "ext" index space.  State s owns slots [pos(s), pos(s)+1+num_arcs(s)),
+//   pos(s) = arc_begin(s) + s, and IS identified by pos(s) everywhere on the device.
+//   rows[pos(s)]      header {(n_emit << 12) | n_eps, original state id, next_eps word of s, 0}
+//   rows[pos(s)+1+i]  arc i {ll_col, next_eps(nextstate), weight bits, pos(nextstate)}; epsilon arcs
+//                     first.  ll_col = log-likelihood column of the ilabel (tid2pdf applied at
+//                     upload), -1 for an input-epsilon arc.
+//   One gather finds a token's arcs, and its cache lines hold the arcs themselves (a separate
+//   8-byte state table cost one more 64-byte fabric request per expanded token).
+//   next_eps word: bit 31 = the state has outgoing epsilon arcs; bits 30..0 = 1 + its ordinal among
+//   the graph's epsilon-TARGET states (0 = no epsilon arc enters it).
+// arc_ilabel[], arc_olabel[], arc_src[] (source row | bit 31 for an epsilon arc): cold arrays in
+//   the same index space.  eps_target_state[k] = row of epsilon-target ordinal k.
 struct GraphDev {
-  const uint2 *state_info;
-  const int4 *arcs;
+  const int4 *arcs;  // rows[]
   const int32_t *arc_ilabel;
   const int32_t *arc_olabel;
   const int32_t *arc_src;

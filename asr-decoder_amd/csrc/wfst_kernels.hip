@@ -73,8 +73,8 @@ __device__ __forceinline__ uint32_t lds_slot_of(uint32_t h, int log2part, int lo
 
 // debug phase timers (WFST_DBG & 32): slot k accumulates {sum, max, count} of 100 MHz ticks
 __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned long long &t_prev) {
-  if (!(D.dbg & (k >= 6 ? 64 : 32))) return;
-  if (k >= 6 && (blockIdx.y & 31) != 0) return;  // sample 1/32 of the insert workgroups
+  if (!(D.dbg & (k >= 11 ? 128 : k >= 6 ? 64 : 32))) return;
+  if (k >= 6 && (blockIdx.x & 15) != 0) return;  // sample 1/16 of the insert / expand workgroups
   const unsigned long long now = wall_clock64();
   const unsigned long long dt = now - t_prev;
   atomicAdd(&D.dbg_t[3 * k], dt);
@@ -88,8 +88,8 @@ __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned l
 // with n_channels % 8 == 0 the workgroups of a channel share an XCD (speed only: its buckets
 // and log-likelihood row stay in one L2).
 // =========================================================================================
-constexpr int kExpandThreads = 256;
-constexpr int kCandPerThread = 4;
+constexpr int kExpandThreads = 512;
+constexpr int kCandPerThread = 2;
 constexpr int kChunk = kExpandThreads * kCandPerThread;  // candidates per counting-sort round
 
 // Work unit = one tile of 256 frontier tokens of one channel.  prep_frame lists the tiles of all
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
   __shared__ int s_ticket;
 
   const int32_t *tile_chan = D.tile_chan + (size_t)group * D.tile_cap;
+  unsigned long long tq = wall_clock64();
   for (int t = blockIdx.x; t < total_tiles;) {
     const int c = tile_chan[t];
     ChanCtl *ctl = D.ctl + c;
@@ -133,9 +134,9 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
       int4 t = tok[i];
       cost = __int_as_float(t.y);
       if (cost <= cutoff) {  // base-inl.h:315
-        uint2 si = D.g.state_info[t.x];
-        deg = (int)(si.y >> kEpsBits);
-        arcbeg = (int)(si.x + (si.y & kEpsMask));
+        const uint32_t dw = (uint32_t)D.g.arcs[t.x].x;  // row header: (n_emit << 12) | n_eps
+        deg = (int)(dw >> kEpsBits);
+        arcbeg = t.x + 1 + (int)(dw & kEpsMask);
         nN++;
         nE += deg;
       }
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
     s_cost[tid] = cost;
     s_arcbeg[tid] = arcbeg;
     __syncthreads();
+    if (tid == 0) dbg_phase(D, 11, tq);
     int wbase = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < kExpandThreads / 64; ++w) {
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
           tmin = fminf(tmin, tot[k]);
         }
       }
+      if (tid == 0) dbg_phase(D, 12, tq);
       // base-inl.h:330-333: tighten next_cutoff by the best candidate seen (wave-aggregated)
       const float cand = wave_min_f(tmin) + ab;
       if (cand < bound) {
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
         }
       }
       __syncthreads();
+      if (tid == 0) dbg_phase(D, 13, tq);
       if (tid < 64) {
         const int cnt = tid < P ? s_cnt[tid] : 0;
         int inc = cnt;
@@ -224,6 +228,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
         s_cnt[tid] = 0;
       }
       __syncthreads();
+      if (tid == 0) dbg_phase(D, 14, tq);
 #pragma unroll
       for (int k = 0; k < kCandPerThread; ++k)
         if (part[k] >= 0) s_rec[s_lbase[part[k]] + rank[k]] = rec[k];
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
         if (gi < bcap) bucket[(size_t)p * bcap + gi] = r;
       }
       __syncthreads();
+      if (tid == 0) dbg_phase(D, 15, tq);
     }
     }
     nN = wave_sum_u64(nN);
@@ -247,10 +253,12 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
       if (nR) atomicAdd(&ctl->cnt_rec, nR);
     }
     // next tile: the first gridDim.x tiles are taken statically, the rest by ticket
+    if (total_tiles <= (int)gridDim.x) break;
     if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(&fc->ticket[par], 1);
     __syncthreads();
     t = s_ticket;
     __syncthreads();
+    if (tid == 0) dbg_phase(D, 16, tq);
   }
 }
 
@@ -586,7 +594,8 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
         live[k] = live[k] && (__int_as_float(ent[k].z) < cutoff);  // base-inl.h:391
       }
 #pragma unroll
-      for (int k = 0; k < kClosureUnroll; ++k) si[k] = live[k] ? D.g.state_info[ent[k].y] : make_uint2(0, 0);
+      for (int k = 0; k < kClosureUnroll; ++k)
+        si[k] = live[k] ? make_uint2((uint32_t)ent[k].y + 1u, (uint32_t)D.g.arcs[ent[k].y].x) : make_uint2(0, 0);
 #pragma unroll
       for (int k = 0; k < kClosureUnroll; ++k)
         arc0[k] = (live[k] && (si[k].y & kEpsMask)) ? D.g.arcs[si[k].x] : make_int4(0, 0, 0, 0);
@@ -812,7 +821,7 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
   float seed = kInf;
   if (n > 0) {
     const int4 bt = tokc[(uint32_t)best];
-    const uint2 si = D.g.state_info[bt.x];
+    const uint2 si = make_uint2((uint32_t)bt.x + 1u, (uint32_t)D.g.arcs[bt.x].x);
     const int deg = (int)(si.y >> kEpsBits), ab0 = (int)(si.x + (si.y & kEpsMask));
     const float *llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
     const float bc = __int_as_float(bt.y);
@@ -1026,7 +1035,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
     const int warc = (int)((uint32_t)T.w & kArcMask);
     const bool eps = prev >= foff[fr];  // backpointer on the same frame <=> epsilon hop
     const int fbp = eps ? fr : fr - 1;
-    const uint2 si = D.g.state_info[Pt.x];
+    const uint2 si = make_uint2((uint32_t)Pt.x + 1u, (uint32_t)D.g.arcs[Pt.x].x);
     const int ne = (int)(si.y & kEpsMask);
     const int ahi = eps ? (int)si.x + ne : (int)si.x + ne + (int)(si.y >> kEpsBits);
     const bool pruned_once = ctl->finalized || m_last >= fbp + 1;
