@@ -100,7 +100,8 @@ struct wfst_decoder {
   DevBuf<int4> bucket, worklist;
   DevBuf<FrameCtl> fctl;
   DevBuf<unsigned long long> dbg_t;
-  DevBuf<int32_t> tile_chan, items;
+  DevBuf<int32_t> items;
+  DevBuf<TileDesc> tiles;
   int insert_wgs = 768;
   std::vector<int> gpar;  // step parity per group (persists across advance calls)
   int expand_wgs = 2048;
@@ -159,7 +160,7 @@ struct wfst_decoder {
     if (p_ctl) (void)hipHostFree(p_ctl);
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); fctl.release(); dbg_t.release(); items.release(); tile_chan.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
+    bucket.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
     bp_ac.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -447,7 +448,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 256 + 2);
   A(d->fctl.alloc(8));
   A(d->dbg_t.alloc(64));
-  A(d->tile_chan.alloc(8 * tile_cap));
+  A(d->tiles.alloc(8 * tile_cap));
   const size_t item_cap = B * (size_t)n_part;
   A(d->items.alloc(8 * item_cap));
   A(d->target.alloc(B));
@@ -486,7 +487,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.worklist = d->worklist.p;
   D.fctl = d->fctl.p;
   D.dbg_t = d->dbg_t.p;
-  D.tile_chan = d->tile_chan.p;
+  D.tiles = d->tiles.p;
   D.tile_cap = (int32_t)tile_cap;
   D.items = d->items.p;
   D.item_cap = (int32_t)item_cap;

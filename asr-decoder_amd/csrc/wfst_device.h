@@ -78,6 +78,20 @@ struct __attribute__((aligned(128))) ChanCtl {
 };
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
 
+// One 256/512-token tile of a channel's frontier, listed by prep_frame for the expansion: everything
+// a workgroup needs to start, in one 32-byte load (instead of tile -> channel -> control block ->
+// log-likelihood pointer, three dependent loads).
+struct __attribute__((aligned(32))) TileDesc {
+  int32_t chan;
+  int32_t tok_begin;    // arena index of the tile's first token
+  int32_t tok_count;    // tokens in the tile (<= tile size)
+  float cutoff;         // GetCutoff() of the frame
+  float adaptive_beam;
+  int32_t pad;
+  const float *llrow;   // log-likelihood row of the frame being decoded
+};
+static_assert(sizeof(TileDesc) == 32, "TileDesc is one 32-byte load");
+
 // per channel-group frame counters, double buffered by step parity
 struct FrameCtl {
   int32_t total_tiles[2];  // tiles published by prep_frame for the step of that parity
@@ -114,7 +128,7 @@ struct DecoderDev {
   int32_t *eps_won_list;        // [c][wl_cap] ordinals whose token an epsilon arc won this frame
   int4 *worklist;               // [c][2][wl_cap] {eps-table slot, state, cost bits, 0}
   FrameCtl *fctl;               // [n_groups]
-  int32_t *tile_chan;           // [n_groups][tile_cap] channel of each 256-token tile of the coming frame
+  TileDesc *tiles;              // [n_groups][tile_cap] tiles of the coming frame
   int32_t tile_cap;
   int32_t *items;               // [n_groups][item_cap] channel << 16 | first partition << 8 | group size
   int32_t item_cap;

@@ -91,6 +91,8 @@ __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned l
 constexpr int kExpandThreads = 512;
 constexpr int kCandPerThread = 2;
 constexpr int kChunk = kExpandThreads * kCandPerThread;  // candidates per counting-sort round
+constexpr int kTokPerThread = 2;
+constexpr int kTileTokens = kExpandThreads * kTokPerThread;  // frontier tokens per tile
 
 // Work unit = one tile of 256 frontier tokens of one channel.  prep_frame lists the tiles of all
 // active channels in tile_chan[]; workgroup w takes tile w, then further tiles from a ticket
@@ -104,52 +106,67 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
   const float kInf = __builtin_huge_valf();
   const int P = D.n_part, log2part = D.log2part, bcap = D.bucket_cap;
 
-  __shared__ int s_base[kExpandThreads + 1];
-  __shared__ int s_arcbeg[kExpandThreads];
-  __shared__ float s_cost[kExpandThreads];
+  __shared__ int s_base[kTileTokens + 1];
+  __shared__ int s_arcbeg[kTileTokens];
+  __shared__ float s_cost[kTileTokens];
   __shared__ int s_wsum[kExpandThreads / 64];
   __shared__ int s_cnt[64], s_lbase[65], s_gbase[64];
   __shared__ int4 s_rec[kChunk];
   __shared__ int s_ticket;
 
-  const int32_t *tile_chan = D.tile_chan + (size_t)group * D.tile_cap;
+  const TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap;
   unsigned long long tq = wall_clock64();
   for (int t = blockIdx.x; t < total_tiles;) {
-    const int c = tile_chan[t];
+    const TileDesc td = tiles[t];
+    const int c = td.chan;
     ChanCtl *ctl = D.ctl + c;
-    const int tile = t - ctl->tile_start;
-    const int n = ctl->front_count;
-    const int fbegin = ctl->front_begin;
+    const int n = td.tok_count;
+    const int fbegin = td.tok_begin;
     const int4 *tok = D.tok + (size_t)c * D.arena_cap + fbegin;
-    const float cutoff = ctl->cur_cutoff, ab = ctl->adaptive_beam;
-    const float *llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
+    const float cutoff = td.cutoff, ab = td.adaptive_beam;
+    const float *llrow = td.llrow;
     int4 *bucket = D.bucket + (size_t)c * P * bcap;
     int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
     u64 nN = 0, nE = 0, nR = 0;
     {
-    const int i = tile * kExpandThreads + tid;
-    int deg = 0, arcbeg = 0;
-    float cost = 0.f;
-    if (i < n) {
-      int4 t = tok[i];
-      cost = __int_as_float(t.y);
-      if (cost <= cutoff) {  // base-inl.h:315
-        const uint32_t dw = (uint32_t)D.g.arcs[t.x].x;  // row header: (n_emit << 12) | n_eps
-        deg = (int)(dw >> kEpsBits);
-        arcbeg = t.x + 1 + (int)(dw & kEpsMask);
+    // two adjacent frontier tokens per thread (a tile is 1024 tokens, so the tiles of a whole
+    // batch fit the chip's resident workgroup slots in one wave)
+    int deg[kTokPerThread], arcbeg[kTokPerThread];
+    float cost[kTokPerThread];
+    int4 tk[kTokPerThread];
+#pragma unroll
+    for (int j = 0; j < kTokPerThread; ++j) {
+      const int i = tid * kTokPerThread + j;
+      tk[j] = i < n ? tok[i] : make_int4(0, 0x7F800000, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < kTokPerThread; ++j) {
+      const int i = tid * kTokPerThread + j;
+      deg[j] = 0; arcbeg[j] = 0;
+      cost[j] = __int_as_float(tk[j].y);
+      if (i < n && cost[j] <= cutoff) {  // base-inl.h:315
+        const uint32_t dw = (uint32_t)D.g.arcs[tk[j].x].x;  // row header: (n_emit << 12) | n_eps
+        deg[j] = (int)(dw >> kEpsBits);
+        arcbeg[j] = tk[j].x + 1 + (int)(dw & kEpsMask);
         nN++;
-        nE += deg;
+        nE += deg[j];
       }
     }
-    int incl = deg;
+    int tsum = 0;
+#pragma unroll
+    for (int j = 0; j < kTokPerThread; ++j) tsum += deg[j];
+    int incl = tsum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       int v = __shfl_up(incl, off, 64);
       if (lane >= off) incl += v;
     }
     if (lane == 63) s_wsum[wave] = incl;
-    s_cost[tid] = cost;
-    s_arcbeg[tid] = arcbeg;
+#pragma unroll
+    for (int j = 0; j < kTokPerThread; ++j) {
+      s_cost[tid * kTokPerThread + j] = cost[j];
+      s_arcbeg[tid * kTokPerThread + j] = arcbeg[j];
+    }
     __syncthreads();
     if (tid == 0) dbg_phase(D, 11, tq);
     int wbase = 0, total = 0;
@@ -159,13 +176,17 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
       if (w < wave) wbase += v;
       total += v;
     }
-    s_base[tid] = wbase + incl - deg;
-    if (tid == 0) s_base[kExpandThreads] = total;
+    {
+      int run = wbase + incl - tsum;
+#pragma unroll
+      for (int j = 0; j < kTokPerThread; ++j) { s_base[tid * kTokPerThread + j] = run; run += deg[j]; }
+    }
+    if (tid == 0) s_base[kTileTokens] = total;
     if (tid < 64) s_cnt[tid] = 0;
     __syncthreads();
 
     float bound = o2f(ld_agent(&ctl->bound));
-    const int tok0 = fbegin + tile * kExpandThreads;  // arena index of the tile's first token
+    const int tok0 = fbegin;  // arena index of the tile's first token
     for (int j0 = 0; j0 < total; j0 += kChunk) {
       int4 rec[kCandPerThread];
       float tot[kCandPerThread];
@@ -175,7 +196,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
         const int j = j0 + k * kExpandThreads + tid;
         tot[k] = kInf;
         if (j < total) {
-          int lo = 0, hi = kExpandThreads;  // s_base[lo] <= j < s_base[hi]
+          int lo = 0, hi = kTileTokens;  // s_base[lo] <= j < s_base[hi]
           while (hi - lo > 1) {
             int mid = (lo + hi) >> 1;
             if (s_base[mid] <= j) lo = mid; else hi = mid;
@@ -845,7 +866,7 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
     ctl->best_next = ~0ull;
     ctl->active = 1;
     // publish this channel's tiles for the expansion (any disjoint range will do)
-    const int ntiles = (n + kExpandThreads - 1) / kExpandThreads;
+    const int ntiles = (n + kTileTokens - 1) / kTileTokens;
     sh.active = 0;
     if (ntiles > 0) {
       const int start = atomicAdd(&D.fctl[group].total_tiles[par], ntiles);
@@ -856,8 +877,18 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
   }
   __syncthreads();
   const int ntl = sh.active;
-  int32_t *tile_chan = D.tile_chan + (size_t)group * D.tile_cap + sh.sel_k;
-  for (int i = tid; i < ntl; i += kBT) tile_chan[i] = c;
+  TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap + sh.sel_k;
+  for (int i = tid; i < ntl; i += kBT) {
+    TileDesc td;
+    td.chan = c;
+    td.tok_begin = ctl->front_begin + i * kTileTokens;
+    td.tok_count = min(kTileTokens, n - i * kTileTokens);
+    td.cutoff = cutoff;
+    td.adaptive_beam = ab;
+    td.pad = 0;
+    td.llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
+    tiles[i] = td;
+  }
   if (tid == 0) dbg_phase(D, 5, tq);
 }
 
