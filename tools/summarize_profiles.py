@@ -21,6 +21,11 @@ P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
 
 
+def newest(pattern):
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
 def per_kernel(path):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
@@ -33,16 +38,16 @@ def per_kernel(path):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(OUT, exist_ok=True)
-    ks = glob.glob(os.path.join(P, "kt", "*", "*_kernel_stats.csv"))
+    ks = newest(os.path.join(P, "kt", "*", "*_kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(OUT, "%s_kernel_stats.csv" % tag))
     bj = os.path.join(P, "bench_kt.json")
     if os.path.exists(bj):
         shutil.copy(bj, os.path.join(OUT, "%s_bench_under_rocprof.json" % tag))
-    fetch = glob.glob(os.path.join(P, "pmc_fetch", "*", "*_counter_collection.csv"))
-    write = glob.glob(os.path.join(P, "pmc_write", "*", "*_counter_collection.csv"))
+    fetch = newest(os.path.join(P, "pmc_fetch", "*", "*_counter_collection.csv"))
+    write = newest(os.path.join(P, "pmc_write", "*", "*_counter_collection.csv"))
     summary = {"unit": "KB per launch as reported by rocprofv3 (FETCH_SIZE / WRITE_SIZE)", "kernels": {}}
-    calib = glob.glob(os.path.join(P, "calib", "*", "*_counter_collection.csv"))
+    calib = newest(os.path.join(P, "calib", "*", "*_counter_collection.csv"))
     if calib:
         c = per_kernel(calib[0])
         summary["fetch_size_calibration"] = {
