@@ -182,11 +182,19 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible; there is no CPU fallback)")
+    # WFST_BENCH_SHARE_GPU=1 (testing only): all ranks use GPU 0 and gather over gloo, so the N>1
+    # code path can be exercised on a 1-GPU box; the driver's runs use one GPU per rank and RCCL.
+    share = os.environ.get("WFST_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     pkg = importlib.import_module("asr-decoder_amd")
     synth, wfstdec, shard = pkg.synth, pkg.wfstdec, pkg.shard
@@ -240,10 +248,11 @@ def main():
             tb[k] += v
         tb["n"] += 1
         if world > 1:  # the path's only collective: gather the final results (RCCL all_gather)
-            shard.gather_results(shard.pack_results(res, Lmax), device=dev)
+            shard.gather_results(shard.pack_results(res, Lmax), device=None if share else dev)
         return res
 
     def fence():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -257,7 +266,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     frames_total = world * B * T * a.steps
@@ -294,7 +303,7 @@ def main():
         out["config"]["mean_expanded_tokens_per_frame"] = N / float(B * T)
         # ---- CPU baseline + live parity on a bounded sample ---------------------------------
         scale = 1.0
-        if a.cpu_sample > 0:
+        if a.cpu_sample > 0 and world == 1:  # the CPU baseline is reported at N=1 only
             ns = min(a.cpu_sample, B)
             nth = a.cpu_threads or min(ns, os.cpu_count() or 1)
             sample = [mats[i] for i in range(ns)]
