@@ -762,9 +762,19 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
 
 // exact k-th smallest (0-based) cost of the frontier: what std::nth_element leaves at
 // _tmp_array[k] (base-inl.h:190-193, 211-216).  MSB-first radix select, 8 bits per pass, LDS
-// histogram.
+// histogram.  The first kSelKeep * 1024 costs stay in registers across the four passes (only a
+// longer frontier is re-read from HBM), and the bin holding the k-th element is found by a
+// wave-parallel prefix scan of the histogram (a serial scan by one thread cost ~7 us per pass).
+constexpr int kSelKeep = 8;
+
 __device__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t keep[kSelKeep];
+#pragma unroll
+  for (int j = 0; j < kSelKeep; ++j) {
+    const int i = j * kBT + tid;
+    keep[j] = i < n ? f2o(__int_as_float(tok[i].y)) : 0xFFFFFFFFu;  // orderable +NaN: sorts last
+  }
   if (tid == 0) { sh.sel_prefix = 0; sh.sel_k = (uint32_t)k; }
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
@@ -772,20 +782,33 @@ __device__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh)
     for (int b = tid; b < 256; b += kBT) sh.hist[b] = 0;
     __syncthreads();
     const uint32_t prefix = sh.sel_prefix;
-    for (int i = tid; i < n; i += kBT) {
+#pragma unroll
+    for (int j = 0; j < kSelKeep; ++j) {
+      if (j * kBT + tid < n && (keep[j] & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(keep[j] >> shift) & 255u], 1u);
+    }
+    for (int i = kSelKeep * kBT + tid; i < n; i += kBT) {
       const uint32_t o = f2o(__int_as_float(tok[i].y));
       if ((o & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(o >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t kk = sh.sel_k, cum = 0;
-      int b = 0;
-      for (; b < 255; ++b) {
-        if (kk < cum + sh.hist[b]) break;
-        cum += sh.hist[b];
+    if (tid < 64) {  // one wave: lane l owns bins 4l..4l+3
+      const uint32_t c0 = sh.hist[4 * lane], c1 = sh.hist[4 * lane + 1], c2 = sh.hist[4 * lane + 2], c3 = sh.hist[4 * lane + 3];
+      uint32_t incl = c0 + c1 + c2 + c3;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
       }
-      sh.sel_prefix = prefix | ((uint32_t)b << shift);
-      sh.sel_k = kk - cum;
+      const uint32_t kk = sh.sel_k;
+      const u64 m = __ballot(incl > kk);  // first lane whose cumulative count passes k
+      const int owner = m ? __ffsll((long long)m) - 1 : 63;
+      if (lane == owner) {
+        uint32_t cum = incl - (c0 + c1 + c2 + c3);
+        int b = 4 * lane;
+        if (kk >= cum + c0) { cum += c0; ++b; if (kk >= cum + c1) { cum += c1; ++b; if (kk >= cum + c2) { cum += c2; ++b; } } }
+        sh.sel_prefix = prefix | ((uint32_t)b << shift);
+        sh.sel_k = kk - cum;
+      }
     }
     __syncthreads();
   }
