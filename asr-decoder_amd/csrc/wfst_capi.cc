@@ -97,7 +97,9 @@ struct wfst_decoder {
   DevBuf<ChanCtl> ctl;
   DevBuf<int4> tok;
   DevBuf<int32_t> frame_off, bucket_cnt, eps_toki, eps_occ_list, eps_won_list, target, chan_list;
-  DevBuf<int4> bucket, worklist;
+  DevBuf<int4> bucket, worklist, links, link_attr;
+  DevBuf<int32_t> link_off;
+  DevBuf<uint32_t> extra;
   DevBuf<FrameCtl> fctl;
   DevBuf<unsigned long long> dbg_t;
   DevBuf<int32_t> items;
@@ -160,7 +162,7 @@ struct wfst_decoder {
     if (p_ctl) (void)hipHostFree(p_ctl);
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
+    bucket.release(); links.release(); link_attr.release(); link_off.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
     bp_ac.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -400,12 +402,13 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   int rc = check_config(cfg);
   if (rc != WFST_OK) return rc;
   HIP_TRY(hipSetDevice(g->device));
-  wfst_limits L = {0, 0, 0};
+  wfst_limits L = {0, 0, 0, 0};
   if (limits) L = *limits;
   if (L.max_frames <= 0) L.max_frames = 4096;
   if (L.max_tokens_per_frame <= 0) L.max_tokens_per_frame = 32768;
   if (L.arena_tokens <= 0) L.arena_tokens = 4194304;
   if (L.arena_tokens > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "arena_tokens must fit int32");
+  if (L.lattice_links < 0 || L.lattice_links > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "lattice_links must fit int32");
   // hash partitions per channel: each insert workgroup owns an LDS table of lds_slots entries;
   // a bucket too full for it is handled in sub-passes, so these are speed knobs, not limits
   const int64_t M = L.max_tokens_per_frame;
@@ -445,6 +448,12 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   A(d->eps_occ_list.alloc(B * (size_t)L.max_tokens_per_frame));
   A(d->eps_won_list.alloc(B * (size_t)L.max_tokens_per_frame));
   A(d->worklist.alloc(B * 2 * (size_t)L.max_tokens_per_frame));
+  if (L.lattice_links > 0) {
+    A(d->links.alloc(B * (size_t)L.lattice_links));
+    A(d->link_attr.alloc(B * (size_t)L.lattice_links));
+    A(d->link_off.alloc(B * ((size_t)L.max_frames + 3)));
+    A(d->extra.alloc(B * (size_t)L.arena_tokens));
+  }
   const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 256 + 2);
   A(d->fctl.alloc(8));
   A(d->dbg_t.alloc(64));
@@ -463,7 +472,8 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   if (e == hipSuccess) A(hipMemsetAsync(d->fctl.p, 0, d->fctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->dbg_t.p, 0, d->dbg_t.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->eps_vals.p, 0xFF, d->eps_vals.bytes(), d->stream));
-  if (e == hipSuccess && lds_slots * 12 > 65536) A((hipError_t)insert_kernel_set_lds(lds_slots * 12));
+  if (e == hipSuccess && lds_slots * (L.lattice_links > 0 ? 16 : 12) > 65536)
+    A((hipError_t)insert_kernel_set_lds(lds_slots * (L.lattice_links > 0 ? 16 : 12)));
 
   if (e == hipSuccess) A(hipMemsetAsync(d->target.p, 0, d->target.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->ll_base.p, 0, d->ll_base.bytes(), d->stream));
@@ -485,6 +495,12 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.eps_occ_list = d->eps_occ_list.p;
   D.eps_won_list = d->eps_won_list.p;
   D.worklist = d->worklist.p;
+  D.links = d->links.p;
+  D.link_attr = d->link_attr.p;
+  D.link_off = d->link_off.p;
+  D.extra = d->extra.p;
+  D.link_cap = L.lattice_links;
+  D.lattice = L.lattice_links > 0 ? 1 : 0;
   D.fctl = d->fctl.p;
   D.dbg_t = d->dbg_t.p;
   D.tiles = d->tiles.p;
@@ -782,6 +798,7 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
     if (d->h_state[c] == 0) return fail(WFST_E_STATE, "FinalizeDecoding before InitDecoding");
   }
   launch_set_finalized(d->D, dev, cnt, d->stream);
+  if (d->D.lattice) launch_lattice_prune(d->D, dev, cnt, d->stream);  // PruneForwardLinksFinal + backward pruning
   HIP_TRY(hipGetLastError());
   for (int i = 0; i < cnt; ++i) d->h_state[channels ? channels[i] : i] = 2;
   return WFST_OK;
@@ -804,6 +821,7 @@ static int check_ctl_errors(wfst_decoder *d) {
       if (e & kErrWorklistFull) m += " epsilon worklist (max_tokens_per_frame)";
       if (e & kErrFramesFull) m += " frames (max_frames)";
       if (e & kErrBucketFull) m += " candidate bucket (max_tokens_per_frame)";
+      if (e & kErrLinksFull) m += " forward links (lattice_links)";
       return fail(WFST_E_CAPACITY, m);
     }
   }
@@ -910,6 +928,102 @@ int wfst_decoder_get_profile(wfst_decoder *d, double ms[3], int64_t launches[3])
     }
     ms[k] = tot;
     launches[k] = (int64_t)d->ev_pairs[k].size();
+  }
+  return WFST_OK;
+}
+
+int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, int32_t cap_states,
+                                 int32_t cap_arcs, int32_t *n_states, int32_t *n_arcs, int32_t *st_final,
+                                 int32_t *st_frame, int32_t *st_state, float *st_cost, int32_t *a_src,
+                                 int32_t *a_dst, int32_t *a_ilabel, int32_t *a_olabel, float *a_graph,
+                                 float *a_acoustic) {
+  if (!d || channel < 0 || channel >= d->n_channels || !n_states || !n_arcs) return fail(WFST_E_ARG, "bad argument");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "GetRawLattice needs a decoder created with wfst_limits.lattice_links > 0");
+  if (d->h_state[channel] != 2) return fail(WFST_E_STATE, "GetRawLattice is served after FinalizeDecoding");
+  HIP_TRY(hipSetDevice(d->device));
+  *n_states = 0;
+  *n_arcs = 0;
+  if (!use_final_probs) return WFST_OK;  // base-inl.h:879-884: finalized && !use_final_probs -> false
+  int rc = read_ctl(d);
+  if (rc != WFST_OK) return rc;
+  rc = check_ctl_errors(d);
+  if (rc != WFST_OK) return rc;
+  const ChanCtl &c = d->p_ctl[channel];
+  const int nd = c.n_decoded;
+  if (nd <= 0) return WFST_OK;
+  const size_t fo = (size_t)d->D.max_frames + 2, lo = (size_t)d->D.max_frames + 3;
+  std::vector<int32_t> foff((size_t)nd + 2), loff((size_t)nd + 2);
+  HIP_TRY(hipMemcpy(foff.data(), d->frame_off.p + (size_t)channel * fo, foff.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(loff.data(), d->link_off.p + (size_t)channel * lo, loff.size() * 4, hipMemcpyDeviceToHost));
+  const int n_tok = foff[nd + 1], n_link = loff[nd + 1];
+  std::vector<int4> tok((size_t)n_tok), lk((size_t)n_link), at((size_t)n_link);
+  std::vector<uint32_t> ex((size_t)n_tok);
+  if (n_tok) {
+    HIP_TRY(hipMemcpy(tok.data(), d->tok.p + (size_t)channel * (size_t)d->D.arena_cap, (size_t)n_tok * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ex.data(), d->extra.p + (size_t)channel * (size_t)d->D.arena_cap, (size_t)n_tok * 4, hipMemcpyDeviceToHost));
+  }
+  if (n_link) {
+    HIP_TRY(hipMemcpy(lk.data(), d->links.p + (size_t)channel * (size_t)d->D.link_cap, (size_t)n_link * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(at.data(), d->link_attr.p + (size_t)channel * (size_t)d->D.link_cap, (size_t)n_link * 16, hipMemcpyDeviceToHost));
+  }
+  const uint32_t inf_o = 0xFF800000u;  // orderable +inf
+  // frame of each token; the reference returns false when a frame has no token left (base-inl.h:906-911)
+  std::vector<int32_t> frame_of((size_t)n_tok), new_id((size_t)n_tok, -1);
+  for (int f = 0; f <= nd; ++f) {
+    bool any = false;
+    for (int i = foff[f]; i < foff[f + 1]; ++i) { frame_of[i] = f; any |= ex[i] < inf_o; }
+    if (!any) return WFST_OK;
+  }
+  // topological numbering inside each frame: depth along the surviving epsilon links
+  std::vector<int32_t> depth((size_t)n_tok, 0);
+  for (int f = 0; f <= nd; ++f) {
+    for (int round = 0; round < 1 << 20; ++round) {
+      bool changed = false;
+      for (int i = loff[f]; i < loff[f + 1]; ++i)
+        if (lk[i].w && lk[i].x >= foff[f] && depth[lk[i].y] < depth[lk[i].x] + 1) { depth[lk[i].y] = depth[lk[i].x] + 1; changed = true; }
+      if (!changed) break;
+    }
+  }
+  int ns = 0;
+  {
+    std::vector<int32_t> order;
+    for (int f = 0; f <= nd; ++f) {
+      order.clear();
+      for (int i = foff[f]; i < foff[f + 1]; ++i)
+        if (ex[i] < inf_o) order.push_back(i);
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth[a] < depth[b]; });
+      for (int i : order) new_id[i] = ns++;
+    }
+  }
+  int na = 0;
+  for (int i = 0; i < n_link; ++i) na += lk[i].w && new_id[lk[i].x] >= 0 && new_id[lk[i].y] >= 0;
+  *n_states = ns;
+  *n_arcs = na;
+  if (ns > cap_states || na > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");
+  bool any_final = false;
+  for (int i = foff[nd]; i < foff[nd + 1]; ++i) any_final |= tok[i].x == d->graph->final_state;
+  const std::vector<int32_t> &pos = d->graph->pos_host;
+  for (int i = 0; i < n_tok; ++i) {
+    const int s = new_id[i];
+    if (s < 0) continue;
+    if (st_final) st_final[s] = frame_of[i] == nd && (!any_final || tok[i].x == d->graph->final_state);
+    if (st_frame) st_frame[s] = frame_of[i];
+    if (st_state) st_state[s] = (int32_t)(std::lower_bound(pos.begin(), pos.end(), tok[i].x) - pos.begin());
+    if (st_cost) memcpy(&st_cost[s], &tok[i].y, 4);
+  }
+  std::vector<int32_t> idx;
+  idx.reserve((size_t)na);
+  for (int i = 0; i < n_link; ++i)
+    if (lk[i].w && new_id[lk[i].x] >= 0 && new_id[lk[i].y] >= 0) idx.push_back(i);
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return new_id[lk[a].x] < new_id[lk[b].x]; });
+  for (int k = 0; k < na; ++k) {
+    const int i = idx[k];
+    if (a_src) a_src[k] = new_id[lk[i].x];
+    if (a_dst) a_dst[k] = new_id[lk[i].y];
+    if (a_ilabel) a_ilabel[k] = at[i].x;
+    if (a_olabel) a_olabel[k] = at[i].y;
+    if (a_graph) memcpy(&a_graph[k], &at[i].z, 4);
+    if (a_acoustic) memcpy(&a_acoustic[k], &at[i].w, 4);
   }
   return WFST_OK;
 }

@@ -42,6 +42,7 @@ constexpr uint32_t kFlagOutEps = 0x80000000u;     // state has outgoing input-ep
 constexpr uint32_t kFlagEpsTarget = 0x40000000u;  // some input-epsilon arc enters the state
 constexpr uint32_t kFlagMask = kFlagOutEps | kFlagEpsTarget;
 constexpr uint32_t kEpsWon = 0x80000000u;         // in a packed eps-table value: won by an epsilon arc
+constexpr uint32_t kEpsOutBit = 0x40000000u;      // in a packed eps-table value: the state has epsilon arcs out
 // token/record flag bits from an arc's next_eps word
 __host__ __device__ inline uint32_t flags_of(uint32_t next_eps) {
   return (next_eps & kFlagOutEps) | ((next_eps & 0x7FFFFFFFu) ? kFlagEpsTarget : 0u);
@@ -54,7 +55,7 @@ constexpr unsigned long long kEmptyVal = ~0ull;
 
 // error bits (ChanCtl::error)
 constexpr int kErrTableFull = 1, kErrArenaFull = 2, kErrFrontierFull = 4, kErrWorklistFull = 8,
-              kErrFramesFull = 16, kErrBucketFull = 32;
+              kErrFramesFull = 16, kErrBucketFull = 32, kErrLinksFull = 64;
 
 // ---- per-channel control block (one 128-byte line each) ----------------------------------
 struct __attribute__((aligned(128))) ChanCtl {
@@ -74,7 +75,9 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t peak_tokens;
   int32_t tile_start;    // first entry of this channel's tiles in tile_chan[] for the coming frame
   unsigned long long cnt_N, cnt_E, cnt_Z, cnt_tok, cnt_rec;  // work counters since init
-  unsigned long long pad1[3];
+  int32_t link_count;    // lattice mode: forward links recorded so far (atomicAdd)
+  int32_t pad2;
+  unsigned long long pad1[2];
 };
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
 
@@ -127,6 +130,16 @@ struct DecoderDev {
   int32_t *eps_occ_list;        // [c][wl_cap] ordinals touched this frame
   int32_t *eps_won_list;        // [c][wl_cap] ordinals whose token an epsilon arc won this frame
   int4 *worklist;               // [c][2][wl_cap] {eps-table slot, state, cost bits, 0}
+  // lattice mode (wfst_limits.lattice_links > 0): every forward link the reference would hold after
+  // FinalizeDecoding is among links[c][0..link_count): {source token, destination token, arc, keep};
+  // segment k = links whose destination is on frame k = [link_off[k], link_off[k+1]);
+  // extra[c][token] = orderable extra_cost (base-inl.h:482-572) filled by lattice_prune_kernel.
+  int4 *links;
+  int4 *link_attr;              // {ilabel, olabel, graph cost bits, acoustic cost bits} of surviving links
+  int32_t *link_off;
+  uint32_t *extra;
+  int64_t link_cap;
+  int32_t lattice;
   FrameCtl *fctl;               // [n_groups]
   TileDesc *tiles;              // [n_groups][tile_cap] tiles of the coming frame
   int32_t tile_cap;
@@ -159,6 +172,7 @@ void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, i
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int do_prep,
                     int group, int par, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
+void launch_lattice_prune(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_best_path(const DecoderDev &D, const int32_t *chan_list_dev, int n, int use_final,
                       int cap, int32_t *ilabel, int32_t *olabel, float *graph, float *ac,
                       int32_t *n_hops, int32_t *chain_scratch, hipStream_t s);

@@ -345,12 +345,15 @@ __global__ __launch_bounds__(256) void plan_kernel(DecoderDev D, int chan_off, i
 
 // insert_kernel: a fixed grid of workgroups pulls the planned items (first gridDim.x statically,
 // then by ticket); 256 threads, dynamic LDS = lds_slots * 12 bytes.
+// kLat = lattice mode (forward links recorded); the best-path instantiation carries none of it.
+template <bool kLat>
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, int group, int par) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int SLmax = D.lds_slots;
   u64 *vals = reinterpret_cast<u64 *>(smem);
   int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)SLmax * 8);
+  int32_t *tidx = reinterpret_cast<int32_t *>(smem + (size_t)SLmax * 12);  // lattice mode only
   // one struct, a multiple of 16 bytes, so the dynamic LDS region behind it stays 16-byte aligned
   // (64-bit LDS atomics on a misaligned table are replayed: cdna_hip_programming.md Guideline 17)
   struct __attribute__((aligned(16))) InsertShared {
@@ -482,6 +485,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
       for (int k = 0; k < kInsertUnroll; ++k) {
         bool winner = false;
         u64 packed = 0;
+        uint32_t wslot = 0;
         if (__int_as_float(r[k].y) < cutoff) {
           const uint32_t h = hash32(r[k].x);
           if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
               if (kk == kEmptyKey) break;
               slot = (slot + 1) & mask;
             }
+            wslot = slot;
           }
         }
         const u64 wm = __ballot(winner);
@@ -505,6 +510,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
         if (winner) {
           idx = base + gpos + wb + lane_rank(wm);
           tok[idx] = r[k];  // {state, cost, source token, arc | flags}
+          if (kLat) tidx[wslot] = idx;
           const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
           best = b < best ? b : best;
         }
@@ -532,6 +538,42 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
           const int wp = (int)(ob >> 32) + lane_rank(sm);
           if (wp < D.wl_cap) wl[wp] = make_int4(0, r[k].x, r[k].y, 0);
           else atomicOr(&ctl->error, kErrWorklistFull);
+        }
+      }
+    }
+    // pass 3 (lattice mode): every surviving candidate is a forward link of the lattice
+    // (base-inl.h:340-341), source token -> the token that won its next state
+    if (kLat) {
+      __syncthreads();
+      int4 *links = D.links + (size_t)c * D.link_cap;
+      for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
+#pragma unroll
+        for (int k = 0; k < kInsertUnroll; ++k) {
+          const int4 r = load_rec(i0 + k * kInsertThreads + tid);
+          bool live = false;
+          int dst = 0;
+          if (__int_as_float(r.y) < cutoff) {
+            const uint32_t h = hash32(r.x);
+            if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
+              uint32_t slot = lds_slot_of(h, log2grp, log2sl);
+              for (int q = 0; q < SL; ++q) {
+                const int32_t kk = keys[slot];
+                if (kk == r.x) { live = true; dst = tidx[slot]; break; }
+                if (kk == kEmptyKey) break;
+                slot = (slot + 1) & mask;
+              }
+            }
+          }
+          const u64 lm = __ballot(live);
+          if (!lm) continue;
+          int lb = 0;
+          if (lane == 0) lb = atomicAdd(&ctl->link_count, __popcll(lm));
+          lb = __shfl(lb, 0, 64);
+          if (live) {
+            const int lp = lb + lane_rank(lm);
+            if ((int64_t)lp < D.link_cap) links[lp] = make_int4(r.z, dst, (int)((uint32_t)r.w & kArcMask), 0);
+            else atomicOr(&ctl->error, kErrLinksFull);
+          }
         }
       }
     }
@@ -578,6 +620,7 @@ struct BoundaryShared {
 // ProcessNonemitting to its fixpoint (base-inl.h:383-430) on the channel's direct-mapped epsilon
 // table, then write the arena records of the tokens an epsilon arc created or improved.  On entry
 // sh.wl_n[0] seeds are in worklist[0], sh.wl_n[1] == 0, sh.nnew / sh.occ continue the counters.
+template <bool kLat>
 __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, u64 *nZ_out) {
   const int tid = threadIdx.x;
   u64 *vals = D.eps_vals + (size_t)c * D.ecap;
@@ -636,7 +679,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
           // FindOrAddToken (base-inl.h:88-136): one atomicMin on the state's own slot.  kEpsWon in
           // the low word makes an emitting arc win an exact cost tie, as the reference's
           // first-arrival rule does (emitting arcs are processed before the closure).
-          const u64 packed = ((u64)otot << 32) | kEpsWon | (uint32_t)a;
+          const u64 packed = ((u64)otot << 32) | kEpsWon | (((uint32_t)arc.y & kFlagOutEps) ? kEpsOutBit : 0u) | (uint32_t)a;
           const u64 old = atomicMin(&vals[ord], packed);
           if (packed < old) {
             if (old == kEmptyVal) {  // a state no emitting arc reached: new token
@@ -688,7 +731,8 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
       const u64 v = ld_agent(&vals[od[k]]);
       const int idx = ld_agent(&toki[od[k]]);
       const int32_t state = D.g.eps_target_state[od[k]];
-      tok[idx] = make_int4(state, __float_as_int(o2f((uint32_t)(v >> 32))), kPrevUnresolved, (int)((uint32_t)v & kArcMask));
+      tok[idx] = make_int4(state, __float_as_int(o2f((uint32_t)(v >> 32))), kPrevUnresolved,
+                           (int)(((uint32_t)v & kArcMask) | kFlagEpsTarget | (((uint32_t)v & kEpsOutBit) ? kFlagOutEps : 0u)));
       const u64 b = (v & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
       best = b < best ? b : best;
     }
@@ -697,6 +741,31 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
   if ((tid & 63) == 0) sh.red64[tid >> 6] = best;
   __syncthreads();  // every read of the table above is done before it is cleared
   if (tid == 0) dbg_phase(D, 2, tq);
+  if (kLat && fits) {
+    // Forward links of the epsilon arcs (base-inl.h:421-422): the reference regenerates a token's
+    // links each time it is re-processed, so what remains are the links computed from its FINAL
+    // cost.  Every token of the frame being built with epsilon arcs out and cost < cutoff emits them.
+    int4 *links = D.links + (size_t)c * D.link_cap;
+    const int n_frame = sh.nnew;
+    for (int i = tid; i < n_frame; i += kBT) {
+      const int4 T = tok[base + i];
+      if (!((uint32_t)T.w & kFlagOutEps)) continue;
+      const float cost = __int_as_float(T.y);
+      if (!(cost < cutoff)) continue;
+      const int neps = (int)((uint32_t)D.g.arcs[T.x].x & kEpsMask);
+      for (int e = 0; e < neps; ++e) {
+        const int a = T.x + 1 + e;
+        const int4 arc = D.g.arcs[a];
+        const float tot = cost + __int_as_float(arc.z);
+        if (!(tot < cutoff)) continue;
+        const int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;
+        const int lp = atomicAdd(&D.ctl[c].link_count, 1);
+        if ((int64_t)lp < D.link_cap) links[lp] = make_int4(base + i, ld_agent(&toki[ord]), a, 0);
+        else atomicOr(&sh.err, kErrLinksFull);
+      }
+    }
+    __syncthreads();
+  }
   for (int i = tid; i < nocc; i += kBT) vals[occ[i]] = kEmptyVal;
   if (tid == 0) {
     u64 b = sh.red64[0];
@@ -708,6 +777,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
   if (tid == 0) dbg_phase(D, 3, tq);
 }
 
+template <bool kLat>
 __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, BoundaryShared &sh) {
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long tq = wall_clock64();
@@ -727,7 +797,7 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
   __syncthreads();
   if (tid == 0) dbg_phase(D, 0, tq);
   u64 nZ = 0;
-  epsilon_closure(D, c, sh, base, cutoff, &nZ);
+  epsilon_closure<kLat>(D, c, sh, base, cutoff, &nZ);
   tq = wall_clock64();
   nZ = wave_sum_u64(nZ);
   if (lane == 0) sh.red64[tid >> 6] = nZ;
@@ -743,6 +813,7 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
     else {
       D.frame_off[(size_t)c * (D.max_frames + 2) + f + 2] = base + nf;
       D.cutoff_hist[(size_t)c * (D.max_frames + 2) + f + 1] = cutoff;
+      if (kLat) D.link_off[(size_t)c * (D.max_frames + 3) + f + 2] = min(ctl->link_count, (int)D.link_cap);
     }
     if (sh.best < ctl->best_next) ctl->best_next = sh.best;
     ctl->cnt_Z += z;
@@ -915,12 +986,13 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
   if (tid == 0) dbg_phase(D, 5, tq);
 }
 
+template <bool kLat>
 __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_t *target, int do_prep, int chan_off,
                                                       int group, int par) {
   __shared__ BoundaryShared sh;
   const int c = blockIdx.x + chan_off;
   ChanCtl *ctl = D.ctl + c;
-  if (ctl->active) finalize_frame(D, c, ctl, sh);
+  if (ctl->active) finalize_frame<kLat>(D, c, ctl, sh);
   __syncthreads();
   if (do_prep) prep_frame(D, c, ctl, target, sh, group, par);  // par: parity of the step it prepares
 }
@@ -959,12 +1031,17 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
   }
   __syncthreads();
   u64 nZ = 0;
-  epsilon_closure(D, c, sh, 0, D.beam, &nZ);  // ProcessNonemitting(_config._beam)
+  if (D.lattice) epsilon_closure<true>(D, c, sh, 0, D.beam, &nZ);  // ProcessNonemitting(_config._beam)
+  else epsilon_closure<false>(D, c, sh, 0, D.beam, &nZ);
   if (tid == 0) {
     int nf = sh.nnew;
     if (sh.err || nf > D.max_tok || nf > D.arena_cap) nf = 0;
     D.frame_off[(size_t)c * (D.max_frames + 2) + 0] = 0;
     D.frame_off[(size_t)c * (D.max_frames + 2) + 1] = nf;
+    if (D.lattice) {
+      D.link_off[(size_t)c * (D.max_frames + 3) + 0] = 0;
+      D.link_off[(size_t)c * (D.max_frames + 3) + 1] = min(ctl->link_count, (int)D.link_cap);
+    }
     D.cutoff_hist[(size_t)c * (D.max_frames + 2) + 0] = D.beam;
     const u64 root = ((u64)f2o(0.0f) << 32) | 0u;
     ctl->best_next = sh.best < root ? sh.best : root;
@@ -1117,6 +1194,128 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
 }
 
 // =========================================================================================
+// lattice_prune_kernel: FinalizeDecoding (PruneForwardLinksFinal + PruneForwardLinks +
+// PruneTokensForFrame, base-inl.h:482-607,725-847) as an edge-parallel backward pass over the
+// recorded forward links; one 1024-thread workgroup per channel.
+//   extra[t]  = min over t's links of (extra[next] + ((cost_t + ac) + graph - cost_next)), links with
+//               more than lattice_beam dropped; last frame seeded with cost + final_cost - best.
+//   links[].w = 1 for a surviving link; a token survives iff its extra is finite (<= lattice_beam).
+// The reference reaches the same fixpoint by sweeping token lists "while changed"; min is
+// order-independent, so atomicMin relaxation gives the same values (its last-frame loop stops at
+// changes <= 1e-5, ours at 0).
+// =========================================================================================
+__global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const int32_t *chans) {
+  const int c = chans ? chans[blockIdx.x] : blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const ChanCtl *ctl = D.ctl + c;
+  const int nd = ctl->n_decoded;
+  const int4 *tok = D.tok + (size_t)c * D.arena_cap;
+  int4 *links = D.links + (size_t)c * D.link_cap;
+  int4 *attr = D.link_attr + (size_t)c * D.link_cap;
+  uint32_t *extra = D.extra + (size_t)c * D.arena_cap;
+  const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
+  const int32_t *loff = D.link_off + (size_t)c * (D.max_frames + 3);
+  const float *ll = D.ll_base[c];
+  const float kInf = __builtin_huge_valf();
+  const uint32_t kInfO = f2o(kInf);
+  __shared__ u64 s_red[2][kBW];
+  __shared__ int s_changed;
+  if (ctl->error) return;
+  // (extra[] was filled with +inf by lattice_fill_kernel: plain stores and the memory-side atomics
+  // below must not meet inside one launch)
+  // ComputeFinalCosts (base-inl.h:670-720) over the last frame
+  u64 b_all = ~0ull, b_fin = ~0ull;
+  for (int i = foff[nd] + tid; i < foff[nd + 1]; i += kBT) {
+    const int4 t = tok[i];
+    const u64 v = (u64)f2o(__int_as_float(t.y));
+    b_all = v < b_all ? v : b_all;
+    if (t.x == D.g.final_state) b_fin = v < b_fin ? v : b_fin;
+  }
+  b_all = wave_min_u64(b_all);
+  b_fin = wave_min_u64(b_fin);
+  if (lane == 0) { s_red[0][wave] = b_all; s_red[1][wave] = b_fin; }
+  __syncthreads();
+  for (int w = 0; w < kBW; ++w) { b_all = s_red[0][w] < b_all ? s_red[0][w] : b_all; b_fin = s_red[1][w] < b_fin ? s_red[1][w] : b_fin; }
+  const bool any_final = b_fin != ~0ull;
+  const float final_best = o2f((uint32_t)(any_final ? b_fin : b_all));
+  for (int i = foff[nd] + tid; i < foff[nd + 1]; i += kBT) {
+    const int4 t = tok[i];
+    const float final_cost = (!any_final || t.x == D.g.final_state) ? 0.0f : kInf;
+    atomicExch(&extra[i], f2o(__int_as_float(t.y) + final_cost - final_best));  // base-inl.h:775
+  }
+  __syncthreads();
+
+  // link_extra of link L given the current extra of its destination (base-inl.h:524-526, 782-784)
+  auto link_extra = [&](const int4 L, int k_src_frame, bool eps) -> float {
+    const int4 S = tok[L.x], Dd = tok[L.y];
+    const int4 A = D.g.arcs[L.z];
+    const float ac = eps ? 0.0f : -ll[(size_t)k_src_frame * D.stride + A.x];
+    const float ed = o2f(ld_agent(&extra[L.y]));
+    return ed + (((__int_as_float(S.y) + ac) + __int_as_float(A.z)) - __int_as_float(Dd.y));
+  };
+  for (int k = nd; k >= 0; --k) {
+    const int fk = foff[k], fk1 = foff[k + 1];
+    // (A) emitting links frame k -> k+1 (in segment k+1, source on frame k)
+    if (k < nd) {
+      for (int i = loff[k + 1] + tid; i < loff[k + 2]; i += kBT) {
+        const int4 L = links[i];
+        if (L.x >= fk1) continue;  // an epsilon link inside frame k+1
+        float le = link_extra(L, k, false);
+        if (le > D.lattice_beam) continue;
+        if (le < 0.0f) le = 0.0f;
+        atomicMin(&extra[L.x], f2o(le));
+      }
+      __syncthreads();
+    }
+    // (B) epsilon links inside frame k (segment k, source on frame k), to the fixpoint
+    for (int round = 0; round < 4096; ++round) {
+      if (tid == 0) s_changed = 0;
+      __syncthreads();
+      for (int i = loff[k] + tid; i < loff[k + 1]; i += kBT) {
+        const int4 L = links[i];
+        if (L.x < fk) continue;  // an emitting link from frame k-1
+        float le = link_extra(L, k, true);
+        if (le > D.lattice_beam) continue;
+        if (le < 0.0f) le = 0.0f;
+        const uint32_t o = f2o(le);
+        if (o < atomicMin(&extra[L.x], o)) s_changed = 1;
+      }
+      __syncthreads();
+      const int ch = s_changed;
+      __syncthreads();
+      if (!ch) break;
+    }
+    // last frame: tokens worse than lattice_beam are pruned (base-inl.h:815-816)
+    if (k == nd) {
+      for (int i = fk + tid; i < fk1; i += kBT)
+        if (o2f(ld_agent(&extra[i])) > D.lattice_beam) atomicExch(&extra[i], kInfO);
+      __syncthreads();
+    }
+    // mark the surviving links whose source is on frame k
+    if (k < nd) {
+      for (int i = loff[k + 1] + tid; i < loff[k + 2]; i += kBT) {
+        const int4 L = links[i];
+        if (L.x >= fk1) continue;
+        const int keep = (link_extra(L, k, false) <= D.lattice_beam) ? 1 : 0;
+        links[i].w = keep;
+        if (keep) {
+          const int4 A = D.g.arcs[L.z];
+          attr[i] = make_int4(D.g.arc_ilabel[L.z], D.g.arc_olabel[L.z], A.z, __float_as_int(-ll[(size_t)k * D.stride + A.x]));
+        }
+      }
+    }
+    for (int i = loff[k] + tid; i < loff[k + 1]; i += kBT) {
+      const int4 L = links[i];
+      if (L.x < fk) continue;
+      const int keep = (link_extra(L, k, true) <= D.lattice_beam) ? 1 : 0;
+      links[i].w = keep;
+      if (keep) attr[i] = make_int4(0, D.g.arc_olabel[L.z], D.g.arcs[L.z].z, __float_as_int(0.0f));
+    }
+    __syncthreads();
+  }
+}
+
+// =========================================================================================
 // launch wrappers
 // =========================================================================================
 static __global__ void set_finalized_kernel(DecoderDev D, const int32_t *chans, int n) {
@@ -1133,14 +1332,17 @@ void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hi
   hipLaunchKernelGGL(expand_kernel, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
 }
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups, hipStream_t s) {
-  const size_t lds = (size_t)D.lds_slots * 12;
+  const size_t lds = (size_t)D.lds_slots * (D.lattice ? 16 : 12);
   hipLaunchKernelGGL(plan_kernel, dim3((chan_cnt + 3) / 4), dim3(256), 0, s, D, chan_off, chan_cnt, group, par);
-  hipLaunchKernelGGL(insert_kernel, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  if (D.lattice) hipLaunchKernelGGL(insert_kernel<true>, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  else hipLaunchKernelGGL(insert_kernel<false>, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
 }
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int do_prep, int group, int par,
                     hipStream_t s) {
-  hipLaunchKernelGGL(closure_kernel, dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off,
-                     group, par);
+  if (D.lattice)
+    hipLaunchKernelGGL(closure_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+  else
+    hipLaunchKernelGGL(closure_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
 }
 void launch_set_finalized(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(set_finalized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, D, chans, n);
@@ -1150,7 +1352,21 @@ void launch_best_path(const DecoderDev &D, const int32_t *chans, int n, int use_
   hipLaunchKernelGGL(best_path_kernel, dim3(n), dim3(kBpThreads), 0, s, D, chans, use_final, cap, ilabel, olabel, graph,
                      ac, n_hops, chain);
 }
+__global__ __launch_bounds__(256) void lattice_fill_kernel(DecoderDev D, const int32_t *chans) {
+  const int c = chans ? chans[blockIdx.x] : blockIdx.x;
+  const ChanCtl *ctl = D.ctl + c;
+  const int n_tok = D.frame_off[(size_t)c * (D.max_frames + 2) + ctl->n_decoded + 1];
+  uint32_t *extra = D.extra + (size_t)c * D.arena_cap;
+  const uint32_t inf_o = f2o(__builtin_huge_valf());
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n_tok; i += gridDim.y * blockDim.x) extra[i] = inf_o;
+}
+void launch_lattice_prune(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
+  hipLaunchKernelGGL(lattice_fill_kernel, dim3(n, 64), dim3(256), 0, s, D, chans);
+  hipLaunchKernelGGL(lattice_prune_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
+}
 int insert_kernel_set_lds(int bytes) {
-  return (int)hipFuncSetAttribute((const void *)insert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  int e = (int)hipFuncSetAttribute((const void *)insert_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e) return e;
+  return (int)hipFuncSetAttribute((const void *)insert_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 }  // namespace wfst

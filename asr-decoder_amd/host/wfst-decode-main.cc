@@ -3,7 +3,11 @@
 // (graph + decoder config + per-utterance matrices -> word ids, scores, real-time factor), with
 // plain files instead of Kaldi tables:
 //
-//   wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] CONFIG GRAPH LOGLIKES [WORDS_OUT]
+//   wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--lattice-out=FILE [--lattice-links=N]]
+//               CONFIG GRAPH LOGLIKES [WORDS_OUT]
+//   --lattice-out  also write GetRawLattice of every utterance as text: "KEY", then one line
+//                  "src dst ilabel olabel graph_cost acoustic_cost" per arc, one line "state" per
+//                  final state, then an empty line (lattice mode: N forward links kept per utterance)
 //
 //   CONFIG    text file of --beam=.. --max-active=.. lines (reference option names)
 //   GRAPH     flat graph in the reference format (Fst::ReadFst)
@@ -61,16 +65,21 @@ int main(int argc, char **argv) {
     std::string tid2pdf_file;
     int batch = 128;
     bool single = false;
+    std::string lattice_file;
+    long long lattice_links = 1ll << 22;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
       std::string a = argv[i];
       if (a.compare(0, 10, "--tid2pdf=") == 0) tid2pdf_file = a.substr(10);
       else if (a.compare(0, 8, "--batch=") == 0) batch = atoi(a.c_str() + 8);
       else if (a == "--single-stream") single = true;
+      else if (a.compare(0, 14, "--lattice-out=") == 0) lattice_file = a.substr(14);
+      else if (a.compare(0, 16, "--lattice-links=") == 0) lattice_links = atoll(a.c_str() + 16);
       else pos.push_back(a);
     }
     if (pos.size() < 3) {
-      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
+      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--lattice-out=FILE "
+                   "[--lattice-links=N]] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
       return 1;
     }
     LatticeFasterDecoderConfig opt;
@@ -90,6 +99,28 @@ int main(int argc, char **argv) {
     std::ofstream fout;
     if (pos.size() > 3) fout.open(pos[3].c_str());
     std::ostream &out = pos.size() > 3 ? (std::ostream &)fout : std::cout;
+
+    std::ofstream lat_out;
+    if (!lattice_file.empty()) {
+      lat_out.open(lattice_file.c_str());
+      lat_out.precision(9);
+    }
+    wfst_limits limits = {0, 0, 0, 0};  // zeros = the library defaults
+    limits.lattice_links = lattice_file.empty() ? 0 : lattice_links;
+    auto emit_lattice = [&](const Utt &u, Lattice &lat, bool ok) {
+      lat_out << u.key << '\n';
+      if (ok)
+        for (StateId s = 0; s < lat.NumStates(); ++s) {
+          LatticeState *st = lat.GetState(s);
+          for (size_t i = 0; i < st->GetArcSize(); ++i) {
+            LatticeArc *a = st->GetArc(i);
+            lat_out << s << ' ' << a->_to << ' ' << a->_input << ' ' << a->_output << ' ' << a->_w.Value1() << ' '
+                    << a->_w.Value2() << '\n';
+          }
+          if (st->IsFinal()) lat_out << s << '\n';
+        }
+      lat_out << '\n';
+    };
 
     std::vector<Utt> utts;
     for (Utt u; ReadUtt(in, &u);) utts.push_back(u);
@@ -114,7 +145,7 @@ int main(int argc, char **argv) {
       ++num_success;
     };
     if (single) {  // the reference's shape: one decoder object, one utterance at a time
-      GpuLatticeDecoder decode(&fst, opt);
+      GpuLatticeDecoder decode(&fst, opt, &limits);
       for (const Utt &u : utts) {
         HostMatrixDecodable decodable(u);
         decode.InitDecoding();
@@ -123,9 +154,14 @@ int main(int argc, char **argv) {
         Lattice best;
         bool ok = decode.GetBestPath(&best);
         emit(u, best, ok);
+        if (lat_out.is_open()) {
+          Lattice lat;
+          bool lok = decode.GetRawLattice(&lat);
+          emit_lattice(u, lat, lok);
+        }
       }
     } else {  // the MI355X shape: `batch` utterances per pass
-      GpuBatchDecoder decode(&fst, opt, batch);
+      GpuBatchDecoder decode(&fst, opt, batch, &limits);
       for (size_t b0 = 0; b0 < utts.size(); b0 += batch) {
         const int n = (int)std::min<size_t>(batch, utts.size() - b0);
         std::vector<int> ch(n), ready(n);
@@ -144,6 +180,11 @@ int main(int argc, char **argv) {
         std::vector<bool> ok;
         decode.GetBestPaths(ch, &best, &ok);
         for (int i = 0; i < n; ++i) emit(utts[b0 + i], best[i], ok[i]);
+        for (int i = 0; i < n && lat_out.is_open(); ++i) {
+          Lattice lat;
+          bool lok = decode.GetRawLattice(i, &lat);
+          emit_lattice(utts[b0 + i], lat, lok);
+        }
       }
     }
     double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

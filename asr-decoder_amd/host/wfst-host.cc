@@ -198,13 +198,42 @@ bool GpuLatticeDecoder::GetBestPath(Lattice *ofst, bool use_final_probs) {
   return false;
 }
 
-bool GpuLatticeDecoder::GetRawLattice(Lattice *ofst, bool) {
+// GetRawLattice (base-inl.h:869-975) of one channel through the C ABI.  Served after
+// FinalizeDecoding by a decoder created in lattice mode (wfst_limits.lattice_links > 0).
+static bool RawLatticeOfChannel(wfst_decoder *dec, int channel, Lattice *ofst, bool use_final_probs) {
   ofst->DeleteStates();
-  Warn("GetRawLattice: the state-level lattice is not produced by the best-path device decoder");
-  return false;
+  int32_t ns = 0, na = 0;
+  int rc = wfst_decoder_get_raw_lattice(dec, channel, use_final_probs ? 1 : 0, 0, 0, &ns, &na, nullptr, nullptr, nullptr,
+                                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc == WFST_E_STATE) { Warn(wfst_last_error()); return false; }
+  if (rc != WFST_OK && !(rc == WFST_E_CAPACITY && ns > 0)) Fatal("GetRawLattice");
+  if (ns == 0) {
+    if (!use_final_probs)  // base-inl.h:879-884
+      Warn("You cannot call FinalizeDecoding() and then call GetRawLattice() with use_final_probs == false");
+    return false;
+  }
+  std::vector<int32_t> fin(ns), src(na), dst(na), il(na), ol(na);
+  std::vector<float> g(na), ac(na);
+  if (wfst_decoder_get_raw_lattice(dec, channel, 1, ns, na, &ns, &na, fin.data(), nullptr, nullptr, nullptr, src.data(),
+                                   dst.data(), il.data(), ol.data(), g.data(), ac.data()) != WFST_OK)
+    Fatal("GetRawLattice");
+  for (int s = 0; s < ns; ++s) {
+    StateId id = ofst->AddState();
+    if (fin[s]) ofst->SetFinal(id);
+  }
+  ofst->SetStart(0);
+  for (int k = 0; k < na; ++k) ofst->AddArc(src[k], LatticeArc(il[k], ol[k], dst[k], LatticeWeight(g[k], ac[k])));
+  return ofst->NumStates() > 0;
+}
+
+bool GpuLatticeDecoder::GetRawLattice(Lattice *ofst, bool use_final_probs) {
+  return RawLatticeOfChannel(_dec, 0, ofst, use_final_probs);
 }
 
 // ---- batch decoder ------------------------------------------------------------------------------
+bool GpuBatchDecoder::GetRawLattice(int channel, Lattice *ofst, bool use_final_probs) {
+  return RawLatticeOfChannel(_dec, channel, ofst, use_final_probs);
+}
 GpuBatchDecoder::GpuBatchDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, int n_channels,
                                  const wfst_limits *limits, void *hip_stream)
     : _dec(nullptr), _n(n_channels) {

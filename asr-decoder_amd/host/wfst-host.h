@@ -179,7 +179,8 @@ class GpuLatticeDecoder : public DecoderItf {
   // past the end, base-inl.h:615; that landmine is not reproduced.)
   bool Decode(AmInterface *decodable) override;
   bool GetBestPath(Lattice *ofst, bool use_final_probs = true) override;
-  bool GetRawLattice(Lattice *ofst, bool use_final_probs = true) override;  // not on this path yet: false
+  // after FinalizeDecoding, decoder created with wfst_limits.lattice_links > 0 (else: warning + false)
+  bool GetRawLattice(Lattice *ofst, bool use_final_probs = true) override;
 
  private:
   void Pull(AmInterface *decodable);
@@ -203,6 +204,7 @@ class GpuBatchDecoder {
   void FinalizeDecoding(const std::vector<int> &channels = std::vector<int>());
   int NumFramesDecoded(int channel) const;
   bool GetBestPath(int channel, Lattice *ofst, bool use_final_probs = true);
+  bool GetRawLattice(int channel, Lattice *ofst, bool use_final_probs = true);
   void GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
                     bool use_final_probs = true);
   wfst_decoder *Handle() { return _dec; }

@@ -26,7 +26,7 @@ SYMBOLS = [
     "wfst_decoder_advance_host", "wfst_decoder_finalize", "wfst_decoder_sync",
     "wfst_decoder_num_frames_decoded", "wfst_decoder_get_best_path", "wfst_lattice_to_vector",
     "wfst_decoder_get_stats", "wfst_decoder_get_frontier", "wfst_decoder_set_profiling",
-    "wfst_decoder_get_profile",
+    "wfst_decoder_get_profile", "wfst_decoder_get_raw_lattice",
 ]
 
 
@@ -51,7 +51,8 @@ class Config(C.Structure):
 
 
 class Limits(C.Structure):
-    _fields_ = [("max_frames", C.c_int32), ("max_tokens_per_frame", C.c_int32), ("arena_tokens", C.c_int64)]
+    _fields_ = [("max_frames", C.c_int32), ("max_tokens_per_frame", C.c_int32), ("arena_tokens", C.c_int64),
+                ("lattice_links", C.c_int64)]
 
 
 _lib = None
@@ -140,10 +141,11 @@ class Graph:
 class BatchDecoder:
     """A batch of decoding channels (one channel == one reference decoder object)."""
 
-    def __init__(self, graph, cfg, n_channels, max_frames=0, max_tokens_per_frame=0, arena_tokens=0, stream=None):
+    def __init__(self, graph, cfg, n_channels, max_frames=0, max_tokens_per_frame=0, arena_tokens=0, stream=None,
+                 lattice_links=0):
         self.graph = graph
         self.n = int(n_channels)
-        lim = Limits(int(max_frames), int(max_tokens_per_frame), int(arena_tokens))
+        lim = Limits(int(max_frames), int(max_tokens_per_frame), int(arena_tokens), int(lattice_links))
         h = C.c_void_p()
         _check(lib().wfst_decoder_create(graph.h, C.byref(cfg), self.n, C.byref(lim),
                                          C.c_void_p(stream) if stream else None, C.byref(h)))
@@ -231,6 +233,27 @@ class BatchDecoder:
         s = (C.c_int64 * 8)()
         _check(lib().wfst_decoder_get_stats(self.h, int(channel), s))
         return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], records=s[6])
+
+    def raw_lattice(self, channel, use_final_probs=True):
+        """GetRawLattice of a finalized channel (lattice mode).  Returns a dict of numpy arrays, or
+        None for the reference's `return false`."""
+        ns, na = C.c_int32(0), C.c_int32(0)
+        rc = lib().wfst_decoder_get_raw_lattice(self.h, int(channel), int(bool(use_final_probs)), 0, 0, C.byref(ns),
+                                                C.byref(na), *([None] * 10))
+        if rc != WFST_OK and not (rc == -4 and ns.value > 0):  # -4 with sizes = "give me bigger buffers"
+            _check(rc)
+        if ns.value == 0:
+            return None
+        S, A = ns.value, na.value
+        fin, fr, gs = (np.zeros(S, np.int32) for _ in range(3))
+        co = np.zeros(S, np.float32)
+        src, dst, il, ol = (np.zeros(A, np.int32) for _ in range(4))
+        gr, ac = np.zeros(A, np.float32), np.zeros(A, np.float32)
+        _check(lib().wfst_decoder_get_raw_lattice(self.h, int(channel), int(bool(use_final_probs)), S, A, C.byref(ns),
+                                                  C.byref(na), _i32(fin), _i32(fr), _i32(gs), _f32(co), _i32(src), _i32(dst),
+                                                  _i32(il), _i32(ol), _f32(gr), _f32(ac)))
+        return dict(n_states=S, st_final=fin, st_frame=fr, st_state=gs, st_cost=co, a_src=src, a_dst=dst, a_ilabel=il,
+                    a_olabel=ol, a_graph=gr, a_acoustic=ac)
 
     def set_profiling(self, on):
         _check(lib().wfst_decoder_set_profiling(self.h, int(bool(on))))

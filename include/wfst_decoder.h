@@ -59,6 +59,9 @@ typedef struct wfst_limits {
   int32_t max_frames;           /* frames per utterance                     (default 4096)    */
   int32_t max_tokens_per_frame; /* distinct states reached in one frame     (default 32768)   */
   int64_t arena_tokens;         /* tokens kept per utterance for traceback  (default 4194304) */
+  int64_t lattice_links;        /* > 0: LATTICE MODE -- record every forward link (capacity per
+                                   utterance) so that FinalizeDecoding can prune by lattice_beam and
+                                   GetRawLattice can be served; 0 (default): best path only        */
 } wfst_limits;
 
 /* Original on-disk / in-memory graph records of the reference format. */
@@ -158,6 +161,22 @@ int wfst_lattice_to_vector(const int32_t *ilabel, const int32_t *olabel, const f
  * traversed, Z epsilon arcs traversed, tokens kept, peak tokens per frame, candidate records
  * bucketed, reserved}.  N and E follow the definitions of the reference loop (base-inl.h:311-347). */
 int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]);
+
+/* GetRawLattice(Lattice*, use_final_probs) (base-inl.h:869-975) of a FINALIZED channel of a
+ * decoder created in lattice mode (wfst_limits.lattice_links > 0): the state-level lattice that is
+ * left after FinalizeDecoding's lattice_beam pruning (base-inl.h:725-847).  States are numbered frame
+ * by frame in a topological order (every arc goes to a higher id; state 0 is the start), like the
+ * reference's TopSortTokens; the numbering inside a frame is implementation defined there too.
+ * Per state: final flag, frame, graph state id, forward cost; per arc (sorted by source):
+ * source, destination, ilabel, olabel, graph cost, acoustic cost.  If a capacity is too small the
+ * needed sizes are returned in n_states/n_arcs with WFST_E_CAPACITY.  n_states == 0 with WFST_OK is
+ * the reference's `return false` (no frames decoded, no token alive, or use_final_probs == 0 after
+ * FinalizeDecoding). */
+int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs,
+                                 int32_t cap_states, int32_t cap_arcs, int32_t *n_states,
+                                 int32_t *n_arcs, int32_t *st_final, int32_t *st_frame,
+                                 int32_t *st_state, float *st_cost, int32_t *a_src, int32_t *a_dst,
+                                 int32_t *a_ilabel, int32_t *a_olabel, float *a_graph, float *a_acoustic);
 
 /* Kernel timing for the roofline report: while enabled, every expand / boundary launch of
  * wfst_decoder_advance is bracketed by HIP events recorded on the decoder's own stream.

@@ -183,9 +183,85 @@ class OracleDecoder(_Base):
 
         self._decode = call
 
+    def set_order_free(self, on):
+        """See oracle/wfst_oracle.c `g_order_free`: apply each frame's FINAL next_cutoff to every arc
+        (what the GPU computes) instead of the reference's visiting-order-dependent evolving one."""
+        self.lib.oracle_set_order_free(int(bool(on)))
+
     def decode(self, *a, **kw):
         r = super().decode(*a, **kw)
         e = self._tls.extra
         r.extra = dict(N=int(e[0]), E=int(e[1]), Z=int(e[2]), tokens_created=int(e[3]), links_created=int(e[4]),
                        ties=int(e[5]), quirk_hops=int(e[6]))
         return r
+
+
+@dataclass
+class RawLattice:
+    ok: bool
+    n_states: int
+    start: int
+    st_final: np.ndarray
+    a_src: np.ndarray
+    a_dst: np.ndarray
+    a_il: np.ndarray
+    a_ol: np.ndarray
+    a_graph: np.ndarray
+    a_ac: np.ndarray
+    st_frame: np.ndarray | None = None   # oracle / GPU only
+    st_gstate: np.ndarray | None = None
+    st_cost: np.ndarray | None = None
+
+    def arc_multiset(self):
+        """Isomorphism-invariant view: sorted rows (ilabel, olabel, graph bits, acoustic bits)."""
+        k = np.stack([self.a_il, self.a_ol, self.a_graph.view(np.int32), self.a_ac.view(np.int32)], axis=1)
+        return k[np.lexsort(k.T[::-1])]
+
+    def labelled_arcs(self):
+        """Rows (src frame, src graph state, dst frame, dst graph state, ilabel, olabel, graph bits, ac bits),
+        sorted: equal for two implementations iff their lattices are identical up to state numbering."""
+        f, g = self.st_frame, self.st_gstate
+        k = np.stack([f[self.a_src], g[self.a_src], f[self.a_dst], g[self.a_dst], self.a_il, self.a_ol,
+                      self.a_graph.view(np.int32), self.a_ac.view(np.int32)], axis=1)
+        return k[np.lexsort(k.T[::-1])]
+
+
+def _raw_lattice(lib, name, labelled, graph_handle, cfg, loglikes, tid2pdf, finalize, use_final_probs, max_states, max_arcs):
+    ll = np.ascontiguousarray(loglikes, dtype=np.float32)
+    T, stride = ll.shape
+    n_tid = stride - 1
+    if tid2pdf is not None:
+        tid2pdf = np.ascontiguousarray(tid2pdf, dtype=np.int32)
+        n_tid = int(tid2pdf.shape[0] - 1)
+    ns, na, st = C.c_int(0), C.c_int(0), C.c_int(0)
+    fin = np.zeros(max_states, np.int32)
+    fr = np.zeros(max_states, np.int32)
+    gs = np.zeros(max_states, np.int32)
+    co = np.zeros(max_states, np.float32)
+    src, dst, il, ol = (np.zeros(max_arcs, np.int32) for _ in range(4))
+    gr, ac = np.zeros(max_arcs, np.float32), np.zeros(max_arcs, np.float32)
+    f = getattr(lib, name)
+    f.restype = C.c_int
+    head = [C.c_void_p(graph_handle), C.byref(cfg), _fp(ll), T, stride, _ip(tid2pdf), n_tid, int(bool(finalize)),
+            int(bool(use_final_probs)), max_states, C.byref(ns), C.byref(st), _ip(fin)]
+    if labelled:
+        head += [_ip(fr), _ip(gs), _fp(co)]
+    ok = f(*head, max_arcs, C.byref(na), _ip(src), _ip(dst), _ip(il), _ip(ol), _fp(gr), _fp(ac))
+    S, A = ns.value, na.value
+    if S > max_states or A > max_arcs:
+        raise ValueError("lattice larger than the caps: %d states, %d arcs" % (S, A))
+    return RawLattice(bool(ok), S, st.value, fin[:S].copy(), src[:A].copy(), dst[:A].copy(), il[:A].copy(), ol[:A].copy(),
+                      gr[:A].copy(), ac[:A].copy(), fr[:S].copy() if labelled else None, gs[:S].copy() if labelled else None,
+                      co[:S].copy() if labelled else None)
+
+
+def ref_raw_lattice(ref, graph_handle, cfg, loglikes, tid2pdf=None, finalize=True, use_final_probs=True,
+                    max_states=1 << 20, max_arcs=1 << 21):
+    return _raw_lattice(ref.lib, "ref_raw_lattice", False, graph_handle, cfg, loglikes, tid2pdf, finalize, use_final_probs,
+                        max_states, max_arcs)
+
+
+def oracle_raw_lattice(orc, graph_handle, cfg, loglikes, tid2pdf=None, finalize=True, use_final_probs=True,
+                       max_states=1 << 20, max_arcs=1 << 21):
+    return _raw_lattice(orc.lib, "oracle_raw_lattice", True, graph_handle, cfg, loglikes, tid2pdf, finalize, use_final_probs,
+                        max_states, max_arcs)

@@ -51,6 +51,8 @@ typedef struct Link {
 typedef struct Token {
   float tot_cost, extra_cost; Link *links; struct Token *next; struct Token *backpointer;
   int is_final; /* stands for membership in _final_costs (value is always 0) */
+  int state;    /* graph state (the reference token does not know it; used to label lattice states) */
+  int lat_id;   /* lattice state id during GetRawLattice */
   int tie;      /* audit only: an equal-cost rival arrived after this cost was set */
 } Token;
 typedef struct { Token *toks; int must_prune_forward_links, must_prune_tokens; } TokenList;
@@ -150,6 +152,7 @@ static Elem *hl_insert(HashList *h, int key, Token *val) { /* hash-list-inl.h:12
 static Token *new_token(Decoder *d, float tot, float extra, Link *links, Token *next, Token *bp) {
   Token *t = (Token *)pool_new(&d->tok_pool);
   t->tot_cost = tot; t->extra_cost = extra; t->links = links; t->next = next; t->backpointer = bp; t->is_final = 0; t->tie = 0;
+  t->state = -1; t->lat_id = -1;
   d->num_toks++; d->cnt_tok_created++; return t;
 }
 static Link *new_link(Decoder *d, Token *nt, int il, int ol, float gc, float ac, Link *next) {
@@ -188,6 +191,7 @@ static Elem *find_or_add_token(Decoder *d, int state, int frame_plus_one, float 
   Elem *e = hl_insert(&d->toks, state, NULL);
   if (e->val == NULL) {
     Token *nt = new_token(d, tot_cost, 0.0f, NULL, *toks, bp);
+    nt->state = state;
     *toks = nt; e->val = nt;
     if (changed) *changed = 1;
   } else {
@@ -302,6 +306,15 @@ static void process_nonemitting(Decoder *d, float cutoff) {
 }
 
 /* ProcessEmitting: base-inl.h:246-351 */
+/* "Order-free" variant used ONLY to state what the GPU path computes (tests/test_oracle_lattice.py,
+ * tests/test_gpu_lattice.py).  The reference admits an arc when its cost is below the next_cutoff AS
+ * IT STANDS when the arc is reached (base-inl.h:326-333), so arcs that are above the frame's FINAL
+ * next_cutoff get in or not depending on the hash-list order.  With the flag set the final
+ * next_cutoff is computed first and applied to every arc: the result is the subset of the reference's
+ * tokens/links that does not depend on the visiting order.  Default 0 = the reference's behaviour. */
+static int g_order_free = 0;
+void oracle_set_order_free(int on) { g_order_free = on; }
+
 static float process_emitting(Decoder *d) {
   const Graph *g = d->g;
   int nnetframe = d->num_frames_decoded;
@@ -321,6 +334,18 @@ static float process_emitting(Decoder *d) {
         float tot_score = tok->tot_cost + arc->w - loglike(d, nnetframe, arc->ilabel);
         if (tot_score + adaptive_beam < next_cutoff) next_cutoff = tot_score + adaptive_beam;
       }
+    }
+  }
+  if (g_order_free) {
+    for (Elem *e = final_toks; e; e = e->tail) {
+      int state = e->key; Token *tok = e->val;
+      if (!(tok->tot_cost <= cur_cutoff)) continue;
+      const Arc *arcs = g->arcs + g->off[state]; unsigned n = g->si[state].num_arcs;
+      for (unsigned i = 0; i < n; ++i)
+        if (arcs[i].ilabel != 0) {
+          float tot_cost = tok->tot_cost + -loglike(d, nnetframe, arcs[i].ilabel) + arcs[i].w;
+          if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
+        }
     }
   }
   for (Elem *e = final_toks, *e_tail; e; e = e_tail) {
@@ -482,6 +507,7 @@ static void init_decoding(Decoder *d) {
   d->n_queue = 0; d->n_tmp = 0; d->warned = 0; d->finalized = 0; d->any_final = 0;
   active_resize(d, 1);
   Token *start_tok = new_token(d, 0.0f, 0.0f, NULL, NULL, NULL);
+  start_tok->state = d->g->start;
   d->active[0].toks = start_tok;
   hl_insert(&d->toks, d->g->start, start_tok);
   d->num_frames_decoded = 0; /* set before the closure: it is not read there */
@@ -626,6 +652,103 @@ int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, i
   if (extra) { extra[0] = d->cnt_N; extra[1] = d->cnt_E; extra[2] = d->cnt_Z; extra[3] = d->cnt_tok_created; extra[4] = d->cnt_link_created; extra[5] = tie_hops; extra[6] = quirk_hops; extra[7] = 0; }
 
   /* teardown */
+  clear_active_tokens(d);
+  hl_delete_elems(&d->toks);
+  for (size_t i = 0; i < d->toks.n_blocks; ++i) free(d->toks.blocks[i]);
+  free(d->toks.blocks); free(d->toks.buckets);
+  pool_destroy(&d->tok_pool); pool_destroy(&d->link_pool);
+  free(d->active); free(d->queue); free(d->tmp);
+  return ok;
+}
+
+/* GetRawLattice (base-inl.h:869-975) after one AdvanceDecoding over all frames (+ FinalizeDecoding).
+ * Same outputs as ref_raw_lattice() in oracle/ref_driver.cc plus, per lattice state, the frame and
+ * graph state of its token (st_frame/st_gstate) so that another implementation can be compared
+ * state by state.  State numbering: frame by frame in token-list order (the reference numbers by
+ * TopSortTokens over an unordered_map keyed by pointers, i.e. implementation defined; compare up to
+ * isomorphism).  State 0 is the start token. */
+int oracle_raw_lattice(void *gp, const Config *rc, const float *loglikes, int T, int stride,
+                       const int *tid2pdf, int n_tid, int do_finalize, int use_final_probs,
+                       int max_states, int *n_states, int *start, int *st_final, int *st_frame,
+                       int *st_gstate, float *st_cost, int max_arcs, int *n_arcs, int *a_src, int *a_dst, int *a_il,
+                       int *a_ol, float *a_graph, float *a_ac) {
+  (void)n_tid;
+  Decoder D; memset(&D, 0, sizeof(D));
+  Decoder *d = &D;
+  d->g = (const Graph *)gp; d->cfg = *rc;
+  d->toks.bucket_list_tail = NOBUCKET;
+  d->tok_pool.elem_size = sizeof(Token); d->link_pool.elem_size = sizeof(Link);
+  d->ll = loglikes; d->T = T; d->stride = stride; d->tid2pdf = tid2pdf; d->frames_ready = T;
+  {
+    float fs = (float)rc->max_active * rc->hash_ratio;
+    size_t sz = fs > 1.0e9f ? (size_t)1000 : (size_t)fs;
+    hl_set_size(&d->toks, sz);
+  }
+  init_decoding(d);
+  advance_decoding(d, -1);
+  if (do_finalize) finalize_decoding(d);
+  *n_states = 0; *n_arcs = 0; *start = -1;
+  int ok = 0;
+  const int num_frames = d->n_active - 1;
+  if (!(d->finalized && !use_final_probs) && num_frames > 0) {
+    int any_final = d->any_final;
+    if (!d->finalized && use_final_probs) compute_final_costs(d, 1, &any_final, NULL, NULL);
+    ok = 1;
+    int ns = 0;
+    /* TopSortTokens (base-inl.h:976-1068): positions num_toks-1..0 in list order, an epsilon link to
+     * a token placed earlier moves that token to a fresh position at the end, repeated until stable;
+     * states are numbered by final position.  The reference walks an unordered_map keyed by the
+     * token POINTER, so its numbering inside a frame is not reproducible; this restatement walks the
+     * list in order (any order gives a valid topological numbering -- what the tests check). */
+    for (int f = 0; f <= num_frames && ok; ++f) {
+      if (d->active[f].toks == NULL) { ok = 0; break; }
+      int n = 0;
+      for (Token *t = d->active[f].toks; t; t = t->next) ++n;
+      Token **arr = (Token **)malloc(sizeof(Token *) * (size_t)n);
+      int cur_pos = 0;
+      for (Token *t = d->active[f].toks; t; t = t->next) { arr[cur_pos] = t; t->lat_id = n - (++cur_pos); }
+      size_t qcap = 64, qn = 0, qi = 0;
+      Token **q = (Token **)malloc(sizeof(Token *) * qcap);
+      for (int i = 0; i < n || qi < qn; ++i) {   /* the list once, then the reprocess queue until empty */
+        Token *t = i < n ? arr[i] : q[qi++];
+        for (Link *l = t->links; l; l = l->next)
+          if (l->ilabel == 0 && l->next_tok->lat_id < t->lat_id) {   /* epsilon links stay inside the frame */
+            l->next_tok->lat_id = cur_pos++;
+            if (qn == qcap) { qcap *= 2; q = (Token **)realloc(q, sizeof(Token *) * qcap); }
+            q[qn++] = l->next_tok;
+          }
+      }
+      /* compact the positions of this frame into consecutive state ids (the reference leaves NULL gaps
+       * in its list and skips them) */
+      int *order = (int *)malloc(sizeof(int) * (size_t)(cur_pos > 0 ? cur_pos : 1));
+      for (int i = 0; i < cur_pos; ++i) order[i] = -1;
+      for (int i = 0; i < n; ++i) order[arr[i]->lat_id] = i;
+      for (int i = 0; i < cur_pos; ++i) if (order[i] >= 0) arr[order[i]]->lat_id = ns++;
+      free(order); free(q); free(arr);
+    }
+    if (ok) {
+      int na = 0;
+      for (int f = 0; f <= num_frames; ++f)
+        for (Token *t = d->active[f].toks; t; t = t->next) {
+          const int s = t->lat_id;
+          float final_cost = 0.0f;
+          int is_fin = 0;
+          if (f == num_frames) {
+            if (use_final_probs && any_final) { if (t->is_final) { is_fin = 1; final_cost = 0.0f; } }
+            else is_fin = 1;
+          }
+          if (s < max_states) { st_final[s] = is_fin; st_frame[s] = f; st_gstate[s] = t->state; st_cost[s] = t->tot_cost; }
+          for (Link *l = t->links; l; l = l->next) {
+            if (na < max_arcs) {
+              a_src[na] = s; a_dst[na] = l->next_tok->lat_id; a_il[na] = l->ilabel; a_ol[na] = l->olabel;
+              a_graph[na] = l->graph_cost + final_cost; a_ac[na] = l->acoustic_cost;
+            }
+            ++na;
+          }
+        }
+      *n_states = ns; *n_arcs = na; *start = 0;
+    }
+  }
   clear_active_tokens(d);
   hl_delete_elems(&d->toks);
   for (size_t i = 0; i < d->toks.n_blocks; ++i) free(d->toks.blocks[i]);

@@ -73,9 +73,71 @@ def run_cases(ref, name, g, tid2pdf, utts, cfgs, modes):
     print("wrote %s.npz: %d cases" % (name, k))
 
 
+def run_lattice_cases(ref, name, g, tid2pdf, utts, cfgs, modes):
+    """GetRawLattice (base-inl.h:869-975) of the reference: state numbering is an implementation
+    detail (hash order), so the vector keeps what is invariant -- state / final-state / arc counts
+    and the sorted multiset of (ilabel, olabel, graph cost bits, acoustic cost bits)."""
+    gb, path = graph_bytes(g)
+    h = ref.load_graph(path)
+    out = {"graph": gb, "n_utt": np.int32(len(utts)),
+           "tid2pdf": np.zeros(0, np.int32) if tid2pdf is None else np.asarray(tid2pdf, np.int32)}
+    meta = {"cfgs": cfgs, "modes": modes, "cases": []}
+    for ui, ll in enumerate(utts):
+        out["ll_%d" % ui] = np.asarray(ll, np.float32)
+    k = 0
+    for ci, cd in enumerate(cfgs):
+        for mi, md in enumerate(modes):
+            for ui, ll in enumerate(utts):
+                L = pyoracle.ref_raw_lattice(ref, h, pyoracle.Config(**cd), ll, tid2pdf, **md)
+                out["c%d_counts" % k] = np.array([L.ok, L.n_states, int(L.st_final.sum()), len(L.a_src), L.start], np.int32)
+                out["c%d_arcs" % k] = L.arc_multiset().astype(np.int32)
+                meta["cases"].append({"cfg": ci, "mode": mi, "utt": ui})
+                k += 1
+    ref.free_graph(h)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote %s.npz: %d lattice cases" % (name, k))
+
+
+def lattice_goldens(ref):
+    n_tid, n_pdf, T = 600, 300, 40
+    g = synth.make_hclg_like(600, seed=11, n_tid=n_tid, n_words=500)
+    m = synth.default_tid2pdf(n_tid)
+    utts = [synth.make_loglikes(g, T, n_pdf, m, seed=s, mu=-2.2, sigma=1.0)[0] for s in range(3)]
+    cfgs = [
+        dict(beam=13.0, max_active=1000000, min_active=0, lattice_beam=7.0),
+        dict(beam=13.0, max_active=1000000, min_active=0, lattice_beam=2.0, prune_interval=10),
+        dict(beam=9.0, max_active=300, min_active=50, lattice_beam=5.0, prune_interval=10),
+    ]
+    modes = [dict(finalize=True, use_final_probs=True), dict(finalize=False, use_final_probs=True),
+             dict(finalize=False, use_final_probs=False), dict(finalize=True, use_final_probs=False)]
+    run_lattice_cases(ref, "lattice_hclg600", g, m, utts, cfgs, modes)
+    ge = synth.graph_from_arc_lists(
+        8, 0,
+        {
+            0: [(0, 7, 0.5, 1), (1, 0, 1.0, 2), (0, 0, 0.1, 5)],
+            1: [(0, 8, 0.25, 3), (2, 0, 0.5, 1)],
+            2: [(1, 0, 0.3, 2), (3, 9, 0.7, 3)],
+            3: [(0, 0, 0.2, 4), (2, 0, 0.4, 3), (3, 0, 0.6, 3)],
+            4: [(1, 10, 0.1, 4), (2, 0, 0.9, 6)],
+            5: [(0, 12, 0.05, 6)],
+            6: [(3, 0, 0.35, 6), (1, 13, 0.15, 7)],
+            7: [(2, 0, 0.2, 7)],
+        },
+        {4: 1.25, 6: 0.5},
+    )
+    rng = np.random.default_rng(5)
+    ue = [rng.normal(-1.5, 0.8, size=(T0, 4)).astype(np.float32) for T0 in (1, 2, 9, 30)]
+    ce = [dict(beam=13.0, max_active=1000, min_active=0, lattice_beam=7.0),
+          dict(beam=13.0, max_active=1000, min_active=0, lattice_beam=0.5, prune_interval=3)]
+    run_lattice_cases(ref, "lattice_eps_chains", ge, None, ue, ce, modes[:2])
+
+
 def main():
     pyoracle.build_ref()
     ref = pyoracle.RefDecoder()
+    if "--lattice-only" in sys.argv:
+        return lattice_goldens(ref)
 
     # 1. small hclg-like graph, several configurations (beam-only, max/min-active binding)
     n_tid, n_pdf, T = 600, 300, 40
@@ -142,6 +204,7 @@ def main():
     run_cases(ref, "no_final", gn, None, un, [ce[0]], [dict(trace=True)])
     run_cases(ref, "dead_end", gd, None, [np.full((T0, 3), -0.5, np.float32) for T0 in (1, 2, 4)],
               [ce[0]], [dict(trace=True, finalize=False), dict(chunk=0, finalize=False)])
+    lattice_goldens(ref)
 
 
 if __name__ == "__main__":

@@ -48,3 +48,55 @@ def test_cli_matches_oracle(mode, synth, oracle, tmp_path):
         assert words[k] == o.words.tolist(), k
         assert abs(scores[k][0] - o.tot_score) <= 1e-4 * max(1.0, abs(o.tot_score))  # printed with 6 digits
     oracle.free_graph(h)
+
+
+@pytest.mark.parametrize("mode", ["batch", "single"])
+def test_cli_lattice_out_matches_oracle(mode, synth, oracle, tmp_path):
+    """DecoderItf::GetRawLattice of the host mirror (lattice mode, --lattice-out) against the oracle
+    in its order-free mode: same number of states / final states and the same arc multiset
+    (labels exact; costs printed with 9 significant digits round-trip to the same float)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m = synth.default_tid2pdf(600)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=12\n--max-active=1000000\n--min-active=0\n--lattice-beam=5\n")
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=5.0)
+    mats = [synth.make_loglikes(g, T, 300, m, seed=500 + i, mu=-2.2)[0] for i, T in enumerate([50, 21, 3])]
+    with open(tmp_path / "ll.bin", "wb") as f:
+        for i, x in enumerate(mats):
+            key = ("utt%03d" % i).encode()
+            f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
+    args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--batch=4", "--lattice-out=" + str(tmp_path / "lat.txt"),
+            "--lattice-links=1000000"]
+    if mode == "single":
+        args.append("--single-stream")
+    p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = (tmp_path / "lat.txt").read_text().split("\n\n")
+    lats = {}
+    for b in blocks:
+        lines = b.strip().splitlines()
+        if not lines:
+            continue
+        arcs = [l.split() for l in lines[1:] if len(l.split()) == 6]
+        finals = [int(l) for l in lines[1:] if len(l.split()) == 1]
+        lats[lines[0]] = (arcs, finals)
+    h = oracle.load_graph(gpath)
+    try:
+        oracle.set_order_free(True)
+        for i, x in enumerate(mats):
+            O = pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**cd), x, m)
+            arcs, finals = lats["utt%03d" % i]
+            assert len(finals) == int(O.st_final.sum())
+            assert len(arcs) == len(O.a_src)
+            n_states = 1 + max(max(int(a[0]), int(a[1])) for a in arcs)
+            assert n_states == O.n_states
+            got = np.array([[int(a[2]), int(a[3]), np.float32(a[4]).view(np.int32), np.float32(a[5]).view(np.int32)] for a in arcs], np.int64)
+            got = got[np.lexsort(got.T[::-1])]
+            assert np.array_equal(got, O.arc_multiset()), "utt %d" % i
+            assert all(int(a[1]) > int(a[0]) for a in arcs)
+    finally:
+        oracle.set_order_free(False)
+        oracle.free_graph(h)

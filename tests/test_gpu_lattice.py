@@ -1,0 +1,157 @@
+"""-m gpu: lattice mode of the HIP path (wfst_limits.lattice_links > 0) through the C ABI.
+FinalizeDecoding's lattice_beam pruning + GetRawLattice (reference base-inl.h:725-975).
+
+The reference admits an arc against next_cutoff as it stands when the arc is visited
+(base-inl.h:326-333), so a handful of links above a frame's FINAL cutoff exist or not depending on
+its hash-list order; the GPU applies the final cutoff to every arc.  Hence:
+(1) against the reference-generated vectors the GPU lattice must be a sub-multiset of the
+    reference's arcs, and equal to it whenever the arc counts agree;
+(2) against the C oracle in its order-free mode (oracle_set_order_free; pinned to the reference by
+    tests/test_oracle_lattice.py) it must be IDENTICAL up to the numbering of states inside a
+    frame: same (frame, graph state) nodes with bit-equal forward costs and final flags, same arcs
+    with bit-equal graph / acoustic costs."""
+import numpy as np
+import pytest
+
+import pyoracle
+from golden_util import Golden, bits
+
+pytestmark = pytest.mark.gpu
+
+LIM = dict(max_frames=512, max_tokens_per_frame=32768, arena_tokens=1 << 21, lattice_links=1 << 22)
+
+
+def gpu_lattices(G, graph, cd, mats, use_final_probs=True, limits=LIM):
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), **limits)
+    dev = G.upload(mats)
+    dec.init()
+    dec.advance([t.data_ptr() for t in dev], [int(m.shape[0]) for m in mats], int(mats[0].shape[1]))
+    dec.finalize()
+    lats = [dec.raw_lattice(c, use_final_probs) for c in range(len(mats))]
+    best = dec.best_paths(use_final_probs=True)
+    dec.free()
+    return lats, best
+
+
+def as_raw(d):
+    return pyoracle.RawLattice(True, d["n_states"], 0, d["st_final"], d["a_src"], d["a_dst"], d["a_ilabel"], d["a_olabel"],
+                               d["a_graph"], d["a_acoustic"], d["st_frame"], d["st_state"], d["st_cost"])
+
+
+def multiset_contains(big, small):
+    from collections import Counter
+
+    cb, cs = Counter(map(tuple, big)), Counter(map(tuple, small))
+    return all(cb[k] >= v for k, v in cs.items())
+
+
+def nodes(L):
+    k = np.stack([L.st_frame, L.st_gstate, L.st_final, bits(L.st_cost)], axis=1)
+    return k[np.lexsort(k.T[::-1])]
+
+
+@pytest.mark.parametrize("name", ["lattice_hclg600", "lattice_eps_chains"])
+def test_gpu_lattice_reproduces_golden(name, tmp_path):
+    import gpu_util as G
+
+    g = Golden(name)
+    graph = G.wfstdec.Graph.load(g.write_graph(str(tmp_path / "g.bin")))
+    if g.tid2pdf is not None:
+        graph.set_tid2pdf(g.tid2pdf)
+    groups = {}
+    for k, cd, md, ui in g.cases():
+        if md["finalize"] and cd["max_active"] >= 1000:   # beam-only regime (DESIGN.md 'Deviations')
+            groups.setdefault((g.meta["cases"][k]["cfg"], md["use_final_probs"]), []).append((k, ui))
+    n = n_equal = 0
+    for (ci, ufp), items in groups.items():
+        cd = dict(g.meta["cfgs"][ci])
+        lats, _ = gpu_lattices(G, graph, cd, [g.utts[ui] for _, ui in items], ufp)
+        for (k, ui), d in zip(items, lats):
+            ok, ns, nf, na = (int(x) for x in g.z["c%d_counts" % k][:4])
+            what = "%s case %d" % (name, k)
+            assert (d is not None) == bool(ok), what
+            if d is None:
+                continue
+            L = as_raw(d)
+            ref_arcs = g.z["c%d_arcs" % k]
+            assert L.n_states <= ns and int(L.st_final.sum()) == nf and len(L.a_src) <= na, what + " counts"
+            assert multiset_contains(ref_arcs, L.arc_multiset()), what + " arcs not among the reference's"
+            if len(L.a_src) == na:
+                assert L.n_states == ns and np.array_equal(L.arc_multiset(), ref_arcs), what
+                n_equal += 1
+            assert np.all(L.a_dst > L.a_src) and np.all(np.diff(L.a_src) >= 0), what + " numbering"
+            n += 1
+    graph.free()
+    assert n > 0 and n_equal >= n - 2
+
+
+@pytest.mark.parametrize("lattice_beam", [0.5, 4.0, 8.0])
+def test_gpu_lattice_equals_oracle_state_by_state(lattice_beam, oracle, synth, tmp_path):
+    import gpu_util as G
+
+    g = synth.make_hclg_like(20000, seed=7, n_tid=2000, n_words=3000)
+    m = synth.default_tid2pdf(2000)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    ho = oracle.load_graph(path)
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=lattice_beam, prune_interval=25)
+    mats = [synth.make_loglikes_multi(g, T, 1000, m, seed=40 + i)[0] for i, T in enumerate((60, 33, 1, 80))]
+    lats, best = gpu_lattices(G, graph, cd, mats)
+    for i, (d, ll) in enumerate(zip(lats, mats)):
+        try:
+            oracle.set_order_free(True)
+            O = pyoracle.oracle_raw_lattice(oracle, ho, pyoracle.Config(**cd), ll, m)
+        finally:
+            oracle.set_order_free(False)
+        assert (d is not None) == O.ok
+        L = as_raw(d)
+        what = "utt %d lattice_beam %g" % (i, lattice_beam)
+        assert np.array_equal(nodes(L), nodes(O)), what + " states"
+        assert np.array_equal(L.labelled_arcs(), O.labelled_arcs()), what + " arcs"
+        assert np.all(L.a_dst > L.a_src), what
+        # the best path is unchanged by lattice mode
+        r = oracle.decode(ho, pyoracle.Config(**cd), ll, m)
+        assert np.array_equal(best[i]["words"], r.words) and np.array_equal(best[i]["tids"], r.tids), what
+    oracle.free_graph(ho)
+    graph.free()
+
+
+def test_gpu_lattice_errors_are_loud(synth, tmp_path):
+    import gpu_util as G
+
+    g = synth.make_hclg_like(600, seed=11, n_tid=600, n_words=500)
+    m = synth.default_tid2pdf(600)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=13.0, max_active=1000000, min_active=0, lattice_beam=7.0)
+    ll = synth.make_loglikes(g, 40, 300, m, seed=0, mu=-2.2, sigma=1.0)[0]
+    # not in lattice mode
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 1, max_frames=64, max_tokens_per_frame=8192, arena_tokens=1 << 18)
+    dev = G.upload([ll])
+    dec.init()
+    dec.advance([dev[0].data_ptr()], [40], ll.shape[1])
+    dec.finalize()
+    with pytest.raises(G.wfstdec.WfstError):
+        dec.raw_lattice(0)
+    dec.free()
+    # lattice mode: before finalize -> state error; link capacity too small -> capacity error
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 1, max_frames=64, max_tokens_per_frame=8192, arena_tokens=1 << 18,
+                                 lattice_links=1 << 20)
+    dec.init()
+    dec.advance([dev[0].data_ptr()], [40], ll.shape[1])
+    with pytest.raises(G.wfstdec.WfstError):
+        dec.raw_lattice(0)
+    dec.free()
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 1, max_frames=64, max_tokens_per_frame=8192, arena_tokens=1 << 18,
+                                 lattice_links=64)
+    dec.init()
+    with pytest.raises(G.wfstdec.WfstError):
+        dec.advance([dev[0].data_ptr()], [40], ll.shape[1])
+        dec.finalize()
+        dec.raw_lattice(0)
+    dec.free()
+    graph.free()
