@@ -1041,7 +1041,7 @@ int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]) {
   stats[4] = (int64_t)c.cnt_tok;
   stats[5] = c.peak_tokens;
   stats[6] = (int64_t)c.cnt_rec;
-  stats[7] = 0;
+  stats[7] = c.link_count;  // lattice mode: forward links recorded
   return WFST_OK;
 }
 

@@ -5,9 +5,12 @@
 //
 //   wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--lattice-out=FILE [--lattice-links=N]]
 //               CONFIG GRAPH LOGLIKES [WORDS_OUT]
-//   --lattice-out  also write GetRawLattice of every utterance as text: "KEY", then one line
-//                  "src dst ilabel olabel graph_cost acoustic_cost" per arc, one line "state" per
-//                  final state, then an empty line (lattice mode: N forward links kept per utterance)
+//   --lattice-out  also write GetRawLattice of every utterance, in utterance order, in the
+//                  reference's on-disk lattice format (Lattice::Write, newfst/lattice-fst.cc:38-64;
+//                  lattice mode: N forward links kept per utterance).  An utterance without a
+//                  lattice is written as an empty one (0 states, start -1).
+//   --lattice-text same lattices as text: "KEY", one line "src dst ilabel olabel graph_cost
+//                  acoustic_cost" per arc, one line "state" per final state, then an empty line
 //
 //   CONFIG    text file of --beam=.. --max-active=.. lines (reference option names)
 //   GRAPH     flat graph in the reference format (Fst::ReadFst)
@@ -65,7 +68,7 @@ int main(int argc, char **argv) {
     std::string tid2pdf_file;
     int batch = 128;
     bool single = false;
-    std::string lattice_file;
+    std::string lattice_file, lattice_text;
     long long lattice_links = 1ll << 22;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -74,12 +77,13 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 8, "--batch=") == 0) batch = atoi(a.c_str() + 8);
       else if (a == "--single-stream") single = true;
       else if (a.compare(0, 14, "--lattice-out=") == 0) lattice_file = a.substr(14);
+      else if (a.compare(0, 15, "--lattice-text=") == 0) lattice_text = a.substr(15);
       else if (a.compare(0, 16, "--lattice-links=") == 0) lattice_links = atoll(a.c_str() + 16);
       else pos.push_back(a);
     }
     if (pos.size() < 3) {
-      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--lattice-out=FILE "
-                   "[--lattice-links=N]] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
+      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--lattice-out=FILE] "
+                   "[--lattice-text=FILE] [--lattice-links=N] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
       return 1;
     }
     LatticeFasterDecoderConfig opt;
@@ -101,13 +105,18 @@ int main(int argc, char **argv) {
     std::ostream &out = pos.size() > 3 ? (std::ostream &)fout : std::cout;
 
     std::ofstream lat_out;
-    if (!lattice_file.empty()) {
-      lat_out.open(lattice_file.c_str());
+    if (!lattice_text.empty()) {
+      lat_out.open(lattice_text.c_str());
       lat_out.precision(9);
     }
+    if (!lattice_file.empty()) remove(lattice_file.c_str());  // Lattice::Write(file) appends
+    const bool want_lattice = !lattice_file.empty() || !lattice_text.empty();
     wfst_limits limits = {0, 0, 0, 0};  // zeros = the library defaults
-    limits.lattice_links = lattice_file.empty() ? 0 : lattice_links;
+    limits.lattice_links = want_lattice ? lattice_links : 0;
     auto emit_lattice = [&](const Utt &u, Lattice &lat, bool ok) {
+      if (!ok) lat.DeleteStates();
+      if (!lattice_file.empty() && !lat.Write(lattice_file)) throw std::runtime_error("cannot write " + lattice_file);
+      if (!lat_out.is_open()) return;
       lat_out << u.key << '\n';
       if (ok)
         for (StateId s = 0; s < lat.NumStates(); ++s) {
@@ -154,7 +163,7 @@ int main(int argc, char **argv) {
         Lattice best;
         bool ok = decode.GetBestPath(&best);
         emit(u, best, ok);
-        if (lat_out.is_open()) {
+        if (want_lattice) {
           Lattice lat;
           bool lok = decode.GetRawLattice(&lat);
           emit_lattice(u, lat, lok);
@@ -180,7 +189,7 @@ int main(int argc, char **argv) {
         std::vector<bool> ok;
         decode.GetBestPaths(ch, &best, &ok);
         for (int i = 0; i < n; ++i) emit(utts[b0 + i], best[i], ok[i]);
-        for (int i = 0; i < n && lat_out.is_open(); ++i) {
+        for (int i = 0; i < n && want_lattice; ++i) {
           Lattice lat;
           bool lok = decode.GetRawLattice(i, &lat);
           emit_lattice(utts[b0 + i], lat, lok);

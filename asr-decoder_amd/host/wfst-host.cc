@@ -112,6 +112,88 @@ bool LatticeToVector(Lattice &best_path, std::vector<int> &words, std::vector<in
   return true;
 }
 
+// ---- on-disk lattice (reference format, see wfst-host.h) ----------------------------------------
+bool Lattice::Write(FILE *fp) {
+  if (!fp) return false;
+  const uint64_t n = _states.size();
+  const int32_t start = _start;
+  if (fwrite(&n, 8, 1, fp) != 1 || fwrite(&start, 4, 1, fp) != 1) {
+    std::cerr << "Write lattice state number error." << std::endl;
+    return false;
+  }
+  for (LatticeState &st : _states) {
+    const int32_t fin = st.IsFinal() ? 1 : 0;
+    const uint64_t na = st.GetArcSize();
+    if (fwrite(&fin, 4, 1, fp) != 1 || fwrite(&na, 8, 1, fp) != 1) {
+      std::cerr << "Write state error." << std::endl;
+      return false;
+    }
+    for (unsigned i = 0; i < na; ++i) {
+      const LatticeArc *a = st.GetArc(i);
+      const int32_t lab[2] = {a->_input, a->_output};
+      const float w[2] = {a->_w.Value1(), a->_w.Value2()};
+      const int32_t to = a->_to;
+      if (fwrite(lab, 4, 2, fp) != 2 || fwrite(w, 4, 2, fp) != 2 || fwrite(&to, 4, 1, fp) != 1) {
+        std::cerr << "Write state arc error." << std::endl;
+        return false;
+      }
+    }
+  }
+  return true;
+}
+bool Lattice::Write(const std::string &file) {
+  FILE *fp = fopen(file.c_str(), "ab");
+  if (!fp) {
+    std::cerr << "Write " << file << " failed." << std::endl;
+    return false;
+  }
+  const bool ok = Write(fp);
+  fclose(fp);
+  if (!ok) std::cerr << "Write " << file << " failed." << std::endl;
+  return ok;
+}
+bool Lattice::Read(FILE *fp) {
+  DeleteStates();
+  if (!fp) return false;
+  uint64_t n = 0;
+  int32_t start = 0;
+  if (fread(&n, 8, 1, fp) != 1 || fread(&start, 4, 1, fp) != 1) return false;  // also: clean end of file
+  for (uint64_t s = 0; s < n; ++s) {
+    int32_t fin = 0;
+    uint64_t na = 0;
+    if (fread(&fin, 4, 1, fp) != 1 || fread(&na, 8, 1, fp) != 1) {
+      std::cerr << "Read state error." << std::endl;
+      DeleteStates();
+      return false;
+    }
+    const StateId id = AddState();
+    if (fin) SetFinal(id);
+    for (uint64_t i = 0; i < na; ++i) {
+      int32_t lab[2], to;
+      float w[2];
+      if (fread(lab, 4, 2, fp) != 2 || fread(w, 4, 2, fp) != 2 || fread(&to, 4, 1, fp) != 1) {
+        std::cerr << "Read state arc " << i << " error." << std::endl;
+        DeleteStates();
+        return false;
+      }
+      AddArc(id, LatticeArc(lab[0], lab[1], to, LatticeWeight(w[0], w[1])));
+    }
+  }
+  _start = start;
+  return true;
+}
+bool Lattice::Read(const std::string &file) {
+  FILE *fp = fopen(file.c_str(), "rb");
+  if (!fp) {
+    std::cerr << "Open " << file << " failed." << std::endl;
+    return false;
+  }
+  const bool ok = Read(fp);
+  fclose(fp);
+  if (!ok) std::cerr << "Read " << file << " failed." << std::endl;
+  return ok;
+}
+
 // ---- single-stream decoder --------------------------------------------------------------------
 GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, const wfst_limits *limits)
     : _dec(nullptr), _stride(0), _rows_ready(0), _inited(false) {

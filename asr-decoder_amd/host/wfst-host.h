@@ -133,6 +133,15 @@ class Lattice {
   StateId Start() const { return _start; }
   StateId NumStates() const { return (StateId)_states.size(); }
   LatticeState *GetState(StateId s) { return &_states[s]; }
+  // The reference's on-disk lattice (newfst/lattice-fst.cc:38-101, lattice-fst.h:124-172,
+  // arc.h:38-86, weigth.h:229-258), little-endian, LP64: u64 number of states, i32 start state,
+  // then per state {i32 final, u64 number of arcs, arcs x {i32 ilabel, i32 olabel, f32 graph cost,
+  // f32 acoustic cost, i32 nextstate}}.  Write(file) APPENDS, as the reference does ("ab"), so one
+  // file holds the lattices of consecutive utterances; Read(FILE*) reads the next one.
+  bool Write(FILE *fp);
+  bool Write(const std::string &file);
+  bool Read(FILE *fp);
+  bool Read(const std::string &file);
 
  private:
   std::vector<LatticeState> _states;

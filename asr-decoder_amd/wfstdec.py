@@ -232,7 +232,7 @@ class BatchDecoder:
     def stats(self, channel):
         s = (C.c_int64 * 8)()
         _check(lib().wfst_decoder_get_stats(self.h, int(channel), s))
-        return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], records=s[6])
+        return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], records=s[6], links=s[7])
 
     def raw_lattice(self, channel, use_final_probs=True):
         """GetRawLattice of a finalized channel (lattice mode).  Returns a dict of numpy arrays, or

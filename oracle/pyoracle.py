@@ -265,3 +265,57 @@ def oracle_raw_lattice(orc, graph_handle, cfg, loglikes, tid2pdf=None, finalize=
                        max_states=1 << 20, max_arcs=1 << 21):
     return _raw_lattice(orc.lib, "oracle_raw_lattice", True, graph_handle, cfg, loglikes, tid2pdf, finalize, use_final_probs,
                         max_states, max_arcs)
+
+
+def ref_lattice_write(ref, graph_handle, cfg, loglikes, path, tid2pdf=None):
+    """Append the reference's GetRawLattice to `path` with the reference's own Lattice::Write."""
+    ll = np.ascontiguousarray(loglikes, dtype=np.float32)
+    T, stride = ll.shape
+    n_tid = stride - 1
+    if tid2pdf is not None:
+        tid2pdf = np.ascontiguousarray(tid2pdf, dtype=np.int32)
+        n_tid = int(tid2pdf.shape[0] - 1)
+    f = ref.lib.ref_lattice_write
+    f.restype = C.c_int
+    return bool(f(C.c_void_p(graph_handle), C.byref(cfg), _fp(ll), T, stride, _ip(tid2pdf), n_tid, path.encode()))
+
+
+def ref_lattice_read(ref, path, index, max_states=1 << 20, max_arcs=1 << 21):
+    """Lattice number `index` of `path`, read with the reference's own Lattice::Read."""
+    ns, na, st = C.c_int(0), C.c_int(0), C.c_int(0)
+    fin = np.zeros(max_states, np.int32)
+    src, dst, il, ol = (np.zeros(max_arcs, np.int32) for _ in range(4))
+    gr, ac = np.zeros(max_arcs, np.float32), np.zeros(max_arcs, np.float32)
+    f = ref.lib.ref_lattice_read
+    f.restype = C.c_int
+    ok = f(path.encode(), int(index), max_states, C.byref(ns), C.byref(st), _ip(fin), max_arcs, C.byref(na), _ip(src),
+           _ip(dst), _ip(il), _ip(ol), _fp(gr), _fp(ac))
+    S, A = ns.value, na.value
+    return RawLattice(bool(ok), S, st.value, fin[:S].copy(), src[:A].copy(), dst[:A].copy(), il[:A].copy(), ol[:A].copy(),
+                      gr[:A].copy(), ac[:A].copy())
+
+
+def parse_lattice_file(data):
+    """All lattices of a file in the reference's on-disk format (newfst/lattice-fst.cc:38-101): a
+    list of RawLattice.  Pure numpy/struct restatement of Lattice::Read for the tests."""
+    import struct
+
+    out, o = [], 0
+    while o < len(data):
+        n, start = struct.unpack_from("<Qi", data, o)
+        o += 12
+        fin, src, rows = [], [], []
+        for s in range(n):
+            f, na = struct.unpack_from("<iQ", data, o)
+            o += 12
+            fin.append(f)
+            a = np.frombuffer(data, dtype=np.dtype([("il", "<i4"), ("ol", "<i4"), ("g", "<f4"), ("ac", "<f4"), ("to", "<i4")]),
+                              count=na, offset=o)
+            o += 20 * na
+            rows.append(a)
+            src.append(np.full(na, s, np.int32))
+        a = np.concatenate(rows) if rows else np.zeros(0, dtype=[("il", "<i4"), ("ol", "<i4"), ("g", "<f4"), ("ac", "<f4"), ("to", "<i4")])
+        src = np.concatenate(src) if src else np.zeros(0, np.int32)
+        out.append(RawLattice(True, n, start, np.asarray(fin, np.int32), src, a["to"].astype(np.int32), a["il"].astype(np.int32),
+                              a["ol"].astype(np.int32), a["g"].astype(np.float32), a["ac"].astype(np.float32)))
+    return out

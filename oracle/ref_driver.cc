@@ -255,4 +255,67 @@ int ref_raw_lattice(void *gp, const RefConfig *rc, const float *loglikes, int T,
   return 1;
 }
 
+// The reference's on-disk lattice format: decode as above and append GetRawLattice to `path` with
+// the reference's own Lattice::Write(std::string&) (newfst/lattice-fst.h:327-342, lattice-fst.cc:38).
+// Returns 1 if a lattice was written.
+int ref_lattice_write(void *gp, const RefConfig *rc, const float *loglikes, int T, int stride,
+                      const int *tid2pdf, int n_tid, const char *path) {
+  Fst *g = static_cast<Fst *>(gp);
+  LatticeFasterDecoderConfig cfg;
+  cfg._beam = rc->beam;
+  cfg._max_active = rc->max_active;
+  cfg._min_active = rc->min_active;
+  cfg._lattice_beam = rc->lattice_beam;
+  cfg._prune_interval = rc->prune_interval;
+  cfg._beam_delta = rc->beam_delta;
+  cfg._hash_ratio = rc->hash_ratio;
+  cfg._prune_scale = rc->prune_scale;
+  ProbeDecoder dec(g, cfg);
+  MatrixDecodable decodable(loglikes, T, stride, tid2pdf, n_tid);
+  dec.InitDecoding();
+  dec.AdvanceDecoding(&decodable);
+  dec.FinalizeDecoding();
+  Lattice lat;
+  if (!dec.GetRawLattice(&lat, true)) return 0;
+  std::string file(path);
+  return lat.Write(file) ? 1 : 0;
+}
+
+// Read lattice number `index` of `path` with the reference's Lattice::Read(FILE*) and dump it like
+// ref_raw_lattice does.  Returns 1 on success.
+int ref_lattice_read(const char *path, int index, int max_states, int *n_states, int *start,
+                     int *st_final, int max_arcs, int *n_arcs, int *a_src, int *a_dst, int *a_il,
+                     int *a_ol, float *a_graph, float *a_ac) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return 0;
+  Lattice lat;
+  bool ok = true;
+  for (int i = 0; i <= index && ok; ++i) ok = lat.Read(fp);
+  fclose(fp);
+  if (!ok) return 0;
+  const int S = lat.NumStates();
+  *n_states = S;
+  *start = lat.Start();
+  int na = 0;
+  for (int s = 0; s < S; ++s) {
+    LatticeState *st = lat.GetState(s);
+    if (s < max_states) st_final[s] = st->IsFinal() ? 1 : 0;
+    const int k = (int)st->GetArcSize();
+    for (int i = 0; i < k; ++i) {
+      LatticeArc *a = st->GetArc(i);
+      if (na < max_arcs) {
+        a_src[na] = s;
+        a_dst[na] = a->_to;
+        a_il[na] = a->_input;
+        a_ol[na] = a->_output;
+        a_graph[na] = a->_w.Value1();
+        a_ac[na] = a->_w.Value2();
+      }
+      ++na;
+    }
+  }
+  *n_arcs = na;
+  return 1;
+}
+
 }  // extern "C"

@@ -132,6 +132,21 @@ def lattice_goldens(ref):
           dict(beam=13.0, max_active=1000, min_active=0, lattice_beam=0.5, prune_interval=3)]
     run_lattice_cases(ref, "lattice_eps_chains", ge, None, ue, ce, modes[:2])
 
+    # on-disk lattice format: three lattices appended to one file by the reference's own
+    # Lattice::Write(std::string&) (newfst/lattice-fst.h:327-342); the file's bytes are the vector
+    tmp = "/tmp/_golden_lattices.bin"
+    if os.path.exists(tmp):
+        os.remove(tmp)
+    gb, path = graph_bytes(g)
+    h = ref.load_graph(path)
+    for ll in utts:
+        assert pyoracle.ref_lattice_write(ref, h, pyoracle.Config(**cfgs[1]), ll, tmp, m)
+    ref.free_graph(h)
+    with open(tmp, "rb") as f:
+        data = np.frombuffer(f.read(), dtype=np.uint8).copy()
+    np.savez_compressed(os.path.join(OUT, "lattice_file.npz"), data=data, n_lattices=np.int32(len(utts)), cfg=np.int32(1))
+    print("wrote lattice_file.npz: %d bytes" % data.size)
+
 
 def main():
     pyoracle.build_ref()

@@ -52,9 +52,10 @@ def test_cli_matches_oracle(mode, synth, oracle, tmp_path):
 
 @pytest.mark.parametrize("mode", ["batch", "single"])
 def test_cli_lattice_out_matches_oracle(mode, synth, oracle, tmp_path):
-    """DecoderItf::GetRawLattice of the host mirror (lattice mode, --lattice-out) against the oracle
-    in its order-free mode: same number of states / final states and the same arc multiset
-    (labels exact; costs printed with 9 significant digits round-trip to the same float)."""
+    """DecoderItf::GetRawLattice of the host mirror (lattice mode) against the oracle in its
+    order-free mode, through both writers of the CLI: --lattice-out (the reference's on-disk format,
+    Lattice::Write: bit-exact costs) and --lattice-text (9 significant digits round-trip to the
+    same float): same number of states / final states and the same arc multiset."""
     subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
     g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
     gpath = str(tmp_path / "g.bin")
@@ -68,8 +69,8 @@ def test_cli_lattice_out_matches_oracle(mode, synth, oracle, tmp_path):
         for i, x in enumerate(mats):
             key = ("utt%03d" % i).encode()
             f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
-    args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--batch=4", "--lattice-out=" + str(tmp_path / "lat.txt"),
-            "--lattice-links=1000000"]
+    args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--batch=4", "--lattice-text=" + str(tmp_path / "lat.txt"),
+            "--lattice-out=" + str(tmp_path / "lat.bin"), "--lattice-links=1000000"]
     if mode == "single":
         args.append("--single-stream")
     p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
@@ -83,11 +84,18 @@ def test_cli_lattice_out_matches_oracle(mode, synth, oracle, tmp_path):
         arcs = [l.split() for l in lines[1:] if len(l.split()) == 6]
         finals = [int(l) for l in lines[1:] if len(l.split()) == 1]
         lats[lines[0]] = (arcs, finals)
+    with open(tmp_path / "lat.bin", "rb") as f:
+        blats = pyoracle.parse_lattice_file(f.read())
+    assert len(blats) == len(mats)
     h = oracle.load_graph(gpath)
     try:
         oracle.set_order_free(True)
         for i, x in enumerate(mats):
             O = pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**cd), x, m)
+            Bl = blats[i]
+            assert (Bl.n_states, Bl.start, int(Bl.st_final.sum())) == (O.n_states, 0, int(O.st_final.sum()))
+            assert np.array_equal(Bl.arc_multiset(), O.arc_multiset()), "utt %d (binary)" % i
+            assert np.all(Bl.a_dst > Bl.a_src)
             arcs, finals = lats["utt%03d" % i]
             assert len(finals) == int(O.st_final.sum())
             assert len(arcs) == len(O.a_src)
