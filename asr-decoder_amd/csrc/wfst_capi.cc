@@ -97,9 +97,10 @@ struct wfst_decoder {
   DevBuf<ChanCtl> ctl;
   DevBuf<int4> tok;
   DevBuf<int32_t> frame_off, bucket_cnt, eps_toki, eps_occ_list, eps_won_list, target, chan_list;
-  DevBuf<int4> bucket, worklist, links, link_attr;
-  DevBuf<int32_t> link_off;
-  DevBuf<uint32_t> extra;
+  DevBuf<int4> bucket, worklist, links, lat_toks;
+  DevBuf<int32_t> link_off, link_mid;
+  DevBuf<uint2> extra;
+  DevBuf<LatArc> lat_arcs;
   DevBuf<FrameCtl> fctl;
   DevBuf<unsigned long long> dbg_t;
   DevBuf<int32_t> items;
@@ -162,7 +163,7 @@ struct wfst_decoder {
     if (p_ctl) (void)hipHostFree(p_ctl);
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); links.release(); link_attr.release(); link_off.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
+    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
     bp_ac.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -434,6 +435,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
     d->own_stream = true;
   }
   const size_t B = (size_t)n_channels, ecap = (size_t)std::max(1, g->n_eps_targets);
+  int64_t lat_arc_cap = 0, lat_tok_cap = 0;
   const size_t fo = (size_t)L.max_frames + 2;
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -450,9 +452,15 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   A(d->worklist.alloc(B * 2 * (size_t)L.max_tokens_per_frame));
   if (L.lattice_links > 0) {
     A(d->links.alloc(B * (size_t)L.lattice_links));
-    A(d->link_attr.alloc(B * (size_t)L.lattice_links));
     A(d->link_off.alloc(B * ((size_t)L.max_frames + 3)));
+    A(d->link_mid.alloc(B * ((size_t)L.max_frames + 3)));
     A(d->extra.alloc(B * (size_t)L.arena_tokens));
+    // the pruned lattice is a small fraction of what was recorded (a few thousand arcs per utterance
+    // out of millions of links at lattice_beam 7)
+    lat_arc_cap = std::min<int64_t>(L.lattice_links, std::max<int64_t>(65536, L.lattice_links / 8));
+    lat_tok_cap = std::min<int64_t>(L.arena_tokens, std::max<int64_t>(65536, L.lattice_links / 8));
+    A(d->lat_arcs.alloc(B * (size_t)lat_arc_cap));
+    A(d->lat_toks.alloc(B * (size_t)lat_tok_cap));
   }
   const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 256 + 2);
   A(d->fctl.alloc(8));
@@ -496,9 +504,13 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.eps_won_list = d->eps_won_list.p;
   D.worklist = d->worklist.p;
   D.links = d->links.p;
-  D.link_attr = d->link_attr.p;
   D.link_off = d->link_off.p;
+  D.link_mid = d->link_mid.p;
   D.extra = d->extra.p;
+  D.lat_arcs = d->lat_arcs.p;
+  D.lat_toks = d->lat_toks.p;
+  D.lat_arc_cap = (int32_t)lat_arc_cap;
+  D.lat_tok_cap = (int32_t)lat_tok_cap;
   D.link_cap = L.lattice_links;
   D.lattice = L.lattice_links > 0 ? 1 : 0;
   D.fctl = d->fctl.p;
@@ -951,79 +963,80 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
   const ChanCtl &c = d->p_ctl[channel];
   const int nd = c.n_decoded;
   if (nd <= 0) return WFST_OK;
-  const size_t fo = (size_t)d->D.max_frames + 2, lo = (size_t)d->D.max_frames + 3;
-  std::vector<int32_t> foff((size_t)nd + 2), loff((size_t)nd + 2);
-  HIP_TRY(hipMemcpy(foff.data(), d->frame_off.p + (size_t)channel * fo, foff.size() * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(loff.data(), d->link_off.p + (size_t)channel * lo, loff.size() * 4, hipMemcpyDeviceToHost));
-  const int n_tok = foff[nd + 1], n_link = loff[nd + 1];
-  std::vector<int4> tok((size_t)n_tok), lk((size_t)n_link), at((size_t)n_link);
-  std::vector<uint32_t> ex((size_t)n_tok);
-  if (n_tok) {
-    HIP_TRY(hipMemcpy(tok.data(), d->tok.p + (size_t)channel * (size_t)d->D.arena_cap, (size_t)n_tok * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ex.data(), d->extra.p + (size_t)channel * (size_t)d->D.arena_cap, (size_t)n_tok * 4, hipMemcpyDeviceToHost));
+  // the pruned lattice was left compacted by lattice_prune_kernel: two small copies
+  const int n_tok = c.lat_toks, n_arc = c.lat_arcs;
+  std::vector<int4> tk((size_t)n_tok);
+  std::vector<LatArc> ar((size_t)n_arc);
+  if (n_tok)
+    HIP_TRY(hipMemcpy(tk.data(), d->lat_toks.p + (size_t)channel * (size_t)d->D.lat_tok_cap, (size_t)n_tok * sizeof(int4), hipMemcpyDeviceToHost));
+  if (n_arc)
+    HIP_TRY(hipMemcpy(ar.data(), d->lat_arcs.p + (size_t)channel * (size_t)d->D.lat_arc_cap, (size_t)n_arc * sizeof(LatArc), hipMemcpyDeviceToHost));
+  // tokens sorted by arena index = by frame, creation order inside a frame
+  std::sort(tk.begin(), tk.end(), [](const int4 &a, const int4 &b) { return a.x < b.x; });
+  auto find_tok = [&](int32_t arena_idx) -> int {
+    auto it = std::lower_bound(tk.begin(), tk.end(), arena_idx, [](const int4 &a, int32_t v) { return a.x < v; });
+    return (it != tk.end() && it->x == arena_idx) ? (int)(it - tk.begin()) : -1;
+  };
+  // the reference returns false when a frame has no token left (base-inl.h:906-911)
+  {
+    std::vector<char> seen((size_t)nd + 1, 0);
+    for (const int4 &t : tk) seen[t.w & 0x3FFFFFFF] = 1;
+    for (int f = 0; f <= nd; ++f)
+      if (!seen[f]) return WFST_OK;
   }
-  if (n_link) {
-    HIP_TRY(hipMemcpy(lk.data(), d->links.p + (size_t)channel * (size_t)d->D.link_cap, (size_t)n_link * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(at.data(), d->link_attr.p + (size_t)channel * (size_t)d->D.link_cap, (size_t)n_link * 16, hipMemcpyDeviceToHost));
-  }
-  const uint32_t inf_o = 0xFF800000u;  // orderable +inf
-  // frame of each token; the reference returns false when a frame has no token left (base-inl.h:906-911)
-  std::vector<int32_t> frame_of((size_t)n_tok), new_id((size_t)n_tok, -1);
-  for (int f = 0; f <= nd; ++f) {
-    bool any = false;
-    for (int i = foff[f]; i < foff[f + 1]; ++i) { frame_of[i] = f; any |= ex[i] < inf_o; }
-    if (!any) return WFST_OK;
+  std::vector<int32_t> src((size_t)n_arc), dst((size_t)n_arc);
+  for (int i = 0; i < n_arc; ++i) {
+    src[i] = find_tok(ar[i].src_tok);
+    dst[i] = find_tok(ar[i].dst_tok);
+    if (src[i] < 0 || dst[i] < 0) return fail(WFST_E_DEVICE, "internal: lattice arc without its tokens");
   }
   // topological numbering inside each frame: depth along the surviving epsilon links
   std::vector<int32_t> depth((size_t)n_tok, 0);
-  for (int f = 0; f <= nd; ++f) {
-    for (int round = 0; round < 1 << 20; ++round) {
-      bool changed = false;
-      for (int i = loff[f]; i < loff[f + 1]; ++i)
-        if (lk[i].w && lk[i].x >= foff[f] && depth[lk[i].y] < depth[lk[i].x] + 1) { depth[lk[i].y] = depth[lk[i].x] + 1; changed = true; }
-      if (!changed) break;
-    }
+  for (int round = 0; round < 1 << 20; ++round) {
+    bool changed = false;
+    for (int i = 0; i < n_arc; ++i)
+      if (ar[i].is_eps && depth[dst[i]] < depth[src[i]] + 1) { depth[dst[i]] = depth[src[i]] + 1; changed = true; }
+    if (!changed) break;
   }
-  int ns = 0;
-  {
-    std::vector<int32_t> order;
-    for (int f = 0; f <= nd; ++f) {
-      order.clear();
-      for (int i = foff[f]; i < foff[f + 1]; ++i)
-        if (ex[i] < inf_o) order.push_back(i);
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth[a] < depth[b]; });
-      for (int i : order) new_id[i] = ns++;
-    }
-  }
-  int na = 0;
-  for (int i = 0; i < n_link; ++i) na += lk[i].w && new_id[lk[i].x] >= 0 && new_id[lk[i].y] >= 0;
-  *n_states = ns;
-  *n_arcs = na;
-  if (ns > cap_states || na > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");
-  bool any_final = false;
-  for (int i = foff[nd]; i < foff[nd + 1]; ++i) any_final |= tok[i].x == d->graph->final_state;
+  std::vector<int32_t> order((size_t)n_tok), new_id((size_t)n_tok);
+  for (int i = 0; i < n_tok; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    const int fa = tk[a].w & 0x3FFFFFFF, fb = tk[b].w & 0x3FFFFFFF;
+    return fa != fb ? fa < fb : depth[a] < depth[b];
+  });
+  for (int i = 0; i < n_tok; ++i) new_id[order[i]] = i;
+  *n_states = n_tok;
+  *n_arcs = n_arc;
+  if (n_tok > cap_states || n_arc > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");
   const std::vector<int32_t> &pos = d->graph->pos_host;
   for (int i = 0; i < n_tok; ++i) {
     const int s = new_id[i];
-    if (s < 0) continue;
-    if (st_final) st_final[s] = frame_of[i] == nd && (!any_final || tok[i].x == d->graph->final_state);
-    if (st_frame) st_frame[s] = frame_of[i];
-    if (st_state) st_state[s] = (int32_t)(std::lower_bound(pos.begin(), pos.end(), tok[i].x) - pos.begin());
-    if (st_cost) memcpy(&st_cost[s], &tok[i].y, 4);
+    if (st_final) st_final[s] = (tk[i].w >> 30) & 1;
+    if (st_frame) st_frame[s] = tk[i].w & 0x3FFFFFFF;
+    if (st_state) st_state[s] = (int32_t)(std::lower_bound(pos.begin(), pos.end(), tk[i].y) - pos.begin());
+    if (st_cost) memcpy(&st_cost[s], &tk[i].z, 4);
   }
-  std::vector<int32_t> idx;
-  idx.reserve((size_t)na);
-  for (int i = 0; i < n_link; ++i)
-    if (lk[i].w && new_id[lk[i].x] >= 0 && new_id[lk[i].y] >= 0) idx.push_back(i);
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return new_id[lk[a].x] < new_id[lk[b].x]; });
-  for (int k = 0; k < na; ++k) {
+  std::vector<int32_t> idx((size_t)n_arc);
+  for (int i = 0; i < n_arc; ++i) idx[i] = i;
+  // arcs sorted by source state; destination / labels / cost keep the order deterministic (the
+  // device appends them in whatever order the waves retire)
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) {
+    const int sa = new_id[src[a]], sb = new_id[src[b]];
+    if (sa != sb) return sa < sb;
+    const int da = new_id[dst[a]], db = new_id[dst[b]];
+    if (da != db) return da < db;
+    if (ar[a].ilabel != ar[b].ilabel) return ar[a].ilabel < ar[b].ilabel;
+    if (ar[a].olabel != ar[b].olabel) return ar[a].olabel < ar[b].olabel;
+    return ar[a].graph < ar[b].graph;
+  });
+  for (int k = 0; k < n_arc; ++k) {
     const int i = idx[k];
-    if (a_src) a_src[k] = new_id[lk[i].x];
-    if (a_dst) a_dst[k] = new_id[lk[i].y];
-    if (a_ilabel) a_ilabel[k] = at[i].x;
-    if (a_olabel) a_olabel[k] = at[i].y;
-    if (a_graph) memcpy(&a_graph[k], &at[i].z, 4);
-    if (a_acoustic) memcpy(&a_acoustic[k], &at[i].w, 4);
+    if (a_src) a_src[k] = new_id[src[i]];
+    if (a_dst) a_dst[k] = new_id[dst[i]];
+    if (a_ilabel) a_ilabel[k] = ar[i].ilabel;
+    if (a_olabel) a_olabel[k] = ar[i].olabel;
+    if (a_graph) a_graph[k] = ar[i].graph;
+    if (a_acoustic) a_acoustic[k] = ar[i].acoustic;
   }
   return WFST_OK;
 }

@@ -76,8 +76,10 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t tile_start;    // first entry of this channel's tiles in tile_chan[] for the coming frame
   unsigned long long cnt_N, cnt_E, cnt_Z, cnt_tok, cnt_rec;  // work counters since init
   int32_t link_count;    // lattice mode: forward links recorded so far (atomicAdd)
+  int32_t lat_arcs;      // lattice mode, after lattice_prune_kernel: surviving links in lat_arcs[]
+  int32_t lat_toks;      //   "   surviving tokens in lat_toks[]
   int32_t pad2;
-  unsigned long long pad1[2];
+  unsigned long long pad1;
 };
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
 
@@ -94,6 +96,15 @@ struct __attribute__((aligned(32))) TileDesc {
   const float *llrow;   // log-likelihood row of the frame being decoded
 };
 static_assert(sizeof(TileDesc) == 32, "TileDesc is one 32-byte load");
+
+// one arc of the pruned lattice (lattice mode)
+struct __attribute__((aligned(32))) LatArc {
+  int32_t src_tok, dst_tok;  // arena indices
+  int32_t ilabel, olabel;
+  float graph, acoustic;
+  int32_t src_frame, is_eps;
+};
+static_assert(sizeof(LatArc) == 32, "LatArc is two 16-byte stores");
 
 // per channel-group frame counters, double buffered by step parity
 struct FrameCtl {
@@ -131,14 +142,20 @@ struct DecoderDev {
   int32_t *eps_won_list;        // [c][wl_cap] ordinals whose token an epsilon arc won this frame
   int4 *worklist;               // [c][2][wl_cap] {eps-table slot, state, cost bits, 0}
   // lattice mode (wfst_limits.lattice_links > 0): every forward link the reference would hold after
-  // FinalizeDecoding is among links[c][0..link_count): {source token, destination token, arc, keep};
-  // segment k = links whose destination is on frame k = [link_off[k], link_off[k+1]);
-  // extra[c][token] = orderable extra_cost (base-inl.h:482-572) filled by lattice_prune_kernel.
+  // FinalizeDecoding is among links[c][0..link_count): {source token, destination token, arc,
+  // cost bits of (source cost + acoustic) + graph}; segment k = links whose destination is on
+  // frame k = [link_off[k], link_off[k+1]): the emitting links from frame k-1 first
+  // [link_off[k], link_mid[k]), then the epsilon links inside frame k [link_mid[k], link_off[k+1]).
+  // extra[c][token] = {orderable extra_cost (base-inl.h:482-572), cost bits of the token}, filled by
+  // lattice_fill_kernel / lattice_prune_kernel, which also leaves the pruned lattice compacted in
+  // lat_arcs[c][0..ctl.lat_arcs) and lat_toks[c][0..ctl.lat_toks).
   int4 *links;
-  int4 *link_attr;              // {ilabel, olabel, graph cost bits, acoustic cost bits} of surviving links
-  int32_t *link_off;
-  uint32_t *extra;
+  int32_t *link_off, *link_mid;  // [c][max_frames+3]
+  uint2 *extra;
+  LatArc *lat_arcs;
+  int4 *lat_toks;               // {arena index, graph row of the state, cost bits, frame | final << 30}
   int64_t link_cap;
+  int32_t lat_arc_cap, lat_tok_cap;
   int32_t lattice;
   FrameCtl *fctl;               // [n_groups]
   TileDesc *tiles;              // [n_groups][tile_cap] tiles of the coming frame

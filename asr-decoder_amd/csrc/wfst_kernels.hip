@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
           lb = __shfl(lb, 0, 64);
           if (live) {
             const int lp = lb + lane_rank(lm);
-            if ((int64_t)lp < D.link_cap) links[lp] = make_int4(r.z, dst, (int)((uint32_t)r.w & kArcMask), 0);
+            if ((int64_t)lp < D.link_cap) links[lp] = make_int4(r.z, dst, (int)((uint32_t)r.w & kArcMask), r.y);
             else atomicOr(&ctl->error, kErrLinksFull);
           }
         }
@@ -760,7 +760,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
         if (!(tot < cutoff)) continue;
         const int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;
         const int lp = atomicAdd(&D.ctl[c].link_count, 1);
-        if ((int64_t)lp < D.link_cap) links[lp] = make_int4(base + i, ld_agent(&toki[ord]), a, 0);
+        if ((int64_t)lp < D.link_cap) links[lp] = make_int4(base + i, ld_agent(&toki[ord]), a, __float_as_int(tot));
         else atomicOr(&sh.err, kErrLinksFull);
       }
     }
@@ -790,6 +790,9 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
     sh.wl_n[0] = ctl->wl_n < D.wl_cap ? ctl->wl_n : D.wl_cap;
     sh.wl_n[1] = 0;
     sh.err = 0;
+    // every emitting link into the new frame is recorded (the insert launch is over): the epsilon
+    // links of the frame start here
+    if (kLat && f + 1 <= D.max_frames) D.link_mid[(size_t)c * (D.max_frames + 3) + f + 1] = min(ctl->link_count, (int)D.link_cap);
   }
   // the insert workgroups read all bucket counters of the channel to form their groups, so the
   // counters stay untouched during that launch and are reset here
@@ -1040,6 +1043,7 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
     D.frame_off[(size_t)c * (D.max_frames + 2) + 1] = nf;
     if (D.lattice) {
       D.link_off[(size_t)c * (D.max_frames + 3) + 0] = 0;
+      D.link_mid[(size_t)c * (D.max_frames + 3) + 0] = 0;
       D.link_off[(size_t)c * (D.max_frames + 3) + 1] = min(ctl->link_count, (int)D.link_cap);
     }
     D.cutoff_hist[(size_t)c * (D.max_frames + 2) + 0] = D.beam;
@@ -1196,10 +1200,14 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
 // =========================================================================================
 // lattice_prune_kernel: FinalizeDecoding (PruneForwardLinksFinal + PruneForwardLinks +
 // PruneTokensForFrame, base-inl.h:482-607,725-847) as an edge-parallel backward pass over the
-// recorded forward links; one 1024-thread workgroup per channel.
-//   extra[t]  = min over t's links of (extra[next] + ((cost_t + ac) + graph - cost_next)), links with
-//               more than lattice_beam dropped; last frame seeded with cost + final_cost - best.
-//   links[].w = 1 for a surviving link; a token survives iff its extra is finite (<= lattice_beam).
+// recorded forward links; one 1024-thread workgroup per channel, frames in descending order.
+//   extra[t]  = min over t's links of (extra[next] + (link cost - cost_next)), links with more than
+//               lattice_beam dropped; last frame seeded with cost + final_cost - best.
+//               link cost = (cost_t + ac) + graph is the candidate cost the expansion computed, kept
+//               in the link record, so one 8-byte gather {extra, cost} of the destination prices a
+//               link; nearly all destinations are dead (extra = +inf) and cost nothing more.
+//   A link survives iff its link_extra <= lattice_beam, a token iff its extra is finite; both are
+//   appended to the channel's compact lat_arcs[] / lat_toks[] as soon as they are known.
 // The reference reaches the same fixpoint by sweeping token lists "while changed"; min is
 // order-independent, so atomicMin relaxation gives the same values (its last-frame loop stops at
 // changes <= 1e-5, ours at 0).
@@ -1207,22 +1215,26 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
 __global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const int32_t *chans) {
   const int c = chans ? chans[blockIdx.x] : blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const ChanCtl *ctl = D.ctl + c;
+  ChanCtl *ctl = D.ctl + c;
   const int nd = ctl->n_decoded;
   const int4 *tok = D.tok + (size_t)c * D.arena_cap;
-  int4 *links = D.links + (size_t)c * D.link_cap;
-  int4 *attr = D.link_attr + (size_t)c * D.link_cap;
-  uint32_t *extra = D.extra + (size_t)c * D.arena_cap;
+  const int4 *links = D.links + (size_t)c * D.link_cap;
+  uint2 *extra = D.extra + (size_t)c * D.arena_cap;
+  LatArc *out_arcs = D.lat_arcs + (size_t)c * D.lat_arc_cap;
+  int4 *out_toks = D.lat_toks + (size_t)c * D.lat_tok_cap;
   const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
   const int32_t *loff = D.link_off + (size_t)c * (D.max_frames + 3);
+  const int32_t *lmid = D.link_mid + (size_t)c * (D.max_frames + 3);
   const float *ll = D.ll_base[c];
   const float kInf = __builtin_huge_valf();
   const uint32_t kInfO = f2o(kInf);
+  const float lb = D.lattice_beam;
   __shared__ u64 s_red[2][kBW];
-  __shared__ int s_changed;
+  __shared__ int s_changed, s_narcs, s_ntoks, s_err;
+  if (tid == 0) { s_narcs = 0; s_ntoks = 0; s_err = 0; }
   if (ctl->error) return;
-  // (extra[] was filled with +inf by lattice_fill_kernel: plain stores and the memory-side atomics
-  // below must not meet inside one launch)
+  // (extra[] was filled with {+inf, cost} by lattice_fill_kernel: plain stores and the memory-side
+  // atomics below must not meet inside one launch)
   // ComputeFinalCosts (base-inl.h:670-720) over the last frame
   u64 b_all = ~0ull, b_fin = ~0ull;
   for (int i = foff[nd] + tid; i < foff[nd + 1]; i += kBT) {
@@ -1241,77 +1253,86 @@ __global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const 
   for (int i = foff[nd] + tid; i < foff[nd + 1]; i += kBT) {
     const int4 t = tok[i];
     const float final_cost = (!any_final || t.x == D.g.final_state) ? 0.0f : kInf;
-    atomicExch(&extra[i], f2o(__int_as_float(t.y) + final_cost - final_best));  // base-inl.h:775
+    float e = __int_as_float(t.y) + final_cost - final_best;  // base-inl.h:775
+    if (e > lb) e = kInf;                                      // base-inl.h:815-816 (tokens without links)
+    atomicExch(&extra[i].x, f2o(e));
   }
   __syncthreads();
 
-  // link_extra of link L given the current extra of its destination (base-inl.h:524-526, 782-784)
-  auto link_extra = [&](const int4 L, int k_src_frame, bool eps) -> float {
-    const int4 S = tok[L.x], Dd = tok[L.y];
+  // link_extra given the CURRENT extra of the destination (base-inl.h:524-526, 782-784); +inf for a
+  // dead destination
+  auto link_extra = [&](const int4 L) -> float {
+    const u64 e = ld_agent(reinterpret_cast<const u64 *>(&extra[L.y]));  // {extra (low), cost (high)}
+    const uint32_t eo = (uint32_t)e;
+    if (eo >= kInfO) return kInf;
+    return o2f(eo) + (__int_as_float(L.w) - __int_as_float((int)(e >> 32)));
+  };
+  auto emit_arc = [&](const int4 L, int k_src_frame, bool eps) {
+    const int p = atomicAdd(&s_narcs, 1);
+    if (p >= D.lat_arc_cap) { s_err = 1; return; }
     const int4 A = D.g.arcs[L.z];
-    const float ac = eps ? 0.0f : -ll[(size_t)k_src_frame * D.stride + A.x];
-    const float ed = o2f(ld_agent(&extra[L.y]));
-    return ed + (((__int_as_float(S.y) + ac) + __int_as_float(A.z)) - __int_as_float(Dd.y));
+    LatArc o;
+    o.src_tok = L.x; o.dst_tok = L.y;
+    o.ilabel = eps ? 0 : D.g.arc_ilabel[L.z];
+    o.olabel = D.g.arc_olabel[L.z];
+    o.graph = __int_as_float(A.z);
+    o.acoustic = eps ? 0.0f : -ll[(size_t)k_src_frame * D.stride + A.x];
+    o.src_frame = k_src_frame; o.is_eps = eps ? 1 : 0;
+    out_arcs[p] = o;
   };
   for (int k = nd; k >= 0; --k) {
     const int fk = foff[k], fk1 = foff[k + 1];
-    // (A) emitting links frame k -> k+1 (in segment k+1, source on frame k)
+    // (A) emitting links frame k -> k+1: the extras of frame k+1 are final, so a link that passes is
+    // a link of the lattice
     if (k < nd) {
-      for (int i = loff[k + 1] + tid; i < loff[k + 2]; i += kBT) {
+      for (int i = loff[k + 1] + tid; i < lmid[k + 1]; i += kBT) {
         const int4 L = links[i];
-        if (L.x >= fk1) continue;  // an epsilon link inside frame k+1
-        float le = link_extra(L, k, false);
-        if (le > D.lattice_beam) continue;
+        float le = link_extra(L);
+        if (!(le <= lb)) continue;
+        emit_arc(L, k, false);
         if (le < 0.0f) le = 0.0f;
-        atomicMin(&extra[L.x], f2o(le));
+        atomicMin(&extra[L.x].x, f2o(le));
       }
       __syncthreads();
     }
-    // (B) epsilon links inside frame k (segment k, source on frame k), to the fixpoint
-    for (int round = 0; round < 4096; ++round) {
+    // (B) epsilon links inside frame k, to the fixpoint
+    const int e0 = lmid[k], e1 = loff[k + 1];
+    for (int round = 0; e0 < e1 && round < 4096; ++round) {
       if (tid == 0) s_changed = 0;
       __syncthreads();
-      for (int i = loff[k] + tid; i < loff[k + 1]; i += kBT) {
+      for (int i = e0 + tid; i < e1; i += kBT) {
         const int4 L = links[i];
-        if (L.x < fk) continue;  // an emitting link from frame k-1
-        float le = link_extra(L, k, true);
-        if (le > D.lattice_beam) continue;
+        float le = link_extra(L);
+        if (!(le <= lb)) continue;
         if (le < 0.0f) le = 0.0f;
         const uint32_t o = f2o(le);
-        if (o < atomicMin(&extra[L.x], o)) s_changed = 1;
+        if (o < atomicMin(&extra[L.x].x, o)) s_changed = 1;
       }
       __syncthreads();
       const int ch = s_changed;
       __syncthreads();
       if (!ch) break;
     }
-    // last frame: tokens worse than lattice_beam are pruned (base-inl.h:815-816)
-    if (k == nd) {
-      for (int i = fk + tid; i < fk1; i += kBT)
-        if (o2f(ld_agent(&extra[i])) > D.lattice_beam) atomicExch(&extra[i], kInfO);
-      __syncthreads();
-    }
-    // mark the surviving links whose source is on frame k
-    if (k < nd) {
-      for (int i = loff[k + 1] + tid; i < loff[k + 2]; i += kBT) {
-        const int4 L = links[i];
-        if (L.x >= fk1) continue;
-        const int keep = (link_extra(L, k, false) <= D.lattice_beam) ? 1 : 0;
-        links[i].w = keep;
-        if (keep) {
-          const int4 A = D.g.arcs[L.z];
-          attr[i] = make_int4(D.g.arc_ilabel[L.z], D.g.arc_olabel[L.z], A.z, __float_as_int(-ll[(size_t)k * D.stride + A.x]));
-        }
-      }
-    }
-    for (int i = loff[k] + tid; i < loff[k + 1]; i += kBT) {
+    for (int i = e0 + tid; i < e1; i += kBT) {
       const int4 L = links[i];
-      if (L.x < fk) continue;
-      const int keep = (link_extra(L, k, true) <= D.lattice_beam) ? 1 : 0;
-      links[i].w = keep;
-      if (keep) attr[i] = make_int4(0, D.g.arc_olabel[L.z], D.g.arcs[L.z].z, __float_as_int(0.0f));
+      if (link_extra(L) <= lb) emit_arc(L, k, true);
+    }
+    // the live tokens of frame k
+    for (int i = fk + tid; i < fk1; i += kBT) {
+      const u64 e = ld_agent(reinterpret_cast<const u64 *>(&extra[i]));
+      if ((uint32_t)e >= kInfO) continue;
+      const int p = atomicAdd(&s_ntoks, 1);
+      if (p >= D.lat_tok_cap) { s_err = 1; continue; }
+      const int4 t = tok[i];
+      const int fin = (k == nd && (!any_final || t.x == D.g.final_state)) ? 1 : 0;
+      out_toks[p] = make_int4(i, t.x, t.y, k | (fin << 30));
     }
     __syncthreads();
+  }
+  if (tid == 0) {
+    ctl->lat_arcs = min(s_narcs, D.lat_arc_cap);
+    ctl->lat_toks = min(s_ntoks, D.lat_tok_cap);
+    if (s_err) ctl->error |= kErrLinksFull;
   }
 }
 
@@ -1356,9 +1377,11 @@ __global__ __launch_bounds__(256) void lattice_fill_kernel(DecoderDev D, const i
   const int c = chans ? chans[blockIdx.x] : blockIdx.x;
   const ChanCtl *ctl = D.ctl + c;
   const int n_tok = D.frame_off[(size_t)c * (D.max_frames + 2) + ctl->n_decoded + 1];
-  uint32_t *extra = D.extra + (size_t)c * D.arena_cap;
+  uint2 *extra = D.extra + (size_t)c * D.arena_cap;
+  const int4 *tok = D.tok + (size_t)c * D.arena_cap;
   const uint32_t inf_o = f2o(__builtin_huge_valf());
-  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n_tok; i += gridDim.y * blockDim.x) extra[i] = inf_o;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n_tok; i += gridDim.y * blockDim.x)
+    extra[i] = make_uint2(inf_o, (uint32_t)tok[i].y);
 }
 void launch_lattice_prune(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(lattice_fill_kernel, dim3(n, 64), dim3(256), 0, s, D, chans);
