@@ -70,3 +70,60 @@ def test_batch128_parity_sample_and_properties(big, oracle):
     if o.extra["ties"] == 0:
         G.assert_same_as_oracle(wide[0], o, "beam 15")
     oracle.free_graph(h)
+
+
+def test_batch128_lattice_mode_properties(big, oracle):
+    """Lattice mode at full size (§8 f.1): FinalizeDecoding's lattice_beam pruning + GetRawLattice for
+    all 128 utterances.  Oracle (order-free mode, see tests/test_gpu_lattice.py) state by state on a
+    sample; for every utterance the size-independent properties of a pruned lattice: topologically
+    numbered, trim (every state reachable from the start and reaching a final state), its shortest
+    path IS the best path, and a narrower lattice_beam gives a sub-lattice."""
+    from test_gpu_lattice import as_raw, gpu_lattices, multiset_contains, nodes
+
+    G = big["G"]
+    lim = dict(LIM, lattice_links=6 << 20)
+    lats, best = gpu_lattices(G, big["graph"], CD, big["mats"], limits=lim)
+    assert all(d is not None for d in lats)
+    h = oracle.load_graph(big["path"])
+    try:
+        oracle.set_order_free(True)
+        for u in (5, 64, 127):
+            O = pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**CD), big["mats"][u], big["m"])
+            L = as_raw(lats[u])
+            assert np.array_equal(nodes(L), nodes(O)), "utt %d states" % u
+            assert np.array_equal(L.labelled_arcs(), O.labelled_arcs()), "utt %d arcs" % u
+    finally:
+        oracle.set_order_free(False)
+        oracle.free_graph(h)
+    for u, d in enumerate(lats):
+        L = as_raw(d)
+        S = L.n_states
+        assert np.all(L.a_dst > L.a_src) and np.all(np.diff(L.a_src) >= 0), u
+        assert L.st_frame[0] == 0 and np.all(np.diff(L.st_frame) >= 0) and L.st_frame[-1] == big["T"], u
+        assert L.st_final.sum() >= 1 and np.all(L.st_frame[L.st_final == 1] == big["T"]), u
+        # forward DP in state order (ids are topological): reachability and shortest path
+        dist = np.full(S, np.inf, np.float32)
+        dist[0] = 0.0
+        w = (L.a_graph + L.a_ac).astype(np.float32)
+        for k in range(len(L.a_src)):   # arcs are sorted by source state
+            c = np.float32(dist[L.a_src[k]] + w[k])
+            if c < dist[L.a_dst[k]]:
+                dist[L.a_dst[k]] = c
+        assert np.all(np.isfinite(dist)), "utt %d: state unreachable from the start" % u
+        co = np.zeros(S, bool)
+        co[L.st_final == 1] = True
+        for k in range(len(L.a_src) - 1, -1, -1):
+            if co[L.a_dst[k]]:
+                co[L.a_src[k]] = True
+        assert co.all(), "utt %d: state that reaches no final state" % u
+        sp = dist[L.st_final == 1].min()
+        assert abs(sp - best[u]["tot_score"]) <= 1e-4 * abs(sp), "utt %d: shortest path %g != best path %g" % (u, sp, best[u]["tot_score"])
+        # forward costs of the states are the tokens' costs: never below the lattice's own shortest distance
+        assert np.all(L.st_cost >= dist - 1e-3 * np.abs(dist) - 1e-3), u
+    # a narrower lattice_beam gives a sub-lattice
+    pick = [0, 31, 77, 100]
+    narrow, _ = gpu_lattices(G, big["graph"], dict(CD, lattice_beam=3.0), [big["mats"][u] for u in pick], limits=lim)
+    for u, d in zip(pick, narrow):
+        A, Bw = as_raw(d), as_raw(lats[u])
+        assert len(A.a_src) < len(Bw.a_src)
+        assert multiset_contains(Bw.labelled_arcs(), A.labelled_arcs()), "utt %d" % u
