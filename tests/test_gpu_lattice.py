@@ -111,6 +111,10 @@ def test_gpu_lattice_equals_oracle_state_by_state(lattice_beam, oracle, synth, t
         assert np.array_equal(nodes(L), nodes(O)), what + " states"
         assert np.array_equal(L.labelled_arcs(), O.labelled_arcs()), what + " arcs"
         assert np.all(L.a_dst > L.a_src), what
+        # the gather payload of the N>1 path (shard.lattice_to_bytes = the reference's on-disk format)
+        (P,) = pyoracle.parse_lattice_file(G.pkg.shard.lattice_to_bytes(d))
+        assert P.n_states == L.n_states and P.start == 0 and np.array_equal(P.st_final, L.st_final), what
+        assert np.array_equal(P.a_src, L.a_src) and np.array_equal(P.a_dst, L.a_dst) and np.array_equal(P.arc_multiset(), L.arc_multiset()), what
         # the best path is unchanged by lattice mode
         r = oracle.decode(ho, pyoracle.Config(**cd), ll, m)
         assert np.array_equal(best[i]["words"], r.words) and np.array_equal(best[i]["tids"], r.tids), what

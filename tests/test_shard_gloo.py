@@ -24,6 +24,68 @@ def _fake_result(u):
                 lm_score=float(np.float32(u / 3.0)))
 
 
+def _fake_lattice(u):
+    """a random topologically numbered lattice in BatchDecoder.raw_lattice's layout; None for u % 5 == 3"""
+    if u % 5 == 3:
+        return None
+    rng = np.random.default_rng(1000 + u)
+    S = int(rng.integers(2, 40))
+    A = int(rng.integers(1, 90))
+    src = np.sort(rng.integers(0, S - 1, size=A)).astype(np.int32)
+    dst = (src + 1 + rng.integers(0, S, size=A) % (S - 1 - src + 0).clip(1)).astype(np.int32)
+    fin = np.zeros(S, np.int32)
+    fin[-1] = 1
+    return dict(n_states=S, st_final=fin, a_src=src, a_dst=dst, a_ilabel=rng.integers(0, 6000, A).astype(np.int32),
+                a_olabel=rng.integers(0, 50000, A).astype(np.int32), a_graph=rng.random(A).astype(np.float32),
+                a_acoustic=rng.random(A).astype(np.float32))
+
+
+def _lattice_worker(rank, world, port, per_rank, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = importlib.import_module("asr-decoder_amd.shard")
+    mine = [shard.lattice_to_bytes(_fake_lattice(u)) for u in shard.shard_range(rank, world, per_rank)]
+    allb = shard.gather_lattices(mine)
+    dist.barrier()
+    if rank == 0:
+        q.put(allb)
+    dist.destroy_process_group()
+
+
+def test_two_rank_lattice_gather_over_gloo():
+    """Lattice mode's N>1 exchange: length-prefixed blobs in the reference's on-disk lattice format,
+    all_gather of lengths then of the padded bytes; rank 0 parses every utterance's lattice back."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyoracle
+
+    world, per_rank = 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lattice_worker, args=(r, world, port, per_rank, q)) for r in range(world)]
+    [p.start() for p in procs]
+    allb = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert len(allb) == world * per_rank
+    for u, blob in enumerate(allb):
+        e = _fake_lattice(u)
+        (L,) = pyoracle.parse_lattice_file(blob)
+        if e is None:
+            assert L.n_states == 0 and L.start == -1
+            continue
+        assert L.n_states == e["n_states"] and L.start == 0 and np.array_equal(L.st_final, e["st_final"])
+        for a, b in ((L.a_src, "a_src"), (L.a_dst, "a_dst"), (L.a_il, "a_ilabel"), (L.a_ol, "a_olabel")):
+            assert np.array_equal(a, e[b]), (u, b)
+        assert np.array_equal(L.a_graph.view(np.int32), e["a_graph"].view(np.int32))
+        assert np.array_equal(L.a_ac.view(np.int32), e["a_acoustic"].view(np.int32))
+
+
 def _worker(rank, world, port, per_rank, lmax, q):
     import torch.distributed as dist
 
