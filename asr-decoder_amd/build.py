@@ -8,8 +8,10 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", "wfst_kernels.hip"), os.path.join(HERE, "csrc", "wfst_capi.cc")]
-HDRS = [os.path.join(HERE, "csrc", "wfst_device.h"), os.path.join(HERE, "..", "include", "wfst_decoder.h")]
+SRCS = [os.path.join(HERE, "csrc", "wfst_kernels.hip"), os.path.join(HERE, "csrc", "wfst_capi.cc"),
+        os.path.join(HERE, "csrc", "wfst_openfst.cc")]
+HDRS = [os.path.join(HERE, "csrc", "wfst_device.h"), os.path.join(HERE, "csrc", "wfst_openfst.h"),
+        os.path.join(HERE, "..", "include", "wfst_decoder.h")]
 LIB = os.path.join(HERE, "lib", "libwfstdec.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the search must round like the reference (no FMA; configure.ac:12-13)

@@ -13,6 +13,7 @@
 
 #include "../../include/wfst_decoder.h"
 #include "wfst_device.h"
+#include "wfst_openfst.h"
 
 using namespace wfst;
 namespace wfst { int insert_kernel_set_lds(int bytes); }
@@ -339,25 +340,22 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
 int wfst_graph_load(const char *path, int device, wfst_graph **out) {
   if (!path || !out) return fail(WFST_E_ARG, "NULL argument");
   *out = nullptr;
-  FILE *fp = fopen(path, "rb");
-  if (!fp) return fail(WFST_E_IO, std::string("cannot open ") + path);
-  int32_t hdr[6];
-  if (fread(hdr, 4, 6, fp) != 6) {
-    fclose(fp);
-    return fail(WFST_E_IO, "truncated header");
-  }
-  const int32_t S = hdr[2], A = hdr[3];
-  if (S <= 0 || A < 0) {
-    fclose(fp);
-    return fail(WFST_E_IO, "bad header");
-  }
-  std::vector<wfst_state_info> si((size_t)S);
-  std::vector<wfst_arc> arcs((size_t)A);
-  bool ok = fread(si.data(), sizeof(wfst_state_info), S, fp) == (size_t)S &&
-            fread(arcs.data(), sizeof(wfst_arc), A, fp) == (size_t)A;
-  fclose(fp);
-  if (!ok) return fail(WFST_E_IO, "truncated graph file");
-  return wfst_graph_from_arrays(hdr[0], hdr[1], S, A, si.data(), arcs.data(), device, out);
+  wfst::HostGraph hg;
+  std::string err;
+  const int rc = wfst::read_graph_file(path, &hg, &err);
+  if (rc != WFST_OK) return fail(rc, err);
+  return wfst_graph_from_arrays(hg.start, hg.final_state, (int32_t)hg.states.size(), (int32_t)hg.arcs.size(),
+                                hg.states.data(), hg.arcs.data(), device, out);
+}
+
+int wfst_graph_convert_file(const char *in_path, const char *flat_out_path) {
+  if (!in_path || !flat_out_path) return fail(WFST_E_ARG, "NULL argument");
+  wfst::HostGraph hg;
+  std::string err;
+  int rc = wfst::read_graph_file(in_path, &hg, &err);
+  if (rc != WFST_OK) return fail(rc, err);
+  rc = wfst::write_flat_graph(flat_out_path, hg, &err);
+  return rc == WFST_OK ? WFST_OK : fail(rc, err);
 }
 
 int wfst_graph_set_tid2pdf(wfst_graph *g, const int32_t *tid2pdf, int32_t n_tid) {

@@ -76,6 +76,67 @@ class Graph:
         return Graph(start, final_state, si, arcs)
 
 
+def to_openfst_bytes(g, fst_type="vector", aligned=False, flags=0):
+    """The flat graph `g` as an OpenFst binary file (StdArc), the input side of the ingestion
+    tests: the super-final construction is undone (a leading <eps>:<eps> arc into g.final_state
+    becomes the state's final weight, every other state gets weight +inf = Zero) and the result is
+    written as a "vector" fst {float final, int64 narcs, arcs} or a "const" fst {ConstState x S,
+    arcs} (optionally 16-byte aligned, OpenFst's --fst_align).  Layout: OpenFst fst/fst.h
+    FstHeader, fst/vector-fst.h, fst/const-fst.h."""
+    import struct
+
+    off = g.row_offsets()
+    S = g.n_states - 1
+    assert g.final_state == S and g.state_info["num_arcs"][S] == 0
+    arcs, si = g.arcs, g.state_info
+    first = off[:S]
+    has = si["num_arcs"][:S] > 0
+    lead = np.zeros(S, bool)
+    fi = first[has]
+    lead[has] = (arcs["ilabel"][fi] == 0) & (arcs["olabel"][fi] == 0) & (arcs["to"][fi] == S)
+    final_w = np.full(S, np.inf, np.float32)
+    final_w[lead] = arcs["w"][first[lead]]
+    keep = np.ones(g.n_arcs, bool)
+    keep[first[lead]] = False
+    body = arcs[keep]
+    narcs = si["num_arcs"][:S].astype(np.int64) - lead
+    nie = si["niepsilons"][:S].astype(np.int64) - lead
+    noe = si["noepsilons"][:S].astype(np.int64) - lead
+
+    def hstr(x):
+        return struct.pack("<i", len(x)) + x.encode()
+
+    flags = int(flags) | (4 if (aligned and fst_type == "const") else 0)
+    version = 2 if not (aligned and fst_type == "const") else 1
+    head = (struct.pack("<i", 2125659606) + hstr(fst_type) + hstr("standard") + struct.pack("<ii", version, flags) +
+            struct.pack("<Q", 0) + struct.pack("<qqq", g.start, S, int(body.shape[0])))
+    out = [head]
+    if fst_type == "vector":
+        pos = np.zeros(S + 1, np.int64)
+        np.cumsum(narcs, out=pos[1:])
+        raw = body.tobytes()
+        for s_ in range(S):
+            out.append(struct.pack("<fq", float(final_w[s_]), int(narcs[s_])))
+            out.append(raw[pos[s_] * 16:pos[s_ + 1] * 16])
+    elif fst_type == "const":
+        pos = np.zeros(S + 1, np.int64)
+        np.cumsum(narcs, out=pos[1:])
+        cs = np.zeros(S, np.dtype([("w", "<f4"), ("pos", "<u4"), ("narcs", "<u4"), ("nie", "<u4"), ("noe", "<u4")]))
+        cs["w"], cs["pos"], cs["narcs"], cs["nie"], cs["noe"] = final_w, pos[:S], narcs, nie, noe
+        n = len(head)
+        if aligned:
+            out.append(b"\0" * ((16 - n % 16) % 16))
+            n += (16 - n % 16) % 16
+        out.append(cs.tobytes())
+        n += S * 20
+        if aligned:
+            out.append(b"\0" * ((16 - n % 16) % 16))
+        out.append(body.tobytes())
+    else:
+        raise ValueError(fst_type)
+    return b"".join(out)
+
+
 def graph_from_arc_lists(n_states, start, arcs_by_state, final_weights):
     """Build a flat graph from python lists (small hand-made cases).
 

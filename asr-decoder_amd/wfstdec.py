@@ -20,7 +20,7 @@ ERR_NAMES = {-1: "WFST_E_ARG", -2: "WFST_E_IO", -3: "WFST_E_DEVICE", -4: "WFST_E
 
 # every symbol include/wfst_decoder.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "wfst_config_default", "wfst_last_error", "wfst_device_count", "wfst_graph_load",
+    "wfst_config_default", "wfst_last_error", "wfst_device_count", "wfst_graph_load", "wfst_graph_convert_file",
     "wfst_graph_from_arrays", "wfst_graph_set_tid2pdf", "wfst_graph_info", "wfst_graph_free",
     "wfst_decoder_create", "wfst_decoder_free", "wfst_decoder_init", "wfst_decoder_advance",
     "wfst_decoder_advance_host", "wfst_decoder_finalize", "wfst_decoder_sync",

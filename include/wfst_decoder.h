@@ -76,8 +76,18 @@ int wfst_device_count(void);
 
 /* Fst::ReadFst(const char*) (newfst/optimize-fst.h:208-280): reads the flat format
  * {start, final_state, total_states, total_arcs, total_niepsilons, total_noepsilons} int32,
- * StateInfo x S, StdArc x A and uploads it as CSR to `device`. */
+ * StateInfo x S, StdArc x A and uploads it as CSR to `device`.
+ * The same call also takes the OpenFst binary files the reference ingests (detected by the OpenFst
+ * magic number): a CONST fst (ConstFst<StdArc,int>::Read + Fst(ConstFst), newfst/const-fst.h:118-245,
+ * newfst/optimize-fst.h:82-134 -- what the service loads with --constfst=true) and a VECTOR fst
+ * (fst_format_convert_tool/read_fst.c:11-187), both with the reference's super-final construction
+ * (final weight on a leading <eps>:<eps> arc to one extra state).  WFST_E_FORMAT for embedded
+ * symbol tables, non-"standard" arcs or other fst types (the reference readers misread those). */
 int wfst_graph_load(const char *path, int device, wfst_graph **out);
+
+/* convert_fst IN OUT (fst_format_convert_tool/convert_fst.c:5-27): read a graph file in any format
+ * wfst_graph_load takes and write the flat format.  Host only -- needs no device. */
+int wfst_graph_convert_file(const char *in_path, const char *flat_out_path);
 
 /* Same from host arrays (what Fst holds after ReadFst or after Fst(ConstFst),
  * newfst/optimize-fst.h:82-134).  Requirements, checked: every state's input-epsilon arcs precede

@@ -319,3 +319,28 @@ def parse_lattice_file(data):
         out.append(RawLattice(True, n, start, np.asarray(fin, np.int32), src, a["to"].astype(np.int32), a["il"].astype(np.int32),
                               a["ol"].astype(np.int32), a["g"].astype(np.float32), a["ac"].astype(np.float32)))
     return out
+
+
+REF_CONVERT = os.path.join(HERE, "_ref", "convert_fst")
+
+
+def ref_convert_fst(in_path, out_path):
+    """The reference's own OpenFst-vector -> flat converter (fst_format_convert_tool/convert_fst.c),
+    compiled as it is into oracle/_ref/convert_fst.  It appends to out_path and prints every arc."""
+    if os.path.exists(out_path):
+        os.remove(out_path)
+    subprocess.check_call([REF_CONVERT, in_path, out_path], stdout=subprocess.DEVNULL)
+
+
+def ref_constfst_dump(ref, path, max_states=1 << 22, max_arcs=1 << 24):
+    """ConstFst<StdArc,int>::Read + Fst(ConstFst) of the reference -> (start, final, state_info[S,3], arcs[A,4] int32)."""
+    st, fin, ns, na = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    si = np.zeros((max_states, 3), np.uint32)
+    arcs = np.zeros((max_arcs, 4), np.int32)
+    f = ref.lib.ref_constfst_dump
+    f.restype = C.c_int
+    ok = f(path.encode(), C.byref(st), C.byref(fin), max_states, C.byref(ns), si.ctypes.data_as(C.POINTER(C.c_uint)), max_arcs,
+           C.byref(na), _ip(arcs))
+    if not ok:
+        raise IOError("reference could not read %s" % path)
+    return st.value, fin.value, si[: ns.value].copy(), arcs[: na.value].copy()

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "src/my-decoder/online-decoder-mempool-base.h"
+#include "src/newfst/const-fst.h"
 #include "src/newfst/lattice-functions.h"
 
 using namespace datemoon;
@@ -253,6 +254,43 @@ int ref_raw_lattice(void *gp, const RefConfig *rc, const float *loglikes, int T,
   }
   *n_arcs = na;
   return 1;
+}
+
+// OpenFst const fst -> the reference's in-memory graph: ConstFst<StdArc,int>::Read
+// (newfst/const-fst.h:173-228) + Fst(ConstFst) (newfst/optimize-fst.h:82-134), dumped as the flat
+// arrays {num_arcs, niepsilons, noepsilons} x S and {ilabel, olabel, weight bits, nextstate} x A.
+// Returns 1 on success; counts are always written.
+int ref_constfst_dump(const char *path, int *start, int *final_state, int max_states, int *n_states,
+                      unsigned *state_info, int max_arcs, int *n_arcs, int *arcs) {
+  ConstFst<StdArc, int> cf;
+  if (!cf.Read(std::string(path))) return 0;
+  Fst fst(cf);
+  *start = fst.Start();
+  const int S = fst.TotState(), A = fst.TotArc();
+  *n_states = S;
+  *n_arcs = A;
+  *final_state = S - 1;
+  if (!fst.IsFinal(S - 1)) return 0;
+  int na = 0;
+  for (int s = 0; s < S; ++s) {
+    StdState *st = fst.GetState(s);
+    const unsigned n = st->GetArcSize();
+    if (s < max_states) {
+      state_info[3 * s + 0] = n;
+      state_info[3 * s + 1] = (unsigned)fst.NumInputEpsilons(s);
+      state_info[3 * s + 2] = (unsigned)fst.NumOutputEpsilons(s);
+    }
+    for (unsigned i = 0; i < n; ++i, ++na) {
+      if (na >= max_arcs) continue;
+      StdArc *a = st->GetArc(i);
+      arcs[4 * na + 0] = a->_input;
+      arcs[4 * na + 1] = a->_output;
+      float w = a->_w.Value();
+      memcpy(&arcs[4 * na + 2], &w, 4);
+      arcs[4 * na + 3] = a->_to;
+    }
+  }
+  return na == A ? 1 : 0;
 }
 
 // The reference's on-disk lattice format: decode as above and append GetRawLattice to `path` with

@@ -148,9 +148,31 @@ def lattice_goldens(ref):
     print("wrote lattice_file.npz: %d bytes" % data.size)
 
 
+def openfst_goldens(ref):
+    """Graph ingestion: an OpenFst vector fst and a const fst of the same small graph (inputs, made by
+    synth.to_openfst_bytes) with what the REFERENCE makes of them: the flat file written by its
+    convert_fst tool (fst_format_convert_tool/) and the arrays of Fst(ConstFst)."""
+    g = synth.make_hclg_like(400, seed=3, n_tid=300, n_words=200)
+    vec, cst = synth.to_openfst_bytes(g, "vector"), synth.to_openfst_bytes(g, "const")
+    with open("/tmp/_golden_vec.fst", "wb") as f:
+        f.write(vec)
+    with open("/tmp/_golden_const.fst", "wb") as f:
+        f.write(cst)
+    pyoracle.ref_convert_fst("/tmp/_golden_vec.fst", "/tmp/_golden_vec.flat")
+    with open("/tmp/_golden_vec.flat", "rb") as f:
+        flat = f.read()
+    st, fin, si, arcs = pyoracle.ref_constfst_dump(ref, "/tmp/_golden_const.fst")
+    np.savez_compressed(os.path.join(OUT, "openfst.npz"), vector_fst=np.frombuffer(vec, np.uint8),
+                        const_fst=np.frombuffer(cst, np.uint8), ref_flat_from_vector=np.frombuffer(flat, np.uint8),
+                        ref_const_start_final=np.array([st, fin], np.int32), ref_const_states=si, ref_const_arcs=arcs)
+    print("wrote openfst.npz: vector %d B, const %d B, flat %d B" % (len(vec), len(cst), len(flat)))
+
+
 def main():
     pyoracle.build_ref()
     ref = pyoracle.RefDecoder()
+    if "--openfst-only" in sys.argv:
+        return openfst_goldens(ref)
     if "--lattice-only" in sys.argv:
         return lattice_goldens(ref)
 
@@ -220,6 +242,7 @@ def main():
     run_cases(ref, "dead_end", gd, None, [np.full((T0, 3), -0.5, np.float32) for T0 in (1, 2, 4)],
               [ce[0]], [dict(trace=True, finalize=False), dict(chunk=0, finalize=False)])
     lattice_goldens(ref)
+    openfst_goldens(ref)
 
 
 if __name__ == "__main__":

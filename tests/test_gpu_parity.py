@@ -237,3 +237,38 @@ def test_errors_are_loud(setup50k, synth):
     with pytest.raises(W.WfstError) as e:
         W.Graph.load("/nonexistent/graph.bin")
     assert e.value.code == -2
+
+
+def test_openfst_vector_and_const_graphs_decode_like_the_flat_graph(synth, oracle, tmp_path):
+    """Graph ingestion (8(f) rank 4) end to end: the same graph loaded from the reference's flat
+    format, an OpenFst vector fst and an OpenFst const fst (plain and 16-byte aligned) through
+    wfst_graph_load gives bit-identical decodes, equal to the oracle's on the flat file."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(5000, seed=13, n_tid=600, n_words=900)
+    m = synth.default_tid2pdf(600)
+    flat = str(tmp_path / "g.flat")
+    g.write(flat)
+    files = {"flat": flat}
+    for name, kw in (("vector", dict(fst_type="vector")), ("const", dict(fst_type="const")),
+                     ("const_aligned", dict(fst_type="const", aligned=True))):
+        files[name] = str(tmp_path / (name + ".fst"))
+        with open(files[name], "wb") as f:
+            f.write(synth.to_openfst_bytes(g, **kw))
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=6.0)
+    mats = [synth.make_loglikes(g, T, 300, m, seed=700 + i, mu=-2.2)[0] for i, T in enumerate((70, 33, 5))]
+    h = oracle.load_graph(flat)
+    want = [oracle.decode(h, pyoracle.Config(**cd), x, m) for x in mats]
+    oracle.free_graph(h)
+    for name, path in files.items():
+        graph = G.wfstdec.Graph.load(path)
+        graph.set_tid2pdf(m)
+        assert graph.info()["n_states"] == g.n_states and graph.info()["n_arcs"] == g.n_arcs, name
+        for r, o in zip(G.decode_batch(graph, cd, mats), want):
+            G.assert_same_as_oracle(r, o, name)
+        graph.free()
+    with pytest.raises(G.wfstdec.WfstError):
+        bad = str(tmp_path / "sym.fst")
+        with open(bad, "wb") as f:
+            f.write(synth.to_openfst_bytes(g, "const", flags=2))
+        G.wfstdec.Graph.load(bad)
