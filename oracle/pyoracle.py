@@ -344,3 +344,18 @@ def ref_constfst_dump(ref, path, max_states=1 << 22, max_arcs=1 << 24):
     if not ok:
         raise IOError("reference could not read %s" % path)
     return st.value, fin.value, si[: ns.value].copy(), arcs[: na.value].copy()
+
+
+def ref_nbest_from_lattice_file(ref, path, index, n, max_len=512):
+    """The reference's own determinize + n-shortest-paths on lattice `index` of a lattice file.
+    Returns (list of (words, tot_score, lm_score), determinized states, determinized arcs) or None."""
+    words = np.zeros((n, max_len), np.int32)
+    nw = np.zeros(n, np.int32)
+    sc = np.zeros((n, 2), np.float32)
+    ds, da = C.c_int(0), C.c_int(0)
+    f = ref.lib.ref_nbest_from_lattice_file
+    f.restype = C.c_int
+    k = f(path.encode(), int(index), int(n), int(max_len), _ip(words), _ip(nw), _fp(sc), C.byref(ds), C.byref(da))
+    if k < 0:
+        return None
+    return [(words[i, : nw[i]].copy(), float(sc[i, 0]), float(sc[i, 1])) for i in range(k)], ds.value, da.value

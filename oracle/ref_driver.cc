@@ -24,6 +24,8 @@
 
 #include "src/my-decoder/online-decoder-mempool-base.h"
 #include "src/newfst/const-fst.h"
+#include "src/newfst/lattice-determinize-api.h"
+#include "src/newfst/lattice-to-nbest.h"
 #include "src/newfst/lattice-functions.h"
 
 using namespace datemoon;
@@ -354,6 +356,50 @@ int ref_lattice_read(const char *path, int index, int max_states, int *n_states,
   }
   *n_arcs = na;
   return 1;
+}
+
+// The service's n-best pipeline on lattice number `index` of `path` (reference on-disk format), all
+// of it the reference's own code: Lattice::Read, LatticeCheckFormat, DeterminizeLatticeWrapper,
+// NShortestPath, ConvertNbestToVector, LatticeToVector (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:
+// 78-105,139-150).  Entry i: words[i*max_len ..], n_words[i], scores[2*i] = tot, [2*i+1] = lm.
+// Returns the number of paths (<= n), -1 if the lattice cannot be read or fails the format check.
+int ref_nbest_from_lattice_file(const char *path, int index, int n, int max_len, int *words,
+                                int *n_words, float *scores, int *det_states, int *det_arcs) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return -1;
+  Lattice lat;
+  bool ok = true;
+  for (int i = 0; i <= index && ok; ++i) ok = lat.Read(fp);
+  fclose(fp);
+  if (!ok) return -1;
+  if (!LatticeCheckFormat(&lat)) return -1;
+  Lattice det;
+  DeterminizeLatticeOptions opts;
+  bool debug = false;
+  if (!DeterminizeLatticeWrapper(&lat, &det, opts, &debug)) return -1;
+  if (!LatticeCheckFormat(&det)) return -1;
+  if (det_states) *det_states = det.NumStates();
+  if (det_arcs) {
+    int na = 0;
+    for (int s = 0; s < det.NumStates(); ++s) na += (int)det.GetState(s)->GetArcSize();
+    *det_arcs = na;
+  }
+  Lattice nbest_lat;
+  NShortestPath(det, &nbest_lat, (size_t)n);
+  std::vector<Lattice> paths;
+  ConvertNbestToVector(nbest_lat, &paths);
+  int k = 0;
+  for (size_t i = 0; i < paths.size() && k < n; ++i) {
+    std::vector<int> w, p;
+    float tot = 0, lm = 0;
+    if (!LatticeToVector(paths[i], w, p, tot, lm)) continue;
+    n_words[k] = (int)w.size();
+    for (int j = 0; j < (int)w.size() && j < max_len; ++j) words[k * max_len + j] = w[j];
+    scores[2 * k] = tot;
+    scores[2 * k + 1] = lm;
+    ++k;
+  }
+  return k;
 }
 
 }  // extern "C"

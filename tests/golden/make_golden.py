@@ -132,6 +132,28 @@ def lattice_goldens(ref):
           dict(beam=13.0, max_active=1000, min_active=0, lattice_beam=0.5, prune_interval=3)]
     run_lattice_cases(ref, "lattice_eps_chains", ge, None, ue, ce, modes[:2])
 
+    # the service's n-best (n = 5) from the reference's own lattice, all reference code:
+    # GetRawLattice -> Lattice::Write -> Read -> LatticeCheckFormat -> DeterminizeLatticeWrapper ->
+    # NShortestPath -> ConvertNbestToVector -> LatticeToVector
+    gb, path = graph_bytes(g)
+    h = ref.load_graph(path)
+    nb = {"n": np.int32(5), "cfgs": np.array([0, 1], np.int32)}
+    for ci in (0, 1):
+        for ui, ll in enumerate(utts):
+            tmpf = "/tmp/_golden_nbest.lat"
+            if os.path.exists(tmpf):
+                os.remove(tmpf)
+            assert pyoracle.ref_lattice_write(ref, h, pyoracle.Config(**cfgs[ci]), ll, tmpf, m)
+            paths, ds, da = pyoracle.ref_nbest_from_lattice_file(ref, tmpf, 0, 5)
+            key = "c%d_u%d_" % (ci, ui)
+            nb[key + "det"] = np.array([ds, da], np.int32)
+            nb[key + "scores"] = np.array([[p[1], p[2]] for p in paths], np.float32)
+            nb[key + "lens"] = np.array([len(p[0]) for p in paths], np.int32)
+            nb[key + "words"] = np.concatenate([p[0] for p in paths]).astype(np.int32) if paths else np.zeros(0, np.int32)
+    ref.free_graph(h)
+    np.savez_compressed(os.path.join(OUT, "nbest_hclg600.npz"), **nb)
+    print("wrote nbest_hclg600.npz")
+
     # on-disk lattice format: three lattices appended to one file by the reference's own
     # Lattice::Write(std::string&) (newfst/lattice-fst.h:327-342); the file's bytes are the vector
     tmp = "/tmp/_golden_lattices.bin"

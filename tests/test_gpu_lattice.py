@@ -159,3 +159,20 @@ def test_gpu_lattice_errors_are_loud(synth, tmp_path):
         dec.raw_lattice(0)
     dec.free()
     graph.free()
+
+
+def test_gpu_lattice_feeds_the_references_nbest(refdec, tmp_path):
+    """Downstream check of the lattice: the GPU's GetRawLattice, written in the reference's on-disk
+    format, through the reference's own DeterminizeLatticeWrapper + NShortestPath (oracle/_ref)
+    gives the n-best word sequences and scores the reference gets from its own lattice."""
+    import gpu_util as G
+    from nbest_util import check_nbest_of_lattice_bytes
+
+    g = Golden("lattice_hclg600")
+    graph = G.wfstdec.Graph.load(g.write_graph(str(tmp_path / "g.bin")))
+    graph.set_tid2pdf(g.tid2pdf)
+    for ci in (0, 1):
+        lats, _ = gpu_lattices(G, graph, dict(g.meta["cfgs"][ci]), g.utts)
+        for ui, d in enumerate(lats):
+            check_nbest_of_lattice_bytes(refdec, G.pkg.shard.lattice_to_bytes(d), ci, ui, tmp_path, "cfg %d utt %d" % (ci, ui))
+    graph.free()

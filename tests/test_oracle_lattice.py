@@ -93,3 +93,28 @@ def test_order_free_lattice_is_the_order_independent_part_of_the_reference(name,
         n_eq += int(len(F.a_src) == len(R.a_src))
     oracle.free_graph(h)
     assert n_sub > 0 and n_eq >= n_sub - 2   # nearly always the same lattice
+
+
+def test_reference_nbest_pipeline_accepts_our_lattices(oracle, refdec, tmp_path):
+    """The lattice in the form the GPU path returns it (order-free, topologically numbered, written
+    by shard.lattice_to_bytes in the reference's on-disk format) goes through the reference's OWN
+    determinizer and n-shortest-paths and gives the n-best of the reference's own lattice
+    (tests/golden/nbest_hclg600.npz).  Needs oracle/_ref."""
+    import importlib
+
+    from nbest_util import check_nbest_of_lattice_bytes
+
+    shard = importlib.import_module("asr-decoder_amd.shard")
+    g = Golden("lattice_hclg600")
+    h = oracle.load_graph(g.write_graph(str(tmp_path / "g.bin")))
+    try:
+        oracle.set_order_free(True)
+        for ci in (0, 1):
+            for ui, ll in enumerate(g.utts):
+                O = pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**g.meta["cfgs"][ci]), ll, g.tid2pdf)
+                d = dict(n_states=O.n_states, st_final=O.st_final, a_src=O.a_src, a_dst=O.a_dst, a_ilabel=O.a_il, a_olabel=O.a_ol,
+                         a_graph=O.a_graph, a_acoustic=O.a_ac)
+                check_nbest_of_lattice_bytes(refdec, shard.lattice_to_bytes(d), ci, ui, tmp_path, "cfg %d utt %d" % (ci, ui))
+    finally:
+        oracle.set_order_free(False)
+        oracle.free_graph(h)
