@@ -8,7 +8,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", "wfst_kernels.hip"), os.path.join(HERE, "csrc", "wfst_capi.cc"),
+SRCS = [os.path.join(HERE, "csrc", "wfst_kernels.hip"), os.path.join(HERE, "csrc", "wfst_nbest.hip"),
+        os.path.join(HERE, "csrc", "wfst_capi.cc"),
         os.path.join(HERE, "csrc", "wfst_openfst.cc")]
 HDRS = [os.path.join(HERE, "csrc", "wfst_device.h"), os.path.join(HERE, "csrc", "wfst_openfst.h"),
         os.path.join(HERE, "..", "include", "wfst_decoder.h")]

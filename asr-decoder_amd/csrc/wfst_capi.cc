@@ -121,6 +121,10 @@ struct wfst_decoder {
   ChanCtl *p_ctl = nullptr;
   // best-path output buffers (device), grown on demand
   DevBuf<int32_t> bp_il, bp_ol, bp_n, bp_chain;
+  DevBuf<NbEntry> nb_list;  // n-best scratch, allocated by the first wfst_decoder_get_nbest
+  DevBuf<int32_t> nb_scratch, nb_out_i;
+  DevBuf<float> nb_out_f;
+  NbestDev nb = {};
   DevBuf<float> bp_g, bp_ac;
   // host-fed log-likelihood history (advance_host)
   std::vector<float *> hist_dev;
@@ -164,7 +168,7 @@ struct wfst_decoder {
     if (p_ctl) (void)hipHostFree(p_ctl);
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
+    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
     bp_ac.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -891,6 +895,59 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
   if (rc != WFST_OK) return rc;
   for (int i = 0; i < cnt; ++i)
     if (n_hops[i] > cap) return fail(WFST_E_CAPACITY, "best path longer than cap hops; n_hops holds the needed size");
+  return WFST_OK;
+}
+
+int wfst_decoder_get_nbest(wfst_decoder *d, const int32_t *channels, int32_t n_channels, int32_t n, int32_t max_words,
+                           int32_t *n_paths, int32_t *n_words, int32_t *words, float *tot_score, float *lm_score) {
+  if (!d || !n_paths || !n_words || !words || !tot_score || !lm_score) return fail(WFST_E_ARG, "NULL argument");
+  if (n <= 0 || n > 16 || max_words <= 0) return fail(WFST_E_ARG, "n must be 1..16 and max_words > 0");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "GetNbest needs a decoder created with wfst_limits.lattice_links > 0");
+  HIP_TRY(hipSetDevice(d->device));
+  const int32_t *dev;
+  int32_t cnt;
+  int rc = stage_channels(d, channels, n_channels, &dev, &cnt);
+  if (rc != WFST_OK) return rc;
+  for (int i = 0; i < cnt; ++i)
+    if (d->h_state[channels ? channels[i] : i] != 2) return fail(WFST_E_STATE, "GetNbest is served after FinalizeDecoding");
+  NbestDev &N = d->nb;
+  if (!d->nb_list.p) {  // first use: per-channel k-best lists and index scratch
+    N.tok_cap = std::min<int32_t>(d->D.lat_tok_cap, 32768);
+    N.arc_cap = std::min<int32_t>(d->D.lat_arc_cap, 131072);
+    N.scratch_ints = 3ll * N.tok_cap + 1 + 2ll * (d->D.max_frames + 2) + N.arc_cap;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(d->nb_list.alloc((size_t)d->n_channels * (size_t)N.tok_cap * 16));
+    HIP_TRY(d->nb_scratch.alloc((size_t)d->n_channels * (size_t)N.scratch_ints));
+    N.list = d->nb_list.p;
+    N.scratch = d->nb_scratch.p;
+  }
+  N.K = 16;
+  N.n = n;
+  N.max_words = max_words;
+  const size_t per_i = 1 + (size_t)n + (size_t)n * max_words, per_f = 2 * (size_t)n;
+  if (d->nb_out_i.n < (size_t)cnt * per_i || d->nb_out_f.n < (size_t)cnt * per_f) {
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(d->nb_out_i.alloc((size_t)d->n_channels * per_i));
+    HIP_TRY(d->nb_out_f.alloc((size_t)d->n_channels * per_f));
+  }
+  N.out_n = d->nb_out_i.p;
+  N.out_nwords = N.out_n + cnt;
+  N.out_words = N.out_nwords + (size_t)cnt * n;
+  N.out_tot = d->nb_out_f.p;
+  N.out_lm = N.out_tot + (size_t)cnt * n;
+  launch_nbest(d->D, N, dev, cnt, d->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(n_paths, N.out_n, (size_t)cnt * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(n_words, N.out_nwords, (size_t)cnt * n * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(words, N.out_words, (size_t)cnt * n * max_words * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(tot_score, N.out_tot, (size_t)cnt * n * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(lm_score, N.out_lm, (size_t)cnt * n * 4, hipMemcpyDeviceToHost, d->stream));
+  rc = read_ctl(d);  // synchronises the stream
+  if (rc != WFST_OK) return rc;
+  rc = check_ctl_errors(d);
+  if (rc != WFST_OK) return rc;
+  for (int i = 0; i < cnt; ++i)
+    if (n_paths[i] < 0) return fail(WFST_E_CAPACITY, "lattice too large for the n-best search (more than 32768 states or 131072 arcs)");
   return WFST_OK;
 }
 

@@ -181,6 +181,27 @@ struct DecoderDev {
   int32_t dbg;  // WFST_DBG ablation bits (timing experiments only; results are wrong when set)
 };
 
+// ---- n-best (wfst_nbest.hip) ---------------------------------------------------------------
+struct NbEntry {            // one partial path of a lattice state's k-best list
+  float tot, lm;            // sum of (graph + acoustic), sum of graph, in path order
+  unsigned long long hash;  // of the word sequence so far
+  int32_t prev;             // (source lattice state << 4) | entry, -1 at the start state
+  int32_t word;             // olabel of the arc that led here (0: none)
+};
+static_assert(sizeof(NbEntry) == 24, "NbEntry");
+struct NbestDev {
+  NbEntry *list;            // [c][tok_cap][K]
+  int32_t *scratch;         // [c][scratch_ints]
+  int32_t tok_cap, arc_cap, K;
+  int64_t scratch_ints;     // 3 * tok_cap + 1 + 2 * (max_frames + 2) + arc_cap
+  int32_t *out_n;           // [cnt]      paths found, or -1: the lattice exceeds tok_cap / arc_cap
+  int32_t *out_nwords;      // [cnt][n]
+  int32_t *out_words;       // [cnt][n][max_words]
+  float *out_tot, *out_lm;  // [cnt][n]
+  int32_t n, max_words;
+};
+void launch_nbest(const DecoderDev &D, const NbestDev &N, const int32_t *chan_list_dev, int cnt, hipStream_t s);
+
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s);

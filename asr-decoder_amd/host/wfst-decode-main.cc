@@ -9,6 +9,9 @@
 //                  reference's on-disk lattice format (Lattice::Write, newfst/lattice-fst.cc:38-64;
 //                  lattice mode: N forward links kept per utterance).  An utterance without a
 //                  lattice is written as an empty one (0 states, start -1).
+//   --nbest=N      also print the N-best word sequences of every utterance (the service's
+//                  GetNbestTxt, kaldi-online-nnet3-my-decoder.cc:139-150) as "KEY-k w1 w2 ..." to
+//                  stdout and "LOG KEY-k tot_score .. lm_score .." to stderr (lattice mode)
 //   --lattice-text same lattices as text: "KEY", one line "src dst ilabel olabel graph_cost
 //                  acoustic_cost" per arc, one line "state" per final state, then an empty line
 //
@@ -70,6 +73,7 @@ int main(int argc, char **argv) {
     bool single = false;
     std::string lattice_file, lattice_text;
     long long lattice_links = 1ll << 22;
+    int nbest = 0;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
       std::string a = argv[i];
@@ -79,6 +83,7 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 14, "--lattice-out=") == 0) lattice_file = a.substr(14);
       else if (a.compare(0, 15, "--lattice-text=") == 0) lattice_text = a.substr(15);
       else if (a.compare(0, 16, "--lattice-links=") == 0) lattice_links = atoll(a.c_str() + 16);
+      else if (a.compare(0, 8, "--nbest=") == 0) nbest = atoi(a.c_str() + 8);
       else pos.push_back(a);
     }
     if (pos.size() < 3) {
@@ -110,7 +115,18 @@ int main(int argc, char **argv) {
       lat_out.precision(9);
     }
     if (!lattice_file.empty()) remove(lattice_file.c_str());  // Lattice::Write(file) appends
-    const bool want_lattice = !lattice_file.empty() || !lattice_text.empty();
+    const bool want_lattice = !lattice_file.empty() || !lattice_text.empty() || nbest > 0;
+    auto emit_nbest = [&](const Utt &u, std::vector<Lattice> &paths) {
+      for (size_t k = 0; k < paths.size(); ++k) {
+        std::vector<int> words, phones;
+        float tot = 0, lm = 0;
+        if (!LatticeToVector(paths[k], words, phones, tot, lm)) continue;
+        out << u.key << '-' << (k + 1);
+        for (int w : words) out << ' ' << w;
+        out << '\n';
+        std::cerr << "LOG " << u.key << '-' << (k + 1) << " tot_score " << tot << " lm_score " << lm << "\n";
+      }
+    };
     wfst_limits limits = {0, 0, 0, 0};  // zeros = the library defaults
     limits.lattice_links = want_lattice ? lattice_links : 0;
     auto emit_lattice = [&](const Utt &u, Lattice &lat, bool ok) {
@@ -168,6 +184,11 @@ int main(int argc, char **argv) {
           bool lok = decode.GetRawLattice(&lat);
           emit_lattice(u, lat, lok);
         }
+        if (nbest > 0) {
+          std::vector<Lattice> paths;
+          decode.GetNbest(paths, nbest);
+          emit_nbest(u, paths);
+        }
       }
     } else {  // the MI355X shape: `batch` utterances per pass
       GpuBatchDecoder decode(&fst, opt, batch, &limits);
@@ -193,6 +214,11 @@ int main(int argc, char **argv) {
           Lattice lat;
           bool lok = decode.GetRawLattice(i, &lat);
           emit_lattice(utts[b0 + i], lat, lok);
+        }
+        for (int i = 0; i < n && nbest > 0; ++i) {
+          std::vector<Lattice> paths;
+          decode.GetNbest(i, paths, nbest);
+          emit_nbest(utts[b0 + i], paths);
         }
       }
     }

@@ -308,11 +308,45 @@ static bool RawLatticeOfChannel(wfst_decoder *dec, int channel, Lattice *ofst, b
   return ofst->NumStates() > 0;
 }
 
+static bool NbestOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> &out, int n) {
+  out.clear();
+  if (n <= 0) return false;
+  const int max_words = 1024;
+  int32_t np = 0;
+  std::vector<int32_t> nw((size_t)n), words((size_t)n * max_words);
+  std::vector<float> tot((size_t)n), lm((size_t)n);
+  const int32_t ch = channel;
+  int rc = wfst_decoder_get_nbest(dec, &ch, 1, n, max_words, &np, nw.data(), words.data(), tot.data(), lm.data());
+  if (rc == WFST_E_STATE) { Warn(wfst_last_error()); return false; }
+  if (rc != WFST_OK) Fatal("GetNbest");
+  for (int k = 0; k < np; ++k) {
+    Lattice lat;
+    StateId cur = lat.AddState();
+    lat.SetStart(cur);
+    const int L = std::min(nw[k], max_words);
+    // the path weight rides on the first arc (an <eps> arc when the path has no word)
+    for (int j = 0; j < std::max(L, 1); ++j) {
+      StateId next = lat.AddState();
+      const LatticeWeight w = j == 0 ? LatticeWeight(lm[k], tot[k] - lm[k]) : LatticeWeight(0.0f, 0.0f);
+      lat.AddArc(cur, LatticeArc(0, L ? words[(size_t)k * max_words + j] : 0, next, w));
+      cur = next;
+    }
+    lat.SetFinal(cur);
+    out.push_back(lat);
+  }
+  return !out.empty();
+}
+
+bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n) { return NbestOfChannel(_dec, 0, nbest_paths, n); }
+
 bool GpuLatticeDecoder::GetRawLattice(Lattice *ofst, bool use_final_probs) {
   return RawLatticeOfChannel(_dec, 0, ofst, use_final_probs);
 }
 
 // ---- batch decoder ------------------------------------------------------------------------------
+bool GpuBatchDecoder::GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n) {
+  return NbestOfChannel(_dec, channel, nbest_paths, n);
+}
 bool GpuBatchDecoder::GetRawLattice(int channel, Lattice *ofst, bool use_final_probs) {
   return RawLatticeOfChannel(_dec, channel, ofst, use_final_probs);
 }

@@ -190,6 +190,12 @@ class GpuLatticeDecoder : public DecoderItf {
   bool GetBestPath(Lattice *ofst, bool use_final_probs = true) override;
   // after FinalizeDecoding, decoder created with wfst_limits.lattice_links > 0 (else: warning + false)
   bool GetRawLattice(Lattice *ofst, bool use_final_probs = true) override;
+  // OnlineClgLatticeFastDecoder::GetNbest (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105):
+  // the n (<= 16) cheapest distinct word sequences of the pruned lattice, each as a linear Lattice
+  // whose arcs carry the words as olabels (ilabel 0, like the reference's determinized output) and
+  // whose FIRST arc carries the path's whole weight (graph = lm_score, acoustic = tot - lm), so
+  // that LatticeToVector gives words, tot_score and lm_score.  Same conditions as GetRawLattice.
+  bool GetNbest(std::vector<Lattice> &nbest_paths, int n);
 
  private:
   void Pull(AmInterface *decodable);
@@ -214,6 +220,7 @@ class GpuBatchDecoder {
   int NumFramesDecoded(int channel) const;
   bool GetBestPath(int channel, Lattice *ofst, bool use_final_probs = true);
   bool GetRawLattice(int channel, Lattice *ofst, bool use_final_probs = true);
+  bool GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n);
   void GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
                     bool use_final_probs = true);
   wfst_decoder *Handle() { return _dec; }

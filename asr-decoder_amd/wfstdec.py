@@ -26,7 +26,7 @@ SYMBOLS = [
     "wfst_decoder_advance_host", "wfst_decoder_finalize", "wfst_decoder_sync",
     "wfst_decoder_num_frames_decoded", "wfst_decoder_get_best_path", "wfst_lattice_to_vector",
     "wfst_decoder_get_stats", "wfst_decoder_get_frontier", "wfst_decoder_set_profiling",
-    "wfst_decoder_get_profile", "wfst_decoder_get_raw_lattice",
+    "wfst_decoder_get_profile", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
 ]
 
 
@@ -254,6 +254,25 @@ class BatchDecoder:
                                                   _i32(il), _i32(ol), _f32(gr), _f32(ac)))
         return dict(n_states=S, st_final=fin, st_frame=fr, st_state=gs, st_cost=co, a_src=src, a_dst=dst, a_ilabel=il,
                     a_olabel=ol, a_graph=gr, a_acoustic=ac)
+
+    def nbest(self, n, channels=None, max_words=256):
+        """GetNbest + LatticeToVector of finalized channels (lattice mode): per channel a list of
+        dicts {words, tot_score, lm_score}, cheapest first."""
+        ch = list(range(self.n)) if channels is None else [int(c) for c in channels]
+        cnt = len(ch)
+        arr = np.asarray(ch, np.int32)
+        npaths = np.zeros(cnt, np.int32)
+        nw = np.zeros((cnt, n), np.int32)
+        words = np.zeros((cnt, n, max_words), np.int32)
+        tot = np.zeros((cnt, n), np.float32)
+        lm = np.zeros((cnt, n), np.float32)
+        _check(lib().wfst_decoder_get_nbest(self.h, _i32(arr), cnt, int(n), int(max_words), _i32(npaths), _i32(nw), _i32(words),
+                                            _f32(tot), _f32(lm)))
+        out = []
+        for i in range(cnt):
+            out.append([dict(words=words[i, k, : min(nw[i, k], max_words)].copy(), n_words=int(nw[i, k]), tot_score=float(tot[i, k]),
+                             lm_score=float(lm[i, k])) for k in range(npaths[i])])
+        return out
 
     def set_profiling(self, on):
         _check(lib().wfst_decoder_set_profiling(self.h, int(bool(on))))

@@ -217,6 +217,8 @@ def main():
     log("[rank %d] graph: %d states, %d arcs (%.1fs)" % (rank, g.n_states, g.n_arcs, time.time() - t0))
     t0 = time.time()
     mats = make_utts(synth, g, m, rank * B, B, T, P, a)
+    if os.environ.get("WFST_BENCH_SAME_UTT"):  # experiment: every channel decodes the same utterance (no load imbalance)
+        mats[:] = mats[int(os.environ["WFST_BENCH_SAME_UTT"])]
     ll_dev = torch.from_numpy(mats).to(dev)  # [B][T][P] resident in HBM
     log("[rank %d] log-likelihoods: %d x [%d x %d] (%.1fs)" % (rank, B, T, P, time.time() - t0))
 

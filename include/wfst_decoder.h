@@ -188,6 +188,20 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
                                  int32_t *st_state, float *st_cost, int32_t *a_src, int32_t *a_dst,
                                  int32_t *a_ilabel, int32_t *a_olabel, float *a_graph, float *a_acoustic);
 
+/* The service's n-best (OnlineClgLatticeFastDecoder::GetNbest, kaldi-nnet3/kaldi-online-nnet3-my-
+ * decoder.cc:50-105: GetRawLattice -> DeterminizeLatticeWrapper -> NShortestPath ->
+ * ConvertNbestToVector, then LatticeToVector per path) of FINALIZED channels of a lattice-mode
+ * decoder: the n (<= 16) lowest-cost DISTINCT word sequences of the pruned lattice, cheapest first,
+ * each with tot_score = sum(graph + acoustic) and lm_score = sum(graph) of its best path.
+ * Computed on the device by a k-best search over the raw lattice (no determinized lattice is
+ * materialised).  Outputs for the i-th listed channel: n_paths[i]; n_words[i*n + k];
+ * words[(i*n + k)*max_words ...] (first max_words ids); tot_score / lm_score [i*n + k].
+ * n_paths[i] == 0: no lattice (see wfst_decoder_get_raw_lattice).  WFST_E_CAPACITY if a lattice has
+ * more than 32768 states or 131072 arcs. */
+int wfst_decoder_get_nbest(wfst_decoder *d, const int32_t *channels, int32_t n_channels, int32_t n,
+                           int32_t max_words, int32_t *n_paths, int32_t *n_words, int32_t *words,
+                           float *tot_score, float *lm_score);
+
 /* Kernel timing for the roofline report: while enabled, every expand / boundary launch of
  * wfst_decoder_advance is bracketed by HIP events recorded on the decoder's own stream.
  * wfst_decoder_get_profile waits for the stream and returns, since the last enable:

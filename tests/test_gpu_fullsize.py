@@ -82,8 +82,15 @@ def test_batch128_lattice_mode_properties(big, oracle):
 
     G = big["G"]
     lim = dict(LIM, lattice_links=6 << 20)
-    lats, best = gpu_lattices(G, big["graph"], CD, big["mats"], limits=lim)
+    lats, best, nbest = gpu_lattices(G, big["graph"], CD, big["mats"], limits=lim, nbest=8)
     assert all(d is not None for d in lats)
+    # n-best of all 128 utterances: the 1-best is GetBestPath's, totals ascend, word sequences are distinct
+    for u, paths in enumerate(nbest):
+        assert len(paths) >= 1 and np.array_equal(paths[0]["words"], best[u]["words"]), u
+        assert abs(paths[0]["tot_score"] - best[u]["tot_score"]) <= 1e-4 * abs(best[u]["tot_score"]), u
+        tots = [p["tot_score"] for p in paths]
+        assert all(b >= a for a, b in zip(tots, tots[1:])), u
+        assert len({tuple(p["words"].tolist()) for p in paths}) == len(paths), u
     h = oracle.load_graph(big["path"])
     try:
         oracle.set_order_free(True)

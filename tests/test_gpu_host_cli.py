@@ -108,3 +108,35 @@ def test_cli_lattice_out_matches_oracle(mode, synth, oracle, tmp_path):
     finally:
         oracle.set_order_free(False)
         oracle.free_graph(h)
+
+
+def test_cli_nbest_matches_the_reference_pipeline(synth, refdec, tmp_path):
+    """--nbest=N (host mirror GetNbest -> LatticeToVector, the service's GetNbestTxt) against the
+    reference's determinizer + NShortestPath run on the lattices the same CLI run wrote."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m = synth.default_tid2pdf(600)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=12\n--max-active=1000000\n--min-active=0\n--lattice-beam=5\n")
+    mats = [synth.make_loglikes(g, T, 300, m, seed=500 + i, mu=-2.2)[0] for i, T in enumerate([50, 21, 3])]
+    with open(tmp_path / "ll.bin", "wb") as f:
+        for i, x in enumerate(mats):
+            key = ("utt%03d" % i).encode()
+            f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
+    for mode in ([], ["--single-stream"]):
+        lat = str(tmp_path / ("lat%d.bin" % len(mode)))
+        p = subprocess.run([CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--batch=4", "--nbest=4", "--lattice-out=" + lat] + mode +
+                           [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got = {l.split()[0]: [int(w) for w in l.split()[1:]] for l in p.stdout.strip().splitlines() if re.match(r"utt\d+-\d+", l)}
+        sc = {mm.group(1): (float(mm.group(2)), float(mm.group(3))) for mm in re.finditer(r"LOG (utt\d+-\d+) tot_score (\S+) lm_score (\S+)", p.stderr)}
+        for i in range(len(mats)):
+            ref = pyoracle.ref_nbest_from_lattice_file(refdec, lat, i, 4)
+            assert ref is not None and len(ref[0]) >= 1
+            for k, (w, tot, lm) in enumerate(ref[0]):
+                key = "utt%03d-%d" % (i, k + 1)
+                assert got[key] == w.tolist(), key
+                assert abs(sc[key][0] - tot) <= 2e-4 * abs(tot) and abs(sc[key][1] - lm) <= 2e-4 * max(1.0, abs(lm)), key
+            assert "utt%03d-%d" % (i, len(ref[0]) + 1) not in got

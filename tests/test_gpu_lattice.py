@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 LIM = dict(max_frames=512, max_tokens_per_frame=32768, arena_tokens=1 << 21, lattice_links=1 << 22)
 
 
-def gpu_lattices(G, graph, cd, mats, use_final_probs=True, limits=LIM):
+def gpu_lattices(G, graph, cd, mats, use_final_probs=True, limits=LIM, nbest=0):
     dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), **limits)
     dev = G.upload(mats)
     dec.init()
@@ -29,8 +29,9 @@ def gpu_lattices(G, graph, cd, mats, use_final_probs=True, limits=LIM):
     dec.finalize()
     lats = [dec.raw_lattice(c, use_final_probs) for c in range(len(mats))]
     best = dec.best_paths(use_final_probs=True)
+    nb = dec.nbest(nbest) if nbest else None
     dec.free()
-    return lats, best
+    return (lats, best, nb) if nbest else (lats, best)
 
 
 def as_raw(d):
@@ -175,4 +176,84 @@ def test_gpu_lattice_feeds_the_references_nbest(refdec, tmp_path):
         lats, _ = gpu_lattices(G, graph, dict(g.meta["cfgs"][ci]), g.utts)
         for ui, d in enumerate(lats):
             check_nbest_of_lattice_bytes(refdec, G.pkg.shard.lattice_to_bytes(d), ci, ui, tmp_path, "cfg %d utt %d" % (ci, ui))
+    graph.free()
+
+
+def _same_nbest(got, want, what):
+    """same word sequences in the same order, scores within 1e-4 relative; entries whose total
+    scores are closer than that may come out in either order"""
+    assert len(got) == len(want), "%s: %d paths, reference %d" % (what, len(got), len(want))
+    used = [False] * len(want)
+    for k, a in enumerate(got):
+        hit = None
+        for j, b in enumerate(want):
+            if not used[j] and np.array_equal(a["words"], b[0]) and abs(a["tot_score"] - b[1]) <= 1e-4 * abs(b[1]):
+                hit = j
+                break
+        assert hit is not None, "%s: path %d (%s, %.4f) is not in the reference's list" % (what, k, a["words"].tolist(), a["tot_score"])
+        used[hit] = True
+        b = want[hit]
+        assert abs(a["lm_score"] - b[2]) <= 1e-4 * max(1.0, abs(b[2])), "%s path %d lm_score" % (what, k)
+        if hit != k:  # only a near-tie may swap places
+            assert abs(want[k][1] - b[1]) <= 2e-4 * abs(b[1]), "%s: path %d out of order" % (what, k)
+
+
+def test_gpu_nbest_matches_the_reference_golden(tmp_path):
+    """wfst_decoder_get_nbest (k-best distinct word sequences on the device) against the n-best the
+    reference gets from ITS OWN lattice with its determinizer + NShortestPath
+    (tests/golden/nbest_hclg600.npz)."""
+    import gpu_util as G
+    from nbest_util import golden_nbest
+
+    g = Golden("lattice_hclg600")
+    graph = G.wfstdec.Graph.load(g.write_graph(str(tmp_path / "g.bin")))
+    graph.set_tid2pdf(g.tid2pdf)
+    for ci in (0, 1):
+        dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(dict(g.meta["cfgs"][ci])), len(g.utts), **LIM)
+        dev = G.upload(g.utts)
+        dec.init()
+        dec.advance([t.data_ptr() for t in dev], [int(m.shape[0]) for m in g.utts], int(g.utts[0].shape[1]))
+        dec.finalize()
+        want_n = golden_nbest(ci, 0)[1]
+        got = dec.nbest(want_n)
+        best = dec.best_paths()
+        for ui in range(len(g.utts)):
+            want, _ = golden_nbest(ci, ui)
+            _same_nbest(got[ui], want, "cfg %d utt %d" % (ci, ui))
+            assert np.array_equal(got[ui][0]["words"], best[ui]["words"])   # 1-best == GetBestPath
+        # a sub-list of channels, other n
+        one = dec.nbest(2, channels=[2])
+        assert len(one) == 1 and [p["words"].tolist() for p in one[0]] == [p["words"].tolist() for p in got[2][:2]]
+        dec.free()
+    graph.free()
+
+
+@pytest.mark.parametrize("lattice_beam", [3.0, 8.0])
+def test_gpu_nbest_equals_reference_pipeline_on_its_own_lattice(lattice_beam, refdec, synth, tmp_path):
+    """Bigger lattices, n = 10: the device n-best against the reference's DeterminizeLatticeWrapper
+    + NShortestPath + LatticeToVector run (oracle/_ref) on the very lattice the device returns."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(20000, seed=7, n_tid=2000, n_words=3000)
+    m = synth.default_tid2pdf(2000)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=lattice_beam)
+    mats = [synth.make_loglikes_multi(g, T, 1000, m, seed=90 + i)[0] for i, T in enumerate((60, 33, 1, 80, 47))]
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), **LIM)
+    dev = G.upload(mats)
+    dec.init()
+    dec.advance([t.data_ptr() for t in dev], [int(x.shape[0]) for x in mats], int(mats[0].shape[1]))
+    dec.finalize()
+    got = dec.nbest(10)
+    for i in range(len(mats)):
+        p = str(tmp_path / ("l%d.lat" % i))
+        with open(p, "wb") as f:
+            f.write(G.pkg.shard.lattice_to_bytes(dec.raw_lattice(i)))
+        ref = pyoracle.ref_nbest_from_lattice_file(refdec, p, 0, 10)
+        assert ref is not None
+        _same_nbest(got[i], ref[0], "utt %d lattice_beam %g" % (i, lattice_beam))
+    dec.free()
     graph.free()
