@@ -13,6 +13,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -29,7 +30,8 @@ def newest(pattern):
 def per_kernel(path):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0].replace("wfst::", "")
+        m = re.search(r"(\w+_kernel|calib_\w+)", r["Kernel_Name"])  # "void wfst::insert_kernel<false>(...)" -> insert_kernel
+        k = m.group(1) if m else r["Kernel_Name"].split("(")[0].replace("wfst::", "")
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
     return {k: {"launches": n, "kb_per_launch": v / n} for k, (n, v) in agg.items()}
