@@ -609,6 +609,7 @@ struct BoundaryShared {
   int err;
   int occ;        // epsilon-table entries touched this frame (continues ChanCtl::eps_occ)
   int nwon;       // tokens won by an epsilon arc this frame
+  int nemit;      // lattice mode: tokens of the frame that emit epsilon links
   float redf[kBW];
   u64 red64[kBW];
   u64 best;
@@ -747,21 +748,64 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
     // cost.  Every token of the frame being built with epsilon arcs out and cost < cutoff emits them.
     int4 *links = D.links + (size_t)c * D.link_cap;
     const int n_frame = sh.nnew;
-    for (int i = tid; i < n_frame; i += kBT) {
-      const int4 T = tok[base + i];
-      if (!((uint32_t)T.w & kFlagOutEps)) continue;
-      const float cost = __int_as_float(T.y);
-      if (!(cost < cutoff)) continue;
-      const int neps = (int)((uint32_t)D.g.arcs[T.x].x & kEpsMask);
-      for (int e = 0; e < neps; ++e) {
-        const int a = T.x + 1 + e;
+    // (1) compact the tokens that emit (a few percent of the frame) -- the closure worklists are
+    // free by now and serve as the list -- so that (2) runs its dependent gathers with full waves
+    int32_t *emit = reinterpret_cast<int32_t *>(D.worklist + (size_t)c * 2 * D.wl_cap);
+    if (tid == 0) sh.nemit = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_frame; i0 += 4 * kBT) {  // 4 independent loads in flight per thread
+      int4 T[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kBT + tid;
+        T[u] = i < n_frame ? tok[base + i] : make_int4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kBT + tid;
+        const bool on = i < n_frame && ((uint32_t)T[u].w & kFlagOutEps) && (__int_as_float(T[u].y) < cutoff);
+        const u64 m = __ballot(on);
+        int wb = 0;
+        if ((tid & 63) == 0 && m) wb = atomicAdd(&sh.nemit, __popcll(m));
+        wb = __shfl(wb, 0, 64);
+        if (on) emit[wb + lane_rank(m)] = i;
+      }
+    }
+    __syncthreads();
+    const int n_emit = sh.nemit;
+    for (int j0 = 0; j0 < n_emit; j0 += kBT) {
+      const int j = j0 + tid;
+      int i = 0, row = 0, neps = 0, npass = 0;
+      float cost = 0.0f;
+      if (j < n_emit) {
+        i = emit[j];
+        const int4 T = tok[base + i];
+        row = T.x;
+        cost = __int_as_float(T.y);
+        neps = (int)((uint32_t)D.g.arcs[row].x & kEpsMask);
+        for (int e = 0; e < neps; ++e) npass += (cost + __int_as_float(D.g.arcs[row + 1 + e].z)) < cutoff;
+      }
+      // one atomicAdd per wave for all its links
+      int ps = npass;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(ps, o, 64);
+        if ((tid & 63) >= o) ps += v;
+      }
+      const int wtot = __shfl(ps, 63, 64);
+      int lb = 0;
+      if ((tid & 63) == 0 && wtot) lb = atomicAdd(&D.ctl[c].link_count, wtot);
+      lb = __shfl(lb, 0, 64);
+      int lp = lb + ps - npass;
+      for (int e = 0; e < neps && npass; ++e) {
+        const int a = row + 1 + e;
         const int4 arc = D.g.arcs[a];
         const float tot = cost + __int_as_float(arc.z);
         if (!(tot < cutoff)) continue;
         const int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;
-        const int lp = atomicAdd(&D.ctl[c].link_count, 1);
         if ((int64_t)lp < D.link_cap) links[lp] = make_int4(base + i, ld_agent(&toki[ord]), a, __float_as_int(tot));
         else atomicOr(&sh.err, kErrLinksFull);
+        ++lp;
       }
     }
     __syncthreads();
