@@ -245,19 +245,30 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
   if (ndev <= 0) return fail(WFST_E_DEVICE, "no HIP device available (this library has no CPU path)");
   if (device < 0 || device >= ndev) return fail(WFST_E_ARG, "device index out of range");
   HIP_TRY(hipSetDevice(device));
-  const int64_t N = (int64_t)n_arcs + n_states;
-  if (N >= (int64_t)kNoArc) return fail(WFST_E_FORMAT, "graphs with states + arcs >= 2^30 are not supported");
+  if ((int64_t)n_arcs + n_states >= (int64_t)kNoArc / 2)
+    return fail(WFST_E_FORMAT, "graphs with states + arcs >= 2^29 are not supported");
+  // A row (header + arcs, 16-byte slots) that fits in k 64-byte lines is placed so that it touches
+  // only k lines: expanding a token is a random gather, priced per LINE, and an unaligned 3-arc row
+  // straddles two.  Costs ~10 % padding slots.  WFST_ROW_ALIGN=1 packs the rows tightly (slots per line).
+  int64_t line_slots = 4;
+  if (const char *e = getenv("WFST_ROW_ALIGN")) line_slots = std::max(1, atoi(e));
 
   // pass 1: validate, positions, epsilon targets
   std::vector<int32_t> pos((size_t)n_states);
   std::vector<uint8_t> is_target((size_t)n_states, 0);
-  int64_t off = 0;
+  int64_t off = 0, next_slot = 0;
   for (int32_t s = 0; s < n_states; ++s) {
+    {
+      const int64_t sz = 1 + (int64_t)states[s].num_arcs, in_line = next_slot % line_slots;
+      if ((in_line + sz + line_slots - 1) / line_slots > (sz + line_slots - 1) / line_slots)
+        next_slot += line_slots - in_line;
+    }
     const uint32_t na = states[s].num_arcs, ne = states[s].niepsilons;
     if (ne > na || off + na > n_arcs) return fail(WFST_E_FORMAT, "state arc counts inconsistent with total_arcs");
     if (ne > kEpsMask) return fail(WFST_E_FORMAT, "state with more than 4095 input-epsilon arcs");
     if (na - ne >= (1u << (32 - kEpsBits))) return fail(WFST_E_FORMAT, "state with 2^20 or more emitting arcs");
-    pos[s] = (int32_t)(off + s);
+    pos[s] = (int32_t)next_slot;
+    next_slot += 1 + (int64_t)na;
     for (uint32_t i = 0; i < na; ++i) {
       const wfst_arc &a = arcs[off + i];
       if ((i < ne) != (a.ilabel == 0))
@@ -268,6 +279,8 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
     off += na;
   }
   if (off != n_arcs) return fail(WFST_E_FORMAT, "sum of num_arcs != total_arcs");
+  const int64_t N = next_slot;  // slots of rows[] (headers + arcs + padding)
+  if (N >= (int64_t)kNoArc) return fail(WFST_E_FORMAT, "graph too large for 30-bit row indices");
   // next_eps word per state: bit 31 = has outgoing epsilon arcs, bits 30..0 = 1 + ordinal among
   // the epsilon-target states (the index of the state's slot in every channel's epsilon table)
   std::vector<uint32_t> next_eps((size_t)n_states, 0u);
@@ -280,7 +293,7 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
     }
   }
   // pass 2: rows
-  std::vector<int4> ext((size_t)N);
+  std::vector<int4> ext((size_t)N, make_int4(0, -1, 0, 0));
   std::vector<int32_t> h_src((size_t)N, 0), h_il((size_t)N, kHeaderLabel), h_ol((size_t)N, 0);
   off = 0;
   for (int32_t s = 0; s < n_states; ++s) {
@@ -415,7 +428,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   // hash partitions per channel: each insert workgroup owns an LDS table of lds_slots entries;
   // a bucket too full for it is handled in sub-passes, so these are speed knobs, not limits
   const int64_t M = L.max_tokens_per_frame;
-  int lds_slots = 4096, log2lds = 12, log2part = 6;
+  int lds_slots = 4096, log2lds = 12, log2part = 5;  // 32 partitions: measured best at batch 128 (16: insert slower, 64: more bucket atomics)
   if (const char *e = getenv("WFST_LOG2_PARTS")) log2part = std::max(0, std::min(6, atoi(e)));
   if (const char *e = getenv("WFST_LOG2_LDS_SLOTS")) { log2lds = std::max(8, std::min(13, atoi(e))); lds_slots = 1 << log2lds; }
   while (log2part > 0 && (int64_t)lds_slots << (log2part - 1) >= 4 * M) --log2part;  // tiny limits: fewer parts

@@ -292,13 +292,16 @@ constexpr int kInsertThreads = 512;
 constexpr int kInsertUnroll = 4;
 
 // Which buckets share a workgroup?  Partitions of a light channel hold a few dozen records each;
-// the largest aligned group of 64 / 16 / 4 partitions whose records fit ONE pass of a small LDS
+// the largest aligned group of 64 / 32 / ... / 2 partitions whose records fit ONE pass of a small LDS
 // table becomes one work item, so a light channel costs 1-4 items while a heavy channel keeps all
-// of its partitions separate.  Returns the group of partition p: {first partition, size, records}.
+// of its partitions separate.  (Halving steps: with 64/16/4 a typical channel sat just above a
+// threshold and was cut four times finer than needed.  Greedy contiguous runs filled to joint_max
+// were tried and are slower: ~700 full items per frame balance worse over 768 workgroups than
+// ~1300 half-full ones.)  Returns the group of partition p: {first partition, size, records}.
 __device__ __forceinline__ void partition_group(int P, int joint_max, int p, int ps /*inclusive prefix of counts, per lane*/,
                                                 int cnt_p, int *g0, int *G, int *n) {
   *G = 1; *g0 = p; *n = cnt_p;
-  for (int cand = P; cand >= 4; cand >>= 2) {
+  for (int cand = P; cand >= 2; cand >>= 1) {
     const int s0 = p & ~(cand - 1);
     const int tot = __shfl(ps, s0 + cand - 1, 64) - (s0 ? __shfl(ps, s0 - 1, 64) : 0);
     if (tot <= joint_max) { *G = cand; *g0 = s0; *n = tot; return; }
