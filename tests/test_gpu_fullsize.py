@@ -134,3 +134,36 @@ def test_batch128_lattice_mode_properties(big, oracle):
         A, Bw = as_raw(d), as_raw(lats[u])
         assert len(A.a_src) < len(Bw.a_src)
         assert multiset_contains(Bw.labelled_arcs(), A.labelled_arcs()), "utt %d" % u
+
+
+def test_config5_beam15_lattice_and_nbest_sample(big, oracle, refdec, tmp_path):
+    """BASELINE configs[4] (lattice-generating decode, beam = 15) on the 10M-arc graph: 16 utterances
+    in lattice mode; two of them state by state against the oracle, their 5-best against the
+    reference's determinizer + NShortestPath run on the lattice the device returned."""
+    from test_gpu_lattice import _same_nbest, as_raw, gpu_lattices, nodes
+
+    G = big["G"]
+    cd = dict(CD, beam=15.0, lattice_beam=8.0)
+    lim = dict(max_frames=304, max_tokens_per_frame=262144, arena_tokens=300 * 60000, lattice_links=24 << 20)
+    mats = big["mats"][:16]
+    lats, best, nbest = gpu_lattices(G, big["graph"], cd, mats, limits=lim, nbest=5)
+    h = oracle.load_graph(big["path"])
+    try:
+        for u in (3, 12):
+            r = oracle.decode(h, pyoracle.Config(**cd), mats[u], big["m"])
+            if r.extra["ties"] == 0:
+                assert np.array_equal(best[u]["words"], r.words) and np.array_equal(best[u]["tids"], r.tids)
+            oracle.set_order_free(True)
+            O = pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**cd), mats[u], big["m"])
+            oracle.set_order_free(False)
+            L = as_raw(lats[u])
+            assert np.array_equal(nodes(L), nodes(O)) and np.array_equal(L.labelled_arcs(), O.labelled_arcs()), u
+            p = str(tmp_path / ("c5_%d.lat" % u))
+            with open(p, "wb") as f:
+                f.write(G.pkg.shard.lattice_to_bytes(lats[u]))
+            ref = pyoracle.ref_nbest_from_lattice_file(refdec, p, 0, 5)
+            assert ref is not None
+            _same_nbest(nbest[u], ref[0], "utt %d" % u)
+    finally:
+        oracle.set_order_free(False)
+        oracle.free_graph(h)

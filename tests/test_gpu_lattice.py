@@ -257,3 +257,60 @@ def test_gpu_nbest_equals_reference_pipeline_on_its_own_lattice(lattice_beam, re
         _same_nbest(got[i], ref[0], "utt %d lattice_beam %g" % (i, lattice_beam))
     dec.free()
     graph.free()
+
+
+def test_gpu_lattice_channel_reuse_ragged_and_no_final_state(oracle, synth, tmp_path):
+    """Lattice mode across utterances: the same decoder object decodes a second, different batch
+    after InitDecoding (links, offsets and compacted lattices of the first must not leak), with
+    ragged lengths and a subset of channels; and a graph whose final state is unreachable (every
+    last-frame token is final, base-inl.h:936-940)."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(3000, seed=17, n_tid=400, n_words=300)
+    m = synth.default_tid2pdf(400)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    ho = oracle.load_graph(path)
+    cd = dict(beam=11.0, max_active=1000000, min_active=0, lattice_beam=5.0)
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 4, **LIM)
+    try:
+        oracle.set_order_free(True)
+        for rnd, (chans, lens) in enumerate((([0, 1, 2, 3], [40, 25, 7, 33]), ([2, 0], [12, 50]), ([3, 1, 0], [1, 30, 30]))):
+            mats = [synth.make_loglikes(g, T, 200, m, seed=1000 * rnd + i, mu=-2.0)[0] for i, T in enumerate(lens)]
+            dev = G.upload(mats)
+            dec.init(chans)
+            dec.advance([t.data_ptr() for t in dev], lens, int(mats[0].shape[1]), channels=chans)
+            dec.finalize(chans)
+            for c, x in zip(chans, mats):
+                O = pyoracle.oracle_raw_lattice(oracle, ho, pyoracle.Config(**cd), x, m)
+                d = dec.raw_lattice(c)
+                assert (d is not None) == O.ok
+                L = as_raw(d)
+                assert np.array_equal(nodes(L), nodes(O)) and np.array_equal(L.labelled_arcs(), O.labelled_arcs()), "round %d channel %d" % (rnd, c)
+            nb = dec.nbest(3, channels=chans)
+            bp = dec.best_paths(channels=chans)
+            for k in range(len(chans)):
+                assert np.array_equal(nb[k][0]["words"], bp[k]["words"])
+    finally:
+        oracle.set_order_free(False)
+        oracle.free_graph(ho)
+    dec.free()
+    graph.free()
+    # no final state reachable: golden graph of tests/golden/no_final.npz
+    gn = Golden("no_final")
+    graph = G.wfstdec.Graph.load(gn.write_graph(str(tmp_path / "nf.bin")))
+    ho = oracle.load_graph(str(tmp_path / "nf.bin"))
+    cdn = dict(gn.meta["cfgs"][0])
+    lats, _ = gpu_lattices(G, graph, cdn, [gn.utts[1]])
+    try:
+        oracle.set_order_free(True)
+        O = pyoracle.oracle_raw_lattice(oracle, ho, pyoracle.Config(**cdn), gn.utts[1], None)
+    finally:
+        oracle.set_order_free(False)
+    L = as_raw(lats[0])
+    assert O.ok and np.array_equal(nodes(L), nodes(O)) and np.array_equal(L.labelled_arcs(), O.labelled_arcs())
+    assert L.st_final.sum() == (L.st_frame == gn.utts[1].shape[0]).sum()   # every last-frame state is final
+    oracle.free_graph(ho)
+    graph.free()
