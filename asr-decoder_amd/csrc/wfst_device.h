@@ -78,7 +78,7 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t link_count;    // lattice mode: forward links recorded so far (atomicAdd)
   int32_t lat_arcs;      // lattice mode, after lattice_prune_kernel: surviving links in lat_arcs[]
   int32_t lat_toks;      //   "   surviving tokens in lat_toks[]
-  int32_t pad2;
+  int32_t tiles_left;    // expansion tiles of the frame not finished yet (the last one plans the insert items)
   unsigned long long pad1;
 };
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
@@ -206,7 +206,7 @@ void launch_nbest(const DecoderDev &D, const NbestDev &N, const int32_t *chan_li
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s);
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups,
-                   hipStream_t s);  // plan + insert
+                   hipStream_t s);
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int do_prep,
                     int group, int par, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);

@@ -83,6 +83,53 @@ __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned l
   t_prev = now;
 }
 
+// Which buckets share a workgroup?  Partitions of a light channel hold a few dozen records each;
+// the largest aligned group of 64 / 32 / ... / 2 partitions whose records fit ONE pass of a small LDS
+// table becomes one work item, so a light channel costs 1-4 items while a heavy channel keeps all
+// of its partitions separate.  (Halving steps: with 64/16/4 a typical channel sat just above a
+// threshold and was cut four times finer than needed.  Greedy contiguous runs filled to joint_max
+// were tried and are slower: ~700 full items per frame balance worse over 768 workgroups than
+// ~1300 half-full ones.)  Returns the group of partition p: {first partition, size, records}.
+__device__ __forceinline__ void partition_group(int P, int joint_max, int p, int ps /*inclusive prefix of counts, per lane*/,
+                                                int cnt_p, int *g0, int *G, int *n) {
+  *G = 1; *g0 = p; *n = cnt_p;
+  for (int cand = P; cand >= 2; cand >>= 1) {
+    const int s0 = p & ~(cand - 1);
+    const int tot = __shfl(ps, s0 + cand - 1, 64) - (s0 ? __shfl(ps, s0 - 1, 64) : 0);
+    if (tot <= joint_max) { *G = cand; *g0 = s0; *n = tot; return; }
+  }
+}
+
+// plan_channel: one wave lists the insert work items of channel c for this frame: item =
+// channel << 16 | first partition << 8 | group size.  Run by the workgroup that finishes the
+// channel's last expansion tile (all bucket counters of the channel are final then; they are only
+// ever touched by device-scope atomics, so this wave reads them with atomic loads).
+__device__ void plan_channel(const DecoderDev &D, int c, int group, int par) {
+  const int lane = threadIdx.x & 63;
+  FrameCtl *fc = D.fctl + group;
+  const int P = D.n_part;
+  const int32_t *cnts = D.bucket_cnt + (size_t)c * P;
+  const int cnt = (lane < P) ? min(ld_agent(&cnts[lane]), D.bucket_cap) : 0;
+  int ps = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int v = __shfl_up(ps, off, 64);
+    if (lane >= off) ps += v;
+  }
+  int g0, G, n;
+  partition_group(P, min(D.joint_max, (D.lds_slots * 3) >> 2), lane < P ? lane : 0, ps, cnt, &g0, &G, &n);
+  const bool leader = lane < P && g0 == lane && n > 0;
+  const u64 m = __ballot(leader);
+  if (!m) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&fc->n_items[par], __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (leader) {
+    const int idx = base + lane_rank(m);
+    if (idx < D.item_cap) D.items[(size_t)group * D.item_cap + idx] = (c << 16) | (g0 << 8) | G;
+  }
+}
+
 // =========================================================================================
 // expand_kernel: grid (n_channels, tiles_per_channel), 256 threads.  blockIdx.x = channel, so
 // with n_channels % 8 == 0 the workgroups of a channel share an XCD (speed only: its buckets
@@ -114,6 +161,13 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
   __shared__ int4 s_rec[kChunk];
   __shared__ int s_ticket;
 
+  __shared__ int s_last;
+  if (blockIdx.x == 0 && tid == 0) {  // lists of the previous step are consumed
+    fc->total_tiles[par ^ 1] = 0;
+    fc->ticket[par ^ 1] = 0;
+    fc->n_items[par ^ 1] = 0;
+    fc->item_ticket[par ^ 1] = 0;
+  }
   const TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap;
   unsigned long long tq = wall_clock64();
   for (int t = blockIdx.x; t < total_tiles;) {
@@ -273,6 +327,12 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
       atomicAdd(&ctl->cnt_E, nE);
       if (nR) atomicAdd(&ctl->cnt_rec, nR);
     }
+    // the channel's last tile plans its insert work items (every thread's bucket atomics have
+    // returned: their results were used above)
+    __syncthreads();
+    if (tid == 0) s_last = atomicSub(&ctl->tiles_left, 1) == 1;
+    __syncthreads();
+    if (s_last && wave == 0) plan_channel(D, c, group, par);
     // next tile: the first gridDim.x tiles are taken statically, the rest by ticket
     if (total_tiles <= (int)gridDim.x) break;
     if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(&fc->ticket[par], 1);
@@ -290,61 +350,6 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
 // =========================================================================================
 constexpr int kInsertThreads = 512;
 constexpr int kInsertUnroll = 4;
-
-// Which buckets share a workgroup?  Partitions of a light channel hold a few dozen records each;
-// the largest aligned group of 64 / 32 / ... / 2 partitions whose records fit ONE pass of a small LDS
-// table becomes one work item, so a light channel costs 1-4 items while a heavy channel keeps all
-// of its partitions separate.  (Halving steps: with 64/16/4 a typical channel sat just above a
-// threshold and was cut four times finer than needed.  Greedy contiguous runs filled to joint_max
-// were tried and are slower: ~700 full items per frame balance worse over 768 workgroups than
-// ~1300 half-full ones.)  Returns the group of partition p: {first partition, size, records}.
-__device__ __forceinline__ void partition_group(int P, int joint_max, int p, int ps /*inclusive prefix of counts, per lane*/,
-                                                int cnt_p, int *g0, int *G, int *n) {
-  *G = 1; *g0 = p; *n = cnt_p;
-  for (int cand = P; cand >= 2; cand >>= 1) {
-    const int s0 = p & ~(cand - 1);
-    const int tot = __shfl(ps, s0 + cand - 1, 64) - (s0 ? __shfl(ps, s0 - 1, 64) : 0);
-    if (tot <= joint_max) { *G = cand; *g0 = s0; *n = tot; return; }
-  }
-}
-
-// plan_kernel: one wave per channel lists the insert work items of the frame: item =
-// channel << 16 | first partition << 8 | group size.  grid ceil(chan_cnt / 4) x 256.
-__global__ __launch_bounds__(256) void plan_kernel(DecoderDev D, int chan_off, int chan_cnt, int group, int par) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  FrameCtl *fc = D.fctl + group;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // lists of the previous step are consumed
-    fc->total_tiles[par ^ 1] = 0;
-    fc->ticket[par ^ 1] = 0;
-    fc->n_items[par ^ 1] = 0;
-    fc->item_ticket[par ^ 1] = 0;
-  }
-  const int ci = blockIdx.x * 4 + wave;
-  if (ci >= chan_cnt) return;
-  const int c = chan_off + ci;
-  if (!D.ctl[c].active) return;
-  const int P = D.n_part;
-  const int32_t *cnts = D.bucket_cnt + (size_t)c * P;
-  const int cnt = (lane < P) ? min(cnts[lane], D.bucket_cap) : 0;
-  int ps = cnt;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int v = __shfl_up(ps, off, 64);
-    if (lane >= off) ps += v;
-  }
-  int g0, G, n;
-  partition_group(P, min(D.joint_max, (D.lds_slots * 3) >> 2), lane < P ? lane : 0, ps, cnt, &g0, &G, &n);
-  const bool leader = lane < P && g0 == lane && n > 0;
-  const u64 m = __ballot(leader);
-  if (!m) return;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(&fc->n_items[par], __popcll(m));
-  base = __shfl(base, 0, 64);
-  if (leader) {
-    const int idx = base + lane_rank(m);
-    if (idx < D.item_cap) D.items[(size_t)group * D.item_cap + idx] = (c << 16) | (g0 << 8) | G;
-  }
-}
 
 // insert_kernel: a fixed grid of workgroups pulls the planned items (first gridDim.x statically,
 // then by ticket); 256 threads, dynamic LDS = lds_slots * 12 bytes.
@@ -1012,6 +1017,7 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
     // publish this channel's tiles for the expansion (any disjoint range will do)
     const int ntiles = (n + kTileTokens - 1) / kTileTokens;
     sh.active = 0;
+    ctl->tiles_left = ntiles;
     if (ntiles > 0) {
       const int start = atomicAdd(&D.fctl[group].total_tiles[par], ntiles);
       ctl->tile_start = start;
@@ -1401,7 +1407,6 @@ void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hi
 }
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups, hipStream_t s) {
   const size_t lds = (size_t)D.lds_slots * (D.lattice ? 16 : 12);
-  hipLaunchKernelGGL(plan_kernel, dim3((chan_cnt + 3) / 4), dim3(256), 0, s, D, chan_off, chan_cnt, group, par);
   if (D.lattice) hipLaunchKernelGGL(insert_kernel<true>, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
   else hipLaunchKernelGGL(insert_kernel<false>, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
 }
