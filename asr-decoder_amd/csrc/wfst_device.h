@@ -14,7 +14,8 @@ namespace wfst {
 
 // ---- graph in HBM: CSR with the row header in front of the row ---------------------------
 // rows[]: ONE int4 array in "ext" index space.  State s owns slots [pos(s), pos(s)+1+num_arcs(s)),
-//   pos(s) = arc_begin(s) + s, and IS identified by pos(s) everywhere on the device.
+//   pos(s) increasing in s (rows are packed, with padding slots where a row would otherwise
+//   straddle one more 64-byte line than it needs), and IS identified by pos(s) everywhere on the device.
 //   rows[pos(s)]      header {(n_emit << 12) | n_eps, original state id, next_eps word of s, 0}
 //   rows[pos(s)+1+i]  arc i {ll_col, next_eps(nextstate), weight bits, pos(nextstate)}; epsilon arcs
 //                     first.  ll_col = log-likelihood column of the ilabel (tid2pdf applied at
