@@ -702,56 +702,59 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (a >= 0 && b >= 0) { (void)hipEventRecord(d->ev_pool[b], st); d->ev_pairs[cls].push_back({a, b}); }
   };
   const std::vector<int> gpar0(d->gpar);  // parity each group starts this call with
-  auto enqueue = [&]() -> hipError_t {
-    hipError_t err = hipSuccess;
-    auto E = [&](hipError_t r) { if (err == hipSuccess) err = r; };
-    if (G > 1) E(hipEventRecord(d->gevents[0], d->stream));
-    for (int g = 0; g < G; ++g) {
-      const int off = g * per, cnt = std::min(per, d->n_channels - off);
-      if (cnt <= 0 || gsteps[g] == 0) continue;
-      hipStream_t st = G > 1 ? d->gstreams[g] : d->stream;
-      if (G > 1) E(hipStreamWaitEvent(st, d->gevents[0], 0));
-      int par = gpar0[g];
-      timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });  // GetCutoff + seed only
-      for (int s = 0; s < gsteps[g]; ++s) {
-        timed(0, st, [&] { launch_expand(d->D, g, par, d->expand_wgs, st); });
-        timed(1, st, [&] { launch_insert(d->D, off, cnt, g, par, d->insert_wgs, st); });
-        timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, s + 1 < gsteps[g], g, par ^ 1, st); });
-        par ^= 1;
-      }
-      if (G > 1) {
-        E(hipEventRecord(d->gevents[1 + g], st));
-        E(hipStreamWaitEvent(d->stream, d->gevents[1 + g], 0));
-      }
+  // the frame loop of one channel group on stream st
+  auto enqueue_group = [&](int g, hipStream_t st) {
+    const int off = g * per, cnt = std::min(per, d->n_channels - off);
+    if (cnt <= 0 || gsteps[g] == 0) return;
+    int par = gpar0[g];
+    timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });  // GetCutoff + seed only
+    for (int s = 0; s < gsteps[g]; ++s) {
+      timed(0, st, [&] { launch_expand(d->D, g, par, d->expand_wgs, st); });
+      timed(1, st, [&] { launch_insert(d->D, off, cnt, g, par, d->insert_wgs, st); });
+      timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, s + 1 < gsteps[g], g, par ^ 1, st); });
+      par ^= 1;
     }
-    return err;
   };
-  if (d->use_graph && !d->profiling && steps >= 4) {
-    // launch-bound inner loop -> hipGraph: per-frame state lives in ChanCtl on the device, so the
-    // captured kernels and their arguments are identical for every call with the same frame counts
-    std::vector<int> key(gsteps);
-    key.push_back((int)stride);
-    for (int g = 0; g < G; ++g) key.push_back(gpar0[g]);
+  // launch-bound inner loop -> hipGraph: per-frame state lives in ChanCtl on the device, so the
+  // captured kernels and their arguments are identical for every call with the same frame counts.
+  // One graph PER CHANNEL GROUP, each launched on its own stream: independent graph launches overlap
+  // on the GPU (parallel branches inside one graph were measured to run serially).
+  auto run_group = [&](int g, hipStream_t st) -> int {
+    if (gsteps[g] == 0) return WFST_OK;
+    if (!(d->use_graph && !d->profiling && gsteps[g] >= 4)) { enqueue_group(g, st); return WFST_OK; }
+    const std::vector<int> key = {g, gsteps[g], (int)stride, gpar0[g]};
     auto it = d->graphs.find(key);
     if (it == d->graphs.end()) {
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
-      HIP_TRY(hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal));
-      hipError_t ce = enqueue();
-      hipError_t ee = hipStreamEndCapture(d->stream, &graph);
-      HIP_TRY(ce);
-      HIP_TRY(ee);
+      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      enqueue_group(g, st);
+      HIP_TRY(hipStreamEndCapture(st, &graph));
       HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       HIP_TRY(hipGraphDestroy(graph));
       if (d->graphs.size() >= 64) {  // bounded cache
+        HIP_TRY(hipDeviceSynchronize());
         for (auto &kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
         d->graphs.clear();
       }
       it = d->graphs.emplace(key, exec).first;
     }
-    HIP_TRY(hipGraphLaunch(it->second, d->stream));
+    HIP_TRY(hipGraphLaunch(it->second, st));
+    return WFST_OK;
+  };
+  if (G == 1) {
+    const int rc = run_group(0, d->stream);
+    if (rc != WFST_OK) return rc;
   } else {
-    HIP_TRY(enqueue());
+    HIP_TRY(hipEventRecord(d->gevents[0], d->stream));  // targets / row pointers are uploaded
+    for (int g = 0; g < G; ++g) {
+      if (gsteps[g] == 0) continue;
+      HIP_TRY(hipStreamWaitEvent(d->gstreams[g], d->gevents[0], 0));
+      const int rc = run_group(g, d->gstreams[g]);
+      if (rc != WFST_OK) return rc;
+      HIP_TRY(hipEventRecord(d->gevents[1 + g], d->gstreams[g]));
+      HIP_TRY(hipStreamWaitEvent(d->stream, d->gevents[1 + g], 0));
+    }
   }
   HIP_TRY(hipGetLastError());
   for (int g = 0; g < G; ++g) d->gpar[g] = gpar0[g] ^ (gsteps[g] & 1);
