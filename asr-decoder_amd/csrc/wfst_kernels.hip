@@ -485,6 +485,12 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
     const int gpos = s_gpos;
 
     // pass 2: the record that won its state writes the token
+    // (lattice mode: an item that fits one sweep -- every planned item does -- keeps each live
+    // record's {source token, arc, cost} and LDS slot in registers for pass 3)
+    const bool one_sweep = n <= kInsertThreads * kInsertUnroll;
+    int lk_src[kInsertUnroll], lk_arc[kInsertUnroll], lk_cost[kInsertUnroll], lk_slot[kInsertUnroll];
+#pragma unroll
+    for (int k = 0; k < kInsertUnroll; ++k) lk_slot[k] = -1;
     for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
       int4 r[kInsertUnroll];
 #pragma unroll
@@ -494,6 +500,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
         bool winner = false;
         u64 packed = 0;
         uint32_t wslot = 0;
+        bool in_table = false;
         if (__int_as_float(r[k].y) < cutoff) {
           const uint32_t h = hash32(r[k].x);
           if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
@@ -501,12 +508,15 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
             uint32_t slot = lds_slot_of(h, log2grp, log2sl);
             for (int q = 0; q < SL; ++q) {
               const int32_t kk = keys[slot];
-              if (kk == r[k].x) { winner = vals[slot] == packed; break; }
+              if (kk == r[k].x) { winner = vals[slot] == packed; in_table = true; break; }
               if (kk == kEmptyKey) break;
               slot = (slot + 1) & mask;
             }
             wslot = slot;
           }
+        }
+        if (kLat && in_table) {
+          lk_src[k] = r[k].z; lk_arc[k] = (int)((uint32_t)r[k].w & kArcMask); lk_cost[k] = r[k].y; lk_slot[k] = (int)wslot;
         }
         const u64 wm = __ballot(winner);
         if (!wm) continue;
@@ -554,6 +564,22 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
     if (kLat) {
       __syncthreads();
       int4 *links = D.links + (size_t)c * D.link_cap;
+      if (one_sweep) {
+#pragma unroll
+        for (int k = 0; k < kInsertUnroll; ++k) {
+          const bool live = lk_slot[k] >= 0;
+          const u64 lm = __ballot(live);
+          if (!lm) continue;
+          int lb = 0;
+          if (lane == 0) lb = atomicAdd(&ctl->link_count, __popcll(lm));
+          lb = __shfl(lb, 0, 64);
+          if (live) {
+            const int lp = lb + lane_rank(lm);
+            if ((int64_t)lp < D.link_cap) links[lp] = make_int4(lk_src[k], tidx[lk_slot[k]], lk_arc[k], lk_cost[k]);
+            else atomicOr(&ctl->error, kErrLinksFull);
+          }
+        }
+      } else {
       for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
 #pragma unroll
         for (int k = 0; k < kInsertUnroll; ++k) {
@@ -583,6 +609,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
             else atomicOr(&ctl->error, kErrLinksFull);
           }
         }
+      }
       }
     }
   }
