@@ -321,7 +321,16 @@ def main():
                 if (np.array_equal(o.words, r["words"]) and np.array_equal(o.tids, r["tids"]) and
                         np.float32(o.tot_score).tobytes() == np.float32(r["tot_score"]).tobytes()):
                     exact += 1
+            # one thread, two utterances: the per-core rate (SURVEY.md 8(d) asks for both)
+            _, fps1, cdt1, _ = cpu_baseline(gpath, cd, sample[:2], m, 1)
+            cpu_model = ""
+            try:
+                with open("/proc/cpuinfo") as f:
+                    cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+            except OSError:
+                pass
             out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": nth, "kind": kind,
+                                   "single_thread_value": fps1, "cpu_model": cpu_model,
                                    "sample": "%d of the %d utterances of rank 0 (%d frames), %.1fs wall on %d host threads, "
                                              "one decoder object per thread over one shared graph" % (ns, B, ns * T, cdt, nth),
                                    "host_cpus": os.cpu_count()}
