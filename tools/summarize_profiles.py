@@ -43,6 +43,9 @@ def main():
     ks = newest(os.path.join(P, "kt", "*", "*_kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(OUT, "%s_kernel_stats.csv" % tag))
+    kl = newest(os.path.join(P, "kt_lattice", "*", "*_kernel_stats.csv"))
+    if kl:
+        shutil.copy(kl[0], os.path.join(OUT, "%s_lattice_mode_kernel_stats.csv" % tag))
     bj = os.path.join(P, "bench_kt.json")
     if os.path.exists(bj):
         shutil.copy(bj, os.path.join(OUT, "%s_bench_under_rocprof.json" % tag))
