@@ -61,6 +61,7 @@ struct wfst_graph {
   std::vector<int32_t> pos_host;  // row position of each original state id (sorted)
   int32_t orig_start = 0, orig_final = 0;
   DevBuf<int32_t> arc_ilabel, arc_olabel, arc_src, eps_target_state;
+  DevBuf<int4> eps_flat;
   uint32_t start_eps = 0;
   int32_t n_eps_targets = 0;
   GraphDev view() const {
@@ -70,6 +71,7 @@ struct wfst_graph {
     g.arc_olabel = arc_olabel.p;
     g.arc_src = arc_src.p;
     g.eps_target_state = eps_target_state.p;
+    g.eps_flat = eps_flat.p;
     g.start_eps = start_eps;
     g.n_eps_targets = n_eps_targets;
     g.start = start;
@@ -84,6 +86,7 @@ struct wfst_graph {
     arc_olabel.release();
     arc_src.release();
     eps_target_state.release();
+    eps_flat.release();
   }
 };
 
@@ -320,6 +323,43 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
     off += na;
   }
 
+  // pass 3: flattened epsilon closures (wfst_device.h "eps_flat"): breadth-first over a state's
+  // epsilon arcs; a closure with more than kFlatMax paths (or an epsilon cycle) stays iterative
+  std::vector<int4> h_flat;
+  if (!getenv("WFST_NO_FLAT")) {
+    std::vector<int64_t> aoff((size_t)n_states + 1, 0);
+    for (int32_t s = 0; s < n_states; ++s) aoff[(size_t)s + 1] = aoff[s] + states[s].num_arcs;
+    struct Node { int32_t state, parent; };
+    for (int32_t s = 0; s < n_states; ++s) {
+      if (!states[s].niepsilons) continue;
+      int4 ent[kFlatMax];
+      Node queue[kFlatMax + 1];
+      int n_ent = 0, qh = 0, qt = 0;
+      bool complete = true;
+      queue[qt++] = Node{s, -1};
+      while (qh < qt && complete) {
+        const Node u = queue[qh++];
+        for (uint32_t i = 0; i < states[u.state].niepsilons; ++i) {
+          if (n_ent == kFlatMax) { complete = false; break; }
+          const wfst_arc &a = arcs[aoff[u.state] + i];
+          const int32_t v = a.nextstate;
+          int4 e;
+          e.x = (int32_t)(next_eps[v] & 0x7FFFFFFFu) - 1;
+          e.y = pos[u.state] + 1 + (int32_t)i;
+          e.z = (u.parent + 1) | (states[v].niepsilons ? 8 : 0);
+          memcpy(&e.w, &a.weight, 4);
+          ent[n_ent] = e;
+          if (states[v].niepsilons) queue[qt++] = Node{v, n_ent};  // qt <= n_ent + 1 <= kFlatMax
+          ++n_ent;
+        }
+      }
+      if (!complete || n_ent == 0) continue;
+      ext[(size_t)pos[s]].w = (int32_t)(((uint32_t)h_flat.size() << 3) | (uint32_t)n_ent);
+      h_flat.insert(h_flat.end(), ent, ent + n_ent);
+    }
+    if (h_flat.size() >= (1u << 28)) return fail(WFST_E_FORMAT, "too many flattened epsilon closures");
+  }
+
   wfst_graph *g = new wfst_graph();
   g->device = device;
   g->start = pos[start];
@@ -335,7 +375,8 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
   hipError_t e;
   if ((e = g->arcs.alloc((size_t)N)) != hipSuccess || (e = g->arc_ilabel.alloc((size_t)N)) != hipSuccess ||
       (e = g->arc_olabel.alloc((size_t)N)) != hipSuccess || (e = g->arc_src.alloc((size_t)N)) != hipSuccess ||
-      (e = g->eps_target_state.alloc(h_targets.size())) != hipSuccess) {
+      (e = g->eps_target_state.alloc(h_targets.size())) != hipSuccess ||
+      (e = g->eps_flat.alloc(std::max<size_t>(1, h_flat.size()))) != hipSuccess) {
     delete g;
     return fail(WFST_E_DEVICE, std::string("hipMalloc(graph): ") + hipGetErrorString(e));
   }
@@ -343,6 +384,7 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
   if (hipMemcpy(g->arc_src.p, h_src.data(), h_src.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(g->arc_olabel.p, h_ol.data(), h_ol.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       (!h_targets.empty() && hipMemcpy(g->eps_target_state.p, h_targets.data(), h_targets.size() * 4, hipMemcpyHostToDevice) != hipSuccess) ||
+      (!h_flat.empty() && hipMemcpy(g->eps_flat.p, h_flat.data(), h_flat.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) ||
       hipMemcpy(g->arc_ilabel.p, g->ilabel_host.data(), g->ilabel_host.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(WFST_E_DEVICE, "hipMemcpy(graph) failed");
   if (rc == WFST_OK) rc = upload_columns(g, nullptr, 0, &ext);
@@ -390,7 +432,7 @@ int wfst_graph_info(const wfst_graph *g, int32_t *start, int32_t *final_state, i
   if (n_arcs) *n_arcs = g->n_arcs;
   if (device_bytes)
     *device_bytes = (int64_t)(g->arcs.bytes() + g->arc_ilabel.bytes() +
-                              g->arc_olabel.bytes() + g->arc_src.bytes() + g->eps_target_state.bytes());
+                              g->arc_olabel.bytes() + g->arc_src.bytes() + g->eps_target_state.bytes() + g->eps_flat.bytes());
   return WFST_OK;
 }
 

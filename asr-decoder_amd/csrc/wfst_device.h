@@ -16,7 +16,8 @@ namespace wfst {
 // rows[]: ONE int4 array in "ext" index space.  State s owns slots [pos(s), pos(s)+1+num_arcs(s)),
 //   pos(s) increasing in s (rows are packed, with padding slots where a row would otherwise
 //   straddle one more 64-byte line than it needs), and IS identified by pos(s) everywhere on the device.
-//   rows[pos(s)]      header {(n_emit << 12) | n_eps, original state id, next_eps word of s, 0}
+//   rows[pos(s)]      header {(n_emit << 12) | n_eps, original state id, next_eps word of s,
+//                     (first entry in eps_flat[] << 3) | entries, entries = 0: not flattened}
 //   rows[pos(s)+1+i]  arc i {ll_col, next_eps(nextstate), weight bits, pos(nextstate)}; epsilon arcs
 //                     first.  ll_col = log-likelihood column of the ilabel (tid2pdf applied at
 //                     upload), -1 for an input-epsilon arc.
@@ -24,6 +25,12 @@ namespace wfst {
 //   8-byte state table cost one more 64-byte fabric request per expanded token).
 //   next_eps word: bit 31 = the state has outgoing epsilon arcs; bits 30..0 = 1 + its ordinal among
 //   the graph's epsilon-TARGET states (0 = no epsilon arc enters it).
+// eps_flat[]: the WHOLE epsilon closure of a state as a list, for states whose closure has at most
+//   kFlatMax paths (nearly all): entry {epsilon-target ordinal of the path's end, last arc (row
+//   index), (parent entry + 1) | 8 if the end state has epsilon arcs out, weight bits of the last arc},
+//   parents before children.  The closure kernel prices such a state's closure in ONE round
+//   (cost of an entry = cost of its parent + weight, in path order, every prefix below the cutoff)
+//   instead of one round per epsilon hop.
 // arc_ilabel[], arc_olabel[], arc_src[] (source row | bit 31 for an epsilon arc): cold arrays in
 //   the same index space.  eps_target_state[k] = row of epsilon-target ordinal k.
 struct GraphDev {
@@ -32,12 +39,14 @@ struct GraphDev {
   const int32_t *arc_olabel;
   const int32_t *arc_src;
   const int32_t *eps_target_state;
+  const int4 *eps_flat;
   int32_t start, final_state, n_states, n_arcs;
   uint32_t start_eps;   // next_eps word of the start state
   int32_t n_eps_targets;
 };
 
 constexpr int kEpsBits = 12;
+constexpr int kFlatMax = 4;  // paths of a flattened epsilon closure (3 bits in the header word)
 constexpr uint32_t kEpsMask = (1u << kEpsBits) - 1;
 constexpr uint32_t kFlagOutEps = 0x80000000u;     // state has outgoing input-epsilon arcs
 constexpr uint32_t kFlagEpsTarget = 0x40000000u;  // some input-epsilon arc enters the state

@@ -693,16 +693,70 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
         // another entry, so a stale cost only repeats work the atomicMin below rejects
         live[k] = live[k] && (__int_as_float(ent[k].z) < cutoff);  // base-inl.h:391
       }
+      uint32_t flat[kClosureUnroll];
+#pragma unroll
+      for (int k = 0; k < kClosureUnroll; ++k) {
+        const int4 hdr = live[k] ? D.g.arcs[ent[k].y] : make_int4(0, 0, 0, 0);
+        si[k] = make_uint2((uint32_t)ent[k].y + 1u, (uint32_t)hdr.x);
+        flat[k] = (uint32_t)hdr.w;  // (first eps_flat entry << 3) | entries; 0: iterate
+      }
 #pragma unroll
       for (int k = 0; k < kClosureUnroll; ++k)
-        si[k] = live[k] ? make_uint2((uint32_t)ent[k].y + 1u, (uint32_t)D.g.arcs[ent[k].y].x) : make_uint2(0, 0);
-#pragma unroll
-      for (int k = 0; k < kClosureUnroll; ++k)
-        arc0[k] = (live[k] && (si[k].y & kEpsMask)) ? D.g.arcs[si[k].x] : make_int4(0, 0, 0, 0);
+        arc0[k] = !(live[k] && (si[k].y & kEpsMask)) ? make_int4(0, 0, 0, 0)
+                  : (flat[k] & 7u) ? D.g.eps_flat[flat[k] >> 3] : D.g.arcs[si[k].x];
+      // FindOrAddToken (base-inl.h:88-136) for one epsilon arrival: one atomicMin on the state's own
+      // slot.  kEpsWon in the low word makes an emitting arc win an exact cost tie, as the
+      // reference's first-arrival rule does (emitting arcs are processed before the closure).
+      // requeue: the state's own epsilon arcs still have to be followed from this cost
+      // (base-inl.h:425); not for a flattened closure, whose deeper entries are those arcs.
+      auto arrive = [&](int ord, int a, float tot, bool out_eps, int next_row, bool requeue) {
+        const uint32_t otot = f2o(tot);
+        const u64 packed = ((u64)otot << 32) | kEpsWon | (out_eps ? kEpsOutBit : 0u) | (uint32_t)a;
+        const u64 old = atomicMin(&vals[ord], packed);
+        if (!(packed < old)) return;
+        if (old == kEmptyVal) {  // a state no emitting arc reached: new token
+          toki[ord] = base + atomicAdd(&sh.nnew, 1);
+          const int op = atomicAdd(&sh.occ, 1);
+          if (op < D.wl_cap) occ[op] = ord; else atomicOr(&sh.err, kErrWorklistFull);
+        }
+        if (old == kEmptyVal || !((uint32_t)old & kEpsWon)) {  // first epsilon win of this token
+          const int wn = atomicAdd(&sh.nwon, 1);
+          if (wn < D.wl_cap) won[wn] = ord; else atomicOr(&sh.err, kErrWorklistFull);
+        }
+        if (requeue && out_eps && otot < (uint32_t)(old >> 32)) {
+          const int wp = atomicAdd(&sh.wl_n[cur ^ 1], 1);
+          if (wp < D.wl_cap) wl_nxt[wp] = make_int4(0, next_row, __float_as_int(tot), 0);
+          else atomicOr(&sh.err, kErrWorklistFull);
+        }
+      };
 #pragma unroll
       for (int k = 0; k < kClosureUnroll; ++k) {
         if (!live[k]) continue;
         const float cost = __int_as_float(ent[k].z);
+        if (flat[k] & 7u) {
+          // the whole closure of this state in one go: entry cost = parent cost + weight, in path
+          // order; an entry whose parent or own cost is not below the cutoff is dead (base-inl.h:391,415)
+          const int cnt = (int)(flat[k] & 7u);
+          const int4 *fl = D.g.eps_flat + (flat[k] >> 3);
+          float pc[kFlatMax];
+#pragma unroll
+          for (int e = 0; e < kFlatMax; ++e) {
+            pc[e] = __builtin_huge_valf();
+            if (e >= cnt) continue;
+            const int4 E = e == 0 ? arc0[k] : fl[e];
+            const int parent = (E.z & 7) - 1;
+            float cp = cost;
+#pragma unroll
+            for (int q = 0; q < kFlatMax - 1; ++q) cp = (parent == q) ? pc[q] : cp;
+            if (!(cp < cutoff)) continue;
+            nZ++;
+            const float tot = cp + __int_as_float(E.w);  // base-inl.h:414
+            if (!(tot < cutoff)) continue;               // base-inl.h:415
+            pc[e] = tot;
+            arrive(E.x, E.y, tot, (E.z & 8) != 0, 0, false);
+          }
+          continue;
+        }
         const int neps = (int)(si[k].y & kEpsMask);
         for (int e = 0; e < neps; ++e) {
           const int a = (int)si[k].x + e;
@@ -710,30 +764,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
           nZ++;
           const float tot = cost + __int_as_float(arc.z);  // base-inl.h:414
           if (!(tot < cutoff)) continue;                    // base-inl.h:415
-          const uint32_t otot = f2o(tot);
-          const int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;  // nextstate is an epsilon target
-          // FindOrAddToken (base-inl.h:88-136): one atomicMin on the state's own slot.  kEpsWon in
-          // the low word makes an emitting arc win an exact cost tie, as the reference's
-          // first-arrival rule does (emitting arcs are processed before the closure).
-          const u64 packed = ((u64)otot << 32) | kEpsWon | (((uint32_t)arc.y & kFlagOutEps) ? kEpsOutBit : 0u) | (uint32_t)a;
-          const u64 old = atomicMin(&vals[ord], packed);
-          if (packed < old) {
-            if (old == kEmptyVal) {  // a state no emitting arc reached: new token
-              toki[ord] = base + atomicAdd(&sh.nnew, 1);
-              const int op = atomicAdd(&sh.occ, 1);
-              if (op < D.wl_cap) occ[op] = ord; else atomicOr(&sh.err, kErrWorklistFull);
-            }
-            if (old == kEmptyVal || !((uint32_t)old & kEpsWon)) {  // first epsilon win of this token
-              const int wn = atomicAdd(&sh.nwon, 1);
-              if (wn < D.wl_cap) won[wn] = ord; else atomicOr(&sh.err, kErrWorklistFull);
-            }
-            // base-inl.h:425: re-queue when the cost changed and the state has epsilon arcs
-            if (otot < (uint32_t)(old >> 32) && ((uint32_t)arc.y & kFlagOutEps)) {
-              const int wp = atomicAdd(&sh.wl_n[cur ^ 1], 1);
-              if (wp < D.wl_cap) wl_nxt[wp] = make_int4(0, arc.w, __float_as_int(tot), 0);
-              else atomicOr(&sh.err, kErrWorklistFull);
-            }
-          }
+          arrive((int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1, a, tot, ((uint32_t)arc.y & kFlagOutEps) != 0, arc.w, true);
         }
       }
     }
