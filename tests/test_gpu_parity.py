@@ -272,3 +272,30 @@ def test_openfst_vector_and_const_graphs_decode_like_the_flat_graph(synth, oracl
         with open(bad, "wb") as f:
             f.write(synth.to_openfst_bytes(g, "const", flags=2))
         G.wfstdec.Graph.load(bad)
+
+
+def test_channel_groups_decode_identically(synth, oracle, tmp_path, monkeypatch):
+    """WFST_GROUPS=2/3 (one hipGraph + stream per channel group, read at wfst_decoder_create) and
+    WFST_NO_GRAPH=1 are scheduling choices only: same bits as the oracle, ragged lengths included."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(6000, seed=29, n_tid=600, n_words=900)
+    m = synth.default_tid2pdf(600)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=6.0)
+    mats = [synth.make_loglikes(g, T, 300, m, seed=800 + i, mu=-2.2)[0] for i, T in enumerate((60, 9, 41, 60, 1, 33, 17))]
+    h = oracle.load_graph(path)
+    want = [oracle.decode(h, pyoracle.Config(**cd), x, m) for x in mats]
+    oracle.free_graph(h)
+    for env in (dict(WFST_GROUPS="2"), dict(WFST_GROUPS="3"), dict(WFST_NO_GRAPH="1"), dict(WFST_GROUPS="2", WFST_NO_GRAPH="1")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for chunk in (0, 7):
+            for r, o in zip(G.decode_batch(graph, cd, mats, chunk=chunk), want):
+                G.assert_same_as_oracle(r, o, "%s chunk %d" % (env, chunk))
+        for k in env:
+            monkeypatch.delenv(k)
+    graph.free()
