@@ -45,3 +45,40 @@ def test_oracle_matches_reference_bitwise(ci, oracle, refdec, synth, tmp_path, c
             _same(refdec.decode(hr, cfg, ll, m, **kw), oracle.decode(ho, cfg, ll, m, **kw))
     refdec.free_graph(hr)
     oracle.free_graph(ho)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_oracle_matches_reference_on_random_graphs(block, oracle, refdec, synth, tmp_path):
+    """The graphs of tests/test_gpu_fuzz.py (dense forward epsilon structure, parallel arcs, several
+    final states, tight beams): best path, token/link counts and the raw lattice's arc multiset of
+    the oracle against the reference decoder itself."""
+    from test_gpu_fuzz import random_graph
+
+    rng = np.random.default_rng(99 + block)
+    n = 0
+    for case in range(10):
+        n_states = int(rng.integers(4, 70))
+        n_labels = int(rng.integers(3, 12))
+        g = random_graph(synth, rng, n_states, n_labels)
+        path = str(tmp_path / ("g%d.bin" % case))
+        g.write(path)
+        hr, ho = refdec.load_graph(path), oracle.load_graph(path)
+        cd = dict(beam=float(rng.uniform(3.0, 14.0)), max_active=int(rng.choice([1000000, 40, 12])), min_active=int(rng.choice([0, 5])),
+                  lattice_beam=float(rng.uniform(0.5, 8.0)), prune_interval=int(rng.integers(3, 30)))
+        cfg = pyoracle.Config(**cd)
+        for T in (int(rng.integers(1, 45)), int(rng.integers(1, 45))):
+            x = rng.normal(-1.5, 1.0, size=(T, n_labels + 1)).astype(np.float32)
+            r = refdec.decode(hr, cfg, x, None, chunk=0)
+            if not r.ok:       # the reference aborts in PruneForwardLinks when every token died; skip those
+                continue
+            _same(r, oracle.decode(ho, cfg, x, None, chunk=0))
+            R = pyoracle.ref_raw_lattice(refdec, hr, cfg, x, None)
+            O = pyoracle.oracle_raw_lattice(oracle, ho, cfg, x, None)
+            assert R.ok == O.ok
+            if R.ok:
+                assert (R.n_states, int(R.st_final.sum())) == (O.n_states, int(O.st_final.sum()))
+                assert np.array_equal(R.arc_multiset(), O.arc_multiset())
+            n += 1
+        refdec.free_graph(hr)
+        oracle.free_graph(ho)
+    assert n >= 10
