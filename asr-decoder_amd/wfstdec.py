@@ -213,9 +213,10 @@ class BatchDecoder:
         # (strictly sequential accumulation); the C entry point wfst_lattice_to_vector does the same
         # per utterance and tests/test_capi_symbols.py holds the two against each other.
         pos = np.arange(cap)[None, :] < nh[:, None]
-        x = np.where(pos, g + ac, np.float32(0)).astype(np.float32)
-        tot = np.cumsum(x, axis=1, dtype=np.float32)
-        lm = np.cumsum(np.where(pos, g, np.float32(0)).astype(np.float32), axis=1, dtype=np.float32)
+        g = np.where(pos, g, np.float32(0)).astype(np.float32)    # slots past a path's end hold no data
+        ac = np.where(pos, ac, np.float32(0)).astype(np.float32)
+        tot = np.cumsum(g + ac, axis=1, dtype=np.float32)
+        lm = np.cumsum(g, axis=1, dtype=np.float32)
         last = np.maximum(nh - 1, 0)
         rows = np.arange(cnt)
         tot_s, lm_s = tot[rows, last], lm[rows, last]

@@ -122,15 +122,19 @@ def cpu_baseline(graph_path, cd, mats, m, n_threads):
     return kind, frames / dt, dt, results
 
 
-def oracle_counts(graph_path, cd, mats, m):
+def oracle_counts(graph_path, cd, mats, m, order_free=False, want_paths=None):
     """N/E/Z work counts of the CPU restatement (algorithmic bytes come from the
-    CPU restatement's counts, not from GPU-side expansion)."""
+    CPU restatement's counts, not from GPU-side expansion).  order_free: the oracle's order-free
+    mode; want_paths: list that receives (transition-ids, tot_score) per utterance."""
     import ctypes as C
 
     import pyoracle
 
     pyoracle.build_oracle()
     orc = pyoracle.OracleDecoder()
+    orc.set_order_free(order_free)
+    if want_paths is not None:
+        want_paths[:] = [None] * len(mats)
     f = orc.lib.oracle_decode_ex
     f.restype = C.c_int
     h = orc.load_graph(graph_path)
@@ -162,10 +166,13 @@ def oracle_counts(graph_path, cd, mats, m):
               C.byref(n[3]), C.byref(n[4]), ex.ctypes.data_as(C.POINTER(C.c_int64)))
             with lock:
                 tot[:] += ex
+                if want_paths is not None:
+                    want_paths[i] = (ib[3][: n[2].value].copy(), np.float32(sc[0].value))
 
     th = [threading.Thread(target=work) for _ in range(min(len(mats), os.cpu_count() or 1))]
     [t.start() for t in th]
     [t.join() for t in th]
+    orc.set_order_free(False)
     orc.free_graph(h)
     return dict(N=int(tot[0]), E=int(tot[1]), Z=int(tot[2]), ties_on_best_path=int(tot[5]))
 
@@ -337,6 +344,15 @@ def main():
             out["config"]["parity"] = "%d/%d sampled utterances bit-exact (words, transition-ids, tot_score) vs the %s CPU decoder" % (
                 exact, ns, "reference" if kind == "reference" else "oracle")
             oc = oracle_counts(gpath, cd, sample, m)
+            if exact < ns:
+                # where max_active / min_active bind, the reference's cutoff depends on tokens it
+                # keeps in hash-list visiting order; the order-independent restatement of the same
+                # algorithm (oracle, order-free mode) is what the GPU must equal bit for bit
+                paths = []
+                oracle_counts(gpath, cd, sample, m, order_free=True, want_paths=paths)
+                ex2 = sum(1 for i in range(ns) if np.array_equal(paths[i][0], res[i]["tids"]) and
+                          np.float32(paths[i][1]).tobytes() == np.float32(res[i]["tot_score"]).tobytes())
+                out["config"]["parity"] += "; %d/%d bit-exact vs the oracle in order-free mode" % (ex2, ns)
             gs = {k: sum(gstats[i][k] for i in range(ns)) for k in ("N", "E", "Z")}
             out["config"]["work_counts_sample"] = {"oracle": oc, "gpu": gs}
             # algorithmic bytes from the CPU restatement's counts, scaled from the sample to the batch

@@ -56,7 +56,10 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         g.write(path)
         graph = G.wfstdec.Graph.load(path)
         ho = oracle.load_graph(path)
-        cd = dict(beam=float(rng.uniform(3.0, 14.0)), max_active=1000000, min_active=0,
+        # blocks 4..7 also bind max_active / min_active (GetCutoff's k-th smallest, adaptive beam)
+        binding = block >= 4
+        cd = dict(beam=float(rng.uniform(3.0, 14.0)), max_active=int(rng.choice([40, 12, 25])) if binding else 1000000,
+                  min_active=int(rng.choice([0, 5, 9])) if binding else 0,
                   lattice_beam=float(rng.uniform(0.5, 8.0)), prune_interval=int(rng.integers(3, 30)))
         lens = [int(rng.integers(1, 45)) for _ in range(int(rng.integers(1, 6)))]
         mats = [rng.normal(-1.5, 1.0, size=(T, n_labels + 1)).astype(np.float32) for T in lens]
@@ -89,7 +92,7 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
                 same_as_ref = np.array_equal(o.tids, ref_mode.tids) and np.array_equal(o.words, ref_mode.words)
                 n_ref_same += int(same_as_ref)
                 n_ref_diff += int(not same_as_ref)
-                if not same_as_ref:  # only where parallel arcs are in play, and never in length
+                if not same_as_ref and not binding:  # only where parallel arcs are in play, and never in length
                     assert ref_mode.extra["quirk_hops"] + o.extra["quirk_hops"] > 0 and len(o.tids) == len(ref_mode.tids), what
             try:
                 oracle.set_order_free(True)
@@ -115,4 +118,6 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         oracle.free_graph(ho)
         graph.free()
     assert n_cases >= 12 and n_lat >= 6 and n_exact >= 6
-    assert n_ref_diff <= 2 and n_ref_same >= 6, (n_ref_same, n_ref_diff)  # the reference's own result: nearly always the same
+    if block < 4:
+        assert n_ref_diff <= 2 and n_ref_same >= 6, (n_ref_same, n_ref_diff)  # the reference's own result: nearly always the same
+    print("block %d: %d utterances, %d exact vs order-free oracle, reference-mode same/different %d/%d" % (block, n_cases, n_exact, n_ref_same, n_ref_diff))
