@@ -121,3 +121,79 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
     if block < 4:
         assert n_ref_diff <= 2 and n_ref_same >= 6, (n_ref_same, n_ref_diff)  # the reference's own result: nearly always the same
     print("block %d: %d utterances, %d exact vs order-free oracle, reference-mode same/different %d/%d" % (block, n_cases, n_exact, n_ref_same, n_ref_diff))
+
+
+def py_nbest(L, n):
+    """Independent restatement for small lattices: k-best DISTINCT word sequences by dynamic
+    programming over the topologically numbered raw lattice (dict word-tuple -> (tot, lm) per state,
+    float32 sums in path order like LatticeToVector).  Each state keeps its 48 cheapest distinct
+    histories (exact for n <= 48; the number of distinct sequences itself grows exponentially)."""
+    S = L.n_states
+    best = [dict() for _ in range(S)]
+    best[0][()] = (np.float32(0), np.float32(0))
+    order = np.argsort(L.a_src, kind="stable")
+    trimmed = -1
+    for k in order:
+        s, d = int(L.a_src[k]), int(L.a_dst[k])
+        if s != trimmed:   # all arcs into s are done (ids are topological, arcs sorted by source)
+            if len(best[s]) > 48:
+                best[s] = dict(sorted(best[s].items(), key=lambda kv: (kv[1][0], kv[0]))[:48])
+            trimmed = s
+        w = (int(L.a_ol[k]),) if L.a_ol[k] else ()
+        step, g = np.float32(L.a_graph[k] + L.a_ac[k]), np.float32(L.a_graph[k])
+        for seq, (tot, lm) in best[s].items():
+            cand = (np.float32(tot + step), np.float32(lm + g))
+            key = seq + w
+            old = best[d].get(key)
+            if old is None or cand[0] < old[0]:
+                best[d][key] = cand
+    fin = {}
+    for s in np.nonzero(L.st_final)[0]:
+        for seq, v in best[int(s)].items():
+            if seq not in fin or v[0] < fin[seq][0]:
+                fin[seq] = v
+    out = sorted(fin.items(), key=lambda kv: (kv[1][0], kv[0]))[:n]
+    return [(np.asarray(seq, np.int32), float(v[0]), float(v[1])) for seq, v in out]
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_fuzz_nbest_against_a_python_restatement(block, synth, tmp_path):
+    """The device n-best on random graphs (many short word sequences, epsilon-only stretches, paths
+    with no word at all) against an exhaustive pure-Python k-best over the lattice the device
+    returned.  (The reference's own determinizer + NShortestPath does not terminate within 10 s on
+    a sixth of these dense-epsilon lattices -- 58 to 1000 states -- so it is the checker only on
+    the speech-like lattices of tests/test_gpu_lattice.py.)"""
+    import gpu_util as G
+    from test_gpu_lattice import _same_nbest, as_raw
+
+    rng = np.random.default_rng(777 + block)
+    n = 0
+    for case in range(8):
+        n_states = int(rng.integers(4, 60))
+        n_labels = int(rng.integers(3, 12))
+        g = random_graph(synth, rng, n_states, n_labels)
+        path = str(tmp_path / ("n%d_%d.bin" % (block, case)))
+        g.write(path)
+        graph = G.wfstdec.Graph.load(path)
+        cd = dict(beam=float(rng.uniform(5.0, 14.0)), max_active=1000000, min_active=0, lattice_beam=float(rng.uniform(1.0, 4.0)))
+        lens = [int(rng.integers(2, 25)) for _ in range(3)]
+        mats = [rng.normal(-1.5, 1.0, size=(T, n_labels + 1)).astype(np.float32) for T in lens]
+        dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), max_frames=64, max_tokens_per_frame=4096,
+                                     arena_tokens=1 << 16, lattice_links=1 << 18)
+        dev = G.upload(mats)
+        dec.init()
+        dec.advance([t.data_ptr() for t in dev], lens, n_labels + 1)
+        dec.finalize()
+        got = dec.nbest(6)
+        for i in range(len(mats)):
+            d = dec.raw_lattice(i)
+            if d is None:
+                assert got[i] == []
+                continue
+            if len(d["a_src"]) > 1500:
+                continue    # keep the Python side quick
+            _same_nbest(got[i], py_nbest(as_raw(d), 6), "block %d case %d utt %d" % (block, case, i))
+            n += 1
+        dec.free()
+        graph.free()
+    assert n >= 12
