@@ -47,7 +47,7 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
     from test_gpu_lattice import as_raw, nodes
 
     rng = np.random.default_rng(1234 + block)
-    n_cases = n_lat = n_exact = n_ref_same = n_ref_diff = 0
+    n_cases = n_lat = n_exact = n_ref_same = n_ref_diff = n_partial = 0
     for case in range(12):
         n_states = int(rng.integers(4, 70))
         n_labels = int(rng.integers(3, 12))
@@ -69,6 +69,23 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         dec.init()
         for r in sorted(set(list(range(7, max(lens), 7)) + [max(lens)])):   # streaming chunks of 7 frames
             dec.advance([t.data_ptr() for t in dev], [min(r, T) for T in lens], n_labels + 1)
+            if r in (7, 21) and r < max(lens):
+                # partial result mid-utterance (the service's GetBestPath(use_final_probs=false)): the
+                # oracle decodes the same prefix; which parallel arc is reported depends on whether a
+                # PruneActiveTokens pass has run yet (prune_interval)
+                part = dec.best_paths(use_final_probs=False)
+                for i, x in enumerate(mats):
+                    k = min(r, lens[i])
+                    try:
+                        oracle.set_order_free(True)
+                        po = oracle.decode(ho, pyoracle.Config(**cd), x[:k], None, chunk=7, finalize=False, use_final_probs=False)
+                    finally:
+                        oracle.set_order_free(False)
+                    assert bool(part[i]["ok"]) == bool(po.ok)
+                    if po.ok and po.extra["ties"] == 0:
+                        assert np.array_equal(part[i]["tids"], po.tids) and np.array_equal(part[i]["words"], po.words), "partial at %d" % r
+                        assert np.array_equal(bits(part[i]["graph"]), bits(po.path_graph)), "partial at %d" % r
+                        n_partial += 1
         dec.finalize()
         best = dec.best_paths()
         nb = dec.nbest(4)
@@ -117,7 +134,7 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         dec.free()
         oracle.free_graph(ho)
         graph.free()
-    assert n_cases >= 12 and n_lat >= 6 and n_exact >= 6
+    assert n_cases >= 12 and n_lat >= 6 and n_exact >= 6 and n_partial >= 6
     if block < 4:
         assert n_ref_diff <= 2 and n_ref_same >= 6, (n_ref_same, n_ref_diff)  # the reference's own result: nearly always the same
     print("block %d: %d utterances, %d exact vs order-free oracle, reference-mode same/different %d/%d" % (block, n_cases, n_exact, n_ref_same, n_ref_diff))
