@@ -120,7 +120,7 @@ static_assert(sizeof(LatArc) == 32, "LatArc is two 16-byte stores");
 struct FrameCtl {
   int32_t total_tiles[2];  // tiles published by prep_frame for the step of that parity
   int32_t ticket[2];       // dynamic tile dispenser of expand_kernel
-  int32_t n_items[2];      // insert work items listed by plan_kernel
+  int32_t n_items[2];      // insert work items listed by plan_channel (expand's last tile of a channel)
   int32_t item_ticket[2];  // dynamic item dispenser of insert_kernel
   int32_t pad[8];
 };

@@ -4,19 +4,23 @@
 // 649-667) for ALL channels of a batch is three launches:
 //
 //   expand_kernel   ProcessEmitting's inner loop (base-inl.h:311-347), load balanced: a workgroup
-//                   takes 256 frontier tokens, scans their emitting out-degrees in LDS and maps
-//                   one lane to one arc, so low-degree HCLG states (2-3 arcs) still fill
-//                   wavefronts.  Survivors of the (evolving) next_cutoff are counting-sorted in LDS
+//                   takes a tile of 1024 frontier tokens of one channel (tiles are listed per
+//                   frame, so a channel with 8x the tokens owns 8x the tiles), scans their emitting
+//                   out-degrees in LDS and maps one lane to one arc, so low-degree HCLG states
+//                   (2-3 arcs) still fill wavefronts.  Survivors of the (evolving) next_cutoff are counting-sorted in LDS
 //                   by hash partition of their next state and appended, coalesced, to that
 //                   partition's bucket in HBM: one global atomic per partition per 1024 candidates
 //                   instead of two per candidate (scattered atomics run at ~26 G/s on MI355X at
 //                   any scope, half the rate of plain random gathers: tools/ubench_atomics.hip).
+//                   The workgroup that finishes a channel's last tile lists that channel's insert
+//                   work items (plan_channel).
 //   insert_kernel   FindOrAddToken (base-inl.h:88-136) as insert-or-min in an LDS hash table, one
-//                   workgroup per (channel, partition): ds_cmpst on the key, ds_min_u64 on
+//                   work item = a group of hash partitions of one channel: ds_cmpst on the key, ds_min_u64 on
 //                   (orderable cost << 32 | arc); the winner of each state writes the 16-byte
 //                   token (state, cost, backpointer, arc) straight into the arena.
 //   closure_kernel  ProcessNonemitting to its fixpoint inside the kernel (base-inl.h:353-431) on
-//                   a small global table that only holds states with epsilon arcs in or out, then
+//                   a direct-mapped per-channel table of the epsilon-target states (a state's whole
+//                   closure in one round where the graph upload could flatten it), then
 //                   GetCutoff (base-inl.h:138-234; exact k-th smallest by LDS radix select) and the
 //                   best-token seeding of next_cutoff (base-inl.h:282-300) for the next frame.
 //
@@ -131,9 +135,8 @@ __device__ void plan_channel(const DecoderDev &D, int c, int group, int par) {
 }
 
 // =========================================================================================
-// expand_kernel: grid (n_channels, tiles_per_channel), 256 threads.  blockIdx.x = channel, so
-// with n_channels % 8 == 0 the workgroups of a channel share an XCD (speed only: its buckets
-// and log-likelihood row stay in one L2).
+// expand_kernel: a fixed grid of 512-thread workgroups; workgroup w takes tile w of the frame's tile
+// list, further tiles by ticket.
 // =========================================================================================
 constexpr int kExpandThreads = 512;
 constexpr int kCandPerThread = 2;
@@ -141,8 +144,8 @@ constexpr int kChunk = kExpandThreads * kCandPerThread;  // candidates per count
 constexpr int kTokPerThread = 2;
 constexpr int kTileTokens = kExpandThreads * kTokPerThread;  // frontier tokens per tile
 
-// Work unit = one tile of 256 frontier tokens of one channel.  prep_frame lists the tiles of all
-// active channels in tile_chan[]; workgroup w takes tile w, then further tiles from a ticket
+// Work unit = one tile of kTileTokens frontier tokens of one channel.  prep_frame lists the tiles of
+// all active channels (TileDesc); workgroup w takes tile w, then further tiles from a ticket
 // counter, so a channel with 8x the tokens simply owns 8x the tiles (per-frame token counts are
 // heavy-tailed across a batch; a fixed share of workgroups per channel made every frame wait for
 // the heaviest one).
@@ -344,15 +347,15 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
 }
 
 // =========================================================================================
-// insert_kernel: grid (n_channels, n_part), 256 threads, dynamic LDS = lds_slots * 12 bytes.
-// A bucket whose records could overfill the LDS table is processed in 2^k sub-passes, each
-// taking the states of one sub-hash class (records >= distinct states, so the test is safe).
+// insert_kernel.  A bucket whose records could overfill the LDS table is processed in 2^k
+// sub-passes, each taking the states of one sub-hash class (records >= distinct states, so the
+// test is safe).
 // =========================================================================================
 constexpr int kInsertThreads = 512;
 constexpr int kInsertUnroll = 4;
 
 // insert_kernel: a fixed grid of workgroups pulls the planned items (first gridDim.x statically,
-// then by ticket); 256 threads, dynamic LDS = lds_slots * 12 bytes.
+// then by ticket); 512 threads, dynamic LDS = lds_slots * 12 bytes (16 in lattice mode).
 // kLat = lattice mode (forward links recorded); the best-path instantiation carries none of it.
 template <bool kLat>
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, int group, int par) {
