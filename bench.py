@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--groups", type=int, default=0, help="channel groups, each with its own stream and hipGraph (0 = library default 1); "
                     "2 overlaps two half-batches: +7 %% frames/s, but per-launch accounting then covers half a batch")
+    ap.add_argument("--arena-per-frame", type=int, default=20000, help="token arena per utterance = frames x this (raise it for wider beams)")
+    ap.add_argument("--lattice-links", type=int, default=0, help="> 0: lattice mode (BASELINE configs[4]): record forward links "
+                    "(capacity per utterance), prune by lattice_beam at finalize; the step then also takes the n-best")
+    ap.add_argument("--lattice-beam", type=float, default=7.0)
+    ap.add_argument("--nbest", type=int, default=5, help="n of the n-best taken per utterance in lattice mode")
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances timed on the host cores (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(sample, host cores)")
     ap.add_argument("--graph-cache", default="/tmp/wfst_bench_graph_%d.bin")
@@ -214,7 +219,7 @@ def main():
     B, T, P = a.batch, a.frames, a.pdfs
     n_tid = 2 * P
     m = synth.default_tid2pdf(n_tid)
-    cd = dict(beam=a.beam, max_active=a.max_active, min_active=a.min_active, lattice_beam=7.0,
+    cd = dict(beam=a.beam, max_active=a.max_active, min_active=a.min_active, lattice_beam=a.lattice_beam,
               prune_interval=25, beam_delta=0.5)
 
     # ---- inputs (untimed) -------------------------------------------------------------------
@@ -237,7 +242,7 @@ def main():
     graph.set_tid2pdf(m)
     stream = torch.cuda.current_stream(dev).cuda_stream
     dec = wfstdec.BatchDecoder(graph, wfstdec.Config(**cd), B, max_frames=T + 2, max_tokens_per_frame=131072,
-                               arena_tokens=int(T * 20000), stream=stream)
+                               arena_tokens=int(T * a.arena_per_frame), stream=stream, lattice_links=a.lattice_links)
     ptrs = [ll_dev[i].data_ptr() for i in range(B)]
     ready = [T] * B
     Lmax = 64
@@ -256,6 +261,10 @@ def main():
             dec.sync()
         t4 = time.perf_counter()
         res = dec.best_paths(cap=2 * T + 64)
+        if a.lattice_links > 0:
+            nb = dec.nbest(a.nbest)
+            for r, paths in zip(res, nb):
+                r["nbest"] = paths
         t5 = time.perf_counter()
         for k, v in zip(("init", "advance_enqueue", "finalize", "sync", "best_paths"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
             tb[k] += v
@@ -295,7 +304,10 @@ def main():
     dec.set_profiling(False)
 
     out = {
-        "metric": "frames/sec decoded (RTFx = value/100) at fixed beam, best-path parity with the reference CPU decoder",
+        "metric": ("frames/sec decoded (RTFx = value/100) at fixed beam, best-path parity with the reference CPU decoder"
+                   if a.lattice_links == 0 else
+                   "frames/sec decoded WITH lattice generation (forward links, lattice-beam pruning at finalize, %d-best per "
+                   "utterance; BASELINE configs[4]), best-path parity with the reference CPU decoder" % a.nbest),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded hclg-like graph + %s log-likelihoods, SURVEY.md 8(d))" % (
