@@ -314,3 +314,35 @@ def test_gpu_lattice_channel_reuse_ragged_and_no_final_state(oracle, synth, tmp_
     assert L.st_final.sum() == (L.st_frame == gn.utts[1].shape[0]).sum()   # every last-frame state is final
     oracle.free_graph(ho)
     graph.free()
+
+
+def test_zero_frame_utterance_in_lattice_mode(synth, oracle, tmp_path):
+    """An utterance with no frames next to a normal one: FinalizeDecoding, GetBestPath, GetRawLattice
+    and GetNbest must not disturb each other (the reference asserts num_frames > 0 in GetRawLattice,
+    base-inl.h:899; here that is 'no lattice')."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(2000, seed=41, n_tid=400, n_words=300)
+    m = synth.default_tid2pdf(400)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=11.0, max_active=1000000, min_active=0, lattice_beam=5.0)
+    x = synth.make_loglikes(g, 20, 200, m, seed=5, mu=-2.0)[0]
+    dev = G.upload([x])
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 2, **LIM)
+    dec.init()
+    dec.advance([dev[0].data_ptr(), dev[0].data_ptr()], [20, 0], int(x.shape[1]))
+    dec.finalize()
+    assert dec.raw_lattice(1) is None
+    nb = dec.nbest(3)
+    assert nb[1] == [] and len(nb[0]) >= 1
+    bp = dec.best_paths()
+    ho = oracle.load_graph(path)
+    o = oracle.decode(ho, pyoracle.Config(**cd), x, m)
+    oracle.free_graph(ho)
+    assert np.array_equal(bp[0]["tids"], o.tids) and np.array_equal(nb[0][0]["words"], o.words)
+    assert len(bp[1]["tids"]) == 0
+    dec.free()
+    graph.free()
