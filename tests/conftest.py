@@ -12,6 +12,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # no test of this suite needs more than a minute; a hang (e.g. a checker that does not terminate)
+    # must not take the whole run with it
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 600
 
 
 @pytest.fixture(scope="session")
