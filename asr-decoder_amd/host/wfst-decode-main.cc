@@ -9,6 +9,10 @@
 //                  reference's on-disk lattice format (Lattice::Write, newfst/lattice-fst.cc:38-64;
 //                  lattice mode: N forward links kept per utterance).  An utterance without a
 //                  lattice is written as an empty one (0 states, start -1).
+//   --inflight=K   batch shape only: K batches in flight, each on its own GpuBatchDecoder (own HIP
+//                  stream) driven by its own host thread -- the reference service's model of one
+//                  decoder object per thread (v2-asrbin/v2-asr-service.cc:95-105); the GPU overlaps
+//                  independent batches.  Output order is unchanged.
 //   --nbest=N      also print the N-best word sequences of every utterance (the service's
 //                  GetNbestTxt, kaldi-online-nnet3-my-decoder.cc:139-150) as "KEY-k w1 w2 ..." to
 //                  stdout and "LOG KEY-k tot_score .. lm_score .." to stderr (lattice mode)
@@ -23,7 +27,9 @@
 //
 // Output lines "key word-ids..." like the reference's words_writer (:126-129); the log at the end
 // prints the reference's "real-time factor assuming 100 frames/sec" (:189-192).
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -73,7 +79,7 @@ int main(int argc, char **argv) {
     bool single = false;
     std::string lattice_file, lattice_text;
     long long lattice_links = 1ll << 22;
-    int nbest = 0;
+    int nbest = 0, inflight = 1;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
       std::string a = argv[i];
@@ -84,10 +90,11 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 15, "--lattice-text=") == 0) lattice_text = a.substr(15);
       else if (a.compare(0, 16, "--lattice-links=") == 0) lattice_links = atoll(a.c_str() + 16);
       else if (a.compare(0, 8, "--nbest=") == 0) nbest = atoi(a.c_str() + 8);
+      else if (a.compare(0, 11, "--inflight=") == 0) inflight = std::max(1, atoi(a.c_str() + 11));
       else pos.push_back(a);
     }
     if (pos.size() < 3) {
-      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--lattice-out=FILE] "
+      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--inflight=K] [--nbest=N] [--lattice-out=FILE] "
                    "[--lattice-text=FILE] [--lattice-links=N] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
       return 1;
     }
@@ -190,36 +197,65 @@ int main(int argc, char **argv) {
           emit_nbest(u, paths);
         }
       }
-    } else {  // the MI355X shape: `batch` utterances per pass
-      GpuBatchDecoder decode(&fst, opt, batch, &limits);
-      for (size_t b0 = 0; b0 < utts.size(); b0 += batch) {
-        const int n = (int)std::min<size_t>(batch, utts.size() - b0);
-        std::vector<int> ch(n), ready(n);
-        std::vector<const float *> rows(n);
-        int stride = utts[b0].cols;
-        for (int i = 0; i < n; ++i) {
-          ch[i] = i;
-          ready[i] = utts[b0 + i].frames;
-          rows[i] = utts[b0 + i].m.data();
-          if (utts[b0 + i].cols != stride) throw std::runtime_error("all matrices of a batch must have the same width");
+    } else {  // the MI355X shape: `batch` utterances per pass, `inflight` passes at a time
+      struct BatchOut {
+        std::vector<Lattice> best, lats;
+        std::vector<bool> ok, lat_ok;
+        std::vector<std::vector<Lattice> > nbest;
+      };
+      const size_t n_batches = (utts.size() + batch - 1) / batch;
+      std::vector<BatchOut> outs(n_batches);
+      std::atomic<size_t> next(0);
+      std::vector<std::string> errors((size_t)inflight);
+      auto worker = [&](int k) {
+        try {
+          GpuBatchDecoder decode(&fst, opt, batch, &limits);  // its own stream
+          for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= n_batches) return;
+            const size_t b0 = b * (size_t)batch;
+            const int n = (int)std::min<size_t>(batch, utts.size() - b0);
+            std::vector<int> ch(n), ready(n);
+            std::vector<const float *> rows(n);
+            const int stride = utts[b0].cols;
+            for (int i = 0; i < n; ++i) {
+              ch[i] = i;
+              ready[i] = utts[b0 + i].frames;
+              rows[i] = utts[b0 + i].m.data();
+              if (utts[b0 + i].cols != stride) throw std::runtime_error("all matrices of a batch must have the same width");
+            }
+            BatchOut &o = outs[b];
+            decode.InitDecoding(ch);
+            decode.AdvanceDecodingHost(ch, rows, ready, stride);
+            decode.FinalizeDecoding(ch);
+            decode.GetBestPaths(ch, &o.best, &o.ok);
+            if (want_lattice) {
+              o.lats.resize(n);
+              o.lat_ok.resize(n);
+              for (int i = 0; i < n; ++i) o.lat_ok[i] = decode.GetRawLattice(i, &o.lats[i]);
+            }
+            if (nbest > 0) {
+              o.nbest.resize(n);
+              for (int i = 0; i < n; ++i) decode.GetNbest(i, o.nbest[i], nbest);
+            }
+          }
+        } catch (const std::exception &e) {
+          errors[(size_t)k] = e.what();
         }
-        decode.InitDecoding(ch);
-        decode.AdvanceDecodingHost(ch, rows, ready, stride);
-        decode.FinalizeDecoding(ch);
-        std::vector<Lattice> best;
-        std::vector<bool> ok;
-        decode.GetBestPaths(ch, &best, &ok);
-        for (int i = 0; i < n; ++i) emit(utts[b0 + i], best[i], ok[i]);
-        for (int i = 0; i < n && want_lattice; ++i) {
-          Lattice lat;
-          bool lok = decode.GetRawLattice(i, &lat);
-          emit_lattice(utts[b0 + i], lat, lok);
-        }
-        for (int i = 0; i < n && nbest > 0; ++i) {
-          std::vector<Lattice> paths;
-          decode.GetNbest(i, paths, nbest);
-          emit_nbest(utts[b0 + i], paths);
-        }
+      };
+      std::vector<std::thread> threads;
+      for (int k = 1; k < inflight; ++k) threads.emplace_back(worker, k);
+      worker(0);
+      for (std::thread &t : threads) t.join();
+      for (const std::string &e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+      for (size_t b = 0; b < n_batches; ++b) {  // results in input order
+        const size_t b0 = b * (size_t)batch;
+        BatchOut &o = outs[b];
+        const int n = (int)o.best.size();
+        for (int i = 0; i < n; ++i) emit(utts[b0 + i], o.best[i], o.ok[i]);
+        for (int i = 0; i < n && want_lattice; ++i) emit_lattice(utts[b0 + i], o.lats[i], o.lat_ok[i]);
+        for (int i = 0; i < n && nbest > 0; ++i) emit_nbest(utts[b0 + i], o.nbest[i]);
       }
     }
     double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

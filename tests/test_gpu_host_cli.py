@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "asr-decoder_amd", "host", "wfst-decode")
 
 
-@pytest.mark.parametrize("mode", ["batch", "single"])
+@pytest.mark.parametrize("mode", ["batch", "single", "inflight"])
 def test_cli_matches_oracle(mode, synth, oracle, tmp_path):
     subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
     g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
@@ -36,8 +36,11 @@ def test_cli_matches_oracle(mode, synth, oracle, tmp_path):
     args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--batch=4"]
     if mode == "single":
         args.append("--single-stream")
+    if mode == "inflight":   # three 2-utterance batches on two decoder threads, output in input order
+        args = args[:-1] + ["--batch=2", "--inflight=2"]
     p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
+    assert [l.split()[0] for l in p.stdout.strip().splitlines()] == ["utt%03d" % i for i in range(5)]
     words = {l.split()[0]: [int(w) for w in l.split()[1:]] for l in p.stdout.strip().splitlines()}
     scores = {mm.group(1): (float(mm.group(2)), float(mm.group(3))) for mm in re.finditer(r"LOG (utt\d+) tot_score (\S+) lm_score (\S+)", p.stderr)}
     assert "real-time factor assuming 100 frames/sec" in p.stderr
