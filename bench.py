@@ -225,11 +225,16 @@ def main():
     # ---- inputs (untimed) -------------------------------------------------------------------
     t0 = time.time()
     gpath = (a.graph_cache % a.states) + (".r%d" % rank if world > 1 else "")
+    g = None
     if os.path.exists(gpath):
-        g = synth.Graph.read(gpath)
-    else:
+        try:
+            g = synth.Graph.read(gpath)
+        except (IOError, ValueError):
+            g = None  # a partial file from an interrupted run: rebuild
+    if g is None:
         g = synth.make_hclg_like(a.states, seed=7, n_tid=n_tid)
-        g.write(gpath)
+        g.write(gpath + ".tmp%d" % os.getpid())
+        os.replace(gpath + ".tmp%d" % os.getpid(), gpath)
     log("[rank %d] graph: %d states, %d arcs (%.1fs)" % (rank, g.n_states, g.n_arcs, time.time() - t0))
     t0 = time.time()
     mats = make_utts(synth, g, m, rank * B, B, T, P, a)
