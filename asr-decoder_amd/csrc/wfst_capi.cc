@@ -130,6 +130,7 @@ struct wfst_decoder {
   NbestDev nb = {};
   DevBuf<float> bp_g, bp_ac;
   // host-fed log-likelihood history (advance_host)
+  hipStream_t copy_stream = nullptr;  // host -> device uploads of advance_host
   std::vector<float *> hist_dev;
   std::vector<size_t> hist_rows_cap;
   std::vector<int32_t> hist_rows;
@@ -159,6 +160,7 @@ struct wfst_decoder {
   ~wfst_decoder() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     for (float *p : hist_dev)
       if (p) (void)hipFree(p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -845,17 +847,36 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
       d->hist_dev[c] = np;
       d->hist_rows_cap[c] = ncap;
     }
-    if (want > have) {
-      if (!loglikes_host[i]) return fail(WFST_E_ARG, "NULL log-likelihood matrix");
-      HIP_TRY(hipMemcpyAsync(d->hist_dev[c] + (size_t)have * stride, loglikes_host[i] + (size_t)have * stride,
-                             (size_t)(want - have) * stride * 4, hipMemcpyHostToDevice, d->stream));
-      d->hist_rows[c] = want;
-    }
+    if (want > have && !loglikes_host[i]) return fail(WFST_E_ARG, "NULL log-likelihood matrix");
     dev_ptrs[i] = d->hist_dev[c];
   }
-  // pageable host memory: the copies above must have consumed the caller's buffers on return
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  return advance_device(d, channels, n, dev_ptrs.data(), n_frames_ready, stride, max_num_frames);
+  // Upload and decode in slices of kSlice frames: the host copies slice k+1 (pageable memory: the
+  // copy call returns when the caller's buffer is consumed) while the GPU decodes slice k, so the
+  // PCIe time of a long hand-over hides behind the search instead of preceding it.
+  if (!d->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+  const int kSlice = 48;
+  int longest = 0;
+  for (int i = 0; i < cnt; ++i) longest = std::max(longest, n_frames_ready[i] - d->hist_rows[channels ? channels[i] : i]);
+  const bool sliced = max_num_frames < 0 && longest > 2 * kSlice && !getenv("WFST_NO_SLICE");
+  std::vector<int32_t> ready((size_t)cnt);
+  for (int done = 0; done < std::max(longest, 1); done += sliced ? kSlice : std::max(longest, 1)) {
+    const int upto = sliced ? done + kSlice : longest;
+    for (int i = 0; i < cnt; ++i) {
+      const int c = channels ? channels[i] : i;
+      const int32_t have = d->hist_rows[c];
+      const int32_t want = std::min<int32_t>(n_frames_ready[i], have + std::max(0, upto - done));
+      if (want > have) {
+        HIP_TRY(hipMemcpyAsync(d->hist_dev[c] + (size_t)have * stride, loglikes_host[i] + (size_t)have * stride,
+                               (size_t)(want - have) * stride * 4, hipMemcpyHostToDevice, d->copy_stream));
+        d->hist_rows[c] = want;
+      }
+      ready[i] = d->hist_rows[c];
+    }
+    HIP_TRY(hipStreamSynchronize(d->copy_stream));  // rows are in HBM (and the caller's buffers consumed)
+    const int rc = advance_device(d, channels, n, dev_ptrs.data(), ready.data(), stride, max_num_frames);
+    if (rc != WFST_OK) return rc;
+  }
+  return WFST_OK;
 }
 
 int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {

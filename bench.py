@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--groups", type=int, default=0, help="channel groups, each with its own stream and hipGraph (0 = library default 1); "
                     "2 overlaps two half-batches: +7 %% frames/s, but per-launch accounting then covers half a batch")
+    ap.add_argument("--host-feed", action="store_true", help="hand the log-likelihoods over as HOST matrices every step "
+                    "(wfst_decoder_advance_host): the PCIe-inclusive rate; never the headline")
     ap.add_argument("--arena-per-frame", type=int, default=20000, help="token arena per utterance = frames x this (raise it for wider beams)")
     ap.add_argument("--lattice-links", type=int, default=0, help="> 0: lattice mode (BASELINE configs[4]): record forward links "
                     "(capacity per utterance), prune by lattice_beam at finalize; the step then also takes the n-best")
@@ -249,6 +251,7 @@ def main():
     dec = wfstdec.BatchDecoder(graph, wfstdec.Config(**cd), B, max_frames=T + 2, max_tokens_per_frame=131072,
                                arena_tokens=int(T * a.arena_per_frame), stream=stream, lattice_links=a.lattice_links)
     ptrs = [ll_dev[i].data_ptr() for i in range(B)]
+    host_rows = [mats[i] for i in range(B)]
     ready = [T] * B
     Lmax = 64
 
@@ -258,7 +261,10 @@ def main():
         t0 = time.perf_counter()
         dec.init()
         t1 = time.perf_counter()
-        dec.advance(ptrs, ready, P)
+        if a.host_feed:
+            dec.advance_host(host_rows, ready)
+        else:
+            dec.advance(ptrs, ready, P)
         t2 = time.perf_counter()
         dec.finalize()
         t3 = time.perf_counter()
@@ -309,7 +315,9 @@ def main():
     dec.set_profiling(False)
 
     out = {
-        "metric": ("frames/sec decoded (RTFx = value/100) at fixed beam, best-path parity with the reference CPU decoder"
+        "metric": ("frames/sec decoded, log-likelihoods handed over as HOST matrices every step (PCIe-inclusive), best-path "
+                   "parity with the reference CPU decoder" if a.host_feed else
+                   "frames/sec decoded (RTFx = value/100) at fixed beam, best-path parity with the reference CPU decoder"
                    if a.lattice_links == 0 else
                    "frames/sec decoded WITH lattice generation (forward links, lattice-beam pruning at finalize, %d-best per "
                    "utterance; BASELINE configs[4]), best-path parity with the reference CPU decoder" % a.nbest),

@@ -132,7 +132,9 @@ int wfst_decoder_advance(wfst_decoder *d, const int32_t *channels, int32_t n,
                          int32_t stride, int32_t max_num_frames);
 
 /* Same with HOST matrices: rows [NumFramesDecoded, n_frames_ready) are copied into a device
- * history buffer owned by the channel (the shape a DecodableInterface-pulling caller needs). */
+ * history buffer owned by the channel (the shape a DecodableInterface-pulling caller needs).  The
+ * caller's buffers are consumed when the call returns.  A long hand-over is uploaded and decoded in
+ * slices, so that the copy of one slice overlaps the search over the previous one. */
 int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t n,
                               const float *const *loglikes_host, const int32_t *n_frames_ready,
                               int32_t stride, int32_t max_num_frames);
