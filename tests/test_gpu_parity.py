@@ -93,6 +93,13 @@ def test_host_fed_matrices_equal_device_resident(setup50k, synth):
     for x, y in zip(a, b):
         s["G"].assert_same_path(x, y.words, y.tids, y.path_ilabel, y.path_olabel, y.path_graph, y.path_ac,
                                 [y.tot_score, y.lm_score])
+    # one long hand-over (> 96 frames): advance_host uploads and decodes it in 48-frame slices
+    mats = _utts(synth, s, [230, 101, 97, 12], 4100)
+    a = s["G"].decode_batch(s["graph"], BEAM_ONLY, mats)
+    b = s["G"].decode_batch(s["graph"], BEAM_ONLY, mats, host_feed=True)
+    for x, y in zip(a, b):
+        s["G"].assert_same_path(x, y.words, y.tids, y.path_ilabel, y.path_olabel, y.path_graph, y.path_ac,
+                                [y.tot_score, y.lm_score])
 
 
 def test_per_frame_best_cost_and_token_subset(setup50k, synth, oracle):
