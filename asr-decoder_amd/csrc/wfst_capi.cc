@@ -131,6 +131,14 @@ struct wfst_decoder {
   DevBuf<float> bp_g, bp_ac;
   // host-fed log-likelihood history (advance_host)
   hipStream_t copy_stream = nullptr;  // host -> device uploads of advance_host
+  // pruned lattices fetched from the device (lattice mode): filled for ALL finalized channels by the
+  // first wfst_decoder_get_raw_lattice after a FinalizeDecoding, dropped by init / finalize
+  std::vector<std::vector<int4> > lat_cache_tok;
+  std::vector<std::vector<LatArc> > lat_cache_arc;
+  std::vector<char> lat_cached;
+  char *lat_pin = nullptr;  // pinned staging for that fetch
+  size_t lat_pin_bytes = 0;
+  std::vector<int32_t> lat_cache_nd;
   std::vector<float *> hist_dev;
   std::vector<size_t> hist_rows_cap;
   std::vector<int32_t> hist_rows;
@@ -161,6 +169,7 @@ struct wfst_decoder {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (lat_pin) (void)hipHostFree(lat_pin);
     for (float *p : hist_dev)
       if (p) (void)hipFree(p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -683,6 +692,7 @@ int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n) {
     d->h_state[c] = 1;
     d->h_ll_base[c] = nullptr;
     d->hist_rows[c] = 0;
+    if (!d->lat_cached.empty()) d->lat_cached[c] = 0;
   }
   return WFST_OK;
 }
@@ -893,7 +903,11 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
   launch_set_finalized(d->D, dev, cnt, d->stream);
   if (d->D.lattice) launch_lattice_prune(d->D, dev, cnt, d->stream);  // PruneForwardLinksFinal + backward pruning
   HIP_TRY(hipGetLastError());
-  for (int i = 0; i < cnt; ++i) d->h_state[channels ? channels[i] : i] = 2;
+  for (int i = 0; i < cnt; ++i) {
+    const int c = channels ? channels[i] : i;
+    d->h_state[c] = 2;
+    if (!d->lat_cached.empty()) d->lat_cached[c] = 0;
+  }
   return WFST_OK;
 }
 
@@ -1090,21 +1104,62 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
   *n_states = 0;
   *n_arcs = 0;
   if (!use_final_probs) return WFST_OK;  // base-inl.h:879-884: finalized && !use_final_probs -> false
-  int rc = read_ctl(d);
-  if (rc != WFST_OK) return rc;
-  rc = check_ctl_errors(d);
-  if (rc != WFST_OK) return rc;
-  const ChanCtl &c = d->p_ctl[channel];
-  const int nd = c.n_decoded;
+  if (d->lat_cached.empty()) {
+    d->lat_cached.assign((size_t)d->n_channels, 0);
+    d->lat_cache_nd.assign((size_t)d->n_channels, 0);
+    d->lat_cache_tok.resize((size_t)d->n_channels);
+    d->lat_cache_arc.resize((size_t)d->n_channels);
+  }
+  if (!d->lat_cached[channel]) {
+    // The pruned lattices were left compacted by lattice_prune_kernel.  One control-block read, then
+    // the two small lists of EVERY finalized channel in one sweep of copies and one synchronisation:
+    // a caller that walks all channels of a batch pays the device round trips once.
+    int rc = read_ctl(d);
+    if (rc != WFST_OK) return rc;
+    rc = check_ctl_errors(d);
+    if (rc != WFST_OK) return rc;
+    // through one pinned staging buffer: the copies are enqueued back to back and waited for once
+    size_t need = 0;
+    for (int c = 0; c < d->n_channels; ++c) {
+      if (d->h_state[c] != 2 || d->lat_cached[c]) continue;
+      need += (size_t)d->p_ctl[c].lat_toks * sizeof(int4) + (size_t)d->p_ctl[c].lat_arcs * sizeof(LatArc);
+    }
+    if (need > d->lat_pin_bytes) {
+      if (d->lat_pin) (void)hipHostFree(d->lat_pin);
+      d->lat_pin = nullptr;
+      d->lat_pin_bytes = 0;
+      HIP_TRY(hipHostMalloc((void **)&d->lat_pin, need + need / 4, hipHostMallocDefault));
+      d->lat_pin_bytes = need + need / 4;
+    }
+    size_t off = 0;
+    for (int c = 0; c < d->n_channels; ++c) {
+      if (d->h_state[c] != 2 || d->lat_cached[c]) continue;
+      const ChanCtl &cc = d->p_ctl[c];
+      const size_t tb = (size_t)cc.lat_toks * sizeof(int4), ab = (size_t)cc.lat_arcs * sizeof(LatArc);
+      if (tb) HIP_TRY(hipMemcpyAsync(d->lat_pin + off, d->lat_toks.p + (size_t)c * (size_t)d->D.lat_tok_cap, tb, hipMemcpyDeviceToHost, d->stream));
+      if (ab) HIP_TRY(hipMemcpyAsync(d->lat_pin + off + tb, d->lat_arcs.p + (size_t)c * (size_t)d->D.lat_arc_cap, ab, hipMemcpyDeviceToHost, d->stream));
+      off += tb + ab;
+    }
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    off = 0;
+    for (int c = 0; c < d->n_channels; ++c) {
+      if (d->h_state[c] != 2 || d->lat_cached[c]) continue;
+      const ChanCtl &cc = d->p_ctl[c];
+      const size_t tb = (size_t)cc.lat_toks * sizeof(int4), ab = (size_t)cc.lat_arcs * sizeof(LatArc);
+      d->lat_cache_nd[c] = cc.n_decoded;
+      d->lat_cache_tok[c].resize((size_t)cc.lat_toks);
+      d->lat_cache_arc[c].resize((size_t)cc.lat_arcs);
+      if (tb) memcpy(d->lat_cache_tok[c].data(), d->lat_pin + off, tb);
+      if (ab) memcpy(d->lat_cache_arc[c].data(), d->lat_pin + off + tb, ab);
+      off += tb + ab;
+      d->lat_cached[c] = 1;
+    }
+  }
+  const int nd = d->lat_cache_nd[channel];
   if (nd <= 0) return WFST_OK;
-  // the pruned lattice was left compacted by lattice_prune_kernel: two small copies
-  const int n_tok = c.lat_toks, n_arc = c.lat_arcs;
-  std::vector<int4> tk((size_t)n_tok);
-  std::vector<LatArc> ar((size_t)n_arc);
-  if (n_tok)
-    HIP_TRY(hipMemcpy(tk.data(), d->lat_toks.p + (size_t)channel * (size_t)d->D.lat_tok_cap, (size_t)n_tok * sizeof(int4), hipMemcpyDeviceToHost));
-  if (n_arc)
-    HIP_TRY(hipMemcpy(ar.data(), d->lat_arcs.p + (size_t)channel * (size_t)d->D.lat_arc_cap, (size_t)n_arc * sizeof(LatArc), hipMemcpyDeviceToHost));
+  std::vector<int4> tk = d->lat_cache_tok[channel];   // sorted below: work on a copy
+  const std::vector<LatArc> &ar = d->lat_cache_arc[channel];
+  const int n_tok = (int)tk.size(), n_arc = (int)ar.size();
   // tokens sorted by arena index = by frame, creation order inside a frame
   std::sort(tk.begin(), tk.end(), [](const int4 &a, const int4 &b) { return a.x < b.x; });
   auto find_tok = [&](int32_t arena_idx) -> int {
@@ -1118,6 +1173,9 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
     for (int f = 0; f <= nd; ++f)
       if (!seen[f]) return WFST_OK;
   }
+  *n_states = n_tok;
+  *n_arcs = n_arc;
+  if (n_tok > cap_states || n_arc > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");  // size probe
   std::vector<int32_t> src((size_t)n_arc), dst((size_t)n_arc);
   for (int i = 0; i < n_arc; ++i) {
     src[i] = find_tok(ar[i].src_tok);
@@ -1139,15 +1197,11 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
     return fa != fb ? fa < fb : depth[a] < depth[b];
   });
   for (int i = 0; i < n_tok; ++i) new_id[order[i]] = i;
-  *n_states = n_tok;
-  *n_arcs = n_arc;
-  if (n_tok > cap_states || n_arc > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");
-  const std::vector<int32_t> &pos = d->graph->pos_host;
   for (int i = 0; i < n_tok; ++i) {
     const int s = new_id[i];
     if (st_final) st_final[s] = (tk[i].w >> 30) & 1;
     if (st_frame) st_frame[s] = tk[i].w & 0x3FFFFFFF;
-    if (st_state) st_state[s] = (int32_t)(std::lower_bound(pos.begin(), pos.end(), tk[i].y) - pos.begin());
+    if (st_state) st_state[s] = tk[i].y;
     if (st_cost) memcpy(&st_cost[s], &tk[i].z, 4);
   }
   std::vector<int32_t> idx((size_t)n_arc);

@@ -163,7 +163,7 @@ struct DecoderDev {
   int32_t *link_off, *link_mid;  // [c][max_frames+3]
   uint2 *extra;
   LatArc *lat_arcs;
-  int4 *lat_toks;               // {arena index, graph row of the state, cost bits, frame | final << 30}
+  int4 *lat_toks;               // {arena index, graph state id, cost bits, frame | final << 30}
   int64_t link_cap;
   int32_t lat_arc_cap, lat_tok_cap;
   int32_t lattice;

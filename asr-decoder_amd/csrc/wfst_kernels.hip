@@ -1439,7 +1439,7 @@ __global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const 
       if (p >= D.lat_tok_cap) { s_err = 1; continue; }
       const int4 t = tok[i];
       const int fin = (k == nd && (!any_final || t.x == D.g.final_state)) ? 1 : 0;
-      out_toks[p] = make_int4(i, t.x, t.y, k | (fin << 30));
+      out_toks[p] = make_int4(i, D.g.arcs[t.x].y, t.y, k | (fin << 30));  // .y: the graph's own state id (row header)
     }
     __syncthreads();
   }

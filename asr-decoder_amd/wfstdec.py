@@ -256,6 +256,24 @@ class BatchDecoder:
         return dict(n_states=S, st_final=fin, st_frame=fr, st_state=gs, st_cost=co, a_src=src, a_dst=dst, a_ilabel=il,
                     a_olabel=ol, a_graph=gr, a_acoustic=ac)
 
+    def raw_lattices(self, channels=None, use_final_probs=True, threads=0):
+        """GetRawLattice of many finalized channels.  The first call fetches the pruned lattices of all
+        finalized channels from the device in one sweep; the per-lattice host work (numbering, arc
+        order) then runs on `threads` host threads (0 = min(16, cpu count))."""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        ch = list(range(self.n)) if channels is None else [int(c) for c in channels]
+        if not ch:
+            return []
+        first = self.raw_lattice(ch[0], use_final_probs)  # fills the host-side cache (single threaded)
+        nt = threads or min(16, os.cpu_count() or 1)
+        if nt <= 1 or len(ch) == 1:
+            return [first] + [self.raw_lattice(c, use_final_probs) for c in ch[1:]]
+        with ThreadPoolExecutor(max_workers=nt) as ex:
+            rest = list(ex.map(lambda c: self.raw_lattice(c, use_final_probs), ch[1:]))
+        return [first] + rest
+
     def nbest(self, n, channels=None, max_words=256):
         """GetNbest + LatticeToVector of finalized channels (lattice mode): per channel a list of
         dicts {words, tot_score, lm_score}, cheapest first."""

@@ -27,10 +27,11 @@ for links in (0, int(os.environ.get("LINKS", 6 << 20))):
     if links:
         st = [dec.stats(c) for c in range(B)]
         print("links per utt: mean %.0f max %d; tokens mean %.0f" % (np.mean([s["links"] for s in st]), max(s["links"] for s in st), np.mean([s["tokens"] for s in st])))
-        t0 = time.time(); L = [dec.raw_lattice(c) for c in range(8)]; t1 = time.time()
+        t0 = time.time(); L = dec.raw_lattices(); dt_lat = (time.time() - t0) * 1e3
         ts = []
         for it in range(5):
             t0 = time.time(); nb = dec.nbest(10 if it < 4 else 1); ts.append((time.time() - t0) * 1e3)
         print("nbest(10) all %d channels, 4 calls + nbest(1): %s ms; paths %s" % (B, [round(x, 1) for x in ts], [len(x) for x in nb[:8]]))
-        print("raw_lattice: %.1f ms per utterance; states %s arcs %s" % ((t1 - t0) * 1e3 / 8, [l["n_states"] for l in L], [len(l["a_src"]) for l in L]))
+        print("raw_lattice of all %d channels: %.1f ms (%.2f ms per utterance); states %s arcs %s" % (
+            B, dt_lat, dt_lat / B, [l["n_states"] for l in L[:8]], [len(l["a_src"]) for l in L[:8]]))
     dec.free()
