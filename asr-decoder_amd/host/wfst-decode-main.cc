@@ -229,11 +229,7 @@ int main(int argc, char **argv) {
             decode.AdvanceDecodingHost(ch, rows, ready, stride);
             decode.FinalizeDecoding(ch);
             decode.GetBestPaths(ch, &o.best, &o.ok);
-            if (want_lattice) {
-              o.lats.resize(n);
-              o.lat_ok.resize(n);
-              for (int i = 0; i < n; ++i) o.lat_ok[i] = decode.GetRawLattice(i, &o.lats[i]);
-            }
+            if (want_lattice) decode.GetRawLattices(ch, &o.lats, &o.lat_ok);
             if (nbest > 0) {
               o.nbest.resize(n);
               for (int i = 0; i < n; ++i) decode.GetNbest(i, o.nbest[i], nbest);

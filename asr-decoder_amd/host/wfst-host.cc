@@ -1,6 +1,8 @@
 // Implementation of wfst-host.h: thin C++ over the C ABI.  No decoding happens on the host.
 #include "wfst-host.h"
 
+#include <atomic>
+#include <thread>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -344,6 +346,36 @@ bool GpuLatticeDecoder::GetRawLattice(Lattice *ofst, bool use_final_probs) {
 }
 
 // ---- batch decoder ------------------------------------------------------------------------------
+void GpuBatchDecoder::GetRawLattices(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
+                                     bool use_final_probs, int threads) {
+  std::vector<int> ch(channels);
+  if (ch.empty())
+    for (int c = 0; c < _n; ++c) ch.push_back(c);
+  const size_t n = ch.size();
+  ofsts->assign(n, Lattice());
+  std::vector<char> good(n, 0);
+  if (n == 0) { ok->clear(); return; }
+  good[0] = RawLatticeOfChannel(_dec, ch[0], &(*ofsts)[0], use_final_probs);  // fetches every finalized channel's lists
+  int nt = threads > 0 ? threads : (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+  nt = (int)std::min<size_t>((size_t)nt, n);
+  std::atomic<size_t> next(1);
+  std::vector<std::string> errors((size_t)nt);
+  auto work = [&](int k) {
+    try {
+      for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1))
+        good[i] = RawLatticeOfChannel(_dec, ch[i], &(*ofsts)[i], use_final_probs);
+    } catch (const std::exception &e) {
+      errors[(size_t)k] = e.what();
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int k = 1; k < nt; ++k) pool.emplace_back(work, k);
+  work(0);
+  for (std::thread &t : pool) t.join();
+  for (const std::string &e : errors)
+    if (!e.empty()) throw std::runtime_error(e);
+  ok->assign(good.begin(), good.end());
+}
 bool GpuBatchDecoder::GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n) {
   return NbestOfChannel(_dec, channel, nbest_paths, n);
 }

@@ -220,6 +220,10 @@ class GpuBatchDecoder {
   int NumFramesDecoded(int channel) const;
   bool GetBestPath(int channel, Lattice *ofst, bool use_final_probs = true);
   bool GetRawLattice(int channel, Lattice *ofst, bool use_final_probs = true);
+  // the raw lattices of many channels: one device fetch, then the per-lattice host work on
+  // `threads` host threads (0: up to 16)
+  void GetRawLattices(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
+                      bool use_final_probs = true, int threads = 0);
   bool GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n);
   void GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
                     bool use_final_probs = true);
