@@ -106,3 +106,25 @@ def test_vectorised_lattice_to_vector_equals_c_entry_point(pkg):
     assert np.float32(tot.value).tobytes() == np.float32(t2).tobytes()
     assert np.float32(lm.value).tobytes() == np.float32(l2).tobytes()
     assert list(words[: nw.value]) == list(ol[ol != 0]) and list(tids[: nt.value]) == list(il[il != 0])
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/wfst_decoder.h must compile as C99 (no C++ in it), and a
+    C program that uses it must link against the library."""
+    import subprocess
+
+    src = tmp_path / "use.c"
+    src.write_text(
+        '#include "wfst_decoder.h"\n'
+        "int main(void) {\n"
+        "  wfst_config c; wfst_limits l = {0, 0, 0, 0}; wfst_arc a = {0, 0, 0.0f, 0}; wfst_state_info s = {0, 0, 0};\n"
+        "  wfst_config_default(&c);\n"
+        "  (void)l; (void)a; (void)s;\n"
+        "  return (c.beam > 0.0f && wfst_last_error() != 0) ? 0 : 1;\n"
+        "}\n")
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "asr-decoder_amd", "lib")
+    exe = str(tmp_path / "use")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + inc, str(src), "-o", exe,
+                           "-L" + libdir, "-lwfstdec", "-Wl,-rpath," + libdir])
+    assert subprocess.run([exe]).returncode == 0
