@@ -34,6 +34,16 @@ constexpr int32_t kFstMagicNumber = 2125659606;  // openfst: fst/fst.h
 constexpr int32_t kHasIsymbols = 1, kHasOsymbols = 2, kIsAligned = 4;
 constexpr int kArchAlignment = 16;               // openfst: fst/const-fst.h / fst/util.h
 
+// bytes from the current position to the end of the file: counts read from a header are checked
+// against it before anything is allocated (a damaged count must not become a 30 GB request)
+long long bytes_left(FILE *fp) {
+  const long pos = ftell(fp);
+  if (pos < 0 || fseek(fp, 0, SEEK_END) != 0) return -1;
+  const long end = ftell(fp);
+  if (fseek(fp, pos, SEEK_SET) != 0) return -1;
+  return (long long)end - pos;
+}
+
 struct Reader {
   FILE *fp;
   bool ok = true;
@@ -73,6 +83,8 @@ int read_flat(FILE *fp, HostGraph *g, std::string *err) {
   if (fread(hdr, 4, 6, fp) != 6) return fail(err, WFST_E_IO, "truncated header");
   const int32_t S = hdr[2], A = hdr[3];
   if (S <= 0 || A < 0) return fail(err, WFST_E_IO, "bad header");
+  if ((long long)S * (long long)sizeof(wfst_state_info) + (long long)A * (long long)sizeof(wfst_arc) > bytes_left(fp))
+    return fail(err, WFST_E_IO, "truncated graph file");
   g->start = hdr[0];
   g->final_state = hdr[1];
   g->total_niepsilons = hdr[4];
@@ -99,6 +111,11 @@ int read_openfst(FILE *fp, HostGraph *g, std::string *err) {
     return fail(err, WFST_E_FORMAT, "the fst embeds symbol tables; strip them first (fstsymbols --clear_isymbols --clear_osymbols)");
   if (numstates <= 0 || numstates >= 0x7FFFFFF0ll || start < 0 || start >= numstates)
     return fail(err, WFST_E_FORMAT, "OpenFst header: no states or bad start state");
+  long long left = bytes_left(fp);  // asked once: seeking would drop the stdio buffer on every call
+  if ((fsttype == "vector" && numstates * 12 > left) ||
+      (fsttype == "const" && (numstates * (long long)sizeof(ConstState) > left || numarcs < 0 ||
+                              numarcs > (left - numstates * (long long)sizeof(ConstState)) / (long long)sizeof(wfst_arc))))
+    return fail(err, WFST_E_IO, "truncated OpenFst file (the header announces more states / arcs than the file holds)");
   const int32_t S = (int32_t)numstates, super_final = S;
   g->start = (int32_t)start;
   g->final_state = super_final;
@@ -110,7 +127,10 @@ int read_openfst(FILE *fp, HostGraph *g, std::string *err) {
     for (int32_t s = 0; s < S; ++s) {
       const float fin = r.get<float>();
       const int64_t na = r.get<int64_t>();
-      if (!r.ok || na < 0 || na > 0x7FFFFFF0ll) return fail(err, WFST_E_IO, "truncated OpenFst vector fst");
+      left -= 12;
+      if (!r.ok || na < 0 || left < 0 || na > left / (long long)sizeof(wfst_arc))
+        return fail(err, WFST_E_IO, "truncated OpenFst vector fst");
+      left -= na * (long long)sizeof(wfst_arc);
       wfst_state_info &si = g->states[(size_t)s];
       if (is_final(fin)) {
         g->arcs.push_back(wfst_arc{0, 0, fin, super_final});
