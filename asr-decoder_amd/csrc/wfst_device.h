@@ -122,7 +122,9 @@ struct FrameCtl {
   int32_t ticket[2];       // dynamic tile dispenser of expand_kernel
   int32_t n_items[2];      // insert work items listed by plan_channel (expand's last tile of a channel)
   int32_t item_ticket[2];  // dynamic item dispenser of insert_kernel
-  int32_t pad[8];
+  int32_t n_small[2];      // of those items, the light ones: listed from the END of items[] so that the
+                           // insert workgroups take the heavy items first (longest-first keeps the tail short)
+  int32_t pad[6];
 };
 
 // ---- decoder (batch of channels) ---------------------------------------------------------

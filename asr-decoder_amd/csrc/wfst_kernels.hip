@@ -87,6 +87,8 @@ __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned l
   t_prev = now;
 }
 
+constexpr int kHeavyItem = 900;  // records: insert items above this are handed out first
+
 // Which buckets share a workgroup?  Partitions of a light channel hold a few dozen records each;
 // the largest aligned group of 64 / 32 / ... / 2 partitions whose records fit ONE pass of a small LDS
 // table becomes one work item, so a light channel costs 1-4 items while a heavy channel keeps all
@@ -125,12 +127,27 @@ __device__ void plan_channel(const DecoderDev &D, int c, int group, int par) {
   const bool leader = lane < P && g0 == lane && n > 0;
   const u64 m = __ballot(leader);
   if (!m) return;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(&fc->n_items[par], __popcll(m));
-  base = __shfl(base, 0, 64);
+  // heavy items are listed from the front of items[], light ones from the back; the insert
+  // workgroups walk heavy first
+  const bool heavy = leader && n > kHeavyItem;
+  const u64 mh = __ballot(heavy), ml = m & ~mh;
+  int bh = 0, bl = 0;
+  if (lane == 0) {
+    if (mh) bh = atomicAdd(&fc->n_items[par], __popcll(mh));
+    if (ml) bl = atomicAdd(&fc->n_small[par], __popcll(ml));
+  }
+  bh = __shfl(bh, 0, 64);
+  bl = __shfl(bl, 0, 64);
   if (leader) {
-    const int idx = base + lane_rank(m);
-    if (idx < D.item_cap) D.items[(size_t)group * D.item_cap + idx] = (c << 16) | (g0 << 8) | G;
+    const int v = (c << 16) | (g0 << 8) | G;
+    int32_t *items = D.items + (size_t)group * D.item_cap;
+    if (heavy) {
+      const int idx = bh + lane_rank(mh);
+      if (idx < D.item_cap / 2) items[idx] = v;
+    } else {
+      const int idx = bl + lane_rank(ml);
+      if (idx < D.item_cap / 2) items[D.item_cap - 1 - idx] = v;
+    }
   }
 }
 
@@ -169,6 +186,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
     fc->total_tiles[par ^ 1] = 0;
     fc->ticket[par ^ 1] = 0;
     fc->n_items[par ^ 1] = 0;
+    fc->n_small[par ^ 1] = 0;
     fc->item_ticket[par ^ 1] = 0;
   }
   const TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap;
@@ -378,11 +396,11 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   u64 *s_best = ish.best;
   int *s_pref = ish.pref;
   FrameCtl *fc = D.fctl + group;
-  const int n_items = min(fc->n_items[par], D.item_cap);
+  const int n_heavy = min(fc->n_items[par], D.item_cap / 2), n_items = n_heavy + min(fc->n_small[par], D.item_cap / 2);
   const int P = D.n_part;
 
   for (int it = blockIdx.x; it < n_items;) {
-  const int item = D.items[(size_t)group * D.item_cap + it];
+  const int item = D.items[(size_t)group * D.item_cap + (it < n_heavy ? it : D.item_cap - 1 - (it - n_heavy))];
   const int c = item >> 16, g0 = (item >> 8) & 0xFF, G = item & 0xFF;
   ChanCtl *ctl = D.ctl + c;
   int n = 0;
