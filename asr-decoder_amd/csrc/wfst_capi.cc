@@ -534,7 +534,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   A(d->fctl.alloc(8));
   A(d->dbg_t.alloc(64));
   A(d->tiles.alloc(8 * tile_cap));
-  const size_t item_cap = B * (size_t)n_part;
+  const size_t item_cap = 2 * B * (size_t)n_part;  // two lists (heavy from the front, light from the back), each sized for the worst case
   A(d->items.alloc(8 * item_cap));
   A(d->target.alloc(B));
   A(d->chan_list.alloc(B));

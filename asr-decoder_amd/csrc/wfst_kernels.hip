@@ -144,9 +144,11 @@ __device__ void plan_channel(const DecoderDev &D, int c, int group, int par) {
     if (heavy) {
       const int idx = bh + lane_rank(mh);
       if (idx < D.item_cap / 2) items[idx] = v;
+      else atomicOr(&D.ctl[c].error, kErrBucketFull);  // cannot happen: each half holds channels x partitions
     } else {
       const int idx = bl + lane_rank(ml);
       if (idx < D.item_cap / 2) items[D.item_cap - 1 - idx] = v;
+      else atomicOr(&D.ctl[c].error, kErrBucketFull);
     }
   }
 }
