@@ -99,5 +99,13 @@ int main() {
   printf("min64 wg noret x16  : %.1f us  %.1f Gops/s\n", t * 1e3, ops * 4 / t / 1e6);
   t = timeit([&] { hipLaunchKernelGGL((k_min64<__HIP_MEMORY_SCOPE_AGENT, false>), blocks, threads, 0, 0, tab64, slots, n_chan, 16); });
   printf("min64 agent noret x16: %.1f us  %.1f Gops/s\n", t * 1e3, ops * 4 / t / 1e6);
+  // how fast can ONE workgroup (one compute unit) issue returning atomics?  (the closure kernel's
+  // heaviest channel does ~3.9 k of them from its single 1024-thread workgroup)
+  for (int wgs = 1; wgs <= 8; wgs *= 2) {
+    t = timeit([&] { hipLaunchKernelGGL((k_min64<__HIP_MEMORY_SCOPE_AGENT, true>), wgs, 1024, 0, 0, tab64, slots, 1, 4 / wgs > 0 ? 4 / wgs : 1); });
+    printf("min64 agent ret, %d x 1024 threads, %d per thread (4096 atomics total): %.1f us\n", wgs, 4 / wgs > 0 ? 4 / wgs : 1, t * 1e3);
+  }
+  t = timeit([&] { hipLaunchKernelGGL(k_gather16, 1, 1024, 0, 0, arcs, n_arcs, 4, sink); });
+  printf("gather 16B random, 1 x 1024 threads x 4: %.1f us\n", t * 1e3);
   return 0;
 }
