@@ -648,7 +648,8 @@ void wfst_decoder_free(wfst_decoder *d) {
         if (t[3 * k + 2])
           fprintf(stderr, "[wfst dbg] %-18s n=%llu mean=%.2f us max=%.2f us\n", names[k], t[3 * k + 2],
                   0.01 * t[3 * k] / t[3 * k + 2], 0.01 * t[3 * k + 1]);
-      fprintf(stderr, "[wfst dbg] closure rounds total=%llu launches*chan=%llu max_seeds=%llu\n", t[40], t[41], t[42]);
+      fprintf(stderr, "[wfst dbg] closure rounds total=%llu launches*chan=%llu max_seeds=%llu max_rounds=%llu first round mean=%.2f us max=%.2f us\n",
+              t[56], t[57], t[58], t[59], t[57] ? 0.01 * t[60] / t[57] : 0.0, 0.01 * t[61]);
     }
   }
   delete d;

@@ -690,15 +690,21 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
   int4 *tok = D.tok + (size_t)c * D.arena_cap;
   u64 nZ = 0;
   unsigned long long tq = wall_clock64();
-  if (tid == 0 && (D.dbg & 32)) { atomicAdd(&D.dbg_t[41], 1ull); atomicMax(&D.dbg_t[42], (unsigned long long)sh.wl_n[0]); }
+  if (tid == 0 && (D.dbg & 32)) { atomicAdd(&D.dbg_t[57], 1ull); atomicMax(&D.dbg_t[58], (unsigned long long)sh.wl_n[0]); }
   if (tid == 0) sh.nwon = 0;
 
   int cur = 0;
+  int dbg_rounds = 0;
+  unsigned long long dbg_t0 = wall_clock64();
   for (;;) {
     __syncthreads();
     const int nw = sh.wl_n[cur];
+    if (tid == 0 && (D.dbg & 32) && dbg_rounds == 1) {  // the first round is over
+      const unsigned long long dt = wall_clock64() - dbg_t0;
+      atomicAdd(&D.dbg_t[60], dt); atomicMax(&D.dbg_t[61], dt);
+    }
     if (nw == 0) break;
-    if (tid == 0 && (D.dbg & 32)) atomicAdd(&D.dbg_t[40], 1ull);
+    if (tid == 0 && (D.dbg & 32)) { atomicAdd(&D.dbg_t[56], 1ull); ++dbg_rounds; }
     const int4 *wl_cur = wl + (size_t)cur * D.wl_cap;
     int4 *wl_nxt = wl + (size_t)(cur ^ 1) * D.wl_cap;
     // four worklist entries per thread in flight (independent load chains issued together)
@@ -799,6 +805,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
     cur ^= 1;
   }
   __syncthreads();
+  if (tid == 0 && (D.dbg & 32)) atomicMax(&D.dbg_t[59], (unsigned long long)dbg_rounds);
   if (tid == 0) dbg_phase(D, 1, tq);
   const int nocc = min(sh.occ, D.wl_cap), nwon = min(sh.nwon, D.wl_cap);
   const bool fits = sh.nnew <= D.max_tok && (int64_t)base + sh.nnew <= D.arena_cap;
