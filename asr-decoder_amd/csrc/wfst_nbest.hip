@@ -219,8 +219,10 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
           if (found != cnt[t]) diff = true;
           if (lane < found) {
             const NbEntry O = list[(size_t)t * K + lane];
+            // the backpointer too: an epsilon-source state of this frame may have re-ordered its list
+            // since the last round without changing any cost here
             if (lane >= cnt[t] || __float_as_uint(O.tot) != __float_as_uint(res.tot) || O.hash != res.hash ||
-                __float_as_uint(O.lm) != __float_as_uint(res.lm))
+                __float_as_uint(O.lm) != __float_as_uint(res.lm) || O.prev != res.prev || O.word != res.word)
               diff = true;
           }
           diff = __ballot(diff) != 0;
