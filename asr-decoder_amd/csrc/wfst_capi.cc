@@ -1006,8 +1006,11 @@ int wfst_decoder_get_nbest(wfst_decoder *d, const int32_t *channels, int32_t n_c
     if (d->h_state[channels ? channels[i] : i] != 2) return fail(WFST_E_STATE, "GetNbest is served after FinalizeDecoding");
   NbestDev &N = d->nb;
   if (!d->nb_list.p) {  // first use: per-channel k-best lists and index scratch
-    N.tok_cap = std::min<int32_t>(d->D.lat_tok_cap, 32768);
-    N.arc_cap = std::min<int32_t>(d->D.lat_arc_cap, 131072);
+    // k-best lists: 16 entries x 24 bytes per lattice state; up to 262144 states per lattice, less
+    // when that would take more than ~4 GB over all channels (never below 32768)
+    const int64_t budget = (int64_t)(4ll << 30) / ((int64_t)d->n_channels * 16 * (int64_t)sizeof(NbEntry));
+    N.tok_cap = (int32_t)std::min<int64_t>(d->D.lat_tok_cap, std::min<int64_t>(262144, std::max<int64_t>(32768, budget)));
+    N.arc_cap = (int32_t)std::min<int64_t>(d->D.lat_arc_cap, 4ll * N.tok_cap);
     N.scratch_ints = 3ll * N.tok_cap + 1 + 2ll * (d->D.max_frames + 2) + N.arc_cap;
     HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(d->nb_list.alloc((size_t)d->n_channels * (size_t)N.tok_cap * 16));
@@ -1041,7 +1044,7 @@ int wfst_decoder_get_nbest(wfst_decoder *d, const int32_t *channels, int32_t n_c
   rc = check_ctl_errors(d);
   if (rc != WFST_OK) return rc;
   for (int i = 0; i < cnt; ++i)
-    if (n_paths[i] < 0) return fail(WFST_E_CAPACITY, "lattice too large for the n-best search (more than 32768 states or 131072 arcs)");
+    if (n_paths[i] < 0) return fail(WFST_E_CAPACITY, ("lattice too large for the n-best search (more than " + std::to_string(N.tok_cap) + " states or " + std::to_string(N.arc_cap) + " arcs)"));
   return WFST_OK;
 }
 

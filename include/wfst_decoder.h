@@ -198,8 +198,9 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
  * Computed on the device by a k-best search over the raw lattice (no determinized lattice is
  * materialised).  Outputs for the i-th listed channel: n_paths[i]; n_words[i*n + k];
  * words[(i*n + k)*max_words ...] (first max_words ids); tot_score / lm_score [i*n + k].
- * n_paths[i] == 0: no lattice (see wfst_decoder_get_raw_lattice).  WFST_E_CAPACITY if a lattice has
- * more than 32768 states or 131072 arcs. */
+ * n_paths[i] == 0: no lattice (see wfst_decoder_get_raw_lattice).  WFST_E_CAPACITY if a lattice is
+ * larger than the search's working set (32768 .. 262144 states depending on the channel count;
+ * the message gives the numbers). */
 int wfst_decoder_get_nbest(wfst_decoder *d, const int32_t *channels, int32_t n_channels, int32_t n,
                            int32_t max_words, int32_t *n_paths, int32_t *n_words, int32_t *words,
                            float *tot_score, float *lm_score);
