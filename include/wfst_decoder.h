@@ -3,7 +3,8 @@
  *
  * This is the drop-in boundary for ONE path of datemoon/ASR-decoder: the frame-synchronous
  * token-passing search of src/my-decoder (ProcessEmitting / ProcessNonemitting / beam pruning
- * over the flat HCLG of src/newfst), precomputed log-likelihoods in, best path out.
+ * over the flat HCLG of src/newfst), precomputed log-likelihoods in; best path, raw lattice and
+ * n-best out.
  * Plain pointers and sizes only; no C++ or torch types.  Every entry point names the reference
  * interface it replaces (paths relative to the reference's src/).
  *
@@ -41,7 +42,8 @@ typedef struct wfst_decoder wfst_decoder; /* a batch of decoding channels; one c
  * wfst_config_default() fills the reference defaults (conf.h:35-44).  hash_ratio and prune_scale
  * are accepted for compatibility: the device hash is sized by wfst_limits, and best-path decoding
  * keeps no forward-link lists to back-prune (prune_interval and lattice_beam still decide which
- * of several parallel arcs GetBestPath reports, exactly as in the reference). */
+ * of several parallel arcs GetBestPath reports, exactly as in the reference).  In lattice mode
+ * (wfst_limits.lattice_links) lattice_beam prunes the recorded links at FinalizeDecoding. */
 typedef struct wfst_config {
   float beam;
   int32_t max_active;
