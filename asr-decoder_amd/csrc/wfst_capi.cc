@@ -144,6 +144,7 @@ struct wfst_decoder {
   std::vector<int32_t> hist_rows;
   int32_t hist_stride = 0;
   int tiles_per_channel = 16;
+  int upload_slice = 48;  // wfst_options.upload_slice_frames
   // the frame loop of one advance call, captured once per (frames per group, stride) and replayed
   bool use_graph = true;
   std::map<std::vector<int>, hipGraphExec_t> graphs;
@@ -201,6 +202,23 @@ void wfst_config_default(wfst_config *c) {  // lattice-faster-decoder-conf.h:35-
   c->prune_scale = 0.1f;
 }
 
+void wfst_options_default(wfst_options *o) {
+  o->channel_groups = 1;
+  o->use_hip_graph = 1;
+  o->log2_partitions = 5;  // 32 partitions: measured best at batch 128 (16: insert slower, 64: more bucket atomics)
+  o->log2_lds_slots = 12;
+  o->joint_max = 1536;
+  o->expand_workgroups = 2048;
+  o->insert_workgroups = 768;
+  o->upload_slice_frames = 48;
+  o->debug = 0;
+}
+
+void wfst_graph_options_default(wfst_graph_options *o) {
+  o->row_align_slots = 4;
+  o->flatten_closures = 1;
+}
+
 const char *wfst_last_error(void) { return g_err.c_str(); }
 
 int wfst_device_count(void) {
@@ -250,7 +268,17 @@ static int upload_columns(wfst_graph *g, const int32_t *tid2pdf, int32_t n_tid, 
 int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states, int32_t n_arcs,
                            const wfst_state_info *states, const wfst_arc *arcs, int device,
                            wfst_graph **out) {
+  return wfst_graph_from_arrays_ex(start, final_state, n_states, n_arcs, states, arcs, device, nullptr, out);
+}
+
+int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_states, int32_t n_arcs,
+                              const wfst_state_info *states, const wfst_arc *arcs, int device,
+                              const wfst_graph_options *gopt, wfst_graph **out) {
   if (!out) return fail(WFST_E_ARG, "out is NULL");
+  wfst_graph_options GO;
+  wfst_graph_options_default(&GO);
+  if (gopt) GO = *gopt;
+  if (GO.row_align_slots < 1 || GO.row_align_slots > 64) return fail(WFST_E_ARG, "row_align_slots must be 1..64");
   *out = nullptr;
   if (n_states <= 0 || n_arcs < 0 || !states || (n_arcs > 0 && !arcs))
     return fail(WFST_E_ARG, "empty graph or NULL arrays");
@@ -263,9 +291,8 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
     return fail(WFST_E_FORMAT, "graphs with states + arcs >= 2^29 are not supported");
   // A row (header + arcs, 16-byte slots) that fits in k 64-byte lines is placed so that it touches
   // only k lines: expanding a token is a random gather, priced per LINE, and an unaligned 3-arc row
-  // straddles two.  Costs ~10 % padding slots.  WFST_ROW_ALIGN=1 packs the rows tightly (slots per line).
-  int64_t line_slots = 4;
-  if (const char *e = getenv("WFST_ROW_ALIGN")) line_slots = std::max(1, atoi(e));
+  // straddles two.  Costs ~10 % padding slots.  row_align_slots = 1 packs the rows tightly.
+  const int64_t line_slots = GO.row_align_slots;
 
   // pass 1: validate, positions, epsilon targets
   std::vector<int32_t> pos((size_t)n_states);
@@ -337,7 +364,7 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
   // pass 3: flattened epsilon closures (wfst_device.h "eps_flat"): breadth-first over a state's
   // epsilon arcs; a closure with more than kFlatMax paths (or an epsilon cycle) stays iterative
   std::vector<int4> h_flat;
-  if (!getenv("WFST_NO_FLAT")) {
+  if (GO.flatten_closures) {
     std::vector<int64_t> aoff((size_t)n_states + 1, 0);
     for (int32_t s = 0; s < n_states; ++s) aoff[(size_t)s + 1] = aoff[s] + states[s].num_arcs;
     struct Node { int32_t state, parent; };
@@ -408,14 +435,18 @@ int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states,
 }
 
 int wfst_graph_load(const char *path, int device, wfst_graph **out) {
+  return wfst_graph_load_ex(path, device, nullptr, out);
+}
+
+int wfst_graph_load_ex(const char *path, int device, const wfst_graph_options *gopt, wfst_graph **out) {
   if (!path || !out) return fail(WFST_E_ARG, "NULL argument");
   *out = nullptr;
   wfst::HostGraph hg;
   std::string err;
   const int rc = wfst::read_graph_file(path, &hg, &err);
   if (rc != WFST_OK) return fail(rc, err);
-  return wfst_graph_from_arrays(hg.start, hg.final_state, (int32_t)hg.states.size(), (int32_t)hg.arcs.size(),
-                                hg.states.data(), hg.arcs.data(), device, out);
+  return wfst_graph_from_arrays_ex(hg.start, hg.final_state, (int32_t)hg.states.size(), (int32_t)hg.arcs.size(),
+                                   hg.states.data(), hg.arcs.data(), device, gopt, out);
 }
 
 int wfst_graph_convert_file(const char *in_path, const char *flat_out_path) {
@@ -465,11 +496,26 @@ static int check_config(const wfst_config *c) {  // LatticeFasterDecoderConfig::
 
 int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
                         const wfst_limits *limits, void *hip_stream, wfst_decoder **out) {
+  return wfst_decoder_create_ex(g, cfg, n_channels, limits, nullptr, hip_stream, out);
+}
+
+int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
+                           const wfst_limits *limits, const wfst_options *options, void *hip_stream,
+                           wfst_decoder **out) {
   if (!out) return fail(WFST_E_ARG, "out is NULL");
   *out = nullptr;
   if (!g || !cfg || n_channels <= 0) return fail(WFST_E_ARG, "NULL graph/config or n_channels <= 0");
+  // insert work items carry the channel in 15 bits (wfst_kernels.hip plan_channel)
+  if (n_channels > 32767) return fail(WFST_E_ARG, "at most 32767 channels per decoder");
   int rc = check_config(cfg);
   if (rc != WFST_OK) return rc;
+  wfst_options O;
+  wfst_options_default(&O);
+  if (options) O = *options;
+  if (O.channel_groups < 1 || O.channel_groups > 8 || O.log2_partitions < 0 || O.log2_partitions > 6 ||
+      O.log2_lds_slots < 8 || O.log2_lds_slots > 13 || O.joint_max < 1 || O.expand_workgroups < 1 ||
+      O.insert_workgroups < 1 || O.upload_slice_frames < 0)
+    return fail(WFST_E_ARG, "wfst_options field out of range");
   HIP_TRY(hipSetDevice(g->device));
   wfst_limits L = {0, 0, 0, 0};
   if (limits) L = *limits;
@@ -481,9 +527,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   // hash partitions per channel: each insert workgroup owns an LDS table of lds_slots entries;
   // a bucket too full for it is handled in sub-passes, so these are speed knobs, not limits
   const int64_t M = L.max_tokens_per_frame;
-  int lds_slots = 4096, log2lds = 12, log2part = 5;  // 32 partitions: measured best at batch 128 (16: insert slower, 64: more bucket atomics)
-  if (const char *e = getenv("WFST_LOG2_PARTS")) log2part = std::max(0, std::min(6, atoi(e)));
-  if (const char *e = getenv("WFST_LOG2_LDS_SLOTS")) { log2lds = std::max(8, std::min(13, atoi(e))); lds_slots = 1 << log2lds; }
+  int log2lds = O.log2_lds_slots, lds_slots = 1 << log2lds, log2part = O.log2_partitions;
   while (log2part > 0 && (int64_t)lds_slots << (log2part - 1) >= 4 * M) --log2part;  // tiny limits: fewer parts
   const int n_part = 1 << log2part;
   const int64_t bucket_cap = std::max<int64_t>(2048, 8 * M / n_part);
@@ -595,7 +639,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.lds_slots = lds_slots;
   D.log2lds = log2lds;
   D.bucket_cap = (int32_t)bucket_cap;
-  D.joint_max = getenv("WFST_JOINT_MAX") ? atoi(getenv("WFST_JOINT_MAX")) : 1536;
+  D.joint_max = O.joint_max;
   D.ecap = (int32_t)ecap;
   D.max_tok = L.max_tokens_per_frame;
   D.wl_cap = L.max_tokens_per_frame;
@@ -607,7 +651,7 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   D.max_active = cfg->max_active;
   D.min_active = cfg->min_active;
   D.prune_interval = cfg->prune_interval;
-  D.dbg = getenv("WFST_DBG") ? atoi(getenv("WFST_DBG")) : 0;
+  D.dbg = O.debug;
   d->h_decoded.assign(B, 0);
   d->h_target.assign(B, 0);
   d->h_state.assign(B, 0);
@@ -615,9 +659,9 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
   d->hist_dev.assign(B, nullptr);
   d->hist_rows_cap.assign(B, 0);
   d->hist_rows.assign(B, 0);
-  if (const char *ng = getenv("WFST_NO_GRAPH")) d->use_graph = atoi(ng) == 0;
-  d->n_groups = 1;
-  if (const char *gs = getenv("WFST_GROUPS")) d->n_groups = std::max(1, std::min(atoi(gs), std::min(8, n_channels)));
+  d->use_graph = O.use_hip_graph != 0;
+  d->upload_slice = O.upload_slice_frames;
+  d->n_groups = std::min(O.channel_groups, n_channels);
   if (d->n_groups > 1) {
     d->gstreams.resize(d->n_groups);
     d->gevents.resize(d->n_groups + 1);
@@ -626,9 +670,8 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
     for (auto &ev : d->gevents) if (ge == hipSuccess) ge = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (ge != hipSuccess) { delete d; return fail(WFST_E_DEVICE, "stream/event creation failed"); }
   }
-  if (const char *tp = getenv("WFST_EXPAND_WGS")) { if (atoi(tp) > 0) d->expand_wgs = atoi(tp); }
-  if (const char *tp = getenv("WFST_INSERT_WGS")) { if (atoi(tp) > 0) d->insert_wgs = atoi(tp); }
-  if (n_channels > 65535) { delete d; return fail(WFST_E_ARG, "at most 65535 channels per decoder"); }
+  d->expand_wgs = O.expand_workgroups;
+  d->insert_wgs = O.insert_workgroups;
   d->gpar.assign(8, 0);
   *out = d;
   return WFST_OK;
@@ -727,14 +770,22 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (target > d->D.max_frames) return fail(WFST_E_CAPACITY, "utterance longer than wfst_limits.max_frames");
     steps = std::max(steps, target - d->h_decoded[c]);
   }
-  if (steps == 0) return WFST_OK;
+  // The device's row pointers follow the caller's even when no frame is decoded by this call: the
+  // matrix may have moved (advance_host regrows its history buffer), and GetBestPath / the lattice
+  // pruning read acoustic costs of PAST frames through ll_base[c].
+  bool moved = false;
+  for (int i = 0; i < cnt; ++i) {
+    const int c = channels ? channels[i] : i;
+    if (loglikes[i] && loglikes[i] != d->h_ll_base[c]) moved = true;
+  }
+  if (steps == 0 && !moved) return WFST_OK;
   HIP_TRY(hipStreamSynchronize(d->stream));  // pinned staging reuse
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     int target = n_frames_ready[i];
     if (max_num_frames >= 0) target = std::min(target, d->h_decoded[c] + max_num_frames);
     d->h_target[c] = target;
-    d->h_ll_base[c] = loglikes[i];
+    if (loglikes[i]) d->h_ll_base[c] = loglikes[i];
   }
   for (int c = 0; c < d->n_channels; ++c) {
     d->p_target[c] = d->h_target[c];
@@ -744,6 +795,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   HIP_TRY(hipMemcpyAsync((void *)d->ll_base.p, (const void *)d->p_ll, (size_t)d->n_channels * sizeof(float *),
                          hipMemcpyHostToDevice, d->stream));
   d->D.stride = stride;
+  if (steps == 0) return WFST_OK;
   // frames to decode per channel group
   const int G = d->n_groups, per = (d->n_channels + G - 1) / G;
   std::vector<int> gsteps(G, 0);
@@ -865,10 +917,10 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
   // copy call returns when the caller's buffer is consumed) while the GPU decodes slice k, so the
   // PCIe time of a long hand-over hides behind the search instead of preceding it.
   if (!d->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
-  const int kSlice = 48;
+  const int kSlice = std::max(1, d->upload_slice);
   int longest = 0;
   for (int i = 0; i < cnt; ++i) longest = std::max(longest, n_frames_ready[i] - d->hist_rows[channels ? channels[i] : i]);
-  const bool sliced = max_num_frames < 0 && longest > 2 * kSlice && !getenv("WFST_NO_SLICE");
+  const bool sliced = max_num_frames < 0 && d->upload_slice > 0 && longest > 2 * kSlice;
   std::vector<int32_t> ready((size_t)cnt);
   for (int done = 0; done < std::max(longest, 1); done += sliced ? kSlice : std::max(longest, 1)) {
     const int upto = sliced ? done + kSlice : longest;

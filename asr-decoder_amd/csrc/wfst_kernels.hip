@@ -139,7 +139,7 @@ __device__ void plan_channel(const DecoderDev &D, int c, int group, int par) {
   bh = __shfl(bh, 0, 64);
   bl = __shfl(bl, 0, 64);
   if (leader) {
-    const int v = (c << 16) | (g0 << 8) | G;
+    const int v = (int)(((uint32_t)c << 16) | ((uint32_t)g0 << 8) | (uint32_t)G);  // c <= 32767 (wfst_decoder_create_ex)
     int32_t *items = D.items + (size_t)group * D.item_cap;
     if (heavy) {
       const int idx = bh + lane_rank(mh);
@@ -402,8 +402,8 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   const int P = D.n_part;
 
   for (int it = blockIdx.x; it < n_items;) {
-  const int item = D.items[(size_t)group * D.item_cap + (it < n_heavy ? it : D.item_cap - 1 - (it - n_heavy))];
-  const int c = item >> 16, g0 = (item >> 8) & 0xFF, G = item & 0xFF;
+  const uint32_t item = (uint32_t)D.items[(size_t)group * D.item_cap + (it < n_heavy ? it : D.item_cap - 1 - (it - n_heavy))];
+  const int c = (int)(item >> 16), g0 = (int)((item >> 8) & 0xFF), G = (int)(item & 0xFF);
   ChanCtl *ctl = D.ctl + c;
   int n = 0;
   {

@@ -33,6 +33,16 @@ typedef int Label;
 const int kNoStateId = -1;
 
 // ---- boundary A: what the decoder calls ---------------------------------------------------
+// Under -DKALDI the reference's AmInterface IS kaldi::DecodableInterface (src/itf/decodable-itf.h:
+// 55-62), so that any Kaldi decodable (nnet3 looped, DecodableMatrixScaledMapped, ...) plugs in.
+// Same switch here: -DWFST_KALDI_DECODABLE (or the reference's own -DKALDI) with Kaldi's src/ on
+// the include path.
+#if defined(WFST_KALDI_DECODABLE) || defined(KALDI)
+}  // namespace datemoon
+#include "itf/decodable-itf.h"
+namespace datemoon {
+typedef kaldi::DecodableInterface DecodableInterface;
+#else
 class DecodableInterface {
  public:
   virtual float LogLikelihood(int frame, int index) = 0;  // already scaled; the decoder negates it
@@ -41,6 +51,7 @@ class DecodableInterface {
   virtual int NumIndices() const = 0;  // indices are 1-based: 1..NumIndices()
   virtual ~DecodableInterface() {}
 };
+#endif
 typedef DecodableInterface AmInterface;
 
 // Optional fast path: a decodable that can hand over its rows in one piece (no per-element

@@ -1,11 +1,12 @@
-"""Utterance sharding across the GPUs of one node, and the one collective of the path.
+"""Utterance sharding across the GPUs of one node, and the one collective step of the path.
 
 Utterances share nothing but the read-only graph: the graph is replicated on every
-GPU, utterance u goes to rank ``u % world`` ... here in contiguous blocks (rank r decodes utterances
-[r*B, (r+1)*B)), every rank runs its own frame loop, and the only exchange is ONE gather of the
-final results per batch: an all_gather of a fixed-shape float32 tensor [B][3 + Lmax] =
-{n_words, tot_score, lm_score, word ids...} (RCCL over xGMI on GPUs -- ``nccl`` backend -- or
-``gloo`` on CPU in the tests).  Word ids are < 2^24, so float32 carries them exactly.
+GPU, rank r decodes the contiguous block of utterances [r*B, (r+1)*B), every rank runs its own frame
+loop, and the only exchange is the gather of the final results per batch (RCCL over xGMI on GPUs --
+``nccl`` backend -- or ``gloo`` on CPU in the tests): an all_gather of the fixed-shape int32 header
+[B][3] = {n_words, tot_score bits, lm_score bits}, then an all_gather of the ranks' word ids,
+concatenated and padded to the longest rank.  Nothing is truncated and nothing is converted: word
+ids and float bit patterns travel as int32.
 """
 from __future__ import annotations
 
@@ -19,45 +20,64 @@ def shard_range(rank, world, per_rank):
     return range(rank * per_rank, (rank + 1) * per_rank)
 
 
-def pack_results(results, lmax):
-    """results: list of dicts with words / tot_score / lm_score (wfstdec.BatchDecoder.best_paths)."""
-    out = np.zeros((len(results), HEADER + lmax), np.float32)
+def pack_results(results):
+    """results: list of dicts with words / tot_score / lm_score (wfstdec.BatchDecoder.best_paths).
+    Returns (header int32 [B][3], words int32 [sum of lengths])."""
+    hdr = np.zeros((len(results), HEADER), np.int32)
+    ws = []
     for i, r in enumerate(results):
-        w = np.asarray(r["words"])
-        if w.size and int(w.max()) >= (1 << 24):
-            raise ValueError("word id does not fit the float32 gather payload")
-        k = min(int(w.shape[0]), lmax)
-        out[i, 0] = int(w.shape[0])
-        out[i, 1] = r["tot_score"]
-        out[i, 2] = r["lm_score"]
-        out[i, HEADER:HEADER + k] = w[:k]
-    return out
+        w = np.asarray(r["words"], dtype=np.int64)
+        if w.size and (int(w.min()) < -(1 << 31) or int(w.max()) >= (1 << 31)):
+            raise ValueError("word id does not fit int32")
+        hdr[i, 0] = int(w.shape[0])
+        hdr[i, 1:3] = np.asarray([r["tot_score"], r["lm_score"]], np.float32).view(np.int32)
+        ws.append(w.astype(np.int32))
+    words = np.concatenate(ws) if ws else np.zeros(0, np.int32)
+    return hdr, words
 
 
-def unpack_results(packed):
-    res = []
-    for row in np.asarray(packed):
-        n = int(row[0])
-        k = min(n, row.shape[0] - HEADER)
-        res.append(dict(n_words=n, tot_score=float(row[1]), lm_score=float(row[2]),
-                        words=row[HEADER:HEADER + k].astype(np.int32)))
+def unpack_results(hdr, words):
+    """Inverse of pack_results for one or several ranks' blocks laid end to end."""
+    res, o = [], 0
+    hdr = np.asarray(hdr, np.int32)
+    sc = hdr[:, 1:3].copy().view(np.float32)
+    for i in range(hdr.shape[0]):
+        n = int(hdr[i, 0])
+        res.append(dict(n_words=n, tot_score=float(sc[i, 0]), lm_score=float(sc[i, 1]),
+                        words=np.asarray(words[o:o + n], np.int32).copy()))
+        o += n
     return res
 
 
 def gather_results(packed, device=None):
-    """all_gather the per-rank [B][3+Lmax] blocks; returns the [world*B][3+Lmax] array in global
-    utterance order (every rank gets it; rank 0 is the consumer).  No-op without a process group."""
+    """packed = pack_results(...) of this rank.  Two collectives (headers, then padded word ids);
+    returns the list of all world*B result dicts in global utterance order (every rank gets it; rank 0
+    is the consumer).  Without a process group: this rank's own results."""
     import torch
     import torch.distributed as dist
 
+    hdr, words = packed
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return np.asarray(packed)
-    t = torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float32))
+        return unpack_results(hdr, words)
+    world = dist.get_world_size()
+    th = torch.from_numpy(np.ascontiguousarray(hdr, dtype=np.int32))
     if device is not None:
-        t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
-    return torch.cat(out, dim=0).cpu().numpy()
+        th = th.to(device)
+    all_h = [torch.empty_like(th) for _ in range(world)]
+    dist.all_gather(all_h, th)
+    all_h = [t.cpu().numpy() for t in all_h]
+    pad = max(1, max(int(h[:, 0].sum()) for h in all_h))
+    mine = np.zeros(pad, np.int32)
+    mine[:words.shape[0]] = words
+    tw = torch.from_numpy(mine)
+    if device is not None:
+        tw = tw.to(device)
+    all_w = [torch.empty_like(tw) for _ in range(world)]
+    dist.all_gather(all_w, tw)
+    res = []
+    for r in range(world):
+        res.extend(unpack_results(all_h[r], all_w[r].cpu().numpy()))
+    return res
 
 
 # ---- lattices (lattice mode, SURVEY.md 8(e)): length-prefixed byte blobs -----------------------

@@ -27,6 +27,8 @@ SYMBOLS = [
     "wfst_decoder_num_frames_decoded", "wfst_decoder_get_best_path", "wfst_lattice_to_vector",
     "wfst_decoder_get_stats", "wfst_decoder_get_frontier", "wfst_decoder_set_profiling",
     "wfst_decoder_get_profile", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
+    "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
+    "wfst_decoder_create_ex",
 ]
 
 
@@ -53,6 +55,34 @@ class Config(C.Structure):
 class Limits(C.Structure):
     _fields_ = [("max_frames", C.c_int32), ("max_tokens_per_frame", C.c_int32), ("arena_tokens", C.c_int64),
                 ("lattice_links", C.c_int64)]
+
+
+class Options(C.Structure):
+    """wfst_options: scheduling choices of a decoder (never a result bit); defaults from the library."""
+
+    _fields_ = [("channel_groups", C.c_int32), ("use_hip_graph", C.c_int32), ("log2_partitions", C.c_int32),
+                ("log2_lds_slots", C.c_int32), ("joint_max", C.c_int32), ("expand_workgroups", C.c_int32),
+                ("insert_workgroups", C.c_int32), ("upload_slice_frames", C.c_int32), ("debug", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().wfst_options_default(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError("unknown wfst_options field %r" % k)
+            setattr(self, k, int(v))
+
+
+class GraphOptions(C.Structure):
+    _fields_ = [("row_align_slots", C.c_int32), ("flatten_closures", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().wfst_graph_options_default(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError("unknown wfst_graph_options field %r" % k)
+            setattr(self, k, int(v))
 
 
 _lib = None
@@ -106,20 +136,22 @@ class Graph:
         self.h = handle
 
     @staticmethod
-    def load(path, device=0):
+    def load(path, device=0, options=None):
         h = C.c_void_p()
-        _check(lib().wfst_graph_load(path.encode(), int(device), C.byref(h)))
+        _check(lib().wfst_graph_load_ex(path.encode(), int(device), C.byref(options) if options is not None else None,
+                                        C.byref(h)))
         return Graph(h)
 
     @staticmethod
-    def from_arrays(start, final_state, state_info, arcs, device=0):
+    def from_arrays(start, final_state, state_info, arcs, device=0, options=None):
         si = np.ascontiguousarray(state_info)
         ar = np.ascontiguousarray(arcs)
         assert si.dtype.itemsize == 12 and ar.dtype.itemsize == 16
         h = C.c_void_p()
-        _check(lib().wfst_graph_from_arrays(int(start), int(final_state), int(si.shape[0]), int(ar.shape[0]),
-                                            si.ctypes.data_as(C.c_void_p), ar.ctypes.data_as(C.c_void_p),
-                                            int(device), C.byref(h)))
+        _check(lib().wfst_graph_from_arrays_ex(int(start), int(final_state), int(si.shape[0]), int(ar.shape[0]),
+                                               si.ctypes.data_as(C.c_void_p), ar.ctypes.data_as(C.c_void_p),
+                                               int(device), C.byref(options) if options is not None else None,
+                                               C.byref(h)))
         return Graph(h)
 
     def set_tid2pdf(self, tid2pdf):
@@ -142,13 +174,14 @@ class BatchDecoder:
     """A batch of decoding channels (one channel == one reference decoder object)."""
 
     def __init__(self, graph, cfg, n_channels, max_frames=0, max_tokens_per_frame=0, arena_tokens=0, stream=None,
-                 lattice_links=0):
+                 lattice_links=0, options=None):
         self.graph = graph
         self.n = int(n_channels)
         lim = Limits(int(max_frames), int(max_tokens_per_frame), int(arena_tokens), int(lattice_links))
         h = C.c_void_p()
-        _check(lib().wfst_decoder_create(graph.h, C.byref(cfg), self.n, C.byref(lim),
-                                         C.c_void_p(stream) if stream else None, C.byref(h)))
+        _check(lib().wfst_decoder_create_ex(graph.h, C.byref(cfg), self.n, C.byref(lim),
+                                            C.byref(options) if options is not None else None,
+                                            C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
 
     def free(self):

@@ -2,20 +2,26 @@
 """Headline benchmark: frames/s decoded by the MI355X WFST token-passing decoder.
 
 Workload = BASELINE.json configs[1] ("1xMI355X, batch=128 utterances, ~10M-arc HCLG, beam=13,
-precomputed nnet3 log-likelihoods"), generated as SURVEY.md section 8(d) prescribes: synthetic
-"hclg-like" graph (2.85M states / ~10.1M arcs, seed 7), float32[300][3000] log-likelihoods per
-utterance (seed = global utterance index), beam 13 with the reference service's max-active 7000 /
-min-active 200.  One "step" = one pass of the hot path over one batch: InitDecoding ->
-AdvanceDecoding(all frames) -> FinalizeDecoding -> GetBestPath + LatticeToVector for every
-utterance (reference call sequence kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:97-129).
-Log-likelihoods are resident in HBM before the timed region starts.
+precomputed nnet3 log-likelihoods"): synthetic "hclg-like" graph of SURVEY.md section 8(d) (2.85M
+states / ~10.1M arcs, seed 7), float32[300][3000] log-likelihoods per utterance (seed = global
+utterance index).  HEADLINE = beam-only pruning (beam 13, max_active never binding, min_active 0:
+the regime where the result is bit-identical to the reference CPU decoder) on log-likelihoods with
+272 live hypotheses per utterance (synth.make_loglikes_multi; why not the single planted path:
+DESIGN.md section 5).  The line also carries `service_point`: the section-8(d) single-planted-path
+generator at the reference service's max_active 7000 / min_active 200, with the word-level
+divergence of the GPU result from the reference decoder's own over the whole batch.
+
+One "step" = one pass of the hot path over one batch: InitDecoding -> AdvanceDecoding(all frames)
+-> FinalizeDecoding -> GetBestPath + LatticeToVector for every utterance (reference call sequence
+kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:97-129).  Log-likelihoods are resident in HBM before the
+timed region starts.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: utterances shard embarrassingly (128 per GPU, graph replicated, weak scaling); the only
-collective is one RCCL all_gather of the padded word-id results per step.
-Rank 0 prints ONE JSON line (metric, roofline, cpu_baseline).
+collective is the gather of the final word-id results per step (RCCL).
+Rank 0 prints ONE JSON line (metric, roofline, cpu_baseline, service_point).
 """
 import argparse
 import importlib
@@ -65,8 +71,12 @@ def parse():
                     "(capacity per utterance), prune by lattice_beam at finalize; the step then also takes the n-best")
     ap.add_argument("--lattice-beam", type=float, default=7.0)
     ap.add_argument("--nbest", type=int, default=5, help="n of the n-best taken per utterance in lattice mode")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances timed on the host cores (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(sample, host cores)")
+    ap.add_argument("--no-hip-graph", action="store_true", help="enqueue the frame loop kernel by kernel (rocprofv3 --pmc passes)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances checked bit for bit against the CPU decoder (0 = skip "
+                    "the CPU legs: parity sample, cpu_baseline, service_point divergence)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of each timed CPU-baseline leg (1 thread, all cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores leg (0 = every CPU this process may run on)")
+    ap.add_argument("--no-service-point", action="store_true", help="skip the second workload (single planted path, 7000/200)")
     ap.add_argument("--graph-cache", default="/tmp/wfst_bench_graph_%d.bin")
     return ap.parse_args()
 
@@ -82,19 +92,42 @@ def make_utts(synth, g, m, first, count, T, P, a):
     return out
 
 
-def cpu_baseline(graph_path, cd, mats, m, n_threads):
-    """Time the CPU decoder on a bounded sample: the UNMODIFIED reference (oracle/_ref, kind
-    "reference") when its prebuilt library is present, else our C restatement (kind "port").
-    One decoder object per thread over one shared read-only graph -- the reference service's
-    threading model (v2-asrbin/v2-asr-service.cc:95-105)."""
+def affinity_cpus():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_decoder():
+    """The CPU checker / baseline: the UNMODIFIED reference (oracle/_ref, kind "reference") when its
+    prebuilt library is present, else our C restatement (kind "port")."""
     import pyoracle
 
-    kind = "reference" if os.path.exists(pyoracle.REF_SO) else "port"
-    if kind == "reference":
-        dec = pyoracle.RefDecoder()
-    else:
-        pyoracle.build_oracle()
-        dec = pyoracle.OracleDecoder()
+    if os.path.exists(pyoracle.REF_SO):
+        return "reference", pyoracle.RefDecoder()
+    pyoracle.build_oracle()
+    return "port", pyoracle.OracleDecoder()
+
+
+class quiet_stderr:
+    """silence the reference's LOG_COM chatter on stderr"""
+
+    def __enter__(self):
+        self.saved = os.dup(2)
+        self.devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self.devnull, 2)
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 2)
+        os.close(self.saved)
+        os.close(self.devnull)
+
+
+def cpu_decode_all(dec, graph_path, cd, mats, m, n_threads):
+    """Decode every matrix once on n_threads host threads (results for parity / divergence)."""
+    import pyoracle
+
     h = dec.load_graph(graph_path)
     cfg = pyoracle.Config(**cd)
     results = [None] * len(mats)
@@ -110,23 +143,78 @@ def cpu_baseline(graph_path, cd, mats, m, n_threads):
                 return
             results[i] = dec.decode(h, cfg, mats[i], m)
 
-    # silence the reference's LOG_COM chatter on stderr during the timed part
-    saved = os.dup(2)
-    devnull = os.open(os.devnull, os.O_WRONLY)
-    os.dup2(devnull, 2)
-    try:
+    with quiet_stderr():
+        th = [threading.Thread(target=work) for _ in range(max(1, min(n_threads, len(mats))))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    dec.free_graph(h)
+    return results
+
+
+def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds):
+    """frames/s of the CPU decoder: n_threads host threads, ONE decoder object per thread over one
+    shared read-only graph -- the reference service's threading model (v2-asrbin/v2-asr-service.cc:
+    95-105) -- each looping over the batch's utterances (thread t takes t, t + n_threads, ...) for
+    `seconds` of wall time (ref_timed_loop / oracle_timed_loop).  Returns (frames/s, wall s, frames)."""
+    import ctypes as C
+
+    import pyoracle
+
+    h = dec.load_graph(graph_path)
+    cfg = pyoracle.Config(**cd)
+    f = getattr(dec.lib, ("ref" if kind == "reference" else "oracle") + "_timed_loop")
+    f.restype = C.c_longlong
+    keep = [np.ascontiguousarray(x, np.float32) for x in mats]
+    ptrs = (C.c_void_p * len(keep))(*[x.ctypes.data for x in keep])
+    Ts = np.asarray([x.shape[0] for x in keep], np.int32)
+    stride = int(keep[0].shape[1])
+    mm = np.ascontiguousarray(m, np.int32)
+    frames = [0] * n_threads
+
+    def work(t):
+        el, nw = C.c_double(0), C.c_longlong(0)
+        frames[t] = f(C.c_void_p(h), C.byref(cfg), ptrs, Ts.ctypes.data_as(C.POINTER(C.c_int)), len(keep), stride,
+                      mm.ctypes.data_as(C.POINTER(C.c_int)), int(mm.shape[0] - 1), t, n_threads, C.c_double(seconds),
+                      C.byref(el), C.byref(nw))
+
+    with quiet_stderr():
         t0 = time.perf_counter()
-        th = [threading.Thread(target=work) for _ in range(n_threads)]
+        th = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
         [t.start() for t in th]
         [t.join() for t in th]
         dt = time.perf_counter() - t0
-    finally:
-        os.dup2(saved, 2)
-        os.close(saved)
-        os.close(devnull)
     dec.free_graph(h)
-    frames = sum(int(x.shape[0]) for x in mats)
-    return kind, frames / dt, dt, results
+    return sum(frames) / dt, dt, sum(frames)
+
+
+def edit_distance(a, b):
+    """word-level Levenshtein distance (what nbest-compute-wer counts, kaldi-bin/bin)"""
+    a, b = list(a), list(b)
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+def divergence(gpu_res, cpu_res):
+    """GPU results vs the CPU decoder's own, utterance by utterance."""
+    n = len(gpu_res)
+    ident = errs = nref = same_words = 0
+    gap = 0.0
+    for r, o in zip(gpu_res, cpu_res):
+        same = (np.array_equal(o.words, r["words"]) and np.array_equal(o.tids, r["tids"]) and
+                np.float32(o.tot_score).tobytes() == np.float32(r["tot_score"]).tobytes())
+        ident += int(same)
+        same_words += int(np.array_equal(o.words, r["words"]))
+        errs += edit_distance(o.words, r["words"])
+        nref += len(o.words)
+        if o.ok and r["ok"] and o.tot_score != 0:
+            gap = max(gap, abs(r["tot_score"] - o.tot_score) / abs(o.tot_score))
+    return {"utterances": n, "bit_identical": ident, "same_words": same_words, "word_errors": errs, "ref_words": nref,
+            "wer": errs / float(max(nref, 1)), "max_rel_cost_gap": gap}
 
 
 def oracle_counts(graph_path, cd, mats, m, order_free=False, want_paths=None):
@@ -188,8 +276,6 @@ def main():
     a = parse()
     if a.mu is None:
         a.mu = -4.0 if a.workload == "multi" else -2.0
-    if a.groups > 0:
-        os.environ["WFST_GROUPS"] = str(a.groups)  # read by wfst_decoder_create
     import torch
     import torch.distributed as dist
 
@@ -248,41 +334,48 @@ def main():
     graph = wfstdec.Graph.from_arrays(g.start, g.final_state, g.state_info, g.arcs, device=local_rank)
     graph.set_tid2pdf(m)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    dec = wfstdec.BatchDecoder(graph, wfstdec.Config(**cd), B, max_frames=T + 2, max_tokens_per_frame=131072,
-                               arena_tokens=int(T * a.arena_per_frame), stream=stream, lattice_links=a.lattice_links)
-    ptrs = [ll_dev[i].data_ptr() for i in range(B)]
-    host_rows = [mats[i] for i in range(B)]
-    ready = [T] * B
-    Lmax = 64
+    opt = wfstdec.Options(use_hip_graph=0 if a.no_hip_graph else 1, **({"channel_groups": a.groups} if a.groups > 0 else {}))
 
+    def new_decoder(cfg_dict):
+        return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=131072,
+                                    arena_tokens=int(T * a.arena_per_frame), stream=stream, lattice_links=a.lattice_links,
+                                    options=opt)
+
+    dec = new_decoder(cd)
+    ready = [T] * B
     tb = {"init": 0.0, "advance_enqueue": 0.0, "finalize": 0.0, "sync": 0.0, "best_paths": 0.0, "n": 0}
 
-    def step():
-        t0 = time.perf_counter()
-        dec.init()
-        t1 = time.perf_counter()
-        if a.host_feed:
-            dec.advance_host(host_rows, ready)
-        else:
-            dec.advance(ptrs, ready, P)
-        t2 = time.perf_counter()
-        dec.finalize()
-        t3 = time.perf_counter()
-        if os.environ.get("WFST_BENCH_BREAKDOWN"):
-            dec.sync()
-        t4 = time.perf_counter()
-        res = dec.best_paths(cap=2 * T + 64)
-        if a.lattice_links > 0:
-            nb = dec.nbest(a.nbest)
-            for r, paths in zip(res, nb):
-                r["nbest"] = paths
-        t5 = time.perf_counter()
-        for k, v in zip(("init", "advance_enqueue", "finalize", "sync", "best_paths"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
-            tb[k] += v
-        tb["n"] += 1
-        if world > 1:  # the path's only collective: gather the final results (RCCL all_gather)
-            shard.gather_results(shard.pack_results(res, Lmax), device=None if share else dev)
-        return res
+    def make_step(dec, ll_dev, host_rows):
+        ptrs = [ll_dev[i].data_ptr() for i in range(B)]
+
+        def step():
+            t0 = time.perf_counter()
+            dec.init()
+            t1 = time.perf_counter()
+            if a.host_feed:
+                dec.advance_host(host_rows, ready)
+            else:
+                dec.advance(ptrs, ready, P)
+            t2 = time.perf_counter()
+            dec.finalize()
+            t3 = time.perf_counter()
+            if os.environ.get("WFST_BENCH_BREAKDOWN"):
+                dec.sync()
+            t4 = time.perf_counter()
+            res = dec.best_paths(cap=2 * T + 64)
+            if a.lattice_links > 0:
+                nb = dec.nbest(a.nbest)
+                for r, paths in zip(res, nb):
+                    r["nbest"] = paths
+            t5 = time.perf_counter()
+            for k, v in zip(("init", "advance_enqueue", "finalize", "sync", "best_paths"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                tb[k] += v
+            tb["n"] += 1
+            if world > 1:  # the path's only collective: gather the final results (RCCL)
+                shard.gather_results(shard.pack_results(res), device=None if share else dev)
+            return res
+
+        return step
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -290,18 +383,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        res = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        res = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(step, warmup, steps):
+        res = None
+        for _ in range(warmup):
+            res = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, res
+
+    step = make_step(dec, ll_dev, [mats[i] for i in range(B)])
+    dt, res = timed(step, a.warmup, a.steps)
     frames_total = world * B * T * a.steps
     value = frames_total / dt
     if os.environ.get("WFST_BENCH_BREAKDOWN"):
@@ -314,13 +413,17 @@ def main():
     prof = dec.profile()
     dec.set_profiling(False)
 
+    regime = ("beam-only pruning (max_active never binds, min_active 0): bit-exact best-path parity with the reference CPU decoder"
+              if a.max_active >= 1000000 and a.min_active == 0 else
+              "max_active %d / min_active %d: where they bind the reference's cutoff depends on its hash-list visiting order "
+              "(order-free parity, DESIGN.md section 4)" % (a.max_active, a.min_active))
     out = {
-        "metric": ("frames/sec decoded, log-likelihoods handed over as HOST matrices every step (PCIe-inclusive), best-path "
-                   "parity with the reference CPU decoder" if a.host_feed else
-                   "frames/sec decoded (RTFx = value/100) at fixed beam, best-path parity with the reference CPU decoder"
+        "metric": ("frames/sec decoded, log-likelihoods handed over as HOST matrices every step (PCIe-inclusive); " + regime
+                   if a.host_feed else
+                   "frames/sec decoded (RTFx = value/100) at fixed beam; " + regime
                    if a.lattice_links == 0 else
                    "frames/sec decoded WITH lattice generation (forward links, lattice-beam pruning at finalize, %d-best per "
-                   "utterance; BASELINE configs[4]), best-path parity with the reference CPU decoder" % a.nbest),
+                   "utterance; BASELINE configs[4]); " % a.nbest + regime),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded hclg-like graph + %s log-likelihoods, SURVEY.md 8(d))" % (
@@ -330,7 +433,7 @@ def main():
                         "max_active=%d, min_active=%d, %d pdfs" % (B, T, g.n_arcs, a.beam, a.max_active, a.min_active, P),
             "global_batch": world * B, "frames_per_utt": T, "parallelism": "utterance-sharded x%d (graph replicated)" % world,
             "rtfx": value / 100.0,
-            "channel_groups": int(os.environ.get("WFST_GROUPS", "1")),
+            "channel_groups": int(opt.channel_groups),
         },
     }
     if rank == 0:
@@ -342,19 +445,18 @@ def main():
         out["config"]["mean_expanded_tokens_per_frame"] = N / float(B * T)
         # ---- CPU baseline + live parity on a bounded sample ---------------------------------
         scale = 1.0
-        if a.cpu_sample > 0 and world == 1:  # the CPU baseline is reported at N=1 only
+        cpus = affinity_cpus()
+        do_cpu = a.cpu_sample > 0 and world == 1  # the CPU legs are reported at N=1 only
+        if do_cpu:
             ns = min(a.cpu_sample, B)
-            nth = a.cpu_threads or min(ns, os.cpu_count() or 1)
+            nth = a.cpu_threads or cpus
+            kind, cdec = cpu_decoder()
             sample = [mats[i] for i in range(ns)]
-            kind, fps, cdt, cres = cpu_baseline(gpath, cd, sample, m, nth)
-            exact = 0
-            for i in range(ns):
-                o, r = cres[i], res[i]
-                if (np.array_equal(o.words, r["words"]) and np.array_equal(o.tids, r["tids"]) and
-                        np.float32(o.tot_score).tobytes() == np.float32(r["tot_score"]).tobytes()):
-                    exact += 1
-            # one thread, two utterances: the per-core rate (SURVEY.md 8(d) asks for both)
-            _, fps1, cdt1, _ = cpu_baseline(gpath, cd, sample[:2], m, 1)
+            cres = cpu_decode_all(cdec, gpath, cd, sample, m, min(ns, cpus))
+            dv = divergence(res[:ns], cres)
+            # timed legs: one thread, then every CPU this process may run on
+            fps1, cdt1, fr1 = cpu_timed(kind, cdec, gpath, cd, list(mats), m, 1, a.cpu_seconds)
+            fps, cdt, fr = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nth, a.cpu_seconds)
             cpu_model = ""
             try:
                 with open("/proc/cpuinfo") as f:
@@ -363,13 +465,14 @@ def main():
                 pass
             out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": nth, "kind": kind,
                                    "single_thread_value": fps1, "cpu_model": cpu_model,
-                                   "sample": "%d of the %d utterances of rank 0 (%d frames), %.1fs wall on %d host threads, "
-                                             "one decoder object per thread over one shared graph" % (ns, B, ns * T, cdt, nth),
-                                   "host_cpus": os.cpu_count()}
+                                   "sample": "the %d utterances of rank 0, each of %d host threads (one decoder object per thread "
+                                             "over one shared graph) looping over them for %.1fs wall: %d frames decoded; "
+                                             "single thread: %d frames in %.1fs" % (B, nth, cdt, fr, fr1, cdt1),
+                                   "affinity_cpus": cpus, "host_cpus": os.cpu_count()}
             out["config"]["parity"] = "%d/%d sampled utterances bit-exact (words, transition-ids, tot_score) vs the %s CPU decoder" % (
-                exact, ns, "reference" if kind == "reference" else "oracle")
+                dv["bit_identical"], ns, "reference" if kind == "reference" else "oracle")
             oc = oracle_counts(gpath, cd, sample, m)
-            if exact < ns:
+            if dv["bit_identical"] < ns:
                 # where max_active / min_active bind, the reference's cutoff depends on tokens it
                 # keeps in hash-list visiting order; the order-independent restatement of the same
                 # algorithm (oracle, order-free mode) is what the GPU must equal bit for bit
@@ -378,6 +481,7 @@ def main():
                 ex2 = sum(1 for i in range(ns) if np.array_equal(paths[i][0], res[i]["tids"]) and
                           np.float32(paths[i][1]).tobytes() == np.float32(res[i]["tot_score"]).tobytes())
                 out["config"]["parity"] += "; %d/%d bit-exact vs the oracle in order-free mode" % (ex2, ns)
+                out["config"]["divergence_vs_%s_sample" % kind] = dv
             gs = {k: sum(gstats[i][k] for i in range(ns)) for k in ("N", "E", "Z")}
             out["config"]["work_counts_sample"] = {"oracle": oc, "gpu": gs}
             # algorithmic bytes from the CPU restatement's counts, scaled from the sample to the batch
@@ -395,21 +499,61 @@ def main():
         avg_ms = k_ms / max(k_n, 1)
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         all_ms = prof["expand_ms"] + prof["insert_ms"] + prof["closure_ms"]
-        traffic = None
+        # HBM traffic per launch comes from rocprofv3 --pmc passes (separate runs, tools/profile_round.sh);
+        # it cannot be collected inside this process, so the stored summary is quoted WITH its origin
+        traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(dom + "_bytes_per_launch")
+                tjd = json.load(open(tj))
+                traffic = tjd.get(dom + "_bytes_per_launch")
+                traffic_src = "NOT measured in this run: profiles/traffic_latest.json (%s)" % tjd.get("origin", tjd.get("note", "stored rocprofv3 --pmc passes"))
             except Exception:
                 traffic = None
+        step_ms = 1000.0 * dt / a.steps
+        whole_bytes = sum(kb.values())
         out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
                            "kernel_ms_per_step": {k: prof[k + "_ms"] for k in ("expand", "insert", "closure")},
-                           "all_kernels_achieved_GBs": (sum(kb.values()) / (all_ms * 1e-3) / 1e9) if all_ms > 0 else 0.0,
+                           "all_kernels_achieved_GBs": (whole_bytes / (all_ms * 1e-3) / 1e9) if all_ms > 0 else 0.0,
+                           "whole_path": {"algorithmic_bytes_per_step": whole_bytes,
+                                          "formula": "28 E + 24 N + 24 Z (SURVEY.md 8(d)), counts of one step of this rank",
+                                          "frac_over_kernel_time": (whole_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms > 0 else 0.0,
+                                          "frac_over_step_time": whole_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                            "measured": "hipEvent pairs around every launch on the decoder's stream, one extra step after the timed region"}
+    # ---- second workload: SURVEY 8(d) generator at the reference service's operating point ----
+    if rank == 0 and world == 1 and not a.no_service_point and a.lattice_links == 0 and not a.host_feed and a.workload == "multi":
+        dec.free()
+        dec = None
+        del ll_dev
+        sa = argparse.Namespace(**vars(a))
+        sa.workload, sa.mu = "single", -2.0
+        t0 = time.time()
+        mats2 = make_utts(synth, g, m, 0, B, T, P, sa)
+        ll2 = torch.from_numpy(mats2).to(dev)
+        cd2 = dict(cd, max_active=7000, min_active=200)
+        dec = new_decoder(cd2)
+        step2 = make_step(dec, ll2, [mats2[i] for i in range(B)])
+        dt2, res2 = timed(step2, 1, max(2, a.steps // 4))
+        n2 = max(2, a.steps // 4)
+        sp = {"workload": "SURVEY.md 8(d) single-planted-path log-likelihoods (mu -2, sigma 1), same graph and batch, beam=%g, "
+                          "max_active=7000, min_active=200 (v1-asrbin/conf/decoder.conf:4-8)" % a.beam,
+              "value": B * T * n2 / dt2, "unit": "frames/s", "ms_per_step": 1000.0 * dt2 / n2, "steps": n2,
+              "mean_active_tokens_per_frame": sum(dec.stats(c)["tokens"] for c in range(B)) / float(B * (T + 1))}
+        if a.cpu_sample > 0:
+            kind, cdec = cpu_decoder()
+            cres2 = cpu_decode_all(cdec, gpath, cd2, list(mats2), m, affinity_cpus())
+            sp["divergence_vs_" + kind] = divergence(res2, cres2)
+            sp["divergence_note"] = ("where max_active/min_active bind, the reference's cutoff depends on its hash-list visiting "
+                                     "order (DESIGN.md section 4, deviation 2): word-level agreement is the claim here, not bits")
+        out["service_point"] = sp
+        log("[rank 0] service point: %.1fs" % (time.time() - t0))
+        del ll2
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    dec.free()
+    if dec is not None:
+        dec.free()
     graph.free()
     if world > 1:
         dist.barrier()

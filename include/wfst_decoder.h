@@ -66,11 +66,36 @@ typedef struct wfst_limits {
                                    GetRawLattice can be served; 0 (default): best path only        */
 } wfst_limits;
 
+/* Scheduling choices of a decoder (NULL / wfst_options_default() = the measured defaults).  None of
+ * them changes a result bit; they replace what a CPU decoder has no use for.  Values out of range are
+ * WFST_E_ARG.  (The library reads no environment variables.) */
+typedef struct wfst_options {
+  int32_t channel_groups;      /* 1..8: channel groups, each with its own stream and hipGraph  (1)    */
+  int32_t use_hip_graph;       /* replay the frame loop of an advance call as a hipGraph        (1)    */
+  int32_t log2_partitions;     /* 0..6: hash partitions (candidate buckets) per channel         (5)    */
+  int32_t log2_lds_slots;      /* 8..13: LDS hash slots of one insert workgroup                 (12)   */
+  int32_t joint_max;           /* records a group of partitions may hold to share a workgroup   (1536) */
+  int32_t expand_workgroups;   /* grid of the expansion kernel                                  (2048) */
+  int32_t insert_workgroups;   /* grid of the insert kernel                                     (768)  */
+  int32_t upload_slice_frames; /* wfst_decoder_advance_host: frames per upload slice, 0 = copy
+                                  everything before decoding                                    (48)   */
+  int32_t debug;               /* kernel phase timers / ablations: timing experiments only      (0)    */
+} wfst_options;
+
+/* Graph upload choices (NULL / wfst_graph_options_default() = defaults). */
+typedef struct wfst_graph_options {
+  int32_t row_align_slots;     /* rows are placed so that they touch as few lines of this many 16-byte
+                                  slots as possible; 1 = packed                                 (4)    */
+  int32_t flatten_closures;    /* precompute each state's whole epsilon closure (<= 4 paths)     (1)    */
+} wfst_graph_options;
+
 /* Original on-disk / in-memory graph records of the reference format. */
 typedef struct wfst_arc { int32_t ilabel, olabel; float weight; int32_t nextstate; } wfst_arc;   /* StdArc, newfst/arc.h:17-26 */
 typedef struct wfst_state_info { uint32_t num_arcs, niepsilons, noepsilons; } wfst_state_info;   /* Fst::StateInfo, newfst/optimize-fst.h:220-225 */
 
 void wfst_config_default(wfst_config *cfg);
+void wfst_options_default(wfst_options *opt);
+void wfst_graph_options_default(wfst_graph_options *opt);
 const char *wfst_last_error(void);
 int wfst_device_count(void);
 
@@ -86,6 +111,7 @@ int wfst_device_count(void);
  * (final weight on a leading <eps>:<eps> arc to one extra state).  WFST_E_FORMAT for embedded
  * symbol tables, non-"standard" arcs or other fst types (the reference readers misread those). */
 int wfst_graph_load(const char *path, int device, wfst_graph **out);
+int wfst_graph_load_ex(const char *path, int device, const wfst_graph_options *opt, wfst_graph **out);
 
 /* convert_fst IN OUT (fst_format_convert_tool/convert_fst.c:5-27): read a graph file in any format
  * wfst_graph_load takes and write the flat format.  Host only -- needs no device. */
@@ -98,6 +124,9 @@ int wfst_graph_convert_file(const char *in_path, const char *flat_out_path);
 int wfst_graph_from_arrays(int32_t start, int32_t final_state, int32_t n_states, int32_t n_arcs,
                            const wfst_state_info *states, const wfst_arc *arcs, int device,
                            wfst_graph **out);
+int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_states, int32_t n_arcs,
+                              const wfst_state_info *states, const wfst_arc *arcs, int device,
+                              const wfst_graph_options *opt, wfst_graph **out);
 
 /* Optional transition-id -> pdf map (Kaldi DecodableMatrixScaledMapped as used by
  * kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:107; hmm/transition-model.h:52-61):
@@ -116,6 +145,10 @@ void wfst_graph_free(wfst_graph *g);
  * (NULL = a stream owned by the decoder); all work is enqueued on it. */
 int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
                         const wfst_limits *limits, void *hip_stream, wfst_decoder **out);
+/* Same with explicit scheduling options (at most 32767 channels per decoder). */
+int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
+                           const wfst_limits *limits, const wfst_options *options, void *hip_stream,
+                           wfst_decoder **out);
 void wfst_decoder_free(wfst_decoder *d);
 
 /* InitDecoding() (base-inl.h:40-67) for the listed channels (channels == NULL: all). */

@@ -18,6 +18,7 @@
 //
 // Never shipped, never imported by the product; `oracle/_ref/` is git-ignored.
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -202,6 +203,50 @@ int ref_decode(void *gp, const RefConfig *rc, const float *loglikes, int T, int 
   for (int i = 0; i < (int)w.size() && i < max_words; ++i) words[i] = w[i];
   for (int i = 0; i < (int)p.size() && i < max_tids; ++i) tids[i] = p[i];
   return 1;
+}
+
+// CPU baseline leg of bench.py: ONE reference decoder object (as one worker thread of the service
+// holds, v2-asr/v2-asr-work-thread.h:66) decodes utterances mats[first], mats[first + step], ...
+// (wrapping around n_mats) with the offline CLI's call sequence (kaldi-hclg-my-decoder.cc:97-129:
+// InitDecoding, AdvanceDecoding, FinalizeDecoding, GetBestPath, LatticeToVector) until `seconds`
+// of wall time have passed; an utterance in flight at the deadline is finished and counted.
+// Returns the frames decoded; *elapsed = this thread's own wall time.  bench.py runs one such
+// loop per host thread over one shared graph.
+long long ref_timed_loop(void *gp, const RefConfig *rc, const float *const *mats, const int *T,
+                         int n_mats, int stride, const int *tid2pdf, int n_tid, int first, int step,
+                         double seconds, double *elapsed, long long *words_out) {
+  Fst *g = static_cast<Fst *>(gp);
+  LatticeFasterDecoderConfig cfg;
+  cfg._beam = rc->beam;
+  cfg._max_active = rc->max_active;
+  cfg._min_active = rc->min_active;
+  cfg._lattice_beam = rc->lattice_beam;
+  cfg._prune_interval = rc->prune_interval;
+  cfg._beam_delta = rc->beam_delta;
+  cfg._hash_ratio = rc->hash_ratio;
+  cfg._prune_scale = rc->prune_scale;
+  ProbeDecoder dec(g, cfg);
+  long long frames = 0, nwords = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  double dt = 0.0;
+  for (int i = first % n_mats;; i = (i + step) % n_mats) {
+    MatrixDecodable decodable(mats[i], T[i], stride, tid2pdf, n_tid);
+    dec.InitDecoding();
+    dec.AdvanceDecoding(&decodable);
+    dec.FinalizeDecoding();
+    Lattice best_path;
+    if (dec.GetBestPath(&best_path, true)) {
+      std::vector<int> w, p;
+      float tot = 0, lm = 0;
+      if (LatticeToVector(best_path, w, p, tot, lm)) nwords += (long long)w.size();
+    }
+    frames += T[i];
+    dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (dt >= seconds) break;
+  }
+  if (elapsed) *elapsed = dt;
+  if (words_out) *words_out = nwords;
+  return frames;
 }
 
 // Decode one utterance (one AdvanceDecoding over all frames + FinalizeDecoding when do_finalize)

@@ -18,7 +18,9 @@
  * /root/reference/src.  Float arithmetic is single precision, left to right,
  * no contraction (reference: -O2 -msse2, configure.ac:12-13).
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -771,4 +773,32 @@ int oracle_decode(void *gp, const Config *rc, const float *loglikes, int T, int 
                           n_path, tot_score, lm_score, words, max_words, n_words, tids, max_tids,
                           n_tids, frame_ntoks, frame_best, dump_frame, dump_states, dump_costs,
                           dump_cap, dump_n, num_toks_end, num_links_end, NULL);
+}
+
+/* CPU baseline leg of bench.py where the prebuilt reference library is absent ("port"): same
+ * contract as ref_timed_loop() in oracle/ref_driver.cc -- decode mats[first], mats[first+step], ...
+ * (wrapping) until `seconds` of wall time have passed; returns the frames decoded. */
+long long oracle_timed_loop(void *gp, const Config *rc, const float *const *mats, const int *T, int n_mats,
+                            int stride, const int *tid2pdf, int n_tid, int first, int step, double seconds,
+                            double *elapsed, long long *words_out) {
+  long long frames = 0, nwords = 0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  double dt = 0.0;
+  for (int i = first % n_mats;; i = (i + step) % n_mats) {
+    const int mp = 4 * T[i] + 64;
+    int *ib = (int *)malloc(sizeof(int) * 4 * (size_t)mp);
+    float *fb = (float *)malloc(sizeof(float) * 2 * (size_t)mp);
+    int np = 0, nw = 0, nt = 0, a = 0, b = 0; float tot = 0, lm = 0;
+    oracle_decode_ex(gp, rc, mats[i], T[i], stride, tid2pdf, n_tid, 0, 1, 1, ib, ib + mp, fb, fb + mp, mp, &np, &tot, &lm,
+                     ib + 2 * mp, mp, &nw, ib + 3 * mp, mp, &nt, NULL, NULL, -1, NULL, NULL, 0, NULL, &a, &b, NULL);
+    free(ib); free(fb);
+    nwords += nw; frames += T[i];
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (dt >= seconds) break;
+  }
+  if (elapsed) *elapsed = dt;
+  if (words_out) *words_out = nwords;
+  return frames;
 }

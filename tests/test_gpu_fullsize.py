@@ -44,16 +44,22 @@ def test_batch128_parity_sample_and_properties(big, oracle):
     cfg = pyoracle.Config(**CD)
     with ThreadPoolExecutor(max_workers=max(1, min(64, os.cpu_count() or 1))) as ex:
         outs = list(ex.map(lambda u: oracle.decode(h, cfg, big["mats"][u], big["m"]), range(big["B"])))
-    n_exact = 0
+    n_tied = 0
     for u, o in enumerate(outs):
         if o.extra["ties"] == 0:
             G.assert_same_as_oracle(res[u], o, "utt %d" % u)
-            n_exact += 1
+        else:
+            # an exact float tie ON the best path: the reference keeps the first arrival in its hash-list
+            # order, the GPU the lowest arc index (deviation 3).  Both paths are
+            # optimal: same length, total within north_star's 1e-4 (the hop sums differ in rounding only)
+            n_tied += 1
+            assert res[u].ok and len(res[u].tids) == len(o.tids), u
+            assert abs(res[u].tot_score - o.tot_score) <= 1e-4 * abs(o.tot_score), u
         # GPU work counters use the reference loop's definitions: they may only fall short by the
         # few order-dependent extras the reference expands at exact-equality cutoffs
         assert abs(res[u].stats["N"] - o.extra["N"]) <= 1e-3 * o.extra["N"]
         assert abs(res[u].stats["E"] - o.extra["E"]) <= 1e-3 * o.extra["E"]
-    assert n_exact >= big["B"] - 2
+    assert n_tied == 0, "%d utterances with an exact cost tie on the best path (none seen so far on these seeds)" % n_tied
     oracle.free_graph(h)
     # determinism: a second run gives the same bits
     res2 = G.decode_batch(big["graph"], CD, big["mats"], limits=LIM)
@@ -74,8 +80,8 @@ def test_batch128_parity_sample_and_properties(big, oracle):
         assert w.tot_score <= nr.tot_score * (1 + 1e-6)
     h = oracle.load_graph(big["path"])
     o = oracle.decode(h, pyoracle.Config(**dict(CD, beam=15.0)), big["mats"][pick[0]], big["m"], finalize=False, use_final_probs=False)
-    if o.extra["ties"] == 0:
-        G.assert_same_as_oracle(wide[0], o, "beam 15")
+    assert o.extra["ties"] == 0
+    G.assert_same_as_oracle(wide[0], o, "beam 15")
     oracle.free_graph(h)
 
 
@@ -158,8 +164,8 @@ def test_config5_beam15_lattice_and_nbest_sample(big, oracle, refdec, tmp_path):
     try:
         for u in (3, 12):
             r = oracle.decode(h, pyoracle.Config(**cd), mats[u], big["m"])
-            if r.extra["ties"] == 0:
-                assert np.array_equal(best[u]["words"], r.words) and np.array_equal(best[u]["tids"], r.tids)
+            assert r.extra["ties"] == 0
+            assert np.array_equal(best[u]["words"], r.words) and np.array_equal(best[u]["tids"], r.tids)
             oracle.set_order_free(True)
             O = pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**cd), mats[u], big["m"])
             oracle.set_order_free(False)
@@ -174,3 +180,36 @@ def test_config5_beam15_lattice_and_nbest_sample(big, oracle, refdec, tmp_path):
     finally:
         oracle.set_order_free(False)
         oracle.free_graph(h)
+
+
+def test_service_operating_point_divergence_from_the_reference(big, synth, refdec, capsys):
+    """max_active 7000 / min_active 200 (the reference service's own configuration,
+    v1-asrbin/conf/decoder.conf:4-8) on the 10 M-arc graph, all 128 utterances, SURVEY 8(d)
+    single-planted-path log-likelihoods: where the limits bind the reference's cutoff depends on its
+    hash-list visiting order (deviation 2), so bits may differ -- WORDS must not,
+    beyond a measured bound.  Checked against the reference decoder ITSELF (oracle/_ref)."""
+    import os
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import divergence
+
+    G = big["G"]
+    cd = dict(beam=13.0, max_active=7000, min_active=200, lattice_beam=7.0)
+    mats = [synth.make_loglikes(big["g"], big["T"], 3000, big["m"], seed=u, mu=-2.0, sigma=1.0)[0] for u in range(big["B"])]
+    res = G.decode_batch(big["graph"], cd, mats, limits=LIM)
+    h = refdec.load_graph(big["path"])
+    cfg = pyoracle.Config(**cd)
+    n_thr = max(1, min(64, len(os.sched_getaffinity(0))))
+    with ThreadPoolExecutor(max_workers=n_thr) as ex:
+        outs = list(ex.map(lambda u: refdec.decode(h, cfg, mats[u], big["m"]), range(big["B"])))
+    refdec.free_graph(h)
+    gpu = [dict(ok=r.ok, words=r.words, tids=r.tids, tot_score=r.tot_score) for r in res]
+    dv = divergence(gpu, outs)
+    with capsys.disabled():
+        print("\n[service point vs reference] %s" % dv)
+    assert all(r.ok and len(r.tids) == big["T"] for r in res)
+    assert dv["wer"] <= 0.02, dv                 # word-level agreement with the reference's own output
+    assert dv["max_rel_cost_gap"] <= 0.01, dv    # every path within 1 % of the reference's cost
+    assert dv["bit_identical"] >= big["B"] // 2, dv

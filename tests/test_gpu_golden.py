@@ -59,8 +59,8 @@ def test_gpu_reproduces_golden(name, oracle, tmp_path):
                 finally:
                     oracle.set_order_free(False)
                     oracle.free_graph(ho)
-                if o.extra["ties"] == 0:
-                    G.assert_same_as_oracle(r, o, what + " (order-free)")
-                    n_checked += 1
+                assert o.extra["ties"] == 0, what + ": exact cost tie on the best path of a golden case"
+                G.assert_same_as_oracle(r, o, what + " (order-free)")
+                n_checked += 1
     graph.free()
     assert n_checked > 0

@@ -212,11 +212,12 @@ def test_max_active_min_active_binding_is_exact_in_order_free_terms(cd, setup50k
         finally:
             oracle.set_order_free(False)
         assert r.ok and len(r.tids) == 120
-        if f.extra["ties"] == 0:
-            s["G"].assert_same_as_oracle(r, f, "utt %d (order-free)" % i)
+        assert f.extra["ties"] == 0, "exact cost tie on the best path (utt %d)" % i
+        s["G"].assert_same_as_oracle(r, f, "utt %d (order-free)" % i)
         assert r.tot_score <= o.tot_score + 0.01 * abs(o.tot_score)
         same += int(np.array_equal(r.words, o.words))
-    assert same >= 3
+    # measured on these seeds (MI355X, round 2): see the assertion message if it moves
+    assert same >= 3, "only %d/8 utterances with the reference's own words" % same
 
 
 def test_errors_are_loud(setup50k, synth):
@@ -294,9 +295,9 @@ def test_openfst_vector_and_const_graphs_decode_like_the_flat_graph(synth, oracl
         G.wfstdec.Graph.load(bad)
 
 
-def test_channel_groups_decode_identically(synth, oracle, tmp_path, monkeypatch):
-    """WFST_GROUPS=2/3 (one hipGraph + stream per channel group, read at wfst_decoder_create) and
-    WFST_NO_GRAPH=1 are scheduling choices only: same bits as the oracle, ragged lengths included."""
+def test_channel_groups_decode_identically(synth, oracle, tmp_path):
+    """wfst_options.channel_groups = 2/3 (one hipGraph + stream per channel group) and use_hip_graph = 0 are
+    scheduling choices only: same bits as the oracle, ragged lengths included."""
     import gpu_util as G
 
     g = synth.make_hclg_like(6000, seed=29, n_tid=600, n_words=900)
@@ -310,12 +311,21 @@ def test_channel_groups_decode_identically(synth, oracle, tmp_path, monkeypatch)
     h = oracle.load_graph(path)
     want = [oracle.decode(h, pyoracle.Config(**cd), x, m) for x in mats]
     oracle.free_graph(h)
-    for env in (dict(WFST_GROUPS="2"), dict(WFST_GROUPS="3"), dict(WFST_NO_GRAPH="1"), dict(WFST_GROUPS="2", WFST_NO_GRAPH="1")):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    lim = dict(max_frames=512, max_tokens_per_frame=32768, arena_tokens=1 << 22)
+    for opt in (dict(channel_groups=2), dict(channel_groups=3), dict(use_hip_graph=0), dict(channel_groups=2, use_hip_graph=0),
+                dict(log2_partitions=0, log2_lds_slots=8), dict(joint_max=64, expand_workgroups=3, insert_workgroups=7),
+                dict(upload_slice_frames=0)):
         for chunk in (0, 7):
-            for r, o in zip(G.decode_batch(graph, cd, mats, chunk=chunk), want):
-                G.assert_same_as_oracle(r, o, "%s chunk %d" % (env, chunk))
-        for k in env:
-            monkeypatch.delenv(k)
+            dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), options=G.wfstdec.Options(**opt), **lim)
+            for r, o in zip(G.decode_batch(graph, cd, mats, chunk=chunk, dec=dec, host_feed="upload_slice_frames" in opt), want):
+                G.assert_same_as_oracle(r, o, "%s chunk %d" % (opt, chunk))
+            dec.free()
+    with pytest.raises(G.wfstdec.WfstError):
+        G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 2, options=G.wfstdec.Options(channel_groups=9), **lim)
+    # unflattened closures / packed rows: graph upload choices, same bits
+    g2 = G.wfstdec.Graph.load(path, options=G.wfstdec.GraphOptions(flatten_closures=0, row_align_slots=1))
+    g2.set_tid2pdf(m)
+    for r, o in zip(G.decode_batch(g2, cd, mats), want):
+        G.assert_same_as_oracle(r, o, "graph options")
+    g2.free()
     graph.free()

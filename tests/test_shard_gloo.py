@@ -19,8 +19,8 @@ def _free_port():
 
 def _fake_result(u):
     rng = np.random.default_rng(u)
-    n = int(rng.integers(0, 20))
-    return dict(words=rng.integers(1, 50000, size=n).astype(np.int32), tot_score=float(np.float32(100.0 + u / 7.0)),
+    n = 300 if u == 7 else int(rng.integers(0, 20))
+    return dict(words=rng.integers(1, 1 << 30, size=n).astype(np.int32), tot_score=float(np.float32(100.0 + u / 7.0)),
                 lm_score=float(np.float32(u / 3.0)))
 
 
@@ -86,7 +86,7 @@ def test_two_rank_lattice_gather_over_gloo():
         assert np.array_equal(L.a_ac.view(np.int32), e["a_acoustic"].view(np.int32))
 
 
-def _worker(rank, world, port, per_rank, lmax, q):
+def _worker(rank, world, port, per_rank, q):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -94,31 +94,42 @@ def _worker(rank, world, port, per_rank, lmax, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     shard = importlib.import_module("asr-decoder_amd.shard")
     mine = [_fake_result(u) for u in shard.shard_range(rank, world, per_rank)]
-    allp = shard.gather_results(shard.pack_results(mine, lmax))
+    got = shard.gather_results(shard.pack_results(mine))
     dist.barrier()
     if rank == 0:
-        q.put(allp)
+        q.put(got)
     dist.destroy_process_group()
 
 
 def test_two_rank_gather_over_gloo():
-    world, per_rank, lmax = 2, 5, 16
+    """variable-length int32 payload: nothing truncated (utterance 7 has 300 words), float scores bit for bit"""
+    world, per_rank = 2, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, lmax, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, q)) for r in range(world)]
     [p.start() for p in procs]
-    allp = q.get(timeout=120)
+    got = q.get(timeout=120)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    shard = importlib.import_module("asr-decoder_amd.shard")
-    got = shard.unpack_results(allp)
     assert len(got) == world * per_rank
     for u, r in enumerate(got):
         e = _fake_result(u)
         assert r["n_words"] == len(e["words"])
-        assert np.array_equal(r["words"], e["words"][:lmax])
-        assert np.float32(r["tot_score"]) == np.float32(e["tot_score"]) and np.float32(r["lm_score"]) == np.float32(e["lm_score"])
+        assert np.array_equal(r["words"], e["words"])
+        assert np.float32(r["tot_score"]).tobytes() == np.float32(e["tot_score"]).tobytes()
+        assert np.float32(r["lm_score"]).tobytes() == np.float32(e["lm_score"]).tobytes()
+
+
+def test_pack_results_refuses_ids_outside_int32():
+    shard = importlib.import_module("asr-decoder_amd.shard")
+    import pytest
+
+    with pytest.raises(ValueError):
+        shard.pack_results([dict(words=np.asarray([1 << 31], np.int64), tot_score=0.0, lm_score=0.0)])
+    hdr, words = shard.pack_results([_fake_result(u) for u in range(4)])
+    back = shard.unpack_results(hdr, words)
+    assert [len(r["words"]) for r in back] == [len(_fake_result(u)["words"]) for u in range(4)]
 
 
 def test_shard_ranges_partition_the_batch():
