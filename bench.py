@@ -526,32 +526,54 @@ def main():
     if rank == 0 and world == 1 and not a.no_service_point and a.lattice_links == 0 and not a.host_feed and a.workload == "multi":
         dec.free()
         dec = None
-        del ll_dev
+        t0 = time.time()
+        cd2 = dict(cd, max_active=7000, min_active=200)
+        n2 = max(2, a.steps // 4)
+
+        def at_service_point(mats2, ll2):
+            """decode at 7000/200; with the CPU legs on: GPU result vs the reference decoder's own, and the
+            reference against ITSELF with nothing but its hash table size changed (hash_ratio 3 instead of
+            2: another visiting order of the same algorithm) -- the yardstick for the first number"""
+            nonlocal dec
+            dec = new_decoder(cd2)
+            step2 = make_step(dec, ll2, [mats2[i] for i in range(B)])
+            dt2, res2 = timed(step2, 1, n2)
+            o = {"value": B * T * n2 / dt2, "unit": "frames/s", "ms_per_step": 1000.0 * dt2 / n2, "steps": n2,
+                 "mean_active_tokens_per_frame": sum(dec.stats(c)["tokens"] for c in range(B)) / float(B * (T + 1))}
+            dec.free()
+            dec = None
+            if a.cpu_sample > 0:
+                kind, cdec = cpu_decoder()
+                cres2 = cpu_decode_all(cdec, gpath, cd2, list(mats2), m, affinity_cpus())
+                o["divergence_vs_" + kind] = divergence(res2, cres2)
+                cres3 = cpu_decode_all(cdec, gpath, dict(cd2, hash_ratio=3.0), list(mats2), m, affinity_cpus())
+                o[kind + "_self_divergence_hash_ratio_3_vs_2"] = divergence(
+                    [dict(ok=r.ok, words=r.words, tids=r.tids, tot_score=r.tot_score) for r in cres3], cres2)
+            return o
+
         sa = argparse.Namespace(**vars(a))
         sa.workload, sa.mu = "single", -2.0
-        t0 = time.time()
         mats2 = make_utts(synth, g, m, 0, B, T, P, sa)
         ll2 = torch.from_numpy(mats2).to(dev)
-        cd2 = dict(cd, max_active=7000, min_active=200)
-        dec = new_decoder(cd2)
-        step2 = make_step(dec, ll2, [mats2[i] for i in range(B)])
-        dt2, res2 = timed(step2, 1, max(2, a.steps // 4))
-        n2 = max(2, a.steps // 4)
         sp = {"workload": "SURVEY.md 8(d) single-planted-path log-likelihoods (mu -2, sigma 1), same graph and batch, beam=%g, "
-                          "max_active=7000, min_active=200 (v1-asrbin/conf/decoder.conf:4-8)" % a.beam,
-              "value": B * T * n2 / dt2, "unit": "frames/s", "ms_per_step": 1000.0 * dt2 / n2, "steps": n2,
-              "mean_active_tokens_per_frame": sum(dec.stats(c)["tokens"] for c in range(B)) / float(B * (T + 1))}
-        if a.cpu_sample > 0:
-            kind, cdec = cpu_decoder()
-            cres2 = cpu_decode_all(cdec, gpath, cd2, list(mats2), m, affinity_cpus())
-            sp["divergence_vs_" + kind] = divergence(res2, cres2)
-            sp["divergence_note"] = ("where max_active/min_active bind, the reference's cutoff depends on its hash-list visiting "
-                                     "order (DESIGN.md section 4, deviation 2): word-level agreement is the claim here, not bits")
+                          "max_active=7000, min_active=200 (v1-asrbin/conf/decoder.conf:4-8)" % a.beam}
+        sp.update(at_service_point(mats2, ll2))
+        del ll2, mats2
+        hp = {"workload": "the headline log-likelihoods at max_active=7000, min_active=200"}
+        hp.update(at_service_point(mats, ll_dev))
+        sp["headline_workload_at_7000_200"] = hp
+        sp["divergence_note"] = ("where max_active/min_active bind, the reference's cutoff depends on its own hash-list visiting "
+                                 "order (DESIGN.md section 4, deviation 2): it then differs from itself when only hash_ratio "
+                                 "changes; the GPU computes the order-independent restatement")
         out["service_point"] = sp
         log("[rank 0] service point: %.1fs" % (time.time() - t0))
-        del ll2
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        def plain(o):  # numpy scalars -> Python numbers
+            if isinstance(o, np.generic):
+                return o.item()
+            raise TypeError("not JSON serialisable: %r" % type(o))
+
+        print(json.dumps(out, default=plain), flush=True)
     if dec is not None:
         dec.free()
     graph.free()

@@ -359,3 +359,115 @@ def ref_nbest_from_lattice_file(ref, path, index, n, max_len=512):
     if k < 0:
         return None
     return [(words[i, : nw[i]].copy(), float(sc[i, 0]), float(sc[i, 1])) for i in range(k)], ds.value, da.value
+
+
+# ---- biglm (BASELINE configs[3]) -----------------------------------------------------------------
+class quiet_stdout:
+    """the reference's ArpaLm::Read / Arpa2Fsa print progress on stdout (arpa2fsa.cc:128,161-171)"""
+
+    def __enter__(self):
+        import sys
+
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        self.devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self.devnull, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        os.close(self.devnull)
+
+
+def ref_arpa2fsa(ref, arpa_path, wordlist_path, out_path, nthread=1):
+    """The reference's own ARPA -> binary LM converter (Arpa2Fsa::ConvertArpa2Fsa + ArpaLm::Write)."""
+    if os.path.exists(out_path):
+        os.remove(out_path)
+    f = ref.lib.ref_arpa2fsa
+    f.restype = C.c_int
+    with quiet_stdout():
+        ok = f(arpa_path.encode(), wordlist_path.encode(), out_path.encode(), int(nthread))
+    if not ok:
+        raise IOError("reference Arpa2Fsa failed on %s" % arpa_path)
+
+
+class Lm:
+    """An LM automaton loaded by one of the checkers (prefix 'ref' or 'oracle')."""
+
+    def __init__(self, dec, path, scale=1.0):
+        self.dec, self.p = dec, dec.PREFIX
+        f = getattr(dec.lib, self.p + "_lm_load")
+        f.restype = C.c_void_p
+        with quiet_stdout():
+            self.h = f(path.encode(), C.c_float(scale))
+        if not self.h:
+            raise IOError("cannot read LM %s" % path)
+
+    def free(self):
+        if self.h:
+            getattr(self.dec.lib, self.p + "_lm_free")(C.c_void_p(self.h))
+            self.h = None
+
+    def start(self):
+        f = getattr(self.dec.lib, self.p + "_lm_start")
+        f.restype = C.c_int
+        return int(f(C.c_void_p(self.h)))
+
+    def final(self, s):
+        f = getattr(self.dec.lib, self.p + "_lm_final")
+        f.restype = C.c_float
+        return float(f(C.c_void_p(self.h), int(s)))
+
+    def getarc_many(self, states, words):
+        """ComposeArpaLm::GetArc for every (state, word): (next states, Value1 costs)"""
+        st = np.ascontiguousarray(states, np.int32)
+        wd = np.ascontiguousarray(words, np.int32)
+        nx = np.zeros(st.shape[0], np.int32)
+        v1 = np.zeros(st.shape[0], np.float32)
+        getattr(self.dec.lib, self.p + "_lm_getarc_many")(C.c_void_p(self.h), int(st.shape[0]), _ip(st), _ip(wd), _ip(nx), _fp(v1))
+        return nx, v1
+
+
+def biglm_decode(dec, graph_handle, cfg, lm1, lm2, loglikes, tid2pdf=None, chunk=0, finalize=True, use_final_probs=True,
+                 trace=False, fixed=True):
+    """One utterance through the biglm decoder of `dec` (RefDecoder: the reference's
+    OnlineLatticeDecoderMempoolBiglm as it is; OracleDecoder: the restatement, `fixed` chooses the
+    DiffArpaLm mode).  lm1 = old LM loaded with scale -1, lm2 = new LM."""
+    ll = np.ascontiguousarray(loglikes, dtype=np.float32)
+    T, stride = ll.shape
+    if tid2pdf is not None:
+        tid2pdf = np.ascontiguousarray(tid2pdf, dtype=np.int32)
+        n_tid = int(tid2pdf.shape[0] - 1)
+    else:
+        n_tid = stride - 1
+    max_path = 4 * T + 64
+    pi, po, words, tids = (np.zeros(max_path, np.int32) for _ in range(4))
+    pg, pa = np.zeros(max_path, np.float32), np.zeros(max_path, np.float32)
+    n_path, n_words, n_tids = C.c_int(0), C.c_int(0), C.c_int(0)
+    tot, lm = C.c_float(0), C.c_float(0)
+    fn = fb = None
+    if trace:
+        chunk = 1
+        fn = np.zeros(T + 1, np.int32)
+        fb = np.zeros(T + 1, np.float32)
+    nt, nl = C.c_int(0), C.c_int(0)
+    is_ref = dec.PREFIX == "ref"
+    f = getattr(dec.lib, dec.PREFIX + "_biglm_decode")
+    f.restype = C.c_int
+    head = [C.c_void_p(graph_handle), C.byref(cfg), C.c_void_p(lm1.h), C.c_void_p(lm2.h)]
+    if not is_ref:
+        head.append(int(bool(fixed)))
+    ex = np.zeros(8, np.int64)
+    args = head + [_fp(ll), T, stride, _ip(tid2pdf), n_tid, int(chunk), int(bool(finalize)), int(bool(use_final_probs)),
+                   _ip(pi), _ip(po), _fp(pg), _fp(pa), max_path, C.byref(n_path), C.byref(tot), C.byref(lm), _ip(words), max_path,
+                   C.byref(n_words), _ip(tids), max_path, C.byref(n_tids), _ip(fn), _fp(fb), C.byref(nt), C.byref(nl)]
+    if not is_ref:
+        args.append(ex.ctypes.data_as(C.POINTER(C.c_int64)))
+    ok = f(*args)
+    n = n_path.value
+    r = Result(bool(ok), words[: n_words.value].copy(), tids[: n_tids.value].copy(), float(tot.value), float(lm.value),
+               pi[:n].copy(), po[:n].copy(), pg[:n].copy(), pa[:n].copy(), fn, fb, None, nt.value, nl.value)
+    if not is_ref:
+        r.extra = dict(N=int(ex[0]), E=int(ex[1]), Z=int(ex[2]), tokens_created=int(ex[3]), links_created=int(ex[4]),
+                       ties=int(ex[5]), quirk_hops=int(ex[6]), lm_pairs=int(ex[7] & ((1 << 40) - 1)), lm_oob=int(ex[7] >> 40))
+    return r

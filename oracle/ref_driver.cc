@@ -12,6 +12,8 @@
 //   InitDecoding/AdvanceDecoding/FinalizeDecoding/GetBestPath
 //                                    src/my-decoder/online-decoder-base-inl.h:41,631,830,1072
 //   LatticeToVector                  src/newfst/lattice-functions.cc:179-217
+//   OnlineLatticeDecoderMempoolBiglm src/my-decoder/online-decoder-mempool-base-biglm.h:570 (biglm, BASELINE configs[3])
+//   ArpaLm / Arpa2Fsa / ComposeArpaLm src/newlm/arpa2fsa.{h,cc}, src/newlm/compose-arpalm.{h,cc}
 // The decodable below plays the role of Kaldi's DecodableMatrixScaledMapped
 // (kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:107) with the scale pre-applied:
 // LogLikelihood(f, tid) = M[f][tid2pdf[tid]].
@@ -24,6 +26,7 @@
 #include <vector>
 
 #include "src/my-decoder/online-decoder-mempool-base.h"
+#include "src/my-decoder/online-decoder-mempool-base-biglm.h"
 #include "src/newfst/const-fst.h"
 #include "src/newfst/lattice-determinize-api.h"
 #include "src/newfst/lattice-to-nbest.h"
@@ -445,6 +448,190 @@ int ref_nbest_from_lattice_file(const char *path, int index, int n, int max_len,
     ++k;
   }
   return k;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// biglm (BASELINE configs[3]): the reference's LM automaton and its on-the-fly rescoring decoder.
+// ---------------------------------------------------------------------------------------------
+
+// Arpa2Fsa::ConvertArpa2Fsa + ArpaLm::Write (newlm/arpa2fsa-bin.cc:10-31): ARPA text + word list ->
+// the reference's binary LM file.  Returns 1 on success.
+int ref_arpa2fsa(const char *arpafile, const char *wordlist, const char *outfile, int nthread) {
+  Arpa2Fsa conv(nthread, arpafile, wordlist);
+  if (!conv.ConvertArpa2Fsa()) return 0;
+  return conv.Write(outfile) ? 1 : 0;
+}
+
+// ArpaLm::Read + Rescale (kaldi-hclg-my-decoder-biglm.cc:55-60 rescales the old LM by -1).
+void *ref_lm_load(const char *path, float scale) {
+  ArpaLm *lm = new ArpaLm();
+  if (!lm->Read(path)) {
+    delete lm;
+    return NULL;
+  }
+  lm->Rescale(scale);
+  return lm;
+}
+void ref_lm_free(void *lm) { delete static_cast<ArpaLm *>(lm); }
+void ref_lm_info(void *lmp, int *bos, int *eos, int *unk, int *order) {
+  ArpaLm *lm = static_cast<ArpaLm *>(lmp);
+  *bos = lm->BosSymbol();
+  *eos = lm->EosSymbol();
+  *unk = lm->UnkSymbol();
+  *order = lm->NgramOrder();
+}
+// ComposeArpaLm (newlm/compose-arpalm.cc:5-70): Start, Final, GetArc with the back-off walk.
+int ref_lm_start(void *lmp) { return ComposeArpaLm(static_cast<ArpaLm *>(lmp)).Start(); }
+float ref_lm_final(void *lmp, int s) { return ComposeArpaLm(static_cast<ArpaLm *>(lmp)).Final(s); }
+void ref_lm_getarc(void *lmp, int s, int word, int *next, float *value1) {
+  ComposeArpaLm c(static_cast<ArpaLm *>(lmp));
+  FsaStateId ns = 0;
+  LatticeWeight w;
+  Label ol = 0;
+  c.GetArc(s, word, &ns, &w, &ol);
+  *next = ns;
+  *value1 = w.Value1();
+}
+// n calls of ref_lm_getarc in one go (states[i], words[i]) -> (next[i], value1[i])
+void ref_lm_getarc_many(void *lmp, int n, const int *states, const int *words, int *next, float *value1) {
+  ComposeArpaLm c(static_cast<ArpaLm *>(lmp));
+  for (int i = 0; i < n; ++i) {
+    FsaStateId ns = 0;
+    LatticeWeight w;
+    Label ol = 0;
+    c.GetArc(states[i], words[i], &ns, &w, &ol);
+    next[i] = ns;
+    value1[i] = w.Value1();
+  }
+}
+
+namespace {
+class ProbeBiglm : public OnlineLatticeDecoderMempoolBiglm {
+ public:
+  ProbeBiglm(Fst *g, const LatticeFasterDecoderConfig &c, ArpaLm *a, ArpaLm *b) : OnlineLatticeDecoderMempoolBiglm(g, c, a, b) {}
+  int CountFrontier(float *best) const {
+    int n = 0;
+    float b = FLOAT_INF;
+    for (const Elem *e = _toks.GetList(); e != NULL; e = e->tail) {
+      ++n;
+      if (e->val->_tot_cost < b) b = e->val->_tot_cost;
+    }
+    *best = b;
+    return n;
+  }
+  int NumToks() const { return _num_toks; }
+  int NumLinks() const { return _num_links; }
+};
+}  // namespace
+
+// ref_decode() with the biglm decoder (kaldi-nnet3bin/kaldi-hclg-my-decoder-biglm.cc:80-102):
+// lm1 = old LM (already rescaled by -1 at load), lm2 = new LM.
+int ref_biglm_decode(void *gp, const RefConfig *rc, void *lm1, void *lm2, const float *loglikes, int T,
+                     int stride, const int *tid2pdf, int n_tid, int chunk, int do_finalize,
+                     int use_final_probs, int *path_ilabel, int *path_olabel, float *path_graph,
+                     float *path_ac, int max_path, int *n_path, float *tot_score, float *lm_score,
+                     int *words, int max_words, int *n_words, int *tids, int max_tids, int *n_tids,
+                     int *frame_ntoks, float *frame_best, int *num_toks_end, int *num_links_end) {
+  Fst *g = static_cast<Fst *>(gp);
+  LatticeFasterDecoderConfig cfg;
+  cfg._beam = rc->beam;
+  cfg._max_active = rc->max_active;
+  cfg._min_active = rc->min_active;
+  cfg._lattice_beam = rc->lattice_beam;
+  cfg._prune_interval = rc->prune_interval;
+  cfg._beam_delta = rc->beam_delta;
+  cfg._hash_ratio = rc->hash_ratio;
+  cfg._prune_scale = rc->prune_scale;
+  ProbeBiglm dec(g, cfg, static_cast<ArpaLm *>(lm1), static_cast<ArpaLm *>(lm2));
+  MatrixDecodable decodable(loglikes, T, stride, tid2pdf, n_tid);
+  dec.InitDecoding();
+  if (chunk == 1 && frame_ntoks) frame_ntoks[0] = dec.CountFrontier(&frame_best[0]);
+  if (chunk <= 0) {
+    dec.AdvanceDecoding(&decodable);
+  } else {
+    for (int r = 0; r < T;) {
+      r = (r + chunk < T) ? r + chunk : T;
+      decodable.SetReady(r);
+      dec.AdvanceDecoding(&decodable);
+      if (chunk == 1 && frame_ntoks) frame_ntoks[r] = dec.CountFrontier(&frame_best[r]);
+    }
+  }
+  if (do_finalize) dec.FinalizeDecoding();
+  if (num_toks_end) *num_toks_end = dec.NumToks();
+  if (num_links_end) *num_links_end = dec.NumLinks();
+  *n_path = 0;
+  *n_words = 0;
+  *n_tids = 0;
+  *tot_score = 0;
+  *lm_score = 0;
+  Lattice best_path;
+  if (!dec.GetBestPath(&best_path, use_final_probs != 0)) return 0;
+  {
+    StateId s = best_path.Start();
+    LatticeState *cur = best_path.GetState(s);
+    int n = 0;
+    while (!cur->IsFinal()) {
+      LatticeArc *arc = cur->GetArc(0);
+      if (n < max_path) {
+        path_ilabel[n] = arc->_input;
+        path_olabel[n] = arc->_output;
+        path_graph[n] = arc->_w.Value1();
+        path_ac[n] = arc->_w.Value2();
+      }
+      ++n;
+      cur = best_path.GetState(arc->_to);
+    }
+    *n_path = n;
+  }
+  std::vector<int> w, p;
+  float tot = 0, lm = 0;
+  if (!LatticeToVector(best_path, w, p, tot, lm)) return 0;
+  *tot_score = tot;
+  *lm_score = lm;
+  *n_words = (int)w.size();
+  *n_tids = (int)p.size();
+  for (int i = 0; i < (int)w.size() && i < max_words; ++i) words[i] = w[i];
+  for (int i = 0; i < (int)p.size() && i < max_tids; ++i) tids[i] = p[i];
+  return 1;
+}
+
+// ref_timed_loop() with ONE biglm decoder object (bench.py --biglm, cpu_baseline leg).
+long long ref_biglm_timed_loop(void *gp, const RefConfig *rc, void *lm1, void *lm2, const float *const *mats,
+                               const int *T, int n_mats, int stride, const int *tid2pdf, int n_tid, int first,
+                               int step, double seconds, double *elapsed, long long *words_out) {
+  Fst *g = static_cast<Fst *>(gp);
+  LatticeFasterDecoderConfig cfg;
+  cfg._beam = rc->beam;
+  cfg._max_active = rc->max_active;
+  cfg._min_active = rc->min_active;
+  cfg._lattice_beam = rc->lattice_beam;
+  cfg._prune_interval = rc->prune_interval;
+  cfg._beam_delta = rc->beam_delta;
+  cfg._hash_ratio = rc->hash_ratio;
+  cfg._prune_scale = rc->prune_scale;
+  ProbeBiglm dec(g, cfg, static_cast<ArpaLm *>(lm1), static_cast<ArpaLm *>(lm2));
+  long long frames = 0, nwords = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  double dt = 0.0;
+  for (int i = first % n_mats;; i = (i + step) % n_mats) {
+    MatrixDecodable decodable(mats[i], T[i], stride, tid2pdf, n_tid);
+    dec.InitDecoding();
+    dec.AdvanceDecoding(&decodable);
+    dec.FinalizeDecoding();
+    Lattice best_path;
+    if (dec.GetBestPath(&best_path, true)) {
+      std::vector<int> w, p;
+      float tot = 0, lm = 0;
+      if (LatticeToVector(best_path, w, p, tot, lm)) nwords += (long long)w.size();
+    }
+    frames += T[i];
+    dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (dt >= seconds) break;
+  }
+  if (elapsed) *elapsed = dt;
+  if (words_out) *words_out = nwords;
+  return frames;
 }
 
 }  // extern "C"

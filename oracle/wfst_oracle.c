@@ -14,6 +14,16 @@
  * tests/golden/ holds reference-generated vectors (tests/golden/make_golden.py)
  * that this file must reproduce where the reference tree is absent.
  *
+ * biglm (BASELINE configs[3], class OnlineLatticeDecoderMempoolBiglm,
+ * my-decoder/online-decoder-mempool-base-biglm.h + newlm/): the same loop over 64-bit
+ * (graph state | LM pair state << 32) keys with the on-the-fly LM difference, in two modes:
+ *   as-written  DiffArpaLm::GetArc hands the PAIR id to both LMs (newlm/diff-lm.h:80,86) and interns
+ *               pair ids in visiting order -- pinned bit for bit to the compiled reference
+ *               (tests/test_oracle_biglm.py, oracle/_ref);
+ *   fixed       the pair's own components (pr.first / pr.second) -- the two-line change the reference
+ *               evidently means; equal to as-written wherever the LM scores do not depend on the
+ *               history (proved on unigram LM pairs), and the mode the HIP path implements.
+ *
  * Every function cites the reference lines it follows; paths are relative to
  * /root/reference/src.  Float arithmetic is single precision, left to right,
  * no contraction (reference: -O2 -msse2, configure.ac:12-13).
@@ -52,15 +62,18 @@ typedef struct Link {
 } Link;
 typedef struct Token {
   float tot_cost, extra_cost; Link *links; struct Token *next; struct Token *backpointer;
-  int is_final; /* stands for membership in _final_costs (value is always 0) */
+  int is_final; /* stands for membership in _final_costs */
+  float final_cost; /* its value there: 0, or the LM final cost in biglm mode */
   int state;    /* graph state (the reference token does not know it; used to label lattice states) */
+  int lm_state; /* biglm: LM pair state of the token's key */
   int lat_id;   /* lattice state id during GetRawLattice */
   int tie;      /* audit only: an equal-cost rival arrived after this cost was set */
 } Token;
 typedef struct { Token *toks; int must_prune_forward_links, must_prune_tokens; } TokenList;
 
 /* ---- HashList<StateId, Token*>: util/hash-list.h:13-105, hash-list-inl.h:15-173 ---- */
-typedef struct Elem { int key; Token *val; struct Elem *tail; } Elem;
+typedef uint64_t Key; /* StateId, or biglm's PairId = state + (lm_state << 32) (biglm.h:77-90) */
+typedef struct Elem { Key key; Token *val; struct Elem *tail; } Elem;
 typedef struct { size_t prev_bucket; Elem *last_elem; } Bucket;
 #define NOBUCKET ((size_t)-1)
 typedef struct {
@@ -74,8 +87,27 @@ typedef struct {
 typedef struct PoolBlock { struct PoolBlock *next; } PoolBlock;
 typedef struct { void *free_head; PoolBlock *blocks; size_t elem_size; } Pool;
 
+/* ---- LM automaton: newlm/arpa2fsa.h:22-247; binary file ArpaLm::Read :355-397 + Fsa::Read arpa2fsa.cc:68-176 ---- */
+typedef struct { int wordid; float weight; int tostateid; } FsaArc;
+typedef struct { int arc_num; float backoff_prob; int backoff_id; } FsaStateInfo;
 typedef struct {
-  const Graph *g; Config cfg; HashList toks;
+  int bos, eos, unk, order;
+  int n_states, n_arcs;
+  FsaStateInfo *st; int64_t *off; FsaArc *arcs;
+} Lm;
+/* DiffArpaLm: newlm/diff-lm.h:13-122 */
+typedef struct { int a, b, id; } PairSlot;
+typedef struct {
+  const Lm *lm1, *lm2;
+  int (*vec)[2]; int n_vec, cap_vec;      /* _state_vec */
+  PairSlot *map; int map_cap, map_n;       /* _state_map (open addressing; only membership matters) */
+  int start_pair[2];
+  int fixed;                               /* 0: as written (pair id handed to both LMs), 1: pr.first / pr.second */
+  int oob;                                 /* an LM state / word id outside the automaton was asked for (undefined in the reference) */
+} DiffLm;
+
+typedef struct {
+  const Graph *g; Config cfg; HashList toks; DiffLm *dlm;
   TokenList *active; int n_active, cap_active;
   const Elem **queue; size_t n_queue, cap_queue;
   float *tmp; size_t n_tmp, cap_tmp;
@@ -131,7 +163,7 @@ static Elem *hl_new(HashList *h) { /* :86-104 */
   }
   Elem *a = h->freed_head; h->freed_head = a->tail; return a;
 }
-static Elem *hl_insert(HashList *h, int key, Token *val) { /* hash-list-inl.h:128-173 */
+static Elem *hl_insert(HashList *h, Key key, Token *val) { /* hash-list-inl.h:128-173 */
   size_t index = (size_t)key % h->hash_size;
   Bucket *b = &h->buckets[index];
   if (b->last_elem) {
@@ -150,11 +182,161 @@ static Elem *hl_insert(HashList *h, int key, Token *val) { /* hash-list-inl.h:12
   return elem;
 }
 
+/* ---- LM automaton ---- */
+/* Fsa::GetArc, newlm/arpa2fsa.cc:244-262 (+ FsaState::SearchArc / SearchStartArc, arpa2fsa.h:194-214).
+ * The reference indexes without bounds checks; *oob is raised instead of reading outside. */
+static int fsa_getarc(const Lm *lm, int id, int wordid, float *weight, int *tostateid, int *oob) {
+  if (id < 0 || id >= lm->n_states) { *oob = 1; *weight = 0.0f; *tostateid = 0; return 1; }
+  if (wordid == 0) { *weight = lm->st[id].backoff_prob; *tostateid = lm->st[id].backoff_id; return 1; }
+  const FsaArc *arc = lm->arcs + lm->off[id], *hit = NULL;
+  const int arc_num = lm->st[id].arc_num;
+  if (id == 0) {                 /* id == start: arc[wordid] */
+    if (wordid < 0 || wordid >= arc_num) { *oob = 1; *weight = 0.0f; *tostateid = 0; return 1; }
+    hit = &arc[wordid];
+  } else {
+    int start = 0, end = arc_num - 1, mid = (start + end) / 2;
+    while (start <= end) {
+      if (arc[mid].wordid > wordid) end = mid - 1;
+      else if (arc[mid].wordid < wordid) start = mid + 1;
+      else { hit = &arc[mid]; break; }
+      mid = (start + end) / 2;
+    }
+  }
+  if (!hit) return 0;
+  *weight = hit->weight; *tostateid = hit->tostateid; return 1;
+}
+/* ComposeArpaLm::GetArc, newlm/compose-arpalm.cc:52-70: back off until the word is found */
+static void compose_getarc(const Lm *lm, int s, int ilabel, int *nextstate, float *value1, int *oob) {
+  float weight = 0.0f, w_arc = 0.0f; int to = 0, guard = 0;
+  while (!fsa_getarc(lm, s, ilabel, &w_arc, &to, oob)) {
+    fsa_getarc(lm, s, 0, &w_arc, &to, oob);
+    s = to; weight += w_arc;
+    if (++guard > 64) { *oob = 1; break; }
+  }
+  weight += w_arc;
+  *value1 = -1 * weight;
+  *nextstate = to;
+}
+static int compose_start(const Lm *lm, int *oob) { /* compose-arpalm.cc:5-13 */
+  float w = 0.0f; int to = 0;
+  fsa_getarc(lm, 0, lm->bos, &w, &to, oob);
+  return to;
+}
+static float compose_final(const Lm *lm, int s, int *oob) { /* compose-arpalm.cc:15-29 */
+  float weight = 0.0f, w_arc = 0.0f; int to = 0, guard = 0;
+  while (!fsa_getarc(lm, s, lm->eos, &w_arc, &to, oob)) {
+    fsa_getarc(lm, s, 0, &w_arc, &to, oob);
+    s = to; weight += w_arc;
+    if (++guard > 64) { *oob = 1; break; }
+  }
+  weight += w_arc;
+  return (float)(-1.0 * weight);
+}
+
+void *oracle_lm_load(const char *path, float scale) { /* ArpaLm::Read + Fsa::Read + Rescale */
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return NULL;
+  Lm *lm = (Lm *)calloc(1, sizeof(Lm));
+  uint64_t ngram = 0; int ok = 1;
+  ok = ok && fread(&lm->bos, 4, 1, fp) == 1 && fread(&lm->eos, 4, 1, fp) == 1 && fread(&lm->unk, 4, 1, fp) == 1 && fread(&ngram, 8, 1, fp) == 1;
+  if (ok && ngram > 64) ok = 0;
+  if (ok) { int tmp[64]; lm->order = (int)ngram; ok = fread(tmp, 4, (size_t)ngram, fp) == (size_t)ngram; }
+  ok = ok && fread(&lm->n_states, 4, 1, fp) == 1 && lm->n_states > 0;
+  if (ok) {
+    lm->st = (FsaStateInfo *)malloc(sizeof(FsaStateInfo) * (size_t)lm->n_states);
+    lm->off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)lm->n_states + 1));
+    ok = fread(lm->st, sizeof(FsaStateInfo), (size_t)lm->n_states, fp) == (size_t)lm->n_states;
+  }
+  if (ok) {
+    int64_t o = 0;
+    for (int i = 0; i < lm->n_states; ++i) { lm->off[i] = o; if (lm->st[i].arc_num < 0) ok = 0; o += lm->st[i].arc_num; }
+    lm->off[lm->n_states] = o;
+    ok = ok && fread(&lm->n_arcs, 4, 1, fp) == 1 && (int64_t)lm->n_arcs == o;
+  }
+  if (ok) {
+    lm->arcs = (FsaArc *)malloc(sizeof(FsaArc) * ((size_t)lm->n_arcs + 1));
+    ok = fread(lm->arcs, sizeof(FsaArc), (size_t)lm->n_arcs, fp) == (size_t)lm->n_arcs;
+  }
+  fclose(fp);
+  if (!ok) { free(lm->st); free(lm->off); free(lm->arcs); free(lm); return NULL; }
+  if (scale != 1) { /* Fsa::Rescale, arpa2fsa.cc:264-275 */
+    for (int i = 0; i < lm->n_arcs; ++i) lm->arcs[i].weight *= scale;
+    for (int i = 0; i < lm->n_states; ++i) lm->st[i].backoff_prob *= scale;
+  }
+  return lm;
+}
+void oracle_lm_free(void *p) { Lm *lm = (Lm *)p; if (!lm) return; free(lm->st); free(lm->off); free(lm->arcs); free(lm); }
+int oracle_lm_start(void *lm) { int oob = 0; return compose_start((const Lm *)lm, &oob); }
+float oracle_lm_final(void *lm, int s) { int oob = 0; return compose_final((const Lm *)lm, s, &oob); }
+void oracle_lm_getarc_many(void *lm, int n, const int *states, const int *words, int *next, float *value1) {
+  int oob = 0;
+  for (int i = 0; i < n; ++i) compose_getarc((const Lm *)lm, states[i], words[i], &next[i], &value1[i], &oob);
+}
+
+/* ---- DiffArpaLm: newlm/diff-lm.h:13-122 ---- */
+static int dlm_intern(DiffLm *d, int a, int b) { /* _state_map.insert + _state_vec.push_back, :92-103 */
+  if (2 * (d->map_n + 1) > d->map_cap) {
+    int ncap = d->map_cap ? 2 * d->map_cap : 1024;
+    PairSlot *nm = (PairSlot *)malloc(sizeof(PairSlot) * (size_t)ncap);
+    for (int i = 0; i < ncap; ++i) nm[i].id = -1;
+    for (int i = 0; i < d->map_cap; ++i) if (d->map[i].id >= 0) {
+      uint32_t h = ((uint32_t)d->map[i].a * 7853u + (uint32_t)d->map[i].b) * 2654435761u;
+      int j = (int)(h & (uint32_t)(ncap - 1));
+      while (nm[j].id >= 0) j = (j + 1) & (ncap - 1);
+      nm[j] = d->map[i];
+    }
+    free(d->map); d->map = nm; d->map_cap = ncap;
+  }
+  uint32_t h = ((uint32_t)a * 7853u + (uint32_t)b) * 2654435761u;
+  int j = (int)(h & (uint32_t)(d->map_cap - 1));
+  while (d->map[j].id >= 0) {
+    if (d->map[j].a == a && d->map[j].b == b) return d->map[j].id;
+    j = (j + 1) & (d->map_cap - 1);
+  }
+  if (d->n_vec == d->cap_vec) { d->cap_vec = d->cap_vec ? 2 * d->cap_vec : 1024; d->vec = (int (*)[2])realloc(d->vec, sizeof(int[2]) * (size_t)d->cap_vec); }
+  d->map[j].a = a; d->map[j].b = b; d->map[j].id = d->n_vec; d->map_n++;
+  d->vec[d->n_vec][0] = a; d->vec[d->n_vec][1] = b;
+  return d->n_vec++;
+}
+static void dlm_reset(DiffLm *d) { /* :37-44 */
+  d->n_vec = 0; d->map_n = 0;
+  for (int i = 0; i < d->map_cap; ++i) d->map[i].id = -1;
+  dlm_intern(d, d->start_pair[0], d->start_pair[1]); /* id 0 == _start_state */
+}
+static void dlm_init(DiffLm *d, const Lm *lm1, const Lm *lm2, int fixed) { /* :19-35 */
+  memset(d, 0, sizeof(*d));
+  d->lm1 = lm1; d->lm2 = lm2; d->fixed = fixed;
+  d->start_pair[0] = compose_start(lm1, &d->oob); d->start_pair[1] = compose_start(lm2, &d->oob);
+  dlm_reset(d);
+}
+static void dlm_free(DiffLm *d) { free(d->vec); free(d->map); }
+static float dlm_final(DiffLm *d, int s) { /* :48-53 */
+  if (s < 0 || s >= d->n_vec) { d->oob = 1; return 0.0f; }
+  return compose_final(d->lm1, d->vec[s][0], &d->oob) + compose_final(d->lm2, d->vec[s][1], &d->oob);
+}
+/* OnlineLatticeDecoderMempoolBaseBiglm::NextLmState (biglm.h:54-70) over DiffArpaLm::GetArc (diff-lm.h:63-111) */
+static int next_lm_state(DiffLm *d, int lm_state, int olabel, float *lm_score) {
+  if (olabel == 0) { *lm_score = 0; return lm_state; }
+  if (lm_state < 0 || lm_state >= d->n_vec) { d->oob = 1; *lm_score = 0; return lm_state; }
+  /* as written: `_lm1.GetArc(s, ...)`, `_lm2.GetArc(s, ...)` with s the PAIR id (diff-lm.h:80,86);
+   * fixed: the pair's own components */
+  const int s1 = d->fixed ? d->vec[lm_state][0] : lm_state, s2 = d->fixed ? d->vec[lm_state][1] : lm_state;
+  int n1, n2; float w1, w2;
+  compose_getarc(d->lm1, s1, olabel, &n1, &w1, &d->oob);
+  compose_getarc(d->lm2, s2, olabel, &n2, &w2, &d->oob);
+  const int id = dlm_intern(d, n1, n2);
+  *lm_score = w1 + w2; /* Times(w1, w2).Value1(), newfst/weigth.h:320 */
+  return id;
+}
+#define KEY_STATE(k) ((int)(uint32_t)(k))             /* PairToState,   biglm.h:82-85 */
+#define KEY_LM(k) ((int)(uint32_t)((k) >> 32))        /* PairToLmState, biglm.h:87-90 */
+static inline Key make_key(int state, int lm_state) { return (Key)(uint32_t)state + ((Key)(uint32_t)lm_state << 32); } /* ConstructPair :77-80 */
+
 /* ---- token / link allocation: online-decoder-mempool-base.h:33-74 ---- */
 static Token *new_token(Decoder *d, float tot, float extra, Link *links, Token *next, Token *bp) {
   Token *t = (Token *)pool_new(&d->tok_pool);
   t->tot_cost = tot; t->extra_cost = extra; t->links = links; t->next = next; t->backpointer = bp; t->is_final = 0; t->tie = 0;
-  t->state = -1; t->lat_id = -1;
+  t->final_cost = 0.0f; t->state = -1; t->lm_state = 0; t->lat_id = -1;
   d->num_toks++; d->cnt_tok_created++; return t;
 }
 static Link *new_link(Decoder *d, Token *nt, int il, int ol, float gc, float ac, Link *next) {
@@ -188,12 +370,12 @@ static void clear_active_tokens(Decoder *d) { /* base-inl.h:69-85 */
 }
 
 /* FindOrAddToken: base-inl.h:88-136 */
-static Elem *find_or_add_token(Decoder *d, int state, int frame_plus_one, float tot_cost, Token *bp, int *changed) {
+static Elem *find_or_add_token(Decoder *d, Key key, int frame_plus_one, float tot_cost, Token *bp, int *changed) {
   Token **toks = &d->active[frame_plus_one].toks;
-  Elem *e = hl_insert(&d->toks, state, NULL);
+  Elem *e = hl_insert(&d->toks, key, NULL);
   if (e->val == NULL) {
     Token *nt = new_token(d, tot_cost, 0.0f, NULL, *toks, bp);
-    nt->state = state;
+    nt->state = KEY_STATE(key); nt->lm_state = KEY_LM(key);
     *toks = nt; e->val = nt;
     if (changed) *changed = 1;
   } else {
@@ -281,10 +463,10 @@ static void process_nonemitting(Decoder *d, float cutoff) {
   int frame = d->n_active - 1;
   if (d->toks.list_head == NULL && !d->warned) d->warned = 1;
   for (const Elem *e = d->toks.list_head; e; e = e->tail)
-    if (g->si[e->key].niepsilons != 0) queue_push(d, e);
+    if (g->si[KEY_STATE(e->key)].niepsilons != 0) queue_push(d, e);
   while (d->n_queue) {
     const Elem *elem = d->queue[--d->n_queue];
-    int state = elem->key; Token *tok = elem->val;
+    int state = KEY_STATE(elem->key), lm_state = KEY_LM(elem->key); Token *tok = elem->val;
     float cur_cost = tok->tot_cost;
     if (cur_cost >= cutoff) continue;
     delete_forward_links(d, tok);
@@ -295,10 +477,16 @@ static void process_nonemitting(Decoder *d, float cutoff) {
       if (arc->ilabel == 0) {
         d->cnt_Z++;
         float graph_cost = arc->w;
+        int next_lm = 0;
+        if (d->dlm) { /* biglm.h:448-451 */
+          float lm_score;
+          next_lm = next_lm_state(d->dlm, lm_state, arc->olabel, &lm_score);
+          graph_cost = arc->w + lm_score;
+        }
         float tot_cost = cur_cost + graph_cost;
         if (tot_cost < cutoff) {
           int changed = 0;
-          Elem *nt = find_or_add_token(d, arc->to, frame, tot_cost, tok, &changed);
+          Elem *nt = find_or_add_token(d, make_key(arc->to, next_lm), frame, tot_cost, tok, &changed);
           tok->links = new_link(d, nt->val, 0, arc->olabel, graph_cost, 0, tok->links);
           if (changed && g->si[arc->to].niepsilons != 0) queue_push(d, nt);
         }
@@ -325,33 +513,42 @@ static float process_emitting(Decoder *d) {
   Elem *final_toks = hl_clear(&d->toks);
   Elem *best_elem = NULL; float adaptive_beam; size_t tok_cnt = 0;
   float cur_cutoff = get_cutoff(d, final_toks, &tok_cnt, &adaptive_beam, &best_elem);
-  possibly_resize_hash(d, tok_cnt);
+  /* biglm: PossiblyResizeHash (biglm.h:335) is the BASE class's and grows the base class's own, unused
+   * `_toks`; the 64-bit-keyed list that holds the tokens keeps its constructor size (biglm.h:28,73) */
+  if (!d->dlm) possibly_resize_hash(d, tok_cnt);
   float next_cutoff = FLOAT_INF;
   if (best_elem) {
-    int state = best_elem->key; Token *tok = best_elem->val;
+    int state = KEY_STATE(best_elem->key), lm_state = KEY_LM(best_elem->key); Token *tok = best_elem->val;
     const Arc *arcs = g->arcs + g->off[state]; unsigned n = g->si[state].num_arcs;
     for (unsigned i = 0; i < n; ++i) {
       const Arc *arc = &arcs[i];
       if (arc->ilabel != 0) {
-        float tot_score = tok->tot_cost + arc->w - loglike(d, nnetframe, arc->ilabel);
+        float tot_score;
+        if (d->dlm) { /* biglm.h:350-353 */
+          float lm_score;
+          next_lm_state(d->dlm, lm_state, arc->olabel, &lm_score);
+          tot_score = lm_score + tok->tot_cost + arc->w - loglike(d, nnetframe, arc->ilabel);
+        } else tot_score = tok->tot_cost + arc->w - loglike(d, nnetframe, arc->ilabel);
         if (tot_score + adaptive_beam < next_cutoff) next_cutoff = tot_score + adaptive_beam;
       }
     }
   }
   if (g_order_free) {
     for (Elem *e = final_toks; e; e = e->tail) {
-      int state = e->key; Token *tok = e->val;
+      int state = KEY_STATE(e->key), lm_state = KEY_LM(e->key); Token *tok = e->val;
       if (!(tok->tot_cost <= cur_cutoff)) continue;
       const Arc *arcs = g->arcs + g->off[state]; unsigned n = g->si[state].num_arcs;
       for (unsigned i = 0; i < n; ++i)
         if (arcs[i].ilabel != 0) {
-          float tot_cost = tok->tot_cost + -loglike(d, nnetframe, arcs[i].ilabel) + arcs[i].w;
+          float graph_cost = arcs[i].w;
+          if (d->dlm) { float lm_score; next_lm_state(d->dlm, lm_state, arcs[i].olabel, &lm_score); graph_cost = arcs[i].w + lm_score; }
+          float tot_cost = tok->tot_cost + -loglike(d, nnetframe, arcs[i].ilabel) + graph_cost;
           if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
         }
     }
   }
   for (Elem *e = final_toks, *e_tail; e; e = e_tail) {
-    int state = e->key; Token *tok = e->val;
+    int state = KEY_STATE(e->key), lm_state = KEY_LM(e->key); Token *tok = e->val;
     if (tok->tot_cost <= cur_cutoff) {
       d->cnt_N++;
       const Arc *arcs = g->arcs + g->off[state]; unsigned n = g->si[state].num_arcs;
@@ -359,13 +556,19 @@ static float process_emitting(Decoder *d) {
         const Arc *arc = &arcs[i];
         if (arc->ilabel != 0) {
           d->cnt_E++;
-          float ac_cost = -loglike(d, nnetframe, arc->ilabel);
           float graph_cost = arc->w;
+          int next_lm = 0;
+          if (d->dlm) { /* biglm.h:377-380: the LM is asked before the acoustic score */
+            float lm_score;
+            next_lm = next_lm_state(d->dlm, lm_state, arc->olabel, &lm_score);
+            graph_cost = arc->w + lm_score;
+          }
+          float ac_cost = -loglike(d, nnetframe, arc->ilabel);
           float cur_cost = tok->tot_cost;
           float tot_cost = cur_cost + ac_cost + graph_cost;
           if (tot_cost >= next_cutoff) continue;
           else if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
-          Elem *nt = find_or_add_token(d, arc->to, frame + 1, tot_cost, tok, NULL);
+          Elem *nt = find_or_add_token(d, make_key(arc->to, next_lm), frame + 1, tot_cost, tok, NULL);
           tok->links = new_link(d, nt->val, arc->ilabel, arc->olabel, graph_cost, ac_cost, tok->links);
         }
       }
@@ -444,10 +647,17 @@ static void compute_final_costs(Decoder *d, int mark, int *any_final, float *fin
   int any = 0;
   for (const Elem *e = d->toks.list_head; e; e = e->tail) {
     Token *tok = e->val;
-    int fst_final = (e->key == d->g->final_state);
+    int fst_final = (KEY_STATE(e->key) == d->g->final_state);
     if (tok->tot_cost < best_cost) best_cost = tok->tot_cost;
-    if (mark) tok->is_final = 0;
-    if (mark && fst_final) { tok->is_final = 1; any = 1; if (tok->tot_cost < best_cost_with_final) best_cost_with_final = tok->tot_cost; }
+    if (mark) { tok->is_final = 0; tok->final_cost = 0.0f; }
+    if (d->dlm) {
+      /* biglm.h:160-215: the LM's final cost enters best_cost_with_final for EVERY token, final in the
+       * graph or not; only graph-final tokens are entered in final_costs */
+      float lm_final = dlm_final(d->dlm, KEY_LM(e->key));
+      float cost_with_final = tok->tot_cost + lm_final;
+      if (cost_with_final < best_cost_with_final) best_cost_with_final = cost_with_final;
+      if (mark && fst_final) { tok->is_final = 1; tok->final_cost = lm_final; any = 1; }
+    } else if (mark && fst_final) { tok->is_final = 1; any = 1; if (tok->tot_cost < best_cost_with_final) best_cost_with_final = tok->tot_cost; }
   }
   if (any_final) *any_final = any;
   if (final_relative_cost) {
@@ -468,7 +678,7 @@ static void prune_forward_links_final(Decoder *d) {
     changed = 0;
     for (Token *tok = d->active[fpo].toks; tok; tok = tok->next) {
       Link *link, *prev_link = NULL;
-      float final_cost = !d->any_final ? 0.0f : (tok->is_final ? 0.0f : FLOAT_INF);
+      float final_cost = !d->any_final ? 0.0f : (tok->is_final ? tok->final_cost : FLOAT_INF);
       float tok_extra_cost = tok->tot_cost + final_cost - d->final_best_cost;
       for (link = tok->links; link;) {
         Token *nt = link->next_tok;
@@ -511,7 +721,8 @@ static void init_decoding(Decoder *d) {
   Token *start_tok = new_token(d, 0.0f, 0.0f, NULL, NULL, NULL);
   start_tok->state = d->g->start;
   d->active[0].toks = start_tok;
-  hl_insert(&d->toks, d->g->start, start_tok);
+  if (d->dlm) dlm_reset(d->dlm); /* biglm.h:110-112: start pair = (graph start, _diff_lm.Start() == 0) */
+  hl_insert(&d->toks, make_key(d->g->start, 0), start_tok);
   d->num_frames_decoded = 0; /* set before the closure: it is not read there */
   process_nonemitting(d, d->cfg.beam);
   d->num_frames_decoded = 0;
@@ -561,7 +772,7 @@ void oracle_graph_free(void *gp) {
 /* Decode one utterance.  Same argument list and meaning as ref_decode() in
  * oracle/ref_driver.cc; `extra` (nullable, 8 x int64) receives
  * {N, E, Z, tokens created, links created, tie hops on best path, quirk hops, 0}. */
-int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, int stride,
+static int decode_impl(void *gp, const Config *rc, DiffLm *dlm, const float *loglikes, int T, int stride,
                      const int *tid2pdf, int n_tid, int chunk, int do_finalize, int use_final_probs,
                      int *path_ilabel, int *path_olabel, float *path_graph, float *path_ac,
                      int max_path, int *n_path, float *tot_score, float *lm_score, int *words,
@@ -572,7 +783,7 @@ int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, i
   (void)n_tid;
   Decoder D; memset(&D, 0, sizeof(D));
   Decoder *d = &D;
-  d->g = (const Graph *)gp; d->cfg = *rc;
+  d->g = (const Graph *)gp; d->cfg = *rc; d->dlm = dlm;
   d->toks.bucket_list_tail = NOBUCKET;
   d->tok_pool.elem_size = sizeof(Token); d->link_pool.elem_size = sizeof(Link);
   d->ll = loglikes; d->T = T; d->stride = stride; d->tid2pdf = tid2pdf; d->frames_ready = T;
@@ -587,7 +798,7 @@ int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, i
     for (const Elem *e_ = d->toks.list_head; e_; e_ = e_->tail) { ++n_; if (e_->val->tot_cost < b_) b_ = e_->val->tot_cost; } \
     frame_ntoks[idx] = n_; frame_best[idx] = b_; } \
     if (chunk == 1 && dump_frame == (idx) && dump_n) { int n_ = 0; \
-    for (const Elem *e_ = d->toks.list_head; e_; e_ = e_->tail) { if (n_ < dump_cap) { dump_states[n_] = e_->key; dump_costs[n_] = e_->val->tot_cost; } ++n_; } \
+    for (const Elem *e_ = d->toks.list_head; e_; e_ = e_->tail) { if (n_ < dump_cap) { dump_states[n_] = KEY_STATE(e_->key); dump_costs[n_] = e_->val->tot_cost; } ++n_; } \
     *dump_n = n_; } } while (0)
 
   init_decoding(d);
@@ -615,7 +826,7 @@ int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, i
     float best_cost = FLOAT_INF; Token *best_tok = NULL;
     for (Token *tok = d->active[d->n_active - 1].toks; tok; tok = tok->next) {
       float cost = tok->tot_cost;
-      if (use_final_probs && any_final) { if (!tok->is_final) cost = FLOAT_INF; }
+      if (use_final_probs && any_final) { if (!tok->is_final) cost = FLOAT_INF; else cost += tok->final_cost; }
       if (cost < best_cost) { best_cost = cost; best_tok = tok; }
     }
     if (best_tok) {
@@ -632,6 +843,7 @@ int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, i
           for (link = tok->backpointer->links; link; link = link->next)
             if (link->next_tok == tok) { il = link->ilabel; ol = link->olabel; gc = link->graph_cost; ac = link->acoustic_cost; break; }
           if (link && (tok->backpointer->tot_cost + ac) + gc != tok->tot_cost) quirk_hops++;
+          if (!link) quirk_hops += 1000000; /* "Error tracing best-path back" (base-inl.h:1187-1191): never expected */
         }
         if (n == cap) { cap *= 2; hi = (int *)realloc(hi, cap * sizeof(int)); ho = (int *)realloc(ho, cap * sizeof(int)); hg = (float *)realloc(hg, cap * sizeof(float)); ha = (float *)realloc(ha, cap * sizeof(float)); }
         hi[n] = il; ho[n] = ol; hg[n] = gc; ha[n] = ac; ++n;
@@ -651,7 +863,8 @@ int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, i
       ok = 1;
     }
   }
-  if (extra) { extra[0] = d->cnt_N; extra[1] = d->cnt_E; extra[2] = d->cnt_Z; extra[3] = d->cnt_tok_created; extra[4] = d->cnt_link_created; extra[5] = tie_hops; extra[6] = quirk_hops; extra[7] = 0; }
+  if (extra) { extra[0] = d->cnt_N; extra[1] = d->cnt_E; extra[2] = d->cnt_Z; extra[3] = d->cnt_tok_created; extra[4] = d->cnt_link_created; extra[5] = tie_hops; extra[6] = quirk_hops;
+               extra[7] = dlm ? ((int64_t)dlm->n_vec | ((int64_t)dlm->oob << 40)) : 0; }
 
   /* teardown */
   clear_active_tokens(d);
@@ -660,6 +873,39 @@ int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, i
   free(d->toks.blocks); free(d->toks.buckets);
   pool_destroy(&d->tok_pool); pool_destroy(&d->link_pool);
   free(d->active); free(d->queue); free(d->tmp);
+  return ok;
+}
+
+int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, int stride,
+                     const int *tid2pdf, int n_tid, int chunk, int do_finalize, int use_final_probs,
+                     int *path_ilabel, int *path_olabel, float *path_graph, float *path_ac,
+                     int max_path, int *n_path, float *tot_score, float *lm_score, int *words,
+                     int max_words, int *n_words, int *tids, int max_tids, int *n_tids,
+                     int *frame_ntoks, float *frame_best, int dump_frame, int *dump_states,
+                     float *dump_costs, int dump_cap, int *dump_n, int *num_toks_end,
+                     int *num_links_end, int64_t *extra) {
+  return decode_impl(gp, rc, NULL, loglikes, T, stride, tid2pdf, n_tid, chunk, do_finalize, use_final_probs, path_ilabel,
+                     path_olabel, path_graph, path_ac, max_path, n_path, tot_score, lm_score, words, max_words, n_words,
+                     tids, max_tids, n_tids, frame_ntoks, frame_best, dump_frame, dump_states, dump_costs, dump_cap,
+                     dump_n, num_toks_end, num_links_end, extra);
+}
+
+/* biglm: same arguments as ref_biglm_decode() in oracle/ref_driver.cc plus `fixed` (0: DiffArpaLm as
+ * written, 1: pair components) and `extra` (8 x int64: as oracle_decode_ex; [7] = LM pair states
+ * interned | (out-of-range LM access seen) << 40).  lm1 = old LM (rescaled by -1 at load), lm2 = new. */
+int oracle_biglm_decode(void *gp, const Config *rc, void *lm1, void *lm2, int fixed, const float *loglikes, int T,
+                        int stride, const int *tid2pdf, int n_tid, int chunk, int do_finalize, int use_final_probs,
+                        int *path_ilabel, int *path_olabel, float *path_graph, float *path_ac, int max_path,
+                        int *n_path, float *tot_score, float *lm_score, int *words, int max_words, int *n_words,
+                        int *tids, int max_tids, int *n_tids, int *frame_ntoks, float *frame_best,
+                        int *num_toks_end, int *num_links_end, int64_t *extra) {
+  DiffLm dlm;
+  dlm_init(&dlm, (const Lm *)lm1, (const Lm *)lm2, fixed);
+  int ok = decode_impl(gp, rc, &dlm, loglikes, T, stride, tid2pdf, n_tid, chunk, do_finalize, use_final_probs, path_ilabel,
+                       path_olabel, path_graph, path_ac, max_path, n_path, tot_score, lm_score, words, max_words, n_words,
+                       tids, max_tids, n_tids, frame_ntoks, frame_best, -1, NULL, NULL, 0, NULL, num_toks_end,
+                       num_links_end, extra);
+  dlm_free(&dlm);
   return ok;
 }
 
@@ -736,7 +982,7 @@ int oracle_raw_lattice(void *gp, const Config *rc, const float *loglikes, int T,
           float final_cost = 0.0f;
           int is_fin = 0;
           if (f == num_frames) {
-            if (use_final_probs && any_final) { if (t->is_final) { is_fin = 1; final_cost = 0.0f; } }
+            if (use_final_probs && any_final) { if (t->is_final) { is_fin = 1; final_cost = t->final_cost; } }
             else is_fin = 1;
           }
           if (s < max_states) { st_final[s] = is_fin; st_frame[s] = f; st_gstate[s] = t->state; st_cost[s] = t->tot_cost; }
