@@ -190,9 +190,91 @@ def openfst_goldens(ref):
     print("wrote openfst.npz: vector %d B, const %d B, flat %d B" % (len(vec), len(cst), len(flat)))
 
 
+def biglm_goldens(ref):
+    """biglm (BASELINE configs[3]): what the reference's OnlineLatticeDecoderMempoolBiglm returns
+    (kaldi-nnet3bin/kaldi-hclg-my-decoder-biglm.cc:55-60,80-102 call sequence: old LM rescaled by -1)
+    for two LM pairs -- bigram vs trigram, and a history-free unigram pair on which DiffArpaLm's
+    pair-id argument (newlm/diff-lm.h:80,86) makes no difference.  The LM files are the reference's
+    own conversions (Arpa2Fsa) of synthetic ARPA text; `lmwalk_*` are ComposeArpaLm::GetArc / Final
+    results on random (state, word) queries."""
+    lmsynth = importlib.import_module("asr-decoder_amd.lmsynth")
+    V, n_tid, n_pdf, T = 120, 600, 300, 40
+    g = synth.make_hclg_like(600, seed=11, n_tid=n_tid, n_words=V)
+    m = synth.default_tid2pdf(n_tid)
+    utts = [synth.make_loglikes(g, T, n_pdf, m, seed=s, mu=-2.2, sigma=1.0)[0] for s in range(4)]
+    gb, gpath = graph_bytes(g)
+    h = ref.load_graph(gpath)
+    pairs = {"ngram": (lmsynth.make_lm(V, 2, 60, 5, 0, 0, seed=21), lmsynth.make_lm(V, 3, 100, 8, 300, 4, seed=22)),
+             "unigram": (lmsynth.make_lm(V, 1, seed=23), lmsynth.make_lm(V, 1, seed=24))}
+    cfgs = [dict(beam=13.0, max_active=7000, min_active=0, lattice_beam=10.0),
+            dict(beam=9.0, max_active=300, min_active=50, lattice_beam=8.0, prune_interval=10),
+            dict(beam=16.0, max_active=2000, min_active=200, lattice_beam=10.0, hash_ratio=1.5)]
+    modes = [dict(trace=True), dict(chunk=0), dict(chunk=7, finalize=False), dict(chunk=0, finalize=False, use_final_probs=False)]
+    out = {"graph": gb, "n_utt": np.int32(len(utts)), "tid2pdf": np.asarray(m, np.int32)}
+    for ui, ll in enumerate(utts):
+        out["ll_%d" % ui] = np.asarray(ll, np.float32)
+    meta = {"cfgs": cfgs, "modes": modes, "pairs": list(pairs), "cases": []}
+    k = 0
+    rng = np.random.default_rng(9)
+    for pname, (old, new) in pairs.items():
+        lms = []
+        for tag, lm in (("old", old), ("new", new)):
+            base = "/tmp/_golden_lm_%s_%s" % (pname, tag)
+            with open(base + ".arpa", "w") as f:
+                f.write(lm.arpa_text())
+            with open(base + ".words", "w") as f:
+                f.write(lm.wordlist_text())
+            pyoracle.ref_arpa2fsa(ref, base + ".arpa", base + ".words", base + ".bin")
+            with open(base + ".bin", "rb") as f:
+                data = f.read()
+            assert data == lm.to_fsa().to_bytes(), "lmsynth.NgramLm.to_fsa() != the reference's Arpa2Fsa"
+            out["lm_%s_%s" % (pname, tag)] = np.frombuffer(data, np.uint8).copy()
+            L = pyoracle.Lm(ref, base + ".bin", -1.0 if tag == "old" else 1.0)
+            ns = lmsynth.Fsa.from_bytes(data).n_states
+            st = rng.integers(0, ns, 4000).astype(np.int32)
+            wd = rng.integers(1, V + 3, 4000).astype(np.int32)
+            nx, v1 = L.getarc_many(st, wd)
+            fs = np.arange(0, ns, max(1, ns // 500)).astype(np.int32)
+            out["lmwalk_%s_%s" % (pname, tag)] = np.stack([st, wd, nx, v1.view(np.int32)])
+            out["lmfinal_%s_%s" % (pname, tag)] = np.stack([fs, np.asarray([L.final(int(x)) for x in fs], np.float32).view(np.int32)])
+            out["lmstart_%s_%s" % (pname, tag)] = np.int32(L.start())
+            lms.append(L)
+        n_ok = 0
+        for ci, cd in enumerate(cfgs):
+            for mi, md in enumerate(modes):
+                for ui, ll in enumerate(utts):
+                    kw = dict(md)
+                    r = pyoracle.biglm_decode(ref, h, pyoracle.Config(**cd), lms[0], lms[1], ll, m, **kw)
+                    p = "c%d_" % k
+                    out[p + "ok"] = np.int32(r.ok)
+                    out[p + "words"] = r.words
+                    out[p + "tids"] = r.tids
+                    out[p + "scores"] = np.array([r.tot_score, r.lm_score], np.float32)
+                    out[p + "path_ilabel"] = r.path_ilabel
+                    out[p + "path_olabel"] = r.path_olabel
+                    out[p + "path_graph"] = r.path_graph
+                    out[p + "path_ac"] = r.path_ac
+                    out[p + "toks_links_end"] = np.array([r.num_toks_end, r.num_links_end], np.int32)
+                    if md.get("trace"):
+                        out[p + "frame_ntoks"] = r.frame_ntoks
+                        out[p + "frame_best"] = r.frame_best
+                    meta["cases"].append({"cfg": ci, "mode": mi, "utt": ui, "pair": pname})
+                    n_ok += int(r.ok)
+                    k += 1
+        print("biglm pair %s: %d cases so far, %d ok in this pair" % (pname, k, n_ok))
+        for L in lms:
+            L.free()
+    ref.free_graph(h)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "biglm_hclg600.npz"), **out)
+    print("wrote biglm_hclg600.npz: %d cases" % k)
+
+
 def main():
     pyoracle.build_ref()
     ref = pyoracle.RefDecoder()
+    if "--biglm-only" in sys.argv:
+        return biglm_goldens(ref)
     if "--openfst-only" in sys.argv:
         return openfst_goldens(ref)
     if "--lattice-only" in sys.argv:
@@ -265,6 +347,7 @@ def main():
               [ce[0]], [dict(trace=True, finalize=False), dict(chunk=0, finalize=False)])
     lattice_goldens(ref)
     openfst_goldens(ref)
+    biglm_goldens(ref)
 
 
 if __name__ == "__main__":
