@@ -56,6 +56,7 @@ struct wfst_graph {
   int device = 0;
   int32_t start = 0, final_state = 0, n_states = 0, n_arcs = 0;
   int32_t max_col = 0;  // largest log-likelihood column any arc reads
+  int32_t max_olabel = 0, min_olabel = 0;  // over all arcs (biglm: the LMs must know every word)
   std::vector<int32_t> ilabel_host;  // original ilabels (re-mapped when tid2pdf changes)
   DevBuf<int4> arcs;  // interleaved rows: header + arcs per state
   std::vector<int32_t> pos_host;  // row position of each original state id (sorted)
@@ -90,6 +91,32 @@ struct wfst_graph {
   }
 };
 
+struct wfst_lm {
+  int device = 0;
+  int32_t bos = 0, eos = 0, unk = 0, n_states = 0, n_arcs = 0, start = 0, start_arcs = 0;
+  DevBuf<int4> st;
+  DevBuf<int32_t> words;
+  DevBuf<int2> wt;
+  LmDev view() const {
+    LmDev L;
+    L.st = st.p;
+    L.words = words.p;
+    L.wt = wt.p;
+    L.n_states = n_states;
+    L.n_arcs = n_arcs;
+    L.bos = bos;
+    L.eos = eos;
+    L.start = start;
+    L.start_arcs = start_arcs;
+    return L;
+  }
+  ~wfst_lm() {
+    st.release();
+    words.release();
+    wt.release();
+  }
+};
+
 struct wfst_decoder {
   const wfst_graph *graph = nullptr;
   int device = 0;
@@ -102,6 +129,8 @@ struct wfst_decoder {
   DevBuf<int4> tok;
   DevBuf<int32_t> frame_off, bucket_cnt, eps_toki, eps_occ_list, eps_won_list, target, chan_list;
   DevBuf<int4> bucket, worklist, links, lat_toks;
+  DevBuf<unsigned long long> pair_keys, eps_keys;  // biglm
+  DevBuf<int32_t> tok_lm, bucket_lm;
   DevBuf<int32_t> link_off, link_mid;
   DevBuf<uint2> extra;
   DevBuf<LatArc> lat_arcs;
@@ -181,6 +210,7 @@ struct wfst_decoder {
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
+    pair_keys.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
     bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
@@ -336,6 +366,7 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
   // pass 2: rows
   std::vector<int4> ext((size_t)N, make_int4(0, -1, 0, 0));
   std::vector<int32_t> h_src((size_t)N, 0), h_il((size_t)N, kHeaderLabel), h_ol((size_t)N, 0);
+  int32_t max_ol = 0, min_ol = 0;
   off = 0;
   for (int32_t s = 0; s < n_states; ++s) {
     const uint32_t na = states[s].num_arcs, ne = states[s].niepsilons;
@@ -357,6 +388,8 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
       h_src[q] = (int32_t)((uint32_t)pos[s] | (i < ne ? 0x80000000u : 0u));
       h_il[q] = a.ilabel;
       h_ol[q] = a.olabel;
+      max_ol = std::max(max_ol, a.olabel);
+      min_ol = std::min(min_ol, a.olabel);
     }
     off += na;
   }
@@ -406,6 +439,8 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
   g->orig_final = final_state;
   g->n_states = n_states;
   g->n_arcs = n_arcs;
+  g->max_olabel = max_ol;
+  g->min_olabel = min_ol;
   g->ilabel_host.swap(h_il);
   g->pos_host.swap(pos);
   g->start_eps = next_eps[start];
@@ -484,6 +519,133 @@ void wfst_graph_free(wfst_graph *g) {
   delete g;
 }
 
+/* ------------------------------------------------------------------- LM */
+
+int wfst_lm_from_arrays(int32_t bos, int32_t eos, int32_t unk, int32_t n_states, const wfst_lm_state *states,
+                        int32_t n_arcs, const wfst_lm_arc *arcs, float scale, int device, wfst_lm **out) {
+  if (!out) return fail(WFST_E_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_states <= 0 || n_arcs < 0 || !states || (n_arcs > 0 && !arcs)) return fail(WFST_E_ARG, "empty LM or NULL arrays");
+  int ndev = wfst_device_count();
+  if (ndev <= 0) return fail(WFST_E_DEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(WFST_E_ARG, "device index out of range");
+  // the checks the reference leaves out (it indexes and follows whatever the file holds)
+  std::vector<int4> st((size_t)n_states);
+  int64_t off = 0;
+  for (int32_t s = 0; s < n_states; ++s) {
+    const wfst_lm_state &x = states[s];
+    if (x.arc_num < 0 || off + x.arc_num > n_arcs) return fail(WFST_E_FORMAT, "LM state arc counts inconsistent with the arc total");
+    if (x.backoff_id < 0 || x.backoff_id >= n_states) return fail(WFST_E_FORMAT, "LM back-off state out of range");
+    int4 v;
+    v.x = (int32_t)off;
+    v.y = x.arc_num;
+    const float bw = scale != 1.0f ? x.backoff_prob * scale : x.backoff_prob;  // Fsa::Rescale, arpa2fsa.cc:264-275
+    memcpy(&v.z, &bw, 4);
+    v.w = x.backoff_id;
+    st[(size_t)s] = v;
+    for (int32_t i = 0; i < x.arc_num; ++i) {
+      const wfst_lm_arc &a = arcs[off + i];
+      if (a.tostateid < 0 || a.tostateid >= n_states) return fail(WFST_E_FORMAT, "LM arc destination out of range");
+      if (s == 0 ? a.wordid != i : (i > 0 && arcs[off + i - 1].wordid >= a.wordid))
+        return fail(WFST_E_FORMAT, s == 0 ? "LM state 0 must hold arc k for word id k (arpa2fsa.cc:253-254)"
+                                          : "LM arcs of a state must be sorted by word id (arpa2fsa.h:194-210)");
+    }
+    off += x.arc_num;
+  }
+  if (off != n_arcs) return fail(WFST_E_FORMAT, "sum of LM arc counts != total arcs");
+  for (int32_t s = 0; s < n_states; ++s) {  // every back-off chain reaches the empty history
+    int32_t t = s, hops = 0;
+    while (t != 0 && hops <= 64) { t = states[t].backoff_id; ++hops; }
+    if (t != 0) return fail(WFST_E_FORMAT, "LM back-off chain does not end in state 0");
+  }
+  if (bos < 0 || bos >= states[0].arc_num || eos < 0 || eos >= states[0].arc_num)
+    return fail(WFST_E_FORMAT, "LM <s> / </s> ids have no arc from the empty-history state");
+  std::vector<int32_t> words((size_t)std::max(n_arcs, 1));
+  std::vector<int2> wt((size_t)std::max(n_arcs, 1));
+  for (int32_t a = 0; a < n_arcs; ++a) {
+    words[(size_t)a] = arcs[a].wordid;
+    const float w = scale != 1.0f ? arcs[a].weight * scale : arcs[a].weight;
+    int2 v;
+    memcpy(&v.x, &w, 4);
+    v.y = arcs[a].tostateid;
+    wt[(size_t)a] = v;
+  }
+  HIP_TRY(hipSetDevice(device));
+  wfst_lm *lm = new wfst_lm();
+  lm->device = device;
+  lm->bos = bos;
+  lm->eos = eos;
+  lm->unk = unk;
+  lm->n_states = n_states;
+  lm->n_arcs = n_arcs;
+  lm->start_arcs = states[0].arc_num;
+  lm->start = arcs[bos].tostateid;  // ComposeArpaLm::Start: the arc of state 0 for <s> (compose-arpalm.cc:5-13)
+  hipError_t e;
+  if ((e = lm->st.alloc(st.size())) != hipSuccess || (e = lm->words.alloc(words.size())) != hipSuccess ||
+      (e = lm->wt.alloc(wt.size())) != hipSuccess ||
+      (e = hipMemcpy(lm->st.p, st.data(), st.size() * sizeof(int4), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(lm->words.p, words.data(), words.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(lm->wt.p, wt.data(), wt.size() * sizeof(int2), hipMemcpyHostToDevice)) != hipSuccess) {
+    delete lm;
+    return fail(WFST_E_DEVICE, std::string("LM upload: ") + hipGetErrorString(e));
+  }
+  *out = lm;
+  return WFST_OK;
+}
+
+int wfst_lm_load(const char *path, float scale, int device, wfst_lm **out) {
+  if (!path || !out) return fail(WFST_E_ARG, "NULL argument");
+  *out = nullptr;
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return fail(WFST_E_IO, std::string("cannot open LM file ") + path);
+  fseek(fp, 0, SEEK_END);
+  const long fsize = ftell(fp);
+  fseek(fp, 0, SEEK_SET);
+  int32_t hdr[3], n_states = 0, n_arcs = 0;
+  uint64_t orders = 0;
+  std::vector<wfst_lm_state> st;
+  std::vector<wfst_lm_arc> ar;
+  int rc = WFST_OK;
+  // sizes are checked against the file before anything is allocated
+  if (fread(hdr, 4, 3, fp) != 3 || fread(&orders, 8, 1, fp) != 1 || orders > 64 ||
+      fseek(fp, (long)(4 * orders), SEEK_CUR) != 0 || fread(&n_states, 4, 1, fp) != 1)
+    rc = fail(WFST_E_IO, "truncated LM file (header)");
+  else if (n_states <= 0 || (int64_t)n_states * 12 > fsize)
+    rc = fail(WFST_E_FORMAT, "LM state count inconsistent with the file size");
+  else {
+    st.resize((size_t)n_states);
+    if (fread(st.data(), sizeof(wfst_lm_state), st.size(), fp) != st.size() || fread(&n_arcs, 4, 1, fp) != 1)
+      rc = fail(WFST_E_IO, "truncated LM file (states)");
+    else if (n_arcs < 0 || (int64_t)n_arcs * 12 > fsize)
+      rc = fail(WFST_E_FORMAT, "LM arc count inconsistent with the file size");
+    else {
+      ar.resize((size_t)n_arcs);
+      if (fread(ar.data(), sizeof(wfst_lm_arc), ar.size(), fp) != ar.size()) rc = fail(WFST_E_IO, "truncated LM file (arcs)");
+    }
+  }
+  fclose(fp);
+  if (rc != WFST_OK) return rc;
+  return wfst_lm_from_arrays(hdr[0], hdr[1], hdr[2], n_states, st.data(), n_arcs, ar.data(), scale, device, out);
+}
+
+int wfst_lm_info(const wfst_lm *lm, int32_t *bos, int32_t *eos, int32_t *n_states, int32_t *n_arcs, int32_t *n_words,
+                 int64_t *device_bytes) {
+  if (!lm) return fail(WFST_E_ARG, "NULL LM");
+  if (bos) *bos = lm->bos;
+  if (eos) *eos = lm->eos;
+  if (n_states) *n_states = lm->n_states;
+  if (n_arcs) *n_arcs = lm->n_arcs;
+  if (n_words) *n_words = lm->start_arcs;
+  if (device_bytes) *device_bytes = (int64_t)(lm->st.bytes() + lm->words.bytes() + lm->wt.bytes());
+  return WFST_OK;
+}
+
+void wfst_lm_free(wfst_lm *lm) {
+  if (!lm) return;
+  (void)hipSetDevice(lm->device);
+  delete lm;
+}
+
 /* -------------------------------------------------------------- decoder */
 
 static int check_config(const wfst_config *c) {  // LatticeFasterDecoderConfig::Check, conf.h:62-67
@@ -502,6 +664,12 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
 int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
                            const wfst_limits *limits, const wfst_options *options, void *hip_stream,
                            wfst_decoder **out) {
+  return wfst_decoder_create_biglm(g, cfg, n_channels, limits, options, nullptr, nullptr, hip_stream, out);
+}
+
+int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
+                              const wfst_limits *limits, const wfst_options *options, const wfst_lm *old_lm,
+                              const wfst_lm *new_lm, void *hip_stream, wfst_decoder **out) {
   if (!out) return fail(WFST_E_ARG, "out is NULL");
   *out = nullptr;
   if (!g || !cfg || n_channels <= 0) return fail(WFST_E_ARG, "NULL graph/config or n_channels <= 0");
@@ -517,8 +685,19 @@ int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t 
       O.insert_workgroups < 1 || O.upload_slice_frames < 0)
     return fail(WFST_E_ARG, "wfst_options field out of range");
   HIP_TRY(hipSetDevice(g->device));
-  wfst_limits L = {0, 0, 0, 0};
+  wfst_limits L = {0, 0, 0, 0, 0};
   if (limits) L = *limits;
+  const bool big = old_lm != nullptr || new_lm != nullptr;
+  if (big) {
+    if (!old_lm || !new_lm) return fail(WFST_E_ARG, "biglm needs both LMs");
+    if (old_lm->device != g->device || new_lm->device != g->device) return fail(WFST_E_ARG, "the LMs must be on the graph's device");
+    if (L.lattice_links > 0) return fail(WFST_E_ARG, "biglm decoders are best-path only (lattice_links must be 0)");
+    const int32_t nw = std::min(old_lm->start_arcs, new_lm->start_arcs);
+    if (g->min_olabel < 0 || g->max_olabel >= nw)
+      return fail(WFST_E_FORMAT, "the graph has output label " + std::to_string(g->max_olabel) + " but the LMs' empty-history state only has arcs for word ids below " + std::to_string(nw));
+    if (L.lm_pairs <= 0) L.lm_pairs = 262144;
+    if (L.lm_pairs > (1ll << 28)) return fail(WFST_E_ARG, "lm_pairs too large");
+  }
   if (L.max_frames <= 0) L.max_frames = 4096;
   if (L.max_tokens_per_frame <= 0) L.max_tokens_per_frame = 32768;
   if (L.arena_tokens <= 0) L.arena_tokens = 4194304;
@@ -546,7 +725,15 @@ int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t 
     }
     d->own_stream = true;
   }
-  const size_t B = (size_t)n_channels, ecap = (size_t)std::max(1, g->n_eps_targets);
+  size_t pair_cap = 0;
+  const size_t B = (size_t)n_channels;
+  size_t ecap = (size_t)std::max(1, g->n_eps_targets);
+  if (big) {  // hashed epsilon table (tokens of one frame on epsilon-target states) and LM pair table: powers of two
+    ecap = 1024;
+    while (ecap < 4 * (size_t)L.max_tokens_per_frame) ecap <<= 1;
+    pair_cap = 1024;
+    while (pair_cap < (size_t)L.lm_pairs + (size_t)L.lm_pairs / 3 + 1) pair_cap <<= 1;  // stays below 3/4 full
+  }
   int64_t lat_arc_cap = 0, lat_tok_cap = 0;
   const size_t fo = (size_t)L.max_frames + 2;
   hipError_t e = hipSuccess;
@@ -562,6 +749,12 @@ int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t 
   A(d->eps_occ_list.alloc(B * (size_t)L.max_tokens_per_frame));
   A(d->eps_won_list.alloc(B * (size_t)L.max_tokens_per_frame));
   A(d->worklist.alloc(B * 2 * (size_t)L.max_tokens_per_frame));
+  if (big) {
+    A(d->pair_keys.alloc(B * pair_cap));
+    A(d->eps_keys.alloc(B * ecap));
+    A(d->tok_lm.alloc(B * (size_t)L.arena_tokens));
+    A(d->bucket_lm.alloc(B * (size_t)n_part * (size_t)bucket_cap));
+  }
   if (L.lattice_links > 0) {
     A(d->links.alloc(B * (size_t)L.lattice_links));
     A(d->link_off.alloc(B * ((size_t)L.max_frames + 3)));
@@ -592,8 +785,10 @@ int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t 
   if (e == hipSuccess) A(hipMemsetAsync(d->fctl.p, 0, d->fctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->dbg_t.p, 0, d->dbg_t.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->eps_vals.p, 0xFF, d->eps_vals.bytes(), d->stream));
-  if (e == hipSuccess && lds_slots * (L.lattice_links > 0 ? 16 : 12) > 65536)
-    A((hipError_t)insert_kernel_set_lds(lds_slots * (L.lattice_links > 0 ? 16 : 12)));
+  if (e == hipSuccess && big) A(hipMemsetAsync(d->eps_keys.p, 0xFF, d->eps_keys.bytes(), d->stream));
+  if (e == hipSuccess && big) A(hipMemsetAsync(d->pair_keys.p, 0xFF, d->pair_keys.bytes(), d->stream));
+  if (e == hipSuccess && lds_slots * ((L.lattice_links > 0 || big) ? 16 : 12) > 65536)
+    A((hipError_t)insert_kernel_set_lds(lds_slots * ((L.lattice_links > 0 || big) ? 16 : 12)));
 
   if (e == hipSuccess) A(hipMemsetAsync(d->target.p, 0, d->target.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->ll_base.p, 0, d->ll_base.bytes(), d->stream));
@@ -625,6 +820,19 @@ int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t 
   D.lat_tok_cap = (int32_t)lat_tok_cap;
   D.link_cap = L.lattice_links;
   D.lattice = L.lattice_links > 0 ? 1 : 0;
+  D.big = big ? 1 : 0;
+  if (big) {
+    D.lm_old = old_lm->view();
+    D.lm_new = new_lm->view();
+  } else {
+    memset(&D.lm_old, 0, sizeof(D.lm_old));
+    memset(&D.lm_new, 0, sizeof(D.lm_new));
+  }
+  D.pair_keys = d->pair_keys.p;
+  D.pair_cap = (int32_t)pair_cap;
+  D.tok_lm = d->tok_lm.p;
+  D.bucket_lm = d->bucket_lm.p;
+  D.eps_keys = d->eps_keys.p;
   D.fctl = d->fctl.p;
   D.dbg_t = d->dbg_t.p;
   D.tiles = d->tiles.p;
@@ -982,6 +1190,7 @@ static int check_ctl_errors(wfst_decoder *d) {
       if (e & kErrFramesFull) m += " frames (max_frames)";
       if (e & kErrBucketFull) m += " candidate bucket (max_tokens_per_frame)";
       if (e & kErrLinksFull) m += " forward links (lattice_links)";
+      if (e & kErrPairsFull) m += " LM pair states (lm_pairs)";
       return fail(WFST_E_CAPACITY, m);
     }
   }

@@ -45,6 +45,22 @@ struct GraphDev {
   int32_t n_eps_targets;
 };
 
+// ---- LM automaton in HBM (biglm, BASELINE configs[3]): the reference's Fsa (newlm/arpa2fsa.h:216-247) ----
+// st[s]    {first arc, arc count, back-off weight bits, back-off state}
+// words[a] word id of arc a (the arcs of a state are word-id sorted: binary search, arpa2fsa.h:194-210;
+//          state 0, the empty history, is indexed directly by word id, arpa2fsa.cc:253-254)
+// wt[a]    {weight bits, destination state}
+// Weights are natural-log probabilities, already rescaled (the old LM by -1).
+struct LmDev {
+  const int4 *st;
+  const int32_t *words;
+  const int2 *wt;
+  int32_t n_states, n_arcs;
+  int32_t bos, eos;
+  int32_t start;       // ComposeArpaLm::Start(): the state after <s> (compose-arpalm.cc:5-13)
+  int32_t start_arcs;  // arcs of state 0 = word ids it can be asked for
+};
+
 constexpr int kEpsBits = 12;
 constexpr int kFlatMax = 4;  // paths of a flattened epsilon closure (3 bits in the header word)
 constexpr uint32_t kEpsMask = (1u << kEpsBits) - 1;
@@ -65,7 +81,7 @@ constexpr unsigned long long kEmptyVal = ~0ull;
 
 // error bits (ChanCtl::error)
 constexpr int kErrTableFull = 1, kErrArenaFull = 2, kErrFrontierFull = 4, kErrWorklistFull = 8,
-              kErrFramesFull = 16, kErrBucketFull = 32, kErrLinksFull = 64;
+              kErrFramesFull = 16, kErrBucketFull = 32, kErrLinksFull = 64, kErrPairsFull = 128;
 
 // ---- per-channel control block (one 128-byte line each) ----------------------------------
 struct __attribute__((aligned(128))) ChanCtl {
@@ -89,7 +105,8 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t lat_arcs;      // lattice mode, after lattice_prune_kernel: surviving links in lat_arcs[]
   int32_t lat_toks;      //   "   surviving tokens in lat_toks[]
   int32_t tiles_left;    // expansion tiles of the frame not finished yet (the last one plans the insert items)
-  unsigned long long pad1;
+  int32_t pair_count;    // biglm: LM pair states interned since InitDecoding (atomicAdd)
+  int32_t pad1;
 };
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
 
@@ -189,6 +206,23 @@ struct DecoderDev {
   // config (LatticeFasterDecoderConfig)
   float beam, lattice_beam, beam_delta;
   int32_t max_active, min_active, prune_interval;
+  // biglm mode (wfst_decoder_create_biglm): a token is identified by (graph row, LM pair state), the
+  // reference's 64-bit PairId (my-decoder/online-decoder-mempool-base-biglm.h:77-90).
+  //   pair_keys[c][pair_cap]  the channel's LM pair-state table, DiffArpaLm's _state_map/_state_vec
+  //                           (newlm/diff-lm.h:92-103) as one open-addressed array: slot = pair id,
+  //                           value = old-LM state | new-LM state << 32; emptied by InitDecoding
+  //                           (DiffArpaLm::Reset)
+  //   tok_lm[c][arena_cap]    pair id of each token;  bucket_lm[c][P][bucket_cap] of each candidate record
+  //   eps_keys[c][ecap]       the epsilon table is HASHED in this mode (the state alone no longer
+  //                           identifies a token): open-addressed keys (row | pair << 32) beside
+  //                           eps_vals / eps_toki, ecap a power of two
+  int32_t big;
+  LmDev lm_old, lm_new;
+  unsigned long long *pair_keys;
+  int32_t pair_cap;             // power of two
+  int32_t *tok_lm;
+  int32_t *bucket_lm;
+  unsigned long long *eps_keys;
   unsigned long long *dbg_t;  // [64] phase timers (WFST_DBG & 32): sums, maxima, counts
   int32_t dbg;  // WFST_DBG ablation bits (timing experiments only; results are wrong when set)
 };

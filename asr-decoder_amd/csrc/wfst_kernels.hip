@@ -27,6 +27,8 @@
 // Float arithmetic follows the reference's operation order exactly (compiled with
 // -ffp-contract=off): tot = (cur + (-loglike)) + graph; seed = (cur + graph) - loglike.
 // There is no MFMA here: the path is irregular graph traversal, bound by HBM/L2 request rate.
+#include <type_traits>
+
 #include "wfst_device.h"
 
 namespace wfst {
@@ -73,6 +75,120 @@ __device__ __forceinline__ uint32_t hash32(int32_t s) { return (uint32_t)s * 265
 __device__ __forceinline__ int part_of(uint32_t h, int log2part) { return log2part ? (int)(h >> (32 - log2part)) : 0; }
 __device__ __forceinline__ uint32_t lds_slot_of(uint32_t h, int log2part, int log2lds) {
   return (h >> (32 - log2part - log2lds)) & ((1u << log2lds) - 1u);
+}
+
+// =========================================================================================
+// biglm (BASELINE configs[3]): on-the-fly LM rescoring.  A token's identity is (graph row, LM pair
+// state) -- the reference's PairId (my-decoder/online-decoder-mempool-base-biglm.h:77-90) -- and every
+// arc with an output label adds cost_newLM(word | history) - cost_oldLM(word | history), each LM
+// walked from its OWN state (DiffArpaLm::GetArc with the pair's components, newlm/diff-lm.h:63-111;
+// the reference text hands the pair id to both LMs, :80,86 -- oracle/wfst_oracle.c, "fixed" mode).
+// =========================================================================================
+__device__ __forceinline__ uint32_t hash_big(int32_t row, int32_t pair) {
+  uint32_t h = (uint32_t)row * 2654435761u;
+  h ^= ((uint32_t)pair + 0x9E3779B9u) * 0x85EBCA6Bu;
+  h ^= h >> 15;
+  return h * 0x2C1B3C6Du;
+}
+__device__ __forceinline__ u64 big_key(int32_t row, int32_t pair) { return (u64)(uint32_t)row | ((u64)(uint32_t)pair << 32); }
+
+// Fsa::GetArc (newlm/arpa2fsa.cc:244-262): the arc of LM state `id` for `word`, false if the state
+// has none (the caller backs off).  State 0 (empty history) is indexed by word id directly
+// (SearchStartArc, arpa2fsa.h:211-214; wfst_decoder_create_biglm checks the graph's labels against
+// its arc count); the others by binary search over their word-id sorted arcs (SearchArc, :194-210).
+__device__ __forceinline__ bool fsa_getarc(const LmDev &L, int id, int word, float *w, int *to) {
+  const int4 st = L.st[id];
+  int a = -1;
+  if (id == 0) {
+    a = st.x + word;
+  } else {
+    int lo = 0, hi = st.y - 1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const int wd = L.words[st.x + mid];
+      if (wd > word) hi = mid - 1;
+      else if (wd < word) lo = mid + 1;
+      else { a = st.x + mid; break; }
+    }
+    if (a < 0) return false;
+  }
+  const int2 x = L.wt[a];
+  *w = __int_as_float(x.x);
+  *to = x.y;
+  return true;
+}
+// ComposeArpaLm::GetArc (newlm/compose-arpalm.cc:52-70): back off until the word is found; the cost
+// is minus the sum of the back-off weights and the arc weight, summed in that order.
+__device__ __forceinline__ void lm_getarc(const LmDev &L, int s, int word, int *next, float *value1) {
+  float weight = 0.0f, w_arc = 0.0f;
+  int to = 0;
+  while (!fsa_getarc(L, s, word, &w_arc, &to)) {
+    const int4 st = L.st[s];
+    w_arc = __int_as_float(st.z);
+    s = st.w;
+    weight += w_arc;
+  }
+  weight += w_arc;
+  *value1 = -1 * weight;
+  *next = to;
+}
+// ComposeArpaLm::Final (compose-arpalm.cc:15-29)
+__device__ __forceinline__ float lm_final_cost(const LmDev &L, int s) {
+  int next;
+  float v;
+  lm_getarc(L, s, L.eos, &next, &v);
+  return v;
+}
+__device__ __forceinline__ uint32_t hash_pair(int s1, int s2) {
+  uint32_t h = (uint32_t)s1 * 7853u + (uint32_t)s2;  // PairHasher, util/stl-util.h:8-17 ...
+  h *= 2654435761u;                                  // ... scrambled for an open-addressed table
+  return h ^ (h >> 15);
+}
+// DiffArpaLm's _state_map.insert + _state_vec.push_back (newlm/diff-lm.h:92-103): the id of the pair
+// (old-LM state, new-LM state), allocating it if new.  One open-addressed array per channel, id =
+// slot; all accesses are agent-scope atomics (workgroups on other XCDs intern into the same table).
+__device__ int pair_intern(const DecoderDev &D, int c, ChanCtl *ctl, int s1, int s2) {
+  u64 *keys = D.pair_keys + (size_t)c * D.pair_cap;
+  const u64 key = (u64)(uint32_t)s1 | ((u64)(uint32_t)s2 << 32);
+  const uint32_t mask = (uint32_t)D.pair_cap - 1u;
+  uint32_t slot = hash_pair(s1, s2) & mask;
+  for (int q = 0; q < D.pair_cap; ++q) {
+    u64 k = ld_agent(&keys[slot]);
+    if (k == kEmptyVal) {
+      k = atomicCAS(&keys[slot], kEmptyVal, key);
+      if (k == kEmptyVal) {
+        if (atomicAdd(&ctl->pair_count, 1) >= (D.pair_cap >> 2) * 3) atomicOr(&ctl->error, kErrPairsFull);
+        return (int)slot;
+      }
+    }
+    if (k == key) return (int)slot;
+    slot = (slot + 1) & mask;
+  }
+  atomicOr(&ctl->error, kErrPairsFull);
+  return 0;
+}
+__device__ int pair_find(const DecoderDev &D, int c, int s1, int s2) {  // -1: never interned
+  const u64 *keys = D.pair_keys + (size_t)c * D.pair_cap;
+  const u64 key = (u64)(uint32_t)s1 | ((u64)(uint32_t)s2 << 32);
+  const uint32_t mask = (uint32_t)D.pair_cap - 1u;
+  uint32_t slot = hash_pair(s1, s2) & mask;
+  for (int q = 0; q < D.pair_cap; ++q) {
+    const u64 k = ld_agent(&keys[slot]);
+    if (k == key) return (int)slot;
+    if (k == kEmptyVal) return -1;
+    slot = (slot + 1) & mask;
+  }
+  return -1;
+}
+// NextLmState (biglm.h:54-70) for a non-epsilon output label: lm_score = Times(w_old, w_new).Value1();
+// the LM states reached are returned for the caller to intern (or not: the next_cutoff seed and the
+// traceback only need the score).
+__device__ __forceinline__ float lm_step(const DecoderDev &D, int c, int pair, int olabel, int *n1, int *n2) {
+  const u64 pk = ld_agent(&D.pair_keys[(size_t)c * D.pair_cap + pair]);
+  float w1, w2;
+  lm_getarc(D.lm_old, (int)(uint32_t)pk, olabel, n1, &w1);
+  lm_getarc(D.lm_new, (int)(uint32_t)(pk >> 32), olabel, n2, &w2);
+  return w1 + w2;
 }
 
 // debug phase timers (WFST_DBG & 32): slot k accumulates {sum, max, count} of 100 MHz ticks
@@ -168,6 +284,8 @@ constexpr int kTileTokens = kExpandThreads * kTokPerThread;  // frontier tokens 
 // counter, so a channel with 8x the tokens simply owns 8x the tiles (per-frame token counts are
 // heavy-tailed across a batch; a fixed share of workgroups per channel made every frame wait for
 // the heaviest one).
+// kBig = biglm mode (the plain instantiation carries none of it).
+template <bool kBig>
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, int group, int par) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   FrameCtl *fc = D.fctl + group;
@@ -181,6 +299,8 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
   __shared__ int s_wsum[kExpandThreads / 64];
   __shared__ int s_cnt[64], s_lbase[65], s_gbase[64];
   __shared__ int4 s_rec[kChunk];
+  __shared__ int s_lm[kBig ? kTileTokens : 1];    // biglm: LM pair state of each token of the tile
+  __shared__ int s_rec_lm[kBig ? kChunk : 1];     //        and of each sorted candidate
   __shared__ int s_ticket;
 
   __shared__ int s_last;
@@ -203,6 +323,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
     const float cutoff = td.cutoff, ab = td.adaptive_beam;
     const float *llrow = td.llrow;
     int4 *bucket = D.bucket + (size_t)c * P * bcap;
+    int32_t *bucket_lm = kBig ? D.bucket_lm + (size_t)c * P * bcap : nullptr;
     int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
     u64 nN = 0, nE = 0, nR = 0;
     {
@@ -215,6 +336,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
     for (int j = 0; j < kTokPerThread; ++j) {
       const int i = tid * kTokPerThread + j;
       tk[j] = i < n ? tok[i] : make_int4(0, 0x7F800000, 0, 0);
+      if constexpr (kBig) s_lm[i] = i < n ? D.tok_lm[(size_t)c * D.arena_cap + fbegin + i] : 0;
     }
 #pragma unroll
     for (int j = 0; j < kTokPerThread; ++j) {
@@ -266,6 +388,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
     const int tok0 = fbegin;  // arena index of the tile's first token
     for (int j0 = 0; j0 < total; j0 += kChunk) {
       int4 rec[kCandPerThread];
+      int rec_lm[kCandPerThread];
       float tot[kCandPerThread];
       float tmin = kInf;
 #pragma unroll
@@ -280,8 +403,21 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
           }
           const int a = s_arcbeg[lo] + (j - s_base[lo]);
           const int4 arc = D.g.arcs[a];
+          float graph_cost = __int_as_float(arc.z);
+          rec_lm[k] = 0;
+          if constexpr (kBig) {  // biglm.h:377-388: graph_cost = arc weight + lm_score, next LM state into the key
+            const int ol = D.g.arc_olabel[a];
+            float lm_score = 0.0f;
+            rec_lm[k] = s_lm[lo];
+            if (ol != 0) {
+              int n1, n2;
+              lm_score = lm_step(D, c, s_lm[lo], ol, &n1, &n2);
+              rec_lm[k] = pair_intern(D, c, ctl, n1, n2);
+            }
+            graph_cost = __int_as_float(arc.z) + lm_score;
+          }
           const float ac_cost = -llrow[arc.x];                         // base-inl.h:326
-          tot[k] = (s_cost[lo] + ac_cost) + __int_as_float(arc.z);      // base-inl.h:329
+          tot[k] = (s_cost[lo] + ac_cost) + graph_cost;                 // base-inl.h:329
           rec[k] = make_int4(arc.w, __float_as_int(tot[k]), tok0 + lo, (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
           tmin = fminf(tmin, tot[k]);
         }
@@ -301,7 +437,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
       for (int k = 0; k < kCandPerThread; ++k) {
         part[k] = -1;
         if (tot[k] < bound) {
-          part[k] = part_of(hash32(rec[k].x), log2part);
+          part[k] = part_of(kBig ? hash_big(rec[k].x, rec_lm[k]) : hash32(rec[k].x), log2part);
           rank[k] = atomicAdd(&s_cnt[part[k]], 1);
         }
       }
@@ -329,15 +465,21 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
       if (tid == 0) dbg_phase(D, 14, tq);
 #pragma unroll
       for (int k = 0; k < kCandPerThread; ++k)
-        if (part[k] >= 0) s_rec[s_lbase[part[k]] + rank[k]] = rec[k];
+        if (part[k] >= 0) {
+          s_rec[s_lbase[part[k]] + rank[k]] = rec[k];
+          if constexpr (kBig) s_rec_lm[s_lbase[part[k]] + rank[k]] = rec_lm[k];
+        }
       __syncthreads();
       const int npass = s_lbase[64];
       nR += (tid == 0) ? (u64)npass : 0;
       for (int q = tid; q < npass; q += kExpandThreads) {
         const int4 r = s_rec[q];
-        const int p = part_of(hash32(r.x), log2part);
+        const int p = part_of(kBig ? hash_big(r.x, s_rec_lm[q]) : hash32(r.x), log2part);
         const int gi = s_gbase[p] + (q - s_lbase[p]);
-        if (gi < bcap) bucket[(size_t)p * bcap + gi] = r;
+        if (gi < bcap) {
+          bucket[(size_t)p * bcap + gi] = r;
+          if constexpr (kBig) bucket_lm[(size_t)p * bcap + gi] = s_rec_lm[q];
+        }
       }
       __syncthreads();
       if (tid == 0) dbg_phase(D, 15, tq);
@@ -377,14 +519,17 @@ constexpr int kInsertUnroll = 4;
 // insert_kernel: a fixed grid of workgroups pulls the planned items (first gridDim.x statically,
 // then by ticket); 512 threads, dynamic LDS = lds_slots * 12 bytes (16 in lattice mode).
 // kLat = lattice mode (forward links recorded); the best-path instantiation carries none of it.
-template <bool kLat>
+// kBig = biglm mode: 64-bit keys (graph row | LM pair state << 32), LDS = lds_slots * 16 bytes.
+template <bool kLat, bool kBig>
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, int group, int par) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int SLmax = D.lds_slots;
+  typedef typename std::conditional<kBig, u64, int32_t>::type KeyT;
+  const KeyT kNoKey = (KeyT)~(KeyT)0;  // == kEmptyKey for the 32-bit table
   u64 *vals = reinterpret_cast<u64 *>(smem);
-  int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)SLmax * 8);
-  int32_t *tidx = reinterpret_cast<int32_t *>(smem + (size_t)SLmax * 12);  // lattice mode only
+  KeyT *keys = reinterpret_cast<KeyT *>(smem + (size_t)SLmax * 8);
+  int32_t *tidx = reinterpret_cast<int32_t *>(smem + (size_t)SLmax * (8 + sizeof(KeyT)));  // lattice mode only
   // one struct, a multiple of 16 bytes, so the dynamic LDS region behind it stays 16-byte aligned
   // (64-bit LDS atomics on a misaligned table are replayed: cdna_hip_programming.md Guideline 17)
   struct __attribute__((aligned(16))) InsertShared {
@@ -402,8 +547,9 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   const int P = D.n_part;
 
   for (int it = blockIdx.x; it < n_items;) {
-  const uint32_t item = (uint32_t)D.items[(size_t)group * D.item_cap + (it < n_heavy ? it : D.item_cap - 1 - (it - n_heavy))];
-  const int c = (int)(item >> 16), g0 = (int)((item >> 8) & 0xFF), G = (int)(item & 0xFF);
+  // (signed decode: channels are < 32768, wfst_decoder_create_ex; the unsigned spelling costs 12 VGPRs and a wave of occupancy)
+  const int item = D.items[(size_t)group * D.item_cap + (it < n_heavy ? it : D.item_cap - 1 - (it - n_heavy))];
+  const int c = item >> 16, g0 = (item >> 8) & 0xFF, G = item & 0xFF;
   ChanCtl *ctl = D.ctl + c;
   int n = 0;
   {
@@ -423,6 +569,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   while ((1 << log2g) < G) ++log2g;
   const int log2grp = D.log2part - log2g;  // hash bits that select this group of partitions
   const int4 *bucket0 = D.bucket + ((size_t)c * P + g0) * D.bucket_cap;
+  const int32_t *bucket_lm0 = kBig ? D.bucket_lm + ((size_t)c * P + g0) * D.bucket_cap : nullptr;
   const float cutoff = o2f(ctl->bound);  // FINAL next_cutoff of this frame
   // table sized to the load: the smallest power of two >= 4 n (records >= distinct states)
   int log2sl = 6;
@@ -443,8 +590,9 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   const int sub_shift = 32 - log2grp - log2sl - log2sub;
   if (sub_shift < 0 && tid == 0) atomicOr(&ctl->error, kErrTableFull);
   __syncthreads();
-  // logical record i of the group -> (bucket, offset)
-  auto load_rec = [&](int i) -> int4 {
+  // logical record i of the group -> (bucket, offset); *lm = its LM pair state (biglm)
+  auto load_rec = [&](int i, int *lm) -> int4 {
+    *lm = 0;
     if (i >= n) return make_int4(0, 0x7F800000, 0, 0);  // cost +inf: never below a cutoff
     int b = 0;
     if (G > 1) {
@@ -455,14 +603,21 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
       }
       b = lo;
     }
-    return bucket0[(size_t)b * D.bucket_cap + (i - s_pref[b])];
+    const size_t pos = (size_t)b * D.bucket_cap + (i - s_pref[b]);
+    if constexpr (kBig) *lm = bucket_lm0[pos];
+    return bucket0[pos];
   };
+  auto key_of = [&](const int4 &r, int lm) -> KeyT {
+    if constexpr (kBig) return big_key(r.x, lm);
+    else return (KeyT)r.x;
+  };
+  auto hash_of = [&](const int4 &r, int lm) -> uint32_t { return kBig ? hash_big(r.x, lm) : hash32(r.x); };
 
   u64 best = ~0ull;
   unsigned long long tq = wall_clock64();
   for (int sub = 0; sub_shift >= 0 && sub < (1 << log2sub); ++sub) {
     __syncthreads();
-    for (int i = tid; i < SL; i += kInsertThreads) { keys[i] = kEmptyKey; vals[i] = kEmptyVal; }
+    for (int i = tid; i < SL; i += kInsertThreads) { keys[i] = kNoKey; vals[i] = kEmptyVal; }
     if (tid == 0) { s_nstates = 0; s_wpos = 0; s_ok = 1; }
     __syncthreads();
     if (tid == 0) dbg_phase(D, 6, tq);
@@ -471,22 +626,24 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
     // reference keeps those order-dependent extras (base-inl.h:330) but never expands them.
     for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
       int4 r[kInsertUnroll];
+      int rl[kInsertUnroll];
 #pragma unroll
-      for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid);
+      for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid, &rl[k]);
 #pragma unroll
       for (int k = 0; k < kInsertUnroll; ++k) {
         if (!(__int_as_float(r[k].y) < cutoff)) continue;
-        const uint32_t h = hash32(r[k].x);
+        const uint32_t h = hash_of(r[k], rl[k]);
         if (log2sub && (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) != sub) continue;
         uint32_t slot = lds_slot_of(h, log2grp, log2sl);
+        const KeyT key = key_of(r[k], rl[k]);
         bool found = false;
         for (int q = 0; q < SL; ++q) {
-          int32_t kk = keys[slot];
-          if (kk == kEmptyKey) {
-            kk = atomicCAS(&keys[slot], kEmptyKey, r[k].x);
-            if (kk == kEmptyKey) { atomicAdd(&s_nstates, 1); found = true; break; }
+          KeyT kk = keys[slot];
+          if (kk == kNoKey) {
+            kk = atomicCAS(&keys[slot], kNoKey, key);
+            if (kk == kNoKey) { atomicAdd(&s_nstates, 1); found = true; break; }
           }
-          if (kk == r[k].x) { found = true; break; }
+          if (kk == key) { found = true; break; }
           slot = (slot + 1) & mask;
         }
         if (found) atomicMin(&vals[slot], ((u64)f2o(__int_as_float(r[k].y)) << 32) | (uint32_t)r[k].w);
@@ -516,8 +673,9 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
     for (int k = 0; k < kInsertUnroll; ++k) lk_slot[k] = -1;
     for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
       int4 r[kInsertUnroll];
+      int rl[kInsertUnroll];
 #pragma unroll
-      for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid);
+      for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid, &rl[k]);
 #pragma unroll
       for (int k = 0; k < kInsertUnroll; ++k) {
         bool winner = false;
@@ -525,14 +683,15 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
         uint32_t wslot = 0;
         bool in_table = false;
         if (__int_as_float(r[k].y) < cutoff) {
-          const uint32_t h = hash32(r[k].x);
+          const uint32_t h = hash_of(r[k], rl[k]);
           if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
             packed = ((u64)f2o(__int_as_float(r[k].y)) << 32) | (uint32_t)r[k].w;
             uint32_t slot = lds_slot_of(h, log2grp, log2sl);
+            const KeyT key = key_of(r[k], rl[k]);
             for (int q = 0; q < SL; ++q) {
-              const int32_t kk = keys[slot];
-              if (kk == r[k].x) { winner = vals[slot] == packed; in_table = true; break; }
-              if (kk == kEmptyKey) break;
+              const KeyT kk = keys[slot];
+              if (kk == key) { winner = vals[slot] == packed; in_table = true; break; }
+              if (kk == kNoKey) break;
               slot = (slot + 1) & mask;
             }
             wslot = slot;
@@ -551,6 +710,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
         if (winner) {
           idx = base + gpos + wb + lane_rank(wm);
           tok[idx] = r[k];  // {state, cost, source token, arc | flags}
+          if constexpr (kBig) D.tok_lm[(size_t)c * D.arena_cap + idx] = rl[k];
           if (kLat) tidx[wslot] = idx;
           const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
           best = b < best ? b : best;
@@ -567,9 +727,24 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
         ob = __shfl(ob, 0, 64);
         if (tgt) {
           const uint32_t arc = (uint32_t)r[k].w & kArcMask;
-          const int ord = (int)((uint32_t)D.g.arcs[arc].y & 0x7FFFFFFFu) - 1;
+          int ord;
+          if constexpr (kBig) {
+            // hashed epsilon table: claim the slot of (row, pair).  Keys of one frame are distinct
+            // (one winner per key), so the claim cannot meet itself; other keys are probed past.
+            u64 *ekeys = D.eps_keys + (size_t)c * D.ecap;
+            const u64 key = big_key(r[k].x, rl[k]);
+            const uint32_t emask = (uint32_t)D.ecap - 1u;
+            uint32_t es = hash_big(r[k].x, rl[k]) & emask;
+            ord = -1;
+            for (int q = 0; q < D.ecap; ++q) {
+              if (ld_agent(&ekeys[es]) == kEmptyVal && atomicCAS(&ekeys[es], kEmptyVal, key) == kEmptyVal) { ord = (int)es; break; }
+              es = (es + 1) & emask;
+            }
+          } else {
+            ord = (int)((uint32_t)D.g.arcs[arc].y & 0x7FFFFFFFu) - 1;
+          }
           const int op = (int)(uint32_t)ob + lane_rank(tm);
-          if (op < D.wl_cap) {
+          if (op < D.wl_cap && ord >= 0) {
             evals[ord] = (packed & 0xFFFFFFFF00000000ull) | arc;
             etoki[ord] = idx;
             eocc[op] = ord;
@@ -577,7 +752,7 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
         }
         if (seed) {
           const int wp = (int)(ob >> 32) + lane_rank(sm);
-          if (wp < D.wl_cap) wl[wp] = make_int4(0, r[k].x, r[k].y, 0);
+          if (wp < D.wl_cap) wl[wp] = make_int4(rl[k], r[k].x, r[k].y, 0);  // {LM pair (biglm), state, cost}
           else atomicOr(&ctl->error, kErrWorklistFull);
         }
       }
@@ -606,17 +781,19 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
       for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
 #pragma unroll
         for (int k = 0; k < kInsertUnroll; ++k) {
-          const int4 r = load_rec(i0 + k * kInsertThreads + tid);
+          int rlm;
+          const int4 r = load_rec(i0 + k * kInsertThreads + tid, &rlm);
           bool live = false;
           int dst = 0;
           if (__int_as_float(r.y) < cutoff) {
-            const uint32_t h = hash32(r.x);
+            const uint32_t h = hash_of(r, rlm);
             if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
               uint32_t slot = lds_slot_of(h, log2grp, log2sl);
+              const KeyT key = key_of(r, rlm);
               for (int q = 0; q < SL; ++q) {
-                const int32_t kk = keys[slot];
-                if (kk == r.x) { live = true; dst = tidx[slot]; break; }
-                if (kk == kEmptyKey) break;
+                const KeyT kk = keys[slot];
+                if (kk == key) { live = true; dst = tidx[slot]; break; }
+                if (kk == kNoKey) break;
                 slot = (slot + 1) & mask;
               }
             }
@@ -679,9 +856,14 @@ struct BoundaryShared {
 // ProcessNonemitting to its fixpoint (base-inl.h:383-430) on the channel's direct-mapped epsilon
 // table, then write the arena records of the tokens an epsilon arc created or improved.  On entry
 // sh.wl_n[0] seeds are in worklist[0], sh.wl_n[1] == 0, sh.nnew / sh.occ continue the counters.
-template <bool kLat>
+// kBig (biglm): the table is hashed by (row, LM pair) -- eps_keys beside eps_vals / eps_toki -- every
+// epsilon arc with an output label moves the LM state (biglm.h:448-456), and the flattened closures
+// (which know nothing of LM states) are not used.
+template <bool kLat, bool kBig>
 __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, u64 *nZ_out) {
   const int tid = threadIdx.x;
+  ChanCtl *ctl = D.ctl + c;
+  u64 *ekeys = kBig ? D.eps_keys + (size_t)c * D.ecap : nullptr;
   u64 *vals = D.eps_vals + (size_t)c * D.ecap;
   int32_t *toki = D.eps_toki + (size_t)c * D.ecap;
   int32_t *occ = D.eps_occ_list + (size_t)c * D.wl_cap;
@@ -727,7 +909,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
       for (int k = 0; k < kClosureUnroll; ++k) {
         const int4 hdr = live[k] ? D.g.arcs[ent[k].y] : make_int4(0, 0, 0, 0);
         si[k] = make_uint2((uint32_t)ent[k].y + 1u, (uint32_t)hdr.x);
-        flat[k] = (uint32_t)hdr.w;  // (first eps_flat entry << 3) | entries; 0: iterate
+        flat[k] = kBig ? 0u : (uint32_t)hdr.w;  // (first eps_flat entry << 3) | entries; 0: iterate
       }
 #pragma unroll
       for (int k = 0; k < kClosureUnroll; ++k)
@@ -738,7 +920,20 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
       // reference's first-arrival rule does (emitting arcs are processed before the closure).
       // requeue: the state's own epsilon arcs still have to be followed from this cost
       // (base-inl.h:425); not for a flattened closure, whose deeper entries are those arcs.
-      auto arrive = [&](int ord, int a, float tot, bool out_eps, int next_row, bool requeue) {
+      auto arrive = [&](int ord, int a, float tot, bool out_eps, int next_row, bool requeue, int next_lm) {
+        if constexpr (kBig) {  // find or claim the slot of (row, pair)
+          const u64 key = big_key(next_row, next_lm);
+          const uint32_t emask = (uint32_t)D.ecap - 1u;
+          uint32_t es = hash_big(next_row, next_lm) & emask;
+          ord = -1;
+          for (int q = 0; q < D.ecap; ++q) {
+            u64 kk = ld_agent(&ekeys[es]);
+            if (kk == kEmptyVal) kk = atomicCAS(&ekeys[es], kEmptyVal, key);
+            if (kk == kEmptyVal || kk == key) { ord = (int)es; break; }
+            es = (es + 1) & emask;
+          }
+          if (ord < 0) { atomicOr(&sh.err, kErrTableFull); return; }
+        }
         const uint32_t otot = f2o(tot);
         const u64 packed = ((u64)otot << 32) | kEpsWon | (out_eps ? kEpsOutBit : 0u) | (uint32_t)a;
         const u64 old = atomicMin(&vals[ord], packed);
@@ -754,7 +949,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
         }
         if (requeue && out_eps && otot < (uint32_t)(old >> 32)) {
           const int wp = atomicAdd(&sh.wl_n[cur ^ 1], 1);
-          if (wp < D.wl_cap) wl_nxt[wp] = make_int4(0, next_row, __float_as_int(tot), 0);
+          if (wp < D.wl_cap) wl_nxt[wp] = make_int4(next_lm, next_row, __float_as_int(tot), 0);
           else atomicOr(&sh.err, kErrWorklistFull);
         }
       };
@@ -782,7 +977,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
             const float tot = cp + __int_as_float(E.w);  // base-inl.h:414
             if (!(tot < cutoff)) continue;               // base-inl.h:415
             pc[e] = tot;
-            arrive(E.x, E.y, tot, (E.z & 8) != 0, 0, false);
+            arrive(E.x, E.y, tot, (E.z & 8) != 0, 0, false, 0);
           }
           continue;
         }
@@ -791,9 +986,22 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
           const int a = (int)si[k].x + e;
           const int4 arc = e == 0 ? arc0[k] : D.g.arcs[a];
           nZ++;
-          const float tot = cost + __int_as_float(arc.z);  // base-inl.h:414
+          float graph_cost = __int_as_float(arc.z);
+          int next_lm = 0;
+          if constexpr (kBig) {  // biglm.h:448-451
+            const int ol = D.g.arc_olabel[a];
+            float lm_score = 0.0f;
+            next_lm = ent[k].x;
+            if (ol != 0) {
+              int n1, n2;
+              lm_score = lm_step(D, c, ent[k].x, ol, &n1, &n2);
+              next_lm = pair_intern(D, c, ctl, n1, n2);
+            }
+            graph_cost = __int_as_float(arc.z) + lm_score;
+          }
+          const float tot = cost + graph_cost;              // base-inl.h:414
           if (!(tot < cutoff)) continue;                    // base-inl.h:415
-          arrive((int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1, a, tot, ((uint32_t)arc.y & kFlagOutEps) != 0, arc.w, true);
+          arrive((int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1, a, tot, ((uint32_t)arc.y & kFlagOutEps) != 0, arc.w, true, next_lm);
         }
       }
     }
@@ -827,7 +1035,14 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
       if (od[k] < 0) continue;
       const u64 v = ld_agent(&vals[od[k]]);
       const int idx = ld_agent(&toki[od[k]]);
-      const int32_t state = D.g.eps_target_state[od[k]];
+      int32_t state;
+      if constexpr (kBig) {
+        const u64 key = ld_agent(&ekeys[od[k]]);
+        state = (int32_t)(uint32_t)key;
+        D.tok_lm[(size_t)c * D.arena_cap + idx] = (int32_t)(uint32_t)(key >> 32);
+      } else {
+        state = D.g.eps_target_state[od[k]];
+      }
       tok[idx] = make_int4(state, __float_as_int(o2f((uint32_t)(v >> 32))), kPrevUnresolved,
                            (int)(((uint32_t)v & kArcMask) | kFlagEpsTarget | (((uint32_t)v & kEpsOutBit) ? kFlagOutEps : 0u)));
       const u64 b = (v & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
@@ -906,7 +1121,10 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
     }
     __syncthreads();
   }
-  for (int i = tid; i < nocc; i += kBT) vals[occ[i]] = kEmptyVal;
+  for (int i = tid; i < nocc; i += kBT) {
+    vals[occ[i]] = kEmptyVal;
+    if constexpr (kBig) ekeys[occ[i]] = kEmptyVal;
+  }
   if (tid == 0) {
     u64 b = sh.red64[0];
     for (int w = 1; w < kBW; ++w) b = sh.red64[w] < b ? sh.red64[w] : b;
@@ -917,7 +1135,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
   if (tid == 0) dbg_phase(D, 3, tq);
 }
 
-template <bool kLat>
+template <bool kLat, bool kBig>
 __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, BoundaryShared &sh) {
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long tq = wall_clock64();
@@ -940,7 +1158,7 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
   __syncthreads();
   if (tid == 0) dbg_phase(D, 0, tq);
   u64 nZ = 0;
-  epsilon_closure<kLat>(D, c, sh, base, cutoff, &nZ);
+  epsilon_closure<kLat, kBig>(D, c, sh, base, cutoff, &nZ);
   tq = wall_clock64();
   nZ = wave_sum_u64(nZ);
   if (lane == 0) sh.red64[tid >> 6] = nZ;
@@ -1029,6 +1247,7 @@ __device__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh)
   return o2f(sh.sel_prefix);
 }
 
+template <bool kBig>
 __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32_t *target, BoundaryShared &sh,
                            int group, int par) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1083,9 +1302,18 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
     const int deg = (int)(si.y >> kEpsBits), ab0 = (int)(si.x + (si.y & kEpsMask));
     const float *llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
     const float bc = __int_as_float(bt.y);
+    const int blm = kBig ? D.tok_lm[(size_t)c * D.arena_cap + (uint32_t)best] : 0;
     for (int e = tid; e < deg; e += kBT) {
       const int4 arc = D.g.arcs[ab0 + e];
-      const float tot_score = (bc + __int_as_float(arc.z)) - llrow[arc.x];  // base-inl.h:295
+      float tot_score;
+      if constexpr (kBig) {  // biglm.h:350-353: lm_score + tot_cost + weight - loglike (the pair is not interned here)
+        const int ol = D.g.arc_olabel[ab0 + e];
+        int n1, n2;
+        const float lm_score = ol != 0 ? lm_step(D, c, blm, ol, &n1, &n2) : 0.0f;
+        tot_score = ((lm_score + bc) + __int_as_float(arc.z)) - llrow[arc.x];
+      } else {
+        tot_score = (bc + __int_as_float(arc.z)) - llrow[arc.x];  // base-inl.h:295
+      }
       seed = fminf(seed, tot_score);
     }
   }
@@ -1130,15 +1358,15 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
   if (tid == 0) dbg_phase(D, 5, tq);
 }
 
-template <bool kLat>
+template <bool kLat, bool kBig>
 __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_t *target, int do_prep, int chan_off,
                                                       int group, int par) {
   __shared__ BoundaryShared sh;
   const int c = blockIdx.x + chan_off;
   ChanCtl *ctl = D.ctl + c;
-  if (ctl->active) finalize_frame<kLat>(D, c, ctl, sh);
+  if (ctl->active) finalize_frame<kLat, kBig>(D, c, ctl, sh);
   __syncthreads();
-  if (do_prep) prep_frame(D, c, ctl, target, sh, group, par);  // par: parity of the step it prepares
+  if (do_prep) prep_frame<kBig>(D, c, ctl, target, sh, group, par);  // par: parity of the step it prepares
 }
 
 // =========================================================================================
@@ -1153,7 +1381,9 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
   // every closure leaves the epsilon table empty; after an error it may not be
   if (ctl->error || ctl->eps_occ || ctl->active) {
     for (int i = tid; i < D.ecap; i += kBT) vals[i] = kEmptyVal;
+    if (D.big) for (int i = tid; i < D.ecap; i += kBT) D.eps_keys[(size_t)c * D.ecap + i] = kEmptyVal;
   }
+  // (biglm: the channel's LM pair table was emptied by clear_pairs_kernel, the launch before this one)
   for (int i = tid; i < D.n_part; i += kBT) D.bucket_cnt[(size_t)c * D.n_part + i] = 0;
   __syncthreads();
   if (tid == 0) {
@@ -1164,19 +1394,31 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
     sh.err = 0; sh.wl_n[0] = 0; sh.wl_n[1] = 0; sh.nnew = 1; sh.occ = 0; sh.best = ~0ull;
     const uint32_t ne = D.g.start_eps, fl = flags_of(ne);
     D.tok[(size_t)c * D.arena_cap] = make_int4(D.g.start, __float_as_int(0.0f), -1, (int)(kNoArc | fl));
+    int start_lm = 0;
+    if (D.big) {  // biglm.h:112: start pair = (graph start, _diff_lm.Start())
+      start_lm = (int)(hash_pair(D.lm_old.start, D.lm_new.start) & ((uint32_t)D.pair_cap - 1u));
+      D.pair_keys[(size_t)c * D.pair_cap + start_lm] = (u64)(uint32_t)D.lm_old.start | ((u64)(uint32_t)D.lm_new.start << 32);
+      D.tok_lm[(size_t)c * D.arena_cap] = start_lm;
+      ctl->pair_count = 1;
+    }
     if (fl & kFlagEpsTarget) {
-      const int ord = (int)(ne & 0x7FFFFFFFu) - 1;
+      int ord = (int)(ne & 0x7FFFFFFFu) - 1;
+      if (D.big) {
+        ord = (int)(hash_big(D.g.start, start_lm) & ((uint32_t)D.ecap - 1u));
+        D.eps_keys[(size_t)c * D.ecap + ord] = big_key(D.g.start, start_lm);
+      }
       vals[ord] = ((u64)f2o(0.0f) << 32) | kNoArc;
       D.eps_toki[(size_t)c * D.ecap + ord] = 0;
       D.eps_occ_list[(size_t)c * D.wl_cap] = ord;
       sh.occ = 1;
     }
-    if (fl & kFlagOutEps) { D.worklist[(size_t)c * 2 * D.wl_cap] = make_int4(0, D.g.start, __float_as_int(0.0f), 0); sh.wl_n[0] = 1; }
+    if (fl & kFlagOutEps) { D.worklist[(size_t)c * 2 * D.wl_cap] = make_int4(start_lm, D.g.start, __float_as_int(0.0f), 0); sh.wl_n[0] = 1; }
   }
   __syncthreads();
   u64 nZ = 0;
-  if (D.lattice) epsilon_closure<true>(D, c, sh, 0, D.beam, &nZ);  // ProcessNonemitting(_config._beam)
-  else epsilon_closure<false>(D, c, sh, 0, D.beam, &nZ);
+  if (D.big) epsilon_closure<false, true>(D, c, sh, 0, D.beam, &nZ);
+  else if (D.lattice) epsilon_closure<true, false>(D, c, sh, 0, D.beam, &nZ);  // ProcessNonemitting(_config._beam)
+  else epsilon_closure<false, false>(D, c, sh, 0, D.beam, &nZ);
   if (tid == 0) {
     int nf = sh.nnew;
     if (sh.err || nf > D.max_tok || nf > D.arena_cap) nf = 0;
@@ -1206,6 +1448,11 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
 // =========================================================================================
 constexpr int kBpThreads = 256;
 
+// kBig (biglm): final costs carry the LM's (ComputeFinalCosts, biglm.h:160-215), hop graph costs are arc
+// weight + lm_score, an epsilon-won token's predecessor is found by (state, LM pair, cost), and after
+// FinalizeDecoding the reference's final pruning can leave NO token (its final_best_cost ranges over
+// every token's cost + LM final cost, graph-final or not, :186-188) -- reproduced: no path.
+template <bool kBig>
 __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, const int32_t *chans, int use_final, int cap,
                                                                int32_t *o_il, int32_t *o_ol, float *o_g, float *o_ac,
                                                                int32_t *n_hops, int32_t *chain) {
@@ -1218,20 +1465,30 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
     if (tid == 0) n_hops[bi] = 0;
     return;
   }
-  __shared__ u64 s_all[kBpThreads / 64], s_fin[kBpThreads / 64];
+  __shared__ u64 s_all[kBpThreads / 64], s_fin[kBpThreads / 64], s_wf[kBpThreads / 64];
   __shared__ int s_len;
   const int4 *tok = D.tok + (size_t)c * D.arena_cap;
+  const int32_t *tok_lm = kBig ? D.tok_lm + (size_t)c * D.arena_cap : nullptr;
   const int fb = ctl->front_begin;
-  u64 best_all = ~0ull, best_fin = ~0ull;
+  u64 best_all = ~0ull, best_fin = ~0ull, best_wf = ~0ull;  // best_wf: min cost + LM final cost over ALL tokens (biglm)
   for (int i = tid; i < n; i += kBpThreads) {
     const int4 t = tok[fb + i];
     const u64 v = ((u64)f2o(__int_as_float(t.y)) << 32) | (uint32_t)(fb + i);
     best_all = v < best_all ? v : best_all;
-    if (t.x == D.g.final_state) best_fin = v < best_fin ? v : best_fin;  // IsFinal, optimize-fst.h:189-192
+    if constexpr (kBig) {
+      const u64 pk = D.pair_keys[(size_t)c * D.pair_cap + tok_lm[fb + i]];
+      const float lm_final = lm_final_cost(D.lm_old, (int)(uint32_t)pk) + lm_final_cost(D.lm_new, (int)(uint32_t)(pk >> 32));  // diff-lm.h:48-53
+      const u64 w = ((u64)f2o(__int_as_float(t.y) + lm_final) << 32) | (uint32_t)(fb + i);
+      best_wf = w < best_wf ? w : best_wf;
+      if (t.x == D.g.final_state) best_fin = w < best_fin ? w : best_fin;
+    } else {
+      if (t.x == D.g.final_state) best_fin = v < best_fin ? v : best_fin;  // IsFinal, optimize-fst.h:189-192
+    }
   }
   best_all = wave_min_u64(best_all);
   best_fin = wave_min_u64(best_fin);
-  if (lane == 0) { s_all[wave] = best_all; s_fin[wave] = best_fin; }
+  best_wf = wave_min_u64(best_wf);
+  if (lane == 0) { s_all[wave] = best_all; s_fin[wave] = best_fin; s_wf[wave] = best_wf; }
   __syncthreads();
   int32_t *ch = chain + (size_t)bi * cap;
   const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
@@ -1240,9 +1497,17 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
     for (int w = 1; w < kBpThreads / 64; ++w) {
       best_all = s_all[w] < best_all ? s_all[w] : best_all;
       best_fin = s_fin[w] < best_fin ? s_fin[w] : best_fin;
+      best_wf = s_wf[w] < best_wf ? s_wf[w] : best_wf;
     }
     const u64 best = (use_final && best_fin != ~0ull) ? best_fin : best_all;
     s_t = (int)(uint32_t)best;
+    if (kBig && ctl->finalized) {
+      // PruneForwardLinksFinal (biglm.h:468-568): tok_extra_cost = tot_cost + final_cost - final_best_cost
+      // of the cheapest candidate; above lattice_beam it -- and with it every token -- is pruned away
+      const float fbc = o2f((uint32_t)(best_wf >> 32));
+      const float own = (best_fin != ~0ull) ? o2f((uint32_t)(best_fin >> 32)) : (o2f((uint32_t)(best_all >> 32)) + 0.0f);
+      if ((own - fbc) > D.lattice_beam) s_t = -1;
+    }
     s_len = 0;
   }
   // Walk the backpointer chain (last hop first, packed against the end of ch[]).  One thread
@@ -1274,8 +1539,27 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
     __syncthreads();
     if (s_need >= 0) {
       const int need = s_need;
-      for (int i = s_lo + tid; i < s_hi; i += kBpThreads)
-        if (tok[i].x == need) s_found = i;
+      for (int i = s_lo + tid; i < s_hi; i += kBpThreads) {
+        const int4 S = tok[i];
+        if (S.x != need) continue;
+        if constexpr (kBig) {
+          // several tokens may sit on the arc's source state, one per LM state: the predecessor is the
+          // one whose LM state and cost lead to this token over the winning arc
+          const int4 T = tok[t];
+          const int a = (int)((uint32_t)T.w & kArcMask);
+          const int ol = D.g.arc_olabel[a];
+          int nlm = tok_lm[i];
+          float lm_score = 0.0f;
+          if (ol != 0) {
+            int n1, n2;
+            lm_score = lm_step(D, c, tok_lm[i], ol, &n1, &n2);
+            nlm = pair_find(D, c, n1, n2);
+          }
+          const float tot = __int_as_float(S.y) + (__int_as_float(D.g.arcs[a].z) + lm_score);
+          if (nlm != tok_lm[t] || __float_as_int(tot) != T.y) continue;
+        }
+        s_found = i;
+      }
       __syncthreads();
       if (tid == 0) s_t = s_found;  // -1 (never expected) ends the walk
     }
@@ -1316,6 +1600,19 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
     const int ahi = eps ? (int)si.x + ne : (int)si.x + ne + (int)(si.y >> kEpsBits);
     const bool pruned_once = ctl->finalized || m_last >= fbp + 1;
     const float *llrow = ll + (size_t)(eps ? 0 : fbp) * D.stride;
+    // biglm: LM score of an arc taken from the predecessor's LM state, and the pair state it leads to
+    // (-1: a pair no token was ever created with)
+    auto arc_lm = [&](int a, float *lm_score) -> int {
+      *lm_score = 0.0f;
+      if constexpr (!kBig) return 0;
+      else {
+        const int ol = D.g.arc_olabel[a];
+        if (ol == 0) return tok_lm[prev];
+        int n1, n2;
+        *lm_score = lm_step(D, c, tok_lm[prev], ol, &n1, &n2);
+        return pair_find(D, c, n1, n2);
+      }
+    };
     int chosen = warc;
     // TraceBackBestPath takes the FIRST link bp->tok; links are prepended in arc order
     // (base-inl.h:340-341, 1169-1186), so a surviving parallel arc of higher index shadows the
@@ -1323,8 +1620,14 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
     for (int a = ahi - 1; a > warc; --a) {
       const int4 B = D.g.arcs[a];
       if (B.w != T.x) continue;
+      float alt_g = __int_as_float(B.z);
+      if constexpr (kBig) {
+        float ls;
+        if (arc_lm(a, &ls) != tok_lm[t]) continue;  // leads to another (state, LM state) token
+        alt_g = __int_as_float(B.z) + ls;
+      }
       const float alt_ac = eps ? 0.f : -llrow[B.x];
-      const float alt_tot = eps ? cb + __int_as_float(B.z) : (cb + alt_ac) + __int_as_float(B.z);
+      const float alt_tot = eps ? cb + alt_g : (cb + alt_ac) + alt_g;
       if (!(alt_tot < cut[fr])) continue;  // link never created
       if (pruned_once && (0.0f + (alt_tot - ct)) > D.lattice_beam) continue;  // base-inl.h:524-532
       chosen = a;
@@ -1333,7 +1636,13 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
     const int4 C = D.g.arcs[chosen];
     il[pos] = D.g.arc_ilabel[chosen];
     ol[pos] = D.g.arc_olabel[chosen];
-    og[pos] = __int_as_float(C.z);
+    if constexpr (kBig) {
+      float ls;
+      arc_lm(chosen, &ls);
+      og[pos] = __int_as_float(C.z) + ls;  // graph_cost = arc weight + lm_score (biglm.h:380,450)
+    } else {
+      og[pos] = __int_as_float(C.z);
+    }
     oa[pos] = eps ? 0.f : -llrow[C.x];
   }
 }
@@ -1485,33 +1794,49 @@ static __global__ void set_finalized_kernel(DecoderDev D, const int32_t *chans, 
   if (i < n) D.ctl[chans ? chans[i] : i].finalized = 1;
 }
 
+// DiffArpaLm::Reset (newlm/diff-lm.h:37-44, biglm.h:110): forget the utterance's LM pair states.  Its own
+// launch, many workgroups per channel: plain stores here, agent-scope atomics in the launches after.
+__global__ __launch_bounds__(256) void clear_pairs_kernel(DecoderDev D, const int32_t *chans) {
+  const int c = chans ? chans[blockIdx.x] : blockIdx.x;
+  u64 *pk = D.pair_keys + (size_t)c * D.pair_cap;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < D.pair_cap; i += gridDim.y * blockDim.x) pk[i] = kEmptyVal;
+}
 void launch_init(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
+  if (D.big) hipLaunchKernelGGL(clear_pairs_kernel, dim3(n, 32), dim3(256), 0, s, D, chans);
   hipLaunchKernelGGL(init_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
 }
 // chan_off / chan_cnt: the channel group a launch covers (groups run on their own streams so that
 // one group's latency-bound closure overlaps another group's expand / insert)
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s) {
-  hipLaunchKernelGGL(expand_kernel, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+  if (D.big) hipLaunchKernelGGL(expand_kernel<true>, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+  else hipLaunchKernelGGL(expand_kernel<false>, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
 }
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups, hipStream_t s) {
-  const size_t lds = (size_t)D.lds_slots * (D.lattice ? 16 : 12);
-  if (D.lattice) hipLaunchKernelGGL(insert_kernel<true>, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
-  else hipLaunchKernelGGL(insert_kernel<false>, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  const size_t lds = (size_t)D.lds_slots * (D.big ? 16 : D.lattice ? 16 : 12);
+  if (D.big) hipLaunchKernelGGL((insert_kernel<false, true>), dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  else if (D.lattice) hipLaunchKernelGGL((insert_kernel<true, false>), dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  else hipLaunchKernelGGL((insert_kernel<false, false>), dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
 }
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int do_prep, int group, int par,
                     hipStream_t s) {
-  if (D.lattice)
-    hipLaunchKernelGGL(closure_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+  if (D.big)
+    hipLaunchKernelGGL((closure_kernel<false, true>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+  else if (D.lattice)
+    hipLaunchKernelGGL((closure_kernel<true, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
   else
-    hipLaunchKernelGGL(closure_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+    hipLaunchKernelGGL((closure_kernel<false, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
 }
 void launch_set_finalized(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(set_finalized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, D, chans, n);
 }
 void launch_best_path(const DecoderDev &D, const int32_t *chans, int n, int use_final, int cap, int32_t *ilabel,
                       int32_t *olabel, float *graph, float *ac, int32_t *n_hops, int32_t *chain, hipStream_t s) {
-  hipLaunchKernelGGL(best_path_kernel, dim3(n), dim3(kBpThreads), 0, s, D, chans, use_final, cap, ilabel, olabel, graph,
-                     ac, n_hops, chain);
+  if (D.big)
+    hipLaunchKernelGGL(best_path_kernel<true>, dim3(n), dim3(kBpThreads), 0, s, D, chans, use_final, cap, ilabel, olabel, graph,
+                       ac, n_hops, chain);
+  else
+    hipLaunchKernelGGL(best_path_kernel<false>, dim3(n), dim3(kBpThreads), 0, s, D, chans, use_final, cap, ilabel, olabel, graph,
+                       ac, n_hops, chain);
 }
 __global__ __launch_bounds__(256) void lattice_fill_kernel(DecoderDev D, const int32_t *chans) {
   const int c = chans ? chans[blockIdx.x] : blockIdx.x;
@@ -1528,8 +1853,10 @@ void launch_lattice_prune(const DecoderDev &D, const int32_t *chans, int n, hipS
   hipLaunchKernelGGL(lattice_prune_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
 }
 int insert_kernel_set_lds(int bytes) {
-  int e = (int)hipFuncSetAttribute((const void *)insert_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  int e = (int)hipFuncSetAttribute((const void *)insert_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e) return e;
-  return (int)hipFuncSetAttribute((const void *)insert_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  e = (int)hipFuncSetAttribute((const void *)insert_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e) return e;
+  return (int)hipFuncSetAttribute((const void *)insert_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 }  // namespace wfst

@@ -28,7 +28,8 @@ SYMBOLS = [
     "wfst_decoder_get_stats", "wfst_decoder_get_frontier", "wfst_decoder_set_profiling",
     "wfst_decoder_get_profile", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
-    "wfst_decoder_create_ex",
+    "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
+    "wfst_decoder_create_biglm",
 ]
 
 
@@ -54,7 +55,7 @@ class Config(C.Structure):
 
 class Limits(C.Structure):
     _fields_ = [("max_frames", C.c_int32), ("max_tokens_per_frame", C.c_int32), ("arena_tokens", C.c_int64),
-                ("lattice_links", C.c_int64)]
+                ("lattice_links", C.c_int64), ("lm_pairs", C.c_int64)]
 
 
 class Options(C.Structure):
@@ -170,18 +171,55 @@ class Graph:
             self.h = None
 
 
+class Lm:
+    """A back-off n-gram LM automaton resident in HBM (replaces the reference's ``ArpaLm``); `scale`
+    is ArpaLm::Rescale -- the biglm CLI loads the OLD LM with -1."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @staticmethod
+    def load(path, scale=1.0, device=0):
+        h = C.c_void_p()
+        _check(lib().wfst_lm_load(path.encode(), C.c_float(scale), int(device), C.byref(h)))
+        return Lm(h)
+
+    @staticmethod
+    def from_arrays(bos, eos, unk, states, arcs, scale=1.0, device=0):
+        st = np.ascontiguousarray(states)
+        ar = np.ascontiguousarray(arcs)
+        assert st.dtype.itemsize == 12 and ar.dtype.itemsize == 12
+        h = C.c_void_p()
+        _check(lib().wfst_lm_from_arrays(int(bos), int(eos), int(unk), int(st.shape[0]), st.ctypes.data_as(C.c_void_p),
+                                         int(ar.shape[0]), ar.ctypes.data_as(C.c_void_p), C.c_float(scale), int(device), C.byref(h)))
+        return Lm(h)
+
+    def info(self):
+        v = [C.c_int32() for _ in range(5)]
+        b = C.c_int64()
+        _check(lib().wfst_lm_info(self.h, *[C.byref(x) for x in v], C.byref(b)))
+        return dict(bos=v[0].value, eos=v[1].value, n_states=v[2].value, n_arcs=v[3].value, n_words=v[4].value, device_bytes=b.value)
+
+    def free(self):
+        if self.h:
+            lib().wfst_lm_free(self.h)
+            self.h = None
+
+
 class BatchDecoder:
-    """A batch of decoding channels (one channel == one reference decoder object)."""
+    """A batch of decoding channels (one channel == one reference decoder object).  old_lm / new_lm:
+    biglm mode (the reference's OnlineLatticeDecoderMempoolBiglm)."""
 
     def __init__(self, graph, cfg, n_channels, max_frames=0, max_tokens_per_frame=0, arena_tokens=0, stream=None,
-                 lattice_links=0, options=None):
+                 lattice_links=0, options=None, old_lm=None, new_lm=None, lm_pairs=0):
         self.graph = graph
         self.n = int(n_channels)
-        lim = Limits(int(max_frames), int(max_tokens_per_frame), int(arena_tokens), int(lattice_links))
+        lim = Limits(int(max_frames), int(max_tokens_per_frame), int(arena_tokens), int(lattice_links), int(lm_pairs))
         h = C.c_void_p()
-        _check(lib().wfst_decoder_create_ex(graph.h, C.byref(cfg), self.n, C.byref(lim),
-                                            C.byref(options) if options is not None else None,
-                                            C.c_void_p(stream) if stream else None, C.byref(h)))
+        _check(lib().wfst_decoder_create_biglm(graph.h, C.byref(cfg), self.n, C.byref(lim),
+                                               C.byref(options) if options is not None else None,
+                                               old_lm.h if old_lm is not None else None, new_lm.h if new_lm is not None else None,
+                                               C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
 
     def free(self):

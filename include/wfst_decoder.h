@@ -37,6 +37,8 @@ extern "C" {
 typedef struct wfst_graph wfst_graph;     /* HCLG resident in HBM; replaces `Fst` (newfst/optimize-fst.h:53-307) */
 typedef struct wfst_decoder wfst_decoder; /* a batch of decoding channels; one channel replaces one
                                              OnlineLatticeDecoderMempool (my-decoder/online-decoder-mempool-base.h:77) */
+typedef struct wfst_lm wfst_lm;           /* a back-off n-gram LM automaton resident in HBM; replaces `ArpaLm`
+                                             (newlm/arpa2fsa.h:249-441) for the biglm decoder */
 
 /* Field-for-field LatticeFasterDecoderConfig (my-decoder/lattice-faster-decoder-conf.h:21-44);
  * wfst_config_default() fills the reference defaults (conf.h:35-44).  hash_ratio and prune_scale
@@ -64,6 +66,8 @@ typedef struct wfst_limits {
   int64_t lattice_links;        /* > 0: LATTICE MODE -- record every forward link (capacity per
                                    utterance) so that FinalizeDecoding can prune by lattice_beam and
                                    GetRawLattice can be served; 0 (default): best path only        */
+  int64_t lm_pairs;             /* biglm decoders: distinct (old-LM state, new-LM state) pairs one
+                                   utterance may reach (default 262144; rounded up to a power of two) */
 } wfst_limits;
 
 /* Scheduling choices of a decoder (NULL / wfst_options_default() = the measured defaults).  None of
@@ -138,6 +142,27 @@ int wfst_graph_info(const wfst_graph *g, int32_t *start, int32_t *final_state, i
                     int32_t *n_arcs, int64_t *device_bytes);
 void wfst_graph_free(wfst_graph *g);
 
+/* ---- language models (biglm: on-the-fly LM rescoring, BASELINE configs[3]) ----------------- */
+
+/* Records of the reference's LM automaton (newlm/arpa2fsa.h:22-40,80-91 and arpa2fsa.cc:62-67). */
+typedef struct wfst_lm_state { int32_t arc_num; float backoff_prob; int32_t backoff_id; } wfst_lm_state;
+typedef struct wfst_lm_arc { int32_t wordid; float weight; int32_t tostateid; } wfst_lm_arc;
+
+/* ArpaLm::Read (newlm/arpa2fsa.h:355-397 + Fsa::Read, newlm/arpa2fsa.cc:68-176) followed by
+ * ArpaLm::Rescale(scale) (arpa2fsa.cc:264-275): reads the binary LM file arpa2fsa-bin writes
+ * {i32 bos, eos, unk; u64 orders; i32 count[orders]; i32 n_states; {i32 arc_num, f32 backoff, i32
+ * backoff_id} x n_states; i32 n_arcs; {i32 wordid, f32 weight, i32 tostate} x n_arcs} and uploads it
+ * to `device`.  The biglm CLI loads the OLD LM (the one compiled into the HCLG) with scale -1 and the
+ * NEW one with scale 1 (kaldi-nnet3bin/kaldi-hclg-my-decoder-biglm.cc:55-60).  Checked, WFST_E_FORMAT
+ * otherwise: counts consistent with the file size, arcs of a state sorted by word id, state 0 holding
+ * arc k for word id k, destinations in range, every back-off chain ending in state 0. */
+int wfst_lm_load(const char *path, float scale, int device, wfst_lm **out);
+int wfst_lm_from_arrays(int32_t bos, int32_t eos, int32_t unk, int32_t n_states, const wfst_lm_state *states,
+                        int32_t n_arcs, const wfst_lm_arc *arcs, float scale, int device, wfst_lm **out);
+int wfst_lm_info(const wfst_lm *lm, int32_t *bos, int32_t *eos, int32_t *n_states, int32_t *n_arcs,
+                 int32_t *n_words /* arcs of the empty-history state */, int64_t *device_bytes);
+void wfst_lm_free(wfst_lm *lm);
+
 /* ---- decoder ----------------------------------------------------------------------------- */
 
 /* Decoder(Fst*, const LatticeFasterDecoderConfig&) (my-decoder/online-decoder-base.h:95,
@@ -149,6 +174,17 @@ int wfst_decoder_create(const wfst_graph *g, const wfst_config *cfg, int32_t n_c
 int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
                            const wfst_limits *limits, const wfst_options *options, void *hip_stream,
                            wfst_decoder **out);
+/* OnlineLatticeDecoderMempoolBiglm(fst, config, oldlm, newlm) (my-decoder/online-decoder-mempool-base-
+ * biglm.h:21-30): every arc with an output label is rescored on the fly with cost_new(word | history) -
+ * cost_old(word | history); a token is identified by (graph state, LM pair state) (:77-90).  Both LMs must
+ * be on the graph's device and stay alive as long as the decoder.  Each LM is walked from its OWN state
+ * (DiffArpaLm with the pair's components; the reference text hands the pair id to both LMs,
+ * newlm/diff-lm.h:80,86 -- see DESIGN.md).  Best path only: limits->lattice_links must be 0.
+ * WFST_E_FORMAT if the graph has an output label the LMs' empty-history state has no arc for (the
+ * reference indexes that state without a bounds check, newlm/arpa2fsa.h:211-214). */
+int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,
+                              const wfst_limits *limits, const wfst_options *options, const wfst_lm *old_lm,
+                              const wfst_lm *new_lm, void *hip_stream, wfst_decoder **out);
 void wfst_decoder_free(wfst_decoder *d);
 
 /* InitDecoding() (base-inl.h:40-67) for the listed channels (channels == NULL: all). */

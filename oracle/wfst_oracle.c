@@ -381,7 +381,12 @@ static Elem *find_or_add_token(Decoder *d, Key key, int frame_plus_one, float to
   } else {
     Token *tok = e->val;
     if (tok->tot_cost > tot_cost) { tok->tot_cost = tot_cost; tok->backpointer = bp; tok->tie = 0; if (changed) *changed = 1; }
-    else { if (tok->tot_cost == tot_cost) tok->tie = 1; if (changed) *changed = 0; }
+    else {
+      /* audit only: an equal cost through ANOTHER predecessor is a real tie (first arrival wins here, lowest
+       * arc index on the GPU); the same predecessor arriving again is the closure re-processing a token */
+      if (tok->tot_cost == tot_cost && tok->backpointer != bp) tok->tie = 1;
+      if (changed) *changed = 0;
+    }
   }
   return e;
 }
