@@ -4,6 +4,9 @@
 // plain files instead of Kaldi tables:
 //
 //   wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--lattice-out=FILE [--lattice-links=N]]
+//               [--lm-old=FILE --lm-new=FILE]
+//   --lm-old/--lm-new  biglm (kaldi-hclg-my-decoder-biglm.cc): rescore on the fly with new LM - old LM; the files
+//                  are the reference's binary LMs (arpa2fsa-bin); the old one is rescaled by -1 as the reference CLI does
 //               CONFIG GRAPH LOGLIKES [WORDS_OUT]
 //   --lattice-out  also write GetRawLattice of every utterance, in utterance order, in the
 //                  reference's on-disk lattice format (Lattice::Write, newfst/lattice-fst.cc:38-64;
@@ -74,7 +77,7 @@ class HostMatrixDecodable : public MatrixDecodable {
 
 int main(int argc, char **argv) {
   try {
-    std::string tid2pdf_file;
+    std::string tid2pdf_file, lm_old_file, lm_new_file;
     int batch = 128;
     bool single = false;
     std::string lattice_file, lattice_text;
@@ -91,11 +94,13 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 16, "--lattice-links=") == 0) lattice_links = atoll(a.c_str() + 16);
       else if (a.compare(0, 8, "--nbest=") == 0) nbest = atoi(a.c_str() + 8);
       else if (a.compare(0, 11, "--inflight=") == 0) inflight = std::max(1, atoi(a.c_str() + 11));
+      else if (a.compare(0, 9, "--lm-old=") == 0) lm_old_file = a.substr(9);
+      else if (a.compare(0, 9, "--lm-new=") == 0) lm_new_file = a.substr(9);
       else pos.push_back(a);
     }
     if (pos.size() < 3) {
       std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--inflight=K] [--nbest=N] [--lattice-out=FILE] "
-                   "[--lattice-text=FILE] [--lattice-links=N] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
+                   "[--lattice-text=FILE] [--lattice-links=N] [--lm-old=FILE --lm-new=FILE] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
       return 1;
     }
     LatticeFasterDecoderConfig opt;
@@ -134,7 +139,15 @@ int main(int argc, char **argv) {
         std::cerr << "LOG " << u.key << '-' << (k + 1) << " tot_score " << tot << " lm_score " << lm << "\n";
       }
     };
-    wfst_limits limits = {0, 0, 0, 0};  // zeros = the library defaults
+    // biglm (kaldi-nnet3bin/kaldi-hclg-my-decoder-biglm.cc:55-60,80): both LM files, the old one rescaled by -1
+    const bool biglm = !lm_old_file.empty() || !lm_new_file.empty();
+    ArpaLm lm1, lm2;
+    if (biglm) {
+      if (lm_old_file.empty() || lm_new_file.empty()) { std::cerr << "--lm-old and --lm-new go together\n"; return 1; }
+      if (!lm1.Read(lm_old_file.c_str()) || !lm2.Read(lm_new_file.c_str())) return 1;
+      lm1.Rescale(-1.0);
+    }
+    wfst_limits limits = {0, 0, 0, 0, 0};  // zeros = the library defaults
     limits.lattice_links = want_lattice ? lattice_links : 0;
     auto emit_lattice = [&](const Utt &u, Lattice &lat, bool ok) {
       if (!ok) lat.DeleteStates();
@@ -177,7 +190,9 @@ int main(int argc, char **argv) {
       ++num_success;
     };
     if (single) {  // the reference's shape: one decoder object, one utterance at a time
-      GpuLatticeDecoder decode(&fst, opt, &limits);
+      std::unique_ptr<GpuLatticeDecoder> decode_p(biglm ? new OnlineLatticeDecoderMempoolBiglm(&fst, opt, &lm1, &lm2, &limits)
+                                                        : new GpuLatticeDecoder(&fst, opt, &limits));
+      GpuLatticeDecoder &decode = *decode_p;
       for (const Utt &u : utts) {
         HostMatrixDecodable decodable(u);
         decode.InitDecoding();
@@ -209,7 +224,9 @@ int main(int argc, char **argv) {
       std::vector<std::string> errors((size_t)inflight);
       auto worker = [&](int k) {
         try {
-          GpuBatchDecoder decode(&fst, opt, batch, &limits);  // its own stream
+          std::unique_ptr<GpuBatchDecoder> decode_p(biglm ? new GpuBatchDecoder(&fst, opt, &lm1, &lm2, batch, &limits)
+                                                          : new GpuBatchDecoder(&fst, opt, batch, &limits));  // its own stream
+          GpuBatchDecoder &decode = *decode_p;
           for (;;) {
             const size_t b = next.fetch_add(1);
             if (b >= n_batches) return;

@@ -196,12 +196,51 @@ bool Lattice::Read(const std::string &file) {
   return ok;
 }
 
+// ---- language model (biglm) -------------------------------------------------------------------
+ArpaLm::~ArpaLm() { wfst_lm_free(_lm); }
+bool ArpaLm::Read(const char *file, int device) {
+  wfst_lm_free(_lm);
+  _lm = nullptr;
+  _file = file;
+  _device = device;
+  if (wfst_lm_load(file, _scale, device, &_lm) != WFST_OK) {  // checks the file now; re-uploaded if Rescale follows
+    std::cerr << "Read " << file << " failed: " << wfst_last_error() << std::endl;
+    return false;
+  }
+  int32_t ns, na, nw;
+  int64_t bytes;
+  wfst_lm_info(_lm, &_bos, &_eos, &ns, &na, &nw, &bytes);
+  return true;
+}
+void ArpaLm::Rescale(float scale) {  // arpa2fsa.cc:264-275: weights *= scale (applied when the automaton is uploaded)
+  if (scale == 1.0f) return;
+  _scale *= scale;
+  wfst_lm_free(_lm);
+  _lm = nullptr;
+}
+const wfst_lm *ArpaLm::Handle() {
+  if (!_lm) {
+    if (_file.empty()) throw std::runtime_error("ArpaLm used before Read()");
+    if (wfst_lm_load(_file.c_str(), _scale, _device, &_lm) != WFST_OK) Fatal("ArpaLm upload");
+  }
+  return _lm;
+}
+
 // ---- single-stream decoder --------------------------------------------------------------------
 GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, const wfst_limits *limits)
     : _dec(nullptr), _stride(0), _rows_ready(0), _inited(false) {
   config.Check();
   wfst_config c = config.ToC();
   if (wfst_decoder_create(graph->Handle(), &c, 1, limits, nullptr, &_dec) != WFST_OK) Fatal("wfst_decoder_create");
+}
+GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm,
+                                     const wfst_limits *limits)
+    : _dec(nullptr), _stride(0), _rows_ready(0), _inited(false) {
+  config.Check();
+  wfst_config c = config.ToC();
+  if (!oldlm || !newlm) throw std::runtime_error("biglm decoder needs both LMs");
+  if (wfst_decoder_create_biglm(graph->Handle(), &c, 1, limits, nullptr, oldlm->Handle(), newlm->Handle(), nullptr, &_dec) != WFST_OK)
+    Fatal("wfst_decoder_create_biglm");
 }
 GpuLatticeDecoder::~GpuLatticeDecoder() { wfst_decoder_free(_dec); }
 
@@ -389,6 +428,16 @@ GpuBatchDecoder::GpuBatchDecoder(Fst *graph, const LatticeFasterDecoderConfig &c
   wfst_config c = config.ToC();
   if (wfst_decoder_create(graph->Handle(), &c, n_channels, limits, hip_stream, &_dec) != WFST_OK)
     Fatal("wfst_decoder_create");
+}
+GpuBatchDecoder::GpuBatchDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm,
+                                 int n_channels, const wfst_limits *limits, void *hip_stream)
+    : _dec(nullptr), _n(n_channels) {
+  config.Check();
+  wfst_config c = config.ToC();
+  if (!oldlm || !newlm) throw std::runtime_error("biglm decoder needs both LMs");
+  if (wfst_decoder_create_biglm(graph->Handle(), &c, n_channels, limits, nullptr, oldlm->Handle(), newlm->Handle(), hip_stream,
+                                &_dec) != WFST_OK)
+    Fatal("wfst_decoder_create_biglm");
 }
 GpuBatchDecoder::~GpuBatchDecoder() { wfst_decoder_free(_dec); }
 

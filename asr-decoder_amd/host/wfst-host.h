@@ -8,6 +8,8 @@
 //   Fst (ReadFst/Start/IsFinal/TotState)  src/newfst/optimize-fst.h:53-307
 //   Lattice / LatticeArc / LatticeWeight  src/newfst/lattice-fst.h:15-346, src/newfst/weigth.h:192-262
 //   LatticeToVector                       src/newfst/lattice-functions.cc:179-217
+//   ArpaLm (Read / Rescale)               src/newlm/arpa2fsa.h:249-441          (biglm)
+//   OnlineLatticeDecoderMempoolBiglm      src/my-decoder/online-decoder-mempool-base-biglm.h:21-30,570
 //
 // GpuLatticeDecoder is the drop-in for OnlineLatticeDecoderMempool (one utterance stream,
 // decodable pulled through LogLikelihood()); GpuBatchDecoder is the batch shape the MI355X wants
@@ -104,6 +106,30 @@ class Fst {
   int32_t _start = 0, _final = 0, _states = 0, _arcs = 0;
 };
 
+// ---- language model (biglm) -----------------------------------------------------------------
+// The reference's ArpaLm as the biglm caller uses it (kaldi-nnet3bin/kaldi-hclg-my-decoder-biglm.cc:
+// 55-60): `lm1.Read(file); lm2.Read(file); lm1.Rescale(-1.0);`.  Read checks the file; the automaton
+// goes to HBM, with the scale applied, when a decoder first asks for it.
+class ArpaLm {
+ public:
+  ArpaLm() : _scale(1.0f), _device(0), _lm(nullptr) {}
+  ~ArpaLm();
+  bool Read(const char *file, int device = 0);  // false (with a message on stderr) on failure
+  void Rescale(float scale);
+  int BosSymbol() const { return _bos; }
+  int EosSymbol() const { return _eos; }
+  const wfst_lm *Handle();
+
+ private:
+  ArpaLm(const ArpaLm &);
+  ArpaLm &operator=(const ArpaLm &);
+  std::string _file;
+  float _scale;
+  int _device;
+  wfst_lm *_lm;
+  int32_t _bos = -1, _eos = -1;
+};
+
 // ---- lattice (linear best path is all this path produces) ---------------------------------------
 struct LatticeWeight {
   float _value1, _value2;  // graph cost, acoustic cost
@@ -185,6 +211,9 @@ class DecoderItf {
 class GpuLatticeDecoder : public DecoderItf {
  public:
   GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, const wfst_limits *limits = nullptr);
+  // OnlineLatticeDecoderMempoolBiglm(fst, config, oldlm, newlm) (biglm.h:21-30): on-the-fly LM rescoring
+  GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm,
+                    const wfst_limits *limits = nullptr);
   ~GpuLatticeDecoder() override;
   void InitDecoding() override;
   void AdvanceDecoding(AmInterface *decodable, int32 max_num_frames = -1) override;
@@ -221,6 +250,8 @@ class GpuBatchDecoder {
  public:
   GpuBatchDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, int n_channels,
                   const wfst_limits *limits = nullptr, void *hip_stream = nullptr);
+  GpuBatchDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm, int n_channels,
+                  const wfst_limits *limits = nullptr, void *hip_stream = nullptr);  // biglm
   ~GpuBatchDecoder();
   void InitDecoding(const std::vector<int> &channels = std::vector<int>());
   void AdvanceDecoding(const std::vector<int> &channels, const std::vector<const float *> &device_loglikes,
@@ -244,6 +275,9 @@ class GpuBatchDecoder {
   wfst_decoder *_dec;
   int _n;
 };
+
+// the reference's name for the biglm decoder (biglm.h:570): `OnlineLatticeDecoderMempoolBiglm decode(&fst, opt, &lm1, &lm2);`
+typedef GpuLatticeDecoder OnlineLatticeDecoderMempoolBiglm;
 
 }  // namespace datemoon
 #endif

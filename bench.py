@@ -77,6 +77,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of each timed CPU-baseline leg (1 thread, all cores)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores leg (0 = every CPU this process may run on)")
     ap.add_argument("--no-service-point", action="store_true", help="skip the second workload (single planted path, 7000/200)")
+    ap.add_argument("--biglm", action="store_true", help="BASELINE configs[3]: on-the-fly LM rescoring (wfst_decoder_create_biglm) with a "
+                    "synthetic bigram (old) / trigram (new) LM pair over the graph's 50k words; NOT the headline")
+    ap.add_argument("--lm-old", default="20000,5,0,0", help="old LM: bigram contexts, successors, trigram contexts, successors")
+    ap.add_argument("--lm-new", default="40000,6,100000,3", help="new LM: same four numbers")
+    ap.add_argument("--lm-pairs", type=int, default=1 << 20, help="LM pair states per utterance (wfst_limits.lm_pairs)")
     ap.add_argument("--graph-cache", default="/tmp/wfst_bench_graph_%d.bin")
     return ap.parse_args()
 
@@ -124,12 +129,14 @@ class quiet_stderr:
         os.close(self.devnull)
 
 
-def cpu_decode_all(dec, graph_path, cd, mats, m, n_threads):
-    """Decode every matrix once on n_threads host threads (results for parity / divergence)."""
+def cpu_decode_all(dec, graph_path, cd, mats, m, n_threads, big=None):
+    """Decode every matrix once on n_threads host threads (results for parity / divergence).
+    big = (old LM path, new LM path): the biglm decoder (the restatement runs in fixed mode)."""
     import pyoracle
 
     h = dec.load_graph(graph_path)
     cfg = pyoracle.Config(**cd)
+    lms = [pyoracle.Lm(dec, big[0], -1.0), pyoracle.Lm(dec, big[1], 1.0)] if big else None
     results = [None] * len(mats)
     nxt = [0]
     lock = threading.Lock()
@@ -141,17 +148,22 @@ def cpu_decode_all(dec, graph_path, cd, mats, m, n_threads):
                 nxt[0] += 1
             if i >= len(mats):
                 return
-            results[i] = dec.decode(h, cfg, mats[i], m)
+            if lms:
+                results[i] = pyoracle.biglm_decode(dec, h, cfg, lms[0], lms[1], mats[i], m, fixed=True)
+            else:
+                results[i] = dec.decode(h, cfg, mats[i], m)
 
     with quiet_stderr():
         th = [threading.Thread(target=work) for _ in range(max(1, min(n_threads, len(mats))))]
         [t.start() for t in th]
         [t.join() for t in th]
+    for L in lms or []:
+        L.free()
     dec.free_graph(h)
     return results
 
 
-def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds):
+def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds, big=None):
     """frames/s of the CPU decoder: n_threads host threads, ONE decoder object per thread over one
     shared read-only graph -- the reference service's threading model (v2-asrbin/v2-asr-service.cc:
     95-105) -- each looping over the batch's utterances (thread t takes t, t + n_threads, ...) for
@@ -162,7 +174,8 @@ def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds):
 
     h = dec.load_graph(graph_path)
     cfg = pyoracle.Config(**cd)
-    f = getattr(dec.lib, ("ref" if kind == "reference" else "oracle") + "_timed_loop")
+    lms = [pyoracle.Lm(dec, big[0], -1.0), pyoracle.Lm(dec, big[1], 1.0)] if big else None
+    f = getattr(dec.lib, ("ref" if kind == "reference" else "oracle") + ("_biglm" if big else "") + "_timed_loop")
     f.restype = C.c_longlong
     keep = [np.ascontiguousarray(x, np.float32) for x in mats]
     ptrs = (C.c_void_p * len(keep))(*[x.ctypes.data for x in keep])
@@ -173,7 +186,8 @@ def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds):
 
     def work(t):
         el, nw = C.c_double(0), C.c_longlong(0)
-        frames[t] = f(C.c_void_p(h), C.byref(cfg), ptrs, Ts.ctypes.data_as(C.POINTER(C.c_int)), len(keep), stride,
+        head = [C.c_void_p(h), C.byref(cfg)] + ([C.c_void_p(lms[0].h), C.c_void_p(lms[1].h)] if lms else [])
+        frames[t] = f(*head, ptrs, Ts.ctypes.data_as(C.POINTER(C.c_int)), len(keep), stride,
                       mm.ctypes.data_as(C.POINTER(C.c_int)), int(mm.shape[0] - 1), t, n_threads, C.c_double(seconds),
                       C.byref(el), C.byref(nw))
 
@@ -183,6 +197,8 @@ def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds):
         [t.start() for t in th]
         [t.join() for t in th]
         dt = time.perf_counter() - t0
+    for L in lms or []:
+        L.free()
     dec.free_graph(h)
     return sum(frames) / dt, dt, sum(frames)
 
@@ -333,13 +349,31 @@ def main():
 
     graph = wfstdec.Graph.from_arrays(g.start, g.final_state, g.state_info, g.arcs, device=local_rank)
     graph.set_tid2pdf(m)
+    big, lm_dev, lm_info = None, [None, None], None
+    if a.biglm:
+        lmsynth = importlib.import_module("asr-decoder_amd.lmsynth")
+        V = int(g.arcs["olabel"].max())
+        t0 = time.time()
+        big = []
+        for tag, spec, order, seed in (("old", a.lm_old, 2, 41), ("new", a.lm_new, 3, 42)):
+            nb, s2, nt, s3 = (int(x) for x in spec.split(","))
+            lp = "/tmp/wfst_bench_lm_%s_%d_%s.bin%s" % (tag, V, spec.replace(",", "_"), ".r%d" % rank if world > 1 else "")
+            if not os.path.exists(lp):
+                lm = lmsynth.make_lm(V, 3 if nt > 0 else 2, nb, s2, nt, s3, seed=seed)
+                lm.to_fsa().write(lp + ".tmp%d" % os.getpid())
+                os.replace(lp + ".tmp%d" % os.getpid(), lp)
+            big.append(lp)
+        lm_dev = [wfstdec.Lm.load(big[0], -1.0, device=local_rank), wfstdec.Lm.load(big[1], 1.0, device=local_rank)]
+        lm_info = [x.info() for x in lm_dev]
+        log("[rank %d] LMs: old %d states / %d arcs, new %d states / %d arcs (%.1fs)" % (
+            rank, lm_info[0]["n_states"], lm_info[0]["n_arcs"], lm_info[1]["n_states"], lm_info[1]["n_arcs"], time.time() - t0))
     stream = torch.cuda.current_stream(dev).cuda_stream
     opt = wfstdec.Options(use_hip_graph=0 if a.no_hip_graph else 1, **({"channel_groups": a.groups} if a.groups > 0 else {}))
 
     def new_decoder(cfg_dict):
         return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=131072,
                                     arena_tokens=int(T * a.arena_per_frame), stream=stream, lattice_links=a.lattice_links,
-                                    options=opt)
+                                    options=opt, old_lm=lm_dev[0], new_lm=lm_dev[1], lm_pairs=a.lm_pairs if a.biglm else 0)
 
     dec = new_decoder(cd)
     ready = [T] * B
@@ -418,7 +452,10 @@ def main():
               "max_active %d / min_active %d: where they bind the reference's cutoff depends on its hash-list visiting order "
               "(order-free parity, DESIGN.md section 4)" % (a.max_active, a.min_active))
     out = {
-        "metric": ("frames/sec decoded, log-likelihoods handed over as HOST matrices every step (PCIe-inclusive); " + regime
+        "metric": ("frames/sec decoded WITH on-the-fly LM rescoring (biglm, BASELINE configs[3]: every word-labelled arc costs "
+                   "new LM - old LM, tokens keyed by (graph state, LM pair state)); parity: bit-exact with the CPU restatement of "
+                   "the reference's biglm decoder in its fixed DiffArpaLm mode (DESIGN.md section 4)" if a.biglm else
+                   "frames/sec decoded, log-likelihoods handed over as HOST matrices every step (PCIe-inclusive); " + regime
                    if a.host_feed else
                    "frames/sec decoded (RTFx = value/100) at fixed beam; " + regime
                    if a.lattice_links == 0 else
@@ -429,8 +466,11 @@ def main():
         "dtype": "f32", "data": "synthetic (seeded hclg-like graph + %s log-likelihoods, SURVEY.md 8(d))" % (
             "%d-live-hypotheses" % a.paths if a.workload == "multi" else "single-planted-path"),
         "config": {
-            "workload": "BASELINE configs[1]: batch=%d utterances/GPU x %d frames, %d-arc HCLG, beam=%g, "
-                        "max_active=%d, min_active=%d, %d pdfs" % (B, T, g.n_arcs, a.beam, a.max_active, a.min_active, P),
+            "workload": ("BASELINE configs[3] (biglm) on " if a.biglm else "") +
+                        "BASELINE configs[1]: batch=%d utterances/GPU x %d frames, %d-arc HCLG, beam=%g, "
+                        "max_active=%d, min_active=%d, %d pdfs" % (B, T, g.n_arcs, a.beam, a.max_active, a.min_active, P) +
+                        (("; old LM %d states / %d arcs (scale -1), new LM %d states / %d arcs" % (
+                            lm_info[0]["n_states"], lm_info[0]["n_arcs"], lm_info[1]["n_states"], lm_info[1]["n_arcs"])) if a.biglm else ""),
             "global_batch": world * B, "frames_per_utt": T, "parallelism": "utterance-sharded x%d (graph replicated)" % world,
             "rtfx": value / 100.0,
             "channel_groups": int(opt.channel_groups),
@@ -452,11 +492,20 @@ def main():
             nth = a.cpu_threads or cpus
             kind, cdec = cpu_decoder()
             sample = [mats[i] for i in range(ns)]
-            cres = cpu_decode_all(cdec, gpath, cd, sample, m, min(ns, cpus))
+            if a.biglm:
+                # parity target: the restatement in FIXED DiffArpaLm mode (the reference as written hands the
+                # pair id to both LMs, newlm/diff-lm.h:80,86); the timed baseline below is the reference's own
+                # biglm decoder where its library is present -- same loop, same amount of LM work
+                import pyoracle
+
+                pyoracle.build_oracle()
+                cres = cpu_decode_all(pyoracle.OracleDecoder(), gpath, cd, sample, m, min(ns, cpus), big=big)
+            else:
+                cres = cpu_decode_all(cdec, gpath, cd, sample, m, min(ns, cpus))
             dv = divergence(res[:ns], cres)
             # timed legs: one thread, then every CPU this process may run on
-            fps1, cdt1, fr1 = cpu_timed(kind, cdec, gpath, cd, list(mats), m, 1, a.cpu_seconds)
-            fps, cdt, fr = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nth, a.cpu_seconds)
+            fps1, cdt1, fr1 = cpu_timed(kind, cdec, gpath, cd, list(mats), m, 1, a.cpu_seconds, big=big)
+            fps, cdt, fr = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nth, a.cpu_seconds, big=big)
             cpu_model = ""
             try:
                 with open("/proc/cpuinfo") as f:
@@ -470,9 +519,15 @@ def main():
                                              "single thread: %d frames in %.1fs" % (B, nth, cdt, fr, fr1, cdt1),
                                    "affinity_cpus": cpus, "host_cpus": os.cpu_count()}
             out["config"]["parity"] = "%d/%d sampled utterances bit-exact (words, transition-ids, tot_score) vs the %s CPU decoder" % (
-                dv["bit_identical"], ns, "reference" if kind == "reference" else "oracle")
-            oc = oracle_counts(gpath, cd, sample, m)
-            if dv["bit_identical"] < ns:
+                dv["bit_identical"], ns, "oracle (biglm, fixed mode)" if a.biglm else "reference" if kind == "reference" else "oracle")
+            if a.biglm:
+                oc = {k: sum(r.extra[k] for r in cres) for k in ("N", "E", "Z", "L")}
+                oc["ties_on_best_path"] = sum(r.extra["ties"] for r in cres)
+                oc["lm_pairs_max"] = max(r.extra["lm_pairs"] for r in cres)
+                n_lm = oc["L"]
+            else:
+                oc = oracle_counts(gpath, cd, sample, m)
+            if dv["bit_identical"] < ns and not a.biglm:
                 # where max_active / min_active bind, the reference's cutoff depends on tokens it
                 # keeps in hash-list visiting order; the order-independent restatement of the same
                 # algorithm (oracle, order-free mode) is what the GPU must equal bit for bit
@@ -493,6 +548,13 @@ def main():
         # backpointer/arena write), 24 B per traversed epsilon arc.  Per kernel (DESIGN.md "Roofline
         # accounting"): expand = 20 E + 16 N, insert = 8 E + 8 N, closure = 24 Z.
         kb = {"expand": scale * (20.0 * E + 16.0 * N), "insert": scale * (8.0 * E + 8.0 * N), "closure": 24.0 * Z}
+        if a.biglm and do_cpu and oc["E"] > 0:
+            # biglm: + 96 B per word-labelled arc traversed (8 B pair key; per LM 16 B state record, 4 B x ~4 probes of
+            # the word-sorted arcs, 8 B arc {weight, next}; 8 B pair-table slot), + 4 B LM pair id per token and record
+            Lb = n_lm * (E / float(max(oc["E"], 1)))   # look-ups of the whole batch, scaled from the sample by the emitting arcs
+            kb["expand"] += 96.0 * Lb + scale * (4.0 * E + 4.0 * N)
+            kb["insert"] += scale * (4.0 * E + 4.0 * N)
+            out["config"]["lm_lookups_per_step"] = Lb
         dom = max(("expand", "insert", "closure"), key=lambda k: prof[k + "_ms"])
         k_ms, k_n, k_bytes = prof[dom + "_ms"], prof[dom + "_launches"], kb[dom]
         per_launch_bytes = k_bytes / max(k_n, 1)
@@ -523,7 +585,7 @@ def main():
                                           "frac_over_step_time": whole_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                            "measured": "hipEvent pairs around every launch on the decoder's stream, one extra step after the timed region"}
     # ---- second workload: SURVEY 8(d) generator at the reference service's operating point ----
-    if rank == 0 and world == 1 and not a.no_service_point and a.lattice_links == 0 and not a.host_feed and a.workload == "multi":
+    if rank == 0 and world == 1 and not a.no_service_point and a.lattice_links == 0 and not a.host_feed and a.workload == "multi" and not a.biglm:
         dec.free()
         dec = None
         t0 = time.time()
@@ -576,6 +638,9 @@ def main():
         print(json.dumps(out, default=plain), flush=True)
     if dec is not None:
         dec.free()
+    for L in lm_dev:
+        if L is not None:
+            L.free()
     graph.free()
     if world > 1:
         dist.barrier()

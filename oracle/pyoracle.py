@@ -457,7 +457,7 @@ def biglm_decode(dec, graph_handle, cfg, lm1, lm2, loglikes, tid2pdf=None, chunk
     head = [C.c_void_p(graph_handle), C.byref(cfg), C.c_void_p(lm1.h), C.c_void_p(lm2.h)]
     if not is_ref:
         head.append(int(bool(fixed)))
-    ex = np.zeros(8, np.int64)
+    ex = np.zeros(10, np.int64)
     args = head + [_fp(ll), T, stride, _ip(tid2pdf), n_tid, int(chunk), int(bool(finalize)), int(bool(use_final_probs)),
                    _ip(pi), _ip(po), _fp(pg), _fp(pa), max_path, C.byref(n_path), C.byref(tot), C.byref(lm), _ip(words), max_path,
                    C.byref(n_words), _ip(tids), max_path, C.byref(n_tids), _ip(fn), _fp(fb), C.byref(nt), C.byref(nl)]
@@ -469,5 +469,5 @@ def biglm_decode(dec, graph_handle, cfg, lm1, lm2, loglikes, tid2pdf=None, chunk
                pi[:n].copy(), po[:n].copy(), pg[:n].copy(), pa[:n].copy(), fn, fb, None, nt.value, nl.value)
     if not is_ref:
         r.extra = dict(N=int(ex[0]), E=int(ex[1]), Z=int(ex[2]), tokens_created=int(ex[3]), links_created=int(ex[4]),
-                       ties=int(ex[5]), quirk_hops=int(ex[6]), lm_pairs=int(ex[7] & ((1 << 40) - 1)), lm_oob=int(ex[7] >> 40))
+                       ties=int(ex[5]), quirk_hops=int(ex[6]), lm_pairs=int(ex[7] & ((1 << 40) - 1)), lm_oob=int(ex[7] >> 40), L=int(ex[8]))
     return r

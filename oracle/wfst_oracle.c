@@ -119,6 +119,7 @@ typedef struct {
   const float *ll; int T, stride; const int *tid2pdf; int frames_ready;
   /* work counters for the roofline's algorithmic bytes */
   int64_t cnt_N, cnt_E, cnt_Z, cnt_tok_created, cnt_link_created;
+  int64_t cnt_L; /* biglm: arcs with an output label traversed (LM look-ups) */
 } Decoder;
 
 static void *pool_new(Pool *p) {
@@ -485,6 +486,7 @@ static void process_nonemitting(Decoder *d, float cutoff) {
         int next_lm = 0;
         if (d->dlm) { /* biglm.h:448-451 */
           float lm_score;
+          if (arc->olabel != 0) d->cnt_L++;
           next_lm = next_lm_state(d->dlm, lm_state, arc->olabel, &lm_score);
           graph_cost = arc->w + lm_score;
         }
@@ -565,6 +567,7 @@ static float process_emitting(Decoder *d) {
           int next_lm = 0;
           if (d->dlm) { /* biglm.h:377-380: the LM is asked before the acoustic score */
             float lm_score;
+            if (arc->olabel != 0) d->cnt_L++;
             next_lm = next_lm_state(d->dlm, lm_state, arc->olabel, &lm_score);
             graph_cost = arc->w + lm_score;
           }
@@ -869,7 +872,8 @@ static int decode_impl(void *gp, const Config *rc, DiffLm *dlm, const float *log
     }
   }
   if (extra) { extra[0] = d->cnt_N; extra[1] = d->cnt_E; extra[2] = d->cnt_Z; extra[3] = d->cnt_tok_created; extra[4] = d->cnt_link_created; extra[5] = tie_hops; extra[6] = quirk_hops;
-               extra[7] = dlm ? ((int64_t)dlm->n_vec | ((int64_t)dlm->oob << 40)) : 0; }
+               extra[7] = dlm ? ((int64_t)dlm->n_vec | ((int64_t)dlm->oob << 40)) : 0;
+               if (dlm) extra[8] = d->cnt_L; /* biglm callers pass 10 slots */ }
 
   /* teardown */
   clear_active_tokens(d);
@@ -896,7 +900,7 @@ int oracle_decode_ex(void *gp, const Config *rc, const float *loglikes, int T, i
 }
 
 /* biglm: same arguments as ref_biglm_decode() in oracle/ref_driver.cc plus `fixed` (0: DiffArpaLm as
- * written, 1: pair components) and `extra` (8 x int64: as oracle_decode_ex; [7] = LM pair states
+ * written, 1: pair components) and `extra` (10 x int64: [0..6] as oracle_decode_ex; [8] = labelled arcs traversed = LM look-ups; [7] = LM pair states
  * interned | (out-of-range LM access seen) << 40).  lm1 = old LM (rescaled by -1 at load), lm2 = new. */
 int oracle_biglm_decode(void *gp, const Config *rc, void *lm1, void *lm2, int fixed, const float *loglikes, int T,
                         int stride, const int *tid2pdf, int n_tid, int chunk, int do_finalize, int use_final_probs,
@@ -1043,6 +1047,32 @@ long long oracle_timed_loop(void *gp, const Config *rc, const float *const *mats
     int np = 0, nw = 0, nt = 0, a = 0, b = 0; float tot = 0, lm = 0;
     oracle_decode_ex(gp, rc, mats[i], T[i], stride, tid2pdf, n_tid, 0, 1, 1, ib, ib + mp, fb, fb + mp, mp, &np, &tot, &lm,
                      ib + 2 * mp, mp, &nw, ib + 3 * mp, mp, &nt, NULL, NULL, -1, NULL, NULL, 0, NULL, &a, &b, NULL);
+    free(ib); free(fb);
+    nwords += nw; frames += T[i];
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (dt >= seconds) break;
+  }
+  if (elapsed) *elapsed = dt;
+  if (words_out) *words_out = nwords;
+  return frames;
+}
+
+/* oracle_timed_loop() for the biglm decoder (fixed mode); bench.py --biglm where oracle/_ref is absent. */
+long long oracle_biglm_timed_loop(void *gp, const Config *rc, void *lm1, void *lm2, const float *const *mats, const int *T,
+                                  int n_mats, int stride, const int *tid2pdf, int n_tid, int first, int step,
+                                  double seconds, double *elapsed, long long *words_out) {
+  long long frames = 0, nwords = 0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  double dt = 0.0;
+  for (int i = first % n_mats;; i = (i + step) % n_mats) {
+    const int mp = 4 * T[i] + 64;
+    int *ib = (int *)malloc(sizeof(int) * 4 * (size_t)mp);
+    float *fb = (float *)malloc(sizeof(float) * 2 * (size_t)mp);
+    int np = 0, nw = 0, nt = 0, a = 0, b = 0; float tot = 0, lm = 0;
+    oracle_biglm_decode(gp, rc, lm1, lm2, 1, mats[i], T[i], stride, tid2pdf, n_tid, 0, 1, 1, ib, ib + mp, fb, fb + mp, mp, &np,
+                        &tot, &lm, ib + 2 * mp, mp, &nw, ib + 3 * mp, mp, &nt, NULL, NULL, &a, &b, NULL);
     free(ib); free(fb);
     nwords += nw; frames += T[i];
     clock_gettime(CLOCK_MONOTONIC, &t1);
