@@ -62,7 +62,8 @@ struct wfst_graph {
   std::vector<int32_t> pos_host;  // row position of each original state id (sorted)
   int32_t orig_start = 0, orig_final = 0;
   DevBuf<int32_t> arc_ilabel, arc_olabel, arc_src, eps_target_state;
-  DevBuf<int4> eps_flat;
+  DevBuf<int4> eps_flat, pseudo;
+  int32_t fused = 0;  // epsilon closures folded into the rows as pseudo arcs (wfst_device.h)
   uint32_t start_eps = 0;
   int32_t n_eps_targets = 0;
   GraphDev view() const {
@@ -73,6 +74,8 @@ struct wfst_graph {
     g.arc_src = arc_src.p;
     g.eps_target_state = eps_target_state.p;
     g.eps_flat = eps_flat.p;
+    g.pseudo = pseudo.p;
+    g.fused = fused;
     g.start_eps = start_eps;
     g.n_eps_targets = n_eps_targets;
     g.start = start;
@@ -88,6 +91,7 @@ struct wfst_graph {
     arc_src.release();
     eps_target_state.release();
     eps_flat.release();
+    pseudo.release();
   }
 };
 
@@ -247,6 +251,7 @@ void wfst_options_default(wfst_options *o) {
 void wfst_graph_options_default(wfst_graph_options *o) {
   o->row_align_slots = 4;
   o->flatten_closures = 1;
+  o->fuse_closures = 1;
 }
 
 const char *wfst_last_error(void) { return g_err.c_str(); }
@@ -317,29 +322,23 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
   if (ndev <= 0) return fail(WFST_E_DEVICE, "no HIP device available (this library has no CPU path)");
   if (device < 0 || device >= ndev) return fail(WFST_E_ARG, "device index out of range");
   HIP_TRY(hipSetDevice(device));
-  if ((int64_t)n_arcs + n_states >= (int64_t)kNoArc / 2)
+  if ((int64_t)n_arcs + n_states >= (int64_t)kNoArc)
     return fail(WFST_E_FORMAT, "graphs with states + arcs >= 2^29 are not supported");
   // A row (header + arcs, 16-byte slots) that fits in k 64-byte lines is placed so that it touches
   // only k lines: expanding a token is a random gather, priced per LINE, and an unaligned 3-arc row
   // straddles two.  Costs ~10 % padding slots.  row_align_slots = 1 packs the rows tightly.
   const int64_t line_slots = GO.row_align_slots;
 
-  // pass 1: validate, positions, epsilon targets
-  std::vector<int32_t> pos((size_t)n_states);
+  // pass 0: validate, arc offsets, epsilon targets
+  std::vector<int64_t> aoff((size_t)n_states + 1, 0);
   std::vector<uint8_t> is_target((size_t)n_states, 0);
-  int64_t off = 0, next_slot = 0;
+  int64_t off = 0;
   for (int32_t s = 0; s < n_states; ++s) {
-    {
-      const int64_t sz = 1 + (int64_t)states[s].num_arcs, in_line = next_slot % line_slots;
-      if ((in_line + sz + line_slots - 1) / line_slots > (sz + line_slots - 1) / line_slots)
-        next_slot += line_slots - in_line;
-    }
     const uint32_t na = states[s].num_arcs, ne = states[s].niepsilons;
     if (ne > na || off + na > n_arcs) return fail(WFST_E_FORMAT, "state arc counts inconsistent with total_arcs");
     if (ne > kEpsMask) return fail(WFST_E_FORMAT, "state with more than 4095 input-epsilon arcs");
     if (na - ne >= (1u << (32 - kEpsBits))) return fail(WFST_E_FORMAT, "state with 2^20 or more emitting arcs");
-    pos[s] = (int32_t)next_slot;
-    next_slot += 1 + (int64_t)na;
+    aoff[(size_t)s] = off;
     for (uint32_t i = 0; i < na; ++i) {
       const wfst_arc &a = arcs[off + i];
       if ((i < ne) != (a.ilabel == 0))
@@ -349,9 +348,62 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
     }
     off += na;
   }
+  aoff[(size_t)n_states] = off;
   if (off != n_arcs) return fail(WFST_E_FORMAT, "sum of num_arcs != total_arcs");
-  const int64_t N = next_slot;  // slots of rows[] (headers + arcs + padding)
-  if (N >= (int64_t)kNoArc) return fail(WFST_E_FORMAT, "graph too large for 30-bit row indices");
+
+  // pass 0b: FUSED epsilon closures (wfst_device.h "pseudo arcs").  The whole epsilon closure of every
+  // state with epsilon arcs out as a list of paths {target, last arc, parent path, weight of the last
+  // arc}, parents first.  Fusable iff every closure is small and shallow (no epsilon cycle) and no
+  // epsilon arc has a negative weight (then a path's cost is never below its prefix's, and one test of
+  // the arrival against the cutoff stands for ProcessNonemitting's test at every hop, base-inl.h:391,415).
+  struct ClPath { int32_t target, src, arc_i, parent, depth; float w; };
+  constexpr int kClPathCap = 48, kClDepthCap = kPseudoDepthMax;
+  std::vector<int32_t> cl_first((size_t)n_states, 0), cl_cnt((size_t)n_states, 0);
+  std::vector<ClPath> cl;
+  bool fused = GO.fuse_closures != 0;
+  for (int32_t s = 0; s < n_states && fused; ++s) {
+    if (!states[s].niepsilons) continue;
+    const size_t first = cl.size();
+    cl_first[(size_t)s] = (int32_t)first;
+    // breadth first: the state's own epsilon arcs, then those of every path's end state in list order
+    for (int64_t k = -1; fused && (k < 0 || (size_t)k < cl.size() - first); ++k) {
+      const int32_t u = k < 0 ? s : cl[first + (size_t)k].target;
+      const int32_t dep = k < 0 ? 1 : cl[first + (size_t)k].depth + 1;
+      for (uint32_t i = 0; i < states[u].niepsilons; ++i) {
+        const wfst_arc &a = arcs[aoff[(size_t)u] + i];
+        if (!(a.weight >= 0.0f) || dep > kClDepthCap || cl.size() - first >= (size_t)kClPathCap) { fused = false; break; }
+        cl.push_back(ClPath{a.nextstate, u, (int32_t)i, (int32_t)k, dep, a.weight});
+      }
+    }
+    cl_cnt[(size_t)s] = (int32_t)(cl.size() - first);
+  }
+  std::vector<int32_t> n_pseudo((size_t)n_states, 0);
+  if (fused) {
+    for (int32_t s = 0; s < n_states && fused; ++s) {
+      int64_t np = 0;
+      for (uint32_t i = states[s].niepsilons; i < states[s].num_arcs; ++i) np += cl_cnt[(size_t)arcs[aoff[(size_t)s] + i].nextstate];
+      if (np >= (1 << 20)) fused = false;
+      n_pseudo[(size_t)s] = (int32_t)np;
+    }
+  }
+  if (!fused) {
+    cl.clear();
+    std::fill(n_pseudo.begin(), n_pseudo.end(), 0);
+    std::fill(cl_cnt.begin(), cl_cnt.end(), 0);
+  }
+
+  // pass 1: positions
+  std::vector<int32_t> pos((size_t)n_states);
+  int64_t next_slot = 0;
+  for (int32_t s = 0; s < n_states; ++s) {
+    const int64_t sz = 1 + (int64_t)states[s].num_arcs + 2 * (int64_t)n_pseudo[(size_t)s], in_line = next_slot % line_slots;
+    if ((in_line + sz + line_slots - 1) / line_slots > (sz + line_slots - 1) / line_slots)
+      next_slot += line_slots - in_line;
+    pos[s] = (int32_t)next_slot;
+    next_slot += sz;
+    if (next_slot >= (int64_t)kNoArc) return fail(WFST_E_FORMAT, "graph too large for 29-bit row indices");
+  }
+  const int64_t N = next_slot;  // slots of rows[] (headers + arcs + pseudo arcs + padding)
   // next_eps word per state: bit 31 = has outgoing epsilon arcs, bits 30..0 = 1 + ordinal among
   // the epsilon-target states (the index of the state's slot in every channel's epsilon table)
   std::vector<uint32_t> next_eps((size_t)n_states, 0u);
@@ -373,9 +425,34 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
     int4 h;
     h.x = (int32_t)(((na - ne) << kEpsBits) | ne);
     h.y = s;
-    h.z = (int32_t)next_eps[s];
+    h.z = n_pseudo[(size_t)s];  // pseudo arcs behind the emitting arcs (fused closures)
     h.w = 0;
     ext[(size_t)pos[s]] = h;
+    {  // pseudo arcs: one per (emitting arc, path of its target's closure)
+      size_t q = (size_t)pos[s] + 1 + na;
+      for (uint32_t i = ne; i < na && fused; ++i) {
+        const wfst_arc &a = arcs[off + i];
+        for (int32_t p = 0; p < cl_cnt[(size_t)a.nextstate]; ++p, q += 2) {
+          const ClPath &cp = cl[(size_t)cl_first[(size_t)a.nextstate] + p];
+          int4 v;  // two slots per pseudo arc, loaded together: no dependent look-up for a one-hop path
+          v.x = -1;
+          v.y = cl_first[(size_t)a.nextstate] + p;  // its path in pseudo[] (walked for paths of several hops)
+          memcpy(&v.z, &a.weight, 4);               // weight of the emitting arc
+          v.w = pos[cp.target];
+          ext[q] = v;
+          h_src[q] = pos[s];
+          h_il[q] = a.ilabel;                        // same log-likelihood column as the emitting arc
+          h_ol[q] = 0;
+          int4 b;
+          b.x = (int32_t)((uint32_t)(pos[cp.src] + 1 + cp.arc_i) | flags_of(next_eps[(size_t)cp.target]));  // last arc | flags of the end state
+          memcpy(&b.y, &cp.w, 4);                    // weight of the last arc
+          b.z = cp.depth;
+          b.w = 0;
+          if (cp.depth >= 2) memcpy(&b.w, &cl[(size_t)cl_first[(size_t)a.nextstate] + cp.parent].w, 4);  // weight of the hop before
+          ext[q + 1] = b;                            // (h_il stays kHeaderLabel: no log-likelihood column here)
+        }
+      }
+    }
     for (uint32_t i = 0; i < na; ++i) {
       const wfst_arc &a = arcs[off + i];
       const size_t q = (size_t)pos[s] + 1 + i;
@@ -398,8 +475,6 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
   // epsilon arcs; a closure with more than kFlatMax paths (or an epsilon cycle) stays iterative
   std::vector<int4> h_flat;
   if (GO.flatten_closures) {
-    std::vector<int64_t> aoff((size_t)n_states + 1, 0);
-    for (int32_t s = 0; s < n_states; ++s) aoff[(size_t)s + 1] = aoff[s] + states[s].num_arcs;
     struct Node { int32_t state, parent; };
     for (int32_t s = 0; s < n_states; ++s) {
       if (!states[s].niepsilons) continue;
@@ -431,8 +506,28 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
     if (h_flat.size() >= (1u << 28)) return fail(WFST_E_FORMAT, "too many flattened epsilon closures");
   }
 
+  // the paths themselves: {last arc (row index) | flags of the target state, parent path or -1, weight bits, depth}
+  std::vector<int4> h_pseudo(cl.size());
+  for (size_t k = 0; k < cl.size(); ++k) {
+    const ClPath &cp = cl[k];
+    int4 v;
+    v.x = (int32_t)((uint32_t)(pos[cp.src] + 1 + cp.arc_i) | flags_of(next_eps[(size_t)cp.target]));
+    v.y = -1;  // parent: set below (indices are relative to the closure's first entry)
+    memcpy(&v.z, &cp.w, 4);
+    v.w = cp.depth;
+    h_pseudo[k] = v;
+  }
+  {
+    for (int32_t s = 0; s < n_states; ++s)
+      for (int32_t p = 0; p < cl_cnt[(size_t)s]; ++p) {
+        const size_t k = (size_t)cl_first[(size_t)s] + p;
+        h_pseudo[k].y = cl[k].parent < 0 ? -1 : cl_first[(size_t)s] + cl[k].parent;
+      }
+  }
+
   wfst_graph *g = new wfst_graph();
   g->device = device;
+  g->fused = fused ? 1 : 0;
   g->start = pos[start];
   g->final_state = (final_state >= 0 && final_state < n_states) ? pos[final_state] : -1;
   g->orig_start = start;
@@ -449,7 +544,8 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
   if ((e = g->arcs.alloc((size_t)N)) != hipSuccess || (e = g->arc_ilabel.alloc((size_t)N)) != hipSuccess ||
       (e = g->arc_olabel.alloc((size_t)N)) != hipSuccess || (e = g->arc_src.alloc((size_t)N)) != hipSuccess ||
       (e = g->eps_target_state.alloc(h_targets.size())) != hipSuccess ||
-      (e = g->eps_flat.alloc(std::max<size_t>(1, h_flat.size()))) != hipSuccess) {
+      (e = g->eps_flat.alloc(std::max<size_t>(1, h_flat.size()))) != hipSuccess ||
+      (e = g->pseudo.alloc(std::max<size_t>(1, h_pseudo.size()))) != hipSuccess) {
     delete g;
     return fail(WFST_E_DEVICE, std::string("hipMalloc(graph): ") + hipGetErrorString(e));
   }
@@ -458,6 +554,7 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
       hipMemcpy(g->arc_olabel.p, h_ol.data(), h_ol.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       (!h_targets.empty() && hipMemcpy(g->eps_target_state.p, h_targets.data(), h_targets.size() * 4, hipMemcpyHostToDevice) != hipSuccess) ||
       (!h_flat.empty() && hipMemcpy(g->eps_flat.p, h_flat.data(), h_flat.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) ||
+      (!h_pseudo.empty() && hipMemcpy(g->pseudo.p, h_pseudo.data(), h_pseudo.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) ||
       hipMemcpy(g->arc_ilabel.p, g->ilabel_host.data(), g->ilabel_host.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(WFST_E_DEVICE, "hipMemcpy(graph) failed");
   if (rc == WFST_OK) rc = upload_columns(g, nullptr, 0, &ext);
@@ -509,7 +606,8 @@ int wfst_graph_info(const wfst_graph *g, int32_t *start, int32_t *final_state, i
   if (n_arcs) *n_arcs = g->n_arcs;
   if (device_bytes)
     *device_bytes = (int64_t)(g->arcs.bytes() + g->arc_ilabel.bytes() +
-                              g->arc_olabel.bytes() + g->arc_src.bytes() + g->eps_target_state.bytes() + g->eps_flat.bytes());
+                              g->arc_olabel.bytes() + g->arc_src.bytes() + g->eps_target_state.bytes() + g->eps_flat.bytes() +
+                              g->pseudo.bytes());
   return WFST_OK;
 }
 
@@ -821,6 +919,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.link_cap = L.lattice_links;
   D.lattice = L.lattice_links > 0 ? 1 : 0;
   D.big = big ? 1 : 0;
+  D.fused = (g->fused && !big && L.lattice_links == 0) ? 1 : 0;
   if (big) {
     D.lm_old = old_lm->view();
     D.lm_new = new_lm->view();

@@ -16,7 +16,7 @@ namespace wfst {
 // rows[]: ONE int4 array in "ext" index space.  State s owns slots [pos(s), pos(s)+1+num_arcs(s)),
 //   pos(s) increasing in s (rows are packed, with padding slots where a row would otherwise
 //   straddle one more 64-byte line than it needs), and IS identified by pos(s) everywhere on the device.
-//   rows[pos(s)]      header {(n_emit << 12) | n_eps, original state id, next_eps word of s,
+//   rows[pos(s)]      header {(n_emit << 12) | n_eps, original state id, pseudo arcs of s (fused closures),
 //                     (first entry in eps_flat[] << 3) | entries, entries = 0: not flattened}
 //   rows[pos(s)+1+i]  arc i {ll_col, next_eps(nextstate), weight bits, pos(nextstate)}; epsilon arcs
 //                     first.  ll_col = log-likelihood column of the ilabel (tid2pdf applied at
@@ -31,6 +31,20 @@ namespace wfst {
 //   parents before children.  The closure kernel prices such a state's closure in ONE round
 //   (cost of an entry = cost of its parent + weight, in path order, every prefix below the cutoff)
 //   instead of one round per epsilon hop.
+// FUSED closures (GraphDev::fused, best-path decoders): the epsilon closure folded into the expansion.
+//   Behind a state's emitting arcs sit its PSEUDO ARCS, header.z of them: one per (emitting arc i ->
+//   s', path p of s''s whole epsilon closure) = {ll_col of arc i, index of p in pseudo[], weight bits of
+//   arc i, row of p's end state}.  pseudo[p] = {last arc of the path (row index) | flags of its end
+//   state, parent path or -1, weight bits of the last arc, hops}.  Expanding a pseudo arc prices
+//   ProcessEmitting's arrival at s' and ProcessNonemitting's walk from it in one go:
+//   ((cur + ac) + w_i) + w_1 + ... + w_k, summed in path order; the candidate it yields is an epsilon
+//   arrival (kEpsRec: loses an exact cost tie to an emitting arc; its token's predecessor is found at
+//   traceback, kPrevUnresolved).  FindOrAddToken is a minimum and float addition is monotone, so
+//   taking the minimum over the arrivals of EVERY candidate at s' equals the reference's walk from the
+//   final cost of the token at s'.  Needs: no epsilon cycle, closures of <= 48 paths and <=
+//   kPseudoDepthMax hops, no negative epsilon weight (a path then never costs less than its prefix, so
+//   one cutoff test on the arrival stands for the test at every hop).  Lattice and biglm decoders, and
+//   graphs that do not qualify, run the separate closure pass instead and ignore the pseudo arcs.
 // arc_ilabel[], arc_olabel[], arc_src[] (source row | bit 31 for an epsilon arc): cold arrays in
 //   the same index space.  eps_target_state[k] = row of epsilon-target ordinal k.
 struct GraphDev {
@@ -40,6 +54,8 @@ struct GraphDev {
   const int32_t *arc_src;
   const int32_t *eps_target_state;
   const int4 *eps_flat;
+  const int4 *pseudo;
+  int32_t fused;
   int32_t start, final_state, n_states, n_arcs;
   uint32_t start_eps;   // next_eps word of the start state
   int32_t n_eps_targets;
@@ -73,8 +89,10 @@ constexpr uint32_t kEpsOutBit = 0x40000000u;      // in a packed eps-table value
 __host__ __device__ inline uint32_t flags_of(uint32_t next_eps) {
   return (next_eps & kFlagOutEps) | ((next_eps & 0x7FFFFFFFu) ? kFlagEpsTarget : 0u);
 }
-constexpr uint32_t kArcMask = ~kFlagMask;          // arc indices are < 2^30
+constexpr uint32_t kEpsRec = 0x20000000u;          // in a candidate record / token: an epsilon arrival (fused closures)
+constexpr uint32_t kArcMask = ~(kFlagMask | kEpsRec);  // arc (row) indices are < 2^29
 constexpr uint32_t kNoArc = kArcMask;              // "no arc" (root token), flags kept beside it
+constexpr int kPseudoDepthMax = 8;                 // hops of a fused closure path
 constexpr int32_t kEmptyKey = -1;
 constexpr int32_t kPrevUnresolved = -3;  // token won by an epsilon arc: backpointer found at traceback
 constexpr unsigned long long kEmptyVal = ~0ull;
@@ -216,6 +234,7 @@ struct DecoderDev {
   //   eps_keys[c][ecap]       the epsilon table is HASHED in this mode (the state alone no longer
   //                           identifies a token): open-addressed keys (row | pair << 32) beside
   //                           eps_vals / eps_toki, ecap a power of two
+  int32_t fused;  // the graph's fused closures are in use (best-path, non-biglm decoder on a graph that has them)
   int32_t big;
   LmDev lm_old, lm_new;
   unsigned long long *pair_keys;

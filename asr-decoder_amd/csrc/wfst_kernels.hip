@@ -203,6 +203,7 @@ __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned l
   t_prev = now;
 }
 
+constexpr u64 kClaimedVal = ~0ull - 1;  // LDS hash value of a state whose token has been written (no record packs to it)
 constexpr int kHeavyItem = 900;  // records: insert items above this are handed out first
 
 // Which buckets share a workgroup?  Partitions of a light channel hold a few dozen records each;
@@ -284,9 +285,10 @@ constexpr int kTileTokens = kExpandThreads * kTokPerThread;  // frontier tokens 
 // counter, so a channel with 8x the tokens simply owns 8x the tiles (per-frame token counts are
 // heavy-tailed across a batch; a fixed share of workgroups per channel made every frame wait for
 // the heaviest one).
-// kBig = biglm mode (the plain instantiation carries none of it).
-template <bool kBig>
-__global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, int group, int par) {
+// kBig = biglm mode (the plain instantiation carries none of it).  kFused = the graph's fused epsilon
+// closures are in use (wfst_device.h): a token's pseudo arcs are expanded with its emitting arcs.
+template <bool kBig, bool kFused>
+__device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int par) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   FrameCtl *fc = D.fctl + group;
   const int total_tiles = fc->total_tiles[par];
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
   __shared__ int s_wsum[kExpandThreads / 64];
   __shared__ int s_cnt[64], s_lbase[65], s_gbase[64];
   __shared__ int4 s_rec[kChunk];
+  __shared__ int s_nemit[kFused ? kTileTokens : 1];  // fused closures: emitting arcs of each token (pseudo arcs follow)
   __shared__ int s_lm[kBig ? kTileTokens : 1];    // biglm: LM pair state of each token of the tile
   __shared__ int s_rec_lm[kBig ? kChunk : 1];     //        and of each sorted candidate
   __shared__ int s_ticket;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
     int4 *bucket = D.bucket + (size_t)c * P * bcap;
     int32_t *bucket_lm = kBig ? D.bucket_lm + (size_t)c * P * bcap : nullptr;
     int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
-    u64 nN = 0, nE = 0, nR = 0;
+    u64 nN = 0, nE = 0, nR = 0, nZf = 0;
     {
     // two adjacent frontier tokens per thread (a tile is 1024 tokens, so the tiles of a whole
     // batch fit the chip's resident workgroup slots in one wave)
@@ -343,13 +346,22 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
       const int i = tid * kTokPerThread + j;
       deg[j] = 0; arcbeg[j] = 0;
       cost[j] = __int_as_float(tk[j].y);
+      int nem = 0;
       if (i < n && cost[j] <= cutoff) {  // base-inl.h:315
-        const uint32_t dw = (uint32_t)D.g.arcs[tk[j].x].x;  // row header: (n_emit << 12) | n_eps
-        deg[j] = (int)(dw >> kEpsBits);
-        arcbeg[j] = tk[j].x + 1 + (int)(dw & kEpsMask);
+        if constexpr (kFused) {
+          const int4 hdr = D.g.arcs[tk[j].x];  // row header: {(n_emit << 12) | n_eps, -, pseudo arcs, -}
+          nem = (int)((uint32_t)hdr.x >> kEpsBits);
+          deg[j] = nem + hdr.z;
+          arcbeg[j] = tk[j].x + 1 + (int)((uint32_t)hdr.x & kEpsMask);
+        } else {
+          const uint32_t dw = (uint32_t)D.g.arcs[tk[j].x].x;  // row header: (n_emit << 12) | n_eps
+          nem = deg[j] = (int)(dw >> kEpsBits);
+          arcbeg[j] = tk[j].x + 1 + (int)(dw & kEpsMask);
+        }
         nN++;
-        nE += deg[j];
+        nE += nem;
       }
+      if constexpr (kFused) s_nemit[i] = nem;
     }
     int tsum = 0;
 #pragma unroll
@@ -401,10 +413,58 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
             int mid = (lo + hi) >> 1;
             if (s_base[mid] <= j) lo = mid; else hi = mid;
           }
-          const int a = s_arcbeg[lo] + (j - s_base[lo]);
+          int a = s_arcbeg[lo] + (j - s_base[lo]);
+          bool pseudo = false;
+          if constexpr (kFused) {
+            const int pi = (j - s_base[lo]) - s_nemit[lo];
+            pseudo = pi >= 0;
+            if (pseudo) a = s_arcbeg[lo] + s_nemit[lo] + 2 * pi;  // pseudo arcs take two slots each
+          }
           const int4 arc = D.g.arcs[a];
           float graph_cost = __int_as_float(arc.z);
           rec_lm[k] = 0;
+          if constexpr (kFused) {
+            // A pseudo arc is the emitting arc's arrival carried on over one path of the target's epsilon
+            // closure -- ((cur + ac) + w) + w_1 + ... + w_k in path order (base-inl.h:329, 414) -- an
+            // epsilon arrival at the path's end state.  It does not tighten next_cutoff (only emitting
+            // arcs do, base-inl.h:330-333 vs 415).  Its second slot {last arc | flags of the end state,
+            // weight of the last arc, hops} and the log-likelihood are loaded by every lane alike (an
+            // emitting arc's lane re-reads its own slot), so that the two kinds of lanes share one
+            // memory round trip instead of taking theirs one after the other.
+            const int4 leaf = D.g.arcs[a + (pseudo ? 1 : 0)];
+            const float base_cost = (s_cost[lo] + (-llrow[arc.x])) + graph_cost;
+            if (pseudo) {
+              float t = base_cost;
+              if (leaf.z == 1) {
+                t = t + __int_as_float(leaf.y);
+              } else if (leaf.z == 2) {  // the second slot also holds the weight of the hop before the last
+                t = (t + __int_as_float(leaf.w)) + __int_as_float(leaf.y);
+              } else {
+                // three hops or more (rare): the hops' weights from pseudo[], collected leaf to root, added root to leaf
+                float w[kPseudoDepthMax];
+                int4 e = D.g.pseudo[arc.y];
+#pragma unroll
+                for (int u = 0; u < kPseudoDepthMax; ++u) {
+                  w[u] = 0.0f;
+                  if (u < leaf.z) {
+                    w[u] = __int_as_float(e.z);
+                    if (u + 1 < leaf.z) e = D.g.pseudo[e.y];
+                  }
+                }
+#pragma unroll
+                for (int u = kPseudoDepthMax - 1; u >= 0; --u)
+                  if (u < leaf.z) t = t + w[u];
+              }
+              tot[k] = t;
+              rec[k] = make_int4(arc.w, __float_as_int(t), kPrevUnresolved, (int)((uint32_t)leaf.x | kEpsRec));
+              nZf++;
+            } else {
+              tot[k] = base_cost;
+              rec[k] = make_int4(arc.w, __float_as_int(base_cost), tok0 + lo, (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
+              tmin = fminf(tmin, base_cost);
+            }
+            continue;
+          }
           if constexpr (kBig) {  // biglm.h:377-388: graph_cost = arc weight + lm_score, next LM state into the key
             const int ol = D.g.arc_olabel[a];
             float lm_score = 0.0f;
@@ -487,10 +547,12 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
     }
     nN = wave_sum_u64(nN);
     nE = wave_sum_u64(nE);
-    if (lane == 0 && (nN | nE | nR)) {
+    if constexpr (kFused) nZf = wave_sum_u64(nZf);
+    if (lane == 0 && (nN | nE | nR | nZf)) {
       atomicAdd(&ctl->cnt_N, nN);
       atomicAdd(&ctl->cnt_E, nE);
       if (nR) atomicAdd(&ctl->cnt_rec, nR);
+      if (nZf) atomicAdd(&ctl->cnt_Z, nZf);  // closure paths priced (per candidate, not per token as the reference counts)
     }
     // the channel's last tile plans its insert work items (every thread's bucket atomics have
     // returned: their results were used above)
@@ -508,6 +570,12 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(DecoderDev D, in
   }
 }
 
+// The launch bounds' second number (waves per SIMD the kernel must fit) holds the plain and the fused
+// instantiation at 80 VGPRs = 6 waves per SIMD; one register more costs a sixth of the latency hiding.
+__global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_plain(DecoderDev D, int group, int par) { expand_body<false, false>(D, group, par); }
+__global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_fused(DecoderDev D, int group, int par) { expand_body<false, true>(D, group, par); }
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm(DecoderDev D, int group, int par) { expand_body<true, false>(D, group, par); }
+
 // =========================================================================================
 // insert_kernel.  A bucket whose records could overfill the LDS table is processed in 2^k
 // sub-passes, each taking the states of one sub-hash class (records >= distinct states, so the
@@ -520,8 +588,8 @@ constexpr int kInsertUnroll = 4;
 // then by ticket); 512 threads, dynamic LDS = lds_slots * 12 bytes (16 in lattice mode).
 // kLat = lattice mode (forward links recorded); the best-path instantiation carries none of it.
 // kBig = biglm mode: 64-bit keys (graph row | LM pair state << 32), LDS = lds_slots * 16 bytes.
-template <bool kLat, bool kBig>
-__global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, int group, int par) {
+template <bool kLat, bool kBig, bool kFused>
+__device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int par) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int SLmax = D.lds_slots;
@@ -690,7 +758,14 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
             const KeyT key = key_of(r[k], rl[k]);
             for (int q = 0; q < SL; ++q) {
               const KeyT kk = keys[slot];
-              if (kk == key) { winner = vals[slot] == packed; in_table = true; break; }
+              if (kk == key) {
+                // the record holding the state's minimum writes the token.  With fused closures two
+                // candidates at one state can yield the SAME epsilon arrival (same last arc, costs equal
+                // after rounding): the first to swap the slot's value away is the one
+                winner = vals[slot] == packed && (!kFused || atomicCAS(&vals[slot], packed, kClaimedVal) == packed);
+                in_table = true;
+                break;
+              }
               if (kk == kNoKey) break;
               slot = (slot + 1) & mask;
             }
@@ -718,6 +793,8 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
         // a token on an epsilon-TARGET state registers itself in the channel's direct-mapped
         // epsilon table (so an epsilon arc arriving later meets its cost); a token with epsilon
         // arcs OUT seeds the closure worklist
+        // (fused closures: the epsilon arrivals are candidates like any other; nothing to register or seed)
+        if constexpr (kFused) continue;
         const bool tgt = winner && (flags & kFlagEpsTarget);
         const bool seed = winner && (flags & kFlagOutEps);
         const u64 tm = __ballot(tgt), sm = __ballot(seed);
@@ -831,6 +908,11 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel(DecoderDev D, in
   }
 }
 
+__global__ __launch_bounds__(kInsertThreads, 6) void insert_kernel_plain(DecoderDev D, int group, int par) { insert_body<false, false, false>(D, group, par); }
+__global__ __launch_bounds__(kInsertThreads, 6) void insert_kernel_fused(DecoderDev D, int group, int par) { insert_body<false, false, true>(D, group, par); }
+__global__ __launch_bounds__(kInsertThreads) void insert_kernel_lattice(DecoderDev D, int group, int par) { insert_body<true, false, false>(D, group, par); }
+__global__ __launch_bounds__(kInsertThreads) void insert_kernel_biglm(DecoderDev D, int group, int par) { insert_body<false, true, false>(D, group, par); }
+
 // =========================================================================================
 // closure_kernel and its pieces.  One 1024-thread workgroup per channel.
 // =========================================================================================
@@ -920,24 +1002,14 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
       // reference's first-arrival rule does (emitting arcs are processed before the closure).
       // requeue: the state's own epsilon arcs still have to be followed from this cost
       // (base-inl.h:425); not for a flattened closure, whose deeper entries are those arcs.
-      auto arrive = [&](int ord, int a, float tot, bool out_eps, int next_row, bool requeue, int next_lm) {
-        if constexpr (kBig) {  // find or claim the slot of (row, pair)
-          const u64 key = big_key(next_row, next_lm);
-          const uint32_t emask = (uint32_t)D.ecap - 1u;
-          uint32_t es = hash_big(next_row, next_lm) & emask;
-          ord = -1;
-          for (int q = 0; q < D.ecap; ++q) {
-            u64 kk = ld_agent(&ekeys[es]);
-            if (kk == kEmptyVal) kk = atomicCAS(&ekeys[es], kEmptyVal, key);
-            if (kk == kEmptyVal || kk == key) { ord = (int)es; break; }
-            es = (es + 1) & emask;
-          }
-          if (ord < 0) { atomicOr(&sh.err, kErrTableFull); return; }
-        }
-        const uint32_t otot = f2o(tot);
-        const u64 packed = ((u64)otot << 32) | kEpsWon | (out_eps ? kEpsOutBit : 0u) | (uint32_t)a;
-        const u64 old = atomicMin(&vals[ord], packed);
+      // The arrivals of a thread are priced level by level (level e = the e-th path of a flattened
+      // closure, or the state's e-th epsilon arc) and the atomicMin of a whole level -- one per entry
+      // in flight -- is issued before any of its results is looked at: a RETURNING global atomic is a
+      // round trip of a few microseconds, and one after the other (up to 16 per thread on the heaviest
+      // channel) they were what the slowest workgroup of the launch spent its time on.
+      auto finish = [&](int ord, float tot, bool out_eps, int next_row, bool requeue, int next_lm, u64 packed, u64 old) {
         if (!(packed < old)) return;
+        const uint32_t otot = (uint32_t)(packed >> 32);
         if (old == kEmptyVal) {  // a state no emitting arc reached: new token
           toki[ord] = base + atomicAdd(&sh.nnew, 1);
           const int op = atomicAdd(&sh.occ, 1);
@@ -953,56 +1025,93 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
           else atomicOr(&sh.err, kErrWorklistFull);
         }
       };
+      int nit[kClosureUnroll];             // levels of entry k: paths of its flattened closure, or its epsilon arcs
+      float pc[kClosureUnroll][kFlatMax - 1];  // flattened closure: cost of path q (a later path's parent)
 #pragma unroll
       for (int k = 0; k < kClosureUnroll; ++k) {
-        if (!live[k]) continue;
-        const float cost = __int_as_float(ent[k].z);
-        if (flat[k] & 7u) {
-          // the whole closure of this state in one go: entry cost = parent cost + weight, in path
-          // order; an entry whose parent or own cost is not below the cutoff is dead (base-inl.h:391,415)
-          const int cnt = (int)(flat[k] & 7u);
-          const int4 *fl = D.g.eps_flat + (flat[k] >> 3);
-          float pc[kFlatMax];
+        nit[k] = !live[k] ? 0 : (flat[k] & 7u) ? (int)(flat[k] & 7u) : (int)(si[k].y & kEpsMask);
 #pragma unroll
-          for (int e = 0; e < kFlatMax; ++e) {
-            pc[e] = __builtin_huge_valf();
-            if (e >= cnt) continue;
-            const int4 E = e == 0 ? arc0[k] : fl[e];
-            const int parent = (E.z & 7) - 1;
+        for (int q = 0; q < kFlatMax - 1; ++q) pc[k][q] = __builtin_huge_valf();
+      }
+      for (int e = 0;; ++e) {
+        bool more = false;
+#pragma unroll
+        for (int k = 0; k < kClosureUnroll; ++k) more |= e < nit[k];
+        if (!__ballot(more)) break;
+        int4 E[kClosureUnroll];
+#pragma unroll
+        for (int k = 0; k < kClosureUnroll; ++k)
+          E[k] = e >= nit[k] ? make_int4(0, 0, 0, 0)
+                 : e == 0 ? arc0[k]
+                 : (flat[k] & 7u) ? D.g.eps_flat[(flat[k] >> 3) + e] : D.g.arcs[si[k].x + e];
+        int c_ord[kClosureUnroll], c_row[kClosureUnroll], c_lm[kClosureUnroll];
+        float c_tot[kClosureUnroll];
+        u64 c_packed[kClosureUnroll], c_old[kClosureUnroll];
+        uint32_t c_flags[kClosureUnroll];  // 1 live, 2 out_eps, 4 requeue
+#pragma unroll
+        for (int k = 0; k < kClosureUnroll; ++k) {
+          c_flags[k] = 0; c_ord[k] = 0; c_row[k] = 0; c_lm[k] = 0; c_tot[k] = 0.0f; c_packed[k] = 0;
+          if (e >= nit[k]) continue;
+          const float cost = __int_as_float(ent[k].z);
+          int a;
+          if (flat[k] & 7u) {
+            // path e of the state's whole closure: cost = parent path's cost + weight, in path order; a
+            // path whose parent or own cost is not below the cutoff is dead (base-inl.h:391,415)
+            const int parent = (E[k].z & 7) - 1;
             float cp = cost;
 #pragma unroll
-            for (int q = 0; q < kFlatMax - 1; ++q) cp = (parent == q) ? pc[q] : cp;
+            for (int q = 0; q < kFlatMax - 1; ++q) cp = (parent == q) ? pc[k][q] : cp;
             if (!(cp < cutoff)) continue;
             nZ++;
-            const float tot = cp + __int_as_float(E.w);  // base-inl.h:414
-            if (!(tot < cutoff)) continue;               // base-inl.h:415
-            pc[e] = tot;
-            arrive(E.x, E.y, tot, (E.z & 8) != 0, 0, false, 0);
-          }
-          continue;
-        }
-        const int neps = (int)(si[k].y & kEpsMask);
-        for (int e = 0; e < neps; ++e) {
-          const int a = (int)si[k].x + e;
-          const int4 arc = e == 0 ? arc0[k] : D.g.arcs[a];
-          nZ++;
-          float graph_cost = __int_as_float(arc.z);
-          int next_lm = 0;
-          if constexpr (kBig) {  // biglm.h:448-451
-            const int ol = D.g.arc_olabel[a];
-            float lm_score = 0.0f;
-            next_lm = ent[k].x;
-            if (ol != 0) {
-              int n1, n2;
-              lm_score = lm_step(D, c, ent[k].x, ol, &n1, &n2);
-              next_lm = pair_intern(D, c, ctl, n1, n2);
+            const float tot = cp + __int_as_float(E[k].w);  // base-inl.h:414
+            if (!(tot < cutoff)) continue;                   // base-inl.h:415
+#pragma unroll
+            for (int q = 0; q < kFlatMax - 1; ++q) pc[k][q] = (e == q) ? tot : pc[k][q];
+            c_ord[k] = E[k].x; a = E[k].y; c_tot[k] = tot;
+            c_flags[k] = 1u | ((E[k].z & 8) ? 2u : 0u);
+          } else {
+            a = (int)si[k].x + e;
+            nZ++;
+            float graph_cost = __int_as_float(E[k].z);
+            if constexpr (kBig) {  // biglm.h:448-451
+              const int ol = D.g.arc_olabel[a];
+              float lm_score = 0.0f;
+              c_lm[k] = ent[k].x;
+              if (ol != 0) {
+                int n1, n2;
+                lm_score = lm_step(D, c, ent[k].x, ol, &n1, &n2);
+                c_lm[k] = pair_intern(D, c, ctl, n1, n2);
+              }
+              graph_cost = __int_as_float(E[k].z) + lm_score;
             }
-            graph_cost = __int_as_float(arc.z) + lm_score;
+            const float tot = cost + graph_cost;              // base-inl.h:414
+            if (!(tot < cutoff)) continue;                    // base-inl.h:415
+            c_ord[k] = (int)((uint32_t)E[k].y & 0x7FFFFFFFu) - 1;
+            c_row[k] = E[k].w; c_tot[k] = tot;
+            c_flags[k] = 1u | (((uint32_t)E[k].y & kFlagOutEps) ? 2u : 0u) | 4u;
+            if constexpr (kBig) {  // find or claim the slot of (row, pair)
+              const u64 key = big_key(c_row[k], c_lm[k]);
+              const uint32_t emask = (uint32_t)D.ecap - 1u;
+              uint32_t es = hash_big(c_row[k], c_lm[k]) & emask;
+              c_ord[k] = -1;
+              for (int q = 0; q < D.ecap; ++q) {
+                u64 kk = ld_agent(&ekeys[es]);
+                if (kk == kEmptyVal) kk = atomicCAS(&ekeys[es], kEmptyVal, key);
+                if (kk == kEmptyVal || kk == key) { c_ord[k] = (int)es; break; }
+                es = (es + 1) & emask;
+              }
+              if (c_ord[k] < 0) { atomicOr(&sh.err, kErrTableFull); c_flags[k] = 0; continue; }
+            }
           }
-          const float tot = cost + graph_cost;              // base-inl.h:414
-          if (!(tot < cutoff)) continue;                    // base-inl.h:415
-          arrive((int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1, a, tot, ((uint32_t)arc.y & kFlagOutEps) != 0, arc.w, true, next_lm);
+          c_packed[k] = ((u64)f2o(c_tot[k]) << 32) | kEpsWon | ((c_flags[k] & 2u) ? kEpsOutBit : 0u) | (uint32_t)a;
         }
+#pragma unroll
+        for (int k = 0; k < kClosureUnroll; ++k)
+          c_old[k] = (c_flags[k] & 1u) ? atomicMin(&vals[c_ord[k]], c_packed[k]) : 0ull;
+#pragma unroll
+        for (int k = 0; k < kClosureUnroll; ++k)
+          if (c_flags[k] & 1u)
+            finish(c_ord[k], c_tot[k], (c_flags[k] & 2u) != 0, c_row[k], (c_flags[k] & 4u) != 0, c_lm[k], c_packed[k], c_old[k]);
       }
     }
     __syncthreads();
@@ -1121,9 +1230,19 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
     }
     __syncthreads();
   }
-  for (int i = tid; i < nocc; i += kBT) {
-    vals[occ[i]] = kEmptyVal;
-    if constexpr (kBig) ekeys[occ[i]] = kEmptyVal;
+  for (int i0 = 0; i0 < nocc; i0 += kBT * kClosureUnroll) {  // the list loads of a thread issued together
+    int od[kClosureUnroll];
+#pragma unroll
+    for (int k = 0; k < kClosureUnroll; ++k) {
+      const int i = i0 + k * kBT + tid;
+      od[k] = i < nocc ? occ[i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < kClosureUnroll; ++k) {
+      if (od[k] < 0) continue;
+      vals[od[k]] = kEmptyVal;
+      if constexpr (kBig) ekeys[od[k]] = kEmptyVal;
+    }
   }
   if (tid == 0) {
     u64 b = sh.red64[0];
@@ -1158,7 +1277,12 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
   __syncthreads();
   if (tid == 0) dbg_phase(D, 0, tq);
   u64 nZ = 0;
-  epsilon_closure<kLat, kBig>(D, c, sh, base, cutoff, &nZ);
+  if (!kLat && !kBig && D.fused) {
+    if (tid == 0) sh.best = ~0ull;  // the frame is complete: its epsilon arrivals went through the insert launch
+    __syncthreads();
+  } else {
+    epsilon_closure<kLat, kBig>(D, c, sh, base, cutoff, &nZ);
+  }
   tq = wall_clock64();
   nZ = wave_sum_u64(nZ);
   if (lane == 0) sh.red64[tid >> 6] = nZ;
@@ -1808,14 +1932,16 @@ void launch_init(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s
 // chan_off / chan_cnt: the channel group a launch covers (groups run on their own streams so that
 // one group's latency-bound closure overlaps another group's expand / insert)
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s) {
-  if (D.big) hipLaunchKernelGGL(expand_kernel<true>, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
-  else hipLaunchKernelGGL(expand_kernel<false>, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+  if (D.big) hipLaunchKernelGGL(expand_kernel_biglm, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+  else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+  else hipLaunchKernelGGL(expand_kernel_plain, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
 }
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups, hipStream_t s) {
   const size_t lds = (size_t)D.lds_slots * (D.big ? 16 : D.lattice ? 16 : 12);
-  if (D.big) hipLaunchKernelGGL((insert_kernel<false, true>), dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
-  else if (D.lattice) hipLaunchKernelGGL((insert_kernel<true, false>), dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
-  else hipLaunchKernelGGL((insert_kernel<false, false>), dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  if (D.big) hipLaunchKernelGGL(insert_kernel_biglm, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  else if (D.lattice) hipLaunchKernelGGL(insert_kernel_lattice, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  else if (D.fused) hipLaunchKernelGGL(insert_kernel_fused, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  else hipLaunchKernelGGL(insert_kernel_plain, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
 }
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int do_prep, int group, int par,
                     hipStream_t s) {
@@ -1853,10 +1979,12 @@ void launch_lattice_prune(const DecoderDev &D, const int32_t *chans, int n, hipS
   hipLaunchKernelGGL(lattice_prune_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
 }
 int insert_kernel_set_lds(int bytes) {
-  int e = (int)hipFuncSetAttribute((const void *)insert_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  int e = (int)hipFuncSetAttribute((const void *)insert_kernel_lattice, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e) return e;
-  e = (int)hipFuncSetAttribute((const void *)insert_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  e = (int)hipFuncSetAttribute((const void *)insert_kernel_biglm, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e) return e;
-  return (int)hipFuncSetAttribute((const void *)insert_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  e = (int)hipFuncSetAttribute((const void *)insert_kernel_fused, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e) return e;
+  return (int)hipFuncSetAttribute((const void *)insert_kernel_plain, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 }  // namespace wfst

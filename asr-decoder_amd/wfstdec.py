@@ -75,7 +75,7 @@ class Options(C.Structure):
 
 
 class GraphOptions(C.Structure):
-    _fields_ = [("row_align_slots", C.c_int32), ("flatten_closures", C.c_int32)]
+    _fields_ = [("row_align_slots", C.c_int32), ("flatten_closures", C.c_int32), ("fuse_closures", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -71,6 +71,10 @@ def parse():
                     "(capacity per utterance), prune by lattice_beam at finalize; the step then also takes the n-best")
     ap.add_argument("--lattice-beam", type=float, default=7.0)
     ap.add_argument("--nbest", type=int, default=5, help="n of the n-best taken per utterance in lattice mode")
+    ap.add_argument("--debug", type=int, default=0, help="wfst_options.debug (kernel phase timers 32 closure / 64 insert / 128 expand: "
+                    "timing experiments only, printed on stderr when the decoder is freed)")
+    ap.add_argument("--no-fuse", action="store_true", help="graph without fused epsilon closures (wfst_graph_options.fuse_closures = 0): "
+                    "the separate closure pass runs every frame")
     ap.add_argument("--no-hip-graph", action="store_true", help="enqueue the frame loop kernel by kernel (rocprofv3 --pmc passes)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances checked bit for bit against the CPU decoder (0 = skip "
                     "the CPU legs: parity sample, cpu_baseline, service_point divergence)")
@@ -347,7 +351,8 @@ def main():
     ll_dev = torch.from_numpy(mats).to(dev)  # [B][T][P] resident in HBM
     log("[rank %d] log-likelihoods: %d x [%d x %d] (%.1fs)" % (rank, B, T, P, time.time() - t0))
 
-    graph = wfstdec.Graph.from_arrays(g.start, g.final_state, g.state_info, g.arcs, device=local_rank)
+    graph = wfstdec.Graph.from_arrays(g.start, g.final_state, g.state_info, g.arcs, device=local_rank,
+                                      options=wfstdec.GraphOptions(fuse_closures=0 if a.no_fuse else 1))
     graph.set_tid2pdf(m)
     big, lm_dev, lm_info = None, [None, None], None
     if a.biglm:
@@ -368,7 +373,7 @@ def main():
         log("[rank %d] LMs: old %d states / %d arcs, new %d states / %d arcs (%.1fs)" % (
             rank, lm_info[0]["n_states"], lm_info[0]["n_arcs"], lm_info[1]["n_states"], lm_info[1]["n_arcs"], time.time() - t0))
     stream = torch.cuda.current_stream(dev).cuda_stream
-    opt = wfstdec.Options(use_hip_graph=0 if a.no_hip_graph else 1, **({"channel_groups": a.groups} if a.groups > 0 else {}))
+    opt = wfstdec.Options(use_hip_graph=0 if a.no_hip_graph else 1, debug=a.debug, **({"channel_groups": a.groups} if a.groups > 0 else {}))
 
     def new_decoder(cfg_dict):
         return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=131072,
@@ -547,7 +552,16 @@ def main():
         # + 8 B hash min-update), 24 B per expanded token (8 B {state,cost} + 8 B arc range + 8 B
         # backpointer/arena write), 24 B per traversed epsilon arc.  Per kernel (DESIGN.md "Roofline
         # accounting"): expand = 20 E + 16 N, insert = 8 E + 8 N, closure = 24 Z.
-        kb = {"expand": scale * (20.0 * E + 16.0 * N), "insert": scale * (8.0 * E + 8.0 * N), "closure": 24.0 * Z}
+        fused = not a.no_fuse and not a.biglm and a.lattice_links == 0
+        if fused and do_cpu:
+            # fused epsilon closures: the closure's arcs are priced by the expansion (16 B pseudo arc) and merged by the
+            # insert launch (8 B hash min-update); Z = the CPU restatement's count (the GPU's own counts one closure
+            # path per CANDIDATE at a state, the reference one per TOKEN), scaled from the sample like N and E
+            Zo = oc["Z"] * (E / float(max(oc["E"], 1)))
+            kb = {"expand": scale * (20.0 * E + 16.0 * N) + 16.0 * Zo, "insert": scale * (8.0 * E + 8.0 * N) + 8.0 * Zo, "closure": 0.0}
+        else:
+            kb = {"expand": scale * (20.0 * E + 16.0 * N), "insert": scale * (8.0 * E + 8.0 * N), "closure": 24.0 * Z}
+        out["config"]["fused_epsilon_closures"] = bool(fused)
         if a.biglm and do_cpu and oc["E"] > 0:
             # biglm: + 96 B per word-labelled arc traversed (8 B pair key; per LM 16 B state record, 4 B x ~4 probes of
             # the word-sorted arcs, 8 B arc {weight, next}; 8 B pair-table slot), + 4 B LM pair id per token and record

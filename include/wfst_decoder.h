@@ -91,6 +91,10 @@ typedef struct wfst_graph_options {
   int32_t row_align_slots;     /* rows are placed so that they touch as few lines of this many 16-byte
                                   slots as possible; 1 = packed                                 (4)    */
   int32_t flatten_closures;    /* precompute each state's whole epsilon closure (<= 4 paths)     (1)    */
+  int32_t fuse_closures;       /* fold the epsilon closures into the expansion (pseudo arcs behind
+                                  each state's emitting arcs) where the graph allows: no epsilon
+                                  cycle, closures of <= 48 paths and <= 8 hops, no negative epsilon
+                                  weight; best-path decoders then run no separate closure pass     (1)    */
 } wfst_graph_options;
 
 /* Original on-disk / in-memory graph records of the reference format. */

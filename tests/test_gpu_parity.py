@@ -323,9 +323,12 @@ def test_channel_groups_decode_identically(synth, oracle, tmp_path):
     with pytest.raises(G.wfstdec.WfstError):
         G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 2, options=G.wfstdec.Options(channel_groups=9), **lim)
     # unflattened closures / packed rows: graph upload choices, same bits
-    g2 = G.wfstdec.Graph.load(path, options=G.wfstdec.GraphOptions(flatten_closures=0, row_align_slots=1))
-    g2.set_tid2pdf(m)
-    for r, o in zip(G.decode_batch(g2, cd, mats), want):
-        G.assert_same_as_oracle(r, o, "graph options")
-    g2.free()
+    # unflattened closures / packed rows / no fused closures (the separate closure pass): graph upload choices, same bits
+    for go in (dict(flatten_closures=0, row_align_slots=1), dict(fuse_closures=0), dict(fuse_closures=0, flatten_closures=0)):
+        g2 = G.wfstdec.Graph.load(path, options=G.wfstdec.GraphOptions(**go))
+        g2.set_tid2pdf(m)
+        for chunk in (0, 7):
+            for r, o in zip(G.decode_batch(g2, cd, mats, chunk=chunk), want):
+                G.assert_same_as_oracle(r, o, "graph options %s chunk %d" % (go, chunk))
+        g2.free()
     graph.free()
