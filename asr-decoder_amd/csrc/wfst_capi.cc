@@ -137,6 +137,7 @@ struct wfst_decoder {
   DevBuf<int32_t> tok_lm, bucket_lm;
   DevBuf<int32_t> link_off, link_mid;
   DevBuf<uint2> extra;
+  DevBuf<int32_t> remap;
   DevBuf<LatArc> lat_arcs;
   DevBuf<FrameCtl> fctl;
   DevBuf<unsigned long long> dbg_t;
@@ -214,7 +215,7 @@ struct wfst_decoder {
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
-    pair_keys.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release();
+    pair_keys.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
     bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
@@ -858,10 +859,11 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     A(d->link_off.alloc(B * ((size_t)L.max_frames + 3)));
     A(d->link_mid.alloc(B * ((size_t)L.max_frames + 3)));
     A(d->extra.alloc(B * (size_t)L.arena_tokens));
-    // the pruned lattice is a small fraction of what was recorded (a few thousand arcs per utterance
-    // out of millions of links at lattice_beam 7)
-    lat_arc_cap = std::min<int64_t>(L.lattice_links, std::max<int64_t>(65536, L.lattice_links / 8));
-    lat_tok_cap = std::min<int64_t>(L.arena_tokens, std::max<int64_t>(65536, L.lattice_links / 8));
+    A(d->remap.alloc(B * (size_t)L.arena_tokens));
+    // GetRawLattice may be asked for at any time (base-inl.h:869-975): everything alive -- the pruned
+    // history and the raw frames since the last PruneActiveTokens pass -- must fit the resolved lists
+    lat_arc_cap = L.lattice_links;
+    lat_tok_cap = L.arena_tokens;
     A(d->lat_arcs.alloc(B * (size_t)lat_arc_cap));
     A(d->lat_toks.alloc(B * (size_t)lat_tok_cap));
   }
@@ -912,6 +914,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.link_off = d->link_off.p;
   D.link_mid = d->link_mid.p;
   D.extra = d->extra.p;
+  D.remap = d->remap.p;
   D.lat_arcs = d->lat_arcs.p;
   D.lat_toks = d->lat_toks.p;
   D.lat_arc_cap = (int32_t)lat_arc_cap;
@@ -1362,8 +1365,14 @@ int wfst_decoder_get_nbest(wfst_decoder *d, const int32_t *channels, int32_t n_c
   int32_t cnt;
   int rc = stage_channels(d, channels, n_channels, &dev, &cnt);
   if (rc != WFST_OK) return rc;
-  for (int i = 0; i < cnt; ++i)
-    if (d->h_state[channels ? channels[i] : i] != 2) return fail(WFST_E_STATE, "GetNbest is served after FinalizeDecoding");
+  bool any_live = false;
+  for (int i = 0; i < cnt; ++i) {
+    const int st = d->h_state[channels ? channels[i] : i];
+    if (st == 0) return fail(WFST_E_STATE, "GetNbest before InitDecoding");
+    any_live |= st == 1;
+  }
+  // mid-utterance (the service's partial n-best, v2-asr/v2-asr-task.h:319): resolve what is alive now
+  if (any_live) launch_lattice_emit(d->D, dev, cnt, 1, d->stream);
   NbestDev &N = d->nb;
   if (!d->nb_list.p) {  // first use: per-channel k-best lists and index scratch
     // k-best lists: 16 entries x 24 bytes per lattice state; up to 262144 states per lattice, less
@@ -1463,19 +1472,45 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
                                  float *a_acoustic) {
   if (!d || channel < 0 || channel >= d->n_channels || !n_states || !n_arcs) return fail(WFST_E_ARG, "bad argument");
   if (!d->D.lattice) return fail(WFST_E_STATE, "GetRawLattice needs a decoder created with wfst_limits.lattice_links > 0");
-  if (d->h_state[channel] != 2) return fail(WFST_E_STATE, "GetRawLattice is served after FinalizeDecoding");
+  if (d->h_state[channel] == 0) return fail(WFST_E_STATE, "GetRawLattice before InitDecoding");
+  const bool live = d->h_state[channel] == 1;  // mid-utterance: everything alive now (base-inl.h:869-975)
   HIP_TRY(hipSetDevice(d->device));
   *n_states = 0;
   *n_arcs = 0;
-  if (!use_final_probs) return WFST_OK;  // base-inl.h:879-884: finalized && !use_final_probs -> false
+  if (!live && !use_final_probs) return WFST_OK;  // base-inl.h:879-884: finalized && !use_final_probs -> false
   if (d->lat_cached.empty()) {
     d->lat_cached.assign((size_t)d->n_channels, 0);
     d->lat_cache_nd.assign((size_t)d->n_channels, 0);
     d->lat_cache_tok.resize((size_t)d->n_channels);
     d->lat_cache_arc.resize((size_t)d->n_channels);
   }
-  if (!d->lat_cached[channel]) {
-    // The pruned lattices were left compacted by lattice_prune_kernel.  One control-block read, then
+  if (live) {
+    // resolve what is alive right now (the pruned history + the raw frames since the last PruneActiveTokens
+    // pass) and fetch this channel's two lists; never cached: the next frame changes them
+    const int32_t *dev;
+    int32_t cnt;
+    int rc = stage_channels(d, &channel, 1, &dev, &cnt);
+    if (rc != WFST_OK) return rc;
+    launch_lattice_emit(d->D, dev, 1, use_final_probs ? 1 : 0, d->stream);
+    HIP_TRY(hipGetLastError());
+    rc = read_ctl(d);
+    if (rc != WFST_OK) return rc;
+    rc = check_ctl_errors(d);
+    if (rc != WFST_OK) return rc;
+    const ChanCtl &cc = d->p_ctl[channel];
+    d->lat_cache_nd[channel] = cc.n_decoded;
+    d->lat_cache_tok[channel].resize((size_t)cc.lat_toks);
+    d->lat_cache_arc[channel].resize((size_t)cc.lat_arcs);
+    if (cc.lat_toks)
+      HIP_TRY(hipMemcpyAsync(d->lat_cache_tok[channel].data(), d->lat_toks.p + (size_t)channel * (size_t)d->D.lat_tok_cap,
+                             (size_t)cc.lat_toks * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
+    if (cc.lat_arcs)
+      HIP_TRY(hipMemcpyAsync(d->lat_cache_arc[channel].data(), d->lat_arcs.p + (size_t)channel * (size_t)d->D.lat_arc_cap,
+                             (size_t)cc.lat_arcs * sizeof(LatArc), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->lat_cached[channel] = 0;
+  } else if (!d->lat_cached[channel]) {
+    // The pruned lattices were left resolved by FinalizeDecoding.  One control-block read, then
     // the two small lists of EVERY finalized channel in one sweep of copies and one synchronisation:
     // a caller that walks all channels of a batch pays the device round trips once.
     int rc = read_ctl(d);

@@ -124,7 +124,7 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t lat_toks;      //   "   surviving tokens in lat_toks[]
   int32_t tiles_left;    // expansion tiles of the frame not finished yet (the last one plans the insert items)
   int32_t pair_count;    // biglm: LM pair states interned since InitDecoding (atomicAdd)
-  int32_t pad1;
+  int32_t pruned_upto;   // lattice mode: NumFramesDecoded() at the last back-pruning pass (frames below hold extras)
 };
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
 
@@ -193,12 +193,15 @@ struct DecoderDev {
   // cost bits of (source cost + acoustic) + graph}; segment k = links whose destination is on
   // frame k = [link_off[k], link_off[k+1]): the emitting links from frame k-1 first
   // [link_off[k], link_mid[k]), then the epsilon links inside frame k [link_mid[k], link_off[k+1]).
-  // extra[c][token] = {orderable extra_cost (base-inl.h:482-572), cost bits of the token}, filled by
-  // lattice_fill_kernel / lattice_prune_kernel, which also leaves the pruned lattice compacted in
-  // lat_arcs[c][0..ctl.lat_arcs) and lat_toks[c][0..ctl.lat_toks).
+  // extra[c][token] = {orderable extra_cost (base-inl.h:482-572), cost bits of the token}, kept up to
+  // date by the back-pruning passes (prune_pass: every prune_interval frames and at FinalizeDecoding),
+  // which also REMOVE the dead tokens and links and move the survivors down, so that tok[] / links[]
+  // hold the surviving history plus the raw frames since the last pass.  lattice_emit_kernel resolves
+  // what is alive into lat_arcs[c][0..ctl.lat_arcs) and lat_toks[c][0..ctl.lat_toks) for GetRawLattice.
   int4 *links;
   int32_t *link_off, *link_mid;  // [c][max_frames+3]
   uint2 *extra;
+  int32_t *remap;               // [c][arena_cap] scratch of the back-pruning passes (previous extras, then new indices)
   LatArc *lat_arcs;
   int4 *lat_toks;               // {arena index, graph state id, cost bits, frame | final << 30}
   int64_t link_cap;
@@ -276,6 +279,7 @@ void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32
                     int group, int par, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_lattice_prune(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
+void launch_lattice_emit(const DecoderDev &D, const int32_t *chan_list_dev, int n, int use_final, hipStream_t s);
 void launch_best_path(const DecoderDev &D, const int32_t *chan_list_dev, int n, int use_final,
                       int cap, int32_t *ilabel, int32_t *olabel, float *graph, float *ac,
                       int32_t *n_hops, int32_t *chain_scratch, hipStream_t s);

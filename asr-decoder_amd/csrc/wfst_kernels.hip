@@ -1482,6 +1482,274 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
   if (tid == 0) dbg_phase(D, 5, tq);
 }
 
+// =========================================================================================
+// Lattice-beam back-pruning (lattice mode): PruneActiveTokens every prune_interval frames
+// (base-inl.h:438-480, called at :660-661), FinalizeDecoding (PruneForwardLinksFinal + PruneForwardLinks
+// + PruneTokensForFrame, :482-607, 725-847), and the COMPACTION that keeps the token arena and the link
+// store bounded; one 1024-thread workgroup per channel.
+//
+//   extra[t]  = min over t's links of (extra[next] + (link cost - cost_next)), links with more than
+//               lattice_beam dropped.  The newest frame is the seed: extra 0 for every token
+//               (PruneActiveTokens), or cost + final_cost - best (FinalizeDecoding).  link cost = (cost_t + ac)
+//               + graph is the candidate cost the expansion computed, kept in the link record, so one 8-byte
+//               gather {extra, cost} of the destination prices a link.
+//   Frames are walked newest to oldest and the walk STOPS at the first frame whose extras come out
+//   bit-equal to the previous pass's: nothing older can change.  This is the reference's own stopping rule
+//   (extra_costs_changed, :458-461) with its tolerance delta = lattice_beam * prune_scale at zero: the
+//   reference leaves extras that moved by less than delta stale (too small), so it keeps a superset of the
+//   links kept here; FinalizeDecoding (delta 0 in the reference too) ends at the same lattice either way.
+//   The reference reaches the fixpoint inside a frame by sweeping token lists "while changed"; min is
+//   order-independent, so atomicMin relaxation gives the same values.
+//   Survivors are then moved down over the dead (tokens frame by frame, links segment by segment, indices
+//   remapped, backpointers and the frontier included): the arena holds the surviving history plus the
+//   raw frames since the last pass -- bounded, whatever the utterance length.
+// =========================================================================================
+struct PruneShared {
+  u64 red[2][kBT / 64];
+  int changed, any_changed, cnt, err;
+  int wsum[kBT / 64];
+};
+
+// exclusive prefix sum of `v` over the workgroup's kBT threads; *total = sum
+__device__ __forceinline__ int block_exscan(int v, PruneShared &ps, int *total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int x = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += x;
+  }
+  __syncthreads();  // ps.wsum free again
+  if (lane == 63) ps.wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBT / 64; ++w) {
+    const int x = ps.wsum[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+// kFinal: FinalizeDecoding.  Returns with extras valid for every frame, dead tokens and links gone, and
+// ctl->pruned_upto = n_decoded.
+template <bool kFinal>
+__device__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ChanCtl *ctl = D.ctl + c;
+  const int nd = ctl->n_decoded;
+  int4 *tok = D.tok + (size_t)c * D.arena_cap;
+  int4 *links = D.links + (size_t)c * D.link_cap;
+  uint2 *extra = D.extra + (size_t)c * D.arena_cap;
+  int32_t *remap = D.remap + (size_t)c * D.arena_cap;   // previous extras while walking, new indices while compacting
+  int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
+  int32_t *loff = D.link_off + (size_t)c * (D.max_frames + 3);
+  int32_t *lmid = D.link_mid + (size_t)c * (D.max_frames + 3);
+  const float kInf = __builtin_huge_valf();
+  const uint32_t kInfO = f2o(kInf);
+  const float lb = D.lattice_beam;
+  if (ctl->error) return;
+  const int n_prev = ctl->pruned_upto;   // frames below hold the extras of an earlier pass
+  const int fn = foff[nd], fn1 = foff[nd + 1];
+  bool any_final = false;
+
+  // link_extra given the CURRENT extra of the destination (base-inl.h:524-526, 782-784); +inf for a dead one
+  auto link_extra = [&](const int4 L) -> float {
+    const u64 e = ld_agent(reinterpret_cast<const u64 *>(&extra[L.y]));  // {extra (low), cost (high)}
+    const uint32_t eo = (uint32_t)e;
+    if (eo >= kInfO) return kInf;
+    return o2f(eo) + (__int_as_float(L.w) - __int_as_float((int)(e >> 32)));
+  };
+  // the epsilon links of a frame, [e0, e1), to their fixpoint; then the dead ones are marked
+  auto relax_eps = [&](int e0, int e1) {
+    for (int round = 0; e0 < e1 && round < 4096; ++round) {
+      if (tid == 0) ps.changed = 0;
+      __syncthreads();
+      for (int i = e0 + tid; i < e1; i += kBT) {
+        const int4 L = links[i];
+        if (L.x < 0) continue;
+        float le = link_extra(L);
+        if (!(le <= lb)) continue;
+        if (le < 0.0f) le = 0.0f;
+        const uint32_t o = f2o(le);
+        if (o < atomicMin(&extra[L.x].x, o)) ps.changed = 1;
+      }
+      __syncthreads();
+      const int ch = ps.changed;
+      __syncthreads();
+      if (!ch) break;
+    }
+    for (int i = e0 + tid; i < e1; i += kBT) {
+      const int4 L = links[i];
+      if (L.x >= 0 && !(link_extra(L) <= lb)) links[i].x = -1;
+    }
+    __syncthreads();
+  };
+
+  // ---- (1) the newest frame ---------------------------------------------------------------------
+  if (kFinal) {
+    // ComputeFinalCosts (base-inl.h:670-720) + PruneForwardLinksFinal (:725-824)
+    u64 b_all = ~0ull, b_fin = ~0ull;
+    for (int i = fn + tid; i < fn1; i += kBT) {
+      const int4 t = tok[i];
+      const u64 v = (u64)f2o(__int_as_float(t.y));
+      b_all = v < b_all ? v : b_all;
+      if (t.x == D.g.final_state) b_fin = v < b_fin ? v : b_fin;
+    }
+    b_all = wave_min_u64(b_all);
+    b_fin = wave_min_u64(b_fin);
+    if (lane == 0) { ps.red[0][wave] = b_all; ps.red[1][wave] = b_fin; }
+    __syncthreads();
+    for (int w = 0; w < kBT / 64; ++w) { b_all = ps.red[0][w] < b_all ? ps.red[0][w] : b_all; b_fin = ps.red[1][w] < b_fin ? ps.red[1][w] : b_fin; }
+    any_final = b_fin != ~0ull;
+    const float final_best = o2f((uint32_t)(any_final ? b_fin : b_all));
+    for (int i = fn + tid; i < fn1; i += kBT) {
+      const int4 t = tok[i];
+      const float final_cost = (!any_final || t.x == D.g.final_state) ? 0.0f : kInf;
+      float e = __int_as_float(t.y) + final_cost - final_best;  // base-inl.h:775
+      if (e > lb) e = kInf;                                      // base-inl.h:815-816 (tokens without links)
+      extra[i] = make_uint2(f2o(e), (uint32_t)t.y);
+    }
+    __syncthreads();
+    relax_eps(lmid[nd], loff[nd + 1]);
+  } else {
+    for (int i = fn + tid; i < fn1; i += kBT) extra[i] = make_uint2(f2o(0.0f), (uint32_t)tok[i].y);
+    __syncthreads();
+  }
+
+  // ---- (2) older frames, newest first, until nothing changes any more --------------------------------
+  int k_lo = nd;   // oldest frame re-priced by this pass
+  for (int k = nd - 1; k >= 0; --k) {
+    const int fk = foff[k], fk1 = foff[k + 1];
+    const bool had_old = k < n_prev;
+    for (int i = fk + tid; i < fk1; i += kBT) {
+      if (had_old) remap[i] = (int32_t)extra[i].x;
+      extra[i] = make_uint2(kInfO, (uint32_t)tok[i].y);
+    }
+    __syncthreads();
+    // emitting links frame k -> k+1
+    for (int i = loff[k + 1] + tid; i < lmid[k + 1]; i += kBT) {
+      const int4 L = links[i];
+      if (L.x < 0) continue;
+      float le = link_extra(L);
+      if (!(le <= lb)) { links[i].x = -1; continue; }
+      if (le < 0.0f) le = 0.0f;
+      atomicMin(&extra[L.x].x, f2o(le));
+    }
+    __syncthreads();
+    relax_eps(lmid[k], loff[k + 1]);
+    k_lo = k;
+    if (had_old) {
+      if (tid == 0) ps.any_changed = 0;
+      __syncthreads();
+      int ch = 0;
+      for (int i = fk + tid; i < fk1; i += kBT) ch |= (int32_t)ld_agent(&extra[i].x) != remap[i];
+      if (ch) ps.any_changed = 1;
+      __syncthreads();
+      const int any = ps.any_changed;
+      __syncthreads();
+      if (!any) break;   // extra_costs_changed == false: older frames keep their extras and links (base-inl.h:458-461)
+    }
+  }
+
+  // ---- (3) compaction: tokens of frames [k_lo, nd], links from the epsilon links of frame k_lo on -------
+  // (nothing older lost anything).  A token is dead iff its extra is +inf; a link iff it was marked.
+  {
+    const int range_lo = foff[k_lo];
+    int new_end = range_lo;
+    int old_lo = range_lo;
+    if (tid == 0) ps.err = 0;
+    __syncthreads();
+    for (int f = k_lo; f <= nd; ++f) {
+      const int old_hi = foff[f + 1];
+      // (a) new index of every survivor of the frame
+      int base = new_end;
+      for (int i0 = old_lo; i0 < old_hi; i0 += kBT) {
+        const int i = i0 + tid;
+        // (PruneActiveTokens never calls PruneTokensForFrame(0), base-inl.h:471-476: frame 0 keeps its dead
+        // tokens, link-less, until FinalizeDecoding)
+        const bool alive = i < old_hi && ((!kFinal && f == 0) || (uint32_t)ld_agent(&extra[i].x) < kInfO);
+        int tot;
+        const int r = block_exscan(alive ? 1 : 0, ps, &tot);
+        if (i < old_hi) remap[i] = alive ? base + r : -1;
+        base += tot;
+      }
+      __syncthreads();
+      // (b) move them (downwards only: a chunk is read whole before it is written)
+      for (int i0 = old_lo; i0 < old_hi; i0 += kBT) {
+        const int i = i0 + tid;
+        const int ni = i < old_hi ? remap[i] : -1;
+        int4 rec = make_int4(0, 0, 0, 0);
+        uint2 ex = make_uint2(0, 0);
+        if (ni >= 0) {
+          rec = tok[i];
+          ex = extra[i];
+          // backpointer: a survivor's predecessor survives (the link between them is the token's own best one);
+          // predecessors below the compacted range have not moved
+          if (rec.z >= range_lo) {
+            rec.z = remap[rec.z];
+            if (rec.z < 0) ps.err = 1;
+          }
+        }
+        __syncthreads();
+        if (ni >= 0) { tok[ni] = rec; extra[ni] = ex; }
+        __syncthreads();
+      }
+      new_end = base;
+      old_lo = old_hi;
+      if (tid == 0) foff[f + 1] = new_end;
+      __syncthreads();
+    }
+    // links: eps(k_lo), then for f = k_lo+1 .. nd: emitting(f), eps(f)
+    int lnew = lmid[k_lo];
+    int seg_lo = lmid[k_lo];
+    const int n_seg = 2 * (nd - k_lo) + 1;
+    for (int sidx = 0; sidx < n_seg; ++sidx) {
+      const int f = k_lo + (sidx + 1) / 2;
+      const bool eps_seg = (sidx & 1) == 0;
+      const int seg_hi = eps_seg ? loff[f + 1] : lmid[f];
+      const int seg_new_lo = lnew;
+      for (int i0 = seg_lo; i0 < seg_hi; i0 += kBT) {
+        const int i = i0 + tid;
+        int4 L = make_int4(-1, 0, 0, 0);
+        if (i < seg_hi) L = links[i];
+        const bool alive = L.x >= 0;
+        int tot;
+        const int r = block_exscan(alive ? 1 : 0, ps, &tot);   // (its barriers separate the reads above from the writes below)
+        if (alive) {
+          L.x = remap[L.x];
+          L.y = remap[L.y];
+          links[lnew + r] = L;
+        }
+        lnew += tot;
+      }
+      __syncthreads();
+      seg_lo = seg_hi;
+      if (tid == 0) {   // a frame's segment = [link_off[f], link_mid[f]) emitting into it, [link_mid[f], link_off[f+1]) epsilon inside it
+        if (eps_seg) { lmid[f] = seg_new_lo; loff[f + 1] = lnew; }
+        else loff[f] = seg_new_lo;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      ctl->link_count = lnew;
+      ctl->front_begin = foff[nd];
+      ctl->front_count = foff[nd + 1] - foff[nd];
+      const u64 b = ctl->best_next;
+      if (b != ~0ull) {
+        const int nb = remap[(uint32_t)b];
+        ctl->best_next = nb >= 0 ? ((b & 0xFFFFFFFF00000000ull) | (uint32_t)nb) : ~0ull;
+      }
+      ctl->pruned_upto = nd;
+      if (ps.err) ctl->error |= kErrLinksFull;  // never expected: a surviving token whose predecessor died
+    }
+    __syncthreads();
+  }
+  (void)any_final;
+}
+
 template <bool kLat, bool kBig>
 __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_t *target, int do_prep, int chan_off,
                                                       int group, int par) {
@@ -1490,6 +1758,16 @@ __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_
   ChanCtl *ctl = D.ctl + c;
   if (ctl->active) finalize_frame<kLat, kBig>(D, c, ctl, sh);
   __syncthreads();
+  if constexpr (kLat) {
+    // PruneActiveTokens at the top of every prune_interval-th frame's iteration (base-inl.h:660-661), i.e.
+    // only when the channel goes on to decode that frame
+    __shared__ PruneShared ps;
+    const int nd = ctl->n_decoded;
+    if (do_prep && nd > 0 && nd % D.prune_interval == 0 && ctl->pruned_upto != nd && nd < target[c] && ctl->error == 0 &&
+        !ctl->finalized && nd < D.max_frames)
+      prune_pass<false>(D, c, ps);
+    __syncthreads();
+  }
   if (do_prep) prep_frame<kBig>(D, c, ctl, target, sh, group, par);  // par: parity of the step it prepares
 }
 
@@ -1771,143 +2049,78 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   }
 }
 
-// =========================================================================================
-// lattice_prune_kernel: FinalizeDecoding (PruneForwardLinksFinal + PruneForwardLinks +
-// PruneTokensForFrame, base-inl.h:482-607,725-847) as an edge-parallel backward pass over the
-// recorded forward links; one 1024-thread workgroup per channel, frames in descending order.
-//   extra[t]  = min over t's links of (extra[next] + (link cost - cost_next)), links with more than
-//               lattice_beam dropped; last frame seeded with cost + final_cost - best.
-//               link cost = (cost_t + ac) + graph is the candidate cost the expansion computed, kept
-//               in the link record, so one 8-byte gather {extra, cost} of the destination prices a
-//               link; nearly all destinations are dead (extra = +inf) and cost nothing more.
-//   A link survives iff its link_extra <= lattice_beam, a token iff its extra is finite; both are
-//   appended to the channel's compact lat_arcs[] / lat_toks[] as soon as they are known.
-// The reference reaches the same fixpoint by sweeping token lists "while changed"; min is
-// order-independent, so atomicMin relaxation gives the same values (its last-frame loop stops at
-// changes <= 1e-5, ours at 0).
-// =========================================================================================
-__global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const int32_t *chans) {
+// GetRawLattice's raw material: every token and link alive right now, resolved to labels and costs, in the
+// channel's compact lat_toks[] / lat_arcs[].  use_final != 0: final states by ComputeFinalCosts (base-inl.h:
+// 670-720, 924-940): the graph-final tokens of the newest frame if there are any, else all of it.
+__global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const int32_t *chans, int use_final) {
   const int c = chans ? chans[blockIdx.x] : blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   ChanCtl *ctl = D.ctl + c;
   const int nd = ctl->n_decoded;
   const int4 *tok = D.tok + (size_t)c * D.arena_cap;
   const int4 *links = D.links + (size_t)c * D.link_cap;
-  uint2 *extra = D.extra + (size_t)c * D.arena_cap;
   LatArc *out_arcs = D.lat_arcs + (size_t)c * D.lat_arc_cap;
   int4 *out_toks = D.lat_toks + (size_t)c * D.lat_tok_cap;
   const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
   const int32_t *loff = D.link_off + (size_t)c * (D.max_frames + 3);
   const int32_t *lmid = D.link_mid + (size_t)c * (D.max_frames + 3);
   const float *ll = D.ll_base[c];
-  const float kInf = __builtin_huge_valf();
-  const uint32_t kInfO = f2o(kInf);
-  const float lb = D.lattice_beam;
-  __shared__ u64 s_red[2][kBW];
-  __shared__ int s_changed, s_narcs, s_ntoks, s_err;
-  if (tid == 0) { s_narcs = 0; s_ntoks = 0; s_err = 0; }
+  __shared__ int s_any_final, s_narcs, s_err;
+  if (tid == 0) { s_any_final = 0; s_narcs = 0; s_err = 0; }
+  __syncthreads();
   if (ctl->error) return;
-  // (extra[] was filled with {+inf, cost} by lattice_fill_kernel: plain stores and the memory-side
-  // atomics below must not meet inside one launch)
-  // ComputeFinalCosts (base-inl.h:670-720) over the last frame
-  u64 b_all = ~0ull, b_fin = ~0ull;
-  for (int i = foff[nd] + tid; i < foff[nd + 1]; i += kBT) {
-    const int4 t = tok[i];
-    const u64 v = (u64)f2o(__int_as_float(t.y));
-    b_all = v < b_all ? v : b_all;
-    if (t.x == D.g.final_state) b_fin = v < b_fin ? v : b_fin;
-  }
-  b_all = wave_min_u64(b_all);
-  b_fin = wave_min_u64(b_fin);
-  if (lane == 0) { s_red[0][wave] = b_all; s_red[1][wave] = b_fin; }
-  __syncthreads();
-  for (int w = 0; w < kBW; ++w) { b_all = s_red[0][w] < b_all ? s_red[0][w] : b_all; b_fin = s_red[1][w] < b_fin ? s_red[1][w] : b_fin; }
-  const bool any_final = b_fin != ~0ull;
-  const float final_best = o2f((uint32_t)(any_final ? b_fin : b_all));
-  for (int i = foff[nd] + tid; i < foff[nd + 1]; i += kBT) {
-    const int4 t = tok[i];
-    const float final_cost = (!any_final || t.x == D.g.final_state) ? 0.0f : kInf;
-    float e = __int_as_float(t.y) + final_cost - final_best;  // base-inl.h:775
-    if (e > lb) e = kInf;                                      // base-inl.h:815-816 (tokens without links)
-    atomicExch(&extra[i].x, f2o(e));
+  if (use_final) {
+    int any = 0;
+    for (int i = foff[nd] + tid; i < foff[nd + 1]; i += kBT) any |= tok[i].x == D.g.final_state;
+    if (any) s_any_final = 1;
   }
   __syncthreads();
-
-  // link_extra given the CURRENT extra of the destination (base-inl.h:524-526, 782-784); +inf for a
-  // dead destination
-  auto link_extra = [&](const int4 L) -> float {
-    const u64 e = ld_agent(reinterpret_cast<const u64 *>(&extra[L.y]));  // {extra (low), cost (high)}
-    const uint32_t eo = (uint32_t)e;
-    if (eo >= kInfO) return kInf;
-    return o2f(eo) + (__int_as_float(L.w) - __int_as_float((int)(e >> 32)));
-  };
-  auto emit_arc = [&](const int4 L, int k_src_frame, bool eps) {
-    const int p = atomicAdd(&s_narcs, 1);
-    if (p >= D.lat_arc_cap) { s_err = 1; return; }
-    const int4 A = D.g.arcs[L.z];
-    LatArc o;
-    o.src_tok = L.x; o.dst_tok = L.y;
-    o.ilabel = eps ? 0 : D.g.arc_ilabel[L.z];
-    o.olabel = D.g.arc_olabel[L.z];
-    o.graph = __int_as_float(A.z);
-    o.acoustic = eps ? 0.0f : -ll[(size_t)k_src_frame * D.stride + A.x];
-    o.src_frame = k_src_frame; o.is_eps = eps ? 1 : 0;
-    out_arcs[p] = o;
-  };
-  for (int k = nd; k >= 0; --k) {
-    const int fk = foff[k], fk1 = foff[k + 1];
-    // (A) emitting links frame k -> k+1: the extras of frame k+1 are final, so a link that passes is
-    // a link of the lattice
-    if (k < nd) {
-      for (int i = loff[k + 1] + tid; i < lmid[k + 1]; i += kBT) {
-        const int4 L = links[i];
-        float le = link_extra(L);
-        if (!(le <= lb)) continue;
-        emit_arc(L, k, false);
-        if (le < 0.0f) le = 0.0f;
-        atomicMin(&extra[L.x].x, f2o(le));
-      }
-      __syncthreads();
-    }
-    // (B) epsilon links inside frame k, to the fixpoint
-    const int e0 = lmid[k], e1 = loff[k + 1];
-    for (int round = 0; e0 < e1 && round < 4096; ++round) {
-      if (tid == 0) s_changed = 0;
-      __syncthreads();
-      for (int i = e0 + tid; i < e1; i += kBT) {
-        const int4 L = links[i];
-        float le = link_extra(L);
-        if (!(le <= lb)) continue;
-        if (le < 0.0f) le = 0.0f;
-        const uint32_t o = f2o(le);
-        if (o < atomicMin(&extra[L.x].x, o)) s_changed = 1;
-      }
-      __syncthreads();
-      const int ch = s_changed;
-      __syncthreads();
-      if (!ch) break;
-    }
-    for (int i = e0 + tid; i < e1; i += kBT) {
-      const int4 L = links[i];
-      if (link_extra(L) <= lb) emit_arc(L, k, true);
-    }
-    // the live tokens of frame k
-    for (int i = fk + tid; i < fk1; i += kBT) {
-      const u64 e = ld_agent(reinterpret_cast<const u64 *>(&extra[i]));
-      if ((uint32_t)e >= kInfO) continue;
-      const int p = atomicAdd(&s_ntoks, 1);
-      if (p >= D.lat_tok_cap) { s_err = 1; continue; }
+  const bool any_final = s_any_final != 0;
+  const int n_tok = foff[nd + 1];
+  // tokens: arena order = frame order; the frame of a token by walking the frame offsets
+  for (int f = 0; f <= nd; ++f) {
+    for (int i = foff[f] + tid; i < foff[f + 1]; i += kBT) {
+      if (i >= D.lat_tok_cap) { s_err = 1; continue; }
       const int4 t = tok[i];
-      const int fin = (k == nd && (!any_final || t.x == D.g.final_state)) ? 1 : 0;
-      out_toks[p] = make_int4(i, D.g.arcs[t.x].y, t.y, k | (fin << 30));  // .y: the graph's own state id (row header)
+      const int fin = (f == nd && (!use_final || !any_final || t.x == D.g.final_state)) ? 1 : 0;
+      out_toks[i] = make_int4(i, D.g.arcs[t.x].y, t.y, f | (fin << 30));  // .y: the graph's own state id (row header)
     }
-    __syncthreads();
   }
+  // links, segment by segment (the segment tells the source frame and whether the arc is an epsilon)
+  for (int f = 0; f <= nd; ++f) {
+    for (int part = 0; part < 2; ++part) {
+      const int lo = part == 0 ? loff[f] : lmid[f], hi = part == 0 ? lmid[f] : loff[f + 1];
+      const bool eps = part == 1;
+      const int src_frame = eps ? f : f - 1;
+      for (int i = lo + tid; i < hi; i += kBT) {
+        const int4 L = links[i];
+        if (L.x < 0) continue;
+        const int p = atomicAdd(&s_narcs, 1);
+        if (p >= D.lat_arc_cap) { s_err = 1; continue; }
+        const int4 A = D.g.arcs[L.z];
+        LatArc o;
+        o.src_tok = L.x; o.dst_tok = L.y;
+        o.ilabel = eps ? 0 : D.g.arc_ilabel[L.z];
+        o.olabel = D.g.arc_olabel[L.z];
+        o.graph = __int_as_float(A.z);
+        o.acoustic = eps ? 0.0f : -ll[(size_t)src_frame * D.stride + A.x];
+        o.src_frame = src_frame; o.is_eps = eps ? 1 : 0;
+        out_arcs[p] = o;
+      }
+    }
+  }
+  __syncthreads();
   if (tid == 0) {
     ctl->lat_arcs = min(s_narcs, D.lat_arc_cap);
-    ctl->lat_toks = min(s_ntoks, D.lat_tok_cap);
+    ctl->lat_toks = min(n_tok, D.lat_tok_cap);
     if (s_err) ctl->error |= kErrLinksFull;
   }
+}
+
+__global__ __launch_bounds__(kBT) void lattice_finalize_kernel(DecoderDev D, const int32_t *chans) {
+  __shared__ PruneShared ps;
+  const int c = chans ? chans[blockIdx.x] : blockIdx.x;
+  prune_pass<true>(D, c, ps);
 }
 
 // =========================================================================================
@@ -1964,19 +2177,12 @@ void launch_best_path(const DecoderDev &D, const int32_t *chans, int n, int use_
     hipLaunchKernelGGL(best_path_kernel<false>, dim3(n), dim3(kBpThreads), 0, s, D, chans, use_final, cap, ilabel, olabel, graph,
                        ac, n_hops, chain);
 }
-__global__ __launch_bounds__(256) void lattice_fill_kernel(DecoderDev D, const int32_t *chans) {
-  const int c = chans ? chans[blockIdx.x] : blockIdx.x;
-  const ChanCtl *ctl = D.ctl + c;
-  const int n_tok = D.frame_off[(size_t)c * (D.max_frames + 2) + ctl->n_decoded + 1];
-  uint2 *extra = D.extra + (size_t)c * D.arena_cap;
-  const int4 *tok = D.tok + (size_t)c * D.arena_cap;
-  const uint32_t inf_o = f2o(__builtin_huge_valf());
-  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n_tok; i += gridDim.y * blockDim.x)
-    extra[i] = make_uint2(inf_o, (uint32_t)tok[i].y);
-}
 void launch_lattice_prune(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
-  hipLaunchKernelGGL(lattice_fill_kernel, dim3(n, 64), dim3(256), 0, s, D, chans);
-  hipLaunchKernelGGL(lattice_prune_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
+  hipLaunchKernelGGL(lattice_finalize_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
+  hipLaunchKernelGGL(lattice_emit_kernel, dim3(n), dim3(kBT), 0, s, D, chans, 1);
+}
+void launch_lattice_emit(const DecoderDev &D, const int32_t *chans, int n, int use_final, hipStream_t s) {
+  hipLaunchKernelGGL(lattice_emit_kernel, dim3(n), dim3(kBT), 0, s, D, chans, use_final);
 }
 int insert_kernel_set_lds(int bytes) {
   int e = (int)hipFuncSetAttribute((const void *)insert_kernel_lattice, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

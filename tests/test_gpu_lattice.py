@@ -143,13 +143,15 @@ def test_gpu_lattice_errors_are_loud(synth, tmp_path):
     with pytest.raises(G.wfstdec.WfstError):
         dec.raw_lattice(0)
     dec.free()
-    # lattice mode: before finalize -> state error; link capacity too small -> capacity error
+    # lattice mode: before InitDecoding -> state error (mid-utterance it is served: tests/test_gpu_running_prune.py);
+    # link capacity too small -> capacity error
     dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 1, max_frames=64, max_tokens_per_frame=8192, arena_tokens=1 << 18,
                                  lattice_links=1 << 20)
-    dec.init()
-    dec.advance([dev[0].data_ptr()], [40], ll.shape[1])
     with pytest.raises(G.wfstdec.WfstError):
         dec.raw_lattice(0)
+    dec.init()
+    dec.advance([dev[0].data_ptr()], [40], ll.shape[1])
+    assert dec.raw_lattice(0) is not None
     dec.free()
     dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 1, max_frames=64, max_tokens_per_frame=8192, arena_tokens=1 << 18,
                                  lattice_links=64)
