@@ -958,6 +958,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.beam = cfg->beam;
   D.lattice_beam = cfg->lattice_beam;
   D.beam_delta = cfg->beam_delta;
+  D.prune_scale = cfg->prune_scale;
   D.max_active = cfg->max_active;
   D.min_active = cfg->min_active;
   D.prune_interval = cfg->prune_interval;
@@ -1001,6 +1002,9 @@ void wfst_decoder_free(wfst_decoder *d) {
         if (t[3 * k + 2])
           fprintf(stderr, "[wfst dbg] %-18s n=%llu mean=%.2f us max=%.2f us\n", names[k], t[3 * k + 2],
                   0.01 * t[3 * k] / t[3 * k + 2], 0.01 * t[3 * k + 1]);
+      if (t[52])
+        fprintf(stderr, "[wfst dbg] prune passes=%llu walk mean=%.1f us compaction mean=%.1f us frames walked mean=%.1f\n", t[52],
+                0.01 * t[51] / t[52], 0.01 * t[54] / t[52], (double)t[53] / t[52]);
       fprintf(stderr, "[wfst dbg] closure rounds total=%llu launches*chan=%llu max_seeds=%llu max_rounds=%llu first round mean=%.2f us max=%.2f us\n",
               t[56], t[57], t[58], t[59], t[57] ? 0.01 * t[60] / t[57] : 0.0, 0.01 * t[61]);
     }

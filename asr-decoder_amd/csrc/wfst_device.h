@@ -225,7 +225,7 @@ struct DecoderDev {
   int32_t max_frames;
   int64_t arena_cap;
   // config (LatticeFasterDecoderConfig)
-  float beam, lattice_beam, beam_delta;
+  float beam, lattice_beam, beam_delta, prune_scale;
   int32_t max_active, min_active, prune_interval;
   // biglm mode (wfst_decoder_create_biglm): a token is identified by (graph row, LM pair state), the
   // reference's 64-bit PairId (my-decoder/online-decoder-mempool-base-biglm.h:77-90).

@@ -1551,40 +1551,58 @@ __device__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
   const uint32_t kInfO = f2o(kInf);
   const float lb = D.lattice_beam;
   if (ctl->error) return;
+  unsigned long long tq = wall_clock64();
   const int n_prev = ctl->pruned_upto;   // frames below hold the extras of an earlier pass
   const int fn = foff[nd], fn1 = foff[nd + 1];
   bool any_final = false;
 
-  // link_extra given the CURRENT extra of the destination (base-inl.h:524-526, 782-784); +inf for a dead one
-  auto link_extra = [&](const int4 L) -> float {
-    const u64 e = ld_agent(reinterpret_cast<const u64 *>(&extra[L.y]));  // {extra (low), cost (high)}
-    const uint32_t eo = (uint32_t)e;
-    if (eo >= kInfO) return kInf;
-    return o2f(eo) + (__int_as_float(L.w) - __int_as_float((int)(e >> 32)));
+  // link_extra = extra of the destination + (link cost - cost of the destination) (base-inl.h:524-526,
+  // 782-784), from one 8-byte gather {extra (low), cost (high)}; +inf for a dead destination
+  // A pass is a chain of short phases over a few thousand links or tokens each: latency, not bytes.  Every
+  // thread therefore takes kPU items of a phase at once -- the link loads together, then the gathers of the
+  // destinations' {extra, cost}, then the atomics -- instead of one dependent chain per item.
+  constexpr int kPU = 6;
+  // f(i, L, le): link i = L is alive and its link_extra is le (maybe above lattice_beam)
+  auto for_links = [&](int lo, int hi, auto &&f) {
+    for (int i0 = lo; i0 < hi; i0 += kBT * kPU) {
+      int4 L[kPU];
+      u64 e[kPU];
+#pragma unroll
+      for (int u = 0; u < kPU; ++u) {
+        const int i = i0 + u * kBT + tid;
+        L[u] = i < hi ? links[i] : make_int4(-1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < kPU; ++u) e[u] = L[u].x >= 0 ? ld_agent(reinterpret_cast<const u64 *>(&extra[L[u].y])) : 0ull;
+#pragma unroll
+      for (int u = 0; u < kPU; ++u) {
+        if (L[u].x < 0) continue;
+        const uint32_t eo = (uint32_t)e[u];
+        const float le = eo >= kInfO ? kInf : o2f(eo) + (__int_as_float(L[u].w) - __int_as_float((int)(e[u] >> 32)));
+        f(i0 + u * kBT + tid, L[u], le);
+      }
+    }
   };
   // the epsilon links of a frame, [e0, e1), to their fixpoint; then the dead ones are marked
   auto relax_eps = [&](int e0, int e1) {
-    for (int round = 0; e0 < e1 && round < 4096; ++round) {
+    if (e0 >= e1) return;
+    for (int round = 0; round < 4096; ++round) {
       if (tid == 0) ps.changed = 0;
       __syncthreads();
-      for (int i = e0 + tid; i < e1; i += kBT) {
-        const int4 L = links[i];
-        if (L.x < 0) continue;
-        float le = link_extra(L);
-        if (!(le <= lb)) continue;
+      for_links(e0, e1, [&](int, const int4 &L, float le) {
+        if (!(le <= lb)) return;
         if (le < 0.0f) le = 0.0f;
         const uint32_t o = f2o(le);
         if (o < atomicMin(&extra[L.x].x, o)) ps.changed = 1;
-      }
+      });
       __syncthreads();
       const int ch = ps.changed;
       __syncthreads();
       if (!ch) break;
     }
-    for (int i = e0 + tid; i < e1; i += kBT) {
-      const int4 L = links[i];
-      if (L.x >= 0 && !(link_extra(L) <= lb)) links[i].x = -1;
-    }
+    for_links(e0, e1, [&](int i, const int4 &, float le) {
+      if (!(le <= lb)) links[i].x = -1;
+    });
     __syncthreads();
   };
 
@@ -1619,82 +1637,140 @@ __device__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
     __syncthreads();
   }
 
-  // ---- (2) older frames, newest first, until nothing changes any more --------------------------------
+  // ---- (2) older frames, newest first ---------------------------------------------------------------
+  // PruneActiveTokens walks on while a frame's extras moved by more than delta = lattice_beam * prune_scale
+  // (base-inl.h:452-461; frames never priced before are always priced); FinalizeDecoding walks every frame
+  // (delta 0, :838-843).  "Moved" is judged on the frame's exact fixpoint against the value before the pass
+  // (the reference judges sweep by sweep over its token list: oracle/wfst_oracle.c prune_forward_links).
+  const float delta = kFinal ? 0.0f : D.lattice_beam * D.prune_scale;
   int k_lo = nd;   // oldest frame re-priced by this pass
+  bool moved = true;
   for (int k = nd - 1; k >= 0; --k) {
     const int fk = foff[k], fk1 = foff[k + 1];
     const bool had_old = k < n_prev;
-    for (int i = fk + tid; i < fk1; i += kBT) {
-      if (had_old) remap[i] = (int32_t)extra[i].x;
-      extra[i] = make_uint2(kInfO, (uint32_t)tok[i].y);
+    if (!kFinal && had_old && !moved) break;
+    for (int i0 = fk; i0 < fk1; i0 += kBT * kPU) {
+      int cy[kPU];
+      uint32_t ox[kPU];
+#pragma unroll
+      for (int u = 0; u < kPU; ++u) {
+        const int i = i0 + u * kBT + tid;
+        cy[u] = i < fk1 ? tok[i].y : 0;
+        ox[u] = (had_old && i < fk1) ? extra[i].x : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kPU; ++u) {
+        const int i = i0 + u * kBT + tid;
+        if (i >= fk1) continue;
+        if (had_old) remap[i] = (int32_t)ox[u];
+        extra[i] = make_uint2(kInfO, (uint32_t)cy[u]);
+      }
     }
     __syncthreads();
     // emitting links frame k -> k+1
-    for (int i = loff[k + 1] + tid; i < lmid[k + 1]; i += kBT) {
-      const int4 L = links[i];
-      if (L.x < 0) continue;
-      float le = link_extra(L);
-      if (!(le <= lb)) { links[i].x = -1; continue; }
+    for_links(loff[k + 1], lmid[k + 1], [&](int i, const int4 &L, float le) {
+      if (!(le <= lb)) { links[i].x = -1; return; }
       if (le < 0.0f) le = 0.0f;
       atomicMin(&extra[L.x].x, f2o(le));
-    }
+    });
     __syncthreads();
     relax_eps(lmid[k], loff[k + 1]);
     k_lo = k;
-    if (had_old) {
+    if (!kFinal) {
       if (tid == 0) ps.any_changed = 0;
       __syncthreads();
       int ch = 0;
-      for (int i = fk + tid; i < fk1; i += kBT) ch |= (int32_t)ld_agent(&extra[i].x) != remap[i];
+      for (int i = fk + tid; i < fk1; i += kBT) {
+        const float now = o2f(ld_agent(&extra[i].x));
+        const float was = had_old ? o2f((uint32_t)remap[i]) : 0.0f;   // a token is created with extra_cost 0 (base-inl.h:103)
+        ch |= fabsf(now - was) > delta;                                // (inf - inf = NaN: not "moved", as in the reference)
+      }
       if (ch) ps.any_changed = 1;
       __syncthreads();
-      const int any = ps.any_changed;
+      moved = ps.any_changed != 0;
       __syncthreads();
-      if (!any) break;   // extra_costs_changed == false: older frames keep their extras and links (base-inl.h:458-461)
     }
   }
 
-  // ---- (3) compaction: tokens of frames [k_lo, nd], links from the epsilon links of frame k_lo on -------
-  // (nothing older lost anything).  A token is dead iff its extra is +inf; a link iff it was marked.
+  if (tid == 0 && (D.dbg & 32)) {
+    const unsigned long long now = wall_clock64();
+    atomicAdd(&D.dbg_t[51], now - tq); atomicAdd(&D.dbg_t[52], 1ull); atomicAdd(&D.dbg_t[53], (unsigned long long)(nd - k_lo));
+    tq = now;
+  }
+  // ---- (3) compaction of what this pass priced for the FIRST time: tokens of frames [c_lo, nd], links from the
+  // epsilon links of frame c_lo on.  That is where nearly everything dies (a raw frame keeps a percent or two of
+  // its tokens).  Frames priced before only lose the odd token now and then: there the dead stay where they are
+  // as holes (a token is dead iff its extra is +inf, a link iff it was marked; lattice_emit_kernel skips both) --
+  // moving the whole history down for them would cost more than the walk itself.
+  if (kFinal) {
+    if (tid == 0) ctl->pruned_upto = nd + 1;   // every frame is priced, the newest included; nothing moves any more
+    __syncthreads();
+    return;
+  }
   {
+    // ... until the holes add up: every eighth pass, or with the arena or the link store half full, the
+    // whole re-priced range is compacted
+    const bool full = (nd / D.prune_interval) % 8 == 0 || 2 * (int64_t)foff[nd + 1] > D.arena_cap ||
+                      2 * (int64_t)ctl->link_count > D.link_cap;
+    const int c_lo = full ? k_lo : max(k_lo, min(n_prev, nd));
+    k_lo = c_lo;
     const int range_lo = foff[k_lo];
     int new_end = range_lo;
     int old_lo = range_lo;
     if (tid == 0) ps.err = 0;
     __syncthreads();
+    constexpr int kCU = 8;   // items per thread and sweep: a raw frame's few thousand tokens or links in one go
     for (int f = k_lo; f <= nd; ++f) {
       const int old_hi = foff[f + 1];
       // (a) new index of every survivor of the frame
       int base = new_end;
-      for (int i0 = old_lo; i0 < old_hi; i0 += kBT) {
-        const int i = i0 + tid;
-        // (PruneActiveTokens never calls PruneTokensForFrame(0), base-inl.h:471-476: frame 0 keeps its dead
-        // tokens, link-less, until FinalizeDecoding)
-        const bool alive = i < old_hi && ((!kFinal && f == 0) || (uint32_t)ld_agent(&extra[i].x) < kInfO);
+      for (int i0 = old_lo; i0 < old_hi; i0 += kBT * kCU) {
+        bool alive[kCU];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < kCU; ++u) {
+          const int i = i0 + tid * kCU + u;
+          // (PruneActiveTokens never calls PruneTokensForFrame(0), base-inl.h:471-476: frame 0 keeps its dead
+          // tokens, link-less, until FinalizeDecoding)
+          alive[u] = i < old_hi && ((!kFinal && f == 0) || (uint32_t)ld_agent(&extra[i].x) < kInfO);
+          cnt += alive[u] ? 1 : 0;
+        }
         int tot;
-        const int r = block_exscan(alive ? 1 : 0, ps, &tot);
-        if (i < old_hi) remap[i] = alive ? base + r : -1;
+        int r = base + block_exscan(cnt, ps, &tot);
+#pragma unroll
+        for (int u = 0; u < kCU; ++u) {
+          const int i = i0 + tid * kCU + u;
+          if (i < old_hi) remap[i] = alive[u] ? r++ : -1;
+        }
         base += tot;
       }
       __syncthreads();
-      // (b) move them (downwards only: a chunk is read whole before it is written)
-      for (int i0 = old_lo; i0 < old_hi; i0 += kBT) {
-        const int i = i0 + tid;
-        const int ni = i < old_hi ? remap[i] : -1;
-        int4 rec = make_int4(0, 0, 0, 0);
-        uint2 ex = make_uint2(0, 0);
-        if (ni >= 0) {
-          rec = tok[i];
-          ex = extra[i];
+      // (b) move them (downwards only: a sweep is read whole before it is written)
+      for (int i0 = old_lo; i0 < old_hi; i0 += kBT * kCU) {
+        int ni[kCU];
+        int4 rec[kCU];
+        uint2 ex[kCU];
+#pragma unroll
+        for (int u = 0; u < kCU; ++u) {
+          const int i = i0 + tid * kCU + u;
+          ni[u] = i < old_hi ? remap[i] : -1;
+          rec[u] = make_int4(0, 0, 0, 0);
+          ex[u] = make_uint2(0, 0);
+          if (ni[u] >= 0) { rec[u] = tok[i]; ex[u] = extra[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < kCU; ++u) {
           // backpointer: a survivor's predecessor survives (the link between them is the token's own best one);
           // predecessors below the compacted range have not moved
-          if (rec.z >= range_lo) {
-            rec.z = remap[rec.z];
-            if (rec.z < 0) ps.err = 1;
+          if (ni[u] >= 0 && rec[u].z >= range_lo) {
+            rec[u].z = remap[rec[u].z];
+            if (rec[u].z < 0) ps.err = 1;
           }
         }
         __syncthreads();
-        if (ni >= 0) { tok[ni] = rec; extra[ni] = ex; }
+#pragma unroll
+        for (int u = 0; u < kCU; ++u)
+          if (ni[u] >= 0) { tok[ni[u]] = rec[u]; extra[ni[u]] = ex[u]; }
         __syncthreads();
       }
       new_end = base;
@@ -1702,27 +1778,35 @@ __device__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
       if (tid == 0) foff[f + 1] = new_end;
       __syncthreads();
     }
-    // links: eps(k_lo), then for f = k_lo+1 .. nd: emitting(f), eps(f)
-    int lnew = lmid[k_lo];
-    int seg_lo = lmid[k_lo];
-    const int n_seg = 2 * (nd - k_lo) + 1;
+    // links: for f = k_lo .. nd: emitting(f) (into frame f: its destinations moved), eps(f)
+    int lnew = loff[k_lo];
+    int seg_lo = loff[k_lo];
+    const int n_seg = 2 * (nd - k_lo) + 2;
     for (int sidx = 0; sidx < n_seg; ++sidx) {
-      const int f = k_lo + (sidx + 1) / 2;
-      const bool eps_seg = (sidx & 1) == 0;
+      const int f = k_lo + sidx / 2;
+      const bool eps_seg = (sidx & 1) != 0;
       const int seg_hi = eps_seg ? loff[f + 1] : lmid[f];
       const int seg_new_lo = lnew;
-      for (int i0 = seg_lo; i0 < seg_hi; i0 += kBT) {
-        const int i = i0 + tid;
-        int4 L = make_int4(-1, 0, 0, 0);
-        if (i < seg_hi) L = links[i];
-        const bool alive = L.x >= 0;
-        int tot;
-        const int r = block_exscan(alive ? 1 : 0, ps, &tot);   // (its barriers separate the reads above from the writes below)
-        if (alive) {
-          L.x = remap[L.x];
-          L.y = remap[L.y];
-          links[lnew + r] = L;
+      for (int i0 = seg_lo; i0 < seg_hi; i0 += kBT * kCU) {
+        int4 L[kCU];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < kCU; ++u) {
+          const int i = i0 + tid * kCU + u;
+          L[u] = i < seg_hi ? links[i] : make_int4(-1, 0, 0, 0);
+          cnt += L[u].x >= 0 ? 1 : 0;
         }
+#pragma unroll
+        for (int u = 0; u < kCU; ++u)
+          if (L[u].x >= 0) {   // (a source below the compacted range has not moved)
+            if (L[u].x >= range_lo) L[u].x = remap[L[u].x];
+            if (L[u].y >= range_lo) L[u].y = remap[L[u].y];
+          }
+        int tot;
+        int r = lnew + block_exscan(cnt, ps, &tot);   // (its barriers separate the reads above from the writes below)
+#pragma unroll
+        for (int u = 0; u < kCU; ++u)
+          if (L[u].x >= 0) links[r++] = L[u];
         lnew += tot;
       }
       __syncthreads();
@@ -1743,6 +1827,7 @@ __device__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
         ctl->best_next = nb >= 0 ? ((b & 0xFFFFFFFF00000000ull) | (uint32_t)nb) : ~0ull;
       }
       ctl->pruned_upto = nd;
+      if (D.dbg & 32) atomicAdd(&D.dbg_t[54], wall_clock64() - tq);
       if (ps.err) ctl->error |= kErrLinksFull;  // never expected: a surviving token whose predecessor died
     }
     __syncthreads();
@@ -2065,8 +2150,8 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
   const int32_t *loff = D.link_off + (size_t)c * (D.max_frames + 3);
   const int32_t *lmid = D.link_mid + (size_t)c * (D.max_frames + 3);
   const float *ll = D.ll_base[c];
-  __shared__ int s_any_final, s_narcs, s_err;
-  if (tid == 0) { s_any_final = 0; s_narcs = 0; s_err = 0; }
+  __shared__ int s_any_final, s_narcs, s_ntoks, s_err;
+  if (tid == 0) { s_any_final = 0; s_narcs = 0; s_ntoks = 0; s_err = 0; }
   __syncthreads();
   if (ctl->error) return;
   if (use_final) {
@@ -2076,15 +2161,44 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
   }
   __syncthreads();
   const bool any_final = s_any_final != 0;
-  const int n_tok = foff[nd + 1];
-  // tokens: arena order = frame order; the frame of a token by walking the frame offsets
-  for (int f = 0; f <= nd; ++f) {
-    for (int i = foff[f] + tid; i < foff[f + 1]; i += kBT) {
-      if (i >= D.lat_tok_cap) { s_err = 1; continue; }
-      const int4 t = tok[i];
-      const int fin = (f == nd && (!use_final || !any_final || t.x == D.g.final_state)) ? 1 : 0;
-      out_toks[i] = make_int4(i, D.g.arcs[t.x].y, t.y, f | (fin << 30));  // .y: the graph's own state id (row header)
+  // tokens, frame by frame.  Frames the back-pruning has priced (below pruned_upto) hold their dead as holes:
+  // extra = +inf -- except frame 0 before FinalizeDecoding, whose dead tokens the reference keeps (link-less:
+  // PruneActiveTokens never calls PruneTokensForFrame(0), base-inl.h:471-476).
+  const uint2 *extra = D.extra + (size_t)c * D.arena_cap;
+  const uint32_t kInfO = f2o(__builtin_huge_valf());
+  const int pruned_upto = ctl->pruned_upto;
+  const bool finalized = ctl->finalized != 0;
+  {  // in arena order (= frame order; the n-best search relies on a frame's states being contiguous)
+    __shared__ PruneShared ps;
+    const int n_all = foff[nd + 1];
+    int base = 0;
+    for (int i0 = 0; i0 < n_all; i0 += kBT) {
+      const int i = i0 + tid;
+      int f = 0;
+      bool alive = false;
+      if (i < n_all) {
+        int lo = 0, hi = nd + 1;  // frame of token i: foff[f] <= i < foff[f+1]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (foff[mid] <= i) lo = mid; else hi = mid;
+        }
+        f = lo;
+        alive = !(f < pruned_upto && !(f == 0 && !finalized) && extra[i].x >= kInfO);
+      }
+      int tot;
+      const int p = base + block_exscan(alive ? 1 : 0, ps, &tot);
+      if (alive) {
+        if (p >= D.lat_tok_cap) s_err = 1;
+        else {
+          const int4 t = tok[i];
+          const int fin = (f == nd && (!use_final || !any_final || t.x == D.g.final_state)) ? 1 : 0;
+          out_toks[p] = make_int4(i, D.g.arcs[t.x].y, t.y, f | (fin << 30));  // .y: the graph's own state id (row header)
+        }
+      }
+      base += tot;
     }
+    if (tid == 0) s_ntoks = base;
+    __syncthreads();
   }
   // links, segment by segment (the segment tells the source frame and whether the arc is an epsilon)
   for (int f = 0; f <= nd; ++f) {
@@ -2112,7 +2226,7 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
   __syncthreads();
   if (tid == 0) {
     ctl->lat_arcs = min(s_narcs, D.lat_arc_cap);
-    ctl->lat_toks = min(n_tok, D.lat_tok_cap);
+    ctl->lat_toks = min(s_ntoks, D.lat_tok_cap);
     if (s_err) ctl->error |= kErrLinksFull;
   }
 }

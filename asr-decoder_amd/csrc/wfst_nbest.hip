@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
   const int K = N.K;
   const int4 *toks = D.lat_toks + (size_t)c * D.lat_tok_cap;
   const LatArc *arcs = D.lat_arcs + (size_t)c * D.lat_arc_cap;
-  uint2 *extra = D.extra + (size_t)c * D.arena_cap;
+  int32_t *state_of = D.remap + (size_t)c * D.arena_cap;  // arena index -> lattice state (scratch of the pruning passes, free between them)
   NbEntry *list = N.list + (size_t)c * N.tok_cap * K;
   int32_t *S = N.scratch + (size_t)c * N.scratch_ints;
   int32_t *off = S;                        // [tok_cap + 1] start of a state's incoming arcs
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
   __syncthreads();
   for (int i = tid; i < nt; i += kNbThreads) {
     const int4 t = toks[i];
-    extra[t.x].y = (uint32_t)i;
+    state_of[t.x] = i;
     off[i] = 0; cnt[i] = 0;
     const int f = t.w & 0x3FFFFFFF;
     if (i == 0 || (toks[i - 1].w & 0x3FFFFFFF) != f) fbeg[f] = i;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
   }
   if (tid == 0) off[nt] = 0;
   __syncthreads();
-  for (int a = tid; a < na; a += kNbThreads) atomicAdd(&off[extra[arcs[a].dst_tok].y], 1);
+  for (int a = tid; a < na; a += kNbThreads) atomicAdd(&off[state_of[arcs[a].dst_tok]], 1);
   __syncthreads();
   {  // exclusive scan of off[0..nt) (one contiguous slice per thread)
     const int per = (nt + kNbThreads - 1) / kNbThreads, b = tid * per, e = min(nt, b + per);
@@ -150,10 +150,10 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
     if (tid == 0) off[nt] = na;
   }
   __syncthreads();
-  for (int a = tid; a < na; a += kNbThreads) in_arcs[atomicAdd(&cur[extra[arcs[a].dst_tok].y], 1)] = a;
+  for (int a = tid; a < na; a += kNbThreads) in_arcs[atomicAdd(&cur[state_of[arcs[a].dst_tok]], 1)] = a;
   __syncthreads();
   // ---- the start state --------------------------------------------------------------------
-  const int root = (int)extra[0].y;  // the root token is arena entry 0; it survives every pruning
+  const int root = state_of[0];  // the root token is arena entry 0; it survives every pruning
   if (tid == 0) {
     NbEntry e;
     e.tot = 0.0f; e.lm = 0.0f; e.hash = 0x243F6A8885A308D3ull; e.prev = -1; e.word = 0;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
             // walk the arcs (uniform loop): arc wa contributes cnt[src] - we entries
             while (wa < a1 && given < 64 - K) {
               const LatArc A = arcs[in_arcs[wa]];
-              const int src = (int)extra[A.src_tok].y;
+              const int src = state_of[A.src_tok];
               const int have = cnt[src] - we;
               const int take = min(have, 64 - K - given);
               if (want >= given && want < given + take) { my_a = wa; my_e = we + (want - given); }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
             more = wa < a1;
             if (my_a >= 0) {
               const LatArc A = arcs[in_arcs[my_a]];
-              const int src = (int)extra[A.src_tok].y;
+              const int src = state_of[A.src_tok];
               const NbEntry E = list[(size_t)src * K + my_e];
               cnd.tot = E.tot + (A.graph + A.acoustic);  // LatticeToVector: tot += graph + acoustic
               cnd.lm = E.lm + A.graph;                   //                  lm  += graph

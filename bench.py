@@ -66,6 +66,7 @@ def parse():
                     "2 overlaps two half-batches: +7 %% frames/s, but per-launch accounting then covers half a batch")
     ap.add_argument("--host-feed", action="store_true", help="hand the log-likelihoods over as HOST matrices every step "
                     "(wfst_decoder_advance_host): the PCIe-inclusive rate; never the headline")
+    ap.add_argument("--max-tokens", type=int, default=131072, help="wfst_limits.max_tokens_per_frame")
     ap.add_argument("--arena-per-frame", type=int, default=20000, help="token arena per utterance = frames x this (raise it for wider beams)")
     ap.add_argument("--lattice-links", type=int, default=0, help="> 0: lattice mode (BASELINE configs[4]): record forward links "
                     "(capacity per utterance), prune by lattice_beam at finalize; the step then also takes the n-best")
@@ -376,7 +377,7 @@ def main():
     opt = wfstdec.Options(use_hip_graph=0 if a.no_hip_graph else 1, debug=a.debug, **({"channel_groups": a.groups} if a.groups > 0 else {}))
 
     def new_decoder(cfg_dict):
-        return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=131072,
+        return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=a.max_tokens,
                                     arena_tokens=int(T * a.arena_per_frame), stream=stream, lattice_links=a.lattice_links,
                                     options=opt, old_lm=lm_dev[0], new_lm=lm_dev[1], lm_pairs=a.lm_pairs if a.biglm else 0)
 

@@ -62,6 +62,7 @@ typedef struct Link {
 } Link;
 typedef struct Token {
   float tot_cost, extra_cost; Link *links; struct Token *next; struct Token *backpointer;
+  float extra_before; /* order-free pruning: extra_cost when PruneForwardLinks was entered */
   int is_final; /* stands for membership in _final_costs */
   float final_cost; /* its value there: 0, or the LM final cost in biglm mode */
   int state;    /* graph state (the reference token does not know it; used to label lattice states) */
@@ -86,6 +87,8 @@ typedef struct {
  * order has no effect on results */
 typedef struct PoolBlock { struct PoolBlock *next; } PoolBlock;
 typedef struct { void *free_head; PoolBlock *blocks; size_t elem_size; } Pool;
+
+static int g_order_free = 0; /* see process_emitting and prune_forward_links */
 
 /* ---- LM automaton: newlm/arpa2fsa.h:22-247; binary file ArpaLm::Read :355-397 + Fsa::Read arpa2fsa.cc:68-176 ---- */
 typedef struct { int wordid; float weight; int tostateid; } FsaArc;
@@ -509,7 +512,6 @@ static void process_nonemitting(Decoder *d, float cutoff) {
  * next_cutoff get in or not depending on the hash-list order.  With the flag set the final
  * next_cutoff is computed first and applied to every arc: the result is the subset of the reference's
  * tokens/links that does not depend on the visiting order.  Default 0 = the reference's behaviour. */
-static int g_order_free = 0;
 void oracle_set_order_free(int on) { g_order_free = on; }
 
 static float process_emitting(Decoder *d) {
@@ -588,10 +590,22 @@ static float process_emitting(Decoder *d) {
   return next_cutoff;
 }
 
-/* PruneForwardLinks: base-inl.h:482-572 */
+/* PruneForwardLinks: base-inl.h:482-572.
+ * Order-free variant (g_order_free, what the GPU computes): the reference sweeps the frame's token list
+ * until a sweep moves no extra_cost by more than delta, and reports "changed" if any sweep did -- with
+ * delta > 0 (PruneActiveTokens: lattice_beam * prune_scale) both the values it stops at (epsilon links
+ * inside the frame, read one sweep stale) and the report depend on the order of the list, i.e. on the
+ * hash-list order the tokens were created in.  The variant sweeps to the exact fixpoint and reports
+ * "changed" iff a token's extra_cost ended more than delta away from where it was BEFORE the call.  It
+ * coincides with the reference whenever no surviving token of the frame has an epsilon link to another
+ * (the usual case) and always with delta = 0 (FinalizeDecoding: the final lattice never differs); in
+ * general it is neither finer nor coarser.  tests/test_oracle_lattice.py counts how often the
+ * mid-utterance lattices of the two differ on the goldens. */
 static void prune_forward_links(Decoder *d, int fpo, int *extra_costs_changed, int *links_pruned, float delta) {
   *extra_costs_changed = 0; *links_pruned = 0;
   if (d->active[fpo].toks == NULL && !d->warned) d->warned = 1;
+  const float sweep_delta = g_order_free ? 0.0f : delta;
+  if (g_order_free) for (Token *tok = d->active[fpo].toks; tok; tok = tok->next) tok->extra_before = tok->extra_cost;
   int changed = 1;
   while (changed) {
     changed = 0;
@@ -611,11 +625,14 @@ static void prune_forward_links(Decoder *d, int fpo, int *extra_costs_changed, i
           prev_link = link; link = link->next;
         }
       }
-      if (fabsf(tok_extra_cost - tok->extra_cost) > delta) changed = 1;
+      if (fabsf(tok_extra_cost - tok->extra_cost) > sweep_delta) changed = 1;
       tok->extra_cost = tok_extra_cost;
     }
-    if (changed) *extra_costs_changed = 1;
+    if (changed && !g_order_free) *extra_costs_changed = 1;
   }
+  if (g_order_free)
+    for (Token *tok = d->active[fpo].toks; tok; tok = tok->next)
+      if (fabsf(tok->extra_cost - tok->extra_before) > delta) *extra_costs_changed = 1;
 }
 
 /* PruneTokensForFrame: base-inl.h:578-607 */

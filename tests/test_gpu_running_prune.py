@@ -4,14 +4,14 @@ COMPACTED, so that (a) GetRawLattice can be served at any time, like the referen
 mid-utterance by kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:58,81), and (b) lattice mode runs in bounded
 memory whatever the utterance length.
 
-The reference stops its backward walk at extras that moved by less than delta = lattice_beam * prune_scale
-(base-inl.h:439-480, 541-542) and leaves them stale -- too small -- so between passes it keeps a few links an
-exact walk drops.  The device walks to the exact fixpoint (delta = 0; its stopping rule is the reference's own,
-extras unchanged).  Hence, against the oracle (order-free mode, pinned to the reference):
-  * with prune_scale -> 0 the mid-utterance lattices are IDENTICAL, state by state;
-  * with the default prune_scale the device's is a sub-lattice of the oracle's with the same best path, and
-    it contains every arc of those frames that FinalizeDecoding keeps in the end;
-  * after FinalizeDecoding (delta 0 in the reference too) the lattices are identical either way.
+The reference walks backwards while a frame's extra costs moved by more than delta = lattice_beam *
+prune_scale (base-inl.h:439-480, 541-542), judging sweep by sweep over its token list -- with delta > 0 an
+order-dependent judgement where surviving tokens of a frame are chained by epsilon links.  The device judges on
+the frame's exact fixpoint against the values before the pass; the oracle's order-free mode states exactly that
+(oracle/wfst_oracle.c prune_forward_links) and is pinned to the reference on the goldens
+(tests/test_oracle_lattice.py).  Against it the mid-utterance lattices are IDENTICAL state by state, for the
+default prune_scale and for prune_scale -> 0 (the exact walk); after FinalizeDecoding (delta 0 in the reference
+too) the lattices are identical in any case.
 """
 import numpy as np
 import pytest
@@ -43,7 +43,7 @@ def _same_lattice(L, O, what):
 
 @pytest.mark.parametrize("prune_scale", [1e-9, 0.1])
 def test_mid_utterance_raw_lattice(prune_scale, synth, oracle, tmp_path):
-    from test_gpu_lattice import as_raw, multiset_contains
+    from test_gpu_lattice import as_raw
 
     G, g, m, path, graph = _setup(synth, tmp_path)
     cd = dict(beam=11.0, max_active=1000000, min_active=0, lattice_beam=5.0, prune_interval=10, prune_scale=prune_scale)
@@ -54,7 +54,7 @@ def test_mid_utterance_raw_lattice(prune_scale, synth, oracle, tmp_path):
     dev = G.upload(mats)
     dec.init()
     h = oracle.load_graph(path)
-    n_checked = n_smaller = 0
+    n_checked = 0
     try:
         oracle.set_order_free(True)
         # after InitDecoding only: the reference asserts num_frames > 0 (base-inl.h:896); the device returns "no lattice"
@@ -72,11 +72,7 @@ def test_mid_utterance_raw_lattice(prune_scale, synth, oracle, tmp_path):
                     L = as_raw(d)
                     what = "frame %d channel %d use_final_probs %s" % (r, c, ufp)
                     assert L.st_frame[0] == 0 and L.st_frame.max() == k and np.all(L.a_dst > L.a_src), what
-                    if prune_scale < 1e-6:
-                        _same_lattice(L, O, what)
-                    else:
-                        assert multiset_contains(O.labelled_arcs(), L.labelled_arcs()), what + ": not a sub-lattice of the oracle's"
-                        n_smaller += int(len(L.a_src) < len(O.a_src))
+                    _same_lattice(L, O, what)
                     n_checked += 1
             # the partial best path does not care about the pruning
             part = dec.best_paths(use_final_probs=False)
@@ -100,8 +96,6 @@ def test_mid_utterance_raw_lattice(prune_scale, synth, oracle, tmp_path):
         dec.free()
         graph.free()
     assert n_checked >= 60
-    if prune_scale >= 0.1:
-        print("mid-utterance lattices strictly smaller than the reference's in %d of %d cases" % (n_smaller, n_checked))
 
 
 def test_long_utterance_in_a_fixed_arena(synth, oracle, tmp_path):
