@@ -385,6 +385,8 @@ def main():
     ready = [T] * B
     tb = {"init": 0.0, "advance_enqueue": 0.0, "finalize": 0.0, "sync": 0.0, "best_paths": 0.0, "n": 0}
 
+    gathered = []  # world > 1: every utterance's result in global order, from the last step's gather
+
     def make_step(dec, ll_dev, host_rows):
         ptrs = [ll_dev[i].data_ptr() for i in range(B)]
 
@@ -412,7 +414,7 @@ def main():
                 tb[k] += v
             tb["n"] += 1
             if world > 1:  # the path's only collective: gather the final results (RCCL)
-                shard.gather_results(shard.pack_results(res), device=None if share else dev)
+                gathered[:] = shard.gather_results(shard.pack_results(res), device=None if share else dev)
             return res
 
         return step
@@ -482,6 +484,22 @@ def main():
             "channel_groups": int(opt.channel_groups),
         },
     }
+    if rank == 0 and world > 1 and os.environ.get("WFST_BENCH_CHECK_GATHER") == "1":
+        # test hook (tests/test_gpu_multirank.py): the gathered results of ALL ranks against the oracle
+        import pyoracle
+
+        pyoracle.build_oracle()
+        orc = pyoracle.OracleDecoder()
+        h = orc.load_graph(gpath)
+        sa = argparse.Namespace(**vars(a))
+        ok = 0
+        for u, r in enumerate(gathered):
+            ll = make_utts(synth, g, m, u, 1, T, P, sa)[0]
+            o = orc.decode(h, pyoracle.Config(**cd), ll, m)
+            ok += int(np.array_equal(o.words, r["words"]) and np.float32(o.tot_score).tobytes() == np.float32(r["tot_score"]).tobytes()
+                      and np.float32(o.lm_score).tobytes() == np.float32(r["lm_score"]).tobytes())
+        orc.free_graph(h)
+        out["config"]["gather_check"] = {"utterances": len(gathered), "bit_exact_vs_oracle": ok}
     if rank == 0:
         N = sum(s["N"] for s in gstats)
         E = sum(s["E"] for s in gstats)

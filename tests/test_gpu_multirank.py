@@ -1,0 +1,38 @@
+"""-m gpu: the N > 1 path of bench.py on ONE GPU -- `python -m torch.distributed.run --nproc-per-node 2 bench.py
+--gpus 2` with WFST_BENCH_SHARE_GPU=1 (both ranks decode on GPU 0 and gather over gloo; the launcher starts
+the ranks before anything touches the GPU).  Each rank decodes its own contiguous block of utterances with its
+own decoder, the results are gathered with shard.gather_results, and rank 0 checks EVERY utterance of both
+ranks against the oracle -- real decodes through the real collective, not fake payloads."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_share_one_gpu_and_gather_real_results():
+    env = dict(os.environ, WFST_BENCH_SHARE_GPU="1", WFST_BENCH_CHECK_GATHER="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "6", "--frames", "60", "--states", "20000", "--pdfs", "1000", "--cpu-sample", "0", "--no-service-point",
+           "--graph-cache", "/tmp/wfst_mr_graph_%d.bin"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 12 and d["scaling"] == "weak"
+    chk = d["config"]["gather_check"]
+    assert chk["utterances"] == 12 and chk["bit_exact_vs_oracle"] == 12, chk
