@@ -162,6 +162,14 @@ struct wfst_decoder {
   DevBuf<int32_t> nb_scratch, nb_out_i;
   DevBuf<float> nb_out_f;
   NbestDev nb = {};
+  // determinization (wfst_decoder_get_determinized_lattice): workspace allocated by the first call
+  DevBuf<int32_t> det_ws, det_result;
+  DevBuf<int4> det_out_a;
+  DevBuf<float2> det_out_w;
+  DetDev det = {};
+  struct DetLattice { int32_t n_states = 0, n_proper = 0, err = 0; std::vector<int4> a; std::vector<float2> w; };
+  std::vector<DetLattice> det_cache;
+  std::vector<char> det_cached;
   DevBuf<float> bp_g, bp_ac;
   // host-fed log-likelihood history (advance_host)
   hipStream_t copy_stream = nullptr;  // host -> device uploads of advance_host
@@ -216,6 +224,7 @@ struct wfst_decoder {
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
     pair_keys.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
+    det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
     bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
@@ -1051,6 +1060,7 @@ int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n) {
     d->h_ll_base[c] = nullptr;
     d->hist_rows[c] = 0;
     if (!d->lat_cached.empty()) d->lat_cached[c] = 0;
+    if (!d->det_cached.empty()) d->det_cached[c] = 0;
   }
   return WFST_OK;
 }
@@ -1274,6 +1284,7 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
     const int c = channels ? channels[i] : i;
     d->h_state[c] = 2;
     if (!d->lat_cached.empty()) d->lat_cached[c] = 0;
+    if (!d->det_cached.empty()) d->det_cached[c] = 0;
   }
   return WFST_OK;
 }
@@ -1628,6 +1639,101 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
     if (a_olabel) a_olabel[k] = ar[i].olabel;
     if (a_graph) a_graph[k] = ar[i].graph;
     if (a_acoustic) a_acoustic[k] = ar[i].acoustic;
+  }
+  return WFST_OK;
+}
+
+int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, int32_t cap_states,
+                                          int32_t cap_arcs, int32_t *n_states, int32_t *n_arcs, int32_t *st_final,
+                                          int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel, int32_t *a_olabel,
+                                          float *a_graph, float *a_acoustic) {
+  if (!d || channel < 0 || channel >= d->n_channels || !n_states || !n_arcs) return fail(WFST_E_ARG, "bad argument");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice needs a decoder created with wfst_limits.lattice_links > 0");
+  if (d->h_state[channel] == 0) return fail(WFST_E_STATE, "GetLattice before InitDecoding");
+  const bool live = d->h_state[channel] == 1;
+  HIP_TRY(hipSetDevice(d->device));
+  *n_states = 0;
+  *n_arcs = 0;
+  if (!live && !use_final_probs) return WFST_OK;  // as GetRawLattice (base-inl.h:879-884)
+  DetDev &X = d->det;
+  if (!d->det_ws.p) {  // first use: per-channel workspace for raw lattices of up to 64 k states / 128 k arcs
+    X.raw_states_cap = (int32_t)std::min<int64_t>(d->D.lat_tok_cap, 65536);
+    X.raw_arcs_cap = (int32_t)std::min<int64_t>(d->D.lat_arc_cap, 131072);
+    const int32_t base = 65536;
+    X.caps.trie = 8 * base; X.caps.pool = 16 * base; X.caps.states = 2 * base; X.caps.initials = 2 * base;
+    X.caps.arcs = 4 * base; X.caps.tmp = std::max(8192, 2 * (X.raw_arcs_cap + X.raw_states_cap));
+    X.out_cap = X.caps.arcs;
+    X.words_per_channel = 3 * (int64_t)X.raw_states_cap + 1 + 5 * (int64_t)X.raw_arcs_cap + det_words(X.caps, X.raw_states_cap) + 16;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(d->det_ws.alloc((size_t)d->n_channels * (size_t)X.words_per_channel));
+    HIP_TRY(d->det_result.alloc((size_t)d->n_channels * 4));
+    HIP_TRY(d->det_out_a.alloc((size_t)d->n_channels * (size_t)X.out_cap));
+    HIP_TRY(d->det_out_w.alloc((size_t)d->n_channels * (size_t)X.out_cap));
+    X.ws = d->det_ws.p;
+    X.result = d->det_result.p;
+    X.out_a = d->det_out_a.p;
+    X.out_w = d->det_out_w.p;
+    d->det_cache.resize((size_t)d->n_channels);
+    d->det_cached.assign((size_t)d->n_channels, 0);
+  }
+  if (live || !d->det_cached[channel]) {
+    // which channels: mid-utterance just this one (its lists are resolved first); after FinalizeDecoding every
+    // finalized channel not determinized yet, in one launch (their lists were resolved by FinalizeDecoding)
+    std::vector<int32_t> list;
+    if (live) list.push_back(channel);
+    else
+      for (int c = 0; c < d->n_channels; ++c)
+        if (d->h_state[c] == 2 && !d->det_cached[c]) list.push_back(c);
+    const int32_t *dev;
+    int32_t cnt;
+    int rc = stage_channels(d, list.data(), (int32_t)list.size(), &dev, &cnt);
+    if (rc != WFST_OK) return rc;
+    if (live) launch_lattice_emit(d->D, dev, cnt, use_final_probs ? 1 : 0, d->stream);
+    launch_determinize(d->D, X, dev, cnt, d->stream);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> res((size_t)cnt * 4);
+    HIP_TRY(hipMemcpyAsync(res.data(), X.result, res.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    rc = read_ctl(d);  // synchronises the stream
+    if (rc != WFST_OK) return rc;
+    rc = check_ctl_errors(d);
+    if (rc != WFST_OK) return rc;
+    for (int i = 0; i < cnt; ++i) {
+      wfst_decoder::DetLattice &L = d->det_cache[(size_t)list[i]];
+      L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
+      L.err = res[4 * i + 2];   // reported when THIS channel's lattice is asked for
+      d->det_cached[(size_t)list[i]] = live ? 0 : 1;
+      if (L.err) continue;
+      L.n_states = res[4 * i];
+      L.n_proper = res[4 * i + 3];
+      const size_t na = (size_t)res[4 * i + 1];
+      L.a.resize(na);
+      L.w.resize(na);
+      if (na) {
+        HIP_TRY(hipMemcpyAsync(L.a.data(), X.out_a + (size_t)i * X.out_cap, na * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipMemcpyAsync(L.w.data(), X.out_w + (size_t)i * X.out_cap, na * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(d->stream));
+  }
+  const wfst_decoder::DetLattice &L = d->det_cache[(size_t)channel];
+  if (L.err == 2)
+    return fail(WFST_E_CAPACITY, "channel " + std::to_string(channel) + ": raw lattice larger than the determinizer takes (" +
+                                     std::to_string(X.raw_states_cap) + " states / " + std::to_string(X.raw_arcs_cap) + " arcs)");
+  if (L.err)
+    return fail(WFST_E_CAPACITY, "channel " + std::to_string(channel) + ": the subset construction outgrew its workspace (lattice not determinizable within bounds)");
+  // the raw lattice's own "no lattice" cases (a frame without tokens, nothing decoded) give an empty result here too
+  *n_states = L.n_states;
+  *n_arcs = (int32_t)L.a.size();
+  if (L.n_states > cap_states || (int32_t)L.a.size() > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");
+  for (int32_t s = 0; s < L.n_states; ++s)
+    if (st_final) st_final[s] = s >= L.n_proper ? 1 : 0;
+  for (size_t k = 0; k < L.a.size(); ++k) {
+    if (a_src) a_src[k] = L.a[k].x;
+    if (a_dst) a_dst[k] = L.a[k].y;
+    if (a_ilabel) a_ilabel[k] = 0;
+    if (a_olabel) a_olabel[k] = L.a[k].z;
+    if (a_graph) a_graph[k] = L.w[k].x;
+    if (a_acoustic) a_acoustic[k] = L.w[k].y;
   }
   return WFST_OK;
 }

@@ -1,0 +1,138 @@
+// determinize_kernel: the reference's DeterminizeLatticeWrapper (newfst/lattice-determinize-api.cc:5-21) on
+// the pruned raw lattices resident on the device (lat_toks[] / lat_arcs[], left there by lattice_emit_kernel),
+// one workgroup per channel.  The workgroup builds the inverted, arc-sorted CSR of its lattice together; the
+// subset construction itself (wfst_determinize.h: a sequential algorithm by its definition, see there) runs
+// on one lane, the lattices of a batch side by side.
+#include "wfst_determinize.h"
+#include "wfst_device.h"
+
+namespace wfst {
+
+constexpr int kDetThreads = 256;
+
+__global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, DetDev X, const int32_t *chans) {
+  const int slot = blockIdx.x;
+  const int c = chans ? chans[slot] : slot;
+  const int tid = threadIdx.x;
+  const ChanCtl *ctl = D.ctl + c;
+  const int nt = ctl->lat_toks, na = ctl->lat_arcs;
+  int32_t *res = X.result + (size_t)slot * 4;   // {states, arcs, status (0 ok, 1 workspace exceeded, 2 lattice too large), -}
+  if (tid == 0) { res[0] = 0; res[1] = 0; res[2] = 0; res[3] = 0; }
+  if (ctl->error || nt <= 0 || ctl->n_decoded <= 0) return;
+  if (nt > X.raw_states_cap || na > X.raw_arcs_cap) {
+    if (tid == 0) res[2] = 2;
+    return;
+  }
+  const int4 *toks = D.lat_toks + (size_t)c * D.lat_tok_cap;
+  const LatArc *larcs = D.lat_arcs + (size_t)c * D.lat_arc_cap;
+  int32_t *state_of = D.remap + (size_t)c * D.arena_cap;   // arena index -> lattice state (scratch between pruning passes)
+  int32_t *base = X.ws + (size_t)c * X.words_per_channel;
+  int32_t *off = base;                       // [raw_states_cap + 1]
+  int32_t *fin = off + X.raw_states_cap + 1; // [raw_states_cap]
+  int32_t *cur = fin + X.raw_states_cap;     // [raw_states_cap]
+  DetArc *arcs = reinterpret_cast<DetArc *>(cur + X.raw_states_cap);  // [raw_arcs_cap]
+  int32_t *rest = reinterpret_cast<int32_t *>(arcs + X.raw_arcs_cap);
+  __shared__ int s_part[kDetThreads];
+
+  // ---- Invert + CSR + ArcSort (lattice-determinize-api.cc:8-11), workgroup-wide -------------------------
+  for (int i = tid; i < nt; i += kDetThreads) {
+    const int4 t = toks[i];
+    state_of[t.x] = i;
+    fin[i] = (t.w >> 30) & 1;
+    off[i] = 0;
+  }
+  if (tid == 0) off[nt] = 0;
+  __syncthreads();
+  for (int a = tid; a < na; a += kDetThreads) atomicAdd(&off[state_of[larcs[a].src_tok]], 1);
+  __syncthreads();
+  {  // exclusive scan of off[0..nt) (one contiguous slice per thread)
+    const int per = (nt + kDetThreads - 1) / kDetThreads, b = tid * per, e = min(nt, b + per);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += off[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int i = 0; i < kDetThreads; ++i) { const int v = s_part[i]; s_part[i] = run; run += v; }
+    }
+    __syncthreads();
+    int run = s_part[tid];
+    for (int i = b; i < e; ++i) { const int v = off[i]; off[i] = run; cur[i] = run; run += v; }
+    if (tid == 0) off[nt] = na;
+  }
+  __syncthreads();
+  for (int a = tid; a < na; a += kDetThreads) {
+    const LatArc A = larcs[a];
+    DetArc d;
+    d.ilabel = A.olabel;   // Invert: the word is the input label now
+    d.olabel = A.ilabel;
+    d.w1 = A.graph;
+    d.w2 = A.acoustic;
+    d.to = state_of[A.dst_tok];
+    arcs[atomicAdd(&cur[state_of[A.src_tok]], 1)] = d;
+  }
+  __syncthreads();
+  for (int s = tid; s < nt; s += kDetThreads) {  // ArcSort: by input label (a state has a handful of arcs)
+    const int b = off[s], e = off[s + 1];
+    for (int i = b + 1; i < e; ++i) {
+      const DetArc x = arcs[i];
+      int j = i;
+      // ties by (destination, costs): any fixed order will do -- the result does not depend on it (wfst_determinize.h)
+      auto after = [](const DetArc &p, const DetArc &q) {  // p sorts after q
+        if (p.ilabel != q.ilabel) return p.ilabel > q.ilabel;
+        if (p.to != q.to) return p.to > q.to;
+        if (p.olabel != q.olabel) return p.olabel > q.olabel;
+        return p.w1 > q.w1;
+      };
+      while (j > b && after(arcs[j - 1], x)) {
+        arcs[j] = arcs[j - 1];
+        --j;
+      }
+      arcs[j] = x;
+    }
+  }
+  __syncthreads();
+  // the root token (arena entry 0) must be state 0: lat_toks is in arena order, so it is
+  // ---- the subset construction: tables cleared by everyone, then one lane ---------------------------------
+  __shared__ DetWs W;
+  if (tid == 0) {
+    W.n_states = nt;
+    W.n_arcs = na;
+    W.off = off;
+    W.arcs = arcs;
+    W.is_final = fin;
+    W.delta = 1.0f / 1024;   // kDelta (DeterminizeLatticeOptions, lattice-determinize-api.h:16-25)
+    det_carve(W, rest, X.caps, nt);
+  }
+  __syncthreads();
+  det_init(W, tid, kDetThreads);
+  __syncthreads();
+  if (tid == 0) {
+    const int err = det_run(W);
+    // OutputNoolabel (lattice-determinize.h:307-377) + Invert: arcs {src, dst, 0, word, graph, acoustic}; a final weight is
+    // an arc <eps>:<eps> to an extra final state
+    int4 *oa = X.out_a + (size_t)slot * X.out_cap;
+    float2 *ow = X.out_w + (size_t)slot * X.out_cap;
+    int ns = W.os_n, no = 0, over = 0;
+    for (int i = 0; i < W.oa_n; ++i) {
+      const DetOutArc t = W.oarcs[i];
+      int dst = t.next;
+      if (t.next < 0) dst = ns++;
+      if (no < X.out_cap) {
+        oa[no] = make_int4(t.src, dst, t.next < 0 ? 0 : t.ilabel, t.next < 0 ? 1 : 0);
+        ow[no] = make_float2(t.w1, t.w2);
+      } else over = 1;
+      ++no;
+    }
+    res[0] = ns;
+    res[1] = no;
+    res[2] = (err || over) ? 1 : 0;
+    res[3] = W.os_n;   // states below this are the determinized states proper; the rest are the final states
+  }
+}
+
+void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chans, int cnt, hipStream_t s) {
+  hipLaunchKernelGGL(determinize_kernel, dim3(cnt), dim3(kDetThreads), 0, s, D, X, chans);
+}
+
+}  // namespace wfst

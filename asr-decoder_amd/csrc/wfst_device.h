@@ -270,6 +270,23 @@ struct NbestDev {
 };
 void launch_nbest(const DecoderDev &D, const NbestDev &N, const int32_t *chan_list_dev, int cnt, hipStream_t s);
 
+// ---- lattice determinization (wfst_determinize.hip / wfst_determinize.h) -------------------------------
+struct DetCaps;
+}  // namespace wfst
+#include "wfst_determinize.h"
+namespace wfst {
+struct DetDev {
+  int32_t *ws;                  // [c][words_per_channel]: the lattice's CSR, then the determinizer's workspace
+  int64_t words_per_channel;
+  int32_t raw_states_cap, raw_arcs_cap;   // largest raw lattice taken
+  DetCaps caps;
+  int32_t *result;              // [cnt][4] {states, arcs, status, determinized states proper}
+  int4 *out_a;                  // [cnt][out_cap] {src, dst, word, is-final-arc}
+  float2 *out_w;                // [cnt][out_cap] {graph, acoustic}
+  int32_t out_cap;
+};
+void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chan_list_dev, int cnt, hipStream_t s);
+
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "wfst_decoder_get_profile", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
-    "wfst_decoder_create_biglm",
+    "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice",
 ]
 
 
@@ -326,6 +326,24 @@ class BatchDecoder:
                                                   _i32(il), _i32(ol), _f32(gr), _f32(ac)))
         return dict(n_states=S, st_final=fin, st_frame=fr, st_state=gs, st_cost=co, a_src=src, a_dst=dst, a_ilabel=il,
                     a_olabel=ol, a_graph=gr, a_acoustic=ac)
+
+    def determinized_lattice(self, channel, use_final_probs=True):
+        """GetLattice (GetRawLattice + DeterminizeLatticeWrapper) of a channel: dict of numpy arrays, or None."""
+        ns, na = C.c_int32(0), C.c_int32(0)
+        rc = lib().wfst_decoder_get_determinized_lattice(self.h, int(channel), int(bool(use_final_probs)), 0, 0, C.byref(ns),
+                                                         C.byref(na), *([None] * 7))
+        if rc != WFST_OK and not (rc == -4 and ns.value > 0):
+            _check(rc)
+        if ns.value == 0:
+            return None
+        S, A = ns.value, na.value
+        fin = np.zeros(S, np.int32)
+        src, dst, il, ol = (np.zeros(A, np.int32) for _ in range(4))
+        gr, ac = np.zeros(A, np.float32), np.zeros(A, np.float32)
+        _check(lib().wfst_decoder_get_determinized_lattice(self.h, int(channel), int(bool(use_final_probs)), S, A, C.byref(ns),
+                                                           C.byref(na), _i32(fin), _i32(src), _i32(dst), _i32(il), _i32(ol),
+                                                           _f32(gr), _f32(ac)))
+        return dict(n_states=S, st_final=fin, a_src=src, a_dst=dst, a_ilabel=il, a_olabel=ol, a_graph=gr, a_acoustic=ac)
 
     def raw_lattices(self, channels=None, use_final_probs=True, threads=0):
         """GetRawLattice of many finalized channels.  The first call fetches the pruned lattices of all

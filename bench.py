@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--lattice-links", type=int, default=0, help="> 0: lattice mode (BASELINE configs[4]): record forward links "
                     "(capacity per utterance), prune by lattice_beam at finalize; the step then also takes the n-best")
     ap.add_argument("--lattice-beam", type=float, default=7.0)
+    ap.add_argument("--determinize", action="store_true", help="lattice mode: the step also builds every utterance's DETERMINIZED lattice "
+                    "on the device (GetLattice, base-inl.h:850-866) and fetches it")
     ap.add_argument("--nbest", type=int, default=5, help="n of the n-best taken per utterance in lattice mode")
     ap.add_argument("--debug", type=int, default=0, help="wfst_options.debug (kernel phase timers 32 closure / 64 insert / 128 expand: "
                     "timing experiments only, printed on stderr when the decoder is freed)")
@@ -409,6 +411,9 @@ def main():
                 nb = dec.nbest(a.nbest)
                 for r, paths in zip(res, nb):
                     r["nbest"] = paths
+                if a.determinize:
+                    for c, r in enumerate(res):
+                        r["det"] = dec.determinized_lattice(c)
             t5 = time.perf_counter()
             for k, v in zip(("init", "advance_enqueue", "finalize", "sync", "best_paths"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 tb[k] += v
@@ -468,7 +473,7 @@ def main():
                    "frames/sec decoded (RTFx = value/100) at fixed beam; " + regime
                    if a.lattice_links == 0 else
                    "frames/sec decoded WITH lattice generation (forward links, lattice-beam pruning at finalize, %d-best per "
-                   "utterance; BASELINE configs[4]); " % a.nbest + regime),
+                   "utterance%s; BASELINE configs[4]); " % (a.nbest, " + the determinized lattice of every utterance" if a.determinize else "") + regime),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded hclg-like graph + %s log-likelihoods, SURVEY.md 8(d))" % (
@@ -507,6 +512,11 @@ def main():
         toks = sum(s["tokens"] for s in gstats)
         out["config"]["mean_active_tokens_per_frame"] = toks / float(B * (T + 1))
         out["config"]["mean_expanded_tokens_per_frame"] = N / float(B * T)
+        if a.lattice_links > 0 and a.determinize:
+            dl = [r["det"] for r in res if r.get("det") is not None]
+            out["config"]["determinized_lattices"] = {
+                "utterances": len(dl), "mean_states": float(np.mean([d["n_states"] for d in dl])) if dl else 0.0,
+                "mean_arcs": float(np.mean([len(d["a_src"]) for d in dl])) if dl else 0.0}
         # ---- CPU baseline + live parity on a bounded sample ---------------------------------
         scale = 1.0
         cpus = affinity_cpus()

@@ -265,6 +265,22 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
                                  int32_t *st_state, float *st_cost, int32_t *a_src, int32_t *a_dst,
                                  int32_t *a_ilabel, int32_t *a_olabel, float *a_graph, float *a_acoustic);
 
+/* GetLattice(Lattice*, use_final_probs) (base-inl.h:850-866) = GetRawLattice + DeterminizeLatticeWrapper
+ * (newfst/lattice-determinize-api.cc:5-21: Invert, ArcSort, LatticeDeterminizer::Determinize in the (graph,
+ * acoustic) lattice semiring, OutputNoolabel, Invert): the word-level deterministic lattice, built on the
+ * device from the raw lattice resident there.  Lattice-mode decoders; finalized channels (the first call
+ * determinizes every finalized channel of the batch at once) or mid-utterance.  State 0 is the start; arcs
+ * carry ilabel 0 and olabel = word; a final weight is an <eps>:<eps> arc into a final state of its own
+ * (OutputNoolabel, lattice-determinize.h:307-377).  Arc for arc (as a multiset: labels and float costs bit for
+ * bit) what the reference's determinizer makes of the same raw lattice.  n_states == 0 with WFST_OK: no
+ * lattice (as wfst_decoder_get_raw_lattice).  WFST_E_CAPACITY: output larger than the given capacities (sizes
+ * returned), or the subset construction outgrew its workspace (the reference's unpruned determinizer has no
+ * bound either: DeterminizeLatticeOptions::_max_mem). */
+int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs,
+                                          int32_t cap_states, int32_t cap_arcs, int32_t *n_states, int32_t *n_arcs,
+                                          int32_t *st_final, int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel,
+                                          int32_t *a_olabel, float *a_graph, float *a_acoustic);
+
 /* The service's n-best (OnlineClgLatticeFastDecoder::GetNbest, kaldi-nnet3/kaldi-online-nnet3-my-
  * decoder.cc:50-105: GetRawLattice -> DeterminizeLatticeWrapper -> NShortestPath ->
  * ConvertNbestToVector, then LatticeToVector per path) of FINALIZED channels of a lattice-mode

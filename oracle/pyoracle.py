@@ -471,3 +471,52 @@ def biglm_decode(dec, graph_handle, cfg, lm1, lm2, loglikes, tid2pdf=None, chunk
         r.extra = dict(N=int(ex[0]), E=int(ex[1]), Z=int(ex[2]), tokens_created=int(ex[3]), links_created=int(ex[4]),
                        ties=int(ex[5]), quirk_hops=int(ex[6]), lm_pairs=int(ex[7] & ((1 << 40) - 1)), lm_oob=int(ex[7] >> 40), L=int(ex[8]))
     return r
+
+
+# ---- determinized lattices -----------------------------------------------------------
+def ref_determinize_lattice_file(ref, path, index, max_states=1 << 20, max_arcs=1 << 21):
+    """The reference's DeterminizeLatticeWrapper (newfst/lattice-determinize-api.cc:5-21) on lattice `index`
+    of a file in its on-disk lattice format: RawLattice of the result (arcs: ilabel 0, olabel word), or None."""
+    ns, na, st = C.c_int(0), C.c_int(0), C.c_int(0)
+    fin = np.zeros(max_states, np.int32)
+    src, dst, il, ol = (np.zeros(max_arcs, np.int32) for _ in range(4))
+    gr, ac = np.zeros(max_arcs, np.float32), np.zeros(max_arcs, np.float32)
+    f = ref.lib.ref_determinize_lattice_file
+    f.restype = C.c_int
+    ok = f(path.encode(), int(index), max_states, C.byref(ns), C.byref(st), _ip(fin), max_arcs, C.byref(na), _ip(src), _ip(dst),
+           _ip(il), _ip(ol), _fp(gr), _fp(ac))
+    if not ok:
+        return None
+    S, A = ns.value, na.value
+    return RawLattice(True, S, st.value, fin[:S].copy(), src[:A].copy(), dst[:A].copy(), il[:A].copy(), ol[:A].copy(),
+                      gr[:A].copy(), ac[:A].copy())
+
+
+DET_HOST_SO = os.path.join(HERE, "_build", "libdet_host.so")
+
+
+def build_det_host():
+    """tests/det_host.cc: asr-decoder_amd/csrc/wfst_determinize.h (the algorithm the device runs) compiled for the host."""
+    src = os.path.join(os.path.dirname(HERE), "tests", "det_host.cc")
+    hdr = os.path.join(os.path.dirname(HERE), "asr-decoder_amd", "csrc", "wfst_determinize.h")
+    if (not os.path.exists(DET_HOST_SO)) or os.path.getmtime(DET_HOST_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        os.makedirs(os.path.dirname(DET_HOST_SO), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-o", DET_HOST_SO, src])
+    return C.CDLL(DET_HOST_SO)
+
+
+def det_host_run(lib, L, cap_scale=4, max_states=1 << 20, max_arcs=1 << 21):
+    """The device's determinization code, run on the host, on the raw lattice L (RawLattice): (status, RawLattice)."""
+    ns, na = C.c_int(0), C.c_int(0)
+    fin = np.zeros(max_states, np.int32)
+    src, dst, il, ol = (np.zeros(max_arcs, np.int32) for _ in range(4))
+    gr, ac = np.zeros(max_arcs, np.float32), np.zeros(max_arcs, np.float32)
+    f = lib.det_host_run
+    f.restype = C.c_int
+    c = lambda a, t: np.ascontiguousarray(a, t)
+    rc = f(int(L.n_states), _ip(c(L.st_final, np.int32)), int(len(L.a_src)), _ip(c(L.a_src, np.int32)), _ip(c(L.a_dst, np.int32)),
+           _ip(c(L.a_il, np.int32)), _ip(c(L.a_ol, np.int32)), _fp(c(L.a_graph, np.float32)), _fp(c(L.a_ac, np.float32)),
+           int(cap_scale), max_states, C.byref(ns), _ip(fin), max_arcs, C.byref(na), _ip(src), _ip(dst), _ip(il), _ip(ol), _fp(gr), _fp(ac))
+    S, A = ns.value, na.value
+    return rc, RawLattice(rc == 0, S, 0, fin[:S].copy(), src[:A].copy(), dst[:A].copy(), il[:A].copy(), ol[:A].copy(),
+                          gr[:A].copy(), ac[:A].copy())

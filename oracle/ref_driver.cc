@@ -451,6 +451,49 @@ int ref_nbest_from_lattice_file(const char *path, int index, int n, int max_len,
 }
 
 
+// The reference's determinized lattice: lattice number `index` of `path` through Lattice::Read,
+// LatticeCheckFormat and DeterminizeLatticeWrapper (newfst/lattice-determinize-api.cc:5-21: Invert,
+// ArcSort, LatticeDeterminizer::Determinize, OutputNoolabel, Invert), dumped like ref_raw_lattice.
+// Returns 1 on success; counts are written even when they exceed the caps.
+int ref_determinize_lattice_file(const char *path, int index, int max_states, int *n_states, int *start,
+                                 int *st_final, int max_arcs, int *n_arcs, int *a_src, int *a_dst, int *a_il,
+                                 int *a_ol, float *a_graph, float *a_ac) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return 0;
+  Lattice lat;
+  bool ok = true;
+  for (int i = 0; i <= index && ok; ++i) ok = lat.Read(fp);
+  fclose(fp);
+  if (!ok || !LatticeCheckFormat(&lat)) return 0;
+  Lattice det;
+  DeterminizeLatticeOptions opts;
+  bool debug = false;
+  if (!DeterminizeLatticeWrapper(&lat, &det, opts, &debug)) return 0;
+  const int S = det.NumStates();
+  *n_states = S;
+  *start = det.Start();
+  int na = 0;
+  for (int s = 0; s < S; ++s) {
+    LatticeState *st = det.GetState(s);
+    if (s < max_states) st_final[s] = st->IsFinal() ? 1 : 0;
+    const int k = (int)st->GetArcSize();
+    for (int i = 0; i < k; ++i) {
+      LatticeArc *a = st->GetArc(i);
+      if (na < max_arcs) {
+        a_src[na] = s;
+        a_dst[na] = a->_to;
+        a_il[na] = a->_input;
+        a_ol[na] = a->_output;
+        a_graph[na] = a->_w.Value1();
+        a_ac[na] = a->_w.Value2();
+      }
+      ++na;
+    }
+  }
+  *n_arcs = na;
+  return 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // biglm (BASELINE configs[3]): the reference's LM automaton and its on-the-fly rescoring decoder.
 // ---------------------------------------------------------------------------------------------

@@ -154,6 +154,29 @@ def lattice_goldens(ref):
     np.savez_compressed(os.path.join(OUT, "nbest_hclg600.npz"), **nb)
     print("wrote nbest_hclg600.npz")
 
+    # determinized lattices (DeterminizeLatticeWrapper, newfst/lattice-determinize-api.cc:5-21) of the reference's own
+    # raw lattices: the raw lattice as the reference wrote it (Lattice::Write bytes) and, of the result, the state /
+    # final-state / arc counts and the sorted multiset (ilabel, olabel, graph bits, acoustic bits)
+    gb, path = graph_bytes(g)
+    h = ref.load_graph(path)
+    dg = {"cfgs": np.array([0, 1, 2], np.int32)}
+    for ci in (0, 1, 2):
+        for ui, ll in enumerate(utts):
+            tmpf = "/tmp/_golden_det.lat"
+            if os.path.exists(tmpf):
+                os.remove(tmpf)
+            assert pyoracle.ref_lattice_write(ref, h, pyoracle.Config(**cfgs[ci]), ll, tmpf, m)
+            D = pyoracle.ref_determinize_lattice_file(ref, tmpf, 0)
+            assert D is not None
+            key = "c%d_u%d_" % (ci, ui)
+            with open(tmpf, "rb") as f:
+                dg[key + "raw"] = np.frombuffer(f.read(), np.uint8).copy()
+            dg[key + "counts"] = np.array([D.n_states, int(D.st_final.sum()), len(D.a_src)], np.int32)
+            dg[key + "arcs"] = D.arc_multiset().astype(np.int32)
+    ref.free_graph(h)
+    np.savez_compressed(os.path.join(OUT, "det_hclg600.npz"), **dg)
+    print("wrote det_hclg600.npz")
+
     # on-disk lattice format: three lattices appended to one file by the reference's own
     # Lattice::Write(std::string&) (newfst/lattice-fst.h:327-342); the file's bytes are the vector
     tmp = "/tmp/_golden_lattices.bin"

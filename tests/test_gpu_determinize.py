@@ -1,0 +1,139 @@
+"""-m gpu: the determinized lattice on the device (BASELINE configs[4]) --
+wfst_decoder_get_determinized_lattice = the reference's GetLattice (base-inl.h:850-866: GetRawLattice +
+DeterminizeLatticeWrapper) -- through the C ABI.  Checked arc for arc (multiset of labels and float costs, bit
+for bit; state and final-state counts) against
+  * the reference's own determinizer run on the raw lattice the device returned (oracle/_ref, where built),
+  * the same algorithm compiled for the host (tests/det_host.cc), always,
+  * the reference-generated goldens, where the device's raw lattice IS the reference's (beam-only cases)."""
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle
+from golden_util import GOLDEN_DIR, Golden
+
+pytestmark = pytest.mark.gpu
+
+
+def as_det(d):
+    return pyoracle.RawLattice(True, d["n_states"], 0, d["st_final"], d["a_src"], d["a_dst"], d["a_ilabel"], d["a_olabel"],
+                               d["a_graph"], d["a_acoustic"])
+
+
+def _check_against(G, dec, c, raw, lib, ref, tmp_path, what, ref_must_accept=True):
+    from test_gpu_lattice import as_raw
+
+    d = dec.determinized_lattice(c)
+    assert (d is not None) == (raw is not None), what
+    if d is None:
+        return None
+    D = as_det(d)
+    L = as_raw(raw)
+    rc, H = pyoracle.det_host_run(lib, L, cap_scale=32)
+    assert rc == 0, what
+    assert [D.n_states, int(D.st_final.sum())] == [H.n_states, int(H.st_final.sum())] and np.array_equal(D.arc_multiset(), H.arc_multiset()), what + " vs host build"
+    if ref is not None:
+        p = str(tmp_path / "raw.lat")
+        with open(p, "wb") as f:
+            f.write(G.pkg.shard.lattice_to_bytes(raw))
+        R = pyoracle.ref_determinize_lattice_file(ref, p, 0)
+        if R is None and not ref_must_accept:
+            return D   # dead ends in the unpruned frames of a mid-utterance raw lattice fail the reference's LatticeCheckFormat
+        assert R is not None, what
+        assert [D.n_states, int(D.st_final.sum())] == [R.n_states, int(R.st_final.sum())], what + " vs reference (counts)"
+        assert np.array_equal(D.arc_multiset(), R.arc_multiset()), what + " vs reference (arcs)"
+    # deterministic on words: no two arcs of a state with the same word; start state 0; arcs carry ilabel 0
+    k = np.stack([D.a_src, D.a_ol], axis=1)[D.a_ol != 0]
+    assert len(np.unique(k, axis=0)) == len(k), what + " not deterministic"
+    assert np.all(D.a_il == 0), what
+    return D
+
+
+def _ref_or_none():
+    return pyoracle.RefDecoder() if os.path.exists(pyoracle.REF_SO) else None
+
+
+def test_golden_utterances(tmp_path):
+    import gpu_util as G
+
+    lib = pyoracle.build_det_host()
+    ref = _ref_or_none()
+    g = Golden("lattice_hclg600")
+    z = np.load(os.path.join(GOLDEN_DIR, "det_hclg600.npz"))
+    graph = G.wfstdec.Graph.load(g.write_graph(str(tmp_path / "g.bin")))
+    graph.set_tid2pdf(g.tid2pdf)
+    lim = dict(max_frames=64, max_tokens_per_frame=16384, arena_tokens=1 << 19, lattice_links=1 << 20)
+    n = n_gold = 0
+    for ci in (0, 1, 2):
+        cd = dict(g.meta["cfgs"][ci])
+        dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(g.utts), **lim)
+        dev = G.upload(g.utts)
+        dec.init()
+        T = [int(x.shape[0]) for x in g.utts]
+        if cd.get("prune_interval", 25) == 10:
+            # mid-utterance request (the service's partial n-best goes through GetLattice too), one frame after a pruning pass
+            dec.advance([t.data_ptr() for t in dev], [min(31, t) for t in T], int(g.utts[0].shape[1]))
+            _check_against(G, dec, 0, dec.raw_lattice(0), lib, ref, tmp_path, "cfg %d mid-utterance" % ci, ref_must_accept=False)
+        dec.advance([t.data_ptr() for t in dev], T, int(g.utts[0].shape[1]))
+        dec.finalize()
+        for ui in range(len(g.utts)):
+            raw = dec.raw_lattice(ui)
+            D = _check_against(G, dec, ui, raw, lib, ref, tmp_path, "cfg %d utt %d" % (ci, ui))
+            key = "c%d_u%d_" % (ci, ui)
+            (Lref,) = pyoracle.parse_lattice_file(bytes(z[key + "raw"]))
+            if D is not None and len(raw["a_src"]) == len(Lref.a_src) and cd["max_active"] >= 1000:
+                # the device's raw lattice is the reference's own (no order-dependent extras in it): so is the determinized one
+                assert [D.n_states, int(D.st_final.sum()), len(D.a_src)] == list(z[key + "counts"]), key
+                assert np.array_equal(D.arc_multiset(), z[key + "arcs"]), key
+                n_gold += 1
+            n += 1
+        dec.free()
+    graph.free()
+    assert n == 9 and n_gold >= 4
+
+
+def test_mid_size_batch_and_refusals(synth, tmp_path):
+    import gpu_util as G
+
+    lib = pyoracle.build_det_host()
+    ref = _ref_or_none()
+    g = synth.make_hclg_like(20000, seed=7, n_tid=2000, n_words=3000)
+    m = synth.default_tid2pdf(2000)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=5.0)
+    mats = [synth.make_loglikes(g, T, 1000, m, seed=60 + i, mu=-2.4)[0] for i, T in enumerate([120, 80, 120, 9, 120, 55])]
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), max_frames=128, max_tokens_per_frame=32768, arena_tokens=1 << 20,
+                                 lattice_links=1 << 21)
+    dev = G.upload(mats)
+    dec.init()
+    dec.advance([t.data_ptr() for t in dev], [int(x.shape[0]) for x in mats], 1000)
+    dec.finalize()
+    best = dec.best_paths()
+    for c in range(len(mats)):
+        D = _check_against(G, dec, c, dec.raw_lattice(c), lib, ref, tmp_path, "channel %d" % c)
+        # the best path of the determinized lattice is the decoder's best path: cheapest word sequence, same cost
+        S = D.n_states
+        dist = np.full(S, np.inf)
+        dist[0] = 0.0
+        order = np.argsort(D.a_src, kind="stable")
+        for _ in range(S):   # Bellman-Ford (the numbering need not be topological)
+            nd = dist.copy()
+            np.minimum.at(nd, D.a_dst[order], dist[D.a_src[order]] + (D.a_graph[order].astype(np.float64) + D.a_ac[order]))
+            if np.array_equal(nd, dist):
+                break
+            dist = nd
+        sp = dist[D.st_final == 1].min()
+        assert abs(sp - best[c]["tot_score"]) <= 1e-3 * abs(sp), c
+    assert dec.determinized_lattice(0, use_final_probs=False) is None   # finalized && !use_final_probs
+    dec.free()
+    # not in lattice mode: refused
+    d2 = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 1, max_frames=128, max_tokens_per_frame=32768, arena_tokens=1 << 20)
+    d2.init()
+    with pytest.raises(G.wfstdec.WfstError):
+        d2.determinized_lattice(0)
+    d2.free()
+    graph.free()

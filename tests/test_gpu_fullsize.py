@@ -152,14 +152,34 @@ def test_batch128_lattice_mode_properties(big, oracle):
 def test_config5_beam15_lattice_and_nbest_sample(big, oracle, refdec, tmp_path):
     """BASELINE configs[4] (lattice-generating decode, beam = 15) on the 10M-arc graph: 16 utterances
     in lattice mode; two of them state by state against the oracle, their 5-best against the
-    reference's determinizer + NShortestPath run on the lattice the device returned."""
+    reference's determinizer + NShortestPath run on the lattice the device returned; the determinized
+    lattices (GetLattice, built on the device) of all 16 arc for arc against the reference's
+    DeterminizeLatticeWrapper run on the raw lattice the device returned."""
+    from test_gpu_determinize import as_det
     from test_gpu_lattice import _same_nbest, as_raw, gpu_lattices, nodes
 
     G = big["G"]
     cd = dict(CD, beam=15.0, lattice_beam=8.0)
     lim = dict(max_frames=304, max_tokens_per_frame=262144, arena_tokens=300 * 60000, lattice_links=24 << 20)
     mats = big["mats"][:16]
-    lats, best, nbest = gpu_lattices(G, big["graph"], cd, mats, limits=lim, nbest=5)
+    dets = []
+    lats, best, nbest = gpu_lattices(G, big["graph"], cd, mats, limits=lim, nbest=5, det_out=dets)
+    det_seconds = dets.pop()
+    lib = pyoracle.build_det_host()
+    for u in range(16):
+        D, L = as_det(dets[u]), as_raw(lats[u])
+        rc, H = pyoracle.det_host_run(lib, L, cap_scale=32)
+        assert rc == 0 and [D.n_states, int(D.st_final.sum())] == [H.n_states, int(H.st_final.sum())], u
+        assert np.array_equal(D.arc_multiset(), H.arc_multiset()), u
+        p = str(tmp_path / "c5_raw.lat")
+        with open(p, "wb") as f:
+            f.write(G.pkg.shard.lattice_to_bytes(lats[u]))
+        R = pyoracle.ref_determinize_lattice_file(refdec, p, 0)
+        assert R is not None and [D.n_states, int(D.st_final.sum())] == [R.n_states, int(R.st_final.sum())], u
+        assert np.array_equal(D.arc_multiset(), R.arc_multiset()), u
+        assert D.n_states < L.n_states   # that is what it is for
+    print("determinized 16 beam-15 lattices on the device in %.3f s (raw states %s -> %s)" % (
+        det_seconds, [int(as_raw(x).n_states) for x in lats[:4]], [int(d["n_states"]) for d in dets[:4]]))
     h = oracle.load_graph(big["path"])
     try:
         for u in (3, 12):

@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 LIM = dict(max_frames=512, max_tokens_per_frame=32768, arena_tokens=1 << 21, lattice_links=1 << 22)
 
 
-def gpu_lattices(G, graph, cd, mats, use_final_probs=True, limits=LIM, nbest=0):
+def gpu_lattices(G, graph, cd, mats, use_final_probs=True, limits=LIM, nbest=0, det_out=None):
+    """det_out: a list that receives the determinized lattices (GetLattice) and, last, the seconds they took"""
     dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), **limits)
     dev = G.upload(mats)
     dec.init()
@@ -30,6 +31,12 @@ def gpu_lattices(G, graph, cd, mats, use_final_probs=True, limits=LIM, nbest=0):
     lats = [dec.raw_lattice(c, use_final_probs) for c in range(len(mats))]
     best = dec.best_paths(use_final_probs=True)
     nb = dec.nbest(nbest) if nbest else None
+    if det_out is not None:
+        import time
+
+        t0 = time.time()
+        det_out.extend(dec.determinized_lattice(c, use_final_probs) for c in range(len(mats)))
+        det_out.append(time.time() - t0)
     dec.free()
     return (lats, best, nb) if nbest else (lats, best)
 
