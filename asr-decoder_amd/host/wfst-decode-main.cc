@@ -3,7 +3,7 @@
 // (graph + decoder config + per-utterance matrices -> word ids, scores, real-time factor), with
 // plain files instead of Kaldi tables:
 //
-//   wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--lattice-out=FILE [--lattice-links=N]]
+//   wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--lattice-out=FILE [--lattice-links=N] [--determinize]]
 //               [--lm-old=FILE --lm-new=FILE]
 //   --lm-old/--lm-new  biglm (kaldi-hclg-my-decoder-biglm.cc): rescore on the fly with new LM - old LM; the files
 //                  are the reference's binary LMs (arpa2fsa-bin); the old one is rescaled by -1 as the reference CLI does
@@ -12,6 +12,8 @@
 //                  reference's on-disk lattice format (Lattice::Write, newfst/lattice-fst.cc:38-64;
 //                  lattice mode: N forward links kept per utterance).  An utterance without a
 //                  lattice is written as an empty one (0 states, start -1).
+//   --determinize  the lattices written are GetLattice's (determinized on the device, base-inl.h:850-866) instead of
+//                  GetRawLattice's
 //   --inflight=K   batch shape only: K batches in flight, each on its own GpuBatchDecoder (own HIP
 //                  stream) driven by its own host thread -- the reference service's model of one
 //                  decoder object per thread (v2-asrbin/v2-asr-service.cc:95-105); the GPU overlaps
@@ -79,7 +81,7 @@ int main(int argc, char **argv) {
   try {
     std::string tid2pdf_file, lm_old_file, lm_new_file;
     int batch = 128;
-    bool single = false;
+    bool single = false, determinize = false;
     std::string lattice_file, lattice_text;
     long long lattice_links = 1ll << 22;
     int nbest = 0, inflight = 1;
@@ -89,6 +91,7 @@ int main(int argc, char **argv) {
       if (a.compare(0, 10, "--tid2pdf=") == 0) tid2pdf_file = a.substr(10);
       else if (a.compare(0, 8, "--batch=") == 0) batch = atoi(a.c_str() + 8);
       else if (a == "--single-stream") single = true;
+      else if (a == "--determinize") determinize = true;
       else if (a.compare(0, 14, "--lattice-out=") == 0) lattice_file = a.substr(14);
       else if (a.compare(0, 15, "--lattice-text=") == 0) lattice_text = a.substr(15);
       else if (a.compare(0, 16, "--lattice-links=") == 0) lattice_links = atoll(a.c_str() + 16);
@@ -99,7 +102,7 @@ int main(int argc, char **argv) {
       else pos.push_back(a);
     }
     if (pos.size() < 3) {
-      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--inflight=K] [--nbest=N] [--lattice-out=FILE] "
+      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--inflight=K] [--nbest=N] [--lattice-out=FILE] [--determinize] "
                    "[--lattice-text=FILE] [--lattice-links=N] [--lm-old=FILE --lm-new=FILE] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
       return 1;
     }
@@ -203,7 +206,7 @@ int main(int argc, char **argv) {
         emit(u, best, ok);
         if (want_lattice) {
           Lattice lat;
-          bool lok = decode.GetRawLattice(&lat);
+          bool lok = determinize ? decode.GetLattice(&lat) : decode.GetRawLattice(&lat);
           emit_lattice(u, lat, lok);
         }
         if (nbest > 0) {
@@ -246,7 +249,13 @@ int main(int argc, char **argv) {
             decode.AdvanceDecodingHost(ch, rows, ready, stride);
             decode.FinalizeDecoding(ch);
             decode.GetBestPaths(ch, &o.best, &o.ok);
-            if (want_lattice) decode.GetRawLattices(ch, &o.lats, &o.lat_ok);
+            if (want_lattice && determinize) {
+              o.lats.assign(n, Lattice());
+              o.lat_ok.assign(n, false);
+              for (int i = 0; i < n; ++i) o.lat_ok[i] = decode.GetLattice(i, &o.lats[i]);
+            } else if (want_lattice) {
+              decode.GetRawLattices(ch, &o.lats, &o.lat_ok);
+            }
             if (nbest > 0) {
               o.nbest.resize(n);
               for (int i = 0; i < n; ++i) decode.GetNbest(i, o.nbest[i], nbest);

@@ -349,6 +349,29 @@ static bool RawLatticeOfChannel(wfst_decoder *dec, int channel, Lattice *ofst, b
   return ofst->NumStates() > 0;
 }
 
+// GetLattice (base-inl.h:850-866) of one channel: the determinized lattice, built on the device.
+static bool DetLatticeOfChannel(wfst_decoder *dec, int channel, Lattice *ofst, bool use_final_probs) {
+  ofst->DeleteStates();
+  int32_t ns = 0, na = 0;
+  int rc = wfst_decoder_get_determinized_lattice(dec, channel, use_final_probs ? 1 : 0, 0, 0, &ns, &na, nullptr, nullptr, nullptr,
+                                                 nullptr, nullptr, nullptr, nullptr);
+  if (rc == WFST_E_STATE) { Warn(wfst_last_error()); return false; }
+  if (rc != WFST_OK && !(rc == WFST_E_CAPACITY && ns > 0)) Fatal("GetLattice");
+  if (ns == 0) return false;
+  std::vector<int32_t> fin(ns), src(na), dst(na), il(na), ol(na);
+  std::vector<float> g(na), ac(na);
+  if (wfst_decoder_get_determinized_lattice(dec, channel, use_final_probs ? 1 : 0, ns, na, &ns, &na, fin.data(), src.data(), dst.data(),
+                                            il.data(), ol.data(), g.data(), ac.data()) != WFST_OK)
+    Fatal("GetLattice");
+  for (int s = 0; s < ns; ++s) {
+    StateId id = ofst->AddState();
+    if (fin[s]) ofst->SetFinal(id);
+  }
+  ofst->SetStart(0);
+  for (int k = 0; k < na; ++k) ofst->AddArc(src[k], LatticeArc(il[k], ol[k], dst[k], LatticeWeight(g[k], ac[k])));
+  return true;
+}
+
 static bool NbestOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> &out, int n) {
   out.clear();
   if (n <= 0) return false;
@@ -379,6 +402,8 @@ static bool NbestOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> 
 }
 
 bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n) { return NbestOfChannel(_dec, 0, nbest_paths, n); }
+
+bool GpuLatticeDecoder::GetLattice(Lattice *ofst, bool use_final_probs) { return DetLatticeOfChannel(_dec, 0, ofst, use_final_probs); }
 
 bool GpuLatticeDecoder::GetRawLattice(Lattice *ofst, bool use_final_probs) {
   return RawLatticeOfChannel(_dec, 0, ofst, use_final_probs);
@@ -417,6 +442,9 @@ void GpuBatchDecoder::GetRawLattices(const std::vector<int> &channels, std::vect
 }
 bool GpuBatchDecoder::GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n) {
   return NbestOfChannel(_dec, channel, nbest_paths, n);
+}
+bool GpuBatchDecoder::GetLattice(int channel, Lattice *ofst, bool use_final_probs) {
+  return DetLatticeOfChannel(_dec, channel, ofst, use_final_probs);
 }
 bool GpuBatchDecoder::GetRawLattice(int channel, Lattice *ofst, bool use_final_probs) {
   return RawLatticeOfChannel(_dec, channel, ofst, use_final_probs);

@@ -230,6 +230,9 @@ class GpuLatticeDecoder : public DecoderItf {
   bool GetBestPath(Lattice *ofst, bool use_final_probs = true) override;
   // after FinalizeDecoding, decoder created with wfst_limits.lattice_links > 0 (else: warning + false)
   bool GetRawLattice(Lattice *ofst, bool use_final_probs = true) override;
+  // GetLattice (online-decoder-base.h:182, base-inl.h:850-866): GetRawLattice + DeterminizeLatticeWrapper, both on
+  // the device; arcs carry ilabel 0 / olabel = word, final states have no arcs (the reference's output convention)
+  bool GetLattice(Lattice *ofst, bool use_final_probs = true);
   // OnlineClgLatticeFastDecoder::GetNbest (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105):
   // the n (<= 16) cheapest distinct word sequences of the pruned lattice, each as a linear Lattice
   // whose arcs carry the words as olabels (ilabel 0, like the reference's determinized output) and
@@ -267,6 +270,8 @@ class GpuBatchDecoder {
   void GetRawLattices(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
                       bool use_final_probs = true, int threads = 0);
   bool GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n);
+  // GetLattice of one channel; the first call after FinalizeDecoding determinizes every finalized channel in one launch
+  bool GetLattice(int channel, Lattice *ofst, bool use_final_probs = true);
   void GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
                     bool use_final_probs = true);
   wfst_decoder *Handle() { return _dec; }

@@ -146,6 +146,37 @@ def test_cli_nbest_matches_the_reference_pipeline(synth, refdec, tmp_path):
 
 
 @pytest.mark.parametrize("mode", ["batch", "single"])
+def test_cli_determinized_lattices_match_the_reference_pipeline(mode, synth, refdec, tmp_path):
+    """--lattice-out --determinize = GetLattice (base-inl.h:850-866) through the host mirrors: the determinized lattices
+    the CLI writes equal the reference's DeterminizeLatticeWrapper run on the raw lattices it writes without the flag."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    g = synth.make_hclg_like(3000, seed=12, n_tid=300, n_words=200)
+    m = synth.default_tid2pdf(300)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=11\n--lattice-beam=4\n--max-active=1000000\n--min-active=0\n")
+    mats = [synth.make_loglikes(g, T, 150, m, seed=90 + i, mu=-2.2)[0] for i, T in enumerate([40, 33, 47])]
+    with open(tmp_path / "ll.bin", "wb") as f:
+        for i, x in enumerate(mats):
+            key = ("utt%03d" % i).encode()
+            f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
+    raw, det = str(tmp_path / "raw.bin"), str(tmp_path / "det.bin")
+    for out, extra in ((raw, []), (det, ["--determinize"])):
+        p = subprocess.run([CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--batch=2", "--lattice-out=" + out] + extra +
+                           (["--single-stream"] if mode == "single" else []) +
+                           [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+    with open(det, "rb") as f:
+        dets = pyoracle.parse_lattice_file(f.read())
+    assert len(dets) == len(mats)
+    for u, D in enumerate(dets):
+        R = pyoracle.ref_determinize_lattice_file(refdec, raw, u)
+        assert R is not None and [D.n_states, int(D.st_final.sum())] == [R.n_states, int(R.st_final.sum())], u
+        assert np.array_equal(D.arc_multiset(), R.arc_multiset()), u
+
+
+@pytest.mark.parametrize("mode", ["batch", "single"])
 def test_cli_biglm_matches_the_fixed_mode_oracle(mode, synth, oracle, tmp_path):
     """The host mirror's biglm shape -- `ArpaLm lm1, lm2; lm1.Read(..); lm2.Read(..); lm1.Rescale(-1.0);
     OnlineLatticeDecoderMempoolBiglm decode(&fst, opt, &lm1, &lm2);`, the reference CLI's own lines
