@@ -247,7 +247,7 @@ void wfst_config_default(wfst_config *c) {  // lattice-faster-decoder-conf.h:35-
 }
 
 void wfst_options_default(wfst_options *o) {
-  o->channel_groups = 1;
+  o->channel_groups = 0;
   o->use_hip_graph = 1;
   o->log2_partitions = 5;  // 32 partitions: measured best at batch 128 (16: insert slower, 64: more bucket atomics)
   o->log2_lds_slots = 12;
@@ -259,7 +259,7 @@ void wfst_options_default(wfst_options *o) {
 }
 
 void wfst_graph_options_default(wfst_graph_options *o) {
-  o->row_align_slots = 4;
+  o->row_align_slots = 8;
   o->flatten_closures = 1;
   o->fuse_closures = 1;
 }
@@ -334,9 +334,11 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
   HIP_TRY(hipSetDevice(device));
   if ((int64_t)n_arcs + n_states >= (int64_t)kNoArc)
     return fail(WFST_E_FORMAT, "graphs with states + arcs >= 2^29 are not supported");
-  // A row (header + arcs, 16-byte slots) that fits in k 64-byte lines is placed so that it touches
-  // only k lines: expanding a token is a random gather, priced per LINE, and an unaligned 3-arc row
-  // straddles two.  Costs ~10 % padding slots.  row_align_slots = 1 packs the rows tightly.
+  // A row (header + arcs, 16-byte slots) that fits in k lines is placed so that it touches only k lines:
+  // expanding a token is a random gather, priced per LINE -- 128 bytes on MI355X, whatever part of it is
+  // used (tools/ubench_gather_granularity.hip: 16-, 32-, 64- and 128-byte aligned random reads all run at
+  // the same ~50 G reads/s; a 128-byte read straddling two lines at 2/3 of that) -- and an unaligned 3-arc
+  // row straddles two.  Costs ~15 % padding slots.  row_align_slots = 1 packs the rows tightly.
   const int64_t line_slots = GO.row_align_slots;
 
   // pass 0: validate, arc offsets, epsilon targets
@@ -788,7 +790,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   wfst_options O;
   wfst_options_default(&O);
   if (options) O = *options;
-  if (O.channel_groups < 1 || O.channel_groups > 8 || O.log2_partitions < 0 || O.log2_partitions > 6 ||
+  if (O.channel_groups < 0 || O.channel_groups > 8 || O.log2_partitions < 0 || O.log2_partitions > 6 ||
       O.log2_lds_slots < 8 || O.log2_lds_slots > 13 || O.joint_max < 1 || O.expand_workgroups < 1 ||
       O.insert_workgroups < 1 || O.upload_slice_frames < 0)
     return fail(WFST_E_ARG, "wfst_options field out of range");
@@ -981,7 +983,10 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   d->hist_rows.assign(B, 0);
   d->use_graph = O.use_hip_graph != 0;
   d->upload_slice = O.upload_slice_frames;
-  d->n_groups = std::min(O.channel_groups, n_channels);
+  // automatic: two groups from 64 channels up -- one group's expansion overlaps the other's insert / closure step
+  // (measured on the bench workload: equal at 64 channels, +5 % at 128, +7 % at 256; three or more streams share
+  // hardware queues and lose)
+  d->n_groups = std::min(O.channel_groups > 0 ? O.channel_groups : (n_channels >= 64 ? 2 : 1), n_channels);
   if (d->n_groups > 1) {
     d->gstreams.resize(d->n_groups);
     d->gevents.resize(d->n_groups + 1);
@@ -1476,6 +1481,42 @@ int wfst_decoder_get_profile(wfst_decoder *d, double ms[3], int64_t launches[3])
     }
     ms[k] = tot;
     launches[k] = (int64_t)d->ev_pairs[k].size();
+  }
+  return WFST_OK;
+}
+
+int wfst_decoder_channel_groups(wfst_decoder *d) { return d ? d->n_groups : fail(WFST_E_ARG, "NULL decoder"); }
+
+int wfst_decoder_get_profile_busy(wfst_decoder *d, double busy_ms[3]) {
+  if (!d || !busy_ms) return fail(WFST_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(d->device));
+  for (hipStream_t st : d->gstreams) HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  // union of the launches' [start, stop] intervals of each kernel class: with several channel groups the launches
+  // of different groups run concurrently, so the sum of their durations counts shared time twice
+  int base = -1;
+  for (int k = 0; k < 3 && base < 0; ++k)
+    if (!d->ev_pairs[k].empty()) base = d->ev_pairs[k][0].first;
+  for (int k = 0; k < 3; ++k) {
+    std::vector<std::pair<float, float>> iv;
+    iv.reserve(d->ev_pairs[k].size());
+    for (auto &pr : d->ev_pairs[k]) {
+      float a = 0, b = 0;
+      HIP_TRY(hipEventElapsedTime(&a, d->ev_pool[base], d->ev_pool[pr.first]));
+      HIP_TRY(hipEventElapsedTime(&b, d->ev_pool[base], d->ev_pool[pr.second]));
+      iv.push_back({a, b});
+    }
+    std::sort(iv.begin(), iv.end());
+    double tot = 0;
+    float lo = 0, hi = 0;
+    bool open = false;
+    for (auto &x : iv) {
+      if (open && x.first <= hi) { hi = std::max(hi, x.second); continue; }
+      if (open) tot += hi - lo;
+      lo = x.first; hi = x.second; open = true;
+    }
+    if (open) tot += hi - lo;
+    busy_ms[k] = tot;
   }
   return WFST_OK;
 }

@@ -49,6 +49,17 @@ template <class T>
 __device__ __forceinline__ T ld_agent(const T *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Workgroup barrier for an LDS-only hand-off.  __syncthreads() carries a workgroup fence that hipcc lowers to
+// s_waitcnt vmcnt(0) lgkmcnt(0) before s_barrier: every global load, store and atomic of the wave is drained at each
+// barrier, so a phase's bucket stores or a prefetched arc load serialise with the next phase.  Where only LDS is handed
+// over, wait for the LDS operations alone and leave the global ones in flight (cdna_hip_programming.md section 5,
+// "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_min_f(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
@@ -274,11 +285,13 @@ __device__ void plan_channel(const DecoderDev &D, int c, int group, int par) {
 // expand_kernel: a fixed grid of 512-thread workgroups; workgroup w takes tile w of the frame's tile
 // list, further tiles by ticket.
 // =========================================================================================
-constexpr int kExpandThreads = 512;
+constexpr int kExpandThreads = 256;
 constexpr int kCandPerThread = 2;
 constexpr int kChunk = kExpandThreads * kCandPerThread;  // candidates per counting-sort round
 constexpr int kTokPerThread = 2;
 constexpr int kTileTokens = kExpandThreads * kTokPerThread;  // frontier tokens per tile
+constexpr int kLog2TileTokens = 9;
+static_assert(kTileTokens == 1 << kLog2TileTokens, "the owner search of expand_body takes exactly log2(kTileTokens) steps");
 
 // Work unit = one tile of kTileTokens frontier tokens of one channel.  prep_frame lists the tiles of
 // all active channels (TileDesc); workgroup w takes tile w, then further tiles from a ticket
@@ -403,37 +416,75 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       int rec_lm[kCandPerThread];
       float tot[kCandPerThread];
       float tmin = kInf;
+      // The candidates of a thread are taken through the stages TOGETHER -- owner search, arc load, second-slot
+      // and log-likelihood load, pricing -- so that their memory round trips overlap.  (Written as one loop per
+      // candidate the compiler keeps the candidates apart: search, arc, wait, log-likelihood, wait, then the
+      // next candidate, i.e. twice as many serial HBM latencies per round.)  A lane without a candidate runs the
+      // loads on slot 0 / column 0 and drops the result.
+      int jv[kCandPerThread], lo[kCandPerThread], av[kCandPerThread];
+      bool pseudo[kCandPerThread];
+      {
+        int hi[kCandPerThread];
+#pragma unroll
+        for (int k = 0; k < kCandPerThread; ++k) {
+          const int j = j0 + k * kExpandThreads + tid;
+          jv[k] = j < total ? j : -1;
+          lo[k] = 0; hi[k] = kTileTokens;  // s_base[lo] <= j < s_base[hi]
+        }
+#pragma unroll
+        for (int step = 0; step < kLog2TileTokens; ++step) {
+#pragma unroll
+          for (int k = 0; k < kCandPerThread; ++k) {
+            const int mid = (lo[k] + hi[k]) >> 1;
+            if (s_base[mid] <= max(jv[k], 0)) lo[k] = mid; else hi[k] = mid;
+          }
+        }
+      }
 #pragma unroll
       for (int k = 0; k < kCandPerThread; ++k) {
-        const int j = j0 + k * kExpandThreads + tid;
+        const int off = max(jv[k], 0) - s_base[lo[k]];
+        av[k] = s_arcbeg[lo[k]] + off;
+        pseudo[k] = false;
+        if constexpr (kFused) {
+          const int nem = s_nemit[lo[k]], pi = off - nem;
+          pseudo[k] = pi >= 0;
+          if (pseudo[k]) av[k] = s_arcbeg[lo[k]] + nem + 2 * pi;  // pseudo arcs take two slots each
+        }
+        if (jv[k] < 0) { av[k] = 0; pseudo[k] = false; }
+      }
+      int4 arcv[kCandPerThread], leafv[kFused ? kCandPerThread : 1];
+      int olv[kBig ? kCandPerThread : 1];
+      float llv[kCandPerThread];
+#pragma unroll
+      for (int k = 0; k < kCandPerThread; ++k) arcv[k] = D.g.arcs[av[k]];
+      // A pseudo arc's second slot {last arc | flags of the end state, weight of the last arc, hops, weight of the
+      // hop before the last}: loaded by every lane alike (an emitting arc's lane re-reads its own slot)
+      if constexpr (kFused) {
+#pragma unroll
+        for (int k = 0; k < kCandPerThread; ++k) leafv[k] = D.g.arcs[av[k] + (pseudo[k] ? 1 : 0)];
+      }
+      if constexpr (kBig) {
+#pragma unroll
+        for (int k = 0; k < kCandPerThread; ++k) olv[k] = D.g.arc_olabel[av[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < kCandPerThread; ++k) llv[k] = llrow[jv[k] >= 0 ? arcv[k].x : 0];
+#pragma unroll
+      for (int k = 0; k < kCandPerThread; ++k) {
         tot[k] = kInf;
-        if (j < total) {
-          int lo = 0, hi = kTileTokens;  // s_base[lo] <= j < s_base[hi]
-          while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (s_base[mid] <= j) lo = mid; else hi = mid;
-          }
-          int a = s_arcbeg[lo] + (j - s_base[lo]);
-          bool pseudo = false;
-          if constexpr (kFused) {
-            const int pi = (j - s_base[lo]) - s_nemit[lo];
-            pseudo = pi >= 0;
-            if (pseudo) a = s_arcbeg[lo] + s_nemit[lo] + 2 * pi;  // pseudo arcs take two slots each
-          }
-          const int4 arc = D.g.arcs[a];
+        rec_lm[k] = 0;
+        if (jv[k] >= 0) {
+          const int4 arc = arcv[k];
+          const int a = av[k];
           float graph_cost = __int_as_float(arc.z);
-          rec_lm[k] = 0;
           if constexpr (kFused) {
             // A pseudo arc is the emitting arc's arrival carried on over one path of the target's epsilon
             // closure -- ((cur + ac) + w) + w_1 + ... + w_k in path order (base-inl.h:329, 414) -- an
             // epsilon arrival at the path's end state.  It does not tighten next_cutoff (only emitting
-            // arcs do, base-inl.h:330-333 vs 415).  Its second slot {last arc | flags of the end state,
-            // weight of the last arc, hops} and the log-likelihood are loaded by every lane alike (an
-            // emitting arc's lane re-reads its own slot), so that the two kinds of lanes share one
-            // memory round trip instead of taking theirs one after the other.
-            const int4 leaf = D.g.arcs[a + (pseudo ? 1 : 0)];
-            const float base_cost = (s_cost[lo] + (-llrow[arc.x])) + graph_cost;
-            if (pseudo) {
+            // arcs do, base-inl.h:330-333 vs 415).
+            const int4 leaf = leafv[k];
+            const float base_cost = (s_cost[lo[k]] + (-llv[k])) + graph_cost;
+            if (pseudo[k]) {
               float t = base_cost;
               if (leaf.z == 1) {
                 t = t + __int_as_float(leaf.y);
@@ -460,25 +511,25 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
               nZf++;
             } else {
               tot[k] = base_cost;
-              rec[k] = make_int4(arc.w, __float_as_int(base_cost), tok0 + lo, (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
+              rec[k] = make_int4(arc.w, __float_as_int(base_cost), tok0 + lo[k], (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
               tmin = fminf(tmin, base_cost);
             }
             continue;
           }
           if constexpr (kBig) {  // biglm.h:377-388: graph_cost = arc weight + lm_score, next LM state into the key
-            const int ol = D.g.arc_olabel[a];
+            const int ol = olv[k];
             float lm_score = 0.0f;
-            rec_lm[k] = s_lm[lo];
+            rec_lm[k] = s_lm[lo[k]];
             if (ol != 0) {
               int n1, n2;
-              lm_score = lm_step(D, c, s_lm[lo], ol, &n1, &n2);
+              lm_score = lm_step(D, c, s_lm[lo[k]], ol, &n1, &n2);
               rec_lm[k] = pair_intern(D, c, ctl, n1, n2);
             }
             graph_cost = __int_as_float(arc.z) + lm_score;
           }
-          const float ac_cost = -llrow[arc.x];                         // base-inl.h:326
-          tot[k] = (s_cost[lo] + ac_cost) + graph_cost;                 // base-inl.h:329
-          rec[k] = make_int4(arc.w, __float_as_int(tot[k]), tok0 + lo, (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
+          const float ac_cost = -llv[k];                                  // base-inl.h:326
+          tot[k] = (s_cost[lo[k]] + ac_cost) + graph_cost;                // base-inl.h:329
+          rec[k] = make_int4(arc.w, __float_as_int(tot[k]), tok0 + lo[k], (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
           tmin = fminf(tmin, tot[k]);
         }
       }
@@ -501,7 +552,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
           rank[k] = atomicAdd(&s_cnt[part[k]], 1);
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (tid == 0) dbg_phase(D, 13, tq);
       if (tid < 64) {
         const int cnt = tid < P ? s_cnt[tid] : 0;
@@ -521,7 +572,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         s_gbase[tid] = g;
         s_cnt[tid] = 0;
       }
-      __syncthreads();
+      lds_barrier();
       if (tid == 0) dbg_phase(D, 14, tq);
 #pragma unroll
       for (int k = 0; k < kCandPerThread; ++k)
@@ -529,7 +580,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
           s_rec[s_lbase[part[k]] + rank[k]] = rec[k];
           if constexpr (kBig) s_rec_lm[s_lbase[part[k]] + rank[k]] = rec_lm[k];
         }
-      __syncthreads();
+      lds_barrier();
       const int npass = s_lbase[64];
       nR += (tid == 0) ? (u64)npass : 0;
       for (int q = tid; q < npass; q += kExpandThreads) {
@@ -541,7 +592,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
           if constexpr (kBig) bucket_lm[(size_t)p * bcap + gi] = s_rec_lm[q];
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (tid == 0) dbg_phase(D, 15, tq);
     }
     }

@@ -26,7 +26,7 @@ SYMBOLS = [
     "wfst_decoder_advance_host", "wfst_decoder_finalize", "wfst_decoder_sync",
     "wfst_decoder_num_frames_decoded", "wfst_decoder_get_best_path", "wfst_lattice_to_vector",
     "wfst_decoder_get_stats", "wfst_decoder_get_frontier", "wfst_decoder_set_profiling",
-    "wfst_decoder_get_profile", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
+    "wfst_decoder_get_profile", "wfst_decoder_get_profile_busy", "wfst_decoder_channel_groups", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
     "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice",
@@ -382,6 +382,10 @@ class BatchDecoder:
                              lm_score=float(lm[i, k])) for k in range(npaths[i])])
         return out
 
+    @property
+    def n_groups(self):
+        return int(lib().wfst_decoder_channel_groups(self.h))
+
     def set_profiling(self, on):
         _check(lib().wfst_decoder_set_profiling(self.h, int(bool(on))))
 
@@ -389,8 +393,10 @@ class BatchDecoder:
         ms = (C.c_double * 3)()
         n = (C.c_int64 * 3)()
         _check(lib().wfst_decoder_get_profile(self.h, ms, n))
+        busy = (C.c_double * 3)()
+        _check(lib().wfst_decoder_get_profile_busy(self.h, busy))
         return dict(expand_ms=ms[0], expand_launches=n[0], insert_ms=ms[1], insert_launches=n[1],
-                    closure_ms=ms[2], closure_launches=n[2])
+                    closure_ms=ms[2], closure_launches=n[2], expand_busy_ms=busy[0], insert_busy_ms=busy[1], closure_busy_ms=busy[2])
 
     def frontier(self, channel, cap=1 << 20):
         st = np.zeros(cap, np.int32)

@@ -78,6 +78,7 @@ def parse():
                     "timing experiments only, printed on stderr when the decoder is freed)")
     ap.add_argument("--no-fuse", action="store_true", help="graph without fused epsilon closures (wfst_graph_options.fuse_closures = 0): "
                     "the separate closure pass runs every frame")
+    ap.add_argument("--row-align", type=int, default=0, help="wfst_graph_options.row_align_slots (0 = library default)")
     ap.add_argument("--no-hip-graph", action="store_true", help="enqueue the frame loop kernel by kernel (rocprofv3 --pmc passes)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances checked bit for bit against the CPU decoder (0 = skip "
                     "the CPU legs: parity sample, cpu_baseline, service_point divergence)")
@@ -355,7 +356,7 @@ def main():
     log("[rank %d] log-likelihoods: %d x [%d x %d] (%.1fs)" % (rank, B, T, P, time.time() - t0))
 
     graph = wfstdec.Graph.from_arrays(g.start, g.final_state, g.state_info, g.arcs, device=local_rank,
-                                      options=wfstdec.GraphOptions(fuse_closures=0 if a.no_fuse else 1))
+                                      options=wfstdec.GraphOptions(fuse_closures=0 if a.no_fuse else 1, **({"row_align_slots": a.row_align} if a.row_align else {})))
     graph.set_tid2pdf(m)
     big, lm_dev, lm_info = None, [None, None], None
     if a.biglm:
@@ -486,7 +487,7 @@ def main():
                             lm_info[0]["n_states"], lm_info[0]["n_arcs"], lm_info[1]["n_states"], lm_info[1]["n_arcs"])) if a.biglm else ""),
             "global_batch": world * B, "frames_per_utt": T, "parallelism": "utterance-sharded x%d (graph replicated)" % world,
             "rtfx": value / 100.0,
-            "channel_groups": int(opt.channel_groups),
+            "channel_groups": int(dec.n_groups),
         },
     }
     if rank == 0 and world > 1 and os.environ.get("WFST_BENCH_CHECK_GATHER") == "1":
@@ -626,7 +627,19 @@ def main():
                                           "formula": "28 E + 24 N + 24 Z (SURVEY.md 8(d)), counts of one step of this rank",
                                           "frac_over_kernel_time": (whole_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms > 0 else 0.0,
                                           "frac_over_step_time": whole_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                           "measured": "hipEvent pairs around every launch on the decoder's stream, one extra step after the timed region"}
+                           "measured": "hipEvent pairs around every launch on the stream it is launched on, one extra step after the timed region"}
+        ng = int(dec.n_groups) if hasattr(dec, "n_groups") else 1
+        if ng > 1:
+            # channel groups: each group's launches run on its own stream and overlap the other group's (that is what the groups
+            # are for), so a launch shares the chip and `achieved` (bytes of ONE launch / its duration) understates the kernel;
+            # the union of the launches' intervals gives the rate at which the chip got through that kernel's bytes
+            busy = prof[dom + "_busy_ms"]
+            out["roofline"]["concurrent_launches"] = {
+                "channel_groups": ng,
+                "note": "the %d groups' launches overlap: per-launch durations include time shared with the other group's kernels" % ng,
+                "kernel_busy_ms_per_step": {k: prof[k + "_busy_ms"] for k in ("expand", "insert", "closure")},
+                "achieved_over_busy_time": (k_bytes / (busy * 1e-3) / 1e9) if busy > 0 else 0.0,
+                "frac_over_busy_time": (k_bytes / (busy * 1e-3) / 1e9 / HBM_PEAK_GBS) if busy > 0 else 0.0}
     # ---- second workload: SURVEY 8(d) generator at the reference service's operating point ----
     if rank == 0 and world == 1 and not a.no_service_point and a.lattice_links == 0 and not a.host_feed and a.workload == "multi" and not a.biglm:
         dec.free()

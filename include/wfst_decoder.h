@@ -74,7 +74,8 @@ typedef struct wfst_limits {
  * them changes a result bit; they replace what a CPU decoder has no use for.  Values out of range are
  * WFST_E_ARG.  (The library reads no environment variables.) */
 typedef struct wfst_options {
-  int32_t channel_groups;      /* 1..8: channel groups, each with its own stream and hipGraph  (1)    */
+  int32_t channel_groups;      /* 1..8: channel groups, each with its own stream and hipGraph; 0 = automatic
+                                  (2 groups from 64 channels up, else 1)                         (0)    */
   int32_t use_hip_graph;       /* replay the frame loop of an advance call as a hipGraph        (1)    */
   int32_t log2_partitions;     /* 0..6: hash partitions (candidate buckets) per channel         (5)    */
   int32_t log2_lds_slots;      /* 8..13: LDS hash slots of one insert workgroup                 (12)   */
@@ -89,7 +90,8 @@ typedef struct wfst_options {
 /* Graph upload choices (NULL / wfst_graph_options_default() = defaults). */
 typedef struct wfst_graph_options {
   int32_t row_align_slots;     /* rows are placed so that they touch as few lines of this many 16-byte
-                                  slots as possible; 1 = packed                                 (4)    */
+                                  slots as possible (8 slots = the 128-byte line a random gather
+                                  costs on MI355X); 1 = packed                                  (8)    */
   int32_t flatten_closures;    /* precompute each state's whole epsilon closure (<= 4 paths)     (1)    */
   int32_t fuse_closures;       /* fold the epsilon closures into the expansion (pseudo arcs behind
                                   each state's emitting arcs) where the graph allows: no epsilon
@@ -304,6 +306,12 @@ int wfst_decoder_get_nbest(wfst_decoder *d, const int32_t *channels, int32_t n_c
  * GetCutoff + next_cutoff seed).  Leave it off in production runs. */
 int wfst_decoder_set_profiling(wfst_decoder *d, int32_t enable);
 int wfst_decoder_get_profile(wfst_decoder *d, double ms[3], int64_t launches[3]);
+/* The time during which at least one launch of each kernel class was executing (union of the launches'
+ * intervals): with several channel groups the launches of different groups overlap, and the sum of their
+ * durations (wfst_decoder_get_profile) counts the shared time once per group. */
+int wfst_decoder_get_profile_busy(wfst_decoder *d, double busy_ms[3]);
+/* The number of channel groups the decoder runs with (wfst_options.channel_groups, resolved). */
+int wfst_decoder_channel_groups(wfst_decoder *d);
 
 /* Frontier of a channel after the last decoded frame (states and costs, unordered); for tests.
  * Returns the number of tokens (may exceed cap; only cap are written). */
