@@ -217,7 +217,7 @@ struct wfst_decoder {
       if (p) (void)hipFree(p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
-    for (hipStream_t st : gstreams) (void)hipStreamDestroy(st);
+    for (hipStream_t st : gstreams) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t ev : gevents) (void)hipEventDestroy(ev);
     if (p_target) (void)hipHostFree(p_target);
     if (p_chan) (void)hipHostFree(p_chan);
@@ -991,7 +991,8 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     d->gstreams.resize(d->n_groups);
     d->gevents.resize(d->n_groups + 1);
     hipError_t ge = hipSuccess;
-    for (auto &st : d->gstreams) if (ge == hipSuccess) ge = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    d->gstreams[0] = nullptr;  // group 0 runs on the decoder's own stream
+    for (size_t g = 1; g < d->gstreams.size(); ++g) if (ge == hipSuccess) ge = hipStreamCreateWithFlags(&d->gstreams[g], hipStreamNonBlocking);
     for (auto &ev : d->gevents) if (ge == hipSuccess) ge = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (ge != hipSuccess) { delete d; return fail(WFST_E_DEVICE, "stream/event creation failed"); }
   }
@@ -1182,15 +1183,22 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     const int rc = run_group(0, d->stream);
     if (rc != WFST_OK) return rc;
   } else {
+    // group 0 runs on the decoder's own stream, the others fork from it and join it again (every stream in use
+    // takes one of the few hardware queues; streams beyond those share a queue and serialise)
     HIP_TRY(hipEventRecord(d->gevents[0], d->stream));  // targets / row pointers are uploaded
-    for (int g = 0; g < G; ++g) {
+    for (int g = 1; g < G; ++g) {
       if (gsteps[g] == 0) continue;
       HIP_TRY(hipStreamWaitEvent(d->gstreams[g], d->gevents[0], 0));
       const int rc = run_group(g, d->gstreams[g]);
       if (rc != WFST_OK) return rc;
       HIP_TRY(hipEventRecord(d->gevents[1 + g], d->gstreams[g]));
-      HIP_TRY(hipStreamWaitEvent(d->stream, d->gevents[1 + g], 0));
     }
+    {
+      const int rc = run_group(0, d->stream);
+      if (rc != WFST_OK) return rc;
+    }
+    for (int g = 1; g < G; ++g)
+      if (gsteps[g] != 0) HIP_TRY(hipStreamWaitEvent(d->stream, d->gevents[1 + g], 0));
   }
   HIP_TRY(hipGetLastError());
   for (int g = 0; g < G; ++g) d->gpar[g] = gpar0[g] ^ (gsteps[g] & 1);
@@ -1490,7 +1498,7 @@ int wfst_decoder_channel_groups(wfst_decoder *d) { return d ? d->n_groups : fail
 int wfst_decoder_get_profile_busy(wfst_decoder *d, double busy_ms[3]) {
   if (!d || !busy_ms) return fail(WFST_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(d->device));
-  for (hipStream_t st : d->gstreams) HIP_TRY(hipStreamSynchronize(st));
+  for (hipStream_t st : d->gstreams) if (st) HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipStreamSynchronize(d->stream));
   // union of the launches' [start, stop] intervals of each kernel class: with several channel groups the launches
   // of different groups run concurrently, so the sum of their durations counts shared time twice

@@ -9,7 +9,7 @@ for r in csv.DictReader(open(f)):
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     n[k][r["Counter_Name"]] += 1
 for k in agg:
-    if not k.endswith("_kernel"):
+    if "kernel" not in k:
         continue
     a = {c: v / n[k][c] for c, v in agg[k].items()}
     line = "%-16s launches %d  " % (k, max(n[k].values())) + "  ".join("%s=%.3g" % (c, v) for c, v in sorted(a.items()))
