@@ -810,7 +810,8 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   }
   if (L.max_frames <= 0) L.max_frames = 4096;
   if (L.max_tokens_per_frame <= 0) L.max_tokens_per_frame = 32768;
-  if (L.arena_tokens <= 0) L.arena_tokens = 4194304;
+  if (L.arena_tokens <= 0)  // room for max_frames frames at 1/32 of the per-frame token limit (include/wfst_decoder.h)
+    L.arena_tokens = std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(4194304, (int64_t)L.max_frames * std::max<int64_t>(256, L.max_tokens_per_frame / 32)));
   if (L.arena_tokens > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "arena_tokens must fit int32");
   if (L.lattice_links < 0 || L.lattice_links > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "lattice_links must fit int32");
   // hash partitions per channel: each insert workgroup owns an LDS table of lds_slots entries;

@@ -41,11 +41,15 @@ typedef struct wfst_lm wfst_lm;           /* a back-off n-gram LM automaton resi
                                              (newlm/arpa2fsa.h:249-441) for the biglm decoder */
 
 /* Field-for-field LatticeFasterDecoderConfig (my-decoder/lattice-faster-decoder-conf.h:21-44);
- * wfst_config_default() fills the reference defaults (conf.h:35-44).  hash_ratio and prune_scale
- * are accepted for compatibility: the device hash is sized by wfst_limits, and best-path decoding
- * keeps no forward-link lists to back-prune (prune_interval and lattice_beam still decide which
- * of several parallel arcs GetBestPath reports, exactly as in the reference).  In lattice mode
- * (wfst_limits.lattice_links) lattice_beam prunes the recorded links at FinalizeDecoding. */
+ * wfst_config_default() fills the reference defaults (conf.h:35-44).  hash_ratio is accepted for
+ * compatibility (the device hash tables are sized by wfst_limits and wfst_options).  Best-path decoders keep
+ * no forward-link lists to back-prune: prune_interval and lattice_beam there only decide which of several
+ * parallel arcs GetBestPath reports, exactly as in the reference.  In LATTICE MODE
+ * (wfst_limits.lattice_links > 0) the reference's PruneActiveTokens runs on the device: every prune_interval
+ * frames the recorded links are pruned backwards by lattice_beam, walking back while a frame's extra costs
+ * move by more than lattice_beam * prune_scale (base-inl.h:439-607, 660-661), and the token arena and link
+ * store are compacted, so that memory stays bounded whatever the utterance length; FinalizeDecoding prunes
+ * with delta 0 like the reference's PruneActiveTokens(0) (base-inl.h:541-607). */
 typedef struct wfst_config {
   float beam;
   int32_t max_active;
@@ -62,7 +66,16 @@ typedef struct wfst_config {
 typedef struct wfst_limits {
   int32_t max_frames;           /* frames per utterance                     (default 4096)    */
   int32_t max_tokens_per_frame; /* distinct states reached in one frame     (default 32768)   */
-  int64_t arena_tokens;         /* tokens kept per utterance for traceback  (default 4194304) */
+  int64_t arena_tokens;         /* token arena of one utterance, 16 bytes a token.  BEST-PATH decoders keep every
+                                   token of the utterance for the traceback (there are no link lists to prune
+                                   them by): an utterance of T frames with n tokens alive per frame needs about
+                                   T x n -- this, not max_frames, is the utterance-length limit of a best-path
+                                   decoder; WFST_E_CAPACITY names it when it is hit.  LATTICE-MODE decoders
+                                   reclaim it every prune_interval frames (see wfst_config) and need ~3x the
+                                   tokens FinalizeDecoding keeps + prune_interval frames of raw tokens, whatever
+                                   the utterance length: use lattice mode for unbounded streaming.
+                                   Default: max_frames x max(256, max_tokens_per_frame / 32), at least 4194304,
+                                   i.e. room for the default max_frames at 1024 tokens per frame             */
   int64_t lattice_links;        /* > 0: LATTICE MODE -- record every forward link (capacity per
                                    utterance) so that FinalizeDecoding can prune by lattice_beam and
                                    GetRawLattice can be served; 0 (default): best path only        */
