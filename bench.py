@@ -22,6 +22,18 @@ timed region starts.
 N > 1: utterances shard embarrassingly (128 per GPU, graph replicated, weak scaling); the only
 collective is the gather of the final word-id results per step (RCCL).
 Rank 0 prints ONE JSON line (metric, roofline, cpu_baseline, service_point).
+
+roofline.achieved: algorithmic bytes (SURVEY.md 8(d) per-unit figures x the units processed) of the slowest
+kernel / its time, from hipEvent pairs around every launch on the stream it is launched on.  The decoder runs
+its channels as two groups on two streams (wfst_options.channel_groups), whose launches overlap: the time is
+then the kernel's BUSY time (union of its launches' intervals) and the per-launch figures sit in
+roofline.per_launch; with --groups 1 both definitions coincide (DESIGN.md section 3 "Roofline accounting").
+
+Other BASELINE configs through the same script (not the headline; `metric` says which):
+    --biglm                          configs[3]: on-the-fly LM rescoring
+    --lattice-links N [--determinize] [--prune-interval K]   configs[4]: lattice-generating decode
+    --beam 15 --lattice-beam 8 --lattice-links 25165824 --arena-per-frame 60000 --max-tokens 262144
+    --host-feed                      PCIe-inclusive (host matrices handed over inside the step)
 """
 import argparse
 import importlib
@@ -73,6 +85,8 @@ def parse():
     ap.add_argument("--lattice-beam", type=float, default=7.0)
     ap.add_argument("--determinize", action="store_true", help="lattice mode: the step also builds every utterance's DETERMINIZED lattice "
                     "on the device (GetLattice, base-inl.h:850-866) and fetches it")
+    ap.add_argument("--prune-interval", type=int, default=25, help="config prune_interval (reference default 25): lattice mode back-prunes and "
+                    "compacts every this many frames; >= --frames: once, at FinalizeDecoding (offline batches that have the memory)")
     ap.add_argument("--nbest", type=int, default=5, help="n of the n-best taken per utterance in lattice mode")
     ap.add_argument("--debug", type=int, default=0, help="wfst_options.debug (kernel phase timers 32 closure / 64 insert / 128 expand: "
                     "timing experiments only, printed on stderr when the decoder is freed)")
@@ -332,7 +346,7 @@ def main():
     n_tid = 2 * P
     m = synth.default_tid2pdf(n_tid)
     cd = dict(beam=a.beam, max_active=a.max_active, min_active=a.min_active, lattice_beam=a.lattice_beam,
-              prune_interval=25, beam_delta=0.5)
+              prune_interval=a.prune_interval, beam_delta=0.5)
 
     # ---- inputs (untimed) -------------------------------------------------------------------
     t0 = time.time()

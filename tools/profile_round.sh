@@ -10,10 +10,14 @@ O="$R/gpurun_out/prof"
 rm -rf "$O"; mkdir -p "$O"
 export TMPDIR=/tmp
 cd "$R"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-service-point > "$O/bench_kt.json" 2> "$O/kt.err"
+# One channel group (--groups 1): every launch covers the whole batch and nothing overlaps, so the per-kernel average
+# durations are the kernels' own (the tracer serialises the two streams of the default two-group run anyway: a traced
+# two-group run measures neither the overlap nor the kernels; it is kept below as kt_groups2 for the record).
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --groups 1 --steps 2 --warmup 1 --cpu-sample 0 --no-service-point > "$O/bench_kt.json" 2> "$O/kt.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_groups2" -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-service-point > "$O/bench_kt_groups2.json" 2> "$O/kt_groups2.err"
 # counter passes: kernels enqueued one by one (--no-hip-graph) so that every dispatch is attributed
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-service-point --no-hip-graph > "$O/bench_fetch.json" 2> "$O/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-service-point --no-hip-graph > "$O/bench_write.json" 2> "$O/write.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 bench.py --groups 1 --steps 1 --warmup 0 --cpu-sample 0 --no-service-point --no-hip-graph > "$O/bench_fetch.json" 2> "$O/fetch.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 bench.py --groups 1 --steps 1 --warmup 0 --cpu-sample 0 --no-service-point --no-hip-graph > "$O/bench_write.json" 2> "$O/write.err"
 # lattice mode (insert_kernel<true>, closure_kernel<true>, lattice_prune_kernel, nbest_kernel)
 B=128 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_lattice" -- python3 tools/lattice_fullsize.py > "$O/lattice.log" 2> "$O/lattice.err"
 # keep the merge-back small: the per-dispatch traces are not needed, the stats and counter CSVs are

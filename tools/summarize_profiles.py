@@ -43,6 +43,9 @@ def main():
     ks = newest(os.path.join(P, "kt", "*", "*_kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(OUT, "%s_kernel_stats.csv" % tag))
+    k2 = newest(os.path.join(P, "kt_groups2", "*", "*_kernel_stats.csv"))
+    if k2:
+        shutil.copy(k2[0], os.path.join(OUT, "%s_kernel_stats_two_groups_traced.csv" % tag))
     kl = newest(os.path.join(P, "kt_lattice", "*", "*_kernel_stats.csv"))
     if kl:
         shutil.copy(kl[0], os.path.join(OUT, "%s_lattice_mode_kernel_stats.csv" % tag))
