@@ -879,7 +879,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     A(d->lat_arcs.alloc(B * (size_t)lat_arc_cap));
     A(d->lat_toks.alloc(B * (size_t)lat_tok_cap));
   }
-  const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 256 + 2);
+  const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 128 + 2);  // tiles of 128 tokens at least (prep_frame)
   A(d->fctl.alloc(8));
   A(d->dbg_t.alloc(64));
   A(d->tiles.alloc(8 * tile_cap));

@@ -304,6 +304,9 @@ template <bool kBig, bool kFused>
 __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int par) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   FrameCtl *fc = D.fctl + group;
+  // (the workgroup's first tile descriptor is read together with the tile count, not after it: one round trip less at
+  // the head of every launch; a slot beyond the count holds a stale descriptor that is not used)
+  const TileDesc td_first = D.tiles[(size_t)group * D.tile_cap + min((int)blockIdx.x, D.tile_cap - 1)];
   const int total_tiles = fc->total_tiles[par];
   const float kInf = __builtin_huge_valf();
   const int P = D.n_part, log2part = D.log2part, bcap = D.bucket_cap;
@@ -330,9 +333,12 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
   const TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap;
   unsigned long long tq = wall_clock64();
   for (int t = blockIdx.x; t < total_tiles;) {
-    const TileDesc td = tiles[t];
+    const TileDesc td = t == (int)blockIdx.x ? td_first : tiles[t];
     const int c = td.chan;
     ChanCtl *ctl = D.ctl + c;
+    // next_cutoff as it stands (it only ever tightens: a stale value prunes less, never wrongly); asked for here,
+    // needed after the scan
+    const uint32_t bound0 = ld_agent(&ctl->bound);
     const int n = td.tok_count;
     const int fbegin = td.tok_begin;
     const int4 *tok = D.tok + (size_t)c * D.arena_cap + fbegin;
@@ -409,7 +415,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
     if (tid < 64) s_cnt[tid] = 0;
     __syncthreads();
 
-    float bound = o2f(ld_agent(&ctl->bound));
+    float bound = o2f(bound0);
     const int tok0 = fbegin;  // arena index of the tile's first token
     for (int j0 = 0; j0 < total; j0 += kChunk) {
       int4 rec[kCandPerThread];
@@ -984,6 +990,7 @@ struct BoundaryShared {
   uint32_t hist[256];
   uint32_t sel_prefix, sel_k;
   int active;
+  int tile_tokens;  // tokens per expansion tile of the coming frame (prep_frame)
 };
 
 // ProcessNonemitting to its fixpoint (base-inl.h:383-430) on the channel's direct-mapped epsilon
@@ -1505,8 +1512,16 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
     ctl->new_count = 0;
     ctl->best_next = ~0ull;
     ctl->active = 1;
-    // publish this channel's tiles for the expansion (any disjoint range will do)
-    const int ntiles = (n + kTileTokens - 1) / kTileTokens;
+    // publish this channel's tiles for the expansion (any disjoint range will do).  Tile size: a tile's sort rounds are
+    // serial (candidates / 512 per round), so smaller tiles shorten the launch -- as long as all tiles of the launch are
+    // resident at once (~1500 workgroups; other groups' launches share them).  Judged per channel on its own token
+    // count times the channels of the launch: 16 channels x 4.3 k tokens get 128-token tiles (16.7 -> 14.1 ms per step),
+    // 64 channels and more the full 512.
+    int tile_tokens = kTileTokens;
+    if ((int64_t)n * (int)gridDim.x <= 700ll * 256) tile_tokens = 256;
+    if ((int64_t)n * (int)gridDim.x <= 700ll * 128) tile_tokens = 128;
+    sh.tile_tokens = tile_tokens;
+    const int ntiles = (n + tile_tokens - 1) / tile_tokens;
     sh.active = 0;
     ctl->tiles_left = ntiles;
     if (ntiles > 0) {
@@ -1522,8 +1537,8 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
   for (int i = tid; i < ntl; i += kBT) {
     TileDesc td;
     td.chan = c;
-    td.tok_begin = ctl->front_begin + i * kTileTokens;
-    td.tok_count = min(kTileTokens, n - i * kTileTokens);
+    td.tok_begin = ctl->front_begin + i * sh.tile_tokens;
+    td.tok_count = min(sh.tile_tokens, n - i * sh.tile_tokens);
     td.cutoff = cutoff;
     td.adaptive_beam = ab;
     td.pad = 0;
