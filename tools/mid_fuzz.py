@@ -1,6 +1,7 @@
 """Hand-run campaign (GPU box): mid-size hclg-like graphs with random shape parameters, random beams,
-lengths and lattice beams, 16 utterances each, lattice mode -- best path vs the oracle (reference
-mode when no max/min-active binds), raw lattice vs the order-free oracle.  python tools/mid_fuzz.py [seed]"""
+lengths, lattice beams and prune intervals, 16 utterances each, once through a lattice-mode decoder and once
+through a best-path decoder (fused closures) -- best paths vs the order-free oracle, raw lattice vs the
+order-free oracle.  python tools/mid_fuzz.py [seed]"""
 import importlib, os, sys
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
@@ -53,6 +54,14 @@ for it in range(int(os.environ.get("N", 12))):
         dec.free(); graph.free()
         continue
     lats = dec.raw_lattices()
+    # the same utterances through a BEST-PATH decoder (fused epsilon closures, two channel groups ...): same best paths
+    dec2 = wfstdec.BatchDecoder(graph, wfstdec.Config(**cd), B, max_frames=128, max_tokens_per_frame=262144, arena_tokens=120 * 60000)
+    dec2.init()
+    for r in steps:
+        dec2.advance([t.data_ptr() for t in dev], [min(r, T) for T in lens], P)
+    dec2.finalize()
+    best2 = dec2.best_paths()
+    dec2.free()
     try:
         nb = dec.nbest(4)
     except wfstdec.WfstError as e:   # lattices beyond the n-best search's capacity: a loud refusal
@@ -74,6 +83,10 @@ for it in range(int(os.environ.get("N", 12))):
         ok = bool(r["ok"]) == bool(o.ok)
         if ok and o.ok and o.extra["ties"] == 0:
             ok = np.array_equal(r["tids"], o.tids) and np.array_equal(r["words"], o.words) and np.float32(r["tot_score"]).tobytes() == np.float32(o.tot_score).tobytes()
+        r2 = best2[u]
+        if ok and o.ok and o.extra["ties"] == 0:   # best-path decoder: the same path, bit for bit
+            ok = bool(r2["ok"]) and np.array_equal(r2["tids"], o.tids) and np.array_equal(r2["words"], o.words) and \
+                np.float32(r2["tot_score"]).tobytes() == np.float32(o.tot_score).tobytes()
         L = lats[u]
         if ok and (L is not None) != O.ok:
             ok = False
