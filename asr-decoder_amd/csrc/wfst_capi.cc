@@ -866,12 +866,13 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     A(d->tok_lm.alloc(B * (size_t)L.arena_tokens));
     A(d->bucket_lm.alloc(B * (size_t)n_part * (size_t)bucket_cap));
   }
+  // new indices while the arena is compacted: the back-pruning of lattice mode, the token collection of best-path mode
+  A(d->remap.alloc(B * (size_t)L.arena_tokens));
   if (L.lattice_links > 0) {
     A(d->links.alloc(B * (size_t)L.lattice_links));
     A(d->link_off.alloc(B * ((size_t)L.max_frames + 3)));
     A(d->link_mid.alloc(B * ((size_t)L.max_frames + 3)));
     A(d->extra.alloc(B * (size_t)L.arena_tokens));
-    A(d->remap.alloc(B * (size_t)L.arena_tokens));
     // GetRawLattice may be asked for at any time (base-inl.h:869-975): everything alive -- the pruned
     // history and the raw frames since the last PruneActiveTokens pass -- must fit the resolved lists
     lat_arc_cap = L.lattice_links;
@@ -1801,7 +1802,7 @@ int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]) {
   stats[4] = (int64_t)c.cnt_tok;
   stats[5] = c.peak_tokens;
   stats[6] = (int64_t)c.cnt_rec;
-  stats[7] = c.link_count;  // lattice mode: forward links recorded
+  stats[7] = d->D.lattice ? c.link_count : c.lat_toks;  // lattice mode: forward links recorded; best-path mode: token collections run
   return WFST_OK;
 }
 

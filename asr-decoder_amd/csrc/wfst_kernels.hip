@@ -1901,6 +1901,196 @@ __device__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
   (void)any_final;
 }
 
+
+// =========================================================================================
+// Best-path decoders: token garbage collection.  A best-path decoder keeps no forward links, so nothing prunes its
+// arena the way PruneActiveTokens prunes the reference's token lists; what GetBestPath can ever need is the
+// backpointer FOREST of the current frontier.  When the arena passes its collection mark (half full; then halfway
+// between what survived and the capacity), every token reachable from the frontier is marked -- frame by frame,
+// newest first; a token won by an epsilon arc (kPrevUnresolved) has its predecessor, the frame's token on the arc's
+// source state, found through an LDS hash of the wanted states and WRITTEN BACK as an ordinary backpointer -- and the
+// survivors are moved down (frame_off[], backpointers, frontier, best token remapped).  GetBestPath is unchanged by it
+// (same chain, same costs; tests/test_gpu_token_gc.py) and the arena then bounds the raw frames between two
+// collections, not the utterance.  One 1024-thread workgroup per channel, inside closure_kernel; only when the mark is
+// passed (never on the bench workload).  biglm: several tokens of a frame may sit on the wanted state (one per LM
+// state); all of them are kept and the backpointer stays unresolved.
+// =========================================================================================
+constexpr int kGcNeedSlots = 4096;  // LDS hash of the states wanted in one sweep (power of two)
+struct GcShared {
+  int32_t key[kGcNeedSlots];    // wanted state (row), -1 empty
+  int32_t found[kGcNeedSlots];  // the frame's token on it
+  int n_need, n_new, overflow;
+};
+
+template <bool kBig>
+__device__ void gc_pass(const DecoderDev &D, int c, PruneShared &ps, GcShared &gs) {
+  const int tid = threadIdx.x;
+  ChanCtl *ctl = D.ctl + c;
+  const int nd = ctl->n_decoded;
+  int4 *tok = D.tok + (size_t)c * D.arena_cap;
+  int32_t *side = (kBig || D.tok_lm) ? D.tok_lm + (size_t)c * D.arena_cap : nullptr;
+  int32_t *remap = D.remap + (size_t)c * D.arena_cap;   // 0 dead, 1 marked, 2 marked and followed; then new indices
+  int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
+  const int end = foff[nd + 1];
+  // (1) mark: the frontier, then what it reaches
+  for (int i = tid; i < end; i += kBT) remap[i] = i >= foff[nd] ? 1 : 0;
+  __syncthreads();
+  for (int f = nd; f >= 0; --f) {
+    const int lo = foff[f], hi = foff[f + 1];
+    for (;;) {   // until no token of the frame is newly marked (epsilon chains inside the frame)
+      for (int i = tid; i < kGcNeedSlots; i += kBT) gs.key[i] = -1;
+      if (tid == 0) { gs.n_need = 0; gs.n_new = 0; gs.overflow = 0; }
+      __syncthreads();
+      for (int i = lo + tid; i < hi; i += kBT) {
+        if (remap[i] != 1) continue;
+        const int4 t = tok[i];
+        bool done = true;
+        if (t.z == kPrevUnresolved) {
+          const int need = D.g.arc_src[(uint32_t)t.w & kArcMask] & 0x7FFFFFFF;
+          // claim a slot for the wanted state (shared by every token that wants it); a full table: next sweep
+          uint32_t slot = hash32(need) & (kGcNeedSlots - 1);
+          done = false;
+          if (atomicAdd(&gs.n_need, 0) < (kGcNeedSlots * 3) / 4) {
+            for (int q = 0; q < kGcNeedSlots; ++q) {
+              const int k = atomicCAS(&gs.key[slot], -1, need);
+              if (k == -1) { atomicAdd(&gs.n_need, 1); done = true; break; }
+              if (k == need) { done = true; break; }
+              slot = (slot + 1) & (kGcNeedSlots - 1);
+            }
+          }
+          if (!done) gs.overflow = 1;
+        } else if (t.z >= lo) {
+          // a backpointer on this same frame (an epsilon hop resolved by an earlier collection)
+          if (remap[t.z] == 0) { remap[t.z] = 1; gs.n_new = 1; }
+        } else if (t.z >= 0) {
+          remap[t.z] = 1;   // on the previous frame
+        }
+        if (done) remap[i] = 2;
+      }
+      __syncthreads();
+      const int n_need = gs.n_need;
+      {
+        const int ov = gs.overflow, nw = gs.n_new;
+        __syncthreads();   // (everyone has read the flags before they are reset)
+        if (n_need == 0 && !ov) {
+          if (!nw) break;
+          continue;
+        }
+      }
+      // the frame's tokens on wanted states
+      for (int i = lo + tid; i < hi; i += kBT) {
+        const int st = tok[i].x;
+        uint32_t slot = hash32(st) & (kGcNeedSlots - 1);
+        for (int q = 0; q < kGcNeedSlots; ++q) {
+          const int k = gs.key[slot];
+          if (k == -1) break;
+          if (k == st) {
+            if constexpr (!kBig) gs.found[slot] = i;
+            if (remap[i] == 0) { remap[i] = 1; gs.n_new = 1; }
+            break;
+          }
+          slot = (slot + 1) & (kGcNeedSlots - 1);
+        }
+      }
+      __syncthreads();
+      if constexpr (!kBig) {
+        // one token per state and frame: the predecessor is unique -- written back as an ordinary backpointer
+        for (int i = lo + tid; i < hi; i += kBT) {
+          if (remap[i] != 2) continue;
+          const int4 t = tok[i];
+          if (t.z != kPrevUnresolved) continue;
+          const int need = D.g.arc_src[(uint32_t)t.w & kArcMask] & 0x7FFFFFFF;
+          uint32_t slot = hash32(need) & (kGcNeedSlots - 1);
+          for (int q = 0; q < kGcNeedSlots; ++q) {
+            const int k = gs.key[slot];
+            if (k == -1) break;
+            if (k == need) { tok[i].z = gs.found[slot]; break; }
+            slot = (slot + 1) & (kGcNeedSlots - 1);
+          }
+        }
+      }
+      __syncthreads();
+      {
+        const int ov = gs.overflow, nw = gs.n_new;
+        __syncthreads();
+        if (!nw && !ov) break;
+      }
+    }
+    __syncthreads();
+  }
+  // (2) move the survivors down, frame by frame
+  constexpr int kCU = 8;
+  int new_end = 0, old_lo = 0;
+  if (tid == 0) ps.err = 0;
+  __syncthreads();
+  for (int f = 0; f <= nd; ++f) {
+    const int old_hi = foff[f + 1];
+    int base = new_end;
+    for (int i0 = old_lo; i0 < old_hi; i0 += kBT * kCU) {
+      bool alive[kCU];
+      int cnt = 0;
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int i = i0 + tid * kCU + u;
+        alive[u] = i < old_hi && remap[i] != 0;
+        cnt += alive[u] ? 1 : 0;
+      }
+      int tot;
+      int r = base + block_exscan(cnt, ps, &tot);
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int i = i0 + tid * kCU + u;
+        if (i < old_hi) remap[i] = alive[u] ? r++ : -1;
+      }
+      base += tot;
+    }
+    __syncthreads();
+    for (int i0 = old_lo; i0 < old_hi; i0 += kBT * kCU) {
+      int ni[kCU], sw[kCU];
+      int4 rec[kCU];
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int i = i0 + tid * kCU + u;
+        ni[u] = i < old_hi ? remap[i] : -1;
+        rec[u] = make_int4(0, 0, 0, 0);
+        sw[u] = 0;
+        if (ni[u] >= 0) {
+          rec[u] = tok[i];
+          if (side) sw[u] = side[i];
+          if (rec[u].z >= 0) {   // predecessor: a survivor of the previous frame (or of this one), already renumbered
+            rec[u].z = remap[rec[u].z];
+            if (rec[u].z < 0) ps.err = 1;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < kCU; ++u)
+        if (ni[u] >= 0) { tok[ni[u]] = rec[u]; if (side) side[ni[u]] = sw[u]; }
+      __syncthreads();
+    }
+    new_end = base;
+    old_lo = old_hi;
+    __syncthreads();
+    if (tid == 0) foff[f + 1] = new_end;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    ctl->front_begin = foff[nd];
+    ctl->front_count = foff[nd + 1] - foff[nd];
+    const u64 b = ctl->best_next;
+    if (b != ~0ull) {
+      const int nb = remap[(uint32_t)b];
+      ctl->best_next = nb >= 0 ? ((b & 0xFFFFFFFF00000000ull) | (uint32_t)nb) : ~0ull;
+    }
+    // next collection: halfway between what survived and the capacity
+    ctl->lat_arcs = new_end + (int)((D.arena_cap - new_end) / 2);   // (best-path decoders: the collection mark)
+    ctl->lat_toks += 1;                                             // (                    collections so far)
+    if (ps.err) ctl->error |= kErrArenaFull;  // never expected: a survivor whose predecessor was not marked
+  }
+  __syncthreads();
+}
+
 template <bool kLat, bool kBig>
 __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_t *target, int do_prep, int chan_off,
                                                       int group, int par) {
@@ -1917,6 +2107,17 @@ __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_
     if (do_prep && nd > 0 && nd % D.prune_interval == 0 && ctl->pruned_upto != nd && nd < target[c] && ctl->error == 0 &&
         !ctl->finalized && nd < D.max_frames)
       prune_pass<false>(D, c, ps);
+    __syncthreads();
+  } else {
+    // best-path decoders: collect the arena's garbage when it passes its mark (gc_pass)
+    __shared__ PruneShared ps;
+    __shared__ GcShared gs;
+    const int nd = ctl->n_decoded;
+    if (do_prep && D.remap && nd > 0 && nd < target[c] && ctl->error == 0 && !ctl->finalized && nd < D.max_frames) {
+      const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
+      const int mark = ctl->lat_arcs > 0 ? ctl->lat_arcs : (int)(D.arena_cap / 2);
+      if (foff[nd + 1] > mark) gc_pass<kBig>(D, c, ps, gs);
+    }
     __syncthreads();
   }
   if (do_prep) prep_frame<kBig>(D, c, ctl, target, sh, group, par);  // par: parity of the step it prepares

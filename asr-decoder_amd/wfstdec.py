@@ -215,6 +215,7 @@ class BatchDecoder:
         self.graph = graph
         self.n = int(n_channels)
         lim = Limits(int(max_frames), int(max_tokens_per_frame), int(arena_tokens), int(lattice_links), int(lm_pairs))
+        self.lattice_links = int(lattice_links)
         h = C.c_void_p()
         _check(lib().wfst_decoder_create_biglm(graph.h, C.byref(cfg), self.n, C.byref(lim),
                                                C.byref(options) if options is not None else None,
@@ -304,7 +305,9 @@ class BatchDecoder:
     def stats(self, channel):
         s = (C.c_int64 * 8)()
         _check(lib().wfst_decoder_get_stats(self.h, int(channel), s))
-        return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], records=s[6], links=s[7])
+        lat = self.lattice_links > 0
+        return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], records=s[6], links=s[7] if lat else 0,
+                    collections=0 if lat else s[7])
 
     def raw_lattice(self, channel, use_final_probs=True):
         """GetRawLattice of a finalized channel (lattice mode).  Returns a dict of numpy arrays, or

@@ -92,6 +92,8 @@ def parse():
                     "timing experiments only, printed on stderr when the decoder is freed)")
     ap.add_argument("--no-fuse", action="store_true", help="graph without fused epsilon closures (wfst_graph_options.fuse_closures = 0): "
                     "the separate closure pass runs every frame")
+    ap.add_argument("--expand-wgs", type=int, default=0, help="wfst_options.expand_workgroups (0 = library default)")
+    ap.add_argument("--insert-wgs", type=int, default=0, help="wfst_options.insert_workgroups (0 = library default)")
     ap.add_argument("--row-align", type=int, default=0, help="wfst_graph_options.row_align_slots (0 = library default)")
     ap.add_argument("--no-hip-graph", action="store_true", help="enqueue the frame loop kernel by kernel (rocprofv3 --pmc passes)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances checked bit for bit against the CPU decoder (0 = skip "
@@ -391,7 +393,9 @@ def main():
         log("[rank %d] LMs: old %d states / %d arcs, new %d states / %d arcs (%.1fs)" % (
             rank, lm_info[0]["n_states"], lm_info[0]["n_arcs"], lm_info[1]["n_states"], lm_info[1]["n_arcs"], time.time() - t0))
     stream = torch.cuda.current_stream(dev).cuda_stream
-    opt = wfstdec.Options(use_hip_graph=0 if a.no_hip_graph else 1, debug=a.debug, **({"channel_groups": a.groups} if a.groups > 0 else {}))
+    opt = wfstdec.Options(use_hip_graph=0 if a.no_hip_graph else 1, debug=a.debug, **({"channel_groups": a.groups} if a.groups > 0 else {}),
+                          **({"expand_workgroups": a.expand_wgs} if a.expand_wgs > 0 else {}),
+                          **({"insert_workgroups": a.insert_wgs} if a.insert_wgs > 0 else {}))
 
     def new_decoder(cfg_dict):
         return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=a.max_tokens,

@@ -69,11 +69,14 @@ typedef struct wfst_limits {
   int64_t arena_tokens;         /* token arena of one utterance, 16 bytes a token.  BEST-PATH decoders keep every
                                    token of the utterance for the traceback (there are no link lists to prune
                                    them by): an utterance of T frames with n tokens alive per frame needs about
-                                   T x n -- this, not max_frames, is the utterance-length limit of a best-path
-                                   decoder; WFST_E_CAPACITY names it when it is hit.  LATTICE-MODE decoders
-                                   reclaim it every prune_interval frames (see wfst_config) and need ~3x the
-                                   tokens FinalizeDecoding keeps + prune_interval frames of raw tokens, whatever
-                                   the utterance length: use lattice mode for unbounded streaming.
+                                   T x n IF nothing is reclaimed; when the arena is half full the decoder
+                                   collects it (keeps what the frontier's backpointers reach, a percent or two,
+                                   and moves it down), so that what the arena must hold is the raw tokens of the
+                                   frames between two collections plus the surviving history -- a few hundred
+                                   frames' worth is plenty for any utterance length; WFST_E_CAPACITY only if one
+                                   collection cannot free half of it.  LATTICE-MODE decoders reclaim it every
+                                   prune_interval frames (see wfst_config) and need ~3x the tokens
+                                   FinalizeDecoding keeps + prune_interval frames of raw tokens.
                                    Default: max_frames x max(256, max_tokens_per_frame / 32), at least 4194304,
                                    i.e. room for the default max_frames at 1024 tokens per frame             */
   int64_t lattice_links;        /* > 0: LATTICE MODE -- record every forward link (capacity per
@@ -261,7 +264,8 @@ int wfst_lattice_to_vector(const int32_t *ilabel, const int32_t *olabel, const f
 
 /* Per-channel work counters since the last init: {frames, N tokens expanded, E emitting arcs
  * traversed, Z epsilon arcs traversed, tokens kept, peak tokens per frame, candidate records
- * bucketed, reserved}.  N and E follow the definitions of the reference loop (base-inl.h:311-347). */
+ * bucketed, forward links recorded (lattice mode) / token collections run (best-path mode)}.  N and E follow the
+ * definitions of the reference loop (base-inl.h:311-347). */
 int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]);
 
 /* GetRawLattice(Lattice*, use_final_probs) (base-inl.h:869-975) of a FINALIZED channel of a

@@ -168,6 +168,8 @@ def test_50k_arc_graph_with_a_100k_ngram_lm_pair(synth, oracle, tmp_path):
         finally:
             oracle.set_order_free(False)
         assert min_ok <= sum(int(o.ok) for o in want) <= max_ok and all(o.extra["lm_oob"] == 0 for o in want)
+        if lb == 25.0:
+            want25 = want
         for chunk in (0, 13):
             res = _decode(G, graph, cd, mats, L1, L2, chunk=chunk, limits=lim)
             for i, (r, o) in enumerate(zip(res, want)):
@@ -175,6 +177,13 @@ def test_50k_arc_graph_with_a_100k_ngram_lm_pair(synth, oracle, tmp_path):
                 _same(r, o, "utt %d chunk %d lattice_beam %g" % (i, chunk, lb))
     cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=25.0)
     res = _decode(G, graph, cd, mats, L1, L2, limits=lim)
+    # token collection in biglm mode (gc_pass<true>: every token on a wanted state is kept, whatever its LM state): the
+    # same batch, streamed, in an arena a fifth of what it creates
+    made = max(r.stats["tokens"] for r in res)
+    res2 = _decode(G, graph, cd, mats, L1, L2, chunk=13, limits=dict(lim, arena_tokens=int(made // 5)))
+    for i, (r, o) in enumerate(zip(res2, want25)):
+        _same(r, o, "utt %d in a small arena" % i)
+    assert max(r.stats["collections"] for r in res2) >= 2
     # a word actually costs the LM difference: the batch's LM scores differ from the plain decoder's
     plain = G.decode_batch(graph, cd, mats, limits=lim)
     assert any(r.ok and p.ok and r.lm_score != p.lm_score for r, p in zip(res, plain))
