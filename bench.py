@@ -92,6 +92,9 @@ def parse():
                     "timing experiments only, printed on stderr when the decoder is freed)")
     ap.add_argument("--no-fuse", action="store_true", help="graph without fused epsilon closures (wfst_graph_options.fuse_closures = 0): "
                     "the separate closure pass runs every frame")
+    ap.add_argument("--log2-parts", type=int, default=-1, help="wfst_options.log2_partitions (-1 = library default)")
+    ap.add_argument("--log2-lds", type=int, default=0, help="wfst_options.log2_lds_slots (0 = library default)")
+    ap.add_argument("--joint-max", type=int, default=0, help="wfst_options.joint_max (0 = library default)")
     ap.add_argument("--expand-wgs", type=int, default=0, help="wfst_options.expand_workgroups (0 = library default)")
     ap.add_argument("--insert-wgs", type=int, default=0, help="wfst_options.insert_workgroups (0 = library default)")
     ap.add_argument("--row-align", type=int, default=0, help="wfst_graph_options.row_align_slots (0 = library default)")
@@ -395,6 +398,9 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     opt = wfstdec.Options(use_hip_graph=0 if a.no_hip_graph else 1, debug=a.debug, **({"channel_groups": a.groups} if a.groups > 0 else {}),
                           **({"expand_workgroups": a.expand_wgs} if a.expand_wgs > 0 else {}),
+                          **({"log2_partitions": a.log2_parts} if a.log2_parts >= 0 else {}),
+                          **({"log2_lds_slots": a.log2_lds} if a.log2_lds > 0 else {}),
+                          **({"joint_max": a.joint_max} if a.joint_max > 0 else {}),
                           **({"insert_workgroups": a.insert_wgs} if a.insert_wgs > 0 else {}))
 
     def new_decoder(cfg_dict):

@@ -49,7 +49,8 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
     from test_gpu_lattice import as_raw, nodes
 
     rng = np.random.default_rng(int(os.environ.get("WFST_FUZZ_SEED", "1234")) + block)   # WFST_FUZZ_SEED: other campaigns
-    n_cases = n_lat = n_exact = n_ref_same = n_ref_diff = n_partial = n_tied = 0
+    n_cases = n_lat = n_exact = n_ref_same = n_ref_diff = n_partial = n_tied = n_det = 0
+    det_lib = pyoracle.build_det_host()
     for case in range(12):
         n_states = int(rng.integers(4, 70))
         n_labels = int(rng.integers(3, 12))
@@ -91,6 +92,20 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         dec.finalize()
         best = dec.best_paths()
         nb = dec.nbest(4)
+        # the same utterances through BEST-PATH decoders: fused epsilon closures where the graph allows them (pseudo
+        # arcs, no closure pass), and the plain closure pass on a graph loaded without them
+        best_bp = []
+        for fuse in (1, 0):
+            g2 = graph if fuse else G.wfstdec.Graph.load(path, options=G.wfstdec.GraphOptions(fuse_closures=0))
+            d2 = G.wfstdec.BatchDecoder(g2, G.gpu_config(cd), len(mats), max_frames=64, max_tokens_per_frame=4096, arena_tokens=1 << 16)
+            d2.init()
+            for r in sorted(set(list(range(7, max(lens), 7)) + [max(lens)])):
+                d2.advance([t.data_ptr() for t in dev], [min(r, T) for T in lens], n_labels + 1)
+            d2.finalize()
+            best_bp.append(d2.best_paths())
+            d2.free()
+            if not fuse:
+                g2.free()
         for i, x in enumerate(mats):
             what = "block %d case %d utt %d (states %d, T %d, beam %.2f, lattice_beam %.2f)" % (
                 block, case, i, n_states, lens[i], cd["beam"], cd["lattice_beam"])
@@ -107,6 +122,9 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
             if o.extra["ties"] == 0:
                 assert np.array_equal(best[i]["words"], o.words) and np.array_equal(best[i]["tids"], o.tids), what
                 assert np.array_equal(bits(best[i]["graph"]), bits(o.path_graph)) and np.array_equal(bits(best[i]["ac"]), bits(o.path_ac)), what
+                for kind, bb in zip(("fused", "plain"), best_bp):
+                    assert np.array_equal(bb[i]["words"], o.words) and np.array_equal(bb[i]["tids"], o.tids), what + " best-path decoder, " + kind
+                    assert np.array_equal(bits(bb[i]["graph"]), bits(o.path_graph)) and np.array_equal(bits(bb[i]["ac"]), bits(o.path_ac)), what + " " + kind
                 n_exact += 1
                 same_as_ref = np.array_equal(o.tids, ref_mode.tids) and np.array_equal(o.words, ref_mode.words)
                 n_ref_same += int(same_as_ref)
@@ -131,6 +149,24 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
                 assert np.array_equal(nodes(L), nodes(O)), what + " lattice states"
                 assert np.array_equal(L.labelled_arcs(), O.labelled_arcs()), what + " lattice arcs"
                 n_lat += 1
+                # GetLattice: the determinized lattice, device vs the same algorithm compiled for the host (itself pinned to the
+                # reference's determinizer, tests/test_determinize_host.py); small lattices only -- the unpruned determinizer is
+                # exponential on dense-epsilon lattices (a refusal for capacity is then the right answer on both sides)
+                if L.n_states <= 80 and len(L.a_src) <= 200 and n_det < 5:
+                    from test_gpu_determinize import as_det
+
+                    rc, H = pyoracle.det_host_run(det_lib, L, cap_scale=2)
+                    try:
+                        dd = dec.determinized_lattice(i)
+                    except G.wfstdec.WfstError as e:
+                        assert e.code == -4, what   # (the device's workspace is the larger one: a refusal there implies one here)
+                        assert rc != 0, what + " determinizer refused on the device only"
+                        dd = None
+                    if rc == 0 and dd is not None:
+                        D = as_det(dd)
+                        assert [D.n_states, int(D.st_final.sum())] == [H.n_states, int(H.st_final.sum())], what + " determinized counts"
+                        assert np.array_equal(D.arc_multiset(), H.arc_multiset()), what + " determinized arcs"
+                        n_det += 1
                 assert len(nb[i]) >= 1, what
                 # GetBestPath reports, among parallel arcs, the first surviving forward link -- not
                 # necessarily the cheapest (deviation 4); the n-best is the true minimum
@@ -142,7 +178,7 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         dec.free()
         oracle.free_graph(ho)
         graph.free()
-    assert n_cases >= 12 and n_lat >= 6 and n_exact >= 6 and n_partial >= 6
+    assert n_cases >= 12 and n_lat >= 6 and n_exact >= 6 and n_partial >= 6 and n_det >= 3
     assert n_tied <= max(1, n_cases // 20), "%d of %d utterances with an exact tie on the best path" % (n_tied, n_cases)
     if block < 4:
         assert n_ref_diff <= 2 and n_ref_same >= 6, (n_ref_same, n_ref_diff)  # the reference's own result: nearly always the same
