@@ -2247,7 +2247,9 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   int32_t *ch = chain + (size_t)bi * cap;
   const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
   __shared__ int s_t, s_need, s_lo, s_hi, s_found;
+  __shared__ float s_extra0;   // extra cost of the best path's tokens after FinalizeDecoding (0 except in biglm, below)
   if (tid == 0) {
+    s_extra0 = 0.0f;
     for (int w = 1; w < kBpThreads / 64; ++w) {
       best_all = s_all[w] < best_all ? s_all[w] : best_all;
       best_fin = s_fin[w] < best_fin ? s_fin[w] : best_fin;
@@ -2261,6 +2263,10 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
       const float fbc = o2f((uint32_t)(best_wf >> 32));
       const float own = (best_fin != ~0ull) ? o2f((uint32_t)(best_fin >> 32)) : (o2f((uint32_t)(best_all >> 32)) + 0.0f);
       if ((own - fbc) > D.lattice_beam) s_t = -1;
+      // final_best_cost ranges over non-final tokens too (biglm.h:186-188), so the best final token -- and with it every
+      // token of its path, whose links to their successors cost nothing extra -- carries this extra cost, and a parallel
+      // arc survives the final pruning only with it counted (the hop loop below)
+      s_extra0 = own - fbc;
     }
     s_len = 0;
   }
@@ -2329,6 +2335,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   // forward links of frame f have met PruneForwardLinks iff a PruneActiveTokens pass started at
   // NumFramesDecoded() = m >= f+1 (base-inl.h:660-661, 445-476) or FinalizeDecoding ran
   const int m_last = ((nd - 1) / D.prune_interval) * D.prune_interval;
+  const float extra0 = s_extra0;
   for (int pos = tid; pos < len; pos += kBpThreads) {
     const int t = ch[cap - len + pos];
     const int4 T = tok[t];
@@ -2383,7 +2390,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
       const float alt_ac = eps ? 0.f : -llrow[B.x];
       const float alt_tot = eps ? cb + alt_g : (cb + alt_ac) + alt_g;
       if (!(alt_tot < cut[fr])) continue;  // link never created
-      if (pruned_once && (0.0f + (alt_tot - ct)) > D.lattice_beam) continue;  // base-inl.h:524-532
+      if (pruned_once && ((ctl->finalized ? extra0 : 0.0f) + (alt_tot - ct)) > D.lattice_beam) continue;  // base-inl.h:524-532
       chosen = a;
       break;
     }

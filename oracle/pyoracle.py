@@ -116,7 +116,7 @@ class _Base:
             n_tid = int(tid2pdf.shape[0] - 1)
         else:
             n_tid = stride - 1
-        max_path = 4 * T + 64
+        max_path = 16 * T + 256   # hops: T emitting + the epsilon hops between them (dense-epsilon graphs: several per frame)
         pi = np.zeros(max_path, np.int32)
         po = np.zeros(max_path, np.int32)
         pg = np.zeros(max_path, np.float32)
@@ -146,6 +146,8 @@ class _Base:
             _ip(fn), _fp(fb), int(dump_frame), _ip(ds), _fp(dc), int(dump_cap), C.byref(dn),
             C.byref(nt), C.byref(nl))
         n = n_path.value
+        if n > max_path:
+            raise RuntimeError("best path of %d hops does not fit the binding's %d-hop buffers" % (n, max_path))
         dump = None
         if dump_frame >= 0:
             k = min(dn.value, dump_cap)
@@ -440,7 +442,7 @@ def biglm_decode(dec, graph_handle, cfg, lm1, lm2, loglikes, tid2pdf=None, chunk
         n_tid = int(tid2pdf.shape[0] - 1)
     else:
         n_tid = stride - 1
-    max_path = 4 * T + 64
+    max_path = 16 * T + 256
     pi, po, words, tids = (np.zeros(max_path, np.int32) for _ in range(4))
     pg, pa = np.zeros(max_path, np.float32), np.zeros(max_path, np.float32)
     n_path, n_words, n_tids = C.c_int(0), C.c_int(0), C.c_int(0)
@@ -465,6 +467,8 @@ def biglm_decode(dec, graph_handle, cfg, lm1, lm2, loglikes, tid2pdf=None, chunk
         args.append(ex.ctypes.data_as(C.POINTER(C.c_int64)))
     ok = f(*args)
     n = n_path.value
+    if n > max_path:
+        raise RuntimeError("best path of %d hops does not fit the binding's %d-hop buffers" % (n, max_path))
     r = Result(bool(ok), words[: n_words.value].copy(), tids[: n_tids.value].copy(), float(tot.value), float(lm.value),
                pi[:n].copy(), po[:n].copy(), pg[:n].copy(), pa[:n].copy(), fn, fb, None, nt.value, nl.value)
     if not is_ref:

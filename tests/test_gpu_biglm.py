@@ -25,12 +25,12 @@ pytestmark = pytest.mark.gpu
 lmsynth = importlib.import_module("asr-decoder_amd.lmsynth")
 
 
-def _decode(G, graph, cd, mats, old, new, chunk=0, finalize=True, use_final_probs=True, limits=None, lm_pairs=0, options=None):
+def _decode(G, graph, cd, mats, old, new, chunk=0, finalize=True, use_final_probs=True, limits=None, lm_pairs=0, options=None, trace=False):
     W = G.wfstdec
     lim = limits or dict(max_frames=512, max_tokens_per_frame=32768, arena_tokens=1 << 21)
     dec = W.BatchDecoder(graph, G.gpu_config(cd), len(mats), old_lm=old, new_lm=new, lm_pairs=lm_pairs, options=options, **lim)
     try:
-        return G.decode_batch(graph, cd, mats, chunk=chunk, finalize=finalize, use_final_probs=use_final_probs, dec=dec)
+        return G.decode_batch(graph, cd, mats, chunk=chunk, finalize=finalize, use_final_probs=use_final_probs, dec=dec, trace=trace)
     finally:
         dec.free()
 
@@ -236,3 +236,58 @@ def test_biglm_refusals(gold, synth, tmp_path):
         with pytest.raises(W.WfstError):
             W.Lm.load(q)
             raise AssertionError("corrupt LM file %d was accepted" % i)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_biglm_fuzz_on_random_dense_epsilon_graphs(block, synth, oracle, tmp_path):
+    """Random small graphs of tests/test_gpu_fuzz.py (word labels on epsilon arcs, epsilon chains, parallel arcs,
+    dead ends) with random back-off LM pairs of order 1-3, random beams, binding and non-binding max/min-active,
+    streamed in chunks: GPU == fixed-mode oracle (order-free) bit for bit wherever the oracle saw no exact tie."""
+    import gpu_util as G
+    from test_gpu_fuzz import random_graph
+
+    rng = np.random.default_rng(int(os.environ.get("WFST_FUZZ_SEED", "4321")) + block)
+    n_cases = n_exact = n_tied = 0
+    for case in range(10):
+        n_states = int(rng.integers(4, 60))
+        n_labels = int(rng.integers(3, 12))
+        g = random_graph(synth, rng, n_states, n_labels)
+        gp = str(tmp_path / ("g%d_%d.bin" % (block, case)))
+        g.write(gp)
+        V = 30   # the generator's word labels are below 30
+        old = lmsynth.make_lm(V, int(rng.integers(1, 3)), int(rng.integers(3, 20)), 3, 0, 0, seed=int(rng.integers(1, 1 << 30)))
+        new = lmsynth.make_lm(V, int(rng.integers(1, 4)), int(rng.integers(3, 25)), 3, int(rng.integers(2, 30)), 2, seed=int(rng.integers(1, 1 << 30)))
+        p1, p2 = str(tmp_path / "old.bin"), str(tmp_path / "new.bin")
+        old.to_fsa().write(p1)
+        new.to_fsa().write(p2)
+        graph = G.wfstdec.Graph.load(gp)
+        L1, L2 = G.wfstdec.Lm.load(p1, -1.0), G.wfstdec.Lm.load(p2, 1.0)
+        h = oracle.load_graph(gp)
+        o1, o2 = pyoracle.Lm(oracle, p1, -1.0), pyoracle.Lm(oracle, p2, 1.0)
+        binding = case % 3 == 2
+        cd = dict(beam=float(rng.uniform(4.0, 14.0)), max_active=int(rng.choice([40, 15])) if binding else 1000000,
+                  min_active=int(rng.choice([0, 6])) if binding else 0, lattice_beam=float(rng.uniform(6.0, 30.0)),
+                  prune_interval=int(rng.integers(3, 30)))
+        lens = [int(rng.integers(1, 40)) for _ in range(int(rng.integers(1, 5)))]
+        mats = [rng.normal(-1.5, 1.0, size=(T, n_labels + 1)).astype(np.float32) for T in lens]
+        chunk = int(rng.choice([0, 7]))
+        res = _decode(G, graph, cd, mats, L1, L2, chunk=chunk, limits=dict(max_frames=64, max_tokens_per_frame=8192, arena_tokens=1 << 17))
+        try:
+            oracle.set_order_free(True)
+            want = [pyoracle.biglm_decode(oracle, h, pyoracle.Config(**cd), o1, o2, x, None, chunk=chunk, fixed=True) for x in mats]
+        finally:
+            oracle.set_order_free(False)
+        for i, (r, o) in enumerate(zip(res, want)):
+            what = "block %d case %d utt %d (states %d, T %d, cfg %s)" % (block, case, i, n_states, lens[i], cd)
+            assert o.extra["lm_oob"] == 0, what
+            assert bool(r.ok) == bool(o.ok), what
+            n_cases += 1
+            if o.ok and o.extra["ties"] == 0:
+                _same(r, o, what)
+                n_exact += 1
+            elif o.ok:
+                n_tied += 1
+                assert len(r.tids) == len(o.tids) and abs(r.tot_score - o.tot_score) <= 1e-4 * max(1.0, abs(o.tot_score)), what
+        o1.free(); o2.free(); oracle.free_graph(h)
+        L1.free(); L2.free(); graph.free()
+    assert n_cases >= 10 and n_exact >= 6 and n_tied <= max(1, n_cases // 10), (n_cases, n_exact, n_tied)
