@@ -49,7 +49,7 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
     from test_gpu_lattice import as_raw, nodes
 
     rng = np.random.default_rng(int(os.environ.get("WFST_FUZZ_SEED", "1234")) + block)   # WFST_FUZZ_SEED: other campaigns
-    n_cases = n_lat = n_exact = n_ref_same = n_ref_diff = n_partial = n_tied = n_det = 0
+    n_cases = n_lat = n_exact = n_ref_same = n_ref_diff = n_partial = n_tied = n_det = n_mid = 0
     det_lib = pyoracle.build_det_host()
     for case in range(12):
         n_states = int(rng.integers(4, 70))
@@ -89,6 +89,20 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
                         assert np.array_equal(part[i]["tids"], po.tids) and np.array_equal(part[i]["words"], po.words), "partial at %d" % r
                         assert np.array_equal(bits(part[i]["graph"]), bits(po.path_graph)), "partial at %d" % r
                         n_partial += 1
+                    # the raw lattice mid-utterance (GetRawLattice before FinalizeDecoding, base-inl.h:869-975): whatever the
+                    # PruneActiveTokens passes so far (every prune_interval frames, delta = lattice_beam * prune_scale) have left
+                    try:
+                        oracle.set_order_free(True)
+                        PO = pyoracle.oracle_raw_lattice(oracle, ho, pyoracle.Config(**cd), x[:k], None, finalize=False, use_final_probs=False)
+                    finally:
+                        oracle.set_order_free(False)
+                    dm = dec.raw_lattice(i, False)
+                    assert (dm is not None) == PO.ok, "mid-utterance lattice at %d" % r
+                    if dm is not None:
+                        LM_ = as_raw(dm)
+                        assert np.array_equal(nodes(LM_), nodes(PO)) and np.array_equal(LM_.labelled_arcs(), PO.labelled_arcs()), \
+                            "block %d case %d utt %d: mid-utterance lattice at frame %d (prune_interval %d)" % (block, case, i, r, cd["prune_interval"])
+                        n_mid += 1
         dec.finalize()
         best = dec.best_paths()
         nb = dec.nbest(4)
@@ -178,7 +192,7 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         dec.free()
         oracle.free_graph(ho)
         graph.free()
-    assert n_cases >= 12 and n_lat >= 6 and n_exact >= 6 and n_partial >= 6 and n_det >= 3
+    assert n_cases >= 12 and n_lat >= 6 and n_exact >= 6 and n_partial >= 6 and n_det >= 3 and n_mid >= 6
     assert n_tied <= max(1, n_cases // 20), "%d of %d utterances with an exact tie on the best path" % (n_tied, n_cases)
     if block < 4:
         assert n_ref_diff <= 2 and n_ref_same >= 6, (n_ref_same, n_ref_diff)  # the reference's own result: nearly always the same
