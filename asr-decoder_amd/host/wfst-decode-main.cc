@@ -14,6 +14,11 @@
 //                  lattice is written as an empty one (0 states, start -1).
 //   --determinize  the lattices written are GetLattice's (determinized on the device, base-inl.h:850-866) instead of
 //                  GetRawLattice's
+//   --chunk=N      single-stream only: the streaming caller's shape (OnlineClgLatticeFastDecoder::ProcessData,
+//                  kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:10-48): NumFramesReady() grows by N frames per
+//                  AdvanceDecoding call; after every call the partial result GetBestPath(use_final_probs = false) is
+//                  printed as "KEY@frames word-ids..." (GetBestPathTxt(..., false), :122-137); with --nbest also the
+//                  partial n-best (lattice mode serves GetNbest mid-utterance)
 //   --inflight=K   batch shape only: K batches in flight, each on its own GpuBatchDecoder (own HIP
 //                  stream) driven by its own host thread -- the reference service's model of one
 //                  decoder object per thread (v2-asrbin/v2-asr-service.cc:95-105); the GPU overlaps
@@ -64,16 +69,18 @@ bool ReadUtt(std::ifstream &in, Utt *u) {
 // DecodableInterface over a host matrix: the shape every reference caller has.
 class HostMatrixDecodable : public MatrixDecodable {
  public:
-  explicit HostMatrixDecodable(const Utt &u) : _u(u) {}
+  explicit HostMatrixDecodable(const Utt &u) : _u(u), _ready(u.frames) {}
   float LogLikelihood(int f, int i) override { return _u.m[(size_t)f * _u.cols + i]; }
   bool IsLastFrame(int f) const override { return f == _u.frames - 1; }
-  int NumFramesReady() const override { return _u.frames; }
+  int NumFramesReady() const override { return _ready; }
+  void SetFramesReady(int n) { _ready = std::min(n, _u.frames); }  // streaming: frames that have "arrived"
   int NumIndices() const override { return _u.cols - 1; }
   const float *HostRows() const override { return _u.m.data(); }
   int Stride() const override { return _u.cols; }
 
  private:
   const Utt &_u;
+  int _ready;
 };
 }  // namespace
 
@@ -84,7 +91,7 @@ int main(int argc, char **argv) {
     bool single = false, determinize = false;
     std::string lattice_file, lattice_text;
     long long lattice_links = 1ll << 22;
-    int nbest = 0, inflight = 1;
+    int nbest = 0, inflight = 1, chunk = 0;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
       std::string a = argv[i];
@@ -97,12 +104,13 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 16, "--lattice-links=") == 0) lattice_links = atoll(a.c_str() + 16);
       else if (a.compare(0, 8, "--nbest=") == 0) nbest = atoi(a.c_str() + 8);
       else if (a.compare(0, 11, "--inflight=") == 0) inflight = std::max(1, atoi(a.c_str() + 11));
+      else if (a.compare(0, 8, "--chunk=") == 0) chunk = std::max(0, atoi(a.c_str() + 8));
       else if (a.compare(0, 9, "--lm-old=") == 0) lm_old_file = a.substr(9);
       else if (a.compare(0, 9, "--lm-new=") == 0) lm_new_file = a.substr(9);
       else pos.push_back(a);
     }
     if (pos.size() < 3) {
-      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream] [--inflight=K] [--nbest=N] [--lattice-out=FILE] [--determinize] "
+      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream [--chunk=N]] [--inflight=K] [--nbest=N] [--lattice-out=FILE] [--determinize] "
                    "[--lattice-text=FILE] [--lattice-links=N] [--lm-old=FILE --lm-new=FILE] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
       return 1;
     }
@@ -199,7 +207,34 @@ int main(int argc, char **argv) {
       for (const Utt &u : utts) {
         HostMatrixDecodable decodable(u);
         decode.InitDecoding();
-        decode.AdvanceDecoding(&decodable);
+        if (chunk > 0) {  // the service's loop: data arrives, AdvanceDecoding, partial result
+          for (int ready = chunk; ; ready += chunk) {
+            decodable.SetFramesReady(ready);
+            decode.AdvanceDecoding(&decodable);
+            if (ready >= u.frames) break;
+            Lattice part;
+            std::vector<int> w, ph;
+            float tot = 0, lm = 0;
+            out << u.key << "@" << decode.NumFramesDecoded();
+            if (decode.GetBestPath(&part, false) && LatticeToVector(part, w, ph, tot, lm))
+              for (size_t k = 0; k < w.size(); ++k) out << " " << w[k];
+            out << "\n";
+            if (nbest > 0) {
+              std::vector<Lattice> paths;
+              decode.GetNbest(paths, nbest);
+              for (size_t k = 0; k < paths.size(); ++k) {
+                std::vector<int> nw, nph;
+                float t2 = 0, l2 = 0;
+                LatticeToVector(paths[k], nw, nph, t2, l2);
+                out << u.key << "@" << decode.NumFramesDecoded() << "-" << (k + 1);
+                for (size_t q = 0; q < nw.size(); ++q) out << " " << nw[q];
+                out << "\n";
+              }
+            }
+          }
+        } else {
+          decode.AdvanceDecoding(&decodable);
+        }
         decode.FinalizeDecoding();
         Lattice best;
         bool ok = decode.GetBestPath(&best);

@@ -225,3 +225,50 @@ def test_cli_biglm_matches_the_fixed_mode_oracle(mode, synth, oracle, tmp_path):
     o1.free()
     o2.free()
     oracle.free_graph(h)
+
+
+@pytest.mark.parametrize("lattice", [False, True])
+def test_cli_streaming_chunks_with_partial_results(lattice, synth, oracle, tmp_path):
+    """--single-stream --chunk=N: the service's caller shape (ProcessData: frames arrive, AdvanceDecoding through the
+    DecodableInterface, GetBestPathTxt(use_final_probs = false) after every chunk, kaldi-online-nnet3-my-decoder.cc:10-48,
+    122-137) through the C++ mirror.  Every partial line equals the oracle's partial best path at that frame count; the
+    final lines equal the unchunked decode.  In lattice mode (--nbest) the partial n-best is served too and its first
+    entry carries the partial best path's words whenever a final state is not reachable yet (no final-probs either way)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m = synth.default_tid2pdf(600)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=12\n--max-active=1000000\n--min-active=0\n--lattice-beam=6\n--prune-interval=10\n")
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=6.0, prune_interval=10)
+    T = [83, 45, 7]
+    mats = [synth.make_loglikes(g, t, 300, m, seed=300 + i, mu=-2.2)[0] for i, t in enumerate(T)]
+    with open(tmp_path / "ll.bin", "wb") as f:
+        for i, x in enumerate(mats):
+            key = ("utt%03d" % i).encode()
+            f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
+    args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--single-stream", "--chunk=16"] + (["--nbest=3"] if lattice else [])
+    p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l.split() for l in p.stdout.strip().splitlines()]
+    partial = {l[0]: [int(w) for w in l[1:]] for l in lines if re.fullmatch(r"utt\d+@\d+", l[0])}
+    part_nb = {l[0]: [int(w) for w in l[1:]] for l in lines if re.fullmatch(r"utt\d+@\d+-\d+", l[0])}
+    final = {l[0]: [int(w) for w in l[1:]] for l in lines if re.fullmatch(r"utt\d+", l[0])}
+    h = oracle.load_graph(gpath)
+    n_part = 0
+    try:
+        for i, x in enumerate(mats):
+            k = "utt%03d" % i
+            assert final[k] == oracle.decode(h, pyoracle.Config(**cd), x, m).words.tolist(), k
+            for r in range(16, T[i], 16):
+                o = oracle.decode(h, pyoracle.Config(**cd), x[:r], m, finalize=False, use_final_probs=False)
+                assert o.extra["ties"] == 0
+                assert partial["%s@%d" % (k, r)] == o.words.tolist(), (k, r)
+                n_part += 1
+                if lattice:
+                    assert "%s@%d-1" % (k, r) in part_nb, (k, r)
+            assert "%s@%d" % (k, T[i]) not in partial   # the last chunk is followed by FinalizeDecoding, not by a partial result
+    finally:
+        oracle.free_graph(h)
+    assert n_part == 5 + 2 and (not lattice or len(part_nb) >= n_part)
