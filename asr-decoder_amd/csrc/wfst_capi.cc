@@ -157,7 +157,7 @@ struct wfst_decoder {
   const float **p_ll = nullptr;
   ChanCtl *p_ctl = nullptr;
   // best-path output buffers (device), grown on demand
-  DevBuf<int32_t> bp_il, bp_ol, bp_n, bp_chain;
+  DevBuf<int32_t> bp_chain;
   DevBuf<NbEntry> nb_list;  // n-best scratch, allocated by the first wfst_decoder_get_nbest
   DevBuf<int32_t> nb_scratch, nb_out_i;
   DevBuf<float> nb_out_f;
@@ -170,7 +170,6 @@ struct wfst_decoder {
   struct DetLattice { int32_t n_states = 0, n_proper = 0, err = 0; std::vector<int4> a; std::vector<float2> w; };
   std::vector<DetLattice> det_cache;
   std::vector<char> det_cached;
-  DevBuf<float> bp_g, bp_ac;
   // host-fed log-likelihood history (advance_host)
   hipStream_t copy_stream = nullptr;  // host -> device uploads of advance_host
   // pruned lattices fetched from the device (lattice mode): filled for ALL finalized channels by the
@@ -179,6 +178,9 @@ struct wfst_decoder {
   std::vector<std::vector<LatArc> > lat_cache_arc;
   std::vector<char> lat_cached;
   char *lat_pin = nullptr;  // pinned staging for that fetch
+  DevBuf<int32_t> bp_all;   // GetBestPath: {n_hops | ilabel | olabel | graph | acoustic} of the listed channels, one D2H copy
+  char *bp_pin = nullptr;   // its pinned staging
+  size_t bp_pin_bytes = 0;
   size_t lat_pin_bytes = 0;
   std::vector<int32_t> lat_cache_nd;
   std::vector<float *> hist_dev;
@@ -213,6 +215,7 @@ struct wfst_decoder {
     if (stream) (void)hipStreamSynchronize(stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (lat_pin) (void)hipHostFree(lat_pin);
+    if (bp_pin) (void)hipHostFree(bp_pin);
     for (float *p : hist_dev)
       if (p) (void)hipFree(p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -227,8 +230,7 @@ struct wfst_decoder {
     det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_il.release(); bp_ol.release(); bp_n.release(); bp_chain.release(); bp_g.release();
-    bp_ac.release();
+    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -1359,25 +1361,36 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
       return fail(WFST_E_STATE, "You cannot call FinalizeDecoding() and then GetBestPath with use_final_probs == false");
   }
   const size_t need = (size_t)cnt * (size_t)cap;
-  if (d->bp_il.n < need) {
+  // one device block {n_hops[cnt] (padded to 4 words) | ilabel | olabel | graph | acoustic} -> one copy into pinned
+  // host memory -> the caller's arrays (five copies into pageable memory cost five staging round trips)
+  const size_t head = ((size_t)cnt + 3) & ~(size_t)3, words = head + 4 * need;
+  if (d->bp_all.n < words || d->bp_chain.n < need) {
     HIP_TRY(hipStreamSynchronize(d->stream));
-    HIP_TRY(d->bp_il.alloc(need));
-    HIP_TRY(d->bp_ol.alloc(need));
+    HIP_TRY(d->bp_all.alloc(words));
     HIP_TRY(d->bp_chain.alloc(need));
-    HIP_TRY(d->bp_g.alloc(need));
-    HIP_TRY(d->bp_ac.alloc(need));
   }
-  if (d->bp_n.n < (size_t)cnt) HIP_TRY(d->bp_n.alloc((size_t)d->n_channels));
-  launch_best_path(d->D, dev, cnt, use_final_probs ? 1 : 0, cap, d->bp_il.p, d->bp_ol.p, d->bp_g.p, d->bp_ac.p,
-                   d->bp_n.p, d->bp_chain.p, d->stream);
+  if (d->bp_pin_bytes < words * 4) {
+    if (d->bp_pin) (void)hipHostFree(d->bp_pin);
+    d->bp_pin = nullptr;
+    d->bp_pin_bytes = 0;
+    HIP_TRY(hipHostMalloc((void **)&d->bp_pin, words * 4, hipHostMallocDefault));
+    d->bp_pin_bytes = words * 4;
+  }
+  int32_t *dn = d->bp_all.p, *dil = dn + head, *dol = dil + need;
+  float *dg = reinterpret_cast<float *>(dol + need), *dac = dg + need;
+  launch_best_path(d->D, dev, cnt, use_final_probs ? 1 : 0, cap, dil, dol, dg, dac, dn, d->bp_chain.p, d->stream);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(n_hops, d->bp_n.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(hipMemcpyAsync(ilabel, d->bp_il.p, need * 4, hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(hipMemcpyAsync(olabel, d->bp_ol.p, need * 4, hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(hipMemcpyAsync(graph_cost, d->bp_g.p, need * 4, hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(hipMemcpyAsync(acoustic_cost, d->bp_ac.p, need * 4, hipMemcpyDeviceToHost, d->stream));
-  rc = read_ctl(d);
+  HIP_TRY(hipMemcpyAsync(d->bp_pin, d->bp_all.p, words * 4, hipMemcpyDeviceToHost, d->stream));
+  rc = read_ctl(d);   // synchronises the stream
   if (rc != WFST_OK) return rc;
+  {
+    const int32_t *hp = reinterpret_cast<const int32_t *>(d->bp_pin);
+    memcpy(n_hops, hp, (size_t)cnt * 4);
+    memcpy(ilabel, hp + head, need * 4);
+    memcpy(olabel, hp + head + need, need * 4);
+    memcpy(graph_cost, hp + head + 2 * need, need * 4);
+    memcpy(acoustic_cost, hp + head + 3 * need, need * 4);
+  }
   rc = check_ctl_errors(d);
   if (rc != WFST_OK) return rc;
   for (int i = 0; i < cnt; ++i)

@@ -273,10 +273,10 @@ class BatchDecoder:
         tot_score, lm_score (LatticeToVector applied to the hop list)."""
         ch, n = self._chan(channels)
         cnt = n if ch is not None else self.n
-        il = np.zeros((cnt, cap), np.int32)
-        ol = np.zeros((cnt, cap), np.int32)
-        g = np.zeros((cnt, cap), np.float32)
-        ac = np.zeros((cnt, cap), np.float32)
+        il = np.empty((cnt, cap), np.int32)    # (the call fills all of it)
+        ol = np.empty((cnt, cap), np.int32)
+        g = np.empty((cnt, cap), np.float32)
+        ac = np.empty((cnt, cap), np.float32)
         nh = np.zeros(cnt, np.int32)
         _check(lib().wfst_decoder_get_best_path(self.h, _i32(ch), n, int(bool(use_final_probs)), int(cap),
                                                 _i32(il), _i32(ol), _f32(g), _f32(ac), _i32(nh)))
@@ -284,12 +284,14 @@ class BatchDecoder:
         # running sums tot += (g + a), lm += g in forward order are exactly np.cumsum in float32
         # (strictly sequential accumulation); the C entry point wfst_lattice_to_vector does the same
         # per utterance and tests/test_capi_symbols.py holds the two against each other.
-        pos = np.arange(cap)[None, :] < nh[:, None]
-        g = np.where(pos, g, np.float32(0)).astype(np.float32)    # slots past a path's end hold no data
-        ac = np.where(pos, ac, np.float32(0)).astype(np.float32)
+        mx = int(min(cap, max(1, int(nh.max()) if cnt else 1)))   # columns beyond the longest path hold no data
+        il, ol, g, ac = il[:, :mx], ol[:, :mx], g[:, :mx], ac[:, :mx]
+        pos = np.arange(mx)[None, :] < nh[:, None]
+        g = np.where(pos, g, np.float32(0))    # slots past a path's end hold no data
+        ac = np.where(pos, ac, np.float32(0))
         tot = np.cumsum(g + ac, axis=1, dtype=np.float32)
         lm = np.cumsum(g, axis=1, dtype=np.float32)
-        last = np.maximum(nh - 1, 0)
+        last = np.clip(nh - 1, 0, mx - 1)
         rows = np.arange(cnt)
         tot_s, lm_s = tot[rows, last], lm[rows, last]
         wmask = pos & (ol != 0)
