@@ -1915,7 +1915,7 @@ __device__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
 // passed (never on the bench workload).  biglm: several tokens of a frame may sit on the wanted state (one per LM
 // state); all of them are kept and the backpointer stays unresolved.
 // =========================================================================================
-constexpr int kGcNeedSlots = 4096;  // LDS hash of the states wanted in one sweep (power of two)
+constexpr int kGcNeedSlots = 2048;  // LDS hash of the states wanted in one sweep (power of two)
 struct GcShared {
   int32_t key[kGcNeedSlots];    // wanted state (row), -1 empty
   int32_t found[kGcNeedSlots];  // the frame's token on it
