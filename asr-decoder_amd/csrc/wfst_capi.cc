@@ -199,7 +199,7 @@ struct wfst_decoder {
   // optional kernel timing (wfst_decoder_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
-  std::vector<std::pair<int, int>> ev_pairs[3];  // [kernel class] -> (start, stop) event indices
+  std::vector<std::pair<int, int>> ev_pairs[4];  // [kernel class] -> (start, stop) event indices; [3] = replayed expansions (timing experiments)
   size_t ev_used = 0;
   int ev_get() {
     if (ev_used == ev_pool.size()) {
@@ -1152,6 +1152,8 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     for (int s = 0; s < gsteps[g]; ++s) {
       timed(0, st, [&] { launch_expand(d->D, g, par, d->expand_wgs, st); });
       timed(1, st, [&] { launch_insert(d->D, off, cnt, g, par, d->insert_wgs, st); });
+      if (d->D.dbg & 0x800)  // timing experiment: the expansion of this frame once more, stages removed (wfst_kernels.hip expand_body kAbl)
+        timed(3, st, [&] { launch_expand_replay(d->D, g, par, (d->D.dbg >> 8) & 7, d->expand_wgs, st); });
       timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, s + 1 < gsteps[g], g, par ^ 1, st); });
       par ^= 1;
     }
@@ -1505,6 +1507,22 @@ int wfst_decoder_get_profile(wfst_decoder *d, double ms[3], int64_t launches[3])
     ms[k] = tot;
     launches[k] = (int64_t)d->ev_pairs[k].size();
   }
+  return WFST_OK;
+}
+
+int wfst_decoder_get_profile_replay(wfst_decoder *d, double *ms, int64_t *launches) {
+  if (!d || !ms || !launches) return fail(WFST_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(d->device));
+  for (hipStream_t st : d->gstreams) if (st) HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  double tot = 0;
+  for (auto &pr : d->ev_pairs[3]) {
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, d->ev_pool[pr.first], d->ev_pool[pr.second]));
+    tot += t;
+  }
+  *ms = tot;
+  *launches = (int64_t)d->ev_pairs[3].size();
   return WFST_OK;
 }
 

@@ -290,6 +290,7 @@ void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *cha
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s);
+void launch_expand_replay(const DecoderDev &D, int group, int par, int variant, int n_workgroups, hipStream_t s);
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups,
                    hipStream_t s);
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int do_prep,

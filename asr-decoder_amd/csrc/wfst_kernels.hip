@@ -300,8 +300,13 @@ static_assert(kTileTokens == 1 << kLog2TileTokens, "the owner search of expand_b
 // the heaviest one).
 // kBig = biglm mode (the plain instantiation carries none of it).  kFused = the graph's fused epsilon
 // closures are in use (wfst_device.h): a token's pseudo arcs are expanded with its emitting arcs.
-template <bool kBig, bool kFused>
+// kAbl != 0: REPLAY instantiations for timing experiments (wfst_options.debug bits 8..11, launched after the frame's insert
+// kernel on the same frontier): no side effects on the decode -- no counters, no countdown, no plan, next_cutoff kept
+// locally from the frame's seed (TileDesc::pad), records written over the consumed buckets -- and stages removed:
+// bit 0 no counting sort / bucket write, bit 1 no arc / second-slot loads, bit 2 no row-header loads.
+template <bool kBig, bool kFused, int kAbl = 0>
 __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int par) {
+  constexpr bool kReplay = kAbl != 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   FrameCtl *fc = D.fctl + group;
   // (the workgroup's first tile descriptor is read together with the tile count, not after it: one round trip less at
@@ -323,7 +328,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
   __shared__ int s_ticket;
 
   __shared__ int s_last;
-  if (blockIdx.x == 0 && tid == 0) {  // lists of the previous step are consumed
+  if (!kReplay && blockIdx.x == 0 && tid == 0) {  // lists of the previous step are consumed
     fc->total_tiles[par ^ 1] = 0;
     fc->ticket[par ^ 1] = 0;
     fc->n_items[par ^ 1] = 0;
@@ -367,7 +372,9 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       cost[j] = __int_as_float(tk[j].y);
       int nem = 0;
       if (i < n && cost[j] <= cutoff) {  // base-inl.h:315
-        if constexpr (kFused) {
+        if constexpr ((kAbl & 4) != 0) {
+          nem = 2; deg[j] = 4; arcbeg[j] = tk[j].x + 1;   // replay without header loads: a typical row
+        } else if constexpr (kFused) {
           const int4 hdr = D.g.arcs[tk[j].x];  // row header: {(n_emit << 12) | n_eps, -, pseudo arcs, -}
           nem = (int)((uint32_t)hdr.x >> kEpsBits);
           deg[j] = nem + hdr.z;
@@ -415,7 +422,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
     if (tid < 64) s_cnt[tid] = 0;
     __syncthreads();
 
-    float bound = o2f(bound0);
+    float bound = kReplay ? o2f((uint32_t)td.pad) : o2f(bound0);   // replay: from the frame's seed, tightened locally
     const int tok0 = fbegin;  // arena index of the tile's first token
     for (int j0 = 0; j0 < total; j0 += kChunk) {
       int4 rec[kCandPerThread];
@@ -462,12 +469,18 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       int olv[kBig ? kCandPerThread : 1];
       float llv[kCandPerThread];
 #pragma unroll
-      for (int k = 0; k < kCandPerThread; ++k) arcv[k] = D.g.arcs[av[k]];
+      for (int k = 0; k < kCandPerThread; ++k) {
+        if constexpr ((kAbl & 2) != 0) arcv[k] = make_int4(1 + (av[k] & 1023), 0, __float_as_int(0.5f), av[k]);   // replay without row traffic
+        else arcv[k] = D.g.arcs[av[k]];
+      }
       // A pseudo arc's second slot {last arc | flags of the end state, weight of the last arc, hops, weight of the
       // hop before the last}: loaded by every lane alike (an emitting arc's lane re-reads its own slot)
       if constexpr (kFused) {
 #pragma unroll
-        for (int k = 0; k < kCandPerThread; ++k) leafv[k] = D.g.arcs[av[k] + (pseudo[k] ? 1 : 0)];
+        for (int k = 0; k < kCandPerThread; ++k) {
+          if constexpr ((kAbl & 2) != 0) leafv[k] = make_int4(av[k], __float_as_int(0.25f), 1, 0);
+          else leafv[k] = D.g.arcs[av[k] + (pseudo[k] ? 1 : 0)];
+        }
       }
       if constexpr (kBig) {
 #pragma unroll
@@ -543,10 +556,19 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       // base-inl.h:330-333: tighten next_cutoff by the best candidate seen (wave-aggregated)
       const float cand = wave_min_f(tmin) + ab;
       if (cand < bound) {
-        uint32_t old = 0;
-        if (lane == 0) old = atomicMin(&ctl->bound, f2o(cand));
-        old = __shfl(old, 0, 64);
-        bound = fminf(o2f(old), cand);
+        if constexpr (kReplay) {
+          bound = cand;
+        } else {
+          uint32_t old = 0;
+          if (lane == 0) old = atomicMin(&ctl->bound, f2o(cand));
+          old = __shfl(old, 0, 64);
+          bound = fminf(o2f(old), cand);
+        }
+      }
+      if constexpr ((kAbl & 1) != 0) {   // replay without the sort / write stage: the pricing kept alive through a count
+#pragma unroll
+        for (int k = 0; k < kCandPerThread; ++k) nR += (tot[k] < bound) ? (u64)(1 + (rec[k].x & 1)) : 0;
+        continue;
       }
       // counting sort of the survivors by hash partition, in LDS
       int part[kCandPerThread], rank[kCandPerThread];
@@ -573,7 +595,8 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         int g = 0;
         if (cnt) {
           g = atomicAdd(&bucket_cnt[tid], cnt);
-          if (g + cnt > bcap) atomicOr(&ctl->error, kErrBucketFull);
+          if constexpr (kReplay) g = (int)((uint32_t)g % (uint32_t)max(1, bcap - kChunk));   // over the consumed bucket, wherever
+          else if (g + cnt > bcap) atomicOr(&ctl->error, kErrBucketFull);
         }
         s_gbase[tid] = g;
         s_cnt[tid] = 0;
@@ -601,6 +624,10 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       lds_barrier();
       if (tid == 0) dbg_phase(D, 15, tq);
     }
+    }
+    if constexpr (kReplay) {
+      if (nR == 0x7FFFFFFFFFFFull) D.dbg_t[63] = nN + nE + nZf;   // (keeps the counts alive)
+      break;   // one tile per workgroup: the replay grid covers every tile
     }
     nN = wave_sum_u64(nN);
     nE = wave_sum_u64(nE);
@@ -632,6 +659,8 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
 __global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_plain(DecoderDev D, int group, int par) { expand_body<false, false>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_fused(DecoderDev D, int group, int par) { expand_body<false, true>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm(DecoderDev D, int group, int par) { expand_body<true, false>(D, group, par); }
+template <int kAbl>
+__global__ __launch_bounds__(kExpandThreads, 6) void expand_replay_fused(DecoderDev D, int group, int par) { expand_body<false, true, kAbl>(D, group, par); }
 
 // =========================================================================================
 // insert_kernel.  A bucket whose records could overfill the LDS table is processed in 2^k
@@ -1541,7 +1570,7 @@ __device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32
     td.tok_count = min(sh.tile_tokens, n - i * sh.tile_tokens);
     td.cutoff = cutoff;
     td.adaptive_beam = ab;
-    td.pad = 0;
+    td.pad = (int32_t)ctl->bound;   // next_cutoff's seed of the frame (the replay instantiations of the expansion start from it)
     td.llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
     tiles[i] = td;
   }
@@ -2536,6 +2565,20 @@ void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hi
   if (D.big) hipLaunchKernelGGL(expand_kernel_biglm, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
   else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
   else hipLaunchKernelGGL(expand_kernel_plain, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+}
+// timing experiments: the frame's expansion once more, without side effects, with stages removed (expand_body kAbl)
+void launch_expand_replay(const DecoderDev &D, int group, int par, int variant, int n_workgroups, hipStream_t s) {
+  if (!D.fused) return;
+  const dim3 g(n_workgroups), b(kExpandThreads);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((expand_replay_fused<8 | 1>), g, b, 0, s, D, group, par); break;
+    case 2: hipLaunchKernelGGL((expand_replay_fused<8 | 2>), g, b, 0, s, D, group, par); break;
+    case 3: hipLaunchKernelGGL((expand_replay_fused<8 | 3>), g, b, 0, s, D, group, par); break;
+    case 4: hipLaunchKernelGGL((expand_replay_fused<8 | 4>), g, b, 0, s, D, group, par); break;
+    case 6: hipLaunchKernelGGL((expand_replay_fused<8 | 6>), g, b, 0, s, D, group, par); break;
+    case 7: hipLaunchKernelGGL((expand_replay_fused<8 | 7>), g, b, 0, s, D, group, par); break;
+    default: hipLaunchKernelGGL((expand_replay_fused<8>), g, b, 0, s, D, group, par); break;
+  }
 }
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups, hipStream_t s) {
   const size_t lds = (size_t)D.lds_slots * (D.big ? 16 : D.lattice ? 16 : 12);

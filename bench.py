@@ -483,6 +483,10 @@ def main():
     dec.set_profiling(True)
     step()
     prof = dec.profile()
+    if a.debug & 0x800:
+        rms, rn = dec.profile_replay()
+        log("[rank %d] expansion replayed with stages removed (variant %d): %.2f us per launch (%d launches); the real expansion: %.2f us" % (
+            rank, (a.debug >> 8) & 7, 1000.0 * rms / max(rn, 1), rn, 1000.0 * prof["expand_ms"] / max(prof["expand_launches"], 1)))
     dec.set_profiling(False)
 
     regime = ("beam-only pruning (max_active never binds, min_active 0): bit-exact best-path parity with the reference CPU decoder"

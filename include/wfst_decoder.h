@@ -327,6 +327,10 @@ int wfst_decoder_get_profile(wfst_decoder *d, double ms[3], int64_t launches[3])
  * intervals): with several channel groups the launches of different groups overlap, and the sum of their
  * durations (wfst_decoder_get_profile) counts the shared time once per group. */
 int wfst_decoder_get_profile_busy(wfst_decoder *d, double busy_ms[3]);
+/* Timing experiments (wfst_options.debug bit 0x800, variant in bits 8..10): every frame's expansion is launched a second
+ * time without side effects and with stages removed (1 no sort / write, 2 no arc loads, 4 no row-header loads, sums
+ * thereof; 0 = everything); the time of those launches since profiling was enabled. */
+int wfst_decoder_get_profile_replay(wfst_decoder *d, double *ms, int64_t *launches);
 /* The number of channel groups the decoder runs with (wfst_options.channel_groups, resolved). */
 int wfst_decoder_channel_groups(wfst_decoder *d);
 
