@@ -63,6 +63,7 @@ struct wfst_graph {
   int32_t orig_start = 0, orig_final = 0;
   DevBuf<int32_t> arc_ilabel, arc_olabel, arc_src, eps_target_state;
   DevBuf<int4> eps_flat, pseudo;
+  DevBuf<float> pseudo_w;  // weights of every fused closure path, root to leaf (kPseudoDepthMax per path)
   int32_t fused = 0;  // epsilon closures folded into the rows as pseudo arcs (wfst_device.h)
   uint32_t start_eps = 0;
   int32_t n_eps_targets = 0;
@@ -75,6 +76,7 @@ struct wfst_graph {
     g.eps_target_state = eps_target_state.p;
     g.eps_flat = eps_flat.p;
     g.pseudo = pseudo.p;
+    g.pseudo_w = pseudo_w.p;
     g.fused = fused;
     g.start_eps = start_eps;
     g.n_eps_targets = n_eps_targets;
@@ -92,6 +94,7 @@ struct wfst_graph {
     eps_target_state.release();
     eps_flat.release();
     pseudo.release();
+    pseudo_w.release();
   }
 };
 
@@ -539,6 +542,20 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
       }
   }
 
+  // ... and their weights in path order, for the expansion of a path of three hops or more (the sums must run root to leaf)
+  std::vector<float> h_pseudo_w(std::max<size_t>(1, cl.size()) * (size_t)kPseudoDepthMax, 0.0f);
+  for (int32_t st = 0; st < n_states; ++st)
+    for (int32_t pth = 0; pth < cl_cnt[(size_t)st]; ++pth) {
+      const size_t k = (size_t)cl_first[(size_t)st] + pth;
+      int32_t q = pth, dep = cl[k].depth;
+      while (q >= 0 && dep > 0) {   // leaf to root
+        const ClPath &cp = cl[(size_t)cl_first[(size_t)st] + q];
+        h_pseudo_w[k * kPseudoDepthMax + (size_t)(dep - 1)] = cp.w;
+        q = cp.parent;
+        --dep;
+      }
+    }
+
   wfst_graph *g = new wfst_graph();
   g->device = device;
   g->fused = fused ? 1 : 0;
@@ -559,7 +576,8 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
       (e = g->arc_olabel.alloc((size_t)N)) != hipSuccess || (e = g->arc_src.alloc((size_t)N)) != hipSuccess ||
       (e = g->eps_target_state.alloc(h_targets.size())) != hipSuccess ||
       (e = g->eps_flat.alloc(std::max<size_t>(1, h_flat.size()))) != hipSuccess ||
-      (e = g->pseudo.alloc(std::max<size_t>(1, h_pseudo.size()))) != hipSuccess) {
+      (e = g->pseudo.alloc(std::max<size_t>(1, h_pseudo.size()))) != hipSuccess ||
+      (e = g->pseudo_w.alloc(h_pseudo_w.size())) != hipSuccess) {
     delete g;
     return fail(WFST_E_DEVICE, std::string("hipMalloc(graph): ") + hipGetErrorString(e));
   }
@@ -569,6 +587,7 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
       (!h_targets.empty() && hipMemcpy(g->eps_target_state.p, h_targets.data(), h_targets.size() * 4, hipMemcpyHostToDevice) != hipSuccess) ||
       (!h_flat.empty() && hipMemcpy(g->eps_flat.p, h_flat.data(), h_flat.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) ||
       (!h_pseudo.empty() && hipMemcpy(g->pseudo.p, h_pseudo.data(), h_pseudo.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) ||
+      hipMemcpy(g->pseudo_w.p, h_pseudo_w.data(), h_pseudo_w.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(g->arc_ilabel.p, g->ilabel_host.data(), g->ilabel_host.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(WFST_E_DEVICE, "hipMemcpy(graph) failed");
   if (rc == WFST_OK) rc = upload_columns(g, nullptr, 0, &ext);
@@ -621,7 +640,7 @@ int wfst_graph_info(const wfst_graph *g, int32_t *start, int32_t *final_state, i
   if (device_bytes)
     *device_bytes = (int64_t)(g->arcs.bytes() + g->arc_ilabel.bytes() +
                               g->arc_olabel.bytes() + g->arc_src.bytes() + g->eps_target_state.bytes() + g->eps_flat.bytes() +
-                              g->pseudo.bytes());
+                              g->pseudo.bytes() + g->pseudo_w.bytes());
   return WFST_OK;
 }
 

@@ -55,6 +55,7 @@ struct GraphDev {
   const int32_t *eps_target_state;
   const int4 *eps_flat;
   const int4 *pseudo;
+  const float *pseudo_w;   // [paths][kPseudoDepthMax]: a path's epsilon weights root to leaf (paths of three hops or more read them)
   int32_t fused;
   int32_t start, final_state, n_states, n_arcs;
   uint32_t start_eps;   // next_eps word of the start state

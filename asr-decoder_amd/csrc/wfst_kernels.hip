@@ -304,7 +304,9 @@ static_assert(kTileTokens == 1 << kLog2TileTokens, "the owner search of expand_b
 // kernel on the same frontier): no side effects on the decode -- no counters, no countdown, no plan, next_cutoff kept
 // locally from the frame's seed (TileDesc::pad), records written over the consumed buckets -- and stages removed:
 // bit 0 no counting sort / bucket write, bit 1 no arc / second-slot loads, bit 2 no row-header loads.
-template <bool kBig, bool kFused, int kAbl = 0>
+// kTimers: the phase timers of wfst_options.debug & 128 (their own instantiation: the production kernel carries neither
+// the clock reads nor their registers -- it sits at the 80-VGPR limit, where every live value more is a spill).
+template <bool kBig, bool kFused, int kAbl = 0, bool kTimers = false>
 __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int par) {
   constexpr bool kReplay = kAbl != 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -336,7 +338,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
     fc->item_ticket[par ^ 1] = 0;
   }
   const TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap;
-  unsigned long long tq = wall_clock64();
+  unsigned long long tq = kTimers ? wall_clock64() : 0ull;
   for (int t = blockIdx.x; t < total_tiles;) {
     const TileDesc td = t == (int)blockIdx.x ? td_first : tiles[t];
     const int c = td.chan;
@@ -352,7 +354,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
     int4 *bucket = D.bucket + (size_t)c * P * bcap;
     int32_t *bucket_lm = kBig ? D.bucket_lm + (size_t)c * P * bcap : nullptr;
     int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
-    u64 nN = 0, nE = 0, nR = 0, nZf = 0;
+    uint32_t nN = 0, nE = 0, nR = 0, nZf = 0;   // per thread and tile: 32 bits are plenty (and four registers less at the 80-VGPR limit)
     {
     // two adjacent frontier tokens per thread (a tile is 1024 tokens, so the tiles of a whole
     // batch fit the chip's resident workgroup slots in one wave)
@@ -405,7 +407,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       s_arcbeg[tid * kTokPerThread + j] = arcbeg[j];
     }
     __syncthreads();
-    if (tid == 0) dbg_phase(D, 11, tq);
+    if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 11, tq); }
     int wbase = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < kExpandThreads / 64; ++w) {
@@ -510,20 +512,9 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
               } else if (leaf.z == 2) {  // the second slot also holds the weight of the hop before the last
                 t = (t + __int_as_float(leaf.w)) + __int_as_float(leaf.y);
               } else {
-                // three hops or more (rare): the hops' weights from pseudo[], collected leaf to root, added root to leaf
-                float w[kPseudoDepthMax];
-                int4 e = D.g.pseudo[arc.y];
-#pragma unroll
-                for (int u = 0; u < kPseudoDepthMax; ++u) {
-                  w[u] = 0.0f;
-                  if (u < leaf.z) {
-                    w[u] = __int_as_float(e.z);
-                    if (u + 1 < leaf.z) e = D.g.pseudo[e.y];
-                  }
-                }
-#pragma unroll
-                for (int u = kPseudoDepthMax - 1; u >= 0; --u)
-                  if (u < leaf.z) t = t + w[u];
+                // three hops or more (rare): the hops' weights from pseudo_w[], stored root to leaf, added in that order
+                const float *pw = D.g.pseudo_w + (size_t)arc.y * kPseudoDepthMax;
+                for (int u = 0; u < leaf.z; ++u) t = t + pw[u];
               }
               tot[k] = t;
               rec[k] = make_int4(arc.w, __float_as_int(t), kPrevUnresolved, (int)((uint32_t)leaf.x | kEpsRec));
@@ -552,7 +543,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
           tmin = fminf(tmin, tot[k]);
         }
       }
-      if (tid == 0) dbg_phase(D, 12, tq);
+      if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 12, tq); }
       // base-inl.h:330-333: tighten next_cutoff by the best candidate seen (wave-aggregated)
       const float cand = wave_min_f(tmin) + ab;
       if (cand < bound) {
@@ -567,7 +558,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       }
       if constexpr ((kAbl & 1) != 0) {   // replay without the sort / write stage: the pricing kept alive through a count
 #pragma unroll
-        for (int k = 0; k < kCandPerThread; ++k) nR += (tot[k] < bound) ? (u64)(1 + (rec[k].x & 1)) : 0;
+        for (int k = 0; k < kCandPerThread; ++k) nR += (tot[k] < bound) ? (uint32_t)(1 + (rec[k].x & 1)) : 0u;
         continue;
       }
       // counting sort of the survivors by hash partition, in LDS
@@ -581,7 +572,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         }
       }
       lds_barrier();
-      if (tid == 0) dbg_phase(D, 13, tq);
+      if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 13, tq); }
       if (tid < 64) {
         const int cnt = tid < P ? s_cnt[tid] : 0;
         int inc = cnt;
@@ -602,7 +593,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         s_cnt[tid] = 0;
       }
       lds_barrier();
-      if (tid == 0) dbg_phase(D, 14, tq);
+      if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 14, tq); }
 #pragma unroll
       for (int k = 0; k < kCandPerThread; ++k)
         if (part[k] >= 0) {
@@ -611,7 +602,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         }
       lds_barrier();
       const int npass = s_lbase[64];
-      nR += (tid == 0) ? (u64)npass : 0;
+      nR += (tid == 0) ? (uint32_t)npass : 0u;
       for (int q = tid; q < npass; q += kExpandThreads) {
         const int4 r = s_rec[q];
         const int p = part_of(kBig ? hash_big(r.x, s_rec_lm[q]) : hash32(r.x), log2part);
@@ -622,21 +613,19 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         }
       }
       lds_barrier();
-      if (tid == 0) dbg_phase(D, 15, tq);
+      if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 15, tq); }
     }
     }
     if constexpr (kReplay) {
-      if (nR == 0x7FFFFFFFFFFFull) D.dbg_t[63] = nN + nE + nZf;   // (keeps the counts alive)
+      if (nR == 0x7FFFFFFFu) D.dbg_t[63] = nN + nE + nZf;   // (keeps the counts alive)
       break;   // one tile per workgroup: the replay grid covers every tile
     }
-    nN = wave_sum_u64(nN);
-    nE = wave_sum_u64(nE);
-    if constexpr (kFused) nZf = wave_sum_u64(nZf);
-    if (lane == 0 && (nN | nE | nR | nZf)) {
-      atomicAdd(&ctl->cnt_N, nN);
-      atomicAdd(&ctl->cnt_E, nE);
-      if (nR) atomicAdd(&ctl->cnt_rec, nR);
-      if (nZf) atomicAdd(&ctl->cnt_Z, nZf);  // closure paths priced (per candidate, not per token as the reference counts)
+    const u64 wN = wave_sum_u64(nN), wE = wave_sum_u64(nE), wZ = kFused ? wave_sum_u64(nZf) : 0ull;
+    if (lane == 0 && (wN | wE | nR | wZ)) {
+      atomicAdd(&ctl->cnt_N, wN);
+      atomicAdd(&ctl->cnt_E, wE);
+      if (nR) atomicAdd(&ctl->cnt_rec, (u64)nR);
+      if (wZ) atomicAdd(&ctl->cnt_Z, wZ);  // closure paths priced (per candidate, not per token as the reference counts)
     }
     // the channel's last tile plans its insert work items (every thread's bucket atomics have
     // returned: their results were used above)
@@ -650,7 +639,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
     __syncthreads();
     t = s_ticket;
     __syncthreads();
-    if (tid == 0) dbg_phase(D, 16, tq);
+    if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 16, tq); }
   }
 }
 
@@ -659,6 +648,9 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
 __global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_plain(DecoderDev D, int group, int par) { expand_body<false, false>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_fused(DecoderDev D, int group, int par) { expand_body<false, true>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm(DecoderDev D, int group, int par) { expand_body<true, false>(D, group, par); }
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel_plain_timed(DecoderDev D, int group, int par) { expand_body<false, false, 0, true>(D, group, par); }
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel_fused_timed(DecoderDev D, int group, int par) { expand_body<false, true, 0, true>(D, group, par); }
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm_timed(DecoderDev D, int group, int par) { expand_body<true, false, 0, true>(D, group, par); }
 template <int kAbl>
 __global__ __launch_bounds__(kExpandThreads, 6) void expand_replay_fused(DecoderDev D, int group, int par) { expand_body<false, true, kAbl>(D, group, par); }
 
@@ -2562,6 +2554,12 @@ void launch_init(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s
 // chan_off / chan_cnt: the channel group a launch covers (groups run on their own streams so that
 // one group's latency-bound closure overlaps another group's expand / insert)
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s) {
+  if (D.dbg & 128) {   // phase timers: their own instantiations
+    if (D.big) hipLaunchKernelGGL(expand_kernel_biglm_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+    else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+    else hipLaunchKernelGGL(expand_kernel_plain_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+    return;
+  }
   if (D.big) hipLaunchKernelGGL(expand_kernel_biglm, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
   else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
   else hipLaunchKernelGGL(expand_kernel_plain, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
