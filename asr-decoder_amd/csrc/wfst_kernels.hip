@@ -158,7 +158,7 @@ __device__ __forceinline__ uint32_t hash_pair(int s1, int s2) {
 // DiffArpaLm's _state_map.insert + _state_vec.push_back (newlm/diff-lm.h:92-103): the id of the pair
 // (old-LM state, new-LM state), allocating it if new.  One open-addressed array per channel, id =
 // slot; all accesses are agent-scope atomics (workgroups on other XCDs intern into the same table).
-__device__ int pair_intern(const DecoderDev &D, int c, ChanCtl *ctl, int s1, int s2) {
+__device__ __forceinline__ int pair_intern(const DecoderDev &D, int c, ChanCtl *ctl, int s1, int s2) {
   u64 *keys = D.pair_keys + (size_t)c * D.pair_cap;
   const u64 key = (u64)(uint32_t)s1 | ((u64)(uint32_t)s2 << 32);
   const uint32_t mask = (uint32_t)D.pair_cap - 1u;
@@ -178,7 +178,7 @@ __device__ int pair_intern(const DecoderDev &D, int c, ChanCtl *ctl, int s1, int
   atomicOr(&ctl->error, kErrPairsFull);
   return 0;
 }
-__device__ int pair_find(const DecoderDev &D, int c, int s1, int s2) {  // -1: never interned
+__device__ __forceinline__ int pair_find(const DecoderDev &D, int c, int s1, int s2) {  // -1: never interned
   const u64 *keys = D.pair_keys + (size_t)c * D.pair_cap;
   const u64 key = (u64)(uint32_t)s1 | ((u64)(uint32_t)s2 << 32);
   const uint32_t mask = (uint32_t)D.pair_cap - 1u;
@@ -238,7 +238,7 @@ __device__ __forceinline__ void partition_group(int P, int joint_max, int p, int
 // channel << 16 | first partition << 8 | group size.  Run by the workgroup that finishes the
 // channel's last expansion tile (all bucket counters of the channel are final then; they are only
 // ever touched by device-scope atomics, so this wave reads them with atomic loads).
-__device__ void plan_channel(const DecoderDev &D, int c, int group, int par) {
+__device__ __forceinline__ void plan_channel(const DecoderDev &D, int c, int group, int par) {
   const int lane = threadIdx.x & 63;
   FrameCtl *fc = D.fctl + group;
   const int P = D.n_part;
@@ -1021,7 +1021,7 @@ struct BoundaryShared {
 // epsilon arc with an output label moves the LM state (biglm.h:448-456), and the flattened closures
 // (which know nothing of LM states) are not used.
 template <bool kLat, bool kBig>
-__device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, u64 *nZ_out) {
+__device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, u64 *nZ_out) {
   const int tid = threadIdx.x;
   ChanCtl *ctl = D.ctl + c;
   u64 *ekeys = kBig ? D.eps_keys + (size_t)c * D.ecap : nullptr;
@@ -1334,7 +1334,7 @@ __device__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, 
 }
 
 template <bool kLat, bool kBig>
-__device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, BoundaryShared &sh) {
+__device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, BoundaryShared &sh) {
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long tq = wall_clock64();
   const int f = ctl->n_decoded;
@@ -1402,7 +1402,7 @@ __device__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, Boundar
 // wave-parallel prefix scan of the histogram (a serial scan by one thread cost ~7 us per pass).
 constexpr int kSelKeep = 8;
 
-__device__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh) {
+__device__ __forceinline__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh) {
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t keep[kSelKeep];
 #pragma unroll
@@ -1451,7 +1451,7 @@ __device__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh)
 }
 
 template <bool kBig>
-__device__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32_t *target, BoundaryShared &sh,
+__device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32_t *target, BoundaryShared &sh,
                            int group, int par) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float kInf = __builtin_huge_valf();
@@ -1623,7 +1623,7 @@ __device__ __forceinline__ int block_exscan(int v, PruneShared &ps, int *total) 
 // kFinal: FinalizeDecoding.  Returns with extras valid for every frame, dead tokens and links gone, and
 // ctl->pruned_upto = n_decoded.
 template <bool kFinal>
-__device__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
+__device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   ChanCtl *ctl = D.ctl + c;
   const int nd = ctl->n_decoded;
@@ -1944,7 +1944,7 @@ struct GcShared {
 };
 
 template <bool kBig>
-__device__ void gc_pass(const DecoderDev &D, int c, PruneShared &ps, GcShared &gs) {
+__device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared &ps, GcShared &gs) {
   const int tid = threadIdx.x;
   ChanCtl *ctl = D.ctl + c;
   const int nd = ctl->n_decoded;
