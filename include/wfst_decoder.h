@@ -74,7 +74,8 @@ typedef struct wfst_limits {
                                    and moves it down), so that what the arena must hold is the raw tokens of the
                                    frames between two collections plus the surviving history -- a few hundred
                                    frames' worth is plenty for any utterance length; WFST_E_CAPACITY only if one
-                                   collection cannot free half of it.  LATTICE-MODE decoders reclaim it every
+                                   collection cannot free half of it.  A collection costs ~5 ms per million
+                                   tokens in the arena: size it so that collections are rare.  LATTICE-MODE decoders reclaim it every
                                    prune_interval frames (see wfst_config) and need ~3x the tokens
                                    FinalizeDecoding keeps + prune_interval frames of raw tokens.
                                    Default: max_frames x max(256, max_tokens_per_frame / 32), at least 4194304,
