@@ -1936,6 +1936,13 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
 // passed (never on the bench workload).  biglm: several tokens of a frame may sit on the wanted state (one per LM
 // state); all of them are kept and the backpointer stays unresolved.
 // =========================================================================================
+// The arena is collected when less than an eighth of it (and at least two frames' worth of tokens at the per-frame limit:
+// one frame can add max_tokens_per_frame tokens before the next check) is left; a collection is not cheap (~5 ms per
+// million tokens in the arena), so it should be rare.  Arenas too small for that reserve collect when half full.
+__device__ __forceinline__ int gc_base_mark(const DecoderDev &D) {
+  const int64_t reserve = max((int64_t)2 * D.max_tok, D.arena_cap / 8);
+  return (int)(reserve < D.arena_cap / 2 ? D.arena_cap - reserve : D.arena_cap / 2);
+}
 constexpr int kGcNeedSlots = 2048;  // LDS hash of the states wanted in one sweep (power of two)
 struct GcShared {
   int32_t key[kGcNeedSlots];    // wanted state (row), -1 empty
@@ -2104,8 +2111,8 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
       const int nb = remap[(uint32_t)b];
       ctl->best_next = nb >= 0 ? ((b & 0xFFFFFFFF00000000ull) | (uint32_t)nb) : ~0ull;
     }
-    // next collection: halfway between what survived and the capacity
-    ctl->lat_arcs = new_end + (int)((D.arena_cap - new_end) / 2);   // (best-path decoders: the collection mark)
+    // next collection: at the usual mark, or -- when much survived -- halfway between what survived and the capacity
+    ctl->lat_arcs = max(gc_base_mark(D), new_end + (int)((D.arena_cap - new_end) / 2));   // (best-path decoders: the collection mark)
     ctl->lat_toks += 1;                                             // (                    collections so far)
     if (ps.err) ctl->error |= kErrArenaFull;  // never expected: a survivor whose predecessor was not marked
   }
@@ -2136,7 +2143,7 @@ __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_
     const int nd = ctl->n_decoded;
     if (do_prep && D.remap && nd > 0 && nd < target[c] && ctl->error == 0 && !ctl->finalized && nd < D.max_frames) {
       const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
-      const int mark = ctl->lat_arcs > 0 ? ctl->lat_arcs : (int)(D.arena_cap / 2);
+      const int mark = ctl->lat_arcs > 0 ? ctl->lat_arcs : gc_base_mark(D);
       if (foff[nd + 1] > mark) gc_pass<kBig>(D, c, ps, gs);
     }
     __syncthreads();
