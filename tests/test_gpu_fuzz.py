@@ -49,7 +49,7 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
     from test_gpu_lattice import as_raw, nodes
 
     rng = np.random.default_rng(int(os.environ.get("WFST_FUZZ_SEED", "1234")) + block)   # WFST_FUZZ_SEED: other campaigns
-    n_cases = n_lat = n_exact = n_ref_same = n_ref_diff = n_partial = n_tied = n_det = n_mid = 0
+    n_cases = n_lat = n_exact = n_ref_same = n_ref_diff = n_partial = n_tied = n_det = n_mid = n_gc = 0
     det_lib = pyoracle.build_det_host()
     for case in range(12):
         n_states = int(rng.integers(4, 70))
@@ -111,12 +111,15 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         best_bp = []
         for fuse in (1, 0):
             g2 = graph if fuse else G.wfstdec.Graph.load(path, options=G.wfstdec.GraphOptions(fuse_closures=0))
-            d2 = G.wfstdec.BatchDecoder(g2, G.gpu_config(cd), len(mats), max_frames=64, max_tokens_per_frame=4096, arena_tokens=1 << 16)
+            # (a small arena: the longer utterances have their tokens collected a few times on the way -- gc_pass on graphs
+            # whose frames are full of unresolved epsilon backpointers)
+            d2 = G.wfstdec.BatchDecoder(g2, G.gpu_config(cd), len(mats), max_frames=64, max_tokens_per_frame=128, arena_tokens=700)
             d2.init()
             for r in sorted(set(list(range(7, max(lens), 7)) + [max(lens)])):
                 d2.advance([t.data_ptr() for t in dev], [min(r, T) for T in lens], n_labels + 1)
             d2.finalize()
             best_bp.append(d2.best_paths())
+            n_gc += sum(d2.stats(c)["collections"] for c in range(len(mats)))
             d2.free()
             if not fuse:
                 g2.free()
@@ -192,7 +195,7 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         dec.free()
         oracle.free_graph(ho)
         graph.free()
-    assert n_cases >= 12 and n_lat >= 6 and n_exact >= 6 and n_partial >= 6 and n_det >= 3 and n_mid >= 6
+    assert n_cases >= 12 and n_lat >= 6 and n_exact >= 6 and n_partial >= 6 and n_det >= 3 and n_mid >= 6 and n_gc >= 4
     assert n_tied <= max(1, n_cases // 20), "%d of %d utterances with an exact tie on the best path" % (n_tied, n_cases)
     if block < 4:
         assert n_ref_diff <= 2 and n_ref_same >= 6, (n_ref_same, n_ref_diff)  # the reference's own result: nearly always the same
