@@ -40,3 +40,42 @@ def refdec():
     if not os.path.exists(pyoracle.REF_SO):
         pytest.skip("oracle/_ref/libref_decoder.so not built (reference tree absent)")
     return pyoracle.RefDecoder()
+
+
+def _campaign_options():
+    """Hand-run campaigns: WFST_TEST_OPTIONS="log2_partitions=1,joint_max=64" (and WFST_TEST_GRAPH_OPTIONS="row_align_slots=1")
+    make every decoder / graph a test creates WITHOUT options of its own use these wfst_options / wfst_graph_options: the
+    suite then runs under extreme settings of the scheduling knobs (tiny LDS tables, one partition, grids of 3 workgroups,
+    three channel groups, no hipGraph, packed rows ...).  A test-side switch: the library itself reads no environment."""
+    spec, gspec = os.environ.get("WFST_TEST_OPTIONS"), os.environ.get("WFST_TEST_GRAPH_OPTIONS")
+    if not spec and not gspec:
+        return
+    pkg = importlib.import_module("asr-decoder_amd")
+    W = pkg.wfstdec
+    parse = lambda s: {k: int(v) for k, v in (kv.split("=") for kv in s.split(",") if kv)}
+    if spec:
+        kw = parse(spec)
+        init = W.BatchDecoder.__init__
+
+        def patched(self, *a, **k):
+            if k.get("options") is None:
+                k["options"] = W.Options(**kw)
+            init(self, *a, **k)
+
+        W.BatchDecoder.__init__ = patched
+    if gspec:
+        gkw = parse(gspec)
+        for name in ("load", "from_arrays"):
+            orig = getattr(W.Graph, name)
+
+            def make(orig):
+                def f(*a, **k):
+                    if k.get("options") is None:
+                        k["options"] = W.GraphOptions(**gkw)
+                    return orig(*a, **k)
+                return staticmethod(f)
+
+            setattr(W.Graph, name, make(orig.__func__ if hasattr(orig, "__func__") else orig))
+
+
+_campaign_options()
