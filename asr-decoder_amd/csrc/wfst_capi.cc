@@ -58,6 +58,8 @@ struct wfst_graph {
   int32_t max_col = 0;  // largest log-likelihood column any arc reads
   int32_t max_olabel = 0, min_olabel = 0;  // over all arcs (biglm: the LMs must know every word)
   std::vector<int32_t> ilabel_host;  // original ilabels (re-mapped when tid2pdf changes)
+  std::vector<uint16_t> code_host;   // degree code of the target state of every arc slot (fused rows; wfst_device.h)
+  int32_t packed = 0;                // the arcs' first word = column | code << kColBits (ilabels below 2^20)
   DevBuf<int4> arcs;  // interleaved rows: header + arcs per state
   std::vector<int32_t> pos_host;  // row position of each original state id (sorted)
   int32_t orig_start = 0, orig_final = 0;
@@ -78,6 +80,8 @@ struct wfst_graph {
     g.pseudo = pseudo.p;
     g.pseudo_w = pseudo_w.p;
     g.fused = fused;
+    g.col_mask = packed ? kColMask : 0x7FFFFFFF;
+    g.degcode = (packed && fused) ? 1 : 0;
     g.start_eps = start_eps;
     g.n_eps_targets = n_eps_targets;
     g.start = start;
@@ -306,7 +310,9 @@ static int upload_columns(wfst_graph *g, const int32_t *tid2pdf, int32_t n_tid, 
         col = il;
       }
       if (col < 0) return fail(WFST_E_ARG, "negative log-likelihood column");
+      if (g->packed && col > kColMask) return fail(WFST_E_ARG, "log-likelihood column beyond 2^20 on a graph whose ilabels stay below it");
       max_col = std::max(max_col, col);
+      if (g->packed) col |= (int32_t)((uint32_t)g->code_host[(size_t)a] << kColBits);
     }
     (*ext)[a].x = col;
   }
@@ -432,6 +438,14 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
       next_eps[st] |= (uint32_t)h_targets.size();
     }
   }
+  // degree code of every state (wfst_device.h), carried by the arcs that lead to it; graphs with ilabels of 2^20 and more
+  // keep the plain column word
+  bool packed = true;
+  for (int64_t i = 0; i < n_arcs && packed; ++i) packed = arcs[i].ilabel >= 0 && arcs[i].ilabel <= kColMask;
+  auto code_of = [&](int32_t st) -> uint32_t {
+    return pack_code(states[st].niepsilons, states[st].num_arcs - states[st].niepsilons, (uint32_t)n_pseudo[(size_t)st]);
+  };
+  std::vector<uint16_t> h_code((size_t)N, (uint16_t)kCodeUnknown);
   // pass 2: rows
   std::vector<int4> ext((size_t)N, make_int4(0, -1, 0, 0));
   std::vector<int32_t> h_src((size_t)N, 0), h_il((size_t)N, kHeaderLabel), h_ol((size_t)N, 0);
@@ -457,6 +471,7 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
           memcpy(&v.z, &a.weight, 4);               // weight of the emitting arc
           v.w = pos[cp.target];
           ext[q] = v;
+          h_code[q] = (uint16_t)code_of(cp.target);  // the token of the path's end state
           h_src[q] = pos[s];
           h_il[q] = a.ilabel;                        // same log-likelihood column as the emitting arc
           h_ol[q] = 0;
@@ -479,6 +494,7 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
       memcpy(&v.z, &a.weight, 4);
       v.w = pos[a.nextstate];
       ext[q] = v;
+      h_code[q] = (uint16_t)code_of(a.nextstate);
       h_src[q] = (int32_t)((uint32_t)pos[s] | (i < ne ? 0x80000000u : 0u));
       h_il[q] = a.ilabel;
       h_ol[q] = a.olabel;
@@ -568,6 +584,8 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
   g->max_olabel = max_ol;
   g->min_olabel = min_ol;
   g->ilabel_host.swap(h_il);
+  g->code_host.swap(h_code);
+  g->packed = packed ? 1 : 0;
   g->pos_host.swap(pos);
   g->start_eps = next_eps[start];
   g->n_eps_targets = (int32_t)h_targets.size();
@@ -957,6 +975,15 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.lattice = L.lattice_links > 0 ? 1 : 0;
   D.big = big ? 1 : 0;
   D.fused = (g->fused && !big && L.lattice_links == 0) ? 1 : 0;
+  // degree codes in the tokens (wfst_device.h): fused rows, a packed graph, and an arena whose indices leave 9 bits of a
+  // backpointer free (up to 2^22 tokens: the default 4194304)
+  D.tok_idx_bits = 31;
+  D.degcode = 0;
+  if (D.fused && g->packed) {
+    int bits = 1;
+    while ((1ll << bits) < L.arena_tokens) ++bits;
+    if (31 - bits >= kCodeRestBits) { D.tok_idx_bits = bits; D.degcode = 1; }
+  }
   if (big) {
     D.lm_old = old_lm->view();
     D.lm_new = new_lm->view();

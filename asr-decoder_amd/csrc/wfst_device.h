@@ -57,6 +57,8 @@ struct GraphDev {
   const int4 *pseudo;
   const float *pseudo_w;   // [paths][kPseudoDepthMax]: a path's epsilon weights root to leaf (paths of three hops or more read them)
   int32_t fused;
+  int32_t col_mask;     // log-likelihood column of an arc = its first word & col_mask (kColMask where the degree codes ride above it)
+  int32_t degcode;      // the arcs of the fused rows carry the degree code of their target state (below)
   int32_t start, final_state, n_states, n_arcs;
   uint32_t start_eps;   // next_eps word of the start state
   int32_t n_eps_targets;
@@ -87,6 +89,24 @@ constexpr uint32_t kFlagMask = kFlagOutEps | kFlagEpsTarget;
 constexpr uint32_t kEpsWon = 0x80000000u;         // in a packed eps-table value: won by an epsilon arc
 constexpr uint32_t kEpsOutBit = 0x40000000u;      // in a packed eps-table value: the state has epsilon arcs out
 // token/record flag bits from an arc's next_eps word
+// DEGREE CODE (fused best-path decoders): what a token needs to find its arcs WITHOUT reading its row header first --
+// the state's epsilon arcs (2 bits, <= 3), emitting arcs (4 bits, <= 15) and pseudo arcs (5 bits, <= 31); kCodeUnknown
+// where a count does not fit (the expansion then reads the header, as it always did).  On the graph side it rides in the
+// arc's first word above the log-likelihood column (graphs whose ilabels stay below 2^20); in a candidate record -- and so,
+// verbatim, in the token the insert kernel writes -- in bits nothing else uses: its two low bits in bits 30..31 of the arc
+// word (the closure pass's flags, idle without a closure pass), the rest above the source-token index (arenas of up to
+// 2^22 tokens leave 9 bits), or, for an epsilon arrival, in the unresolved-backpointer sentinel: z = kPrevUnresolved - rest.
+// The row-header loads it saves are a fifth of the expansion (10 of 51 us per launch, measured by replay).
+constexpr int kColBits = 20;
+constexpr int32_t kColMask = (1 << kColBits) - 1;
+constexpr uint32_t kCodeUnknown = 0x7FFu;
+constexpr int kCodeRestBits = 9;   // code >> 2
+__host__ __device__ inline uint32_t pack_code(uint32_t n_eps, uint32_t n_emit, uint32_t n_pseudo) {
+  if (n_eps > 3u || n_emit > 15u || n_pseudo > 31u) return kCodeUnknown;
+  const uint32_t c = n_eps | (n_emit << 2) | (n_pseudo << 6);
+  return c == kCodeUnknown ? kCodeUnknown : c;   // (3, 15, 31) itself reads as unknown: the header path is always right
+}
+
 __host__ __device__ inline uint32_t flags_of(uint32_t next_eps) {
   return (next_eps & kFlagOutEps) | ((next_eps & 0x7FFFFFFFu) ? kFlagEpsTarget : 0u);
 }
@@ -211,6 +231,8 @@ struct DecoderDev {
   FrameCtl *fctl;               // [n_groups]
   TileDesc *tiles;              // [n_groups][tile_cap] tiles of the coming frame
   int32_t tile_cap;
+  int32_t tok_idx_bits;         // bits of a token's backpointer that hold the arena index (31: all of them; less: a degree code above)
+  int32_t degcode;              // tokens and records carry degree codes (fused rows, packed graph, arena small enough)
   int32_t *items;               // [n_groups][item_cap] channel << 16 | first partition << 8 | group size
   int32_t item_cap;
   const float *const *ll_base;  // [n_channels] device pointers to row 0 of each utterance matrix

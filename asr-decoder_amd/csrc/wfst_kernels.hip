@@ -377,10 +377,23 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         if constexpr ((kAbl & 4) != 0) {
           nem = 2; deg[j] = 4; arcbeg[j] = tk[j].x + 1;   // replay without header loads: a typical row
         } else if constexpr (kFused) {
-          const int4 hdr = D.g.arcs[tk[j].x];  // row header: {(n_emit << 12) | n_eps, -, pseudo arcs, -}
-          nem = (int)((uint32_t)hdr.x >> kEpsBits);
-          deg[j] = nem + hdr.z;
-          arcbeg[j] = tk[j].x + 1 + (int)((uint32_t)hdr.x & kEpsMask);
+          // the token's degree code (wfst_device.h): its arcs without a look at the row header
+          uint32_t code = kCodeUnknown;
+          if (D.degcode) {
+            const int zz = tk[j].z;
+            const uint32_t rest = zz >= 0 ? (uint32_t)zz >> D.tok_idx_bits : zz <= kPrevUnresolved ? (uint32_t)(kPrevUnresolved - zz) : (kCodeUnknown >> 2);
+            code = (rest << 2) | ((uint32_t)tk[j].w >> 30);
+          }
+          if (code != kCodeUnknown) {
+            nem = (int)((code >> 2) & 15u);
+            deg[j] = nem + (int)(code >> 6);
+            arcbeg[j] = tk[j].x + 1 + (int)(code & 3u);
+          } else {
+            const int4 hdr = D.g.arcs[tk[j].x];  // row header: {(n_emit << 12) | n_eps, -, pseudo arcs, -}
+            nem = (int)((uint32_t)hdr.x >> kEpsBits);
+            deg[j] = nem + hdr.z;
+            arcbeg[j] = tk[j].x + 1 + (int)((uint32_t)hdr.x & kEpsMask);
+          }
         } else {
           const uint32_t dw = (uint32_t)D.g.arcs[tk[j].x].x;  // row header: (n_emit << 12) | n_eps
           nem = deg[j] = (int)(dw >> kEpsBits);
@@ -489,7 +502,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         for (int k = 0; k < kCandPerThread; ++k) olv[k] = D.g.arc_olabel[av[k]];
       }
 #pragma unroll
-      for (int k = 0; k < kCandPerThread; ++k) llv[k] = llrow[jv[k] >= 0 ? arcv[k].x : 0];
+      for (int k = 0; k < kCandPerThread; ++k) llv[k] = llrow[jv[k] >= 0 ? (arcv[k].x & D.g.col_mask) : 0];
 #pragma unroll
       for (int k = 0; k < kCandPerThread; ++k) {
         tot[k] = kInf;
@@ -523,6 +536,13 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
               tot[k] = base_cost;
               rec[k] = make_int4(arc.w, __float_as_int(base_cost), tok0 + lo[k], (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
               tmin = fminf(tmin, base_cost);
+            }
+            if (D.degcode) {
+              // the degree code of the state arrived at (above the column in the arc's first word) goes into the record: two
+              // bits in place of the closure pass's flags, the rest above the source-token index / in the unresolved sentinel
+              const uint32_t code = (uint32_t)arc.x >> kColBits;
+              rec[k].w = (int)(((uint32_t)rec[k].w & 0x3FFFFFFFu) | (code << 30));
+              rec[k].z = pseudo[k] ? kPrevUnresolved - (int)(code >> 2) : (int)((uint32_t)rec[k].z | ((code >> 2) << D.tok_idx_bits));
             }
             continue;
           }
@@ -1513,9 +1533,9 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
         const int ol = D.g.arc_olabel[ab0 + e];
         int n1, n2;
         const float lm_score = ol != 0 ? lm_step(D, c, blm, ol, &n1, &n2) : 0.0f;
-        tot_score = ((lm_score + bc) + __int_as_float(arc.z)) - llrow[arc.x];
+        tot_score = ((lm_score + bc) + __int_as_float(arc.z)) - llrow[arc.x & D.g.col_mask];
       } else {
-        tot_score = (bc + __int_as_float(arc.z)) - llrow[arc.x];  // base-inl.h:295
+        tot_score = (bc + __int_as_float(arc.z)) - llrow[arc.x & D.g.col_mask];  // base-inl.h:295
       }
       seed = fminf(seed, tot_score);
     }
@@ -1960,6 +1980,7 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
   int32_t *remap = D.remap + (size_t)c * D.arena_cap;   // 0 dead, 1 marked, 2 marked and followed; then new indices
   int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
   const int end = foff[nd + 1];
+  const uint32_t idx_mask = D.tok_idx_bits >= 31 ? 0x7FFFFFFFu : ((1u << D.tok_idx_bits) - 1u);
   // (1) mark: the frontier, then what it reaches
   for (int i = tid; i < end; i += kBT) remap[i] = i >= foff[nd] ? 1 : 0;
   __syncthreads();
@@ -1973,7 +1994,8 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
         if (remap[i] != 1) continue;
         const int4 t = tok[i];
         bool done = true;
-        if (t.z == kPrevUnresolved) {
+        const int zi = t.z >= 0 ? (int)((uint32_t)t.z & idx_mask) : t.z;   // the arena index under a degree code, if any
+        if (t.z <= kPrevUnresolved) {
           const int need = D.g.arc_src[(uint32_t)t.w & kArcMask] & 0x7FFFFFFF;
           // claim a slot for the wanted state (shared by every token that wants it); a full table: next sweep
           uint32_t slot = hash32(need) & (kGcNeedSlots - 1);
@@ -1987,11 +2009,11 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
             }
           }
           if (!done) gs.overflow = 1;
-        } else if (t.z >= lo) {
+        } else if (zi >= lo) {
           // a backpointer on this same frame (an epsilon hop resolved by an earlier collection)
-          if (remap[t.z] == 0) { remap[t.z] = 1; gs.n_new = 1; }
-        } else if (t.z >= 0) {
-          remap[t.z] = 1;   // on the previous frame
+          if (remap[zi] == 0) { remap[zi] = 1; gs.n_new = 1; }
+        } else if (zi >= 0) {
+          remap[zi] = 1;   // on the previous frame
         }
         if (done) remap[i] = 2;
       }
@@ -2026,13 +2048,13 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
         for (int i = lo + tid; i < hi; i += kBT) {
           if (remap[i] != 2) continue;
           const int4 t = tok[i];
-          if (t.z != kPrevUnresolved) continue;
+          if (t.z > kPrevUnresolved) continue;
           const int need = D.g.arc_src[(uint32_t)t.w & kArcMask] & 0x7FFFFFFF;
           uint32_t slot = hash32(need) & (kGcNeedSlots - 1);
           for (int q = 0; q < kGcNeedSlots; ++q) {
             const int k = gs.key[slot];
             if (k == -1) break;
-            if (k == need) { tok[i].z = gs.found[slot]; break; }
+            if (k == need) { tok[i].z = (int)((uint32_t)gs.found[slot] | ((uint32_t)(kPrevUnresolved - t.z) << D.tok_idx_bits)); break; }
             slot = (slot + 1) & (kGcNeedSlots - 1);
           }
         }
@@ -2086,8 +2108,9 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
           rec[u] = tok[i];
           if (side) sw[u] = side[i];
           if (rec[u].z >= 0) {   // predecessor: a survivor of the previous frame (or of this one), already renumbered
-            rec[u].z = remap[rec[u].z];
-            if (rec[u].z < 0) ps.err = 1;
+            const int nz = remap[(uint32_t)rec[u].z & idx_mask];
+            if (nz < 0) ps.err = 1;
+            rec[u].z = (int)((uint32_t)nz | ((uint32_t)rec[u].z & ~idx_mask));   // (the degree code above the index stays)
           }
         }
       }
@@ -2201,6 +2224,25 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
   if (D.big) epsilon_closure<false, true>(D, c, sh, 0, D.beam, &nZ);
   else if (D.lattice) epsilon_closure<true, false>(D, c, sh, 0, D.beam, &nZ);  // ProcessNonemitting(_config._beam)
   else epsilon_closure<false, false>(D, c, sh, 0, D.beam, &nZ);
+  if (D.degcode) {
+    // degree codes (wfst_device.h): the tokens of the start state's closure -- the only ones a closure pass ever creates
+    // for such a decoder -- take theirs from the row headers (the root keeps -1: no code, header path)
+    __syncthreads();
+    const int nf0 = min(sh.nnew, (int)min((int64_t)D.max_tok, D.arena_cap));
+    for (int i = tid; i < nf0; i += blockDim.x) {
+      int4 t = D.tok[(size_t)c * D.arena_cap + i];
+      const int4 hdr = D.g.arcs[t.x];
+      const uint32_t code = pack_code((uint32_t)hdr.x & kEpsMask, (uint32_t)hdr.x >> kEpsBits, (uint32_t)hdr.z);
+      if (t.z == kPrevUnresolved) {
+        t.w = (int)(((uint32_t)t.w & 0x3FFFFFFFu) | (code << 30));
+        t.z = kPrevUnresolved - (int)(code >> 2);
+      } else {
+        t.w = (int)((uint32_t)t.w | (3u << 30));   // the root (z = -1) reads as "no code": its row header is read
+      }
+      D.tok[(size_t)c * D.arena_cap + i] = t;
+    }
+    __syncthreads();
+  }
   if (tid == 0) {
     int nf = sh.nnew;
     if (sh.err || nf > D.max_tok || nf > D.arena_cap) nf = 0;
@@ -2310,7 +2352,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
       if (s_len < cap) ch[cap - 1 - s_len] = t;
       ++s_len;
       s_need = -1;
-      if (T.z == kPrevUnresolved) {
+      if (T.z <= kPrevUnresolved) {
         int lo = 0, hi = nd + 1;  // frame of t: frame_off[f] <= t < frame_off[f+1]
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
@@ -2321,7 +2363,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
         s_need = D.g.arc_src[(uint32_t)T.w & kArcMask] & 0x7FFFFFFF;
         s_found = -1;
       } else {
-        s_t = T.z;
+        s_t = T.z >= 0 ? (int)((uint32_t)T.z & (D.tok_idx_bits >= 31 ? 0x7FFFFFFFu : ((1u << D.tok_idx_bits) - 1u))) : T.z;   // (a degree code may sit above the index)
       }
     }
     __syncthreads();
@@ -2415,7 +2457,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
         if (arc_lm(a, &ls) != tok_lm[t]) continue;  // leads to another (state, LM state) token
         alt_g = __int_as_float(B.z) + ls;
       }
-      const float alt_ac = eps ? 0.f : -llrow[B.x];
+      const float alt_ac = eps ? 0.f : -llrow[B.x & D.g.col_mask];
       const float alt_tot = eps ? cb + alt_g : (cb + alt_ac) + alt_g;
       if (!(alt_tot < cut[fr])) continue;  // link never created
       if (pruned_once && ((ctl->finalized ? extra0 : 0.0f) + (alt_tot - ct)) > D.lattice_beam) continue;  // base-inl.h:524-532
@@ -2432,7 +2474,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
     } else {
       og[pos] = __int_as_float(C.z);
     }
-    oa[pos] = eps ? 0.f : -llrow[C.x];
+    oa[pos] = eps ? 0.f : -llrow[C.x & D.g.col_mask];
   }
 }
 
@@ -2519,7 +2561,7 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
         o.ilabel = eps ? 0 : D.g.arc_ilabel[L.z];
         o.olabel = D.g.arc_olabel[L.z];
         o.graph = __int_as_float(A.z);
-        o.acoustic = eps ? 0.0f : -ll[(size_t)src_frame * D.stride + A.x];
+        o.acoustic = eps ? 0.0f : -ll[(size_t)src_frame * D.stride + (A.x & D.g.col_mask)];
         o.src_frame = src_frame; o.is_eps = eps ? 1 : 0;
         out_arcs[p] = o;
       }

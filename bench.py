@@ -79,7 +79,9 @@ def parse():
     ap.add_argument("--host-feed", action="store_true", help="hand the log-likelihoods over as HOST matrices every step "
                     "(wfst_decoder_advance_host): the PCIe-inclusive rate; never the headline")
     ap.add_argument("--max-tokens", type=int, default=131072, help="wfst_limits.max_tokens_per_frame")
-    ap.add_argument("--arena-per-frame", type=int, default=20000, help="token arena per utterance = frames x this (raise it for wider beams)")
+    ap.add_argument("--arena-per-frame", type=int, default=13900, help="token arena per utterance = frames x this (raise it for wider beams); "
+                    "300 x 13900 stays below 2^22 tokens, where a token's backpointer has room for its state's degree code "
+                    "(wfst_device.h: the expansion then skips the row-header loads); the heaviest utterance of the workload needs 3.4 M")
     ap.add_argument("--lattice-links", type=int, default=0, help="> 0: lattice mode (BASELINE configs[4]): record forward links "
                     "(capacity per utterance), prune by lattice_beam at finalize; the step then also takes the n-best")
     ap.add_argument("--lattice-beam", type=float, default=7.0)

@@ -28,7 +28,7 @@ def big(synth, oracle, tmp_path_factory):
     graph.free()
 
 
-LIM = dict(max_frames=304, max_tokens_per_frame=131072, arena_tokens=300 * 20000)
+LIM = dict(max_frames=304, max_tokens_per_frame=131072, arena_tokens=300 * 13900)   # (<= 2^22 tokens: the tokens carry degree codes)
 CD = dict(beam=13.0, max_active=1000000, min_active=0, lattice_beam=7.0)
 
 
