@@ -75,7 +75,9 @@ typedef struct wfst_limits {
                                    frames between two collections plus the surviving history -- a few hundred
                                    frames' worth is plenty for any utterance length; WFST_E_CAPACITY only if one
                                    collection cannot free half of it.  A collection costs ~5 ms per million
-                                   tokens in the arena: size it so that collections are rare.  LATTICE-MODE decoders reclaim it every
+                                   tokens in the arena: size it so that collections are rare.  Arenas of at most 4194304
+                                   tokens (the default) leave room in a token's backpointer for its state's degree
+                                   code: the expansion then skips the row-header reads (a third of its fetches).  LATTICE-MODE decoders reclaim it every
                                    prune_interval frames (see wfst_config) and need ~3x the tokens
                                    FinalizeDecoding keeps + prune_interval frames of raw tokens.
                                    Default: max_frames x max(256, max_tokens_per_frame / 32), at least 4194304,
