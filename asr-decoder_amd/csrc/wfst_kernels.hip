@@ -329,7 +329,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
   __shared__ int s_rec_lm[kBig ? kChunk : 1];     //        and of each sorted candidate
   __shared__ int s_ticket;
 
-  __shared__ int s_last;
+  __shared__ uint32_t s_stat[4];   // work counters of the tile, summed over the workgroup
   if (!kReplay && blockIdx.x == 0 && tid == 0) {  // lists of the previous step are consumed
     fc->total_tiles[par ^ 1] = 0;
     fc->ticket[par ^ 1] = 0;
@@ -338,6 +338,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
     fc->item_ticket[par ^ 1] = 0;
   }
   const TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap;
+  if (tid < 4) s_stat[tid] = 0;   // (barriers follow before the first use)
   unsigned long long tq = kTimers ? wall_clock64() : 0ull;
   for (int t = blockIdx.x; t < total_tiles;) {
     const TileDesc td = t == (int)blockIdx.x ? td_first : tiles[t];
@@ -640,19 +641,32 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       if (nR == 0x7FFFFFFFu) D.dbg_t[63] = nN + nE + nZf;   // (keeps the counts alive)
       break;   // one tile per workgroup: the replay grid covers every tile
     }
-    const u64 wN = wave_sum_u64(nN), wE = wave_sum_u64(nE), wZ = kFused ? wave_sum_u64(nZf) : 0ull;
-    if (lane == 0 && (wN | wE | nR | wZ)) {
-      atomicAdd(&ctl->cnt_N, wN);
-      atomicAdd(&ctl->cnt_E, wE);
-      if (nR) atomicAdd(&ctl->cnt_rec, (u64)nR);
-      if (wZ) atomicAdd(&ctl->cnt_Z, wZ);  // closure paths priced (per candidate, not per token as the reference counts)
+    // work counters: summed over the workgroup in LDS, then one set of atomics per tile from a wave that has nothing else to
+    // wait for -- every atomic on the channel's control line queues behind the other tiles' (next_cutoff, the countdown)
+    {
+      const uint32_t wN = (uint32_t)wave_sum_u64(nN), wE = (uint32_t)wave_sum_u64(nE), wZ = kFused ? (uint32_t)wave_sum_u64(nZf) : 0u;
+      if (lane == 0) {
+        if (wN) atomicAdd(&s_stat[0], wN);
+        if (wE) atomicAdd(&s_stat[1], wE);
+        if (nR) atomicAdd(&s_stat[2], nR);
+        if (wZ) atomicAdd(&s_stat[3], wZ);
+      }
     }
-    // the channel's last tile plans its insert work items (every thread's bucket atomics have
-    // returned: their results were used above)
-    __syncthreads();
-    if (tid == 0) s_last = atomicSub(&ctl->tiles_left, 1) == 1;
-    __syncthreads();
-    if (s_last && wave == 0) plan_channel(D, c, group, par);
+    // the channel's last tile plans its insert work items.  Every wave's bucket atomics have returned (their results were
+    // used above), so an LDS-only barrier orders them before the countdown; only wave 0 waits for the countdown's answer
+    lds_barrier();
+    if (wave == 1 && lane < 4) {
+      const uint32_t v = s_stat[lane];
+      s_stat[lane] = 0;
+      u64 *dst = lane == 0 ? &ctl->cnt_N : lane == 1 ? &ctl->cnt_E : lane == 2 ? &ctl->cnt_rec : &ctl->cnt_Z;
+      if (v) atomicAdd(dst, (u64)v);   // (cnt_Z: closure paths priced, per candidate, not per token as the reference counts)
+    }
+    if (wave == 0) {
+      int last = 0;
+      if (lane == 0) last = atomicSub(&ctl->tiles_left, 1) == 1;
+      last = __shfl(last, 0, 64);
+      if (last) plan_channel(D, c, group, par);
+    }
     // next tile: the first gridDim.x tiles are taken statically, the rest by ticket
     if (total_tiles <= (int)gridDim.x) break;
     if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(&fc->ticket[par], 1);
