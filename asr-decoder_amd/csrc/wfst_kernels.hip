@@ -677,10 +677,12 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
   }
 }
 
-// The launch bounds' second number (waves per SIMD the kernel must fit) holds the plain and the fused
-// instantiation at 80 VGPRs = 6 waves per SIMD; one register more costs a sixth of the latency hiding.
+// The launch bounds' second number = waves per SIMD the kernel must fit.  The plain instantiation fits 80 VGPRs (6 waves)
+// nearly without spilling; the fused one needs 96 (5 waves per SIMD = 5 workgroups per CU = 1280 resident workgroups, still
+// every tile of a 128-channel frame at once): at 80 it spilled into its candidate loop, and 5 waves without spills beat 6
+// with them by 3 % of the step (22.7 vs 23.5 ms).
 __global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_plain(DecoderDev D, int group, int par) { expand_body<false, false>(D, group, par); }
-__global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_fused(DecoderDev D, int group, int par) { expand_body<false, true>(D, group, par); }
+__global__ __launch_bounds__(kExpandThreads, 5) void expand_kernel_fused(DecoderDev D, int group, int par) { expand_body<false, true>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm(DecoderDev D, int group, int par) { expand_body<true, false>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel_plain_timed(DecoderDev D, int group, int par) { expand_body<false, false, 0, true>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel_fused_timed(DecoderDev D, int group, int par) { expand_body<false, true, 0, true>(D, group, par); }
