@@ -79,9 +79,10 @@ def parse():
     ap.add_argument("--host-feed", action="store_true", help="hand the log-likelihoods over as HOST matrices every step "
                     "(wfst_decoder_advance_host): the PCIe-inclusive rate; never the headline")
     ap.add_argument("--max-tokens", type=int, default=131072, help="wfst_limits.max_tokens_per_frame")
-    ap.add_argument("--arena-per-frame", type=int, default=13900, help="token arena per utterance = frames x this (raise it for wider beams); "
+    ap.add_argument("--arena-per-frame", type=int, default=0, help="token arena per utterance = frames x this (raise it for wider beams); "
                     "300 x 13900 stays below 2^22 tokens, where a token's backpointer has room for its state's degree code "
-                    "(wfst_device.h: the expansion then skips the row-header loads); the heaviest utterance of the workload needs 3.4 M")
+                    "(wfst_device.h: the expansion then skips the row-header loads); the heaviest utterance of rank 0's workload needs 3.4 M. "
+                    "0 = 13900 on one GPU, 20000 on several (other ranks decode other utterances: no rank shall start collecting tokens)")
     ap.add_argument("--lattice-links", type=int, default=0, help="> 0: lattice mode (BASELINE configs[4]): record forward links "
                     "(capacity per utterance), prune by lattice_beam at finalize; the step then also takes the n-best")
     ap.add_argument("--lattice-beam", type=float, default=7.0)
@@ -350,6 +351,8 @@ def main():
     pkg.build.build()
 
     B, T, P = a.batch, a.frames, a.pdfs
+    if a.arena_per_frame <= 0:
+        a.arena_per_frame = 13900 if world == 1 else 20000
     n_tid = 2 * P
     m = synth.default_tid2pdf(n_tid)
     cd = dict(beam=a.beam, max_active=a.max_active, min_active=a.min_active, lattice_beam=a.lattice_beam,
