@@ -806,9 +806,11 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
 
     // pass 1: insert-or-min.  Candidates that lost against the final cutoff are dropped here: the
     // reference keeps those order-dependent extras (base-inl.h:330) but never expands them.
+    // (an item that fits one sweep -- every planned item does -- keeps its records in registers for pass 2)
+    const bool one_sweep = n <= kInsertThreads * kInsertUnroll;
+    int4 r[kInsertUnroll];
+    int rl[kInsertUnroll];
     for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
-      int4 r[kInsertUnroll];
-      int rl[kInsertUnroll];
 #pragma unroll
       for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid, &rl[k]);
 #pragma unroll
@@ -849,15 +851,14 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
     // pass 2: the record that won its state writes the token
     // (lattice mode: an item that fits one sweep -- every planned item does -- keeps each live
     // record's {source token, arc, cost} and LDS slot in registers for pass 3)
-    const bool one_sweep = n <= kInsertThreads * kInsertUnroll;
     int lk_src[kInsertUnroll], lk_arc[kInsertUnroll], lk_cost[kInsertUnroll], lk_slot[kInsertUnroll];
 #pragma unroll
     for (int k = 0; k < kInsertUnroll; ++k) lk_slot[k] = -1;
     for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
-      int4 r[kInsertUnroll];
-      int rl[kInsertUnroll];
+      if (!one_sweep) {
 #pragma unroll
-      for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid, &rl[k]);
+        for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid, &rl[k]);
+      }
 #pragma unroll
       for (int k = 0; k < kInsertUnroll; ++k) {
         bool winner = false;
