@@ -1529,6 +1529,30 @@ int wfst_lattice_to_vector(const int32_t *ilabel, const int32_t *olabel, const f
   return WFST_OK;
 }
 
+int wfst_lattice_to_vector_batch(const int32_t *ilabel, const int32_t *olabel, const float *graph_cost,
+                                 const float *acoustic_cost, const int32_t *n_hops, int32_t n_paths, int32_t cap,
+                                 float *tot_score, float *lm_score, int32_t *n_words, int32_t *n_tids) {
+  if (!ilabel || !olabel || !graph_cost || !acoustic_cost || !n_hops || !tot_score || !lm_score || n_paths < 0 || cap <= 0)
+    return fail(WFST_E_ARG, "bad argument");
+  for (int32_t p = 0; p < n_paths; ++p) {
+    const size_t o = (size_t)p * (size_t)cap;
+    const int32_t n = std::min(std::max(n_hops[p], 0), cap);
+    float tot = 0, lm = 0;   // newfst/lattice-functions.cc:179-217: sequential float sums in forward order
+    int32_t nw = 0, nt = 0;
+    for (int32_t k = 0; k < n; ++k) {
+      nt += ilabel[o + k] != 0;
+      nw += olabel[o + k] != 0;
+      lm += graph_cost[o + k];
+      tot += graph_cost[o + k] + acoustic_cost[o + k];
+    }
+    tot_score[p] = tot;
+    lm_score[p] = lm;
+    if (n_words) n_words[p] = nw;
+    if (n_tids) n_tids[p] = nt;
+  }
+  return WFST_OK;
+}
+
 int wfst_decoder_set_profiling(wfst_decoder *d, int32_t enable) {
   if (!d) return fail(WFST_E_ARG, "NULL decoder");
   HIP_TRY(hipSetDevice(d->device));

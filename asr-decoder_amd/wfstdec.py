@@ -24,7 +24,7 @@ SYMBOLS = [
     "wfst_graph_from_arrays", "wfst_graph_set_tid2pdf", "wfst_graph_info", "wfst_graph_free",
     "wfst_decoder_create", "wfst_decoder_free", "wfst_decoder_init", "wfst_decoder_advance",
     "wfst_decoder_advance_host", "wfst_decoder_finalize", "wfst_decoder_sync",
-    "wfst_decoder_num_frames_decoded", "wfst_decoder_get_best_path", "wfst_lattice_to_vector",
+    "wfst_decoder_num_frames_decoded", "wfst_decoder_get_best_path", "wfst_lattice_to_vector", "wfst_lattice_to_vector_batch",
     "wfst_decoder_get_stats", "wfst_decoder_get_frontier", "wfst_decoder_set_profiling",
     "wfst_decoder_get_profile", "wfst_decoder_get_profile_busy", "wfst_decoder_get_profile_replay", "wfst_decoder_channel_groups", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
@@ -280,27 +280,19 @@ class BatchDecoder:
         nh = np.zeros(cnt, np.int32)
         _check(lib().wfst_decoder_get_best_path(self.h, _i32(ch), n, int(bool(use_final_probs)), int(cap),
                                                 _i32(il), _i32(ol), _f32(g), _f32(ac), _i32(nh)))
-        # LatticeToVector (newfst/lattice-functions.cc:179-217) for all channels at once: the float32
-        # running sums tot += (g + a), lm += g in forward order are exactly np.cumsum in float32
-        # (strictly sequential accumulation); the C entry point wfst_lattice_to_vector does the same
-        # per utterance and tests/test_capi_symbols.py holds the two against each other.
-        mx = int(min(cap, max(1, int(nh.max()) if cnt else 1)))   # columns beyond the longest path hold no data
-        il, ol, g, ac = il[:, :mx], ol[:, :mx], g[:, :mx], ac[:, :mx]
-        pos = np.arange(mx)[None, :] < nh[:, None]
-        g = np.where(pos, g, np.float32(0))    # slots past a path's end hold no data
-        ac = np.where(pos, ac, np.float32(0))
-        tot = np.cumsum(g + ac, axis=1, dtype=np.float32)
-        lm = np.cumsum(g, axis=1, dtype=np.float32)
-        last = np.clip(nh - 1, 0, mx - 1)
-        rows = np.arange(cnt)
-        tot_s, lm_s = tot[rows, last], lm[rows, last]
-        wmask = pos & (ol != 0)
-        tmask = pos & (il != 0)
+        # LatticeToVector (newfst/lattice-functions.cc:179-217) for all channels at once: the float32 running sums
+        # tot += (g + a), lm += g in forward order, by the C entry point (tests/test_capi_symbols.py holds it against
+        # wfst_lattice_to_vector and against numpy's sequential cumsum)
+        tot_s = np.zeros(cnt, np.float32)
+        lm_s = np.zeros(cnt, np.float32)
+        _check(lib().wfst_lattice_to_vector_batch(_i32(il), _i32(ol), _f32(g), _f32(ac), _i32(nh), cnt, int(cap), _f32(tot_s), _f32(lm_s),
+                                                  None, None))
         out = []
         for i in range(cnt):
             k = int(nh[i])
-            out.append(dict(ok=k > 0, ilabel=il[i, :k], olabel=ol[i, :k], graph=g[i, :k], ac=ac[i, :k],
-                            words=ol[i][wmask[i]], tids=il[i][tmask[i]],
+            ili, oli = il[i, :k], ol[i, :k]
+            out.append(dict(ok=k > 0, ilabel=ili, olabel=oli, graph=g[i, :k], ac=ac[i, :k],
+                            words=oli[oli != 0], tids=ili[ili != 0],
                             tot_score=float(tot_s[i]) if k else 0.0, lm_score=float(lm_s[i]) if k else 0.0))
         return out
 

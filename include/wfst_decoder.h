@@ -265,6 +265,13 @@ int wfst_lattice_to_vector(const int32_t *ilabel, const int32_t *olabel, const f
                            int32_t max_words, int32_t *n_words, int32_t *tids, int32_t max_tids,
                            int32_t *n_tids, float *tot_score, float *lm_score);
 
+/* The same for a batch of hop lists laid out as wfst_decoder_get_best_path returns them ([n_paths][cap] arrays, n_hops per
+ * path): tot_score / lm_score of every path (the sequential float sums of LatticeToVector) and the number of words and
+ * transition-ids in it.  Host-only. */
+int wfst_lattice_to_vector_batch(const int32_t *ilabel, const int32_t *olabel, const float *graph_cost,
+                                 const float *acoustic_cost, const int32_t *n_hops, int32_t n_paths, int32_t cap,
+                                 float *tot_score, float *lm_score, int32_t *n_words, int32_t *n_tids);
+
 /* Per-channel work counters since the last init: {frames, N tokens expanded, E emitting arcs
  * traversed, Z epsilon arcs traversed, tokens kept, peak tokens per frame, candidate records
  * bucketed, forward links recorded (lattice mode) / token collections run (best-path mode)}.  N and E follow the

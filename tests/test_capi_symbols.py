@@ -106,6 +106,19 @@ def test_vectorised_lattice_to_vector_equals_c_entry_point(pkg):
     assert np.float32(tot.value).tobytes() == np.float32(t2).tobytes()
     assert np.float32(lm.value).tobytes() == np.float32(l2).tobytes()
     assert list(words[: nw.value]) == list(ol[ol != 0]) and list(tids[: nt.value]) == list(il[il != 0])
+    # the batch form (what wfstdec.BatchDecoder.best_paths calls): three hop lists of different lengths in [3][cap] arrays
+    cap = n + 5
+    nh = np.array([n, 0, 123], np.int32)
+    pad = lambda x: np.stack([np.concatenate([x, np.full(5, 7, x.dtype)])] * 3)
+    IL, OL, GG, AA = pad(il), pad(ol), pad(g), pad(a)
+    ts, ls = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    cw, ct = np.zeros(3, np.int32), np.zeros(3, np.int32)
+    rc = pkg.wfstdec.lib().wfst_lattice_to_vector_batch(f(IL, ctypes.c_int32), f(OL, ctypes.c_int32), f(GG, ctypes.c_float), f(AA, ctypes.c_float),
+                                                        f(nh, ctypes.c_int32), 3, cap, f(ts, ctypes.c_float), f(ls, ctypes.c_float),
+                                                        f(cw, ctypes.c_int32), f(ct, ctypes.c_int32))
+    assert rc == 0 and ts[0].tobytes() == np.float32(t2).tobytes() and ls[0].tobytes() == np.float32(l2).tobytes()
+    assert ts[1] == 0 and ls[1] == 0 and [cw[0], ct[0], cw[1], ct[1]] == [int((ol != 0).sum()), int((il != 0).sum()), 0, 0]
+    assert ts[2].tobytes() == np.cumsum((g[:123] + a[:123]).astype(np.float32), dtype=np.float32)[-1].tobytes()
 
 
 def test_header_is_plain_c(tmp_path):
