@@ -650,7 +650,12 @@ def main():
         # it cannot be collected inside this process, so the stored summary is quoted WITH its origin
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tj):
+        # (the passes were made on the headline workload: any other configuration reports null)
+        headline = (not a.biglm and a.lattice_links == 0 and a.batch == 128 and a.frames == 300 and a.states == 2850000 and
+                    a.beam == 13.0 and a.max_active == 1000000 and a.min_active == 0 and a.workload == "multi")
+        if not headline:
+            traffic_src = "not measured for this configuration (profiles/traffic_latest.json holds the headline workload's passes)"
+        elif os.path.exists(tj):
             try:
                 tjd = json.load(open(tj))
                 traffic = tjd.get(dom + "_bytes_per_launch")
