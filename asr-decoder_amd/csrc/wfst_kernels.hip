@@ -887,7 +887,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
             wslot = slot;
           }
         }
-        if (kLat && in_table) {
+        if (kLat && in_table && !(kFused && ((uint32_t)r[k].w & kEpsRec))) {   // (a fused epsilon arrival is no link: epsilon_links)
           lk_src[k] = r[k].z; lk_arc[k] = (int)((uint32_t)r[k].w & kArcMask); lk_cost[k] = r[k].y; lk_slot[k] = (int)wslot;
         }
         const u64 wm = __ballot(winner);
@@ -908,8 +908,17 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
         // a token on an epsilon-TARGET state registers itself in the channel's direct-mapped
         // epsilon table (so an epsilon arc arriving later meets its cost); a token with epsilon
         // arcs OUT seeds the closure worklist
-        // (fused closures: the epsilon arrivals are candidates like any other; nothing to register or seed)
-        if constexpr (kFused) continue;
+        // (fused closures: the epsilon arrivals are candidates like any other; nothing to register or seed --
+        // except, in lattice mode, the token of an epsilon-target state for the link pass of the closure kernel)
+        if constexpr (kFused) {
+          if constexpr (kLat) {
+            if (winner && (flags & kFlagEpsTarget)) {
+              const int ord = (int)((uint32_t)D.g.arcs[(uint32_t)r[k].w & kArcMask].y & 0x7FFFFFFFu) - 1;
+              if (ord >= 0) etoki[ord] = idx;
+            }
+          }
+          continue;
+        }
         const bool tgt = winner && (flags & kFlagEpsTarget);
         const bool seed = winner && (flags & kFlagOutEps);
         const u64 tm = __ballot(tgt), sm = __ballot(seed);
@@ -977,7 +986,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
           const int4 r = load_rec(i0 + k * kInsertThreads + tid, &rlm);
           bool live = false;
           int dst = 0;
-          if (__int_as_float(r.y) < cutoff) {
+          if (__int_as_float(r.y) < cutoff && !(kFused && ((uint32_t)r.w & kEpsRec))) {
             const uint32_t h = hash_of(r, rlm);
             if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
               uint32_t slot = lds_slot_of(h, log2grp, log2sl);
@@ -1026,6 +1035,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
 __global__ __launch_bounds__(kInsertThreads, 6) void insert_kernel_plain(DecoderDev D, int group, int par) { insert_body<false, false, false>(D, group, par); }
 __global__ __launch_bounds__(kInsertThreads, 6) void insert_kernel_fused(DecoderDev D, int group, int par) { insert_body<false, false, true>(D, group, par); }
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel_lattice(DecoderDev D, int group, int par) { insert_body<true, false, false>(D, group, par); }
+__global__ __launch_bounds__(kInsertThreads) void insert_kernel_lattice_fused(DecoderDev D, int group, int par) { insert_body<true, false, true>(D, group, par); }
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel_biglm(DecoderDev D, int group, int par) { insert_body<false, true, false>(D, group, par); }
 
 // =========================================================================================
@@ -1050,6 +1060,81 @@ struct BoundaryShared {
   int active;
   int tile_tokens;  // tokens per expansion tile of the coming frame (prep_frame)
 };
+
+// Forward links of the epsilon arcs of the frame being built (lattice mode; base-inl.h:421-422), once every token of the
+// frame has its final cost -- after the closure's fixpoint, or, with fused closures, right after the insert launch.
+// toki[] = the channel's direct-mapped epsilon table: the frame's token on each epsilon-target state.
+__device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff) {
+  const int tid = threadIdx.x;
+  int4 *tok = D.tok + (size_t)c * D.arena_cap;
+  const int32_t *toki = D.eps_toki + (size_t)c * D.ecap;
+  // Forward links of the epsilon arcs (base-inl.h:421-422): the reference regenerates a token's
+  // links each time it is re-processed, so what remains are the links computed from its FINAL
+  // cost.  Every token of the frame being built with epsilon arcs out and cost < cutoff emits them.
+  int4 *links = D.links + (size_t)c * D.link_cap;
+  const int n_frame = sh.nnew;
+  // (1) compact the tokens that emit (a few percent of the frame) -- the closure worklists are
+  // free by now and serve as the list -- so that (2) runs its dependent gathers with full waves
+  int32_t *emit = reinterpret_cast<int32_t *>(D.worklist + (size_t)c * 2 * D.wl_cap);
+  if (tid == 0) sh.nemit = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n_frame; i0 += 4 * kBT) {  // 4 independent loads in flight per thread
+    int4 T[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kBT + tid;
+      T[u] = i < n_frame ? tok[base + i] : make_int4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kBT + tid;
+      const bool on = i < n_frame && ((uint32_t)T[u].w & kFlagOutEps) && (__int_as_float(T[u].y) < cutoff);
+      const u64 m = __ballot(on);
+      int wb = 0;
+      if ((tid & 63) == 0 && m) wb = atomicAdd(&sh.nemit, __popcll(m));
+      wb = __shfl(wb, 0, 64);
+      if (on) emit[wb + lane_rank(m)] = i;
+    }
+  }
+  __syncthreads();
+  const int n_emit = sh.nemit;
+  for (int j0 = 0; j0 < n_emit; j0 += kBT) {
+    const int j = j0 + tid;
+    int i = 0, row = 0, neps = 0, npass = 0;
+    float cost = 0.0f;
+    if (j < n_emit) {
+      i = emit[j];
+      const int4 T = tok[base + i];
+      row = T.x;
+      cost = __int_as_float(T.y);
+      neps = (int)((uint32_t)D.g.arcs[row].x & kEpsMask);
+      for (int e = 0; e < neps; ++e) npass += (cost + __int_as_float(D.g.arcs[row + 1 + e].z)) < cutoff;
+    }
+    // one atomicAdd per wave for all its links
+    int ps = npass;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(ps, o, 64);
+      if ((tid & 63) >= o) ps += v;
+    }
+    const int wtot = __shfl(ps, 63, 64);
+    int lb = 0;
+    if ((tid & 63) == 0 && wtot) lb = atomicAdd(&D.ctl[c].link_count, wtot);
+    lb = __shfl(lb, 0, 64);
+    int lp = lb + ps - npass;
+    for (int e = 0; e < neps && npass; ++e) {
+      const int a = row + 1 + e;
+      const int4 arc = D.g.arcs[a];
+      const float tot = cost + __int_as_float(arc.z);
+      if (!(tot < cutoff)) continue;
+      const int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;
+      if ((int64_t)lp < D.link_cap) links[lp] = make_int4(base + i, ld_agent(&toki[ord]), a, __float_as_int(tot));
+      else atomicOr(&sh.err, kErrLinksFull);
+      ++lp;
+    }
+  }
+  __syncthreads();
+}
 
 // ProcessNonemitting to its fixpoint (base-inl.h:383-430) on the channel's direct-mapped epsilon
 // table, then write the arena records of the tokens an epsilon arc created or improved.  On entry
@@ -1278,74 +1363,7 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
   if ((tid & 63) == 0) sh.red64[tid >> 6] = best;
   __syncthreads();  // every read of the table above is done before it is cleared
   if (tid == 0) dbg_phase(D, 2, tq);
-  if (kLat && fits) {
-    // Forward links of the epsilon arcs (base-inl.h:421-422): the reference regenerates a token's
-    // links each time it is re-processed, so what remains are the links computed from its FINAL
-    // cost.  Every token of the frame being built with epsilon arcs out and cost < cutoff emits them.
-    int4 *links = D.links + (size_t)c * D.link_cap;
-    const int n_frame = sh.nnew;
-    // (1) compact the tokens that emit (a few percent of the frame) -- the closure worklists are
-    // free by now and serve as the list -- so that (2) runs its dependent gathers with full waves
-    int32_t *emit = reinterpret_cast<int32_t *>(D.worklist + (size_t)c * 2 * D.wl_cap);
-    if (tid == 0) sh.nemit = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < n_frame; i0 += 4 * kBT) {  // 4 independent loads in flight per thread
-      int4 T[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * kBT + tid;
-        T[u] = i < n_frame ? tok[base + i] : make_int4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * kBT + tid;
-        const bool on = i < n_frame && ((uint32_t)T[u].w & kFlagOutEps) && (__int_as_float(T[u].y) < cutoff);
-        const u64 m = __ballot(on);
-        int wb = 0;
-        if ((tid & 63) == 0 && m) wb = atomicAdd(&sh.nemit, __popcll(m));
-        wb = __shfl(wb, 0, 64);
-        if (on) emit[wb + lane_rank(m)] = i;
-      }
-    }
-    __syncthreads();
-    const int n_emit = sh.nemit;
-    for (int j0 = 0; j0 < n_emit; j0 += kBT) {
-      const int j = j0 + tid;
-      int i = 0, row = 0, neps = 0, npass = 0;
-      float cost = 0.0f;
-      if (j < n_emit) {
-        i = emit[j];
-        const int4 T = tok[base + i];
-        row = T.x;
-        cost = __int_as_float(T.y);
-        neps = (int)((uint32_t)D.g.arcs[row].x & kEpsMask);
-        for (int e = 0; e < neps; ++e) npass += (cost + __int_as_float(D.g.arcs[row + 1 + e].z)) < cutoff;
-      }
-      // one atomicAdd per wave for all its links
-      int ps = npass;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(ps, o, 64);
-        if ((tid & 63) >= o) ps += v;
-      }
-      const int wtot = __shfl(ps, 63, 64);
-      int lb = 0;
-      if ((tid & 63) == 0 && wtot) lb = atomicAdd(&D.ctl[c].link_count, wtot);
-      lb = __shfl(lb, 0, 64);
-      int lp = lb + ps - npass;
-      for (int e = 0; e < neps && npass; ++e) {
-        const int a = row + 1 + e;
-        const int4 arc = D.g.arcs[a];
-        const float tot = cost + __int_as_float(arc.z);
-        if (!(tot < cutoff)) continue;
-        const int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;
-        if ((int64_t)lp < D.link_cap) links[lp] = make_int4(base + i, ld_agent(&toki[ord]), a, __float_as_int(tot));
-        else atomicOr(&sh.err, kErrLinksFull);
-        ++lp;
-      }
-    }
-    __syncthreads();
-  }
+  if (kLat && fits) epsilon_links(D, c, sh, base, cutoff);
   for (int i0 = 0; i0 < nocc; i0 += kBT * kClosureUnroll) {  // the list loads of a thread issued together
     int od[kClosureUnroll];
 #pragma unroll
@@ -1393,9 +1411,15 @@ __device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanC
   __syncthreads();
   if (tid == 0) dbg_phase(D, 0, tq);
   u64 nZ = 0;
-  if (!kLat && !kBig && D.fused) {
+  if (!kBig && D.fused) {
     if (tid == 0) sh.best = ~0ull;  // the frame is complete: its epsilon arrivals went through the insert launch
     __syncthreads();
+    if constexpr (kLat) {
+      // lattice mode: all that is left of ProcessNonemitting are the epsilon links, one flat pass over the frame
+      const bool fits = sh.nnew <= D.max_tok && (int64_t)base + sh.nnew <= D.arena_cap && ctl->error == 0;
+      if (fits) epsilon_links(D, c, sh, base, cutoff);
+      __syncthreads();
+    }
   } else {
     epsilon_closure<kLat, kBig>(D, c, sh, base, cutoff, &nZ);
   }
@@ -2647,6 +2671,7 @@ void launch_expand_replay(const DecoderDev &D, int group, int par, int variant, 
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups, hipStream_t s) {
   const size_t lds = (size_t)D.lds_slots * (D.big ? 16 : D.lattice ? 16 : 12);
   if (D.big) hipLaunchKernelGGL(insert_kernel_biglm, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  else if (D.lattice && D.fused) hipLaunchKernelGGL(insert_kernel_lattice_fused, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
   else if (D.lattice) hipLaunchKernelGGL(insert_kernel_lattice, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
   else if (D.fused) hipLaunchKernelGGL(insert_kernel_fused, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
   else hipLaunchKernelGGL(insert_kernel_plain, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);

@@ -623,7 +623,7 @@ def main():
         # + 8 B hash min-update), 24 B per expanded token (8 B {state,cost} + 8 B arc range + 8 B
         # backpointer/arena write), 24 B per traversed epsilon arc.  Per kernel (DESIGN.md "Roofline
         # accounting"): expand = 20 E + 16 N, insert = 8 E + 8 N, closure = 24 Z.
-        fused = not a.no_fuse and not a.biglm and a.lattice_links == 0
+        fused = not a.no_fuse and not a.biglm and (a.lattice_links == 0 or not (a.debug & 0x1000))
         if fused and do_cpu:
             # fused epsilon closures: the closure's arcs are priced by the expansion (16 B pseudo arc) and merged by the
             # insert launch (8 B hash min-update); Z = the CPU restatement's count (the GPU's own counts one closure

@@ -66,8 +66,11 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
                   lattice_beam=float(rng.uniform(0.5, 8.0)), prune_interval=int(rng.integers(3, 30)))
         lens = [int(rng.integers(1, 45)) for _ in range(int(rng.integers(1, 6)))]
         mats = [rng.normal(-1.5, 1.0, size=(T, n_labels + 1)).astype(np.float32) for T in lens]
+        # the lattice-mode decoder: fused closures + the flat epsilon-link pass on even cases, the iterated closure pass
+        # (wfst_options.debug 0x1000; what graphs without fused rows and the biglm decoder run) on odd ones
+        lat_opt = {} if case % 2 == 0 else {"options": G.wfstdec.Options(debug=0x1000)}
         dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), max_frames=64, max_tokens_per_frame=4096,
-                                     arena_tokens=1 << 16, lattice_links=1 << 18)
+                                     arena_tokens=1 << 16, lattice_links=1 << 18, **lat_opt)
         dev = G.upload(mats)
         dec.init()
         for r in sorted(set(list(range(7, max(lens), 7)) + [max(lens)])):   # streaming chunks of 7 frames
