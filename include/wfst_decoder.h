@@ -104,6 +104,8 @@ typedef struct wfst_options {
   int32_t upload_slice_frames; /* wfst_decoder_advance_host: frames per upload slice, 0 = copy
                                   everything before decoding                                    (48)   */
   int32_t debug;               /* kernel phase timers / ablations: timing experiments only      (0)    */
+                               /* (0x1000: lattice decoders run the iterated epsilon-closure pass instead of
+                                  the fused rows + flat epsilon-link pass; same results, for comparison) */
 } wfst_options;
 
 /* Graph upload choices (NULL / wfst_graph_options_default() = defaults). */
