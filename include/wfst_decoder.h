@@ -117,7 +117,8 @@ typedef struct wfst_graph_options {
   int32_t fuse_closures;       /* fold the epsilon closures into the expansion (pseudo arcs behind
                                   each state's emitting arcs) where the graph allows: no epsilon
                                   cycle, closures of <= 48 paths and <= 8 hops, no negative epsilon
-                                  weight; best-path decoders then run no separate closure pass     (1)    */
+                                  weight; best-path and lattice decoders then run no separate closure
+                                  pass (lattice mode keeps one flat pass that lists the epsilon links) (1)    */
 } wfst_graph_options;
 
 /* Original on-disk / in-memory graph records of the reference format. */
