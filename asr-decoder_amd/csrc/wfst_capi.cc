@@ -132,6 +132,7 @@ struct wfst_decoder {
   const wfst_graph *graph = nullptr;
   int device = 0;
   wfst_config cfg;
+  wfst_limits lim = {0, 0, 0, 0, 0, 0, 0, 0};   // as resolved by create
   int32_t n_channels = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -177,6 +178,9 @@ struct wfst_decoder {
   struct DetLattice { int32_t n_states = 0, n_proper = 0, err = 0; std::vector<int4> a; std::vector<float2> w; };
   std::vector<DetLattice> det_cache;
   std::vector<char> det_cached;
+  std::vector<int32_t> det_live_nd;   // NumFramesDecoded() the cached lattice of a LIVE channel belongs to (-1: none)
+  std::vector<char> det_live_final = std::vector<char>();
+  int32_t det_slots = 0;              // lattices one determinize launch takes (workspace slots)
   // host-fed log-likelihood history (advance_host)
   hipStream_t copy_stream = nullptr;  // host -> device uploads of advance_host
   // pruned lattices fetched from the device (lattice mode): filled for ALL finalized channels by the
@@ -834,8 +838,9 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
       O.insert_workgroups < 1 || O.upload_slice_frames < 0)
     return fail(WFST_E_ARG, "wfst_options field out of range");
   HIP_TRY(hipSetDevice(g->device));
-  wfst_limits L = {0, 0, 0, 0, 0};
+  wfst_limits L = {0, 0, 0, 0, 0, 0, 0, 0};
   if (limits) L = *limits;
+  if (L.det_raw_states < 0 || L.det_raw_arcs < 0 || L.det_workspace_bytes < 0) return fail(WFST_E_ARG, "negative determinizer limit");
   const bool big = old_lm != nullptr || new_lm != nullptr;
   if (big) {
     if (!old_lm || !new_lm) return fail(WFST_E_ARG, "biglm needs both LMs");
@@ -865,6 +870,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   d->graph = g;
   d->device = g->device;
   d->cfg = *cfg;
+  d->lim = L;
   d->n_channels = n_channels;
   if (hip_stream) {
     d->stream = (hipStream_t)hip_stream;
@@ -1118,7 +1124,7 @@ int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n) {
     d->h_ll_base[c] = nullptr;
     d->hist_rows[c] = 0;
     if (!d->lat_cached.empty()) d->lat_cached[c] = 0;
-    if (!d->det_cached.empty()) d->det_cached[c] = 0;
+    if (!d->det_cached.empty()) { d->det_cached[c] = 0; d->det_live_nd[c] = -1; }
   }
   return WFST_OK;
 }
@@ -1351,7 +1357,7 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
     const int c = channels ? channels[i] : i;
     d->h_state[c] = 2;
     if (!d->lat_cached.empty()) d->lat_cached[c] = 0;
-    if (!d->det_cached.empty()) d->det_cached[c] = 0;
+    if (!d->det_cached.empty()) { d->det_cached[c] = 0; d->det_live_nd[c] = -1; }
   }
   return WFST_OK;
 }
@@ -1375,6 +1381,7 @@ static int check_ctl_errors(wfst_decoder *d) {
       if (e & kErrBucketFull) m += " candidate bucket (max_tokens_per_frame)";
       if (e & kErrLinksFull) m += " forward links (lattice_links)";
       if (e & kErrPairsFull) m += " LM pair states (lm_pairs)";
+      if (e & kErrInternal) return fail(WFST_E_DEVICE, "channel " + std::to_string(c) + ": internal invariant violated on the device (a forward link without its token, or a backpointer without its predecessor)");
       return fail(WFST_E_CAPACITY, m);
     }
   }
@@ -1464,8 +1471,26 @@ int wfst_decoder_get_nbest(wfst_decoder *d, const int32_t *channels, int32_t n_c
     if (st == 0) return fail(WFST_E_STATE, "GetNbest before InitDecoding");
     any_live |= st == 1;
   }
-  // mid-utterance (the service's partial n-best, v2-asr/v2-asr-task.h:319): resolve what is alive now
-  if (any_live) launch_lattice_emit(d->D, dev, cnt, 1, d->stream);
+  // mid-utterance (the service's partial n-best, v2-asr/v2-asr-task.h:319): resolve what is alive now -- for the LIVE
+  // channels of the list only (the finalized ones were resolved by FinalizeDecoding)
+  if (any_live) {
+    std::vector<int32_t> live_list;
+    for (int i = 0; i < cnt; ++i) {
+      const int c = channels ? channels[i] : i;
+      if (d->h_state[c] == 1) live_list.push_back(c);
+    }
+    if ((int32_t)live_list.size() == cnt) {
+      launch_lattice_emit(d->D, dev, cnt, 1, d->stream);
+    } else {
+      const int32_t *ldev;
+      int32_t lcnt;
+      rc = stage_channels(d, live_list.data(), (int32_t)live_list.size(), &ldev, &lcnt);
+      if (rc != WFST_OK) return rc;
+      launch_lattice_emit(d->D, ldev, lcnt, 1, d->stream);
+      rc = stage_channels(d, channels, n_channels, &dev, &cnt);   // (waits for the emit launch before the list is reused)
+      if (rc != WFST_OK) return rc;
+    }
+  }
   NbestDev &N = d->nb;
   if (!d->nb_list.p) {  // first use: per-channel k-best lists and index scratch
     // k-best lists: 16 entries x 24 bytes per lattice state; up to 262144 states per lattice, less
@@ -1607,9 +1632,15 @@ int wfst_decoder_get_profile_busy(wfst_decoder *d, double busy_ms[3]) {
   HIP_TRY(hipStreamSynchronize(d->stream));
   // union of the launches' [start, stop] intervals of each kernel class: with several channel groups the launches
   // of different groups run concurrently, so the sum of their durations counts shared time twice
+  // time base: the EARLIEST recorded start event (with several channel groups the first pair listed is not it)
   int base = -1;
-  for (int k = 0; k < 3 && base < 0; ++k)
-    if (!d->ev_pairs[k].empty()) base = d->ev_pairs[k][0].first;
+  for (int k = 0; k < 3; ++k)
+    for (auto &pr : d->ev_pairs[k]) {
+      if (base < 0) { base = pr.first; continue; }
+      float dt = 0;
+      HIP_TRY(hipEventElapsedTime(&dt, d->ev_pool[base], d->ev_pool[pr.first]));
+      if (dt < 0) base = pr.first;
+    }
   for (int k = 0; k < 3; ++k) {
     std::vector<std::pair<float, float>> iv;
     iv.reserve(d->ev_pairs[k].size());
@@ -1810,64 +1841,81 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
   *n_arcs = 0;
   if (!live && !use_final_probs) return WFST_OK;  // as GetRawLattice (base-inl.h:879-884)
   DetDev &X = d->det;
-  if (!d->det_ws.p) {  // first use: per-channel workspace for raw lattices of up to 64 k states / 128 k arcs
-    X.raw_states_cap = (int32_t)std::min<int64_t>(d->D.lat_tok_cap, 65536);
-    X.raw_arcs_cap = (int32_t)std::min<int64_t>(d->D.lat_arc_cap, 131072);
-    const int32_t base = 65536;
+  if (!d->det_ws.p) {
+    // first use: the determinizer's workspace (wfst_limits.det_raw_states / det_raw_arcs / det_workspace_bytes), for
+    // det_slots lattices at a time -- every channel of the decoder where the budget allows
+    X.raw_states_cap = (int32_t)std::min<int64_t>(d->D.lat_tok_cap, d->lim.det_raw_states > 0 ? d->lim.det_raw_states : 65536);
+    X.raw_arcs_cap = (int32_t)std::min<int64_t>(d->D.lat_arc_cap, d->lim.det_raw_arcs > 0 ? d->lim.det_raw_arcs : 2ll * X.raw_states_cap);
+    const int32_t base = std::max(4096, X.raw_states_cap);
     X.caps.trie = 8 * base; X.caps.pool = 16 * base; X.caps.states = 2 * base; X.caps.initials = 2 * base;
     X.caps.arcs = 4 * base; X.caps.tmp = std::max(8192, 2 * (X.raw_arcs_cap + X.raw_states_cap));
     X.out_cap = X.caps.arcs;
     X.words_per_channel = 3 * (int64_t)X.raw_states_cap + 1 + 5 * (int64_t)X.raw_arcs_cap + det_words(X.caps, X.raw_states_cap) + 16;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const int64_t per = X.words_per_channel * 4 + (int64_t)X.out_cap * (int64_t)(sizeof(int4) + sizeof(float2));
+    const int64_t budget = d->lim.det_workspace_bytes > 0 ? d->lim.det_workspace_bytes : (int64_t)(total_b / 8);
+    d->det_slots = (int32_t)std::max<int64_t>(1, std::min<int64_t>(d->n_channels, budget / per));
     HIP_TRY(hipStreamSynchronize(d->stream));
-    HIP_TRY(d->det_ws.alloc((size_t)d->n_channels * (size_t)X.words_per_channel));
-    HIP_TRY(d->det_result.alloc((size_t)d->n_channels * 4));
-    HIP_TRY(d->det_out_a.alloc((size_t)d->n_channels * (size_t)X.out_cap));
-    HIP_TRY(d->det_out_w.alloc((size_t)d->n_channels * (size_t)X.out_cap));
+    HIP_TRY(d->det_ws.alloc((size_t)d->det_slots * (size_t)X.words_per_channel));
+    HIP_TRY(d->det_result.alloc((size_t)d->det_slots * 4));
+    HIP_TRY(d->det_out_a.alloc((size_t)d->det_slots * (size_t)X.out_cap));
+    HIP_TRY(d->det_out_w.alloc((size_t)d->det_slots * (size_t)X.out_cap));
     X.ws = d->det_ws.p;
     X.result = d->det_result.p;
     X.out_a = d->det_out_a.p;
     X.out_w = d->det_out_w.p;
     d->det_cache.resize((size_t)d->n_channels);
     d->det_cached.assign((size_t)d->n_channels, 0);
+    d->det_live_nd.assign((size_t)d->n_channels, -1);
+    d->det_live_final.assign((size_t)d->n_channels, 0);
   }
-  if (live || !d->det_cached[channel]) {
+  // a live channel's result is kept for as long as the channel has not moved on (the size query and the fetch of one request
+  // are two calls: the second reuses the first's work)
+  const bool live_hit = live && d->det_live_nd[(size_t)channel] == d->h_decoded[channel] &&
+                        d->det_live_final[(size_t)channel] == (use_final_probs ? 1 : 0);
+  if ((live && !live_hit) || (!live && !d->det_cached[channel])) {
     // which channels: mid-utterance just this one (its lists are resolved first); after FinalizeDecoding every
-    // finalized channel not determinized yet, in one launch (their lists were resolved by FinalizeDecoding)
-    std::vector<int32_t> list;
-    if (live) list.push_back(channel);
+    // finalized channel not determinized yet (their lists were resolved by FinalizeDecoding), det_slots per launch
+    std::vector<int32_t> all;
+    if (live) all.push_back(channel);
     else
       for (int c = 0; c < d->n_channels; ++c)
-        if (d->h_state[c] == 2 && !d->det_cached[c]) list.push_back(c);
-    const int32_t *dev;
-    int32_t cnt;
-    int rc = stage_channels(d, list.data(), (int32_t)list.size(), &dev, &cnt);
-    if (rc != WFST_OK) return rc;
-    if (live) launch_lattice_emit(d->D, dev, cnt, use_final_probs ? 1 : 0, d->stream);
-    launch_determinize(d->D, X, dev, cnt, d->stream);
-    HIP_TRY(hipGetLastError());
-    std::vector<int32_t> res((size_t)cnt * 4);
-    HIP_TRY(hipMemcpyAsync(res.data(), X.result, res.size() * 4, hipMemcpyDeviceToHost, d->stream));
-    rc = read_ctl(d);  // synchronises the stream
-    if (rc != WFST_OK) return rc;
-    rc = check_ctl_errors(d);
-    if (rc != WFST_OK) return rc;
-    for (int i = 0; i < cnt; ++i) {
-      wfst_decoder::DetLattice &L = d->det_cache[(size_t)list[i]];
-      L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
-      L.err = res[4 * i + 2];   // reported when THIS channel's lattice is asked for
-      d->det_cached[(size_t)list[i]] = live ? 0 : 1;
-      if (L.err) continue;
-      L.n_states = res[4 * i];
-      L.n_proper = res[4 * i + 3];
-      const size_t na = (size_t)res[4 * i + 1];
-      L.a.resize(na);
-      L.w.resize(na);
-      if (na) {
-        HIP_TRY(hipMemcpyAsync(L.a.data(), X.out_a + (size_t)i * X.out_cap, na * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
-        HIP_TRY(hipMemcpyAsync(L.w.data(), X.out_w + (size_t)i * X.out_cap, na * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
+        if (d->h_state[c] == 2 && !d->det_cached[c]) all.push_back(c);
+    for (size_t first = 0; first < all.size(); first += (size_t)d->det_slots) {
+      const std::vector<int32_t> list(all.begin() + (long)first, all.begin() + (long)std::min(all.size(), first + (size_t)d->det_slots));
+      const int32_t *dev;
+      int32_t cnt;
+      int rc = stage_channels(d, list.data(), (int32_t)list.size(), &dev, &cnt);
+      if (rc != WFST_OK) return rc;
+      if (live) launch_lattice_emit(d->D, dev, cnt, use_final_probs ? 1 : 0, d->stream);
+      launch_determinize(d->D, X, dev, cnt, d->stream);
+      HIP_TRY(hipGetLastError());
+      std::vector<int32_t> res((size_t)cnt * 4);
+      HIP_TRY(hipMemcpyAsync(res.data(), X.result, res.size() * 4, hipMemcpyDeviceToHost, d->stream));
+      rc = read_ctl(d);  // synchronises the stream
+      if (rc != WFST_OK) return rc;
+      rc = check_ctl_errors(d);
+      if (rc != WFST_OK) return rc;
+      for (int i = 0; i < cnt; ++i) {
+        wfst_decoder::DetLattice &L = d->det_cache[(size_t)list[i]];
+        L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
+        L.err = res[4 * i + 2];   // reported when THIS channel's lattice is asked for
+        d->det_cached[(size_t)list[i]] = live ? 0 : 1;
+        if (live) { d->det_live_nd[(size_t)list[i]] = d->h_decoded[list[i]]; d->det_live_final[(size_t)list[i]] = use_final_probs ? 1 : 0; }
+        if (L.err) continue;
+        L.n_states = res[4 * i];
+        L.n_proper = res[4 * i + 3];
+        const size_t na = (size_t)res[4 * i + 1];
+        L.a.resize(na);
+        L.w.resize(na);
+        if (na) {
+          HIP_TRY(hipMemcpyAsync(L.a.data(), X.out_a + (size_t)i * X.out_cap, na * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
+          HIP_TRY(hipMemcpyAsync(L.w.data(), X.out_w + (size_t)i * X.out_cap, na * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
+        }
       }
+      HIP_TRY(hipStreamSynchronize(d->stream));
     }
-    HIP_TRY(hipStreamSynchronize(d->stream));
   }
   const wfst_decoder::DetLattice &L = d->det_cache[(size_t)channel];
   if (L.err == 2)

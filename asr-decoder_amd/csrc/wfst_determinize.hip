@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
   const int4 *toks = D.lat_toks + (size_t)c * D.lat_tok_cap;
   const LatArc *larcs = D.lat_arcs + (size_t)c * D.lat_arc_cap;
   int32_t *state_of = D.remap + (size_t)c * D.arena_cap;   // arena index -> lattice state (scratch between pruning passes)
-  int32_t *base = X.ws + (size_t)c * X.words_per_channel;
+  int32_t *base = X.ws + (size_t)slot * X.words_per_channel;   // workspace slots go with the launch's list, not the channel
   int32_t *off = base;                       // [raw_states_cap + 1]
   int32_t *fin = off + X.raw_states_cap + 1; // [raw_states_cap]
   int32_t *cur = fin + X.raw_states_cap;     // [raw_states_cap]

@@ -43,8 +43,9 @@ namespace wfst {
 //   taking the minimum over the arrivals of EVERY candidate at s' equals the reference's walk from the
 //   final cost of the token at s'.  Needs: no epsilon cycle, closures of <= 48 paths and <=
 //   kPseudoDepthMax hops, no negative epsilon weight (a path then never costs less than its prefix, so
-//   one cutoff test on the arrival stands for the test at every hop).  Lattice and biglm decoders, and
-//   graphs that do not qualify, run the separate closure pass instead and ignore the pseudo arcs.
+//   one cutoff test on the arrival stands for the test at every hop).  Lattice decoders use the fused rows too
+//   (the epsilon arrivals come through the insert launch; one flat pass then lists the frame's epsilon links);
+//   biglm decoders, and graphs that do not qualify, run the separate closure pass instead and ignore the pseudo arcs.
 // arc_ilabel[], arc_olabel[], arc_src[] (source row | bit 31 for an epsilon arc): cold arrays in
 //   the same index space.  eps_target_state[k] = row of epsilon-target ordinal k.
 struct GraphDev {
@@ -120,7 +121,8 @@ constexpr unsigned long long kEmptyVal = ~0ull;
 
 // error bits (ChanCtl::error)
 constexpr int kErrTableFull = 1, kErrArenaFull = 2, kErrFrontierFull = 4, kErrWorklistFull = 8,
-              kErrFramesFull = 16, kErrBucketFull = 32, kErrLinksFull = 64, kErrPairsFull = 128;
+              kErrFramesFull = 16, kErrBucketFull = 32, kErrLinksFull = 64, kErrPairsFull = 128,
+              kErrInternal = 256;   // an invariant of the kernels did not hold (never expected; reported, not papered over)
 
 // ---- per-channel control block (one 128-byte line each) ----------------------------------
 struct __attribute__((aligned(128))) ChanCtl {

@@ -1128,7 +1128,11 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
       const float tot = cost + __int_as_float(arc.z);
       if (!(tot < cutoff)) continue;
       const int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;
-      if ((int64_t)lp < D.link_cap) links[lp] = make_int4(base + i, ld_agent(&toki[ord]), a, __float_as_int(tot));
+      // the destination's token of THIS frame (every epsilon arrival below the cutoff made one, through the insert launch or
+      // the closure pass); an entry from an older frame would mean that invariant broke: reported, never linked
+      const int dst = ord >= 0 ? ld_agent(&toki[ord]) : -1;
+      if (dst < base) atomicOr(&sh.err, kErrInternal);
+      else if ((int64_t)lp < D.link_cap) links[lp] = make_int4(base + i, dst, a, __float_as_int(tot));
       else atomicOr(&sh.err, kErrLinksFull);
       ++lp;
     }
@@ -1641,11 +1645,13 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
 //               (PruneActiveTokens), or cost + final_cost - best (FinalizeDecoding).  link cost = (cost_t + ac)
 //               + graph is the candidate cost the expansion computed, kept in the link record, so one 8-byte
 //               gather {extra, cost} of the destination prices a link.
-//   Frames are walked newest to oldest and the walk STOPS at the first frame whose extras come out
-//   bit-equal to the previous pass's: nothing older can change.  This is the reference's own stopping rule
-//   (extra_costs_changed, :458-461) with its tolerance delta = lattice_beam * prune_scale at zero: the
-//   reference leaves extras that moved by less than delta stale (too small), so it keeps a superset of the
-//   links kept here; FinalizeDecoding (delta 0 in the reference too) ends at the same lattice either way.
+//   Frames are walked newest to oldest and the walk STOPS at the first frame none of whose extras moved by more
+//   than delta = lattice_beam * prune_scale against the previous pass's -- the reference's own stopping rule
+//   (extra_costs_changed, :458-461, :541-542), judged here on the frame's exact fixpoint where the reference judges
+//   sweep by sweep over its token list (order dependent): a running pass may therefore stop at another frame than
+//   the reference's, and a mid-utterance lattice may differ from the reference's at that moment by the links that
+//   difference prices (it equals the order-free oracle's); FinalizeDecoding (delta 0, every frame walked, in the
+//   reference too) ends at the same lattice either way.
 //   The reference reaches the fixpoint inside a frame by sweeping token lists "while changed"; min is
 //   order-independent, so atomicMin relaxation gives the same values.
 //   Survivors are then moved down over the dead (tokens frame by frame, links segment by segment, indices
@@ -1976,7 +1982,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       }
       ctl->pruned_upto = nd;
       if (D.dbg & 32) atomicAdd(&D.dbg_t[54], wall_clock64() - tq);
-      if (ps.err) ctl->error |= kErrLinksFull;  // never expected: a surviving token whose predecessor died
+      if (ps.err) ctl->error |= kErrInternal;  // never expected: a surviving token whose predecessor died
     }
     __syncthreads();
   }
@@ -1987,7 +1993,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
 // =========================================================================================
 // Best-path decoders: token garbage collection.  A best-path decoder keeps no forward links, so nothing prunes its
 // arena the way PruneActiveTokens prunes the reference's token lists; what GetBestPath can ever need is the
-// backpointer FOREST of the current frontier.  When the arena passes its collection mark (half full; then halfway
+// backpointer FOREST of the current frontier.  When the arena passes its collection mark (an eighth of it left; then halfway
 // between what survived and the capacity), every token reachable from the frontier is marked -- frame by frame,
 // newest first; a token won by an epsilon arc (kPrevUnresolved) has its predecessor, the frame's token on the arc's
 // source state, found through an LDS hash of the wanted states and WRITTEN BACK as an ordinary backpointer -- and the
@@ -2028,7 +2034,7 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
   for (int f = nd; f >= 0; --f) {
     const int lo = foff[f], hi = foff[f + 1];
     for (;;) {   // until no token of the frame is newly marked (epsilon chains inside the frame)
-      for (int i = tid; i < kGcNeedSlots; i += kBT) gs.key[i] = -1;
+      for (int i = tid; i < kGcNeedSlots; i += kBT) { gs.key[i] = -1; gs.found[i] = -1; }
       if (tid == 0) { gs.n_need = 0; gs.n_new = 0; gs.overflow = 0; }
       __syncthreads();
       for (int i = lo + tid; i < hi; i += kBT) {
@@ -2095,7 +2101,11 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
           for (int q = 0; q < kGcNeedSlots; ++q) {
             const int k = gs.key[slot];
             if (k == -1) break;
-            if (k == need) { tok[i].z = (int)((uint32_t)gs.found[slot] | ((uint32_t)(kPrevUnresolved - t.z) << D.tok_idx_bits)); break; }
+            if (k == need) {
+              if (gs.found[slot] < 0) ps.err = 2;   // the frame holds no token on the arc's source state: never expected
+              else tok[i].z = (int)((uint32_t)gs.found[slot] | ((uint32_t)(kPrevUnresolved - t.z) << D.tok_idx_bits));
+              break;
+            }
             slot = (slot + 1) & (kGcNeedSlots - 1);
           }
         }
@@ -2178,7 +2188,7 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
     // next collection: at the usual mark, or -- when much survived -- halfway between what survived and the capacity
     ctl->lat_arcs = max(gc_base_mark(D), new_end + (int)((D.arena_cap - new_end) / 2));   // (best-path decoders: the collection mark)
     ctl->lat_toks += 1;                                             // (                    collections so far)
-    if (ps.err) ctl->error |= kErrArenaFull;  // never expected: a survivor whose predecessor was not marked
+    if (ps.err) ctl->error |= kErrInternal;  // never expected: a survivor whose predecessor was not marked or not found
   }
   __syncthreads();
 }

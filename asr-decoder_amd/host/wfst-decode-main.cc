@@ -157,6 +157,8 @@ int main(int argc, char **argv) {
       if (lm_old_file.empty() || lm_new_file.empty()) { std::cerr << "--lm-old and --lm-new go together\n"; return 1; }
       if (!lm1.Read(lm_old_file.c_str()) || !lm2.Read(lm_new_file.c_str())) return 1;
       lm1.Rescale(-1.0);
+      lm1.Handle();   // both automata go to HBM here, once, before any worker thread asks for them
+      lm2.Handle();
     }
     wfst_limits limits = {0, 0, 0, 0, 0};  // zeros = the library defaults
     limits.lattice_links = want_lattice ? lattice_links : 0;

@@ -219,9 +219,14 @@ void ArpaLm::Rescale(float scale) {  // arpa2fsa.cc:264-275: weights *= scale (a
   _lm = nullptr;
 }
 const wfst_lm *ArpaLm::Handle() {
+  // several worker threads construct their decoders over the same two LMs at once (wfst-decode --inflight): the upload
+  // happens once, under the lock, into a local that is published only when complete
+  std::lock_guard<std::mutex> lock(_mu);
   if (!_lm) {
     if (_file.empty()) throw std::runtime_error("ArpaLm used before Read()");
-    if (wfst_lm_load(_file.c_str(), _scale, _device, &_lm) != WFST_OK) Fatal("ArpaLm upload");
+    wfst_lm *lm = nullptr;
+    if (wfst_lm_load(_file.c_str(), _scale, _device, &lm) != WFST_OK) Fatal("ArpaLm upload");
+    _lm = lm;
   }
   return _lm;
 }

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <limits>
 #include <stdexcept>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -127,6 +128,7 @@ class ArpaLm {
   float _scale;
   int _device;
   wfst_lm *_lm;
+  std::mutex _mu;   // Handle() may be called by several worker threads at once (one decoder per thread over shared LMs)
   int32_t _bos = -1, _eos = -1;
 };
 

@@ -55,7 +55,8 @@ class Config(C.Structure):
 
 class Limits(C.Structure):
     _fields_ = [("max_frames", C.c_int32), ("max_tokens_per_frame", C.c_int32), ("arena_tokens", C.c_int64),
-                ("lattice_links", C.c_int64), ("lm_pairs", C.c_int64)]
+                ("lattice_links", C.c_int64), ("lm_pairs", C.c_int64), ("det_raw_states", C.c_int32), ("det_raw_arcs", C.c_int32),
+                ("det_workspace_bytes", C.c_int64)]
 
 
 class Options(C.Structure):
@@ -211,10 +212,12 @@ class BatchDecoder:
     biglm mode (the reference's OnlineLatticeDecoderMempoolBiglm)."""
 
     def __init__(self, graph, cfg, n_channels, max_frames=0, max_tokens_per_frame=0, arena_tokens=0, stream=None,
-                 lattice_links=0, options=None, old_lm=None, new_lm=None, lm_pairs=0):
+                 lattice_links=0, options=None, old_lm=None, new_lm=None, lm_pairs=0, det_raw_states=0, det_raw_arcs=0,
+                 det_workspace_bytes=0):
         self.graph = graph
         self.n = int(n_channels)
-        lim = Limits(int(max_frames), int(max_tokens_per_frame), int(arena_tokens), int(lattice_links), int(lm_pairs))
+        lim = Limits(int(max_frames), int(max_tokens_per_frame), int(arena_tokens), int(lattice_links), int(lm_pairs),
+                     int(det_raw_states), int(det_raw_arcs), int(det_workspace_bytes))
         self.lattice_links = int(lattice_links)
         h = C.c_void_p()
         _check(lib().wfst_decoder_create_biglm(graph.h, C.byref(cfg), self.n, C.byref(lim),

@@ -348,7 +348,14 @@ def main():
 
     pkg = importlib.import_module("asr-decoder_amd")
     synth, wfstdec, shard = pkg.synth, pkg.wfstdec, pkg.shard
-    pkg.build.build()
+    # one build per node: rank 0 compiles if the library is stale, the others wait (N ranks writing one .so at once
+    # would race); every rank then loads the same file
+    if world == 1:
+        pkg.build.build()
+    else:
+        if rank == 0:
+            pkg.build.build()
+        dist.barrier()
 
     B, T, P = a.batch, a.frames, a.pdfs
     if a.arena_per_frame <= 0:

@@ -87,6 +87,14 @@ typedef struct wfst_limits {
                                    GetRawLattice can be served; 0 (default): best path only        */
   int64_t lm_pairs;             /* biglm decoders: distinct (old-LM state, new-LM state) pairs one
                                    utterance may reach (default 262144; rounded up to a power of two) */
+  int32_t det_raw_states;       /* GetLattice (wfst_decoder_get_determinized_lattice): the largest raw lattice the on-device
+                                   determinizer takes, in states (default 65536) ...                                    */
+  int32_t det_raw_arcs;         /* ... and arcs (default 2 x det_raw_states).  The determinizer's workspace is allocated by
+                                   the first GetLattice call: about 1.2 KB per raw state and lattice (79 MB at the default),
+                                   for as many lattices at a time as det_workspace_bytes allows                          */
+  int64_t det_workspace_bytes;  /* upper bound of that workspace (default: room for every channel of the decoder, at most an
+                                   eighth of the device's memory).  Lattices beyond it are determinized in further launches:
+                                   a speed knob, never a refusal (at least one lattice's workspace is always allocated)   */
 } wfst_limits;
 
 /* Scheduling choices of a decoder (NULL / wfst_options_default() = the measured defaults).  None of
@@ -281,9 +289,16 @@ int wfst_lattice_to_vector_batch(const int32_t *ilabel, const int32_t *olabel, c
  * definitions of the reference loop (base-inl.h:311-347). */
 int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]);
 
-/* GetRawLattice(Lattice*, use_final_probs) (base-inl.h:869-975) of a FINALIZED channel of a
- * decoder created in lattice mode (wfst_limits.lattice_links > 0): the state-level lattice that is
- * left after FinalizeDecoding's lattice_beam pruning (base-inl.h:725-847).  States are numbered frame
+/* GetRawLattice(Lattice*, use_final_probs) (base-inl.h:869-975) of a channel of a decoder created in
+ * lattice mode (wfst_limits.lattice_links > 0).  After FinalizeDecoding: the state-level lattice that is
+ * left after its lattice_beam pruning (base-inl.h:725-847).  MID-UTTERANCE (any time after InitDecoding, as
+ * the service asks for it: kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:58,81): everything alive right now
+ * -- the history as the last PruneActiveTokens pass left it plus the raw frames since.  One documented
+ * deviation there: the running passes judge "extra costs moved by more than lattice_beam * prune_scale" on
+ * each frame's exact fixpoint, the reference sweep by sweep over its token list, so a pass may stop walking
+ * back at another frame than the reference's and a mid-utterance lattice may hold a few links more or fewer
+ * than the reference's at that moment (it equals the order-free oracle's, DESIGN.md section 4 deviation 7);
+ * after FinalizeDecoding (delta 0 in the reference too) the lattices are identical.  States are numbered frame
  * by frame in a topological order (every arc goes to a higher id; state 0 is the start), like the
  * reference's TopSortTokens; the numbering inside a frame is implementation defined there too.
  * Per state: final flag, frame, graph state id, forward cost; per arc (sorted by source):
@@ -315,8 +330,8 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
 
 /* The service's n-best (OnlineClgLatticeFastDecoder::GetNbest, kaldi-nnet3/kaldi-online-nnet3-my-
  * decoder.cc:50-105: GetRawLattice -> DeterminizeLatticeWrapper -> NShortestPath ->
- * ConvertNbestToVector, then LatticeToVector per path) of FINALIZED channels of a lattice-mode
- * decoder: the n (<= 16) lowest-cost DISTINCT word sequences of the pruned lattice, cheapest first,
+ * ConvertNbestToVector, then LatticeToVector per path) of channels of a lattice-mode decoder, finalized
+ * or mid-utterance (the service's partial n-best; what is alive now, see wfst_decoder_get_raw_lattice): the n (<= 16) lowest-cost DISTINCT word sequences of the pruned lattice, cheapest first,
  * each with tot_score = sum(graph + acoustic) and lm_score = sum(graph) of its best path.
  * Computed on the device by a k-best search over the raw lattice (no determinized lattice is
  * materialised).  Outputs for the i-th listed channel: n_paths[i]; n_words[i*n + k];
