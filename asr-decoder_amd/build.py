@@ -39,6 +39,19 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines):
+    """Kernel experiments: the library built with extra -D flags as lib/libwfstdec_<name>.so (wfstdec.py loads it when
+    WFST_LIB_VARIANT=<name>; tools/ab_bench.sh)."""
+    out = os.path.join(HERE, "lib", "libwfstdec_%s.so" % name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call([HIPCC] + FLAGS + list(defines) + ["-o", out] + SRCS)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")]))
+    else:
+        build(force="--force" in sys.argv, verbose=True)
+        print(LIB)

@@ -999,6 +999,18 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     memset(&D.lm_old, 0, sizeof(D.lm_old));
     memset(&D.lm_new, 0, sizeof(D.lm_new));
   }
+  // two launches per frame (wfst_device.h): fused best-path decoders whose max_active can never bind (it is at least the
+  // per-frame token limit) and whose min_active is 0; every gc_stride-th frame keeps the closure launch (token collection
+  // check), gc_stride + 1 frames at the per-frame limit fitting the arena's collection reserve (gc_base_mark)
+  D.best_row = (D.fused && !D.lattice && !big) ? 1 : 0;
+  D.two_launch = 0;
+  D.gc_stride = 1;
+  if (D.best_row && !(O.debug & 0x2000) && cfg->max_active >= L.max_tokens_per_frame && cfg->min_active == 0) {
+    int64_t reserve = std::max<int64_t>(2ll * L.max_tokens_per_frame, L.arena_tokens / 8);
+    if (reserve >= L.arena_tokens / 2) reserve = L.arena_tokens / 2;
+    const int64_t stride = reserve / std::max<int64_t>(1, L.max_tokens_per_frame) - 1;
+    if (stride >= 1) { D.two_launch = 1; D.gc_stride = (int32_t)std::min<int64_t>(stride, 16); }
+  }
   D.pair_keys = d->pair_keys.p;
   D.pair_cap = (int32_t)pair_cap;
   D.tok_lm = d->tok_lm.p;
@@ -1204,11 +1216,15 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     int par = gpar0[g];
     timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });  // GetCutoff + seed only
     for (int s = 0; s < gsteps[g]; ++s) {
+      // two launches per frame where the decoder allows (wfst_device.h two_launch): the insert launch closes the frame and
+      // prepares the next; every gc_stride-th frame is a classic one (its closure launch checks the token arena)
+      const bool classic = !d->D.two_launch || (d->D.dbg & 0x800) || (s % d->D.gc_stride) == d->D.gc_stride - 1;
+      const bool more = s + 1 < gsteps[g];
       timed(0, st, [&] { launch_expand(d->D, g, par, d->expand_wgs, st); });
-      timed(1, st, [&] { launch_insert(d->D, off, cnt, g, par, d->insert_wgs, st); });
+      timed(1, st, [&] { launch_insert(d->D, off, cnt, d->target.p, classic ? 0 : more ? 1 : 2, g, par, d->insert_wgs, st); });
       if (d->D.dbg & 0x800)  // timing experiment: the expansion of this frame once more, stages removed (wfst_kernels.hip expand_body kAbl)
         timed(3, st, [&] { launch_expand_replay(d->D, g, par, (d->D.dbg >> 8) & 7, d->expand_wgs, st); });
-      timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, s + 1 < gsteps[g], g, par ^ 1, st); });
+      if (classic) timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, more, g, par ^ 1, st); });
       par ^= 1;
     }
   };

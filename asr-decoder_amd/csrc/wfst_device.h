@@ -146,7 +146,11 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t lat_arcs;      // lattice mode, after lattice_prune_kernel: surviving links in lat_arcs[]
   int32_t lat_toks;      //   "   surviving tokens in lat_toks[]
   int32_t tiles_left;    // expansion tiles of the frame not finished yet (the last one plans the insert items)
-  int32_t pair_count;    // biglm: LM pair states interned since InitDecoding (atomicAdd)
+  union {
+    int32_t pair_count;  // biglm: LM pair states interned since InitDecoding (atomicAdd)
+    int32_t items_left;  // fused best-path decoders: insert work items of the frame not finished yet (the workgroup that
+                         // finishes the last one closes the frame and prepares the next: frame_boundary_fused)
+  };
   int32_t pruned_upto;   // lattice mode: NumFramesDecoded() at the last back-pruning pass (frames below hold extras)
 };
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
@@ -263,6 +267,15 @@ struct DecoderDev {
   //                           identifies a token): open-addressed keys (row | pair << 32) beside
   //                           eps_vals / eps_toki, ecap a power of two
   int32_t fused;  // the graph's fused closures are in use (best-path, non-biglm decoder on a graph that has them)
+  // Two launches per frame (fused best-path decoders whose max_active / min_active can never bind: GetCutoff is then
+  // best + beam and needs no look at the tokens): the insert workgroup that finishes a channel's last work item closes the
+  // frame and prepares the next one (frame_boundary_fused), so the third launch of a frame disappears -- except on every
+  // gc_stride-th frame of an advance call, which runs the classic three launches: the closure kernel there checks whether the
+  // token arena wants collecting (the arena's reserve covers gc_stride + 1 frames at the per-frame limit).
+  // best_row: ChanCtl::best_next carries the best token's graph ROW in its low word instead of its arena index (all the
+  // seeding of next_cutoff needs, with no token read behind other workgroups' stores; ties on the best cost then go to the
+  // lowest row: deterministic, where the arena order is not).
+  int32_t two_launch, gc_stride, best_row;
   int32_t big;
   LmDev lm_old, lm_new;
   unsigned long long *pair_keys;
@@ -316,8 +329,10 @@ void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *cha
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s);
 void launch_expand_replay(const DecoderDev &D, int group, int par, int variant, int n_workgroups, hipStream_t s);
-void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups,
-                   hipStream_t s);
+// boundary: 0 = the closure kernel follows (classic frame); 1 = the insert launch closes the frame and prepares the next
+// (two-launch frame); 2 = closes the frame only (last frame of an advance call)
+void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int boundary, int group, int par,
+                   int n_workgroups, hipStream_t s);
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int do_prep,
                     int group, int par, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);

@@ -234,6 +234,15 @@ __device__ __forceinline__ void partition_group(int P, int joint_max, int p, int
   }
 }
 
+// An insert work item without records (group size 0) for channel c: listed where a channel of a two-launch frame has nothing
+// to insert, so that an insert workgroup still closes its frame (frame_boundary_fused).
+__device__ __forceinline__ void push_empty_item(const DecoderDev &D, int c, int group, int par) {
+  FrameCtl *fc = D.fctl + group;
+  const int idx = atomicAdd(&fc->n_small[par], 1);
+  if (idx < D.item_cap / 2) D.items[(size_t)group * D.item_cap + D.item_cap - 1 - idx] = (int)((uint32_t)c << 16);
+  else atomicOr(&D.ctl[c].error, kErrBucketFull);   // cannot happen: the list holds channels x partitions
+}
+
 // plan_channel: one wave lists the insert work items of channel c for this frame: item =
 // channel << 16 | first partition << 8 | group size.  Run by the workgroup that finishes the
 // channel's last expansion tile (all bucket counters of the channel are final then; they are only
@@ -254,7 +263,13 @@ __device__ __forceinline__ void plan_channel(const DecoderDev &D, int c, int gro
   partition_group(P, min(D.joint_max, (D.lds_slots * 3) >> 2), lane < P ? lane : 0, ps, cnt, &g0, &G, &n);
   const bool leader = lane < P && g0 == lane && n > 0;
   const u64 m = __ballot(leader);
-  if (!m) return;
+  if (D.two_launch && lane == 0) D.ctl[c].items_left = m ? __popcll(m) : 1;   // (read by the insert launch: frame_boundary_fused)
+  if (!m) {
+    // no candidate survived: nothing to insert -- but with two launches per frame SOME insert workgroup has to close the
+    // channel's frame: an empty item (group size 0)
+    if (D.two_launch && lane == 0) push_empty_item(D, c, group, par);
+    return;
+  }
   // heavy items are listed from the front of items[], light ones from the back; the insert
   // workgroups walk heavy first
   const bool heavy = leader && n > kHeavyItem;
@@ -702,8 +717,19 @@ constexpr int kInsertUnroll = 4;
 // then by ticket); 512 threads, dynamic LDS = lds_slots * 12 bytes (16 in lattice mode).
 // kLat = lattice mode (forward links recorded); the best-path instantiation carries none of it.
 // kBig = biglm mode: 64-bit keys (graph row | LM pair state << 32), LDS = lds_slots * 16 bytes.
+struct BoundaryLite {   // frame_boundary_fused's few words of LDS
+  float redf[16];
+  u64 best;
+  int active, n, nd, front_begin, ntiles, tile_tokens, tile_start, pad_bits;
+};
+template <int kT>
+__device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c, const int32_t *target, int chan_cnt, int group,
+                                                     int par_next, bool do_prep, BoundaryLite &sh);
+
 template <bool kLat, bool kBig, bool kFused>
-__device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int par) {
+__device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int par, const int32_t *target = nullptr, int boundary = 0,
+                                            int chan_cnt = 0) {
+  constexpr bool kTwo = kFused && !kLat && !kBig;   // the instantiation that can close a frame itself (two launches per frame)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int SLmax = D.lds_slots;
@@ -721,7 +747,8 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   };
   static_assert(sizeof(InsertShared) % 16 == 0, "keep the dynamic LDS base aligned");
   __shared__ InsertShared ish;
-  int &s_nstates = ish.nstates, &s_gpos = ish.gpos, &s_wpos = ish.wpos, &s_ok = ish.ok, &s_item = ish.item;
+  int &s_nstates = ish.nstates, &s_gpos = ish.gpos, &s_wpos = ish.wpos, &s_ok = ish.ok, &s_item = ish.item, &s_last = ish.pad[0];
+  __shared__ BoundaryLite bsh;
   u64 *s_best = ish.best;
   int *s_pref = ish.pref;
   FrameCtl *fc = D.fctl + group;
@@ -902,7 +929,8 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
           tok[idx] = r[k];  // {state, cost, source token, arc | flags}
           if constexpr (kBig) D.tok_lm[(size_t)c * D.arena_cap + idx] = rl[k];
           if (kLat) tidx[wslot] = idx;
-          const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
+          // (kTwo: the best token's graph ROW rides in the low word -- all the next frame's seed needs, DecoderDev::best_row)
+          const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)(kTwo ? r[k].x : idx);
           best = b < best ? b : best;
         }
         // a token on an epsilon-TARGET state registers itself in the channel's direct-mapped
@@ -1024,16 +1052,30 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
     for (int w = 1; w < kInsertThreads / 64; ++w) b = s_best[w] < b ? s_best[w] : b;
     if (b != ~0ull) atomicMin(&ctl->best_next, b);
     dbg_phase(D, 10, tq);
+    int last = 0;
+    if (kTwo && boundary) {
+      // two launches per frame: the workgroup whose item is the channel's last closes the frame.  Everything this workgroup
+      // sent to the channel's control line (token count, best token, error bits) has arrived before it counts itself out.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      last = atomicSub(&ctl->items_left, 1) == 1;
+    }
+    s_last = last;
     s_item = (int)gridDim.x + atomicAdd(&fc->item_ticket[par], 1);
   }
   __syncthreads();
   it = s_item;
+  const int last = s_last;
   __syncthreads();
+  if constexpr (kTwo) {
+    if (last) frame_boundary_fused<kInsertThreads>(D, c, target, chan_cnt, group, par ^ 1, boundary == 1, bsh);
+  }
   }
 }
 
 __global__ __launch_bounds__(kInsertThreads, 6) void insert_kernel_plain(DecoderDev D, int group, int par) { insert_body<false, false, false>(D, group, par); }
-__global__ __launch_bounds__(kInsertThreads, 6) void insert_kernel_fused(DecoderDev D, int group, int par) { insert_body<false, false, true>(D, group, par); }
+__global__ __launch_bounds__(kInsertThreads, 6) void insert_kernel_fused(DecoderDev D, int group, int par, const int32_t *target, int boundary, int chan_cnt) {
+  insert_body<false, false, true>(D, group, par, target, boundary, chan_cnt);
+}
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel_lattice(DecoderDev D, int group, int par) { insert_body<true, false, false>(D, group, par); }
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel_lattice_fused(DecoderDev D, int group, int par) { insert_body<true, false, true>(D, group, par); }
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel_biglm(DecoderDev D, int group, int par) { insert_body<false, true, false>(D, group, par); }
@@ -1359,7 +1401,7 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
       }
       tok[idx] = make_int4(state, __float_as_int(o2f((uint32_t)(v >> 32))), kPrevUnresolved,
                            (int)(((uint32_t)v & kArcMask) | kFlagEpsTarget | (((uint32_t)v & kEpsOutBit) ? kFlagOutEps : 0u)));
-      const u64 b = (v & 0xFFFFFFFF00000000ull) | (uint32_t)idx;
+      const u64 b = (v & 0xFFFFFFFF00000000ull) | (uint32_t)(D.best_row ? state : idx);
       best = b < best ? b : best;
     }
   }
@@ -1565,7 +1607,9 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
   // seed next_cutoff from the best token's emitting arcs, base-inl.h:282-300
   float seed = kInf;
   if (n > 0) {
-    const int4 bt = tokc[(uint32_t)best];
+    int4 bt;
+    if (D.best_row) bt = make_int4((int)(uint32_t)best, __float_as_int(best_w), 0, 0);   // the best token's row rides in best_next itself
+    else bt = tokc[(uint32_t)best];
     const uint2 si = make_uint2((uint32_t)bt.x + 1u, (uint32_t)D.g.arcs[bt.x].x);
     const int deg = (int)(si.y >> kEpsBits), ab0 = (int)(si.x + (si.y & kEpsMask));
     const float *llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
@@ -1610,6 +1654,10 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
     const int ntiles = (n + tile_tokens - 1) / tile_tokens;
     sh.active = 0;
     ctl->tiles_left = ntiles;
+    if (ntiles == 0 && D.two_launch) {   // a channel without tokens: no tile will plan its insert items, yet its frame must be closed
+      ctl->items_left = 1;
+      push_empty_item(D, c, group, par);
+    }
     if (ntiles > 0) {
       const int start = atomicAdd(&D.fctl[group].total_tiles[par], ntiles);
       ctl->tile_start = start;
@@ -1632,6 +1680,122 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
     tiles[i] = td;
   }
   if (tid == 0) dbg_phase(D, 5, tq);
+}
+
+// =========================================================================================
+// Two launches per frame (DecoderDev::two_launch): what closure_kernel<false,false> does for a fused best-path decoder -- close
+// the frame the insert launch has just built (finalize_frame) and prepare the next one (prep_frame: GetCutoff, the seed of
+// next_cutoff from the best token's arcs, the tile list) -- run by the insert workgroup that finishes the channel's last work
+// item, kT threads.  Preconditions (wfst_decoder_create): max_active can never bind and min_active is 0, so GetCutoff is
+// best + beam (base-inl.h:138-234 with both limits out of reach) and needs no look at the frame's tokens; the best token's
+// cost AND graph row arrive in ChanCtl::best_next (atomicMin), so nothing another workgroup wrote with plain stores in this
+// launch is read here: the fields other workgroups changed -- by atomics -- are read through L2 (ld_agent).  Float arithmetic
+// as prep_frame's.
+// =========================================================================================
+template <int kT>
+__device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c, const int32_t *target, int chan_cnt, int group,
+                                                     int par_next, bool do_prep, BoundaryLite &sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ChanCtl *ctl = D.ctl + c;
+  const float kInf = __builtin_huge_valf();
+  // every item of the channel is done with the bucket counters: reset for the next expansion
+  for (int i = tid; i < D.n_part; i += kT) D.bucket_cnt[(size_t)c * D.n_part + i] = 0;
+  if (tid == 0) {
+    const int f = ctl->n_decoded;                         // (unchanged during this launch)
+    const int base = ctl->front_begin + ctl->front_count;
+    const uint32_t bound_o = ld_agent(&ctl->bound);
+    int nf = ld_agent(&ctl->new_count);
+    const int err = ld_agent(&ctl->error);
+    const u64 best = ld_agent(&ctl->best_next);
+    int add_err = 0;
+    if (nf > D.max_tok || (int64_t)base + nf > D.arena_cap) nf = 0;   // (the insert workgroups have raised the error bit)
+    if (err) nf = 0;   // a channel that hit a limit stops producing tokens
+    if (f + 2 > D.max_frames + 1) add_err = kErrFramesFull;
+    else {
+      D.frame_off[(size_t)c * (D.max_frames + 2) + f + 2] = base + nf;
+      D.cutoff_hist[(size_t)c * (D.max_frames + 2) + f + 1] = o2f(bound_o);
+    }
+    ctl->cnt_tok += (u64)nf;
+    if (nf > ctl->peak_tokens) ctl->peak_tokens = nf;
+    ctl->front_begin = base;
+    ctl->front_count = nf;
+    ctl->n_decoded = f + 1;
+    ctl->active = 0;
+    if (add_err) atomicOr(&ctl->error, add_err);
+    // the next frame (prep_frame)
+    int act = do_prep && (f + 1 < target[c]) && !(err | add_err) && !ctl->finalized;
+    if (act && f + 1 >= D.max_frames) { atomicOr(&ctl->error, kErrFramesFull); act = 0; }
+    sh.active = act;
+    sh.n = nf;
+    sh.nd = f + 1;
+    sh.front_begin = base;
+    sh.best = best;
+  }
+  __syncthreads();
+  if (!sh.active) return;
+  const int n = sh.n, nd = sh.nd;
+  const u64 best = sh.best;
+  const float best_w = n > 0 ? o2f((uint32_t)(best >> 32)) : kInf;
+  // GetCutoff with max_active and min_active out of reach (base-inl.h:138-234; prep_frame's general path gives the same)
+  const float ab = D.beam, cutoff = best_w + D.beam;
+  const float *llrow = D.ll_base[c] + (size_t)nd * D.stride;
+  // seed next_cutoff from the best token's emitting arcs, base-inl.h:282-300
+  float seed = kInf;
+  if (n > 0) {
+    const int brow = (int)(uint32_t)best;
+    const uint32_t hx = (uint32_t)D.g.arcs[brow].x;
+    const int deg = (int)(hx >> kEpsBits), ab0 = brow + 1 + (int)(hx & kEpsMask);
+    for (int e = tid; e < deg; e += kT) {
+      const int4 arc = D.g.arcs[ab0 + e];
+      seed = fminf(seed, (best_w + __int_as_float(arc.z)) - llrow[arc.x & D.g.col_mask]);  // base-inl.h:295
+    }
+  }
+  seed = wave_min_f(seed);
+  if (lane == 0) sh.redf[wave] = seed;
+  __syncthreads();
+  if (tid == 0) {
+    float s = sh.redf[0];
+    for (int w = 1; w < kT / 64; ++w) s = fminf(s, sh.redf[w]);
+    const float next_cutoff = s + ab;
+    ctl->cur_cutoff = cutoff;
+    ctl->adaptive_beam = ab;
+    ctl->bound = f2o(s < kInf ? next_cutoff : kInf);
+    ctl->new_count = 0;
+    ctl->best_next = ~0ull;
+    ctl->active = 1;
+    int tile_tokens = kTileTokens;   // (as prep_frame)
+    if ((int64_t)n * chan_cnt <= 700ll * 256) tile_tokens = 256;
+    if ((int64_t)n * chan_cnt <= 700ll * 128) tile_tokens = 128;
+    const int ntiles = (n + tile_tokens - 1) / tile_tokens;
+    sh.tile_tokens = tile_tokens;
+    sh.ntiles = 0;
+    ctl->tiles_left = ntiles;
+    if (ntiles == 0) {   // a channel without tokens: an empty insert item closes its next frame
+      ctl->items_left = 1;
+      push_empty_item(D, c, group, par_next);
+    } else {
+      const int start = atomicAdd(&D.fctl[group].total_tiles[par_next], ntiles);
+      ctl->tile_start = start;
+      if (start + ntiles <= D.tile_cap) { sh.tile_start = start; sh.ntiles = ntiles; }
+      else atomicOr(&ctl->error, kErrFrontierFull);
+    }
+    sh.pad_bits = (int32_t)f2o(s < kInf ? next_cutoff : kInf);   // next_cutoff's seed as the tiles carry it (TileDesc::pad)
+  }
+  __syncthreads();
+  const int ntl = sh.ntiles;
+  TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap + sh.tile_start;
+  const int32_t pad_bits = sh.pad_bits;
+  for (int i = tid; i < ntl; i += kT) {
+    TileDesc td;
+    td.chan = c;
+    td.tok_begin = sh.front_begin + i * sh.tile_tokens;
+    td.tok_count = min(sh.tile_tokens, n - i * sh.tile_tokens);
+    td.cutoff = cutoff;
+    td.adaptive_beam = ab;
+    td.pad = pad_bits;
+    td.llrow = llrow;
+    tiles[i] = td;
+  }
 }
 
 // =========================================================================================
@@ -2181,12 +2345,17 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared 
     ctl->front_begin = foff[nd];
     ctl->front_count = foff[nd + 1] - foff[nd];
     const u64 b = ctl->best_next;
-    if (b != ~0ull) {
+    if (b != ~0ull && !D.best_row) {   // (best_row: the low word is the token's graph row, which does not move)
       const int nb = remap[(uint32_t)b];
       ctl->best_next = nb >= 0 ? ((b & 0xFFFFFFFF00000000ull) | (uint32_t)nb) : ~0ull;
     }
     // next collection: at the usual mark, or -- when much survived -- halfway between what survived and the capacity
-    ctl->lat_arcs = max(gc_base_mark(D), new_end + (int)((D.arena_cap - new_end) / 2));   // (best-path decoders: the collection mark)
+    // (two-launch decoders check the mark every gc_stride frames only: the room behind it covers that many frames)
+    {
+      int mark = max(gc_base_mark(D), new_end + (int)((D.arena_cap - new_end) / 2));
+      if (D.two_launch) mark = max(gc_base_mark(D), (int)min((int64_t)mark, D.arena_cap - (int64_t)(D.gc_stride + 1) * D.max_tok));
+      ctl->lat_arcs = mark;   // (best-path decoders: the collection mark)
+    }
     ctl->lat_toks += 1;                                             // (                    collections so far)
     if (ps.err) ctl->error |= kErrInternal;  // never expected: a survivor whose predecessor was not marked or not found
   }
@@ -2305,7 +2474,7 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
       D.link_off[(size_t)c * (D.max_frames + 3) + 1] = min(ctl->link_count, (int)D.link_cap);
     }
     D.cutoff_hist[(size_t)c * (D.max_frames + 2) + 0] = D.beam;
-    const u64 root = ((u64)f2o(0.0f) << 32) | 0u;
+    const u64 root = ((u64)f2o(0.0f) << 32) | (D.best_row ? (uint32_t)D.g.start : 0u);
     ctl->best_next = sh.best < root ? sh.best : root;
     ctl->front_begin = 0;
     ctl->front_count = nf;
@@ -2678,12 +2847,13 @@ void launch_expand_replay(const DecoderDev &D, int group, int par, int variant, 
     default: hipLaunchKernelGGL((expand_replay_fused<8>), g, b, 0, s, D, group, par); break;
   }
 }
-void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, int group, int par, int n_workgroups, hipStream_t s) {
+void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int boundary, int group, int par,
+                   int n_workgroups, hipStream_t s) {
   const size_t lds = (size_t)D.lds_slots * (D.big ? 16 : D.lattice ? 16 : 12);
   if (D.big) hipLaunchKernelGGL(insert_kernel_biglm, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
   else if (D.lattice && D.fused) hipLaunchKernelGGL(insert_kernel_lattice_fused, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
   else if (D.lattice) hipLaunchKernelGGL(insert_kernel_lattice, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
-  else if (D.fused) hipLaunchKernelGGL(insert_kernel_fused, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  else if (D.fused) hipLaunchKernelGGL(insert_kernel_fused, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par, target, boundary, chan_cnt);
   else hipLaunchKernelGGL(insert_kernel_plain, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
 }
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int do_prep, int group, int par,

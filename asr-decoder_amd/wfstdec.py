@@ -12,7 +12,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libwfstdec.so")
+# (WFST_LIB_VARIANT: kernel experiments only -- tools/ab_bench.sh builds variants of the library beside the product one with
+# `build.py --variant NAME -D...` and times them on one box; the product path never sets it)
+LIB_PATH = os.path.join(HERE, "lib", "libwfstdec%s.so" % (("_" + os.environ["WFST_LIB_VARIANT"]) if os.environ.get("WFST_LIB_VARIANT") else ""))
 
 WFST_OK = 0
 ERR_NAMES = {-1: "WFST_E_ARG", -2: "WFST_E_IO", -3: "WFST_E_DEVICE", -4: "WFST_E_CAPACITY",

@@ -78,7 +78,8 @@ def parse():
                     "2 overlaps two half-batches: +7 %% frames/s, but per-launch accounting then covers half a batch")
     ap.add_argument("--host-feed", action="store_true", help="hand the log-likelihoods over as HOST matrices every step "
                     "(wfst_decoder_advance_host): the PCIe-inclusive rate; never the headline")
-    ap.add_argument("--max-tokens", type=int, default=131072, help="wfst_limits.max_tokens_per_frame")
+    ap.add_argument("--max-tokens", type=int, default=65536, help="wfst_limits.max_tokens_per_frame (the headline workload peaks at 40 k tokens "
+                    "in one frame; the service-point legs, whose frames reach beyond that before max_active cuts them, run with 131072)")
     ap.add_argument("--arena-per-frame", type=int, default=0, help="token arena per utterance = frames x this (raise it for wider beams); "
                     "300 x 13900 stays below 2^22 tokens, where a token's backpointer has room for its state's degree code "
                     "(wfst_device.h: the expansion then skips the row-header loads); the heaviest utterance of rank 0's workload needs 3.4 M. "
@@ -415,8 +416,8 @@ def main():
                           **({"joint_max": a.joint_max} if a.joint_max > 0 else {}),
                           **({"insert_workgroups": a.insert_wgs} if a.insert_wgs > 0 else {}))
 
-    def new_decoder(cfg_dict):
-        return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=a.max_tokens,
+    def new_decoder(cfg_dict, max_tokens=None):
+        return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=max_tokens or a.max_tokens,
                                     arena_tokens=int(T * a.arena_per_frame), stream=stream, lattice_links=a.lattice_links,
                                     options=opt, old_lm=lm_dev[0], new_lm=lm_dev[1], lm_pairs=a.lm_pairs if a.biglm else 0)
 
@@ -553,6 +554,8 @@ def main():
         toks = sum(s["tokens"] for s in gstats)
         out["config"]["mean_active_tokens_per_frame"] = toks / float(B * (T + 1))
         out["config"]["mean_expanded_tokens_per_frame"] = N / float(B * T)
+        out["config"]["peak_tokens_in_a_frame"] = max(s["peak_tokens"] for s in gstats)
+        out["config"]["max_tokens_per_frame_limit"] = a.max_tokens
         if a.lattice_links > 0 and a.determinize:
             dl = [r["det"] for r in res if r.get("det") is not None]
             out["config"]["determinized_lattices"] = {
@@ -713,7 +716,7 @@ def main():
             reference against ITSELF with nothing but its hash table size changed (hash_ratio 3 instead of
             2: another visiting order of the same algorithm) -- the yardstick for the first number"""
             nonlocal dec
-            dec = new_decoder(cd2)
+            dec = new_decoder(cd2, max_tokens=max(a.max_tokens, 131072))
             step2 = make_step(dec, ll2, [mats2[i] for i in range(B)])
             dt2, res2 = timed(step2, 1, n2)
             o = {"value": B * T * n2 / dt2, "unit": "frames/s", "ms_per_step": 1000.0 * dt2 / n2, "steps": n2,
