@@ -1005,6 +1005,8 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.best_row = (D.fused && !D.lattice && !big) ? 1 : 0;
   D.two_launch = 0;
   D.gc_stride = 1;
+  D.staged = (D.fused && !big && !(O.debug & 0x8880)) ? 1 : 0;   // (0x800 replay / 0x80 phase timers: expand_body's; 0x8000: A/B)
+  D.seed_tiles = (D.best_row && !(O.debug & 0x4800)) ? 1 : 0;   // (0x800: the replay experiments start from the frame's seed; 0x4000: A/B)
   if (D.best_row && !(O.debug & 0x2000) && cfg->max_active >= L.max_tokens_per_frame && cfg->min_active == 0) {
     int64_t reserve = std::max<int64_t>(2ll * L.max_tokens_per_frame, L.arena_tokens / 8);
     if (reserve >= L.arena_tokens / 2) reserve = L.arena_tokens / 2;

@@ -276,6 +276,12 @@ struct DecoderDev {
   // seeding of next_cutoff needs, with no token read behind other workgroups' stores; ties on the best cost then go to the
   // lowest row: deterministic, where the arena order is not).
   int32_t two_launch, gc_stride, best_row;
+  // seed_tiles (best_row decoders): next_cutoff's seed from the best token's arcs (base-inl.h:282-300) is computed by the
+  // EXPANSION -- one extra tile per channel, listed first (TileDesc with tok_count 0: tok_begin = the best token's row, cutoff
+  // = its cost) -- instead of by the frame boundary, whose serial tail it was three dependent round trips of; the tiles read
+  // next_cutoff afresh every round, so the seed (and every other tile's tightening) reaches them as soon as it lands.
+  int32_t seed_tiles;
+  int32_t staged;   // fused (non-biglm) decoders: expand_kernel_staged (the tile's arcs staged in LDS by gather DMA) instead of expand_kernel_fused
   int32_t big;
   LmDev lm_old, lm_new;
   unsigned long long *pair_keys;

@@ -296,6 +296,40 @@ __device__ __forceinline__ void plan_channel(const DecoderDev &D, int c, int gro
   }
 }
 
+// The end of an expansion tile (expand_body, expand_kernel_staged): the tile's work counters to the channel's control block,
+// the countdown of the channel's tiles, and -- by the workgroup that finishes the channel's LAST tile -- the plan of its insert
+// work items.  s_stat[4]: the workgroup's LDS accumulators {N, E, records, Z} (zero on entry; zero again on exit).
+__device__ __forceinline__ void tile_tail(const DecoderDev &D, int c, ChanCtl *ctl, int group, int par, uint32_t nN, uint32_t nE,
+                                          uint32_t nR, uint32_t nZf, uint32_t *s_stat) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // work counters: summed over the workgroup in LDS, then one set of atomics per tile from a wave that has nothing else to
+  // wait for -- every atomic on the channel's control line queues behind the other tiles' (next_cutoff, the countdown)
+  {
+    const uint32_t wN = (uint32_t)wave_sum_u64(nN), wE = (uint32_t)wave_sum_u64(nE), wZ = (uint32_t)wave_sum_u64(nZf);
+    if (lane == 0) {
+      if (wN) atomicAdd(&s_stat[0], wN);
+      if (wE) atomicAdd(&s_stat[1], wE);
+      if (nR) atomicAdd(&s_stat[2], nR);
+      if (wZ) atomicAdd(&s_stat[3], wZ);
+    }
+  }
+  // the channel's last tile plans its insert work items.  Every wave's bucket atomics have returned (their results were
+  // used above), so an LDS-only barrier orders them before the countdown; only wave 0 waits for the countdown's answer
+  lds_barrier();
+  if (wave == 1 && lane < 4) {
+    const uint32_t v = s_stat[lane];
+    s_stat[lane] = 0;
+    u64 *dst = lane == 0 ? &ctl->cnt_N : lane == 1 ? &ctl->cnt_E : lane == 2 ? &ctl->cnt_rec : &ctl->cnt_Z;
+    if (v) atomicAdd(dst, (u64)v);   // (cnt_Z: closure paths priced, per candidate, not per token as the reference counts)
+  }
+  if (wave == 0) {
+    int last = 0;
+    if (lane == 0) last = atomicSub(&ctl->tiles_left, 1) == 1;
+    last = __shfl(last, 0, 64);
+    if (last) plan_channel(D, c, group, par);
+  }
+}
+
 // =========================================================================================
 // expand_kernel: a fixed grid of 512-thread workgroups; workgroup w takes tile w of the frame's tile
 // list, further tiles by ticket.
@@ -371,7 +405,22 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
     int32_t *bucket_lm = kBig ? D.bucket_lm + (size_t)c * P * bcap : nullptr;
     int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
     uint32_t nN = 0, nE = 0, nR = 0, nZf = 0;   // per thread and tile: 32 bits are plenty (and four registers less at the 80-VGPR limit)
-    {
+    if (kFused && !kBig && !kReplay && n == 0) {
+      // SEED TILE (DecoderDev::seed_tiles): next_cutoff's seed from the best token's emitting arcs, base-inl.h:282-300 --
+      // td.tok_begin = the token's row, td.cutoff = its cost.  (bc + w) - loglike as the reference writes it (:295), then
+      // + adaptive_beam: min(x) + ab == min(x + ab), float addition being monotone
+      const int brow = td.tok_begin;
+      const float bc = td.cutoff;
+      const uint32_t hx = (uint32_t)D.g.arcs[brow].x;
+      const int deg = (int)(hx >> kEpsBits), ab0 = brow + 1 + (int)(hx & kEpsMask);
+      float seed = kInf;
+      for (int e = tid; e < deg; e += kExpandThreads) {
+        const int4 arc = D.g.arcs[ab0 + e];
+        seed = fminf(seed, (bc + __int_as_float(arc.z)) - llrow[arc.x & D.g.col_mask]);
+      }
+      seed = wave_min_f(seed);
+      if (lane == 0 && seed < kInf) atomicMin(&ctl->bound, f2o(seed + ab));
+    } else {
     // two adjacent frontier tokens per thread (a tile is 1024 tokens, so the tiles of a whole
     // batch fit the chip's resident workgroup slots in one wave)
     int deg[kTokPerThread], arcbeg[kTokPerThread];
@@ -499,6 +548,10 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       int4 arcv[kCandPerThread], leafv[kFused ? kCandPerThread : 1];
       int olv[kBig ? kCandPerThread : 1];
       float llv[kCandPerThread];
+      // next_cutoff as it stands NOW, asked for with the arcs (it arrives with them): what the seed tile and the other tiles
+      // of the channel have tightened since this tile's last look
+      uint32_t bfresh = 0xFFFFFFFFu;
+      if constexpr (!kReplay) bfresh = ld_agent(&ctl->bound);
 #pragma unroll
       for (int k = 0; k < kCandPerThread; ++k) {
         if constexpr ((kAbl & 2) != 0) arcv[k] = make_int4(1 + (av[k] & 1023), 0, __float_as_int(0.5f), av[k]);   // replay without row traffic
@@ -580,6 +633,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         }
       }
       if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 12, tq); }
+      if constexpr (!kReplay) bound = fminf(bound, o2f(bfresh));
       // base-inl.h:330-333: tighten next_cutoff by the best candidate seen (wave-aggregated)
       const float cand = wave_min_f(tmin) + ab;
       if (cand < bound) {
@@ -656,32 +710,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       if (nR == 0x7FFFFFFFu) D.dbg_t[63] = nN + nE + nZf;   // (keeps the counts alive)
       break;   // one tile per workgroup: the replay grid covers every tile
     }
-    // work counters: summed over the workgroup in LDS, then one set of atomics per tile from a wave that has nothing else to
-    // wait for -- every atomic on the channel's control line queues behind the other tiles' (next_cutoff, the countdown)
-    {
-      const uint32_t wN = (uint32_t)wave_sum_u64(nN), wE = (uint32_t)wave_sum_u64(nE), wZ = kFused ? (uint32_t)wave_sum_u64(nZf) : 0u;
-      if (lane == 0) {
-        if (wN) atomicAdd(&s_stat[0], wN);
-        if (wE) atomicAdd(&s_stat[1], wE);
-        if (nR) atomicAdd(&s_stat[2], nR);
-        if (wZ) atomicAdd(&s_stat[3], wZ);
-      }
-    }
-    // the channel's last tile plans its insert work items.  Every wave's bucket atomics have returned (their results were
-    // used above), so an LDS-only barrier orders them before the countdown; only wave 0 waits for the countdown's answer
-    lds_barrier();
-    if (wave == 1 && lane < 4) {
-      const uint32_t v = s_stat[lane];
-      s_stat[lane] = 0;
-      u64 *dst = lane == 0 ? &ctl->cnt_N : lane == 1 ? &ctl->cnt_E : lane == 2 ? &ctl->cnt_rec : &ctl->cnt_Z;
-      if (v) atomicAdd(dst, (u64)v);   // (cnt_Z: closure paths priced, per candidate, not per token as the reference counts)
-    }
-    if (wave == 0) {
-      int last = 0;
-      if (lane == 0) last = atomicSub(&ctl->tiles_left, 1) == 1;
-      last = __shfl(last, 0, 64);
-      if (last) plan_channel(D, c, group, par);
-    }
+    tile_tail(D, c, ctl, group, par, nN, nE, nR, kFused ? nZf : 0u, s_stat);
     // next tile: the first gridDim.x tiles are taken statically, the rest by ticket
     if (total_tiles <= (int)gridDim.x) break;
     if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(&fc->ticket[par], 1);
@@ -704,6 +733,275 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel_fused_timed(Deco
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm_timed(DecoderDev D, int group, int par) { expand_body<true, false, 0, true>(D, group, par); }
 template <int kAbl>
 __global__ __launch_bounds__(kExpandThreads, 6) void expand_replay_fused(DecoderDev D, int group, int par) { expand_body<false, true, kAbl>(D, group, par); }
+
+// =========================================================================================
+// expand_kernel_staged: the expansion of decoders on the fused rows (best-path and lattice, not biglm) with a tile's
+// arcs STAGED IN LDS by the chip's gather DMA (global_load_lds_dwordx4 with per-lane source addresses, MI355X_MICROARCH
+// "Indexed rows: gather into LDS").
+//
+// expand_body keeps a thread's candidates in registers, two at a time, so a 512-token tile is four to five ROUNDS of
+// {arc load -> log-likelihood load -> bucket atomic -> write}: ~19 dependent memory round trips per tile, and the launch
+// lasts as long as its slowest tile's chain.  Here every row slot of the tile (emitting arcs; both slots of the pseudo arcs)
+// is one lane's 16-byte DMA into an LDS image of the tile -- 64 slots per wave instruction, all of a tile's instructions
+// issued back to back, no register per slot -- then one 4-byte DMA per slot fetches its log-likelihood, and the whole
+// tile is priced, pruned, ranked by hash partition (LDS atomics) and written to the buckets in ONE pass: tokens -> arcs ->
+// log-likelihoods -> bucket atomics -> stores, five round trips whatever the tile holds, one global atomic per partition
+// per TILE.  The records go to their bucket slots straight from the LDS image (rank within the tile's share of the
+// bucket): neighbouring lanes write to different partitions, the lines fill in L2.
+// A tile is kStTokens = 256 frontier tokens (one per thread); its slots beyond kStSlots are staged in further passes.
+// LDS: 24 KB slots + 6 KB log-likelihoods + 4 KB per-token scan = 34.5 KB: four workgroups per CU.
+// Arithmetic, pruning and record layout are expand_body<false, true>'s, to the bit.
+// =========================================================================================
+constexpr int kStThreads = 256;
+constexpr int kStTokens = 256;
+constexpr int kLog2StTokens = 8;
+constexpr int kStSlots = 1536;
+constexpr int kStIter = kStSlots / kStThreads;   // slots per thread and pass
+typedef __attribute__((address_space(3))) void *lds_void_p;
+typedef const __attribute__((address_space(1))) void *gbl_void_p;
+
+__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev D, int group, int par) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  FrameCtl *fc = D.fctl + group;
+  const TileDesc td_first = D.tiles[(size_t)group * D.tile_cap + min((int)blockIdx.x, D.tile_cap - 1)];
+  const int total_tiles = fc->total_tiles[par];
+  const float kInf = __builtin_huge_valf();
+  const int P = D.n_part, log2part = D.log2part, bcap = D.bucket_cap;
+
+  __shared__ int4 s_arc[kStSlots];     // the tile's row slots as they stand in rows[]; a priced candidate's record replaces its slot
+  __shared__ float s_ll[kStSlots];     // the log-likelihood of each slot's column
+  __shared__ int s_base[kStTokens + 1], s_arcbeg[kStTokens], s_nemit[kStTokens];
+  __shared__ float s_cost[kStTokens];
+  __shared__ int s_wsum[kStThreads / 64], s_cnt[64], s_gbase[64];
+  __shared__ uint32_t s_stat[4], s_bound;
+  __shared__ int s_ticket;
+
+  if (blockIdx.x == 0 && tid == 0) {  // lists of the previous step are consumed
+    fc->total_tiles[par ^ 1] = 0;
+    fc->ticket[par ^ 1] = 0;
+    fc->n_items[par ^ 1] = 0;
+    fc->n_small[par ^ 1] = 0;
+    fc->item_ticket[par ^ 1] = 0;
+  }
+  const TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap;
+  if (tid < 4) s_stat[tid] = 0;
+  if (tid < 64) s_cnt[tid] = 0;
+  for (int t = blockIdx.x; t < total_tiles;) {
+    const TileDesc td = t == (int)blockIdx.x ? td_first : tiles[t];
+    const int c = td.chan;
+    ChanCtl *ctl = D.ctl + c;
+    const int n = td.tok_count;
+    const int tok0 = td.tok_begin;
+    const float cutoff = td.cutoff, ab = td.adaptive_beam;
+    const float *llrow = td.llrow;
+    int4 *bucket = D.bucket + (size_t)c * P * bcap;
+    int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
+    uint32_t nN = 0, nE = 0, nR = 0, nZf = 0;
+    if (n == 0) {
+      // SEED TILE (DecoderDev::seed_tiles): next_cutoff's seed from the best token's emitting arcs, base-inl.h:282-300 --
+      // td.tok_begin = the token's row, td.cutoff = its cost.  (bc + w) - loglike as the reference writes it (:295), then
+      // + adaptive_beam: min(x) + ab == min(x + ab), float addition being monotone
+      const int brow = td.tok_begin;
+      const float bc = td.cutoff;
+      const uint32_t hx = (uint32_t)D.g.arcs[brow].x;
+      const int deg = (int)(hx >> kEpsBits), ab0 = brow + 1 + (int)(hx & kEpsMask);
+      float seed = kInf;
+      for (int e = tid; e < deg; e += kStThreads) {
+        const int4 arc = D.g.arcs[ab0 + e];
+        seed = fminf(seed, (bc + __int_as_float(arc.z)) - llrow[arc.x & D.g.col_mask]);
+      }
+      seed = wave_min_f(seed);
+      if (lane == 0 && seed < kInf) atomicMin(&ctl->bound, f2o(seed + ab));
+    } else {
+      // ---- the tile's tokens: one per thread; its row slots = emitting arcs + two per pseudo arc -------------------
+      {
+        const int4 tk = tid < n ? (D.tok + (size_t)c * D.arena_cap + tok0)[tid] : make_int4(0, 0x7F800000, 0, 0);
+        const float cost = __int_as_float(tk.y);
+        int nem = 0, slots = 0, arcbeg = 0;
+        if (tid < n && cost <= cutoff) {  // base-inl.h:315
+          uint32_t code = kCodeUnknown;
+          if (D.degcode) {   // the token's degree code (wfst_device.h): its arcs without a look at the row header
+            const int zz = tk.z;
+            const uint32_t rest = zz >= 0 ? (uint32_t)zz >> D.tok_idx_bits : zz <= kPrevUnresolved ? (uint32_t)(kPrevUnresolved - zz) : (kCodeUnknown >> 2);
+            code = (rest << 2) | ((uint32_t)tk.w >> 30);
+          }
+          if (code != kCodeUnknown) {
+            nem = (int)((code >> 2) & 15u);
+            slots = nem + 2 * (int)(code >> 6);
+            arcbeg = tk.x + 1 + (int)(code & 3u);
+          } else {
+            const int4 hdr = D.g.arcs[tk.x];  // row header: {(n_emit << 12) | n_eps, -, pseudo arcs, -}
+            nem = (int)((uint32_t)hdr.x >> kEpsBits);
+            slots = nem + 2 * hdr.z;
+            arcbeg = tk.x + 1 + (int)((uint32_t)hdr.x & kEpsMask);
+          }
+          nN++;
+          nE += nem;
+        }
+        s_nemit[tid] = nem;
+        s_cost[tid] = cost;
+        s_arcbeg[tid] = arcbeg;
+        int incl = slots;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int v = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kStThreads / 64; ++w) {
+          const int v = s_wsum[w];
+          if (w < wave) wbase += v;
+          tot += v;
+        }
+        s_base[tid] = wbase + incl - slots;
+        if (tid == 0) { s_base[kStTokens] = tot; s_bound = 0xFFFFFFFFu; }
+        __syncthreads();
+      }
+      const int total = s_base[kStTokens];
+      float bound = kInf;
+      for (int s0 = 0; s0 < total; s0 += kStSlots) {
+        const int S = min(kStSlots, total - s0);
+        // ---- (a) every slot of the pass: one lane's 16-byte DMA into the LDS image (64 consecutive slots per instruction) ----
+        int lo[kStIter];
+#pragma unroll
+        for (int i = 0; i < kStIter; ++i) {
+          const int g = wave + i * (kStThreads / 64);   // this wave's i-th group of 64 slots
+          const int j = g * 64 + lane;
+          int l = 0, h = kStTokens;  // s_base[l] <= s0 + j < s_base[h]
+          const int J = s0 + min(j, S - 1);
+#pragma unroll
+          for (int step = 0; step < kLog2StTokens; ++step) {
+            const int mid = (l + h) >> 1;
+            if (s_base[mid] <= J) l = mid; else h = mid;
+          }
+          lo[i] = l;
+          if (g * 64 < S) {   // (wave-uniform)
+            const int4 *src = D.g.arcs + (s_arcbeg[l] + (J - s_base[l]));
+            if (j < S) __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(s_arc + g * 64), 16, 0, 0);
+          }
+        }
+        // next_cutoff as it stands now (the seed tile's and the other tiles' tightenings): asked for here, back with the arcs
+        const uint32_t bfresh = ld_agent(&ctl->bound);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slots have landed (a lane reads back its own)
+        // ---- (b) the log-likelihood of every arc slot: one lane's 4-byte DMA (a pseudo arc's second slot has no column) ----
+#pragma unroll
+        for (int i = 0; i < kStIter; ++i) {
+          const int g = wave + i * (kStThreads / 64);
+          const int j = g * 64 + lane;
+          if (g * 64 < S) {
+            const int off = s0 + min(j, S - 1) - s_base[lo[i]], pi = off - s_nemit[lo[i]];
+            const bool second = pi >= 0 && (pi & 1);
+            const int col = (j < S && !second) ? (s_arc[j].x & D.g.col_mask) : 0;
+            if (j < S) __builtin_amdgcn_global_load_lds((gbl_void_p)(llrow + col), (lds_void_p)(s_ll + g * 64), 4, 0, 0);
+          }
+        }
+        bound = fminf(bound, o2f(bfresh));
+        __syncthreads();   // (drains the DMAs; a pseudo arc's second slot may be another wave's)
+        // ---- (c) price every candidate; its record takes the place of its slot ------------------------------------------
+        float tmin = kInf;
+        uint32_t cand_mask = 0;   // bit i: slot i of this thread is a candidate (not a pseudo arc's second slot, not padding)
+#pragma unroll
+        for (int i = 0; i < kStIter; ++i) {
+          const int g = wave + i * (kStThreads / 64);
+          const int j = g * 64 + lane;
+          if (j >= S) continue;
+          const int l = lo[i];
+          const int off = s0 + j - s_base[l], nem = s_nemit[l], pi = off - nem;
+          if (pi >= 0 && (pi & 1)) continue;   // second slot of a pseudo arc
+          const bool pseudo = pi >= 0;
+          const int a = s_arcbeg[l] + off;     // the slot's index in rows[]
+          const int4 arc = s_arc[j];
+          const float base_cost = (s_cost[l] + (-s_ll[j])) + __int_as_float(arc.z);   // base-inl.h:326-329
+          int4 rec;
+          if (pseudo) {
+            // the emitting arc's arrival carried on over one path of the target's epsilon closure -- ((cur + ac) + w) + w_1
+            // + ... + w_k in path order (base-inl.h:329, 414): an epsilon arrival at the path's end state; it does not
+            // tighten next_cutoff (only emitting arcs do, base-inl.h:330-333 vs 415)
+            const int4 leaf = (j + 1 < S) ? s_arc[j + 1] : D.g.arcs[a + 1];   // (a pair cut by the end of the pass)
+            float tt = base_cost;
+            if (leaf.z == 1) {
+              tt = tt + __int_as_float(leaf.y);
+            } else if (leaf.z == 2) {
+              tt = (tt + __int_as_float(leaf.w)) + __int_as_float(leaf.y);
+            } else {
+              const float *pw = D.g.pseudo_w + (size_t)arc.y * kPseudoDepthMax;
+              for (int u = 0; u < leaf.z; ++u) tt = tt + pw[u];
+            }
+            rec = make_int4(arc.w, __float_as_int(tt), kPrevUnresolved, (int)((uint32_t)leaf.x | kEpsRec));
+            nZf++;
+          } else {
+            rec = make_int4(arc.w, __float_as_int(base_cost), tok0 + l, (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
+            tmin = fminf(tmin, base_cost);
+          }
+          if (D.degcode) {   // the degree code of the state arrived at rides in the record (expand_body)
+            const uint32_t code = (uint32_t)arc.x >> kColBits;
+            rec.w = (int)(((uint32_t)rec.w & 0x3FFFFFFFu) | (code << 30));
+            rec.z = pseudo ? kPrevUnresolved - (int)(code >> 2) : (int)((uint32_t)rec.z | ((code >> 2) << D.tok_idx_bits));
+          }
+          s_arc[j] = rec;
+          cand_mask |= 1u << i;
+        }
+        // base-inl.h:330-333: next_cutoff tightened by the tile's best emitting candidate -- once for the whole tile
+        {
+          const float wmin = wave_min_f(tmin);
+          if (lane == 0 && wmin < kInf) atomicMin(&s_bound, f2o(wmin + ab));
+          lds_barrier();
+          const uint32_t tb = s_bound;
+          if (o2f(tb) < bound) {
+            if (tid == 0) atomicMin(&ctl->bound, tb);   // (the other tiles read it afresh: bfresh)
+            bound = o2f(tb);
+          }
+        }
+        // ---- (d) survivors: rank within the tile's share of their hash partition -------------------------------------
+        int pr[kStIter];
+#pragma unroll
+        for (int i = 0; i < kStIter; ++i) {
+          pr[i] = -1;
+          if (!(cand_mask & (1u << i))) continue;
+          const int j = (wave + i * (kStThreads / 64)) * 64 + lane;
+          const int2 xy = *reinterpret_cast<const int2 *>(&s_arc[j]);
+          if (__int_as_float(xy.y) < bound) {
+            const int part = part_of(hash32(xy.x), log2part);
+            pr[i] = (part << 16) | atomicAdd(&s_cnt[part], 1);
+          }
+        }
+        lds_barrier();
+        if (tid < 64) {
+          const int cnt = tid < P ? s_cnt[tid] : 0;
+          int g = 0;
+          if (cnt) {
+            g = atomicAdd(&bucket_cnt[tid], cnt);   // ONE global atomic per partition and tile
+            if (g + cnt > bcap) atomicOr(&ctl->error, kErrBucketFull);
+          }
+          s_gbase[tid] = g;
+          s_cnt[tid] = 0;
+          nR += (uint32_t)wave_sum_u64((u64)cnt) * (tid == 0 ? 1u : 0u);
+        }
+        lds_barrier();
+        // ---- (e) the records, straight from the LDS image to their bucket slots ------------------------------------------
+#pragma unroll
+        for (int i = 0; i < kStIter; ++i) {
+          if (pr[i] < 0) continue;
+          const int j = (wave + i * (kStThreads / 64)) * 64 + lane;
+          const int p = pr[i] >> 16, gi = s_gbase[p] + (pr[i] & 0xFFFF);
+          if (gi < bcap) bucket[(size_t)p * bcap + gi] = s_arc[j];
+        }
+        __syncthreads();   // the image is free for the next pass / tile
+        if (tid == 0) s_bound = 0xFFFFFFFFu;
+      }
+    }
+    tile_tail(D, c, ctl, group, par, nN, nE, nR, nZf, s_stat);
+    // next tile: the first gridDim.x tiles are taken statically, the rest by ticket
+    if (total_tiles <= (int)gridDim.x) break;
+    if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(&fc->ticket[par], 1);
+    __syncthreads();
+    t = s_ticket;
+    __syncthreads();
+  }
+}
 
 // =========================================================================================
 // insert_kernel.  A bucket whose records could overfill the LDS table is processed in 2^k
@@ -1060,6 +1358,8 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
       last = atomicSub(&ctl->items_left, 1) == 1;
     }
     s_last = last;
+    // (the ticket is taken when the item is DONE: asked for earlier, a busy workgroup would sit on an item that an idle one
+    // could have had -- measured: +1.5 ms per step)
     s_item = (int)gridDim.x + atomicAdd(&fc->item_ticket[par], 1);
   }
   __syncthreads();
@@ -1604,9 +1904,9 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
     }
   }
 
-  // seed next_cutoff from the best token's emitting arcs, base-inl.h:282-300
+  // seed next_cutoff from the best token's emitting arcs, base-inl.h:282-300 (seed_tiles: left to the expansion's seed tile)
   float seed = kInf;
-  if (n > 0) {
+  if (n > 0 && !(!kBig && D.seed_tiles)) {
     int4 bt;
     if (D.best_row) bt = make_int4((int)(uint32_t)best, __float_as_int(best_w), 0, 0);   // the best token's row rides in best_next itself
     else bt = tokc[(uint32_t)best];
@@ -1647,36 +1947,44 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
     // resident at once (~1500 workgroups; other groups' launches share them).  Judged per channel on its own token
     // count times the channels of the launch: 16 channels x 4.3 k tokens get 128-token tiles (16.7 -> 14.1 ms per step),
     // 64 channels and more the full 512.
-    int tile_tokens = kTileTokens;
+    int tile_tokens = D.staged ? kStTokens : kTileTokens;
     if ((int64_t)n * (int)gridDim.x <= 700ll * 256) tile_tokens = 256;
     if ((int64_t)n * (int)gridDim.x <= 700ll * 128) tile_tokens = 128;
     sh.tile_tokens = tile_tokens;
     const int ntiles = (n + tile_tokens - 1) / tile_tokens;
     sh.active = 0;
-    ctl->tiles_left = ntiles;
+    const int nseed = (!kBig && D.seed_tiles && ntiles > 0) ? 1 : 0;   // the seed tile, listed first
+    ctl->tiles_left = ntiles + nseed;
     if (ntiles == 0 && D.two_launch) {   // a channel without tokens: no tile will plan its insert items, yet its frame must be closed
       ctl->items_left = 1;
       push_empty_item(D, c, group, par);
     }
     if (ntiles > 0) {
-      const int start = atomicAdd(&D.fctl[group].total_tiles[par], ntiles);
+      const int start = atomicAdd(&D.fctl[group].total_tiles[par], ntiles + nseed);
       ctl->tile_start = start;
-      if (start + ntiles <= D.tile_cap) { sh.sel_k = (uint32_t)start; sh.active = ntiles; }
+      if (start + ntiles + nseed <= D.tile_cap) { sh.sel_k = (uint32_t)start; sh.active = ntiles + nseed; }
       else ctl->error |= kErrFrontierFull;
     }
   }
   __syncthreads();
   const int ntl = sh.active;
+  const int nseed = (!kBig && D.seed_tiles && ntl > 0) ? 1 : 0;
   TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap + sh.sel_k;
   for (int i = tid; i < ntl; i += kBT) {
     TileDesc td;
     td.chan = c;
-    td.tok_begin = ctl->front_begin + i * sh.tile_tokens;
-    td.tok_count = min(sh.tile_tokens, n - i * sh.tile_tokens);
+    const int k = i - nseed;
+    td.tok_begin = ctl->front_begin + k * sh.tile_tokens;
+    td.tok_count = min(sh.tile_tokens, n - k * sh.tile_tokens);
     td.cutoff = cutoff;
     td.adaptive_beam = ab;
     td.pad = (int32_t)ctl->bound;   // next_cutoff's seed of the frame (the replay instantiations of the expansion start from it)
     td.llrow = D.ll_base[c] + (size_t)ctl->n_decoded * D.stride;
+    if (k < 0) {   // the seed tile: the best token's row and cost
+      td.tok_begin = (int32_t)(uint32_t)best;
+      td.tok_count = 0;
+      td.cutoff = best_w;
+    }
     tiles[i] = td;
   }
   if (tid == 0) dbg_phase(D, 5, tq);
@@ -1739,9 +2047,9 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
   // GetCutoff with max_active and min_active out of reach (base-inl.h:138-234; prep_frame's general path gives the same)
   const float ab = D.beam, cutoff = best_w + D.beam;
   const float *llrow = D.ll_base[c] + (size_t)nd * D.stride;
-  // seed next_cutoff from the best token's emitting arcs, base-inl.h:282-300
+  // seed next_cutoff from the best token's emitting arcs, base-inl.h:282-300 (seed_tiles: left to the expansion's seed tile)
   float seed = kInf;
-  if (n > 0) {
+  if (n > 0 && !D.seed_tiles) {
     const int brow = (int)(uint32_t)best;
     const uint32_t hx = (uint32_t)D.g.arcs[brow].x;
     const int deg = (int)(hx >> kEpsBits), ab0 = brow + 1 + (int)(hx & kEpsMask);
@@ -1750,12 +2058,14 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
       seed = fminf(seed, (best_w + __int_as_float(arc.z)) - llrow[arc.x & D.g.col_mask]);  // base-inl.h:295
     }
   }
-  seed = wave_min_f(seed);
-  if (lane == 0) sh.redf[wave] = seed;
-  __syncthreads();
+  if (!D.seed_tiles) {   // (uniform over the workgroup)
+    seed = wave_min_f(seed);
+    if (lane == 0) sh.redf[wave] = seed;
+    __syncthreads();
+  }
   if (tid == 0) {
-    float s = sh.redf[0];
-    for (int w = 1; w < kT / 64; ++w) s = fminf(s, sh.redf[w]);
+    float s = kInf;
+    if (!D.seed_tiles) for (int w = 0; w < kT / 64; ++w) s = fminf(s, sh.redf[w]);
     const float next_cutoff = s + ab;
     ctl->cur_cutoff = cutoff;
     ctl->adaptive_beam = ab;
@@ -1763,20 +2073,21 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
     ctl->new_count = 0;
     ctl->best_next = ~0ull;
     ctl->active = 1;
-    int tile_tokens = kTileTokens;   // (as prep_frame)
+    int tile_tokens = D.staged ? kStTokens : kTileTokens;   // (as prep_frame)
     if ((int64_t)n * chan_cnt <= 700ll * 256) tile_tokens = 256;
     if ((int64_t)n * chan_cnt <= 700ll * 128) tile_tokens = 128;
     const int ntiles = (n + tile_tokens - 1) / tile_tokens;
+    const int nseed = (D.seed_tiles && ntiles > 0) ? 1 : 0;   // the seed tile, listed first
     sh.tile_tokens = tile_tokens;
     sh.ntiles = 0;
-    ctl->tiles_left = ntiles;
+    ctl->tiles_left = ntiles + nseed;
     if (ntiles == 0) {   // a channel without tokens: an empty insert item closes its next frame
       ctl->items_left = 1;
       push_empty_item(D, c, group, par_next);
     } else {
-      const int start = atomicAdd(&D.fctl[group].total_tiles[par_next], ntiles);
+      const int start = atomicAdd(&D.fctl[group].total_tiles[par_next], ntiles + nseed);
       ctl->tile_start = start;
-      if (start + ntiles <= D.tile_cap) { sh.tile_start = start; sh.ntiles = ntiles; }
+      if (start + ntiles + nseed <= D.tile_cap) { sh.tile_start = start; sh.ntiles = ntiles + nseed; }
       else atomicOr(&ctl->error, kErrFrontierFull);
     }
     sh.pad_bits = (int32_t)f2o(s < kInf ? next_cutoff : kInf);   // next_cutoff's seed as the tiles carry it (TileDesc::pad)
@@ -1785,15 +2096,22 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
   const int ntl = sh.ntiles;
   TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap + sh.tile_start;
   const int32_t pad_bits = sh.pad_bits;
+  const int nseed = (D.seed_tiles && ntl > 0) ? 1 : 0;
   for (int i = tid; i < ntl; i += kT) {
     TileDesc td;
     td.chan = c;
-    td.tok_begin = sh.front_begin + i * sh.tile_tokens;
-    td.tok_count = min(sh.tile_tokens, n - i * sh.tile_tokens);
+    const int k = i - nseed;
+    td.tok_begin = sh.front_begin + k * sh.tile_tokens;
+    td.tok_count = min(sh.tile_tokens, n - k * sh.tile_tokens);
     td.cutoff = cutoff;
     td.adaptive_beam = ab;
     td.pad = pad_bits;
     td.llrow = llrow;
+    if (k < 0) {   // the seed tile: the best token's row and cost
+      td.tok_begin = (int32_t)(uint32_t)best;
+      td.tok_count = 0;
+      td.cutoff = best_w;
+    }
     tiles[i] = td;
   }
 }
@@ -2830,6 +3148,7 @@ void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hi
     return;
   }
   if (D.big) hipLaunchKernelGGL(expand_kernel_biglm, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+  else if (D.fused && D.staged) hipLaunchKernelGGL(expand_kernel_staged, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
   else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
   else hipLaunchKernelGGL(expand_kernel_plain, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
 }
