@@ -1005,7 +1005,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.best_row = (D.fused && !D.lattice && !big) ? 1 : 0;
   D.two_launch = 0;
   D.gc_stride = 1;
-  D.staged = (D.fused && !big && !(O.debug & 0x8880)) ? 1 : 0;   // (0x800 replay / 0x80 phase timers: expand_body's; 0x8000: A/B)
+  D.staged = (D.fused && !big && !(O.debug & 0x8800)) ? 1 : 0;   // (0x800: the replay experiments are expand_body's; 0x8000: A/B)
   D.seed_tiles = (D.best_row && !(O.debug & 0x4800)) ? 1 : 0;   // (0x800: the replay experiments start from the frame's seed; 0x4000: A/B)
   if (D.best_row && !(O.debug & 0x2000) && cfg->max_active >= L.max_tokens_per_frame && cfg->min_active == 0) {
     int64_t reserve = std::max<int64_t>(2ll * L.max_tokens_per_frame, L.arena_tokens / 8);
@@ -1083,8 +1083,8 @@ void wfst_decoder_free(wfst_decoder *d) {
     if (hipMemcpy(t, d->dbg_t.p, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
       const char *names[] = {"closure:setup", "closure:rounds", "closure:commit", "closure:clear", "closure:finalize", "closure:prep",
                              "insert:init", "insert:pass1", "insert:alloc", "insert:pass2", "insert:tail",
-                             "expand:tile-load+scan", "expand:candidates", "expand:bound+count", "expand:bucket-atomics",
-                             "expand:write", "expand:stats+ticket"};
+                             "expand:tile-load+scan", "expand:candidates (staged: arcs landed)", "expand:bound+count (staged: loglikes landed)", "expand:bucket-atomics (staged: priced)",
+                             "expand:write (staged: ranked + bucket atomics)", "expand:stats+ticket (staged: written)"};
       for (int k = 0; k < 17; ++k)
         if (t[3 * k + 2])
           fprintf(stderr, "[wfst dbg] %-18s n=%llu mean=%.2f us max=%.2f us\n", names[k], t[3 * k + 2],

@@ -755,13 +755,15 @@ __global__ __launch_bounds__(kExpandThreads, 6) void expand_replay_fused(Decoder
 constexpr int kStThreads = 256;
 constexpr int kStTokens = 256;
 constexpr int kLog2StTokens = 8;
-constexpr int kStSlots = 1536;
+constexpr int kStSlots = 1536;   // (1280 / 1024 with five / six workgroups per CU measured slower: more tiles need a second pass)
 constexpr int kStIter = kStSlots / kStThreads;   // slots per thread and pass
 typedef __attribute__((address_space(3))) void *lds_void_p;
 typedef const __attribute__((address_space(1))) void *gbl_void_p;
 
-__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev D, int group, int par) {
+template <bool kTimers>
+__device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int group, int par) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long tq = kTimers ? wall_clock64() : 0ull;
   FrameCtl *fc = D.fctl + group;
   const TileDesc td_first = D.tiles[(size_t)group * D.tile_cap + min((int)blockIdx.x, D.tile_cap - 1)];
   const int total_tiles = fc->total_tiles[par];
@@ -862,6 +864,7 @@ __global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev
       }
       const int total = s_base[kStTokens];
       float bound = kInf;
+      if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 11, tq); }
       for (int s0 = 0; s0 < total; s0 += kStSlots) {
         const int S = min(kStSlots, total - s0);
         // ---- (a) every slot of the pass: one lane's 16-byte DMA into the LDS image (64 consecutive slots per instruction) ----
@@ -886,6 +889,7 @@ __global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev
         // next_cutoff as it stands now (the seed tile's and the other tiles' tightenings): asked for here, back with the arcs
         const uint32_t bfresh = ld_agent(&ctl->bound);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slots have landed (a lane reads back its own)
+        if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 12, tq); }
         // ---- (b) the log-likelihood of every arc slot: one lane's 4-byte DMA (a pseudo arc's second slot has no column) ----
 #pragma unroll
         for (int i = 0; i < kStIter; ++i) {
@@ -900,6 +904,7 @@ __global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev
         }
         bound = fminf(bound, o2f(bfresh));
         __syncthreads();   // (drains the DMAs; a pseudo arc's second slot may be another wave's)
+        if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 13, tq); }
         // ---- (c) price every candidate; its record takes the place of its slot ------------------------------------------
         float tmin = kInf;
         uint32_t cand_mask = 0;   // bit i: slot i of this thread is a candidate (not a pseudo arc's second slot, not padding)
@@ -955,6 +960,7 @@ __global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev
             bound = o2f(tb);
           }
         }
+        if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 14, tq); }
         // ---- (d) survivors: rank within the tile's share of their hash partition -------------------------------------
         int pr[kStIter];
 #pragma unroll
@@ -981,6 +987,7 @@ __global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev
           nR += (uint32_t)wave_sum_u64((u64)cnt) * (tid == 0 ? 1u : 0u);
         }
         lds_barrier();
+        if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 15, tq); }
         // ---- (e) the records, straight from the LDS image to their bucket slots ------------------------------------------
 #pragma unroll
         for (int i = 0; i < kStIter; ++i) {
@@ -991,6 +998,7 @@ __global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev
         }
         __syncthreads();   // the image is free for the next pass / tile
         if (tid == 0) s_bound = 0xFFFFFFFFu;
+        if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 16, tq); }
       }
     }
     tile_tail(D, c, ctl, group, par, nN, nE, nR, nZf, s_stat);
@@ -1000,8 +1008,11 @@ __global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev
     __syncthreads();
     t = s_ticket;
     __syncthreads();
+    if constexpr (kTimers) tq = wall_clock64();
   }
 }
+__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev D, int group, int par) { expand_staged_body<false>(D, group, par); }
+__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged_timed(DecoderDev D, int group, int par) { expand_staged_body<true>(D, group, par); }
 
 // =========================================================================================
 // insert_kernel.  A bucket whose records could overfill the LDS table is processed in 2^k
@@ -1360,7 +1371,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
     s_last = last;
     // (the ticket is taken when the item is DONE: asked for earlier, a busy workgroup would sit on an item that an idle one
     // could have had -- measured: +1.5 ms per step)
-    s_item = (int)gridDim.x + atomicAdd(&fc->item_ticket[par], 1);
+    s_item = n_items > (int)gridDim.x ? (int)gridDim.x + atomicAdd(&fc->item_ticket[par], 1) : n_items;   // (no ticket where every item had its workgroup from the start)
   }
   __syncthreads();
   it = s_item;
@@ -3142,7 +3153,8 @@ void launch_init(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s
 // one group's latency-bound closure overlaps another group's expand / insert)
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s) {
   if (D.dbg & 128) {   // phase timers: their own instantiations
-    if (D.big) hipLaunchKernelGGL(expand_kernel_biglm_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+    if (D.fused && D.staged) hipLaunchKernelGGL(expand_kernel_staged_timed, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
+    else if (D.big) hipLaunchKernelGGL(expand_kernel_biglm_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
     else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
     else hipLaunchKernelGGL(expand_kernel_plain_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
     return;
