@@ -1005,7 +1005,11 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.best_row = (D.fused && !D.lattice && !big) ? 1 : 0;
   D.two_launch = 0;
   D.gc_stride = 1;
-  D.staged = (D.fused && !big && !(O.debug & 0x8800)) ? 1 : 0;   // (0x800: the replay experiments are expand_body's; 0x8000: A/B)
+  // expand_kernel_staged (the tile's arcs staged in LDS by gather DMA): fused decoders whose max_active cannot bind.  Where it
+  // binds, most of a frame's tokens lie above the cutoff and are not expanded: the staged kernel's fixed cost per 256-token tile
+  // then buys a fraction of a tile's work (measured at the service's 7000: 42.6 vs 31.4 ms of expansion per step), and
+  // expand_kernel_fused's 512-token tiles stay.  (0x800: the replay experiments are expand_body's; 0x8000: A/B)
+  D.staged = (D.fused && !big && cfg->max_active >= L.max_tokens_per_frame && !(O.debug & 0x8800)) ? 1 : 0;
   D.seed_tiles = (D.best_row && !(O.debug & 0x4800)) ? 1 : 0;   // (0x800: the replay experiments start from the frame's seed; 0x4000: A/B)
   if (D.best_row && !(O.debug & 0x2000) && cfg->max_active >= L.max_tokens_per_frame && cfg->min_active == 0) {
     int64_t reserve = std::max<int64_t>(2ll * L.max_tokens_per_frame, L.arena_tokens / 8);
