@@ -108,6 +108,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of each timed CPU-baseline leg (1 thread, all cores)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores leg (0 = every CPU this process may run on)")
     ap.add_argument("--no-service-point", action="store_true", help="skip the second workload (single planted path, 7000/200)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the biglm (BASELINE configs[3]) and beam-15 lattice (configs[4]) legs the "
+                    "default run appends to its line (each a child process running this script with --biglm / --lattice-links)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="keep the live parity sample but skip the timed CPU legs (the legs' runs)")
     ap.add_argument("--biglm", action="store_true", help="BASELINE configs[3]: on-the-fly LM rescoring (wfst_decoder_create_biglm) with a "
                     "synthetic bigram (old) / trigram (new) LM pair over the graph's 50k words; NOT the headline")
     ap.add_argument("--lm-old", default="20000,5,0,0", help="old LM: bigram contexts, successors, trigram contexts, successors")
@@ -581,29 +584,51 @@ def main():
             else:
                 cres = cpu_decode_all(cdec, gpath, cd, sample, m, min(ns, cpus))
             dv = divergence(res[:ns], cres)
-            # timed legs: one thread, then every CPU this process may run on
-            fps1, cdt1, fr1 = cpu_timed(kind, cdec, gpath, cd, list(mats), m, 1, a.cpu_seconds, big=big)
-            fps, cdt, fr = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nth, a.cpu_seconds, big=big)
-            # a point in between (how the CPU decoder scales over one shared graph: it is bound by random access to it)
-            curve = {}
-            for nmid in (8, 32):
-                if nmid < nth:
-                    curve[str(nmid)] = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nmid, max(2.0, a.cpu_seconds / 3), big=big)[0]
-            cpu_model = ""
-            try:
-                with open("/proc/cpuinfo") as f:
-                    cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
-            except OSError:
-                pass
-            curve = dict(curve, **{"1": fps1, str(nth): fps})
-            best_n = max(curve, key=lambda k: curve[k])   # the CPU's best: more threads than that lose (random access to one shared graph)
-            out["cpu_baseline"] = {"value": curve[best_n], "unit": "frames/s", "cores": int(best_n), "kind": kind,
-                                   "single_thread_value": fps1, "all_cpus_value": fps, "cpu_model": cpu_model,
-                                   "sample": "the %d utterances of rank 0, each host thread (one decoder object per thread over one shared "
-                                             "graph) looping over them; legs of 1, 8, 32 and %d threads (%.1fs wall for the first and the "
-                                             "last: %d and %d frames decoded); value = the best leg" % (B, nth, cdt, fr1, fr),
-                                   "threads_to_value": curve,
-                                   "affinity_cpus": cpus, "host_cpus": os.cpu_count()}
+            if not a.no_cpu_baseline:
+                # timed legs: one thread, then every CPU this process may run on
+                fps1, cdt1, fr1 = cpu_timed(kind, cdec, gpath, cd, list(mats), m, 1, a.cpu_seconds, big=big)
+                fps, cdt, fr = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nth, a.cpu_seconds, big=big)
+                # a point in between (how the CPU decoder scales over one shared graph: it is bound by random access to it)
+                curve = {}
+                for nmid in (8, 32):
+                    if nmid < nth:
+                        curve[str(nmid)] = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nmid, max(2.0, a.cpu_seconds / 3), big=big)[0]
+                cpu_model = ""
+                try:
+                    with open("/proc/cpuinfo") as f:
+                        cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+                except OSError:
+                    pass
+                curve = dict(curve, **{"1": fps1, str(nth): fps})
+                best_n = max(curve, key=lambda k: curve[k])   # the CPU's best: more threads than that lose (random access to one shared graph)
+                out["cpu_baseline"] = {"value": curve[best_n], "unit": "frames/s", "cores": int(best_n), "kind": kind,
+                                       "single_thread_value": fps1, "all_cpus_value": fps, "cpu_model": cpu_model,
+                                       "sample": "the %d utterances of rank 0, each host thread (one decoder object per thread over one shared "
+                                                 "graph) looping over them; legs of 1, 8, 32 and %d threads (%.1fs wall for the first and the "
+                                                 "last: %d and %d frames decoded); value = the best leg" % (B, nth, cdt, fr1, fr),
+                                       "threads_to_value": curve,
+                                       "affinity_cpus": cpus, "host_cpus": os.cpu_count()}
+            if a.lattice_links > 0:
+                # lattice mode: the raw lattice itself (GetRawLattice after FinalizeDecoding), state by state and arc by arc
+                # against the CPU restatement in its order-free mode (deviation 6), on the first utterances
+                import pyoracle
+
+                pyoracle.build_oracle()
+                orc = pyoracle.OracleDecoder()
+                orc.set_order_free(True)
+                hh = orc.load_graph(gpath)
+                nl, okl = min(ns, 2), 0
+                for i in range(nl):
+                    O = pyoracle.oracle_raw_lattice(orc, hh, pyoracle.Config(**cd), mats[i], m)
+                    dl = dec.raw_lattice(i)
+                    if dl is None or O is None:
+                        continue
+                    L = pyoracle.RawLattice(True, dl["n_states"], 0, dl["st_final"], dl["a_src"], dl["a_dst"], dl["a_ilabel"], dl["a_olabel"],
+                                            dl["a_graph"], dl["a_acoustic"], dl["st_frame"], dl["st_state"], dl["st_cost"])
+                    okl += int(L.n_states == O.n_states and np.array_equal(L.labelled_arcs(), O.labelled_arcs()))
+                orc.set_order_free(False)
+                orc.free_graph(hh)
+                out["config"]["lattice_parity"] = "%d/%d sampled raw lattices arc for arc equal to the CPU restatement's (order-free mode)" % (okl, nl)
             out["config"]["parity"] = "%d/%d sampled utterances bit-exact (words, transition-ids, tot_score) vs the %s CPU decoder" % (
                 dv["bit_identical"], ns, "oracle (biglm, fixed mode)" if a.biglm else "reference" if kind == "reference" else "oracle")
             if a.biglm:
@@ -748,6 +773,38 @@ def main():
                                  "changes; the GPU computes the order-independent restatement")
         out["service_point"] = sp
         log("[rank 0] service point: %.1fs" % (time.time() - t0))
+    headline_run = (not a.biglm and a.lattice_links == 0 and not a.host_feed and a.workload == "multi")
+    if rank == 0 and world == 1 and headline_run and not a.no_legs:
+        # ---- the other BASELINE configurations, driver-observed: configs[3] (biglm) and configs[4] (lattice-generating decode at
+        # beam 15 + the determinized lattices), each a child process running this script on the same graph and utterances
+        # for a few steps, with its own live parity sample, token counts, per-kernel times and roofline; the child's line
+        # is embedded as it is (minus the bulky parts).  This process has released its decoder: the child has the GPU to itself.
+        import subprocess
+
+        if dec is not None:
+            dec.free()
+            dec = None
+        del ll_dev
+        torch.cuda.empty_cache()
+        n2 = max(2, a.steps // 5)
+        common = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "1", "--no-service-point", "--no-legs", "--no-cpu-baseline",
+                  "--batch", str(B), "--frames", str(T), "--states", str(a.states), "--pdfs", str(P)]
+        legs = {"biglm": ["--biglm", "--steps", str(n2), "--cpu-sample", "8", "--max-tokens", "131072"],
+                "lattice_beam15": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
+                                   "--max-tokens", "262144", "--determinize", "--steps", str(max(2, n2 // 2)), "--cpu-sample", "4"]}
+        for name, extra in legs.items():
+            t0 = time.time()
+            try:
+                pr = subprocess.run(common + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                line = pr.stdout.decode().strip().splitlines()[-1]
+                o = json.loads(line)
+                keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "roofline") if k in o}
+                keep["config"] = {k: v for k, v in o["config"].items() if k not in ("divergence_vs_reference_sample",)}
+                keep["wall_s"] = time.time() - t0
+                out[name] = keep
+            except Exception as e:  # a leg that fails is reported, not hidden
+                out[name] = {"error": repr(e), "stderr_tail": pr.stderr.decode()[-600:] if "pr" in dir() else ""}
+            log("[rank 0] leg %s: %.1fs" % (name, time.time() - t0))
     if rank == 0:
         def plain(o):  # numpy scalars -> Python numbers
             if isinstance(o, np.generic):
