@@ -1096,6 +1096,10 @@ void wfst_decoder_free(wfst_decoder *d) {
       if (t[52])
         fprintf(stderr, "[wfst dbg] prune passes=%llu walk mean=%.1f us compaction mean=%.1f us frames walked mean=%.1f\n", t[52],
                 0.01 * t[51] / t[52], 0.01 * t[54] / t[52], (double)t[53] / t[52]);
+      if (t[52])
+        fprintf(stderr, "[wfst dbg] per pass: walk raw frames %.1f us, old frames %.1f us; frames in LDS %.1f, in HBM %.1f; compaction: token flags %.1f us, token move %.1f us, link flags %.1f us, link move %.1f us; raw tokens %.0f, raw links %.0f, survivors %.0f\n",
+                0.01 * t[40] / t[52], 0.01 * t[41] / t[52], (double)t[42] / t[52], (double)t[43] / t[52], 0.01 * t[44] / t[52], 0.01 * t[45] / t[52], 0.01 * t[46] / t[52], 0.01 * t[47] / t[52],
+                (double)t[48] / t[52], (double)t[49] / t[52], (double)t[50] / t[52]);
       fprintf(stderr, "[wfst dbg] closure rounds total=%llu launches*chan=%llu max_seeds=%llu max_rounds=%llu first round mean=%.2f us max=%.2f us\n",
               t[56], t[57], t[58], t[59], t[57] ? 0.01 * t[60] / t[57] : 0.0, 0.01 * t[61]);
     }
@@ -1215,12 +1219,24 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (a >= 0 && b >= 0) { (void)hipEventRecord(d->ev_pool[b], st); d->ev_pairs[cls].push_back({a, b}); }
   };
   const std::vector<int> gpar0(d->gpar);  // parity each group starts this call with
+  // lattice mode: does step s of group g bring a channel to a multiple of prune_interval, with frames left to decode?
+  auto prune_step = [&](int g, int s) -> bool {
+    if (!d->D.lattice) return false;
+    const int off = g * per, hi = std::min(d->n_channels, off + per);
+    for (int c = off; c < hi; ++c) {
+      const int nd = d->h_decoded[c] + s + 1;
+      if (d->h_state[c] == 1 && nd > 0 && nd <= d->h_target[c] - 1 && nd % d->cfg.prune_interval == 0) return true;   // (s = -1: where the channel stands)
+    }
+    return false;
+  };
   // the frame loop of one channel group on stream st
   auto enqueue_group = [&](int g, hipStream_t st) {
     const int off = g * per, cnt = std::min(per, d->n_channels - off);
     if (cnt <= 0 || gsteps[g] == 0) return;
     int par = gpar0[g];
-    timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });  // GetCutoff + seed only
+    // GetCutoff + tile list only -- behind PruneActiveTokens where the call before this one stopped at a multiple of prune_interval
+    if (prune_step(g, -1)) timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par, st); });
+    else timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });
     for (int s = 0; s < gsteps[g]; ++s) {
       // two launches per frame where the decoder allows (wfst_device.h two_launch): the insert launch closes the frame and
       // prepares the next; every gc_stride-th frame is a classic one (its closure launch checks the token arena)
@@ -1230,7 +1246,11 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
       timed(1, st, [&] { launch_insert(d->D, off, cnt, d->target.p, classic ? 0 : more ? 1 : 2, g, par, d->insert_wgs, st); });
       if (d->D.dbg & 0x800)  // timing experiment: the expansion of this frame once more, stages removed (wfst_kernels.hip expand_body kAbl)
         timed(3, st, [&] { launch_expand_replay(d->D, g, par, (d->D.dbg >> 8) & 7, d->expand_wgs, st); });
-      if (classic) timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, more, g, par ^ 1, st); });
+      // lattice mode: PruneActiveTokens (base-inl.h:660-661) on the steps at which a channel of the group reaches a multiple of
+      // prune_interval and goes on decoding -- a launch of its own, which also prepares the next frame
+      const bool prune = more && prune_step(g, s);
+      if (classic) timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, more && !prune, g, par ^ 1, st); });
+      if (prune) timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par ^ 1, st); });
       par ^= 1;
     }
   };
@@ -1241,7 +1261,9 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   auto run_group = [&](int g, hipStream_t st) -> int {
     if (gsteps[g] == 0) return WFST_OK;
     if (!(d->use_graph && !d->profiling && gsteps[g] >= 4)) { enqueue_group(g, st); return WFST_OK; }
-    const std::vector<int> key = {g, gsteps[g], (int)stride, gpar0[g]};
+    std::vector<int> key = {g, gsteps[g], (int)stride, gpar0[g]};
+    for (int s = -1; s < gsteps[g]; ++s)
+      if (prune_step(g, s)) key.push_back(s);   // (the launch sequence differs with the steps that prune)
     auto it = d->graphs.find(key);
     if (it == d->graphs.end()) {
       hipGraph_t graph = nullptr;

@@ -341,6 +341,7 @@ void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_
                    int n_workgroups, hipStream_t s);
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int do_prep,
                     int group, int par, hipStream_t s);
+void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int group, int par, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_lattice_prune(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_lattice_emit(const DecoderDev &D, const int32_t *chan_list_dev, int n, int use_final, hipStream_t s);

@@ -2151,14 +2151,24 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
 //   remapped, backpointers and the frontier included): the arena holds the surviving history plus the
 //   raw frames since the last pass -- bounded, whatever the utterance length.
 // =========================================================================================
-struct PruneShared {
+constexpr int kPrLds = 16384;    // {extra, cost} pairs of the walk kept in LDS (128 KB): the frame being priced, and the frame after it where both fit
+constexpr int kPrChunk = 8192;   // items of one compaction sweep (kBT threads x 8)
+struct ScanShared {
   u64 red[2][kBT / 64];
   int changed, any_changed, cnt, err;
   int wsum[kBT / 64];
+  int flag[3];
+};
+struct PruneShared : ScanShared {
+  // the walk: {orderable extra, cost bits} of the frame being priced and of the frame after it; the compaction (which runs after the walk) reuses the space for a sweep's exclusive prefix
+  union {
+    struct { uint2 e[kPrLds]; } w;
+    int pre[kPrChunk + 1];
+  };
 };
 
 // exclusive prefix sum of `v` over the workgroup's kBT threads; *total = sum
-__device__ __forceinline__ int block_exscan(int v, PruneShared &ps, int *total) {
+__device__ __forceinline__ int block_exscan(int v, ScanShared &ps, int *total) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int incl = v;
 #pragma unroll
@@ -2285,17 +2295,214 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
   }
 
   // ---- (2) older frames, newest first ---------------------------------------------------------------
-  // PruneActiveTokens walks on while a frame's extras moved by more than delta = lattice_beam * prune_scale
+  // PruneActiveTokens walks on while a frame's extra costs moved by more than delta = lattice_beam * prune_scale
   // (base-inl.h:452-461; frames never priced before are always priced); FinalizeDecoding walks every frame
   // (delta 0, :838-843).  "Moved" is judged on the frame's exact fixpoint against the value before the pass
   // (the reference judges sweep by sweep over its token list: oracle/wfst_oracle.c prune_forward_links).
+  //
+  // A frame's pricing is a chain -- links -> {extra, cost} of their destinations -> atomicMin on their sources ->
+  // (epsilon links: again, to the fixpoint) -- and a pass walks a hundred and more frames: with the pairs in HBM every
+  // step of it was a dependent round trip.  A frame of up to kPrLds tokens (every frame an earlier pass has pruned; most
+  // raw frames at beam 13) is therefore priced IN LDS: its pairs are built there from one coalesced read of the
+  // tokens' costs, the frame after it is still there from the step before, the links come in by one coalesced read,
+  // and the pairs go back to HBM with one coalesced store -- one round trip per frame instead of five.  Larger
+  // frames take the HBM path (for_links / relax_eps above).
   const float delta = kFinal ? 0.0f : D.lattice_beam * D.prune_scale;
   int k_lo = nd;   // oldest frame re-priced by this pass
   bool moved = true;
+  int have = -1, hb = 0;   // ps.w.e[hb] holds the final pairs of frame `have`
+  unsigned long long tw = wall_clock64();
   for (int k = nd - 1; k >= 0; --k) {
-    const int fk = foff[k], fk1 = foff[k + 1];
+    if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[(k + 1 < n_prev) ? 41 : 40], now - tw); tw = now; }
+    const int fk = foff[k], fk1 = foff[k + 1], fk2 = foff[k + 2];
+    const int nk = fk1 - fk, n1 = fk2 - fk1;
     const bool had_old = k < n_prev;
     if (!kFinal && had_old && !moved) break;
+    k_lo = k;
+    if (nk <= kPrLds) {
+      // ---- the frame in LDS ----
+      // Placement: the pairs of frame k+1 sit at one end of the buffer (left there by the step before); frame k's go to the
+      // other end.  Where both do not fit, frame k+1's are read from HBM instead (next_lds false).
+      const bool next_had = have == k + 1;                 // frame k+1's pairs are in LDS (at the `hb` end)
+      const bool next_fits = n1 + nk <= kPrLds;
+      uint2 *E1 = nullptr;
+      int cur_end;                                          // 0: frame k at the low end, 1: at the high end
+      if (next_had && next_fits) {
+        E1 = hb == 0 ? ps.w.e : ps.w.e + (kPrLds - n1);
+        cur_end = hb ^ 1;
+      } else if (next_fits) {                               // fetch them (through L2: the HBM path prices with atomics)
+        E1 = ps.w.e;
+        for (int i = tid; i < n1; i += kBT) {
+          const u64 v = ld_agent(reinterpret_cast<const u64 *>(&extra[fk1 + i]));
+          ps.w.e[i] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+        }
+        cur_end = 1;
+      } else {
+        cur_end = 0;                                        // frame k alone; its successor's pairs come from HBM link by link
+      }
+      uint2 *E0 = cur_end == 0 ? ps.w.e : ps.w.e + (kPrLds - nk);
+      // everything a SMALL frame needs from HBM is asked for at once, before the first barrier: the tokens' costs, their
+      // extras of the previous pass, its emitting links and epsilon links (a pruned frame: a few hundred tokens, a
+      // thousand links); a larger one streams them
+      constexpr int kTU = 4;
+      const bool small = nk <= kTU * kBT;
+      const int m_lo = loff[k + 1], m_hi = lmid[k + 1];   // emitting links frame k -> k+1
+      const int e0 = lmid[k], e1 = loff[k + 1];           // epsilon links inside frame k
+      int cy[kTU];
+      uint32_t ox[kTU];
+      int4 ML[kPU], EL[kPU];
+#pragma unroll
+      for (int u = 0; u < kTU; ++u) {
+        const int i = u * kBT + tid;
+        cy[u] = (small && i < nk) ? tok[fk + i].y : 0;
+        ox[u] = (small && had_old && i < nk) ? extra[fk + i].x : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kPU; ++u) {
+        const int i = m_lo + u * kBT + tid;
+        ML[u] = i < m_hi ? links[i] : make_int4(-1, 0, 0, 0);
+      }
+      const bool eps_in_regs = e1 - e0 <= kBT * kPU;
+#pragma unroll
+      for (int u = 0; u < kPU; ++u) {
+        const int i = e0 + u * kBT + tid;
+        EL[u] = (eps_in_regs && i < e1) ? links[i] : make_int4(-1, 0, 0, 0);
+      }
+      if (small) {
+#pragma unroll
+        for (int u = 0; u < kTU; ++u) {
+          const int i = u * kBT + tid;
+          if (i < nk) E0[i] = make_uint2(kInfO, (uint32_t)cy[u]);
+        }
+      } else {
+        for (int i = tid; i < nk; i += kBT) E0[i] = make_uint2(kInfO, (uint32_t)tok[fk + i].y);
+      }
+      // (flags: three in rotation, so that a round needs ONE barrier -- flag r % 3 is raised in round r and read after the round's
+      // barrier; the next round's flag is cleared during this round, when nobody reads or raises it)
+      if (tid < 3) ps.flag[tid] = 0;
+      __syncthreads();
+      auto price0 = [&](const int4 &X) -> float {   // a link into frame k itself (epsilon links)
+        const uint2 en = E0[X.y - fk];
+        return en.x >= kInfO ? kInf : o2f(en.x) + (__int_as_float(X.w) - __uint_as_float(en.y));
+      };
+      // emitting links frame k -> k+1
+      for (int i0 = m_lo; i0 < m_hi; i0 += kBT * kPU) {
+        if (i0 != m_lo) {
+#pragma unroll
+          for (int u = 0; u < kPU; ++u) {
+            const int i = i0 + u * kBT + tid;
+            ML[u] = i < m_hi ? links[i] : make_int4(-1, 0, 0, 0);
+          }
+        }
+        u64 en[kPU];
+        if (E1) {
+#pragma unroll
+          for (int u = 0; u < kPU; ++u) {
+            const uint2 v = ML[u].x >= 0 ? E1[ML[u].y - fk1] : make_uint2(0, 0);
+            en[u] = (u64)v.x | ((u64)v.y << 32);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kPU; ++u) en[u] = ML[u].x >= 0 ? ld_agent(reinterpret_cast<const u64 *>(&extra[ML[u].y])) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kPU; ++u) {
+          if (ML[u].x < 0) continue;
+          const uint32_t eo = (uint32_t)en[u];
+          float le = eo >= kInfO ? kInf : o2f(eo) + (__int_as_float(ML[u].w) - __int_as_float((int)(en[u] >> 32)));
+          if (!(le <= lb)) { links[i0 + u * kBT + tid].x = -1; continue; }
+          if (le < 0.0f) le = 0.0f;
+          atomicMin(&E0[ML[u].x - fk].x, f2o(le));
+        }
+      }
+      __syncthreads();
+      // the epsilon links inside frame k, to their fixpoint
+      if (e0 < e1) {
+        for (int round = 0; round < 4096; ++round) {
+          int ch = 0;
+          if (eps_in_regs) {
+#pragma unroll
+            for (int u = 0; u < kPU; ++u) {
+              if (EL[u].x < 0) continue;
+              float le = price0(EL[u]);
+              if (!(le <= lb)) continue;
+              if (le < 0.0f) le = 0.0f;
+              const uint32_t o = f2o(le);
+              if (o < atomicMin(&E0[EL[u].x - fk].x, o)) ch = 1;
+            }
+          } else {
+            for (int i = e0 + tid; i < e1; i += kBT) {
+              const int4 X = links[i];
+              if (X.x < 0) continue;
+              float le = price0(X);
+              if (!(le <= lb)) continue;
+              if (le < 0.0f) le = 0.0f;
+              const uint32_t o = f2o(le);
+              if (o < atomicMin(&E0[X.x - fk].x, o)) ch = 1;
+            }
+          }
+          const int fl = round % 3;
+          if (ch) ps.flag[fl] = 1;
+          if (tid == 0) ps.flag[(fl + 1) % 3] = 0;   // (last read two barriers ago, next raised after this round's barrier)
+          __syncthreads();
+          if (!ps.flag[fl]) break;
+        }
+        // the dead ones are marked
+        if (eps_in_regs) {
+#pragma unroll
+          for (int u = 0; u < kPU; ++u) {
+            if (EL[u].x < 0) continue;
+            if (!(price0(EL[u]) <= lb)) links[e0 + u * kBT + tid].x = -1;
+          }
+        } else {
+          for (int i = e0 + tid; i < e1; i += kBT) {
+            const int4 X = links[i];
+            if (X.x >= 0 && !(price0(X) <= lb)) links[i].x = -1;
+          }
+        }
+      }
+      // the frame's pairs go to HBM; did they move?
+      int ch = 0;
+      if (small) {
+#pragma unroll
+        for (int u = 0; u < kTU; ++u) {
+          const int i = u * kBT + tid;
+          if (i >= nk) continue;
+          const uint2 v = E0[i];
+          extra[fk + i] = v;
+          if (!kFinal) {
+            const float now = o2f(v.x);
+            const float was = had_old ? o2f(ox[u]) : 0.0f;   // a token is created with extra_cost 0 (base-inl.h:103)
+            ch |= fabsf(now - was) > delta;                   // (inf - inf = NaN: not "moved", as in the reference)
+          }
+        }
+      } else {
+        for (int i = tid; i < nk; i += kBT) {
+          const uint2 v = E0[i];
+          if (!kFinal) {
+            const float now = o2f(v.x);
+            const float was = had_old ? o2f(extra[fk + i].x) : 0.0f;
+            ch |= fabsf(now - was) > delta;
+          }
+          extra[fk + i] = v;
+        }
+      }
+      if (!kFinal) {
+        if (tid == 0) ps.any_changed = 0;
+        __syncthreads();
+        if (ch) ps.any_changed = 1;
+        __syncthreads();
+        moved = ps.any_changed != 0;
+      }
+      __syncthreads();   // (the next frame rewrites the other end of the buffer and the flags)
+      have = k;
+      hb = cur_end;
+      if (tid == 0 && (D.dbg & 32)) atomicAdd(&D.dbg_t[42], 1ull);
+      continue;
+    }
+    // ---- the frame in HBM (more tokens than the LDS buffers take) ----
+    have = -1;
+    if (tid == 0 && (D.dbg & 32)) atomicAdd(&D.dbg_t[43], 1ull);
     for (int i0 = fk; i0 < fk1; i0 += kBT * kPU) {
       int cy[kPU];
       uint32_t ox[kPU];
@@ -2322,7 +2529,6 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     });
     __syncthreads();
     relax_eps(lmid[k], loff[k + 1]);
-    k_lo = k;
     if (!kFinal) {
       if (tid == 0) ps.any_changed = 0;
       __syncthreads();
@@ -2338,6 +2544,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       __syncthreads();
     }
   }
+  __syncthreads();
 
   if (tid == 0 && (D.dbg & 32)) {
     const unsigned long long now = wall_clock64();
@@ -2361,109 +2568,162 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
                       2 * (int64_t)ctl->link_count > D.link_cap;
     const int c_lo = full ? k_lo : max(k_lo, min(n_prev, nd));
     k_lo = c_lo;
-    const int range_lo = foff[k_lo];
-    int new_end = range_lo;
-    int old_lo = range_lo;
+    const int range_lo = foff[k_lo], end = foff[nd + 1];
+    const int f0_hi = (k_lo == 0) ? foff[1] : 0;   // PruneActiveTokens never calls PruneTokensForFrame(0) (base-inl.h:471-476): frame 0
+                                                   // keeps its dead tokens, link-less, until FinalizeDecoding
     if (tid == 0) ps.err = 0;
     __syncthreads();
-    constexpr int kCU = 8;   // items per thread and sweep: a raw frame's few thousand tokens or links in one go
-    for (int f = k_lo; f <= nd; ++f) {
-      const int old_hi = foff[f + 1];
-      // (a) new index of every survivor of the frame
-      int base = new_end;
-      for (int i0 = old_lo; i0 < old_hi; i0 += kBT * kCU) {
-        bool alive[kCU];
-        int cnt = 0;
+    tw = wall_clock64();
+    constexpr int kCU = kPrChunk / kBT;   // items per thread and sweep
+    // FLAT sweeps over the whole range (not frame by frame: a raw frame is a few thousand tokens, a pruned one a few hundred --
+    // a sweep per frame was mostly barriers), and the MOVES run over the survivors only (a raw frame keeps a percent or two
+    // of its tokens and links): sweep (a) leaves, besides every item's exclusive prefix, the list of the survivors' old
+    // indices, and sweep (b) walks that list.  Scratch: the channel's lat_toks / lat_arcs (they hold nothing between two
+    // lattice_emit launches; int32 views).
+    int32_t *surv = reinterpret_cast<int32_t *>(D.lat_toks + (size_t)c * D.lat_tok_cap);    // [new index] -> old index (tokens)
+    int32_t *lsurv = reinterpret_cast<int32_t *>(D.lat_arcs + (size_t)c * D.lat_arc_cap);   // [new index] -> old index (links)
+    int32_t *lpre = lsurv + D.link_cap;                                                      // [old index] -> survivors below it
+    // (a) remap[i] = new index of a survivor, ~(survivors below i) of a dead token: the exclusive prefix either way
+    // (a chunk's items in wave-coalesced order -- wave w, step u, lane l: item (w * kCU + u) * 64 + l -- and the survivors'
+    // ranks from ballots: a lane reads 4 or 16 bytes beside its neighbour's, where a thread owning 8 consecutive items read
+    // a line per lane)
+    auto chunk_ranks = [&](const bool (&alive)[kCU], int base, int (&rank)[kCU]) -> int {
+      u64 m[kCU];
+      int wc = 0;
 #pragma unroll
-        for (int u = 0; u < kCU; ++u) {
-          const int i = i0 + tid * kCU + u;
-          // (PruneActiveTokens never calls PruneTokensForFrame(0), base-inl.h:471-476: frame 0 keeps its dead
-          // tokens, link-less, until FinalizeDecoding)
-          alive[u] = i < old_hi && ((!kFinal && f == 0) || (uint32_t)ld_agent(&extra[i].x) < kInfO);
-          cnt += alive[u] ? 1 : 0;
-        }
-        int tot;
-        int r = base + block_exscan(cnt, ps, &tot);
+      for (int u = 0; u < kCU; ++u) { m[u] = __ballot(alive[u]); wc += __popcll(m[u]); }
+      __syncthreads();  // ps.wsum free again
+      if (lane == 0) ps.wsum[wave] = wc;
+      __syncthreads();
+      int wb = 0, tot = 0;
 #pragma unroll
-        for (int u = 0; u < kCU; ++u) {
-          const int i = i0 + tid * kCU + u;
-          if (i < old_hi) remap[i] = alive[u] ? r++ : -1;
+      for (int w = 0; w < kBT / 64; ++w) {
+        const int x = ps.wsum[w];
+        if (w < wave) wb += x;
+        tot += x;
+      }
+      int run = base + wb;
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) { rank[u] = run + lane_rank(m[u]); run += __popcll(m[u]); }
+      return tot;
+    };
+    int new_end = range_lo;
+    for (int c0 = range_lo; c0 < end; c0 += kPrChunk) {
+      bool alive[kCU];
+      int rank[kCU];
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int i = c0 + (wave * kCU + u) * 64 + lane;
+        alive[u] = i < end && (i < f0_hi || (uint32_t)ld_agent(&extra[i].x) < kInfO);
+      }
+      const int tot = chunk_ranks(alive, new_end, rank);
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int i = c0 + (wave * kCU + u) * 64 + lane;
+        if (i < end) {
+          remap[i] = alive[u] ? rank[u] : ~rank[u];
+          if (alive[u]) surv[rank[u]] = i;
         }
-        base += tot;
+      }
+      new_end += tot;
+    }
+    __syncthreads();
+    if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[44], now - tw); tw = now; }
+    // the frames' new offsets: survivors below each old offset
+    for (int f = k_lo + tid; f <= nd; f += kBT) {
+      const int p = foff[f + 1];
+      int q = new_end;
+      if (p < end) { q = remap[p]; q = q < 0 ? ~q : q; }
+      foff[f + 1] = q;
+    }
+    // (b) the survivors move down (a sweep is read whole before it is written; new index <= old index, so a sweep's writes
+    // land on positions that this sweep or an earlier one has read)
+    for (int j0 = range_lo; j0 < new_end; j0 += kPrChunk) {
+      int oi[kCU];
+      int4 rec[kCU];
+      uint2 ex[kCU];
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int j = j0 + u * kBT + tid;
+        oi[u] = j < new_end ? surv[j] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        rec[u] = make_int4(0, 0, 0, 0);
+        ex[u] = make_uint2(0, 0);
+        if (oi[u] >= 0) { rec[u] = tok[oi[u]]; ex[u] = extra[oi[u]]; }
+      }
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        // backpointer: a survivor's predecessor survives (the link between them is the token's own best one);
+        // predecessors below the compacted range have not moved
+        if (oi[u] >= 0 && rec[u].z >= range_lo) {
+          rec[u].z = remap[rec[u].z];
+          if (rec[u].z < 0) ps.err = 1;
+        }
       }
       __syncthreads();
-      // (b) move them (downwards only: a sweep is read whole before it is written)
-      for (int i0 = old_lo; i0 < old_hi; i0 += kBT * kCU) {
-        int ni[kCU];
-        int4 rec[kCU];
-        uint2 ex[kCU];
 #pragma unroll
-        for (int u = 0; u < kCU; ++u) {
-          const int i = i0 + tid * kCU + u;
-          ni[u] = i < old_hi ? remap[i] : -1;
-          rec[u] = make_int4(0, 0, 0, 0);
-          ex[u] = make_uint2(0, 0);
-          if (ni[u] >= 0) { rec[u] = tok[i]; ex[u] = extra[i]; }
-        }
-#pragma unroll
-        for (int u = 0; u < kCU; ++u) {
-          // backpointer: a survivor's predecessor survives (the link between them is the token's own best one);
-          // predecessors below the compacted range have not moved
-          if (ni[u] >= 0 && rec[u].z >= range_lo) {
-            rec[u].z = remap[rec[u].z];
-            if (rec[u].z < 0) ps.err = 1;
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < kCU; ++u)
-          if (ni[u] >= 0) { tok[ni[u]] = rec[u]; extra[ni[u]] = ex[u]; }
-        __syncthreads();
+      for (int u = 0; u < kCU; ++u) {
+        const int j = j0 + u * kBT + tid;
+        if (oi[u] >= 0) { tok[j] = rec[u]; extra[j] = ex[u]; }
       }
-      new_end = base;
-      old_lo = old_hi;
-      if (tid == 0) foff[f + 1] = new_end;
       __syncthreads();
     }
-    // links: for f = k_lo .. nd: emitting(f) (into frame f: its destinations moved), eps(f)
-    int lnew = loff[k_lo];
-    int seg_lo = loff[k_lo];
-    const int n_seg = 2 * (nd - k_lo) + 2;
-    for (int sidx = 0; sidx < n_seg; ++sidx) {
-      const int f = k_lo + sidx / 2;
-      const bool eps_seg = (sidx & 1) != 0;
-      const int seg_hi = eps_seg ? loff[f + 1] : lmid[f];
-      const int seg_new_lo = lnew;
-      for (int i0 = seg_lo; i0 < seg_hi; i0 += kBT * kCU) {
-        int4 L[kCU];
-        int cnt = 0;
+    if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[45], now - tw); tw = now; }
+    // links, flat: from the emitting links INTO frame k_lo (their destinations moved) to the end of the store
+    const int l_lo = loff[k_lo], l_end = loff[nd + 1];
+    int lnew = l_lo;
+    for (int c0 = l_lo; c0 < l_end; c0 += kPrChunk) {
+      bool alive[kCU];
+      int rank[kCU];
 #pragma unroll
-        for (int u = 0; u < kCU; ++u) {
-          const int i = i0 + tid * kCU + u;
-          L[u] = i < seg_hi ? links[i] : make_int4(-1, 0, 0, 0);
-          cnt += L[u].x >= 0 ? 1 : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < kCU; ++u)
-          if (L[u].x >= 0) {   // (a source below the compacted range has not moved)
-            if (L[u].x >= range_lo) L[u].x = remap[L[u].x];
-            if (L[u].y >= range_lo) L[u].y = remap[L[u].y];
-          }
-        int tot;
-        int r = lnew + block_exscan(cnt, ps, &tot);   // (its barriers separate the reads above from the writes below)
-#pragma unroll
-        for (int u = 0; u < kCU; ++u)
-          if (L[u].x >= 0) links[r++] = L[u];
-        lnew += tot;
+      for (int u = 0; u < kCU; ++u) {
+        const int i = c0 + (wave * kCU + u) * 64 + lane;
+        alive[u] = i < l_end && links[i].x >= 0;
       }
+      const int tot = chunk_ranks(alive, lnew, rank);
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int i = c0 + (wave * kCU + u) * 64 + lane;
+        if (i < l_end) {
+          lpre[i] = rank[u];
+          if (alive[u]) lsurv[rank[u]] = i;
+        }
+      }
+      lnew += tot;
+    }
+    __syncthreads();
+    if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[46], now - tw); tw = now; }
+    // a frame's segment = [link_off[f], link_mid[f]) emitting into it, [link_mid[f], link_off[f+1]) epsilon inside it
+    for (int q = tid; q < 2 * (nd - k_lo) + 2; q += kBT) {
+      int *slot = (q & 1) ? &loff[k_lo + (q >> 1) + 1] : &lmid[k_lo + (q >> 1)];
+      const int p = *slot;
+      *slot = p < l_end ? lpre[p] : lnew;
+    }
+    for (int j0 = l_lo; j0 < lnew; j0 += kPrChunk) {
+      int4 L[kCU];
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int j = j0 + u * kBT + tid;
+        const int oi = j < lnew ? lsurv[j] : -1;
+        L[u] = oi >= 0 ? links[oi] : make_int4(-1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < kCU; ++u)
+        if (L[u].x >= 0) {   // (an endpoint below the compacted range has not moved)
+          if (L[u].x >= range_lo) L[u].x = remap[L[u].x];
+          if (L[u].y >= range_lo) L[u].y = remap[L[u].y];
+        }
       __syncthreads();
-      seg_lo = seg_hi;
-      if (tid == 0) {   // a frame's segment = [link_off[f], link_mid[f]) emitting into it, [link_mid[f], link_off[f+1]) epsilon inside it
-        if (eps_seg) { lmid[f] = seg_new_lo; loff[f + 1] = lnew; }
-        else loff[f] = seg_new_lo;
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int j = j0 + u * kBT + tid;
+        if (j < lnew) links[j] = L[u];
       }
       __syncthreads();
     }
+    if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[47], now - tw); atomicAdd(&D.dbg_t[48], (unsigned long long)(end - range_lo)); atomicAdd(&D.dbg_t[49], (unsigned long long)(l_end - l_lo)); atomicAdd(&D.dbg_t[50], (unsigned long long)((new_end - range_lo) + (lnew - l_lo))); }
     if (tid == 0) {
       ctl->link_count = lnew;
       ctl->front_begin = foff[nd];
@@ -2511,7 +2771,7 @@ struct GcShared {
 };
 
 template <bool kBig>
-__device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, PruneShared &ps, GcShared &gs) {
+__device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, ScanShared &ps, GcShared &gs) {
   const int tid = threadIdx.x;
   ChanCtl *ctl = D.ctl + c;
   const int nd = ctl->n_decoded;
@@ -2700,17 +2960,11 @@ __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_
   if (ctl->active) finalize_frame<kLat, kBig>(D, c, ctl, sh);
   __syncthreads();
   if constexpr (kLat) {
-    // PruneActiveTokens at the top of every prune_interval-th frame's iteration (base-inl.h:660-661), i.e.
-    // only when the channel goes on to decode that frame
-    __shared__ PruneShared ps;
-    const int nd = ctl->n_decoded;
-    if (do_prep && nd > 0 && nd % D.prune_interval == 0 && ctl->pruned_upto != nd && nd < target[c] && ctl->error == 0 &&
-        !ctl->finalized && nd < D.max_frames)
-      prune_pass<false>(D, c, ps);
-    __syncthreads();
+    // (PruneActiveTokens, every prune_interval-th frame: lattice_prune_kernel, a launch of its own between this one -- which then
+    // only closes the frame, do_prep 0 -- and the next expansion: its 128 KB of LDS would otherwise sit on every closure launch)
   } else {
     // best-path decoders: collect the arena's garbage when it passes its mark (gc_pass)
-    __shared__ PruneShared ps;
+    __shared__ ScanShared ps;
     __shared__ GcShared gs;
     const int nd = ctl->n_decoded;
     if (do_prep && D.remap && nd > 0 && nd < target[c] && ctl->error == 0 && !ctl->finalized && nd < D.max_frames) {
@@ -2721,6 +2975,24 @@ __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_
     __syncthreads();
   }
   if (do_prep) prep_frame<kBig>(D, c, ctl, target, sh, group, par);  // par: parity of the step it prepares
+}
+
+// PruneActiveTokens at the top of every prune_interval-th frame's iteration (base-inl.h:660-661), i.e. only when the channel
+// goes on to decode that frame; then the frame's preparation (prep_frame: the pass has moved the frontier).  Launched by
+// wfst_decoder_advance after the closure launch (do_prep 0) of the steps at which some channel of the group reaches a multiple
+// of prune_interval; one 1024-thread workgroup per channel.
+template <bool kBig>
+__global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const int32_t *target, int chan_off, int group, int par) {
+  __shared__ PruneShared ps;
+  __shared__ BoundaryShared sh;
+  const int c = blockIdx.x + chan_off;
+  ChanCtl *ctl = D.ctl + c;
+  const int nd = ctl->n_decoded;
+  if (nd > 0 && nd % D.prune_interval == 0 && ctl->pruned_upto != nd && nd < target[c] && ctl->error == 0 && !ctl->finalized &&
+      nd < D.max_frames)
+    prune_pass<false>(D, c, ps);
+  __syncthreads();
+  prep_frame<kBig>(D, c, ctl, target, sh, group, par);
 }
 
 // =========================================================================================
@@ -3062,7 +3334,7 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
   const int pruned_upto = ctl->pruned_upto;
   const bool finalized = ctl->finalized != 0;
   {  // in arena order (= frame order; the n-best search relies on a frame's states being contiguous)
-    __shared__ PruneShared ps;
+    __shared__ ScanShared ps;
     const int n_all = foff[nd + 1];
     int base = 0;
     for (int i0 = 0; i0 < n_all; i0 += kBT) {
@@ -3195,6 +3467,10 @@ void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32
     hipLaunchKernelGGL((closure_kernel<true, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
   else
     hipLaunchKernelGGL((closure_kernel<false, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+}
+void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int group, int par, hipStream_t s) {
+  if (D.big) hipLaunchKernelGGL(lattice_prune_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
+  else hipLaunchKernelGGL(lattice_prune_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
 }
 void launch_set_finalized(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(set_finalized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, D, chans, n);
