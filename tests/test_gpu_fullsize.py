@@ -202,6 +202,161 @@ def test_config5_beam15_lattice_and_nbest_sample(big, oracle, refdec, tmp_path):
         oracle.free_graph(h)
 
 
+def test_config4_biglm_batch128_full_size(big, synth, oracle, tmp_path):
+    """BASELINE configs[3] at full size (VERDICT r2 next #1a): on-the-fly LM rescoring, 128 utterances x 300 frames on the
+    10 M-arc graph with the bench's LM pair (old: 156 k-state bigram scaled -1, new: 622 k-state trigram).  The fixed-mode
+    oracle (bit for bit: words, transition-ids, per-hop labels and costs, scores) on 16 utterances; on ALL 128: a path per
+    utterance with one transition-id per frame, run-to-run determinism, and batch invariance (the same utterance alone, in
+    another channel, in a smaller batch)."""
+    import importlib
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    from test_gpu_biglm import _same
+
+    lmsynth = importlib.import_module("asr-decoder_amd.lmsynth")
+    G = big["G"]
+    V = int(big["g"].arcs["olabel"].max())
+    paths = []
+    for tag, spec, seed in (("old", (20000, 5, 0, 0), 41), ("new", (40000, 6, 100000, 3), 42)):   # bench.py --lm-old / --lm-new
+        nb, s2, nt, s3 = spec
+        lp = str(tmp_path / ("lm_%s.bin" % tag))
+        lmsynth.make_lm(V, 3 if nt > 0 else 2, nb, s2, nt, s3, seed=seed).to_fsa().write(lp)
+        paths.append(lp)
+    L1, L2 = G.wfstdec.Lm.load(paths[0], -1.0), G.wfstdec.Lm.load(paths[1], 1.0)
+    assert L1.info()["n_states"] > 100000 and L2.info()["n_states"] > 500000
+    lim = dict(max_frames=304, max_tokens_per_frame=131072, arena_tokens=300 * 13900)
+    cd = dict(CD)
+
+    def run(mats):
+        dec = G.wfstdec.BatchDecoder(big["graph"], G.gpu_config(cd), len(mats), old_lm=L1, new_lm=L2, lm_pairs=1 << 20, **lim)
+        try:
+            return G.decode_batch(big["graph"], cd, mats, dec=dec)
+        finally:
+            dec.free()
+
+    res = run(big["mats"])
+    # (the reference's biglm final pruning -- final_best_cost ranges over non-final tokens too, biglm.h:186-188 -- leaves some
+    # utterances without a path at lattice_beam 7: reproduced, and checked against the oracle on the sample below)
+    n_ok = sum(int(r.ok) for r in res)
+    assert n_ok >= 32 and all(len(r.tids) == big["T"] for r in res if r.ok), n_ok
+    print("biglm full size: %d of %d utterances keep a path at lattice_beam %g" % (n_ok, big["B"], cd["lattice_beam"]))
+    # the oracle in FIXED DiffArpaLm mode (DESIGN.md section 4 "biglm"), order-free, on 16 utterances
+    h = oracle.load_graph(big["path"])
+    o1, o2 = pyoracle.Lm(oracle, paths[0], -1.0), pyoracle.Lm(oracle, paths[1], 1.0)
+    sample = list(range(0, 128, 8))
+    try:
+        oracle.set_order_free(True)
+        with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as ex:
+            want = list(ex.map(lambda u: pyoracle.biglm_decode(oracle, h, pyoracle.Config(**cd), o1, o2, big["mats"][u], big["m"], fixed=True), sample))
+    finally:
+        oracle.set_order_free(False)
+    for u, o in zip(sample, want):
+        assert o.extra["lm_oob"] == 0 and o.extra["ties"] == 0, u
+        _same(res[u], o, "utt %d" % u)
+    o1.free()
+    o2.free()
+    oracle.free_graph(h)
+    # the LM difference is really applied: LM scores differ from the plain decoder's on most utterances
+    plain = G.decode_batch(big["graph"], cd, big["mats"][:8], limits=lim)
+    assert sum(int(a.ok and a.lm_score != b.lm_score) for a, b in zip(res[:8], plain)) >= 1
+    # determinism: a second run gives the same bits; batch invariance: 8 of them alone, in other channels
+    res2 = run(big["mats"])
+    for a, b in zip(res, res2):
+        G.assert_same_path(a, b.words, b.tids, b.path_ilabel, b.path_olabel, b.path_graph, b.path_ac, [b.tot_score, b.lm_score])
+    pick = [3, 30, 60, 64, 90, 99, 120, 126]
+    sub = run([big["mats"][u] for u in pick])
+    for u, b in zip(pick, sub):
+        a = res[u]
+        G.assert_same_path(a, b.words, b.tids, b.path_ilabel, b.path_olabel, b.path_graph, b.path_ac, [b.tot_score, b.lm_score])
+    L1.free()
+    L2.free()
+
+
+def test_config5_beam15_lattices_batch128(big, oracle, refdec, tmp_path):
+    """BASELINE configs[4] at BATCH 128 (VERDICT r2 next #1a): lattice-generating decode at beam 15 / lattice-beam 8 with the
+    reference's running back-pruning (prune_interval 25), all 128 utterances in one decoder.  On all 128: the raw lattice's
+    size-independent properties (topological numbering, trim, shortest path = best path), the 5-best (1-best = GetBestPath,
+    ascending, distinct) and the determinized lattice built on the device (deterministic in its word labels, fewer states
+    than the raw lattice, same best cost).  On a sample: the raw lattice state by state against the order-free oracle, and
+    the determinized lattice arc for arc against the REFERENCE's determinizer (oracle/_ref) run on the raw lattice."""
+    from test_gpu_determinize import as_det
+    from test_gpu_lattice import as_raw, gpu_lattices, nodes
+
+    G = big["G"]
+    cd = dict(CD, beam=15.0, lattice_beam=8.0)
+    lim = dict(max_frames=304, max_tokens_per_frame=262144, arena_tokens=300 * 60000, lattice_links=24 << 20)
+    dets = []
+    lats, best, nbest = gpu_lattices(G, big["graph"], cd, big["mats"], limits=lim, nbest=5, det_out=dets)
+    det_seconds = dets.pop()
+    assert all(d is not None for d in lats) and all(d is not None for d in dets)
+    for u in range(big["B"]):
+        L, D = as_raw(lats[u]), as_det(dets[u])
+        S = L.n_states
+        assert np.all(L.a_dst > L.a_src) and np.all(np.diff(L.a_src) >= 0), u
+        assert L.st_frame[0] == 0 and np.all(np.diff(L.st_frame) >= 0) and L.st_frame[-1] == big["T"], u
+        assert L.st_final.sum() >= 1 and np.all(L.st_frame[L.st_final == 1] == big["T"]), u
+        dist = np.full(S, np.inf, np.float32)
+        dist[0] = 0.0
+        w = (L.a_graph + L.a_ac).astype(np.float32)
+        for k in range(len(L.a_src)):   # arcs are sorted by source state, ids are topological
+            c = np.float32(dist[L.a_src[k]] + w[k])
+            if c < dist[L.a_dst[k]]:
+                dist[L.a_dst[k]] = c
+        assert np.all(np.isfinite(dist)), "utt %d: state unreachable from the start" % u
+        co = np.zeros(S, bool)
+        co[L.st_final == 1] = True
+        for k in range(len(L.a_src) - 1, -1, -1):
+            if co[L.a_dst[k]]:
+                co[L.a_src[k]] = True
+        assert co.all(), "utt %d: state that reaches no final state" % u
+        sp = dist[L.st_final == 1].min()
+        assert abs(sp - best[u]["tot_score"]) <= 1e-4 * abs(sp), u
+        paths = nbest[u]
+        assert len(paths) >= 1 and np.array_equal(paths[0]["words"], best[u]["words"]), u
+        tots = [p["tot_score"] for p in paths]
+        assert all(b >= a for a, b in zip(tots, tots[1:])) and len({tuple(p["words"].tolist()) for p in paths}) == len(paths), u
+        # the determinized lattice: at most one arc per (state, word), fewer states, and the same best cost
+        assert D.n_states < L.n_states, u
+        key = D.a_src.astype(np.int64) * (1 << 32) + D.a_ol.astype(np.int64)
+        nonfinal = D.a_ol != 0
+        assert len(np.unique(key[nonfinal])) == int(nonfinal.sum()), "utt %d: two arcs with one word out of a state" % u
+        dd = np.full(D.n_states, np.inf, np.float64)
+        dd[0] = 0.0
+        order = np.argsort(D.a_src, kind="stable")
+        changed = True
+        for _ in range(D.n_states + 1):   # Bellman-Ford (the state numbering of a determinized lattice is not topological)
+            if not changed:
+                break
+            changed = False
+            for k in order:
+                c = dd[D.a_src[k]] + float(D.a_graph[k]) + float(D.a_ac[k])
+                if c < dd[D.a_dst[k]] - 1e-9:
+                    dd[D.a_dst[k]] = c
+                    changed = True
+        assert abs(dd[D.st_final == 1].min() - sp) <= 2e-3 + 1e-4 * abs(sp), (u, dd[D.st_final == 1].min(), sp)
+    print("batch 128 at beam 15: raw states mean %.0f, determinized mean %.0f; 128 determinized lattices in %.3f s" % (
+        np.mean([d["n_states"] for d in lats]), np.mean([d["n_states"] for d in dets]), det_seconds))
+    h = oracle.load_graph(big["path"])
+    try:
+        for u in (7, 70, 121):
+            oracle.set_order_free(True)
+            O = pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**cd), big["mats"][u], big["m"])
+            oracle.set_order_free(False)
+            L = as_raw(lats[u])
+            assert np.array_equal(nodes(L), nodes(O)) and np.array_equal(L.labelled_arcs(), O.labelled_arcs()), u
+            p = str(tmp_path / ("c5b_%d.lat" % u))
+            with open(p, "wb") as f:
+                f.write(G.pkg.shard.lattice_to_bytes(lats[u]))
+            R = pyoracle.ref_determinize_lattice_file(refdec, p, 0)
+            D = as_det(dets[u])
+            assert R is not None and [D.n_states, int(D.st_final.sum())] == [R.n_states, int(R.st_final.sum())], u
+            assert np.array_equal(D.arc_multiset(), R.arc_multiset()), u
+    finally:
+        oracle.set_order_free(False)
+        oracle.free_graph(h)
+
+
 def test_service_operating_point_divergence_from_the_reference(big, synth, refdec, capsys):
     """max_active 7000 / min_active 200 (the reference service's own configuration,
     v1-asrbin/conf/decoder.conf:4-8) on the 10 M-arc graph, all 128 utterances, against the reference
