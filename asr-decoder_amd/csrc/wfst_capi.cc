@@ -845,7 +845,6 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   if (big) {
     if (!old_lm || !new_lm) return fail(WFST_E_ARG, "biglm needs both LMs");
     if (old_lm->device != g->device || new_lm->device != g->device) return fail(WFST_E_ARG, "the LMs must be on the graph's device");
-    if (L.lattice_links > 0) return fail(WFST_E_ARG, "biglm decoders are best-path only (lattice_links must be 0)");
     const int32_t nw = std::min(old_lm->start_arcs, new_lm->start_arcs);
     if (g->min_olabel < 0 || g->max_olabel >= nw)
       return fail(WFST_E_FORMAT, "the graph has output label " + std::to_string(g->max_olabel) + " but the LMs' empty-history state only has arcs for word ids below " + std::to_string(nw));
@@ -945,8 +944,10 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   if (e == hipSuccess) A(hipMemsetAsync(d->eps_vals.p, 0xFF, d->eps_vals.bytes(), d->stream));
   if (e == hipSuccess && big) A(hipMemsetAsync(d->eps_keys.p, 0xFF, d->eps_keys.bytes(), d->stream));
   if (e == hipSuccess && big) A(hipMemsetAsync(d->pair_keys.p, 0xFF, d->pair_keys.bytes(), d->stream));
-  if (e == hipSuccess && lds_slots * ((L.lattice_links > 0 || big) ? 16 : 12) > 65536)
-    A((hipError_t)insert_kernel_set_lds(lds_slots * ((L.lattice_links > 0 || big) ? 16 : 12)));
+  {
+    const int per_slot = (L.lattice_links > 0 && big) ? 20 : (L.lattice_links > 0 || big) ? 16 : 12;
+    if (e == hipSuccess && lds_slots * per_slot > 65536) A((hipError_t)insert_kernel_set_lds(lds_slots * per_slot));
+  }
 
   if (e == hipSuccess) A(hipMemsetAsync(d->target.p, 0, d->target.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->ll_base.p, 0, d->ll_base.bytes(), d->stream));

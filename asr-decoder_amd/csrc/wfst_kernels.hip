@@ -1390,6 +1390,7 @@ __global__ __launch_bounds__(kInsertThreads, 6) void insert_kernel_fused(Decoder
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel_lattice(DecoderDev D, int group, int par) { insert_body<true, false, false>(D, group, par); }
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel_lattice_fused(DecoderDev D, int group, int par) { insert_body<true, false, true>(D, group, par); }
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel_biglm(DecoderDev D, int group, int par) { insert_body<false, true, false>(D, group, par); }
+__global__ __launch_bounds__(kInsertThreads) void insert_kernel_lattice_biglm(DecoderDev D, int group, int par) { insert_body<true, true, false>(D, group, par); }
 
 // =========================================================================================
 // closure_kernel and its pieces.  One 1024-thread workgroup per channel.
@@ -1417,8 +1418,13 @@ struct BoundaryShared {
 // Forward links of the epsilon arcs of the frame being built (lattice mode; base-inl.h:421-422), once every token of the
 // frame has its final cost -- after the closure's fixpoint, or, with fused closures, right after the insert launch.
 // toki[] = the channel's direct-mapped epsilon table: the frame's token on each epsilon-target state.
+template <bool kBig = false>
 __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff) {
   const int tid = threadIdx.x;
+  // biglm: a token is (row, LM pair); an epsilon arc with a word label moves the LM (biglm.h:448-456), the link's cost carries
+  // the LM difference, and the destination's token is found in the channel's HASHED epsilon table (keys beside toki[])
+  const u64 *ekeys = kBig ? D.eps_keys + (size_t)c * D.ecap : nullptr;
+  const int32_t *tlm = kBig ? D.tok_lm + (size_t)c * D.arena_cap : nullptr;
   int4 *tok = D.tok + (size_t)c * D.arena_cap;
   const int32_t *toki = D.eps_toki + (size_t)c * D.ecap;
   // Forward links of the epsilon arcs (base-inl.h:421-422): the reference regenerates a token's
@@ -1455,13 +1461,32 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
     const int j = j0 + tid;
     int i = 0, row = 0, neps = 0, npass = 0;
     float cost = 0.0f;
+    int plm = 0;
+    // cost of the arrival over epsilon arc a from this token, and (biglm) the LM pair it arrives with
+    auto arrival = [&](int a, const int4 &arc, int *next_lm) -> float {
+      if constexpr (kBig) {
+        const int ol = D.g.arc_olabel[a];
+        float lm_score = 0.0f;
+        *next_lm = plm;
+        if (ol != 0) {
+          int n1, n2;
+          lm_score = lm_step(D, c, plm, ol, &n1, &n2);
+          *next_lm = pair_find(D, c, n1, n2);
+        }
+        return cost + (__int_as_float(arc.z) + lm_score);   // cur_cost + (arc weight + lm_score), biglm.h:448-452
+      } else {
+        *next_lm = 0;
+        return cost + __int_as_float(arc.z);
+      }
+    };
     if (j < n_emit) {
       i = emit[j];
       const int4 T = tok[base + i];
       row = T.x;
       cost = __int_as_float(T.y);
+      if constexpr (kBig) plm = tlm[base + i];
       neps = (int)((uint32_t)D.g.arcs[row].x & kEpsMask);
-      for (int e = 0; e < neps; ++e) npass += (cost + __int_as_float(D.g.arcs[row + 1 + e].z)) < cutoff;
+      for (int e = 0; e < neps; ++e) { int nl; npass += arrival(row + 1 + e, D.g.arcs[row + 1 + e], &nl) < cutoff; }
     }
     // one atomicAdd per wave for all its links
     int ps = npass;
@@ -1478,9 +1503,22 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
     for (int e = 0; e < neps && npass; ++e) {
       const int a = row + 1 + e;
       const int4 arc = D.g.arcs[a];
-      const float tot = cost + __int_as_float(arc.z);
+      int nlm;
+      const float tot = arrival(a, arc, &nlm);
       if (!(tot < cutoff)) continue;
-      const int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;
+      int ord = (int)((uint32_t)arc.y & 0x7FFFFFFFu) - 1;
+      if constexpr (kBig) {   // the slot of (destination row, LM pair) in the hashed table
+        const u64 key = big_key(arc.w, nlm);
+        const uint32_t emask = (uint32_t)D.ecap - 1u;
+        uint32_t es = hash_big(arc.w, nlm) & emask;
+        ord = -1;
+        for (int q = 0; q < D.ecap && nlm >= 0; ++q) {
+          const u64 kk = ld_agent(&ekeys[es]);
+          if (kk == key) { ord = (int)es; break; }
+          if (kk == kEmptyVal) break;
+          es = (es + 1) & emask;
+        }
+      }
       // the destination's token of THIS frame (every epsilon arrival below the cutoff made one, through the insert launch or
       // the closure pass); an entry from an older frame would mean that invariant broke: reported, never linked
       const int dst = ord >= 0 ? ld_agent(&toki[ord]) : -1;
@@ -1720,7 +1758,7 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
   if ((tid & 63) == 0) sh.red64[tid >> 6] = best;
   __syncthreads();  // every read of the table above is done before it is cleared
   if (tid == 0) dbg_phase(D, 2, tq);
-  if (kLat && fits) epsilon_links(D, c, sh, base, cutoff);
+  if (kLat && fits) epsilon_links<kBig>(D, c, sh, base, cutoff);
   for (int i0 = 0; i0 < nocc; i0 += kBT * kClosureUnroll) {  // the list loads of a thread issued together
     int od[kClosureUnroll];
 #pragma unroll
@@ -2266,12 +2304,25 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
   // ---- (1) the newest frame ---------------------------------------------------------------------
   if (kFinal) {
     // ComputeFinalCosts (base-inl.h:670-720) + PruneForwardLinksFinal (:725-824)
+    // (biglm: ComputeFinalCosts of biglm.h:160-215 -- the LM's final cost enters best_cost_with_final for EVERY token, final
+    // in the graph or not; only graph-final tokens are final, each with its LM final cost)
+    const int32_t *tlm = D.big ? D.tok_lm + (size_t)c * D.arena_cap : nullptr;
+    const u64 *pkeys = D.big ? D.pair_keys + (size_t)c * D.pair_cap : nullptr;
+    auto lm_final = [&](int i) -> float {
+      const u64 pk = pkeys[tlm[i]];
+      return lm_final_cost(D.lm_old, (int)(uint32_t)pk) + lm_final_cost(D.lm_new, (int)(uint32_t)(pk >> 32));   // diff-lm.h:48-53
+    };
     u64 b_all = ~0ull, b_fin = ~0ull;
+    int any_fin = 0;
     for (int i = fn + tid; i < fn1; i += kBT) {
       const int4 t = tok[i];
       const u64 v = (u64)f2o(__int_as_float(t.y));
       b_all = v < b_all ? v : b_all;
-      if (t.x == D.g.final_state) b_fin = v < b_fin ? v : b_fin;
+      if (D.big) {
+        const u64 w = (u64)f2o(__int_as_float(t.y) + lm_final(i));
+        b_fin = w < b_fin ? w : b_fin;                      // best_cost_with_final: over all tokens
+        any_fin |= t.x == D.g.final_state;
+      } else if (t.x == D.g.final_state) b_fin = v < b_fin ? v : b_fin;
     }
     b_all = wave_min_u64(b_all);
     b_fin = wave_min_u64(b_fin);
@@ -2279,10 +2330,17 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     __syncthreads();
     for (int w = 0; w < kBT / 64; ++w) { b_all = ps.red[0][w] < b_all ? ps.red[0][w] : b_all; b_fin = ps.red[1][w] < b_fin ? ps.red[1][w] : b_fin; }
     any_final = b_fin != ~0ull;
-    const float final_best = o2f((uint32_t)(any_final ? b_fin : b_all));
+    if (D.big) {   // the final-cost set is non-empty iff some token is final in the graph
+      if (tid == 0) ps.cnt = 0;
+      __syncthreads();
+      if (any_fin) ps.cnt = 1;
+      __syncthreads();
+      any_final = ps.cnt != 0;
+    }
+    const float final_best = o2f((uint32_t)(b_fin != ~0ull ? b_fin : b_all));
     for (int i = fn + tid; i < fn1; i += kBT) {
       const int4 t = tok[i];
-      const float final_cost = (!any_final || t.x == D.g.final_state) ? 0.0f : kInf;
+      const float final_cost = !any_final ? 0.0f : t.x == D.g.final_state ? (D.big ? lm_final(i) : 0.0f) : kInf;
       float e = __int_as_float(t.y) + final_cost - final_best;  // base-inl.h:775
       if (e > lb) e = kInf;                                      // base-inl.h:815-816 (tokens without links)
       extra[i] = make_uint2(f2o(e), (uint32_t)t.y);
@@ -2639,9 +2697,10 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     // (b) the survivors move down (a sweep is read whole before it is written; new index <= old index, so a sweep's writes
     // land on positions that this sweep or an earlier one has read)
     for (int j0 = range_lo; j0 < new_end; j0 += kPrChunk) {
-      int oi[kCU];
+      int oi[kCU], sl[kCU];
       int4 rec[kCU];
       uint2 ex[kCU];
+      int32_t *side = D.big ? D.tok_lm + (size_t)c * D.arena_cap : nullptr;   // biglm: the tokens' LM pair states move along
 #pragma unroll
       for (int u = 0; u < kCU; ++u) {
         const int j = j0 + u * kBT + tid;
@@ -2651,7 +2710,8 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       for (int u = 0; u < kCU; ++u) {
         rec[u] = make_int4(0, 0, 0, 0);
         ex[u] = make_uint2(0, 0);
-        if (oi[u] >= 0) { rec[u] = tok[oi[u]]; ex[u] = extra[oi[u]]; }
+        sl[u] = 0;
+        if (oi[u] >= 0) { rec[u] = tok[oi[u]]; ex[u] = extra[oi[u]]; if (side) sl[u] = side[oi[u]]; }
       }
 #pragma unroll
       for (int u = 0; u < kCU; ++u) {
@@ -2666,7 +2726,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
 #pragma unroll
       for (int u = 0; u < kCU; ++u) {
         const int j = j0 + u * kBT + tid;
-        if (oi[u] >= 0) { tok[j] = rec[u]; extra[j] = ex[u]; }
+        if (oi[u] >= 0) { tok[j] = rec[u]; extra[j] = ex[u]; if (side) side[j] = sl[u]; }
       }
       __syncthreads();
     }
@@ -3042,7 +3102,8 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
   }
   __syncthreads();
   u64 nZ = 0;
-  if (D.big) epsilon_closure<false, true>(D, c, sh, 0, D.beam, &nZ);
+  if (D.big && D.lattice) epsilon_closure<true, true>(D, c, sh, 0, D.beam, &nZ);
+  else if (D.big) epsilon_closure<false, true>(D, c, sh, 0, D.beam, &nZ);
   else if (D.lattice) epsilon_closure<true, false>(D, c, sh, 0, D.beam, &nZ);  // ProcessNonemitting(_config._beam)
   else epsilon_closure<false, false>(D, c, sh, 0, D.beam, &nZ);
   if (D.degcode) {
@@ -3382,6 +3443,10 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
         o.ilabel = eps ? 0 : D.g.arc_ilabel[L.z];
         o.olabel = D.g.arc_olabel[L.z];
         o.graph = __int_as_float(A.z);
+        if (D.big && o.olabel != 0) {   // biglm: graph_cost = arc weight + lm_score from the source token's LM state (biglm.h:377-388, 448-452)
+          int n1, n2;
+          o.graph = __int_as_float(A.z) + lm_step(D, c, D.tok_lm[(size_t)c * D.arena_cap + L.x], o.olabel, &n1, &n2);
+        }
         o.acoustic = eps ? 0.0f : -ll[(size_t)src_frame * D.stride + (A.x & D.g.col_mask)];
         o.src_frame = src_frame; o.is_eps = eps ? 1 : 0;
         out_arcs[p] = o;
@@ -3452,8 +3517,9 @@ void launch_expand_replay(const DecoderDev &D, int group, int par, int variant, 
 }
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int boundary, int group, int par,
                    int n_workgroups, hipStream_t s) {
-  const size_t lds = (size_t)D.lds_slots * (D.big ? 16 : D.lattice ? 16 : 12);
-  if (D.big) hipLaunchKernelGGL(insert_kernel_biglm, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  const size_t lds = (size_t)D.lds_slots * ((D.big && D.lattice) ? 20 : D.big ? 16 : D.lattice ? 16 : 12);
+  if (D.big && D.lattice) hipLaunchKernelGGL(insert_kernel_lattice_biglm, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
+  else if (D.big) hipLaunchKernelGGL(insert_kernel_biglm, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
   else if (D.lattice && D.fused) hipLaunchKernelGGL(insert_kernel_lattice_fused, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
   else if (D.lattice) hipLaunchKernelGGL(insert_kernel_lattice, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
   else if (D.fused) hipLaunchKernelGGL(insert_kernel_fused, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par, target, boundary, chan_cnt);
@@ -3461,7 +3527,9 @@ void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_
 }
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int do_prep, int group, int par,
                     hipStream_t s) {
-  if (D.big)
+  if (D.big && D.lattice)
+    hipLaunchKernelGGL((closure_kernel<true, true>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+  else if (D.big)
     hipLaunchKernelGGL((closure_kernel<false, true>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
   else if (D.lattice)
     hipLaunchKernelGGL((closure_kernel<true, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
@@ -3495,6 +3563,10 @@ int insert_kernel_set_lds(int bytes) {
   int e = (int)hipFuncSetAttribute((const void *)insert_kernel_lattice, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e) return e;
   e = (int)hipFuncSetAttribute((const void *)insert_kernel_biglm, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e) return e;
+  e = (int)hipFuncSetAttribute((const void *)insert_kernel_lattice_biglm, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e) return e;
+  e = (int)hipFuncSetAttribute((const void *)insert_kernel_lattice_fused, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e) return e;
   e = (int)hipFuncSetAttribute((const void *)insert_kernel_fused, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e) return e;

@@ -215,7 +215,11 @@ int wfst_decoder_create_ex(const wfst_graph *g, const wfst_config *cfg, int32_t 
  * cost_old(word | history); a token is identified by (graph state, LM pair state) (:77-90).  Both LMs must
  * be on the graph's device and stay alive as long as the decoder.  Each LM is walked from its OWN state
  * (DiffArpaLm with the pair's components; the reference text hands the pair id to both LMs,
- * newlm/diff-lm.h:80,86 -- see DESIGN.md).  Best path only: limits->lattice_links must be 0.
+ * newlm/diff-lm.h:80,86 -- see DESIGN.md).  With limits->lattice_links > 0 it is the LATTICE decoder it is in the reference
+ * (the service asks a `biglm-hclg` decoder for GetRawLattice / GetLattice / n-best, kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:
+ * 58,81,97-105): forward links carry graph cost = arc weight + LM difference (:377-392, :448-458), FinalizeDecoding prunes with
+ * the LM's final costs (:160-215, 469-560), and -- as in the reference's GetRawLattice (base-inl.h:930-966) -- a raw lattice only
+ * FLAGS its final states: the LM's final cost of a final token is not part of the lattice.
  * WFST_E_FORMAT if the graph has an output label the LMs' empty-history state has no arc for (the
  * reference indexes that state without a bounds check, newlm/arpa2fsa.h:211-214). */
 int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32_t n_channels,

@@ -269,6 +269,41 @@ def oracle_raw_lattice(orc, graph_handle, cfg, loglikes, tid2pdf=None, finalize=
                         max_states, max_arcs)
 
 
+def biglm_raw_lattice(dec, graph_handle, cfg, lm1, lm2, loglikes, tid2pdf=None, finalize=True, use_final_probs=True, fixed=True,
+                      max_states=1 << 20, max_arcs=1 << 21):
+    """GetRawLattice of the biglm decoder of `dec` (RefDecoder: the reference's OnlineLatticeDecoderMempoolBiglm as it is;
+    OracleDecoder: the restatement, `fixed` chooses the DiffArpaLm mode, states labelled with frame / graph state / cost)."""
+    ll = np.ascontiguousarray(loglikes, dtype=np.float32)
+    T, stride = ll.shape
+    n_tid = stride - 1
+    if tid2pdf is not None:
+        tid2pdf = np.ascontiguousarray(tid2pdf, dtype=np.int32)
+        n_tid = int(tid2pdf.shape[0] - 1)
+    is_ref = dec.PREFIX == "ref"
+    ns, na, st = C.c_int(0), C.c_int(0), C.c_int(0)
+    fin, fr, gs = (np.zeros(max_states, np.int32) for _ in range(3))
+    co = np.zeros(max_states, np.float32)
+    src, dst, il, ol = (np.zeros(max_arcs, np.int32) for _ in range(4))
+    gr, ac = np.zeros(max_arcs, np.float32), np.zeros(max_arcs, np.float32)
+    f = getattr(dec.lib, dec.PREFIX + "_biglm_raw_lattice")
+    f.restype = C.c_int
+    head = [C.c_void_p(graph_handle), C.byref(cfg), C.c_void_p(lm1.h), C.c_void_p(lm2.h)]
+    if not is_ref:
+        head.append(int(bool(fixed)))
+    head += [_fp(ll), T, stride, _ip(tid2pdf), n_tid, int(bool(finalize)), int(bool(use_final_probs)), max_states, C.byref(ns),
+             C.byref(st), _ip(fin)]
+    if not is_ref:
+        head += [_ip(fr), _ip(gs), _fp(co)]
+    ok = f(*head, max_arcs, C.byref(na), _ip(src), _ip(dst), _ip(il), _ip(ol), _fp(gr), _fp(ac))
+    S, A = ns.value, na.value
+    if S > max_states or A > max_arcs:
+        raise ValueError("lattice larger than the caps: %d states, %d arcs" % (S, A))
+    lab = not is_ref
+    return RawLattice(bool(ok), S, st.value, fin[:S].copy(), src[:A].copy(), dst[:A].copy(), il[:A].copy(), ol[:A].copy(),
+                      gr[:A].copy(), ac[:A].copy(), fr[:S].copy() if lab else None, gs[:S].copy() if lab else None,
+                      co[:S].copy() if lab else None)
+
+
 def ref_lattice_write(ref, graph_handle, cfg, loglikes, path, tid2pdf=None):
     """Append the reference's GetRawLattice to `path` with the reference's own Lattice::Write."""
     ll = np.ascontiguousarray(loglikes, dtype=np.float32)

@@ -639,6 +639,58 @@ int ref_biglm_decode(void *gp, const RefConfig *rc, void *lm1, void *lm2, const 
   return 1;
 }
 
+// ref_raw_lattice() with the biglm decoder: GetRawLattice(use_final_probs) of OnlineLatticeDecoderMempoolBiglm -- what the
+// service takes from a `biglm-hclg` decoder (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:58,81).
+int ref_biglm_raw_lattice(void *gp, const RefConfig *rc, void *lm1, void *lm2, const float *loglikes, int T, int stride,
+                          const int *tid2pdf, int n_tid, int do_finalize, int use_final_probs,
+                          int max_states, int *n_states, int *start, int *st_final, int max_arcs,
+                          int *n_arcs, int *a_src, int *a_dst, int *a_il, int *a_ol, float *a_graph,
+                          float *a_ac) {
+  Fst *g = static_cast<Fst *>(gp);
+  LatticeFasterDecoderConfig cfg;
+  cfg._beam = rc->beam;
+  cfg._max_active = rc->max_active;
+  cfg._min_active = rc->min_active;
+  cfg._lattice_beam = rc->lattice_beam;
+  cfg._prune_interval = rc->prune_interval;
+  cfg._beam_delta = rc->beam_delta;
+  cfg._hash_ratio = rc->hash_ratio;
+  cfg._prune_scale = rc->prune_scale;
+  ProbeBiglm dec(g, cfg, static_cast<ArpaLm *>(lm1), static_cast<ArpaLm *>(lm2));
+  MatrixDecodable decodable(loglikes, T, stride, tid2pdf, n_tid);
+  dec.InitDecoding();
+  dec.AdvanceDecoding(&decodable);
+  if (do_finalize) dec.FinalizeDecoding();
+  Lattice lat;
+  *n_states = 0;
+  *n_arcs = 0;
+  *start = -1;
+  if (!dec.GetRawLattice(&lat, use_final_probs != 0)) return 0;
+  const int S = lat.NumStates();
+  *n_states = S;
+  *start = lat.Start();
+  int na = 0;
+  for (int s = 0; s < S; ++s) {
+    LatticeState *st = lat.GetState(s);
+    if (s < max_states) st_final[s] = st->IsFinal() ? 1 : 0;
+    const int k = (int)st->GetArcSize();
+    for (int i = 0; i < k; ++i) {
+      LatticeArc *a = st->GetArc(i);
+      if (na < max_arcs) {
+        a_src[na] = s;
+        a_dst[na] = a->_to;
+        a_il[na] = a->_input;
+        a_ol[na] = a->_output;
+        a_graph[na] = a->_w.Value1();
+        a_ac[na] = a->_w.Value2();
+      }
+      ++na;
+    }
+  }
+  *n_arcs = na;
+  return 1;
+}
+
 // ref_timed_loop() with ONE biglm decoder object (bench.py --biglm, cpu_baseline leg).
 long long ref_biglm_timed_loop(void *gp, const RefConfig *rc, void *lm1, void *lm2, const float *const *mats,
                                const int *T, int n_mats, int stride, const int *tid2pdf, int n_tid, int first,

@@ -941,7 +941,7 @@ int oracle_biglm_decode(void *gp, const Config *rc, void *lm1, void *lm2, int fi
  * state by state.  State numbering: frame by frame in token-list order (the reference numbers by
  * TopSortTokens over an unordered_map keyed by pointers, i.e. implementation defined; compare up to
  * isomorphism).  State 0 is the start token. */
-int oracle_raw_lattice(void *gp, const Config *rc, const float *loglikes, int T, int stride,
+static int raw_lattice_impl(void *gp, const Config *rc, DiffLm *dlm, const float *loglikes, int T, int stride,
                        const int *tid2pdf, int n_tid, int do_finalize, int use_final_probs,
                        int max_states, int *n_states, int *start, int *st_final, int *st_frame,
                        int *st_gstate, float *st_cost, int max_arcs, int *n_arcs, int *a_src, int *a_dst, int *a_il,
@@ -949,7 +949,7 @@ int oracle_raw_lattice(void *gp, const Config *rc, const float *loglikes, int T,
   (void)n_tid;
   Decoder D; memset(&D, 0, sizeof(D));
   Decoder *d = &D;
-  d->g = (const Graph *)gp; d->cfg = *rc;
+  d->g = (const Graph *)gp; d->cfg = *rc; d->dlm = dlm;
   d->toks.bucket_list_tail = NOBUCKET;
   d->tok_pool.elem_size = sizeof(Token); d->link_pool.elem_size = sizeof(Link);
   d->ll = loglikes; d->T = T; d->stride = stride; d->tid2pdf = tid2pdf; d->frames_ready = T;
@@ -1029,6 +1029,33 @@ int oracle_raw_lattice(void *gp, const Config *rc, const float *loglikes, int T,
   free(d->toks.blocks); free(d->toks.buckets);
   pool_destroy(&d->tok_pool); pool_destroy(&d->link_pool);
   free(d->active); free(d->queue); free(d->tmp);
+  return ok;
+}
+
+int oracle_raw_lattice(void *gp, const Config *rc, const float *loglikes, int T, int stride,
+                       const int *tid2pdf, int n_tid, int do_finalize, int use_final_probs,
+                       int max_states, int *n_states, int *start, int *st_final, int *st_frame,
+                       int *st_gstate, float *st_cost, int max_arcs, int *n_arcs, int *a_src, int *a_dst, int *a_il,
+                       int *a_ol, float *a_graph, float *a_ac) {
+  return raw_lattice_impl(gp, rc, NULL, loglikes, T, stride, tid2pdf, n_tid, do_finalize, use_final_probs, max_states, n_states, start,
+                          st_final, st_frame, st_gstate, st_cost, max_arcs, n_arcs, a_src, a_dst, a_il, a_ol, a_graph, a_ac);
+}
+
+/* The same from the biglm decoder (my-decoder/online-decoder-mempool-base-biglm.h: a lattice decoder -- the service asks it for
+ * GetRawLattice / GetLattice / n-best, kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:58,81,97-105): links carry graph cost = arc
+ * weight + lm_score (:377-392, :448-458), FinalizeDecoding prunes with the LM's final costs (:469-560, ComputeFinalCosts
+ * :160-215).  As in the base class's GetRawLattice a final token is only FLAGGED final: its final cost is added to the graph
+ * cost of its out-links (base-inl.h:930-966), of which a graph-final token has none.  `fixed` as oracle_biglm_decode. */
+int oracle_biglm_raw_lattice(void *gp, const Config *rc, void *lm1, void *lm2, int fixed, const float *loglikes, int T, int stride,
+                             const int *tid2pdf, int n_tid, int do_finalize, int use_final_probs,
+                             int max_states, int *n_states, int *start, int *st_final, int *st_frame,
+                             int *st_gstate, float *st_cost, int max_arcs, int *n_arcs, int *a_src, int *a_dst, int *a_il,
+                             int *a_ol, float *a_graph, float *a_ac) {
+  DiffLm dlm;
+  dlm_init(&dlm, (const Lm *)lm1, (const Lm *)lm2, fixed);
+  const int ok = raw_lattice_impl(gp, rc, &dlm, loglikes, T, stride, tid2pdf, n_tid, do_finalize, use_final_probs, max_states, n_states,
+                                  start, st_final, st_frame, st_gstate, st_cost, max_arcs, n_arcs, a_src, a_dst, a_il, a_ol, a_graph, a_ac);
+  dlm_free(&dlm);
   return ok;
 }
 

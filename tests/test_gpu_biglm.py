@@ -204,11 +204,10 @@ def test_biglm_refusals(gold, synth, tmp_path):
     W = G.wfstdec
     old, new = gold["lms"]["ngram"]
     cd = dict(beam=10.0, max_active=7000, min_active=0, lattice_beam=8.0)
-    # one LM only / lattice mode
+    # one LM only
     with pytest.raises(W.WfstError):
         W.BatchDecoder(gold["graph"], G.gpu_config(cd), 1, old_lm=old)
-    with pytest.raises(W.WfstError):
-        W.BatchDecoder(gold["graph"], G.gpu_config(cd), 1, old_lm=old, new_lm=new, lattice_links=1 << 20)
+    # (lattice mode is served: test_biglm_lattice_mode_equals_the_fixed_mode_oracle_state_by_state)
     # a graph with a word the LMs do not know: refused at creation (the reference would index out of range)
     g2 = synth.make_hclg_like(500, seed=5, n_tid=600, n_words=5000)
     p = str(tmp_path / "g2.bin")
@@ -291,3 +290,85 @@ def test_biglm_fuzz_on_random_dense_epsilon_graphs(block, synth, oracle, tmp_pat
         o1.free(); o2.free(); oracle.free_graph(h)
         L1.free(); L2.free(); graph.free()
     assert n_cases >= 10 and n_exact >= 6 and n_tied <= max(1, n_cases // 10), (n_cases, n_exact, n_tied)
+
+
+def test_biglm_lattice_mode_equals_the_fixed_mode_oracle_state_by_state(gold, oracle):
+    """The biglm decoder as the LATTICE decoder it is in the reference (VERDICT r2 missing #1): forward links with graph cost =
+    arc weight + LM difference, running back-pruning, FinalizeDecoding with the LM's final costs (biglm.h:160-215, 469-560),
+    GetRawLattice after FinalizeDecoding and mid-utterance, n-best and GetLattice -- every golden configuration in the
+    beam-only regime and both LM pairs, as one ragged batch each, against the oracle (fixed DiffArpaLm, order-free): the raw
+    lattice state by state and arc by arc, the best path bit for bit; the determinized lattice against the host build of
+    the determinizer run on the same raw lattice; the n-best ascending and no costlier than the best path."""
+    from test_gpu_determinize import as_det
+    from test_gpu_lattice import as_raw, nodes
+
+    G, meta = gold["G"], gold["meta"]
+    W = G.wfstdec
+    lib = pyoracle.build_det_host()
+    h = oracle.load_graph(gold["gpath"])
+    n_lat = n_mid = 0
+    try:
+        oracle.set_order_free(True)
+        for pname in meta["pairs"]:
+            old, new = gold["lms"][pname]
+            o1 = pyoracle.Lm(oracle, gold["lm_paths"][(pname, "old")], -1.0)
+            o2 = pyoracle.Lm(oracle, gold["lm_paths"][(pname, "new")], 1.0)
+            # (+ a lattice_beam wide enough that the reference's final pruning -- its final_best_cost ranges over non-final tokens
+            # too, biglm.h:186-188 -- leaves every utterance its lattice)
+            for cd in [c for c in meta["cfgs"] if _beam_only(c)] + [dict(beam=13.0, max_active=1000000, min_active=0, lattice_beam=25.0)]:
+                cd = dict(cd, prune_interval=7)
+                mats = [u[: 40 - 7 * i] for i, u in enumerate(gold["utts"])]   # ragged lengths
+                dec = W.BatchDecoder(gold["graph"], G.gpu_config(cd), len(mats), old_lm=old, new_lm=new, max_frames=64,
+                                     max_tokens_per_frame=32768, arena_tokens=1 << 20, lattice_links=1 << 21)
+                dev = G.upload(mats)
+                ptrs = [t.data_ptr() for t in dev]
+                dec.init()
+                # mid-utterance: after 20 frames (running passes at 7 and 14 have pruned and compacted)
+                dec.advance(ptrs, [min(20, x.shape[0]) for x in mats], int(mats[0].shape[1]))
+                for i, ll in enumerate(mats):
+                    k = min(20, ll.shape[0])
+                    for ufp in (True, False):
+                        O = pyoracle.biglm_raw_lattice(oracle, h, pyoracle.Config(**cd), o1, o2, ll[:k], gold["m"], finalize=False, use_final_probs=ufp, fixed=True)
+                        d = dec.raw_lattice(i, use_final_probs=ufp)
+                        assert (d is not None) == bool(O.ok), (pname, cd, i, ufp)
+                        if d is None:
+                            continue
+                        L = as_raw(d)
+                        assert np.array_equal(nodes(L), nodes(O)) and np.array_equal(L.labelled_arcs(), O.labelled_arcs()), "mid %s %s utt %d %s" % (pname, cd, i, ufp)
+                        n_mid += 1
+                dec.advance(ptrs, [int(x.shape[0]) for x in mats], int(mats[0].shape[1]))
+                dec.finalize()
+                best = dec.best_paths()
+                nb = dec.nbest(4)
+                for i, ll in enumerate(mats):
+                    what = "%s %s utt %d" % (pname, cd, i)
+                    o = pyoracle.biglm_decode(oracle, h, pyoracle.Config(**cd), o1, o2, ll, gold["m"], fixed=True)
+                    assert o.extra["ties"] == 0
+                    _same(G.GpuResult(best[i]), o, what)
+                    O = pyoracle.biglm_raw_lattice(oracle, h, pyoracle.Config(**cd), o1, o2, ll, gold["m"], fixed=True)
+                    d = dec.raw_lattice(i)
+                    assert (d is not None) == bool(O.ok), what
+                    if d is None:
+                        assert len(nb[i]) == 0 and dec.determinized_lattice(i) is None, what
+                        continue
+                    L = as_raw(d)
+                    assert np.array_equal(nodes(L), nodes(O)), what + " states"
+                    assert np.array_equal(L.labelled_arcs(), O.labelled_arcs()), what + " arcs"
+                    n_lat += 1
+                    if o.ok:
+                        # (the raw lattice only FLAGS its final states -- GetRawLattice drops the LM's final costs, base-inl.h:930-966 --
+                        # so its cheapest path need not be GetBestPath's, which counts them: it costs no more)
+                        tots = [p_["tot_score"] for p_ in nb[i]]
+                        assert len(nb[i]) >= 1 and all(b >= a for a, b in zip(tots, tots[1:])), what + " n-best order"
+                        assert tots[0] <= o.tot_score + 1e-3, what + " cheapest lattice path vs best path"
+                    D = as_det(dec.determinized_lattice(i))
+                    rc, H = pyoracle.det_host_run(lib, L, cap_scale=32)
+                    assert rc == 0 and [D.n_states, int(D.st_final.sum())] == [H.n_states, int(H.st_final.sum())], what
+                    assert np.array_equal(D.arc_multiset(), H.arc_multiset()), what + " determinized"
+                dec.free()
+            o1.free()
+            o2.free()
+    finally:
+        oracle.set_order_free(False)
+        oracle.free_graph(h)
+    assert n_lat >= 10 and n_mid >= 20, (n_lat, n_mid)

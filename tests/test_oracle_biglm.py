@@ -197,3 +197,54 @@ def test_as_written_mode_equals_the_compiled_reference_on_fresh_seeds(refdec, or
         refdec.free_graph(hr)
         oracle.free_graph(ho)
     assert n_ok >= 20
+
+
+def test_biglm_raw_lattice_as_written_equals_the_compiled_reference(refdec, oracle, synth, tmp_path):
+    """The biglm decoder is a LATTICE decoder (the service takes GetRawLattice / GetLattice / n-best from it,
+    kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:58,81,97-105): the restatement's raw lattice -- links with graph cost = arc
+    weight + LM difference, FinalizeDecoding's pruning with the LM's final costs -- against the compiled reference's, as
+    an arc multiset (labels and float costs bit for bit) with state and final-state counts; after FinalizeDecoding and
+    mid-utterance.  In fixed mode, the order-free switch (what the HIP path is held to) gives a sub-lattice of the default order's."""
+    from collections import Counter
+
+    n_ok = 0
+    for seed in range(3):
+        V = 150 + 40 * seed
+        g = synth.make_hclg_like(1500 + 700 * seed, seed=80 + seed, n_tid=600, n_words=V)
+        m = synth.default_tid2pdf(600)
+        gp = str(tmp_path / ("g%d.bin" % seed))
+        g.write(gp)
+        p1, p2 = str(tmp_path / ("a%d.bin" % seed)), str(tmp_path / ("b%d.bin" % seed))
+        lmsynth.make_lm(V, 2, 80, 5, 0, 0, seed=160 + seed).to_fsa().write(p1)
+        lmsynth.make_lm(V, 3, 120, 8, 500, 5, seed=170 + seed).to_fsa().write(p2)
+        hr, ho = refdec.load_graph(gp), oracle.load_graph(gp)
+        r1, r2 = pyoracle.Lm(refdec, p1, -1.0), pyoracle.Lm(refdec, p2, 1.0)
+        o1, o2 = pyoracle.Lm(oracle, p1, -1.0), pyoracle.Lm(oracle, p2, 1.0)
+        for cd in (dict(beam=11.0, max_active=7000, min_active=0, lattice_beam=10.0), dict(beam=12.0, max_active=7000, min_active=0, lattice_beam=20.0, prune_interval=7)):
+            for u in range(3):
+                ll = synth.make_loglikes(g, 40, 300, m, seed=1900 + 10 * seed + u, mu=-2.2)[0]
+                for md in (dict(), dict(finalize=False), dict(finalize=False, use_final_probs=False)):
+                    R = pyoracle.biglm_raw_lattice(refdec, hr, pyoracle.Config(**cd), r1, r2, ll, m, **md)
+                    O = pyoracle.biglm_raw_lattice(oracle, ho, pyoracle.Config(**cd), o1, o2, ll, m, fixed=False, **md)
+                    what = "seed %d %s %s utt %d" % (seed, cd, md, u)
+                    assert R.ok == O.ok, what
+                    assert [O.n_states, int(O.st_final.sum()), len(O.a_src)] == [R.n_states, int(R.st_final.sum()), len(R.a_src)], what
+                    assert np.array_equal(O.arc_multiset(), R.arc_multiset()), what
+                    n_ok += int(R.ok)
+                    if md:
+                        continue
+                    # (in FIXED mode: as written, the pair ids handed to the LMs depend on the visiting order themselves)
+                    O2 = pyoracle.biglm_raw_lattice(oracle, ho, pyoracle.Config(**cd), o1, o2, ll, m, fixed=True)
+                    try:
+                        oracle.set_order_free(True)
+                        F = pyoracle.biglm_raw_lattice(oracle, ho, pyoracle.Config(**cd), o1, o2, ll, m, fixed=True)
+                    finally:
+                        oracle.set_order_free(False)
+                    assert F.ok == O2.ok, what
+                    cb, cs = Counter(map(tuple, O2.arc_multiset())), Counter(map(tuple, F.arc_multiset()))
+                    assert all(cb[k] >= v for k, v in cs.items()), what + ": order-free lattice is not a sub-lattice"
+        for L in (r1, r2, o1, o2):
+            L.free()
+        refdec.free_graph(hr)
+        oracle.free_graph(ho)
+    assert n_ok >= 20
