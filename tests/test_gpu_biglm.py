@@ -246,7 +246,7 @@ def test_biglm_fuzz_on_random_dense_epsilon_graphs(block, synth, oracle, tmp_pat
     from test_gpu_fuzz import random_graph
 
     rng = np.random.default_rng(int(os.environ.get("WFST_FUZZ_SEED", "4321")) + block)
-    n_cases = n_exact = n_tied = 0
+    n_cases = n_exact = n_tied = n_lat = 0
     for case in range(10):
         n_states = int(rng.integers(4, 60))
         n_labels = int(rng.integers(3, 12))
@@ -276,6 +276,18 @@ def test_biglm_fuzz_on_random_dense_epsilon_graphs(block, synth, oracle, tmp_pat
             want = [pyoracle.biglm_decode(oracle, h, pyoracle.Config(**cd), o1, o2, x, None, chunk=chunk, fixed=True) for x in mats]
         finally:
             oracle.set_order_free(False)
+        # the same batch through a LATTICE-mode biglm decoder: best paths again, and the raw lattice of every utterance state by
+        # state against the oracle's (order-free, fixed mode)
+        from test_gpu_lattice import as_raw, nodes
+
+        ldec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), old_lm=L1, new_lm=L2, max_frames=64, max_tokens_per_frame=8192,
+                                      arena_tokens=1 << 17, lattice_links=1 << 19)
+        lres = G.decode_batch(graph, cd, mats, chunk=chunk, dec=ldec)
+        try:
+            oracle.set_order_free(True)
+            wlat = [pyoracle.biglm_raw_lattice(oracle, h, pyoracle.Config(**cd), o1, o2, x, None, fixed=True) for x in mats]
+        finally:
+            oracle.set_order_free(False)
         for i, (r, o) in enumerate(zip(res, want)):
             what = "block %d case %d utt %d (states %d, T %d, cfg %s)" % (block, case, i, n_states, lens[i], cd)
             assert o.extra["lm_oob"] == 0, what
@@ -283,13 +295,22 @@ def test_biglm_fuzz_on_random_dense_epsilon_graphs(block, synth, oracle, tmp_pat
             n_cases += 1
             if o.ok and o.extra["ties"] == 0:
                 _same(r, o, what)
+                _same(lres[i], o, what + " (lattice-mode decoder)")
                 n_exact += 1
             elif o.ok:
                 n_tied += 1
                 assert len(r.tids) == len(o.tids) and abs(r.tot_score - o.tot_score) <= 1e-4 * max(1.0, abs(o.tot_score)), what
+            if o.extra["ties"] == 0 and not binding:
+                d = ldec.raw_lattice(i)
+                assert (d is not None) == bool(wlat[i].ok), what + " lattice"
+                if d is not None:
+                    L = as_raw(d)
+                    assert np.array_equal(nodes(L), nodes(wlat[i])) and np.array_equal(L.labelled_arcs(), wlat[i].labelled_arcs()), what + " lattice"
+                    n_lat += 1
+        ldec.free()
         o1.free(); o2.free(); oracle.free_graph(h)
         L1.free(); L2.free(); graph.free()
-    assert n_cases >= 10 and n_exact >= 6 and n_tied <= max(1, n_cases // 10), (n_cases, n_exact, n_tied)
+    assert n_cases >= 10 and n_exact >= 6 and n_tied <= max(1, n_cases // 10) and n_lat >= 3, (n_cases, n_exact, n_tied, n_lat)
 
 
 def test_biglm_lattice_mode_equals_the_fixed_mode_oracle_state_by_state(gold, oracle):
