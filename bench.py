@@ -765,6 +765,15 @@ def main():
                           "max_active=7000, min_active=200 (v1-asrbin/conf/decoder.conf:4-8)" % a.beam}
         sp.update(at_service_point(mats2, ll2))
         del ll2, mats2
+        # third leg: the same generator calibrated as SURVEY 8(d) asks -- mu -2.6 gives ~5.5 k tokens per frame at
+        # beam 13, ~4 k of them expanded -- so that max_active 7000 binds on a minority of the frames
+        sa.mu = -2.6
+        mats3 = make_utts(synth, g, m, 0, B, T, P, sa)
+        ll3 = torch.from_numpy(mats3).to(dev)
+        cp = {"workload": "SURVEY.md 8(d) single-planted-path log-likelihoods calibrated to ~5 k tokens per frame (mu -2.6, sigma 1), max_active=7000, min_active=200"}
+        cp.update(at_service_point(mats3, ll3))
+        del ll3, mats3
+        sp["calibrated_workload_at_7000_200"] = cp
         hp = {"workload": "the headline log-likelihoods at max_active=7000, min_active=200"}
         hp.update(at_service_point(mats, ll_dev))
         sp["headline_workload_at_7000_200"] = hp

@@ -389,8 +389,11 @@ def test_service_operating_point_divergence_from_the_reference(big, synth, refde
 
     as_gpu = lambda rs: [dict(ok=r.ok, words=r.words, tids=r.tids, tot_score=r.tot_score) for r in rs]
     single = [synth.make_loglikes(big["g"], big["T"], 3000, big["m"], seed=u, mu=-2.0, sigma=1.0)[0] for u in range(big["B"])]
+    # (c) the same generator calibrated as SURVEY 8(d) asks (mu -2.6: ~5.5 k tokens per frame at beam 13, ~4 k expanded), where
+    #     max_active 7000 binds on a minority of the frames
+    calibrated = [synth.make_loglikes(big["g"], big["T"], 3000, big["m"], seed=u, mu=-2.6, sigma=1.0)[0] for u in range(big["B"])]
     out = {}
-    for name, mats in (("headline", big["mats"]), ("single", single)):
+    for name, mats in (("headline", big["mats"]), ("single", single), ("calibrated", calibrated)):
         res = G.decode_batch(big["graph"], cd, mats, limits=LIM)
         assert all(r.ok and len(r.tids) == big["T"] for r in res)
         r2 = ref_all(mats)
@@ -401,6 +404,8 @@ def test_service_operating_point_divergence_from_the_reference(big, synth, refde
     refdec.free_graph(h)
     for name, (dv, self_dv) in out.items():
         assert dv["max_rel_cost_gap"] <= 0.03, (name, dv)                      # every path within 3 % of the reference's cost
-        assert dv["wer"] <= 2.5 * self_dv["wer"] + 0.02, (name, dv, self_dv)
-        assert dv["bit_identical"] >= 0.7 * self_dv["bit_identical"] - 2, (name, dv, self_dv)
+        # bounded by what was measured (round 2: single 0.236 vs 0.169 self, 80 vs 94 identical): the divergence from the reference
+        # stays within 1.5x the reference's own order dependence
+        assert dv["wer"] <= 1.5 * self_dv["wer"] + 0.005, (name, dv, self_dv)
+        assert dv["bit_identical"] >= 0.8 * self_dv["bit_identical"], (name, dv, self_dv)
     assert out["headline"][0]["wer"] <= 0.05, out["headline"]
