@@ -147,6 +147,7 @@ struct wfst_decoder {
   DevBuf<uint2> extra;
   DevBuf<int32_t> remap;
   DevBuf<LatArc> lat_arcs;
+  DevBuf<unsigned long long> lat_stats;
   DevBuf<FrameCtl> fctl;
   DevBuf<unsigned long long> dbg_t;
   DevBuf<int32_t> items;
@@ -241,7 +242,7 @@ struct wfst_decoder {
     det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
+    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); lat_stats.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -923,6 +924,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     lat_tok_cap = L.arena_tokens;
     A(d->lat_arcs.alloc(B * (size_t)lat_arc_cap));
     A(d->lat_toks.alloc(B * (size_t)lat_tok_cap));
+    A(d->lat_stats.alloc(B * 4));
   }
   const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 128 + 2);  // tiles of 128 tokens at least (prep_frame)
   A(d->fctl.alloc(8));
@@ -976,6 +978,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.remap = d->remap.p;
   D.lat_arcs = d->lat_arcs.p;
   D.lat_toks = d->lat_toks.p;
+  D.lat_stats = d->lat_stats.p;
   D.lat_arc_cap = (int32_t)lat_arc_cap;
   D.lat_tok_cap = (int32_t)lat_tok_cap;
   D.link_cap = L.lattice_links;
@@ -1999,6 +2002,21 @@ int wfst_decoder_get_stats(wfst_decoder *d, int32_t channel, int64_t stats[8]) {
   stats[5] = c.peak_tokens;
   stats[6] = (int64_t)c.cnt_rec;
   stats[7] = d->D.lattice ? c.link_count : c.lat_toks;  // lattice mode: forward links recorded; best-path mode: token collections run
+  return WFST_OK;
+}
+
+int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t stats[5]) {
+  if (!d || !stats || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "lattice statistics need a decoder created with wfst_limits.lattice_links > 0");
+  HIP_TRY(hipSetDevice(d->device));
+  unsigned long long v[4];
+  HIP_TRY(hipMemcpyAsync(v, d->lat_stats.p + (size_t)channel * 4, sizeof(v), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  stats[0] = (int64_t)v[0];
+  stats[1] = (int64_t)v[1];
+  stats[2] = (int64_t)v[2];
+  stats[3] = (int64_t)(v[3] & 0xFFFFFFFFull);
+  stats[4] = (int64_t)(v[3] >> 32);
   return WFST_OK;
 }
 

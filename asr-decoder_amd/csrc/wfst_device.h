@@ -230,6 +230,8 @@ struct DecoderDev {
   uint2 *extra;
   int32_t *remap;               // [c][arena_cap] scratch of the back-pruning passes (previous extras, then new indices)
   LatArc *lat_arcs;
+  unsigned long long *lat_stats;  // [c][4] since InitDecoding: {forward links recorded, links priced by the back-pruning walks (one per
+                                  // link and sweep), tokens priced by them, tokens + links scanned by the compactions | moved << 32 ... see wfst_decoder_get_lattice_stats}
   int4 *lat_toks;               // {arena index, graph state id, cost bits, frame | final << 30}
   int64_t link_cap;
   int32_t lat_arc_cap, lat_tok_cap;

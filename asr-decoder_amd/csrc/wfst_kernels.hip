@@ -1833,7 +1833,11 @@ __device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanC
     else {
       D.frame_off[(size_t)c * (D.max_frames + 2) + f + 2] = base + nf;
       D.cutoff_hist[(size_t)c * (D.max_frames + 2) + f + 1] = cutoff;
-      if (kLat) D.link_off[(size_t)c * (D.max_frames + 3) + f + 2] = min(ctl->link_count, (int)D.link_cap);
+      if (kLat) {
+        const int lend = min(ctl->link_count, (int)D.link_cap);
+        D.lat_stats[(size_t)c * 4 + 0] += (u64)max(0, lend - D.link_off[(size_t)c * (D.max_frames + 3) + f + 1]);   // links recorded for this frame
+        D.link_off[(size_t)c * (D.max_frames + 3) + f + 2] = lend;
+      }
     }
     if (sh.best < ctl->best_next) ctl->best_next = sh.best;
     ctl->cnt_Z += z;
@@ -2369,6 +2373,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
   int k_lo = nd;   // oldest frame re-priced by this pass
   bool moved = true;
   int have = -1, hb = 0;   // ps.w.e[hb] holds the final pairs of frame `have`
+  u64 st_links = 0, st_toks = 0;   // links / tokens priced by this walk (wfst_decoder_get_lattice_stats)
   unsigned long long tw = wall_clock64();
   for (int k = nd - 1; k >= 0; --k) {
     if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[(k + 1 < n_prev) ? 41 : 40], now - tw); tw = now; }
@@ -2377,6 +2382,8 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     const bool had_old = k < n_prev;
     if (!kFinal && had_old && !moved) break;
     k_lo = k;
+    st_links += (u64)(lmid[k + 1] - loff[k + 1]) + 2ull * (u64)(loff[k + 1] - lmid[k]);   // (an epsilon link: priced, then confirmed)
+    st_toks += (u64)nk;
     if (nk <= kPrLds) {
       // ---- the frame in LDS ----
       // Placement: the pairs of frame k+1 sit at one end of the buffer (left there by the step before); frame k's go to the
@@ -2604,6 +2611,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
   }
   __syncthreads();
 
+  if (tid == 0) { D.lat_stats[(size_t)c * 4 + 1] += st_links; D.lat_stats[(size_t)c * 4 + 2] += st_toks; }
   if (tid == 0 && (D.dbg & 32)) {
     const unsigned long long now = wall_clock64();
     atomicAdd(&D.dbg_t[51], now - tq); atomicAdd(&D.dbg_t[52], 1ull); atomicAdd(&D.dbg_t[53], (unsigned long long)(nd - k_lo));
@@ -2784,6 +2792,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       __syncthreads();
     }
     if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[47], now - tw); atomicAdd(&D.dbg_t[48], (unsigned long long)(end - range_lo)); atomicAdd(&D.dbg_t[49], (unsigned long long)(l_end - l_lo)); atomicAdd(&D.dbg_t[50], (unsigned long long)((new_end - range_lo) + (lnew - l_lo))); }
+    if (tid == 0) D.lat_stats[(size_t)c * 4 + 3] += (u64)(end - range_lo) + (u64)(l_end - l_lo) + (((u64)(new_end - range_lo) + (u64)(lnew - l_lo)) << 32);
     if (tid == 0) {
       ctl->link_count = lnew;
       ctl->front_begin = foff[nd];
@@ -3073,6 +3082,7 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
   for (int i = tid; i < D.n_part; i += kBT) D.bucket_cnt[(size_t)c * D.n_part + i] = 0;
   __syncthreads();
   if (tid == 0) {
+    if (D.lat_stats) for (int q = 0; q < 4; ++q) D.lat_stats[(size_t)c * 4 + q] = 0;
     ChanCtl z;
     memset(&z, 0, sizeof(z));
     z.best_next = ~0ull;

@@ -31,7 +31,7 @@ SYMBOLS = [
     "wfst_decoder_get_profile", "wfst_decoder_get_profile_busy", "wfst_decoder_get_profile_replay", "wfst_decoder_channel_groups", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
-    "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice",
+    "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats",
 ]
 
 
@@ -307,6 +307,11 @@ class BatchDecoder:
         lat = self.lattice_links > 0
         return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], records=s[6], links=s[7] if lat else 0,
                     collections=0 if lat else s[7])
+
+    def lattice_stats(self, channel):
+        s = (C.c_int64 * 5)()
+        _check(lib().wfst_decoder_get_lattice_stats(self.h, int(channel), s))
+        return dict(links_recorded=s[0], walk_links=s[1], walk_tokens=s[2], compaction_scanned=s[3], compaction_moved=s[4])
 
     def raw_lattice(self, channel, use_final_probs=True):
         """GetRawLattice of a finalized channel (lattice mode).  Returns a dict of numpy arrays, or

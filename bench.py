@@ -668,6 +668,16 @@ def main():
         else:
             kb = {"expand": scale * (20.0 * E + 16.0 * N), "insert": scale * (8.0 * E + 8.0 * N), "closure": 24.0 * Z}
         out["config"]["fused_epsilon_closures"] = bool(fused)
+        if a.lattice_links > 0:
+            # lattice mode adds (DESIGN.md "Roofline accounting"): 16 B per forward link recorded (insert launch); per back-pruning
+            # sweep 16 B link + 8 B {extra, cost} of its destination per link priced and 8 + 8 B per token priced; per compaction 12 B
+            # per item scanned (8 B token pair / 16 B link) and 2 x 16 B per survivor moved -- counted on the device
+            # (wfst_decoder_get_lattice_stats), one step's worth
+            ls = [dec.lattice_stats(c) for c in range(B)]
+            lk = {k: float(sum(x[k] for x in ls)) for k in ls[0]}
+            kb["insert"] += 16.0 * lk["links_recorded"]
+            kb["closure"] += 24.0 * lk["walk_links"] + 16.0 * lk["walk_tokens"] + 12.0 * lk["compaction_scanned"] + 32.0 * lk["compaction_moved"]
+            out["config"]["lattice_work_per_step"] = lk
         if a.biglm and do_cpu and oc["E"] > 0:
             # biglm: + 96 B per word-labelled arc traversed (8 B pair key; per LM 16 B state record, 4 B x ~4 probes of
             # the word-sorted arcs, 8 B arc {weight, next}; 8 B pair-table slot), + 4 B LM pair id per token and record
@@ -685,16 +695,22 @@ def main():
         # it cannot be collected inside this process, so the stored summary is quoted WITH its origin
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        # (the passes were made on the headline workload: any other configuration reports null)
-        headline = (not a.biglm and a.lattice_links == 0 and a.batch == 128 and a.frames == 300 and a.states == 2850000 and
-                    a.beam == 13.0 and a.max_active == 1000000 and a.min_active == 0 and a.workload == "multi")
-        if not headline:
-            traffic_src = "not measured for this configuration (profiles/traffic_latest.json holds the headline workload's passes)"
+        # the passes were made on three configurations: the headline workload, the biglm leg and the beam-15 lattice leg
+        std = a.batch == 128 and a.frames == 300 and a.states == 2850000 and a.workload == "multi" and a.max_active == 1000000 and a.min_active == 0
+        which = None
+        if std and a.biglm and a.beam == 13.0 and a.lattice_links == 0:
+            which = "biglm"
+        elif std and not a.biglm and a.lattice_links > 0 and a.beam == 15.0 and a.lattice_beam == 8.0:
+            which = "lattice_beam15"
+        elif std and not a.biglm and a.lattice_links == 0 and a.beam == 13.0:
+            which = "headline"
+        if which is None:
+            traffic_src = "not measured for this configuration (profiles/traffic_latest.json holds the passes of the headline, biglm and beam-15 lattice configurations)"
         elif os.path.exists(tj):
             try:
                 tjd = json.load(open(tj))
-                traffic = tjd.get(dom + "_bytes_per_launch")
-                traffic_src = "NOT measured in this run: profiles/traffic_latest.json (%s)" % tjd.get("origin", tjd.get("note", "stored rocprofv3 --pmc passes"))
+                traffic = tjd.get(which, {}).get(dom + "_bytes_per_launch")
+                traffic_src = "NOT measured in this run: profiles/traffic_latest.json [%s] (%s); one channel group, i.e. whole-batch launches" % (which, tjd.get("origin", "stored rocprofv3 --pmc passes"))
             except Exception:
                 traffic = None
         step_ms = 1000.0 * dt / a.steps

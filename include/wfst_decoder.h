@@ -366,6 +366,11 @@ int wfst_decoder_get_profile_replay(wfst_decoder *d, double *ms, int64_t *launch
 /* The number of channel groups the decoder runs with (wfst_options.channel_groups, resolved). */
 int wfst_decoder_channel_groups(wfst_decoder *d);
 
+/* Lattice-mode work counters of a channel since its last init, for the byte model of the back-pruning (bench.py): {forward links
+ * recorded, links priced by the PruneActiveTokens / FinalizeDecoding walks (one per link and sweep), tokens priced by them,
+ * tokens + links scanned by the compactions, tokens + links the compactions moved}. */
+int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t stats[5]);
+
 /* Frontier of a channel after the last decoded frame (states and costs, unordered); for tests.
  * Returns the number of tokens (may exceed cap; only cap are written). */
 int wfst_decoder_get_frontier(wfst_decoder *d, int32_t channel, int32_t cap, int32_t *states,

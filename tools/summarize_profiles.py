@@ -1,20 +1,17 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs under gpurun_out/prof/ into the small tracked files under profiles/.
+"""Turn the rocprofv3 outputs under gpurun_out/prof/ (tools/profile_round.sh) into the small tracked files under profiles/.
 
-    python tools/summarize_profiles.py r01        # round tag
+    python tools/summarize_profiles.py r03        # round tag
 
-Inputs (produced on the GPU box, see profiles/README.md for the exact commands):
-  gpurun_out/prof/kt/*/..._kernel_stats.csv            rocprofv3 --kernel-trace --stats
-  gpurun_out/prof/pmc_fetch|pmc_write/*/..._counter_collection.csv   separate --pmc passes
-  gpurun_out/prof/calib/*/..._counter_collection.csv   FETCH_SIZE calibration (tools/ubench_fetch_calib)
-"""
-import collections
-import csv
+Per configuration (headline / biglm / lattice_beam15): <tag>[_<config>]_kernel_stats.csv, <tag>[_<config>]_bench_under_rocprof.json,
+and in <tag>_pmc_summary.json the FETCH_SIZE / WRITE_SIZE sums per kernel.  traffic_latest.json: per configuration and kernel
+CLASS (expand / insert / closure = the three event classes of bench.py) the HBM bytes per launch, (2 x FETCH_SIZE + WRITE_SIZE) x
+1024 (MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 128-B fabric requests at 64 B on gfx950)."""
 import glob
 import json
 import os
-import re
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,71 +19,60 @@ P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
 
 
-def newest(pattern):
-    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
-    return fs[-1:] if fs else []
-
-
-def per_kernel(path):
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(path)):
-        m = re.search(r"(\w+_kernel|calib_\w+)", r["Kernel_Name"])  # "void wfst::insert_kernel<false>(...)" -> insert_kernel
-        k = m.group(1) if m else r["Kernel_Name"].split("(")[0].replace("wfst::", "")
-        agg[k][0] += 1
-        agg[k][1] += float(r["Counter_Value"])
-    return {k: {"launches": n, "kb_per_launch": v / n} for k, (n, v) in agg.items()}
+def klass(k):
+    if k.startswith("expand_kernel"):
+        return "expand"
+    if k.startswith("insert_kernel"):
+        return "insert"
+    if k.startswith("closure_kernel") or k.startswith("lattice_prune_kernel"):
+        return "closure"
+    return None
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     os.makedirs(OUT, exist_ok=True)
-    ks = newest(os.path.join(P, "kt", "*", "*_kernel_stats.csv"))
-    if ks:
-        shutil.copy(ks[0], os.path.join(OUT, "%s_kernel_stats.csv" % tag))
-    k2 = newest(os.path.join(P, "kt_groups2", "*", "*_kernel_stats.csv"))
-    if k2:
-        shutil.copy(k2[0], os.path.join(OUT, "%s_kernel_stats_two_groups_traced.csv" % tag))
-    kl = newest(os.path.join(P, "kt_lattice", "*", "*_kernel_stats.csv"))
-    if kl:
-        shutil.copy(kl[0], os.path.join(OUT, "%s_lattice_mode_kernel_stats.csv" % tag))
-    bj = os.path.join(P, "bench_kt.json")
-    if os.path.exists(bj):
-        shutil.copy(bj, os.path.join(OUT, "%s_bench_under_rocprof.json" % tag))
-    fetch = newest(os.path.join(P, "pmc_fetch", "*", "*_counter_collection.csv"))
-    write = newest(os.path.join(P, "pmc_write", "*", "*_counter_collection.csv"))
-    summary = {"unit": "KB per launch as reported by rocprofv3 (FETCH_SIZE / WRITE_SIZE)", "kernels": {}}
-    calib = newest(os.path.join(P, "calib", "*", "*_counter_collection.csv"))
-    if calib:
-        c = per_kernel(calib[0])
-        summary["fetch_size_calibration"] = {
-            "stream16_1GiB_reported_KB": c.get("calib_stream16", {}).get("kb_per_launch"),
-            "gather16_8388608_requests_reported_KB": c.get("calib_gather16", {}).get("kb_per_launch"),
-            "gather8_8388608_requests_reported_KB": c.get("calib_gather8", {}).get("kb_per_launch"),
-            "reading": "a 16 B/lane coalesced stream is reported at exactly 1/2 of its bytes (the guide's gfx950 "
-                       "correction); a random 8 or 16 B gather is reported as 64 B per request",
-        }
-    traffic = {}
-    if fetch and write:
-        f, w = per_kernel(fetch[0]), per_kernel(write[0])
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        head = "unknown"
+    summary = {"unit": "KB as reported by rocprofv3 (FETCH_SIZE / WRITE_SIZE), summed over the launches of one bench step", "configs": {}}
+    traffic = {"note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch per kernel class: MI355X_MICROARCH.md HBM section (FETCH_SIZE counts "
+                       "128-B fabric requests at 64 B on gfx950); separate --pmc passes (tools/profile_round.sh); round " + tag,
+               "origin": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s, summarised at commit %s" % (tag, head)}
+    for name in ("headline", "biglm", "lattice_beam15"):
+        suffix = "" if name == "headline" else "_" + name
+        ks = sorted(glob.glob(os.path.join(P, "kt_" + name, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+        if ks:
+            shutil.copy(ks[-1], os.path.join(OUT, "%s%s_kernel_stats.csv" % (tag, suffix)))
+        bj = os.path.join(P, "bench_kt_%s.json" % name)
+        if os.path.exists(bj) and os.path.getsize(bj) > 0:
+            shutil.copy(bj, os.path.join(OUT, "%s%s_bench_under_rocprof.json" % (tag, suffix)))
+        fj, wj = os.path.join(P, "fetch_%s.json" % name), os.path.join(P, "write_%s.json" % name)
+        if not (os.path.exists(fj) and os.path.exists(wj)):
+            continue
+        f, w = json.load(open(fj)), json.load(open(wj))
+        per = {}
+        cls = {}
         for k in sorted(set(f) | set(w)):
-            if not k.endswith("_kernel"):
-                continue
-            fk, wk = f.get(k, {}).get("kb_per_launch", 0.0), w.get(k, {}).get("kb_per_launch", 0.0)
-            summary["kernels"][k] = {"launches": f.get(k, {}).get("launches"), "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
-                                     "hbm_bytes_per_launch_raw": (fk + wk) * 1024.0,
-                                     "hbm_bytes_per_launch_corrected": (2.0 * fk + wk) * 1024.0}
-            traffic[k.replace("_kernel", "") + "_bytes_per_launch"] = (2.0 * fk + wk) * 1024.0
-        traffic["note"] = ("(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch: MI355X_MICROARCH.md HBM section (FETCH_SIZE counts "
-                           "128-B fabric requests at 64 B on gfx950); separate --pmc passes; round " + tag)
-        try:
-            import subprocess
-            head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
-        except Exception:
-            head = "unknown"
-        traffic["origin"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s, summarised at commit %s" % (tag, head)
-        json.dump(traffic, open(os.path.join(OUT, "traffic_latest.json"), "w"), indent=1)
+            n = f.get(k, w.get(k))["launches"]
+            fk, wk = f.get(k, {}).get("sum_kb", 0.0), w.get(k, {}).get("sum_kb", 0.0)
+            per[k] = {"launches": n, "FETCH_SIZE_KB_per_launch": fk / n, "WRITE_SIZE_KB_per_launch": wk / n,
+                      "hbm_bytes_per_launch_corrected": (2.0 * fk + wk) * 1024.0 / n}
+            c = klass(k)
+            if c:
+                a = cls.setdefault(c, [0, 0.0])
+                a[0] += n
+                a[1] += (2.0 * fk + wk) * 1024.0
+        summary["configs"][name] = per
+        traffic[name] = {c + "_bytes_per_launch": v / n for c, (n, v) in cls.items()}
+        traffic[name]["launches"] = {c: n for c, (n, v) in cls.items()}
+    k2 = sorted(glob.glob(os.path.join(P, "kt_groups2", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if k2:
+        shutil.copy(k2[-1], os.path.join(OUT, "%s_kernel_stats_two_groups_traced.csv" % tag))
+    json.dump(traffic, open(os.path.join(OUT, "traffic_latest.json"), "w"), indent=1)
     json.dump(summary, open(os.path.join(OUT, "%s_pmc_summary.json" % tag), "w"), indent=1)
-    print(json.dumps(summary, indent=1)[:1500])
+    print(json.dumps(traffic, indent=1))
 
 
 if __name__ == "__main__":
