@@ -2440,7 +2440,13 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
           if (i < nk) E0[i] = make_uint2(kInfO, (uint32_t)cy[u]);
         }
       } else {
-        for (int i = tid; i < nk; i += kBT) E0[i] = make_uint2(kInfO, (uint32_t)tok[fk + i].y);
+        for (int i0 = 0; i0 < nk; i0 += 4 * kBT) {   // four loads in flight per thread
+          int c4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBT + tid; c4[u] = i < nk ? tok[fk + i].y : 0; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBT + tid; if (i < nk) E0[i] = make_uint2(kInfO, (uint32_t)c4[u]); }
+        }
       }
       // (flags: three in rotation, so that a round needs ONE barrier -- flag r % 3 is raised in round r and read after the round's
       // barrier; the next round's flag is cleared during this round, when nobody reads or raises it)
@@ -2542,14 +2548,22 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
           }
         }
       } else {
-        for (int i = tid; i < nk; i += kBT) {
-          const uint2 v = E0[i];
-          if (!kFinal) {
-            const float now = o2f(v.x);
-            const float was = had_old ? o2f(extra[fk + i].x) : 0.0f;
-            ch |= fabsf(now - was) > delta;
+        for (int i0 = 0; i0 < nk; i0 += 4 * kBT) {
+          uint32_t o4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBT + tid; o4[u] = (!kFinal && had_old && i < nk) ? extra[fk + i].x : 0u; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kBT + tid;
+            if (i >= nk) continue;
+            const uint2 v = E0[i];
+            if (!kFinal) {
+              const float now = o2f(v.x);
+              const float was = had_old ? o2f(o4[u]) : 0.0f;
+              ch |= fabsf(now - was) > delta;
+            }
+            extra[fk + i] = v;
           }
-          extra[fk + i] = v;
         }
       }
       if (!kFinal) {
@@ -2653,11 +2667,13 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     // (a chunk's items in wave-coalesced order -- wave w, step u, lane l: item (w * kCU + u) * 64 + l -- and the survivors'
     // ranks from ballots: a lane reads 4 or 16 bytes beside its neighbour's, where a thread owning 8 consecutive items read
     // a line per lane)
-    auto chunk_ranks = [&](const bool (&alive)[kCU], int base, int (&rank)[kCU]) -> int {
-      u64 m[kCU];
+    constexpr int kFU = 16;                   // items per thread of a FLAG sweep (4 bytes each in flight: twice a move sweep's)
+    constexpr int kFlagChunk = kBT * kFU;
+    auto chunk_ranks = [&](const bool (&alive)[kFU], int base, int (&rank)[kFU]) -> int {
+      u64 m[kFU];
       int wc = 0;
 #pragma unroll
-      for (int u = 0; u < kCU; ++u) { m[u] = __ballot(alive[u]); wc += __popcll(m[u]); }
+      for (int u = 0; u < kFU; ++u) { m[u] = __ballot(alive[u]); wc += __popcll(m[u]); }
       __syncthreads();  // ps.wsum free again
       if (lane == 0) ps.wsum[wave] = wc;
       __syncthreads();
@@ -2670,22 +2686,22 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       }
       int run = base + wb;
 #pragma unroll
-      for (int u = 0; u < kCU; ++u) { rank[u] = run + lane_rank(m[u]); run += __popcll(m[u]); }
+      for (int u = 0; u < kFU; ++u) { rank[u] = run + lane_rank(m[u]); run += __popcll(m[u]); }
       return tot;
     };
     int new_end = range_lo;
-    for (int c0 = range_lo; c0 < end; c0 += kPrChunk) {
-      bool alive[kCU];
-      int rank[kCU];
+    for (int c0 = range_lo; c0 < end; c0 += kFlagChunk) {
+      bool alive[kFU];
+      int rank[kFU];
 #pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        const int i = c0 + (wave * kCU + u) * 64 + lane;
+      for (int u = 0; u < kFU; ++u) {
+        const int i = c0 + (wave * kFU + u) * 64 + lane;
         alive[u] = i < end && (i < f0_hi || (uint32_t)ld_agent(&extra[i].x) < kInfO);
       }
       const int tot = chunk_ranks(alive, new_end, rank);
 #pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        const int i = c0 + (wave * kCU + u) * 64 + lane;
+      for (int u = 0; u < kFU; ++u) {
+        const int i = c0 + (wave * kFU + u) * 64 + lane;
         if (i < end) {
           remap[i] = alive[u] ? rank[u] : ~rank[u];
           if (alive[u]) surv[rank[u]] = i;
@@ -2742,18 +2758,18 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     // links, flat: from the emitting links INTO frame k_lo (their destinations moved) to the end of the store
     const int l_lo = loff[k_lo], l_end = loff[nd + 1];
     int lnew = l_lo;
-    for (int c0 = l_lo; c0 < l_end; c0 += kPrChunk) {
-      bool alive[kCU];
-      int rank[kCU];
+    for (int c0 = l_lo; c0 < l_end; c0 += kFlagChunk) {
+      bool alive[kFU];
+      int rank[kFU];
 #pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        const int i = c0 + (wave * kCU + u) * 64 + lane;
+      for (int u = 0; u < kFU; ++u) {
+        const int i = c0 + (wave * kFU + u) * 64 + lane;
         alive[u] = i < l_end && links[i].x >= 0;
       }
       const int tot = chunk_ranks(alive, lnew, rank);
 #pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        const int i = c0 + (wave * kCU + u) * 64 + lane;
+      for (int u = 0; u < kFU; ++u) {
+        const int i = c0 + (wave * kFU + u) * 64 + lane;
         if (i < l_end) {
           lpre[i] = rank[u];
           if (alive[u]) lsurv[rank[u]] = i;
