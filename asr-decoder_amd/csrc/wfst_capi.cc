@@ -108,6 +108,8 @@ struct wfst_lm {
   DevBuf<int4> st;
   DevBuf<int32_t> words;
   DevBuf<int2> wt;
+  DevBuf<int4> hash;
+  uint32_t hmask = 0;
   LmDev view() const {
     LmDev L;
     L.st = st.p;
@@ -119,12 +121,15 @@ struct wfst_lm {
     L.eos = eos;
     L.start = start;
     L.start_arcs = start_arcs;
+    L.hash = hash.p;
+    L.hmask = hmask;
     return L;
   }
   ~wfst_lm() {
     st.release();
     words.release();
     wt.release();
+    hash.release();
   }
 };
 
@@ -724,6 +729,22 @@ int wfst_lm_from_arrays(int32_t bos, int32_t eos, int32_t unk, int32_t n_states,
     v.y = arcs[a].tostateid;
     wt[(size_t)a] = v;
   }
+  // the (state, word) table of every state but the empty history (LmDev::hash)
+  size_t hsize = 1024;
+  while (hsize < 2 * (size_t)std::max(1, n_arcs - states[0].arc_num)) hsize <<= 1;
+  std::vector<int4> htab(hsize, make_int4(-1, -1, 0, 0));
+  {
+    int64_t o = 0;
+    for (int32_t s = 0; s < n_states; ++s) {
+      for (int32_t i = 0; i < states[s].arc_num && s != 0; ++i) {
+        const wfst_lm_arc &a = arcs[o + i];
+        uint32_t slot = lm_hash(s, a.wordid) & (uint32_t)(hsize - 1);
+        while (htab[slot].x >= 0) slot = (slot + 1) & (uint32_t)(hsize - 1);
+        htab[slot] = make_int4(s, a.wordid, wt[(size_t)(o + i)].x, a.tostateid);
+      }
+      o += states[s].arc_num;
+    }
+  }
   HIP_TRY(hipSetDevice(device));
   wfst_lm *lm = new wfst_lm();
   lm->device = device;
@@ -733,13 +754,16 @@ int wfst_lm_from_arrays(int32_t bos, int32_t eos, int32_t unk, int32_t n_states,
   lm->n_states = n_states;
   lm->n_arcs = n_arcs;
   lm->start_arcs = states[0].arc_num;
+  lm->hmask = (uint32_t)(hsize - 1);
   lm->start = arcs[bos].tostateid;  // ComposeArpaLm::Start: the arc of state 0 for <s> (compose-arpalm.cc:5-13)
   hipError_t e;
   if ((e = lm->st.alloc(st.size())) != hipSuccess || (e = lm->words.alloc(words.size())) != hipSuccess ||
       (e = lm->wt.alloc(wt.size())) != hipSuccess ||
       (e = hipMemcpy(lm->st.p, st.data(), st.size() * sizeof(int4), hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemcpy(lm->words.p, words.data(), words.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemcpy(lm->wt.p, wt.data(), wt.size() * sizeof(int2), hipMemcpyHostToDevice)) != hipSuccess) {
+      (e = hipMemcpy(lm->wt.p, wt.data(), wt.size() * sizeof(int2), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = lm->hash.alloc(htab.size())) != hipSuccess ||
+      (e = hipMemcpy(lm->hash.p, htab.data(), htab.size() * sizeof(int4), hipMemcpyHostToDevice)) != hipSuccess) {
     delete lm;
     return fail(WFST_E_DEVICE, std::string("LM upload: ") + hipGetErrorString(e));
   }
@@ -790,7 +814,7 @@ int wfst_lm_info(const wfst_lm *lm, int32_t *bos, int32_t *eos, int32_t *n_state
   if (n_states) *n_states = lm->n_states;
   if (n_arcs) *n_arcs = lm->n_arcs;
   if (n_words) *n_words = lm->start_arcs;
-  if (device_bytes) *device_bytes = (int64_t)(lm->st.bytes() + lm->words.bytes() + lm->wt.bytes());
+  if (device_bytes) *device_bytes = (int64_t)(lm->st.bytes() + lm->words.bytes() + lm->wt.bytes() + lm->hash.bytes());
   return WFST_OK;
 }
 
@@ -1066,7 +1090,9 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // automatic: two groups from 64 channels up -- one group's expansion overlaps the other's insert / closure step
   // (measured on the bench workload: equal at 64 channels, +5 % at 128, +7 % at 256; three or more streams share
   // hardware queues and lose)
-  d->n_groups = std::min(O.channel_groups > 0 ? O.channel_groups : (n_channels >= 64 ? 2 : 1), n_channels);
+  // (biglm decoders: three -- their launches are chains of LM look-ups on small frontiers, a third stream still finds idle
+  // CUs: 36.5 vs 40.7 ms per step at 128 channels; a fourth shares a hardware queue and loses)
+  d->n_groups = std::min(O.channel_groups > 0 ? O.channel_groups : (big && n_channels >= 96) ? 3 : (n_channels >= 64 ? 2 : 1), n_channels);
   if (d->n_groups > 1) {
     d->gstreams.resize(d->n_groups);
     d->gevents.resize(d->n_groups + 1);

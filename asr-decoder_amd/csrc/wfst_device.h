@@ -79,7 +79,18 @@ struct LmDev {
   int32_t bos, eos;
   int32_t start;       // ComposeArpaLm::Start(): the state after <s> (compose-arpalm.cc:5-13)
   int32_t start_arcs;  // arcs of state 0 = word ids it can be asked for
+  // arcs of every state but the empty history as ONE open-addressed table {state, word, weight bits, destination} (empty: state
+  // -1): Fsa::GetArc's binary search over a state's word-sorted arcs (arpa2fsa.h:194-210) is three to five dependent loads,
+  // a probe of this table is one -- and an LM step is a chain of such look-ups (back-off by back-off, LM by LM) that a whole
+  // wavefront waits for.  Same arcs, same answers.
+  const int4 *hash;
+  uint32_t hmask;      // table size - 1 (a power of two, at most half full)
 };
+__host__ __device__ inline uint32_t lm_hash(int32_t state, int32_t word) {
+  uint32_t h = (uint32_t)state * 0x9E3779B1u ^ ((uint32_t)word + 0x7F4A7C15u) * 0x85EBCA77u;
+  h ^= h >> 15;
+  return h * 0x2C1B3C6Du;
+}
 
 constexpr int kEpsBits = 12;
 constexpr int kFlatMax = 4;  // paths of a flattened epsilon closure (3 bits in the header word)

@@ -108,25 +108,20 @@ __device__ __forceinline__ u64 big_key(int32_t row, int32_t pair) { return (u64)
 // (SearchStartArc, arpa2fsa.h:211-214; wfst_decoder_create_biglm checks the graph's labels against
 // its arc count); the others by binary search over their word-id sorted arcs (SearchArc, :194-210).
 __device__ __forceinline__ bool fsa_getarc(const LmDev &L, int id, int word, float *w, int *to) {
-  const int4 st = L.st[id];
-  int a = -1;
-  if (id == 0) {
-    a = st.x + word;
-  } else {
-    int lo = 0, hi = st.y - 1;
-    while (lo <= hi) {
-      const int mid = (lo + hi) >> 1;
-      const int wd = L.words[st.x + mid];
-      if (wd > word) hi = mid - 1;
-      else if (wd < word) lo = mid + 1;
-      else { a = st.x + mid; break; }
-    }
-    if (a < 0) return false;
+  if (id == 0) {   // (state 0's arcs start the arc array: wfst_lm_from_arrays)
+    const int2 x = L.wt[word];
+    *w = __int_as_float(x.x);
+    *to = x.y;
+    return true;
   }
-  const int2 x = L.wt[a];
-  *w = __int_as_float(x.x);
-  *to = x.y;
-  return true;
+  // every other state: one probe of the LM's (state, word) table instead of a binary search over the state's arcs
+  uint32_t slot = lm_hash(id, word) & L.hmask;
+  for (;;) {
+    const int4 e = L.hash[slot];
+    if (e.x == id && e.y == word) { *w = __int_as_float(e.z); *to = e.w; return true; }
+    if (e.x < 0) return false;
+    slot = (slot + 1) & L.hmask;
+  }
 }
 // ComposeArpaLm::GetArc (newlm/compose-arpalm.cc:52-70): back off until the word is found; the cost
 // is minus the sum of the back-off weights and the arc weight, summed in that order.
@@ -194,12 +189,42 @@ __device__ __forceinline__ int pair_find(const DecoderDev &D, int c, int s1, int
 // NextLmState (biglm.h:54-70) for a non-epsilon output label: lm_score = Times(w_old, w_new).Value1();
 // the LM states reached are returned for the caller to intern (or not: the next_cutoff seed and the
 // traceback only need the score).
+// The two LMs are walked in LOCKSTEP: a back-off level of either is one round trip -- the probe of its (state, word) table and,
+// speculatively, the state's back-off record are asked for together, for both LMs at once -- instead of the old LM's whole
+// chain, then the new one's (an LM step sits on the critical path of every round of the expansion and of the closure pass:
+// the wavefront waits for its slowest lane's chain).  Same look-ups, same float sums (ComposeArpaLm::GetArc, lm_getarc).
 __device__ __forceinline__ float lm_step(const DecoderDev &D, int c, int pair, int olabel, int *n1, int *n2) {
   const u64 pk = ld_agent(&D.pair_keys[(size_t)c * D.pair_cap + pair]);
-  float w1, w2;
-  lm_getarc(D.lm_old, (int)(uint32_t)pk, olabel, n1, &w1);
-  lm_getarc(D.lm_new, (int)(uint32_t)(pk >> 32), olabel, n2, &w2);
-  return w1 + w2;
+  int s0 = (int)(uint32_t)pk, s1 = (int)(uint32_t)(pk >> 32);
+  float a0 = 0.0f, a1 = 0.0f;   // sums of the back-off weights so far
+  float r0 = 0.0f, r1 = 0.0f;   // the results: -(back-offs + arc weight)
+  int p0 = 0, p1 = 0;           // linear-probe offsets
+  bool d0 = false, d1 = false;
+  while (!(d0 && d1)) {
+    int4 e0 = make_int4(0, 0, 0, 0), e1 = e0, b0 = e0, b1 = e0;
+    int2 x0 = make_int2(0, 0), x1 = x0;
+    if (!d0) {
+      if (s0 == 0) x0 = D.lm_old.wt[olabel];
+      else { e0 = D.lm_old.hash[(lm_hash(s0, olabel) + (uint32_t)p0) & D.lm_old.hmask]; b0 = D.lm_old.st[s0]; }
+    }
+    if (!d1) {
+      if (s1 == 0) x1 = D.lm_new.wt[olabel];
+      else { e1 = D.lm_new.hash[(lm_hash(s1, olabel) + (uint32_t)p1) & D.lm_new.hmask]; b1 = D.lm_new.st[s1]; }
+    }
+    if (!d0) {
+      if (s0 == 0) { r0 = -1 * (a0 + __int_as_float(x0.x)); *n1 = x0.y; d0 = true; }
+      else if (e0.x == s0 && e0.y == olabel) { r0 = -1 * (a0 + __int_as_float(e0.z)); *n1 = e0.w; d0 = true; }
+      else if (e0.x < 0) { a0 += __int_as_float(b0.z); s0 = b0.w; p0 = 0; }   // no such arc: back off (compose-arpalm.cc:58-64)
+      else ++p0;
+    }
+    if (!d1) {
+      if (s1 == 0) { r1 = -1 * (a1 + __int_as_float(x1.x)); *n2 = x1.y; d1 = true; }
+      else if (e1.x == s1 && e1.y == olabel) { r1 = -1 * (a1 + __int_as_float(e1.z)); *n2 = e1.w; d1 = true; }
+      else if (e1.x < 0) { a1 += __int_as_float(b1.z); s1 = b1.w; p1 = 0; }
+      else ++p1;
+    }
+  }
+  return r0 + r1;
 }
 
 // debug phase timers (WFST_DBG & 32): slot k accumulates {sum, max, count} of 100 MHz ticks
