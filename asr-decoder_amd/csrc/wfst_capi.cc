@@ -877,7 +877,9 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     if (L.lm_pairs > (1ll << 28)) return fail(WFST_E_ARG, "lm_pairs too large");
   }
   if (L.max_frames <= 0) L.max_frames = 4096;
-  if (L.max_tokens_per_frame <= 0) L.max_tokens_per_frame = 32768;
+  // (default: 32768, or four times a finite max_active -- that many tokens are expanded per frame, their arrivals are more -- up to 262144)
+  if (L.max_tokens_per_frame <= 0)
+    L.max_tokens_per_frame = cfg->max_active < (1 << 28) ? (int32_t)std::min<int64_t>(262144, std::max<int64_t>(32768, 4ll * cfg->max_active)) : 32768;
   if (L.arena_tokens <= 0)  // room for max_frames frames at 1/32 of the per-frame token limit (include/wfst_decoder.h)
     L.arena_tokens = std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(4194304, (int64_t)L.max_frames * std::max<int64_t>(256, L.max_tokens_per_frame / 32)));
   if (L.arena_tokens > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "arena_tokens must fit int32");
@@ -2044,6 +2046,14 @@ int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t sta
   stats[3] = (int64_t)(v[3] & 0xFFFFFFFFull);
   stats[4] = (int64_t)(v[3] >> 32);
   return WFST_OK;
+}
+
+int wfst_decoder_get_degraded_frames(wfst_decoder *d, int32_t channel) {
+  if (!d || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(d->device));
+  int rc = read_ctl(d);
+  if (rc != WFST_OK) return rc;
+  return d->p_ctl[channel].degraded;
 }
 
 int wfst_decoder_get_frontier(wfst_decoder *d, int32_t channel, int32_t cap, int32_t *states, float *costs) {
