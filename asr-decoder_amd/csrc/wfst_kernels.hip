@@ -778,10 +778,10 @@ __global__ __launch_bounds__(kExpandThreads, 6) void expand_replay_fused(Decoder
 // Arithmetic, pruning and record layout are expand_body<false, true>'s, to the bit.
 // =========================================================================================
 constexpr int kStThreads = 256;
-constexpr int kStTokens = 256;
-constexpr int kLog2StTokens = 8;
+constexpr int kStTokens = 256;   // (tiles of 128 / 192 / 320 / 384 tokens measured slower by 10-25 %, 512 the same)
+constexpr int kLog2StTokens = kStTokens <= 256 ? 8 : kStTokens <= 512 ? 9 : 10;   // steps of the owner search
 constexpr int kStSlots = 1536;   // (1280 / 1024 with five / six workgroups per CU measured slower: more tiles need a second pass)
-constexpr int kStIter = kStSlots / kStThreads;   // slots per thread and pass
+constexpr int kStIter = (kStSlots + kStThreads - 1) / kStThreads;   // slots per thread and pass
 typedef __attribute__((address_space(3))) void *lds_void_p;
 typedef const __attribute__((address_space(1))) void *gbl_void_p;
 
@@ -2078,6 +2078,7 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
     int tile_tokens = D.staged ? kStTokens : kTileTokens;
     if ((int64_t)n * (int)gridDim.x <= 700ll * 256) tile_tokens = 256;
     if ((int64_t)n * (int)gridDim.x <= 700ll * 128) tile_tokens = 128;
+    if (D.staged) tile_tokens = min(tile_tokens, kStTokens);
     sh.tile_tokens = tile_tokens;
     const int ntiles = (n + tile_tokens - 1) / tile_tokens;
     sh.active = 0;
@@ -2203,6 +2204,7 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
     int tile_tokens = D.staged ? kStTokens : kTileTokens;   // (as prep_frame)
     if ((int64_t)n * chan_cnt <= 700ll * 256) tile_tokens = 256;
     if ((int64_t)n * chan_cnt <= 700ll * 128) tile_tokens = 128;
+    if (D.staged) tile_tokens = min(tile_tokens, kStTokens);
     const int ntiles = (n + tile_tokens - 1) / tile_tokens;
     const int nseed = (D.seed_tiles && ntiles > 0) ? 1 : 0;   // the seed tile, listed first
     sh.tile_tokens = tile_tokens;
