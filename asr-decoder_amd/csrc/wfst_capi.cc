@@ -2048,14 +2048,6 @@ int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t sta
   return WFST_OK;
 }
 
-int wfst_decoder_get_degraded_frames(wfst_decoder *d, int32_t channel) {
-  if (!d || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
-  HIP_TRY(hipSetDevice(d->device));
-  int rc = read_ctl(d);
-  if (rc != WFST_OK) return rc;
-  return d->p_ctl[channel].degraded;
-}
-
 int wfst_decoder_get_frontier(wfst_decoder *d, int32_t channel, int32_t cap, int32_t *states, float *costs) {
   if (!d || channel < 0 || channel >= d->n_channels || cap < 0) return fail(WFST_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(d->device));

@@ -151,7 +151,7 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t error;         // sticky kErr* bits
   int32_t finalized;
   int32_t peak_tokens;
-  int32_t degraded;      // frames whose arrivals were cut down to max_tokens_per_frame (insert_body: degrade instead of refuse)
+  int32_t spare0;        // (unused)
   unsigned long long cnt_N, cnt_E, cnt_Z, cnt_tok, cnt_rec;  // work counters since init
   int32_t link_count;    // lattice mode: forward links recorded so far (atomicAdd)
   int32_t lat_arcs;      // lattice mode, after lattice_prune_kernel: surviving links in lat_arcs[]

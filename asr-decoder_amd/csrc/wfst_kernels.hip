@@ -1113,57 +1113,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   const int log2grp = D.log2part - log2g;  // hash bits that select this group of partitions
   const int4 *bucket0 = D.bucket + ((size_t)c * P + g0) * D.bucket_cap;
   const int32_t *bucket_lm0 = kBig ? D.bucket_lm + ((size_t)c * P + g0) * D.bucket_cap : nullptr;
-  float cutoff = o2f(ctl->bound);  // FINAL next_cutoff of this frame
-  // DEGRADE INSTEAD OF REFUSE: a frame whose arrivals (records of ALL the channel's buckets) outnumber max_tokens_per_frame could
-  // make more tokens than the per-frame structures take.  The reference has no such limit; what it has for this is max_active
-  // (base-inl.h:188-203): keep the best.  So the frame's cutoff is tightened to the max_tokens_per_frame-th smallest arrival
-  // cost -- an exact radix select over the channel's records, computed identically by every workgroup that holds an item of
-  // the channel (same records, same answer: deterministic) -- and the frame is counted (ChanCtl::degraded).  Never on a
-  // frame that fits.
-  {
-    const int32_t *call = D.bucket_cnt + (size_t)c * P;
-    int rc = (lane < P) ? min(call[lane], D.bucket_cap) : 0;
-    rc = (int)wave_sum_u64((u64)rc);
-    if (rc > D.max_tok) {
-      uint32_t *hist = reinterpret_cast<uint32_t *>(smem);          // 256 bins + {prefix, k}: the table's space, not in use yet
-      uint32_t prefix = 0, kk = (uint32_t)D.max_tok;
-      const int4 *ball = D.bucket + (size_t)c * P * D.bucket_cap;
-      for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        __syncthreads();
-        for (int b = tid; b < 256; b += kInsertThreads) hist[b] = 0;
-        __syncthreads();
-        for (int p = 0; p < P; ++p) {
-          const int cp = min(call[p], D.bucket_cap);
-          for (int i = tid; i < cp; i += kInsertThreads) {
-            const uint32_t o = f2o(__int_as_float(ball[(size_t)p * D.bucket_cap + i].y));
-            if ((o & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(o >> shift) & 255u], 1u);
-          }
-        }
-        __syncthreads();
-        // (every thread walks the 256 bins itself: a rare path, and no broadcast to get wrong)
-        uint32_t cum = 0;
-        int b = 0;
-        for (; b < 255; ++b) {
-          const uint32_t h = hist[b];
-          if (kk < cum + h) break;
-          cum += h;
-        }
-        prefix |= (uint32_t)b << shift;
-        kk -= cum;
-      }
-      __syncthreads();
-      const float kth = o2f(prefix);   // the arrival of rank max_tokens_per_frame (0-based): fewer than that many cost less
-      if (kth < cutoff) {
-        cutoff = kth;
-        if (tid == 0) {
-          atomicMin(&ctl->bound, f2o(kth));              // (the frame boundary records it; the other items compute the same)
-          if (g0 == 0) atomicAdd(&ctl->degraded, 1);     // once per frame: by the item that holds partition 0
-        }
-      }
-    }
-  }
+  const float cutoff = o2f(ctl->bound);  // FINAL next_cutoff of this frame
   // table sized to the load: the smallest power of two >= 4 n (records >= distinct states)
   int log2sl = 6;
   while ((1 << log2sl) < 4 * n && log2sl < D.log2lds) ++log2sl;

@@ -31,7 +31,7 @@ SYMBOLS = [
     "wfst_decoder_get_profile", "wfst_decoder_get_profile_busy", "wfst_decoder_get_profile_replay", "wfst_decoder_channel_groups", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
-    "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_degraded_frames",
+    "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats",
 ]
 
 
@@ -307,12 +307,6 @@ class BatchDecoder:
         lat = self.lattice_links > 0
         return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], records=s[6], links=s[7] if lat else 0,
                     collections=0 if lat else s[7])
-
-    def degraded_frames(self, channel):
-        n = int(lib().wfst_decoder_get_degraded_frames(self.h, int(channel)))
-        if n < 0:
-            _check(n)
-        return n
 
     def lattice_stats(self, channel):
         s = (C.c_int64 * 5)()

@@ -61,10 +61,8 @@ typedef struct wfst_config {
   float prune_scale;
 } wfst_config;
 
-/* Per-channel device capacities (0 = default).  Exceeding an ARENA (arena_tokens, lattice_links, lm_pairs, max_frames) makes the
- * affected call return WFST_E_CAPACITY; nothing is silently dropped.  max_tokens_per_frame DEGRADES instead: a frame with more
- * arrivals than that keeps the best max_tokens_per_frame of them (as max_active would) and is counted
- * (wfst_decoder_get_degraded_frames); only a frame with more than 8x that many arrivals overflows its buckets and is refused. */
+/* Per-channel device capacities (0 = default).  Exceeding one makes the affected call return
+ * WFST_E_CAPACITY; nothing is silently dropped. */
 typedef struct wfst_limits {
   int32_t max_frames;           /* frames per utterance                     (default 4096)    */
   int32_t max_tokens_per_frame; /* distinct states reached in one frame     (default 32768, or 4 x a finite max_active, at most 262144) */
@@ -372,11 +370,6 @@ int wfst_decoder_channel_groups(wfst_decoder *d);
  * recorded, links priced by the PruneActiveTokens / FinalizeDecoding walks (one per link and sweep), tokens priced by them,
  * tokens + links scanned by the compactions, tokens + links the compactions moved}. */
 int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t stats[5]);
-
-/* Frames of the channel (since its last init) whose arrivals outnumbered wfst_limits.max_tokens_per_frame and were cut down to the
- * best max_tokens_per_frame of them -- what max_active does in the reference (base-inl.h:188-203), applied where the reference,
- * which has no such structure limit, would simply have grown.  0 = the decode is the reference's.  Negative: an error code. */
-int wfst_decoder_get_degraded_frames(wfst_decoder *d, int32_t channel);
 
 /* Frontier of a channel after the last decoded frame (states and costs, unordered); for tests.
  * Returns the number of tokens (may exceed cap; only cap are written). */
