@@ -780,7 +780,7 @@ __global__ __launch_bounds__(kExpandThreads, 6) void expand_replay_fused(Decoder
 constexpr int kStThreads = 256;
 constexpr int kStTokens = 256;   // (tiles of 128 / 192 / 320 / 384 tokens measured slower by 10-25 %, 512 the same)
 constexpr int kLog2StTokens = kStTokens <= 256 ? 8 : kStTokens <= 512 ? 9 : 10;   // steps of the owner search
-constexpr int kStSlots = 1536;   // (1280 / 1024 with five / six workgroups per CU measured slower: more tiles need a second pass)
+constexpr int kStSlots = 1536;   // (1392 slots at five workgroups per CU -- every tile of a half-batch launch resident at once -- measured 11 % slower: 96 VGPRs spill)   // (1280 / 1024 with five / six workgroups per CU measured slower: more tiles need a second pass)
 constexpr int kStIter = (kStSlots + kStThreads - 1) / kStThreads;   // slots per thread and pass
 typedef __attribute__((address_space(3))) void *lds_void_p;
 typedef const __attribute__((address_space(1))) void *gbl_void_p;
