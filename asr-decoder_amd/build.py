@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, "csrc", "wfst_kernels.hip"), os.path.join(HERE, "csrc", "wfst_nbest.hip"),
-        os.path.join(HERE, "csrc", "wfst_determinize.hip"),
+        os.path.join(HERE, "csrc", "wfst_determinize.hip"), os.path.join(HERE, "csrc", "wfst_compose.hip"),
         os.path.join(HERE, "csrc", "wfst_capi.cc"),
         os.path.join(HERE, "csrc", "wfst_openfst.cc")]
 HDRS = [os.path.join(HERE, "csrc", "wfst_device.h"), os.path.join(HERE, "csrc", "wfst_determinize.h"), os.path.join(HERE, "csrc", "wfst_openfst.h"),

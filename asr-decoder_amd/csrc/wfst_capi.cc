@@ -181,6 +181,11 @@ struct wfst_decoder {
   DevBuf<int4> det_out_a;
   DevBuf<float2> det_out_w;
   DetDev det = {};
+  // second-pass LM composition (wfst_decoder_get_rescored_lattice): workspace allocated by the first call
+  DevBuf<int32_t> cmp_ws, cmp_result, cmp_fin;
+  DevBuf<int4> cmp_out_a;
+  DevBuf<float2> cmp_out_w;
+  CmpDev cmp = {};
   struct DetLattice { int32_t n_states = 0, n_proper = 0, err = 0; std::vector<int4> a; std::vector<float2> w; };
   std::vector<DetLattice> det_cache;
   std::vector<char> det_cached;
@@ -245,6 +250,7 @@ struct wfst_decoder {
     if (p_ctl) (void)hipHostFree(p_ctl);
     pair_keys.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
     det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
+    cmp_ws.release(); cmp_result.release(); cmp_fin.release(); cmp_out_a.release(); cmp_out_w.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
     bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); lat_stats.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
@@ -2012,6 +2018,84 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
     if (a_olabel) a_olabel[k] = L.a[k].z;
     if (a_graph) a_graph[k] = L.w[k].x;
     if (a_acoustic) a_acoustic[k] = L.w[k].y;
+  }
+  return WFST_OK;
+}
+
+int wfst_decoder_get_rescored_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, const wfst_lm *old_lm, const wfst_lm *new_lm,
+                                      int32_t cap_states, int32_t cap_arcs, int32_t *n_states, int32_t *n_arcs, int32_t *st_final,
+                                      int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel, int32_t *a_olabel, float *a_graph, float *a_acoustic) {
+  if (!d || channel < 0 || channel >= d->n_channels || !n_states || !n_arcs || !old_lm || !new_lm) return fail(WFST_E_ARG, "bad argument");
+  if (old_lm->device != d->device || new_lm->device != d->device) return fail(WFST_E_ARG, "the LMs must be on the decoder's device");
+  // GetLattice of the service under --use-second: the determinized lattice first (its device copy stays in workspace slot 0 when this
+  // channel is determinized alone) ...
+  int32_t ns = 0, na = 0;
+  *n_states = 0;
+  *n_arcs = 0;
+  if (d->h_state[channel] == 0) return fail(WFST_E_STATE, "GetLattice before InitDecoding");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice needs a decoder created with wfst_limits.lattice_links > 0");
+  // force a determinization of THIS channel into slot 0 (a cached host copy of an earlier batch determinization does not hold
+  // the device copy any more)
+  if (!d->det_cached.empty()) { d->det_cached[channel] = 0; d->det_live_nd[channel] = -1; }
+  {
+    // determinize only this channel: temporarily hide the other finalized channels from the batch sweep
+    std::vector<char> saved(d->det_cached);
+    if (!saved.empty())
+      for (int c = 0; c < d->n_channels; ++c)
+        if (c != channel) d->det_cached[c] = 1;
+    int rc = wfst_decoder_get_determinized_lattice(d, channel, use_final_probs, 0, 0, &ns, &na, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (!saved.empty())
+      for (int c = 0; c < d->n_channels; ++c)
+        if (c != channel) d->det_cached[c] = saved[c];
+    if (rc != WFST_OK && !(rc == WFST_E_CAPACITY && ns > 0)) return rc;
+  }
+  if (ns == 0) return WFST_OK;   // no lattice (as wfst_decoder_get_raw_lattice)
+  HIP_TRY(hipSetDevice(d->device));
+  CmpDev &Y = d->cmp;
+  if (!d->cmp_ws.p) {
+    Y.pair_cap = 65536;
+    Y.arc_cap = 262144;
+    Y.ws_ints = 11ll * Y.arc_cap + 13ll * Y.pair_cap + 64;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(d->cmp_ws.alloc((size_t)Y.ws_ints));
+    HIP_TRY(d->cmp_result.alloc(4));
+    HIP_TRY(d->cmp_fin.alloc((size_t)Y.pair_cap));
+    HIP_TRY(d->cmp_out_a.alloc((size_t)Y.arc_cap));
+    HIP_TRY(d->cmp_out_w.alloc((size_t)Y.arc_cap));
+    Y.ws = d->cmp_ws.p;
+    Y.result = d->cmp_result.p;
+    Y.out_fin = d->cmp_fin.p;
+    Y.out_a = d->cmp_out_a.p;
+    Y.out_w = d->cmp_out_w.p;
+  }
+  // ... then ComposeLattice with the old LM and with the new one, on the device
+  launch_compose2(d->det, Y, old_lm->view(), new_lm->view(), d->stream);
+  HIP_TRY(hipGetLastError());
+  int32_t res[4];
+  HIP_TRY(hipMemcpyAsync(res, Y.result, sizeof(res), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  if (res[2] != 0) return fail(WFST_E_CAPACITY, "the composed lattice outgrew the composition workspace (" + std::to_string(Y.pair_cap) + " states / " + std::to_string(Y.arc_cap) + " arcs)");
+  *n_states = res[0];
+  *n_arcs = res[1];
+  if (res[0] > cap_states || res[1] > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");
+  std::vector<int4> oa((size_t)res[1]);
+  std::vector<float2> ow((size_t)res[1]);
+  std::vector<int32_t> fin((size_t)res[0]);
+  if (res[1]) {
+    HIP_TRY(hipMemcpyAsync(oa.data(), Y.out_a, oa.size() * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(ow.data(), Y.out_w, ow.size() * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
+  }
+  if (res[0]) HIP_TRY(hipMemcpyAsync(fin.data(), Y.out_fin, fin.size() * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  for (int32_t s = 0; s < res[0]; ++s)
+    if (st_final) st_final[s] = fin[(size_t)s];
+  for (int32_t k = 0; k < res[1]; ++k) {
+    if (a_src) a_src[k] = oa[(size_t)k].x;
+    if (a_dst) a_dst[k] = oa[(size_t)k].y;
+    if (a_ilabel) a_ilabel[k] = 0;
+    if (a_olabel) a_olabel[k] = oa[(size_t)k].z;
+    if (a_graph) a_graph[k] = ow[(size_t)k].x;
+    if (a_acoustic) a_acoustic[k] = ow[(size_t)k].y;
   }
   return WFST_OK;
 }

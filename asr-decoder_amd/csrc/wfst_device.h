@@ -92,6 +92,51 @@ __host__ __device__ inline uint32_t lm_hash(int32_t state, int32_t word) {
   return h * 0x2C1B3C6Du;
 }
 
+#if defined(__HIPCC__)
+// Fsa::GetArc (newlm/arpa2fsa.cc:244-262): the arc of LM state `id` for `word`, false if the state
+// has none (the caller backs off).  State 0 (empty history) is indexed by word id directly
+// (SearchStartArc, arpa2fsa.h:211-214; wfst_decoder_create_biglm checks the graph's labels against
+// its arc count); the others by binary search over their word-id sorted arcs (SearchArc, :194-210).
+__device__ __forceinline__ bool fsa_getarc(const LmDev &L, int id, int word, float *w, int *to) {
+  if (id == 0) {   // (state 0's arcs start the arc array: wfst_lm_from_arrays)
+    const int2 x = L.wt[word];
+    *w = __int_as_float(x.x);
+    *to = x.y;
+    return true;
+  }
+  // every other state: one probe of the LM's (state, word) table instead of a binary search over the state's arcs
+  uint32_t slot = lm_hash(id, word) & L.hmask;
+  for (;;) {
+    const int4 e = L.hash[slot];
+    if (e.x == id && e.y == word) { *w = __int_as_float(e.z); *to = e.w; return true; }
+    if (e.x < 0) return false;
+    slot = (slot + 1) & L.hmask;
+  }
+}
+// ComposeArpaLm::GetArc (newlm/compose-arpalm.cc:52-70): back off until the word is found; the cost
+// is minus the sum of the back-off weights and the arc weight, summed in that order.
+__device__ __forceinline__ void lm_getarc(const LmDev &L, int s, int word, int *next, float *value1) {
+  float weight = 0.0f, w_arc = 0.0f;
+  int to = 0;
+  while (!fsa_getarc(L, s, word, &w_arc, &to)) {
+    const int4 st = L.st[s];
+    w_arc = __int_as_float(st.z);
+    s = st.w;
+    weight += w_arc;
+  }
+  weight += w_arc;
+  *value1 = -1 * weight;
+  *next = to;
+}
+// ComposeArpaLm::Final (compose-arpalm.cc:15-29)
+__device__ __forceinline__ float lm_final_cost(const LmDev &L, int s) {
+  int next;
+  float v;
+  lm_getarc(L, s, L.eos, &next, &v);
+  return v;
+}
+#endif
+
 constexpr int kEpsBits = 12;
 constexpr int kFlatMax = 4;  // paths of a flattened epsilon closure (3 bits in the header word)
 constexpr uint32_t kEpsMask = (1u << kEpsBits) - 1;
@@ -343,6 +388,22 @@ struct DetDev {
   int32_t out_cap;
 };
 void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chan_list_dev, int cnt, hipStream_t s);
+
+// ---- second-pass LM composition on determinized lattices (wfst_compose.hip) ------------------------------------
+// ComposeLattice (newfst/compose-lat-inl.h:15-130) of the determinized lattice of workspace slot 0 (DetDev::out_a / out_w, as
+// determinize_kernel left it) with ComposeArpaLm(lm1), then of the result with ComposeArpaLm(lm2) -- what the service's GetLattice
+// does under --use-second (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:53-78) -- each followed by Connect.
+struct CmpDev {
+  int32_t *ws;            // workspace (ints): see wfst_compose.hip
+  int64_t ws_ints;
+  int32_t pair_cap;       // composed states per pass (hash slots = 2 x)
+  int32_t arc_cap;        // arcs per pass
+  int32_t *result;        // {states, arcs, status (0 ok, 1 capacity), -}
+  int4 *out_a;            // [arc_cap] {src, dst, olabel, final flag of dst}
+  float2 *out_w;          // [arc_cap] {graph, acoustic}
+  int32_t *out_fin;       // [pair_cap] final flag per state
+};
+void launch_compose2(const DetDev &X, const CmpDev &Y, const LmDev &lm1, const LmDev &lm2, hipStream_t s);
 
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);

@@ -103,48 +103,7 @@ __device__ __forceinline__ uint32_t hash_big(int32_t row, int32_t pair) {
 }
 __device__ __forceinline__ u64 big_key(int32_t row, int32_t pair) { return (u64)(uint32_t)row | ((u64)(uint32_t)pair << 32); }
 
-// Fsa::GetArc (newlm/arpa2fsa.cc:244-262): the arc of LM state `id` for `word`, false if the state
-// has none (the caller backs off).  State 0 (empty history) is indexed by word id directly
-// (SearchStartArc, arpa2fsa.h:211-214; wfst_decoder_create_biglm checks the graph's labels against
-// its arc count); the others by binary search over their word-id sorted arcs (SearchArc, :194-210).
-__device__ __forceinline__ bool fsa_getarc(const LmDev &L, int id, int word, float *w, int *to) {
-  if (id == 0) {   // (state 0's arcs start the arc array: wfst_lm_from_arrays)
-    const int2 x = L.wt[word];
-    *w = __int_as_float(x.x);
-    *to = x.y;
-    return true;
-  }
-  // every other state: one probe of the LM's (state, word) table instead of a binary search over the state's arcs
-  uint32_t slot = lm_hash(id, word) & L.hmask;
-  for (;;) {
-    const int4 e = L.hash[slot];
-    if (e.x == id && e.y == word) { *w = __int_as_float(e.z); *to = e.w; return true; }
-    if (e.x < 0) return false;
-    slot = (slot + 1) & L.hmask;
-  }
-}
-// ComposeArpaLm::GetArc (newlm/compose-arpalm.cc:52-70): back off until the word is found; the cost
-// is minus the sum of the back-off weights and the arc weight, summed in that order.
-__device__ __forceinline__ void lm_getarc(const LmDev &L, int s, int word, int *next, float *value1) {
-  float weight = 0.0f, w_arc = 0.0f;
-  int to = 0;
-  while (!fsa_getarc(L, s, word, &w_arc, &to)) {
-    const int4 st = L.st[s];
-    w_arc = __int_as_float(st.z);
-    s = st.w;
-    weight += w_arc;
-  }
-  weight += w_arc;
-  *value1 = -1 * weight;
-  *next = to;
-}
-// ComposeArpaLm::Final (compose-arpalm.cc:15-29)
-__device__ __forceinline__ float lm_final_cost(const LmDev &L, int s) {
-  int next;
-  float v;
-  lm_getarc(L, s, L.eos, &next, &v);
-  return v;
-}
+// (Fsa::GetArc / ComposeArpaLm::GetArc / ComposeArpaLm::Final on the device: fsa_getarc, lm_getarc, lm_final_cost in wfst_device.h)
 __device__ __forceinline__ uint32_t hash_pair(int s1, int s2) {
   uint32_t h = (uint32_t)s1 * 7853u + (uint32_t)s2;  // PairHasher, util/stl-util.h:8-17 ...
   h *= 2654435761u;                                  // ... scrambled for an open-addressed table

@@ -377,6 +377,31 @@ static bool DetLatticeOfChannel(wfst_decoder *dec, int channel, Lattice *ofst, b
   return true;
 }
 
+// GetLattice under --use-second (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:53-78): determinized lattice o old LM (scale -1) o new LM,
+// ComposeLattice twice on the device.
+static bool RescoredLatticeOfChannel(wfst_decoder *dec, int channel, Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs) {
+  ofst->DeleteStates();
+  if (!oldlm || !newlm) throw std::runtime_error("second-pass GetLattice needs both LMs");
+  int32_t ns = 0, na = 0;
+  int rc = wfst_decoder_get_rescored_lattice(dec, channel, use_final_probs ? 1 : 0, oldlm->Handle(), newlm->Handle(), 0, 0, &ns, &na, nullptr,
+                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc == WFST_E_STATE) { Warn(wfst_last_error()); return false; }
+  if (rc != WFST_OK && !(rc == WFST_E_CAPACITY && ns > 0)) Fatal("GetLattice (second pass)");
+  if (ns == 0) return false;
+  std::vector<int32_t> fin(ns), src(na), dst(na), il(na), ol(na);
+  std::vector<float> g(na), ac(na);
+  if (wfst_decoder_get_rescored_lattice(dec, channel, use_final_probs ? 1 : 0, oldlm->Handle(), newlm->Handle(), ns, na, &ns, &na, fin.data(),
+                                        src.data(), dst.data(), il.data(), ol.data(), g.data(), ac.data()) != WFST_OK)
+    Fatal("GetLattice (second pass)");
+  for (int s = 0; s < ns; ++s) {
+    StateId id = ofst->AddState();
+    if (fin[s]) ofst->SetFinal(id);
+  }
+  ofst->SetStart(0);
+  for (int k = 0; k < na; ++k) ofst->AddArc(src[k], LatticeArc(il[k], ol[k], dst[k], LatticeWeight(g[k], ac[k])));
+  return true;
+}
+
 static bool NbestOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> &out, int n) {
   out.clear();
   if (n <= 0) return false;
@@ -409,6 +434,9 @@ static bool NbestOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> 
 bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n) { return NbestOfChannel(_dec, 0, nbest_paths, n); }
 
 bool GpuLatticeDecoder::GetLattice(Lattice *ofst, bool use_final_probs) { return DetLatticeOfChannel(_dec, 0, ofst, use_final_probs); }
+bool GpuLatticeDecoder::GetLattice(Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs) {
+  return RescoredLatticeOfChannel(_dec, 0, ofst, oldlm, newlm, use_final_probs);
+}
 
 bool GpuLatticeDecoder::GetRawLattice(Lattice *ofst, bool use_final_probs) {
   return RawLatticeOfChannel(_dec, 0, ofst, use_final_probs);
@@ -450,6 +478,9 @@ bool GpuBatchDecoder::GetNbest(int channel, std::vector<Lattice> &nbest_paths, i
 }
 bool GpuBatchDecoder::GetLattice(int channel, Lattice *ofst, bool use_final_probs) {
   return DetLatticeOfChannel(_dec, channel, ofst, use_final_probs);
+}
+bool GpuBatchDecoder::GetLattice(int channel, Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs) {
+  return RescoredLatticeOfChannel(_dec, channel, ofst, oldlm, newlm, use_final_probs);
 }
 bool GpuBatchDecoder::GetRawLattice(int channel, Lattice *ofst, bool use_final_probs) {
   return RawLatticeOfChannel(_dec, channel, ofst, use_final_probs);

@@ -235,6 +235,9 @@ class GpuLatticeDecoder : public DecoderItf {
   // GetLattice (online-decoder-base.h:182, base-inl.h:850-866): GetRawLattice + DeterminizeLatticeWrapper, both on
   // the device; arcs carry ilabel 0 / olabel = word, final states have no arcs (the reference's output convention)
   bool GetLattice(Lattice *ofst, bool use_final_probs = true);
+  // the same with the service's second LM pass (--use-second, kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:53-78): the determinized
+  // lattice composed with the old LM (rescaled by -1) and with the new one -- ComposeLattice twice (newfst/compose-lat-inl.h), on the device
+  bool GetLattice(Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs = true);
   // OnlineClgLatticeFastDecoder::GetNbest (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105):
   // the n (<= 16) cheapest distinct word sequences of the pruned lattice, each as a linear Lattice
   // whose arcs carry the words as olabels (ilabel 0, like the reference's determinized output) and
@@ -274,6 +277,7 @@ class GpuBatchDecoder {
   bool GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n);
   // GetLattice of one channel; the first call after FinalizeDecoding determinizes every finalized channel in one launch
   bool GetLattice(int channel, Lattice *ofst, bool use_final_probs = true);
+  bool GetLattice(int channel, Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs = true);   // with the second LM pass
   void GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
                     bool use_final_probs = true);
   wfst_decoder *Handle() { return _dec; }

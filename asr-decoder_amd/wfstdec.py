@@ -31,7 +31,7 @@ SYMBOLS = [
     "wfst_decoder_get_profile", "wfst_decoder_get_profile_busy", "wfst_decoder_get_profile_replay", "wfst_decoder_channel_groups", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
-    "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats",
+    "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice",
 ]
 
 
@@ -350,6 +350,24 @@ class BatchDecoder:
         _check(lib().wfst_decoder_get_determinized_lattice(self.h, int(channel), int(bool(use_final_probs)), S, A, C.byref(ns),
                                                            C.byref(na), _i32(fin), _i32(src), _i32(dst), _i32(il), _i32(ol),
                                                            _f32(gr), _f32(ac)))
+        return dict(n_states=S, st_final=fin, a_src=src, a_dst=dst, a_ilabel=il, a_olabel=ol, a_graph=gr, a_acoustic=ac)
+
+    def rescored_lattice(self, channel, old_lm, new_lm, use_final_probs=True):
+        """GetLattice under --use-second: determinized lattice o old LM (scale -1) o new LM, composed on the device."""
+        ns, na = C.c_int32(0), C.c_int32(0)
+        rc = lib().wfst_decoder_get_rescored_lattice(self.h, int(channel), int(bool(use_final_probs)), old_lm.h, new_lm.h, 0, 0,
+                                                     C.byref(ns), C.byref(na), *([None] * 7))
+        if rc != WFST_OK and not (rc == -4 and ns.value > 0):
+            _check(rc)
+        if ns.value == 0:
+            return None
+        S, A = ns.value, na.value
+        fin = np.zeros(S, np.int32)
+        src, dst, il, ol = (np.zeros(A, np.int32) for _ in range(4))
+        gr, ac = np.zeros(A, np.float32), np.zeros(A, np.float32)
+        _check(lib().wfst_decoder_get_rescored_lattice(self.h, int(channel), int(bool(use_final_probs)), old_lm.h, new_lm.h, S, A,
+                                                       C.byref(ns), C.byref(na), _i32(fin), _i32(src), _i32(dst), _i32(il), _i32(ol),
+                                                       _f32(gr), _f32(ac)))
         return dict(n_states=S, st_final=fin, a_src=src, a_dst=dst, a_ilabel=il, a_olabel=ol, a_graph=gr, a_acoustic=ac)
 
     def raw_lattices(self, channels=None, use_final_probs=True, threads=0):

@@ -332,6 +332,17 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
                                           int32_t *st_final, int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel,
                                           int32_t *a_olabel, float *a_graph, float *a_acoustic);
 
+/* GetLattice of the service with --use-second (OnlineClgLatticeFastDecoder::GetLattice, kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:
+ * 50-78): the determinized lattice composed with the OLD LM (loaded with scale -1: its scores are taken out) and then with the NEW
+ * one -- ComposeLattice twice (newfst/compose-lat-inl.h:15-130: pairs (lattice state, LM state) breadth first, a word-labelled arc
+ * steps ComposeArpaLm and adds its cost, an arc into a final state adds the LM's final cost and makes the composed state final),
+ * each followed by Connect -- on the device, over the determinized lattice resident there and the LM automata in HBM.  Outputs as
+ * wfst_decoder_get_determinized_lattice (st_final here marks the composed final states).  One channel per call. */
+int wfst_decoder_get_rescored_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, const wfst_lm *old_lm,
+                                      const wfst_lm *new_lm, int32_t cap_states, int32_t cap_arcs, int32_t *n_states,
+                                      int32_t *n_arcs, int32_t *st_final, int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel,
+                                      int32_t *a_olabel, float *a_graph, float *a_acoustic);
+
 /* The service's n-best (OnlineClgLatticeFastDecoder::GetNbest, kaldi-nnet3/kaldi-online-nnet3-my-
  * decoder.cc:50-105: GetRawLattice -> DeterminizeLatticeWrapper -> NShortestPath ->
  * ConvertNbestToVector, then LatticeToVector per path) of channels of a lattice-mode decoder, finalized

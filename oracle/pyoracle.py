@@ -531,6 +531,91 @@ def ref_determinize_lattice_file(ref, path, index, max_states=1 << 20, max_arcs=
                       gr[:A].copy(), ac[:A].copy())
 
 
+def ref_rescore_lattice_file(ref, path, index, lm1, lm2, max_states=1 << 20, max_arcs=1 << 21):
+    """The service's GetLattice under --use-second (kaldi-online-nnet3-my-decoder.cc:53-78): determinize, then ComposeLattice with the
+    old LM (loaded with scale -1) and with the new one, by the compiled reference; RawLattice of the result, or None."""
+    ns, na, st = C.c_int(0), C.c_int(0), C.c_int(0)
+    fin = np.zeros(max_states, np.int32)
+    src, dst, il, ol = (np.zeros(max_arcs, np.int32) for _ in range(4))
+    gr, ac = np.zeros(max_arcs, np.float32), np.zeros(max_arcs, np.float32)
+    f = ref.lib.ref_rescore_lattice_file
+    f.restype = C.c_int
+    ok = f(path.encode(), int(index), C.c_void_p(lm1.h), C.c_void_p(lm2.h), max_states, C.byref(ns), C.byref(st), _ip(fin), max_arcs,
+           C.byref(na), _ip(src), _ip(dst), _ip(il), _ip(ol), _fp(gr), _fp(ac))
+    if not ok:
+        return None
+    S, A = ns.value, na.value
+    return RawLattice(True, S, st.value, fin[:S].copy(), src[:A].copy(), dst[:A].copy(), il[:A].copy(), ol[:A].copy(),
+                      gr[:A].copy(), ac[:A].copy())
+
+
+def compose_lattice(det, lm, scale=1.0):
+    """ComposeLattice (newfst/compose-lat-inl.h:15-130) + Connect (newfst/connect-fst.cc:10-22), restated: `det` a RawLattice (state 0 =
+    start), `lm` a pyoracle.Lm of the C oracle (ComposeArpaLm::GetArc / Final / Start = its getarc_many / final / start).  Pairs
+    (lattice state, LM state) breadth first in the reference's order; float32 arithmetic in its operation order.  Pure Python: for the
+    determinized lattices of the tests (a few hundred states)."""
+    f32 = np.float32
+    S = det.n_states
+    order = np.argsort(det.a_src, kind="stable")
+    by_src = [[] for _ in range(S)]
+    for k in order:
+        by_src[int(det.a_src[k])].append(int(k))
+    ids = {(det.start, lm.start()): 0}
+    queue = [(det.start, lm.start())]
+    fin = [0]
+    arcs = []
+    qi = 0
+    sc = f32(scale)
+    while qi < len(queue):
+        s1, s2 = queue[qi]
+        sid = qi
+        qi += 1
+        for k in by_src[s1]:
+            ol = int(det.a_ol[k])
+            n1 = int(det.a_dst[k])
+            n2, lw = s2, f32(0.0)
+            if ol != 0:
+                nx, v = lm.getarc_many(np.array([s2], np.int32), np.array([ol], np.int32))
+                n2, lw = int(nx[0]), f32(v[0])
+            key = (n1, n2)
+            if key not in ids:
+                ids[key] = len(queue)
+                queue.append(key)
+                fin.append(0)
+            nid = ids[key]
+            final_score = f32(0.0)
+            if det.st_final[n1]:
+                final_score = f32(lm.final(n2))
+                if np.isinf(final_score):
+                    final_score = f32(0.0)
+                else:
+                    fin[nid] = 1
+            g, a = f32(det.a_graph[k]), f32(det.a_ac[k])
+            if ol == 0:
+                arcs.append((sid, nid, int(det.a_il[k]), 0, f32(g + f32(final_score * sc)), a))
+            else:
+                arcs.append((sid, nid, int(det.a_il[k]), ol, f32(g + f32(f32(lw + final_score) * sc)), f32(a + f32(f32(0.0) * sc))))
+    n = len(queue)
+    keep = list(fin)
+    changed = True
+    while changed:   # Connect: every composed state is accessible; keep the ones that reach a final state
+        changed = False
+        for (s, d, _, _, _, _) in arcs:
+            if keep[d] and not keep[s]:
+                keep[s] = 1
+                changed = True
+    renum = {}
+    for i in range(n):
+        if keep[i]:
+            renum[i] = len(renum)
+    kept = [(renum[s], renum[d], il, ol, g, a) for (s, d, il, ol, g, a) in arcs if s in renum and d in renum]
+    fin2 = np.asarray([fin[i] for i in range(n) if keep[i]], np.int32)
+    A = len(kept)
+    col = lambda j, t: np.asarray([x[j] for x in kept], t) if A else np.zeros(0, t)
+    return RawLattice(True, len(renum), 0, fin2, col(0, np.int32), col(1, np.int32), col(2, np.int32), col(3, np.int32), col(4, np.float32),
+                      col(5, np.float32))
+
+
 DET_HOST_SO = os.path.join(HERE, "_build", "libdet_host.so")
 
 

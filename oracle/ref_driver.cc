@@ -31,6 +31,8 @@
 #include "src/newfst/lattice-determinize-api.h"
 #include "src/newfst/lattice-to-nbest.h"
 #include "src/newfst/lattice-functions.h"
+#include "src/newfst/compose-lat.h"
+#include "src/newlm/compose-arpalm.h"
 
 using namespace datemoon;
 
@@ -475,6 +477,51 @@ int ref_determinize_lattice_file(const char *path, int index, int max_states, in
   int na = 0;
   for (int s = 0; s < S; ++s) {
     LatticeState *st = det.GetState(s);
+    if (s < max_states) st_final[s] = st->IsFinal() ? 1 : 0;
+    const int k = (int)st->GetArcSize();
+    for (int i = 0; i < k; ++i) {
+      LatticeArc *a = st->GetArc(i);
+      if (na < max_arcs) {
+        a_src[na] = s;
+        a_dst[na] = a->_to;
+        a_il[na] = a->_input;
+        a_ol[na] = a->_output;
+        a_graph[na] = a->_w.Value1();
+        a_ac[na] = a->_w.Value2();
+      }
+      ++na;
+    }
+  }
+  *n_arcs = na;
+  return 1;
+}
+
+// The service's GetLattice under --use-second (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:53-78) on lattice `index` of `path`:
+// DeterminizeLatticeWrapper, then ComposeLattice with ComposeArpaLm(lm1) and with ComposeArpaLm(lm2) (newfst/compose-lat-inl.h),
+// dumped like ref_determinize_lattice_file.  lm1 = old LM (rescaled by -1 at load), lm2 = new LM.
+int ref_rescore_lattice_file(const char *path, int index, void *lm1, void *lm2, int max_states, int *n_states, int *start,
+                             int *st_final, int max_arcs, int *n_arcs, int *a_src, int *a_dst, int *a_il, int *a_ol, float *a_graph,
+                             float *a_ac) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return 0;
+  Lattice lat;
+  bool ok = true;
+  for (int i = 0; i <= index && ok; ++i) ok = lat.Read(fp);
+  fclose(fp);
+  if (!ok || !LatticeCheckFormat(&lat)) return 0;
+  Lattice det, lat1, out;
+  DeterminizeLatticeOptions opts;
+  bool debug = false;
+  if (!DeterminizeLatticeWrapper(&lat, &det, opts, &debug)) return 0;
+  ComposeArpaLm c1(static_cast<ArpaLm *>(lm1)), c2(static_cast<ArpaLm *>(lm2));
+  ComposeLattice<FsaStateId>(&det, static_cast<LatticeComposeItf<FsaStateId> *>(&c1), &lat1);
+  ComposeLattice<FsaStateId>(&lat1, static_cast<LatticeComposeItf<FsaStateId> *>(&c2), &out);
+  const int S = out.NumStates();
+  *n_states = S;
+  *start = out.Start();
+  int na = 0;
+  for (int s = 0; s < S; ++s) {
+    LatticeState *st = out.GetState(s);
     if (s < max_states) st_final[s] = st->IsFinal() ? 1 : 0;
     const int k = (int)st->GetArcSize();
     for (int i = 0; i < k; ++i) {
