@@ -238,17 +238,21 @@ WFST_HD inline int32_t det_closure(DetWs &W, DetElem *e, int32_t n) {
   DetElem *cur = W.tc;     // the current best element of every state reached
   DetElem *queue = W.tb;   // FIFO of elements to expand (a ring: an improved state is queued again)
   int32_t ncur = 0;
-  int64_t qh = 0, qt = 0;
+  int32_t qh = 0, qt = 0, qn = 0;   // ring: head, tail, elements queued (no 64-bit modulo: the lane is instruction-bound)
   const int32_t cap = W.cap.tmp;
   for (int32_t i = 0; i < n; ++i) {
     if (ncur >= cap) { W.err = 6; break; }
     W.cl_idx[e[i].state] = ncur;
     cur[ncur++] = e[i];
-    queue[qt++ % cap] = e[i];
+    queue[qt] = e[i];
+    if (++qt == cap) qt = 0;
+    ++qn;
   }
   bool replaced = false;
-  while (qh < qt && !W.err) {
-    const DetElem el = queue[qh++ % cap];
+  while (qn > 0 && !W.err) {
+    const DetElem el = queue[qh];
+    if (++qh == cap) qh = 0;
+    --qn;
     if (replaced) {  // a better element for this state is further down the queue: skip the stale one
       const DetElem &c = cur[W.cl_idx[el.state]];
       if (c.str != el.str || c.w1 != el.w1 || c.w2 != el.w2) continue;
@@ -275,8 +279,10 @@ WFST_HD inline int32_t det_closure(DetWs &W, DetElem *e, int32_t n) {
         replaced = true;
       }
       if (push) {
-        if (qt - qh >= cap) { W.err = 6; break; }
-        queue[qt++ % cap] = nx;
+        if (qn >= cap) { W.err = 6; break; }
+        queue[qt] = nx;
+        if (++qt == cap) qt = 0;
+        ++qn;
       }
     }
   }

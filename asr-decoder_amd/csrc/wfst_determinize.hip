@@ -3,6 +3,16 @@
 // one workgroup per channel.  The workgroup builds the inverted, arc-sorted CSR of its lattice together; the
 // subset construction itself (wfst_determinize.h: a sequential algorithm by its definition, see there) runs
 // on one lane, the lattices of a batch side by side.
+//
+// What bounds that lane (round 3, measured: tools/ubench_chase.hip and in-kernel timers on the 128 beam-15 lattices of the bench):
+// a beam-15 lattice of 2.5-14 k states costs 2.2-2.7 us per string-trie node it creates (8 ms for the smallest, 69 ms for the
+// largest of the batch, 17 ms on average -- the launch lasts as long as its largest lattice).  One lane pays 25 ns for a
+// dependent LDS load, 55-100 ns for a dependent L1 / L2 load and 2-4 ns per dependent ALU instruction; every load that follows a
+// store also waits for that store's acknowledgement (one in-order counter on gfx9).  Tried and dropped: the hot tables (first 8192
+// trie nodes + a 16-bit hash, closure buffers, state index) in LDS behind low / high accessors -- slower (mean 18.8 vs 16.9 ms,
+// largest 88 vs 69 ms: the accessors' instructions cost more than the loads save); walking straight stretches of the raw
+// lattice without queue / index traffic -- 5 % (and it changes the closure's visiting order).  What did pay: the closure's ring
+// buffer without 64-bit modulo (-10 %).  Speeding this up for real needs parallelism INSIDE a lattice.
 #include "wfst_determinize.h"
 #include "wfst_device.h"
 
