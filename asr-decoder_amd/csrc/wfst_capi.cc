@@ -183,6 +183,9 @@ struct wfst_decoder {
   DetDev det = {};
   // second-pass LM composition (wfst_decoder_get_rescored_lattice): workspace allocated by the first call
   DevBuf<int32_t> cmp_ws, cmp_result, cmp_fin;
+  DevBuf<int32_t> np_ws, np_out, np_off, np_arcs;   // n cheapest paths of a determinized / rescored lattice (wfst_decoder_get_nbest_paths)
+  DevBuf<float> np_tot;
+  DevBuf<NbPathEntry> np_lists;
   DevBuf<int4> cmp_out_a;
   DevBuf<float2> cmp_out_w;
   CmpDev cmp = {};
@@ -251,6 +254,7 @@ struct wfst_decoder {
     pair_keys.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
     det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
     cmp_ws.release(); cmp_result.release(); cmp_fin.release(); cmp_out_a.release(); cmp_out_w.release();
+    np_ws.release(); np_out.release(); np_off.release(); np_arcs.release(); np_tot.release(); np_lists.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
     bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); lat_stats.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
@@ -2022,35 +2026,24 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
   return WFST_OK;
 }
 
-int wfst_decoder_get_rescored_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, const wfst_lm *old_lm, const wfst_lm *new_lm,
-                                      int32_t cap_states, int32_t cap_arcs, int32_t *n_states, int32_t *n_arcs, int32_t *st_final,
-                                      int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel, int32_t *a_olabel, float *a_graph, float *a_acoustic) {
-  if (!d || channel < 0 || channel >= d->n_channels || !n_states || !n_arcs || !old_lm || !new_lm) return fail(WFST_E_ARG, "bad argument");
-  if (old_lm->device != d->device || new_lm->device != d->device) return fail(WFST_E_ARG, "the LMs must be on the decoder's device");
-  // GetLattice of the service under --use-second: the determinized lattice first (its device copy stays in workspace slot 0 when this
-  // channel is determinized alone) ...
-  int32_t ns = 0, na = 0;
-  *n_states = 0;
-  *n_arcs = 0;
-  if (d->h_state[channel] == 0) return fail(WFST_E_STATE, "GetLattice before InitDecoding");
-  if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice needs a decoder created with wfst_limits.lattice_links > 0");
-  // force a determinization of THIS channel into slot 0 (a cached host copy of an earlier batch determinization does not hold
-  // the device copy any more)
+// The determinized lattice of ONE channel into workspace slot 0 (a cached host copy of an earlier batch determinization does not
+// hold the device copy any more): the other finalized channels are hidden from the batch sweep for the call.
+static int determinize_alone(wfst_decoder *d, int32_t channel, int32_t use_final_probs, int32_t *ns, int32_t *na) {
   if (!d->det_cached.empty()) { d->det_cached[channel] = 0; d->det_live_nd[channel] = -1; }
-  {
-    // determinize only this channel: temporarily hide the other finalized channels from the batch sweep
-    std::vector<char> saved(d->det_cached);
-    if (!saved.empty())
-      for (int c = 0; c < d->n_channels; ++c)
-        if (c != channel) d->det_cached[c] = 1;
-    int rc = wfst_decoder_get_determinized_lattice(d, channel, use_final_probs, 0, 0, &ns, &na, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    if (!saved.empty())
-      for (int c = 0; c < d->n_channels; ++c)
-        if (c != channel) d->det_cached[c] = saved[c];
-    if (rc != WFST_OK && !(rc == WFST_E_CAPACITY && ns > 0)) return rc;
-  }
-  if (ns == 0) return WFST_OK;   // no lattice (as wfst_decoder_get_raw_lattice)
-  HIP_TRY(hipSetDevice(d->device));
+  std::vector<char> saved(d->det_cached);
+  if (!saved.empty())
+    for (int c = 0; c < d->n_channels; ++c)
+      if (c != channel) d->det_cached[c] = 1;
+  int rc = wfst_decoder_get_determinized_lattice(d, channel, use_final_probs, 0, 0, ns, na, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (!saved.empty())
+    for (int c = 0; c < d->n_channels; ++c)
+      if (c != channel) d->det_cached[c] = saved[c];
+  if (rc != WFST_OK && !(rc == WFST_E_CAPACITY && *ns > 0)) return rc;
+  return WFST_OK;
+}
+
+// ComposeLattice with the old LM and with the new one over the determinized lattice of slot 0, on the device; res = {states, arcs}
+static int compose_slot0(wfst_decoder *d, const wfst_lm *old_lm, const wfst_lm *new_lm, int32_t res[4]) {
   CmpDev &Y = d->cmp;
   if (!d->cmp_ws.p) {
     Y.pair_cap = 65536;
@@ -2068,13 +2061,35 @@ int wfst_decoder_get_rescored_lattice(wfst_decoder *d, int32_t channel, int32_t 
     Y.out_a = d->cmp_out_a.p;
     Y.out_w = d->cmp_out_w.p;
   }
-  // ... then ComposeLattice with the old LM and with the new one, on the device
   launch_compose2(d->det, Y, old_lm->view(), new_lm->view(), d->stream);
   HIP_TRY(hipGetLastError());
-  int32_t res[4];
-  HIP_TRY(hipMemcpyAsync(res, Y.result, sizeof(res), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(res, Y.result, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   if (res[2] != 0) return fail(WFST_E_CAPACITY, "the composed lattice outgrew the composition workspace (" + std::to_string(Y.pair_cap) + " states / " + std::to_string(Y.arc_cap) + " arcs)");
+  return WFST_OK;
+}
+
+int wfst_decoder_get_rescored_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, const wfst_lm *old_lm, const wfst_lm *new_lm,
+                                      int32_t cap_states, int32_t cap_arcs, int32_t *n_states, int32_t *n_arcs, int32_t *st_final,
+                                      int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel, int32_t *a_olabel, float *a_graph, float *a_acoustic) {
+  if (!d || channel < 0 || channel >= d->n_channels || !n_states || !n_arcs || !old_lm || !new_lm) return fail(WFST_E_ARG, "bad argument");
+  if (old_lm->device != d->device || new_lm->device != d->device) return fail(WFST_E_ARG, "the LMs must be on the decoder's device");
+  // GetLattice of the service under --use-second: the determinized lattice first (its device copy stays in workspace slot 0 when this
+  // channel is determinized alone) ...
+  int32_t ns = 0, na = 0;
+  *n_states = 0;
+  *n_arcs = 0;
+  if (d->h_state[channel] == 0) return fail(WFST_E_STATE, "GetLattice before InitDecoding");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice needs a decoder created with wfst_limits.lattice_links > 0");
+  int rc = determinize_alone(d, channel, use_final_probs, &ns, &na);
+  if (rc != WFST_OK) return rc;
+  if (ns == 0) return WFST_OK;   // no lattice (as wfst_decoder_get_raw_lattice)
+  HIP_TRY(hipSetDevice(d->device));
+  // ... then ComposeLattice with the old LM and with the new one, on the device
+  int32_t res[4];
+  rc = compose_slot0(d, old_lm, new_lm, res);
+  if (rc != WFST_OK) return rc;
+  CmpDev &Y = d->cmp;
   *n_states = res[0];
   *n_arcs = res[1];
   if (res[0] > cap_states || res[1] > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");
@@ -2096,6 +2111,90 @@ int wfst_decoder_get_rescored_lattice(wfst_decoder *d, int32_t channel, int32_t 
     if (a_olabel) a_olabel[k] = oa[(size_t)k].z;
     if (a_graph) a_graph[k] = ow[(size_t)k].x;
     if (a_acoustic) a_acoustic[k] = ow[(size_t)k].y;
+  }
+  return WFST_OK;
+}
+
+int wfst_decoder_get_nbest_paths(wfst_decoder *d, int32_t channel, int32_t n, int32_t use_final_probs, const wfst_lm *old_lm,
+                                 const wfst_lm *new_lm, int32_t cap_paths, int32_t cap_arcs, int32_t *n_paths, int32_t *total_arcs,
+                                 int32_t *path_off, float *path_tot, int32_t *a_olabel, float *a_graph, float *a_acoustic) {
+  if (!d || channel < 0 || channel >= d->n_channels || !n_paths || !total_arcs || n < 1 || n > 4096 || (old_lm == nullptr) != (new_lm == nullptr))
+    return fail(WFST_E_ARG, "bad argument (1 <= n <= 4096; both LMs or neither)");
+  if (old_lm && (old_lm->device != d->device || new_lm->device != d->device)) return fail(WFST_E_ARG, "the LMs must be on the decoder's device");
+  *n_paths = 0;
+  *total_arcs = 0;
+  if (d->h_state[channel] == 0) return fail(WFST_E_STATE, "GetNbest before InitDecoding");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "GetNbest needs a decoder created with wfst_limits.lattice_links > 0");
+  // GetLattice (the determinized lattice, into workspace slot 0; with LMs its second-pass rescoring) ...
+  int32_t ns = 0, na = 0;
+  int rc = determinize_alone(d, channel, use_final_probs, &ns, &na);
+  if (rc != WFST_OK) return rc;
+  if (ns == 0) return WFST_OK;
+  HIP_TRY(hipSetDevice(d->device));
+  NbPathsDev P = {};
+  std::vector<int4> oa;
+  std::vector<float2> ow;
+  if (old_lm) {
+    int32_t res[4];
+    rc = compose_slot0(d, old_lm, new_lm, res);
+    if (rc != WFST_OK) return rc;
+    ns = res[0];
+    na = res[1];
+    if (ns == 0) return WFST_OK;   // (nothing reaches a final state of both LMs)
+    P.a = d->cmp.out_a; P.w = d->cmp.out_w; P.res = d->cmp.result; P.fin = d->cmp.out_fin;
+    oa.resize((size_t)na);
+    ow.resize((size_t)na);
+    if (na) {
+      HIP_TRY(hipMemcpyAsync(oa.data(), d->cmp.out_a, oa.size() * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
+      HIP_TRY(hipMemcpyAsync(ow.data(), d->cmp.out_w, ow.size() * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
+    }
+  } else {
+    P.a = d->det.out_a; P.w = d->det.out_w; P.res = d->det.result; P.fin = nullptr;
+  }
+  // ... then NShortestPath on the device
+  const int64_t nmax = std::max(ns, na);
+  const int64_t ws_ints = 7ll * ns + 4ll * nmax + na + 16;
+  const int64_t list_cap = std::min<int64_t>((int64_t)ns * n + 1, 1ll << 26);   // (a gigabyte of partial paths at most)
+  const int64_t out_cap = std::min<int64_t>((int64_t)n * ns, 1ll << 24);
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  if ((int64_t)d->np_ws.n < ws_ints) HIP_TRY(d->np_ws.alloc((size_t)ws_ints));
+  if ((int64_t)d->np_lists.n < list_cap) HIP_TRY(d->np_lists.alloc((size_t)list_cap));
+  if ((int64_t)d->np_arcs.n < out_cap) HIP_TRY(d->np_arcs.alloc((size_t)out_cap));
+  if ((int64_t)d->np_off.n < n + 1) { HIP_TRY(d->np_off.alloc((size_t)n + 1)); HIP_TRY(d->np_tot.alloc((size_t)n)); }
+  if (!d->np_out.p) HIP_TRY(d->np_out.alloc(4));
+  P.n = n;
+  P.ws = d->np_ws.p; P.ws_ints = (int64_t)d->np_ws.n;
+  P.lists = d->np_lists.p; P.list_cap = (int64_t)d->np_lists.n;
+  P.out = d->np_out.p; P.out_off = d->np_off.p; P.out_tot = d->np_tot.p;
+  P.out_arcs = d->np_arcs.p; P.out_cap = (int32_t)std::min<int64_t>((int64_t)d->np_arcs.n, 0x7fffffff);
+  launch_nbest_paths(P, d->stream);
+  HIP_TRY(hipGetLastError());
+  int32_t out[4];
+  HIP_TRY(hipMemcpyAsync(out, P.out, sizeof(out), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  if (out[2] == 3) return fail(WFST_E_DEVICE, "n-best: the lattice has a cycle");
+  if (out[2] != 0) return fail(WFST_E_CAPACITY, "n-best: " + std::to_string(n) + " paths over " + std::to_string(ns) + " states outgrew the path workspace");
+  *n_paths = out[0];
+  *total_arcs = out[1];
+  if (out[0] > cap_paths || out[1] > cap_arcs) return fail(WFST_E_CAPACITY, "n-best larger than the given capacities");
+  std::vector<int32_t> off((size_t)out[0] + 1), arcs((size_t)out[1]);
+  std::vector<float> tot((size_t)out[0]);
+  HIP_TRY(hipMemcpyAsync(off.data(), P.out_off, off.size() * 4, hipMemcpyDeviceToHost, d->stream));
+  if (out[0]) HIP_TRY(hipMemcpyAsync(tot.data(), P.out_tot, tot.size() * 4, hipMemcpyDeviceToHost, d->stream));
+  if (out[1]) HIP_TRY(hipMemcpyAsync(arcs.data(), P.out_arcs, arcs.size() * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  const wfst_decoder::DetLattice &L = d->det_cache[(size_t)channel];
+  for (int32_t p = 0; p <= out[0]; ++p)
+    if (path_off) path_off[p] = off[(size_t)p];
+  for (int32_t p = 0; p < out[0]; ++p)
+    if (path_tot) path_tot[p] = tot[(size_t)p];
+  for (int32_t k = 0; k < out[1]; ++k) {
+    const size_t a = (size_t)arcs[(size_t)k];
+    const int4 A = old_lm ? oa[a] : L.a[a];
+    const float2 W = old_lm ? ow[a] : L.w[a];
+    if (a_olabel) a_olabel[k] = A.z;
+    if (a_graph) a_graph[k] = W.x;
+    if (a_acoustic) a_acoustic[k] = W.y;
   }
   return WFST_OK;
 }

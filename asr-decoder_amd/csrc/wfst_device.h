@@ -389,6 +389,26 @@ struct DetDev {
 };
 void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chan_list_dev, int cnt, hipStream_t s);
 
+// ---- n cheapest paths of a determinized / rescored lattice (wfst_nbest.hip: nbest_paths_kernel) --------------------------------
+struct NbPathEntry { float cost; int32_t arc, rank, pad; };   // a partial path: its cost, the arc it arrives by (-1: the start), its rank in that arc's source list
+struct NbPathsDev {
+  const int4 *a;                // the lattice's arcs {src, dst, word, -} ...
+  const float2 *w;              // ... and their {graph, acoustic} costs
+  const int32_t *res;           // {states, arcs, status, determinized states proper} as determinize_kernel / compose2_kernel leave it
+  const int32_t *fin;           // final flag per state, or null: the states from res[3] on
+  int32_t n;                    // paths wanted (<= 4096)
+  int32_t *ws;                  // scratch: 7 states + 4 max(states, arcs) + arcs + 16 ints
+  int64_t ws_ints;
+  NbPathEntry *lists;           // the states' lists, packed
+  int64_t list_cap;
+  int32_t *out;                 // {paths found, arcs on them, status (0 ok, 1 a capacity, 2 no input, 3 cyclic input), -}
+  int32_t *out_off;             // [n + 1] first arc of each path in out_arcs
+  float *out_tot;               // [n] cost of each path
+  int32_t *out_arcs;            // arc indices (into a / w), path after path, front to back
+  int32_t out_cap;
+};
+void launch_nbest_paths(const NbPathsDev &P, hipStream_t s);
+
 // ---- second-pass LM composition on determinized lattices (wfst_compose.hip) ------------------------------------
 // ComposeLattice (newfst/compose-lat-inl.h:15-130) of the determinized lattice of workspace slot 0 (DetDev::out_a / out_w, as
 // determinize_kernel left it) with ComposeArpaLm(lm1), then of the result with ComposeArpaLm(lm2) -- what the service's GetLattice

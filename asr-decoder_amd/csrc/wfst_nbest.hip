@@ -296,6 +296,261 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
   }
 }
 
+// ---- nbest_paths_kernel: NShortestPath on a determinized (or rescored) lattice ---------------------------------------------
+// The service's GetNbest (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105) runs NShortestPath (newfst/lattice-to-nbest.cc:15-147)
+// on the lattice GetLattice returns and hands every path out as a linear lattice with the lattice's own arcs on it
+// (ConvertNbestToVector, :149-199).  Here: the same n cheapest paths -- cost of a path = its arc costs (graph + acoustic) added
+// front to back in float, as NShortestPath's forward weights are -- by a k-best dynamic program over the (acyclic) lattice in
+// topological order: the list of a state = the n cheapest of its predecessors' lists extended by the arcs between them.  Any n up
+// to half the sort buffer (4096); paths come out as sequences of arc indices of the input lattice.  One workgroup per lattice:
+// the candidate lists of a state are merged by a bitonic sort in LDS (chunked when they exceed the buffer: the n kept so far
+// plus the next candidates), equal costs in the order (arc, rank).
+constexpr int kNpThreads = 1024, kNpSlots = 8192;
+
+__device__ __forceinline__ void np_sort(u64 *key, u64 *pay, int S2) {   // ascending bitonic sort of key[0..S2) (S2 a power of two), pay along
+  const int tid = threadIdx.x;
+  for (int k = 2; k <= S2; k <<= 1)
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      for (int i = tid; i < S2; i += kNpThreads) {
+        const int l = i ^ j;
+        if (l > i) {
+          const u64 a = key[i], b = key[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            key[i] = b; key[l] = a;
+            const u64 pa = pay[i]; pay[i] = pay[l]; pay[l] = pa;
+          }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kNpThreads) void nbest_paths_kernel(NbPathsDev P) {
+  __shared__ u64 s_key[kNpSlots];
+  __shared__ u64 s_pay[kNpSlots];
+  __shared__ int s_flag, s_maxlevel, s_lnext, s_total;
+  const int tid = threadIdx.x;
+  int32_t *out = P.out;
+  if (tid == 0) { out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 0; s_maxlevel = 0; s_lnext = 0; }
+  __syncthreads();
+  const int ns = P.res[0], na = P.res[1], n = P.n;
+  if (P.res[2] != 0 || ns <= 0) {
+    if (tid == 0) out[2] = P.res[2] != 0 ? 2 : 0;
+    return;
+  }
+  const int nmax = ns > na ? ns : na;
+  if (7ll * ns + 4ll * nmax + na + 16 > P.ws_ints || 2 * n > kNpSlots) {
+    if (tid == 0) out[2] = 1;
+    return;
+  }
+  int32_t *in_off = P.ws;            // [ns + 1]
+  int32_t *in_fill = in_off + ns + 1;  // [ns]
+  int32_t *level = in_fill + ns;     // [ns]
+  int32_t *order = level + ns;       // [ns]
+  int32_t *lvl_off = order + ns;     // [ns + 2]
+  int32_t *cnt = lvl_off + ns + 2;   // [ns]
+  int32_t *loff = cnt + ns;          // [ns]
+  int32_t *in_arcs = loff + ns;      // [na]
+  int32_t *pre = in_arcs + na;       // [nmax + 1]
+  int32_t *csrc = pre + nmax + 1;    // [nmax]
+  int32_t *carc = csrc + nmax;       // [nmax]
+  const int4 *A = P.a;
+  const float2 *Wt = P.w;
+  // ---- incoming arcs by target state -------------------------------------------------------------------------------
+  for (int s = tid; s <= ns; s += kNpThreads) { in_off[s] = 0; lvl_off[s] = 0; }
+  if (tid == 0) lvl_off[ns + 1] = 0;
+  for (int s = tid; s < ns; s += kNpThreads) { level[s] = -1; cnt[s] = 0; loff[s] = 0; }
+  __syncthreads();
+  for (int a = tid; a < na; a += kNpThreads) atomicAdd(&in_off[A[a].y + 1], 1);
+  __syncthreads();
+  if (tid == 0) {
+    for (int s = 0; s < ns; ++s) in_off[s + 1] += in_off[s];
+    level[0] = 0;
+  }
+  __syncthreads();
+  for (int s = tid; s < ns; s += kNpThreads) in_fill[s] = in_off[s];
+  __syncthreads();
+  for (int a = tid; a < na; a += kNpThreads) in_arcs[atomicAdd(&in_fill[A[a].y], 1)] = a;
+  __syncthreads();
+  // (a state's incoming arcs in ascending arc order: the tie order must not depend on the atomics)
+  for (int s = tid; s < ns; s += kNpThreads) {
+    const int b = in_off[s], e = in_off[s + 1];
+    for (int i = b + 1; i < e; ++i) {
+      const int x = in_arcs[i];
+      int j = i;
+      while (j > b && in_arcs[j - 1] > x) { in_arcs[j] = in_arcs[j - 1]; --j; }
+      in_arcs[j] = x;
+    }
+  }
+  // ---- topological levels: the longest distance from the start state (state 0) -----------------------------------------
+  for (int it = 0;; ++it) {
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    for (int a = tid; a < na; a += kNpThreads) {
+      const int4 t = A[a];
+      const int ls = level[t.x];
+      if (ls >= 0 && level[t.y] < ls + 1) { atomicMax(&level[t.y], ls + 1); s_flag = 1; }
+    }
+    __syncthreads();
+    const int f = s_flag;
+    __syncthreads();
+    if (!f) break;
+    if (it > ns) {   // a cycle: not a lattice
+      if (tid == 0) out[2] = 3;
+      return;
+    }
+  }
+  for (int s = tid; s < ns; s += kNpThreads)
+    if (level[s] >= 0) { atomicAdd(&lvl_off[level[s] + 1], 1); atomicMax(&s_maxlevel, level[s]); }
+  __syncthreads();
+  if (tid == 0)
+    for (int l = 0; l <= s_maxlevel; ++l) lvl_off[l + 1] += lvl_off[l];
+  __syncthreads();
+  const int n_reached = lvl_off[s_maxlevel + 1];
+  for (int s = tid; s < ns; s += kNpThreads) in_fill[s] = 0;
+  __syncthreads();
+  for (int s = tid; s < ns; s += kNpThreads)
+    if (level[s] >= 0) order[lvl_off[level[s]] + atomicAdd(&in_fill[level[s]], 1)] = s;
+  __syncthreads();
+  // ---- the lists, level by level ----------------------------------------------------------------------------------------
+  if (tid == 0) {
+    NbPathEntry e0;
+    e0.cost = 0.0f; e0.arc = -1; e0.rank = 0; e0.pad = 0;
+    if (P.list_cap > 0) P.lists[0] = e0;
+    cnt[0] = 1; loff[0] = 0; s_lnext = 1;
+  }
+  __syncthreads();
+  // idx < n_reached: state order[idx]; idx == n_reached: the super-final state (AddSuperFinalState, lattice-functions.cc:163-178)
+  for (int idx = 0; idx <= n_reached; ++idx) {
+    const bool super = idx == n_reached;
+    const int t = super ? -1 : order[idx];
+    if (t == 0) continue;   // the start state: the empty path only
+    int m;
+    if (!super) {
+      m = in_off[t + 1] - in_off[t];
+      for (int j = tid; j < m; j += kNpThreads) {
+        const int arc = in_arcs[in_off[t] + j];
+        csrc[j] = A[arc].x;
+        carc[j] = arc;
+      }
+    } else {
+      // the final states, in state order
+      if (tid == 0) {
+        int k = 0;
+        for (int s = 0; s < ns; ++s) {
+          const bool fin = P.fin ? P.fin[s] != 0 : s >= P.res[3];
+          if (fin && level[s] >= 0 && cnt[s] > 0) { csrc[k] = s; carc[k] = -(s + 2); ++k; }
+        }
+        s_total = k;
+      }
+      __syncthreads();
+      m = s_total;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int j = 0; j < m; ++j) { pre[j] = run; run += cnt[csrc[j]]; }
+      pre[m] = run;
+      s_total = run;
+    }
+    __syncthreads();
+    const int C = s_total;
+    int kept = 0;
+    for (int qbase = 0; qbase < C;) {
+      const int take = min(C - qbase, kNpSlots - kept);
+      for (int i = tid; i < take; i += kNpThreads) {
+        const int q = qbase + i;
+        int lo = 0, hi = m;   // pre[lo] <= q < pre[hi]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (pre[mid] <= q) lo = mid; else hi = mid;
+        }
+        const int r = q - pre[lo], src = csrc[lo], arc = carc[lo];
+        const NbPathEntry E = P.lists[(size_t)loff[src] + r];
+        float add = 0.0f;
+        if (arc >= 0) { const float2 w = Wt[arc]; add = w.x + w.y; }   // LatticeWeight::Value() (weigth.h:200)
+        const float cost = E.cost + add;                               // NShortestPath: p.second + arc->_w.Value() (:121)
+        s_key[kept + i] = ((u64)nb_f2o(cost) << 32) | (u64)(uint32_t)q;
+        s_pay[kept + i] = ((u64)(uint32_t)arc << 32) | (u64)(uint32_t)r;
+      }
+      const int filled = kept + take;
+      int S2 = 64;
+      while (S2 < filled) S2 <<= 1;
+      for (int i = filled + tid; i < S2; i += kNpThreads) { s_key[i] = ~0ull; s_pay[i] = 0; }
+      __syncthreads();
+      np_sort(s_key, s_pay, S2);
+      kept = min(n, filled);
+      qbase += take;
+      // (the entries kept keep their keys: their candidate numbers are below every later one's)
+    }
+    __syncthreads();
+    if (!super) {
+      if (tid == 0) {
+        loff[t] = s_lnext;
+        cnt[t] = kept;
+        s_lnext += kept;
+      }
+      __syncthreads();
+      if ((int64_t)s_lnext > P.list_cap) {
+        if (tid == 0) out[2] = 1;
+        return;
+      }
+      for (int i = tid; i < kept; i += kNpThreads) {
+        NbPathEntry e;
+        e.cost = __uint_as_float(0);
+        const uint32_t o = (uint32_t)(s_key[i] >> 32);
+        const uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);   // inverse of nb_f2o
+        e.cost = __uint_as_float(u);
+        e.arc = (int32_t)(uint32_t)(s_pay[i] >> 32);
+        e.rank = (int32_t)(uint32_t)(s_pay[i] & 0xFFFFFFFFu);
+        e.pad = 0;
+        P.lists[(size_t)loff[t] + i] = e;
+      }
+      __syncthreads();
+    } else {
+      // ---- the paths: backtrack each from its final state, write its arcs front to back -----------------------------------
+      const int found = kept;
+      for (int p = tid; p < found; p += kNpThreads) {
+        int state = -((int32_t)(uint32_t)(s_pay[p] >> 32)) - 2, rank = (int32_t)(uint32_t)(s_pay[p] & 0xFFFFFFFFu), len = 0;
+        for (;;) {
+          const NbPathEntry E = P.lists[(size_t)loff[state] + rank];
+          if (E.arc < 0) break;
+          ++len;
+          state = A[E.arc].x;
+          rank = E.rank;
+        }
+        P.out_off[p + 1] = len;
+        const uint32_t o = (uint32_t)(s_key[p] >> 32);
+        P.out_tot[p] = __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+      }
+      __syncthreads();
+      if (tid == 0) {
+        P.out_off[0] = 0;
+        for (int p = 0; p < found; ++p) P.out_off[p + 1] += P.out_off[p];
+        out[0] = found;
+        out[1] = P.out_off[found];
+        if (P.out_off[found] > P.out_cap) out[2] = 1;
+      }
+      __syncthreads();
+      if (out[2] == 0)
+        for (int p = tid; p < found; p += kNpThreads) {
+          int state = -((int32_t)(uint32_t)(s_pay[p] >> 32)) - 2, rank = (int32_t)(uint32_t)(s_pay[p] & 0xFFFFFFFFu);
+          int k = P.out_off[p + 1];
+          for (;;) {
+            const NbPathEntry E = P.lists[(size_t)loff[state] + rank];
+            if (E.arc < 0) break;
+            P.out_arcs[--k] = E.arc;
+            state = A[E.arc].x;
+            rank = E.rank;
+          }
+        }
+    }
+  }
+}
+
+void launch_nbest_paths(const NbPathsDev &P, hipStream_t s) { hipLaunchKernelGGL(nbest_paths_kernel, dim3(1), dim3(kNpThreads), 0, s, P); }
+
 void launch_nbest(const DecoderDev &D, const NbestDev &N, const int32_t *chans, int cnt, hipStream_t s) {
   hipLaunchKernelGGL(nbest_kernel, dim3(cnt), dim3(kNbThreads), 0, s, D, N, chans);
 }

@@ -8,6 +8,9 @@
 //   --lm-old/--lm-new  biglm (kaldi-hclg-my-decoder-biglm.cc): rescore on the fly with new LM - old LM; the files
 //                  are the reference's binary LMs (arpa2fsa-bin); the old one is rescaled by -1 as the reference CLI does
 //               CONFIG GRAPH LOGLIKES [WORDS_OUT]
+//   --second-lm-old/--second-lm-new  the service's --use-second: GetLattice (--determinize) and GetNbest (--nbest) run the second LM pass
+//                  (ComposeLattice with the old LM rescaled by -1, then with the new one) on the determinized lattice, on the device
+//   --nbest-lattice-out  also write every n-best path as the linear lattice GetNbest returns (NShortestPath + ConvertNbestToVector)
 //   --lattice-out  also write GetRawLattice of every utterance, in utterance order, in the
 //                  reference's on-disk lattice format (Lattice::Write, newfst/lattice-fst.cc:38-64;
 //                  lattice mode: N forward links kept per utterance).  An utterance without a
@@ -86,7 +89,7 @@ class HostMatrixDecodable : public MatrixDecodable {
 
 int main(int argc, char **argv) {
   try {
-    std::string tid2pdf_file, lm_old_file, lm_new_file;
+    std::string tid2pdf_file, lm_old_file, lm_new_file, second_old_file, second_new_file, nbest_lattice_file;
     int batch = 128;
     bool single = false, determinize = false;
     std::string lattice_file, lattice_text;
@@ -107,11 +110,14 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 8, "--chunk=") == 0) chunk = std::max(0, atoi(a.c_str() + 8));
       else if (a.compare(0, 9, "--lm-old=") == 0) lm_old_file = a.substr(9);
       else if (a.compare(0, 9, "--lm-new=") == 0) lm_new_file = a.substr(9);
+      else if (a.compare(0, 16, "--second-lm-old=") == 0) second_old_file = a.substr(16);
+      else if (a.compare(0, 16, "--second-lm-new=") == 0) second_new_file = a.substr(16);
+      else if (a.compare(0, 20, "--nbest-lattice-out=") == 0) nbest_lattice_file = a.substr(20);
       else pos.push_back(a);
     }
     if (pos.size() < 3) {
       std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream [--chunk=N]] [--inflight=K] [--nbest=N] [--lattice-out=FILE] [--determinize] "
-                   "[--lattice-text=FILE] [--lattice-links=N] [--lm-old=FILE --lm-new=FILE] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
+                   "[--lattice-text=FILE] [--lattice-links=N] [--lm-old=FILE --lm-new=FILE] [--second-lm-old=FILE --second-lm-new=FILE] [--nbest-lattice-out=FILE] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
       return 1;
     }
     LatticeFasterDecoderConfig opt;
@@ -138,11 +144,13 @@ int main(int argc, char **argv) {
       lat_out.precision(9);
     }
     if (!lattice_file.empty()) remove(lattice_file.c_str());  // Lattice::Write(file) appends
+    if (!nbest_lattice_file.empty()) remove(nbest_lattice_file.c_str());
     const bool want_lattice = !lattice_file.empty() || !lattice_text.empty() || nbest > 0;
     auto emit_nbest = [&](const Utt &u, std::vector<Lattice> &paths) {
       for (size_t k = 0; k < paths.size(); ++k) {
         std::vector<int> words, phones;
         float tot = 0, lm = 0;
+        if (!nbest_lattice_file.empty() && !paths[k].Write(nbest_lattice_file)) throw std::runtime_error("cannot write " + nbest_lattice_file);
         if (!LatticeToVector(paths[k], words, phones, tot, lm)) continue;
         out << u.key << '-' << (k + 1);
         for (int w : words) out << ' ' << w;
@@ -160,6 +168,19 @@ int main(int argc, char **argv) {
       lm1.Handle();   // both automata go to HBM here, once, before any worker thread asks for them
       lm2.Handle();
     }
+    // the service's second pass (--use-second, kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:53-78): GetLattice / GetNbest compose the
+    // determinized lattice with the old LM (rescaled by -1) and with the new one
+    const bool second = !second_old_file.empty() || !second_new_file.empty();
+    ArpaLm slm1, slm2;
+    if (second) {
+      if (second_old_file.empty() || second_new_file.empty()) { std::cerr << "--second-lm-old and --second-lm-new go together\n"; return 1; }
+      if (!slm1.Read(second_old_file.c_str()) || !slm2.Read(second_new_file.c_str())) return 1;
+      slm1.Rescale(-1.0);
+      slm1.Handle();
+      slm2.Handle();
+    }
+    // exact n-best (NShortestPath on the determinized lattice) where its lattices are asked for, a second pass runs or the list is long
+    const bool exact_nbest = !nbest_lattice_file.empty() || second || nbest > 16;
     wfst_limits limits = {0, 0, 0, 0, 0};  // zeros = the library defaults
     limits.lattice_links = want_lattice ? lattice_links : 0;
     auto emit_lattice = [&](const Utt &u, Lattice &lat, bool ok) {
@@ -222,8 +243,10 @@ int main(int argc, char **argv) {
               for (size_t k = 0; k < w.size(); ++k) out << " " << w[k];
             out << "\n";
             if (nbest > 0) {
+              // (partial lists come from the raw lattice: its unpruned last frames make the mid-utterance lattice expensive to
+              // determinize, for the reference as much as here)
               std::vector<Lattice> paths;
-              decode.GetNbest(paths, nbest);
+              decode.GetNbestShortlist(paths, std::min(nbest, 16));
               for (size_t k = 0; k < paths.size(); ++k) {
                 std::vector<int> nw, nph;
                 float t2 = 0, l2 = 0;
@@ -243,12 +266,14 @@ int main(int argc, char **argv) {
         emit(u, best, ok);
         if (want_lattice) {
           Lattice lat;
-          bool lok = determinize ? decode.GetLattice(&lat) : decode.GetRawLattice(&lat);
+          bool lok = determinize ? (second ? decode.GetLattice(&lat, &slm1, &slm2) : decode.GetLattice(&lat)) : decode.GetRawLattice(&lat);
           emit_lattice(u, lat, lok);
         }
         if (nbest > 0) {
           std::vector<Lattice> paths;
-          decode.GetNbest(paths, nbest);
+          if (!exact_nbest) decode.GetNbestShortlist(paths, nbest);
+          else if (second) decode.GetNbest(paths, nbest, &slm1, &slm2);
+          else decode.GetNbest(paths, nbest);
           emit_nbest(u, paths);
         }
       }
@@ -289,13 +314,18 @@ int main(int argc, char **argv) {
             if (want_lattice && determinize) {
               o.lats.assign(n, Lattice());
               o.lat_ok.assign(n, false);
-              for (int i = 0; i < n; ++i) o.lat_ok[i] = decode.GetLattice(i, &o.lats[i]);
+              for (int i = 0; i < n; ++i) o.lat_ok[i] = second ? decode.GetLattice(i, &o.lats[i], &slm1, &slm2) : decode.GetLattice(i, &o.lats[i]);
             } else if (want_lattice) {
               decode.GetRawLattices(ch, &o.lats, &o.lat_ok);
             }
             if (nbest > 0) {
               o.nbest.resize(n);
-              for (int i = 0; i < n; ++i) decode.GetNbest(i, o.nbest[i], nbest);
+              // (short lists for the whole batch come from one launch on the raw lattices; longer ones are NShortestPath per channel)
+              for (int i = 0; i < n; ++i) {
+                if (!exact_nbest) decode.GetNbestShortlist(i, o.nbest[i], nbest);
+                else if (second) decode.GetNbest(i, o.nbest[i], nbest, &slm1, &slm2);
+                else decode.GetNbest(i, o.nbest[i], nbest);
+              }
             }
           }
         } catch (const std::exception &e) {

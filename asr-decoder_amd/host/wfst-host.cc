@@ -402,7 +402,7 @@ static bool RescoredLatticeOfChannel(wfst_decoder *dec, int channel, Lattice *of
   return true;
 }
 
-static bool NbestOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> &out, int n) {
+static bool ShortlistOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> &out, int n) {
   out.clear();
   if (n <= 0) return false;
   const int max_words = 1024;
@@ -431,7 +431,48 @@ static bool NbestOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> 
   return !out.empty();
 }
 
-bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n) { return NbestOfChannel(_dec, 0, nbest_paths, n); }
+// GetNbest as the service defines it: NShortestPath over GetLattice's result, every path a linear lattice shaped as
+// ConvertNbestToVector leaves it (newfst/lattice-to-nbest.cc:149-199): an <eps> arc of weight One in front (the start state the
+// second Reverse adds), the lattice's arcs, the final weight's arc, the super-final state's arc and the first Reverse's <eps>.
+static bool NbestOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> &out, int n, ArpaLm *oldlm, ArpaLm *newlm) {
+  out.clear();
+  if (n <= 0) return false;
+  if ((oldlm == nullptr) != (newlm == nullptr)) throw std::runtime_error("second-pass GetNbest needs both LMs");
+  const wfst_lm *l1 = oldlm ? oldlm->Handle() : nullptr, *l2 = newlm ? newlm->Handle() : nullptr;
+  int32_t np = 0, na = 0;
+  std::vector<int32_t> off((size_t)n + 1), ol((size_t)n * 128);
+  std::vector<float> tot((size_t)n), g(ol.size()), ac(ol.size());
+  int rc = wfst_decoder_get_nbest_paths(dec, channel, n, 1, l1, l2, n, (int32_t)ol.size(), &np, &na, off.data(), tot.data(), ol.data(), g.data(), ac.data());
+  if (rc == WFST_E_CAPACITY && na > (int32_t)ol.size()) {
+    ol.resize((size_t)na); g.resize((size_t)na); ac.resize((size_t)na);
+    rc = wfst_decoder_get_nbest_paths(dec, channel, n, 1, l1, l2, n, na, &np, &na, off.data(), tot.data(), ol.data(), g.data(), ac.data());
+  }
+  if (rc == WFST_E_STATE) { Warn(wfst_last_error()); return false; }
+  if (rc != WFST_OK) Fatal("GetNbest");
+  for (int k = 0; k < np; ++k) {
+    Lattice lat;
+    StateId cur = lat.AddState();
+    lat.SetStart(cur);
+    auto add = [&](int word, float w1, float w2) {
+      StateId next = lat.AddState();
+      lat.AddArc(cur, LatticeArc(0, word, next, LatticeWeight(w1, w2)));
+      cur = next;
+    };
+    add(0, 0.0f, 0.0f);
+    for (int j = off[k]; j < off[k + 1]; ++j) add(ol[j], g[j], ac[j]);
+    add(0, 0.0f, 0.0f);
+    add(0, 0.0f, 0.0f);
+    lat.SetFinal(cur);
+    out.push_back(lat);
+  }
+  return !out.empty();
+}
+
+bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n) { return NbestOfChannel(_dec, 0, nbest_paths, n, nullptr, nullptr); }
+bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n, ArpaLm *oldlm, ArpaLm *newlm) {
+  return NbestOfChannel(_dec, 0, nbest_paths, n, oldlm, newlm);
+}
+bool GpuLatticeDecoder::GetNbestShortlist(std::vector<Lattice> &nbest_paths, int n) { return ShortlistOfChannel(_dec, 0, nbest_paths, n); }
 
 bool GpuLatticeDecoder::GetLattice(Lattice *ofst, bool use_final_probs) { return DetLatticeOfChannel(_dec, 0, ofst, use_final_probs); }
 bool GpuLatticeDecoder::GetLattice(Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs) {
@@ -474,7 +515,13 @@ void GpuBatchDecoder::GetRawLattices(const std::vector<int> &channels, std::vect
   ok->assign(good.begin(), good.end());
 }
 bool GpuBatchDecoder::GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n) {
-  return NbestOfChannel(_dec, channel, nbest_paths, n);
+  return NbestOfChannel(_dec, channel, nbest_paths, n, nullptr, nullptr);
+}
+bool GpuBatchDecoder::GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n, ArpaLm *oldlm, ArpaLm *newlm) {
+  return NbestOfChannel(_dec, channel, nbest_paths, n, oldlm, newlm);
+}
+bool GpuBatchDecoder::GetNbestShortlist(int channel, std::vector<Lattice> &nbest_paths, int n) {
+  return ShortlistOfChannel(_dec, channel, nbest_paths, n);
 }
 bool GpuBatchDecoder::GetLattice(int channel, Lattice *ofst, bool use_final_probs) {
   return DetLatticeOfChannel(_dec, channel, ofst, use_final_probs);

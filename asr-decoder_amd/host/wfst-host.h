@@ -238,12 +238,17 @@ class GpuLatticeDecoder : public DecoderItf {
   // the same with the service's second LM pass (--use-second, kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:53-78): the determinized
   // lattice composed with the old LM (rescaled by -1) and with the new one -- ComposeLattice twice (newfst/compose-lat-inl.h), on the device
   bool GetLattice(Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs = true);
-  // OnlineClgLatticeFastDecoder::GetNbest (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105):
-  // the n (<= 16) cheapest distinct word sequences of the pruned lattice, each as a linear Lattice
-  // whose arcs carry the words as olabels (ilabel 0, like the reference's determinized output) and
-  // whose FIRST arc carries the path's whole weight (graph = lm_score, acoustic = tot - lm), so
-  // that LatticeToVector gives words, tot_score and lm_score.  Same conditions as GetRawLattice.
+  // OnlineClgLatticeFastDecoder::GetNbest (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105): GetLattice + NShortestPath +
+  // ConvertNbestToVector (newfst/lattice-to-nbest.cc), on the device: the n (<= 4096) cheapest paths of the determinized lattice,
+  // each a linear Lattice with that lattice's own arcs on it (ilabel 0, olabel = word, both costs per arc) between the epsilon
+  // arcs the reference's Reverse / AddSuperFinalState leave -- arc for arc what the reference returns.  With LMs: over the
+  // second-pass lattice (--use-second).  Same conditions as GetRawLattice.
   bool GetNbest(std::vector<Lattice> &nbest_paths, int n);
+  bool GetNbest(std::vector<Lattice> &nbest_paths, int n, ArpaLm *oldlm, ArpaLm *newlm);
+  // the short list computed on the raw lattice without determinizing it (n <= 16, every channel of a batch in one launch): the same
+  // word sequences and totals; each path's FIRST arc carries its whole weight (graph = lm_score, acoustic = tot - lm), so that
+  // LatticeToVector gives words, tot_score and lm_score
+  bool GetNbestShortlist(std::vector<Lattice> &nbest_paths, int n);
 
  private:
   void Pull(AmInterface *decodable);
@@ -275,6 +280,8 @@ class GpuBatchDecoder {
   void GetRawLattices(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
                       bool use_final_probs = true, int threads = 0);
   bool GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n);
+  bool GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n, ArpaLm *oldlm, ArpaLm *newlm);
+  bool GetNbestShortlist(int channel, std::vector<Lattice> &nbest_paths, int n);   // (n <= 16; see GpuLatticeDecoder)
   // GetLattice of one channel; the first call after FinalizeDecoding determinizes every finalized channel in one launch
   bool GetLattice(int channel, Lattice *ofst, bool use_final_probs = true);
   bool GetLattice(int channel, Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs = true);   // with the second LM pass

@@ -31,7 +31,7 @@ SYMBOLS = [
     "wfst_decoder_get_profile", "wfst_decoder_get_profile_busy", "wfst_decoder_get_profile_replay", "wfst_decoder_channel_groups", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
-    "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice",
+    "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice", "wfst_decoder_get_nbest_paths",
 ]
 
 
@@ -369,6 +369,30 @@ class BatchDecoder:
                                                        C.byref(ns), C.byref(na), _i32(fin), _i32(src), _i32(dst), _i32(il), _i32(ol),
                                                        _f32(gr), _f32(ac)))
         return dict(n_states=S, st_final=fin, a_src=src, a_dst=dst, a_ilabel=il, a_olabel=ol, a_graph=gr, a_acoustic=ac)
+
+    def nbest_paths(self, channel, n, old_lm=None, new_lm=None, use_final_probs=True):
+        """GetNbest as lattices: NShortestPath over the determinized lattice (with LMs: over its second-pass rescoring), on the
+        device.  List of paths in ascending cost, each dict(olabel, graph, acoustic: per-arc arrays front to back, the last arc
+        the final weight's; tot: the path's cost)."""
+        npth, na = C.c_int32(0), C.c_int32(0)
+        lm1 = old_lm.h if old_lm is not None else None
+        lm2 = new_lm.h if new_lm is not None else None
+        K, A = int(n), min(int(n) * 256, 1 << 22)   # (one call in the common case; a second one with the sizes it returned otherwise)
+        for attempt in range(2):
+            off = np.zeros(K + 1, np.int32)
+            tot = np.zeros(K, np.float32)
+            ol = np.zeros(A, np.int32)
+            gr, ac = np.zeros(A, np.float32), np.zeros(A, np.float32)
+            rc = lib().wfst_decoder_get_nbest_paths(self.h, int(channel), int(n), int(bool(use_final_probs)), lm1, lm2, K, A,
+                                                    C.byref(npth), C.byref(na), _i32(off), _f32(tot), _i32(ol), _f32(gr), _f32(ac))
+            if rc == -4 and attempt == 0 and (npth.value > K or na.value > A):
+                K, A = max(K, npth.value), max(A, na.value)
+                continue
+            _check(rc)
+            break
+        K = npth.value
+        return [dict(olabel=ol[off[i]:off[i + 1]].copy(), graph=gr[off[i]:off[i + 1]].copy(), acoustic=ac[off[i]:off[i + 1]].copy(),
+                     tot=float(tot[i])) for i in range(K)]
 
     def raw_lattices(self, channels=None, use_final_probs=True, threads=0):
         """GetRawLattice of many finalized channels.  The first call fetches the pruned lattices of all

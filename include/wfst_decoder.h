@@ -343,6 +343,21 @@ int wfst_decoder_get_rescored_lattice(wfst_decoder *d, int32_t channel, int32_t 
                                       int32_t *n_arcs, int32_t *st_final, int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel,
                                       int32_t *a_olabel, float *a_graph, float *a_acoustic);
 
+/* GetNbest of the service as it is defined (OnlineClgLatticeFastDecoder::GetNbest, kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105):
+ * NShortestPath (newfst/lattice-to-nbest.cc:15-147) over the lattice GetLattice returns -- the determinized lattice, or with
+ * old_lm / new_lm (both or neither) its second-pass rescoring -- each path with the lattice's own arcs on it, as
+ * ConvertNbestToVector (:149-199) hands them out: path i = arcs path_off[i] .. path_off[i + 1] of a_olabel / a_graph /
+ * a_acoustic, front to back (word or 0, and both costs, of every arc; the last arc of a path is the final weight's
+ * <eps>:<eps> arc), path_tot[i] its cost (arc costs added front to back in float, as NShortestPath adds them), paths in
+ * ascending cost.  On the device: a k-best dynamic program over the lattice resident there; any n up to 4096 (the reference has
+ * no bound; wfst_decoder_get_nbest above is the batched short-list form on the raw lattice, n <= 16, words and totals only).
+ * A determinized lattice has one path per word sequence, so the paths are distinct word sequences.  One channel per call;
+ * finalized channels or mid-utterance.  *n_paths == 0 with WFST_OK: no lattice.  WFST_E_CAPACITY: more paths / arcs than the
+ * given capacities (the sizes are returned), or n paths over this lattice outgrow the path workspace. */
+int wfst_decoder_get_nbest_paths(wfst_decoder *d, int32_t channel, int32_t n, int32_t use_final_probs, const wfst_lm *old_lm,
+                                 const wfst_lm *new_lm, int32_t cap_paths, int32_t cap_arcs, int32_t *n_paths, int32_t *total_arcs,
+                                 int32_t *path_off, float *path_tot, int32_t *a_olabel, float *a_graph, float *a_acoustic);
+
 /* The service's n-best (OnlineClgLatticeFastDecoder::GetNbest, kaldi-nnet3/kaldi-online-nnet3-my-
  * decoder.cc:50-105: GetRawLattice -> DeterminizeLatticeWrapper -> NShortestPath ->
  * ConvertNbestToVector, then LatticeToVector per path) of channels of a lattice-mode decoder, finalized

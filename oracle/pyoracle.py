@@ -549,6 +549,98 @@ def ref_rescore_lattice_file(ref, path, index, lm1, lm2, max_states=1 << 20, max
                       gr[:A].copy(), ac[:A].copy())
 
 
+def ref_nbest_paths_from_lattice_file(ref, path, index, n, lm1=None, lm2=None, max_arcs=1 << 21):
+    """The service's GetNbest as lattices (kaldi-online-nnet3-my-decoder.cc:97-105): determinize [+ ComposeLattice with lm1, lm2] +
+    NShortestPath + ConvertNbestToVector by the compiled reference.  List of paths, each a dict of per-arc arrays
+    (ilabel, olabel, graph, acoustic) in the order the linear lattice is walked from its start; None on failure."""
+    off = np.zeros(n + 2, np.int32)
+    il, ol = np.zeros(max_arcs, np.int32), np.zeros(max_arcs, np.int32)
+    gr, ac = np.zeros(max_arcs, np.float32), np.zeros(max_arcs, np.float32)
+    na = C.c_int(0)
+    f = ref.lib.ref_nbest_paths_from_lattice_file
+    f.restype = C.c_int
+    k = f(path.encode(), int(index), int(n), C.c_void_p(lm1.h if lm1 else None), C.c_void_p(lm2.h if lm2 else None), int(n), _ip(off),
+          max_arcs, C.byref(na), _ip(il), _ip(ol), _fp(gr), _fp(ac))
+    if k < 0 or na.value > max_arcs:
+        return None
+    return [dict(ilabel=il[off[i]:off[i + 1]].copy(), olabel=ol[off[i]:off[i + 1]].copy(), graph=gr[off[i]:off[i + 1]].copy(),
+                 acoustic=ac[off[i]:off[i + 1]].copy()) for i in range(k)]
+
+
+def nshortest_paths(L, n):
+    """NShortestPath + ConvertNbestToVector (newfst/lattice-to-nbest.cc:15-199), restated on a RawLattice whose state 0 is the start
+    (a determinized or rescored lattice): backward best costs in topological order, then best-first expansion of (state, forward
+    cost) pairs ordered by forward + backward cost, a state expanded at most n times, until n paths have reached the super-final
+    state (AddSuperFinalState: a 0-cost arc from every final state).  Forward costs are float32 sums front to back, an arc's cost
+    is graph + acoustic in float32.  Returns the paths in the order they are found: dict(olabel, graph, acoustic, tot), arcs front
+    to back (without the epsilon arcs the two Reverse calls and the super-final state add)."""
+    import heapq
+
+    S = L.n_states
+    out = [[] for _ in range(S)]
+    for k in range(len(L.a_src)):
+        out[int(L.a_src[k])].append(k)
+    val = (L.a_graph.astype(np.float32) + L.a_ac.astype(np.float32)).astype(np.float32)
+    # topological order (TopSort, topsort.cc) -- any one will do for the backward costs
+    indeg = np.zeros(S, np.int64)
+    for k in range(len(L.a_src)):
+        indeg[L.a_dst[k]] += 1
+    order, stack = [], [s for s in range(S) if indeg[s] == 0]
+    while stack:
+        s = stack.pop()
+        order.append(s)
+        for k in out[s]:
+            indeg[L.a_dst[k]] -= 1
+            if indeg[L.a_dst[k]] == 0:
+                stack.append(int(L.a_dst[k]))
+    back = np.full(S + 1, np.inf, np.float32)   # [S] = the super-final state
+    back[S] = 0.0
+    for s in reversed(order):
+        if L.st_final[s]:
+            back[s] = np.float32(0.0) + back[S]   # its arc to the super-final state
+        for k in out[s]:
+            c = np.float32(val[k] + back[L.a_dst[k]])
+            if c < back[s]:
+                back[s] = c
+    pairs = [(0, np.float32(0.0), -1, -1)]   # (state, forward cost, parent pair, arc)
+    heap = [(np.float32(back[0]), 0, 0)]
+    r = {}
+    finals = []
+    seq = 1
+    while heap:
+        _, _, pid = heapq.heappop(heap)
+        st, w, _, _ = pairs[pid]
+        r[st] = r.get(st, 0) + 1
+        if len(finals) == n:
+            break
+        if r[st] > n:
+            continue
+        if st == S:
+            finals.append(pid)
+            continue
+        succ = [(int(L.a_dst[k]), np.float32(w + val[k]), k) for k in out[st]]
+        if L.st_final[st]:
+            succ.append((S, np.float32(w + np.float32(0.0)), -2))
+        for (to, w2, k) in succ:
+            pairs.append((to, w2, pid, k))
+            heapq.heappush(heap, (np.float32(w2 + back[to]), seq, len(pairs) - 1))
+            seq += 1
+    res = []
+    for pid in finals:
+        arcs = []
+        tot = pairs[pid][1]
+        while pid > 0:
+            _, _, par, k = pairs[pid]
+            if k >= 0:
+                arcs.append(k)
+            pid = par
+        arcs.reverse()
+        a = np.array(arcs, np.int64)
+        res.append(dict(olabel=L.a_ol[a].astype(np.int32), graph=L.a_graph[a].astype(np.float32), acoustic=L.a_ac[a].astype(np.float32),
+                        tot=float(tot)))
+    return res
+
+
 def compose_lattice(det, lm, scale=1.0):
     """ComposeLattice (newfst/compose-lat-inl.h:15-130) + Connect (newfst/connect-fst.cc:10-22), restated: `det` a RawLattice (state 0 =
     start), `lm` a pyoracle.Lm of the C oracle (ComposeArpaLm::GetArc / Final / Start = its getarc_many / final / start).  Pairs

@@ -541,6 +541,60 @@ int ref_rescore_lattice_file(const char *path, int index, void *lm1, void *lm2, 
   return 1;
 }
 
+// The service's GetNbest as LATTICES (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105): GetLattice -- determinize, and with
+// lm1 / lm2 given the two ComposeLattice passes of --use-second -- then NShortestPath and ConvertNbestToVector
+// (newfst/lattice-to-nbest.cc:15-199).  Path i = arcs path_off[i] .. path_off[i+1]: the arcs of the i-th linear lattice walked from
+// its start state (labels and both costs of every arc, the epsilon arcs Reverse adds included).  Returns the number of paths,
+// -1 on a read / format failure; *n_arcs is the total even beyond max_arcs.
+int ref_nbest_paths_from_lattice_file(const char *path, int index, int n, void *lm1, void *lm2, int max_paths, int *path_off, int max_arcs,
+                                      int *n_arcs, int *a_il, int *a_ol, float *a_graph, float *a_ac) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return -1;
+  Lattice lat;
+  bool ok = true;
+  for (int i = 0; i <= index && ok; ++i) ok = lat.Read(fp);
+  fclose(fp);
+  if (!ok || !LatticeCheckFormat(&lat)) return -1;
+  Lattice det, lat1, olat;
+  DeterminizeLatticeOptions opts;
+  bool debug = false;
+  if (!DeterminizeLatticeWrapper(&lat, &det, opts, &debug)) return -1;
+  Lattice *src = &det;
+  if (lm1 && lm2) {
+    ComposeArpaLm c1(static_cast<ArpaLm *>(lm1)), c2(static_cast<ArpaLm *>(lm2));
+    ComposeLattice<FsaStateId>(&det, static_cast<LatticeComposeItf<FsaStateId> *>(&c1), &lat1);
+    ComposeLattice<FsaStateId>(&lat1, static_cast<LatticeComposeItf<FsaStateId> *>(&c2), &olat);
+    src = &olat;
+  }
+  Lattice nbest_lat;
+  NShortestPath(*src, &nbest_lat, (size_t)n);
+  std::vector<Lattice> paths;
+  ConvertNbestToVector(nbest_lat, &paths);
+  int k = 0, na = 0;
+  for (size_t i = 0; i < paths.size() && k < max_paths; ++i) {
+    Lattice &P = paths[i];
+    if (P.Start() == kNoStateId) continue;
+    path_off[k] = na;
+    LatticeState *st = P.GetState(P.Start());
+    int guard = 0;
+    while (!st->IsFinal() && st->GetArcSize() > 0 && guard++ < (1 << 20)) {
+      LatticeArc *a = st->GetArc(0);
+      if (na < max_arcs) {
+        a_il[na] = a->_input;
+        a_ol[na] = a->_output;
+        a_graph[na] = a->_w.Value1();
+        a_ac[na] = a->_w.Value2();
+      }
+      ++na;
+      st = P.GetState(a->_to);
+    }
+    ++k;
+  }
+  path_off[k] = na;
+  *n_arcs = na;
+  return k;
+}
+
 // ---------------------------------------------------------------------------------------------
 // biglm (BASELINE configs[3]): the reference's LM automaton and its on-the-fly rescoring decoder.
 // ---------------------------------------------------------------------------------------------

@@ -146,6 +146,59 @@ def test_cli_nbest_matches_the_reference_pipeline(synth, refdec, tmp_path):
 
 
 @pytest.mark.parametrize("mode", ["batch", "single"])
+def test_cli_nbest_lattices_and_second_pass_match_the_reference(mode, synth, refdec, tmp_path):
+    """--nbest-lattice-out: the linear lattices GetNbest returns (host mirror, wfst_decoder_get_nbest_paths) arc for arc -- the
+    epsilon arcs Reverse / AddSuperFinalState leave included -- what the reference's determinizer + NShortestPath +
+    ConvertNbestToVector make of the raw lattices the same run wrote; n = 40 (beyond the short list).  With --second-lm-old /
+    --second-lm-new: the service's --use-second pipeline (ComposeLattice twice before NShortestPath)."""
+    import importlib
+
+    lmsynth = importlib.import_module("asr-decoder_amd.lmsynth")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    V = 200
+    g = synth.make_hclg_like(3000, seed=14, n_tid=300, n_words=V)
+    m = synth.default_tid2pdf(300)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=11\n--lattice-beam=5\n--max-active=1000000\n--min-active=0\n")
+    p1, p2 = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    lmsynth.make_lm(V, 2, 80, 5, 0, 0, seed=301).to_fsa().write(p1)
+    lmsynth.make_lm(V, 3, 120, 8, 500, 5, seed=302).to_fsa().write(p2)
+    mats = [synth.make_loglikes(g, T, 150, m, seed=190 + i, mu=-2.2)[0] for i, T in enumerate([40, 33])]
+    with open(tmp_path / "ll.bin", "wb") as f:
+        for i, x in enumerate(mats):
+            key = ("utt%03d" % i).encode()
+            f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
+    r1, r2 = pyoracle.Lm(refdec, p1, -1.0), pyoracle.Lm(refdec, p2, 1.0)
+    try:
+        for second in (False, True):
+            lat, nlat = str(tmp_path / "raw.bin"), str(tmp_path / "nb.bin")
+            args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--batch=2", "--nbest=40", "--lattice-out=" + lat, "--nbest-lattice-out=" + nlat]
+            args += ["--single-stream"] if mode == "single" else []
+            args += ["--second-lm-old=" + p1, "--second-lm-new=" + p2] if second else []
+            p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
+            assert p.returncode == 0, p.stderr[-2000:]
+            got = pyoracle.parse_lattice_file(open(nlat, "rb").read())
+            k = 0
+            for i in range(len(mats)):
+                ref = pyoracle.ref_nbest_paths_from_lattice_file(refdec, lat, i, 40, r1 if second else None, r2 if second else None)
+                assert ref is not None and len(ref) >= 2
+                for j, R in enumerate(ref):
+                    L = got[k]
+                    k += 1
+                    # a linear lattice: state s --arc--> s + 1, the last state final
+                    assert L.n_states == len(R["olabel"]) + 1 and L.st_final[-1] == 1 and L.st_final.sum() == 1, (i, j)
+                    assert np.array_equal(L.a_src, np.arange(len(R["olabel"]))) and np.array_equal(L.a_dst, L.a_src + 1), (i, j)
+                    assert np.array_equal(L.a_il, R["ilabel"]) and np.array_equal(L.a_ol, R["olabel"]), (i, j, second)
+                    assert np.array_equal(L.a_graph, R["graph"]) and np.array_equal(L.a_ac, R["acoustic"]), (i, j, second)
+            assert k == len(got)
+    finally:
+        r1.free()
+        r2.free()
+
+
+@pytest.mark.parametrize("mode", ["batch", "single"])
 def test_cli_determinized_lattices_match_the_reference_pipeline(mode, synth, refdec, tmp_path):
     """--lattice-out --determinize = GetLattice (base-inl.h:850-866) through the host mirrors: the determinized lattices
     the CLI writes equal the reference's DeterminizeLatticeWrapper run on the raw lattices it writes without the flag."""

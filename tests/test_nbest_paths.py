@@ -1,0 +1,140 @@
+"""GetNbest as the service defines it (VERDICT r2 missing #3): NShortestPath over the lattice GetLattice returns, every path a linear
+lattice carrying the lattice's own arcs (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105, newfst/lattice-to-nbest.cc:15-199), for
+any n -- with and without the second LM pass.
+
+CPU: oracle/pyoracle.py's restatement (nshortest_paths, on the host determinizer's output) against the compiled reference run on the
+same raw lattice.  GPU: wfst_decoder_get_nbest_paths (nbest_paths_kernel over the device's own determinized / rescored lattice)
+against the reference: the same paths in the same order, labels and both costs of every arc bit for bit."""
+import importlib
+
+import numpy as np
+import pytest
+
+import pyoracle
+from test_compose_lattice import _as_dict, _setup
+
+shard = importlib.import_module("asr-decoder_amd.shard")
+
+
+def _strip(p):
+    """a reference path: one epsilon arc in front (the second Reverse's start state), then the lattice's arcs, the final weight's arc,
+    the super-final arc and the first Reverse's epsilon -- all three <eps>:<eps>, the last two free"""
+    il, ol, g, ac = p["ilabel"], p["olabel"], p["graph"], p["acoustic"]
+    assert np.all(il == 0)
+    assert ol[0] == 0 and g[0] == 0 and ac[0] == 0
+    assert np.all(ol[-2:] == 0) and np.all(g[-2:] == 0) and np.all(ac[-2:] == 0)
+    return ol[1:-2], g[1:-2], ac[1:-2]
+
+
+def _same_paths(got, ref, what):
+    assert len(got) == len(ref), "%s: %d paths, the reference has %d" % (what, len(got), len(ref))
+    # same order wherever the costs differ; paths of exactly equal cost may swap (the reference's heap order)
+    key = lambda ol, g, ac: (tuple(ol.tolist()), tuple(g.tolist()), tuple(ac.tolist()))
+    R = [_strip(p) for p in ref]
+    rt = [float(np.float32(sum(np.float32(x) + np.float32(y) for x, y in zip(g, ac)))) for (_, g, ac) in R]
+    i = 0
+    while i < len(got):
+        j = i
+        while j + 1 < len(got) and abs(got[j + 1]["tot"] - got[i]["tot"]) <= 1e-5 * max(1.0, abs(got[i]["tot"])):
+            j += 1
+        a = sorted(key(p["olabel"], p["graph"], p["acoustic"]) for p in got[i : j + 1])
+        b = sorted(key(*r) for r in R[i : j + 1])
+        assert a == b, "%s: paths %d..%d differ" % (what, i, j)
+        i = j + 1
+    tots = [p["tot"] for p in got]
+    assert all(y >= x - 1e-5 * max(1.0, abs(x)) for x, y in zip(tots, tots[1:])), what
+    for p, t in zip(got, rt):
+        assert abs(p["tot"] - t) <= 2e-5 * max(1.0, abs(t)), what
+
+
+def test_nbest_restatement_equals_the_compiled_reference(oracle, refdec, synth, tmp_path):
+    lib = pyoracle.build_det_host()
+    n_checked = 0
+    for seed in range(2):
+        g, m, gp, p1, p2, lls = _setup(synth, tmp_path, seed)
+        h = oracle.load_graph(gp)
+        r1, r2 = pyoracle.Lm(refdec, p1, -1.0), pyoracle.Lm(refdec, p2, 1.0)
+        o1, o2 = pyoracle.Lm(oracle, p1, -1.0), pyoracle.Lm(oracle, p2, 1.0)
+        cd = dict(beam=11.0, max_active=7000, min_active=0, lattice_beam=6.0)
+        try:
+            oracle.set_order_free(True)
+            for u, ll in enumerate(lls):
+                O = pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**cd), ll, m)
+                if not O.ok:
+                    continue
+                p = str(tmp_path / "raw.lat")
+                with open(p, "wb") as f:
+                    f.write(shard.lattice_to_bytes(_as_dict(O)))
+                rc, D = pyoracle.det_host_run(lib, O, cap_scale=32)
+                assert rc == 0
+                for n in (1, 4, 30):
+                    ref = pyoracle.ref_nbest_paths_from_lattice_file(refdec, p, 0, n)
+                    assert ref is not None and 1 <= len(ref) <= n
+                    _same_paths(pyoracle.nshortest_paths(D, n), ref, "seed %d utt %d n %d" % (seed, u, n))
+                C2 = pyoracle.compose_lattice(pyoracle.compose_lattice(D, o1), o2)
+                ref = pyoracle.ref_nbest_paths_from_lattice_file(refdec, p, 0, 12, r1, r2)
+                assert ref is not None
+                _same_paths(pyoracle.nshortest_paths(C2, 12), ref, "seed %d utt %d second pass" % (seed, u))
+                n_checked += 1
+        finally:
+            oracle.set_order_free(False)
+            oracle.free_graph(h)
+            for L in (r1, r2, o1, o2):
+                L.free()
+    assert n_checked >= 4
+
+
+@pytest.mark.gpu
+def test_device_nbest_paths_equal_the_reference(oracle, refdec, synth, tmp_path):
+    import gpu_util as G
+
+    W = G.wfstdec
+    n_checked = 0
+    for seed in range(2):
+        g, m, gp, p1, p2, lls = _setup(synth, tmp_path, seed)
+        graph = W.Graph.load(gp)
+        graph.set_tid2pdf(m)
+        L1, L2 = W.Lm.load(p1, -1.0), W.Lm.load(p2, 1.0)
+        r1, r2 = pyoracle.Lm(refdec, p1, -1.0), pyoracle.Lm(refdec, p2, 1.0)
+        cd = dict(beam=11.0, max_active=7000, min_active=0, lattice_beam=6.0)
+        dec = W.BatchDecoder(graph, G.gpu_config(cd), len(lls), max_frames=64, max_tokens_per_frame=32768, arena_tokens=1 << 20, lattice_links=1 << 21)
+        dev = G.upload(lls)
+        dec.init()
+        dec.advance([t.data_ptr() for t in dev], [20] * len(lls), 300)
+        # mid-utterance: served, ascending, the cheapest path first
+        mid = dec.nbest_paths(0, 7, use_final_probs=False)
+        assert 1 <= len(mid) <= 7 and all(b["tot"] >= a["tot"] for a, b in zip(mid, mid[1:]))
+        dec.advance([t.data_ptr() for t in dev], [40] * len(lls), 300)
+        dec.finalize()
+        for c in range(len(lls)):
+            raw = dec.raw_lattice(c)
+            if raw is None:
+                assert dec.nbest_paths(c, 5) == []
+                continue
+            p = str(tmp_path / "raw.lat")
+            with open(p, "wb") as f:
+                f.write(shard.lattice_to_bytes(raw))
+            for n in (1, 5, 40, 700):
+                ref = pyoracle.ref_nbest_paths_from_lattice_file(refdec, p, 0, n)
+                assert ref is not None
+                _same_paths(dec.nbest_paths(c, n), ref, "seed %d utt %d n %d" % (seed, c, n))
+            for n in (3, 60):
+                ref = pyoracle.ref_nbest_paths_from_lattice_file(refdec, p, 0, n, r1, r2)
+                assert ref is not None
+                _same_paths(dec.nbest_paths(c, n, L1, L2), ref, "seed %d utt %d n %d second pass" % (seed, c, n))
+            # the short list on the raw lattice agrees on the word sequences
+            short = dec.nbest(5)[c]
+            long_ = dec.nbest_paths(c, 5)
+            assert [tuple(x["words"].tolist()) for x in short] == [tuple(int(w) for w in q["olabel"] if w != 0) for q in long_]
+            n_checked += 1
+        with pytest.raises(Exception):
+            dec.nbest_paths(0, 5000)
+        with pytest.raises(Exception):
+            dec.nbest_paths(0, 5, L1, None)
+        dec.free()
+        for L in (r1, r2):
+            L.free()
+        L1.free()
+        L2.free()
+        graph.free()
+    assert n_checked >= 4
