@@ -741,7 +741,7 @@ int wfst_lm_from_arrays(int32_t bos, int32_t eos, int32_t unk, int32_t n_states,
   }
   // the (state, word) table of every state but the empty history (LmDev::hash)
   size_t hsize = 1024;
-  while (hsize < 2 * (size_t)std::max(1, n_arcs - states[0].arc_num)) hsize <<= 1;
+  while (hsize < 4 * (size_t)std::max(1, n_arcs - states[0].arc_num)) hsize <<= 1;   // (at most a quarter full: short probe sequences, lm_step)
   std::vector<int4> htab(hsize, make_int4(-1, -1, 0, 0));
   {
     int64_t o = 0;

@@ -84,7 +84,7 @@ struct LmDev {
   // a probe of this table is one -- and an LM step is a chain of such look-ups (back-off by back-off, LM by LM) that a whole
   // wavefront waits for.  Same arcs, same answers.
   const int4 *hash;
-  uint32_t hmask;      // table size - 1 (a power of two, at most half full)
+  uint32_t hmask;      // table size - 1 (a power of two, at most a quarter full)
 };
 __host__ __device__ inline uint32_t lm_hash(int32_t state, int32_t word) {
   uint32_t h = (uint32_t)state * 0x9E3779B1u ^ ((uint32_t)word + 0x7F4A7C15u) * 0x85EBCA77u;

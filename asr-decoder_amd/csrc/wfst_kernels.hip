@@ -159,28 +159,58 @@ __device__ __forceinline__ float lm_step(const DecoderDev &D, int c, int pair, i
   float r0 = 0.0f, r1 = 0.0f;   // the results: -(back-offs + arc weight)
   int p0 = 0, p1 = 0;           // linear-probe offsets
   bool d0 = false, d1 = false;
+  // kLmProbe consecutive slots of the (state, word) table per round trip (64 bytes, one or two lines): a probe sequence -- the
+  // unsuccessful ones of a back-off above all -- ends within them nearly always, so a back-off level costs ONE trip whatever the
+  // clustering (the wavefront waits for its slowest lane: the tail of the probe lengths was the tail of the launch)
+  constexpr int kLmProbe = 4;
   while (!(d0 && d1)) {
-    int4 e0 = make_int4(0, 0, 0, 0), e1 = e0, b0 = e0, b1 = e0;
+    int4 e0[kLmProbe], e1[kLmProbe], b0 = make_int4(0, 0, 0, 0), b1 = b0;
     int2 x0 = make_int2(0, 0), x1 = x0;
+#pragma unroll
+    for (int q = 0; q < kLmProbe; ++q) e0[q] = e1[q] = make_int4(0, 0, 0, 0);
     if (!d0) {
       if (s0 == 0) x0 = D.lm_old.wt[olabel];
-      else { e0 = D.lm_old.hash[(lm_hash(s0, olabel) + (uint32_t)p0) & D.lm_old.hmask]; b0 = D.lm_old.st[s0]; }
+      else {
+        const uint32_t h = lm_hash(s0, olabel) + (uint32_t)p0;
+#pragma unroll
+        for (int q = 0; q < kLmProbe; ++q) e0[q] = D.lm_old.hash[(h + (uint32_t)q) & D.lm_old.hmask];
+        b0 = D.lm_old.st[s0];
+      }
     }
     if (!d1) {
       if (s1 == 0) x1 = D.lm_new.wt[olabel];
-      else { e1 = D.lm_new.hash[(lm_hash(s1, olabel) + (uint32_t)p1) & D.lm_new.hmask]; b1 = D.lm_new.st[s1]; }
+      else {
+        const uint32_t h = lm_hash(s1, olabel) + (uint32_t)p1;
+#pragma unroll
+        for (int q = 0; q < kLmProbe; ++q) e1[q] = D.lm_new.hash[(h + (uint32_t)q) & D.lm_new.hmask];
+        b1 = D.lm_new.st[s1];
+      }
     }
     if (!d0) {
       if (s0 == 0) { r0 = -1 * (a0 + __int_as_float(x0.x)); *n1 = x0.y; d0 = true; }
-      else if (e0.x == s0 && e0.y == olabel) { r0 = -1 * (a0 + __int_as_float(e0.z)); *n1 = e0.w; d0 = true; }
-      else if (e0.x < 0) { a0 += __int_as_float(b0.z); s0 = b0.w; p0 = 0; }   // no such arc: back off (compose-arpalm.cc:58-64)
-      else ++p0;
+      else {
+        bool decided = false;
+#pragma unroll
+        for (int q = 0; q < kLmProbe; ++q) {
+          if (decided) continue;
+          if (e0[q].x == s0 && e0[q].y == olabel) { r0 = -1 * (a0 + __int_as_float(e0[q].z)); *n1 = e0[q].w; d0 = true; decided = true; }
+          else if (e0[q].x < 0) { a0 += __int_as_float(b0.z); s0 = b0.w; p0 = 0; decided = true; }   // no such arc: back off (compose-arpalm.cc:58-64)
+        }
+        if (!decided) p0 += kLmProbe;
+      }
     }
     if (!d1) {
       if (s1 == 0) { r1 = -1 * (a1 + __int_as_float(x1.x)); *n2 = x1.y; d1 = true; }
-      else if (e1.x == s1 && e1.y == olabel) { r1 = -1 * (a1 + __int_as_float(e1.z)); *n2 = e1.w; d1 = true; }
-      else if (e1.x < 0) { a1 += __int_as_float(b1.z); s1 = b1.w; p1 = 0; }
-      else ++p1;
+      else {
+        bool decided = false;
+#pragma unroll
+        for (int q = 0; q < kLmProbe; ++q) {
+          if (decided) continue;
+          if (e1[q].x == s1 && e1[q].y == olabel) { r1 = -1 * (a1 + __int_as_float(e1[q].z)); *n2 = e1[q].w; d1 = true; decided = true; }
+          else if (e1[q].x < 0) { a1 += __int_as_float(b1.z); s1 = b1.w; p1 = 0; decided = true; }
+        }
+        if (!decided) p1 += kLmProbe;
+      }
     }
   }
   return r0 + r1;
