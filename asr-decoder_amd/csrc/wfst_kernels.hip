@@ -152,8 +152,7 @@ __device__ __forceinline__ int pair_find(const DecoderDev &D, int c, int s1, int
 // speculatively, the state's back-off record are asked for together, for both LMs at once -- instead of the old LM's whole
 // chain, then the new one's (an LM step sits on the critical path of every round of the expansion and of the closure pass:
 // the wavefront waits for its slowest lane's chain).  Same look-ups, same float sums (ComposeArpaLm::GetArc, lm_getarc).
-__device__ __forceinline__ float lm_step(const DecoderDev &D, int c, int pair, int olabel, int *n1, int *n2) {
-  const u64 pk = ld_agent(&D.pair_keys[(size_t)c * D.pair_cap + pair]);
+__device__ __forceinline__ float lm_step_pk(const DecoderDev &D, u64 pk, int olabel, int *n1, int *n2) {   // pk: the pair's two LM states (pair_keys)
   int s0 = (int)(uint32_t)pk, s1 = (int)(uint32_t)(pk >> 32);
   float a0 = 0.0f, a1 = 0.0f;   // sums of the back-off weights so far
   float r0 = 0.0f, r1 = 0.0f;   // the results: -(back-offs + arc weight)
@@ -214,6 +213,9 @@ __device__ __forceinline__ float lm_step(const DecoderDev &D, int c, int pair, i
     }
   }
   return r0 + r1;
+}
+__device__ __forceinline__ float lm_step(const DecoderDev &D, int c, int pair, int olabel, int *n1, int *n2) {
+  return lm_step_pk(D, ld_agent(&D.pair_keys[(size_t)c * D.pair_cap + pair]), olabel, n1, n2);
 }
 
 // debug phase timers (WFST_DBG & 32): slot k accumulates {sum, max, count} of 100 MHz ticks
@@ -389,6 +391,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
   __shared__ int4 s_rec[kChunk];
   __shared__ int s_nemit[kFused ? kTileTokens : 1];  // fused closures: emitting arcs of each token (pseudo arcs follow)
   __shared__ int s_lm[kBig ? kTileTokens : 1];    // biglm: LM pair state of each token of the tile
+  __shared__ u64 s_pk[kBig ? kTileTokens : 1];    //        and the pair's two LM states (asked for with the row headers: one round trip off every LM step)
   __shared__ int s_rec_lm[kBig ? kChunk : 1];     //        and of each sorted candidate
   __shared__ int s_ticket;
 
@@ -446,6 +449,14 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       tk[j] = i < n ? tok[i] : make_int4(0, 0x7F800000, 0, 0);
       if constexpr (kBig) s_lm[i] = i < n ? D.tok_lm[(size_t)c * D.arena_cap + fbegin + i] : 0;
     }
+    u64 pkv[kBig ? kTokPerThread : 1];
+    if constexpr (kBig) {
+#pragma unroll
+      for (int j = 0; j < kTokPerThread; ++j) {
+        const int i = tid * kTokPerThread + j;
+        pkv[j] = i < n ? ld_agent(&D.pair_keys[(size_t)c * D.pair_cap + s_lm[i]]) : 0ull;   // (in flight with the header loads below)
+      }
+    }
 #pragma unroll
     for (int j = 0; j < kTokPerThread; ++j) {
       const int i = tid * kTokPerThread + j;
@@ -482,6 +493,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         nE += nem;
       }
       if constexpr (kFused) s_nemit[i] = nem;
+      if constexpr (kBig) s_pk[i] = pkv[j];
     }
     int tsum = 0;
 #pragma unroll
@@ -635,7 +647,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
             rec_lm[k] = s_lm[lo[k]];
             if (ol != 0) {
               int n1, n2;
-              lm_score = lm_step(D, c, s_lm[lo[k]], ol, &n1, &n2);
+              lm_score = lm_step_pk(D, s_pk[lo[k]], ol, &n1, &n2);
               rec_lm[k] = pair_intern(D, c, ctl, n1, n2);
             }
             graph_cost = __int_as_float(arc.z) + lm_score;
@@ -1597,16 +1609,23 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
         live[k] = live[k] && (__int_as_float(ent[k].z) < cutoff);  // base-inl.h:391
       }
       uint32_t flat[kClosureUnroll];
+      // biglm: what an LM step will need is asked for as early as its address is known -- the pair's LM states with the row header,
+      // the arc's output label with the arc -- two round trips off every round of the pass
+      u64 pk[kBig ? kClosureUnroll : 1];
+      int ol0[kBig ? kClosureUnroll : 1];
 #pragma unroll
       for (int k = 0; k < kClosureUnroll; ++k) {
+        if constexpr (kBig) pk[k] = live[k] ? ld_agent(&D.pair_keys[(size_t)c * D.pair_cap + ent[k].x]) : 0ull;
         const int4 hdr = live[k] ? D.g.arcs[ent[k].y] : make_int4(0, 0, 0, 0);
         si[k] = make_uint2((uint32_t)ent[k].y + 1u, (uint32_t)hdr.x);
         flat[k] = kBig ? 0u : (uint32_t)hdr.w;  // (first eps_flat entry << 3) | entries; 0: iterate
       }
 #pragma unroll
-      for (int k = 0; k < kClosureUnroll; ++k)
-        arc0[k] = !(live[k] && (si[k].y & kEpsMask)) ? make_int4(0, 0, 0, 0)
-                  : (flat[k] & 7u) ? D.g.eps_flat[flat[k] >> 3] : D.g.arcs[si[k].x];
+      for (int k = 0; k < kClosureUnroll; ++k) {
+        const bool has = live[k] && (si[k].y & kEpsMask);
+        arc0[k] = !has ? make_int4(0, 0, 0, 0) : (flat[k] & 7u) ? D.g.eps_flat[flat[k] >> 3] : D.g.arcs[si[k].x];
+        if constexpr (kBig) ol0[k] = has ? D.g.arc_olabel[si[k].x] : 0;
+      }
       // FindOrAddToken (base-inl.h:88-136) for one epsilon arrival: one atomicMin on the state's own
       // slot.  kEpsWon in the low word makes an emitting arc win an exact cost tie, as the
       // reference's first-arrival rule does (emitting arcs are processed before the closure).
@@ -1649,11 +1668,14 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
         for (int k = 0; k < kClosureUnroll; ++k) more |= e < nit[k];
         if (!__ballot(more)) break;
         int4 E[kClosureUnroll];
+        int OL[kBig ? kClosureUnroll : 1];
 #pragma unroll
-        for (int k = 0; k < kClosureUnroll; ++k)
+        for (int k = 0; k < kClosureUnroll; ++k) {
           E[k] = e >= nit[k] ? make_int4(0, 0, 0, 0)
                  : e == 0 ? arc0[k]
                  : (flat[k] & 7u) ? D.g.eps_flat[(flat[k] >> 3) + e] : D.g.arcs[si[k].x + e];
+          if constexpr (kBig) OL[k] = e >= nit[k] ? 0 : e == 0 ? ol0[k] : D.g.arc_olabel[si[k].x + e];
+        }
         int c_ord[kClosureUnroll], c_row[kClosureUnroll], c_lm[kClosureUnroll];
         float c_tot[kClosureUnroll];
         u64 c_packed[kClosureUnroll], c_old[kClosureUnroll];
@@ -1684,12 +1706,12 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
             nZ++;
             float graph_cost = __int_as_float(E[k].z);
             if constexpr (kBig) {  // biglm.h:448-451
-              const int ol = D.g.arc_olabel[a];
+              const int ol = OL[k];
               float lm_score = 0.0f;
               c_lm[k] = ent[k].x;
               if (ol != 0) {
                 int n1, n2;
-                lm_score = lm_step(D, c, ent[k].x, ol, &n1, &n2);
+                lm_score = lm_step_pk(D, pk[k], ol, &n1, &n2);
                 c_lm[k] = pair_intern(D, c, ctl, n1, n2);
               }
               graph_cost = __int_as_float(E[k].z) + lm_score;
