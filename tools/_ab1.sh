@@ -1,9 +1,5 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R"
-for g in 3 3; do
-python3 bench.py --biglm --max-tokens 131072 --groups $g --cpu-sample 0 --no-service-point --no-legs --steps 6 --warmup 2 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernel_ms_per_step']
-print('groups $g  %.2f ms/step  expand %.2f insert %.2f closure %.2f' % (d['ms_per_step'], k['expand'], k['insert'], k['closure']))"
-done
-timeout 900 python -m pytest tests/test_gpu_biglm.py -x -q -m gpu 2>&1 | tail -3
+export WFST_BENCH_BREAKDOWN=1
+python3 bench.py --cpu-sample 0 --no-service-point --no-legs --steps 10 --warmup 3 2>&1 | grep -E "host-side|ms_per_step" | sed -e 's/.*"ms_per_step": \([0-9.]*\).*/ms_per_step \1/'
+python3 bench.py --cpu-sample 0 --no-service-point --no-legs --lattice-links 8388608 --steps 4 --warmup 1 2>&1 | grep -E "host-side|ms_per_step" | sed -e 's/.*"ms_per_step": \([0-9.]*\).*/ms_per_step \1/'
