@@ -610,7 +610,8 @@ int wfst_graph_from_arrays_ex(int32_t start, int32_t final_state, int32_t n_stat
   g->start_eps = next_eps[start];
   g->n_eps_targets = (int32_t)h_targets.size();
   hipError_t e;
-  if ((e = g->arcs.alloc((size_t)N)) != hipSuccess || (e = g->arc_ilabel.alloc((size_t)N)) != hipSuccess ||
+  if ((e = g->arcs.alloc((size_t)N + 8)) != hipSuccess ||   // (+8: kernels that ask for a row's first arcs WITH its header read a few slots past a short row)
+      (e = g->arc_ilabel.alloc((size_t)N)) != hipSuccess ||
       (e = g->arc_olabel.alloc((size_t)N)) != hipSuccess || (e = g->arc_src.alloc((size_t)N)) != hipSuccess ||
       (e = g->eps_target_state.alloc(h_targets.size())) != hipSuccess ||
       (e = g->eps_flat.alloc(std::max<size_t>(1, h_flat.size()))) != hipSuccess ||

@@ -196,7 +196,8 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t error;         // sticky kErr* bits
   int32_t finalized;
   int32_t peak_tokens;
-  int32_t spare0;        // (unused)
+  int32_t emit_n;        // lattice mode on the fused rows: entries of the channel's emitter list (tokens of the frame being built that have
+                         // epsilon arcs out: listed by the insert launch, read and reset by the closure launch's epsilon_links)
   unsigned long long cnt_N, cnt_E, cnt_Z, cnt_tok, cnt_rec;  // work counters since init
   int32_t link_count;    // lattice mode: forward links recorded so far (atomicAdd)
   int32_t lat_arcs;      // lattice mode, after lattice_prune_kernel: surviving links in lat_arcs[]

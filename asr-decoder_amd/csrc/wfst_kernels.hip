@@ -230,6 +230,7 @@ __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned l
   t_prev = now;
 }
 
+constexpr int kEmitChunk = 16;   // entries of the channel's emitter list an insert item reserves up front (lattice mode on the fused rows)
 constexpr u64 kClaimedVal = ~0ull - 1;  // LDS hash value of a state whose token has been written (no record packs to it)
 constexpr int kHeavyItem = 900;  // records: insert items above this are handed out first
 
@@ -1083,6 +1084,8 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   static_assert(sizeof(InsertShared) % 16 == 0, "keep the dynamic LDS base aligned");
   __shared__ InsertShared ish;
   int &s_nstates = ish.nstates, &s_gpos = ish.gpos, &s_wpos = ish.wpos, &s_ok = ish.ok, &s_item = ish.item, &s_last = ish.pad[0];
+  int &s_ech = ish.pad[1], &s_efill = ish.pad[2];   // lattice mode on the fused rows: this item's chunk of the channel's emitter list, entries used
+  constexpr bool kListEmit = kLat && kFused && !kBig;
   __shared__ BoundaryLite bsh;
   u64 *s_best = ish.best;
   int *s_pref = ish.pref;
@@ -1095,6 +1098,10 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   const int item = D.items[(size_t)group * D.item_cap + (it < n_heavy ? it : D.item_cap - 1 - (it - n_heavy))];
   const int c = item >> 16, g0 = (item >> 8) & 0xFF, G = item & 0xFF;
   ChanCtl *ctl = D.ctl + c;
+  if (kListEmit && tid == 0) {   // (asked for now, used in pass 2: the atomic's round trip hides behind pass 1)
+    s_efill = 0;
+    s_ech = G ? atomicAdd(&ctl->emit_n, kEmitChunk) : 0;
+  }
   int n = 0;
   {
     const int32_t *cnts = D.bucket_cnt + (size_t)c * P;
@@ -1280,6 +1287,22 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
               if (ord >= 0) etoki[ord] = idx;
             }
           }
+          if constexpr (kListEmit) {
+            // a token with epsilon arcs out goes on the channel's emitter list (epsilon_links reads the list instead of sweeping
+            // the frame): positions from the item's chunk, beyond it one by one
+            const bool em = winner && (flags & kFlagOutEps);
+            const u64 emm = __ballot(em);
+            if (emm) {
+              int eb = 0;
+              if (lane == 0) eb = atomicAdd(&s_efill, __popcll(emm));
+              eb = __shfl(eb, 0, 64);
+              if (em) {
+                const int p = eb + lane_rank(emm);
+                const int pos = p < kEmitChunk ? s_ech + p : atomicAdd(&ctl->emit_n, 1);
+                if (pos < 8 * D.wl_cap) reinterpret_cast<int32_t *>(D.worklist + (size_t)c * 2 * D.wl_cap)[pos] = idx;
+              }
+            }
+          }
           continue;
         }
         const bool tgt = winner && (flags & kFlagEpsTarget);
@@ -1379,6 +1402,10 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   }
   __syncthreads();
   if (tid == 0) dbg_phase(D, 9, tq);
+  if constexpr (kListEmit) {   // the unused entries of the item's chunk of the emitter list
+    if (G && tid < kEmitChunk && tid >= s_efill && s_ech + tid < 8 * D.wl_cap)
+      reinterpret_cast<int32_t *>(D.worklist + (size_t)c * 2 * D.wl_cap)[s_ech + tid] = -1;
+  }
   best = wave_min_u64(best);
   if (lane == 0) s_best[wave] = best;
   __syncthreads();
@@ -1445,7 +1472,7 @@ struct BoundaryShared {
 // frame has its final cost -- after the closure's fixpoint, or, with fused closures, right after the insert launch.
 // toki[] = the channel's direct-mapped epsilon table: the frame's token on each epsilon-target state.
 template <bool kBig = false>
-__device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff) {
+__device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, bool listed = false) {
   const int tid = threadIdx.x;
   // biglm: a token is (row, LM pair); an epsilon arc with a word label moves the LM (biglm.h:448-456), the link's cost carries
   // the LM difference, and the destination's token is found in the channel's HASHED epsilon table (keys beside toki[])
@@ -1458,34 +1485,40 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
   // cost.  Every token of the frame being built with epsilon arcs out and cost < cutoff emits them.
   int4 *links = D.links + (size_t)c * D.link_cap;
   const int n_frame = sh.nnew;
-  // (1) compact the tokens that emit (a few percent of the frame) -- the closure worklists are
-  // free by now and serve as the list -- so that (2) runs its dependent gathers with full waves
+  // (1) the tokens that emit (a few percent of the frame), as arena indices (-1: none) in the channel's worklist space (free by
+  // now): LISTED by the insert launch on the fused rows (insert_body, kListEmit -- every token it writes is below the final
+  // cutoff), else compacted here by a sweep over the frame -- so that (2) runs its dependent gathers with full waves
   int32_t *emit = reinterpret_cast<int32_t *>(D.worklist + (size_t)c * 2 * D.wl_cap);
-  if (tid == 0) sh.nemit = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < n_frame; i0 += 4 * kBT) {  // 4 independent loads in flight per thread
-    int4 T[4];
+  int n_emit = 0;
+  if (listed && D.ctl[c].emit_n <= 8 * D.wl_cap) {
+    n_emit = D.ctl[c].emit_n;
+  } else {
+    if (tid == 0) sh.nemit = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_frame; i0 += 4 * kBT) {  // 4 independent loads in flight per thread
+      int4 T[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * kBT + tid;
-      T[u] = i < n_frame ? tok[base + i] : make_int4(0, 0, 0, 0);
-    }
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kBT + tid;
+        T[u] = i < n_frame ? tok[base + i] : make_int4(0, 0, 0, 0);
+      }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * kBT + tid;
-      const bool on = i < n_frame && ((uint32_t)T[u].w & kFlagOutEps) && (__int_as_float(T[u].y) < cutoff);
-      const u64 m = __ballot(on);
-      int wb = 0;
-      if ((tid & 63) == 0 && m) wb = atomicAdd(&sh.nemit, __popcll(m));
-      wb = __shfl(wb, 0, 64);
-      if (on) emit[wb + lane_rank(m)] = i;
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kBT + tid;
+        const bool on = i < n_frame && ((uint32_t)T[u].w & kFlagOutEps) && (__int_as_float(T[u].y) < cutoff);
+        const u64 m = __ballot(on);
+        int wb = 0;
+        if ((tid & 63) == 0 && m) wb = atomicAdd(&sh.nemit, __popcll(m));
+        wb = __shfl(wb, 0, 64);
+        if (on) emit[wb + lane_rank(m)] = base + i;
+      }
     }
+    __syncthreads();
+    n_emit = sh.nemit;
   }
-  __syncthreads();
-  const int n_emit = sh.nemit;
   for (int j0 = 0; j0 < n_emit; j0 += kBT) {
     const int j = j0 + tid;
-    int i = 0, row = 0, neps = 0, npass = 0;
+    int idx = -1, row = 0, neps = 0, npass = 0;
     float cost = 0.0f;
     int plm = 0;
     // cost of the arrival over epsilon arc a from this token, and (biglm) the LM pair it arrives with
@@ -1505,14 +1538,24 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
         return cost + __int_as_float(arc.z);
       }
     };
-    if (j < n_emit) {
-      i = emit[j];
-      const int4 T = tok[base + i];
+    // the first epsilon arcs of the row are asked for WITH its header (their addresses need only the row; a state has one or
+    // two epsilon arcs nearly always): token -> {header, arcs} -> destination tokens -> links, four round trips
+    constexpr int kSpec = kBig ? 1 : 3;
+    int4 A[kSpec];
+    if (j < n_emit) idx = emit[j];
+    if (idx >= 0) {
+      const int4 T = tok[idx];
       row = T.x;
       cost = __int_as_float(T.y);
-      if constexpr (kBig) plm = tlm[base + i];
-      neps = (int)((uint32_t)D.g.arcs[row].x & kEpsMask);
-      for (int e = 0; e < neps; ++e) { int nl; npass += arrival(row + 1 + e, D.g.arcs[row + 1 + e], &nl) < cutoff; }
+      if (!(cost < cutoff) || !((uint32_t)T.w & kFlagOutEps)) idx = -1;
+    }
+    if (idx >= 0) {
+      if constexpr (kBig) plm = tlm[idx];
+      const int4 hdr = D.g.arcs[row];
+#pragma unroll
+      for (int e = 0; e < kSpec; ++e) A[e] = D.g.arcs[row + 1 + e];   // (rows end in padding up to their line: reading past the last arc stays in the image)
+      neps = (int)((uint32_t)hdr.x & kEpsMask);
+      for (int e = 0; e < neps; ++e) { int nl; npass += arrival(row + 1 + e, e < kSpec ? A[e < kSpec ? e : 0] : D.g.arcs[row + 1 + e], &nl) < cutoff; }
     }
     // one atomicAdd per wave for all its links
     int ps = npass;
@@ -1528,7 +1571,7 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
     int lp = lb + ps - npass;
     for (int e = 0; e < neps && npass; ++e) {
       const int a = row + 1 + e;
-      const int4 arc = D.g.arcs[a];
+      const int4 arc = e < kSpec ? A[e < kSpec ? e : 0] : D.g.arcs[a];
       int nlm;
       const float tot = arrival(a, arc, &nlm);
       if (!(tot < cutoff)) continue;
@@ -1549,7 +1592,7 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
       // the closure pass); an entry from an older frame would mean that invariant broke: reported, never linked
       const int dst = ord >= 0 ? ld_agent(&toki[ord]) : -1;
       if (dst < base) atomicOr(&sh.err, kErrInternal);
-      else if ((int64_t)lp < D.link_cap) links[lp] = make_int4(base + i, dst, a, __float_as_int(tot));
+      else if ((int64_t)lp < D.link_cap) links[lp] = make_int4(idx, dst, a, __float_as_int(tot));
       else atomicOr(&sh.err, kErrLinksFull);
       ++lp;
     }
@@ -1848,8 +1891,9 @@ __device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanC
     if constexpr (kLat) {
       // lattice mode: all that is left of ProcessNonemitting are the epsilon links, one flat pass over the frame
       const bool fits = sh.nnew <= D.max_tok && (int64_t)base + sh.nnew <= D.arena_cap && ctl->error == 0;
-      if (fits) epsilon_links(D, c, sh, base, cutoff);
+      if (fits) epsilon_links(D, c, sh, base, cutoff, true);
       __syncthreads();
+      if (tid == 0) ctl->emit_n = 0;   // (the next frame's insert launch lists afresh)
     }
   } else {
     epsilon_closure<kLat, kBig>(D, c, sh, base, cutoff, &nZ);
