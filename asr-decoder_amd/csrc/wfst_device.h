@@ -196,8 +196,7 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t error;         // sticky kErr* bits
   int32_t finalized;
   int32_t peak_tokens;
-  int32_t emit_n;        // lattice mode on the fused rows: entries of the channel's emitter list (tokens of the frame being built that have
-                         // epsilon arcs out: listed by the insert launch, read and reset by the closure launch's epsilon_links)
+  int32_t spare0;        // (unused)
   unsigned long long cnt_N, cnt_E, cnt_Z, cnt_tok, cnt_rec;  // work counters since init
   int32_t link_count;    // lattice mode: forward links recorded so far (atomicAdd)
   int32_t lat_arcs;      // lattice mode, after lattice_prune_kernel: surviving links in lat_arcs[]
@@ -267,6 +266,9 @@ struct DecoderDev {
   float *cutoff_hist;
   int4 *bucket;
   int32_t *bucket_cnt;
+  int32_t *emit_cnt;     // [c][32] (a line each): lattice mode on the fused rows -- entries of the channel's emitter list (the tokens of the
+                         // frame being built that have epsilon arcs out: listed by the insert launch in the channel's worklist space,
+                         // read and reset by the closure launch's epsilon_links)
   unsigned long long *eps_vals;
   int32_t *eps_toki;
   int32_t *eps_occ_list;        // [c][wl_cap] ordinals touched this frame

@@ -1098,9 +1098,12 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   const int item = D.items[(size_t)group * D.item_cap + (it < n_heavy ? it : D.item_cap - 1 - (it - n_heavy))];
   const int c = item >> 16, g0 = (item >> 8) & 0xFF, G = item & 0xFF;
   ChanCtl *ctl = D.ctl + c;
-  if (kListEmit && tid == 0) {   // (asked for now, used in pass 2: the atomic's round trip hides behind pass 1)
+  // this item's chunk of the channel's emitter list: asked for now, its answer is looked at after pass 1 (the atomic's round
+  // trip hides behind the record loads); the list's counter has a line of its own (the channel's control line is busy enough)
+  int ech_reg = 0;
+  if (kListEmit && tid == 0) {
     s_efill = 0;
-    s_ech = G ? atomicAdd(&ctl->emit_n, kEmitChunk) : 0;
+    if (G) ech_reg = atomicAdd(&D.emit_cnt[c * 32], kEmitChunk);
   }
   int n = 0;
   {
@@ -1209,6 +1212,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
     if (tid == 0) {
       int g = atomicAdd(&ctl->new_count, ns);
       s_gpos = g;
+      if constexpr (kListEmit) s_ech = ech_reg;
       if (g + ns > D.max_tok) { atomicOr(&ctl->error, kErrFrontierFull); s_ok = 0; }
       if ((int64_t)base + g + ns > D.arena_cap) { atomicOr(&ctl->error, kErrArenaFull); s_ok = 0; }
     }
@@ -1296,9 +1300,15 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
               int eb = 0;
               if (lane == 0) eb = atomicAdd(&s_efill, __popcll(emm));
               eb = __shfl(eb, 0, 64);
+              const int p = eb + lane_rank(emm);
+              const u64 ovm = __ballot(em && p >= kEmitChunk);   // beyond the chunk: one more atomic for the wave's overflow
+              int ob = 0;
+              if (ovm) {
+                if (lane == 0) ob = atomicAdd(&D.emit_cnt[c * 32], __popcll(ovm));
+                ob = __shfl(ob, 0, 64);
+              }
               if (em) {
-                const int p = eb + lane_rank(emm);
-                const int pos = p < kEmitChunk ? s_ech + p : atomicAdd(&ctl->emit_n, 1);
+                const int pos = p < kEmitChunk ? s_ech + p : ob + lane_rank(ovm);
                 if (pos < 8 * D.wl_cap) reinterpret_cast<int32_t *>(D.worklist + (size_t)c * 2 * D.wl_cap)[pos] = idx;
               }
             }
@@ -1490,8 +1500,8 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
   // cutoff), else compacted here by a sweep over the frame -- so that (2) runs its dependent gathers with full waves
   int32_t *emit = reinterpret_cast<int32_t *>(D.worklist + (size_t)c * 2 * D.wl_cap);
   int n_emit = 0;
-  if (listed && D.ctl[c].emit_n <= 8 * D.wl_cap) {
-    n_emit = D.ctl[c].emit_n;
+  if (listed && D.emit_cnt[c * 32] <= 8 * D.wl_cap) {
+    n_emit = D.emit_cnt[c * 32];
   } else {
     if (tid == 0) sh.nemit = 0;
     __syncthreads();
@@ -1893,7 +1903,7 @@ __device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanC
       const bool fits = sh.nnew <= D.max_tok && (int64_t)base + sh.nnew <= D.arena_cap && ctl->error == 0;
       if (fits) epsilon_links(D, c, sh, base, cutoff, true);
       __syncthreads();
-      if (tid == 0) ctl->emit_n = 0;   // (the next frame's insert launch lists afresh)
+      if (tid == 0) D.emit_cnt[c * 32] = 0;   // (the next frame's insert launch lists afresh)
     }
   } else {
     epsilon_closure<kLat, kBig>(D, c, sh, base, cutoff, &nZ);
@@ -3179,6 +3189,7 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
   __syncthreads();
   if (tid == 0) {
     if (D.lat_stats) for (int q = 0; q < 4; ++q) D.lat_stats[(size_t)c * 4 + q] = 0;
+    D.emit_cnt[c * 32] = 0;
     ChanCtl z;
     memset(&z, 0, sizeof(z));
     z.best_next = ~0ull;
