@@ -2350,7 +2350,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
   // A pass is a chain of short phases over a few thousand links or tokens each: latency, not bytes.  Every
   // thread therefore takes kPU items of a phase at once -- the link loads together, then the gathers of the
   // destinations' {extra, cost}, then the atomics -- instead of one dependent chain per item.
-  constexpr int kPU = 6;
+  constexpr int kPU = 6;   // (8: the same; 10: spills, +4 %)
   // f(i, L, le): link i = L is alive and its link_extra is le (maybe above lattice_beam)
   auto for_links = [&](int lo, int hi, auto &&f) {
     for (int i0 = lo; i0 < hi; i0 += kBT * kPU) {
@@ -2474,12 +2474,15 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     k_lo = k;
     st_links += (u64)(lmid[k + 1] - loff[k + 1]) + 2ull * (u64)(loff[k + 1] - lmid[k]);   // (an epsilon link: priced, then confirmed)
     st_toks += (u64)nk;
-    if (nk <= kPrLds) {
+    if (nk <= 2 * kPrLds) {
       // ---- the frame in LDS ----
+      // (WIDE frames, kPrLds < nk <= 2 kPrLds -- the raw frames of a heavy channel at beam 15: only the 4-byte extras live in LDS,
+      // 32 768 of them; the costs the epsilon links and the write-back need are read from the tokens)
+      const bool wide = nk > kPrLds;
       // Placement: the pairs of frame k+1 sit at one end of the buffer (left there by the step before); frame k's go to the
       // other end.  Where both do not fit, frame k+1's are read from HBM instead (next_lds false).
       const bool next_had = have == k + 1;                 // frame k+1's pairs are in LDS (at the `hb` end)
-      const bool next_fits = n1 + nk <= kPrLds;
+      const bool next_fits = !wide && n1 + nk <= kPrLds;
       uint2 *E1 = nullptr;
       int cur_end;                                          // 0: frame k at the low end, 1: at the high end
       if (next_had && next_fits) {
@@ -2495,7 +2498,8 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       } else {
         cur_end = 0;                                        // frame k alone; its successor's pairs come from HBM link by link
       }
-      uint2 *E0 = cur_end == 0 ? ps.w.e : ps.w.e + (kPrLds - nk);
+      uint2 *E0 = (cur_end == 0 || wide) ? ps.w.e : ps.w.e + (kPrLds - nk);
+      uint32_t *E0x = reinterpret_cast<uint32_t *>(ps.w.e);   // (wide frames)
       // everything a SMALL frame needs from HBM is asked for at once, before the first barrier: the tokens' costs, their
       // extras of the previous pass, its emitting links and epsilon links (a pruned frame: a few hundred tokens, a
       // thousand links); a larger one streams them
@@ -2530,6 +2534,9 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
           if (i < nk) E0[i] = make_uint2(kInfO, (uint32_t)cy[u]);
         }
       } else {
+        if (wide) {
+          for (int i = tid; i < nk; i += kBT) E0x[i] = kInfO;
+        } else {
         for (int i0 = 0; i0 < nk; i0 += 4 * kBT) {   // four loads in flight per thread
           int c4[4];
 #pragma unroll
@@ -2537,15 +2544,19 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
 #pragma unroll
           for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBT + tid; if (i < nk) E0[i] = make_uint2(kInfO, (uint32_t)c4[u]); }
         }
+        }
       }
       // (flags: three in rotation, so that a round needs ONE barrier -- flag r % 3 is raised in round r and read after the round's
       // barrier; the next round's flag is cleared during this round, when nobody reads or raises it)
       if (tid < 3) ps.flag[tid] = 0;
       __syncthreads();
       auto price0 = [&](const int4 &X) -> float {   // a link into frame k itself (epsilon links)
-        const uint2 en = E0[X.y - fk];
+        uint2 en;
+        if (wide) { en.x = E0x[X.y - fk]; en.y = en.x >= kInfO ? 0u : (uint32_t)tok[X.y].y; }
+        else en = E0[X.y - fk];
         return en.x >= kInfO ? kInf : o2f(en.x) + (__int_as_float(X.w) - __uint_as_float(en.y));
       };
+      auto min0 = [&](int i, uint32_t o) -> uint32_t { return wide ? atomicMin(&E0x[i], o) : atomicMin(&E0[i].x, o); };
       // emitting links frame k -> k+1
       for (int i0 = m_lo; i0 < m_hi; i0 += kBT * kPU) {
         if (i0 != m_lo) {
@@ -2573,7 +2584,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
           float le = eo >= kInfO ? kInf : o2f(eo) + (__int_as_float(ML[u].w) - __int_as_float((int)(en[u] >> 32)));
           if (!(le <= lb)) { links[i0 + u * kBT + tid].x = -1; continue; }
           if (le < 0.0f) le = 0.0f;
-          atomicMin(&E0[ML[u].x - fk].x, f2o(le));
+          min0(ML[u].x - fk, f2o(le));
         }
       }
       __syncthreads();
@@ -2589,7 +2600,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
               if (!(le <= lb)) continue;
               if (le < 0.0f) le = 0.0f;
               const uint32_t o = f2o(le);
-              if (o < atomicMin(&E0[EL[u].x - fk].x, o)) ch = 1;
+              if (o < min0(EL[u].x - fk, o)) ch = 1;
             }
           } else {
             for (int i = e0 + tid; i < e1; i += kBT) {
@@ -2599,7 +2610,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
               if (!(le <= lb)) continue;
               if (le < 0.0f) le = 0.0f;
               const uint32_t o = f2o(le);
-              if (o < atomicMin(&E0[X.x - fk].x, o)) ch = 1;
+              if (o < min0(X.x - fk, o)) ch = 1;
             }
           }
           const int fl = round % 3;
@@ -2640,13 +2651,18 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       } else {
         for (int i0 = 0; i0 < nk; i0 += 4 * kBT) {
           uint32_t o4[4];
+          int c4[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBT + tid; o4[u] = (!kFinal && had_old && i < nk) ? extra[fk + i].x : 0u; }
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kBT + tid;
+            o4[u] = (!kFinal && had_old && i < nk) ? extra[fk + i].x : 0u;
+            c4[u] = (wide && i < nk) ? tok[fk + i].y : 0;
+          }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * kBT + tid;
             if (i >= nk) continue;
-            const uint2 v = E0[i];
+            const uint2 v = wide ? make_uint2(E0x[i], (uint32_t)c4[u]) : E0[i];
             if (!kFinal) {
               const float now = o2f(v.x);
               const float was = had_old ? o2f(o4[u]) : 0.0f;
@@ -2664,7 +2680,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
         moved = ps.any_changed != 0;
       }
       __syncthreads();   // (the next frame rewrites the other end of the buffer and the flags)
-      have = k;
+      have = wide ? -1 : k;   // (a wide frame leaves extras only: its predecessor reads the pairs from HBM)
       hb = cur_end;
       if (tid == 0 && (D.dbg & 32)) atomicAdd(&D.dbg_t[42], 1ull);
       continue;

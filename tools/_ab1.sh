@@ -1,7 +1,7 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R"
 for rep in 1 2; do
-for v in "" nolist; do
+for v in "" kpu8 kpu10; do
 WFST_LIB_VARIANT="$v" python3 bench.py --groups 2 --cpu-sample 0 --no-service-point --no-legs --lattice-links 8388608 --steps 6 --warmup 3 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernel_ms_per_step']
