@@ -1078,6 +1078,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   // (64-bit LDS atomics on a misaligned table are replayed: cdna_hip_programming.md Guideline 17)
   struct __attribute__((aligned(16))) InsertShared {
     int nstates, gpos, wpos, ok, item, pad[3];
+    int lw[12];   // lattice mode: links per wave of the item, [8] = the item's first link
     u64 best[kInsertThreads / 64];
     int pref[68];  // record offsets of the buckets of the current item
   };
@@ -1360,19 +1361,36 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
       __syncthreads();
       int4 *links = D.links + (size_t)c * D.link_cap;
       if (one_sweep) {
+        // ONE atomic on the channel's link counter per item (a wave-by-wave append was ~800 returning atomics on one address per
+        // frame of a heavy channel at beam 15, serialised in L2 -- and on the control line every other atomic of the frame uses):
+        // links per thread -> prefix over the workgroup -> the item's block
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kInsertUnroll; ++k) cnt += lk_slot[k] >= 0;
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int v = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += v;
+        }
+        if (lane == 63) ish.lw[wave] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kInsertThreads / 64; ++w) {
+          const int v = ish.lw[w];
+          if (w < wave) wbase += v;
+          tot += v;
+        }
+        if (tid == 0) ish.lw[8] = tot ? atomicAdd(&ctl->link_count, tot) : 0;
+        __syncthreads();
+        int lp = ish.lw[8] + wbase + incl - cnt;
 #pragma unroll
         for (int k = 0; k < kInsertUnroll; ++k) {
-          const bool live = lk_slot[k] >= 0;
-          const u64 lm = __ballot(live);
-          if (!lm) continue;
-          int lb = 0;
-          if (lane == 0) lb = atomicAdd(&ctl->link_count, __popcll(lm));
-          lb = __shfl(lb, 0, 64);
-          if (live) {
-            const int lp = lb + lane_rank(lm);
-            if ((int64_t)lp < D.link_cap) links[lp] = make_int4(lk_src[k], tidx[lk_slot[k]], lk_arc[k], lk_cost[k]);
-            else atomicOr(&ctl->error, kErrLinksFull);
-          }
+          if (lk_slot[k] < 0) continue;
+          if ((int64_t)lp < D.link_cap) links[lp] = make_int4(lk_src[k], tidx[lk_slot[k]], lk_arc[k], lk_cost[k]);
+          else atomicOr(&ctl->error, kErrLinksFull);
+          ++lp;
         }
       } else {
       for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {

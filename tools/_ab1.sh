@@ -1,7 +1,7 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R"
 for rep in 1 2; do
-for v in "" kpu8 kpu10; do
+for v in ""; do
 WFST_LIB_VARIANT="$v" python3 bench.py --groups 2 --cpu-sample 0 --no-service-point --no-legs --lattice-links 8388608 --steps 6 --warmup 3 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernel_ms_per_step']
@@ -12,3 +12,4 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernel
 print('beam15 [%-6s] %.2f ms/step  %.0f f/s expand %.2f insert %.2f closure %.2f' % ('$v', d['ms_per_step'], d['value'], k['expand'], k['insert'], k['closure']))"
 done
 done
+timeout 1500 python -m pytest tests/test_gpu_lattice.py tests/test_gpu_running_prune.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -3
