@@ -464,7 +464,7 @@ WFST_HD inline void det_process_state(DetWs &W, int32_t out) {
 // Table initialisation, shared out over `nthreads` callers (the device calls it workgroup-wide, tid = thread index;
 // the host once with (0, 1)).  A barrier must separate it from det_run.
 WFST_HD inline void det_init(DetWs &W, int32_t tid, int32_t nthreads) {
-  for (int32_t i = tid; i < 2 * W.cap.trie; i += nthreads) W.tr_hash[i] = -1;
+  for (int32_t i = tid; i < W.tr_hcap; i += nthreads) W.tr_hash[i] = -1;   // (the slots in use: the device starts with a part of the table)
   for (int32_t i = tid; i < 2 * W.cap.states; i += nthreads) W.mh_head[i] = -1;
   for (int32_t i = tid; i < 2 * W.cap.initials; i += nthreads) W.ih_head[i] = -1;
   for (int32_t s = tid; s < W.n_states; s += nthreads) {

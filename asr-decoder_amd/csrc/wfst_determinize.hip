@@ -115,10 +115,29 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
     det_carve(W, rest, X.caps, nt);
   }
   __syncthreads();
-  det_init(W, tid, kDetThreads);
-  __syncthreads();
+  // The string trie's hash table is carved for the workspace's full capacity (a million slots, 4 MB); a lattice of a few thousand
+  // states makes 1.5-2 nodes per raw state, so the table is first used at 16 slots per raw state (a few hundred KB: its probes
+  // stay in L2) and the construction is run again over the whole table in the rare case that it outgrows that.
+  __shared__ int s_err;
+  const int32_t hcap_full = W.tr_hcap;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (tid == 0) {
+      int32_t h = hcap_full;
+      if (attempt == 0) {
+        h = 4096;
+        while (h < 16 * nt && h < hcap_full) h <<= 1;
+      }
+      W.tr_hcap = h < hcap_full ? h : hcap_full;
+    }
+    __syncthreads();
+    det_init(W, tid, kDetThreads);
+    __syncthreads();
+    if (tid == 0) s_err = det_run(W);
+    __syncthreads();
+    if (!(s_err == 1 && W.tr_hcap < hcap_full)) break;   // (1: the trie -- its node array or its hash table -- was outgrown)
+  }
   if (tid == 0) {
-    const int err = det_run(W);
+    const int err = s_err;
     // OutputNoolabel (lattice-determinize.h:307-377) + Invert: arcs {src, dst, 0, word, graph, acoustic}; a final weight is
     // an arc <eps>:<eps> to an extra final state
     int4 *oa = X.out_a + (size_t)slot * X.out_cap;
