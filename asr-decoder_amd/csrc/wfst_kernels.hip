@@ -3514,6 +3514,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
 // GetRawLattice's raw material: every token and link alive right now, resolved to labels and costs, in the
 // channel's compact lat_toks[] / lat_arcs[].  use_final != 0: final states by ComputeFinalCosts (base-inl.h:
 // 670-720, 924-940): the graph-final tokens of the newest frame if there are any, else all of it.
+constexpr int kEmitFrames = 4096, kEmitU = 8;   // frames whose bounds lattice_emit_kernel keeps in LDS (longer utterances read them from HBM); items per thread and sweep
 __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const int32_t *chans, int use_final) {
   const int c = chans ? chans[blockIdx.x] : blockIdx.x;
   const int tid = threadIdx.x;
@@ -3528,6 +3529,9 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
   const int32_t *lmid = D.link_mid + (size_t)c * (D.max_frames + 3);
   const float *ll = D.ll_base[c];
   __shared__ int s_any_final, s_narcs, s_ntoks, s_err;
+#if defined(WFST_EXP_EMIT_T)
+  const long long te0 = wall_clock64();
+#endif
   if (tid == 0) { s_any_final = 0; s_narcs = 0; s_ntoks = 0; s_err = 0; }
   __syncthreads();
   if (ctl->error) return;
@@ -3545,66 +3549,126 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
   const uint32_t kInfO = f2o(__builtin_huge_valf());
   const int pruned_upto = ctl->pruned_upto;
   const bool finalized = ctl->finalized != 0;
-  {  // in arena order (= frame order; the n-best search relies on a frame's states being contiguous)
+  // The frame bounds (tokens) and the link segments' bounds go to LDS: every token and every link finds its frame by a binary search.
+  __shared__ int s_foff[kEmitFrames + 2], s_lseg[2 * (kEmitFrames + 2)];   // s_lseg[2 f] = loff[f], [2 f + 1] = lmid[f]
+  const bool in_lds = nd + 2 <= kEmitFrames + 2;
+  if (in_lds) {
+    for (int f = tid; f <= nd + 1; f += kBT) { s_foff[f] = foff[f]; s_lseg[2 * f] = loff[f]; s_lseg[2 * f + 1] = f <= nd ? lmid[f] : loff[f]; }
+  }
+  __syncthreads();
+  auto emit_all = [&](auto foff_at, auto lseg_at) {
+  {  // in arena order (= frame order; the n-best search relies on a frame's states being contiguous): kEmitU tokens per thread
+     // and sweep (consecutive ones, so that a thread's survivors stay in order), one workgroup-wide prefix per sweep
     __shared__ ScanShared ps;
-    const int n_all = foff[nd + 1];
+    const int n_all = foff_at(nd + 1);
+    const int f_pruned = foff_at(min(max(pruned_upto, 0), nd + 1)), f_one = foff_at(1);   // first token of the first unpriced frame; of frame 1
     int base = 0;
-    for (int i0 = 0; i0 < n_all; i0 += kBT) {
-      const int i = i0 + tid;
-      int f = 0;
-      bool alive = false;
-      if (i < n_all) {
-        int lo = 0, hi = nd + 1;  // frame of token i: foff[f] <= i < foff[f+1]
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (foff[mid] <= i) lo = mid; else hi = mid;
+    for (int i0 = 0; i0 < n_all; i0 += kBT * kEmitU) {
+      int fr[kEmitU];
+      bool alive[kEmitU];
+      uint32_t ex[kEmitU];
+#pragma unroll
+      for (int u = 0; u < kEmitU; ++u) {
+        const int i = i0 + tid * kEmitU + u;
+        ex[u] = i < n_all ? extra[i].x : 0u;
+      }
+      int cnt = 0;
+#pragma unroll
+      for (int u = 0; u < kEmitU; ++u) {
+        const int i = i0 + tid * kEmitU + u;
+        fr[u] = 0;
+        // dead = priced by the back-pruning (its frame is below pruned_upto), extra +inf, and not one of frame 0's before
+        // FinalizeDecoding; only the living look their frame up
+        alive[u] = i < n_all && !(ex[u] >= kInfO && i < f_pruned && !(i < f_one && !finalized));
+        if (alive[u]) {
+          int lo = 0, hi = nd + 1;  // frame of token i: foff[f] <= i < foff[f+1]
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (foff_at(mid) <= i) lo = mid; else hi = mid;
+          }
+          fr[u] = lo;
         }
-        f = lo;
-        alive = !(f < pruned_upto && !(f == 0 && !finalized) && extra[i].x >= kInfO);
+        cnt += alive[u] ? 1 : 0;
       }
       int tot;
-      const int p = base + block_exscan(alive ? 1 : 0, ps, &tot);
-      if (alive) {
+      int p = base + block_exscan(cnt, ps, &tot);
+#pragma unroll
+      for (int u = 0; u < kEmitU; ++u) {
+        if (!alive[u]) continue;
+        const int i = i0 + tid * kEmitU + u;
         if (p >= D.lat_tok_cap) s_err = 1;
         else {
           const int4 t = tok[i];
+          const int f = fr[u];
           const int fin = (f == nd && (!use_final || !any_final || t.x == D.g.final_state)) ? 1 : 0;
           out_toks[p] = make_int4(i, D.g.arcs[t.x].y, t.y, f | (fin << 30));  // .y: the graph's own state id (row header)
         }
+        ++p;
       }
       base += tot;
     }
     if (tid == 0) s_ntoks = base;
     __syncthreads();
+#if defined(WFST_EXP_EMIT_T)
+    if (tid == 0 && blockIdx.x < 3) printf("EMIT c %d n_all %d toks %d t_tok %lld\n", c, n_all, base, wall_clock64() - te0);
+#endif
   }
-  // links, segment by segment (the segment tells the source frame and whether the arc is an epsilon)
-  for (int f = 0; f <= nd; ++f) {
-    for (int part = 0; part < 2; ++part) {
-      const int lo = part == 0 ? loff[f] : lmid[f], hi = part == 0 ? lmid[f] : loff[f + 1];
-      const bool eps = part == 1;
-      const int src_frame = eps ? f : f - 1;
-      for (int i = lo + tid; i < hi; i += kBT) {
-        const int4 L = links[i];
-        if (L.x < 0) continue;
+  // links: one flat pass over the link store, kEmitU per thread in flight; a link's segment (found in the bounds) tells the source
+  // frame and whether the arc is an epsilon
+  {
+    const int l_lo = lseg_at(0), l_hi = lseg_at(2 * (nd + 1));
+    for (int i0 = l_lo; i0 < l_hi; i0 += kBT * kEmitU) {
+      int4 L[kEmitU];
+#pragma unroll
+      for (int u = 0; u < kEmitU; ++u) {
+        const int i = i0 + u * kBT + tid;
+        L[u] = i < l_hi ? links[i] : make_int4(-1, 0, 0, 0);
+      }
+      int4 A[kEmitU];
+      int il[kEmitU], ol[kEmitU];
+#pragma unroll
+      for (int u = 0; u < kEmitU; ++u) {
+        const bool on = L[u].x >= 0;
+        A[u] = on ? D.g.arcs[L[u].z] : make_int4(0, 0, 0, 0);
+        il[u] = on ? D.g.arc_ilabel[L[u].z] : 0;
+        ol[u] = on ? D.g.arc_olabel[L[u].z] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kEmitU; ++u) {
+        if (L[u].x < 0) continue;
+        const int i = i0 + u * kBT + tid;
+        int lo = 0, hi = 2 * (nd + 1);   // segment q: lseg[q] <= i < lseg[q + 1]; q = 2 f: emitting links into frame f, 2 f + 1: epsilon links inside f
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (lseg_at(mid) <= i) lo = mid; else hi = mid;
+        }
+        const int f = lo >> 1;
+        const bool eps = lo & 1;
+        const int src_frame = eps ? f : f - 1;
         const int p = atomicAdd(&s_narcs, 1);
         if (p >= D.lat_arc_cap) { s_err = 1; continue; }
-        const int4 A = D.g.arcs[L.z];
         LatArc o;
-        o.src_tok = L.x; o.dst_tok = L.y;
-        o.ilabel = eps ? 0 : D.g.arc_ilabel[L.z];
-        o.olabel = D.g.arc_olabel[L.z];
-        o.graph = __int_as_float(A.z);
+        o.src_tok = L[u].x; o.dst_tok = L[u].y;
+        o.ilabel = eps ? 0 : il[u];
+        o.olabel = ol[u];
+        o.graph = __int_as_float(A[u].z);
         if (D.big && o.olabel != 0) {   // biglm: graph_cost = arc weight + lm_score from the source token's LM state (biglm.h:377-388, 448-452)
           int n1, n2;
-          o.graph = __int_as_float(A.z) + lm_step(D, c, D.tok_lm[(size_t)c * D.arena_cap + L.x], o.olabel, &n1, &n2);
+          o.graph = __int_as_float(A[u].z) + lm_step(D, c, D.tok_lm[(size_t)c * D.arena_cap + L[u].x], o.olabel, &n1, &n2);
         }
-        o.acoustic = eps ? 0.0f : -ll[(size_t)src_frame * D.stride + (A.x & D.g.col_mask)];
+        o.acoustic = eps ? 0.0f : -ll[(size_t)src_frame * D.stride + (A[u].x & D.g.col_mask)];
         o.src_frame = src_frame; o.is_eps = eps ? 1 : 0;
         out_arcs[p] = o;
       }
     }
   }
+  };
+  if (in_lds) emit_all([&](int f) { return s_foff[f]; }, [&](int q) { return s_lseg[q]; });
+  else emit_all([&](int f) { return foff[f]; }, [&](int q) { return (q & 1) ? ((q >> 1) <= nd ? lmid[q >> 1] : loff[q >> 1]) : loff[q >> 1]; });
   __syncthreads();
+#if defined(WFST_EXP_EMIT_T)
+  if (tid == 0 && blockIdx.x < 3) printf("EMIT c %d links %d..%d arcs %d t_all %lld nd %d\n", c, loff[0], loff[nd + 1], s_narcs, wall_clock64() - te0, nd);
+#endif
   if (tid == 0) {
     ctl->lat_arcs = min(s_narcs, D.lat_arc_cap);
     ctl->lat_toks = min(s_ntoks, D.lat_tok_cap);
