@@ -90,6 +90,7 @@ def test_device_nbest_paths_equal_the_reference(oracle, refdec, synth, tmp_path)
 
     W = G.wfstdec
     n_checked = 0
+    most = 0
     for seed in range(2):
         g, m, gp, p1, p2, lls = _setup(synth, tmp_path, seed)
         graph = W.Graph.load(gp)
@@ -114,10 +115,12 @@ def test_device_nbest_paths_equal_the_reference(oracle, refdec, synth, tmp_path)
             p = str(tmp_path / "raw.lat")
             with open(p, "wb") as f:
                 f.write(shard.lattice_to_bytes(raw))
-            for n in (1, 5, 40, 700):
+            for n in (1, 5, 40, 700, 4096):   # (4096: the sort buffer's limit -- candidate lists merged in chunks)
                 ref = pyoracle.ref_nbest_paths_from_lattice_file(refdec, p, 0, n)
                 assert ref is not None
-                _same_paths(dec.nbest_paths(c, n), ref, "seed %d utt %d n %d" % (seed, c, n))
+                got = dec.nbest_paths(c, n)
+                _same_paths(got, ref, "seed %d utt %d n %d" % (seed, c, n))
+                most = max(most, len(got))
             for n in (3, 60):
                 ref = pyoracle.ref_nbest_paths_from_lattice_file(refdec, p, 0, n, r1, r2)
                 assert ref is not None
@@ -138,3 +141,4 @@ def test_device_nbest_paths_equal_the_reference(oracle, refdec, synth, tmp_path)
         L2.free()
         graph.free()
     assert n_checked >= 4
+    assert most > 2048, "no lattice with enough paths to fill more than half the sort buffer (%d)" % most
