@@ -144,7 +144,7 @@ struct wfst_decoder {
   DecoderDev D;
   DevBuf<ChanCtl> ctl;
   DevBuf<int4> tok;
-  DevBuf<int32_t> emit_cnt;
+  DevBuf<int32_t> emit_cnt, prune_par;
   DevBuf<int32_t> frame_off, bucket_cnt, eps_toki, eps_occ_list, eps_won_list, target, chan_list;
   DevBuf<int4> bucket, worklist, links, lat_toks;
   DevBuf<unsigned long long> pair_keys, eps_keys;  // biglm
@@ -256,7 +256,7 @@ struct wfst_decoder {
     det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
     cmp_ws.release(); cmp_result.release(); cmp_fin.release(); cmp_out_a.release(); cmp_out_w.release();
     np_ws.release(); np_out.release(); np_off.release(); np_arcs.release(); np_tot.release(); np_lists.release();
-    ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); emit_cnt.release();
+    ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); emit_cnt.release(); prune_par.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
     bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); lat_stats.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -939,6 +939,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   A(d->bucket.alloc(B * (size_t)n_part * (size_t)bucket_cap));
   A(d->bucket_cnt.alloc(B * (size_t)n_part));
   A(d->emit_cnt.alloc(B * 32));
+  A(d->prune_par.alloc(B * 32));
   A(d->eps_vals.alloc(B * ecap));
   A(d->eps_toki.alloc(B * ecap));
   A(d->eps_occ_list.alloc(B * (size_t)L.max_tokens_per_frame));
@@ -981,6 +982,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   if (e == hipSuccess) A(hipMemsetAsync(d->ctl.p, 0, d->ctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->bucket_cnt.p, 0, d->bucket_cnt.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->emit_cnt.p, 0, d->emit_cnt.bytes(), d->stream));
+  if (e == hipSuccess) A(hipMemsetAsync(d->prune_par.p, 0, d->prune_par.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->fctl.p, 0, d->fctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->dbg_t.p, 0, d->dbg_t.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->eps_vals.p, 0xFF, d->eps_vals.bytes(), d->stream));
@@ -1007,6 +1009,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.bucket = d->bucket.p;
   D.bucket_cnt = d->bucket_cnt.p;
   D.emit_cnt = d->emit_cnt.p;
+  D.prune_par = d->prune_par.p;
   D.eps_vals = d->eps_vals.p;
   D.eps_toki = d->eps_toki.p;
   D.eps_occ_list = d->eps_occ_list.p;

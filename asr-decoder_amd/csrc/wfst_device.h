@@ -266,6 +266,7 @@ struct DecoderDev {
   float *cutoff_hist;
   int4 *bucket;
   int32_t *bucket_cnt;
+  int32_t *prune_par;    // [c][32]: lattice mode -- what a running back-pruning pass hands to its compaction launches (wfst_kernels.hip: kPrParInts)
   int32_t *emit_cnt;     // [c][32] (a line each): lattice mode on the fused rows -- entries of the channel's emitter list (the tokens of the
                          // frame being built that have epsilon arcs out: listed by the insert launch in the channel's worklist space,
                          // read and reset by the closure launch's epsilon_links)

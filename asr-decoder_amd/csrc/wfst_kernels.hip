@@ -2303,6 +2303,8 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
 // =========================================================================================
 constexpr int kPrLds = 16384;    // {extra, cost} pairs of the walk kept in LDS (128 KB): the frame being priced, and the frame after it where both fit
 constexpr int kPrChunk = 8192;   // items of one compaction sweep (kBT threads x 8)
+constexpr int kPrSlabs = 4;      // workgroups per channel of a compaction's flag sweeps (prune_flags)
+constexpr int kPrParInts = 32;   // a channel's compaction parameters (DecoderDev::prune_par): {run, c_lo, tokens lo / hi, frame-0 bound, links lo / hi, nd, slab counts}
 struct ScanShared {
   u64 red[2][kBT / 64];
   int changed, any_changed, cnt, err;
@@ -2771,184 +2773,269 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     const bool full = (nd / D.prune_interval) % 8 == 0 || 2 * (int64_t)foff[nd + 1] > D.arena_cap ||
                       2 * (int64_t)ctl->link_count > D.link_cap;
     const int c_lo = full ? k_lo : max(k_lo, min(n_prev, nd));
-    k_lo = c_lo;
-    const int range_lo = foff[k_lo], end = foff[nd + 1];
-    const int f0_hi = (k_lo == 0) ? foff[1] : 0;   // PruneActiveTokens never calls PruneTokensForFrame(0) (base-inl.h:471-476): frame 0
-                                                   // keeps its dead tokens, link-less, until FinalizeDecoding
-    if (tid == 0) ps.err = 0;
-    __syncthreads();
-    tw = wall_clock64();
-    constexpr int kCU = kPrChunk / kBT;   // items per thread and sweep
-    // FLAT sweeps over the whole range (not frame by frame: a raw frame is a few thousand tokens, a pruned one a few hundred --
-    // a sweep per frame was mostly barriers), and the MOVES run over the survivors only (a raw frame keeps a percent or two
-    // of its tokens and links): sweep (a) leaves, besides every item's exclusive prefix, the list of the survivors' old
-    // indices, and sweep (b) walks that list.  Scratch: the channel's lat_toks / lat_arcs (they hold nothing between two
-    // lattice_emit launches; int32 views).
-    int32_t *surv = reinterpret_cast<int32_t *>(D.lat_toks + (size_t)c * D.lat_tok_cap);    // [new index] -> old index (tokens)
-    int32_t *lsurv = reinterpret_cast<int32_t *>(D.lat_arcs + (size_t)c * D.lat_arc_cap);   // [new index] -> old index (links)
-    int32_t *lpre = lsurv + D.link_cap;                                                      // [old index] -> survivors below it
-    // (a) remap[i] = new index of a survivor, ~(survivors below i) of a dead token: the exclusive prefix either way
-    // (a chunk's items in wave-coalesced order -- wave w, step u, lane l: item (w * kCU + u) * 64 + l -- and the survivors'
-    // ranks from ballots: a lane reads 4 or 16 bytes beside its neighbour's, where a thread owning 8 consecutive items read
-    // a line per lane)
-    constexpr int kFU = 16;                   // items per thread of a FLAG sweep (4 bytes each in flight: twice a move sweep's)
-    constexpr int kFlagChunk = kBT * kFU;
-    auto chunk_ranks = [&](const bool (&alive)[kFU], int base, int (&rank)[kFU]) -> int {
-      u64 m[kFU];
-      int wc = 0;
-#pragma unroll
-      for (int u = 0; u < kFU; ++u) { m[u] = __ballot(alive[u]); wc += __popcll(m[u]); }
-      __syncthreads();  // ps.wsum free again
-      if (lane == 0) ps.wsum[wave] = wc;
-      __syncthreads();
-      int wb = 0, tot = 0;
-#pragma unroll
-      for (int w = 0; w < kBT / 64; ++w) {
-        const int x = ps.wsum[w];
-        if (w < wave) wb += x;
-        tot += x;
-      }
-      int run = base + wb;
-#pragma unroll
-      for (int u = 0; u < kFU; ++u) { rank[u] = run + lane_rank(m[u]); run += __popcll(m[u]); }
-      return tot;
-    };
-    int new_end = range_lo;
-    for (int c0 = range_lo; c0 < end; c0 += kFlagChunk) {
-      bool alive[kFU];
-      int rank[kFU];
-#pragma unroll
-      for (int u = 0; u < kFU; ++u) {
-        const int i = c0 + (wave * kFU + u) * 64 + lane;
-        alive[u] = i < end && (i < f0_hi || (uint32_t)ld_agent(&extra[i].x) < kInfO);
-      }
-      const int tot = chunk_ranks(alive, new_end, rank);
-#pragma unroll
-      for (int u = 0; u < kFU; ++u) {
-        const int i = c0 + (wave * kFU + u) * 64 + lane;
-        if (i < end) {
-          remap[i] = alive[u] ? rank[u] : ~rank[u];
-          if (alive[u]) surv[rank[u]] = i;
-        }
-      }
-      new_end += tot;
-    }
-    __syncthreads();
-    if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[44], now - tw); tw = now; }
-    // the frames' new offsets: survivors below each old offset
-    for (int f = k_lo + tid; f <= nd; f += kBT) {
-      const int p = foff[f + 1];
-      int q = new_end;
-      if (p < end) { q = remap[p]; q = q < 0 ? ~q : q; }
-      foff[f + 1] = q;
-    }
-    // (b) the survivors move down (a sweep is read whole before it is written; new index <= old index, so a sweep's writes
-    // land on positions that this sweep or an earlier one has read)
-    for (int j0 = range_lo; j0 < new_end; j0 += kPrChunk) {
-      int oi[kCU], sl[kCU];
-      int4 rec[kCU];
-      uint2 ex[kCU];
-      int32_t *side = D.big ? D.tok_lm + (size_t)c * D.arena_cap : nullptr;   // biglm: the tokens' LM pair states move along
-#pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        const int j = j0 + u * kBT + tid;
-        oi[u] = j < new_end ? surv[j] : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        rec[u] = make_int4(0, 0, 0, 0);
-        ex[u] = make_uint2(0, 0);
-        sl[u] = 0;
-        if (oi[u] >= 0) { rec[u] = tok[oi[u]]; ex[u] = extra[oi[u]]; if (side) sl[u] = side[oi[u]]; }
-      }
-#pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        // backpointer: a survivor's predecessor survives (the link between them is the token's own best one);
-        // predecessors below the compacted range have not moved
-        if (oi[u] >= 0 && rec[u].z >= range_lo) {
-          rec[u].z = remap[rec[u].z];
-          if (rec[u].z < 0) ps.err = 1;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        const int j = j0 + u * kBT + tid;
-        if (oi[u] >= 0) { tok[j] = rec[u]; extra[j] = ex[u]; if (side) side[j] = sl[u]; }
-      }
-      __syncthreads();
-    }
-    if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[45], now - tw); tw = now; }
-    // links, flat: from the emitting links INTO frame k_lo (their destinations moved) to the end of the store
-    const int l_lo = loff[k_lo], l_end = loff[nd + 1];
-    int lnew = l_lo;
-    for (int c0 = l_lo; c0 < l_end; c0 += kFlagChunk) {
-      bool alive[kFU];
-      int rank[kFU];
-#pragma unroll
-      for (int u = 0; u < kFU; ++u) {
-        const int i = c0 + (wave * kFU + u) * 64 + lane;
-        alive[u] = i < l_end && links[i].x >= 0;
-      }
-      const int tot = chunk_ranks(alive, lnew, rank);
-#pragma unroll
-      for (int u = 0; u < kFU; ++u) {
-        const int i = c0 + (wave * kFU + u) * 64 + lane;
-        if (i < l_end) {
-          lpre[i] = rank[u];
-          if (alive[u]) lsurv[rank[u]] = i;
-        }
-      }
-      lnew += tot;
-    }
-    __syncthreads();
-    if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[46], now - tw); tw = now; }
-    // a frame's segment = [link_off[f], link_mid[f]) emitting into it, [link_mid[f], link_off[f+1]) epsilon inside it
-    for (int q = tid; q < 2 * (nd - k_lo) + 2; q += kBT) {
-      int *slot = (q & 1) ? &loff[k_lo + (q >> 1) + 1] : &lmid[k_lo + (q >> 1)];
-      const int p = *slot;
-      *slot = p < l_end ? lpre[p] : lnew;
-    }
-    for (int j0 = l_lo; j0 < lnew; j0 += kPrChunk) {
-      int4 L[kCU];
-#pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        const int j = j0 + u * kBT + tid;
-        const int oi = j < lnew ? lsurv[j] : -1;
-        L[u] = oi >= 0 ? links[oi] : make_int4(-1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < kCU; ++u)
-        if (L[u].x >= 0) {   // (an endpoint below the compacted range has not moved)
-          if (L[u].x >= range_lo) L[u].x = remap[L[u].x];
-          if (L[u].y >= range_lo) L[u].y = remap[L[u].y];
-        }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < kCU; ++u) {
-        const int j = j0 + u * kBT + tid;
-        if (j < lnew) links[j] = L[u];
-      }
-      __syncthreads();
-    }
-    if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[47], now - tw); atomicAdd(&D.dbg_t[48], (unsigned long long)(end - range_lo)); atomicAdd(&D.dbg_t[49], (unsigned long long)(l_end - l_lo)); atomicAdd(&D.dbg_t[50], (unsigned long long)((new_end - range_lo) + (lnew - l_lo))); }
-    if (tid == 0) D.lat_stats[(size_t)c * 4 + 3] += (u64)(end - range_lo) + (u64)(l_end - l_lo) + (((u64)(new_end - range_lo) + (u64)(lnew - l_lo)) << 32);
+    // The compaction runs as launches of its own (prune_flags: several workgroups per channel; prune_move), which read the range here
     if (tid == 0) {
-      ctl->link_count = lnew;
-      ctl->front_begin = foff[nd];
-      ctl->front_count = foff[nd + 1] - foff[nd];
-      const u64 b = ctl->best_next;
-      if (b != ~0ull) {
-        const int nb = remap[(uint32_t)b];
-        ctl->best_next = nb >= 0 ? ((b & 0xFFFFFFFF00000000ull) | (uint32_t)nb) : ~0ull;
-      }
-      ctl->pruned_upto = nd;
-      if (D.dbg & 32) atomicAdd(&D.dbg_t[54], wall_clock64() - tq);
-      if (ps.err) ctl->error |= kErrInternal;  // never expected: a surviving token whose predecessor died
+      int32_t *pp = D.prune_par + (size_t)c * kPrParInts;
+      pp[0] = 1;                                   // a pass ran: compact
+      pp[1] = c_lo;
+      pp[2] = foff[c_lo]; pp[3] = foff[nd + 1];    // tokens [range_lo, end)
+      pp[4] = (c_lo == 0) ? foff[1] : 0;           // PruneActiveTokens never calls PruneTokensForFrame(0) (base-inl.h:471-476): frame 0
+                                                   // keeps its dead tokens, link-less, until FinalizeDecoding
+      pp[5] = loff[c_lo]; pp[6] = loff[nd + 1];    // links [l_lo, l_end): from the emitting links INTO frame c_lo (their destinations move)
+      pp[7] = nd;
     }
     __syncthreads();
   }
   (void)any_final;
+}
+
+// ---- the compaction of a running pass -----------------------------------------------------------------------------------------
+// What the pass priced for the FIRST time is compacted: tokens of frames [c_lo, nd], links from the epsilon links of frame c_lo on.
+// That is where nearly everything dies (a raw frame keeps a percent or two of its tokens).  Frames priced before only lose the odd
+// token now and then: there the dead stay where they are as holes (a token is dead iff its extra is +inf, a link iff it was marked;
+// lattice_emit_kernel skips both) until the holes add up (every eighth pass, or arena / link store half full: `full` above).
+//
+// FLAT sweeps over the whole range, and the MOVES run over the survivors only.  The FLAG sweeps -- nine tenths of the items a
+// compaction touches -- are shared out over kPrSlabs workgroups per channel (prune_flags, a launch of its own: the kernel boundary
+// orders it after the walk and before the moves): slab g of the token range and of the link range gets slab-relative ranks,
+//   remap[i] = rank of a surviving token in its slab, ~(survivors of the slab below i) of a dead one;  lpre[i] likewise for links,
+// the survivors' old indices listed per slab (at the slab's own offset of surv[] / lsurv[]: a slab has no more survivors than
+// items), and its survivor count in the channel's parameter block.  prune_move (one workgroup: the moves are in place and ordered)
+// turns the slab counts into bases -- new index = range_lo + base[slab] + rank -- and moves the survivors down.
+// Scratch: the channel's lat_toks / lat_arcs (they hold nothing between two lattice_emit launches; int32 views).
+constexpr int kPrFU = 16;                     // items per thread of a FLAG sweep (4 bytes each in flight)
+constexpr int kPrFlagChunk = kBT * kPrFU;
+
+__device__ __forceinline__ int pr_slab_len(int len) { return ((len + kPrSlabs - 1) / kPrSlabs + 63) & ~63; }
+
+__device__ __forceinline__ void prune_flags(const DecoderDev &D, int c, int g, ScanShared &ps) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t *pp = D.prune_par + (size_t)c * kPrParInts;
+  if (pp[0] != 1) return;
+  const int range_lo = pp[2], end = pp[3], f0_hi = pp[4], l_lo = pp[5], l_end = pp[6];
+  const uint2 *extra = D.extra + (size_t)c * D.arena_cap;
+  const int4 *links = D.links + (size_t)c * D.link_cap;
+  int32_t *remap = D.remap + (size_t)c * D.arena_cap;
+  int32_t *surv = reinterpret_cast<int32_t *>(D.lat_toks + (size_t)c * D.lat_tok_cap);    // [slab offset + rank] -> old index (tokens)
+  int32_t *lsurv = reinterpret_cast<int32_t *>(D.lat_arcs + (size_t)c * D.lat_arc_cap);   // [slab offset + rank] -> old index (links)
+  int32_t *lpre = lsurv + D.link_cap;                                                      // [old index] -> survivors of its slab below it
+  const uint32_t kInfO = f2o(__builtin_huge_valf());
+  // (a chunk's items in wave-coalesced order -- wave w, step u, lane l: item (w * kPrFU + u) * 64 + l -- and the survivors'
+  // ranks from ballots: a lane reads 4 or 16 bytes beside its neighbour's)
+  auto chunk_ranks = [&](const bool (&alive)[kPrFU], int base, int (&rank)[kPrFU]) -> int {
+    u64 m[kPrFU];
+    int wc = 0;
+#pragma unroll
+    for (int u = 0; u < kPrFU; ++u) { m[u] = __ballot(alive[u]); wc += __popcll(m[u]); }
+    __syncthreads();  // ps.wsum free again
+    if (lane == 0) ps.wsum[wave] = wc;
+    __syncthreads();
+    int wb = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBT / 64; ++w) {
+      const int x = ps.wsum[w];
+      if (w < wave) wb += x;
+      tot += x;
+    }
+    int run = base + wb;
+#pragma unroll
+    for (int u = 0; u < kPrFU; ++u) { rank[u] = run + lane_rank(m[u]); run += __popcll(m[u]); }
+    return tot;
+  };
+  unsigned long long tw = wall_clock64();
+  {  // tokens of slab g
+    const int sl = pr_slab_len(end - range_lo), lo = min(end, range_lo + g * sl), hi = min(end, lo + sl);
+    int cnt = 0;
+    for (int c0 = lo; c0 < hi; c0 += kPrFlagChunk) {
+      bool alive[kPrFU];
+      int rank[kPrFU];
+#pragma unroll
+      for (int u = 0; u < kPrFU; ++u) {
+        const int i = c0 + (wave * kPrFU + u) * 64 + lane;
+        alive[u] = i < hi && (i < f0_hi || extra[i].x < kInfO);
+      }
+      const int tot = chunk_ranks(alive, cnt, rank);
+#pragma unroll
+      for (int u = 0; u < kPrFU; ++u) {
+        const int i = c0 + (wave * kPrFU + u) * 64 + lane;
+        if (i < hi) {
+          remap[i] = alive[u] ? rank[u] : ~rank[u];
+          if (alive[u]) surv[(lo - range_lo) + rank[u]] = i;
+        }
+      }
+      cnt += tot;
+    }
+    if (tid == 0) pp[8 + g] = cnt;
+  }
+  if (tid == 0 && g == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[44], now - tw); atomicAdd(&D.dbg_t[54], now - tw); tw = now; }
+  {  // links of slab g
+    const int sl = pr_slab_len(l_end - l_lo), lo = min(l_end, l_lo + g * sl), hi = min(l_end, lo + sl);
+    int cnt = 0;
+    for (int c0 = lo; c0 < hi; c0 += kPrFlagChunk) {
+      bool alive[kPrFU];
+      int rank[kPrFU];
+#pragma unroll
+      for (int u = 0; u < kPrFU; ++u) {
+        const int i = c0 + (wave * kPrFU + u) * 64 + lane;
+        alive[u] = i < hi && links[i].x >= 0;
+      }
+      const int tot = chunk_ranks(alive, cnt, rank);
+#pragma unroll
+      for (int u = 0; u < kPrFU; ++u) {
+        const int i = c0 + (wave * kPrFU + u) * 64 + lane;
+        if (i < hi) {
+          lpre[i] = rank[u];
+          if (alive[u]) lsurv[(lo - l_lo) + rank[u]] = i;
+        }
+      }
+      cnt += tot;
+    }
+    if (tid == 0) pp[8 + kPrSlabs + g] = cnt;
+  }
+  if (tid == 0 && g == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[46], now - tw); atomicAdd(&D.dbg_t[54], now - tw); }
+}
+
+__device__ __forceinline__ void prune_move(const DecoderDev &D, int c, ScanShared &ps) {
+  const int tid = threadIdx.x;
+  int32_t *pp = D.prune_par + (size_t)c * kPrParInts;
+  if (pp[0] != 1) return;
+  ChanCtl *ctl = D.ctl + c;
+  const int k_lo = pp[1], range_lo = pp[2], end = pp[3], l_lo = pp[5], l_end = pp[6], nd = pp[7];
+  int4 *tok = D.tok + (size_t)c * D.arena_cap;
+  int4 *links = D.links + (size_t)c * D.link_cap;
+  uint2 *extra = D.extra + (size_t)c * D.arena_cap;
+  int32_t *remap = D.remap + (size_t)c * D.arena_cap;
+  int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
+  int32_t *loff = D.link_off + (size_t)c * (D.max_frames + 3);
+  int32_t *lmid = D.link_mid + (size_t)c * (D.max_frames + 3);
+  const int32_t *surv = reinterpret_cast<const int32_t *>(D.lat_toks + (size_t)c * D.lat_tok_cap);
+  const int32_t *lsurv = reinterpret_cast<const int32_t *>(D.lat_arcs + (size_t)c * D.lat_arc_cap);
+  const int32_t *lpre = lsurv + D.link_cap;
+  unsigned long long tw = wall_clock64();
+  // the slabs' bases: survivors of the slabs below
+  int tb[kPrSlabs + 1], lb[kPrSlabs + 1];
+  tb[0] = 0; lb[0] = 0;
+#pragma unroll
+  for (int g = 0; g < kPrSlabs; ++g) { tb[g + 1] = tb[g] + pp[8 + g]; lb[g + 1] = lb[g] + pp[8 + kPrSlabs + g]; }
+  const int tsl = pr_slab_len(end - range_lo), lsl = pr_slab_len(l_end - l_lo);
+  const int new_end = range_lo + tb[kPrSlabs], lnew = l_lo + lb[kPrSlabs];
+  // new index of token i of the range (negative: dead, ~(survivors below it))
+  auto tok_new = [&](int i) -> int {
+    const int g = (i - range_lo) / tsl, r = remap[i];
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < kPrSlabs; ++q) base = (q == g) ? tb[q] : base;
+    return r >= 0 ? range_lo + base + r : ~(range_lo + base + ~r);
+  };
+  auto surv_at = [&](const int32_t *list, const int (&base)[kPrSlabs + 1], int sl, int j) -> int {   // old index of survivor j (0-based within the range)
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < kPrSlabs; ++q) g += j >= base[q] ? 1 : 0;
+    int bg = 0;
+#pragma unroll
+    for (int q = 0; q < kPrSlabs; ++q) bg = (q == g) ? base[q] : bg;
+    return list[g * sl + (j - bg)];
+  };
+  if (tid == 0) ps.err = 0;
+  __syncthreads();
+  constexpr int kCU = kPrChunk / kBT;   // items per thread and sweep
+  // the frames' new offsets: survivors below each old offset
+  for (int f = k_lo + tid; f <= nd; f += kBT) {
+    const int p = foff[f + 1];
+    int q = new_end;
+    if (p < end) { q = tok_new(p); q = q < 0 ? ~q : q; }
+    foff[f + 1] = q;
+  }
+  __syncthreads();
+  // the survivors move down (a sweep is read whole before it is written; new index <= old index, so a sweep's writes land on
+  // positions that this sweep or an earlier one has read)
+  for (int j0 = range_lo; j0 < new_end; j0 += kPrChunk) {
+    int oi[kCU], sl[kCU];
+    int4 rec[kCU];
+    uint2 ex[kCU];
+    int32_t *side = D.big ? D.tok_lm + (size_t)c * D.arena_cap : nullptr;   // biglm: the tokens' LM pair states move along
+#pragma unroll
+    for (int u = 0; u < kCU; ++u) {
+      const int j = j0 + u * kBT + tid;
+      oi[u] = j < new_end ? surv_at(surv, tb, tsl, j - range_lo) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < kCU; ++u) {
+      rec[u] = make_int4(0, 0, 0, 0);
+      ex[u] = make_uint2(0, 0);
+      sl[u] = 0;
+      if (oi[u] >= 0) { rec[u] = tok[oi[u]]; ex[u] = extra[oi[u]]; if (side) sl[u] = side[oi[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kCU; ++u) {
+      // backpointer: a survivor's predecessor survives (the link between them is the token's own best one);
+      // predecessors below the compacted range have not moved
+      if (oi[u] >= 0 && rec[u].z >= range_lo) {
+        rec[u].z = tok_new(rec[u].z);
+        if (rec[u].z < 0) ps.err = 1;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kCU; ++u) {
+      const int j = j0 + u * kBT + tid;
+      if (oi[u] >= 0) { tok[j] = rec[u]; extra[j] = ex[u]; if (side) side[j] = sl[u]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[45], now - tw); atomicAdd(&D.dbg_t[54], now - tw); tw = now; }
+  // a frame's segment = [link_off[f], link_mid[f]) emitting into it, [link_mid[f], link_off[f+1]) epsilon inside it
+  auto link_new = [&](int p) -> int {   // survivors below link p, as a new index
+    const int g = (p - l_lo) / lsl;
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < kPrSlabs; ++q) base = (q == g) ? lb[q] : base;
+    return l_lo + base + lpre[p];
+  };
+  for (int q = tid; q < 2 * (nd - k_lo) + 2; q += kBT) {
+    int *slot = (q & 1) ? &loff[k_lo + (q >> 1) + 1] : &lmid[k_lo + (q >> 1)];
+    const int p = *slot;
+    *slot = p < l_end ? link_new(p) : lnew;
+  }
+  for (int j0 = l_lo; j0 < lnew; j0 += kPrChunk) {
+    int4 L[kCU];
+#pragma unroll
+    for (int u = 0; u < kCU; ++u) {
+      const int j = j0 + u * kBT + tid;
+      const int oi = j < lnew ? surv_at(lsurv, lb, lsl, j - l_lo) : -1;
+      L[u] = oi >= 0 ? links[oi] : make_int4(-1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < kCU; ++u)
+      if (L[u].x >= 0) {   // (an endpoint below the compacted range has not moved)
+        if (L[u].x >= range_lo) L[u].x = tok_new(L[u].x);
+        if (L[u].y >= range_lo) L[u].y = tok_new(L[u].y);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kCU; ++u) {
+      const int j = j0 + u * kBT + tid;
+      if (j < lnew) links[j] = L[u];
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[47], now - tw); atomicAdd(&D.dbg_t[54], now - tw); atomicAdd(&D.dbg_t[48], (unsigned long long)(end - range_lo)); atomicAdd(&D.dbg_t[49], (unsigned long long)(l_end - l_lo)); atomicAdd(&D.dbg_t[50], (unsigned long long)((new_end - range_lo) + (lnew - l_lo))); }
+  if (tid == 0) D.lat_stats[(size_t)c * 4 + 3] += (u64)(end - range_lo) + (u64)(l_end - l_lo) + (((u64)(new_end - range_lo) + (u64)(lnew - l_lo)) << 32);
+  __syncthreads();
+  if (tid == 0) {
+    ctl->link_count = lnew;
+    ctl->front_begin = foff[nd];
+    ctl->front_count = foff[nd + 1] - foff[nd];
+    const u64 b = ctl->best_next;
+    if (b != ~0ull) {
+      const int nb = tok_new((int)(uint32_t)b);
+      ctl->best_next = nb >= 0 ? ((b & 0xFFFFFFFF00000000ull) | (uint32_t)nb) : ~0ull;
+    }
+    ctl->pruned_upto = nd;
+    if (ps.err) ctl->error |= kErrInternal;  // never expected: a surviving token whose predecessor died
+    pp[0] = 0;
+  }
+  __syncthreads();
 }
 
 
@@ -3197,11 +3284,27 @@ __global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const 
   const int c = blockIdx.x + chan_off;
   ChanCtl *ctl = D.ctl + c;
   const int nd = ctl->n_decoded;
+  if (threadIdx.x == 0) D.prune_par[(size_t)c * kPrParInts] = 0;
+  __syncthreads();
   if (nd > 0 && nd % D.prune_interval == 0 && ctl->pruned_upto != nd && nd < target[c] && ctl->error == 0 && !ctl->finalized &&
       nd < D.max_frames)
     prune_pass<false>(D, c, ps);
+  (void)sh; (void)group; (void)par;
+}
+// the compaction's flag sweeps: kPrSlabs workgroups per channel
+__global__ __launch_bounds__(kBT) void lattice_prune_flags_kernel(DecoderDev D, int chan_off) {
+  __shared__ ScanShared ps;
+  prune_flags(D, (int)(blockIdx.x / kPrSlabs) + chan_off, (int)(blockIdx.x % kPrSlabs), ps);
+}
+// the compaction's moves, then the frame's preparation (prep_frame: the pass has moved the frontier)
+template <bool kBig>
+__global__ __launch_bounds__(kBT) void lattice_prune_move_kernel(DecoderDev D, const int32_t *target, int chan_off, int group, int par) {
+  __shared__ ScanShared ps;
+  __shared__ BoundaryShared sh;
+  const int c = blockIdx.x + chan_off;
+  prune_move(D, c, ps);
   __syncthreads();
-  prep_frame<kBig>(D, c, ctl, target, sh, group, par);
+  prep_frame<kBig>(D, c, D.ctl + c, target, sh, group, par);
 }
 
 // =========================================================================================
@@ -3752,8 +3855,13 @@ void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32
     hipLaunchKernelGGL((closure_kernel<false, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
 }
 void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int group, int par, hipStream_t s) {
+  // the walk (one workgroup per channel, 130 KB of LDS), the compaction's flag sweeps (kPrSlabs workgroups per channel), its moves +
+  // the next frame's preparation
   if (D.big) hipLaunchKernelGGL(lattice_prune_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
   else hipLaunchKernelGGL(lattice_prune_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
+  hipLaunchKernelGGL(lattice_prune_flags_kernel, dim3(chan_cnt * kPrSlabs), dim3(kBT), 0, s, D, chan_off);
+  if (D.big) hipLaunchKernelGGL(lattice_prune_move_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
+  else hipLaunchKernelGGL(lattice_prune_move_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
 }
 void launch_set_finalized(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(set_finalized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, D, chans, n);
