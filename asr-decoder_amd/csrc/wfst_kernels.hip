@@ -2895,7 +2895,9 @@ __device__ __forceinline__ void prune_flags(const DecoderDev &D, int c, int g, S
   if (tid == 0 && g == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[46], now - tw); atomicAdd(&D.dbg_t[54], now - tw); }
 }
 
-__device__ __forceinline__ void prune_move(const DecoderDev &D, int c, ScanShared &ps) {
+// role 0: the tokens (frame offsets, moves, the channel's frontier and best token); role 1: the links (segment bounds, moves, the link
+// counter) -- two workgroups side by side: the links' new endpoints come from remap[] and the slab bases, not from the moved tokens
+__device__ __forceinline__ void prune_move(const DecoderDev &D, int c, int role, ScanShared &ps) {
   const int tid = threadIdx.x;
   int32_t *pp = D.prune_par + (size_t)c * kPrParInts;
   if (pp[0] != 1) return;
@@ -2939,6 +2941,7 @@ __device__ __forceinline__ void prune_move(const DecoderDev &D, int c, ScanShare
   if (tid == 0) ps.err = 0;
   __syncthreads();
   constexpr int kCU = kPrChunk / kBT;   // items per thread and sweep
+  if (role == 0) {
   // the frames' new offsets: survivors below each old offset
   for (int f = k_lo + tid; f <= nd; f += kBT) {
     const int p = foff[f + 1];
@@ -2984,6 +2987,20 @@ __device__ __forceinline__ void prune_move(const DecoderDev &D, int c, ScanShare
     __syncthreads();
   }
   if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[45], now - tw); atomicAdd(&D.dbg_t[54], now - tw); tw = now; }
+  if (tid == 0) {
+    ctl->front_begin = foff[nd];
+    ctl->front_count = foff[nd + 1] - foff[nd];
+    const u64 b = ctl->best_next;
+    if (b != ~0ull) {
+      const int nb = tok_new((int)(uint32_t)b);
+      ctl->best_next = nb >= 0 ? ((b & 0xFFFFFFFF00000000ull) | (uint32_t)nb) : ~0ull;
+    }
+    ctl->pruned_upto = nd;
+    if (ps.err) atomicOr(&ctl->error, kErrInternal);  // never expected: a surviving token whose predecessor died
+  }
+  __syncthreads();
+  return;
+  }
   // a frame's segment = [link_off[f], link_mid[f]) emitting into it, [link_mid[f], link_off[f+1]) epsilon inside it
   auto link_new = [&](int p) -> int {   // survivors below link p, as a new index
     const int g = (p - l_lo) / lsl;
@@ -3022,19 +3039,7 @@ __device__ __forceinline__ void prune_move(const DecoderDev &D, int c, ScanShare
   if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[47], now - tw); atomicAdd(&D.dbg_t[54], now - tw); atomicAdd(&D.dbg_t[48], (unsigned long long)(end - range_lo)); atomicAdd(&D.dbg_t[49], (unsigned long long)(l_end - l_lo)); atomicAdd(&D.dbg_t[50], (unsigned long long)((new_end - range_lo) + (lnew - l_lo))); }
   if (tid == 0) D.lat_stats[(size_t)c * 4 + 3] += (u64)(end - range_lo) + (u64)(l_end - l_lo) + (((u64)(new_end - range_lo) + (u64)(lnew - l_lo)) << 32);
   __syncthreads();
-  if (tid == 0) {
-    ctl->link_count = lnew;
-    ctl->front_begin = foff[nd];
-    ctl->front_count = foff[nd + 1] - foff[nd];
-    const u64 b = ctl->best_next;
-    if (b != ~0ull) {
-      const int nb = tok_new((int)(uint32_t)b);
-      ctl->best_next = nb >= 0 ? ((b & 0xFFFFFFFF00000000ull) | (uint32_t)nb) : ~0ull;
-    }
-    ctl->pruned_upto = nd;
-    if (ps.err) ctl->error |= kErrInternal;  // never expected: a surviving token whose predecessor died
-    pp[0] = 0;
-  }
+  if (tid == 0) ctl->link_count = lnew;
   __syncthreads();
 }
 
@@ -3301,10 +3306,10 @@ template <bool kBig>
 __global__ __launch_bounds__(kBT) void lattice_prune_move_kernel(DecoderDev D, const int32_t *target, int chan_off, int group, int par) {
   __shared__ ScanShared ps;
   __shared__ BoundaryShared sh;
-  const int c = blockIdx.x + chan_off;
-  prune_move(D, c, ps);
+  const int c = blockIdx.x + chan_off, role = blockIdx.y;
+  prune_move(D, c, role, ps);
   __syncthreads();
-  prep_frame<kBig>(D, c, D.ctl + c, target, sh, group, par);
+  if (role == 0) prep_frame<kBig>(D, c, D.ctl + c, target, sh, group, par);
 }
 
 // =========================================================================================
@@ -3860,8 +3865,8 @@ void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, 
   if (D.big) hipLaunchKernelGGL(lattice_prune_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
   else hipLaunchKernelGGL(lattice_prune_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
   hipLaunchKernelGGL(lattice_prune_flags_kernel, dim3(chan_cnt * kPrSlabs), dim3(kBT), 0, s, D, chan_off);
-  if (D.big) hipLaunchKernelGGL(lattice_prune_move_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
-  else hipLaunchKernelGGL(lattice_prune_move_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
+  if (D.big) hipLaunchKernelGGL(lattice_prune_move_kernel<true>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
+  else hipLaunchKernelGGL(lattice_prune_move_kernel<false>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
 }
 void launch_set_finalized(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(set_finalized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, D, chans, n);
