@@ -3622,115 +3622,102 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
 // GetRawLattice's raw material: every token and link alive right now, resolved to labels and costs, in the
 // channel's compact lat_toks[] / lat_arcs[].  use_final != 0: final states by ComputeFinalCosts (base-inl.h:
 // 670-720, 924-940): the graph-final tokens of the newest frame if there are any, else all of it.
-constexpr int kEmitFrames = 4096, kEmitU = 8;   // frames whose bounds lattice_emit_kernel keeps in LDS (longer utterances read them from HBM); items per thread and sweep
+constexpr int kEmitFrames = 4096, kEmitU = 8;   // frames whose bounds the emit kernels keep in LDS (longer utterances read them from HBM); items per thread and sweep
+constexpr int kEmitSlabs = 4;                   // workgroups per channel of the emit sweeps
+// GetRawLattice's listing (base-inl.h:869-975) of what is alive in the arena and in the link store -- after FinalizeDecoding, or
+// mid-utterance -- into lat_toks[] (arena order = frame order: the n-best search relies on a frame's states being contiguous) and
+// lat_arcs[] (any order).  Both stores hold their dead as holes (a channel at beam 13: 130-330 k arena entries for 1-2.5 k living
+// tokens), so the listing is two sweeps over everything; kEmitSlabs workgroups per channel share them:
+//   lattice_emit_kernel    slab g of the arena: slab-relative rank of every living token (remap[], -1 dead) and the slab's count;
+//                          slab g of the link store: every living link appended to lat_arcs[] (one counter per channel, one atomic per wave)
+//   lattice_emit_tokens_kernel   the slabs' bases from their counts; the living tokens of slab g written to lat_toks[base + rank]
+// (the channel's counters sit in its parameter block, DecoderDev::prune_par[16..]: slab counts, link counter, error; reset by
+// lattice_emit_reset_kernel).
+struct EmitBounds {
+  int foff[kEmitFrames + 2], lseg[2 * (kEmitFrames + 2)];   // lseg[2 f] = link_off[f], [2 f + 1] = link_mid[f]
+};
+__device__ __forceinline__ int emit_slab_len(int len) { return ((len + kEmitSlabs - 1) / kEmitSlabs + 63) & ~63; }
+
+__global__ void lattice_emit_reset_kernel(DecoderDev D, const int32_t *chans, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 16) return;
+  const int c = chans ? chans[i >> 4] : (i >> 4);
+  D.prune_par[(size_t)c * kPrParInts + 16 + (i & 15)] = 0;
+}
+
 __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const int32_t *chans, int use_final) {
   const int c = chans ? chans[blockIdx.x] : blockIdx.x;
-  const int tid = threadIdx.x;
+  const int g = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
   ChanCtl *ctl = D.ctl + c;
   const int nd = ctl->n_decoded;
-  const int4 *tok = D.tok + (size_t)c * D.arena_cap;
   const int4 *links = D.links + (size_t)c * D.link_cap;
   LatArc *out_arcs = D.lat_arcs + (size_t)c * D.lat_arc_cap;
-  int4 *out_toks = D.lat_toks + (size_t)c * D.lat_tok_cap;
   const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
   const int32_t *loff = D.link_off + (size_t)c * (D.max_frames + 3);
   const int32_t *lmid = D.link_mid + (size_t)c * (D.max_frames + 3);
   const float *ll = D.ll_base[c];
-  __shared__ int s_any_final, s_narcs, s_ntoks, s_err;
-#if defined(WFST_EXP_EMIT_T)
-  const long long te0 = wall_clock64();
-#endif
-  if (tid == 0) { s_any_final = 0; s_narcs = 0; s_ntoks = 0; s_err = 0; }
-  __syncthreads();
+  int32_t *pp = D.prune_par + (size_t)c * kPrParInts + 16;   // [g] living tokens of slab g, [8] links listed, [9] error
+  int32_t *remap = D.remap + (size_t)c * D.arena_cap;
   if (ctl->error) return;
-  if (use_final) {
-    int any = 0;
-    for (int i = foff[nd] + tid; i < foff[nd + 1]; i += kBT) any |= tok[i].x == D.g.final_state;
-    if (any) s_any_final = 1;
-  }
-  __syncthreads();
-  const bool any_final = s_any_final != 0;
-  // tokens, frame by frame.  Frames the back-pruning has priced (below pruned_upto) hold their dead as holes:
-  // extra = +inf -- except frame 0 before FinalizeDecoding, whose dead tokens the reference keeps (link-less:
-  // PruneActiveTokens never calls PruneTokensForFrame(0), base-inl.h:471-476).
+  // tokens.  Frames the back-pruning has priced (below pruned_upto) hold their dead as holes: extra = +inf -- except frame 0 before
+  // FinalizeDecoding, whose dead tokens the reference keeps (link-less: PruneActiveTokens never calls PruneTokensForFrame(0),
+  // base-inl.h:471-476).
   const uint2 *extra = D.extra + (size_t)c * D.arena_cap;
   const uint32_t kInfO = f2o(__builtin_huge_valf());
   const int pruned_upto = ctl->pruned_upto;
   const bool finalized = ctl->finalized != 0;
-  // The frame bounds (tokens) and the link segments' bounds go to LDS: every token and every link finds its frame by a binary search.
-  __shared__ int s_foff[kEmitFrames + 2], s_lseg[2 * (kEmitFrames + 2)];   // s_lseg[2 f] = loff[f], [2 f + 1] = lmid[f]
+  __shared__ EmitBounds sb;
+  __shared__ ScanShared ps;
   const bool in_lds = nd + 2 <= kEmitFrames + 2;
   if (in_lds) {
-    for (int f = tid; f <= nd + 1; f += kBT) { s_foff[f] = foff[f]; s_lseg[2 * f] = loff[f]; s_lseg[2 * f + 1] = f <= nd ? lmid[f] : loff[f]; }
+    for (int f = tid; f <= nd + 1; f += kBT) { sb.lseg[2 * f] = loff[f]; sb.lseg[2 * f + 1] = f <= nd ? lmid[f] : loff[f]; }
   }
   __syncthreads();
-  auto emit_all = [&](auto foff_at, auto lseg_at) {
-  {  // in arena order (= frame order; the n-best search relies on a frame's states being contiguous): kEmitU tokens per thread
-     // and sweep (consecutive ones, so that a thread's survivors stay in order), one workgroup-wide prefix per sweep
-    __shared__ ScanShared ps;
-    const int n_all = foff_at(nd + 1);
-    const int f_pruned = foff_at(min(max(pruned_upto, 0), nd + 1)), f_one = foff_at(1);   // first token of the first unpriced frame; of frame 1
+  {  // the slab's living tokens: rank within the slab (kEmitU consecutive tokens per thread and sweep, one workgroup-wide prefix per sweep)
+    const int n_all = foff[nd + 1];
+    const int f_pruned = foff[min(max(pruned_upto, 0), nd + 1)], f_one = foff[1];   // first token of the first unpriced frame; of frame 1
+    const int sl = emit_slab_len(n_all), lo = min(n_all, g * sl), hi = min(n_all, lo + sl);
     int base = 0;
-    for (int i0 = 0; i0 < n_all; i0 += kBT * kEmitU) {
-      int fr[kEmitU];
+    for (int i0 = lo; i0 < hi; i0 += kBT * kEmitU) {
       bool alive[kEmitU];
       uint32_t ex[kEmitU];
 #pragma unroll
       for (int u = 0; u < kEmitU; ++u) {
         const int i = i0 + tid * kEmitU + u;
-        ex[u] = i < n_all ? extra[i].x : 0u;
+        ex[u] = i < hi ? extra[i].x : 0u;
       }
       int cnt = 0;
 #pragma unroll
       for (int u = 0; u < kEmitU; ++u) {
         const int i = i0 + tid * kEmitU + u;
-        fr[u] = 0;
-        // dead = priced by the back-pruning (its frame is below pruned_upto), extra +inf, and not one of frame 0's before
-        // FinalizeDecoding; only the living look their frame up
-        alive[u] = i < n_all && !(ex[u] >= kInfO && i < f_pruned && !(i < f_one && !finalized));
-        if (alive[u]) {
-          int lo = 0, hi = nd + 1;  // frame of token i: foff[f] <= i < foff[f+1]
-          while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (foff_at(mid) <= i) lo = mid; else hi = mid;
-          }
-          fr[u] = lo;
-        }
+        // dead = priced by the back-pruning (its frame is below pruned_upto), extra +inf, and not one of frame 0's before FinalizeDecoding
+        alive[u] = i < hi && !(ex[u] >= kInfO && i < f_pruned && !(i < f_one && !finalized));
         cnt += alive[u] ? 1 : 0;
       }
       int tot;
       int p = base + block_exscan(cnt, ps, &tot);
 #pragma unroll
       for (int u = 0; u < kEmitU; ++u) {
-        if (!alive[u]) continue;
         const int i = i0 + tid * kEmitU + u;
-        if (p >= D.lat_tok_cap) s_err = 1;
-        else {
-          const int4 t = tok[i];
-          const int f = fr[u];
-          const int fin = (f == nd && (!use_final || !any_final || t.x == D.g.final_state)) ? 1 : 0;
-          out_toks[p] = make_int4(i, D.g.arcs[t.x].y, t.y, f | (fin << 30));  // .y: the graph's own state id (row header)
-        }
-        ++p;
+        if (i < hi) remap[i] = alive[u] ? p : -1;
+        p += alive[u] ? 1 : 0;
       }
       base += tot;
     }
-    if (tid == 0) s_ntoks = base;
-    __syncthreads();
-#if defined(WFST_EXP_EMIT_T)
-    if (tid == 0 && blockIdx.x < 3) printf("EMIT c %d n_all %d toks %d t_tok %lld\n", c, n_all, base, wall_clock64() - te0);
-#endif
+    if (tid == 0) pp[g] = base;
   }
-  // links: one flat pass over the link store, kEmitU per thread in flight; a link's segment (found in the bounds) tells the source
+  // links: a flat pass over the slab, kEmitU per thread in flight; a living link's segment (found in the bounds) tells the source
   // frame and whether the arc is an epsilon
-  {
+  auto emit_links = [&](auto lseg_at) {
     const int l_lo = lseg_at(0), l_hi = lseg_at(2 * (nd + 1));
-    for (int i0 = l_lo; i0 < l_hi; i0 += kBT * kEmitU) {
+    const int sl = emit_slab_len(l_hi - l_lo), lo = min(l_hi, l_lo + g * sl), hi = min(l_hi, lo + sl);
+    for (int i0 = lo; i0 < hi; i0 += kBT * kEmitU) {
       int4 L[kEmitU];
 #pragma unroll
       for (int u = 0; u < kEmitU; ++u) {
         const int i = i0 + u * kBT + tid;
-        L[u] = i < l_hi ? links[i] : make_int4(-1, 0, 0, 0);
+        L[u] = i < hi ? links[i] : make_int4(-1, 0, 0, 0);
       }
       int4 A[kEmitU];
       int il[kEmitU], ol[kEmitU];
@@ -3743,18 +3730,24 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
       }
 #pragma unroll
       for (int u = 0; u < kEmitU; ++u) {
-        if (L[u].x < 0) continue;
+        const bool on = L[u].x >= 0;
+        const u64 m = __ballot(on);
+        if (!m) continue;
+        int wb = 0;
+        if (lane == 0) wb = atomicAdd(&pp[8], __popcll(m));
+        wb = __shfl(wb, 0, 64);
+        if (!on) continue;
         const int i = i0 + u * kBT + tid;
-        int lo = 0, hi = 2 * (nd + 1);   // segment q: lseg[q] <= i < lseg[q + 1]; q = 2 f: emitting links into frame f, 2 f + 1: epsilon links inside f
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (lseg_at(mid) <= i) lo = mid; else hi = mid;
+        int lo2 = 0, hi2 = 2 * (nd + 1);   // segment q: lseg[q] <= i < lseg[q + 1]; q = 2 f: emitting links into frame f, 2 f + 1: epsilon links inside f
+        while (hi2 - lo2 > 1) {
+          const int mid = (lo2 + hi2) >> 1;
+          if (lseg_at(mid) <= i) lo2 = mid; else hi2 = mid;
         }
-        const int f = lo >> 1;
-        const bool eps = lo & 1;
+        const int f = lo2 >> 1;
+        const bool eps = lo2 & 1;
         const int src_frame = eps ? f : f - 1;
-        const int p = atomicAdd(&s_narcs, 1);
-        if (p >= D.lat_arc_cap) { s_err = 1; continue; }
+        const int p = wb + lane_rank(m);
+        if (p >= D.lat_arc_cap) { pp[9] = 1; continue; }
         LatArc o;
         o.src_tok = L[u].x; o.dst_tok = L[u].y;
         o.ilabel = eps ? 0 : il[u];
@@ -3769,18 +3762,73 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
         out_arcs[p] = o;
       }
     }
-  }
   };
-  if (in_lds) emit_all([&](int f) { return s_foff[f]; }, [&](int q) { return s_lseg[q]; });
-  else emit_all([&](int f) { return foff[f]; }, [&](int q) { return (q & 1) ? ((q >> 1) <= nd ? lmid[q >> 1] : loff[q >> 1]) : loff[q >> 1]; });
+  if (in_lds) emit_links([&](int q) { return sb.lseg[q]; });
+  else emit_links([&](int q) { return (q & 1) ? ((q >> 1) <= nd ? lmid[q >> 1] : loff[q >> 1]) : loff[q >> 1]; });
+}
+
+__global__ __launch_bounds__(kBT) void lattice_emit_tokens_kernel(DecoderDev D, const int32_t *chans, int use_final) {
+  const int c = chans ? chans[blockIdx.x] : blockIdx.x;
+  const int g = blockIdx.y;
+  const int tid = threadIdx.x;
+  ChanCtl *ctl = D.ctl + c;
+  const int nd = ctl->n_decoded;
+  const int4 *tok = D.tok + (size_t)c * D.arena_cap;
+  int4 *out_toks = D.lat_toks + (size_t)c * D.lat_tok_cap;
+  const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
+  const int32_t *pp = D.prune_par + (size_t)c * kPrParInts + 16;
+  const int32_t *remap = D.remap + (size_t)c * D.arena_cap;
+  __shared__ int s_any_final, s_err;
+  __shared__ int s_foff[kEmitFrames + 2];
+  if (tid == 0) { s_any_final = 0; s_err = 0; }
   __syncthreads();
-#if defined(WFST_EXP_EMIT_T)
-  if (tid == 0 && blockIdx.x < 3) printf("EMIT c %d links %d..%d arcs %d t_all %lld nd %d\n", c, loff[0], loff[nd + 1], s_narcs, wall_clock64() - te0, nd);
-#endif
-  if (tid == 0) {
-    ctl->lat_arcs = min(s_narcs, D.lat_arc_cap);
-    ctl->lat_toks = min(s_ntoks, D.lat_tok_cap);
-    if (s_err) ctl->error |= kErrLinksFull;
+  if (ctl->error) return;
+  if (use_final) {
+    int any = 0;
+    for (int i = foff[nd] + tid; i < foff[nd + 1]; i += kBT) any |= tok[i].x == D.g.final_state;
+    if (any) s_any_final = 1;
+  }
+  const bool in_lds = nd + 2 <= kEmitFrames + 2;
+  if (in_lds)
+    for (int f = tid; f <= nd + 1; f += kBT) s_foff[f] = foff[f];
+  __syncthreads();
+  const bool any_final = s_any_final != 0;
+  int base = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < kEmitSlabs; ++q) { base += q < g ? pp[q] : 0; total += pp[q]; }
+  const int n_all = foff[nd + 1];
+  const int sl = emit_slab_len(n_all), lo = min(n_all, g * sl), hi = min(n_all, lo + sl);
+  auto write_slab = [&](auto foff_at) {
+    for (int i0 = lo; i0 < hi; i0 += kBT * kEmitU) {
+      int r[kEmitU];
+#pragma unroll
+      for (int u = 0; u < kEmitU; ++u) {
+        const int i = i0 + u * kBT + tid;
+        r[u] = i < hi ? remap[i] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kEmitU; ++u) {
+        if (r[u] < 0) continue;
+        const int i = i0 + u * kBT + tid, p = base + r[u];
+        if (p >= D.lat_tok_cap) { s_err = 1; continue; }
+        int flo = 0, fhi = nd + 1;  // frame of token i: foff[f] <= i < foff[f+1]
+        while (fhi - flo > 1) {
+          const int mid = (flo + fhi) >> 1;
+          if (foff_at(mid) <= i) flo = mid; else fhi = mid;
+        }
+        const int4 t = tok[i];
+        const int fin = (flo == nd && (!use_final || !any_final || t.x == D.g.final_state)) ? 1 : 0;
+        out_toks[p] = make_int4(i, D.g.arcs[t.x].y, t.y, flo | (fin << 30));  // .y: the graph's own state id (row header)
+      }
+    }
+  };
+  if (in_lds) write_slab([&](int f) { return s_foff[f]; });
+  else write_slab([&](int f) { return foff[f]; });
+  __syncthreads();
+  if (tid == 0 && (s_err || (g == 0 && pp[9]))) atomicOr(&ctl->error, kErrLinksFull);
+  if (tid == 0 && g == 0) {
+    ctl->lat_arcs = min(pp[8], D.lat_arc_cap);
+    ctl->lat_toks = min(total, D.lat_tok_cap);
   }
 }
 
@@ -3880,12 +3928,15 @@ void launch_best_path(const DecoderDev &D, const int32_t *chans, int n, int use_
     hipLaunchKernelGGL(best_path_kernel<false>, dim3(n), dim3(kBpThreads), 0, s, D, chans, use_final, cap, ilabel, olabel, graph,
                        ac, n_hops, chain);
 }
+void launch_lattice_emit(const DecoderDev &D, const int32_t *chans, int n, int use_final, hipStream_t s);
 void launch_lattice_prune(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(lattice_finalize_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
-  hipLaunchKernelGGL(lattice_emit_kernel, dim3(n), dim3(kBT), 0, s, D, chans, 1);
+  launch_lattice_emit(D, chans, n, 1, s);
 }
 void launch_lattice_emit(const DecoderDev &D, const int32_t *chans, int n, int use_final, hipStream_t s) {
-  hipLaunchKernelGGL(lattice_emit_kernel, dim3(n), dim3(kBT), 0, s, D, chans, use_final);
+  hipLaunchKernelGGL(lattice_emit_reset_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, s, D, chans, n);
+  hipLaunchKernelGGL(lattice_emit_kernel, dim3(n, kEmitSlabs), dim3(kBT), 0, s, D, chans, use_final);
+  hipLaunchKernelGGL(lattice_emit_tokens_kernel, dim3(n, kEmitSlabs), dim3(kBT), 0, s, D, chans, use_final);
 }
 int insert_kernel_set_lds(int bytes) {
   int e = (int)hipFuncSetAttribute((const void *)insert_kernel_lattice, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
