@@ -62,6 +62,8 @@ struct DetWs {
   int32_t oa_n;
   // scratch
   DetElem *ta, *tb, *tc, *td, *te;  // [tmp] each
+  DetElem *tb_lo, *tc_lo;           // [tmp_lo] each, or null: a faster home (the device: LDS) for the closure's queue and element
+  int32_t tmp_lo;                   // list -- what the one lane stores and reads back right away; a closure that outgrows it is run again in tb / tc
   int32_t *ta_label;            // [tmp] labels beside ta
   int32_t *cl_idx;              // [n_states] closure: state -> index in tc, -1
   int32_t *labs;                // [tmp] label sequences
@@ -95,6 +97,7 @@ WFST_HD inline int32_t det_pow2_le(int64_t x) {
 WFST_HD inline void det_carve(DetWs &W, int32_t *base, const DetCaps &c, int32_t n_states) {
   int32_t *p = base;
   W.cap = c;
+  W.tb_lo = nullptr; W.tc_lo = nullptr; W.tmp_lo = 0;   // (the caller may set them after det_carve)
   W.osf = p; p += n_states;
   W.tr_parent = p; p += c.trie;
   W.tr_label = p; p += c.trie;
@@ -235,60 +238,70 @@ WFST_HD inline void det_sort_by_state(DetElem *e, int32_t n) {  // subsets are s
 
 // EpsilonClosure (:842-936) of subset e[0..n) (one element per state), in place; returns the new size, sorted by state
 WFST_HD inline int32_t det_closure(DetWs &W, DetElem *e, int32_t n) {
-  DetElem *cur = W.tc;     // the current best element of every state reached
-  DetElem *queue = W.tb;   // FIFO of elements to expand (a ring: an improved state is queued again)
-  int32_t ncur = 0;
-  int32_t qh = 0, qt = 0, qn = 0;   // ring: head, tail, elements queued (no 64-bit modulo: the lane is instruction-bound)
-  const int32_t cap = W.cap.tmp;
-  for (int32_t i = 0; i < n; ++i) {
-    if (ncur >= cap) { W.err = 6; break; }
-    W.cl_idx[e[i].state] = ncur;
-    cur[ncur++] = e[i];
-    queue[qt] = e[i];
-    if (++qt == cap) qt = 0;
-    ++qn;
-  }
-  bool replaced = false;
-  while (qn > 0 && !W.err) {
-    const DetElem el = queue[qh];
-    if (++qh == cap) qh = 0;
-    --qn;
-    if (replaced) {  // a better element for this state is further down the queue: skip the stale one
-      const DetElem &c = cur[W.cl_idx[el.state]];
-      if (c.str != el.str || c.w1 != el.w1 || c.w2 != el.w2) continue;
+  for (int pass = (W.tmp_lo > 0 && n <= W.tmp_lo) ? 0 : 1; pass < 2; ++pass) {
+    DetElem *cur = pass == 0 ? W.tc_lo : W.tc;     // the current best element of every state reached
+    DetElem *queue = pass == 0 ? W.tb_lo : W.tb;   // FIFO of elements to expand (a ring: an improved state is queued again)
+    const int32_t cap = pass == 0 ? W.tmp_lo : W.cap.tmp;
+    int32_t ncur = 0;
+    int32_t qh = 0, qt = 0, qn = 0;   // ring: head, tail, elements queued (no 64-bit modulo: the lane is instruction-bound)
+    bool over = false;
+    for (int32_t i = 0; i < n; ++i) {
+      if (ncur >= cap) { over = true; break; }
+      W.cl_idx[e[i].state] = ncur;
+      cur[ncur++] = e[i];
+      queue[qt] = e[i];
+      if (++qt == cap) qt = 0;
+      ++qn;
     }
-    for (int32_t a = W.off[el.state]; a < W.off[el.state + 1]; ++a) {
-      const DetArc &arc = W.arcs[a];
-      if (arc.ilabel != 0) break;  // sorted: no more epsilons
-      if (det_is_zero(arc.w1, arc.w2)) continue;
-      DetElem nx;
-      nx.state = arc.to;
-      nx.w1 = el.w1 + arc.w1;
-      nx.w2 = el.w2 + arc.w2;
-      nx.str = arc.olabel == 0 ? el.str : det_succ(W, el.str, arc.olabel);
-      const int32_t idx = W.cl_idx[nx.state];
-      bool push = false;
-      if (idx < 0) {
-        if (ncur >= cap) { W.err = 6; break; }
-        W.cl_idx[nx.state] = ncur;
-        cur[ncur++] = nx;
-        push = true;
-      } else if (det_cmp(W, nx.w1, nx.w2, nx.str, cur[idx].w1, cur[idx].w2, cur[idx].str) == 1) {
-        cur[idx].w1 = nx.w1; cur[idx].w2 = nx.w2; cur[idx].str = nx.str;
-        push = true;
-        replaced = true;
+    bool replaced = false;
+    while (qn > 0 && !W.err && !over) {
+      const DetElem el = queue[qh];
+      if (++qh == cap) qh = 0;
+      --qn;
+      if (replaced) {  // a better element for this state is further down the queue: skip the stale one
+        const DetElem &c = cur[W.cl_idx[el.state]];
+        if (c.str != el.str || c.w1 != el.w1 || c.w2 != el.w2) continue;
       }
-      if (push) {
-        if (qn >= cap) { W.err = 6; break; }
-        queue[qt] = nx;
-        if (++qt == cap) qt = 0;
-        ++qn;
+      for (int32_t a = W.off[el.state]; a < W.off[el.state + 1]; ++a) {
+        const DetArc &arc = W.arcs[a];
+        if (arc.ilabel != 0) break;  // sorted: no more epsilons
+        if (det_is_zero(arc.w1, arc.w2)) continue;
+        DetElem nx;
+        nx.state = arc.to;
+        nx.w1 = el.w1 + arc.w1;
+        nx.w2 = el.w2 + arc.w2;
+        nx.str = arc.olabel == 0 ? el.str : det_succ(W, el.str, arc.olabel);
+        const int32_t idx = W.cl_idx[nx.state];
+        bool push = false;
+        if (idx < 0) {
+          if (ncur >= cap) { over = true; break; }
+          W.cl_idx[nx.state] = ncur;
+          cur[ncur++] = nx;
+          push = true;
+        } else if (det_cmp(W, nx.w1, nx.w2, nx.str, cur[idx].w1, cur[idx].w2, cur[idx].str) == 1) {
+          cur[idx].w1 = nx.w1; cur[idx].w2 = nx.w2; cur[idx].str = nx.str;
+          push = true;
+          replaced = true;
+        }
+        if (push) {
+          if (qn >= cap) { over = true; break; }
+          queue[qt] = nx;
+          if (++qt == cap) qt = 0;
+          ++qn;
+        }
       }
     }
+    if (over) {
+      for (int32_t i = 0; i < ncur; ++i) W.cl_idx[cur[i].state] = -1;
+      if (pass == 0) continue;   // (outgrew the fast buffers: once more in the workspace's; the trie nodes made so far are found again)
+      W.err = 6;
+      return 0;
+    }
+    for (int32_t i = 0; i < ncur; ++i) { W.cl_idx[cur[i].state] = -1; e[i] = cur[i]; }
+    det_sort_by_state(e, ncur);
+    return ncur;
   }
-  for (int32_t i = 0; i < ncur; ++i) { W.cl_idx[cur[i].state] = -1; e[i] = cur[i]; }
-  det_sort_by_state(e, ncur);
-  return ncur;
+  return 0;
 }
 
 // ConvertToMinimal (:940-957)

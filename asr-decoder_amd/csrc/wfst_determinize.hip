@@ -10,7 +10,8 @@
 // dependent LDS load, 55-100 ns for a dependent L1 / L2 load and 2-4 ns per dependent ALU instruction; every load that follows a
 // store also waits for that store's acknowledgement (one in-order counter on gfx9).  Tried and dropped: the hot tables (first 8192
 // trie nodes + a 16-bit hash, closure buffers, state index) in LDS behind low / high accessors -- slower (mean 18.8 vs 16.9 ms,
-// largest 88 vs 69 ms: the accessors' instructions cost more than the loads save); walking straight stretches of the raw
+// largest 88 vs 69 ms: the accessors' instructions cost more than the loads save -- the closure's queue and element list ALONE in LDS,
+// as plain pointers with a rerun in the workspace's buffers on overflow, are kept: -3 %); walking straight stretches of the raw
 // lattice without queue / index traffic -- 5 % (and it changes the closure's visiting order).  What did pay: the closure's ring
 // buffer without 64-bit modulo (-10 %).  Speeding this up for real needs parallelism INSIDE a lattice.
 #include "wfst_determinize.h"
@@ -19,6 +20,7 @@
 namespace wfst {
 
 constexpr int kDetThreads = 256;
+constexpr int kDetLowTmp = 1024;   // elements of the closure's LDS buffers (a closure that outgrows them runs again in the workspace's)
 
 __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, DetDev X, const int32_t *chans) {
   const int slot = blockIdx.x;
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
   // the root token (arena entry 0) must be state 0: lat_toks is in arena order, so it is
   // ---- the subset construction: tables cleared by everyone, then one lane ---------------------------------
   __shared__ DetWs W;
+  __shared__ DetElem s_tb[kDetLowTmp], s_tc[kDetLowTmp];
   if (tid == 0) {
     W.n_states = nt;
     W.n_arcs = na;
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
     W.is_final = fin;
     W.delta = 1.0f / 1024;   // kDelta (DeterminizeLatticeOptions, lattice-determinize-api.h:16-25)
     det_carve(W, rest, X.caps, nt);
+    W.tb_lo = s_tb; W.tc_lo = s_tc; W.tmp_lo = kDetLowTmp;   // the closure's queue and element list in LDS
   }
   __syncthreads();
   // The string trie's hash table is carved for the workspace's full capacity (a million slots, 4 MB); a lattice of a few thousand

@@ -721,8 +721,10 @@ def build_det_host():
     return C.CDLL(DET_HOST_SO)
 
 
-def det_host_run(lib, L, cap_scale=4, max_states=1 << 20, max_arcs=1 << 21):
-    """The device's determinization code, run on the host, on the raw lattice L (RawLattice): (status, RawLattice)."""
+def det_host_run(lib, L, cap_scale=4, max_states=1 << 20, max_arcs=1 << 21, low_tmp=0):
+    """The device's determinization code, run on the host, on the raw lattice L (RawLattice): (status, RawLattice).
+    low_tmp > 0: the closure's fast buffers (LDS on the device) emulated at this many elements."""
+    lib.det_host_set_low(int(low_tmp))
     ns, na = C.c_int(0), C.c_int(0)
     fin = np.zeros(max_states, np.int32)
     src, dst, il, ol = (np.zeros(max_arcs, np.int32) for _ in range(4))

@@ -11,7 +11,11 @@
 
 using namespace wfst;
 
+// the closure's fast buffers (LDS on the device) emulated at a tiny size, so that closures outgrow them (det_host_set_low)
+static int g_low_tmp = 0;
+
 extern "C" {
+void det_host_set_low(int tmp_lo) { g_low_tmp = tmp_lo; }
 // Raw lattice in: states 0..S-1 (0 = start), final flags, arcs {src, dst, ilabel (transition-id), olabel (word),
 // graph, acoustic}.  Determinized lattice out, in the wrapper's output form (after its last Invert): arcs
 // {src, dst, ilabel 0, olabel word or 0, graph, acoustic}; a final weight is an arc to an extra final state.
@@ -47,6 +51,8 @@ int det_host_run(int S, const int *is_final, int A, const int *a_src, const int 
   W.n_states = S; W.n_arcs = A; W.off = off.data(); W.arcs = arcs.data(); W.is_final = fin.data();
   W.delta = 1.0f / 1024;   // kDelta, DeterminizeLatticeOptions (lattice-determinize-api.h:16-25)
   det_carve(W, ws.data(), c, S);
+  std::vector<DetElem> lo_b((size_t)g_low_tmp + 1), lo_c((size_t)g_low_tmp + 1);
+  if (g_low_tmp > 0) { W.tb_lo = lo_b.data(); W.tc_lo = lo_c.data(); W.tmp_lo = g_low_tmp; }
   det_init(W, 0, 1);
   const int err = det_run(W);
   // OutputNoolabel (:307-377) + Invert
