@@ -109,7 +109,8 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
   int32_t *cnt = cur + N.tok_cap;          // [tok_cap]     entries in a state's list
   int32_t *fbeg = cnt + N.tok_cap;         // [max_frames + 2] first state of a frame
   int32_t *fend = fbeg + D.max_frames + 2; // [max_frames + 2]
-  int32_t *in_arcs = fend + D.max_frames + 2;  // [arc_cap]
+  int32_t *feps = fend + D.max_frames + 2; // [max_frames + 2] the frame has arcs between its own states (epsilon arcs)
+  int32_t *in_arcs = feps + D.max_frames + 2;  // [arc_cap]
   __shared__ int s_part[kNbThreads];
   __shared__ int s_changed;
   if (tid == 0) N.out_n[slot] = 0;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
     return;
   }
   // ---- index: arena index -> lattice state, frames, incoming-arc lists ------------------------
-  for (int f = tid; f <= nd; f += kNbThreads) { fbeg[f] = 0; fend[f] = 0; }
+  for (int f = tid; f <= nd; f += kNbThreads) { fbeg[f] = 0; fend[f] = 0; feps[f] = 0; }
   __syncthreads();
   for (int i = tid; i < nt; i += kNbThreads) {
     const int4 t = toks[i];
@@ -132,7 +133,11 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
   }
   if (tid == 0) off[nt] = 0;
   __syncthreads();
-  for (int a = tid; a < na; a += kNbThreads) atomicAdd(&off[state_of[arcs[a].dst_tok]], 1);
+  for (int a = tid; a < na; a += kNbThreads) {
+    const LatArc A = arcs[a];
+    atomicAdd(&off[state_of[A.dst_tok]], 1);
+    if (A.is_eps) feps[A.src_frame] = 1;   // (an epsilon arc stays inside its frame)
+  }
   __syncthreads();
   {  // exclusive scan of off[0..nt) (one contiguous slice per thread)
     const int per = (nt + kNbThreads - 1) / kNbThreads, b = tid * per, e = min(nt, b + per);
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
       }
       const int ch = s_changed;
       __syncthreads();
-      if (!ch) break;
+      // (a frame without arcs between its own states -- five in six -- is final after one round: its lists depend on earlier frames only)
+      if (!ch || !feps[f]) break;
     }
   }
   // ---- the final states: merge their lists, trace the paths back ------------------------------
