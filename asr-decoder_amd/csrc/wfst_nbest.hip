@@ -283,20 +283,25 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
       const size_t o = (size_t)slot * N.n + lane;
       N.out_tot[o] = keep.tot;
       N.out_lm[o] = keep.lm;
-      // pass 1: count the words; pass 2: write them back to front
+      // ONE walk down the path (a few hundred dependent hops): the words come out last to first, then the short list is turned round
+      int32_t *w = N.out_words + o * N.max_words;
       int nw = 0;
       for (int p = keep.prev; p >= 0;) {
         const NbEntry E = list[(size_t)(p >> 4) * K + (p & 15)];
-        nw += E.word != 0;
+        if (E.word != 0) { if (nw < N.max_words) w[nw] = E.word; ++nw; }
         p = E.prev;
       }
       N.out_nwords[o] = nw;
-      int32_t *w = N.out_words + o * N.max_words;
-      int k = nw;
-      for (int p = keep.prev; p >= 0;) {
-        const NbEntry E = list[(size_t)(p >> 4) * K + (p & 15)];
-        if (E.word != 0) { --k; if (k < N.max_words) w[k] = E.word; }
-        p = E.prev;
+      if (nw <= N.max_words) {
+        for (int i = 0, j = nw - 1; i < j; ++i, --j) { const int32_t x = w[i]; w[i] = w[j]; w[j] = x; }
+      } else {
+        // (more words than the caller's buffer takes: it wants the FIRST max_words -- the walk met them last; once more, keeping those)
+        int k = nw;
+        for (int p = keep.prev; p >= 0;) {
+          const NbEntry E = list[(size_t)(p >> 4) * K + (p & 15)];
+          if (E.word != 0) { --k; if (k < N.max_words) w[k] = E.word; }
+          p = E.prev;
+        }
       }
     }
   }
