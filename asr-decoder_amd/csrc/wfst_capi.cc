@@ -1111,8 +1111,11 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // (measured on the bench workload: equal at 64 channels, +5 % at 128, +7 % at 256; three or more streams share
   // hardware queues and lose)
   // (biglm decoders: three -- their launches are chains of LM look-ups on small frontiers, a third stream still finds idle
-  // CUs: 36.5 vs 40.7 ms per step at 128 channels; a fourth shares a hardware queue and loses)
-  d->n_groups = std::min(O.channel_groups > 0 ? O.channel_groups : (big && n_channels >= 96) ? 3 : (n_channels >= 64 ? 2 : 1), n_channels);
+  // CUs: 36.5 vs 40.7 ms per step at 128 channels; a fourth shares a hardware queue and loses; lattice decoders: three as well --
+  // the back-pruning steps and the per-frame link work of one group leave room beside two others: 54.2 -> 52.3 ms per step at
+  // beam 13, 183.6 -> 170.4 at beam 15)
+  const bool three = (big || L.lattice_links > 0) && n_channels >= 96;
+  d->n_groups = std::min(O.channel_groups > 0 ? O.channel_groups : three ? 3 : (n_channels >= 64 ? 2 : 1), n_channels);
   if (d->n_groups > 1) {
     d->gstreams.resize(d->n_groups);
     d->gevents.resize(d->n_groups + 1);
