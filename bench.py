@@ -472,15 +472,23 @@ def main():
         torch.cuda.synchronize(dev)
 
     def timed(step, warmup, steps):
+        import gc
+
         res = None
         for _ in range(warmup):
             res = step()
         fence()
+        # (the interpreter's cyclic collector is kept out of the timed region: with torch's millions of objects alive, the one full
+        # collection an early step triggers is a ~35 ms pause of the HOST -- a lattice step builds 128 x 5 result dicts -- that has
+        # nothing to do with the decoder; collected before, re-enabled after)
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         for _ in range(steps):
             res = step()
         fence()
         dt = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
