@@ -825,7 +825,7 @@ def main():
         legs = {"biglm": ["--biglm", "--steps", str(n2), "--cpu-sample", "8", "--max-tokens", "131072"],
                 "lattice_beam15": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
                                    "--max-tokens", "262144", "--determinize", "--steps", str(max(2, n2 // 2)), "--cpu-sample", "4",
-                                   "--warmup", "2"]}   # (the n-best / determinizer paths allocate their workspaces on first use and the second call still pays a one-off)
+                                   "--warmup", "2"]}   # (the n-best / determinizer paths allocate their workspaces on first use)
         for name, extra in legs.items():
             t0 = time.time()
             try:
