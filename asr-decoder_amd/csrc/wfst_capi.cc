@@ -156,7 +156,7 @@ struct wfst_decoder {
   DevBuf<unsigned long long> lat_stats;
   DevBuf<FrameCtl> fctl;
   DevBuf<unsigned long long> dbg_t;
-  DevBuf<int32_t> items;
+  DevBuf<int32_t> items, item_pref;
   DevBuf<TileDesc> tiles;
   int insert_wgs = 768;
   std::vector<int> gpar;  // step parity per group (persists across advance calls)
@@ -258,7 +258,7 @@ struct wfst_decoder {
     np_ws.release(); np_out.release(); np_off.release(); np_arcs.release(); np_tot.release(); np_lists.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); emit_cnt.release(); prune_par.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); lat_stats.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
+    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); lat_stats.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); item_pref.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -968,10 +968,11 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   }
   const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 128 + 2);  // tiles of 128 tokens at least (prep_frame)
   A(d->fctl.alloc(8));
-  A(d->dbg_t.alloc(64));
+  A(d->dbg_t.alloc(128));
   A(d->tiles.alloc(8 * tile_cap));
   const size_t item_cap = 2 * B * (size_t)n_part;  // two lists (heavy from the front, light from the back), each sized for the worst case
   A(d->items.alloc(8 * item_cap));
+  A(d->item_pref.alloc(8 * item_cap * 64));   // the record prefix of every listed item, beside it (plan_channel)
   A(d->target.alloc(B));
   A(d->chan_list.alloc(B));
   A(d->ll_base.alloc(B));
@@ -1058,6 +1059,8 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // then buys a fraction of a tile's work (measured at the service's 7000: 42.6 vs 31.4 ms of expansion per step), and
   // expand_kernel_fused's 512-token tiles stay.  (0x800: the replay experiments are expand_body's; 0x8000: A/B)
   D.staged = (D.fused && !big && cfg->max_active >= L.max_tokens_per_frame && !(O.debug & 0x8800)) ? 1 : 0;
+  // the expansion finds the frame's best token itself (its cheapest candidate): the staged kernel of best_row decoders (0x20000: A/B)
+  D.best_exp = (D.staged && D.best_row && !(O.debug & 0x20000)) ? 1 : 0;
   D.seed_tiles = (D.best_row && !(O.debug & 0x4800)) ? 1 : 0;   // (0x800: the replay experiments start from the frame's seed; 0x4000: A/B)
   if (D.best_row && !(O.debug & 0x2000) && cfg->max_active >= L.max_tokens_per_frame && cfg->min_active == 0) {
     int64_t reserve = std::max<int64_t>(2ll * L.max_tokens_per_frame, L.arena_tokens / 8);
@@ -1075,6 +1078,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.tiles = d->tiles.p;
   D.tile_cap = (int32_t)tile_cap;
   D.items = d->items.p;
+  D.item_pref = d->item_pref.p;
   D.item_cap = (int32_t)item_cap;
   D.ll_base = d->ll_base.p;
   D.n_channels = n_channels;
@@ -1134,7 +1138,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
 
 void wfst_decoder_free(wfst_decoder *d) {
   if (d && (d->D.dbg & 224)) {  // debug phase timers (100 MHz ticks)
-    unsigned long long t[64];
+    unsigned long long t[128];
     (void)hipSetDevice(d->device);
     (void)hipDeviceSynchronize();
     if (hipMemcpy(t, d->dbg_t.p, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1146,6 +1150,13 @@ void wfst_decoder_free(wfst_decoder *d) {
         if (t[3 * k + 2])
           fprintf(stderr, "[wfst dbg] %-18s n=%llu mean=%.2f us max=%.2f us\n", names[k], t[3 * k + 2],
                   0.01 * t[3 * k] / t[3 * k + 2], 0.01 * t[3 * k + 1]);
+      {
+        const char *more[] = {"insert:head (launch/ticket -> item known)", "insert:countdown+ticket", "insert:frame boundary"};
+        for (int k = 22; k < 25; ++k)
+          if (t[3 * k + 2]) fprintf(stderr, "[wfst dbg] %-18s n=%llu mean=%.2f us max=%.2f us\n", more[k - 22], t[3 * k + 2], 0.01 * t[3 * k] / t[3 * k + 2], 0.01 * t[3 * k + 1]);
+      }
+      if (t[62] && (d->D.dbg & 128))
+        fprintf(stderr, "[wfst dbg] %-18s n=%llu mean=%.2f us max=%.2f us\n", "expand:descriptor+tokens landed", t[62], 0.01 * t[60] / t[62], 0.01 * t[61]);
       if (t[52])
         fprintf(stderr, "[wfst dbg] prune passes=%llu walk mean=%.1f us compaction mean=%.1f us frames walked mean=%.1f\n", t[52],
                 0.01 * t[51] / t[52], 0.01 * t[54] / t[52], (double)t[53] / t[52]);
@@ -1258,6 +1269,13 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   HIP_TRY(hipMemcpyAsync((void *)d->ll_base.p, (const void *)d->p_ll, (size_t)d->n_channels * sizeof(float *),
                          hipMemcpyHostToDevice, d->stream));
   d->D.stride = stride;
+  {
+    // expand_kernel_staged_row (wfst_kernels.hip): the frame's log-likelihood row of a tile's channel staged in LDS by 16-byte DMAs
+    bool ok = d->D.staged && !(d->D.dbg & 0x10000) && (stride & 3) == 0 && stride <= 3072;
+    for (int c = 0; ok && c < d->n_channels; ++c)
+      if (d->h_ll_base[c] && ((uintptr_t)d->h_ll_base[c] & 15u)) ok = false;
+    d->D.ll_row = ok ? 1 : 0;
+  }
   if (steps == 0) return WFST_OK;
   // frames to decode per channel group
   const int G = d->n_groups, per = (d->n_channels + G - 1) / G;
@@ -1314,7 +1332,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   auto run_group = [&](int g, hipStream_t st) -> int {
     if (gsteps[g] == 0) return WFST_OK;
     if (!(d->use_graph && !d->profiling && gsteps[g] >= 4)) { enqueue_group(g, st); return WFST_OK; }
-    std::vector<int> key = {g, gsteps[g], (int)stride, gpar0[g]};
+    std::vector<int> key = {g, gsteps[g], (int)stride, gpar0[g], (int)d->D.ll_row};
     for (int s = -1; s < gsteps[g]; ++s)
       if (prune_step(g, s)) key.push_back(s);   // (the launch sequence differs with the steps that prune)
     auto it = d->graphs.find(key);

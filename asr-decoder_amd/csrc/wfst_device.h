@@ -8,6 +8,7 @@
 #define WFST_DEVICE_H_
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace wfst {
@@ -189,26 +190,29 @@ struct __attribute__((aligned(128))) ChanCtl {
   uint32_t bound;        // orderable next_cutoff, tightened during expansion (atomicMin)
   float cur_cutoff;      // GetCutoff() result for the frame being expanded
   float adaptive_beam;
-  int32_t new_count;     // tokens of the frame being built (atomicAdd by the insert workgroups)
-  unsigned long long best_next;  // min (orderable cost << 32 | arena index) over the new frame
+  int32_t peak_tokens;
+  unsigned long long best_next;  // min (orderable cost << 32 | arena index) over the new frame (best_row decoders: | graph row; staged
+                                 // best_row decoders: set by the EXPANSION -- the cheapest candidate is the cheapest token)
   int32_t eps_occ;       // occupied slots of the epsilon table   } one 8-byte word: the insert
   int32_t wl_n;          // epsilon-closure seeds queued          } workgroups bump both at once
   int32_t error;         // sticky kErr* bits
   int32_t finalized;
-  int32_t peak_tokens;
-  int32_t spare0;        // (unused)
+  // one 8-byte word: two-launch decoders allocate an item's tokens (add to the low half) and count the item out (subtract from
+  // the high half) with 64-bit atomics on it, so the workgroup that counts the LAST item out learns the frame's token count
+  // from the same answer (kFrameErrBit: an item of this frame could not write its tokens)
+  int32_t new_count;     // tokens of the frame being built (atomicAdd by the insert workgroups)
+  int32_t items_left;    // fused best-path decoders: insert work items of the frame not finished yet (the workgroup that
+                         // finishes the last one closes the frame and prepares the next: frame_boundary_fused)
   unsigned long long cnt_N, cnt_E, cnt_Z, cnt_tok, cnt_rec;  // work counters since init
   int32_t link_count;    // lattice mode: forward links recorded so far (atomicAdd)
   int32_t lat_arcs;      // lattice mode, after lattice_prune_kernel: surviving links in lat_arcs[]
   int32_t lat_toks;      //   "   surviving tokens in lat_toks[]
   int32_t tiles_left;    // expansion tiles of the frame not finished yet (the last one plans the insert items)
-  union {
-    int32_t pair_count;  // biglm: LM pair states interned since InitDecoding (atomicAdd)
-    int32_t items_left;  // fused best-path decoders: insert work items of the frame not finished yet (the workgroup that
-                         // finishes the last one closes the frame and prepares the next: frame_boundary_fused)
-  };
+  int32_t pair_count;    // biglm: LM pair states interned since InitDecoding (atomicAdd)
   int32_t pruned_upto;   // lattice mode: NumFramesDecoded() at the last back-pruning pass (frames below hold extras)
 };
+static_assert(offsetof(ChanCtl, new_count) % 8 == 0 && offsetof(ChanCtl, items_left) == offsetof(ChanCtl, new_count) + 4, "the {new_count, items_left} word");
+constexpr unsigned long long kFrameErrBit = 1ull << 62;   // in the {new_count, items_left} word (items_left stays below 2^16)
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
 
 // One 256/512-token tile of a channel's frontier, listed by prep_frame for the expansion: everything
@@ -303,6 +307,8 @@ struct DecoderDev {
   int32_t degcode;              // tokens and records carry degree codes (fused rows, packed graph, arena small enough)
   int32_t *items;               // [n_groups][item_cap] channel << 16 | first partition << 8 | group size
   int32_t item_cap;
+  int32_t *item_pref;           // [n_groups][item_cap][64]: entry i of an item = records in its first i + 1 buckets (plan_channel writes the
+                                // prefix it has in registers; the insert workgroup gets it with the item instead of loading the counters behind it)
   const float *const *ll_base;  // [n_channels] device pointers to row 0 of each utterance matrix
   int32_t n_channels;
   int32_t stride;               // floats per log-likelihood row
@@ -344,6 +350,9 @@ struct DecoderDev {
   // next_cutoff afresh every round, so the seed (and every other tile's tightening) reaches them as soon as it lands.
   int32_t seed_tiles;
   int32_t staged;   // fused (non-biglm) decoders: expand_kernel_staged (the tile's arcs staged in LDS by gather DMA) instead of expand_kernel_fused
+  int32_t best_exp; // staged best_row decoders: ChanCtl::best_next is set by the expansion (the insert launch does not look for the best token)
+  int32_t ll_row;   // staged decoders: the tile's whole log-likelihood row is staged in LDS too (rows of at most 3072 columns, a multiple of
+                    // four, 16-byte aligned: set by wfst_decoder_advance from the matrices it is handed); 0: one 4-byte gather per arc slot
   int32_t big;
   LmDev lm_old, lm_new;
   unsigned long long *pair_keys;

@@ -220,7 +220,7 @@ __device__ __forceinline__ float lm_step(const DecoderDev &D, int c, int pair, i
 
 // debug phase timers (WFST_DBG & 32): slot k accumulates {sum, max, count} of 100 MHz ticks
 __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned long long &t_prev) {
-  if (!(D.dbg & (k >= 11 ? 128 : k >= 6 ? 64 : 32))) return;
+  if (!(D.dbg & (k >= 22 ? 64 : k >= 11 ? 128 : k >= 6 ? 64 : 32))) return;   // (slots 22..: insert again)
   if (k >= 6 && (blockIdx.x & 15) != 0) return;  // sample 1/16 of the insert / expand workgroups
   const unsigned long long now = wall_clock64();
   const unsigned long long dt = now - t_prev;
@@ -298,18 +298,26 @@ __device__ __forceinline__ void plan_channel(const DecoderDev &D, int c, int gro
   }
   bh = __shfl(bh, 0, 64);
   bl = __shfl(bl, 0, 64);
+  int slot = -1;   // the item's place in items[]
   if (leader) {
     const int v = (int)(((uint32_t)c << 16) | ((uint32_t)g0 << 8) | (uint32_t)G);  // c <= 32767 (wfst_decoder_create_ex)
     int32_t *items = D.items + (size_t)group * D.item_cap;
     if (heavy) {
       const int idx = bh + lane_rank(mh);
-      if (idx < D.item_cap / 2) items[idx] = v;
+      if (idx < D.item_cap / 2) items[slot = idx] = v;
       else atomicOr(&D.ctl[c].error, kErrBucketFull);  // cannot happen: each half holds channels x partitions
     } else {
       const int idx = bl + lane_rank(ml);
-      if (idx < D.item_cap / 2) items[D.item_cap - 1 - idx] = v;
+      if (idx < D.item_cap / 2) items[slot = D.item_cap - 1 - idx] = v;
       else atomicOr(&D.ctl[c].error, kErrBucketFull);
     }
+  }
+  // the item's record prefix over its buckets, beside it (DecoderDev::item_pref): every lane is a bucket of exactly one group
+  {
+    const int gslot = __shfl(slot, g0, 64);
+    const int below = __shfl(ps, max(g0 - 1, 0), 64);   // (every lane takes part in the shuffle)
+    const int gbase = g0 ? below : 0;
+    if (lane < P && gslot >= 0) D.item_pref[((size_t)group * D.item_cap + gslot) * 64 + (lane - g0)] = ps - gbase;
   }
 }
 
@@ -782,13 +790,21 @@ __global__ __launch_bounds__(kExpandThreads, 6) void expand_replay_fused(Decoder
 constexpr int kStThreads = 256;
 constexpr int kStTokens = 256;   // (tiles of 128 / 192 / 320 / 384 tokens measured slower by 10-25 %, 512 the same)
 constexpr int kLog2StTokens = kStTokens <= 256 ? 8 : kStTokens <= 512 ? 9 : 10;   // steps of the owner search
-constexpr int kStSlots = 1536;   // (1392 slots at five workgroups per CU -- every tile of a half-batch launch resident at once -- measured 11 % slower: 96 VGPRs spill)   // (1280 / 1024 with five / six workgroups per CU measured slower: more tiles need a second pass)
-constexpr int kStIter = (kStSlots + kStThreads - 1) / kStThreads;   // slots per thread and pass
+constexpr int kStSlotsGather = 1536;   // (1392 slots at five workgroups per CU -- every tile of a half-batch launch resident at once -- measured 11 % slower: 96 VGPRs spill)   // (1280 / 1024 with five / six workgroups per CU measured slower: more tiles need a second pass)
+// kRow instantiation (DecoderDev::ll_row): the tile's whole log-likelihood ROW staged in LDS beside the arcs -- one coalesced
+// 16-byte DMA per four columns, asked for with the tile's tokens -- instead of one 4-byte gather per arc slot (a request each at
+// the memory side: 1.9 M per frame of 128 utterances against 0.9 M row lines; the gathers were a round trip of their own
+// between the arcs and the pricing).  Rows of up to kStRowFloats columns, a multiple of four, 16-byte aligned (what
+// wfst_decoder_advance checks); 22 KB slots + 12 KB row + 4 KB scan = 38.5 KB: still four workgroups per CU.
+constexpr int kStSlotsRow = 1408;
+constexpr int kStRowFloats = 3072;
 typedef __attribute__((address_space(3))) void *lds_void_p;
 typedef const __attribute__((address_space(1))) void *gbl_void_p;
 
-template <bool kTimers>
+template <bool kTimers, bool kRow>
 __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int group, int par) {
+  constexpr int kStSlots = kRow ? kStSlotsRow : kStSlotsGather;
+  constexpr int kStIter = (kStSlots + kStThreads - 1) / kStThreads;   // slots per thread and pass
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long tq = kTimers ? wall_clock64() : 0ull;
   FrameCtl *fc = D.fctl + group;
@@ -798,11 +814,13 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
   const int P = D.n_part, log2part = D.log2part, bcap = D.bucket_cap;
 
   __shared__ int4 s_arc[kStSlots];     // the tile's row slots as they stand in rows[]; a priced candidate's record replaces its slot
-  __shared__ float s_ll[kStSlots];     // the log-likelihood of each slot's column
+  __shared__ float s_ll[kRow ? 1 : kStSlots];     // the log-likelihood of each slot's column (gathered form)
+  __shared__ __attribute__((aligned(16))) float s_row[kRow ? kStRowFloats : 4];   // kRow: the frame's log-likelihood row of the tile's channel
   __shared__ int s_base[kStTokens + 1], s_arcbeg[kStTokens], s_nemit[kStTokens];
   __shared__ float s_cost[kStTokens];
   __shared__ int s_wsum[kStThreads / 64], s_cnt[64], s_gbase[64];
   __shared__ uint32_t s_stat[4], s_bound;
+  __shared__ u64 s_best;   // best_exp: the tile's cheapest candidate, orderable cost << 32 | row of its state
   __shared__ int s_ticket;
 
   if (blockIdx.x == 0 && tid == 0) {  // lists of the previous step are consumed
@@ -815,8 +833,9 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
   const TileDesc *tiles = D.tiles + (size_t)group * D.tile_cap;
   if (tid < 4) s_stat[tid] = 0;
   if (tid < 64) s_cnt[tid] = 0;
+  const float *row_have = nullptr;   // kRow: the row s_row holds
+  TileDesc td = td_first;
   for (int t = blockIdx.x; t < total_tiles;) {
-    const TileDesc td = t == (int)blockIdx.x ? td_first : tiles[t];
     const int c = td.chan;
     ChanCtl *ctl = D.ctl + c;
     const int n = td.tok_count;
@@ -825,7 +844,8 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
     const float *llrow = td.llrow;
     int4 *bucket = D.bucket + (size_t)c * P * bcap;
     int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
-    uint32_t nN = 0, nE = 0, nR = 0, nZf = 0;
+    uint32_t nR = 0, nZf = 0;   // (the tile's N and E are read back from the scan arrays at its end: no register across the passes)
+    bool counted = false;
     if (n == 0) {
       // SEED TILE (DecoderDev::seed_tiles): next_cutoff's seed from the best token's emitting arcs, base-inl.h:282-300 --
       // td.tok_begin = the token's row, td.cutoff = its cost.  (bc + w) - loglike as the reference writes it (:295), then
@@ -844,8 +864,10 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
     } else {
       // ---- the tile's tokens: one per thread; its row slots = emitting arcs + two per pseudo arc -------------------
       {
-        const int4 tk = tid < n ? (D.tok + (size_t)c * D.arena_cap + tok0)[tid] : make_int4(0, 0x7F800000, 0, 0);
+        int4 tk = make_int4(0, 0x7F800000, 0, 0);
+        if (tid < n) tk = (D.tok + (size_t)c * D.arena_cap + tok0)[tid];
         const float cost = __int_as_float(tk.y);
+        if constexpr (kTimers) { if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_phase(D, 20, tq); } }   // (descriptor + tokens landed)
         int nem = 0, slots = 0, arcbeg = 0;
         if (tid < n && cost <= cutoff) {  // base-inl.h:315
           uint32_t code = kCodeUnknown;
@@ -864,8 +886,6 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
             slots = nem + 2 * hdr.z;
             arcbeg = tk.x + 1 + (int)((uint32_t)hdr.x & kEpsMask);
           }
-          nN++;
-          nE += nem;
         }
         s_nemit[tid] = nem;
         s_cost[tid] = cost;
@@ -886,35 +906,69 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
           tot += v;
         }
         s_base[tid] = wbase + incl - slots;
-        if (tid == 0) { s_base[kStTokens] = tot; s_bound = 0xFFFFFFFFu; }
-        __syncthreads();
+        if (tid == 0) { s_base[kStTokens] = tot; s_bound = 0xFFFFFFFFu; s_best = ~0ull; }
+        lds_barrier();   // (LDS only: the row's DMAs stay in flight)
       }
       const int total = s_base[kStTokens];
+      counted = true;
       float bound = kInf;
       if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 11, tq); }
       for (int s0 = 0; s0 < total; s0 += kStSlots) {
         const int S = min(kStSlots, total - s0);
         // ---- (a) every slot of the pass: one lane's 16-byte DMA into the LDS image (64 consecutive slots per instruction) ----
         int lo[kStIter];
+        {
+          // the owner of each of this thread's slots: kStIter binary searches over the scanned offsets, run in LOCKSTEP (a search is
+          // a chain of dependent LDS reads; one after the other they were ~2 us in front of the pass's last DMA)
 #pragma unroll
-        for (int i = 0; i < kStIter; ++i) {
-          const int g = wave + i * (kStThreads / 64);   // this wave's i-th group of 64 slots
-          const int j = g * 64 + lane;
-          int l = 0, h = kStTokens;  // s_base[l] <= s0 + j < s_base[h]
-          const int J = s0 + min(j, S - 1);
+          for (int i = 0; i < kStIter; ++i) lo[i] = 0;   // s_base[lo] <= s0 + j: the largest such index (s_base[0] = 0)
+          static_assert(kStTokens == 1 << kLog2StTokens, "the owner search halves a power of two");
 #pragma unroll
-          for (int step = 0; step < kLog2StTokens; ++step) {
-            const int mid = (l + h) >> 1;
-            if (s_base[mid] <= J) l = mid; else h = mid;
+          for (int step = kStTokens >> 1; step >= 1; step >>= 1) {
+            int bm[kStIter];
+#pragma unroll
+            for (int i = 0; i < kStIter; ++i) bm[i] = s_base[lo[i] + step];
+#pragma unroll
+            for (int i = 0; i < kStIter; ++i) {
+              const int J = s0 + min((wave + i * (kStThreads / 64)) * 64 + lane, S - 1);
+              if (bm[i] <= J) lo[i] += step;
+            }
           }
-          lo[i] = l;
-          if (g * 64 < S) {   // (wave-uniform)
-            const int4 *src = D.g.arcs + (s_arcbeg[l] + (J - s_base[l]));
-            if (j < S) __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(s_arc + g * 64), 16, 0, 0);
+          int ab_[kStIter], bs_[kStIter];
+#pragma unroll
+          for (int i = 0; i < kStIter; ++i) { ab_[i] = s_arcbeg[lo[i]]; bs_[i] = s_base[lo[i]]; }
+#pragma unroll
+          for (int i = 0; i < kStIter; ++i) {
+            const int g = wave + i * (kStThreads / 64);   // this wave's i-th group of 64 slots
+            const int j = g * 64 + lane;
+            const int J = s0 + min(j, S - 1);
+            if (g * 64 < S) {   // (wave-uniform)
+              const int4 *src = D.g.arcs + (ab_[i] + (J - bs_[i]));
+              if (j < S) __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(s_arc + g * 64), 16, 0, 0);
+            }
+          }
+        }
+        if constexpr (kRow) {
+          // the frame's log-likelihood row of this channel, BEHIND the arcs in issue order (a wave's vector-memory results come back
+          // in issue order: the tokens and the arcs are what the tile waits for; the row is needed with the arcs, at the pricing):
+          // 16 bytes per lane, 1 KB per wave instruction, straight into LDS
+          if (llrow != row_have) {   // (a workgroup's consecutive tiles are often one channel's)
+            const int n16 = D.stride >> 2;
+#pragma unroll
+            for (int i = 0; i < kStRowFloats / 4 / kStThreads; ++i) {
+              const int g = wave + i * (kStThreads / 64);
+              if (g * 64 < n16) {   // (wave-uniform)
+                const int j = g * 64 + lane;
+                if (j < n16) __builtin_amdgcn_global_load_lds((gbl_void_p)(llrow + 4 * j), (lds_void_p)(s_row + g * 256), 16, 0, 0);
+              }
+            }
+            row_have = llrow;
           }
         }
         // next_cutoff as it stands now (the seed tile's and the other tiles' tightenings): asked for here, back with the arcs
         const uint32_t bfresh = ld_agent(&ctl->bound);
+        const u64 best_seen = D.best_exp ? ld_agent(&ctl->best_next) : 0ull;   // (the frame's cheapest candidate so far)
+        if constexpr (!kRow) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slots have landed (a lane reads back its own)
         if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 12, tq); }
         // ---- (b) the log-likelihood of every arc slot: one lane's 4-byte DMA (a pseudo arc's second slot has no column) ----
@@ -929,62 +983,114 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
             if (j < S) __builtin_amdgcn_global_load_lds((gbl_void_p)(llrow + col), (lds_void_p)(s_ll + g * 64), 4, 0, 0);
           }
         }
+        }
         bound = fminf(bound, o2f(bfresh));
-        __syncthreads();   // (drains the DMAs; a pseudo arc's second slot may be another wave's)
+        if constexpr (kRow) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // (drains the DMAs -- kRow: the arcs and the channel's row; a pseudo arc's second slot may be another wave's)
+        if constexpr (kRow && kTimers) { if (tid == 0) dbg_phase(D, 12, tq); }
         if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 13, tq); }
         // ---- (c) price every candidate; its record takes the place of its slot ------------------------------------------
         float tmin = kInf;
+        u64 cbest = ~0ull;        // best_exp: this thread's cheapest candidate (emitting or epsilon arrival)
         uint32_t cand_mask = 0;   // bit i: slot i of this thread is a candidate (not a pseudo arc's second slot, not padding)
+        // (kPrB slots at a time: their LDS reads are asked for together -- slot by slot, behind branches, a thread's pricing was a chain
+        // of dependent LDS round trips per slot)
+#ifndef WFST_PRB
+#define WFST_PRB 1
+#endif
+        constexpr int kPrB = WFST_PRB;
 #pragma unroll
-        for (int i = 0; i < kStIter; ++i) {
-          const int g = wave + i * (kStThreads / 64);
-          const int j = g * 64 + lane;
-          if (j >= S) continue;
-          const int l = lo[i];
-          const int off = s0 + j - s_base[l], nem = s_nemit[l], pi = off - nem;
-          if (pi >= 0 && (pi & 1)) continue;   // second slot of a pseudo arc
-          const bool pseudo = pi >= 0;
-          const int a = s_arcbeg[l] + off;     // the slot's index in rows[]
-          const int4 arc = s_arc[j];
-          const float base_cost = (s_cost[l] + (-s_ll[j])) + __int_as_float(arc.z);   // base-inl.h:326-329
-          int4 rec;
-          if (pseudo) {
-            // the emitting arc's arrival carried on over one path of the target's epsilon closure -- ((cur + ac) + w) + w_1
-            // + ... + w_k in path order (base-inl.h:329, 414): an epsilon arrival at the path's end state; it does not
-            // tighten next_cutoff (only emitting arcs do, base-inl.h:330-333 vs 415)
-            const int4 leaf = (j + 1 < S) ? s_arc[j + 1] : D.g.arcs[a + 1];   // (a pair cut by the end of the pass)
-            float tt = base_cost;
-            if (leaf.z == 1) {
-              tt = tt + __int_as_float(leaf.y);
-            } else if (leaf.z == 2) {
-              tt = (tt + __int_as_float(leaf.w)) + __int_as_float(leaf.y);
+        for (int i0 = 0; i0 < kStIter; i0 += kPrB) {
+          int4 arc_[kPrB];
+          int off_[kPrB], nem_[kPrB], abeg_[kPrB];
+          float cost_[kPrB], ll_[kPrB];
+#pragma unroll
+          for (int q = 0; q < kPrB; ++q) {
+            const int i = i0 + q;
+            if (i >= kStIter) continue;   // (compile time)
+            const int j = min((wave + i * (kStThreads / 64)) * 64 + lane, S - 1), l = lo[i];
+            off_[q] = s0 + j - s_base[l];
+            nem_[q] = s_nemit[l];
+            abeg_[q] = s_arcbeg[l];
+            cost_[q] = s_cost[l];
+            arc_[q] = s_arc[j];
+          }
+#pragma unroll
+          for (int q = 0; q < kPrB; ++q) {
+            const int i = i0 + q;
+            if (i >= kStIter) continue;
+            ll_[q] = kRow ? s_row[arc_[q].x & D.g.col_mask] : s_ll[min((wave + i * (kStThreads / 64)) * 64 + lane, S - 1)];
+          }
+#pragma unroll
+          for (int q = 0; q < kPrB; ++q) {
+            const int i = i0 + q;
+            if (i >= kStIter) continue;
+            const int j = (wave + i * (kStThreads / 64)) * 64 + lane;
+            if (j >= S) continue;
+            const int l = lo[i];
+            const int off = off_[q], pi = off - nem_[q];
+            if (pi >= 0 && (pi & 1)) continue;   // second slot of a pseudo arc
+            const bool pseudo = pi >= 0;
+            const int a = abeg_[q] + off;     // the slot's index in rows[]
+            const int4 arc = arc_[q];
+            const float base_cost = (cost_[q] + (-ll_[q])) + __int_as_float(arc.z);   // base-inl.h:326-329
+            int4 rec;
+            if (pseudo) {
+              // the emitting arc's arrival carried on over one path of the target's epsilon closure -- ((cur + ac) + w) + w_1
+              // + ... + w_k in path order (base-inl.h:329, 414): an epsilon arrival at the path's end state; it does not
+              // tighten next_cutoff (only emitting arcs do, base-inl.h:330-333 vs 415)
+              const int4 leaf = (j + 1 < S) ? s_arc[j + 1] : D.g.arcs[a + 1];   // (a pair cut by the end of the pass)
+              float tt = base_cost;
+              if (leaf.z == 1) {
+                tt = tt + __int_as_float(leaf.y);
+              } else if (leaf.z == 2) {
+                tt = (tt + __int_as_float(leaf.w)) + __int_as_float(leaf.y);
+              } else {
+                const float *pw = D.g.pseudo_w + (size_t)arc.y * kPseudoDepthMax;
+                for (int u = 0; u < leaf.z; ++u) tt = tt + pw[u];
+              }
+              rec = make_int4(arc.w, __float_as_int(tt), kPrevUnresolved, (int)((uint32_t)leaf.x | kEpsRec));
+              nZf++;
             } else {
-              const float *pw = D.g.pseudo_w + (size_t)arc.y * kPseudoDepthMax;
-              for (int u = 0; u < leaf.z; ++u) tt = tt + pw[u];
+              rec = make_int4(arc.w, __float_as_int(base_cost), tok0 + l, (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
+              tmin = fminf(tmin, base_cost);
             }
-            rec = make_int4(arc.w, __float_as_int(tt), kPrevUnresolved, (int)((uint32_t)leaf.x | kEpsRec));
-            nZf++;
-          } else {
-            rec = make_int4(arc.w, __float_as_int(base_cost), tok0 + l, (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
-            tmin = fminf(tmin, base_cost);
+            if (D.degcode) {   // the degree code of the state arrived at rides in the record (expand_body)
+              const uint32_t code = (uint32_t)arc.x >> kColBits;
+              rec.w = (int)(((uint32_t)rec.w & 0x3FFFFFFFu) | (code << 30));
+              rec.z = pseudo ? kPrevUnresolved - (int)(code >> 2) : (int)((uint32_t)rec.z | ((code >> 2) << D.tok_idx_bits));
+            }
+            s_arc[j] = rec;
+            cand_mask |= 1u << i;
+            if (D.best_exp) {
+              const u64 cb = ((u64)f2o(__int_as_float(rec.y)) << 32) | (uint32_t)rec.x;
+              cbest = cb < cbest ? cb : cbest;
+            }
           }
-          if (D.degcode) {   // the degree code of the state arrived at rides in the record (expand_body)
-            const uint32_t code = (uint32_t)arc.x >> kColBits;
-            rec.w = (int)(((uint32_t)rec.w & 0x3FFFFFFFu) | (code << 30));
-            rec.z = pseudo ? kPrevUnresolved - (int)(code >> 2) : (int)((uint32_t)rec.z | ((code >> 2) << D.tok_idx_bits));
-          }
-          s_arc[j] = rec;
-          cand_mask |= 1u << i;
         }
         // base-inl.h:330-333: next_cutoff tightened by the tile's best emitting candidate -- once for the whole tile
         {
           const float wmin = wave_min_f(tmin);
           if (lane == 0 && wmin < kInf) atomicMin(&s_bound, f2o(wmin + ab));
+          if (D.best_exp) {
+            // the cheapest candidate IS the cheapest token of the frame being built (FindOrAddToken keeps a state's minimum;
+            // ties go to the lowest row): ChanCtl::best_next is complete when the expansion launch ends, and the insert launch
+            // neither looks for the best token nor waits for its own atomics before it counts an item out
+            const u64 cv = cbest < best_seen ? cbest : ~0ull;
+            if (__ballot(cv != ~0ull)) {   // (wave-uniform; few waves of few tiles: the frame's best moves a handful of times)
+              const u64 wb = wave_min_u64(cv);
+              if (lane == 0) atomicMin(&s_best, wb);
+            }
+          }
           lds_barrier();
           const uint32_t tb = s_bound;
           if (o2f(tb) < bound) {
             if (tid == 0) atomicMin(&ctl->bound, tb);   // (the other tiles read it afresh: bfresh)
             bound = o2f(tb);
+          }
+          if (D.best_exp && tid == 0) {
+            const u64 tbest = s_best;
+            if (tbest < best_seen) atomicMin(&ctl->best_next, tbest);
           }
         }
         if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 14, tq); }
@@ -1024,22 +1130,30 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
           if (gi < bcap) bucket[(size_t)p * bcap + gi] = s_arc[j];
         }
         __syncthreads();   // the image is free for the next pass / tile
-        if (tid == 0) s_bound = 0xFFFFFFFFu;
+        if (tid == 0) { s_bound = 0xFFFFFFFFu; s_best = ~0ull; }
         if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 16, tq); }
       }
     }
-    tile_tail(D, c, ctl, group, par, nN, nE, nR, nZf, s_stat);
+    {
+      const bool exp = counted && s_cost[tid] <= cutoff;   // (the tokens beyond the tile's count carry +inf)
+      tile_tail(D, c, ctl, group, par, exp ? 1u : 0u, exp ? (uint32_t)s_nemit[tid] : 0u, nR, nZf, s_stat);
+    }
     // next tile: the first gridDim.x tiles are taken statically, the rest by ticket
     if (total_tiles <= (int)gridDim.x) break;
     if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(&fc->ticket[par], 1);
     __syncthreads();
-    t = s_ticket;
+    // (t is uniform: the next descriptor comes as ONE scalar load -- read through a vector register the compiler fetched it
+    // field by field, three dependent round trips for every tile after a workgroup's first)
+    t = __builtin_amdgcn_readfirstlane(s_ticket);
     __syncthreads();
+    if (t < total_tiles) td = tiles[t];
     if constexpr (kTimers) tq = wall_clock64();
   }
 }
-__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev D, int group, int par) { expand_staged_body<false>(D, group, par); }
-__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged_timed(DecoderDev D, int group, int par) { expand_staged_body<true>(D, group, par); }
+__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged(DecoderDev D, int group, int par) { expand_staged_body<false, false>(D, group, par); }
+__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged_timed(DecoderDev D, int group, int par) { expand_staged_body<true, false>(D, group, par); }
+__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged_row(DecoderDev D, int group, int par) { expand_staged_body<false, true>(D, group, par); }
+__global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged_row_timed(DecoderDev D, int group, int par) { expand_staged_body<true, true>(D, group, par); }
 
 // =========================================================================================
 // insert_kernel.  A bucket whose records could overfill the LDS table is processed in 2^k
@@ -1057,6 +1171,10 @@ struct BoundaryLite {   // frame_boundary_fused's few words of LDS
   float redf[16];
   u64 best;
   int active, n, nd, front_begin, ntiles, tile_tokens, tile_start, pad_bits;
+  // what the workgroup that counted the channel's last item out already holds (nothing is loaded behind the countdown):
+  u64 h_best;         // ChanCtl::best_next as the expansion left it
+  int h_nf, h_err;    // the frame's token count (the countdown's own answer), error bits (as of the item's start | this frame's)
+  uint32_t h_bound;   // the final next_cutoff
 };
 template <int kT>
 __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c, const int32_t *target, int chan_cnt, int group,
@@ -1094,9 +1212,13 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   const int n_heavy = min(fc->n_items[par], D.item_cap / 2), n_items = n_heavy + min(fc->n_small[par], D.item_cap / 2);
   const int P = D.n_part;
 
+  unsigned long long th = wall_clock64();   // (phase timers: the head of an item -- launch or ticket to its records' addresses)
   for (int it = blockIdx.x; it < n_items;) {
   // (signed decode: channels are < 32768, wfst_decoder_create_ex; the unsigned spelling costs 12 VGPRs and a wave of occupancy)
-  const int item = D.items[(size_t)group * D.item_cap + (it < n_heavy ? it : D.item_cap - 1 - (it - n_heavy))];
+  // (the item's index is uniform: a scalar load; its record prefix -- written beside it by plan_channel -- comes in the same round trip)
+  const int islot = __builtin_amdgcn_readfirstlane(it < n_heavy ? it : D.item_cap - 1 - (it - n_heavy));
+  const int item = D.items[(size_t)group * D.item_cap + islot];
+  const int my_pref = D.item_pref[((size_t)group * D.item_cap + islot) * 64 + lane];
   const int c = item >> 16, g0 = (item >> 8) & 0xFF, G = item & 0xFF;
   ChanCtl *ctl = D.ctl + c;
   // this item's chunk of the channel's emitter list: asked for now, its answer is looked at after pass 1 (the atomic's round
@@ -1108,16 +1230,9 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   }
   int n = 0;
   {
-    const int32_t *cnts = D.bucket_cnt + (size_t)c * P;
-    const int cnt = (lane < G) ? min(cnts[g0 + lane], D.bucket_cap) : 0;  // every wave computes the same
-    int ps = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int v = __shfl_up(ps, off, 64);
-      if (lane >= off) ps += v;
-    }
-    n = __shfl(ps, 63, 64);
-    if (wave == 0 && lane < G) s_pref[lane + 1] = ps;
+    // records in the item's buckets: the inclusive prefix plan_channel left beside the item (every wave holds the same)
+    n = G ? __shfl(my_pref, G - 1, 64) : 0;
+    if (wave == 0 && lane < G) s_pref[lane + 1] = my_pref;
     if (tid == 0) s_pref[0] = 0;
   }
   int log2g = 0;
@@ -1125,7 +1240,12 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   const int log2grp = D.log2part - log2g;  // hash bits that select this group of partitions
   const int4 *bucket0 = D.bucket + ((size_t)c * P + g0) * D.bucket_cap;
   const int32_t *bucket_lm0 = kBig ? D.bucket_lm + ((size_t)c * P + g0) * D.bucket_cap : nullptr;
-  const float cutoff = o2f(ctl->bound);  // FINAL next_cutoff of this frame
+  const uint32_t bound_o = ctl->bound;
+  const float cutoff = o2f(bound_o);  // FINAL next_cutoff of this frame
+  // two launches per frame: what the workgroup that counts the channel's last item out will need to close the frame, asked for
+  // with everything else (complete since the expansion launch ended: the best candidate; the error bits so far)
+  const u64 best_early = (kTwo && D.best_exp) ? ctl->best_next : ~0ull;
+  const int err_early = kTwo ? ctl->error : 0;
   // table sized to the load: the smallest power of two >= 4 n (records >= distinct states)
   int log2sl = 6;
   while ((1 << log2sl) < 4 * n && log2sl < D.log2lds) ++log2sl;
@@ -1169,6 +1289,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   auto hash_of = [&](const int4 &r, int lm) -> uint32_t { return kBig ? hash_big(r.x, lm) : hash32(r.x); };
 
   u64 best = ~0ull;
+  if (tid == 0) dbg_phase(D, 22, th);
   unsigned long long tq = wall_clock64();
   for (int sub = 0; sub_shift >= 0 && sub < (1 << log2sub); ++sub) {
     __syncthreads();
@@ -1216,6 +1337,8 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
       if constexpr (kListEmit) s_ech = ech_reg;
       if (g + ns > D.max_tok) { atomicOr(&ctl->error, kErrFrontierFull); s_ok = 0; }
       if ((int64_t)base + g + ns > D.arena_cap) { atomicOr(&ctl->error, kErrArenaFull); s_ok = 0; }
+      // (the frame's boundary learns it from the countdown's answer: this item's tokens are counted but not written)
+      if (kTwo && !s_ok) atomicOr(reinterpret_cast<u64 *>(&ctl->new_count), kFrameErrBit);
     }
     __syncthreads();
     if (!s_ok) break;
@@ -1277,8 +1400,10 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
           if constexpr (kBig) D.tok_lm[(size_t)c * D.arena_cap + idx] = rl[k];
           if (kLat) tidx[wslot] = idx;
           // (kTwo: the best token's graph ROW rides in the low word -- all the next frame's seed needs, DecoderDev::best_row)
-          const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)(kTwo ? r[k].x : idx);
-          best = b < best ? b : best;
+          if (!(kTwo && D.best_exp)) {   // (best_exp: the expansion has found the best token already)
+            const u64 b = (packed & 0xFFFFFFFF00000000ull) | (uint32_t)(kTwo ? r[k].x : idx);
+            best = b < best ? b : best;
+          }
         }
         // a token on an epsilon-TARGET state registers itself in the channel's direct-mapped
         // epsilon table (so an epsilon arc arriving later meets its cost); a token with epsilon
@@ -1434,20 +1559,35 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
     if (G && tid < kEmitChunk && tid >= s_efill && s_ech + tid < 8 * D.wl_cap)
       reinterpret_cast<int32_t *>(D.worklist + (size_t)c * 2 * D.wl_cap)[s_ech + tid] = -1;
   }
-  best = wave_min_u64(best);
-  if (lane == 0) s_best[wave] = best;
-  __syncthreads();
+  const bool own_best = !(kTwo && D.best_exp);   // (uniform)
+  if (own_best) {
+    best = wave_min_u64(best);
+    if (lane == 0) s_best[wave] = best;
+    __syncthreads();
+  }
   if (tid == 0) {
-    u64 b = s_best[0];
-    for (int w = 1; w < kInsertThreads / 64; ++w) b = s_best[w] < b ? s_best[w] : b;
-    if (b != ~0ull) atomicMin(&ctl->best_next, b);
+    if (own_best) {
+      u64 b = s_best[0];
+      for (int w = 1; w < kInsertThreads / 64; ++w) b = s_best[w] < b ? s_best[w] : b;
+      if (b != ~0ull) atomicMin(&ctl->best_next, b);
+    }
     dbg_phase(D, 10, tq);
     int last = 0;
     if (kTwo && boundary) {
-      // two launches per frame: the workgroup whose item is the channel's last closes the frame.  Everything this workgroup
-      // sent to the channel's control line (token count, best token, error bits) has arrived before it counts itself out.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      last = atomicSub(&ctl->items_left, 1) == 1;
+      // two launches per frame: the workgroup whose item is the channel's last closes the frame.  The countdown is a 64-bit
+      // add on {new_count, items_left}: its answer carries the frame's token count (every item's allocation has RETURNED before
+      // that item counts itself out) and the frame's error bit (set, where it is, by this same lane on this same word) -- so
+      // with the best token known since the expansion (best_exp) nothing this workgroup sent has to be waited for, and nothing
+      // is loaded behind the countdown.  Without best_exp the best token travels by atomicMin from here: drained first.
+      if (own_best) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const u64 old = atomicAdd(reinterpret_cast<u64 *>(&ctl->new_count), 0xFFFFFFFF00000000ull);
+      last = ((old >> 32) & 0xFFFFull) == 1;
+      if (last) {
+        bsh.h_nf = (int)(uint32_t)old;
+        bsh.h_err = err_early | ((old & kFrameErrBit) ? kErrInternal : 0);   // (the sticky bit itself was set where the error arose)
+        bsh.h_bound = bound_o;
+        bsh.h_best = best_early;
+      }
     }
     s_last = last;
     // (the ticket is taken when the item is DONE: asked for earlier, a busy workgroup would sit on an item that an idle one
@@ -1458,9 +1598,14 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   it = s_item;
   const int last = s_last;
   __syncthreads();
+  if (tid == 0) dbg_phase(D, 23, tq);   // (countdown + ticket answered)
   if constexpr (kTwo) {
-    if (last) frame_boundary_fused<kInsertThreads>(D, c, target, chan_cnt, group, par ^ 1, boundary == 1, bsh);
+    if (last) {
+      frame_boundary_fused<kInsertThreads>(D, c, target, chan_cnt, group, par ^ 1, boundary == 1, bsh);
+      if (tid == 0) dbg_phase(D, 24, tq);   // (the frame boundary)
+    }
   }
+  th = wall_clock64();
   }
 }
 
@@ -2172,10 +2317,10 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
   if (tid == 0) {
     const int f = ctl->n_decoded;                         // (unchanged during this launch)
     const int base = ctl->front_begin + ctl->front_count;
-    const uint32_t bound_o = ld_agent(&ctl->bound);
-    int nf = ld_agent(&ctl->new_count);
-    const int err = ld_agent(&ctl->error);
-    const u64 best = ld_agent(&ctl->best_next);
+    const uint32_t bound_o = sh.h_bound;
+    int nf = sh.h_nf;
+    const int err = sh.h_err;
+    const u64 best = D.best_exp ? sh.h_best : ld_agent(&ctl->best_next);
     int add_err = 0;
     if (nf > D.max_tok || (int64_t)base + nf > D.arena_cap) nf = 0;   // (the insert workgroups have raised the error bit)
     if (err) nf = 0;   // a channel that hit a limit stops producing tokens
@@ -3861,13 +4006,15 @@ void launch_init(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s
 // one group's latency-bound closure overlaps another group's expand / insert)
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s) {
   if (D.dbg & 128) {   // phase timers: their own instantiations
-    if (D.fused && D.staged) hipLaunchKernelGGL(expand_kernel_staged_timed, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
+    if (D.fused && D.staged && D.ll_row) hipLaunchKernelGGL(expand_kernel_staged_row_timed, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
+    else if (D.fused && D.staged) hipLaunchKernelGGL(expand_kernel_staged_timed, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
     else if (D.big) hipLaunchKernelGGL(expand_kernel_biglm_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
     else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
     else hipLaunchKernelGGL(expand_kernel_plain_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
     return;
   }
   if (D.big) hipLaunchKernelGGL(expand_kernel_biglm, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
+  else if (D.fused && D.staged && D.ll_row) hipLaunchKernelGGL(expand_kernel_staged_row, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
   else if (D.fused && D.staged) hipLaunchKernelGGL(expand_kernel_staged, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
   else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
   else hipLaunchKernelGGL(expand_kernel_plain, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
