@@ -156,7 +156,7 @@ struct wfst_decoder {
   DevBuf<unsigned long long> lat_stats;
   DevBuf<FrameCtl> fctl;
   DevBuf<unsigned long long> dbg_t;
-  DevBuf<int32_t> items, item_pref;
+  DevBuf<int32_t> items, item_pref, degraded;
   DevBuf<TileDesc> tiles;
   int insert_wgs = 768;
   std::vector<int> gpar;  // step parity per group (persists across advance calls)
@@ -258,7 +258,7 @@ struct wfst_decoder {
     np_ws.release(); np_out.release(); np_off.release(); np_arcs.release(); np_tot.release(); np_lists.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); emit_cnt.release(); prune_par.release();
     eps_toki.release(); eps_occ_list.release(); eps_won_list.release(); worklist.release(); target.release(); chan_list.release();
-    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); lat_stats.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); item_pref.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
+    bucket.release(); links.release(); lat_toks.release(); lat_arcs.release(); lat_stats.release(); link_off.release(); link_mid.release(); extra.release(); fctl.release(); dbg_t.release(); items.release(); item_pref.release(); degraded.release(); tiles.release(); cutoff_hist.release(); eps_vals.release(); ll_base.release(); nb_list.release(); nb_scratch.release(); nb_out_i.release(); nb_out_f.release(); bp_chain.release(); bp_all.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -889,11 +889,11 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     if (L.lm_pairs > (1ll << 28)) return fail(WFST_E_ARG, "lm_pairs too large");
   }
   if (L.max_frames <= 0) L.max_frames = 4096;
-  // (default: 32768, or four times a finite max_active -- that many tokens are expanded per frame, their arrivals are more -- up to 262144)
+  // (default: 65536 -- best-path decoders degrade at it, they do not fail: DecoderDev::soft_limit --, or four times a finite max_active -- that many tokens are expanded per frame, their arrivals are more -- up to 262144)
   if (L.max_tokens_per_frame <= 0)
-    L.max_tokens_per_frame = cfg->max_active < (1 << 28) ? (int32_t)std::min<int64_t>(262144, std::max<int64_t>(32768, 4ll * cfg->max_active)) : 32768;
-  if (L.arena_tokens <= 0)  // room for max_frames frames at 1/32 of the per-frame token limit (include/wfst_decoder.h)
-    L.arena_tokens = std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(4194304, (int64_t)L.max_frames * std::max<int64_t>(256, L.max_tokens_per_frame / 32)));
+    L.max_tokens_per_frame = cfg->max_active < (1 << 28) ? (int32_t)std::min<int64_t>(262144, std::max<int64_t>(32768, 4ll * cfg->max_active)) : 65536;
+  if (L.arena_tokens <= 0)  // room for max_frames frames at 1/64 of the per-frame token limit (include/wfst_decoder.h)
+    L.arena_tokens = std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(4194304, (int64_t)L.max_frames * std::max<int64_t>(256, L.max_tokens_per_frame / 64)));
   if (L.arena_tokens > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "arena_tokens must fit int32");
   if (L.lattice_links < 0 || L.lattice_links > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "lattice_links must fit int32");
   // hash partitions per channel: each insert workgroup owns an LDS table of lds_slots entries;
@@ -966,13 +966,16 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     A(d->lat_toks.alloc(B * (size_t)lat_tok_cap));
     A(d->lat_stats.alloc(B * 4));
   }
-  const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 128 + 2);  // tiles of 128 tokens at least (prep_frame)
+  // tiles of 128 tokens at least (prep_frame); a frame of a soft-limit decoder may hold several times the per-frame limit (every
+  // candidate the buckets took can be a token: 8 x the limit): room for every channel at twice the limit and then some
+  const size_t tile_cap = B * ((size_t)L.max_tokens_per_frame / 64 + 2) + (size_t)L.max_tokens_per_frame / 16;
   A(d->fctl.alloc(8));
   A(d->dbg_t.alloc(128));
   A(d->tiles.alloc(8 * tile_cap));
   const size_t item_cap = 2 * B * (size_t)n_part;  // two lists (heavy from the front, light from the back), each sized for the worst case
   A(d->items.alloc(8 * item_cap));
   A(d->item_pref.alloc(8 * item_cap * 64));   // the record prefix of every listed item, beside it (plan_channel)
+  A(d->degraded.alloc(B));
   A(d->target.alloc(B));
   A(d->chan_list.alloc(B));
   A(d->ll_base.alloc(B));
@@ -994,6 +997,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     if (e == hipSuccess && lds_slots * per_slot > 65536) A((hipError_t)insert_kernel_set_lds(lds_slots * per_slot));
   }
 
+  if (e == hipSuccess) A(hipMemsetAsync(d->degraded.p, 0, d->degraded.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->target.p, 0, d->target.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->ll_base.p, 0, d->ll_base.bytes(), d->stream));
   if (e == hipSuccess) A(hipStreamSynchronize(d->stream));
@@ -1062,7 +1066,10 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // the expansion finds the frame's best token itself (its cheapest candidate): the staged kernel of best_row decoders (0x20000: A/B)
   D.best_exp = (D.staged && D.best_row && !(O.debug & 0x20000)) ? 1 : 0;
   D.seed_tiles = (D.best_row && !(O.debug & 0x4800)) ? 1 : 0;   // (0x800: the replay experiments start from the frame's seed; 0x4000: A/B)
-  if (D.best_row && !(O.debug & 0x2000) && cfg->max_active >= L.max_tokens_per_frame && cfg->min_active == 0) {
+  // fused best-path decoders: max_tokens_per_frame is a max_active, not a capacity (the frame keeps every token the arena takes and
+  // GetCutoff tightens to the limit-th cheapest; wfst_decoder_get_degraded_frames counts the frames on which it did)
+  D.soft_limit = D.best_row;
+  if (D.best_row && !(O.debug & 0x2000)) {
     int64_t reserve = std::max<int64_t>(2ll * L.max_tokens_per_frame, L.arena_tokens / 8);
     if (reserve >= L.arena_tokens / 2) reserve = L.arena_tokens / 2;
     const int64_t stride = reserve / std::max<int64_t>(1, L.max_tokens_per_frame) - 1;
@@ -1079,6 +1086,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.tile_cap = (int32_t)tile_cap;
   D.items = d->items.p;
   D.item_pref = d->item_pref.p;
+  D.degraded = d->degraded.p;
   D.item_cap = (int32_t)item_cap;
   D.ll_base = d->ll_base.p;
   D.n_channels = n_channels;
@@ -2257,6 +2265,14 @@ int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t sta
   stats[2] = (int64_t)v[2];
   stats[3] = (int64_t)(v[3] & 0xFFFFFFFFull);
   stats[4] = (int64_t)(v[3] >> 32);
+  return WFST_OK;
+}
+
+int wfst_decoder_get_degraded_frames(wfst_decoder *d, int32_t channel, int32_t *n_frames) {
+  if (!d || !n_frames || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipMemcpyAsync(n_frames, d->degraded.p + channel, sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
   return WFST_OK;
 }
 

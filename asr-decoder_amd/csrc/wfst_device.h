@@ -208,10 +208,16 @@ struct __attribute__((aligned(128))) ChanCtl {
   int32_t lat_arcs;      // lattice mode, after lattice_prune_kernel: surviving links in lat_arcs[]
   int32_t lat_toks;      //   "   surviving tokens in lat_toks[]
   int32_t tiles_left;    // expansion tiles of the frame not finished yet (the last one plans the insert items)
-  int32_t pair_count;    // biglm: LM pair states interned since InitDecoding (atomicAdd)
+  union {
+    int32_t pair_count;  // biglm: LM pair states interned since InitDecoding (atomicAdd)
+    int32_t stores_left; // two-launch decoders: insert items of the frame whose token stores have not all landed yet (counted down,
+                         // behind every wave's drain, AFTER the item has counted itself out of items_left: the frame boundary waits
+                         // for it only where GetCutoff has to look at the frame's tokens)
+  };
   int32_t pruned_upto;   // lattice mode: NumFramesDecoded() at the last back-pruning pass (frames below hold extras)
 };
 static_assert(offsetof(ChanCtl, new_count) % 8 == 0 && offsetof(ChanCtl, items_left) == offsetof(ChanCtl, new_count) + 4, "the {new_count, items_left} word");
+constexpr int32_t kRiskyBit = 1 << 29;   // in items_left (plan_channel): the frame's boundary may have to read the frame's tokens
 constexpr unsigned long long kFrameErrBit = 1ull << 62;   // in the {new_count, items_left} word (items_left stays below 2^16)
 static_assert(sizeof(ChanCtl) == 128, "ChanCtl must be one 128-byte line");
 
@@ -350,6 +356,9 @@ struct DecoderDev {
   // next_cutoff afresh every round, so the seed (and every other tile's tightening) reaches them as soon as it lands.
   int32_t seed_tiles;
   int32_t staged;   // fused (non-biglm) decoders: expand_kernel_staged (the tile's arcs staged in LDS by gather DMA) instead of expand_kernel_fused
+  int32_t soft_limit;   // fused best-path decoders: max_tokens_per_frame is not a capacity but a max_active -- a frame may hold more tokens
+                        // (while the arena and the candidate buckets take them); GetCutoff then tightens to the limit-th cheapest
+  int32_t *degraded;    // [c] frames of the utterance on which that happened (wfst_decoder_get_degraded_frames)
   int32_t best_exp; // staged best_row decoders: ChanCtl::best_next is set by the expansion (the insert launch does not look for the best token)
   int32_t ll_row;   // staged decoders: the tile's whole log-likelihood row is staged in LDS too (rows of at most 3072 columns, a multiple of
                     // four, 16-byte aligned: set by wfst_decoder_advance from the matrices it is handed); 0: one 4-byte gather per arc slot

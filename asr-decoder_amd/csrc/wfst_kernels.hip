@@ -265,7 +265,8 @@ __device__ __forceinline__ void push_empty_item(const DecoderDev &D, int c, int 
 // channel's last expansion tile (all bucket counters of the channel are final then; they are only
 // ever touched by device-scope atomics, so this wave reads them with atomic loads).
 __device__ __forceinline__ void plan_channel(const DecoderDev &D, int c, int group, int par) {
-  const int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));   // (opaque: the addresses derived from it are computed here, not hoisted to the kernel's entry and spilled)
   FrameCtl *fc = D.fctl + group;
   const int P = D.n_part;
   const int32_t *cnts = D.bucket_cnt + (size_t)c * P;
@@ -280,7 +281,18 @@ __device__ __forceinline__ void plan_channel(const DecoderDev &D, int c, int gro
   partition_group(P, min(D.joint_max, (D.lds_slots * 3) >> 2), lane < P ? lane : 0, ps, cnt, &g0, &G, &n);
   const bool leader = lane < P && g0 == lane && n > 0;
   const u64 m = __ballot(leader);
-  if (D.two_launch && lane == 0) D.ctl[c].items_left = m ? __popcll(m) : 1;   // (read by the insert launch: frame_boundary_fused)
+  const int n_rec = __shfl(ps, 63, 64);   // the channel's candidate records
+  if (D.two_launch && lane == 0) {   // (read by the insert launch: frame_boundary_fused)
+    // Can GetCutoff of the frame being built need a look at its tokens (frame_boundary_fused)?  Only with more tokens than
+    // max_active / the per-frame limit -- and a frame has at most as many tokens as candidate records --, or with a min_active
+    // behind a frame whose adaptive beam was not the plain beam.  Only then do the channel's insert items store their tokens
+    // write-through, drain and count themselves out of stores_left (kRiskyBit rides above the item count).
+    const int max_eff = D.soft_limit ? min(D.max_active, D.max_tok) : D.max_active;
+    const bool risky = n_rec > max_eff || (D.min_active > 0 && !(D.ctl[c].adaptive_beam == D.beam));
+    const int k = m ? __popcll(m) : 1;
+    D.ctl[c].stores_left = k;
+    D.ctl[c].items_left = k | (risky ? kRiskyBit : 0);
+  }
   if (!m) {
     // no candidate survived: nothing to insert -- but with two launches per frame SOME insert workgroup has to close the
     // channel's frame: an empty item (group size 0)
@@ -326,7 +338,9 @@ __device__ __forceinline__ void plan_channel(const DecoderDev &D, int c, int gro
 // work items.  s_stat[4]: the workgroup's LDS accumulators {N, E, records, Z} (zero on entry; zero again on exit).
 __device__ __forceinline__ void tile_tail(const DecoderDev &D, int c, ChanCtl *ctl, int group, int par, uint32_t nN, uint32_t nE,
                                           uint32_t nR, uint32_t nZf, uint32_t *s_stat) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));   // (opaque: see plan_channel)
+  const int wave = threadIdx.x >> 6;
   // work counters: summed over the workgroup in LDS, then one set of atomics per tile from a wave that has nothing else to
   // wait for -- every atomic on the channel's control line queues behind the other tiles' (next_cutoff, the countdown)
   {
@@ -1161,7 +1175,10 @@ __global__ __launch_bounds__(kStThreads, 4) void expand_kernel_staged_row_timed(
 // test is safe).
 // =========================================================================================
 constexpr int kInsertThreads = 512;
-constexpr int kInsertUnroll = 4;
+#ifndef WFST_INSERT_UNROLL
+#define WFST_INSERT_UNROLL 3
+#endif
+constexpr int kInsertUnroll = WFST_INSERT_UNROLL;   // (1536 records in one sweep: wfst_options.joint_max's default; a fourth record per thread cost five VGPRs at the 80-register limit)
 
 // insert_kernel: a fixed grid of workgroups pulls the planned items (first gridDim.x statically,
 // then by ticket); 512 threads, dynamic LDS = lds_slots * 12 bytes (16 in lattice mode).
@@ -1172,13 +1189,31 @@ struct BoundaryLite {   // frame_boundary_fused's few words of LDS
   u64 best;
   int active, n, nd, front_begin, ntiles, tile_tokens, tile_start, pad_bits;
   // what the workgroup that counted the channel's last item out already holds (nothing is loaded behind the countdown):
+  uint32_t hist[256];   // GetCutoff's radix select (the slow path: max_active / min_active / the per-frame limit bind)
+  uint32_t sel_prefix, sel_k;
+  float prev_ab;        // adaptive_beam of the frame being closed
   u64 h_best;         // ChanCtl::best_next as the expansion left it
+  int h_risky;        // the frame's items stored their tokens write-through and count themselves out of stores_left
   int h_nf, h_err;    // the frame's token count (the countdown's own answer), error bits (as of the item's start | this frame's)
   uint32_t h_bound;   // the final next_cutoff
 };
 template <int kT>
 __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c, const int32_t *target, int chan_cnt, int group,
                                                      int par_next, bool do_prep, BoundaryLite &sh);
+template <int kT, bool kSc1, class Sh, int kKeep>
+__device__ __forceinline__ float kth_smallest_t(const int4 *tok, int n, int k, Sh &sh);
+#ifndef WFST_NOINLINE_COLD
+#define WFST_COLD __forceinline__
+#else
+#define WFST_COLD __attribute__((noinline))
+#endif
+#ifndef WFST_COLD_KEEP
+#define WFST_COLD_KEEP 2   // costs a thread keeps in registers across the selection's four passes (the rest are re-read)
+#endif
+template <int kT>
+__device__ WFST_COLD float kth_smallest_cold(const int4 *tok, int n, int k, BoundaryLite *sh) {
+  return kth_smallest_t<kT, true, BoundaryLite, WFST_COLD_KEEP>(tok, n, k, *sh);
+}
 
 template <bool kLat, bool kBig, bool kFused>
 __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int par, const int32_t *target = nullptr, int boundary = 0,
@@ -1246,6 +1281,9 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   // with everything else (complete since the expansion launch ended: the best candidate; the error bits so far)
   const u64 best_early = (kTwo && D.best_exp) ? ctl->best_next : ~0ull;
   const int err_early = kTwo ? ctl->error : 0;
+  // (kRiskyBit of items_left, set by plan_channel: this frame's boundary may have to read the frame's tokens -- the bit does not
+  // change during the launch, whatever the countdown does to the bits below it)
+  const bool risky = kTwo && boundary && (ctl->items_left & kRiskyBit);
   // table sized to the load: the smallest power of two >= 4 n (records >= distinct states)
   int log2sl = 6;
   while ((1 << log2sl) < 4 * n && log2sl < D.log2lds) ++log2sl;
@@ -1335,7 +1373,9 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
       int g = atomicAdd(&ctl->new_count, ns);
       s_gpos = g;
       if constexpr (kListEmit) s_ech = ech_reg;
-      if (g + ns > D.max_tok) { atomicOr(&ctl->error, kErrFrontierFull); s_ok = 0; }
+      // (fused best-path decoders: the per-frame limit is a max_active, not a capacity -- DecoderDev::soft_limit -- and the frame
+      // takes what the arena takes)
+      if (!(kTwo && D.soft_limit) && g + ns > D.max_tok) { atomicOr(&ctl->error, kErrFrontierFull); s_ok = 0; }
       if ((int64_t)base + g + ns > D.arena_cap) { atomicOr(&ctl->error, kErrArenaFull); s_ok = 0; }
       // (the frame's boundary learns it from the countdown's answer: this item's tokens are counted but not written)
       if (kTwo && !s_ok) atomicOr(reinterpret_cast<u64 *>(&ctl->new_count), kFrameErrBit);
@@ -1344,6 +1384,8 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
     if (!s_ok) break;
     if (tid == 0) dbg_phase(D, 8, tq);
     const int gpos = s_gpos;
+    // (kTwo: the frame's tokens as a raw buffer -- base = the frame's first token, 2 GB of range; dword 3 as for any raw 32-bit buffer)
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t tok_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(tok + base), 0, 0x7FFFFFF0, 0x00020000);
 
     // pass 2: the record that won its state writes the token
     // (lattice mode: an item that fits one sweep -- every planned item does -- keeps each live
@@ -1396,7 +1438,15 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
         const uint32_t flags = (uint32_t)r[k].w & kFlagMask;
         if (winner) {
           idx = base + gpos + wb + lane_rank(wm);
-          tok[idx] = r[k];  // {state, cost, source token, arc | flags}
+          // {state, cost, source token, arc | flags}.  Two-launch decoders, on the frames whose GetCutoff may have to look at the
+          // tokens (risky): WRITE-THROUGH (sc1) -- the workgroup that closes the frame reads the frame's costs in this same launch
+          if (kTwo && risky) {   // (uniform)
+            typedef int v4i_t __attribute__((ext_vector_type(4)));
+            const v4i_t v = {r[k].x, r[k].y, r[k].z, r[k].w};
+            __builtin_amdgcn_raw_buffer_store_b128(v, tok_rsrc, (gpos + wb + lane_rank(wm)) * 16, 0, 16);   // (aux 16 = sc1)
+          } else {
+            tok[idx] = r[k];
+          }
           if constexpr (kBig) D.tok_lm[(size_t)c * D.arena_cap + idx] = rl[k];
           if (kLat) tidx[wslot] = idx;
           // (kTwo: the best token's graph ROW rides in the low word -- all the next frame's seed needs, DecoderDev::best_row)
@@ -1585,6 +1635,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
       if (last) {
         bsh.h_nf = (int)(uint32_t)old;
         bsh.h_err = err_early | ((old & kFrameErrBit) ? kErrInternal : 0);   // (the sticky bit itself was set where the error arose)
+        bsh.h_risky = risky ? 1 : 0;
         bsh.h_bound = bound_o;
         bsh.h_best = best_early;
       }
@@ -1594,10 +1645,14 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
     // could have had -- measured: +1.5 ms per step)
     s_item = n_items > (int)gridDim.x ? (int)gridDim.x + atomicAdd(&fc->item_ticket[par], 1) : n_items;   // (no ticket where every item had its workgroup from the start)
   }
+  // two launches per frame: every wave's token stores have LANDED before the item counts itself out of stores_left (behind the
+  // barrier below; the wait overlaps the countdown's round trip, which wave 0 is waiting for anyway)
+  if (risky) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   it = s_item;
   const int last = s_last;
   __syncthreads();
+  if (risky && tid == 0) atomicSub(&ctl->stores_left, 1);
   if (tid == 0) dbg_phase(D, 23, tq);   // (countdown + ticket answered)
   if constexpr (kTwo) {
     if (last) {
@@ -2080,7 +2135,7 @@ __device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanC
     for (int w = 0; w < kBW; ++w) z += sh.red64[w];
     int err = sh.err;
     int nf = sh.nnew;
-    if (nf > D.max_tok || (int64_t)base + nf > D.arena_cap) nf = 0;
+    if ((!D.soft_limit && nf > D.max_tok) || (int64_t)base + nf > D.arena_cap) nf = 0;   // (soft_limit: the per-frame limit is a max_active)
     if (ctl->error | err) nf = 0;  // a channel that hit a limit stops producing tokens
     if (f + 2 > D.max_frames + 1) err |= kErrFramesFull;
     else {
@@ -2115,27 +2170,37 @@ __device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanC
 // wave-parallel prefix scan of the histogram (a serial scan by one thread cost ~7 us per pass).
 constexpr int kSelKeep = 8;
 
-__device__ __forceinline__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  uint32_t keep[kSelKeep];
+// kT threads; kSc1: the costs are read with agent-scope (sc1) loads -- the tokens were written, write-through, by OTHER workgroups
+// of this launch (frame_boundary_fused's slow path; cdna_hip_programming.md Guideline 16: every load of handed-off bytes).
+template <int kT, bool kSc1, class Sh, int kKeep>
+__device__ __forceinline__ float kth_smallest_t(const int4 *tok, int n, int k, Sh &sh) {
+  int tid = threadIdx.x;
+  if (kSc1) asm volatile("" : "+v"(tid));   // (inside the insert kernel: see frame_boundary_fused)
+  const int lane = tid & 63;
+  auto cost_of = [&](int i) -> uint32_t {
+    const int *p = reinterpret_cast<const int *>(tok + i) + 1;
+    const int bits = kSc1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+    return f2o(__int_as_float(bits));
+  };
+  uint32_t keep[kKeep];
 #pragma unroll
-  for (int j = 0; j < kSelKeep; ++j) {
-    const int i = j * kBT + tid;
-    keep[j] = i < n ? f2o(__int_as_float(tok[i].y)) : 0xFFFFFFFFu;  // orderable +NaN: sorts last
+  for (int j = 0; j < kKeep; ++j) {
+    const int i = j * kT + tid;
+    keep[j] = i < n ? cost_of(i) : 0xFFFFFFFFu;  // orderable +NaN: sorts last
   }
   if (tid == 0) { sh.sel_prefix = 0; sh.sel_k = (uint32_t)k; }
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
     const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-    for (int b = tid; b < 256; b += kBT) sh.hist[b] = 0;
+    for (int b = tid; b < 256; b += kT) sh.hist[b] = 0;
     __syncthreads();
     const uint32_t prefix = sh.sel_prefix;
 #pragma unroll
-    for (int j = 0; j < kSelKeep; ++j) {
-      if (j * kBT + tid < n && (keep[j] & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(keep[j] >> shift) & 255u], 1u);
+    for (int j = 0; j < kKeep; ++j) {
+      if (j * kT + tid < n && (keep[j] & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(keep[j] >> shift) & 255u], 1u);
     }
-    for (int i = kSelKeep * kBT + tid; i < n; i += kBT) {
-      const uint32_t o = f2o(__int_as_float(tok[i].y));
+    for (int i = kKeep * kT + tid; i < n; i += kT) {
+      const uint32_t o = cost_of(i);
       if ((o & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(o >> shift) & 255u], 1u);
     }
     __syncthreads();
@@ -2162,6 +2227,12 @@ __device__ __forceinline__ float kth_smallest(const int4 *tok, int n, int k, Bou
   }
   return o2f(sh.sel_prefix);
 }
+__device__ __forceinline__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh) {
+  return kth_smallest_t<kBT, false, BoundaryShared, kSelKeep>(tok, n, k, sh);
+}
+// The selection of frame_boundary_fused's slow path, OUT OF LINE: a handful of frames take it, and inlined its registers (the costs
+// kept across the four passes) and its code sit in the insert kernel's hot loops' allocation (insert +8 % per launch, measured).
+// Nothing of the decoder block is passed: a function taking it by reference makes the compiler copy the kernel argument to scratch.
 
 template <bool kBig>
 __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *ctl, const int32_t *target, BoundaryShared &sh,
@@ -2185,13 +2256,19 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
 
   // GetCutoff, base-inl.h:138-234
   float cutoff, ab;
-  if (D.max_active == 2147483647 && D.min_active == 0) {
+  if (D.max_active == 2147483647 && D.min_active == 0 && !D.soft_limit) {
     ab = D.beam;
     cutoff = best_w + D.beam;
   } else {
     const float beam_cutoff = best_w + D.beam;
     float min_active_cutoff = kInf, max_active_cutoff = kInf;
-    if (n > D.max_active) max_active_cutoff = kth_smallest(tok, n, D.max_active, sh);
+    // (soft_limit decoders: the per-frame token limit acts as a max_active -- the frame holds every token the arena took, the
+    // expansion goes on from the limit-th cheapest: what the reference does at that max_active, base-inl.h:188-203)
+    const int max_eff = D.soft_limit ? min(D.max_active, D.max_tok) : D.max_active;
+    if (n > max_eff) {
+      max_active_cutoff = kth_smallest(tok, n, max_eff, sh);
+      if (tid == 0 && D.soft_limit && D.max_tok < D.max_active) D.degraded[c] += 1;
+    }
     if (max_active_cutoff < beam_cutoff) {
       ab = max_active_cutoff - best_w + D.beam_delta;
       cutoff = max_active_cutoff;
@@ -2263,7 +2340,7 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
     const int nseed = (!kBig && D.seed_tiles && ntiles > 0) ? 1 : 0;   // the seed tile, listed first
     ctl->tiles_left = ntiles + nseed;
     if (ntiles == 0 && D.two_launch) {   // a channel without tokens: no tile will plan its insert items, yet its frame must be closed
-      ctl->items_left = 1;
+      ctl->items_left = ctl->stores_left = 1;
       push_empty_item(D, c, group, par);
     }
     if (ntiles > 0) {
@@ -2309,7 +2386,12 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
 template <int kT>
 __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c, const int32_t *target, int chan_cnt, int group,
                                                      int par_next, bool do_prep, BoundaryLite &sh) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (an opaque copy of the thread index: what the boundary derives from it -- addresses of the tile list, of the counters -- is
+  // then computed HERE; hoisted to the kernel's entry, as loop invariants of the item loop, those values lived across the insert
+  // passes and were spilled there: 0.2 ms per step per spilled register, the spill stores sit in front of an item's first loads)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   ChanCtl *ctl = D.ctl + c;
   const float kInf = __builtin_huge_valf();
   // every item of the channel is done with the bucket counters: reset for the next expansion
@@ -2322,7 +2404,8 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
     const int err = sh.h_err;
     const u64 best = D.best_exp ? sh.h_best : ld_agent(&ctl->best_next);
     int add_err = 0;
-    if (nf > D.max_tok || (int64_t)base + nf > D.arena_cap) nf = 0;   // (the insert workgroups have raised the error bit)
+    // (the per-frame token limit is a max_active here, not a capacity: DecoderDev::soft_limit; the arena is one)
+    if ((!D.soft_limit && nf > D.max_tok) || (int64_t)base + nf > D.arena_cap) nf = 0;   // (the insert workgroups have raised the error bit)
     if (err) nf = 0;   // a channel that hit a limit stops producing tokens
     if (f + 2 > D.max_frames + 1) add_err = kErrFramesFull;
     else {
@@ -2331,6 +2414,7 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
     }
     ctl->cnt_tok += (u64)nf;
     if (nf > ctl->peak_tokens) ctl->peak_tokens = nf;
+    sh.prev_ab = ctl->adaptive_beam;   // (of the frame being closed)
     ctl->front_begin = base;
     ctl->front_count = nf;
     ctl->n_decoded = f + 1;
@@ -2350,8 +2434,62 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
   const int n = sh.n, nd = sh.nd;
   const u64 best = sh.best;
   const float best_w = n > 0 ? o2f((uint32_t)(best >> 32)) : kInf;
-  // GetCutoff with max_active and min_active out of reach (base-inl.h:138-234; prep_frame's general path gives the same)
-  const float ab = D.beam, cutoff = best_w + D.beam;
+  // GetCutoff (base-inl.h:138-234), as prep_frame computes it.  The frame's tokens are needed only where a limit can bind:
+  //  * more tokens than max_active (or than the per-frame limit, which acts as one): the exact max_active-th cheapest cost;
+  //  * min_active: the frame was built below next_cutoff = best + adaptive_beam of the frame before (every candidate, emitting
+  //    or epsilon arrival, costs at least the cheapest emitting one, whose cost + adaptive_beam IS the final next_cutoff:
+  //    min(x) + b == min(x + b)); while that adaptive beam was the plain beam every token lies below best + beam, the
+  //    min_active-th cheapest too, and the cutoff is best + beam without a look at the tokens; after a frame whose cutoff
+  //    min_active (or max_active) set, the selection runs.
+  // Those frames read the tokens the OTHER insert workgroups of this launch wrote: stored write-through (sc1), drained by every
+  // storing wave, counted down in ChanCtl::stores_left behind the drain, read here with sc1 loads once that count is zero
+  // (cdna_hip_programming.md Guideline 16; MI355X_MICROARCH.md, Valid forms, first row of the table).
+  const float beam_cutoff = best_w + D.beam;
+  const int max_eff = D.soft_limit ? min(D.max_active, D.max_tok) : D.max_active;
+#ifdef WFST_LEAN_BOUNDARY   // (A/B builds: the boundary without its slow path)
+  const bool need_max = false, need_min = false;
+#else
+  const bool need_max = n > max_eff;
+  const bool need_min = D.min_active > 0 && n > D.min_active && !(sh.prev_ab == D.beam);
+#endif
+  float ab = D.beam, cutoff = beam_cutoff;
+  if (need_max || need_min) {   // (uniform over the workgroup)
+    if (tid == 0) {
+      if (!sh.h_risky) atomicOr(&ctl->error, kErrInternal);   // (plan_channel's test covers every such frame: never expected)
+      int spins = 0;
+      while (sh.h_risky && ld_agent(&ctl->stores_left) != 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 22)) { atomicOr(&ctl->error, kErrInternal); break; }   // (never expected; reported, not hung on)
+      }
+      if (need_max && D.max_tok < D.max_active) D.degraded[c] += 1;   // (the per-frame limit, not the caller's max_active, binds)
+    }
+    __syncthreads();
+    const int4 *tok = D.tok + (size_t)c * D.arena_cap + sh.front_begin;
+    float min_active_cutoff = kInf, max_active_cutoff = kInf;
+    if (n > D.min_active) min_active_cutoff = best_w;   // (min_active 0, or every token below best + beam: any value at or below it decides the same)
+    // (ONE call site for the selection -- the max_active-th cheapest first, the min_active-th only where that does not bind:
+    // inlined twice the selection was 12 KB of the insert kernel's 28, and the launch 4 % slower for code that rarely runs)
+#pragma nounroll
+    for (int stage = need_max ? 0 : 1; stage < 2; ++stage) {
+      if (stage == 1 && !need_min) break;
+      const float v = kth_smallest_cold<kT>(tok, n, stage == 0 ? max_eff : D.min_active, &sh);
+      if (stage == 0) {
+        max_active_cutoff = v;
+        if (max_active_cutoff < beam_cutoff) break;
+      } else {
+        min_active_cutoff = v;
+      }
+    }
+    if (max_active_cutoff < beam_cutoff) {
+      ab = max_active_cutoff - best_w + D.beam_delta;
+      cutoff = max_active_cutoff;
+    } else if (min_active_cutoff > beam_cutoff) {
+      ab = min_active_cutoff - best_w + D.beam_delta;
+      cutoff = min_active_cutoff;
+    }
+  } else if (n <= D.min_active) {   // count <= min_active: min_active_cutoff stays +inf (base-inl.h:205-226)
+    if (kInf > beam_cutoff) { ab = kInf - best_w + D.beam_delta; cutoff = kInf; }
+  }
   const float *llrow = D.ll_base[c] + (size_t)nd * D.stride;
   // seed next_cutoff from the best token's emitting arcs, base-inl.h:282-300 (seed_tiles: left to the expansion's seed tile)
   float seed = kInf;
@@ -2389,7 +2527,7 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
     sh.ntiles = 0;
     ctl->tiles_left = ntiles + nseed;
     if (ntiles == 0) {   // a channel without tokens: an empty insert item closes its next frame
-      ctl->items_left = 1;
+      ctl->items_left = ctl->stores_left = 1;
       push_empty_item(D, c, group, par_next);
     } else {
       const int start = atomicAdd(&D.fctl[group].total_tiles[par_next], ntiles + nseed);
@@ -3477,6 +3615,7 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
   if (tid == 0) {
     if (D.lat_stats) for (int q = 0; q < 4; ++q) D.lat_stats[(size_t)c * 4 + q] = 0;
     D.emit_cnt[c * 32] = 0;
+    D.degraded[c] = 0;
     ChanCtl z;
     memset(&z, 0, sizeof(z));
     z.best_next = ~0ull;

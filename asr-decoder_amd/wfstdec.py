@@ -32,6 +32,7 @@ SYMBOLS = [
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
     "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice", "wfst_decoder_get_nbest_paths",
+    "wfst_decoder_get_degraded_frames",
 ]
 
 
@@ -307,6 +308,12 @@ class BatchDecoder:
         lat = self.lattice_links > 0
         return dict(frames=s[0], N=s[1], E=s[2], Z=s[3], tokens=s[4], peak_tokens=s[5], records=s[6], links=s[7] if lat else 0,
                     collections=0 if lat else s[7])
+
+    def degraded_frames(self, channel):
+        """Frames of the utterance on which the per-frame token limit acted as a max_active (wfst_decoder_get_degraded_frames)."""
+        n = C.c_int32(0)
+        _check(lib().wfst_decoder_get_degraded_frames(self.h, int(channel), C.byref(n)))
+        return int(n.value)
 
     def lattice_stats(self, channel):
         s = (C.c_int64 * 5)()

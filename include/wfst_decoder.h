@@ -65,7 +65,9 @@ typedef struct wfst_config {
  * WFST_E_CAPACITY; nothing is silently dropped. */
 typedef struct wfst_limits {
   int32_t max_frames;           /* frames per utterance                     (default 4096)    */
-  int32_t max_tokens_per_frame; /* distinct states reached in one frame     (default 32768, or 4 x a finite max_active, at most 262144) */
+  int32_t max_tokens_per_frame; /* distinct states reached in one frame     (default 65536, or 4 x a finite max_active, at most 262144).
+                                   Best-path decoders on the fused rows do not fail at it: it acts as a max_active
+                                   (wfst_decoder_get_degraded_frames); lattice and biglm decoders return WFST_E_CAPACITY */
   int64_t arena_tokens;         /* token arena of one utterance, 16 bytes a token.  BEST-PATH decoders keep every
                                    token of the utterance for the traceback (there are no link lists to prune
                                    them by): an utterance of T frames with n tokens alive per frame needs about
@@ -80,7 +82,7 @@ typedef struct wfst_limits {
                                    code: the expansion then skips the row-header reads (a third of its fetches).  LATTICE-MODE decoders reclaim it every
                                    prune_interval frames (see wfst_config) and need ~3x the tokens
                                    FinalizeDecoding keeps + prune_interval frames of raw tokens.
-                                   Default: max_frames x max(256, max_tokens_per_frame / 32), at least 4194304,
+                                   Default: max_frames x max(256, max_tokens_per_frame / 64), at least 4194304,
                                    i.e. room for the default max_frames at 1024 tokens per frame             */
   int64_t lattice_links;        /* > 0: LATTICE MODE -- record every forward link (capacity per
                                    utterance) so that FinalizeDecoding can prune by lattice_beam and
@@ -397,6 +399,14 @@ int wfst_decoder_channel_groups(wfst_decoder *d);
  * recorded, links priced by the PruneActiveTokens / FinalizeDecoding walks (one per link and sweep), tokens priced by them,
  * tokens + links scanned by the compactions, tokens + links the compactions moved}. */
 int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t stats[5]);
+
+/* Frames of the channel's utterance (since its last init) on which the per-frame token limit BOUND: best-path decoders on
+ * the fused graph rows treat wfst_limits.max_tokens_per_frame as a max_active, not as a capacity -- a frame that reaches
+ * more distinct states keeps every token (the arena permitting) and the search goes on from the limit-th cheapest, exactly
+ * what the reference does at that max_active (GetCutoff, base-inl.h:188-203) where it grows its hash and pools instead
+ * (base-inl.h:237-244, util/mem-pool.h:17-65).  0 = the result is the one the caller's config alone defines.  Lattice and
+ * biglm decoders report 0 and keep WFST_E_CAPACITY for that limit. */
+int wfst_decoder_get_degraded_frames(wfst_decoder *d, int32_t channel, int32_t *n_frames);
 
 /* Frontier of a channel after the last decoded frame (states and costs, unordered); for tests.
  * Returns the number of tokens (may exceed cap; only cap are written). */

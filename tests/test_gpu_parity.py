@@ -220,6 +220,37 @@ def test_max_active_min_active_binding_is_exact_in_order_free_terms(cd, setup50k
     assert same >= 3, "only %d/8 utterances with the reference's own words" % same
 
 
+@pytest.mark.parametrize("limit,cd", [(1500, BEAM_ONLY), (64, BEAM_ONLY),
+                                      (1200, dict(beam=13.0, max_active=2147483647, min_active=200, lattice_beam=7.0))])
+def test_per_frame_limit_degrades_like_max_active(limit, cd, setup50k, synth, oracle):
+    """wfst_limits.max_tokens_per_frame reached mid-utterance: the reference never refuses a frame -- it grows its hash
+    (base-inl.h:237-244) and pools (util/mem-pool.h:17-65) and tightens with max_active (:188-203).  A best-path decoder here
+    keeps the frame's tokens and goes on from the limit-th cheapest: bit for bit the (order-free) reference algorithm run
+    with max_active = the limit; wfst_decoder_get_degraded_frames says on how many frames."""
+    s = setup50k
+    W = s["G"].wfstdec
+    mats = _utts(synth, s, [120] * 4, 7100, mu=-2.3)
+    dec = W.BatchDecoder(s["graph"], s["G"].gpu_config(cd), len(mats), max_frames=512, max_tokens_per_frame=limit, arena_tokens=1 << 22)
+    res = s["G"].decode_batch(s["graph"], cd, mats, dec=dec)
+    ocd = dict(cd, max_active=limit)
+    try:
+        oracle.set_order_free(True)
+        for i, (r, ll) in enumerate(zip(res, mats)):
+            f = oracle.decode(s["h"], pyoracle.Config(**ocd), ll, s["m"])
+            assert r.ok and f.ok and len(r.tids) == 120
+            assert f.extra["ties"] == 0, "exact cost tie on the best path (utt %d)" % i
+            s["G"].assert_same_as_oracle(r, f, "utt %d (limit %d as max_active)" % (i, limit))
+            assert dec.degraded_frames(i) > 0, "the limit never bound (utt %d)" % i
+    finally:
+        oracle.set_order_free(False)
+    # an utterance the limit does not touch reports none
+    dec.free()
+    dec = W.BatchDecoder(s["graph"], s["G"].gpu_config(cd), 1, max_frames=512, max_tokens_per_frame=32768, arena_tokens=1 << 22)
+    s["G"].decode_batch(s["graph"], cd, mats[:1], dec=dec)
+    assert dec.degraded_frames(0) == 0
+    dec.free()
+
+
 def test_errors_are_loud(setup50k, synth):
     s = setup50k
     G = s["G"]
@@ -247,8 +278,9 @@ def test_errors_are_loud(setup50k, synth):
     assert e.value.code == -5
     assert dec.best_paths(channels=[1])[0]["ok"] is False  # no frames decoded -> GetBestPath false
     dec.free()
-    # a frame that does not fit max_tokens_per_frame must fail, not silently drop tokens
-    tiny = W.BatchDecoder(s["graph"], G.gpu_config(BEAM_ONLY), 1, max_frames=64, max_tokens_per_frame=64, arena_tokens=1 << 16)
+    # an utterance that does not fit its token arena must fail, not silently drop tokens (the per-frame token limit of a
+    # best-path decoder is no such capacity: test_per_frame_limit_degrades_like_max_active)
+    tiny = W.BatchDecoder(s["graph"], G.gpu_config(BEAM_ONLY), 1, max_frames=64, max_tokens_per_frame=4096, arena_tokens=1 << 10)
     tiny.init()
     tiny.advance([dev[0].data_ptr()], [30], 3000)
     with pytest.raises(W.WfstError) as e:
