@@ -157,6 +157,7 @@ struct wfst_decoder {
   DevBuf<FrameCtl> fctl;
   DevBuf<unsigned long long> dbg_t;
   DevBuf<int32_t> items, item_pref, degraded;
+  int32_t det_only = -1;   // determinize_alone: the one channel wfst_decoder_get_determinized_lattice shall determinize, afresh
   DevBuf<TileDesc> tiles;
   int insert_wgs = 768;
   std::vector<int> gpar;  // step parity per group (persists across advance calls)
@@ -1997,11 +1998,12 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
   // are two calls: the second reuses the first's work)
   const bool live_hit = live && d->det_live_nd[(size_t)channel] == d->h_decoded[channel] &&
                         d->det_live_final[(size_t)channel] == (use_final_probs ? 1 : 0);
-  if ((live && !live_hit) || (!live && !d->det_cached[channel])) {
+  const bool only = d->det_only == channel;   // (determinize_alone: this channel alone, into workspace slot 0, not from a cache)
+  if (only || (live && !live_hit) || (!live && !d->det_cached[channel])) {
     // which channels: mid-utterance just this one (its lists are resolved first); after FinalizeDecoding every
     // finalized channel not determinized yet (their lists were resolved by FinalizeDecoding), det_slots per launch
     std::vector<int32_t> all;
-    if (live) all.push_back(channel);
+    if (live || only) all.push_back(channel);
     else
       for (int c = 0; c < d->n_channels; ++c)
         if (d->h_state[c] == 2 && !d->det_cached[c]) all.push_back(c);
@@ -2066,15 +2068,11 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
 // The determinized lattice of ONE channel into workspace slot 0 (a cached host copy of an earlier batch determinization does not
 // hold the device copy any more): the other finalized channels are hidden from the batch sweep for the call.
 static int determinize_alone(wfst_decoder *d, int32_t channel, int32_t use_final_probs, int32_t *ns, int32_t *na) {
-  if (!d->det_cached.empty()) { d->det_cached[channel] = 0; d->det_live_nd[channel] = -1; }
-  std::vector<char> saved(d->det_cached);
-  if (!saved.empty())
-    for (int c = 0; c < d->n_channels; ++c)
-      if (c != channel) d->det_cached[c] = 1;
+  // (det_only: the call below determinizes exactly this channel, afresh, whatever is cached and whichever other channels are
+  // finalized -- also when it is the decoder's first determinizer use and the caches do not exist yet)
+  d->det_only = channel;
   int rc = wfst_decoder_get_determinized_lattice(d, channel, use_final_probs, 0, 0, ns, na, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-  if (!saved.empty())
-    for (int c = 0; c < d->n_channels; ++c)
-      if (c != channel) d->det_cached[c] = saved[c];
+  d->det_only = -1;
   if (rc != WFST_OK && !(rc == WFST_E_CAPACITY && *ns > 0)) return rc;
   return WFST_OK;
 }

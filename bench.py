@@ -83,7 +83,7 @@ def parse():
     ap.add_argument("--arena-per-frame", type=int, default=0, help="token arena per utterance = frames x this (raise it for wider beams); "
                     "300 x 13900 stays below 2^22 tokens, where a token's backpointer has room for its state's degree code "
                     "(wfst_device.h: the expansion then skips the row-header loads); the heaviest utterance of rank 0's workload needs 3.4 M. "
-                    "0 = 13900 on one GPU, 20000 on several (other ranks decode other utterances: no rank shall start collecting tokens)")
+                    "0 = 13900 at every N (the token collection takes care of an utterance that outgrows it)")
     ap.add_argument("--lattice-links", type=int, default=0, help="> 0: lattice mode (BASELINE configs[4]): record forward links "
                     "(capacity per utterance), prune by lattice_beam at finalize; the step then also takes the n-best")
     ap.add_argument("--lattice-beam", type=float, default=7.0)
@@ -252,8 +252,9 @@ def edit_distance(a, b):
 def divergence(gpu_res, cpu_res):
     """GPU results vs the CPU decoder's own, utterance by utterance."""
     n = len(gpu_res)
-    ident = errs = nref = same_words = 0
+    ident = errs = nref = same_words = with_path = 0
     gap = 0.0
+    signed = []   # (tot_first - tot_second) / |tot_second| of the utterances both sides found a path for: > 0 = the first one's path costs more
     for r, o in zip(gpu_res, cpu_res):
         same = (np.array_equal(o.words, r["words"]) and np.array_equal(o.tids, r["tids"]) and
                 np.float32(o.tot_score).tobytes() == np.float32(r["tot_score"]).tobytes())
@@ -261,10 +262,19 @@ def divergence(gpu_res, cpu_res):
         same_words += int(np.array_equal(o.words, r["words"]))
         errs += edit_distance(o.words, r["words"])
         nref += len(o.words)
+        with_path += int(bool(r["ok"]))
         if o.ok and r["ok"] and o.tot_score != 0:
             gap = max(gap, abs(r["tot_score"] - o.tot_score) / abs(o.tot_score))
+            signed.append((float(r["tot_score"]) - float(o.tot_score)) / abs(float(o.tot_score)))
+    sg = np.asarray(signed, np.float64) if signed else np.zeros(1)
     return {"utterances": n, "bit_identical": ident, "same_words": same_words, "word_errors": errs, "ref_words": nref,
-            "wer": errs / float(max(nref, 1)), "max_rel_cost_gap": gap}
+            "wer": errs / float(max(nref, 1)), "max_rel_cost_gap": gap,
+            # path cost is the only quality measure without transcripts: the SIGN of the difference says which side searched better
+            "utterances_with_path": with_path,
+            "signed_rel_cost_gap": {"mean": float(sg.mean()), "median": float(np.median(sg)),
+                                    "first_cheaper": int((sg < 0).sum()), "second_cheaper": int((sg > 0).sum()), "equal": int((sg == 0).sum()),
+                                    "note": "(tot_first - tot_second) / |tot_second| over utterances with a path on both sides; first = the "
+                                            "decoder under test (GPU, or the reference at hash_ratio 3), second = the reference"}}
 
 
 def oracle_counts(graph_path, cd, mats, m, order_free=False, want_paths=None):
@@ -363,7 +373,9 @@ def main():
 
     B, T, P = a.batch, a.frames, a.pdfs
     if a.arena_per_frame <= 0:
-        a.arena_per_frame = 13900 if world == 1 else 20000
+        # the SAME decoder configuration at every N (an arena above 2^22 tokens would drop the degree codes: every rank of an N > 1
+        # run would then read the row headers the N = 1 headline skips); an utterance that outgrows it collects its tokens
+        a.arena_per_frame = 13900
     n_tid = 2 * P
     m = synth.default_tid2pdf(n_tid)
     cd = dict(beam=a.beam, max_active=a.max_active, min_active=a.min_active, lattice_beam=a.lattice_beam,
@@ -542,6 +554,25 @@ def main():
             "channel_groups": int(dec.n_groups),
         },
     }
+    if world > 1:
+        # N > 1: a live parity sample on EVERY rank -- its first two utterances against the CPU restatement (bit for bit: words,
+        # transition-ids, tot_score) --, summed over the ranks
+        import pyoracle
+
+        if rank == 0:
+            pyoracle.build_oracle()
+        dist.barrier()
+        orc = pyoracle.OracleDecoder()
+        h = orc.load_graph(gpath)
+        okr = 0
+        for i in range(min(2, B)):
+            o = orc.decode(h, pyoracle.Config(**cd), mats[i], m)
+            okr += int(np.array_equal(o.words, res[i]["words"]) and np.array_equal(o.tids, res[i]["tids"]) and
+                       np.float32(o.tot_score).tobytes() == np.float32(res[i]["tot_score"]).tobytes())
+        orc.free_graph(h)
+        tt = torch.tensor([okr, min(2, B)], dtype=torch.int64, device="cpu" if share else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        out["config"]["parity_per_rank_sample"] = "%d/%d utterances (two per rank) bit-exact vs the CPU restatement" % (int(tt[0].item()), int(tt[1].item()))
     if rank == 0 and world > 1 and os.environ.get("WFST_BENCH_CHECK_GATHER") == "1":
         # test hook (tests/test_gpu_multirank.py): the gathered results of ALL ranks against the oracle
         import pyoracle
@@ -567,6 +598,12 @@ def main():
         out["config"]["mean_expanded_tokens_per_frame"] = N / float(B * T)
         out["config"]["peak_tokens_in_a_frame"] = max(s["peak_tokens"] for s in gstats)
         out["config"]["max_tokens_per_frame_limit"] = a.max_tokens
+        out["config"]["max_tokens_per_frame_note"] = ("a best-path decoder does not fail at this limit, it goes on from the limit-th cheapest token "
+                                                      "(degraded_frames counts the frames on which it did); the limit also sizes the arena's collection "
+                                                      "reserve: every gc_stride-th frame (reserve / limit - 1, at most 16) runs the classic three launches")
+        if a.lattice_links == 0 and not a.biglm:
+            out["config"]["degraded_frames"] = int(sum(dec.degraded_frames(c) for c in range(B)))
+        out["config"]["utterances_with_path"] = int(sum(1 for r in res if r["ok"]))
         if a.lattice_links > 0 and a.determinize:
             dl = [r["det"] for r in res if r.get("det") is not None]
             out["config"]["determinized_lattices"] = {
@@ -801,6 +838,24 @@ def main():
         hp = {"workload": "the headline log-likelihoods at max_active=7000, min_active=200"}
         hp.update(at_service_point(mats, ll_dev))
         sp["headline_workload_at_7000_200"] = hp
+        # the reference's DEFAULT limits (lattice-faster-decoder-conf.h:35-44: max_active INT_MAX, min_active 200) on the headline
+        # workload: min_active binds on the first frames of an utterance only -- the two-launch frames and the staged expansion stay
+        def at_limits(cd3, label):
+            nonlocal dec
+            dec = new_decoder(cd3)
+            step3 = make_step(dec, ll_dev, [mats[i] for i in range(B)])
+            dt3, res3 = timed(step3, 1, max(4, n2))
+            o = {"workload": label, "value": B * T * max(4, n2) / dt3, "unit": "frames/s", "ms_per_step": 1000.0 * dt3 / max(4, n2), "steps": max(4, n2)}
+            dec.free()
+            dec = None
+            if a.cpu_sample > 0:
+                kind, cdec = cpu_decoder()
+                ns3 = min(a.cpu_sample, B)
+                o["divergence_vs_" + kind] = divergence(res3[:ns3], cpu_decode_all(cdec, gpath, cd3, [mats[i] for i in range(ns3)], m, min(ns3, affinity_cpus())))
+            return o
+
+        out["reference_default_limits"] = at_limits(dict(cd, max_active=2147483647, min_active=200),
+                                                    "the headline log-likelihoods at the reference's default limits: max_active=INT_MAX, min_active=200")
         sp["divergence_note"] = ("where max_active/min_active bind, the reference's cutoff depends on its own hash-list visiting "
                                  "order (DESIGN.md section 4, deviation 2): it then differs from itself when only hash_ratio "
                                  "changes; the GPU computes the order-independent restatement")
@@ -823,8 +878,11 @@ def main():
         common = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "1", "--no-service-point", "--no-legs", "--no-cpu-baseline",
                   "--batch", str(B), "--frames", str(T), "--states", str(a.states), "--pdfs", str(P)]
         legs = {"biglm": ["--biglm", "--steps", str(n2), "--cpu-sample", "8", "--max-tokens", "131072"],
+                "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2"],
+                "lattice_beam15_no_determinizer": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
+                                                   "--max-tokens", "262144", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "2", "--warmup", "2"],
                 "lattice_beam15": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
-                                   "--max-tokens", "262144", "--determinize", "--steps", str(max(2, n2 // 2)), "--cpu-sample", "4",
+                                   "--max-tokens", "262144", "--determinize", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "4",
                                    "--warmup", "2"]}   # (the n-best / determinizer paths allocate their workspaces on first use)
         for name, extra in legs.items():
             t0 = time.time()

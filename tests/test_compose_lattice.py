@@ -93,7 +93,9 @@ def test_device_second_pass_equals_reference_and_restatement(oracle, refdec, syn
         dec.init()
         dec.advance([t.data_ptr() for t in dev], [40] * len(lls), 300)
         dec.finalize()
-        for c in range(len(lls)):
+        # (last channel first: the decoder's FIRST determinizer use is then a second-pass query on a channel that is not the lowest
+        # finalized one -- it must determinize and compose that channel, not whichever lands in workspace slot 0 of a batch sweep)
+        for c in reversed(range(len(lls))):
             raw = dec.raw_lattice(c)
             got = dec.rescored_lattice(c, L1, L2)
             assert (raw is None) == (got is None)
