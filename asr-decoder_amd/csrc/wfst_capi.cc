@@ -1063,7 +1063,9 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // binds, most of a frame's tokens lie above the cutoff and are not expanded: the staged kernel's fixed cost per 256-token tile
   // then buys a fraction of a tile's work (measured at the service's 7000: 42.6 vs 31.4 ms of expansion per step), and
   // expand_kernel_fused's 512-token tiles stay.  (0x800: the replay experiments are expand_body's; 0x8000: A/B)
-  D.staged = (D.fused && !big && cfg->max_active >= L.max_tokens_per_frame && !(O.debug & 0x8800)) ? 1 : 0;
+  // (round 4: also where max_active binds -- the frame boundary then cuts COMPACTING tiles, wfst_kernels.hip kStSuper: the dead
+  // tokens of a frame no longer cost a tile's round trips; 0x40000: A/B, the round-2 expansion for those decoders)
+  D.staged = (D.fused && !big && (cfg->max_active >= L.max_tokens_per_frame || !(O.debug & 0x40000)) && !(O.debug & 0x8800)) ? 1 : 0;
   // the expansion finds the frame's best token itself (its cheapest candidate): the staged kernel of best_row decoders (0x20000: A/B)
   D.best_exp = (D.staged && D.best_row && !(O.debug & 0x20000)) ? 1 : 0;
   D.seed_tiles = (D.best_row && !(O.debug & 0x4800)) ? 1 : 0;   // (0x800: the replay experiments start from the frame's seed; 0x4000: A/B)

@@ -60,20 +60,60 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+// Wave-wide scans and reductions on the DPP crossbar (gfx9 row_shr / row_bcast modifiers of v_mov_b32): seven dependent VALU
+// moves for all 64 lanes, no LDS traffic and -- unlike the __shfl family, which hipcc lowers to ds_bpermute_b32 with one
+// precomputed address register per shuffle distance -- no index registers: the expansion kernels held a dozen VGPRs of shuffle
+// addresses across their passes, at the 128-register limit (round 4: the compacting tiles spilled on them).
+// dpp_ctrl: 0x111..0x11F row_shr:1..15, 0x142 row_bcast:15, 0x143 row_bcast:31.  A lane whose source lies outside its row, or
+// that the row / bank mask excludes, keeps `old` = the operation's identity.
+#define WFST_DPP(old, src, ctrl, rmask, bmask) __builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, rmask, bmask, false)
+// inclusive prefix sum over the wave's 64 lanes
+__device__ __forceinline__ int wave_incl_scan(int v0) {
+  int v = v0 + WFST_DPP(0, v0, 0x111, 0xf, 0xf);
+  v += WFST_DPP(0, v0, 0x112, 0xf, 0xf);
+  v += WFST_DPP(0, v0, 0x113, 0xf, 0xf);
+  v += WFST_DPP(0, v, 0x114, 0xf, 0xe);
+  v += WFST_DPP(0, v, 0x118, 0xf, 0xc);
+  v += WFST_DPP(0, v, 0x142, 0xa, 0xf);
+  v += WFST_DPP(0, v, 0x143, 0xc, 0xf);
   return v;
 }
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    u64 o = __shfl_xor(v, m, 64);
-    v = o < v ? o : v;
-  }
-  return v;
+// the wave's total, in every lane (uniform)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan((int)x), 63); }
+__device__ __forceinline__ float wave_min_f(float x) {
+  const int id = 0x7F800000;   // +inf
+  int v0 = __float_as_int(x);
+  auto mn = [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); };
+  int v = mn(v0, WFST_DPP(id, v0, 0x111, 0xf, 0xf));
+  v = mn(v, WFST_DPP(id, v0, 0x112, 0xf, 0xf));
+  v = mn(v, WFST_DPP(id, v0, 0x113, 0xf, 0xf));
+  v = mn(v, WFST_DPP(id, v, 0x114, 0xf, 0xe));
+  v = mn(v, WFST_DPP(id, v, 0x118, 0xf, 0xc));
+  v = mn(v, WFST_DPP(id, v, 0x142, 0xa, 0xf));
+  v = mn(v, WFST_DPP(id, v, 0x143, 0xc, 0xf));
+  return __int_as_float(__builtin_amdgcn_readlane(v, 63));
 }
-__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+__device__ __forceinline__ u64 wave_min_u64(u64 x) {
+  uint32_t lo0 = (uint32_t)x, hi0 = (uint32_t)(x >> 32), lo = lo0, hi = hi0;
+  auto step = [&](uint32_t slo, uint32_t shi, int ctrl_sel) {
+    uint32_t tl, th;
+    switch (ctrl_sel) {   // (dpp_ctrl and the masks are instruction immediates)
+      case 0: tl = (uint32_t)WFST_DPP(-1, slo, 0x111, 0xf, 0xf); th = (uint32_t)WFST_DPP(-1, shi, 0x111, 0xf, 0xf); break;
+      case 1: tl = (uint32_t)WFST_DPP(-1, slo, 0x112, 0xf, 0xf); th = (uint32_t)WFST_DPP(-1, shi, 0x112, 0xf, 0xf); break;
+      case 2: tl = (uint32_t)WFST_DPP(-1, slo, 0x113, 0xf, 0xf); th = (uint32_t)WFST_DPP(-1, shi, 0x113, 0xf, 0xf); break;
+      case 3: tl = (uint32_t)WFST_DPP(-1, slo, 0x114, 0xf, 0xe); th = (uint32_t)WFST_DPP(-1, shi, 0x114, 0xf, 0xe); break;
+      case 4: tl = (uint32_t)WFST_DPP(-1, slo, 0x118, 0xf, 0xc); th = (uint32_t)WFST_DPP(-1, shi, 0x118, 0xf, 0xc); break;
+      case 5: tl = (uint32_t)WFST_DPP(-1, slo, 0x142, 0xa, 0xf); th = (uint32_t)WFST_DPP(-1, shi, 0x142, 0xa, 0xf); break;
+      default: tl = (uint32_t)WFST_DPP(-1, slo, 0x143, 0xc, 0xf); th = (uint32_t)WFST_DPP(-1, shi, 0x143, 0xc, 0xf); break;
+    }
+    const u64 t = ((u64)th << 32) | tl, a = ((u64)hi << 32) | lo, m = t < a ? t : a;
+    lo = (uint32_t)m; hi = (uint32_t)(m >> 32);
+  };
+  step(lo0, hi0, 0); step(lo0, hi0, 1); step(lo0, hi0, 2);
+  step(lo, hi, 3); step(lo, hi, 4); step(lo, hi, 5); step(lo, hi, 6);
+  return ((u64)(uint32_t)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+}
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {   // (the cold kernels' sums of wide counters)
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
@@ -272,16 +312,12 @@ __device__ __forceinline__ void plan_channel(const DecoderDev &D, int c, int gro
   const int32_t *cnts = D.bucket_cnt + (size_t)c * P;
   const int cnt = (lane < P) ? min(ld_agent(&cnts[lane]), D.bucket_cap) : 0;
   int ps = cnt;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int v = __shfl_up(ps, off, 64);
-    if (lane >= off) ps += v;
-  }
+  ps = wave_incl_scan(ps);
   int g0, G, n;
   partition_group(P, min(D.joint_max, (D.lds_slots * 3) >> 2), lane < P ? lane : 0, ps, cnt, &g0, &G, &n);
   const bool leader = lane < P && g0 == lane && n > 0;
   const u64 m = __ballot(leader);
-  const int n_rec = __shfl(ps, 63, 64);   // the channel's candidate records
+  const int n_rec = __builtin_amdgcn_readlane(ps, 63);   // the channel's candidate records
   if (D.two_launch && lane == 0) {   // (read by the insert launch: frame_boundary_fused)
     // Can GetCutoff of the frame being built need a look at its tokens (frame_boundary_fused)?  Only with more tokens than
     // max_active / the per-frame limit -- and a frame has at most as many tokens as candidate records --, or with a min_active
@@ -308,8 +344,8 @@ __device__ __forceinline__ void plan_channel(const DecoderDev &D, int c, int gro
     if (mh) bh = atomicAdd(&fc->n_items[par], __popcll(mh));
     if (ml) bl = atomicAdd(&fc->n_small[par], __popcll(ml));
   }
-  bh = __shfl(bh, 0, 64);
-  bl = __shfl(bl, 0, 64);
+  bh = __builtin_amdgcn_readfirstlane(bh);
+  bl = __builtin_amdgcn_readfirstlane(bl);
   int slot = -1;   // the item's place in items[]
   if (leader) {
     const int v = (int)(((uint32_t)c << 16) | ((uint32_t)g0 << 8) | (uint32_t)G);  // c <= 32767 (wfst_decoder_create_ex)
@@ -344,7 +380,7 @@ __device__ __forceinline__ void tile_tail(const DecoderDev &D, int c, ChanCtl *c
   // work counters: summed over the workgroup in LDS, then one set of atomics per tile from a wave that has nothing else to
   // wait for -- every atomic on the channel's control line queues behind the other tiles' (next_cutoff, the countdown)
   {
-    const uint32_t wN = (uint32_t)wave_sum_u64(nN), wE = (uint32_t)wave_sum_u64(nE), wZ = (uint32_t)wave_sum_u64(nZf);
+    const uint32_t wN = wave_sum_u32(nN), wE = wave_sum_u32(nE), wZ = wave_sum_u32(nZf);
     if (lane == 0) {
       if (wN) atomicAdd(&s_stat[0], wN);
       if (wE) atomicAdd(&s_stat[1], wE);
@@ -364,7 +400,7 @@ __device__ __forceinline__ void tile_tail(const DecoderDev &D, int c, ChanCtl *c
   if (wave == 0) {
     int last = 0;
     if (lane == 0) last = atomicSub(&ctl->tiles_left, 1) == 1;
-    last = __shfl(last, 0, 64);
+    last = __builtin_amdgcn_readfirstlane(last);
     if (last) plan_channel(D, c, group, par);
   }
 }
@@ -522,11 +558,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
 #pragma unroll
     for (int j = 0; j < kTokPerThread; ++j) tsum += deg[j];
     int incl = tsum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
+    incl = wave_incl_scan(incl);
     if (lane == 63) s_wsum[wave] = incl;
 #pragma unroll
     for (int j = 0; j < kTokPerThread; ++j) {
@@ -715,11 +747,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       if (tid < 64) {
         const int cnt = tid < P ? s_cnt[tid] : 0;
         int inc = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          int v = __shfl_up(inc, off, 64);
-          if (lane >= off) inc += v;
-        }
+        inc = wave_incl_scan(inc);
         s_lbase[tid] = inc - cnt;
         if (tid == 63) s_lbase[64] = inc;
         int g = 0;
@@ -811,6 +839,13 @@ constexpr int kStSlotsGather = 1536;   // (1392 slots at five workgroups per CU 
 // between the arcs and the pricing).  Rows of up to kStRowFloats columns, a multiple of four, 16-byte aligned (what
 // wfst_decoder_advance checks); 22 KB slots + 12 KB row + 4 KB scan = 38.5 KB: still four workgroups per CU.
 constexpr int kStSlotsRow = 1408;
+constexpr int kStSuper = 4;   // a compacting tile holds up to kStSuper x kStTokens frontier tokens (frame_boundary_fused / prep_frame size it)
+// Tokens per compacting tile of a frame of n tokens of which about n_live lie at or below the cutoff: as many as hold ~7/8 of a
+// round's worth of live ones (a tile whose live tokens exceed a round pays a second round: the whole chain of round trips again)
+__device__ __forceinline__ int super_tile_tokens(int n, int n_live) {
+  const long long t = (long long)(kStTokens - kStTokens / 8) * n / max(n_live, 1);
+  return (int)min((long long)kStSuper * kStTokens, max((long long)kStTokens, t & ~63ll));
+}
 constexpr int kStRowFloats = 3072;
 typedef __attribute__((address_space(3))) void *lds_void_p;
 typedef const __attribute__((address_space(1))) void *gbl_void_p;
@@ -833,6 +868,7 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
   __shared__ int s_base[kStTokens + 1], s_arcbeg[kStTokens], s_nemit[kStTokens];
   __shared__ float s_cost[kStTokens];
   __shared__ int s_wsum[kStThreads / 64], s_cnt[64], s_gbase[64];
+  __shared__ int s_tidx[kStTokens];   // compacting tiles: the token (index within the tile) each thread owns this round
   __shared__ uint32_t s_stat[4], s_bound;
   __shared__ u64 s_best;   // best_exp: the tile's cheapest candidate, orderable cost << 32 | row of its state
   __shared__ int s_ticket;
@@ -858,7 +894,8 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
     const float *llrow = td.llrow;
     int4 *bucket = D.bucket + (size_t)c * P * bcap;
     int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
-    uint32_t nR = 0, nZf = 0;   // (the tile's N and E are read back from the scan arrays at its end: no register across the passes)
+    // (the tile's work counts -- N, E, closure paths priced -- are read back from the scan arrays at the end of a round, the records
+    // written go to the workgroup's LDS accumulator as they are counted: no register of them across the passes)
     bool counted = false;
     if (n == 0) {
       // SEED TILE (DecoderDev::seed_tiles): next_cutoff's seed from the best token's emitting arcs, base-inl.h:282-300 --
@@ -876,14 +913,62 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
       seed = wave_min_f(seed);
       if (lane == 0 && seed < kInf) atomicMin(&ctl->bound, f2o(seed + ab));
     } else {
-      // ---- the tile's tokens: one per thread; its row slots = emitting arcs + two per pseudo arc -------------------
+      // COMPACTING TILE (tok_count > kStTokens, up to kStSuper x as many: the frame boundary cuts such tiles where a binding
+      // max_active -- or the per-frame limit -- leaves most of a frame's tokens above the cutoff): the costs alone are read first,
+      // the tokens at or below the cutoff numbered, and the tile expanded in ROUNDS of kStTokens of them (one round as a rule:
+      // the boundary sizes the tile to the expected share of live tokens) -- a tile of 256 consecutive tokens of which 60 are
+      // expanded cost the same five round trips as a full one.
+      const bool super = n > kStTokens;
+      const int4 *tokc = D.tok + (size_t)c * D.arena_cap + tok0;
+      int n_live = min(n, kStTokens);   // (compacting tiles: known after the first round's count)
+      for (int rnd = 0; rnd * kStTokens < n_live; ++rnd) {
+      // ---- the round's tokens: one per thread; its row slots = emitting arcs + two per pseudo arc -------------------
       {
+        int my_i = tid;   // the token's index within the tile
+        if (super) {   // (uniform)
+          // the tile's live tokens, numbered in token order; this round takes numbers [rnd * kStTokens, + kStTokens).  (Counted afresh
+          // every round -- a second round is rare -- rather than carried in three registers across the passes.)
+          float cst[kStSuper];
+#pragma unroll
+          for (int r = 0; r < kStSuper; ++r) {
+            const int i = r * kStTokens + tid;
+            cst[r] = i < n ? __int_as_float(reinterpret_cast<const int *>(tokc + i)[1]) : kInf;
+          }
+          uint32_t live_mask = 0;
+          int cnt = 0;
+#pragma unroll
+          for (int r = 0; r < kStSuper; ++r) {
+            if (cst[r] <= cutoff) { live_mask |= 1u << r; ++cnt; }   // base-inl.h:315
+          }
+          int incl = cnt;
+          incl = wave_incl_scan(incl);
+          if (lane == 63) s_wsum[wave] = incl;
+          __syncthreads();
+          int wbase = 0, tot = 0;
+#pragma unroll
+          for (int w = 0; w < kStThreads / 64; ++w) {
+            const int v = s_wsum[w];
+            if (w < wave) wbase += v;
+            tot += v;
+          }
+          const int live_base = wbase + incl - cnt - rnd * kStTokens;
+          n_live = __builtin_amdgcn_readfirstlane(tot);
+#pragma unroll
+          for (int r = 0; r < kStSuper; ++r) {
+            if (live_mask & (1u << r)) {
+              const int p = live_base + __popc(live_mask & ((1u << r) - 1u));
+              if (p >= 0 && p < kStTokens) s_tidx[p] = r * kStTokens + tid;
+            }
+          }
+          __syncthreads();   // (s_tidx complete; s_wsum is the scan's again below)
+          my_i = tid < n_live - rnd * kStTokens ? s_tidx[tid] : n;
+        }
         int4 tk = make_int4(0, 0x7F800000, 0, 0);
-        if (tid < n) tk = (D.tok + (size_t)c * D.arena_cap + tok0)[tid];
+        if (my_i < n) tk = tokc[my_i];
         const float cost = __int_as_float(tk.y);
         if constexpr (kTimers) { if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_phase(D, 20, tq); } }   // (descriptor + tokens landed)
         int nem = 0, slots = 0, arcbeg = 0;
-        if (tid < n && cost <= cutoff) {  // base-inl.h:315
+        if (my_i < n && cost <= cutoff) {  // base-inl.h:315
           uint32_t code = kCodeUnknown;
           if (D.degcode) {   // the token's degree code (wfst_device.h): its arcs without a look at the row header
             const int zz = tk.z;
@@ -905,11 +990,7 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
         s_cost[tid] = cost;
         s_arcbeg[tid] = arcbeg;
         int incl = slots;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int v = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += v;
-        }
+        incl = wave_incl_scan(incl);
         if (lane == 63) s_wsum[wave] = incl;
         __syncthreads();
         int wbase = 0, tot = 0;
@@ -1064,9 +1145,8 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
                 for (int u = 0; u < leaf.z; ++u) tt = tt + pw[u];
               }
               rec = make_int4(arc.w, __float_as_int(tt), kPrevUnresolved, (int)((uint32_t)leaf.x | kEpsRec));
-              nZf++;
             } else {
-              rec = make_int4(arc.w, __float_as_int(base_cost), tok0 + l, (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
+              rec = make_int4(arc.w, __float_as_int(base_cost), tok0 + (super ? s_tidx[l] : l), (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
               tmin = fminf(tmin, base_cost);
             }
             if (D.degcode) {   // the degree code of the state arrived at rides in the record (expand_body)
@@ -1131,7 +1211,8 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
           }
           s_gbase[tid] = g;
           s_cnt[tid] = 0;
-          nR += (uint32_t)wave_sum_u64((u64)cnt) * (tid == 0 ? 1u : 0u);
+          const uint32_t wrote = wave_sum_u32((uint32_t)cnt);
+          if (tid == 0 && wrote) atomicAdd(&s_stat[2], wrote);
         }
         lds_barrier();
         if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 15, tq); }
@@ -1147,10 +1228,22 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
         if (tid == 0) { s_bound = 0xFFFFFFFFu; s_best = ~0ull; }
         if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 16, tq); }
       }
+      if ((rnd + 1) * kStTokens < n_live) {
+        // (a further round follows: this round's counts now -- the last round's are read back by the tile's tail below)
+        const bool exp = s_cost[tid] <= cutoff;
+        const int nem = s_nemit[tid], zt = (s_base[tid + 1] - s_base[tid] - nem) >> 1;
+        const uint32_t wN = (uint32_t)__popcll(__ballot(exp)), wE = wave_sum_u32(exp ? (uint32_t)nem : 0u),
+                       wZ = wave_sum_u32(exp ? (uint32_t)zt : 0u);
+        if (lane == 0) { if (wN) atomicAdd(&s_stat[0], wN); if (wE) atomicAdd(&s_stat[1], wE); if (wZ) atomicAdd(&s_stat[3], wZ); }
+        __syncthreads();   // (s_tidx and the scan arrays are the next round's)
+      }
+      }   // (rounds)
     }
     {
-      const bool exp = counted && s_cost[tid] <= cutoff;   // (the tokens beyond the tile's count carry +inf)
-      tile_tail(D, c, ctl, group, par, exp ? 1u : 0u, exp ? (uint32_t)s_nemit[tid] : 0u, nR, nZf, s_stat);
+      // (a token's closure paths priced = its pseudo arcs = (slots - emitting arcs) / 2; tokens beyond the round's count carry +inf)
+      const bool exp = counted && s_cost[tid] <= cutoff;
+      const int nem = exp ? s_nemit[tid] : 0, zt = exp ? (s_base[tid + 1] - s_base[tid] - nem) >> 1 : 0;
+      tile_tail(D, c, ctl, group, par, exp ? 1u : 0u, (uint32_t)nem, 0u, (uint32_t)zt, s_stat);
     }
     // next tile: the first gridDim.x tiles are taken statically, the rest by ticket
     if (total_tiles <= (int)gridDim.x) break;
@@ -1199,20 +1292,20 @@ struct BoundaryLite {   // frame_boundary_fused's few words of LDS
 };
 template <int kT>
 __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c, const int32_t *target, int chan_cnt, int group,
-                                                     int par_next, bool do_prep, BoundaryLite &sh);
+                                                     int par_next, bool do_prep, BoundaryLite &sh, uint32_t *sel_cache, int sel_cache_cap);
 template <int kT, bool kSc1, class Sh, int kKeep>
-__device__ __forceinline__ float kth_smallest_t(const int4 *tok, int n, int k, Sh &sh);
+__device__ __forceinline__ float kth_smallest_t(const int4 *tok, int n, int k, Sh &sh, uint32_t *cache, int cache_cap, uint32_t lo_o, uint32_t hi_o);
 #ifndef WFST_NOINLINE_COLD
 #define WFST_COLD __forceinline__
 #else
 #define WFST_COLD __attribute__((noinline))
 #endif
 #ifndef WFST_COLD_KEEP
-#define WFST_COLD_KEEP 2   // costs a thread keeps in registers across the selection's four passes (the rest are re-read)
+#define WFST_COLD_KEEP 4   // costs a thread keeps in registers across the selection's four passes (the rest are re-read)
 #endif
 template <int kT>
-__device__ WFST_COLD float kth_smallest_cold(const int4 *tok, int n, int k, BoundaryLite *sh) {
-  return kth_smallest_t<kT, true, BoundaryLite, WFST_COLD_KEEP>(tok, n, k, *sh);
+__device__ WFST_COLD float kth_smallest_cold(const int4 *tok, int n, int k, BoundaryLite *sh, uint32_t *cache, int cache_cap, uint32_t lo_o, uint32_t hi_o) {
+  return kth_smallest_t<kT, true, BoundaryLite, WFST_COLD_KEEP>(tok, n, k, *sh, cache, cache_cap, lo_o, hi_o);
 }
 
 template <bool kLat, bool kBig, bool kFused>
@@ -1433,7 +1526,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
         if (!wm) continue;
         int wb = 0;
         if (lane == 0) wb = atomicAdd(&s_wpos, __popcll(wm));
-        wb = __shfl(wb, 0, 64);
+        wb = __builtin_amdgcn_readfirstlane(wb);
         int idx = 0;
         const uint32_t flags = (uint32_t)r[k].w & kFlagMask;
         if (winner) {
@@ -1543,11 +1636,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
 #pragma unroll
         for (int k = 0; k < kInsertUnroll; ++k) cnt += lk_slot[k] >= 0;
         int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int v = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += v;
-        }
+        incl = wave_incl_scan(incl);
         if (lane == 63) ish.lw[wave] = incl;
         __syncthreads();
         int wbase = 0, tot = 0;
@@ -1656,7 +1745,8 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   if (tid == 0) dbg_phase(D, 23, tq);   // (countdown + ticket answered)
   if constexpr (kTwo) {
     if (last) {
-      frame_boundary_fused<kInsertThreads>(D, c, target, chan_cnt, group, par ^ 1, boundary == 1, bsh);
+      // (the hash table's LDS is free now: the selection of a binding limit parks the frame's costs there)
+      frame_boundary_fused<kInsertThreads>(D, c, target, chan_cnt, group, par ^ 1, boundary == 1, bsh, reinterpret_cast<uint32_t *>(smem), SLmax * 3);
       if (tid == 0) dbg_phase(D, 24, tq);   // (the frame boundary)
     }
   }
@@ -1737,7 +1827,7 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
         const u64 m = __ballot(on);
         int wb = 0;
         if ((tid & 63) == 0 && m) wb = atomicAdd(&sh.nemit, __popcll(m));
-        wb = __shfl(wb, 0, 64);
+        wb = __builtin_amdgcn_readfirstlane(wb);
         if (on) emit[wb + lane_rank(m)] = base + i;
       }
     }
@@ -1786,13 +1876,8 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
       for (int e = 0; e < neps; ++e) { int nl; npass += arrival(row + 1 + e, e < kSpec ? A[e < kSpec ? e : 0] : D.g.arcs[row + 1 + e], &nl) < cutoff; }
     }
     // one atomicAdd per wave for all its links
-    int ps = npass;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(ps, o, 64);
-      if ((tid & 63) >= o) ps += v;
-    }
-    const int wtot = __shfl(ps, 63, 64);
+    int ps = wave_incl_scan(npass);
+    const int wtot = __builtin_amdgcn_readlane(ps, 63);
     int lb = 0;
     if ((tid & 63) == 0 && wtot) lb = atomicAdd(&D.ctl[c].link_count, wtot);
     lb = __shfl(lb, 0, 64);
@@ -2173,7 +2258,13 @@ constexpr int kSelKeep = 8;
 // kT threads; kSc1: the costs are read with agent-scope (sc1) loads -- the tokens were written, write-through, by OTHER workgroups
 // of this launch (frame_boundary_fused's slow path; cdna_hip_programming.md Guideline 16: every load of handed-off bytes).
 template <int kT, bool kSc1, class Sh, int kKeep>
-__device__ __forceinline__ float kth_smallest_t(const int4 *tok, int n, int k, Sh &sh) {
+__device__ __forceinline__ float kth_smallest_t(const int4 *tok, int n, int k, Sh &sh, uint32_t *cache, int cache_cap, uint32_t lo_o, uint32_t hi_o) {
+  // cache / cache_cap: LDS that is free during the selection (the insert workgroup's hash table): the orderable costs beyond the
+  // ones kept in registers are parked there on the first pass instead of being read from memory again on the later ones.
+  // lo_o / hi_o: orderable bounds of EVERY cost of the frame (the best token's cost; the frame's final next_cutoff, which every
+  // token lies below) or 0 / ~0.  The bits the two share are the selection's prefix from the start: a frame's costs sit within
+  // one beam of each other, so their top 12-16 bits agree -- a first pass over those bits put every token into ONE histogram bin,
+  // n serialised LDS atomics on one address (33 us for the frame boundary of a 20 k-token frame, measured), and decided nothing.
   int tid = threadIdx.x;
   if (kSc1) asm volatile("" : "+v"(tid));   // (inside the insert kernel: see frame_boundary_fused)
   const int lane = tid & 63;
@@ -2182,36 +2273,53 @@ __device__ __forceinline__ float kth_smallest_t(const int4 *tok, int n, int k, S
     const int bits = kSc1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
     return f2o(__int_as_float(bits));
   };
+  constexpr int kSelBatch = kSc1 ? 4 : 8;   // loads of costs in flight per thread beyond the kept ones (the insert kernel has 80 registers)
   uint32_t keep[kKeep];
 #pragma unroll
   for (int j = 0; j < kKeep; ++j) {
     const int i = j * kT + tid;
     keep[j] = i < n ? cost_of(i) : 0xFFFFFFFFu;  // orderable +NaN: sorts last
   }
-  if (tid == 0) { sh.sel_prefix = 0; sh.sel_k = (uint32_t)k; }
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+  const int n_cached = min(n, kKeep * kT + cache_cap);   // costs [kKeep * kT, n_cached) live in `cache` after the first pass
+  if (hi_o <= lo_o) { lo_o = 0u; hi_o = 0xFFFFFFFFu; }
+  const uint32_t diff = lo_o ^ hi_o;
+  const int R = 32 - __clz((int)diff);   // low bits in which the costs can differ (diff != 0 here)
+  const int n_pass = (R + 7) >> 3;
+  if (tid == 0) { sh.sel_prefix = R >= 32 ? 0u : ((lo_o >> R) << R); sh.sel_k = (uint32_t)k; }
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int top = R - 8 * pass;            // this pass decides bits [shift, top)
+    const int shift = max(0, top - 8);
+    const uint32_t dmask = (1u << (top - shift)) - 1u;
+    const uint32_t hi_mask = top >= 32 ? 0u : (0xFFFFFFFFu << top);
     for (int b = tid; b < 256; b += kT) sh.hist[b] = 0;
     __syncthreads();
     const uint32_t prefix = sh.sel_prefix;
 #pragma unroll
     for (int j = 0; j < kKeep; ++j) {
-      if (j * kT + tid < n && (keep[j] & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(keep[j] >> shift) & 255u], 1u);
+      if (j * kT + tid < n && (keep[j] & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(keep[j] >> shift) & dmask], 1u);
     }
-    for (int i = kKeep * kT + tid; i < n; i += kT) {
-      const uint32_t o = cost_of(i);
-      if ((o & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(o >> shift) & 255u], 1u);
+    // (the costs beyond the registers, kSelBatch loads in flight per thread: one after the other -- a load, its histogram atomic,
+    // the next load -- a 20 k-token frame was forty dependent round trips per pass)
+    for (int i0 = kKeep * kT + tid; i0 < n; i0 += kSelBatch * kT) {
+      uint32_t o[kSelBatch];
+#pragma unroll
+      for (int u = 0; u < kSelBatch; ++u) {
+        const int i = i0 + u * kT;
+        o[u] = 0xFFFFFFFFu;
+        if (i < n) o[u] = (i < n_cached && pass != 0) ? cache[i - kKeep * kT] : cost_of(i);
+      }
+#pragma unroll
+      for (int u = 0; u < kSelBatch; ++u) {
+        const int i = i0 + u * kT;
+        if (i >= n) continue;
+        if (pass == 0 && i < n_cached) cache[i - kKeep * kT] = o[u];   // (each thread re-reads its own entries: no barrier needed)
+        if ((o[u] & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.hist[(o[u] >> shift) & dmask], 1u);
+      }
     }
     __syncthreads();
     if (tid < 64) {  // one wave: lane l owns bins 4l..4l+3
       const uint32_t c0 = sh.hist[4 * lane], c1 = sh.hist[4 * lane + 1], c2 = sh.hist[4 * lane + 2], c3 = sh.hist[4 * lane + 3];
-      uint32_t incl = c0 + c1 + c2 + c3;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-      }
+      uint32_t incl = (uint32_t)wave_incl_scan((int)(c0 + c1 + c2 + c3));
       const uint32_t kk = sh.sel_k;
       const u64 m = __ballot(incl > kk);  // first lane whose cumulative count passes k
       const int owner = m ? __ffsll((long long)m) - 1 : 63;
@@ -2227,8 +2335,8 @@ __device__ __forceinline__ float kth_smallest_t(const int4 *tok, int n, int k, S
   }
   return o2f(sh.sel_prefix);
 }
-__device__ __forceinline__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh) {
-  return kth_smallest_t<kBT, false, BoundaryShared, kSelKeep>(tok, n, k, sh);
+__device__ __forceinline__ float kth_smallest(const int4 *tok, int n, int k, BoundaryShared &sh, uint32_t lo_o = 0u, uint32_t hi_o = 0xFFFFFFFFu) {
+  return kth_smallest_t<kBT, false, BoundaryShared, kSelKeep>(tok, n, k, sh, nullptr, 0, lo_o, hi_o);
 }
 // The selection of frame_boundary_fused's slow path, OUT OF LINE: a handful of frames take it, and inlined its registers (the costs
 // kept across the four passes) and its code sit in the insert kernel's hot loops' allocation (insert +8 % per launch, measured).
@@ -2256,26 +2364,34 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
 
   // GetCutoff, base-inl.h:138-234
   float cutoff, ab;
+  int super_k = 1;
   if (D.max_active == 2147483647 && D.min_active == 0 && !D.soft_limit) {
     ab = D.beam;
     cutoff = best_w + D.beam;
   } else {
     const float beam_cutoff = best_w + D.beam;
     float min_active_cutoff = kInf, max_active_cutoff = kInf;
+    // the selection's range (kth_smallest_t): fused decoders' frames lie between the best token's cost and the frame's final
+    // next_cutoff (every token was admitted below it; the initial frame, built by InitDecoding, has none: bound 0)
+    const uint32_t sel_lo = (D.fused && !kBig) ? f2o(best_w) : 0u, sel_hi = (D.fused && !kBig) ? ctl->bound : 0xFFFFFFFFu;
     // (soft_limit decoders: the per-frame token limit acts as a max_active -- the frame holds every token the arena took, the
     // expansion goes on from the limit-th cheapest: what the reference does at that max_active, base-inl.h:188-203)
     const int max_eff = D.soft_limit ? min(D.max_active, D.max_tok) : D.max_active;
     if (n > max_eff) {
-      max_active_cutoff = kth_smallest(tok, n, max_eff, sh);
+      max_active_cutoff = kth_smallest(tok, n, max_eff, sh, sel_lo, sel_hi);
       if (tid == 0 && D.soft_limit && D.max_tok < D.max_active) D.degraded[c] += 1;
+      if (max_active_cutoff < beam_cutoff) super_k = super_tile_tokens(n, max_eff);   // (compacting tiles: see frame_boundary_fused)
     }
     if (max_active_cutoff < beam_cutoff) {
       ab = max_active_cutoff - best_w + D.beam_delta;
       cutoff = max_active_cutoff;
     } else {
       if (n > D.min_active) {
-        if (D.min_active == 0) min_active_cutoff = best_w;
-        else min_active_cutoff = kth_smallest(tok, n, D.min_active, sh);
+        // (fused decoders whose frame was built under the plain beam: every token lies below best + beam -- frame_boundary_fused --,
+        // the min_active-th cheapest too: any value at or below it decides the same, without the selection)
+        const bool below_beam = D.fused && !kBig && ctl->n_decoded > 0 && ctl->adaptive_beam == D.beam;
+        if (D.min_active == 0 || below_beam) min_active_cutoff = best_w;
+        else min_active_cutoff = kth_smallest(tok, n, D.min_active, sh, sel_lo, sel_hi);
       }
       if (min_active_cutoff > beam_cutoff) {
         ab = min_active_cutoff - best_w + D.beam_delta;
@@ -2334,6 +2450,7 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
     if ((int64_t)n * (int)gridDim.x <= 700ll * 256) tile_tokens = 256;
     if ((int64_t)n * (int)gridDim.x <= 700ll * 128) tile_tokens = 128;
     if (D.staged) tile_tokens = min(tile_tokens, kStTokens);
+    if (D.staged && !kBig && super_k > 1) tile_tokens = super_k;
     sh.tile_tokens = tile_tokens;
     const int ntiles = (n + tile_tokens - 1) / tile_tokens;
     sh.active = 0;
@@ -2385,7 +2502,7 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
 // =========================================================================================
 template <int kT>
 __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c, const int32_t *target, int chan_cnt, int group,
-                                                     int par_next, bool do_prep, BoundaryLite &sh) {
+                                                     int par_next, bool do_prep, BoundaryLite &sh, uint32_t *sel_cache, int sel_cache_cap) {
   // (an opaque copy of the thread index: what the boundary derives from it -- addresses of the tile list, of the counters -- is
   // then computed HERE; hoisted to the kernel's entry, as loop invariants of the item loop, those values lived across the insert
   // passes and were spilled there: 0.2 ms per step per spilled register, the spill stores sit in front of an item's first loads)
@@ -2472,7 +2589,8 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
 #pragma nounroll
     for (int stage = need_max ? 0 : 1; stage < 2; ++stage) {
       if (stage == 1 && !need_min) break;
-      const float v = kth_smallest_cold<kT>(tok, n, stage == 0 ? max_eff : D.min_active, &sh);
+      const float v = kth_smallest_cold<kT>(tok, n, stage == 0 ? max_eff : D.min_active, &sh, sel_cache, sel_cache_cap,
+                                            f2o(best_w), sh.h_bound);   // (every token of the frame costs at least the best one's and less than its final next_cutoff)
       if (stage == 0) {
         max_active_cutoff = v;
         if (max_active_cutoff < beam_cutoff) break;
@@ -2521,6 +2639,9 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
     if ((int64_t)n * chan_cnt <= 700ll * 256) tile_tokens = 256;
     if ((int64_t)n * chan_cnt <= 700ll * 128) tile_tokens = 128;
     if (D.staged) tile_tokens = min(tile_tokens, kStTokens);
+    // a binding max_active (or per-frame limit) leaves n - max_eff tokens above the cutoff: compacting tiles (expand_kernel_staged)
+    // of as many tokens as hold one tile's worth of live ones
+    if (D.staged && need_max && cutoff < beam_cutoff) tile_tokens = super_tile_tokens(n, max_eff);
     const int ntiles = (n + tile_tokens - 1) / tile_tokens;
     const int nseed = (D.seed_tiles && ntiles > 0) ? 1 : 0;   // the seed tile, listed first
     sh.tile_tokens = tile_tokens;
@@ -2605,12 +2726,7 @@ struct PruneShared : ScanShared {
 // exclusive prefix sum of `v` over the workgroup's kBT threads; *total = sum
 __device__ __forceinline__ int block_exscan(int v, ScanShared &ps, int *total) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int incl = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int x = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += x;
-  }
+  int incl = wave_incl_scan(v);
   __syncthreads();  // ps.wsum free again
   if (lane == 63) ps.wsum[wave] = incl;
   __syncthreads();
@@ -4019,7 +4135,7 @@ __global__ __launch_bounds__(kBT) void lattice_emit_kernel(DecoderDev D, const i
         if (!m) continue;
         int wb = 0;
         if (lane == 0) wb = atomicAdd(&pp[8], __popcll(m));
-        wb = __shfl(wb, 0, 64);
+        wb = __builtin_amdgcn_readfirstlane(wb);
         if (!on) continue;
         const int i = i0 + u * kBT + tid;
         int lo2 = 0, hi2 = 2 * (nd + 1);   // segment q: lseg[q] <= i < lseg[q + 1]; q = 2 f: emitting links into frame f, 2 f + 1: epsilon links inside f

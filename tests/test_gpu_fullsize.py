@@ -408,4 +408,10 @@ def test_service_operating_point_divergence_from_the_reference(big, synth, refde
         # stays within 1.5x the reference's own order dependence
         assert dv["wer"] <= 1.5 * self_dv["wer"] + 0.005, (name, dv, self_dv)
         assert dv["bit_identical"] >= 0.8 * self_dv["bit_identical"], (name, dv, self_dv)
+        # the SIGN of the cost differences (VERDICT r3 next #6a): without transcripts, path cost is the quality measure -- the GPU's
+        # paths must not be systematically costlier than the reference's (mean within twice the reference's own hash_ratio spread,
+        # and no more "reference cheaper" utterances than twice the self figure + 4)
+        sg, ss = dv["signed_rel_cost_gap"], self_dv["signed_rel_cost_gap"]
+        assert sg["mean"] <= 2.0 * abs(ss["mean"]) + 1e-4, (name, sg, ss)
+        assert sg["second_cheaper"] <= 2 * ss["second_cheaper"] + 4, (name, sg, ss)
     assert out["headline"][0]["wer"] <= 0.05, out["headline"]
