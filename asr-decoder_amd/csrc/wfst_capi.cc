@@ -226,7 +226,7 @@ struct wfst_decoder {
   // optional kernel timing (wfst_decoder_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
-  std::vector<std::pair<int, int>> ev_pairs[4];  // [kernel class] -> (start, stop) event indices; [3] = replayed expansions (timing experiments)
+  std::vector<std::pair<int, int>> ev_pairs[4];  // [kernel class] -> (start, stop) event indices
   size_t ev_used = 0;
   int ev_get() {
     if (ev_used == ev_pool.size()) {
@@ -839,6 +839,16 @@ void wfst_lm_free(wfst_lm *lm) {
 
 /* -------------------------------------------------------------- decoder */
 
+// wfst_options.debug carries, besides the kernel phase timers (32 / 64 / 128) and the lattice decoders' comparison mode (0x1000),
+// A/B switches of timing experiments (0x2000 no two-launch frames, 0x4000 no seed tiles, 0x10000 gathered log-likelihoods, 0x20000
+// the insert launch looks for the best token): honoured only by a library built with -DWFST_AB_SWITCHES (tools/ab_bench.sh),
+// ignored by the product build.
+#ifdef WFST_AB_SWITCHES
+static constexpr bool kAbSwitches = true;
+#else
+static constexpr bool kAbSwitches = false;
+#endif
+
 static int check_config(const wfst_config *c) {  // LatticeFasterDecoderConfig::Check, conf.h:62-67
   if (!(c->beam > 0.0f && c->max_active > 1 && c->lattice_beam > 0.0f && c->prune_interval > 0 &&
         c->beam_delta > 0.0f && c->hash_ratio >= 1.0f && c->prune_scale > 0.0f && c->prune_scale < 1.0f))
@@ -1059,20 +1069,20 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   D.best_row = (D.fused && !D.lattice && !big) ? 1 : 0;
   D.two_launch = 0;
   D.gc_stride = 1;
-  // expand_kernel_staged (the tile's arcs staged in LDS by gather DMA): fused decoders whose max_active cannot bind.  Where it
-  // binds, most of a frame's tokens lie above the cutoff and are not expanded: the staged kernel's fixed cost per 256-token tile
-  // then buys a fraction of a tile's work (measured at the service's 7000: 42.6 vs 31.4 ms of expansion per step), and
-  // expand_kernel_fused's 512-token tiles stay.  (0x800: the replay experiments are expand_body's; 0x8000: A/B)
-  // (round 4: also where max_active binds -- the frame boundary then cuts COMPACTING tiles, wfst_kernels.hip kStSuper: the dead
-  // tokens of a frame no longer cost a tile's round trips; 0x40000: A/B, the round-2 expansion for those decoders)
-  D.staged = (D.fused && !big && (cfg->max_active >= L.max_tokens_per_frame || !(O.debug & 0x40000)) && !(O.debug & 0x8800)) ? 1 : 0;
+  // expand_kernel_staged (the tile's arcs staged in LDS by gather DMA): every decoder on the fused rows.  Where max_active (or the
+  // per-frame limit) binds, most of a frame's tokens lie above the cutoff: the frame boundary then cuts COMPACTING tiles
+  // (wfst_kernels.hip kStSuper), whose dead tokens do not cost a tile's round trips -- round 3 kept the round-2 expansion
+  // (two candidates per thread in registers, rounds of 512) for those decoders; it is gone.  (Timing-experiment bits of
+  // wfst_options.debug are honoured by WFST_AB_SWITCHES builds only.)
+  const int ab_bits = kAbSwitches ? O.debug : 0;
+  D.staged = (D.fused && !big) ? 1 : 0;
   // the expansion finds the frame's best token itself (its cheapest candidate): the staged kernel of best_row decoders (0x20000: A/B)
-  D.best_exp = (D.staged && D.best_row && !(O.debug & 0x20000)) ? 1 : 0;
-  D.seed_tiles = (D.best_row && !(O.debug & 0x4800)) ? 1 : 0;   // (0x800: the replay experiments start from the frame's seed; 0x4000: A/B)
+  D.best_exp = (D.staged && D.best_row && !(ab_bits & 0x20000)) ? 1 : 0;
+  D.seed_tiles = (D.best_row && !(ab_bits & 0x4000)) ? 1 : 0;
   // fused best-path decoders: max_tokens_per_frame is a max_active, not a capacity (the frame keeps every token the arena takes and
   // GetCutoff tightens to the limit-th cheapest; wfst_decoder_get_degraded_frames counts the frames on which it did)
   D.soft_limit = D.best_row;
-  if (D.best_row && !(O.debug & 0x2000)) {
+  if (D.best_row && !(ab_bits & 0x2000)) {
     int64_t reserve = std::max<int64_t>(2ll * L.max_tokens_per_frame, L.arena_tokens / 8);
     if (reserve >= L.arena_tokens / 2) reserve = L.arena_tokens / 2;
     const int64_t stride = reserve / std::max<int64_t>(1, L.max_tokens_per_frame) - 1;
@@ -1282,7 +1292,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   d->D.stride = stride;
   {
     // expand_kernel_staged_row (wfst_kernels.hip): the frame's log-likelihood row of a tile's channel staged in LDS by 16-byte DMAs
-    bool ok = d->D.staged && !(d->D.dbg & 0x10000) && (stride & 3) == 0 && stride <= 3072;
+    bool ok = d->D.staged && !(kAbSwitches && (d->D.dbg & 0x10000)) && (stride & 3) == 0 && stride <= 3072;
     for (int c = 0; ok && c < d->n_channels; ++c)
       if (d->h_ll_base[c] && ((uintptr_t)d->h_ll_base[c] & 15u)) ok = false;
     d->D.ll_row = ok ? 1 : 0;
@@ -1322,12 +1332,10 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     for (int s = 0; s < gsteps[g]; ++s) {
       // two launches per frame where the decoder allows (wfst_device.h two_launch): the insert launch closes the frame and
       // prepares the next; every gc_stride-th frame is a classic one (its closure launch checks the token arena)
-      const bool classic = !d->D.two_launch || (d->D.dbg & 0x800) || (s % d->D.gc_stride) == d->D.gc_stride - 1;
+      const bool classic = !d->D.two_launch || (s % d->D.gc_stride) == d->D.gc_stride - 1;
       const bool more = s + 1 < gsteps[g];
       timed(0, st, [&] { launch_expand(d->D, g, par, d->expand_wgs, st); });
       timed(1, st, [&] { launch_insert(d->D, off, cnt, d->target.p, classic ? 0 : more ? 1 : 2, g, par, d->insert_wgs, st); });
-      if (d->D.dbg & 0x800)  // timing experiment: the expansion of this frame once more, stages removed (wfst_kernels.hip expand_body kAbl)
-        timed(3, st, [&] { launch_expand_replay(d->D, g, par, (d->D.dbg >> 8) & 7, d->expand_wgs, st); });
       // lattice mode: PruneActiveTokens (base-inl.h:660-661) on the steps at which a channel of the group reaches a multiple of
       // prune_interval and goes on decoding -- a launch of its own, which also prepares the next frame
       const bool prune = more && prune_step(g, s);
@@ -1733,23 +1741,15 @@ int wfst_decoder_get_profile(wfst_decoder *d, double ms[3], int64_t launches[3])
   return WFST_OK;
 }
 
-int wfst_decoder_get_profile_replay(wfst_decoder *d, double *ms, int64_t *launches) {
-  if (!d || !ms || !launches) return fail(WFST_E_ARG, "bad argument");
-  HIP_TRY(hipSetDevice(d->device));
-  for (hipStream_t st : d->gstreams) if (st) HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  double tot = 0;
-  for (auto &pr : d->ev_pairs[3]) {
-    float t = 0;
-    HIP_TRY(hipEventElapsedTime(&t, d->ev_pool[pr.first], d->ev_pool[pr.second]));
-    tot += t;
-  }
-  *ms = tot;
-  *launches = (int64_t)d->ev_pairs[3].size();
+int wfst_decoder_channel_groups(wfst_decoder *d) { return d ? d->n_groups : fail(WFST_E_ARG, "NULL decoder"); }
+
+int wfst_decoder_get_path_flags(wfst_decoder *d, int32_t flags[8]) {
+  if (!d || !flags) return fail(WFST_E_ARG, "bad argument");
+  const DecoderDev &D = d->D;
+  flags[0] = D.staged; flags[1] = D.two_launch; flags[2] = D.gc_stride; flags[3] = D.degcode;
+  flags[4] = D.ll_row; flags[5] = D.best_exp; flags[6] = D.soft_limit; flags[7] = d->n_groups;
   return WFST_OK;
 }
-
-int wfst_decoder_channel_groups(wfst_decoder *d) { return d ? d->n_groups : fail(WFST_E_ARG, "NULL decoder"); }
 
 int wfst_decoder_get_profile_busy(wfst_decoder *d, double busy_ms[3]) {
   if (!d || !busy_ms) return fail(WFST_E_ARG, "bad argument");

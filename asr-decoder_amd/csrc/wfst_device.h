@@ -450,7 +450,6 @@ void launch_compose2(const DetDev &X, const CmpDev &Y, const LmDev &lm1, const L
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hipStream_t s);
-void launch_expand_replay(const DecoderDev &D, int group, int par, int variant, int n_workgroups, hipStream_t s);
 // boundary: 0 = the closure kernel follows (classic frame); 1 = the insert launch closes the frame and prepares the next
 // (two-launch frame); 2 = closes the frame only (last frame of an advance call)
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int boundary, int group, int par,

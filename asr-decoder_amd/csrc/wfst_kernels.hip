@@ -803,13 +803,9 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
 // every tile of a 128-channel frame at once): at 80 it spilled into its candidate loop, and 5 waves without spills beat 6
 // with them by 3 % of the step (22.7 vs 23.5 ms).
 __global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_plain(DecoderDev D, int group, int par) { expand_body<false, false>(D, group, par); }
-__global__ __launch_bounds__(kExpandThreads, 5) void expand_kernel_fused(DecoderDev D, int group, int par) { expand_body<false, true>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm(DecoderDev D, int group, int par) { expand_body<true, false>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel_plain_timed(DecoderDev D, int group, int par) { expand_body<false, false, 0, true>(D, group, par); }
-__global__ __launch_bounds__(kExpandThreads) void expand_kernel_fused_timed(DecoderDev D, int group, int par) { expand_body<false, true, 0, true>(D, group, par); }
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm_timed(DecoderDev D, int group, int par) { expand_body<true, false, 0, true>(D, group, par); }
-template <int kAbl>
-__global__ __launch_bounds__(kExpandThreads, 6) void expand_replay_fused(DecoderDev D, int group, int par) { expand_body<false, true, kAbl>(D, group, par); }
 
 // =========================================================================================
 // expand_kernel_staged: the expansion of decoders on the fused rows (best-path and lattice, not biglm) with a tile's
@@ -4264,29 +4260,13 @@ void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hi
     if (D.fused && D.staged && D.ll_row) hipLaunchKernelGGL(expand_kernel_staged_row_timed, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
     else if (D.fused && D.staged) hipLaunchKernelGGL(expand_kernel_staged_timed, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
     else if (D.big) hipLaunchKernelGGL(expand_kernel_biglm_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
-    else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
     else hipLaunchKernelGGL(expand_kernel_plain_timed, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
     return;
   }
   if (D.big) hipLaunchKernelGGL(expand_kernel_biglm, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
   else if (D.fused && D.staged && D.ll_row) hipLaunchKernelGGL(expand_kernel_staged_row, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
   else if (D.fused && D.staged) hipLaunchKernelGGL(expand_kernel_staged, dim3(n_workgroups), dim3(kStThreads), 0, s, D, group, par);
-  else if (D.fused) hipLaunchKernelGGL(expand_kernel_fused, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
   else hipLaunchKernelGGL(expand_kernel_plain, dim3(n_workgroups), dim3(kExpandThreads), 0, s, D, group, par);
-}
-// timing experiments: the frame's expansion once more, without side effects, with stages removed (expand_body kAbl)
-void launch_expand_replay(const DecoderDev &D, int group, int par, int variant, int n_workgroups, hipStream_t s) {
-  if (!D.fused) return;
-  const dim3 g(n_workgroups), b(kExpandThreads);
-  switch (variant) {
-    case 1: hipLaunchKernelGGL((expand_replay_fused<8 | 1>), g, b, 0, s, D, group, par); break;
-    case 2: hipLaunchKernelGGL((expand_replay_fused<8 | 2>), g, b, 0, s, D, group, par); break;
-    case 3: hipLaunchKernelGGL((expand_replay_fused<8 | 3>), g, b, 0, s, D, group, par); break;
-    case 4: hipLaunchKernelGGL((expand_replay_fused<8 | 4>), g, b, 0, s, D, group, par); break;
-    case 6: hipLaunchKernelGGL((expand_replay_fused<8 | 6>), g, b, 0, s, D, group, par); break;
-    case 7: hipLaunchKernelGGL((expand_replay_fused<8 | 7>), g, b, 0, s, D, group, par); break;
-    default: hipLaunchKernelGGL((expand_replay_fused<8>), g, b, 0, s, D, group, par); break;
-  }
 }
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int boundary, int group, int par,
                    int n_workgroups, hipStream_t s) {

@@ -28,11 +28,11 @@ SYMBOLS = [
     "wfst_decoder_advance_host", "wfst_decoder_finalize", "wfst_decoder_sync",
     "wfst_decoder_num_frames_decoded", "wfst_decoder_get_best_path", "wfst_lattice_to_vector", "wfst_lattice_to_vector_batch",
     "wfst_decoder_get_stats", "wfst_decoder_get_frontier", "wfst_decoder_set_profiling",
-    "wfst_decoder_get_profile", "wfst_decoder_get_profile_busy", "wfst_decoder_get_profile_replay", "wfst_decoder_channel_groups", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
+    "wfst_decoder_get_profile", "wfst_decoder_get_profile_busy", "wfst_decoder_channel_groups", "wfst_decoder_get_raw_lattice", "wfst_decoder_get_nbest",
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
     "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice", "wfst_decoder_get_nbest_paths",
-    "wfst_decoder_get_degraded_frames",
+    "wfst_decoder_get_degraded_frames", "wfst_decoder_get_path_flags",
 ]
 
 
@@ -438,10 +438,11 @@ class BatchDecoder:
                              lm_score=float(lm[i, k])) for k in range(npaths[i])])
         return out
 
-    def profile_replay(self):
-        ms, n = C.c_double(0), C.c_int64(0)
-        _check(lib().wfst_decoder_get_profile_replay(self.h, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+    def path_flags(self):
+        """Which kernel paths the decoder runs (wfst_decoder_get_path_flags)."""
+        f = (C.c_int32 * 8)()
+        _check(lib().wfst_decoder_get_path_flags(self.h, f))
+        return dict(zip(("staged", "two_launch", "gc_stride", "degcode", "ll_row", "best_exp", "soft_limit", "channel_groups"), [int(x) for x in f]))
 
     @property
     def n_groups(self):

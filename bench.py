@@ -519,10 +519,6 @@ def main():
     dec.set_profiling(True)
     step()
     prof = dec.profile()
-    if a.debug & 0x800:
-        rms, rn = dec.profile_replay()
-        log("[rank %d] expansion replayed with stages removed (variant %d): %.2f us per launch (%d launches); the real expansion: %.2f us" % (
-            rank, (a.debug >> 8) & 7, 1000.0 * rms / max(rn, 1), rn, 1000.0 * prof["expand_ms"] / max(prof["expand_launches"], 1)))
     dec.set_profiling(False)
 
     regime = ("beam-only pruning (max_active never binds, min_active 0): bit-exact best-path parity with the reference CPU decoder"
@@ -554,7 +550,15 @@ def main():
             "channel_groups": int(dec.n_groups),
         },
     }
+    pf = dec.path_flags()
+    out["config"]["decoder_paths"] = pf
     if world > 1:
+        # N > 1: every rank runs the configuration rank 0 reports (the kernel paths a decoder takes follow from its limits)
+        tv = torch.tensor([pf[k] for k in sorted(pf)], dtype=torch.int64, device="cpu" if share else dev)
+        tmin, tmax = tv.clone(), tv.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        out["config"]["decoder_paths_same_on_every_rank"] = bool(torch.equal(tmin, tmax))
         # N > 1: a live parity sample on EVERY rank -- its first two utterances against the CPU restatement (bit for bit: words,
         # transition-ids, tot_score) --, summed over the ranks
         import pyoracle

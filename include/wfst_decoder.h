@@ -114,9 +114,12 @@ typedef struct wfst_options {
   int32_t insert_workgroups;   /* grid of the insert kernel                                     (768)  */
   int32_t upload_slice_frames; /* wfst_decoder_advance_host: frames per upload slice, 0 = copy
                                   everything before decoding                                    (48)   */
-  int32_t debug;               /* kernel phase timers / ablations: timing experiments only      (0)    */
+  int32_t debug;               /* kernel phase timers (32 closure / 64 insert / 128 expansion, printed when the
+                                  decoder is freed)                                              (0)    */
                                /* (0x1000: lattice decoders run the iterated epsilon-closure pass instead of
-                                  the fused rows + flat epsilon-link pass; same results, for comparison) */
+                                  the fused rows + flat epsilon-link pass; same results, for comparison.
+                                  Further bits are A/B switches of timing experiments, honoured only by a
+                                  library built with -DWFST_AB_SWITCHES) */
 } wfst_options;
 
 /* Graph upload choices (NULL / wfst_graph_options_default() = defaults). */
@@ -388,10 +391,11 @@ int wfst_decoder_get_profile(wfst_decoder *d, double ms[3], int64_t launches[3])
  * intervals): with several channel groups the launches of different groups overlap, and the sum of their
  * durations (wfst_decoder_get_profile) counts the shared time once per group. */
 int wfst_decoder_get_profile_busy(wfst_decoder *d, double busy_ms[3]);
-/* Timing experiments (wfst_options.debug bit 0x800, variant in bits 8..10): every frame's expansion is launched a second
- * time without side effects and with stages removed (1 no sort / write, 2 no arc loads, 4 no row-header loads, sums
- * thereof; 0 = everything); the time of those launches since profiling was enabled. */
-int wfst_decoder_get_profile_replay(wfst_decoder *d, double *ms, int64_t *launches);
+/* Which of the library's kernel paths this decoder runs (for benchmarks and tests: the N > 1 ranks of a sharded run must report
+ * what the N = 1 run does): {staged expansion, two launches per frame, frames between two token-collection checks (gc_stride),
+ * degree codes in the tokens, log-likelihood row staged in LDS (known after the first advance), best token found by the
+ * expansion, the per-frame limit degrades (soft limit), channel groups}. */
+int wfst_decoder_get_path_flags(wfst_decoder *d, int32_t flags[8]);
 /* The number of channel groups the decoder runs with (wfst_options.channel_groups, resolved). */
 int wfst_decoder_channel_groups(wfst_decoder *d);
 

@@ -239,7 +239,8 @@ def test_config4_biglm_batch128_full_size(big, synth, oracle, tmp_path):
     # (the reference's biglm final pruning -- final_best_cost ranges over non-final tokens too, biglm.h:186-188 -- leaves some
     # utterances without a path at lattice_beam 7: reproduced, and checked against the oracle on the sample below)
     n_ok = sum(int(r.ok) for r in res)
-    assert n_ok >= 32 and all(len(r.tids) == big["T"] for r in res if r.ok), n_ok
+    # (measured: 45 of these 128 utterances keep a path -- bench.py's biglm leg reports the same count as utterances_with_path)
+    assert abs(n_ok - 45) <= 2 and all(len(r.tids) == big["T"] for r in res if r.ok), n_ok
     print("biglm full size: %d of %d utterances keep a path at lattice_beam %g" % (n_ok, big["B"], cd["lattice_beam"]))
     # the oracle in FIXED DiffArpaLm mode (DESIGN.md section 4 "biglm"), order-free, on 16 utterances
     h = oracle.load_graph(big["path"])
@@ -269,6 +270,63 @@ def test_config4_biglm_batch128_full_size(big, synth, oracle, tmp_path):
     for u, b in zip(pick, sub):
         a = res[u]
         G.assert_same_path(a, b.words, b.tids, b.path_ilabel, b.path_olabel, b.path_graph, b.path_ac, [b.tot_score, b.lm_score])
+    L1.free()
+    L2.free()
+
+
+def test_config4_biglm_lattice_mode_full_size(big, synth, oracle, tmp_path):
+    """The biglm decoder as the LATTICE decoder the reference's service runs (kaldi-online-nnet3-my-decoder.h:275-283), at full size
+    (VERDICT r3 next #6b): 16 utterances x 300 frames on the 10 M-arc graph with the bench's LM pair, lattice mode with the
+    running back-pruning -- the raw lattice of every one state by state and arc by arc against the fixed-mode oracle (order-free),
+    the best path bit for bit."""
+    import importlib
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    from test_gpu_biglm import _same
+    from test_gpu_lattice import as_raw, nodes
+
+    lmsynth = importlib.import_module("asr-decoder_amd.lmsynth")
+    G = big["G"]
+    V = int(big["g"].arcs["olabel"].max())
+    paths = []
+    for tag, spec, seed in (("old", (20000, 5, 0, 0), 41), ("new", (40000, 6, 100000, 3), 42)):   # bench.py --lm-old / --lm-new
+        nb, s2, nt, s3 = spec
+        lp = str(tmp_path / ("lm_%s.bin" % tag))
+        lmsynth.make_lm(V, 3 if nt > 0 else 2, nb, s2, nt, s3, seed=seed).to_fsa().write(lp)
+        paths.append(lp)
+    L1, L2 = G.wfstdec.Lm.load(paths[0], -1.0), G.wfstdec.Lm.load(paths[1], 1.0)
+    cd = dict(CD, lattice_beam=9.0)
+    sample = list(range(3, 128, 8))
+    mats = [big["mats"][u] for u in sample]
+    dec = G.wfstdec.BatchDecoder(big["graph"], G.gpu_config(cd), len(mats), old_lm=L1, new_lm=L2, lm_pairs=1 << 20, max_frames=304,
+                                 max_tokens_per_frame=131072, arena_tokens=300 * 13900, lattice_links=8 << 20)
+    res = G.decode_batch(big["graph"], cd, mats, dec=dec)
+    lats = [dec.raw_lattice(i) for i in range(len(mats))]
+    dec.free()
+    h = oracle.load_graph(big["path"])
+    o1, o2 = pyoracle.Lm(oracle, paths[0], -1.0), pyoracle.Lm(oracle, paths[1], 1.0)
+    try:
+        oracle.set_order_free(True)
+        with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as ex:
+            want = list(ex.map(lambda ll: (pyoracle.biglm_decode(oracle, h, pyoracle.Config(**cd), o1, o2, ll, big["m"], fixed=True),
+                                           pyoracle.biglm_raw_lattice(oracle, h, pyoracle.Config(**cd), o1, o2, ll, big["m"], fixed=True)), mats))
+    finally:
+        oracle.set_order_free(False)
+    n_lat = 0
+    for u, r, d, (o, O) in zip(sample, res, lats, want):
+        assert o.extra["lm_oob"] == 0 and o.extra["ties"] == 0, u
+        _same(r, o, "utt %d" % u)
+        assert (d is not None) == bool(O.ok), u
+        if d is not None:
+            L = as_raw(d)
+            assert np.array_equal(nodes(L), nodes(O)) and np.array_equal(L.labelled_arcs(), O.labelled_arcs()), "utt %d lattice" % u
+            n_lat += 1
+    print("biglm lattice mode at full size: %d of %d utterances with a lattice, each equal to the oracle's" % (n_lat, len(sample)))
+    assert n_lat >= 4, n_lat
+    o1.free()
+    o2.free()
+    oracle.free_graph(h)
     L1.free()
     L2.free()
 
@@ -339,12 +397,22 @@ def test_config5_beam15_lattices_batch128(big, oracle, refdec, tmp_path):
         np.mean([d["n_states"] for d in lats]), np.mean([d["n_states"] for d in dets]), det_seconds))
     h = oracle.load_graph(big["path"])
     try:
-        for u in (7, 70, 121):
-            oracle.set_order_free(True)
-            O = pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**cd), big["mats"][u], big["m"])
-            oracle.set_order_free(False)
+        # the raw lattice state by state and arc by arc against the order-free oracle on 16 of the 128 utterances (VERDICT r3 next
+        # #6c; the oracle's runs in parallel host threads) ...
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        sample = sorted(set(list(range(5, 128, 9)) + [7, 70, 121]))[:16]
+        oracle.set_order_free(True)
+        with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as ex:
+            want = list(ex.map(lambda u: pyoracle.oracle_raw_lattice(oracle, h, pyoracle.Config(**cd), big["mats"][u], big["m"]), sample))
+        oracle.set_order_free(False)
+        for u, O in zip(sample, want):
             L = as_raw(lats[u])
             assert np.array_equal(nodes(L), nodes(O)) and np.array_equal(L.labelled_arcs(), O.labelled_arcs()), u
+        # ... and the determinized lattice arc for arc against the REFERENCE's determinizer on three
+        for u in (7, 70, 121):
+            L = as_raw(lats[u])
             p = str(tmp_path / ("c5b_%d.lat" % u))
             with open(p, "wb") as f:
                 f.write(G.pkg.shard.lattice_to_bytes(lats[u]))

@@ -36,3 +36,9 @@ def test_two_ranks_share_one_gpu_and_gather_real_results():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 12 and d["scaling"] == "weak"
     chk = d["config"]["gather_check"]
     assert chk["utterances"] == 12 and chk["bit_exact_vs_oracle"] == 12, chk
+    # every rank runs the decoder configuration of the N = 1 headline: staged expansion, two launches per frame, degree codes in
+    # the tokens, the log-likelihood row in LDS -- and says so
+    pf = d["config"]["decoder_paths"]
+    assert d["config"]["decoder_paths_same_on_every_rank"] is True
+    assert pf["staged"] == 1 and pf["two_launch"] == 1 and pf["degcode"] == 1 and pf["ll_row"] == 1 and pf["best_exp"] == 1, pf
+    assert d["config"]["parity_per_rank_sample"].startswith("4/4"), d["config"]["parity_per_rank_sample"]

@@ -2,7 +2,7 @@
 # A/B timing of bench.py argument sets on ONE box (box-to-box spread is ~4 %, more than most kernel changes):
 #   gpurun -- 'bash tools/ab_args.sh "" "--debug 65536" ...'     ("" = the defaults)
 # Each argument set runs bench.py REPS times (default 2), interleaved (A B C A B C), without the CPU legs; prints ms per step.
-R="${GRAFT_REPO_ROOT:-$PWD}"
+R="${GRAFT_REPO_ROOT:-$PWD}"   # (A/B switches of wfst_options.debug need a library built with -DWFST_AB_SWITCHES)
 cd "$R"
 mkdir -p gpurun_out/ab
 COMMON="${AB_COMMON:---steps 10 --warmup 3 --no-service-point --no-legs --cpu-sample 4 --no-cpu-baseline}"
