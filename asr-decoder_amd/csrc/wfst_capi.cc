@@ -191,6 +191,18 @@ struct wfst_decoder {
   DevBuf<int4> cmp_out_a;
   DevBuf<float2> cmp_out_w;
   CmpDev cmp = {};
+  int32_t cmp_slots = 0;              // lattices one compose launch takes
+  // results of the batched post-processing (wfst_decoder_rescore_lattices / wfst_decoder_nbest_paths_batch), served by the per-channel
+  // fetch calls while they still belong to the channel's state and to the same request
+  struct PostKey { const wfst_lm *o = nullptr, *n = nullptr; int32_t use_final = 0, n_paths = 0, decoded = -1; bool valid = false; };
+  struct RescLattice { PostKey key; int32_t n_states = 0; std::vector<int4> a; std::vector<float2> w; std::vector<int32_t> fin; };
+  struct NbPaths { PostKey key; std::vector<int32_t> off, olabel; std::vector<float> tot, graph, ac; };
+  std::vector<RescLattice> resc_cache;
+  std::vector<NbPaths> nbp_cache;
+  // what the determinizer's / the composition's workspace slots hold since the last batched call (one chunk): a batch of n-best
+  // requests right behind the batch of second passes of the same channels starts from those lattices
+  std::vector<int32_t> post_dev_list, post_dev_decoded, post_dev_dres, post_dev_cres;
+  const wfst_lm *post_dev_o = nullptr, *post_dev_n = nullptr;
   struct DetLattice { int32_t n_states = 0, n_proper = 0, err = 0; std::vector<int4> a; std::vector<float2> w; };
   std::vector<DetLattice> det_cache;
   std::vector<char> det_cached;
@@ -1232,6 +1244,8 @@ int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n) {
     d->hist_rows[c] = 0;
     if (!d->lat_cached.empty()) d->lat_cached[c] = 0;
     if (!d->det_cached.empty()) { d->det_cached[c] = 0; d->det_live_nd[c] = -1; }
+    if (!d->resc_cache.empty()) { d->resc_cache[(size_t)c].key.valid = false; d->nbp_cache[(size_t)c].key.valid = false; }
+    d->post_dev_list.clear();
   }
   return WFST_OK;
 }
@@ -1492,6 +1506,8 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
     d->h_state[c] = 2;
     if (!d->lat_cached.empty()) d->lat_cached[c] = 0;
     if (!d->det_cached.empty()) { d->det_cached[c] = 0; d->det_live_nd[c] = -1; }
+    if (!d->resc_cache.empty()) { d->resc_cache[(size_t)c].key.valid = false; d->nbp_cache[(size_t)c].key.valid = false; }
+    d->post_dev_list.clear();
   }
   return WFST_OK;
 }
@@ -1954,6 +1970,41 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
   return WFST_OK;
 }
 
+// first use of the determinizer: its workspace (wfst_limits.det_raw_states / det_raw_arcs / det_workspace_bytes), for det_slots
+// lattices at a time -- every channel of the decoder where the budget allows
+static int ensure_det_workspace(wfst_decoder *d) {
+  DetDev &X = d->det;
+  if (d->det_ws.p) return WFST_OK;
+    // first use: the determinizer's workspace (wfst_limits.det_raw_states / det_raw_arcs / det_workspace_bytes), for
+  // det_slots lattices at a time -- every channel of the decoder where the budget allows
+  X.raw_states_cap = (int32_t)std::min<int64_t>(d->D.lat_tok_cap, d->lim.det_raw_states > 0 ? d->lim.det_raw_states : 65536);
+  X.raw_arcs_cap = (int32_t)std::min<int64_t>(d->D.lat_arc_cap, d->lim.det_raw_arcs > 0 ? d->lim.det_raw_arcs : 2ll * X.raw_states_cap);
+  const int32_t base = std::max(4096, X.raw_states_cap);
+  X.caps.trie = 8 * base; X.caps.pool = 16 * base; X.caps.states = 2 * base; X.caps.initials = 2 * base;
+  X.caps.arcs = 4 * base; X.caps.tmp = std::max(8192, 2 * (X.raw_arcs_cap + X.raw_states_cap));
+  X.out_cap = X.caps.arcs;
+  X.words_per_channel = 3 * (int64_t)X.raw_states_cap + 1 + 5 * (int64_t)X.raw_arcs_cap + det_words(X.caps, X.raw_states_cap) + 16;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const int64_t per = X.words_per_channel * 4 + (int64_t)X.out_cap * (int64_t)(sizeof(int4) + sizeof(float2));
+  const int64_t budget = d->lim.det_workspace_bytes > 0 ? d->lim.det_workspace_bytes : (int64_t)(total_b / 8);
+  d->det_slots = (int32_t)std::max<int64_t>(1, std::min<int64_t>(d->n_channels, budget / per));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  HIP_TRY(d->det_ws.alloc((size_t)d->det_slots * (size_t)X.words_per_channel));
+  HIP_TRY(d->det_result.alloc((size_t)d->det_slots * 4));
+  HIP_TRY(d->det_out_a.alloc((size_t)d->det_slots * (size_t)X.out_cap));
+  HIP_TRY(d->det_out_w.alloc((size_t)d->det_slots * (size_t)X.out_cap));
+  X.ws = d->det_ws.p;
+  X.result = d->det_result.p;
+  X.out_a = d->det_out_a.p;
+  X.out_w = d->det_out_w.p;
+  d->det_cache.resize((size_t)d->n_channels);
+  d->det_cached.assign((size_t)d->n_channels, 0);
+  d->det_live_nd.assign((size_t)d->n_channels, -1);
+  d->det_live_final.assign((size_t)d->n_channels, 0);
+  return WFST_OK;
+}
+
 int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, int32_t cap_states,
                                           int32_t cap_arcs, int32_t *n_states, int32_t *n_arcs, int32_t *st_final,
                                           int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel, int32_t *a_olabel,
@@ -1967,34 +2018,9 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
   *n_arcs = 0;
   if (!live && !use_final_probs) return WFST_OK;  // as GetRawLattice (base-inl.h:879-884)
   DetDev &X = d->det;
-  if (!d->det_ws.p) {
-    // first use: the determinizer's workspace (wfst_limits.det_raw_states / det_raw_arcs / det_workspace_bytes), for
-    // det_slots lattices at a time -- every channel of the decoder where the budget allows
-    X.raw_states_cap = (int32_t)std::min<int64_t>(d->D.lat_tok_cap, d->lim.det_raw_states > 0 ? d->lim.det_raw_states : 65536);
-    X.raw_arcs_cap = (int32_t)std::min<int64_t>(d->D.lat_arc_cap, d->lim.det_raw_arcs > 0 ? d->lim.det_raw_arcs : 2ll * X.raw_states_cap);
-    const int32_t base = std::max(4096, X.raw_states_cap);
-    X.caps.trie = 8 * base; X.caps.pool = 16 * base; X.caps.states = 2 * base; X.caps.initials = 2 * base;
-    X.caps.arcs = 4 * base; X.caps.tmp = std::max(8192, 2 * (X.raw_arcs_cap + X.raw_states_cap));
-    X.out_cap = X.caps.arcs;
-    X.words_per_channel = 3 * (int64_t)X.raw_states_cap + 1 + 5 * (int64_t)X.raw_arcs_cap + det_words(X.caps, X.raw_states_cap) + 16;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const int64_t per = X.words_per_channel * 4 + (int64_t)X.out_cap * (int64_t)(sizeof(int4) + sizeof(float2));
-    const int64_t budget = d->lim.det_workspace_bytes > 0 ? d->lim.det_workspace_bytes : (int64_t)(total_b / 8);
-    d->det_slots = (int32_t)std::max<int64_t>(1, std::min<int64_t>(d->n_channels, budget / per));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    HIP_TRY(d->det_ws.alloc((size_t)d->det_slots * (size_t)X.words_per_channel));
-    HIP_TRY(d->det_result.alloc((size_t)d->det_slots * 4));
-    HIP_TRY(d->det_out_a.alloc((size_t)d->det_slots * (size_t)X.out_cap));
-    HIP_TRY(d->det_out_w.alloc((size_t)d->det_slots * (size_t)X.out_cap));
-    X.ws = d->det_ws.p;
-    X.result = d->det_result.p;
-    X.out_a = d->det_out_a.p;
-    X.out_w = d->det_out_w.p;
-    d->det_cache.resize((size_t)d->n_channels);
-    d->det_cached.assign((size_t)d->n_channels, 0);
-    d->det_live_nd.assign((size_t)d->n_channels, -1);
-    d->det_live_final.assign((size_t)d->n_channels, 0);
+  {
+    const int rcw = ensure_det_workspace(d);
+    if (rcw != WFST_OK) return rcw;
   }
   // a live channel's result is kept for as long as the channel has not moved on (the size query and the fetch of one request
   // are two calls: the second reuses the first's work)
@@ -2016,6 +2042,7 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
       int rc = stage_channels(d, list.data(), (int32_t)list.size(), &dev, &cnt);
       if (rc != WFST_OK) return rc;
       if (live) launch_lattice_emit(d->D, dev, cnt, use_final_probs ? 1 : 0, d->stream);
+      d->post_dev_list.clear();   // (the slots are about to hold other lattices than the last batched call's)
       launch_determinize(d->D, X, dev, cnt, d->stream);
       HIP_TRY(hipGetLastError());
       std::vector<int32_t> res((size_t)cnt * 4);
@@ -2070,6 +2097,7 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
 // The determinized lattice of ONE channel into workspace slot 0 (a cached host copy of an earlier batch determinization does not
 // hold the device copy any more): the other finalized channels are hidden from the batch sweep for the call.
 static int determinize_alone(wfst_decoder *d, int32_t channel, int32_t use_final_probs, int32_t *ns, int32_t *na) {
+  d->post_dev_list.clear();   // (slot 0 is about to hold another lattice)
   // (det_only: the call below determinizes exactly this channel, afresh, whatever is cached and whichever other channels are
   // finalized -- also when it is the decoder's first determinizer use and the caches do not exist yet)
   d->det_only = channel;
@@ -2079,31 +2107,228 @@ static int determinize_alone(wfst_decoder *d, int32_t channel, int32_t use_final
   return WFST_OK;
 }
 
-// ComposeLattice with the old LM and with the new one over the determinized lattice of slot 0, on the device; res = {states, arcs}
-static int compose_slot0(wfst_decoder *d, const wfst_lm *old_lm, const wfst_lm *new_lm, int32_t res[4]) {
+// ComposeLattice with the old LM and with the new one over the determinized lattices of workspace slots [0, cnt), on the device, in ONE
+// launch (a workgroup per lattice); res[4 * i ..] = {states, arcs, status, -} of slot i
+static int compose_slots(wfst_decoder *d, const wfst_lm *old_lm, const wfst_lm *new_lm, int32_t cnt, int32_t *res) {
   CmpDev &Y = d->cmp;
-  if (!d->cmp_ws.p) {
+  if (d->cmp_slots < cnt) {
     Y.pair_cap = 65536;
     Y.arc_cap = 262144;
     Y.ws_ints = 11ll * Y.arc_cap + 13ll * Y.pair_cap + 64;
     HIP_TRY(hipStreamSynchronize(d->stream));
-    HIP_TRY(d->cmp_ws.alloc((size_t)Y.ws_ints));
-    HIP_TRY(d->cmp_result.alloc(4));
-    HIP_TRY(d->cmp_fin.alloc((size_t)Y.pair_cap));
-    HIP_TRY(d->cmp_out_a.alloc((size_t)Y.arc_cap));
-    HIP_TRY(d->cmp_out_w.alloc((size_t)Y.arc_cap));
+    HIP_TRY(d->cmp_ws.alloc((size_t)cnt * (size_t)Y.ws_ints));
+    HIP_TRY(d->cmp_result.alloc((size_t)cnt * 4));
+    HIP_TRY(d->cmp_fin.alloc((size_t)cnt * (size_t)Y.pair_cap));
+    HIP_TRY(d->cmp_out_a.alloc((size_t)cnt * (size_t)Y.arc_cap));
+    HIP_TRY(d->cmp_out_w.alloc((size_t)cnt * (size_t)Y.arc_cap));
     Y.ws = d->cmp_ws.p;
     Y.result = d->cmp_result.p;
     Y.out_fin = d->cmp_fin.p;
     Y.out_a = d->cmp_out_a.p;
     Y.out_w = d->cmp_out_w.p;
+    d->cmp_slots = cnt;
   }
-  launch_compose2(d->det, Y, old_lm->view(), new_lm->view(), d->stream);
+  launch_compose2(d->det, Y, old_lm->view(), new_lm->view(), cnt, d->stream);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(res, Y.result, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(res, Y.result, (size_t)cnt * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
-  if (res[2] != 0) return fail(WFST_E_CAPACITY, "the composed lattice outgrew the composition workspace (" + std::to_string(Y.pair_cap) + " states / " + std::to_string(Y.arc_cap) + " arcs)");
   return WFST_OK;
+}
+static int compose_slot0(wfst_decoder *d, const wfst_lm *old_lm, const wfst_lm *new_lm, int32_t res[4]) {
+  int rc = compose_slots(d, old_lm, new_lm, 1, res);
+  if (rc != WFST_OK) return rc;
+  if (res[2] != 0) return fail(WFST_E_CAPACITY, "the composed lattice outgrew the composition workspace (" + std::to_string(d->cmp.pair_cap) + " states / " + std::to_string(d->cmp.arc_cap) + " arcs)");
+  return WFST_OK;
+}
+
+// ---- the service's post-processing as a BATCH (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:50-105: GetLattice, its second LM pass
+// under --use-second, GetNbest -- the reference runs them per utterance, one worker thread each, concurrently,
+// v2-asr/v2-asr-work-thread.h:66): the determinized lattices of a list of FINALIZED channels, ComposeLattice x 2 and NShortestPath
+// for all of them in one launch each (a workgroup per lattice), the results fetched once and kept for the per-channel fetch calls.
+static int postprocess_batch(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs, const wfst_lm *old_lm,
+                             const wfst_lm *new_lm, int32_t n_paths) {
+  if (!d || (old_lm == nullptr) != (new_lm == nullptr)) return fail(WFST_E_ARG, "bad argument (both LMs or neither)");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice / GetNbest need a decoder created with wfst_limits.lattice_links > 0");
+  if (old_lm && (old_lm->device != d->device || new_lm->device != d->device)) return fail(WFST_E_ARG, "the LMs must be on the decoder's device");
+  if (n_paths < 0 || n_paths > 4096) return fail(WFST_E_ARG, "1 <= n <= 4096 paths");
+  HIP_TRY(hipSetDevice(d->device));
+  std::vector<int32_t> all;
+  if (channels) {
+    if (n <= 0 || n > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
+    std::vector<char> seen((size_t)d->n_channels, 0);
+    for (int i = 0; i < n; ++i) {
+      const int c = channels[i];
+      if (c < 0 || c >= d->n_channels || seen[(size_t)c]) return fail(WFST_E_ARG, "channel index out of range or listed twice");
+      seen[(size_t)c] = 1;
+      if (d->h_state[c] != 2) return fail(WFST_E_STATE, "the batched post-processing takes finalized channels (mid-utterance: the per-channel calls)");
+      all.push_back(c);
+    }
+  } else {
+    for (int c = 0; c < d->n_channels; ++c)
+      if (d->h_state[c] == 2) all.push_back(c);
+  }
+  if (d->resc_cache.empty()) { d->resc_cache.resize((size_t)d->n_channels); d->nbp_cache.resize((size_t)d->n_channels); }
+  wfst_decoder::PostKey key;
+  key.o = old_lm; key.n = new_lm; key.use_final = use_final_probs ? 1 : 0; key.n_paths = n_paths; key.valid = true;
+  auto store_empty = [&](int c) {
+    key.decoded = d->h_decoded[c];
+    if (n_paths) { wfst_decoder::NbPaths &R = d->nbp_cache[(size_t)c]; R = wfst_decoder::NbPaths(); R.key = key; R.off.assign(1, 0); }
+    else { wfst_decoder::RescLattice &R = d->resc_cache[(size_t)c]; R = wfst_decoder::RescLattice(); R.key = key; }
+  };
+  if (!use_final_probs) {   // a finalized channel without final-probs has no lattice (GetRawLattice, base-inl.h:879-884)
+    for (int c : all) store_empty(c);
+    return WFST_OK;
+  }
+  if (all.empty()) return WFST_OK;
+  int rc = ensure_det_workspace(d);
+  if (rc != WFST_OK) return rc;
+  DetDev &X = d->det;
+  const size_t chunk = (size_t)std::max(1, std::min(d->det_slots, 128));
+  for (size_t first = 0; first < all.size(); first += chunk) {
+    const std::vector<int32_t> list(all.begin() + (long)first, all.begin() + (long)std::min(all.size(), first + chunk));
+    int32_t cnt = (int32_t)list.size();
+    std::vector<int32_t> decoded((size_t)cnt);
+    for (int i = 0; i < cnt; ++i) decoded[(size_t)i] = d->h_decoded[list[(size_t)i]];
+    // (the slots still hold these very lattices -- the batch of second passes just before this batch of n-best requests?)
+    const bool held = list == d->post_dev_list && decoded == d->post_dev_decoded && (!old_lm || (d->post_dev_o == old_lm && d->post_dev_n == new_lm));
+    std::vector<int32_t> dres, cres;
+    if (held) {
+      dres = d->post_dev_dres;
+      if (old_lm) cres = d->post_dev_cres;
+    } else {
+      d->post_dev_list.clear();
+      const int32_t *dev;
+      rc = stage_channels(d, list.data(), (int32_t)list.size(), &dev, &cnt);
+      if (rc != WFST_OK) return rc;
+      // GetLattice: the determinized lattices of the chunk, list[i] in workspace slot i
+      launch_determinize(d->D, X, dev, cnt, d->stream);
+      HIP_TRY(hipGetLastError());
+      dres.resize((size_t)cnt * 4);
+      HIP_TRY(hipMemcpyAsync(dres.data(), X.result, dres.size() * 4, hipMemcpyDeviceToHost, d->stream));
+      rc = read_ctl(d);  // synchronises the stream
+      if (rc != WFST_OK) return rc;
+      rc = check_ctl_errors(d);
+      if (rc != WFST_OK) return rc;
+      for (int i = 0; i < cnt; ++i) {
+        if (dres[(size_t)4 * i + 2] == 2)
+          return fail(WFST_E_CAPACITY, "channel " + std::to_string(list[(size_t)i]) + ": raw lattice larger than the determinizer takes");
+        if (dres[(size_t)4 * i + 2])
+          return fail(WFST_E_CAPACITY, "channel " + std::to_string(list[(size_t)i]) + ": the subset construction outgrew its workspace");
+      }
+      // ... the second LM pass: ComposeLattice with the old LM and with the new one
+      if (old_lm) {
+        cres.resize((size_t)cnt * 4);
+        rc = compose_slots(d, old_lm, new_lm, cnt, cres.data());
+        if (rc != WFST_OK) return rc;
+        for (int i = 0; i < cnt; ++i)
+          if (cres[(size_t)4 * i + 2] == 1)
+            return fail(WFST_E_CAPACITY, "channel " + std::to_string(list[(size_t)i]) + ": the composed lattice outgrew the composition workspace");
+      }
+      d->post_dev_list = list; d->post_dev_decoded = decoded; d->post_dev_dres = dres; d->post_dev_cres = cres;
+      d->post_dev_o = old_lm; d->post_dev_n = new_lm;
+    }
+    const std::vector<int32_t> &lres = old_lm ? cres : dres;   // {states, arcs, ...} of the lattices the paths / the fetch are taken from
+    const int4 *la = old_lm ? d->cmp.out_a : X.out_a;
+    const float2 *lw = old_lm ? d->cmp.out_w : X.out_w;
+    const int64_t lstride = old_lm ? d->cmp.arc_cap : X.out_cap;
+    // the lattices' arcs (the paths report labels and costs of their arcs; the lattice fetch returns them)
+    std::vector<std::vector<int4>> ha((size_t)cnt);
+    std::vector<std::vector<float2>> hw((size_t)cnt);
+    std::vector<std::vector<int32_t>> hfin((size_t)cnt);
+    for (int i = 0; i < cnt; ++i) {
+      const size_t na = (size_t)std::max(0, lres[(size_t)4 * i + 1]), nsi = (size_t)std::max(0, lres[(size_t)4 * i]);
+      ha[(size_t)i].resize(na);
+      hw[(size_t)i].resize(na);
+      if (na) {
+        HIP_TRY(hipMemcpyAsync(ha[(size_t)i].data(), la + (size_t)i * (size_t)lstride, na * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipMemcpyAsync(hw[(size_t)i].data(), lw + (size_t)i * (size_t)lstride, na * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
+      }
+      if (old_lm && !n_paths && nsi) {
+        hfin[(size_t)i].resize(nsi);
+        HIP_TRY(hipMemcpyAsync(hfin[(size_t)i].data(), d->cmp.out_fin + (size_t)i * (size_t)d->cmp.pair_cap, nsi * 4, hipMemcpyDeviceToHost, d->stream));
+      }
+    }
+    if (!n_paths) {
+      HIP_TRY(hipStreamSynchronize(d->stream));
+      for (int i = 0; i < cnt; ++i) {
+        const int c = list[(size_t)i];
+        wfst_decoder::RescLattice &R = d->resc_cache[(size_t)c];
+        key.decoded = d->h_decoded[c];
+        R.key = key;
+        R.n_states = std::max(0, lres[(size_t)4 * i]);
+        R.a.swap(ha[(size_t)i]);
+        R.w.swap(hw[(size_t)i]);
+        R.fin.swap(hfin[(size_t)i]);
+      }
+      continue;
+    }
+    // ... NShortestPath: one workgroup per lattice
+    int32_t ns_max = 1, na_max = 1;
+    for (int i = 0; i < cnt; ++i) { ns_max = std::max(ns_max, lres[(size_t)4 * i]); na_max = std::max(na_max, lres[(size_t)4 * i + 1]); }
+    NbPathsDev P = {};
+    P.a = la; P.w = lw; P.res = old_lm ? d->cmp.result : X.result; P.fin = old_lm ? d->cmp.out_fin : nullptr;
+    P.in_stride = lstride; P.fin_stride = old_lm ? d->cmp.pair_cap : 0;
+    const int64_t nmax = std::max(ns_max, na_max);
+    P.ws_ints = 7ll * ns_max + 4ll * nmax + na_max + 16;
+    P.list_cap = std::min<int64_t>((int64_t)ns_max * n_paths + 1, 1ll << 24);
+    const int64_t out_cap = std::min<int64_t>((int64_t)n_paths * ns_max, 1ll << 22);
+    if ((int64_t)d->np_ws.n < P.ws_ints * cnt) HIP_TRY(d->np_ws.alloc((size_t)(P.ws_ints * cnt)));
+    if ((int64_t)d->np_lists.n < P.list_cap * cnt) HIP_TRY(d->np_lists.alloc((size_t)(P.list_cap * cnt)));
+    if ((int64_t)d->np_arcs.n < out_cap * cnt) HIP_TRY(d->np_arcs.alloc((size_t)(out_cap * cnt)));
+    if ((int64_t)d->np_off.n < (int64_t)(n_paths + 1) * cnt) { HIP_TRY(d->np_off.alloc((size_t)(n_paths + 1) * (size_t)cnt)); HIP_TRY(d->np_tot.alloc((size_t)n_paths * (size_t)cnt)); }
+    if ((int64_t)d->np_out.n < 4ll * cnt) HIP_TRY(d->np_out.alloc((size_t)cnt * 4));
+    P.n = n_paths;
+    P.ws = d->np_ws.p; P.lists = d->np_lists.p;
+    P.out = d->np_out.p; P.out_off = d->np_off.p; P.out_tot = d->np_tot.p;
+    P.out_arcs = d->np_arcs.p; P.out_cap = (int32_t)out_cap;
+    launch_nbest_paths(P, cnt, d->stream);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> pout((size_t)cnt * 4), poff((size_t)cnt * (size_t)(n_paths + 1));
+    std::vector<float> ptot((size_t)cnt * (size_t)n_paths);
+    HIP_TRY(hipMemcpyAsync(pout.data(), P.out, pout.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(poff.data(), P.out_off, poff.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(ptot.data(), P.out_tot, ptot.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for (int i = 0; i < cnt; ++i) {
+      const int32_t *o = &pout[(size_t)4 * i];
+      if (lres[(size_t)4 * i] <= 0) continue;   // (no lattice: no paths)
+      if (o[2] == 3) return fail(WFST_E_DEVICE, "n-best: the lattice has a cycle");
+      if (o[2] != 0) return fail(WFST_E_CAPACITY, "n-best: channel " + std::to_string(list[(size_t)i]) + " outgrew the batch's path workspace (ask for it alone: wfst_decoder_get_nbest_paths)");
+    }
+    for (int i = 0; i < cnt; ++i) {
+      const int c = list[(size_t)i];
+      wfst_decoder::NbPaths &R = d->nbp_cache[(size_t)c];
+      R = wfst_decoder::NbPaths();
+      key.decoded = d->h_decoded[c];
+      R.key = key;
+      const int32_t found = lres[(size_t)4 * i] > 0 ? pout[(size_t)4 * i] : 0, total = lres[(size_t)4 * i] > 0 ? pout[(size_t)4 * i + 1] : 0;
+      R.off.assign(1, 0);
+      if (found) R.off.assign(poff.begin() + (long)i * (n_paths + 1), poff.begin() + (long)i * (n_paths + 1) + found + 1);
+      R.tot.assign(ptot.begin() + (long)i * n_paths, ptot.begin() + (long)i * n_paths + found);
+      std::vector<int32_t> arcs((size_t)total);
+      if (total) HIP_TRY(hipMemcpy(arcs.data(), P.out_arcs + (size_t)i * (size_t)P.out_cap, (size_t)total * 4, hipMemcpyDeviceToHost));
+      R.olabel.resize((size_t)total); R.graph.resize((size_t)total); R.ac.resize((size_t)total);
+      for (int32_t k = 0; k < total; ++k) {
+        const size_t aidx = (size_t)arcs[(size_t)k];
+        R.olabel[(size_t)k] = ha[(size_t)i][aidx].z;
+        R.graph[(size_t)k] = hw[(size_t)i][aidx].x;
+        R.ac[(size_t)k] = hw[(size_t)i][aidx].y;
+      }
+    }
+  }
+  return WFST_OK;
+}
+
+int wfst_decoder_rescore_lattices(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs, const wfst_lm *old_lm,
+                                  const wfst_lm *new_lm) {
+  if (!old_lm || !new_lm) return fail(WFST_E_ARG, "the second pass needs both LMs");
+  return postprocess_batch(d, channels, n, use_final_probs, old_lm, new_lm, 0);
+}
+
+int wfst_decoder_nbest_paths_batch(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t n_paths, int32_t use_final_probs,
+                                   const wfst_lm *old_lm, const wfst_lm *new_lm) {
+  if (n_paths < 1) return fail(WFST_E_ARG, "1 <= n <= 4096 paths");
+  return postprocess_batch(d, channels, n, use_final_probs, old_lm, new_lm, n_paths);
 }
 
 int wfst_decoder_get_rescored_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, const wfst_lm *old_lm, const wfst_lm *new_lm,
@@ -2118,6 +2343,25 @@ int wfst_decoder_get_rescored_lattice(wfst_decoder *d, int32_t channel, int32_t 
   *n_arcs = 0;
   if (d->h_state[channel] == 0) return fail(WFST_E_STATE, "GetLattice before InitDecoding");
   if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice needs a decoder created with wfst_limits.lattice_links > 0");
+  if (!d->resc_cache.empty()) {   // a result of wfst_decoder_rescore_lattices for this very request
+    const wfst_decoder::RescLattice &R = d->resc_cache[(size_t)channel];
+    if (R.key.valid && R.key.o == old_lm && R.key.n == new_lm && R.key.use_final == (use_final_probs ? 1 : 0) && R.key.decoded == d->h_decoded[channel] && d->h_state[channel] == 2) {
+      *n_states = R.n_states;
+      *n_arcs = (int32_t)R.a.size();
+      if (R.n_states > cap_states || (int32_t)R.a.size() > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");
+      for (int32_t q = 0; q < R.n_states; ++q)
+        if (st_final) st_final[q] = R.fin[(size_t)q];
+      for (size_t q = 0; q < R.a.size(); ++q) {
+        if (a_src) a_src[q] = R.a[q].x;
+        if (a_dst) a_dst[q] = R.a[q].y;
+        if (a_ilabel) a_ilabel[q] = 0;
+        if (a_olabel) a_olabel[q] = R.a[q].z;
+        if (a_graph) a_graph[q] = R.w[q].x;
+        if (a_acoustic) a_acoustic[q] = R.w[q].y;
+      }
+      return WFST_OK;
+    }
+  }
   int rc = determinize_alone(d, channel, use_final_probs, &ns, &na);
   if (rc != WFST_OK) return rc;
   if (ns == 0) return WFST_OK;   // no lattice (as wfst_decoder_get_raw_lattice)
@@ -2162,6 +2406,26 @@ int wfst_decoder_get_nbest_paths(wfst_decoder *d, int32_t channel, int32_t n, in
   *total_arcs = 0;
   if (d->h_state[channel] == 0) return fail(WFST_E_STATE, "GetNbest before InitDecoding");
   if (!d->D.lattice) return fail(WFST_E_STATE, "GetNbest needs a decoder created with wfst_limits.lattice_links > 0");
+  if (!d->nbp_cache.empty()) {   // a result of wfst_decoder_nbest_paths_batch for this very request
+    const wfst_decoder::NbPaths &R = d->nbp_cache[(size_t)channel];
+    if (R.key.valid && R.key.o == old_lm && R.key.n == new_lm && R.key.use_final == (use_final_probs ? 1 : 0) && R.key.n_paths == n &&
+        R.key.decoded == d->h_decoded[channel] && d->h_state[channel] == 2) {
+      const int32_t found = (int32_t)R.tot.size(), total = (int32_t)R.olabel.size();
+      *n_paths = found;
+      *total_arcs = total;
+      if (found > cap_paths || total > cap_arcs) return fail(WFST_E_CAPACITY, "n-best larger than the given capacities");
+      for (int32_t q = 0; q <= found; ++q)
+        if (path_off) path_off[q] = R.off[(size_t)q];
+      for (int32_t q = 0; q < found; ++q)
+        if (path_tot) path_tot[q] = R.tot[(size_t)q];
+      for (int32_t q = 0; q < total; ++q) {
+        if (a_olabel) a_olabel[q] = R.olabel[(size_t)q];
+        if (a_graph) a_graph[q] = R.graph[(size_t)q];
+        if (a_acoustic) a_acoustic[q] = R.ac[(size_t)q];
+      }
+      return WFST_OK;
+    }
+  }
   // GetLattice (the determinized lattice, into workspace slot 0; with LMs its second-pass rescoring) ...
   int32_t ns = 0, na = 0;
   int rc = determinize_alone(d, channel, use_final_probs, &ns, &na);
@@ -2204,7 +2468,7 @@ int wfst_decoder_get_nbest_paths(wfst_decoder *d, int32_t channel, int32_t n, in
   P.lists = d->np_lists.p; P.list_cap = (int64_t)d->np_lists.n;
   P.out = d->np_out.p; P.out_off = d->np_off.p; P.out_tot = d->np_tot.p;
   P.out_arcs = d->np_arcs.p; P.out_cap = (int32_t)std::min<int64_t>((int64_t)d->np_arcs.n, 0x7fffffff);
-  launch_nbest_paths(P, d->stream);
+  launch_nbest_paths(P, 1, d->stream);
   HIP_TRY(hipGetLastError());
   int32_t out[4];
   HIP_TRY(hipMemcpyAsync(out, P.out, sizeof(out), hipMemcpyDeviceToHost, d->stream));

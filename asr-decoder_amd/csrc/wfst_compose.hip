@@ -141,6 +141,14 @@ __device__ bool compose_once(const LmDev &L, float scale, int n_in, const int32_
 
 __global__ __launch_bounds__(kCmpThreads) void compose2_kernel(DetDev X, CmpDev Y, LmDev lm1, LmDev lm2) {
   const int tid = threadIdx.x;
+  {
+    // one workgroup per lattice: workgroup b composes the determinized lattice of the determinizer's workspace slot b into slot b
+    // of the composition's buffers (a batch of the service's --use-second requests is ONE launch, not one per utterance)
+    const size_t b = blockIdx.x;
+    X.result += 4 * b; X.out_a += b * (size_t)X.out_cap; X.out_w += b * (size_t)X.out_cap;
+    Y.ws += b * (size_t)Y.ws_ints; Y.result += 4 * b;
+    Y.out_a += b * (size_t)Y.arc_cap; Y.out_w += b * (size_t)Y.arc_cap; Y.out_fin += b * (size_t)Y.pair_cap;
+  }
   const int32_t *res = X.result;   // slot 0: {states, arcs, status, determinized states proper}
   int32_t *ores = Y.result;
   if (tid == 0) { ores[0] = 0; ores[1] = 0; ores[2] = 0; ores[3] = 0; }
@@ -193,8 +201,8 @@ __global__ __launch_bounds__(kCmpThreads) void compose2_kernel(DetDev X, CmpDev 
   if (tid == 0) { ores[0] = n2; ores[1] = a2; }
 }
 
-void launch_compose2(const DetDev &X, const CmpDev &Y, const LmDev &lm1, const LmDev &lm2, hipStream_t s) {
-  hipLaunchKernelGGL(compose2_kernel, dim3(1), dim3(kCmpThreads), 0, s, X, Y, lm1, lm2);
+void launch_compose2(const DetDev &X, const CmpDev &Y, const LmDev &lm1, const LmDev &lm2, int n_slots, hipStream_t s) {
+  hipLaunchKernelGGL(compose2_kernel, dim3(n_slots), dim3(kCmpThreads), 0, s, X, Y, lm1, lm2);
 }
 
 }  // namespace wfst

@@ -418,6 +418,8 @@ struct NbPathsDev {
   const float2 *w;              // ... and their {graph, acoustic} costs
   const int32_t *res;           // {states, arcs, status, determinized states proper} as determinize_kernel / compose2_kernel leave it
   const int32_t *fin;           // final flag per state, or null: the states from res[3] on
+  int64_t in_stride, fin_stride;   // a batch: slot b's lattice sits at a / w + b * in_stride, res + 4 b, fin + b * fin_stride; its workspace,
+                                // lists and outputs at b * ws_ints, b * list_cap, out + 4 b, out_off + b (n + 1), out_tot + b n, out_arcs + b out_cap
   int32_t n;                    // paths wanted (<= 4096)
   int32_t *ws;                  // scratch: 7 states + 4 max(states, arcs) + arcs + 16 ints
   int64_t ws_ints;
@@ -429,7 +431,7 @@ struct NbPathsDev {
   int32_t *out_arcs;            // arc indices (into a / w), path after path, front to back
   int32_t out_cap;
 };
-void launch_nbest_paths(const NbPathsDev &P, hipStream_t s);
+void launch_nbest_paths(const NbPathsDev &P, int n_slots, hipStream_t s);
 
 // ---- second-pass LM composition on determinized lattices (wfst_compose.hip) ------------------------------------
 // ComposeLattice (newfst/compose-lat-inl.h:15-130) of the determinized lattice of workspace slot 0 (DetDev::out_a / out_w, as
@@ -445,7 +447,7 @@ struct CmpDev {
   float2 *out_w;          // [arc_cap] {graph, acoustic}
   int32_t *out_fin;       // [pair_cap] final flag per state
 };
-void launch_compose2(const DetDev &X, const CmpDev &Y, const LmDev &lm1, const LmDev &lm2, hipStream_t s);
+void launch_compose2(const DetDev &X, const CmpDev &Y, const LmDev &lm1, const LmDev &lm2, int n_slots, hipStream_t s);
 
 // launch wrappers (wfst_kernels.hip)
 void launch_init(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);

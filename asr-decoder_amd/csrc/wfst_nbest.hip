@@ -342,6 +342,14 @@ __global__ __launch_bounds__(kNpThreads) void nbest_paths_kernel(NbPathsDev P) {
   __shared__ u64 s_pay[kNpSlots];
   __shared__ int s_flag, s_maxlevel, s_lnext, s_total;
   const int tid = threadIdx.x;
+  {
+    // one workgroup per lattice (a batch of GetNbest requests is one launch): workgroup b takes slot b of every buffer
+    const size_t b = blockIdx.x;
+    P.a += b * (size_t)P.in_stride; P.w += b * (size_t)P.in_stride; P.res += 4 * b;
+    if (P.fin) P.fin += b * (size_t)P.fin_stride;
+    P.ws += b * (size_t)P.ws_ints; P.lists += b * (size_t)P.list_cap;
+    P.out += 4 * b; P.out_off += b * (size_t)(P.n + 1); P.out_tot += b * (size_t)P.n; P.out_arcs += b * (size_t)P.out_cap;
+  }
   int32_t *out = P.out;
   if (tid == 0) { out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 0; s_maxlevel = 0; s_lnext = 0; }
   __syncthreads();
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(kNpThreads) void nbest_paths_kernel(NbPathsDev P) {
   }
 }
 
-void launch_nbest_paths(const NbPathsDev &P, hipStream_t s) { hipLaunchKernelGGL(nbest_paths_kernel, dim3(1), dim3(kNpThreads), 0, s, P); }
+void launch_nbest_paths(const NbPathsDev &P, int n_slots, hipStream_t s) { hipLaunchKernelGGL(nbest_paths_kernel, dim3(n_slots), dim3(kNpThreads), 0, s, P); }
 
 void launch_nbest(const DecoderDev &D, const NbestDev &N, const int32_t *chans, int cnt, hipStream_t s) {
   hipLaunchKernelGGL(nbest_kernel, dim3(cnt), dim3(kNbThreads), 0, s, D, N, chans);

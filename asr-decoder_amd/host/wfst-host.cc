@@ -532,6 +532,33 @@ bool GpuBatchDecoder::GetLattice(int channel, Lattice *ofst, ArpaLm *oldlm, Arpa
 bool GpuBatchDecoder::GetRawLattice(int channel, Lattice *ofst, bool use_final_probs) {
   return RawLatticeOfChannel(_dec, channel, ofst, use_final_probs);
 }
+void GpuBatchDecoder::GetLattices(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok, ArpaLm *oldlm,
+                                  ArpaLm *newlm, bool use_final_probs) {
+  if (!oldlm || !newlm) throw std::runtime_error("second-pass GetLattice needs both LMs");
+  std::vector<int32_t> ch(channels.begin(), channels.end());
+  const int rc = wfst_decoder_rescore_lattices(_dec, ch.empty() ? nullptr : ch.data(), (int32_t)ch.size(), use_final_probs ? 1 : 0,
+                                               oldlm->Handle(), newlm->Handle());
+  if (rc == WFST_E_STATE) Warn(wfst_last_error());   // (a channel that is not finalized: the per-channel calls below serve it)
+  else if (rc != WFST_OK) Fatal("GetLattices");
+  ofsts->assign(channels.size(), Lattice());
+  ok->assign(channels.size(), false);
+  for (size_t i = 0; i < channels.size(); ++i) (*ok)[i] = RescoredLatticeOfChannel(_dec, channels[i], &(*ofsts)[i], oldlm, newlm, use_final_probs);
+}
+void GpuBatchDecoder::GetNbests(const std::vector<int> &channels, std::vector<std::vector<Lattice> > *nbests, std::vector<bool> *ok, int n,
+                                ArpaLm *oldlm, ArpaLm *newlm) {
+  if ((oldlm == nullptr) != (newlm == nullptr)) throw std::runtime_error("second-pass GetNbest needs both LMs");
+  nbests->assign(channels.size(), std::vector<Lattice>());
+  ok->assign(channels.size(), false);
+  if (n <= 0) return;
+  std::vector<int32_t> ch(channels.begin(), channels.end());
+  if (n <= 4096) {
+    const int rc = wfst_decoder_nbest_paths_batch(_dec, ch.empty() ? nullptr : ch.data(), (int32_t)ch.size(), n, 1,
+                                                  oldlm ? oldlm->Handle() : nullptr, newlm ? newlm->Handle() : nullptr);
+    if (rc == WFST_E_STATE || rc == WFST_E_CAPACITY) Warn(wfst_last_error());   // (the per-channel calls below serve what the batch could not)
+    else if (rc != WFST_OK) Fatal("GetNbests");
+  }
+  for (size_t i = 0; i < channels.size(); ++i) (*ok)[i] = NbestOfChannel(_dec, channels[i], (*nbests)[i], n, oldlm, newlm);
+}
 GpuBatchDecoder::GpuBatchDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, int n_channels,
                                  const wfst_limits *limits, void *hip_stream)
     : _dec(nullptr), _n(n_channels) {

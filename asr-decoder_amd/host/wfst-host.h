@@ -287,6 +287,14 @@ class GpuBatchDecoder {
   bool GetLattice(int channel, Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs = true);   // with the second LM pass
   void GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok,
                     bool use_final_probs = true);
+  // The service's post-processing for MANY finalized channels at once -- GetLattice under --use-second and GetNbest, which the
+  // reference runs per utterance on one worker thread each (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:50-105,
+  // v2-asr/v2-asr-work-thread.h:66): every stage is one launch for the whole list (wfst_decoder_rescore_lattices /
+  // wfst_decoder_nbest_paths_batch), the results come back once.  (*ok)[i] = what the per-channel call would return.
+  void GetLattices(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok, ArpaLm *oldlm, ArpaLm *newlm,
+                   bool use_final_probs = true);
+  void GetNbests(const std::vector<int> &channels, std::vector<std::vector<Lattice> > *nbests, std::vector<bool> *ok, int n,
+                 ArpaLm *oldlm = nullptr, ArpaLm *newlm = nullptr);
   wfst_decoder *Handle() { return _dec; }
 
  private:

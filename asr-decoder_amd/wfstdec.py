@@ -32,7 +32,7 @@ SYMBOLS = [
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
     "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice", "wfst_decoder_get_nbest_paths",
-    "wfst_decoder_get_degraded_frames", "wfst_decoder_get_path_flags",
+    "wfst_decoder_get_degraded_frames", "wfst_decoder_get_path_flags", "wfst_decoder_rescore_lattices", "wfst_decoder_nbest_paths_batch",
 ]
 
 
@@ -376,6 +376,21 @@ class BatchDecoder:
                                                        C.byref(ns), C.byref(na), _i32(fin), _i32(src), _i32(dst), _i32(il), _i32(ol),
                                                        _f32(gr), _f32(ac)))
         return dict(n_states=S, st_final=fin, a_src=src, a_dst=dst, a_ilabel=il, a_olabel=ol, a_graph=gr, a_acoustic=ac)
+
+    def rescore_lattices(self, old_lm, new_lm, channels=None, use_final_probs=True):
+        """The second LM pass of a BATCH of finalized channels (None: all of them) in one launch per stage
+        (wfst_decoder_rescore_lattices); rescored_lattice(c, ...) with the same LMs then returns the kept result."""
+        ch = None if channels is None else np.ascontiguousarray(channels, np.int32)
+        _check(lib().wfst_decoder_rescore_lattices(self.h, _i32(ch) if ch is not None else None, 0 if ch is None else len(ch),
+                                                   int(bool(use_final_probs)), old_lm.h, new_lm.h))
+
+    def nbest_paths_batch(self, n, old_lm=None, new_lm=None, channels=None, use_final_probs=True):
+        """GetNbest of a BATCH of finalized channels (None: all of them): one launch per stage (wfst_decoder_nbest_paths_batch);
+        nbest_paths(c, n, ...) with the same arguments then returns the kept result."""
+        ch = None if channels is None else np.ascontiguousarray(channels, np.int32)
+        _check(lib().wfst_decoder_nbest_paths_batch(self.h, _i32(ch) if ch is not None else None, 0 if ch is None else len(ch), int(n),
+                                                    int(bool(use_final_probs)), old_lm.h if old_lm is not None else None,
+                                                    new_lm.h if new_lm is not None else None))
 
     def nbest_paths(self, channel, n, old_lm=None, new_lm=None, use_final_probs=True):
         """GetNbest as lattices: NShortestPath over the determinized lattice (with LMs: over its second-pass rescoring), on the

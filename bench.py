@@ -92,6 +92,8 @@ def parse():
     ap.add_argument("--prune-interval", type=int, default=25, help="config prune_interval (reference default 25): lattice mode back-prunes and "
                     "compacts every this many frames; >= --frames: once, at FinalizeDecoding (offline batches that have the memory)")
     ap.add_argument("--nbest", type=int, default=5, help="n of the n-best taken per utterance in lattice mode")
+    ap.add_argument("--postprocess", action="store_true", help="lattice mode: after the timed steps, the service's post-processing of the whole "
+                    "batch -- GetLattice with the second LM pass and the 10-best of it -- through the batched calls, next to one channel alone")
     ap.add_argument("--debug", type=int, default=0, help="wfst_options.debug (kernel phase timers 32 closure / 64 insert / 128 expand: "
                     "timing experiments only, printed on stderr when the decoder is freed)")
     ap.add_argument("--no-fuse", action="store_true", help="graph without fused epsilon closures (wfst_graph_options.fuse_closures = 0): "
@@ -406,7 +408,8 @@ def main():
                                       options=wfstdec.GraphOptions(fuse_closures=0 if a.no_fuse else 1, **({"row_align_slots": a.row_align} if a.row_align else {})))
     graph.set_tid2pdf(m)
     big, lm_dev, lm_info = None, [None, None], None
-    if a.biglm:
+    post_lms = None
+    if a.biglm or a.postprocess:
         lmsynth = importlib.import_module("asr-decoder_amd.lmsynth")
         V = int(g.arcs["olabel"].max())
         t0 = time.time()
@@ -421,6 +424,8 @@ def main():
             big.append(lp)
         lm_dev = [wfstdec.Lm.load(big[0], -1.0, device=local_rank), wfstdec.Lm.load(big[1], 1.0, device=local_rank)]
         lm_info = [x.info() for x in lm_dev]
+        if not a.biglm:   # (--postprocess: the LMs of the service's second pass, not of the search)
+            post_lms, lm_dev, big = lm_dev, [None, None], None
         log("[rank %d] LMs: old %d states / %d arcs, new %d states / %d arcs (%.1fs)" % (
             rank, lm_info[0]["n_states"], lm_info[0]["n_arcs"], lm_info[1]["n_states"], lm_info[1]["n_arcs"], time.time() - t0))
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -514,6 +519,34 @@ def main():
     if os.environ.get("WFST_BENCH_BREAKDOWN"):
         log("[rank %d] host-side ms per step: %s" % (rank, {k: round(1000.0 * v / max(tb["n"], 1), 2) for k, v in tb.items() if k != "n"}))
 
+    if a.postprocess and a.lattice_links > 0 and rank == 0 and post_lms is not None:
+        # the service's post-processing (kaldi-online-nnet3-my-decoder.cc:50-105) of the batch the last step left finalized: the
+        # second LM pass of every determinized lattice, then the 10-best of the result -- one launch per stage, a workgroup per
+        # lattice -- next to ONE channel's request served alone
+        P1, P2 = post_lms
+        dec.rescore_lattices(P1, P2)   # (first use: workspaces)
+        dec.nbest_paths_batch(10, P1, P2)
+        one = []
+        for c in (0, B // 2, B - 1):   # (other requests than the kept ones: computed alone -- which also takes the workspace slots)
+            t3 = time.perf_counter()
+            dec.nbest_paths(c, 11, P1, P2)
+            one.append(time.perf_counter() - t3)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        dec.rescore_lattices(P1, P2)       # determinize x 128, ComposeLattice x 2 x 128, fetch
+        lat2 = [dec.rescored_lattice(c, P1, P2) for c in range(B)]
+        t1 = time.perf_counter()
+        dec.nbest_paths_batch(10, P1, P2)  # NShortestPath x 128 on the rescored lattices the slots still hold, fetch
+        nb2 = [dec.nbest_paths(c, 10, P1, P2) for c in range(B)]
+        t2 = time.perf_counter()
+        post = {"utterances": B, "second_pass_lattices_ms": 1e3 * (t1 - t0), "nbest10_of_them_ms": 1e3 * (t2 - t1),
+                "one_channel_alone_ms": 1e3 * float(np.median(one)),
+                "lattices": sum(x is not None for x in lat2), "mean_rescored_states": float(np.mean([x["n_states"] for x in lat2 if x is not None] or [0])),
+                "mean_paths": float(np.mean([len(x) for x in nb2])),
+                "what": "wfst_decoder_rescore_lattices + fetch of all; wfst_decoder_nbest_paths_batch(10) + fetch of all; "
+                        "wfst_decoder_get_nbest_paths(11) of one channel alone (determinize + ComposeLattice x 2 + NShortestPath), median of three"}
+    else:
+        post = None
     # ---- roofline pass: one more step with HIP events around every kernel launch -----------
     gstats = [dec.stats(c) for c in range(B)]
     dec.set_profiling(True)
@@ -552,6 +585,8 @@ def main():
     }
     pf = dec.path_flags()
     out["config"]["decoder_paths"] = pf
+    if post is not None:
+        out["postprocess"] = post
     if world > 1:
         # N > 1: every rank runs the configuration rank 0 reports (the kernel paths a decoder takes follow from its limits)
         tv = torch.tensor([pf[k] for k in sorted(pf)], dtype=torch.int64, device="cpu" if share else dev)
@@ -883,7 +918,7 @@ def main():
         common = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "1", "--no-service-point", "--no-legs", "--no-cpu-baseline",
                   "--batch", str(B), "--frames", str(T), "--states", str(a.states), "--pdfs", str(P)]
         legs = {"biglm": ["--biglm", "--steps", str(n2), "--cpu-sample", "8", "--max-tokens", "131072"],
-                "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2"],
+                "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2", "--postprocess"],
                 "lattice_beam15_no_determinizer": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
                                                    "--max-tokens", "262144", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "2", "--warmup", "2"],
                 "lattice_beam15": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
@@ -895,7 +930,7 @@ def main():
                 pr = subprocess.run(common + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
                 line = pr.stdout.decode().strip().splitlines()[-1]
                 o = json.loads(line)
-                keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "roofline") if k in o}
+                keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "roofline", "postprocess") if k in o}
                 keep["config"] = {k: v for k, v in o["config"].items() if k not in ("divergence_vs_reference_sample",)}
                 keep["wall_s"] = time.time() - t0
                 out[name] = keep
@@ -911,7 +946,7 @@ def main():
         print(json.dumps(out, default=plain), flush=True)
     if dec is not None:
         dec.free()
-    for L in lm_dev:
+    for L in list(lm_dev) + list(post_lms or []):
         if L is not None:
             L.free()
     graph.free()

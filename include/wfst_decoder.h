@@ -364,6 +364,19 @@ int wfst_decoder_get_nbest_paths(wfst_decoder *d, int32_t channel, int32_t n, in
                                  const wfst_lm *new_lm, int32_t cap_paths, int32_t cap_arcs, int32_t *n_paths, int32_t *total_arcs,
                                  int32_t *path_off, float *path_tot, int32_t *a_olabel, float *a_graph, float *a_acoustic);
 
+/* The service's post-processing as a BATCH.  The reference runs GetLattice (+ the second LM pass under --use-second) and GetNbest per
+ * utterance, one worker thread each, concurrently (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:50-105, v2-asr/v2-asr-work-thread.h:66);
+ * here the listed FINALIZED channels (NULL: every finalized channel) are determinized, composed with the two LMs
+ * (newfst/compose-lat-inl.h:15-130, twice) and -- the second call -- searched for their n cheapest paths (newfst/lattice-to-nbest.cc)
+ * in ONE launch each, a workgroup per lattice, and the results are fetched once: the per-channel calls
+ * wfst_decoder_get_rescored_lattice / wfst_decoder_get_nbest_paths with the same arguments then return them without device work
+ * (until the channel is initialised again).  old_lm / new_lm of the second call: both NULL = the paths of the determinized lattice.
+ * WFST_E_STATE for a channel that is not finalized (mid-utterance requests: the per-channel calls). */
+int wfst_decoder_rescore_lattices(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs, const wfst_lm *old_lm,
+                                  const wfst_lm *new_lm);
+int wfst_decoder_nbest_paths_batch(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t n_paths, int32_t use_final_probs,
+                                   const wfst_lm *old_lm, const wfst_lm *new_lm);
+
 /* The service's n-best (OnlineClgLatticeFastDecoder::GetNbest, kaldi-nnet3/kaldi-online-nnet3-my-
  * decoder.cc:50-105: GetRawLattice -> DeterminizeLatticeWrapper -> NShortestPath ->
  * ConvertNbestToVector, then LatticeToVector per path) of channels of a lattice-mode decoder, finalized

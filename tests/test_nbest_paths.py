@@ -142,3 +142,63 @@ def test_device_nbest_paths_equal_the_reference(oracle, refdec, synth, tmp_path)
         graph.free()
     assert n_checked >= 4
     assert most > 2048, "no lattice with enough paths to fill more than half the sort buffer (%d)" % most
+
+
+@pytest.mark.gpu
+def test_batched_postprocessing_equals_the_per_channel_calls(synth, tmp_path):
+    """The service's post-processing as a batch (VERDICT r3 missing #2): wfst_decoder_rescore_lattices and
+    wfst_decoder_nbest_paths_batch -- one launch per stage for all finalized channels, a workgroup per lattice -- give, channel by
+    channel, what the per-channel calls compute one lattice at a time (on a second decoder fed the same utterances: arc for arc, bit
+    for bit), for the second LM pass and for the n-best with and without it; a channel list, and the kept results' lifetime."""
+    import time
+
+    import gpu_util as G
+
+    W = G.wfstdec
+    g, m, gp, p1, p2, lls = _setup(synth, tmp_path, 0)
+    lls = lls + [ll[:30] for ll in lls]   # (a second helping, shorter: other lattices)
+    graph = W.Graph.load(gp)
+    graph.set_tid2pdf(m)
+    L1, L2 = W.Lm.load(p1, -1.0), W.Lm.load(p2, 1.0)
+    cd = dict(beam=11.0, max_active=7000, min_active=0, lattice_beam=6.0)
+    decs = []
+    for _ in range(2):
+        dec = W.BatchDecoder(graph, G.gpu_config(cd), len(lls), max_frames=64, max_tokens_per_frame=32768, arena_tokens=1 << 20, lattice_links=1 << 21)
+        dev = G.upload(lls)
+        dec.init()
+        dec.advance([t.data_ptr() for t in dev], [int(x.shape[0]) for x in lls], 300)
+        dec.finalize()
+        decs.append(dec)
+    A, B = decs   # A: batched; B: one channel at a time
+    C = len(lls)
+    eq = lambda x, y: (x is None and y is None) or (x is not None and y is not None and all(np.array_equal(x[k], y[k]) for k in x))
+    same_paths = lambda x, y: len(x) == len(y) and all(np.array_equal(p[k], q[k]) for p, q in zip(x, y) for k in ("olabel", "graph", "acoustic")) \
+        and all(np.float32(p["tot"]).tobytes() == np.float32(q["tot"]).tobytes() for p, q in zip(x, y))
+    t0 = time.perf_counter()
+    A.rescore_lattices(L1, L2)
+    got = [A.rescored_lattice(c, L1, L2) for c in range(C)]
+    t_batch = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want = [B.rescored_lattice(c, L1, L2) for c in range(C)]
+    t_single = time.perf_counter() - t0
+    assert sum(x is not None for x in want) >= C // 2
+    for c in range(C):
+        assert eq(got[c], want[c]), "second pass, channel %d" % c
+    for n, lms in ((10, (L1, L2)), (5, (None, None)), (300, (None, None))):
+        A.nbest_paths_batch(n, *lms)
+        for c in range(C):
+            assert same_paths(A.nbest_paths(c, n, *lms), B.nbest_paths(c, n, *lms)), "n-best %d, channel %d" % (n, c)
+    # a channel list; a request the batch did not cover is computed alone (and agrees)
+    A.nbest_paths_batch(7, L1, L2, channels=[C - 1, 0])
+    for c in (0, C - 1, 1):
+        assert same_paths(A.nbest_paths(c, 7, L1, L2), B.nbest_paths(c, 7, L1, L2)), c
+    # the kept results die with the utterance
+    A.init(channels=[0])
+    with pytest.raises(W.WfstError):
+        A.nbest_paths_batch(5, channels=[0])   # not finalized
+    print("second pass of %d lattices: batched %.1f ms, one at a time %.1f ms" % (C, 1e3 * t_batch, 1e3 * t_single))
+    for d in decs:
+        d.free()
+    L1.free()
+    L2.free()
+    graph.free()
