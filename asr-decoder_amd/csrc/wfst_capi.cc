@@ -1151,7 +1151,9 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // CUs: 36.5 vs 40.7 ms per step at 128 channels; a fourth shares a hardware queue and loses; lattice decoders: three as well --
   // the back-pruning steps and the per-frame link work of one group leave room beside two others: 54.2 -> 52.3 ms per step at
   // beam 13, 183.6 -> 170.4 at beam 15)
-  const bool three = (big || L.lattice_links > 0) && n_channels >= 96;
+  // (round 4: best-path decoders too -- with the shorter launches of this round a third group's frame chain finds room beside two
+  // others: 18.65-19.1 -> 18.33 ms per step at 128 channels; four groups: 27.8, a fifth stream shares a hardware queue)
+  const bool three = n_channels >= 96;
   d->n_groups = std::min(O.channel_groups > 0 ? O.channel_groups : three ? 3 : (n_channels >= 64 ? 2 : 1), n_channels);
   if (d->n_groups > 1) {
     d->gstreams.resize(d->n_groups);

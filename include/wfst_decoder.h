@@ -104,8 +104,7 @@ typedef struct wfst_limits {
  * WFST_E_ARG.  (The library reads no environment variables.) */
 typedef struct wfst_options {
   int32_t channel_groups;      /* 1..8: channel groups, each with its own stream and hipGraph; 0 = automatic
-                                  (2 groups from 64 channels up, 3 for biglm and lattice
-                                  decoders from 96 up, else 1)                                   (0)    */
+                                  (2 groups from 64 channels up, 3 from 96 up, else 1)           (0)    */
   int32_t use_hip_graph;       /* replay the frame loop of an advance call as a hipGraph        (1)    */
   int32_t log2_partitions;     /* 0..6: hash partitions (candidate buckets) per channel         (5)    */
   int32_t log2_lds_slots;      /* 8..13: LDS hash slots of one insert workgroup                 (12)   */
