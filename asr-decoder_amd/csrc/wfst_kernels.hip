@@ -1420,6 +1420,11 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
   unsigned long long tq = wall_clock64();
   for (int sub = 0; sub_shift >= 0 && sub < (1 << log2sub); ++sub) {
     __syncthreads();
+    // (the first sweep's records are asked for BEFORE the table is cleared: their round trip runs behind the clearing)
+    int4 r[kInsertUnroll];
+    int rl[kInsertUnroll];
+#pragma unroll
+    for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(k * kInsertThreads + tid, &rl[k]);
     for (int i = tid; i < SL; i += kInsertThreads) { keys[i] = kNoKey; vals[i] = kEmptyVal; }
     if (tid == 0) { s_nstates = 0; s_wpos = 0; s_ok = 1; }
     __syncthreads();
@@ -1429,11 +1434,11 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
     // reference keeps those order-dependent extras (base-inl.h:330) but never expands them.
     // (an item that fits one sweep -- every planned item does -- keeps its records in registers for pass 2)
     const bool one_sweep = n <= kInsertThreads * kInsertUnroll;
-    int4 r[kInsertUnroll];
-    int rl[kInsertUnroll];
     for (int i0 = 0; i0 < n; i0 += kInsertThreads * kInsertUnroll) {
+      if (i0 > 0) {
 #pragma unroll
-      for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid, &rl[k]);
+        for (int k = 0; k < kInsertUnroll; ++k) r[k] = load_rec(i0 + k * kInsertThreads + tid, &rl[k]);
+      }
 #pragma unroll
       for (int k = 0; k < kInsertUnroll; ++k) {
         if (!(__int_as_float(r[k].y) < cutoff)) continue;
