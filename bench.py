@@ -171,7 +171,8 @@ def cpu_decode_all(dec, graph_path, cd, mats, m, n_threads, big=None):
     import pyoracle
 
     h = dec.load_graph(graph_path)
-    cfg = pyoracle.Config(**cd)
+    # (never hand the reference a max_active beyond 10^6: it sizes its hash table by it, base-inl.h:27 -- 68 GB per decoder at INT_MAX)
+    cfg = pyoracle.Config(**dict(cd, max_active=min(int(cd.get("max_active", 1000000)), 1000000)))
     lms = [pyoracle.Lm(dec, big[0], -1.0), pyoracle.Lm(dec, big[1], 1.0)] if big else None
     results = [None] * len(mats)
     nxt = [0]
@@ -209,7 +210,7 @@ def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds, big=None):
     import pyoracle
 
     h = dec.load_graph(graph_path)
-    cfg = pyoracle.Config(**cd)
+    cfg = pyoracle.Config(**dict(cd, max_active=min(int(cd.get("max_active", 1000000)), 1000000)))   # (see cpu_decode_all)
     lms = [pyoracle.Lm(dec, big[0], -1.0), pyoracle.Lm(dec, big[1], 1.0)] if big else None
     f = getattr(dec.lib, ("ref" if kind == "reference" else "oracle") + ("_biglm" if big else "") + "_timed_loop")
     f.restype = C.c_longlong
@@ -296,7 +297,7 @@ def oracle_counts(graph_path, cd, mats, m, order_free=False, want_paths=None):
     f.restype = C.c_int
     h = orc.load_graph(graph_path)
     tot = np.zeros(8, np.int64)
-    cfg = pyoracle.Config(**cd)
+    cfg = pyoracle.Config(**dict(cd, max_active=min(int(cd.get("max_active", 1000000)), 1000000)))   # (see cpu_decode_all)
     lock = threading.Lock()
     idx = [0]
 
@@ -891,7 +892,10 @@ def main():
             if a.cpu_sample > 0:
                 kind, cdec = cpu_decoder()
                 ns3 = min(a.cpu_sample, B)
-                o["divergence_vs_" + kind] = divergence(res3[:ns3], cpu_decode_all(cdec, gpath, cd3, [mats[i] for i in range(ns3)], m, min(ns3, affinity_cpus())))
+                # (the reference sizes its hash table max_active x hash_ratio, base-inl.h:27: 68 GB per decoder object at INT_MAX --
+                # on the host it runs with a max_active that never binds either, 10^6: the same search)
+                cd3_cpu = dict(cd3, max_active=min(int(cd3["max_active"]), 1000000))
+                o["divergence_vs_" + kind] = divergence(res3[:ns3], cpu_decode_all(cdec, gpath, cd3_cpu, [mats[i] for i in range(ns3)], m, min(ns3, affinity_cpus())))
             return o
 
         out["reference_default_limits"] = at_limits(dict(cd, max_active=2147483647, min_active=200),
