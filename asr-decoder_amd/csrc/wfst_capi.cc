@@ -298,6 +298,7 @@ void wfst_options_default(wfst_options *o) {
   o->expand_workgroups = 2048;
   o->insert_workgroups = 768;
   o->upload_slice_frames = 48;
+  o->tile_tokens = 256;
   o->debug = 0;
 }
 
@@ -895,7 +896,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   if (options) O = *options;
   if (O.channel_groups < 0 || O.channel_groups > 8 || O.log2_partitions < 0 || O.log2_partitions > 6 ||
       O.log2_lds_slots < 8 || O.log2_lds_slots > 13 || O.joint_max < 1 || O.expand_workgroups < 1 ||
-      O.insert_workgroups < 1 || O.upload_slice_frames < 0)
+      O.insert_workgroups < 1 || O.upload_slice_frames < 0 || O.tile_tokens < 64 || O.tile_tokens > 256)
     return fail(WFST_E_ARG, "wfst_options field out of range");
   HIP_TRY(hipSetDevice(g->device));
   wfst_limits L = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1088,6 +1089,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // wfst_options.debug are honoured by WFST_AB_SWITCHES builds only.)
   const int ab_bits = kAbSwitches ? O.debug : 0;
   D.staged = (D.fused && !big) ? 1 : 0;
+  D.st_tile_tokens = O.tile_tokens & ~7;
   // the expansion finds the frame's best token itself (its cheapest candidate): the staged kernel of best_row decoders (0x20000: A/B)
   D.best_exp = (D.staged && D.best_row && !(ab_bits & 0x20000)) ? 1 : 0;
   D.seed_tiles = (D.best_row && !(ab_bits & 0x4000)) ? 1 : 0;

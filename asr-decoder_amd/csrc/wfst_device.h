@@ -359,6 +359,7 @@ struct DecoderDev {
   int32_t soft_limit;   // fused best-path decoders: max_tokens_per_frame is not a capacity but a max_active -- a frame may hold more tokens
                         // (while the arena and the candidate buckets take them); GetCutoff then tightens to the limit-th cheapest
   int32_t *degraded;    // [c] frames of the utterance on which that happened (wfst_decoder_get_degraded_frames)
+  int32_t st_tile_tokens;   // staged expansion: frontier tokens per tile (wfst_options.tile_tokens; at most the kernel's 256 threads)
   int32_t best_exp; // staged best_row decoders: ChanCtl::best_next is set by the expansion (the insert launch does not look for the best token)
   int32_t ll_row;   // staged decoders: the tile's whole log-likelihood row is staged in LDS too (rows of at most 3072 columns, a multiple of
                     // four, 16-byte aligned: set by wfst_decoder_advance from the matrices it is handed); 0: one 4-byte gather per arc slot

@@ -853,7 +853,19 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long tq = kTimers ? wall_clock64() : 0ull;
   FrameCtl *fc = D.fctl + group;
-  const TileDesc td_first = D.tiles[(size_t)group * D.tile_cap + min((int)blockIdx.x, D.tile_cap - 1)];
+  // XCD-aware static assignment: workgroups b and b + 8 share an XCD (round-robin dispatch), the tile list holds a channel's tiles
+  // side by side -- within every aligned block of 128 workgroups, XCD x takes 16 CONSECUTIVE tiles (a bijection of the block that
+  // needs no count: the first descriptor is asked for with everything else), so a channel's log-likelihood row and control line
+  // are fetched into two or three L2s instead of all eight
+#ifndef WFST_XCD_TILES
+#define WFST_XCD_TILES 3   // log2 of the run of consecutive tiles an XCD takes (0: none)
+#endif
+  int b0 = (int)blockIdx.x;
+  {
+    constexpr int kRun = WFST_XCD_TILES, kBlk = 8 << kRun;
+    if (kRun && (gridDim.x & (unsigned)(kBlk - 1)) == 0u) b0 = (b0 & ~(kBlk - 1)) | ((b0 & 7) << kRun) | ((b0 >> 3) & ((1 << kRun) - 1));
+  }
+  const TileDesc td_first = D.tiles[(size_t)group * D.tile_cap + min(b0, D.tile_cap - 1)];
   const int total_tiles = fc->total_tiles[par];
   const float kInf = __builtin_huge_valf();
   const int P = D.n_part, log2part = D.log2part, bcap = D.bucket_cap;
@@ -881,7 +893,7 @@ __device__ __forceinline__ void expand_staged_body(const DecoderDev &D, int grou
   if (tid < 64) s_cnt[tid] = 0;
   const float *row_have = nullptr;   // kRow: the row s_row holds
   TileDesc td = td_first;
-  for (int t = blockIdx.x; t < total_tiles;) {
+  for (int t = b0; t < total_tiles;) {
     const int c = td.chan;
     ChanCtl *ctl = D.ctl + c;
     const int n = td.tok_count;
@@ -2447,10 +2459,11 @@ __device__ __forceinline__ void prep_frame(const DecoderDev &D, int c, ChanCtl *
     // resident at once (~1500 workgroups; other groups' launches share them).  Judged per channel on its own token
     // count times the channels of the launch: 16 channels x 4.3 k tokens get 128-token tiles (16.7 -> 14.1 ms per step),
     // 64 channels and more the full 512.
-    int tile_tokens = D.staged ? kStTokens : kTileTokens;
+    int tile_tokens = D.staged ? D.st_tile_tokens : kTileTokens;
     if ((int64_t)n * (int)gridDim.x <= 700ll * 256) tile_tokens = 256;
     if ((int64_t)n * (int)gridDim.x <= 700ll * 128) tile_tokens = 128;
-    if (D.staged) tile_tokens = min(tile_tokens, kStTokens);
+    // (biglm at 64 tokens per tile -- one candidate, one LM walk per thread -- measured the same: 32.4 vs 32.1 ms per step)
+    if (D.staged) tile_tokens = min(tile_tokens, D.st_tile_tokens);
     if (D.staged && !kBig && super_k > 1) tile_tokens = super_k;
     sh.tile_tokens = tile_tokens;
     const int ntiles = (n + tile_tokens - 1) / tile_tokens;
@@ -2636,10 +2649,10 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
     ctl->new_count = 0;
     ctl->best_next = ~0ull;
     ctl->active = 1;
-    int tile_tokens = D.staged ? kStTokens : kTileTokens;   // (as prep_frame)
+    int tile_tokens = D.staged ? D.st_tile_tokens : kTileTokens;   // (as prep_frame)
     if ((int64_t)n * chan_cnt <= 700ll * 256) tile_tokens = 256;
     if ((int64_t)n * chan_cnt <= 700ll * 128) tile_tokens = 128;
-    if (D.staged) tile_tokens = min(tile_tokens, kStTokens);
+    if (D.staged) tile_tokens = min(tile_tokens, D.st_tile_tokens);
     // a binding max_active (or per-frame limit) leaves n - max_eff tokens above the cutoff: compacting tiles (expand_kernel_staged)
     // of as many tokens as hold one tile's worth of live ones
     if (D.staged && need_max && cutoff < beam_cutoff) tile_tokens = super_tile_tokens(n, max_eff);

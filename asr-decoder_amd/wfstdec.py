@@ -67,7 +67,7 @@ class Options(C.Structure):
 
     _fields_ = [("channel_groups", C.c_int32), ("use_hip_graph", C.c_int32), ("log2_partitions", C.c_int32),
                 ("log2_lds_slots", C.c_int32), ("joint_max", C.c_int32), ("expand_workgroups", C.c_int32),
-                ("insert_workgroups", C.c_int32), ("upload_slice_frames", C.c_int32), ("debug", C.c_int32)]
+                ("insert_workgroups", C.c_int32), ("upload_slice_frames", C.c_int32), ("tile_tokens", C.c_int32), ("debug", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -103,6 +103,7 @@ def parse():
     ap.add_argument("--joint-max", type=int, default=0, help="wfst_options.joint_max (0 = library default)")
     ap.add_argument("--expand-wgs", type=int, default=0, help="wfst_options.expand_workgroups (0 = library default)")
     ap.add_argument("--insert-wgs", type=int, default=0, help="wfst_options.insert_workgroups (0 = library default)")
+    ap.add_argument("--tile-tokens", type=int, default=0, help="wfst_options.tile_tokens (0 = library default)")
     ap.add_argument("--row-align", type=int, default=0, help="wfst_graph_options.row_align_slots (0 = library default)")
     ap.add_argument("--no-hip-graph", action="store_true", help="enqueue the frame loop kernel by kernel (rocprofv3 --pmc passes)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances checked bit for bit against the CPU decoder (0 = skip "
@@ -435,7 +436,8 @@ def main():
                           **({"log2_partitions": a.log2_parts} if a.log2_parts >= 0 else {}),
                           **({"log2_lds_slots": a.log2_lds} if a.log2_lds > 0 else {}),
                           **({"joint_max": a.joint_max} if a.joint_max > 0 else {}),
-                          **({"insert_workgroups": a.insert_wgs} if a.insert_wgs > 0 else {}))
+                          **({"insert_workgroups": a.insert_wgs} if a.insert_wgs > 0 else {}),
+                          **({"tile_tokens": a.tile_tokens} if a.tile_tokens > 0 else {}))
 
     def new_decoder(cfg_dict, max_tokens=None):
         return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=max_tokens or a.max_tokens,

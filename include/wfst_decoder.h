@@ -113,6 +113,7 @@ typedef struct wfst_options {
   int32_t insert_workgroups;   /* grid of the insert kernel                                     (768)  */
   int32_t upload_slice_frames; /* wfst_decoder_advance_host: frames per upload slice, 0 = copy
                                   everything before decoding                                    (48)   */
+  int32_t tile_tokens;         /* 64..256: frontier tokens per tile of the staged expansion     (256)  */
   int32_t debug;               /* kernel phase timers (32 closure / 64 insert / 128 expansion, printed when the
                                   decoder is freed)                                              (0)    */
                                /* (0x1000: lattice decoders run the iterated epsilon-closure pass instead of
