@@ -3826,6 +3826,8 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
 // in start->final order; hop 0 is the root token's (0,0,One) arc.
 // =========================================================================================
 constexpr int kBpThreads = 256;
+constexpr int kBpChainLds = 4096;   // hops of the backpointer walk kept in LDS (the walk's own list; longer paths go on in HBM)
+constexpr int kBpFrames = 3072;   // utterances up to this many frames keep their frame bounds in LDS (longer ones read them from HBM)
 
 // kBig (biglm): final costs carry the LM's (ComputeFinalCosts, biglm.h:160-215), hop graph costs are arc
 // weight + lm_score, an epsilon-won token's predecessor is found by (state, LM pair, cost), and after
@@ -3870,7 +3872,13 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   if (lane == 0) { s_all[wave] = best_all; s_fin[wave] = best_fin; s_wf[wave] = best_wf; }
   __syncthreads();
   int32_t *ch = chain + (size_t)bi * cap;
-  const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
+  const int32_t *foff_g = D.frame_off + (size_t)c * (D.max_frames + 2);
+  // the frame bounds of the utterance in LDS (both the walk and the hop pass search them; from HBM a search was nine dependent loads)
+  __shared__ int32_t s_foff[kBpFrames + 2];
+  const bool foff_lds = nd + 2 <= kBpFrames + 2;
+  if (foff_lds) for (int i = tid; i < nd + 2; i += kBpThreads) s_foff[i] = foff_g[i];
+  const int32_t *foff = foff_lds ? s_foff : foff_g;
+  __shared__ int32_t s_chain[kBpChainLds];   // the walk's hops, last hop first
   __shared__ int s_t, s_need, s_lo, s_hi, s_found;
   __shared__ float s_extra0;   // extra cost of the best path's tokens after FinalizeDecoding (0 except in biglm, below)
   if (tid == 0) {
@@ -3900,33 +3908,52 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   // whole workgroup scans its frame for the token of the arc's source state.
   for (;;) {
     __syncthreads();
-    const int t = s_t;
-    if (t < 0) break;
+    if (s_t < 0) break;
     if (tid == 0) {
-      const int4 T = tok[t];
-      if (s_len < cap) ch[cap - 1 - s_len] = t;
-      ++s_len;
+      // resolved backpointers are followed in one go (a dependent load per hop, nothing else on the chain); the walk stops at a
+      // token won by an epsilon arc, whose predecessor the whole workgroup looks for
+      int t = s_t, len = s_len;
+      const uint32_t idx_mask = D.tok_idx_bits >= 31 ? 0x7FFFFFFFu : ((1u << D.tok_idx_bits) - 1u);   // (a degree code may sit above the index)
       s_need = -1;
-      if (T.z <= kPrevUnresolved) {
-        int lo = 0, hi = nd + 1;  // frame of t: frame_off[f] <= t < frame_off[f+1]
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (foff[mid] <= t) lo = mid; else hi = mid;
+      while (t >= 0 && len < (1 << 24)) {   // (the bound: a damaged arena must not hang the device)
+        const int4 T = tok[t];
+        // (the hop list stays in LDS until the walk is over: on this target a load issued behind a global store waits for the store)
+        if (len < kBpChainLds) s_chain[len] = t;
+        else if (len < cap) ch[cap - 1 - len] = t;
+        ++len;
+        if (T.z <= kPrevUnresolved) {
+          int lo = 0, hi = nd + 1;  // frame of t: frame_off[f] <= t < frame_off[f+1]
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (foff[mid] <= t) lo = mid; else hi = mid;
+          }
+          s_lo = foff[lo];
+          s_hi = foff[lo + 1];
+          s_need = D.g.arc_src[(uint32_t)T.w & kArcMask] & 0x7FFFFFFF;
+          s_found = -1;
+          break;
         }
-        s_lo = foff[lo];
-        s_hi = foff[lo + 1];
-        s_need = D.g.arc_src[(uint32_t)T.w & kArcMask] & 0x7FFFFFFF;
-        s_found = -1;
-      } else {
-        s_t = T.z >= 0 ? (int)((uint32_t)T.z & (D.tok_idx_bits >= 31 ? 0x7FFFFFFFu : ((1u << D.tok_idx_bits) - 1u))) : T.z;   // (a degree code may sit above the index)
+        t = T.z >= 0 ? (int)((uint32_t)T.z & idx_mask) : T.z;
       }
+      s_t = t;
+      s_len = len;
     }
     __syncthreads();
     if (s_need >= 0) {
-      const int need = s_need;
-      for (int i = s_lo + tid; i < s_hi; i += kBpThreads) {
-        const int4 S = tok[i];
-        if (S.x != need) continue;
+      const int need = s_need, t = s_t;
+      constexpr int kScanU = 4;   // states of the frame in flight per thread
+      for (int i0 = s_lo + tid; i0 < s_hi; i0 += kBpThreads * kScanU) {
+        int sx[kScanU];
+#pragma unroll
+        for (int u = 0; u < kScanU; ++u) {
+          const int i = i0 + u * kBpThreads;
+          sx[u] = i < s_hi ? reinterpret_cast<const int *>(tok + i)[0] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kScanU; ++u) {
+        const int i = i0 + u * kBpThreads;
+        if (sx[u] != need) continue;
+        [[maybe_unused]] const int4 S = tok[i];
         if constexpr (kBig) {
           // several tokens may sit on the arc's source state, one per LM state: the predecessor is the
           // one whose LM state and cost lead to this token over the winning arc
@@ -3944,6 +3971,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
           if (nlm != tok_lm[t] || __float_as_int(tot) != T.y) continue;
         }
         s_found = i;
+        }
       }
       __syncthreads();
       if (tid == 0) s_t = s_found;  // -1 (never expected) ends the walk
@@ -3953,6 +3981,8 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   __syncthreads();
   const int len = s_len;
   if (len > cap) return;
+  for (int p = tid; p < min(len, kBpChainLds); p += kBpThreads) ch[cap - 1 - p] = s_chain[p];
+  __syncthreads();
   int32_t *il = o_il + (size_t)bi * cap, *ol = o_ol + (size_t)bi * cap;
   float *og = o_g + (size_t)bi * cap, *oa = o_ac + (size_t)bi * cap;
   const float *cut = D.cutoff_hist + (size_t)c * (D.max_frames + 2);
@@ -3962,9 +3992,10 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   const int m_last = ((nd - 1) / D.prune_interval) * D.prune_interval;
   const float extra0 = s_extra0;
   for (int pos = tid; pos < len; pos += kBpThreads) {
-    const int t = ch[cap - len + pos];
+    auto hop_at = [&](int q) { const int p = len - 1 - q; return p < kBpChainLds ? s_chain[p] : ch[cap - 1 - p]; };
+    const int t = hop_at(pos);
     const int4 T = tok[t];
-    const int prev = pos > 0 ? ch[cap - len + pos - 1] : -1;  // the chain itself holds the resolved backpointers
+    const int prev = pos > 0 ? hop_at(pos - 1) : -1;  // the chain itself holds the resolved backpointers
     if (prev < 0) {  // base-inl.h:1193-1198
       il[pos] = 0; ol[pos] = 0; og[pos] = 0.f; oa[pos] = 0.f;
       continue;
