@@ -209,6 +209,14 @@ struct wfst_decoder {
   std::vector<int32_t> det_live_nd;   // NumFramesDecoded() the cached lattice of a LIVE channel belongs to (-1: none)
   std::vector<char> det_live_final = std::vector<char>();
   int32_t det_slots = 0;              // lattices one determinize launch takes (workspace slots)
+  // wfst_decoder_prefetch_determinized: a determinize launch in flight on a side stream (its channels, its result words)
+  bool pf_pending = false;
+  std::vector<int32_t> pf_list, pf_res;
+  int32_t *pf_pin = nullptr;          // [2][n_channels * 4] pinned: the channel list going up, the launch's result words coming down (a copy from or
+                                      // to pageable memory would hold the calling thread until the launch is over)
+  DevBuf<int32_t> pf_dev;
+  hipStream_t det_stream = nullptr;   // (a decoder without channel groups; otherwise the second group's stream, idle between advances)
+  hipEvent_t pf_ev_start = nullptr, pf_ev_done = nullptr;
   // host-fed log-likelihood history (advance_host)
   hipStream_t copy_stream = nullptr;  // host -> device uploads of advance_host
   // pruned lattices fetched from the device (lattice mode): filled for ALL finalized channels by the
@@ -252,7 +260,11 @@ struct wfst_decoder {
   ~wfst_decoder() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (pf_pending && pf_ev_done) (void)hipEventSynchronize(pf_ev_done);   // (a prefetching determinizer still reads the decoder's buffers)
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (det_stream) (void)hipStreamDestroy(det_stream);
+    if (pf_ev_start) (void)hipEventDestroy(pf_ev_start);
+    if (pf_ev_done) (void)hipEventDestroy(pf_ev_done);
     if (lat_pin) (void)hipHostFree(lat_pin);
     if (bp_pin) (void)hipHostFree(bp_pin);
     for (float *p : hist_dev)
@@ -265,6 +277,7 @@ struct wfst_decoder {
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
+    if (pf_pin) (void)hipHostFree(pf_pin);
     pair_keys.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
     det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
     cmp_ws.release(); cmp_result.release(); cmp_fin.release(); cmp_out_a.release(); cmp_out_w.release();
@@ -1230,9 +1243,12 @@ static int stage_channels(wfst_decoder *d, const int32_t *channels, int32_t n, c
   return WFST_OK;
 }
 
+static int finish_prefetch(wfst_decoder *d);
+
 int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n) {
   if (!d) return fail(WFST_E_ARG, "NULL decoder");
   HIP_TRY(hipSetDevice(d->device));
+  { const int rcp = finish_prefetch(d); if (rcp != WFST_OK) return rcp; }   // (the determinizer may be reading these channels' lattices)
   const int32_t *dev;
   int32_t cnt;
   int rc = stage_channels(d, channels, n, &dev, &cnt);
@@ -1259,6 +1275,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   if (!loglikes || !n_frames_ready) return fail(WFST_E_ARG, "NULL loglikes / n_frames_ready");
   const int32_t cnt = channels ? n : d->n_channels;
   if (cnt <= 0 || cnt > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
+  { const int rcp = finish_prefetch(d); if (rcp != WFST_OK) return rcp; }   // (a prefetching determinizer borrows the second group's stream)
   if (stride <= d->graph->max_col)
     return fail(WFST_E_ARG, "stride too small: the graph reads log-likelihood column " + std::to_string(d->graph->max_col));
   if (d->D.stride != 0 && d->D.stride != stride) {
@@ -1494,6 +1511,7 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
 int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
   if (!d) return fail(WFST_E_ARG, "NULL decoder");
   HIP_TRY(hipSetDevice(d->device));
+  { const int rcp = finish_prefetch(d); if (rcp != WFST_OK) return rcp; }
   const int32_t *dev;
   int32_t cnt;
   int rc = stage_channels(d, channels, n, &dev, &cnt);
@@ -2009,6 +2027,89 @@ static int ensure_det_workspace(wfst_decoder *d) {
   return WFST_OK;
 }
 
+// The results of a determinize launch over `list` (workspace slot i = list[i]; res = the launch's result words, on their way or
+// here already) into the host cache: waits for the decoder's stream, checks the channels' error words, fetches the arcs.
+static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &list, const std::vector<int32_t> &res, bool live, int32_t use_final_probs) {
+  DetDev &X = d->det;
+  int rc = read_ctl(d);  // synchronises the stream
+  if (rc != WFST_OK) return rc;
+  rc = check_ctl_errors(d);
+  if (rc != WFST_OK) return rc;
+  for (int i = 0; i < (int)list.size(); ++i) {
+    wfst_decoder::DetLattice &L = d->det_cache[(size_t)list[i]];
+    L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
+    L.err = res[4 * i + 2];   // reported when THIS channel's lattice is asked for
+    d->det_cached[(size_t)list[i]] = live ? 0 : 1;
+    if (live) { d->det_live_nd[(size_t)list[i]] = d->h_decoded[list[i]]; d->det_live_final[(size_t)list[i]] = use_final_probs ? 1 : 0; }
+    if (L.err) continue;
+    L.n_states = res[4 * i];
+    L.n_proper = res[4 * i + 3];
+    const size_t na = (size_t)res[4 * i + 1];
+    L.a.resize(na);
+    L.w.resize(na);
+    if (na) {
+      HIP_TRY(hipMemcpyAsync(L.a.data(), X.out_a + (size_t)i * X.out_cap, na * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
+      HIP_TRY(hipMemcpyAsync(L.w.data(), X.out_w + (size_t)i * X.out_cap, na * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return WFST_OK;
+}
+
+// GetLattice ahead of its request (include/wfst_decoder.h): the finalized channels not determinized yet go to the determinizer
+// NOW, on a side stream -- one lane per lattice, a launch as long as its largest lattice, beside which the decoder's own stream
+// serves best paths and n-best lists (both only read the raw lattices; the arena-index -> lattice-state map the n-best search
+// and the determinizer each write is the same map).  The first wfst_decoder_get_determinized_lattice finds the work done or waits.
+int wfst_decoder_prefetch_determinized(wfst_decoder *d) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice needs a decoder created with wfst_limits.lattice_links > 0");
+  HIP_TRY(hipSetDevice(d->device));
+  int rc = finish_prefetch(d);
+  if (rc != WFST_OK) return rc;
+  rc = ensure_det_workspace(d);
+  if (rc != WFST_OK) return rc;
+  std::vector<int32_t> list;
+  for (int c = 0; c < d->n_channels && (int32_t)list.size() < d->det_slots; ++c)   // (one launch's worth; the rest on request)
+    if (d->h_state[c] == 2 && !d->det_cached[c]) list.push_back(c);
+  if (list.empty()) return WFST_OK;
+  hipStream_t side = d->n_groups > 1 ? d->gstreams[1] : d->det_stream;
+  if (!side) {
+    HIP_TRY(hipStreamCreateWithFlags(&d->det_stream, hipStreamNonBlocking));
+    side = d->det_stream;
+  }
+  if (!d->pf_ev_start) {
+    HIP_TRY(hipEventCreateWithFlags(&d->pf_ev_start, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d->pf_ev_done, hipEventDisableTiming));
+  }
+  if (!d->pf_dev.p) {
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(d->pf_dev.alloc((size_t)d->n_channels));
+    HIP_TRY(hipHostMalloc((void **)&d->pf_pin, (size_t)d->n_channels * 8 * 4, hipHostMallocDefault));
+  }
+  d->pf_list = list;
+  int32_t *pin_list = d->pf_pin, *pin_res = d->pf_pin + (size_t)d->n_channels * 4;
+  for (size_t i = 0; i < list.size(); ++i) pin_list[i] = list[i];
+  d->post_dev_list.clear();   // (the slots are about to hold other lattices than the last batched call's)
+  HIP_TRY(hipMemcpyAsync(d->pf_dev.p, pin_list, list.size() * 4, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipEventRecord(d->pf_ev_start, d->stream));   // FinalizeDecoding's pruning and listing are done, the channel list is up
+  HIP_TRY(hipStreamWaitEvent(side, d->pf_ev_start, 0));
+  launch_determinize(d->D, d->det, d->pf_dev.p, (int32_t)list.size(), side);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(pin_res, d->det.result, list.size() * 4 * 4, hipMemcpyDeviceToHost, side));
+  HIP_TRY(hipEventRecord(d->pf_ev_done, side));
+  d->pf_pending = true;
+  return WFST_OK;
+}
+
+static int finish_prefetch(wfst_decoder *d) {
+  if (!d->pf_pending) return WFST_OK;
+  d->pf_pending = false;
+  HIP_TRY(hipEventSynchronize(d->pf_ev_done));
+  d->pf_res.assign(d->pf_pin + (size_t)d->n_channels * 4, d->pf_pin + (size_t)d->n_channels * 4 + d->pf_list.size() * 4);
+  // (a channel initialised or finalized anew since the launch: hooks in front of those calls came here first)
+  return harvest_determinized(d, d->pf_list, d->pf_res, false, 1);
+}
+
 int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, int32_t cap_states,
                                           int32_t cap_arcs, int32_t *n_states, int32_t *n_arcs, int32_t *st_final,
                                           int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel, int32_t *a_olabel,
@@ -2025,6 +2126,8 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
   {
     const int rcw = ensure_det_workspace(d);
     if (rcw != WFST_OK) return rcw;
+    const int rcp = finish_prefetch(d);   // (the workspace slots are the prefetch's until it is harvested)
+    if (rcp != WFST_OK) return rcp;
   }
   // a live channel's result is kept for as long as the channel has not moved on (the size query and the fetch of one request
   // are two calls: the second reuses the first's work)
@@ -2051,28 +2154,8 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
       HIP_TRY(hipGetLastError());
       std::vector<int32_t> res((size_t)cnt * 4);
       HIP_TRY(hipMemcpyAsync(res.data(), X.result, res.size() * 4, hipMemcpyDeviceToHost, d->stream));
-      rc = read_ctl(d);  // synchronises the stream
+      rc = harvest_determinized(d, list, res, live, use_final_probs);
       if (rc != WFST_OK) return rc;
-      rc = check_ctl_errors(d);
-      if (rc != WFST_OK) return rc;
-      for (int i = 0; i < cnt; ++i) {
-        wfst_decoder::DetLattice &L = d->det_cache[(size_t)list[i]];
-        L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
-        L.err = res[4 * i + 2];   // reported when THIS channel's lattice is asked for
-        d->det_cached[(size_t)list[i]] = live ? 0 : 1;
-        if (live) { d->det_live_nd[(size_t)list[i]] = d->h_decoded[list[i]]; d->det_live_final[(size_t)list[i]] = use_final_probs ? 1 : 0; }
-        if (L.err) continue;
-        L.n_states = res[4 * i];
-        L.n_proper = res[4 * i + 3];
-        const size_t na = (size_t)res[4 * i + 1];
-        L.a.resize(na);
-        L.w.resize(na);
-        if (na) {
-          HIP_TRY(hipMemcpyAsync(L.a.data(), X.out_a + (size_t)i * X.out_cap, na * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
-          HIP_TRY(hipMemcpyAsync(L.w.data(), X.out_w + (size_t)i * X.out_cap, na * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
-        }
-      }
-      HIP_TRY(hipStreamSynchronize(d->stream));
     }
   }
   const wfst_decoder::DetLattice &L = d->det_cache[(size_t)channel];
@@ -2185,6 +2268,8 @@ static int postprocess_batch(wfst_decoder *d, const int32_t *channels, int32_t n
   }
   if (all.empty()) return WFST_OK;
   int rc = ensure_det_workspace(d);
+  if (rc != WFST_OK) return rc;
+  rc = finish_prefetch(d);
   if (rc != WFST_OK) return rc;
   DetDev &X = d->det;
   const size_t chunk = (size_t)std::max(1, std::min(d->det_slots, 128));

@@ -310,6 +310,7 @@ int main(int argc, char **argv) {
             decode.InitDecoding(ch);
             decode.AdvanceDecodingHost(ch, rows, ready, stride);
             decode.FinalizeDecoding(ch);
+            if (want_lattice && determinize && !second) decode.PrefetchLattices();   // the determinizer runs beside the best paths
             decode.GetBestPaths(ch, &o.best, &o.ok);
             if (want_lattice && determinize) {
               o.lats.assign(n, Lattice());

@@ -532,6 +532,9 @@ bool GpuBatchDecoder::GetLattice(int channel, Lattice *ofst, ArpaLm *oldlm, Arpa
 bool GpuBatchDecoder::GetRawLattice(int channel, Lattice *ofst, bool use_final_probs) {
   return RawLatticeOfChannel(_dec, channel, ofst, use_final_probs);
 }
+void GpuBatchDecoder::PrefetchLattices() {
+  if (wfst_decoder_prefetch_determinized(_dec) != WFST_OK) Fatal("wfst_decoder_prefetch_determinized");
+}
 void GpuBatchDecoder::GetLattices(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok, ArpaLm *oldlm,
                                   ArpaLm *newlm, bool use_final_probs) {
   if (!oldlm || !newlm) throw std::runtime_error("second-pass GetLattice needs both LMs");

@@ -282,6 +282,9 @@ class GpuBatchDecoder {
   bool GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n);
   bool GetNbest(int channel, std::vector<Lattice> &nbest_paths, int n, ArpaLm *oldlm, ArpaLm *newlm);
   bool GetNbestShortlist(int channel, std::vector<Lattice> &nbest_paths, int n);   // (n <= 16; see GpuLatticeDecoder)
+  // GetLattice ahead of its request: the finalized channels go to the determinizer now, on a side stream; GetBestPaths / GetNbest
+  // run beside it and the first GetLattice finds the work done or waits (wfst_decoder_prefetch_determinized)
+  void PrefetchLattices();
   // GetLattice of one channel; the first call after FinalizeDecoding determinizes every finalized channel in one launch
   bool GetLattice(int channel, Lattice *ofst, bool use_final_probs = true);
   bool GetLattice(int channel, Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs = true);   // with the second LM pass

@@ -33,6 +33,7 @@ SYMBOLS = [
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
     "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice", "wfst_decoder_get_nbest_paths",
     "wfst_decoder_get_degraded_frames", "wfst_decoder_get_path_flags", "wfst_decoder_rescore_lattices", "wfst_decoder_nbest_paths_batch",
+    "wfst_decoder_prefetch_determinized",
 ]
 
 
@@ -340,6 +341,11 @@ class BatchDecoder:
                                                   _i32(il), _i32(ol), _f32(gr), _f32(ac)))
         return dict(n_states=S, st_final=fin, st_frame=fr, st_state=gs, st_cost=co, a_src=src, a_dst=dst, a_ilabel=il,
                     a_olabel=ol, a_graph=gr, a_acoustic=ac)
+
+    def prefetch_determinized(self):
+        """Start the determinization of every finalized channel now, on a side stream (wfst_decoder_prefetch_determinized):
+        best_paths() / nbest() run beside it, determinized_lattice(c) finds the work done or waits."""
+        _check(lib().wfst_decoder_prefetch_determinized(self.h))
 
     def determinized_lattice(self, channel, use_final_probs=True):
         """GetLattice (GetRawLattice + DeterminizeLatticeWrapper) of a channel: dict of numpy arrays, or None."""

@@ -103,6 +103,8 @@ def parse():
     ap.add_argument("--joint-max", type=int, default=0, help="wfst_options.joint_max (0 = library default)")
     ap.add_argument("--expand-wgs", type=int, default=0, help="wfst_options.expand_workgroups (0 = library default)")
     ap.add_argument("--insert-wgs", type=int, default=0, help="wfst_options.insert_workgroups (0 = library default)")
+    ap.add_argument("--no-prefetch", action="store_true", help="lattice mode with --determinize: the determinizer starts when the first "
+                    "lattice is asked for (behind the best paths and the n-best lists) instead of right after FinalizeDecoding")
     ap.add_argument("--tile-tokens", type=int, default=0, help="wfst_options.tile_tokens (0 = library default)")
     ap.add_argument("--row-align", type=int, default=0, help="wfst_graph_options.row_align_slots (0 = library default)")
     ap.add_argument("--no-hip-graph", action="store_true", help="enqueue the frame loop kernel by kernel (rocprofv3 --pmc passes)")
@@ -463,6 +465,8 @@ def main():
                 dec.advance(ptrs, ready, P)
             t2 = time.perf_counter()
             dec.finalize()
+            if a.lattice_links > 0 and a.determinize and not a.no_prefetch:
+                dec.prefetch_determinized()   # GetLattice's determinizer starts now, beside the best paths and the n-best lists
             t3 = time.perf_counter()
             if os.environ.get("WFST_BENCH_BREAKDOWN"):
                 dec.sync()

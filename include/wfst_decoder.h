@@ -322,6 +322,17 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
                                  int32_t *st_state, float *st_cost, int32_t *a_src, int32_t *a_dst,
                                  int32_t *a_ilabel, int32_t *a_olabel, float *a_graph, float *a_acoustic);
 
+/* GetLattice ahead of its request: sends the finalized channels that have no determinized lattice yet to the determinizer
+ * NOW, on a side stream, and returns at once (the determinizer is one lane per lattice and a launch lasts as long as its
+ * largest lattice -- tens of milliseconds during which the device is all but idle).  wfst_decoder_get_best_path and
+ * wfst_decoder_get_nbest served meanwhile run beside it; the first wfst_decoder_get_determinized_lattice (or batched
+ * post-processing call) finds the work done or waits for it.  Results and errors are those of the calls that fetch: this
+ * call changes when the work is done, not what it gives (kaldi-online-nnet3-my-decoder.cc:50-105 asks for the best path,
+ * the n-best list and the lattice of a finished utterance one after the other).  One launch's worth of channels
+ * (wfst_limits.det_workspace_bytes); the rest are determinized on request.  wfst_decoder_init / _advance / _finalize wait for
+ * a prefetch in flight. */
+int wfst_decoder_prefetch_determinized(wfst_decoder *d);
+
 /* GetLattice(Lattice*, use_final_probs) (base-inl.h:850-866) = GetRawLattice + DeterminizeLatticeWrapper
  * (newfst/lattice-determinize-api.cc:5-21: Invert, ArcSort, LatticeDeterminizer::Determinize in the (graph,
  * acoustic) lattice semiring, OutputNoolabel, Invert): the word-level deterministic lattice, built on the

@@ -137,3 +137,90 @@ def test_mid_size_batch_and_refusals(synth, tmp_path):
         d2.determinized_lattice(0)
     d2.free()
     graph.free()
+
+
+def test_prefetched_determinization_gives_the_same_lattices(synth, tmp_path):
+    """wfst_decoder_prefetch_determinized changes WHEN the determinizer runs (right after FinalizeDecoding, on a side stream,
+    beside the best paths and the n-best lists), not what anything returns: best paths, n-best lists, raw and determinized
+    lattices equal those of a decoder that never prefetched -- with one channel group and with two, with channels initialised
+    anew while a prefetch is in flight, and as a decoder's first determinizer use."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(20000, seed=17, n_tid=2000, n_words=3000)
+    m = synth.default_tid2pdf(2000)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=5.0)
+    mats = [synth.make_loglikes(g, T, 1000, m, seed=160 + i, mu=-2.4)[0] for i, T in enumerate([120, 80, 120, 9, 120, 55, 100, 33])]
+    lim = dict(max_frames=128, max_tokens_per_frame=32768, arena_tokens=1 << 20, lattice_links=1 << 21)
+    dev = G.upload(mats)
+    ptrs, T = [t.data_ptr() for t in dev], [int(x.shape[0]) for x in mats]
+
+    def run(dec, prefetch):
+        dec.init()
+        dec.advance(ptrs, T, 1000)
+        dec.finalize()
+        if prefetch:
+            dec.prefetch_determinized()
+        best = dec.best_paths()
+        nb = dec.nbest(4)
+        det = [dec.determinized_lattice(c) for c in range(len(mats))]
+        raw = [dec.raw_lattice(c) for c in range(len(mats))]
+        return best, nb, det, raw
+
+    def same(a, b, what):
+        for x, y in zip(a[0], b[0]):
+            assert np.array_equal(x["words"], y["words"]) and x["tot_score"] == y["tot_score"], what
+        for x, y in zip(a[1], b[1]):
+            assert len(x) == len(y), what + " n-best"
+            for px, py in zip(x, y):
+                assert np.array_equal(px["words"], py["words"]) and px["tot_score"] == py["tot_score"] and px["lm_score"] == py["lm_score"], what + " n-best"
+        for x, y in zip(a[2], b[2]):
+            assert (x is None) == (y is None), what
+            if x is not None:
+                for key in x:
+                    assert np.array_equal(x[key], y[key]), (what, key)
+        for x, y in zip(a[3], b[3]):   # (a raw lattice lists its states in arena order, which is a run's own: the same states and arcs)
+            assert np.array_equal(np.sort(x["st_state"]), np.sort(y["st_state"])) and len(x["a_src"]) == len(y["a_src"]), what + " raw"
+            assert np.array_equal(np.sort(x["a_graph"]), np.sort(y["a_graph"])) and np.array_equal(np.sort(x["a_acoustic"]), np.sort(y["a_acoustic"])), what + " raw"
+
+    plain = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), **lim)
+    want = run(plain, False)
+    plain.free()
+    for opt in (dict(channel_groups=1), dict(channel_groups=2)):
+        dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), options=G.wfstdec.Options(**opt), **lim)
+        same(run(dec, True), want, "first use %s" % opt)      # the decoder's first determinizer use IS the prefetch
+        same(run(dec, True), want, "second utterance %s" % opt)
+        # a prefetch nobody harvests before the channels are initialised anew: init waits for it, the next utterance is unharmed
+        dec.init()
+        dec.advance(ptrs, T, 1000)
+        dec.finalize()
+        dec.prefetch_determinized()
+        same(run(dec, False), want, "after an abandoned prefetch %s" % opt)
+        # twice in a row, then a batched second pass right behind it: the slots are harvested before they are reused
+        dec.init()
+        dec.advance(ptrs, T, 1000)
+        dec.finalize()
+        dec.prefetch_determinized()
+        dec.prefetch_determinized()
+        det = [dec.determinized_lattice(c) for c in range(len(mats))]
+        for x, y in zip(det, want[2]):
+            for key in x:
+                assert np.array_equal(x[key], y[key]), key
+        dec.free()
+    # a decoder freed with a prefetch in flight
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), **lim)
+    dec.init()
+    dec.advance(ptrs, T, 1000)
+    dec.finalize()
+    dec.prefetch_determinized()
+    dec.free()
+    # not in lattice mode: refused
+    d2 = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), 1, max_frames=128, max_tokens_per_frame=32768, arena_tokens=1 << 20)
+    d2.init()
+    with pytest.raises(G.wfstdec.WfstError):
+        d2.prefetch_determinized()
+    d2.free()
+    graph.free()
