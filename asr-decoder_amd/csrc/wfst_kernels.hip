@@ -1935,6 +1935,12 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
 template <bool kLat, bool kBig>
 __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, u64 *nZ_out) {
   const int tid = threadIdx.x;
+#ifndef WFST_BIG_CLOSURE_UNROLL
+#define WFST_BIG_CLOSURE_UNROLL 1
+#endif
+  // worklist entries a thread takes through a sweep together.  biglm: ONE -- a frame seeds a few hundred entries for the 1024
+  // threads, and an entry's LM state, keys and claims held four-fold put 21 registers of the closure launch into scratch
+  constexpr int kCU = kBig ? WFST_BIG_CLOSURE_UNROLL : kClosureUnroll;
   ChanCtl *ctl = D.ctl + c;
   u64 *ekeys = kBig ? D.eps_keys + (size_t)c * D.ecap : nullptr;
   u64 *vals = D.eps_vals + (size_t)c * D.ecap;
@@ -1963,13 +1969,13 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
     const int4 *wl_cur = wl + (size_t)cur * D.wl_cap;
     int4 *wl_nxt = wl + (size_t)(cur ^ 1) * D.wl_cap;
     // four worklist entries per thread in flight (independent load chains issued together)
-    for (int i0 = 0; i0 < nw; i0 += kBT * kClosureUnroll) {
-      int4 ent[kClosureUnroll];
-      uint2 si[kClosureUnroll];
-      int4 arc0[kClosureUnroll];
-      bool live[kClosureUnroll];
+    for (int i0 = 0; i0 < nw; i0 += kBT * kCU) {
+      int4 ent[kCU];
+      uint2 si[kCU];
+      int4 arc0[kCU];
+      bool live[kCU];
 #pragma unroll
-      for (int k = 0; k < kClosureUnroll; ++k) {
+      for (int k = 0; k < kCU; ++k) {
         const int i = i0 + k * kBT + tid;
         live[k] = i < nw;
         ent[k] = live[k] ? wl_cur[i] : make_int4(0, 0, 0x7F800000, 0);
@@ -1977,20 +1983,20 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
         // another entry, so a stale cost only repeats work the atomicMin below rejects
         live[k] = live[k] && (__int_as_float(ent[k].z) < cutoff);  // base-inl.h:391
       }
-      uint32_t flat[kClosureUnroll];
+      uint32_t flat[kCU];
       // biglm: what an LM step will need is asked for as early as its address is known -- the pair's LM states with the row header,
       // the arc's output label with the arc -- two round trips off every round of the pass
-      u64 pk[kBig ? kClosureUnroll : 1];
-      int ol0[kBig ? kClosureUnroll : 1];
+      u64 pk[kBig ? kCU : 1];
+      int ol0[kBig ? kCU : 1];
 #pragma unroll
-      for (int k = 0; k < kClosureUnroll; ++k) {
+      for (int k = 0; k < kCU; ++k) {
         if constexpr (kBig) pk[k] = live[k] ? ld_agent(&D.pair_keys[(size_t)c * D.pair_cap + ent[k].x]) : 0ull;
         const int4 hdr = live[k] ? D.g.arcs[ent[k].y] : make_int4(0, 0, 0, 0);
         si[k] = make_uint2((uint32_t)ent[k].y + 1u, (uint32_t)hdr.x);
         flat[k] = kBig ? 0u : (uint32_t)hdr.w;  // (first eps_flat entry << 3) | entries; 0: iterate
       }
 #pragma unroll
-      for (int k = 0; k < kClosureUnroll; ++k) {
+      for (int k = 0; k < kCU; ++k) {
         const bool has = live[k] && (si[k].y & kEpsMask);
         arc0[k] = !has ? make_int4(0, 0, 0, 0) : (flat[k] & 7u) ? D.g.eps_flat[flat[k] >> 3] : D.g.arcs[si[k].x];
         if constexpr (kBig) ol0[k] = has ? D.g.arc_olabel[si[k].x] : 0;
@@ -2023,10 +2029,10 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
           else atomicOr(&sh.err, kErrWorklistFull);
         }
       };
-      int nit[kClosureUnroll];             // levels of entry k: paths of its flattened closure, or its epsilon arcs
-      float pc[kClosureUnroll][kFlatMax - 1];  // flattened closure: cost of path q (a later path's parent)
+      int nit[kCU];             // levels of entry k: paths of its flattened closure, or its epsilon arcs
+      float pc[kCU][kFlatMax - 1];  // flattened closure: cost of path q (a later path's parent)
 #pragma unroll
-      for (int k = 0; k < kClosureUnroll; ++k) {
+      for (int k = 0; k < kCU; ++k) {
         nit[k] = !live[k] ? 0 : (flat[k] & 7u) ? (int)(flat[k] & 7u) : (int)(si[k].y & kEpsMask);
 #pragma unroll
         for (int q = 0; q < kFlatMax - 1; ++q) pc[k][q] = __builtin_huge_valf();
@@ -2034,23 +2040,23 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
       for (int e = 0;; ++e) {
         bool more = false;
 #pragma unroll
-        for (int k = 0; k < kClosureUnroll; ++k) more |= e < nit[k];
+        for (int k = 0; k < kCU; ++k) more |= e < nit[k];
         if (!__ballot(more)) break;
-        int4 E[kClosureUnroll];
-        int OL[kBig ? kClosureUnroll : 1];
+        int4 E[kCU];
+        int OL[kBig ? kCU : 1];
 #pragma unroll
-        for (int k = 0; k < kClosureUnroll; ++k) {
+        for (int k = 0; k < kCU; ++k) {
           E[k] = e >= nit[k] ? make_int4(0, 0, 0, 0)
                  : e == 0 ? arc0[k]
                  : (flat[k] & 7u) ? D.g.eps_flat[(flat[k] >> 3) + e] : D.g.arcs[si[k].x + e];
           if constexpr (kBig) OL[k] = e >= nit[k] ? 0 : e == 0 ? ol0[k] : D.g.arc_olabel[si[k].x + e];
         }
-        int c_ord[kClosureUnroll], c_row[kClosureUnroll], c_lm[kClosureUnroll];
-        float c_tot[kClosureUnroll];
-        u64 c_packed[kClosureUnroll], c_old[kClosureUnroll];
-        uint32_t c_flags[kClosureUnroll];  // 1 live, 2 out_eps, 4 requeue
+        int c_ord[kCU], c_row[kCU], c_lm[kCU];
+        float c_tot[kCU];
+        u64 c_packed[kCU], c_old[kCU];
+        uint32_t c_flags[kCU];  // 1 live, 2 out_eps, 4 requeue
 #pragma unroll
-        for (int k = 0; k < kClosureUnroll; ++k) {
+        for (int k = 0; k < kCU; ++k) {
           c_flags[k] = 0; c_ord[k] = 0; c_row[k] = 0; c_lm[k] = 0; c_tot[k] = 0.0f; c_packed[k] = 0;
           if (e >= nit[k]) continue;
           const float cost = __int_as_float(ent[k].z);
@@ -2107,10 +2113,10 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
           c_packed[k] = ((u64)f2o(c_tot[k]) << 32) | kEpsWon | ((c_flags[k] & 2u) ? kEpsOutBit : 0u) | (uint32_t)a;
         }
 #pragma unroll
-        for (int k = 0; k < kClosureUnroll; ++k)
+        for (int k = 0; k < kCU; ++k)
           c_old[k] = (c_flags[k] & 1u) ? atomicMin(&vals[c_ord[k]], c_packed[k]) : 0ull;
 #pragma unroll
-        for (int k = 0; k < kClosureUnroll; ++k)
+        for (int k = 0; k < kCU; ++k)
           if (c_flags[k] & 1u)
             finish(c_ord[k], c_tot[k], (c_flags[k] & 2u) != 0, c_row[k], (c_flags[k] & 4u) != 0, c_lm[k], c_packed[k], c_old[k]);
       }
@@ -2133,15 +2139,15 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
   // scanning the frame for that state -- a few epsilon hops per utterance instead of a dependent
   // lookup chain per token on every frame's critical path.
   u64 best = ~0ull;
-  for (int i0 = 0; fits && i0 < nwon; i0 += kBT * kClosureUnroll) {
-    int od[kClosureUnroll];
+  for (int i0 = 0; fits && i0 < nwon; i0 += kBT * kCU) {
+    int od[kCU];
 #pragma unroll
-    for (int k = 0; k < kClosureUnroll; ++k) {
+    for (int k = 0; k < kCU; ++k) {
       const int i = i0 + k * kBT + tid;
       od[k] = i < nwon ? won[i] : -1;
     }
 #pragma unroll
-    for (int k = 0; k < kClosureUnroll; ++k) {
+    for (int k = 0; k < kCU; ++k) {
       if (od[k] < 0) continue;
       const u64 v = ld_agent(&vals[od[k]]);
       const int idx = ld_agent(&toki[od[k]]);
@@ -2164,15 +2170,15 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
   __syncthreads();  // every read of the table above is done before it is cleared
   if (tid == 0) dbg_phase(D, 2, tq);
   if (kLat && fits) epsilon_links<kBig>(D, c, sh, base, cutoff);
-  for (int i0 = 0; i0 < nocc; i0 += kBT * kClosureUnroll) {  // the list loads of a thread issued together
-    int od[kClosureUnroll];
+  for (int i0 = 0; i0 < nocc; i0 += kBT * kCU) {  // the list loads of a thread issued together
+    int od[kCU];
 #pragma unroll
-    for (int k = 0; k < kClosureUnroll; ++k) {
+    for (int k = 0; k < kCU; ++k) {
       const int i = i0 + k * kBT + tid;
       od[k] = i < nocc ? occ[i] : -1;
     }
 #pragma unroll
-    for (int k = 0; k < kClosureUnroll; ++k) {
+    for (int k = 0; k < kCU; ++k) {
       if (od[k] < 0) continue;
       vals[od[k]] = kEmptyVal;
       if constexpr (kBig) ekeys[od[k]] = kEmptyVal;
