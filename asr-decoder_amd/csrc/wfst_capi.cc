@@ -1356,15 +1356,17 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     }
     return false;
   };
-  // the frame loop of one channel group on stream st
-  auto enqueue_group = [&](int g, hipStream_t st) {
+  // the frame loop of one channel group on stream st: steps [s_lo, s_hi) of the call's gsteps[g]
+  auto enqueue_group = [&](int g, hipStream_t st, int s_lo, int s_hi) {
     const int off = g * per, cnt = std::min(per, d->n_channels - off);
     if (cnt <= 0 || gsteps[g] == 0) return;
-    int par = gpar0[g];
-    // GetCutoff + tile list only -- behind PruneActiveTokens where the call before this one stopped at a multiple of prune_interval
-    if (prune_step(g, -1)) timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par, st); });
-    else timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });
-    for (int s = 0; s < gsteps[g]; ++s) {
+    int par = gpar0[g] ^ (s_lo & 1);
+    if (s_lo == 0) {
+      // GetCutoff + tile list only -- behind PruneActiveTokens where the call before this one stopped at a multiple of prune_interval
+      if (prune_step(g, -1)) timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par, st); });
+      else timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });
+    }
+    for (int s = s_lo; s < s_hi; ++s) {
       // two launches per frame where the decoder allows (wfst_device.h two_launch): the insert launch closes the frame and
       // prepares the next; every gc_stride-th frame is a classic one (its closure launch checks the token arena)
       const bool classic = !d->D.two_launch || (s % d->D.gc_stride) == d->D.gc_stride - 1;
@@ -1383,10 +1385,20 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   // captured kernels and their arguments are identical for every call with the same frame counts.
   // One graph PER CHANNEL GROUP, each launched on its own stream: independent graph launches overlap
   // on the GPU (parallel branches inside one graph were measured to run serially).
-  auto run_group = [&](int g, hipStream_t st) -> int {
+  // A graph launch costs the calling thread ~0.5 us per node BEFORE the device sees the first of them (a 300-frame group: 0.35 ms;
+  // three groups one after the other: the last one's frame chain -- the step's critical path -- started a millisecond late).  A long
+  // call is therefore launched as a short HEAD graph (kHeadSteps frames) and the REST: every group's head is on the device
+  // within microseconds, the rests are submitted while the heads run.  part 0: the whole call as one graph (short calls),
+  // 1: the head, 2: the rest.
+  constexpr int kHeadSteps = 32;
+  auto graphed = [&](int g) { return d->use_graph && !d->profiling && gsteps[g] >= 4; };
+  auto split = [&](int g) { return graphed(g) && gsteps[g] >= 4 * kHeadSteps; };
+  auto run_group = [&](int g, hipStream_t st, int part) -> int {
     if (gsteps[g] == 0) return WFST_OK;
-    if (!(d->use_graph && !d->profiling && gsteps[g] >= 4)) { enqueue_group(g, st); return WFST_OK; }
-    std::vector<int> key = {g, gsteps[g], (int)stride, gpar0[g], (int)d->D.ll_row};
+    if (!graphed(g)) { if (part != 2) enqueue_group(g, st, 0, gsteps[g]); return WFST_OK; }
+    if (!split(g) && part == 2) return WFST_OK;
+    const int s_lo = (split(g) && part == 2) ? kHeadSteps : 0, s_hi = (split(g) && part != 2) ? kHeadSteps : gsteps[g];
+    std::vector<int> key = {g, gsteps[g], (int)stride, gpar0[g], (int)d->D.ll_row, s_lo, s_hi};
     for (int s = -1; s < gsteps[g]; ++s)
       if (prune_step(g, s)) key.push_back(s);   // (the launch sequence differs with the steps that prune)
     auto it = d->graphs.find(key);
@@ -1394,7 +1406,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
       HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      enqueue_group(g, st);
+      enqueue_group(g, st, s_lo, s_hi);
       HIP_TRY(hipStreamEndCapture(st, &graph));
       HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       HIP_TRY(hipGraphDestroy(graph));
@@ -1409,21 +1421,23 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     return WFST_OK;
   };
   if (G == 1) {
-    const int rc = run_group(0, d->stream);
-    if (rc != WFST_OK) return rc;
+    for (int part = 1; part <= 2; ++part) {
+      const int rc = run_group(0, d->stream, part);
+      if (rc != WFST_OK) return rc;
+    }
   } else {
     // group 0 runs on the decoder's own stream, the others fork from it and join it again (every stream in use
     // takes one of the few hardware queues; streams beyond those share a queue and serialise)
     HIP_TRY(hipEventRecord(d->gevents[0], d->stream));  // targets / row pointers are uploaded
-    for (int g = 1; g < G; ++g) {
-      if (gsteps[g] == 0) continue;
-      HIP_TRY(hipStreamWaitEvent(d->gstreams[g], d->gevents[0], 0));
-      const int rc = run_group(g, d->gstreams[g]);
-      if (rc != WFST_OK) return rc;
-      HIP_TRY(hipEventRecord(d->gevents[1 + g], d->gstreams[g]));
-    }
-    {
-      const int rc = run_group(0, d->stream);
+    for (int part = 1; part <= 2; ++part) {   // every group's head first, then the rests
+      for (int g = 1; g < G; ++g) {
+        if (gsteps[g] == 0) continue;
+        if (part == 1) HIP_TRY(hipStreamWaitEvent(d->gstreams[g], d->gevents[0], 0));
+        const int rc = run_group(g, d->gstreams[g], part);
+        if (rc != WFST_OK) return rc;
+        if (part == 2) HIP_TRY(hipEventRecord(d->gevents[1 + g], d->gstreams[g]));
+      }
+      const int rc = run_group(0, d->stream, part);
       if (rc != WFST_OK) return rc;
     }
     for (int g = 1; g < G; ++g)
@@ -1749,6 +1763,26 @@ int wfst_lattice_to_vector_batch(const int32_t *ilabel, const int32_t *olabel, c
     if (n_words) n_words[p] = nw;
     if (n_tids) n_tids[p] = nt;
   }
+  return WFST_OK;
+}
+
+int wfst_lattice_labels_batch(const int32_t *ilabel, const int32_t *olabel, const int32_t *n_hops, int32_t n_paths, int32_t cap,
+                              int32_t *words, int32_t *word_off, int32_t *tids, int32_t *tid_off) {
+  if (!ilabel || !olabel || !n_hops || !words || !word_off || !tids || !tid_off || n_paths < 0 || cap <= 0)
+    return fail(WFST_E_ARG, "bad argument");
+  int32_t nw = 0, nt = 0;
+  for (int32_t p = 0; p < n_paths; ++p) {
+    const size_t o = (size_t)p * (size_t)cap;
+    const int32_t n = std::min(std::max(n_hops[p], 0), cap);
+    word_off[p] = nw;
+    tid_off[p] = nt;
+    for (int32_t k = 0; k < n; ++k) {   // newfst/lattice-functions.cc:195-206: the nonzero labels in hop order
+      if (ilabel[o + k] != 0) tids[nt++] = ilabel[o + k];
+      if (olabel[o + k] != 0) words[nw++] = olabel[o + k];
+    }
+  }
+  word_off[n_paths] = nw;
+  tid_off[n_paths] = nt;
   return WFST_OK;
 }
 

@@ -33,8 +33,43 @@ SYMBOLS = [
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
     "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice", "wfst_decoder_get_nbest_paths",
     "wfst_decoder_get_degraded_frames", "wfst_decoder_get_path_flags", "wfst_decoder_rescore_lattices", "wfst_decoder_nbest_paths_batch",
-    "wfst_decoder_prefetch_determinized",
+    "wfst_decoder_prefetch_determinized", "wfst_lattice_labels_batch",
 ]
+
+
+class _BestPaths(object):
+    """What best_paths() returns: a read-only sequence of per-channel dicts over the batch's hop arrays.  Everything the call
+    computes -- hops, scores, the words and transition-ids of every path -- is in host arrays when it returns (the epsilons are
+    dropped for the whole batch at once, wfst_lattice_labels_batch); an utterance's dict is put together when it is first looked at and kept (a service
+    that decodes 128 utterances per step does not pay a Python loop over them inside the step)."""
+
+    def __init__(self, il, ol, g, ac, nh, tot_s, lm_s, words, woff, tids, toff):
+        self._a = (il, ol, g, ac, nh, tot_s, lm_s)
+        self._words, self._woff, self._tids, self._toff = words, woff, tids, toff   # (wfst_lattice_labels_batch: path after path, hop order)
+        self._items = [None] * len(nh)
+
+    def __len__(self):
+        return len(self._items)
+
+    def _make(self, i):
+        il, ol, g, ac, nh, tot_s, lm_s = self._a
+        k = int(nh[i])
+        return dict(ok=k > 0, ilabel=il[i, :k], olabel=ol[i, :k], graph=g[i, :k], ac=ac[i, :k],
+                    words=self._words[self._woff[i]:self._woff[i + 1]], tids=self._tids[self._toff[i]:self._toff[i + 1]],
+                    tot_score=float(tot_s[i]) if k else 0.0, lm_score=float(lm_s[i]) if k else 0.0)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self._items)))]
+        if i < 0:
+            i += len(self._items)
+        if self._items[i] is None:
+            self._items[i] = self._make(i)
+        return self._items[i]
+
+    def __iter__(self):
+        for i in range(len(self._items)):
+            yield self[i]
 
 
 class WfstError(RuntimeError):
@@ -292,16 +327,13 @@ class BatchDecoder:
         # wfst_lattice_to_vector and against numpy's sequential cumsum)
         tot_s = np.zeros(cnt, np.float32)
         lm_s = np.zeros(cnt, np.float32)
+        nw, nt = np.zeros(cnt, np.int32), np.zeros(cnt, np.int32)
         _check(lib().wfst_lattice_to_vector_batch(_i32(il), _i32(ol), _f32(g), _f32(ac), _i32(nh), cnt, int(cap), _f32(tot_s), _f32(lm_s),
-                                                  None, None))
-        out = []
-        for i in range(cnt):
-            k = int(nh[i])
-            ili, oli = il[i, :k], ol[i, :k]
-            out.append(dict(ok=k > 0, ilabel=ili, olabel=oli, graph=g[i, :k], ac=ac[i, :k],
-                            words=oli[oli != 0], tids=ili[ili != 0],
-                            tot_score=float(tot_s[i]) if k else 0.0, lm_score=float(lm_s[i]) if k else 0.0))
-        return out
+                                                  _i32(nw), _i32(nt)))
+        words, tids = np.empty(max(1, int(nw.sum())), np.int32), np.empty(max(1, int(nt.sum())), np.int32)
+        woff, toff = np.zeros(cnt + 1, np.int32), np.zeros(cnt + 1, np.int32)
+        _check(lib().wfst_lattice_labels_batch(_i32(il), _i32(ol), _i32(nh), cnt, int(cap), _i32(words), _i32(woff), _i32(tids), _i32(toff)))
+        return _BestPaths(il, ol, g, ac, nh, tot_s, lm_s, words, woff, tids, toff)
 
     def stats(self, channel):
         s = (C.c_int64 * 8)()

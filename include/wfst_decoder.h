@@ -293,6 +293,13 @@ int wfst_lattice_to_vector_batch(const int32_t *ilabel, const int32_t *olabel, c
                                  const float *acoustic_cost, const int32_t *n_hops, int32_t n_paths, int32_t cap,
                                  float *tot_score, float *lm_score, int32_t *n_words, int32_t *n_tids);
 
+/* The label half of LatticeToVector for the same batch layout: the nonzero olabels (words) and ilabels (transition-ids) of
+ * every path in hop order, packed path after path -- path p's words are words[word_off[p] .. word_off[p + 1]).  words / tids
+ * hold the sums of wfst_lattice_to_vector_batch's n_words / n_tids (at most n_paths * cap), the offset arrays n_paths + 1
+ * entries.  Host-only. */
+int wfst_lattice_labels_batch(const int32_t *ilabel, const int32_t *olabel, const int32_t *n_hops, int32_t n_paths, int32_t cap,
+                              int32_t *words, int32_t *word_off, int32_t *tids, int32_t *tid_off);
+
 /* Per-channel work counters since the last init: {frames, N tokens expanded, E emitting arcs
  * traversed, Z epsilon arcs traversed, tokens kept, peak tokens per frame, candidate records
  * bucketed, forward links recorded (lattice mode) / token collections run (best-path mode)}.  N and E follow the

@@ -119,6 +119,14 @@ def test_vectorised_lattice_to_vector_equals_c_entry_point(pkg):
     assert rc == 0 and ts[0].tobytes() == np.float32(t2).tobytes() and ls[0].tobytes() == np.float32(l2).tobytes()
     assert ts[1] == 0 and ls[1] == 0 and [cw[0], ct[0], cw[1], ct[1]] == [int((ol != 0).sum()), int((il != 0).sum()), 0, 0]
     assert ts[2].tobytes() == np.cumsum((g[:123] + a[:123]).astype(np.float32), dtype=np.float32)[-1].tobytes()
+    # ... and its label half: every path's words / transition-ids packed path after path (best_paths hands out slices of them)
+    W, T = np.zeros(int(cw.sum()), np.int32), np.zeros(int(ct.sum()), np.int32)
+    wo, to = np.zeros(4, np.int32), np.zeros(4, np.int32)
+    rc = pkg.wfstdec.lib().wfst_lattice_labels_batch(f(IL, ctypes.c_int32), f(OL, ctypes.c_int32), f(nh, ctypes.c_int32), 3, cap,
+                                                     f(W, ctypes.c_int32), f(wo, ctypes.c_int32), f(T, ctypes.c_int32), f(to, ctypes.c_int32))
+    assert rc == 0 and list(wo) == [0, int(cw[0]), int(cw[0]), int(cw[0] + cw[2])] and list(to) == [0, int(ct[0]), int(ct[0]), int(ct[0] + ct[2])]
+    assert list(W[: wo[1]]) == list(ol[ol != 0]) and list(T[: to[1]]) == list(il[il != 0])
+    assert list(W[wo[2]:]) == list(ol[:123][ol[:123] != 0]) and list(T[to[2]:]) == list(il[:123][il[:123] != 0])
 
 
 def test_header_is_plain_c(tmp_path):
