@@ -37,6 +37,33 @@ SYMBOLS = [
 ]
 
 
+class _LazyList(object):
+    """A read-only sequence whose items are put together from the batch's host arrays when first looked at, and kept."""
+
+    def __init__(self, n, make):
+        self._items = [None] * n
+        self._make = make
+
+    def __len__(self):
+        return len(self._items)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self._items)))]
+        if i < 0:
+            i += len(self._items)
+        if self._items[i] is None:
+            self._items[i] = self._make(i)
+        return self._items[i]
+
+    def __iter__(self):
+        for i in range(len(self._items)):
+            yield self[i]
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
 class _BestPaths(object):
     """What best_paths() returns: a read-only sequence of per-channel dicts over the batch's hop arrays.  Everything the call
     computes -- hops, scores, the words and transition-ids of every path -- is in host arrays when it returns (the epsilons are
@@ -382,20 +409,24 @@ class BatchDecoder:
     def determinized_lattice(self, channel, use_final_probs=True):
         """GetLattice (GetRawLattice + DeterminizeLatticeWrapper) of a channel: dict of numpy arrays, or None."""
         ns, na = C.c_int32(0), C.c_int32(0)
-        rc = lib().wfst_decoder_get_determinized_lattice(self.h, int(channel), int(bool(use_final_probs)), 0, 0, C.byref(ns),
-                                                         C.byref(na), *([None] * 7))
-        if rc != WFST_OK and not (rc == -4 and ns.value > 0):
+        S, A = 1024, 2048   # (a determinized lattice is a narrow chain: one call as a rule; a second one with the sizes it returned otherwise)
+        for attempt in range(2):
+            fin = np.empty(S, np.int32)
+            ibuf = np.empty((4, A), np.int32)
+            fbuf = np.empty((2, A), np.float32)
+            rc = lib().wfst_decoder_get_determinized_lattice(self.h, int(channel), int(bool(use_final_probs)), S, A, C.byref(ns),
+                                                             C.byref(na), _i32(fin), _i32(ibuf[0]), _i32(ibuf[1]), _i32(ibuf[2]), _i32(ibuf[3]),
+                                                             _f32(fbuf[0]), _f32(fbuf[1]))
+            if rc == -4 and attempt == 0 and (ns.value > S or na.value > A):
+                S, A = max(S, ns.value), max(A, na.value)
+                continue
             _check(rc)
+            break
         if ns.value == 0:
             return None
         S, A = ns.value, na.value
-        fin = np.zeros(S, np.int32)
-        src, dst, il, ol = (np.zeros(A, np.int32) for _ in range(4))
-        gr, ac = np.zeros(A, np.float32), np.zeros(A, np.float32)
-        _check(lib().wfst_decoder_get_determinized_lattice(self.h, int(channel), int(bool(use_final_probs)), S, A, C.byref(ns),
-                                                           C.byref(na), _i32(fin), _i32(src), _i32(dst), _i32(il), _i32(ol),
-                                                           _f32(gr), _f32(ac)))
-        return dict(n_states=S, st_final=fin, a_src=src, a_dst=dst, a_ilabel=il, a_olabel=ol, a_graph=gr, a_acoustic=ac)
+        return dict(n_states=S, st_final=fin[:S].copy(), a_src=ibuf[0, :A].copy(), a_dst=ibuf[1, :A].copy(), a_ilabel=ibuf[2, :A].copy(),
+                    a_olabel=ibuf[3, :A].copy(), a_graph=fbuf[0, :A].copy(), a_acoustic=fbuf[1, :A].copy())
 
     def rescored_lattice(self, channel, old_lm, new_lm, use_final_probs=True):
         """GetLattice under --use-second: determinized lattice o old LM (scale -1) o new LM, composed on the device."""
@@ -485,11 +516,8 @@ class BatchDecoder:
         lm = np.zeros((cnt, n), np.float32)
         _check(lib().wfst_decoder_get_nbest(self.h, _i32(arr), cnt, int(n), int(max_words), _i32(npaths), _i32(nw), _i32(words),
                                             _f32(tot), _f32(lm)))
-        out = []
-        for i in range(cnt):
-            out.append([dict(words=words[i, k, : min(nw[i, k], max_words)].copy(), n_words=int(nw[i, k]), tot_score=float(tot[i, k]),
-                             lm_score=float(lm[i, k])) for k in range(npaths[i])])
-        return out
+        return _LazyList(cnt, lambda i: [dict(words=words[i, k, : min(nw[i, k], max_words)].copy(), n_words=int(nw[i, k]), tot_score=float(tot[i, k]),
+                                              lm_score=float(lm[i, k])) for k in range(npaths[i])])
 
     def path_flags(self):
         """Which kernel paths the decoder runs (wfst_decoder_get_path_flags)."""
