@@ -422,17 +422,12 @@ static_assert(kTileTokens == 1 << kLog2TileTokens, "the owner search of expand_b
 // counter, so a channel with 8x the tokens simply owns 8x the tiles (per-frame token counts are
 // heavy-tailed across a batch; a fixed share of workgroups per channel made every frame wait for
 // the heaviest one).
-// kBig = biglm mode (the plain instantiation carries none of it).  kFused = the graph's fused epsilon
-// closures are in use (wfst_device.h): a token's pseudo arcs are expanded with its emitting arcs.
-// kAbl != 0: REPLAY instantiations for timing experiments (wfst_options.debug bits 8..11, launched after the frame's insert
-// kernel on the same frontier): no side effects on the decode -- no counters, no countdown, no plan, next_cutoff kept
-// locally from the frame's seed (TileDesc::pad), records written over the consumed buckets -- and stages removed:
-// bit 0 no counting sort / bucket write, bit 1 no arc / second-slot loads, bit 2 no row-header loads.
+// kBig = biglm mode (the plain instantiation carries none of it).  (The fused rows -- pseudo arcs, degree codes, seed tiles --
+// are the staged kernel's below; this one serves graphs whose closures cannot be folded, and biglm decoders.)
 // kTimers: the phase timers of wfst_options.debug & 128 (their own instantiation: the production kernel carries neither
 // the clock reads nor their registers -- it sits at the 80-VGPR limit, where every live value more is a spill).
-template <bool kBig, bool kFused, int kAbl = 0, bool kTimers = false>
+template <bool kBig, bool kTimers = false>
 __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int par) {
-  constexpr bool kReplay = kAbl != 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   FrameCtl *fc = D.fctl + group;
   // (the workgroup's first tile descriptor is read together with the tile count, not after it: one round trip less at
@@ -448,14 +443,13 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
   __shared__ int s_wsum[kExpandThreads / 64];
   __shared__ int s_cnt[64], s_lbase[65], s_gbase[64];
   __shared__ int4 s_rec[kChunk];
-  __shared__ int s_nemit[kFused ? kTileTokens : 1];  // fused closures: emitting arcs of each token (pseudo arcs follow)
   __shared__ int s_lm[kBig ? kTileTokens : 1];    // biglm: LM pair state of each token of the tile
   __shared__ u64 s_pk[kBig ? kTileTokens : 1];    //        and the pair's two LM states (asked for with the row headers: one round trip off every LM step)
   __shared__ int s_rec_lm[kBig ? kChunk : 1];     //        and of each sorted candidate
   __shared__ int s_ticket;
 
   __shared__ uint32_t s_stat[4];   // work counters of the tile, summed over the workgroup
-  if (!kReplay && blockIdx.x == 0 && tid == 0) {  // lists of the previous step are consumed
+  if (blockIdx.x == 0 && tid == 0) {  // lists of the previous step are consumed
     fc->total_tiles[par ^ 1] = 0;
     fc->ticket[par ^ 1] = 0;
     fc->n_items[par ^ 1] = 0;
@@ -480,23 +474,8 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
     int4 *bucket = D.bucket + (size_t)c * P * bcap;
     int32_t *bucket_lm = kBig ? D.bucket_lm + (size_t)c * P * bcap : nullptr;
     int32_t *bucket_cnt = D.bucket_cnt + (size_t)c * P;
-    uint32_t nN = 0, nE = 0, nR = 0, nZf = 0;   // per thread and tile: 32 bits are plenty (and four registers less at the 80-VGPR limit)
-    if (kFused && !kBig && !kReplay && n == 0) {
-      // SEED TILE (DecoderDev::seed_tiles): next_cutoff's seed from the best token's emitting arcs, base-inl.h:282-300 --
-      // td.tok_begin = the token's row, td.cutoff = its cost.  (bc + w) - loglike as the reference writes it (:295), then
-      // + adaptive_beam: min(x) + ab == min(x + ab), float addition being monotone
-      const int brow = td.tok_begin;
-      const float bc = td.cutoff;
-      const uint32_t hx = (uint32_t)D.g.arcs[brow].x;
-      const int deg = (int)(hx >> kEpsBits), ab0 = brow + 1 + (int)(hx & kEpsMask);
-      float seed = kInf;
-      for (int e = tid; e < deg; e += kExpandThreads) {
-        const int4 arc = D.g.arcs[ab0 + e];
-        seed = fminf(seed, (bc + __int_as_float(arc.z)) - llrow[arc.x & D.g.col_mask]);
-      }
-      seed = wave_min_f(seed);
-      if (lane == 0 && seed < kInf) atomicMin(&ctl->bound, f2o(seed + ab));
-    } else {
+    uint32_t nN = 0, nE = 0, nR = 0;   // per thread and tile: 32 bits are plenty (and four registers less at the 80-VGPR limit)
+    {
     // two adjacent frontier tokens per thread (a tile is 1024 tokens, so the tiles of a whole
     // batch fit the chip's resident workgroup slots in one wave)
     int deg[kTokPerThread], arcbeg[kTokPerThread];
@@ -523,35 +502,12 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       cost[j] = __int_as_float(tk[j].y);
       int nem = 0;
       if (i < n && cost[j] <= cutoff) {  // base-inl.h:315
-        if constexpr ((kAbl & 4) != 0) {
-          nem = 2; deg[j] = 4; arcbeg[j] = tk[j].x + 1;   // replay without header loads: a typical row
-        } else if constexpr (kFused) {
-          // the token's degree code (wfst_device.h): its arcs without a look at the row header
-          uint32_t code = kCodeUnknown;
-          if (D.degcode) {
-            const int zz = tk[j].z;
-            const uint32_t rest = zz >= 0 ? (uint32_t)zz >> D.tok_idx_bits : zz <= kPrevUnresolved ? (uint32_t)(kPrevUnresolved - zz) : (kCodeUnknown >> 2);
-            code = (rest << 2) | ((uint32_t)tk[j].w >> 30);
-          }
-          if (code != kCodeUnknown) {
-            nem = (int)((code >> 2) & 15u);
-            deg[j] = nem + (int)(code >> 6);
-            arcbeg[j] = tk[j].x + 1 + (int)(code & 3u);
-          } else {
-            const int4 hdr = D.g.arcs[tk[j].x];  // row header: {(n_emit << 12) | n_eps, -, pseudo arcs, -}
-            nem = (int)((uint32_t)hdr.x >> kEpsBits);
-            deg[j] = nem + hdr.z;
-            arcbeg[j] = tk[j].x + 1 + (int)((uint32_t)hdr.x & kEpsMask);
-          }
-        } else {
-          const uint32_t dw = (uint32_t)D.g.arcs[tk[j].x].x;  // row header: (n_emit << 12) | n_eps
-          nem = deg[j] = (int)(dw >> kEpsBits);
-          arcbeg[j] = tk[j].x + 1 + (int)(dw & kEpsMask);
-        }
+        const uint32_t dw = (uint32_t)D.g.arcs[tk[j].x].x;  // row header: (n_emit << 12) | n_eps
+        nem = deg[j] = (int)(dw >> kEpsBits);
+        arcbeg[j] = tk[j].x + 1 + (int)(dw & kEpsMask);
         nN++;
         nE += nem;
       }
-      if constexpr (kFused) s_nemit[i] = nem;
       if constexpr (kBig) s_pk[i] = pkv[j];
     }
     int tsum = 0;
@@ -583,7 +539,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
     if (tid < 64) s_cnt[tid] = 0;
     __syncthreads();
 
-    float bound = kReplay ? o2f((uint32_t)td.pad) : o2f(bound0);   // replay: from the frame's seed, tightened locally
+    float bound = o2f(bound0);
     const int tok0 = fbegin;  // arena index of the tile's first token
     for (int j0 = 0; j0 < total; j0 += kChunk) {
       int4 rec[kCandPerThread];
@@ -596,7 +552,6 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       // next candidate, i.e. twice as many serial HBM latencies per round.)  A lane without a candidate runs the
       // loads on slot 0 / column 0 and drops the result.
       int jv[kCandPerThread], lo[kCandPerThread], av[kCandPerThread];
-      bool pseudo[kCandPerThread];
       {
         int hi[kCandPerThread];
 #pragma unroll
@@ -618,35 +573,16 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       for (int k = 0; k < kCandPerThread; ++k) {
         const int off = max(jv[k], 0) - s_base[lo[k]];
         av[k] = s_arcbeg[lo[k]] + off;
-        pseudo[k] = false;
-        if constexpr (kFused) {
-          const int nem = s_nemit[lo[k]], pi = off - nem;
-          pseudo[k] = pi >= 0;
-          if (pseudo[k]) av[k] = s_arcbeg[lo[k]] + nem + 2 * pi;  // pseudo arcs take two slots each
-        }
-        if (jv[k] < 0) { av[k] = 0; pseudo[k] = false; }
+        if (jv[k] < 0) av[k] = 0;
       }
-      int4 arcv[kCandPerThread], leafv[kFused ? kCandPerThread : 1];
+      int4 arcv[kCandPerThread];
       int olv[kBig ? kCandPerThread : 1];
       float llv[kCandPerThread];
       // next_cutoff as it stands NOW, asked for with the arcs (it arrives with them): what the seed tile and the other tiles
       // of the channel have tightened since this tile's last look
-      uint32_t bfresh = 0xFFFFFFFFu;
-      if constexpr (!kReplay) bfresh = ld_agent(&ctl->bound);
+      const uint32_t bfresh = ld_agent(&ctl->bound);
 #pragma unroll
-      for (int k = 0; k < kCandPerThread; ++k) {
-        if constexpr ((kAbl & 2) != 0) arcv[k] = make_int4(1 + (av[k] & 1023), 0, __float_as_int(0.5f), av[k]);   // replay without row traffic
-        else arcv[k] = D.g.arcs[av[k]];
-      }
-      // A pseudo arc's second slot {last arc | flags of the end state, weight of the last arc, hops, weight of the
-      // hop before the last}: loaded by every lane alike (an emitting arc's lane re-reads its own slot)
-      if constexpr (kFused) {
-#pragma unroll
-        for (int k = 0; k < kCandPerThread; ++k) {
-          if constexpr ((kAbl & 2) != 0) leafv[k] = make_int4(av[k], __float_as_int(0.25f), 1, 0);
-          else leafv[k] = D.g.arcs[av[k] + (pseudo[k] ? 1 : 0)];
-        }
-      }
+      for (int k = 0; k < kCandPerThread; ++k) arcv[k] = D.g.arcs[av[k]];
       if constexpr (kBig) {
 #pragma unroll
         for (int k = 0; k < kCandPerThread; ++k) olv[k] = D.g.arc_olabel[av[k]];
@@ -661,41 +597,6 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
           const int4 arc = arcv[k];
           const int a = av[k];
           float graph_cost = __int_as_float(arc.z);
-          if constexpr (kFused) {
-            // A pseudo arc is the emitting arc's arrival carried on over one path of the target's epsilon
-            // closure -- ((cur + ac) + w) + w_1 + ... + w_k in path order (base-inl.h:329, 414) -- an
-            // epsilon arrival at the path's end state.  It does not tighten next_cutoff (only emitting
-            // arcs do, base-inl.h:330-333 vs 415).
-            const int4 leaf = leafv[k];
-            const float base_cost = (s_cost[lo[k]] + (-llv[k])) + graph_cost;
-            if (pseudo[k]) {
-              float t = base_cost;
-              if (leaf.z == 1) {
-                t = t + __int_as_float(leaf.y);
-              } else if (leaf.z == 2) {  // the second slot also holds the weight of the hop before the last
-                t = (t + __int_as_float(leaf.w)) + __int_as_float(leaf.y);
-              } else {
-                // three hops or more (rare): the hops' weights from pseudo_w[], stored root to leaf, added in that order
-                const float *pw = D.g.pseudo_w + (size_t)arc.y * kPseudoDepthMax;
-                for (int u = 0; u < leaf.z; ++u) t = t + pw[u];
-              }
-              tot[k] = t;
-              rec[k] = make_int4(arc.w, __float_as_int(t), kPrevUnresolved, (int)((uint32_t)leaf.x | kEpsRec));
-              nZf++;
-            } else {
-              tot[k] = base_cost;
-              rec[k] = make_int4(arc.w, __float_as_int(base_cost), tok0 + lo[k], (int)((uint32_t)a | flags_of((uint32_t)arc.y)));
-              tmin = fminf(tmin, base_cost);
-            }
-            if (D.degcode) {
-              // the degree code of the state arrived at (above the column in the arc's first word) goes into the record: two
-              // bits in place of the closure pass's flags, the rest above the source-token index / in the unresolved sentinel
-              const uint32_t code = (uint32_t)arc.x >> kColBits;
-              rec[k].w = (int)(((uint32_t)rec[k].w & 0x3FFFFFFFu) | (code << 30));
-              rec[k].z = pseudo[k] ? kPrevUnresolved - (int)(code >> 2) : (int)((uint32_t)rec[k].z | ((code >> 2) << D.tok_idx_bits));
-            }
-            continue;
-          }
           if constexpr (kBig) {  // biglm.h:377-388: graph_cost = arc weight + lm_score, next LM state into the key
             const int ol = olv[k];
             float lm_score = 0.0f;
@@ -714,23 +615,14 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         }
       }
       if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 12, tq); }
-      if constexpr (!kReplay) bound = fminf(bound, o2f(bfresh));
+      bound = fminf(bound, o2f(bfresh));
       // base-inl.h:330-333: tighten next_cutoff by the best candidate seen (wave-aggregated)
       const float cand = wave_min_f(tmin) + ab;
       if (cand < bound) {
-        if constexpr (kReplay) {
-          bound = cand;
-        } else {
-          uint32_t old = 0;
-          if (lane == 0) old = atomicMin(&ctl->bound, f2o(cand));
-          old = __shfl(old, 0, 64);
-          bound = fminf(o2f(old), cand);
-        }
-      }
-      if constexpr ((kAbl & 1) != 0) {   // replay without the sort / write stage: the pricing kept alive through a count
-#pragma unroll
-        for (int k = 0; k < kCandPerThread; ++k) nR += (tot[k] < bound) ? (uint32_t)(1 + (rec[k].x & 1)) : 0u;
-        continue;
+        uint32_t old = 0;
+        if (lane == 0) old = atomicMin(&ctl->bound, f2o(cand));
+        old = __shfl(old, 0, 64);
+        bound = fminf(o2f(old), cand);
       }
       // counting sort of the survivors by hash partition, in LDS
       int part[kCandPerThread], rank[kCandPerThread];
@@ -753,8 +645,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
         int g = 0;
         if (cnt) {
           g = atomicAdd(&bucket_cnt[tid], cnt);
-          if constexpr (kReplay) g = (int)((uint32_t)g % (uint32_t)max(1, bcap - kChunk));   // over the consumed bucket, wherever
-          else if (g + cnt > bcap) atomicOr(&ctl->error, kErrBucketFull);
+          if (g + cnt > bcap) atomicOr(&ctl->error, kErrBucketFull);
         }
         s_gbase[tid] = g;
         s_cnt[tid] = 0;
@@ -783,11 +674,7 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
       if constexpr (kTimers) { if (tid == 0) dbg_phase(D, 15, tq); }
     }
     }
-    if constexpr (kReplay) {
-      if (nR == 0x7FFFFFFFu) D.dbg_t[63] = nN + nE + nZf;   // (keeps the counts alive)
-      break;   // one tile per workgroup: the replay grid covers every tile
-    }
-    tile_tail(D, c, ctl, group, par, nN, nE, nR, kFused ? nZf : 0u, s_stat);
+    tile_tail(D, c, ctl, group, par, nN, nE, nR, 0u, s_stat);
     // next tile: the first gridDim.x tiles are taken statically, the rest by ticket
     if (total_tiles <= (int)gridDim.x) break;
     if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(&fc->ticket[par], 1);
@@ -799,13 +686,11 @@ __device__ __forceinline__ void expand_body(const DecoderDev &D, int group, int 
 }
 
 // The launch bounds' second number = waves per SIMD the kernel must fit.  The plain instantiation fits 80 VGPRs (6 waves)
-// nearly without spilling; the fused one needs 96 (5 waves per SIMD = 5 workgroups per CU = 1280 resident workgroups, still
-// every tile of a 128-channel frame at once): at 80 it spilled into its candidate loop, and 5 waves without spills beat 6
-// with them by 3 % of the step (22.7 vs 23.5 ms).
-__global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_plain(DecoderDev D, int group, int par) { expand_body<false, false>(D, group, par); }
-__global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm(DecoderDev D, int group, int par) { expand_body<true, false>(D, group, par); }
-__global__ __launch_bounds__(kExpandThreads) void expand_kernel_plain_timed(DecoderDev D, int group, int par) { expand_body<false, false, 0, true>(D, group, par); }
-__global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm_timed(DecoderDev D, int group, int par) { expand_body<true, false, 0, true>(D, group, par); }
+// without spilling; the biglm one takes what it needs (124: four waves).
+__global__ __launch_bounds__(kExpandThreads, 6) void expand_kernel_plain(DecoderDev D, int group, int par) { expand_body<false>(D, group, par); }
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm(DecoderDev D, int group, int par) { expand_body<true>(D, group, par); }
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel_plain_timed(DecoderDev D, int group, int par) { expand_body<false, true>(D, group, par); }
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm_timed(DecoderDev D, int group, int par) { expand_body<true, true>(D, group, par); }
 
 // =========================================================================================
 // expand_kernel_staged: the expansion of decoders on the fused rows (best-path and lattice, not biglm) with a tile's
@@ -823,7 +708,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel_biglm_timed(Deco
 // bucket): neighbouring lanes write to different partitions, the lines fill in L2.
 // A tile is kStTokens = 256 frontier tokens (one per thread); its slots beyond kStSlots are staged in further passes.
 // LDS: 24 KB slots + 6 KB log-likelihoods + 4 KB per-token scan = 34.5 KB: four workgroups per CU.
-// Arithmetic, pruning and record layout are expand_body<false, true>'s, to the bit.
+// Arithmetic, pruning and record layout are those of the round-2 expansion of the fused rows (retired in round 4), to the bit.
 // =========================================================================================
 constexpr int kStThreads = 256;
 constexpr int kStTokens = 256;   // (tiles of 128 / 192 / 320 / 384 tokens measured slower by 10-25 %, 512 the same)
