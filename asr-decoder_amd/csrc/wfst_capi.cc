@@ -148,7 +148,7 @@ struct wfst_decoder {
   DevBuf<int32_t> frame_off, bucket_cnt, eps_toki, eps_occ_list, eps_won_list, target, chan_list;
   DevBuf<int4> bucket, worklist, links, lat_toks;
   DevBuf<unsigned long long> pair_keys, eps_keys;  // biglm
-  DevBuf<int32_t> tok_lm, bucket_lm;
+  DevBuf<int32_t> tok_lm, bucket_lm, pair_list;
   DevBuf<int32_t> link_off, link_mid;
   DevBuf<uint2> extra;
   DevBuf<int32_t> remap;
@@ -278,7 +278,7 @@ struct wfst_decoder {
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
     if (pf_pin) (void)hipHostFree(pf_pin);
-    pair_keys.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
+    pair_keys.release(); pair_list.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
     det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
     cmp_ws.release(); cmp_result.release(); cmp_fin.release(); cmp_out_a.release(); cmp_out_w.release();
     np_ws.release(); np_out.release(); np_off.release(); np_arcs.release(); np_tot.release(); np_lists.release();
@@ -984,6 +984,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   A(d->worklist.alloc(B * 2 * (size_t)L.max_tokens_per_frame));
   if (big) {
     A(d->pair_keys.alloc(B * pair_cap));
+    A(d->pair_list.alloc(B * pair_cap));
     A(d->eps_keys.alloc(B * ecap));
     A(d->tok_lm.alloc(B * (size_t)L.arena_tokens));
     A(d->bucket_lm.alloc(B * (size_t)n_part * (size_t)bucket_cap));
@@ -1116,6 +1117,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     if (stride >= 1) { D.two_launch = 1; D.gc_stride = (int32_t)std::min<int64_t>(stride, 16); }
   }
   D.pair_keys = d->pair_keys.p;
+  D.pair_list = d->pair_list.p;
   D.pair_cap = (int32_t)pair_cap;
   D.tok_lm = d->tok_lm.p;
   D.bucket_lm = d->bucket_lm.p;

@@ -366,6 +366,7 @@ struct DecoderDev {
   int32_t big;
   LmDev lm_old, lm_new;
   unsigned long long *pair_keys;
+  int32_t *pair_list;           // [n_channels][pair_cap] the table slots claimed since InitDecoding, in claiming order (clear_pairs_kernel)
   int32_t pair_cap;             // power of two
   int32_t *tok_lm;
   int32_t *bucket_lm;

@@ -162,7 +162,10 @@ __device__ __forceinline__ int pair_intern(const DecoderDev &D, int c, ChanCtl *
     if (k == kEmptyVal) {
       k = atomicCAS(&keys[slot], kEmptyVal, key);
       if (k == kEmptyVal) {
-        if (atomicAdd(&ctl->pair_count, 1) >= (D.pair_cap >> 2) * 3) atomicOr(&ctl->error, kErrPairsFull);
+        // (the claimed slots are listed: the next InitDecoding empties exactly those -- clear_pairs_kernel)
+        const int nth = atomicAdd(&ctl->pair_count, 1);
+        if (nth >= (D.pair_cap >> 2) * 3) atomicOr(&ctl->error, kErrPairsFull);
+        else D.pair_list[(size_t)c * D.pair_cap + nth] = (int32_t)slot;
         return (int)slot;
       }
     }
@@ -3649,6 +3652,7 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
       start_lm = (int)(hash_pair(D.lm_old.start, D.lm_new.start) & ((uint32_t)D.pair_cap - 1u));
       D.pair_keys[(size_t)c * D.pair_cap + start_lm] = (u64)(uint32_t)D.lm_old.start | ((u64)(uint32_t)D.lm_new.start << 32);
       D.tok_lm[(size_t)c * D.arena_cap] = start_lm;
+      D.pair_list[(size_t)c * D.pair_cap] = start_lm;
       ctl->pair_count = 1;
     }
     if (fl & kFlagEpsTarget) {
@@ -4184,13 +4188,22 @@ static __global__ void set_finalized_kernel(DecoderDev D, const int32_t *chans, 
 
 // DiffArpaLm::Reset (newlm/diff-lm.h:37-44, biglm.h:110): forget the utterance's LM pair states.  Its own
 // launch, many workgroups per channel: plain stores here, agent-scope atomics in the launches after.
+// The slots the utterance before claimed are listed (pair_intern: pair_list[0 .. pair_count)): those are emptied -- a few
+// thousand of a million (the whole table was 2.1 GB of stores per InitDecoding of 128 channels); a table that overflowed
+// (kErrPairsFull: claims beyond the list) is emptied whole.  Runs in front of init_kernel, which resets the count.
 __global__ __launch_bounds__(256) void clear_pairs_kernel(DecoderDev D, const int32_t *chans) {
   const int c = chans ? chans[blockIdx.x] : blockIdx.x;
   u64 *pk = D.pair_keys + (size_t)c * D.pair_cap;
-  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < D.pair_cap; i += gridDim.y * blockDim.x) pk[i] = kEmptyVal;
+  const int n = D.ctl[c].pair_count;
+  if (n >= (D.pair_cap >> 2) * 3) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < D.pair_cap; i += gridDim.y * blockDim.x) pk[i] = kEmptyVal;
+  } else {
+    const int32_t *list = D.pair_list + (size_t)c * D.pair_cap;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) pk[list[i]] = kEmptyVal;
+  }
 }
 void launch_init(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
-  if (D.big) hipLaunchKernelGGL(clear_pairs_kernel, dim3(n, 32), dim3(256), 0, s, D, chans);
+  if (D.big) hipLaunchKernelGGL(clear_pairs_kernel, dim3(n, 8), dim3(256), 0, s, D, chans);
   hipLaunchKernelGGL(init_kernel, dim3(n), dim3(kBT), 0, s, D, chans);
 }
 // chan_off / chan_cnt: the channel group a launch covers (groups run on their own streams so that
