@@ -1171,6 +1171,12 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // (round 4: best-path decoders too -- with the shorter launches of this round a third group's frame chain finds room beside two
   // others: 18.65-19.1 -> 18.33 ms per step at 128 channels; four groups: 27.8, a fifth stream shares a hardware queue)
   const bool three = n_channels >= 96;
+  // (round 4: FOUR groups pay for biglm and lattice decoders of 128 channels -- their frames are chains of small launches -- where the
+  // process runs with eight hardware queues (GPU_MAX_HW_QUEUES=8 in its environment before the HIP runtime starts): the runtime's
+  // default of four makes the fifth stream of a process share a queue, and two streams on one queue take turns (biglm 63 ms per
+  // step); with eight: biglm 30.2 -> 27.7 ms, lattice mode 50.6 -> 49.6 / 225 -> 223; five groups: 60 ms -- more than four queues
+  // busy at once is the wall; best-path decoders: 18.7 against 18.4 with three.  The library reads no environment: a host that sets
+  // the runtime up that way asks for wfst_options.channel_groups = 4 -- bench.py does)
   d->n_groups = std::min(O.channel_groups > 0 ? O.channel_groups : three ? 3 : (n_channels >= 64 ? 2 : 1), n_channels);
   if (d->n_groups > 1) {
     d->gstreams.resize(d->n_groups);

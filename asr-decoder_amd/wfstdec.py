@@ -12,6 +12,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# (eight hardware queues for the process's HIP streams where nothing else is asked for: has an effect if this module is imported
+# before the HIP runtime starts -- a decoder with four channel groups has five streams, and the runtime's default is four queues)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # (WFST_LIB_VARIANT: kernel experiments only -- tools/ab_bench.sh builds variants of the library beside the product one with
 # `build.py --variant NAME -D...` and times them on one box; the product path never sets it)
 LIB_PATH = os.path.join(HERE, "lib", "libwfstdec%s.so" % (("_" + os.environ["WFST_LIB_VARIANT"]) if os.environ.get("WFST_LIB_VARIANT") else ""))

@@ -43,6 +43,12 @@ import sys
 import threading
 import time
 
+# Eight hardware queues for the process's HIP streams (the runtime's default is four: a decoder with four channel groups has five
+# streams, and two streams on one queue take turns) -- read by the HIP runtime when it starts, i.e. before anything below touches the
+# GPU.  With them, biglm and lattice decoders of 128 channels are asked for FOUR channel groups below (wfst_options.channel_groups;
+# the library's own default is three, it reads no environment).  An exported value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -433,6 +439,8 @@ def main():
         log("[rank %d] LMs: old %d states / %d arcs, new %d states / %d arcs (%.1fs)" % (
             rank, lm_info[0]["n_states"], lm_info[0]["n_arcs"], lm_info[1]["n_states"], lm_info[1]["n_arcs"], time.time() - t0))
     stream = torch.cuda.current_stream(dev).cuda_stream
+    if a.groups <= 0 and (a.biglm or a.lattice_links > 0) and B >= 128 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) >= 8:
+        a.groups = 4   # (chains of small launches: a fourth group finds room -- with eight hardware queues only, see the top of the file)
     opt = wfstdec.Options(use_hip_graph=0 if a.no_hip_graph else 1, debug=a.debug, **({"channel_groups": a.groups} if a.groups > 0 else {}),
                           **({"expand_workgroups": a.expand_wgs} if a.expand_wgs > 0 else {}),
                           **({"log2_partitions": a.log2_parts} if a.log2_parts >= 0 else {}),

@@ -4,6 +4,9 @@ import sys
 
 import pytest
 
+# (as bench.py: eight hardware queues for the process's HIP streams, set before anything starts the HIP runtime)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
