@@ -364,3 +364,34 @@ def test_channel_groups_decode_identically(synth, oracle, tmp_path):
                 G.assert_same_as_oracle(r, o, "graph options %s chunk %d" % (go, chunk))
         g2.free()
     graph.free()
+
+
+def test_long_calls_split_into_head_and_rest_graphs(synth, oracle, tmp_path):
+    """An AdvanceDecoding call of 128 frames and more is launched as a 32-frame head graph and the rest (wfst_capi.cc: the
+    device sees the first frames while the calling thread is still submitting the others); shorter calls, calls that start
+    mid-utterance, ragged lengths (channels that end inside the head, inside the rest, or before the call) and the tile size
+    knob (wfst_options.tile_tokens) are scheduling only: same bits as the oracle, for best-path and lattice decoders, on one
+    channel group and on three."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(6000, seed=31, n_tid=600, n_words=900)
+    m = synth.default_tid2pdf(600)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=11.0, max_active=1000000, min_active=0, lattice_beam=6.0)
+    Ts = (190, 133, 20, 160, 128, 45, 175, 1)
+    mats = [synth.make_loglikes(g, T, 300, m, seed=900 + i, mu=-2.2)[0] for i, T in enumerate(Ts)]
+    h = oracle.load_graph(path)
+    want = [oracle.decode(h, pyoracle.Config(**cd), x, m) for x in mats]
+    oracle.free_graph(h)
+    for lat in (0, 1 << 21):
+        lim = dict(max_frames=256, max_tokens_per_frame=32768, arena_tokens=1 << 22, lattice_links=lat)
+        for opt in (dict(channel_groups=1), dict(channel_groups=3), dict(channel_groups=2, tile_tokens=64), dict(tile_tokens=136)):
+            for chunk in (0, 150, 40):   # one call of 190 frames (split); 150 + 40 (split + whole); five short calls
+                dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), options=G.wfstdec.Options(**opt), **lim)
+                for r, o in zip(G.decode_batch(graph, cd, mats, chunk=chunk, dec=dec), want):
+                    G.assert_same_as_oracle(r, o, "lattice_links %d %s chunk %d" % (lat, opt, chunk))
+                dec.free()
+    graph.free()
