@@ -1338,6 +1338,9 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     bool ok = d->D.staged && !(kAbSwitches && (d->D.dbg & 0x10000)) && (stride & 3) == 0 && stride <= 3072;
     for (int c = 0; ok && c < d->n_channels; ++c)
       if (d->h_ll_base[c] && ((uintptr_t)d->h_ll_base[c] & 15u)) ok = false;
+#ifdef WFST_FORCE_GATHER   // (A/B builds: the gather form of the staged expansion whatever the stride)
+    ok = false;
+#endif
     d->D.ll_row = ok ? 1 : 0;
   }
   if (steps == 0) return WFST_OK;
