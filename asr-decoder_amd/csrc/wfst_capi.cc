@@ -1110,11 +1110,20 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // fused best-path decoders: max_tokens_per_frame is a max_active, not a capacity (the frame keeps every token the arena takes and
   // GetCutoff tightens to the limit-th cheapest; wfst_decoder_get_degraded_frames counts the frames on which it did)
   D.soft_limit = D.best_row;
-  if (D.best_row && !(ab_bits & 0x2000)) {
-    int64_t reserve = std::max<int64_t>(2ll * L.max_tokens_per_frame, L.arena_tokens / 8);
-    if (reserve >= L.arena_tokens / 2) reserve = L.arena_tokens / 2;
-    const int64_t stride = reserve / std::max<int64_t>(1, L.max_tokens_per_frame) - 1;
-    if (stride >= 1) { D.two_launch = 1; D.gc_stride = (int32_t)std::min<int64_t>(stride, 16); }
+  // the token collection's reserve (wfst_kernels.hip gc_base_mark): an eighth of the arena, two frames at the per-frame limit at least;
+  // a two-launch decoder checks the mark every gc_stride-th frame only (a third launch on that frame), so it takes up to a quarter
+  // of the arena where that buys a longer stride (17 frames at the limit cover the longest, 16); never more than half
+  {
+    const int64_t M = std::max<int64_t>(1, L.max_tokens_per_frame), A = L.arena_tokens;
+    int64_t reserve = std::max<int64_t>(2 * M, A / 8);
+    const bool two = D.best_row && !(ab_bits & 0x2000);
+    if (two) reserve = std::max<int64_t>(reserve, std::min<int64_t>(17 * M, A / 4));
+    if (reserve >= A / 2) reserve = A / 2;
+    D.gc_reserve = reserve;
+    if (two) {
+      const int64_t stride = reserve / M - 1;
+      if (stride >= 1) { D.two_launch = 1; D.gc_stride = (int32_t)std::min<int64_t>(stride, 16); }
+    }
   }
   D.pair_keys = d->pair_keys.p;
   D.pair_list = d->pair_list.p;

@@ -327,6 +327,7 @@ struct DecoderDev {
   int32_t wl_cap;
   int32_t max_frames;
   int64_t arena_cap;
+  int64_t gc_reserve;           // best-path decoders: the token collection's mark lies this far below arena_cap (gc_base_mark)
   // config (LatticeFasterDecoderConfig)
   float beam, lattice_beam, beam_delta, prune_scale;
   int32_t max_active, min_active, prune_interval;

@@ -3364,13 +3364,12 @@ __device__ __forceinline__ void prune_move(const DecoderDev &D, int c, int role,
 // passed (never on the bench workload).  biglm: several tokens of a frame may sit on the wanted state (one per LM
 // state); all of them are kept and the backpointer stays unresolved.
 // =========================================================================================
-// The arena is collected when less than an eighth of it (and at least two frames' worth of tokens at the per-frame limit:
-// one frame can add max_tokens_per_frame tokens before the next check) is left; a collection is not cheap (~5 ms per
-// million tokens in the arena), so it should be rare.  Arenas too small for that reserve collect when half full.
-__device__ __forceinline__ int gc_base_mark(const DecoderDev &D) {
-  const int64_t reserve = max((int64_t)2 * D.max_tok, D.arena_cap / 8);
-  return (int)(reserve < D.arena_cap / 2 ? D.arena_cap - reserve : D.arena_cap / 2);
-}
+// The arena is collected when less than DecoderDev::gc_reserve of it is left: an eighth (and at least two frames' worth of tokens at
+// the per-frame limit: one frame can add max_tokens_per_frame tokens before the next check); two-launch decoders, which look at
+// the mark every gc_stride-th frame only, up to a quarter where that buys a longer stride -- the check is a third launch on that
+// frame (wfst_capi.cc).  A collection is not cheap (~5 ms per million tokens in the arena), so it should be rare.  Arenas too
+// small for that reserve collect when half full.
+__device__ __forceinline__ int gc_base_mark(const DecoderDev &D) { return (int)(D.arena_cap - D.gc_reserve); }
 constexpr int kGcNeedSlots = 2048;  // LDS hash of the states wanted in one sweep (power of two)
 struct GcShared {
   int32_t key[kGcNeedSlots];    // wanted state (row), -1 empty

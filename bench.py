@@ -654,7 +654,7 @@ def main():
         out["config"]["max_tokens_per_frame_limit"] = a.max_tokens
         out["config"]["max_tokens_per_frame_note"] = ("a best-path decoder does not fail at this limit, it goes on from the limit-th cheapest token "
                                                       "(degraded_frames counts the frames on which it did); the limit also sizes the arena's collection "
-                                                      "reserve: every gc_stride-th frame (reserve / limit - 1, at most 16) runs the classic three launches")
+                                                      "reserve (a quarter of the arena at most): every gc_stride-th frame (reserve / limit - 1, at most 16) runs the classic three launches")
         if a.lattice_links == 0 and not a.biglm:
             out["config"]["degraded_frames"] = int(sum(dec.degraded_frames(c) for c in range(B)))
         out["config"]["utterances_with_path"] = int(sum(1 for r in res if r["ok"]))

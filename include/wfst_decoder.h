@@ -71,7 +71,7 @@ typedef struct wfst_limits {
   int64_t arena_tokens;         /* token arena of one utterance, 16 bytes a token.  BEST-PATH decoders keep every
                                    token of the utterance for the traceback (there are no link lists to prune
                                    them by): an utterance of T frames with n tokens alive per frame needs about
-                                   T x n IF nothing is reclaimed; when less than an eighth of the arena is left
+                                   T x n IF nothing is reclaimed; when less than an eighth of the arena (a quarter: two-launch decoders) is left
                                    the decoder collects it (keeps what the frontier's backpointers reach, a percent or two,
                                    and moves it down), so that what the arena must hold is the raw tokens of the
                                    frames between two collections plus the surviving history -- a few hundred
