@@ -209,6 +209,11 @@ struct wfst_decoder {
   std::vector<int32_t> det_live_nd;   // NumFramesDecoded() the cached lattice of a LIVE channel belongs to (-1: none)
   std::vector<char> det_live_final = std::vector<char>();
   int32_t det_slots = 0;              // lattices one determinize launch takes (workspace slots)
+  // a batch's determinized lattices packed back to back on the device (det_pack_kernel) and their pinned landing place on the host
+  DevBuf<int4> det_pack_a;
+  DevBuf<float2> det_pack_w;
+  void *det_pack_pin = nullptr;
+  size_t det_pack_pin_bytes = 0;
   // wfst_decoder_prefetch_determinized: a determinize launch in flight on a side stream (its channels, its result words)
   bool pf_pending = false;
   std::vector<int32_t> pf_list, pf_res;
@@ -278,6 +283,7 @@ struct wfst_decoder {
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
     if (pf_pin) (void)hipHostFree(pf_pin);
+    if (det_pack_pin) (void)hipHostFree(det_pack_pin);
     pair_keys.release(); pair_list.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
     det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
     cmp_ws.release(); cmp_result.release(); cmp_fin.release(); cmp_out_a.release(); cmp_out_w.release();
@@ -2089,6 +2095,33 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
   if (rc != WFST_OK) return rc;
   rc = check_ctl_errors(d);
   if (rc != WFST_OK) return rc;
+  // a batch: the lattices packed back to back on the device, two copies for all of them (two per lattice were 256 copy calls for
+  // 128 utterances); a single lattice, or a batch beyond the packing buffers: straight from its slot
+  size_t total = 0;
+  for (int i = 0; i < (int)list.size(); ++i)
+    if (!res[4 * i + 2]) total += (size_t)std::min(res[4 * i + 1], X.out_cap);
+  constexpr size_t kPackCap = (size_t)1 << 20;
+  const bool packed = list.size() > 1 && total > 0 && total <= kPackCap;
+  if (packed) {
+    if (!d->det_pack_a.p) {
+      HIP_TRY(d->det_pack_a.alloc(kPackCap));
+      HIP_TRY(d->det_pack_w.alloc(kPackCap));
+    }
+    const size_t need = total * (sizeof(int4) + sizeof(float2));
+    if (d->det_pack_pin_bytes < need) {
+      if (d->det_pack_pin) (void)hipHostFree(d->det_pack_pin);
+      d->det_pack_pin = nullptr;
+      d->det_pack_pin_bytes = 0;
+      HIP_TRY(hipHostMalloc(&d->det_pack_pin, need + need / 2, hipHostMallocDefault));
+      d->det_pack_pin_bytes = need + need / 2;
+    }
+    launch_det_pack(X, (int)list.size(), d->det_pack_a.p, d->det_pack_w.p, (int64_t)kPackCap, d->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(d->det_pack_pin, d->det_pack_a.p, total * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync((char *)d->det_pack_pin + total * sizeof(int4), d->det_pack_w.p, total * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+  }
+  size_t off = 0;
   for (int i = 0; i < (int)list.size(); ++i) {
     wfst_decoder::DetLattice &L = d->det_cache[(size_t)list[i]];
     L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
@@ -2098,10 +2131,15 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
     if (L.err) continue;
     L.n_states = res[4 * i];
     L.n_proper = res[4 * i + 3];
-    const size_t na = (size_t)res[4 * i + 1];
+    const size_t na = (size_t)std::min(res[4 * i + 1], X.out_cap);
     L.a.resize(na);
     L.w.resize(na);
-    if (na) {
+    if (!na) continue;
+    if (packed) {
+      memcpy(L.a.data(), (const int4 *)d->det_pack_pin + off, na * sizeof(int4));
+      memcpy(L.w.data(), (const float2 *)((const char *)d->det_pack_pin + total * sizeof(int4)) + off, na * sizeof(float2));
+      off += na;
+    } else {
       HIP_TRY(hipMemcpyAsync(L.a.data(), X.out_a + (size_t)i * X.out_cap, na * sizeof(int4), hipMemcpyDeviceToHost, d->stream));
       HIP_TRY(hipMemcpyAsync(L.w.data(), X.out_w + (size_t)i * X.out_cap, na * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
     }

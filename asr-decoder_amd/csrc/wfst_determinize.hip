@@ -164,6 +164,23 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
   }
 }
 
+// The determinized lattices of workspace slots [0, cnt) packed back to back (slot i's arcs at the sum of the arc counts of the
+// slots before it; a slot that failed contributes none): the host fetches a batch's lattices with two copies instead of two per
+// lattice.  One workgroup per slot.
+__global__ __launch_bounds__(256) void det_pack_kernel(DetDev X, int cnt, int4 *pack_a, float2 *pack_w, int64_t pack_cap) {
+  const int slot = blockIdx.x;
+  int64_t off = 0;
+  for (int j = 0; j < slot; ++j) off += X.result[4 * j + 2] ? 0 : min(X.result[4 * j + 1], X.out_cap);
+  const int n = X.result[4 * slot + 2] ? 0 : min(X.result[4 * slot + 1], X.out_cap);
+  if (off + n > pack_cap) return;   // (the host sized the buffers from the same counts: not expected)
+  const int4 *a = X.out_a + (size_t)slot * X.out_cap;
+  const float2 *w = X.out_w + (size_t)slot * X.out_cap;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { pack_a[off + i] = a[i]; pack_w[off + i] = w[i]; }
+}
+void launch_det_pack(const DetDev &X, int cnt, int4 *pack_a, float2 *pack_w, int64_t pack_cap, hipStream_t s) {
+  hipLaunchKernelGGL(det_pack_kernel, dim3(cnt), dim3(256), 0, s, X, cnt, pack_a, pack_w, pack_cap);
+}
+
 void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chans, int cnt, hipStream_t s) {
   hipLaunchKernelGGL(determinize_kernel, dim3(cnt), dim3(kDetThreads), 0, s, D, X, chans);
 }

@@ -413,6 +413,7 @@ struct DetDev {
   int32_t out_cap;
 };
 void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chan_list_dev, int cnt, hipStream_t s);
+void launch_det_pack(const DetDev &X, int cnt, int4 *pack_a, float2 *pack_w, int64_t pack_cap, hipStream_t s);
 
 // ---- n cheapest paths of a determinized / rescored lattice (wfst_nbest.hip: nbest_paths_kernel) --------------------------------
 struct NbPathEntry { float cost; int32_t arc, rank, pad; };   // a partial path: its cost, the arc it arrives by (-1: the start), its rank in that arc's source list
