@@ -285,7 +285,7 @@ struct wfst_decoder {
     if (pf_pin) (void)hipHostFree(pf_pin);
     if (det_pack_pin) (void)hipHostFree(det_pack_pin);
     pair_keys.release(); pair_list.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
-    det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release();
+    det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release(); det_pack_a.release(); det_pack_w.release(); pf_dev.release();
     cmp_ws.release(); cmp_result.release(); cmp_fin.release(); cmp_out_a.release(); cmp_out_w.release();
     np_ws.release(); np_out.release(); np_off.release(); np_arcs.release(); np_tot.release(); np_lists.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); emit_cnt.release(); prune_par.release();

@@ -414,12 +414,13 @@ class BatchDecoder:
         ns, na = C.c_int32(0), C.c_int32(0)
         S, A = 1024, 2048   # (a determinized lattice is a narrow chain: one call as a rule; a second one with the sizes it returned otherwise)
         for attempt in range(2):
-            fin = np.empty(S, np.int32)
-            ibuf = np.empty((4, A), np.int32)
-            fbuf = np.empty((2, A), np.float32)
+            buf = np.empty(S + 6 * A, np.int32)   # one block per call: final flags | src | dst | ilabel | olabel | graph | acoustic
+            p = buf.ctypes.data
+            I32, F32 = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+            at = lambda k, T: C.cast(p + 4 * (S + k * A), T)
             rc = lib().wfst_decoder_get_determinized_lattice(self.h, int(channel), int(bool(use_final_probs)), S, A, C.byref(ns),
-                                                             C.byref(na), _i32(fin), _i32(ibuf[0]), _i32(ibuf[1]), _i32(ibuf[2]), _i32(ibuf[3]),
-                                                             _f32(fbuf[0]), _f32(fbuf[1]))
+                                                             C.byref(na), C.cast(p, I32), at(0, I32), at(1, I32), at(2, I32), at(3, I32),
+                                                             at(4, F32), at(5, F32))
             if rc == -4 and attempt == 0 and (ns.value > S or na.value > A):
                 S, A = max(S, ns.value), max(A, na.value)
                 continue
@@ -427,9 +428,10 @@ class BatchDecoder:
             break
         if ns.value == 0:
             return None
-        S, A = ns.value, na.value
-        return dict(n_states=S, st_final=fin[:S].copy(), a_src=ibuf[0, :A].copy(), a_dst=ibuf[1, :A].copy(), a_ilabel=ibuf[2, :A].copy(),
-                    a_olabel=ibuf[3, :A].copy(), a_graph=fbuf[0, :A].copy(), a_acoustic=fbuf[1, :A].copy())
+        s_, a_ = ns.value, na.value
+        seg = lambda k: buf[S + k * A: S + k * A + a_]
+        return dict(n_states=s_, st_final=buf[:s_], a_src=seg(0), a_dst=seg(1), a_ilabel=seg(2), a_olabel=seg(3),
+                    a_graph=seg(4).view(np.float32), a_acoustic=seg(5).view(np.float32))
 
     def rescored_lattice(self, channel, old_lm, new_lm, use_final_probs=True):
         """GetLattice under --use-second: determinized lattice o old LM (scale -1) o new LM, composed on the device."""
