@@ -216,6 +216,10 @@ struct wfst_decoder {
   size_t det_pack_pin_bytes = 0;
   // wfst_decoder_prefetch_determinized: a determinize launch in flight on a side stream (its channels, its result words)
   bool pf_pending = false;
+  bool pf_detached = false;           // the pending prefetch runs detached (wfst_decoder_prefetch_determinized_detached)
+  std::vector<DetLattice> pf_cache;   // detached: the lattices of the last harvested prefetch, whatever the channels have gone on to
+  std::vector<char> pf_have;
+  std::vector<int32_t> fin_epoch, pf_epoch;   // FinalizeDecoding calls per channel; ... as of the pending prefetch
   std::vector<int32_t> pf_list, pf_res;
   int32_t *pf_pin = nullptr;          // [2][n_channels * 4] pinned: the channel list going up, the launch's result words coming down (a copy from or
                                       // to pageable memory would hold the calling thread until the launch is over)
@@ -1271,7 +1275,7 @@ static int finish_prefetch(wfst_decoder *d);
 int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n) {
   if (!d) return fail(WFST_E_ARG, "NULL decoder");
   HIP_TRY(hipSetDevice(d->device));
-  { const int rcp = finish_prefetch(d); if (rcp != WFST_OK) return rcp; }   // (the determinizer may be reading these channels' lattices)
+  if (!d->pf_detached) { const int rcp = finish_prefetch(d); if (rcp != WFST_OK) return rcp; }   // (the determinizer may be reading these channels' lattices; a detached one has read them)
   const int32_t *dev;
   int32_t cnt;
   int rc = stage_channels(d, channels, n, &dev, &cnt);
@@ -1298,7 +1302,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   if (!loglikes || !n_frames_ready) return fail(WFST_E_ARG, "NULL loglikes / n_frames_ready");
   const int32_t cnt = channels ? n : d->n_channels;
   if (cnt <= 0 || cnt > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
-  { const int rcp = finish_prefetch(d); if (rcp != WFST_OK) return rcp; }   // (a prefetching determinizer borrows the second group's stream)
+  if (!d->pf_detached) { const int rcp = finish_prefetch(d); if (rcp != WFST_OK) return rcp; }   // (a prefetching determinizer borrows the second group's stream; a detached one has its own)
   if (stride <= d->graph->max_col)
     return fail(WFST_E_ARG, "stride too small: the graph reads log-likelihood column " + std::to_string(d->graph->max_col));
   if (d->D.stride != 0 && d->D.stride != stride) {
@@ -1551,7 +1555,7 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
 int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
   if (!d) return fail(WFST_E_ARG, "NULL decoder");
   HIP_TRY(hipSetDevice(d->device));
-  { const int rcp = finish_prefetch(d); if (rcp != WFST_OK) return rcp; }
+  if (!d->pf_detached) { const int rcp = finish_prefetch(d); if (rcp != WFST_OK) return rcp; }
   const int32_t *dev;
   int32_t cnt;
   int rc = stage_channels(d, channels, n, &dev, &cnt);
@@ -1566,6 +1570,8 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     d->h_state[c] = 2;
+    if (d->fin_epoch.empty()) d->fin_epoch.assign((size_t)d->n_channels, 0);
+    ++d->fin_epoch[(size_t)c];
     if (!d->lat_cached.empty()) d->lat_cached[c] = 0;
     if (!d->det_cached.empty()) { d->det_cached[c] = 0; d->det_live_nd[c] = -1; }
     if (!d->resc_cache.empty()) { d->resc_cache[(size_t)c].key.valid = false; d->nbp_cache[(size_t)c].key.valid = false; }
@@ -2089,12 +2095,19 @@ static int ensure_det_workspace(wfst_decoder *d) {
 
 // The results of a determinize launch over `list` (workspace slot i = list[i]; res = the launch's result words, on their way or
 // here already) into the host cache: waits for the decoder's stream, checks the channels' error words, fetches the arcs.
-static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &list, const std::vector<int32_t> &res, bool live, int32_t use_final_probs) {
+static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &list, const std::vector<int32_t> &res, bool live, int32_t use_final_probs,
+                                bool detached = false) {
   DetDev &X = d->det;
-  int rc = read_ctl(d);  // synchronises the stream
-  if (rc != WFST_OK) return rc;
-  rc = check_ctl_errors(d);
-  if (rc != WFST_OK) return rc;
+  if (!detached) {
+    int rc = read_ctl(d);  // synchronises the stream
+    if (rc != WFST_OK) return rc;
+    rc = check_ctl_errors(d);
+    if (rc != WFST_OK) return rc;
+  } else {
+    // (a detached prefetch: the channels may be in the middle of their next utterances -- the errors of the utterances these
+    // lattices belong to were reported when their best paths were fetched)
+    if (d->pf_cache.empty()) { d->pf_cache.resize((size_t)d->n_channels); d->pf_have.assign((size_t)d->n_channels, 0); }
+  }
   // a batch: the lattices packed back to back on the device, two copies for all of them (two per lattice were 256 copy calls for
   // 128 utterances); a single lattice, or a batch beyond the packing buffers: straight from its slot
   size_t total = 0;
@@ -2123,11 +2136,14 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
   }
   size_t off = 0;
   for (int i = 0; i < (int)list.size(); ++i) {
-    wfst_decoder::DetLattice &L = d->det_cache[(size_t)list[i]];
+    wfst_decoder::DetLattice &L = detached ? d->pf_cache[(size_t)list[i]] : d->det_cache[(size_t)list[i]];
     L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
     L.err = res[4 * i + 2];   // reported when THIS channel's lattice is asked for
-    d->det_cached[(size_t)list[i]] = live ? 0 : 1;
-    if (live) { d->det_live_nd[(size_t)list[i]] = d->h_decoded[list[i]]; d->det_live_final[(size_t)list[i]] = use_final_probs ? 1 : 0; }
+    if (detached) d->pf_have[(size_t)list[i]] = 1;
+    else {
+      d->det_cached[(size_t)list[i]] = live ? 0 : 1;
+      if (live) { d->det_live_nd[(size_t)list[i]] = d->h_decoded[list[i]]; d->det_live_final[(size_t)list[i]] = use_final_probs ? 1 : 0; }
+    }
     if (L.err) continue;
     L.n_states = res[4 * i];
     L.n_proper = res[4 * i + 3];
@@ -2145,6 +2161,13 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
     }
   }
   HIP_TRY(hipStreamSynchronize(d->stream));
+  if (detached) {
+    // a channel that still holds the very utterance (finalized, not finalized again since): GetLattice finds the work done too
+    for (int i = 0; i < (int)list.size(); ++i) {
+      const int c = list[i];
+      if (d->h_state[c] == 2 && d->pf_epoch[(size_t)i] == d->fin_epoch[(size_t)c]) { d->det_cache[(size_t)c] = d->pf_cache[(size_t)c]; d->det_cached[(size_t)c] = 1; }
+    }
+  }
   return WFST_OK;
 }
 
@@ -2152,7 +2175,16 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
 // NOW, on a side stream -- one lane per lattice, a launch as long as its largest lattice, beside which the decoder's own stream
 // serves best paths and n-best lists (both only read the raw lattices; the arena-index -> lattice-state map the n-best search
 // and the determinizer each write is the same map).  The first wfst_decoder_get_determinized_lattice finds the work done or waits.
-int wfst_decoder_prefetch_determinized(wfst_decoder *d) {
+static int prefetch_determinized(wfst_decoder *d, bool detached);
+int wfst_decoder_prefetch_determinized(wfst_decoder *d) { return prefetch_determinized(d, false); }
+// ... DETACHED: the determinizer's first phase -- everything that reads the channels' state: control blocks, resolved lists, the
+// arena-index scratch; a fraction of a millisecond -- runs on the decoder's stream, the subset construction (tens of milliseconds on
+// one lane per lattice) on a stream of its own, on the workspace alone: wfst_decoder_init / _advance / _finalize do NOT wait for it,
+// the channels go on to their next utterances beside it.  The lattices are kept per channel (wfst_decoder_get_prefetched_lattice)
+// until the next detached prefetch is harvested.
+int wfst_decoder_prefetch_determinized_detached(wfst_decoder *d) { return prefetch_determinized(d, true); }
+
+static int prefetch_determinized(wfst_decoder *d, bool detached) {
   if (!d) return fail(WFST_E_ARG, "NULL decoder");
   if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice needs a decoder created with wfst_limits.lattice_links > 0");
   HIP_TRY(hipSetDevice(d->device));
@@ -2164,11 +2196,14 @@ int wfst_decoder_prefetch_determinized(wfst_decoder *d) {
   for (int c = 0; c < d->n_channels && (int32_t)list.size() < d->det_slots; ++c)   // (one launch's worth; the rest on request)
     if (d->h_state[c] == 2 && !d->det_cached[c]) list.push_back(c);
   if (list.empty()) return WFST_OK;
-  hipStream_t side = d->n_groups > 1 ? d->gstreams[1] : d->det_stream;
+  hipStream_t side = (d->n_groups > 1 && !detached) ? d->gstreams[1] : d->det_stream;   // (detached: a stream the frame loop never uses)
   if (!side) {
     HIP_TRY(hipStreamCreateWithFlags(&d->det_stream, hipStreamNonBlocking));
     side = d->det_stream;
   }
+  if (d->fin_epoch.empty()) d->fin_epoch.assign((size_t)d->n_channels, 0);
+  d->pf_epoch.resize(list.size());
+  for (size_t i = 0; i < list.size(); ++i) d->pf_epoch[i] = d->fin_epoch[(size_t)list[i]];
   if (!d->pf_ev_start) {
     HIP_TRY(hipEventCreateWithFlags(&d->pf_ev_start, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d->pf_ev_done, hipEventDisableTiming));
@@ -2183,23 +2218,67 @@ int wfst_decoder_prefetch_determinized(wfst_decoder *d) {
   for (size_t i = 0; i < list.size(); ++i) pin_list[i] = list[i];
   d->post_dev_list.clear();   // (the slots are about to hold other lattices than the last batched call's)
   HIP_TRY(hipMemcpyAsync(d->pf_dev.p, pin_list, list.size() * 4, hipMemcpyHostToDevice, d->stream));
+  if (detached) launch_determinize(d->D, d->det, d->pf_dev.p, (int32_t)list.size(), d->stream, 1);   // the CSR: in stream order before anything the channels do next
   HIP_TRY(hipEventRecord(d->pf_ev_start, d->stream));   // FinalizeDecoding's pruning and listing are done, the channel list is up
   HIP_TRY(hipStreamWaitEvent(side, d->pf_ev_start, 0));
-  launch_determinize(d->D, d->det, d->pf_dev.p, (int32_t)list.size(), side);
+  launch_determinize(d->D, d->det, d->pf_dev.p, (int32_t)list.size(), side, detached ? 2 : 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(pin_res, d->det.result, list.size() * 4 * 4, hipMemcpyDeviceToHost, side));
   HIP_TRY(hipEventRecord(d->pf_ev_done, side));
   d->pf_pending = true;
+  d->pf_detached = detached;
   return WFST_OK;
 }
 
 static int finish_prefetch(wfst_decoder *d) {
   if (!d->pf_pending) return WFST_OK;
   d->pf_pending = false;
+  const bool detached = d->pf_detached;
+  d->pf_detached = false;
   HIP_TRY(hipEventSynchronize(d->pf_ev_done));
   d->pf_res.assign(d->pf_pin + (size_t)d->n_channels * 4, d->pf_pin + (size_t)d->n_channels * 4 + d->pf_list.size() * 4);
   // (a channel initialised or finalized anew since the launch: hooks in front of those calls came here first)
-  return harvest_determinized(d, d->pf_list, d->pf_res, false, 1);
+  return harvest_determinized(d, d->pf_list, d->pf_res, false, 1, detached);
+}
+
+// Waits for a prefetch in flight and takes its lattices over (what the next prefetch, or any other use of the determinizer, does
+// by itself).
+int wfst_decoder_harvest_prefetched(wfst_decoder *d) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  HIP_TRY(hipSetDevice(d->device));
+  return finish_prefetch(d);
+}
+
+// The determinized lattice of `channel` as the last HARVESTED detached prefetch left it -- the lattice of the utterance the
+// channel had finalized when that wfst_decoder_prefetch_determinized_detached was called, whatever the channel has gone on to
+// since.  (A prefetch still in flight is not waited for: the call before it is what this returns -- a service fetches utterance
+// k - 1's lattices right after it has started utterance k's.)  Same outputs as wfst_decoder_get_determinized_lattice;
+// WFST_E_STATE if no harvested detached prefetch has covered the channel.
+int wfst_decoder_get_prefetched_lattice(wfst_decoder *d, int32_t channel, int32_t cap_states, int32_t cap_arcs, int32_t *n_states, int32_t *n_arcs,
+                                        int32_t *st_final, int32_t *a_src, int32_t *a_dst, int32_t *a_ilabel, int32_t *a_olabel, float *a_graph,
+                                        float *a_acoustic) {
+  if (!d || channel < 0 || channel >= d->n_channels || !n_states || !n_arcs) return fail(WFST_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(d->device));
+  *n_states = 0;
+  *n_arcs = 0;
+  if (d->pf_have.empty() || !d->pf_have[(size_t)channel]) return fail(WFST_E_STATE, "no harvested detached prefetch has covered this channel");
+  const wfst_decoder::DetLattice &L = d->pf_cache[(size_t)channel];
+  if (L.err == 2) return fail(WFST_E_CAPACITY, "channel " + std::to_string(channel) + ": raw lattice larger than the determinizer takes");
+  if (L.err) return fail(WFST_E_CAPACITY, "channel " + std::to_string(channel) + ": the subset construction outgrew its workspace (lattice not determinizable within bounds)");
+  *n_states = L.n_states;
+  *n_arcs = (int32_t)L.a.size();
+  if (L.n_states > cap_states || (int32_t)L.a.size() > cap_arcs) return fail(WFST_E_CAPACITY, "lattice larger than the given capacities");
+  for (int32_t s = 0; s < L.n_states; ++s)
+    if (st_final) st_final[s] = s >= L.n_proper ? 1 : 0;
+  for (size_t k = 0; k < L.a.size(); ++k) {
+    if (a_src) a_src[k] = L.a[k].x;
+    if (a_dst) a_dst[k] = L.a[k].y;
+    if (a_ilabel) a_ilabel[k] = 0;
+    if (a_olabel) a_olabel[k] = L.a[k].z;
+    if (a_graph) a_graph[k] = L.w[k].x;
+    if (a_acoustic) a_acoustic[k] = L.w[k].y;
+  }
+  return WFST_OK;
 }
 
 int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int32_t use_final_probs, int32_t cap_states,

@@ -22,24 +22,36 @@ namespace wfst {
 constexpr int kDetThreads = 256;
 constexpr int kDetLowTmp = 1024;   // elements of the closure's LDS buffers (a closure that outgrows them runs again in the workspace's)
 
-__global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, DetDev X, const int32_t *chans) {
+// phase 0: the whole thing.  1: the CSR only -- everything that reads the DECODER's state (the channel's control block, its resolved
+// token / link lists, the arena-index scratch) -- leaving {-, -, status, raw states} in the result words and the CSR in the
+// workspace; 2: the subset construction from there, which touches the workspace and the outputs alone: it may run on a side
+// stream while the channel goes on to its next utterance (wfst_decoder_prefetch_determinized_detached).
+__global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, DetDev X, const int32_t *chans, int phase) {
   const int slot = blockIdx.x;
   const int c = chans ? chans[slot] : slot;
   const int tid = threadIdx.x;
   const ChanCtl *ctl = D.ctl + c;
-  const int nt = ctl->lat_toks, na = ctl->lat_arcs;
   int32_t *res = X.result + (size_t)slot * 4;   // {states, arcs, status (0 ok, 1 workspace exceeded, 2 lattice too large), -}
-  if (tid == 0) { res[0] = 0; res[1] = 0; res[2] = 0; res[3] = 0; }
-  if (ctl->error || nt <= 0 || ctl->n_decoded <= 0) return;
-  if (nt > X.raw_states_cap || na > X.raw_arcs_cap) {
-    if (tid == 0) res[2] = 2;
-    return;
+  int32_t *base = X.ws + (size_t)slot * X.words_per_channel;   // workspace slots go with the launch's list, not the channel
+  int32_t *off = base;                       // [raw_states_cap + 1]
+  int nt, na;
+  if (phase == 2) {
+    nt = res[3];               // (phase 1 left the raw lattice's size here; 0: nothing to do, the result words say why)
+    if (nt <= 0) return;
+    na = off[nt];
+  } else {
+    nt = ctl->lat_toks;
+    na = ctl->lat_arcs;
+    if (tid == 0) { res[0] = 0; res[1] = 0; res[2] = 0; res[3] = 0; }
+    if (ctl->error || nt <= 0 || ctl->n_decoded <= 0) return;
+    if (nt > X.raw_states_cap || na > X.raw_arcs_cap) {
+      if (tid == 0) res[2] = 2;
+      return;
+    }
   }
   const int4 *toks = D.lat_toks + (size_t)c * D.lat_tok_cap;
   const LatArc *larcs = D.lat_arcs + (size_t)c * D.lat_arc_cap;
   int32_t *state_of = D.remap + (size_t)c * D.arena_cap;   // arena index -> lattice state (scratch between pruning passes)
-  int32_t *base = X.ws + (size_t)slot * X.words_per_channel;   // workspace slots go with the launch's list, not the channel
-  int32_t *off = base;                       // [raw_states_cap + 1]
   int32_t *fin = off + X.raw_states_cap + 1; // [raw_states_cap]
   int32_t *cur = fin + X.raw_states_cap;     // [raw_states_cap]
   DetArc *arcs = reinterpret_cast<DetArc *>(cur + X.raw_states_cap);  // [raw_arcs_cap]
@@ -47,6 +59,7 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
   __shared__ int s_part[kDetThreads];
 
   // ---- Invert + CSR + ArcSort (lattice-determinize-api.cc:8-11), workgroup-wide -------------------------
+  if (phase != 2) {
   for (int i = tid; i < nt; i += kDetThreads) {
     const int4 t = toks[i];
     state_of[t.x] = i;
@@ -105,6 +118,11 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
   }
   __syncthreads();
   // the root token (arena entry 0) must be state 0: lat_toks is in arena order, so it is
+  if (phase == 1) {
+    if (tid == 0) res[3] = nt;   // (the CSR is complete: off[nt] = na)
+    return;
+  }
+  }
   // ---- the subset construction: tables cleared by everyone, then one lane ---------------------------------
   __shared__ DetWs W;
   __shared__ DetElem s_tb[kDetLowTmp], s_tc[kDetLowTmp];
@@ -181,8 +199,8 @@ void launch_det_pack(const DetDev &X, int cnt, int4 *pack_a, float2 *pack_w, int
   hipLaunchKernelGGL(det_pack_kernel, dim3(cnt), dim3(256), 0, s, X, cnt, pack_a, pack_w, pack_cap);
 }
 
-void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chans, int cnt, hipStream_t s) {
-  hipLaunchKernelGGL(determinize_kernel, dim3(cnt), dim3(kDetThreads), 0, s, D, X, chans);
+void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chans, int cnt, hipStream_t s, int phase) {
+  hipLaunchKernelGGL(determinize_kernel, dim3(cnt), dim3(kDetThreads), 0, s, D, X, chans, phase);
 }
 
 }  // namespace wfst

@@ -412,7 +412,7 @@ struct DetDev {
   float2 *out_w;                // [cnt][out_cap] {graph, acoustic}
   int32_t out_cap;
 };
-void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chan_list_dev, int cnt, hipStream_t s);
+void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chan_list_dev, int cnt, hipStream_t s, int phase = 0);   // phase: wfst_determinize.hip
 void launch_det_pack(const DetDev &X, int cnt, int4 *pack_a, float2 *pack_w, int64_t pack_cap, hipStream_t s);
 
 // ---- n cheapest paths of a determinized / rescored lattice (wfst_nbest.hip: nbest_paths_kernel) --------------------------------

@@ -37,6 +37,7 @@ SYMBOLS = [
     "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice", "wfst_decoder_get_nbest_paths",
     "wfst_decoder_get_degraded_frames", "wfst_decoder_get_path_flags", "wfst_decoder_rescore_lattices", "wfst_decoder_nbest_paths_batch",
     "wfst_decoder_prefetch_determinized", "wfst_lattice_labels_batch",
+    "wfst_decoder_prefetch_determinized_detached", "wfst_decoder_get_prefetched_lattice", "wfst_decoder_harvest_prefetched",
 ]
 
 
@@ -404,13 +405,27 @@ class BatchDecoder:
         return dict(n_states=S, st_final=fin, st_frame=fr, st_state=gs, st_cost=co, a_src=src, a_dst=dst, a_ilabel=il,
                     a_olabel=ol, a_graph=gr, a_acoustic=ac)
 
-    def prefetch_determinized(self):
+    def prefetch_determinized(self, detached=False):
         """Start the determinization of every finalized channel now, on a side stream (wfst_decoder_prefetch_determinized):
-        best_paths() / nbest() run beside it, determinized_lattice(c) finds the work done or waits."""
-        _check(lib().wfst_decoder_prefetch_determinized(self.h))
+        best_paths() / nbest() run beside it, determinized_lattice(c) finds the work done or waits.  detached=True: init /
+        advance / finalize do not wait for it either -- the channels decode their next utterances beside it -- and the lattices
+        are fetched with prefetched_lattice(c) (wfst_decoder_prefetch_determinized_detached)."""
+        _check((lib().wfst_decoder_prefetch_determinized_detached if detached else lib().wfst_decoder_prefetch_determinized)(self.h))
+
+    def harvest_prefetched(self):
+        """Wait for a prefetch in flight and take its lattices over (wfst_decoder_harvest_prefetched)."""
+        _check(lib().wfst_decoder_harvest_prefetched(self.h))
+
+    def prefetched_lattice(self, channel):
+        """The determinized lattice the last HARVESTED detached prefetch made of `channel`'s utterance (never waits: right behind
+        the prefetch call for utterance k it returns utterance k - 1's)."""
+        return self._det_fetch(lambda *a: lib().wfst_decoder_get_prefetched_lattice(self.h, int(channel), *a))
 
     def determinized_lattice(self, channel, use_final_probs=True):
         """GetLattice (GetRawLattice + DeterminizeLatticeWrapper) of a channel: dict of numpy arrays, or None."""
+        return self._det_fetch(lambda *a: lib().wfst_decoder_get_determinized_lattice(self.h, int(channel), int(bool(use_final_probs)), *a))
+
+    def _det_fetch(self, call):
         ns, na = C.c_int32(0), C.c_int32(0)
         S, A = 1024, 2048   # (a determinized lattice is a narrow chain: one call as a rule; a second one with the sizes it returned otherwise)
         for attempt in range(2):
@@ -418,9 +433,7 @@ class BatchDecoder:
             p = buf.ctypes.data
             I32, F32 = C.POINTER(C.c_int32), C.POINTER(C.c_float)
             at = lambda k, T: C.cast(p + 4 * (S + k * A), T)
-            rc = lib().wfst_decoder_get_determinized_lattice(self.h, int(channel), int(bool(use_final_probs)), S, A, C.byref(ns),
-                                                             C.byref(na), C.cast(p, I32), at(0, I32), at(1, I32), at(2, I32), at(3, I32),
-                                                             at(4, F32), at(5, F32))
+            rc = call(S, A, C.byref(ns), C.byref(na), C.cast(p, I32), at(0, I32), at(1, I32), at(2, I32), at(3, I32), at(4, F32), at(5, F32))
             if rc == -4 and attempt == 0 and (ns.value > S or na.value > A):
                 S, A = max(S, ns.value), max(A, na.value)
                 continue

@@ -340,6 +340,25 @@ int wfst_decoder_get_raw_lattice(wfst_decoder *d, int32_t channel, int32_t use_f
  * a prefetch in flight. */
 int wfst_decoder_prefetch_determinized(wfst_decoder *d);
 
+/* ... DETACHED: for a service that refills its channels at once.  The part of the determinizer that reads the channels' state
+ * (a fraction of a millisecond) runs on the decoder's stream; the subset construction runs on a stream of its own, on the
+ * determinizer's workspace alone, and wfst_decoder_init / _advance / _finalize do NOT wait for it: the channels decode their next
+ * utterances beside it.  The lattices -- those of the utterances the channels had finalized at this call -- are kept per
+ * channel and fetched with wfst_decoder_get_prefetched_lattice once harvested (by the next prefetch call, or by
+ * wfst_decoder_harvest_prefetched), until the harvest after that; a channel that still holds the very utterance also serves them through
+ * wfst_decoder_get_determinized_lattice.  The side stream is one more HIP stream of the process: with the runtime's default of
+ * four hardware queues it can end up sharing a queue with a channel group's stream, whose launches then wait behind the
+ * determinizer -- export GPU_MAX_HW_QUEUES=8 before the process's first HIP call. */
+int wfst_decoder_prefetch_determinized_detached(wfst_decoder *d);
+/* Waits for a prefetch in flight and takes its lattices over -- what the next prefetch (or any other use of the determinizer)
+ * does by itself; for the last utterance of a stream of them.  wfst_decoder_get_prefetched_lattice returns the lattices of the
+ * last HARVESTED detached prefetch and never waits: right behind the call that started utterance k's determinization it returns
+ * utterance k - 1's. */
+int wfst_decoder_harvest_prefetched(wfst_decoder *d);
+int wfst_decoder_get_prefetched_lattice(wfst_decoder *d, int32_t channel, int32_t cap_states, int32_t cap_arcs,
+                                        int32_t *n_states, int32_t *n_arcs, int32_t *st_final, int32_t *a_src, int32_t *a_dst,
+                                        int32_t *a_ilabel, int32_t *a_olabel, float *a_graph, float *a_acoustic);
+
 /* GetLattice(Lattice*, use_final_probs) (base-inl.h:850-866) = GetRawLattice + DeterminizeLatticeWrapper
  * (newfst/lattice-determinize-api.cc:5-21: Invert, ArcSort, LatticeDeterminizer::Determinize in the (graph,
  * acoustic) lattice semiring, OutputNoolabel, Invert): the word-level deterministic lattice, built on the

@@ -224,3 +224,71 @@ def test_prefetched_determinization_gives_the_same_lattices(synth, tmp_path):
         d2.prefetch_determinized()
     d2.free()
     graph.free()
+
+
+def test_detached_prefetch_keeps_the_lattices_of_the_utterance_before(synth, tmp_path):
+    """wfst_decoder_prefetch_determinized_detached: the channels go on to their NEXT utterances while the determinizer works on
+    the lattices of the ones they just finalized; wfst_decoder_get_prefetched_lattice returns those -- array for array what a
+    decoder that determinizes on request returns for the same utterances -- whatever the channels are doing by then (initialised
+    anew, mid-utterance, finalized again), and the utterances decoded beside the determinizer are unharmed."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(20000, seed=23, n_tid=2000, n_words=3000)
+    m = synth.default_tid2pdf(2000)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=5.0)
+    Ts = [120, 80, 120, 9, 120, 55]
+    sets = [[synth.make_loglikes(g, T, 1000, m, seed=300 + 10 * k + i, mu=-2.4)[0] for i, T in enumerate(Ts)] for k in range(3)]
+    lim = dict(max_frames=128, max_tokens_per_frame=32768, arena_tokens=1 << 20, lattice_links=1 << 21)
+
+    def decode(dec, mats):
+        dev = G.upload(mats)
+        dec.init()
+        dec.advance([t.data_ptr() for t in dev], [int(x.shape[0]) for x in mats], 1000)
+        dec.finalize()
+        return dev
+
+    plain = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(Ts), **lim)
+    want = []
+    for mats in sets:
+        decode(plain, mats)
+        want.append(([dict(words=b["words"].copy(), tot=b["tot_score"]) for b in plain.best_paths()], [plain.determinized_lattice(c) for c in range(len(Ts))]))
+    plain.free()
+
+    def same_det(got, exp, what):
+        for x, y in zip(got, exp):
+            assert (x is None) == (y is None), what
+            if x is not None:
+                for key in x:
+                    assert np.array_equal(x[key], y[key]), (what, key)
+
+    for opt in (dict(channel_groups=1), dict(channel_groups=2)):
+        dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(Ts), options=G.wfstdec.Options(**opt), **lim)
+        with pytest.raises(G.wfstdec.WfstError):
+            dec.prefetched_lattice(0)               # nothing prefetched yet
+        keep = []
+        for k, mats in enumerate(sets):
+            keep.append(decode(dec, mats))
+            dec.prefetch_determinized(detached=True)   # harvests utterance k - 1, starts utterance k
+            best = dec.best_paths()
+            for b, w in zip(best, want[k][0]):
+                assert np.array_equal(b["words"], w["words"]) and b["tot_score"] == w["tot"], "best paths beside the determinizer %s" % opt
+            if k > 0:
+                same_det([dec.prefetched_lattice(c) for c in range(len(Ts))], want[k - 1][1], "utterance %d, fetched while %d is finalized %s" % (k - 1, k, opt))
+        # the last utterance's lattices: fetched while the channels are already mid-way through another one
+        dev = G.upload(sets[0])
+        dec.init()
+        dec.advance([t.data_ptr() for t in dev], [min(5, int(x.shape[0])) for x in sets[0]], 1000)
+        same_det([dec.prefetched_lattice(c) for c in range(len(Ts))], want[1][1], "not harvested yet: still the utterance before %s" % opt)
+        dec.harvest_prefetched()
+        same_det([dec.prefetched_lattice(c) for c in range(len(Ts))], want[2][1], "the last utterance, channels live again %s" % opt)
+        # ... and a channel that still holds its utterance serves them through GetLattice too
+        decode(dec, sets[1])
+        dec.prefetch_determinized(detached=True)
+        same_det([dec.determinized_lattice(c) for c in range(len(Ts))], want[1][1], "GetLattice behind a detached prefetch %s" % opt)
+        dec.prefetch_determinized(detached=True)       # nothing left to do
+        dec.free()
+    graph.free()
