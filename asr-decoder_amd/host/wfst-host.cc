@@ -535,6 +535,32 @@ bool GpuBatchDecoder::GetRawLattice(int channel, Lattice *ofst, bool use_final_p
 void GpuBatchDecoder::PrefetchLattices() {
   if (wfst_decoder_prefetch_determinized(_dec) != WFST_OK) Fatal("wfst_decoder_prefetch_determinized");
 }
+void GpuBatchDecoder::PrefetchLatticesDetached() {
+  if (wfst_decoder_prefetch_determinized_detached(_dec) != WFST_OK) Fatal("wfst_decoder_prefetch_determinized_detached");
+}
+void GpuBatchDecoder::HarvestPrefetchedLattices() {
+  if (wfst_decoder_harvest_prefetched(_dec) != WFST_OK) Fatal("wfst_decoder_harvest_prefetched");
+}
+bool GpuBatchDecoder::GetPrefetchedLattice(int channel, Lattice *ofst) {
+  ofst->DeleteStates();
+  int32_t ns = 0, na = 0;
+  int rc = wfst_decoder_get_prefetched_lattice(_dec, channel, 0, 0, &ns, &na, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc == WFST_E_STATE) { Warn(wfst_last_error()); return false; }
+  if (rc != WFST_OK && !(rc == WFST_E_CAPACITY && ns > 0)) Fatal("GetPrefetchedLattice");
+  if (ns == 0) return false;
+  std::vector<int32_t> fin(ns), src(na), dst(na), il(na), ol(na);
+  std::vector<float> g(na), ac(na);
+  if (wfst_decoder_get_prefetched_lattice(_dec, channel, ns, na, &ns, &na, fin.data(), src.data(), dst.data(), il.data(), ol.data(), g.data(),
+                                          ac.data()) != WFST_OK)
+    Fatal("GetPrefetchedLattice");
+  for (int s = 0; s < ns; ++s) {
+    StateId id = ofst->AddState();
+    if (fin[s]) ofst->SetFinal(id);
+  }
+  ofst->SetStart(0);
+  for (int k = 0; k < na; ++k) ofst->AddArc(src[k], LatticeArc(il[k], ol[k], dst[k], LatticeWeight(g[k], ac[k])));
+  return true;
+}
 void GpuBatchDecoder::GetLattices(const std::vector<int> &channels, std::vector<Lattice> *ofsts, std::vector<bool> *ok, ArpaLm *oldlm,
                                   ArpaLm *newlm, bool use_final_probs) {
   if (!oldlm || !newlm) throw std::runtime_error("second-pass GetLattice needs both LMs");

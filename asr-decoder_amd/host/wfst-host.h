@@ -285,6 +285,12 @@ class GpuBatchDecoder {
   // GetLattice ahead of its request: the finalized channels go to the determinizer now, on a side stream; GetBestPaths / GetNbest
   // run beside it and the first GetLattice finds the work done or waits (wfst_decoder_prefetch_determinized)
   void PrefetchLattices();
+  // ... detached: the channels go on to their next utterances beside the determinizer (wfst_decoder_prefetch_determinized_detached);
+  // the lattices of the utterances finalized at that call are fetched with GetPrefetchedLattice once harvested -- by the next
+  // PrefetchLatticesDetached, or by HarvestPrefetchedLattices (which waits)
+  void PrefetchLatticesDetached();
+  void HarvestPrefetchedLattices();
+  bool GetPrefetchedLattice(int channel, Lattice *ofst);
   // GetLattice of one channel; the first call after FinalizeDecoding determinizes every finalized channel in one launch
   bool GetLattice(int channel, Lattice *ofst, bool use_final_probs = true);
   bool GetLattice(int channel, Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs = true);   // with the second LM pass
