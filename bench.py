@@ -962,7 +962,7 @@ def main():
         n2 = max(2, a.steps // 5)
         common = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "1", "--no-service-point", "--no-legs", "--no-cpu-baseline",
                   "--batch", str(B), "--frames", str(T), "--states", str(a.states), "--pdfs", str(P)]
-        legs = {"biglm": ["--biglm", "--steps", str(n2), "--cpu-sample", "8", "--max-tokens", "131072"],
+        legs = {"biglm": ["--biglm", "--steps", str(max(6, n2)), "--cpu-sample", "8", "--max-tokens", "131072"],
                 "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2", "--postprocess"],
                 "lattice_beam15_no_determinizer": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
                                                    "--max-tokens", "262144", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "2", "--warmup", "2"],
