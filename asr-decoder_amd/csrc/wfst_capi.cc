@@ -2161,12 +2161,24 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
     }
   }
   HIP_TRY(hipStreamSynchronize(d->stream));
+  bool all_current = !live;   // every channel of the list still holds the utterance these lattices were made of
   if (detached) {
     // a channel that still holds the very utterance (finalized, not finalized again since): GetLattice finds the work done too
     for (int i = 0; i < (int)list.size(); ++i) {
       const int c = list[i];
       if (d->h_state[c] == 2 && d->pf_epoch[(size_t)i] == d->fin_epoch[(size_t)c]) { d->det_cache[(size_t)c] = d->pf_cache[(size_t)c]; d->det_cached[(size_t)c] = 1; }
+      else all_current = false;
     }
+  }
+  for (int i = 0; i < (int)list.size(); ++i) all_current = all_current && d->h_state[list[i]] == 2 && res[4 * i + 2] == 0;
+  if (all_current) {
+    // the workspace slots hold these lattices: a batched second pass / n-best right behind starts from them (postprocess_batch)
+    d->post_dev_list = list;
+    d->post_dev_decoded.resize(list.size());
+    for (size_t i = 0; i < list.size(); ++i) d->post_dev_decoded[i] = d->h_decoded[list[i]];
+    d->post_dev_dres = res;
+    d->post_dev_cres.clear();
+    d->post_dev_o = nullptr; d->post_dev_n = nullptr;
   }
   return WFST_OK;
 }
@@ -2449,26 +2461,32 @@ static int postprocess_batch(wfst_decoder *d, const int32_t *channels, int32_t n
     int32_t cnt = (int32_t)list.size();
     std::vector<int32_t> decoded((size_t)cnt);
     for (int i = 0; i < cnt; ++i) decoded[(size_t)i] = d->h_decoded[list[(size_t)i]];
-    // (the slots still hold these very lattices -- the batch of second passes just before this batch of n-best requests?)
-    const bool held = list == d->post_dev_list && decoded == d->post_dev_decoded && (!old_lm || (d->post_dev_o == old_lm && d->post_dev_n == new_lm));
+    // (the determinizer's slots still hold these very lattices -- a prefetch harvested just before, or the batch of second passes
+    // just before this batch of n-best requests?  The composition's too, under the same LMs?)
+    const bool det_held = list == d->post_dev_list && decoded == d->post_dev_decoded;
+    const bool held = det_held && (!old_lm || (d->post_dev_o == old_lm && d->post_dev_n == new_lm && d->post_dev_cres.size() == (size_t)cnt * 4));
     std::vector<int32_t> dres, cres;
     if (held) {
       dres = d->post_dev_dres;
       if (old_lm) cres = d->post_dev_cres;
     } else {
-      d->post_dev_list.clear();
-      const int32_t *dev;
-      rc = stage_channels(d, list.data(), (int32_t)list.size(), &dev, &cnt);
-      if (rc != WFST_OK) return rc;
-      // GetLattice: the determinized lattices of the chunk, list[i] in workspace slot i
-      launch_determinize(d->D, X, dev, cnt, d->stream);
-      HIP_TRY(hipGetLastError());
-      dres.resize((size_t)cnt * 4);
-      HIP_TRY(hipMemcpyAsync(dres.data(), X.result, dres.size() * 4, hipMemcpyDeviceToHost, d->stream));
-      rc = read_ctl(d);  // synchronises the stream
-      if (rc != WFST_OK) return rc;
-      rc = check_ctl_errors(d);
-      if (rc != WFST_OK) return rc;
+      if (det_held) {
+        dres = d->post_dev_dres;   // GetLattice is done (wfst_decoder_prefetch_determinized ran it beside the best paths): the second pass starts here
+      } else {
+        d->post_dev_list.clear();
+        const int32_t *dev;
+        rc = stage_channels(d, list.data(), (int32_t)list.size(), &dev, &cnt);
+        if (rc != WFST_OK) return rc;
+        // GetLattice: the determinized lattices of the chunk, list[i] in workspace slot i
+        launch_determinize(d->D, X, dev, cnt, d->stream);
+        HIP_TRY(hipGetLastError());
+        dres.resize((size_t)cnt * 4);
+        HIP_TRY(hipMemcpyAsync(dres.data(), X.result, dres.size() * 4, hipMemcpyDeviceToHost, d->stream));
+        rc = read_ctl(d);  // synchronises the stream
+        if (rc != WFST_OK) return rc;
+        rc = check_ctl_errors(d);
+        if (rc != WFST_OK) return rc;
+      }
       for (int i = 0; i < cnt; ++i) {
         if (dres[(size_t)4 * i + 2] == 2)
           return fail(WFST_E_CAPACITY, "channel " + std::to_string(list[(size_t)i]) + ": raw lattice larger than the determinizer takes");
