@@ -1,0 +1,503 @@
+// The subset construction of wfst_determinize.h run by ONE WAVE per lattice instead of one lane (device only).
+//
+// The algorithm, its order and its float arithmetic are those of wfst_determinize.h (the reference's LatticeDeterminizer,
+// newfst/lattice-determinize.h:300-1468): output states leave a LIFO queue, an epsilon closure is a FIFO relaxation, subsets
+// are matched within delta.  What changes is who does the work:
+//
+//  * EpsilonClosure (:842-936), two thirds of the dependent memory round trips of a lattice: the closure's element list, its FIFO and
+//    its state index live in LDS; the next kDwWin queue entries are PRICED side by side, one lane each -- the entry's row of
+//    epsilon arcs read, the successor strings looked up or created in the trie (lock-free: a node is allocated, written, then published
+//    by a compare-and-swap on its hash slot; two lanes after the same (parent, label) end up with the same node), the offers
+//    (state, weight, string) staged in LDS -- and then COMMITTED in queue order by one lane, which touches LDS only.  A queue entry's
+//    offers depend on nothing but the entry itself (Element copied at push time, :864-865), whether they are made depends on the
+//    entry still being its state's best when its turn comes (:874-875): that test and every comparison against the current best
+//    run at commit time, in the reference's order, so the result is the sequential one bit for bit; what the lanes do ahead of it are
+//    pure look-ups (an entry that turns out stale has at most left trie nodes nobody refers to).
+//  * everything else (ProcessFinal, the transition pairs, NormalizeSubset, the two subset tables) still runs on lane 0 through the
+//    functions of wfst_determinize.h, between the closures.
+//
+// A closure that outgrows the LDS buffers is run again by det_closure() in the workspace's.
+#ifndef WFST_DETERMINIZE_WAVE_H_
+#define WFST_DETERMINIZE_WAVE_H_
+
+#include <hip/hip_runtime.h>
+
+#include "wfst_determinize.h"
+
+namespace wfst {
+
+constexpr int kDwCur = 1024;     // closure elements held in LDS
+constexpr int kDwQueue = 1024;   // FIFO ring
+constexpr int kDwMap = 2048;     // state -> element index, open addressing
+constexpr int kDwWin = 16;       // queue entries priced side by side
+constexpr int kDwArcs = 4;       // epsilon arcs a lane prices for its entry (an entry with more is priced alone, a lane per arc)
+constexpr int kDwOffers = kDwWin * kDwArcs;   // = 64: also what the lane-per-arc path stages per pass
+
+struct DwShared {
+  DetElem cur[kDwCur];
+  DetElem queue[kDwQueue];
+  uint32_t map[kDwMap];          // 0 = empty, else (state << 11) | (index + 1)
+  uint16_t cur_slot[kDwCur];     // where element i sits in map[] (cleared from here when the closure is done)
+  uint32_t sortk[kDwCur];
+  DetElem offer[kDwOffers];
+  int32_t offer_cnt[kDwWin];
+  int32_t bc[16];                // lane 0 -> wave
+  long long tm[8];               // (development timers)
+};
+
+__host__ __device__ inline int64_t detw_extra_words(const DetCaps &, int32_t) { return 0; }
+
+// compiler-level ordering of LDS / global traffic between the lanes of the one wave (no instruction: a wave's memory operations
+// are issued in order)
+#define DETW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// Accesses to the workspace go through these: the pointers of DetWs are generic (they are carved at run time), and a generic
+// access is a flat_ instruction -- it counts in BOTH memory counters, so every LDS read behind it waits for it and every wait
+// for it drains the stores too.  Cast to the global address space they become global_load / global_store.
+#define DW_G(T) __attribute__((address_space(1))) T
+typedef int dw_v4i __attribute__((ext_vector_type(4), aligned(4)));
+__device__ inline int32_t dw_ld(const int32_t *p) { return *(const DW_G(int32_t) *)p; }
+__device__ inline void dw_st(int32_t *p, int32_t v) { *(DW_G(int32_t) *)p = v; }
+__device__ inline DetElem dw_ld_elem(const DetElem *p) {
+  const dw_v4i v = *(const DW_G(dw_v4i) *)p;
+  DetElem e;
+  e.state = v.x; e.str = v.y; e.w1 = __int_as_float(v.z); e.w2 = __int_as_float(v.w);
+  return e;
+}
+__device__ inline void dw_st_elem(DetElem *p, const DetElem &e) {
+  dw_v4i v;
+  v.x = e.state; v.y = e.str; v.z = __float_as_int(e.w1); v.w = __float_as_int(e.w2);
+  *(DW_G(dw_v4i) *)p = v;
+}
+__device__ inline DetArc dw_ld_arc(const DetArc *p) {
+  const dw_v4i v = *(const DW_G(dw_v4i) *)p;
+  DetArc a;
+  a.ilabel = v.x; a.olabel = v.y; a.w1 = __int_as_float(v.z); a.w2 = __int_as_float(v.w);
+  a.to = *(const DW_G(int32_t) *)(&p->to);
+  return a;
+}
+
+// Successor (:58-79), callable by any lanes at once.
+__device__ inline int32_t detw_succ(DetWs &W, int32_t parent, int32_t label) {
+  const uint32_t mask = (uint32_t)W.tr_hcap - 1u;
+  uint32_t s = det_hash2(parent, label) & mask;
+  int32_t mine = -1;
+  for (;;) {
+    const int32_t n = __hip_atomic_load((DW_G(int32_t) *)(W.tr_hash + s), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (n >= 0) {
+      if (dw_ld(W.tr_parent + n) == parent && dw_ld(W.tr_label + n) == label) return n;   // (a node allocated and not published stays unreferenced)
+      s = (s + 1) & mask;
+      continue;
+    }
+    if (mine < 0) {
+      mine = atomicAdd(&W.tr_n, 1);
+      if (mine >= W.cap.trie || 2 * (int64_t)mine >= W.tr_hcap) { W.err = 1; return 0; }
+      dw_st(W.tr_parent + mine, parent);
+      dw_st(W.tr_label + mine, label);
+      dw_st(W.tr_depth + mine, dw_ld(W.tr_depth + parent) + 1);
+    }
+    int32_t expect = -1;
+    if (__hip_atomic_compare_exchange_strong((DW_G(int32_t) *)(W.tr_hash + s), &expect, mine, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return mine;
+    // (somebody took the slot: look at it again)
+  }
+}
+
+__device__ inline uint32_t detw_mapslot(int32_t state) { return ((uint32_t)state * 2654435761u) >> (32 - 11); }   // kDwMap = 2^11
+
+// index of `state` in cur[], -1
+__device__ inline int detw_map_find(const DwShared &S, int32_t state, uint32_t *slot_out) {
+  uint32_t h = detw_mapslot(state);
+  for (;;) {
+    const uint32_t v = S.map[h];
+    if (v == 0) { *slot_out = h; return -1; }
+    if ((int32_t)(v >> 11) == state) { *slot_out = h; return (int)(v & 2047u) - 1; }
+    h = (h + 1) & (kDwMap - 1);
+  }
+}
+
+// bitonic sort of S.sortk[0..n) (ascending), n <= kDwCur, by the wave
+__device__ inline void detw_sort_keys(DwShared &S, int n, int lane) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  for (int i = n + lane; i < p; i += 64) S.sortk[i] = 0xFFFFFFFFu;
+  DETW_SYNC();
+  for (int k = 2; k <= p; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < p / 2; t += 64) {
+        const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+        const bool up = ((lo & k) == 0);
+        const uint32_t a = S.sortk[lo], b = S.sortk[hi];
+        if ((a > b) == up) { S.sortk[lo] = b; S.sortk[hi] = a; }
+      }
+      DETW_SYNC();
+    }
+}
+
+// EpsilonClosure of e[0..n) (global, one element per state) in place, by the wave; returns the new size (sorted by state),
+// -1 when the LDS buffers were outgrown (nothing changed then but the trie: the caller runs det_closure()).
+__device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int lane) {
+  if (n > kDwCur || W.n_states >= (1 << 21)) return -1;
+  for (int i = lane; i < n; i += 64) {
+    const DetElem x = dw_ld_elem(e + i);
+    S.cur[i] = x;
+    S.queue[i] = x;
+    uint32_t h = detw_mapslot(x.state);
+    for (;;) {
+      if (atomicCAS(&S.map[h], 0u, ((uint32_t)x.state << 11) | (uint32_t)(i + 1)) == 0u) break;
+      h = (h + 1) & (kDwMap - 1);
+    }
+    S.cur_slot[i] = (uint16_t)h;
+  }
+  DETW_SYNC();
+  int nc = n, qh = 0, qn = n;
+  bool over = false;
+  long long tp = 0, tc = 0, iters = 0, ents = 0, tA = clock64();
+  while (qn > 0 && !over) {
+    const int win = qn < kDwWin ? qn : kDwWin;
+    ++iters; ents += win;
+    long long c0 = clock64();
+    // ---- price the window: lane i takes queue entry qh + i ---------------------------------------------------
+    bool big = false;
+    long long x0 = clock64(), x1 = x0, x2 = x0, xs = 0;
+    if (lane < win) {
+      const DetElem el = S.queue[(qh + lane) & (kDwQueue - 1)];
+      uint32_t slot;
+      const int idx = detw_map_find(S, el.state, &slot);
+      int cnt = -1;
+      const DetElem c = S.cur[idx];
+      if (c.str == el.str && c.w1 == el.w1 && c.w2 == el.w2) {   // (else: stale already)
+        cnt = 0;
+        x1 = clock64();
+        const int32_t a1 = dw_ld(W.off + el.state + 1);
+        int32_t a = dw_ld(W.off + el.state);
+        if (a1 < 0) big = true;
+        x2 = clock64();
+        for (; a < a1; ++a) {
+          const DetArc arc = dw_ld_arc(W.arcs + a);
+          if (arc.ilabel != 0) break;
+          if (det_is_zero(arc.w1, arc.w2)) continue;
+          if (cnt == kDwArcs) { big = true; break; }
+          DetElem nx;
+          nx.state = arc.to;
+          nx.w1 = el.w1 + arc.w1;
+          nx.w2 = el.w2 + arc.w2;
+          long long y0 = clock64();
+          nx.str = arc.olabel == 0 ? el.str : detw_succ(W, el.str, arc.olabel);
+          xs += clock64() - y0;
+          S.offer[lane * kDwArcs + cnt] = nx;
+          ++cnt;
+        }
+      }
+      S.offer_cnt[lane] = cnt;
+    }
+    if (lane == 0) { S.tm[6] += x1 - x0; S.tm[7] += x2 - x1; S.tm[4] += xs; }
+    const unsigned long long bigmask = __ballot(big);
+    tp += clock64() - c0; c0 = clock64();
+    int use = win;
+    if (bigmask) use = __ffsll((long long)bigmask) - 1;
+    DETW_SYNC();
+    if (use == 0) {
+      // ---- the head entry has more epsilon arcs than a lane prices: a lane per arc, 64 at a time -----------------
+      const DetElem el = S.queue[qh & (kDwQueue - 1)];
+      const int32_t a0 = dw_ld(W.off + el.state), a1 = dw_ld(W.off + el.state + 1);
+      bool more;
+      {
+        uint32_t slot;
+        const int idx = detw_map_find(S, el.state, &slot);
+        const DetElem c = S.cur[idx];
+        more = (c.str == el.str && c.w1 == el.w1 && c.w2 == el.w2);   // (else: stale)
+      }
+      for (int32_t base = a0; base < a1 && more && !over; base += 64) {
+        const int32_t a = base + lane;
+        bool live = false, noneps = false;
+        if (a < a1) {
+          const DetArc arc = dw_ld_arc(W.arcs + a);
+          if (arc.ilabel != 0) noneps = true;
+          else if (!det_is_zero(arc.w1, arc.w2)) {
+            live = true;
+            DetElem nx;
+            nx.state = arc.to;
+            nx.w1 = el.w1 + arc.w1;
+            nx.w2 = el.w2 + arc.w2;
+            nx.str = arc.olabel == 0 ? el.str : detw_succ(W, el.str, arc.olabel);
+            S.offer[lane] = nx;
+          }
+        }
+        const unsigned long long livemask = __ballot(live);
+        if (__ballot(noneps)) more = false;   // sorted: the epsilons end in this pass
+        DETW_SYNC();
+        if (lane == 0) {
+          for (unsigned long long mk = livemask; mk && !over; mk &= mk - 1) {
+            const DetElem nx = S.offer[__ffsll((long long)mk) - 1];
+            uint32_t slot;
+            const int idx = detw_map_find(S, nx.state, &slot);
+            bool push = false;
+            if (idx < 0) {
+              if (nc >= kDwCur) { over = true; break; }
+              S.map[slot] = ((uint32_t)nx.state << 11) | (uint32_t)(nc + 1);
+              S.cur_slot[nc] = (uint16_t)slot;
+              S.cur[nc++] = nx;
+              push = true;
+            } else {
+              const DetElem c = S.cur[idx];
+              if (det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) == 1) { S.cur[idx] = nx; push = true; }
+            }
+            if (push) {
+              if (qn >= kDwQueue) { over = true; break; }
+              S.queue[(qh + qn) & (kDwQueue - 1)] = nx;
+              ++qn;
+            }
+          }
+          S.bc[0] = nc; S.bc[1] = qn; S.bc[2] = over ? 1 : 0;
+        }
+        DETW_SYNC();
+        nc = S.bc[0]; qn = S.bc[1]; over = S.bc[2] != 0;
+        DETW_SYNC();
+      }
+      qh = (qh + 1) & (kDwQueue - 1);
+      --qn;
+      if (W.err) break;
+      continue;
+    }
+    // ---- commit entries [0, use) in queue order: one lane, LDS only --------------------------------------------
+    if (lane == 0) {
+      int tail = qn;   // entries in the ring counted from qh (the window's are still in it)
+      for (int i = 0; i < use && !over; ++i) {
+        const int cnt = S.offer_cnt[i];
+        if (cnt <= 0) continue;
+        {  // the entry may have been overtaken by an offer committed since it was priced
+          const DetElem el = S.queue[(qh + i) & (kDwQueue - 1)];
+          uint32_t slot;
+          const int idx = detw_map_find(S, el.state, &slot);
+          const DetElem c = S.cur[idx];
+          if (!(c.str == el.str && c.w1 == el.w1 && c.w2 == el.w2)) continue;
+        }
+        for (int j = 0; j < cnt; ++j) {
+          const DetElem nx = S.offer[i * kDwArcs + j];
+          uint32_t slot;
+          const int idx = detw_map_find(S, nx.state, &slot);
+          bool push = false;
+          if (idx < 0) {
+            if (nc >= kDwCur) { over = true; break; }
+            S.map[slot] = ((uint32_t)nx.state << 11) | (uint32_t)(nc + 1);
+            S.cur_slot[nc] = (uint16_t)slot;
+            S.cur[nc++] = nx;
+            push = true;
+          } else {
+            const DetElem c = S.cur[idx];
+            if (det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) == 1) { S.cur[idx] = nx; push = true; }
+          }
+          if (push) {
+            if (tail >= kDwQueue) { over = true; break; }
+            S.queue[(qh + tail) & (kDwQueue - 1)] = nx;
+            ++tail;
+          }
+        }
+      }
+      S.bc[0] = nc; S.bc[1] = tail - use; S.bc[2] = over ? 1 : 0;
+    }
+    DETW_SYNC();
+    nc = S.bc[0]; qn = S.bc[1]; over = S.bc[2] != 0;
+    qh = (qh + use) & (kDwQueue - 1);
+    DETW_SYNC();
+    tc += clock64() - c0;
+    if (W.err) break;
+  }
+  long long tB = clock64();
+  // ---- out: clear the index, sort by state ------------------------------------------------------------------
+  for (int i = lane; i < nc; i += 64) {
+    S.map[S.cur_slot[i]] = 0u;
+    S.sortk[i] = ((uint32_t)S.cur[i].state << 10) | (uint32_t)i;
+  }
+  DETW_SYNC();
+  if (over || W.err) return -1;
+  detw_sort_keys(S, nc, lane);
+  for (int i = lane; i < nc; i += 64) dw_st_elem(e + i, S.cur[S.sortk[i] & 1023u]);
+  DETW_SYNC();
+  if (lane == 0) { S.tm[0] += tp; S.tm[1] += tc; S.tm[2] += iters; S.tm[3] += ents; S.tm[5] += tB - tA; }
+  return nc;
+}
+
+// the closure by the wave, or -- when it outgrows LDS -- by lane 0 in the workspace's buffers
+__device__ inline int detw_closure_any(DetWs &W, DwShared &S, DetElem *e, int n, int lane) {
+  int m = detw_closure(W, S, e, n, lane);
+  if (m >= 0) return m;
+  if (lane == 0) S.bc[3] = W.err ? 0 : det_closure(W, e, n);
+  DETW_SYNC();
+  return S.bc[3];
+}
+
+// ProcessFinal + the transition pairs of output state `out` sorted by (label, state) into W.td / W.ta_label: the first half of
+// det_process_state().  Returns the number of pairs.
+__device__ inline int32_t detw_pairs(DetWs &W, int32_t out) {
+  const int32_t n = W.os_len[out];
+  {
+    bool is_final = false;
+    float f1 = __builtin_huge_valf(), f2 = __builtin_huge_valf();
+    int32_t fs = 0;
+    for (int32_t i = 0; i < n; ++i) {
+      const DetElem el = W.pool[W.os_off[out] + i];
+      if (!W.is_final[el.state]) continue;
+      if (!is_final || det_cmp(W, el.w1, el.w2, el.str, f1, f2, fs) == 1) { is_final = true; f1 = el.w1; f2 = el.w2; fs = el.str; }
+    }
+    if (is_final) det_add_arc(W, out, 0, -1, f1, f2);
+  }
+  int32_t m = 0;
+  for (int32_t i = 0; i < n && !W.err; ++i) {
+    const DetElem el = W.pool[W.os_off[out] + i];
+    for (int32_t a = W.off[el.state]; a < W.off[el.state + 1]; ++a) {
+      const DetArc &arc = W.arcs[a];
+      if (arc.ilabel == 0 || det_is_zero(arc.w1, arc.w2)) continue;
+      if (m >= W.cap.tmp) { W.err = 6; break; }
+      DetElem nx;
+      nx.state = arc.to;
+      nx.w1 = el.w1 + arc.w1;
+      nx.w2 = el.w2 + arc.w2;
+      nx.str = arc.olabel == 0 ? el.str : det_succ(W, el.str, arc.olabel);
+      W.td[m] = nx;
+      W.ta_label[m] = arc.ilabel;
+      ++m;
+    }
+  }
+  for (int32_t gap = m > 64 ? 40 : 1; gap >= 1; gap = gap > 1 ? (gap == 40 ? 13 : gap == 13 ? 4 : 1) : 0)
+    for (int32_t i = gap; i < m; ++i) {
+      const DetElem x = W.td[i];
+      const int32_t xl = W.ta_label[i];
+      int32_t j = i;
+      while (j >= gap && (W.ta_label[j - gap] > xl || (W.ta_label[j - gap] == xl && W.td[j - gap].state > x.state))) {
+        W.td[j] = W.td[j - gap]; W.ta_label[j] = W.ta_label[j - gap]; j -= gap;
+      }
+      W.td[j] = x; W.ta_label[j] = xl;
+    }
+  return m;
+}
+
+// The whole construction for one lattice, called by every thread of a 256-thread workgroup; wave 0 runs it.
+// res {output states, output arcs, error, trie nodes}; timers: clock64 sums (lane 0).
+__device__ inline void detw_run_block(const int32_t *off, const DetArc *arcs, const int32_t *fin, int32_t n_states, int32_t n_arcs,
+                                      int32_t *ws, const DetCaps &caps, DetOutArc *out, int32_t *res, long long *timers, int variant) {
+  __shared__ DetWs W;
+  __shared__ DwShared S;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) {
+    W.n_states = n_states; W.n_arcs = n_arcs; W.off = off; W.arcs = arcs; W.is_final = fin; W.delta = 1.0f / 1024;
+    det_carve(W, ws, caps, n_states);
+    int32_t h = 4096;
+    while (h < 16 * n_states && h < W.tr_hcap) h <<= 1;
+    W.tr_hcap = h < W.tr_hcap ? h : W.tr_hcap;
+  }
+  for (int i = tid; i < kDwMap; i += blockDim.x) S.map[i] = 0u;
+  if (tid < 8) S.tm[tid] = 0;
+  __syncthreads();
+  det_init(W, tid, blockDim.x);
+  __syncthreads();
+  if (tid >= 64) return;
+  long long t_clo = 0, t_pairs = 0, t_sub = 0, t_fin = 0, t0 = clock64();
+  if (lane == 0) {
+    W.err = 0;
+    W.tr_n = 1; W.tr_parent[0] = 0; W.tr_label[0] = 0; W.tr_depth[0] = 0;
+    W.pool_n = 0; W.os_n = 0; W.ih_n = 0; W.q_n = 0; W.oa_n = 0;
+    W.ta[0].state = 0; W.ta[0].str = 0; W.ta[0].w1 = 0.0f; W.ta[0].w2 = 0.0f;
+  }
+  DETW_SYNC();
+  if (n_states > 0) {
+    int m = detw_closure_any(W, S, W.ta, 1, lane);
+    if (lane == 0) {
+      m = det_minimal(W, W.ta, m);
+      det_minimal_to_state(W, W.ta, m, false);
+    }
+    DETW_SYNC();
+    for (;;) {
+      if (W.q_n <= 0 || W.err) break;
+      long long c0 = clock64();
+      if (lane == 0) {
+        const int32_t o = W.queue[--W.q_n];
+        S.bc[4] = o;
+        S.bc[5] = detw_pairs(W, o);
+      }
+      DETW_SYNC();
+      const int32_t o = S.bc[4], mp = S.bc[5];
+      t_pairs += clock64() - c0;
+      int32_t i = 0;
+      while (i < mp && !W.err) {
+        c0 = clock64();
+        if (lane == 0) {
+          const int32_t ilabel = W.ta_label[i];
+          DetElem *sub = W.te;
+          int32_t k = 0;
+          while (i < mp && W.ta_label[i] == ilabel) {
+            DetElem cur = W.td[i];
+            ++i;
+            while (i < mp && W.ta_label[i] == ilabel && W.td[i].state == cur.state) {
+              const DetElem &x = W.td[i];
+              if (det_cmp(W, x.w1, x.w2, x.str, cur.w1, cur.w2, cur.str) == 1) { cur.w1 = x.w1; cur.w2 = x.w2; cur.str = x.str; }
+              ++i;
+            }
+            sub[k++] = cur;
+          }
+          float t1, t2;
+          int32_t common;
+          det_normalize(W, sub, k, &t1, &t2, &common);
+          // InitialToStateId, first half: the look-up
+          const uint32_t b = det_subset_hash(sub, k) & ((uint32_t)W.ih_hcap - 1u);
+          int32_t found = -1;
+          for (int32_t q = W.ih_head[b]; q >= 0; q = W.ih_next[q])
+            if (det_subset_equal(sub, k, W.pool + W.ih_off[q], W.ih_len[q], W.delta)) { found = q; break; }
+          if (found >= 0) {
+            det_add_arc(W, o, ilabel, W.ih_state[found], t1 + W.ih_w1[found], t2 + W.ih_w2[found]);
+          } else {
+            if (k > W.cap.tmp) W.err = 6;
+            for (int32_t q = 0; q < k && !W.err; ++q) W.ta[q] = sub[q];
+          }
+          S.bc[6] = i; S.bc[7] = found; S.bc[8] = k; S.bc[9] = ilabel; S.bc[10] = (int32_t)b;
+          S.bc[11] = __float_as_int(t1); S.bc[12] = __float_as_int(t2);
+        }
+        DETW_SYNC();
+        i = S.bc[6];
+        const int32_t found = S.bc[7], k = S.bc[8];
+        t_sub += clock64() - c0;
+        if (found < 0 && !W.err) {
+          c0 = clock64();
+          int m2 = detw_closure_any(W, S, W.ta, k, lane);
+          t_clo += clock64() - c0;
+          c0 = clock64();
+          if (lane == 0 && !W.err) {
+            // InitialToStateId, second half
+            DetElem *s = W.ta;
+            m2 = det_minimal(W, s, m2);
+            float w1, w2;
+            int32_t str;
+            det_normalize(W, s, m2, &w1, &w2, &str);
+            const int32_t ans = det_minimal_to_state(W, s, m2, true);
+            if (W.ih_n >= W.cap.initials) W.err = 4;
+            else {
+              const int32_t q = W.ih_n++;
+              const uint32_t b = (uint32_t)S.bc[10];
+              W.ih_off[q] = det_store(W, W.te, k);
+              W.ih_len[q] = k;
+              W.ih_state[q] = ans; W.ih_w1[q] = w1; W.ih_w2[q] = w2; W.ih_str[q] = str;
+              W.ih_next[q] = W.ih_head[b];
+              W.ih_head[b] = q;
+              det_add_arc(W, o, S.bc[9], ans, __int_as_float(S.bc[11]) + w1, __int_as_float(S.bc[12]) + w2);
+            }
+          }
+          DETW_SYNC();
+          t_fin += clock64() - c0;
+        }
+      }
+    }
+  }
+  DETW_SYNC();
+  if (lane == 0) {
+    res[0] = W.os_n; res[1] = W.oa_n; res[2] = W.err; res[3] = W.tr_n;
+    if (timers) { timers[0] = clock64() - t0; timers[1] = t_clo; timers[2] = t_pairs; timers[3] = t_sub; timers[4] = t_fin; for (int q = 0; q < 8; ++q) timers[5 + q] = S.tm[q]; }
+  }
+  if (out) {
+    const int32_t na = W.oa_n < caps.arcs ? W.oa_n : caps.arcs;
+    for (int i = lane; i < na; i += 64) out[i] = W.oarcs[i];
+  }
+  (void)variant;
+}
+
+}  // namespace wfst
+#endif

@@ -16,12 +16,13 @@ One "step" = one pass of the hot path over one batch: InitDecoding -> AdvanceDec
 kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:97-129).  Log-likelihoods are resident in HBM before the
 timed region starts.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: utterances shard embarrassingly (128 per GPU, graph replicated, weak scaling); the only
 collective is the gather of the final word-id results per step (RCCL).
-Rank 0 prints ONE JSON line (metric, roofline, cpu_baseline, service_point).
+Rank 0 prints ONE JSON line, under 4 KB (summary_line(): metric, value, config, roofline, cpu_baseline and one dict of scalars
+per leg); everything else -- curves, counts, notes, every leg's own config and roofline -- goes to bench_detail.json.
 
 roofline.achieved: algorithmic bytes (SURVEY.md 8(d) per-unit figures x the units processed) of the slowest
 kernel / its time, from hipEvent pairs around every launch on the stream it is launched on.  The decoder runs
@@ -66,8 +67,8 @@ def log(*a):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--states", type=int, default=2850000)
@@ -131,6 +132,9 @@ def parse():
     ap.add_argument("--lm-new", default="40000,6,100000,3", help="new LM: same four numbers")
     ap.add_argument("--lm-pairs", type=int, default=1 << 20, help="LM pair states per utterance (wfst_limits.lm_pairs)")
     ap.add_argument("--graph-cache", default="/tmp/wfst_bench_graph_%d.bin")
+    ap.add_argument("--detail-out", default="", help="where the FULL result (every leg, curve, count and note) is written as JSON; default "
+                    "bench_detail.json beside this script (and gpurun_out/bench_detail.json when that directory exists).  The final "
+                    "stdout line is the compact summary of it (summary_line(): < 4 KB, scalars only)")
     return ap.parse_args()
 
 
@@ -212,11 +216,14 @@ def cpu_decode_all(dec, graph_path, cd, mats, m, n_threads, big=None):
     return results
 
 
-def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds, big=None):
+def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds, big=None, lattice=None):
     """frames/s of the CPU decoder: n_threads host threads, ONE decoder object per thread over one
     shared read-only graph -- the reference service's threading model (v2-asrbin/v2-asr-service.cc:
     95-105) -- each looping over the batch's utterances (thread t takes t, t + n_threads, ...) for
-    `seconds` of wall time (ref_timed_loop / oracle_timed_loop).  Returns (frames/s, wall s, frames)."""
+    `seconds` of wall time (ref_timed_loop / oracle_timed_loop).  Returns (frames/s, wall s, frames, extra).
+    lattice = n of the n-best: the reference's LATTICE pipeline per utterance (ref_lattice_timed_loop: decode with forward links
+    and back-pruning, best path, GetRawLattice, DeterminizeLatticeWrapper, NShortestPath(n)); extra then carries the stage times
+    summed over the threads and the determinizer's ms per lattice (reference library only)."""
     import ctypes as C
 
     import pyoracle
@@ -224,7 +231,9 @@ def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds, big=None):
     h = dec.load_graph(graph_path)
     cfg = pyoracle.Config(**dict(cd, max_active=min(int(cd.get("max_active", 1000000)), 1000000)))   # (see cpu_decode_all)
     lms = [pyoracle.Lm(dec, big[0], -1.0), pyoracle.Lm(dec, big[1], 1.0)] if big else None
-    f = getattr(dec.lib, ("ref" if kind == "reference" else "oracle") + ("_biglm" if big else "") + "_timed_loop")
+    if lattice is not None and kind != "reference":
+        raise RuntimeError("the lattice pipeline's CPU baseline is the reference's own (oracle/_ref absent)")
+    f = getattr(dec.lib, ("ref" if kind == "reference" else "oracle") + ("_biglm" if big else "_lattice" if lattice is not None else "") + "_timed_loop")
     f.restype = C.c_longlong
     keep = [np.ascontiguousarray(x, np.float32) for x in mats]
     ptrs = (C.c_void_p * len(keep))(*[x.ctypes.data for x in keep])
@@ -232,10 +241,17 @@ def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds, big=None):
     stride = int(keep[0].shape[1])
     mm = np.ascontiguousarray(m, np.int32)
     frames = [0] * n_threads
+    stage = np.zeros((n_threads, 4), np.float64)
+    cnt = np.zeros((n_threads, 4), np.int64)
 
     def work(t):
         el, nw = C.c_double(0), C.c_longlong(0)
         head = [C.c_void_p(h), C.byref(cfg)] + ([C.c_void_p(lms[0].h), C.c_void_p(lms[1].h)] if lms else [])
+        if lattice is not None:
+            frames[t] = f(*head, ptrs, Ts.ctypes.data_as(C.POINTER(C.c_int)), len(keep), stride,
+                          mm.ctypes.data_as(C.POINTER(C.c_int)), int(mm.shape[0] - 1), t, n_threads, C.c_double(seconds), 1, int(lattice),
+                          C.byref(el), stage[t].ctypes.data_as(C.POINTER(C.c_double)), cnt[t].ctypes.data_as(C.POINTER(C.c_longlong)))
+            return
         frames[t] = f(*head, ptrs, Ts.ctypes.data_as(C.POINTER(C.c_int)), len(keep), stride,
                       mm.ctypes.data_as(C.POINTER(C.c_int)), int(mm.shape[0] - 1), t, n_threads, C.c_double(seconds),
                       C.byref(el), C.byref(nw))
@@ -249,7 +265,15 @@ def cpu_timed(kind, dec, graph_path, cd, mats, m, n_threads, seconds, big=None):
     for L in lms or []:
         L.free()
     dec.free_graph(h)
-    return sum(frames) / dt, dt, sum(frames)
+    extra = {}
+    if lattice is not None:
+        st, cn = stage.sum(0), cnt.sum(0)
+        extra = {"stage_thread_seconds": {"decode_finalize_best_path": float(st[0]), "get_raw_lattice": float(st[1]),
+                                          "determinize": float(st[2]), "nbest": float(st[3])},
+                 "lattices": int(cn[0]), "mean_raw_states": float(cn[1]) / max(int(cn[0]), 1), "mean_determinized_states": float(cn[2]) / max(int(cn[0]), 1),
+                 "mean_nbest_paths": float(cn[3]) / max(int(cn[0]), 1),
+                 "determinizer_ms_per_lattice": 1e3 * float(st[2]) / max(int(cn[0]), 1)}
+    return sum(frames) / dt, dt, sum(frames), extra
 
 
 def edit_distance(a, b):
@@ -290,6 +314,164 @@ def divergence(gpu_res, cpu_res):
                                     "first_cheaper": int((sg < 0).sum()), "second_cheaper": int((sg > 0).sum()), "equal": int((sg == 0).sum()),
                                     "note": "(tot_first - tot_second) / |tot_second| over utterances with a path on both sides; first = the "
                                             "decoder under test (GPU, or the reference at hash_ratio 3), second = the reference"}}
+
+
+LINE_LIMIT = 4000   # bytes of the final stdout line (the driver parses it; round 4's 29 KB line was not parsed)
+
+
+def _short(x):
+    """numbers as the line carries them: 6 significant digits, numpy scalars as Python numbers"""
+    if isinstance(x, np.generic):
+        x = x.item()
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None   # strict JSON: no NaN / Infinity
+        return float("%.6g" % x)
+    raise TypeError("summary_line carries scalars only, not %r" % type(x))
+
+
+def _ratio(text):
+    """'16/16 sampled utterances bit-exact ...' -> '16/16'"""
+    import re
+
+    m = re.match(r"\s*(\d+/\d+)", text or "")
+    return m.group(1) if m else None
+
+
+def leg_scalars(o):
+    """One leg of the line: scalars only (its full dict stays in bench_detail.json)."""
+    if "error" in o:
+        return {"error": str(o["error"])[:120]}
+    r, c, b = o.get("roofline", {}), o.get("config", {}), o.get("cpu_baseline", {})
+    k = {"value": o.get("value"), "ms_per_step": o.get("ms_per_step"), "steps": o.get("steps"),
+         "kernel": r.get("kernel"), "frac": r.get("frac"), "whole_path_frac": r.get("whole_path", {}).get("frac_over_step_time"),
+         "parity": _ratio(c.get("parity")), "utterances_with_path": c.get("utterances_with_path"),
+         "cpu_baseline_value": b.get("value"), "cpu_baseline_cores": b.get("cores"), "cpu_baseline_kind": b.get("kind")}
+    if "lattice_parity" in c:
+        k["lattice_parity"] = _ratio(c["lattice_parity"])
+    if "determinizer_ms_per_lattice" in b:
+        k["cpu_determinizer_ms_per_lattice"] = b["determinizer_ms_per_lattice"]
+    for dk in ("divergence_vs_reference", "divergence_vs_port"):   # service-point legs: word-level divergence over the whole batch
+        if dk in o:
+            k["bit_identical"] = "%d/%d" % (o[dk]["bit_identical"], o[dk]["utterances"])
+            k["wer_vs_cpu"] = o[dk]["wer"]
+    for dk in ("reference_self_divergence_hash_ratio_3_vs_2", "port_self_divergence_hash_ratio_3_vs_2"):
+        if dk in o:
+            k["cpu_self_bit_identical"] = "%d/%d" % (o[dk]["bit_identical"], o[dk]["utterances"])
+            k["cpu_self_wer"] = o[dk]["wer"]
+    if "degraded_frames" in o:
+        k["degraded_frames"] = o["degraded_frames"]
+    return {a: _short(v) for a, v in k.items() if v is not None}
+
+
+def summary_line(out, detail_path=None):
+    """The ONE stdout line: strict JSON under LINE_LIMIT bytes.  Top level = the bench contract's keys; config, roofline and
+    cpu_baseline hold scalars; `legs` holds one dict of scalars per further configuration (BASELINE configs[3], configs[4], the
+    service-point workloads).  Shape of reference: the one RTF line of kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:189-192."""
+    top = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data")}
+    top["metric"] = str(top["metric"])[:150]
+    c = out.get("config", {})
+    cfg = {k: c[k] for k in ("workload", "global_batch", "frames_per_utt", "parallelism", "rtfx", "channel_groups",
+                             "mean_active_tokens_per_frame", "peak_tokens_in_a_frame", "max_tokens_per_frame_limit", "degraded_frames",
+                             "utterances_with_path", "fused_epsilon_closures", "decoder_paths_same_on_every_rank") if k in c}
+    if "workload" in cfg:
+        cfg["workload"] = str(cfg["workload"])[:260]
+    for k in ("parity", "lattice_parity", "parity_per_rank_sample"):
+        if k in c:
+            cfg[k] = _ratio(c[k])
+    if "parity" in c:
+        cfg["parity_vs"] = "oracle (biglm, fixed mode)" if "fixed mode" in c["parity"] else "reference" if "reference" in c["parity"] else "oracle"
+    if "gather_check" in c:
+        cfg["gather_check"] = "%d/%d" % (c["gather_check"]["bit_exact_vs_oracle"], c["gather_check"]["utterances"])
+    if "lattice_gather_check" in c:
+        cfg["lattice_gather_check"] = c["lattice_gather_check"]
+    top["config"] = {k: w for k, w in ((k, _short(v)) for k, v in cfg.items()) if w is not None}
+    r = out.get("roofline")
+    if r:
+        rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                    "avg_launch_ms", "launches", "channel_groups", "profiled_step_ms")}
+        rr["traffic_measured_in_run"] = bool(r.get("traffic_measured_in_run", False))
+        rr["whole_path_frac"] = r.get("whole_path", {}).get("frac_over_step_time")
+        rr["whole_path_bytes_per_step"] = r.get("whole_path", {}).get("algorithmic_bytes_per_step")
+        for k in ("expand", "insert", "closure"):
+            rr[k + "_ms_per_step"] = r.get("kernel_ms_per_step", {}).get(k)
+            if "kernel_busy_ms_per_step" in r:
+                rr[k + "_busy_ms_per_step"] = r["kernel_busy_ms_per_step"].get(k)
+        if "per_launch" in r:
+            rr["per_launch_frac"] = r["per_launch"]["frac"]
+        top["roofline"] = {k: _short(v) for k, v in rr.items() if v is not None or k == "traffic"}
+    b = out.get("cpu_baseline")
+    if b:
+        bb = {k: b.get(k) for k in ("value", "unit", "cores", "kind", "single_thread_value", "all_cpus_value", "cpu_model", "affinity_cpus")}
+        bb["sample"] = str(b.get("sample", ""))[:110]
+        top["cpu_baseline"] = {k: _short(v) for k, v in bb.items() if v is not None}
+    legs = {}
+    for name, o in out.get("legs", {}).items():
+        legs[name] = leg_scalars(o)
+    if legs:
+        top["legs"] = legs
+    if detail_path:
+        top["detail"] = detail_path
+
+    def plain(o):
+        if isinstance(o, np.generic):
+            return o.item()
+        raise TypeError("not JSON serialisable: %r" % type(o))
+
+    def dump():
+        return json.dumps(top, default=plain, allow_nan=False, separators=(",", ":"))
+
+    # (a line over the limit loses its optional parts, in this order, rather than its contract keys -- and is printed in any case)
+    core = ("value", "ms_per_step", "steps", "frac", "parity", "cpu_baseline_value", "error")
+    line = dump()
+    if len(line) > LINE_LIMIT:
+        for part, key, n in (("cpu_baseline", "sample", 60), ("config", "workload", 120), ("config", "parallelism", 40)):
+            if part in top and key in top[part]:
+                top[part][key] = str(top[part][key])[:n]
+        top["metric"] = top["metric"][:100]
+        line = dump()
+    if len(line) > LINE_LIMIT and "legs" in top:
+        top["legs"] = {name: {k: v for k, v in leg.items() if k in core} for name, leg in top["legs"].items()}
+        line = dump()
+    while len(line) > LINE_LIMIT and top.get("legs"):
+        top["legs"].pop(next(reversed(top["legs"])))   # (last added first; bench_detail.json has them all)
+        top["legs_dropped_from_line"] = top.get("legs_dropped_from_line", 0) + 1
+        line = dump()
+    return line
+
+
+def write_detail(out, path):
+    """The full result -- what the line summarises -- as indented JSON (NaN / Infinity as null)."""
+    def clean(o):
+        if isinstance(o, dict):
+            return {str(k): clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, np.generic):
+            o = o.item()
+        if isinstance(o, np.ndarray):
+            return clean(o.tolist())
+        if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+            return None
+        return o
+
+    txt = json.dumps(clean(out), indent=1, allow_nan=False)
+    paths = [path] if path else [os.path.join(ROOT, "bench_detail.json")]
+    if not path and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for q in paths:
+        try:
+            with open(q + ".tmp", "w") as f:
+                f.write(txt)
+            os.replace(q + ".tmp", q)
+            written = written or q
+        except OSError as e:   # (a read-only tree: the line still goes out)
+            log("bench detail not written to %s: %r" % (q, e))
+    return written
 
 
 def oracle_counts(graph_path, cd, mats, m, order_free=False, want_paths=None):
@@ -613,7 +795,13 @@ def main():
     # ---- roofline pass: one more step with HIP events around every kernel launch -----------
     gstats = [dec.stats(c) for c in range(B)]
     dec.set_profiling(True)
-    step()
+    torch.cuda.synchronize(dev)
+    tp0 = time.perf_counter()
+    res_p = step()
+    if hasattr(step, "drain"):
+        step.drain(res_p)
+    torch.cuda.synchronize(dev)
+    profiled_step_ms = 1e3 * (time.perf_counter() - tp0)   # the instrumented step itself (slower than a timed one: event pairs, no hipGraph)
     prof = dec.profile()
     dec.set_profiling(False)
 
@@ -737,13 +925,14 @@ def main():
             dv = divergence(res[:ns], cres)
             if not a.no_cpu_baseline:
                 # timed legs: one thread, then every CPU this process may run on
-                fps1, cdt1, fr1 = cpu_timed(kind, cdec, gpath, cd, list(mats), m, 1, a.cpu_seconds, big=big)
-                fps, cdt, fr = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nth, a.cpu_seconds, big=big)
+                lat_n = a.nbest if (a.lattice_links > 0 and a.determinize and kind == "reference") else None
+                fps1, cdt1, fr1, ex1 = cpu_timed(kind, cdec, gpath, cd, list(mats), m, 1, a.cpu_seconds, big=big, lattice=lat_n)
+                fps, cdt, fr, exn = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nth, a.cpu_seconds, big=big, lattice=lat_n)
                 # a point in between (how the CPU decoder scales over one shared graph: it is bound by random access to it)
                 curve = {}
                 for nmid in (8, 32):
                     if nmid < nth:
-                        curve[str(nmid)] = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nmid, max(2.0, a.cpu_seconds / 3), big=big)[0]
+                        curve[str(nmid)] = cpu_timed(kind, cdec, gpath, cd, list(mats), m, nmid, max(2.0, a.cpu_seconds / 3), big=big, lattice=lat_n)[0]
                 cpu_model = ""
                 try:
                     with open("/proc/cpuinfo") as f:
@@ -759,6 +948,19 @@ def main():
                                                  "last: %d and %d frames decoded); value = the best leg" % (B, nth, cdt, fr1, fr),
                                        "threads_to_value": curve,
                                        "affinity_cpus": cpus, "host_cpus": os.cpu_count()}
+                if a.biglm:
+                    out["cpu_baseline"]["what"] = ("the reference's biglm decoder (kaldi-hclg-my-decoder-biglm.cc:80-102: InitDecoding, AdvanceDecoding, "
+                                                   "FinalizeDecoding, GetBestPath) with the same two LMs" if kind == "reference" else "the restatement's biglm decoder")
+                elif lat_n is not None:
+                    out["cpu_baseline"]["what"] = ("the reference's lattice pipeline per utterance: lattice-mode decode (forward links, PruneActiveTokens every "
+                                                   "prune_interval frames), FinalizeDecoding, GetBestPath, GetRawLattice, DeterminizeLatticeWrapper, "
+                                                   "NShortestPath(%d) (kaldi-online-nnet3-my-decoder.cc:50-105)" % lat_n)
+                    out["cpu_baseline"]["determinizer_ms_per_lattice"] = ex1.get("determinizer_ms_per_lattice")   # one thread: a core to itself
+                    out["cpu_baseline"]["one_thread_stages"] = ex1
+                    out["cpu_baseline"]["all_threads_stages"] = exn
+                elif a.lattice_links > 0:
+                    out["cpu_baseline"]["what"] = ("the reference decoder's best-path call sequence (it always records forward links and back-prunes); "
+                                                   "GetRawLattice / determinizer / n-best not included")
             if a.lattice_links > 0:
                 # lattice mode: the raw lattice itself (GetRawLattice after FinalizeDecoding), state by state and arc by arc
                 # against the CPU restatement in its order-free mode (deviation 6), on the first utterances
@@ -871,8 +1073,13 @@ def main():
                            "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
                            "kernel_ms_per_step": {k: prof[k + "_ms"] for k in ("expand", "insert", "closure")},
                            "all_kernels_achieved_GBs": (whole_bytes / (all_ms * 1e-3) / 1e9) if all_ms > 0 else 0.0,
+                           "profiled_step_ms": profiled_step_ms,
                            "whole_path": {"algorithmic_bytes_per_step": whole_bytes,
-                                          "formula": "28 E + 24 N + 24 Z (SURVEY.md 8(d)), counts of one step of this rank",
+                                          "formula": ("28 E + 24 N + 24 Z (SURVEY.md 8(d)), counts of one step of this rank" +
+                                                      ("; + lattice terms (builder-defined, DESIGN.md 'Roofline accounting'): 16 B per forward link recorded, "
+                                                       "24 B per link and 16 B per token priced by a back-pruning sweep, 12 B per item scanned and 32 B per "
+                                                       "survivor moved by a compaction" if a.lattice_links > 0 else "") +
+                                                      ("; + biglm terms (builder-defined): 96 B per LM look-up, 4 B pair id per token and record" if a.biglm else "")),
                                           "frac_over_kernel_time": (whole_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms > 0 else 0.0,
                                           "frac_over_step_time": whole_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                            "measured": "hipEvent pairs around every launch on the stream it is launched on, one extra step after the timed region"}
@@ -964,12 +1171,17 @@ def main():
                 o["divergence_vs_" + kind] = divergence(res3[:ns3], cpu_decode_all(cdec, gpath, cd3_cpu, [mats[i] for i in range(ns3)], m, min(ns3, affinity_cpus())))
             return o
 
-        out["reference_default_limits"] = at_limits(dict(cd, max_active=2147483647, min_active=200),
-                                                    "the headline log-likelihoods at the reference's default limits: max_active=INT_MAX, min_active=200")
+        rdl = at_limits(dict(cd, max_active=2147483647, min_active=200),
+                        "the headline log-likelihoods at the reference's default limits: max_active=INT_MAX, min_active=200")
         sp["divergence_note"] = ("where max_active/min_active bind, the reference's cutoff depends on its own hash-list visiting "
                                  "order (DESIGN.md section 4, deviation 2): it then differs from itself when only hash_ratio "
                                  "changes; the GPU computes the order-independent restatement")
         out["service_point"] = sp
+        L = out.setdefault("legs", {})
+        L["service_point_7000_200"] = {k: v for k, v in sp.items() if k not in ("calibrated_workload_at_7000_200", "headline_workload_at_7000_200")}
+        L["calibrated_7000_200"] = cp
+        L["headline_at_7000_200"] = hp
+        L["reference_default_limits"] = rdl
         log("[rank 0] service point: %.1fs" % (time.time() - t0))
     headline_run = (not a.biglm and a.lattice_links == 0 and not a.host_feed and a.workload == "multi")
     if rank == 0 and world == 1 and headline_run and not a.no_legs:
@@ -985,41 +1197,45 @@ def main():
         del ll_dev
         torch.cuda.empty_cache()
         n2 = max(2, a.steps // 5)
-        common = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "1", "--no-service-point", "--no-legs", "--no-cpu-baseline",
+        common = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "1", "--no-service-point", "--no-legs",
                   "--batch", str(B), "--frames", str(T), "--states", str(a.states), "--pdfs", str(P)]
-        legs = {"biglm": ["--biglm", "--steps", str(max(6, n2)), "--cpu-sample", "8", "--max-tokens", "131072"],
-                "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2", "--postprocess"],
+        # the reference's own CPU path timed beside configs[3] and configs[4] (1 / 32 / all host threads): its biglm decoder
+        # (kaldi-hclg-my-decoder-biglm.cc:80-102) and its lattice pipeline (decode, GetRawLattice, DeterminizeLatticeWrapper,
+        # NShortestPath: kaldi-online-nnet3-my-decoder.cc:50-105); the other legs vary the same two configurations and carry none
+        cpu_on = ["--cpu-seconds", str(min(a.cpu_seconds, 5.0)), "--cpu-threads", str(min(64, a.cpu_threads or affinity_cpus()))] if (a.cpu_sample > 0 and not a.no_cpu_baseline) else ["--no-cpu-baseline"]
+        cpu_off = ["--no-cpu-baseline"]
+        legs = {"biglm": ["--biglm", "--steps", str(max(6, n2)), "--cpu-sample", "8", "--max-tokens", "131072"] + cpu_on,
+                "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2", "--postprocess"] + cpu_off,
                 "lattice_beam15_no_determinizer": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
-                                                   "--max-tokens", "262144", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "2", "--warmup", "2"],
+                                                   "--max-tokens", "262144", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "2", "--warmup", "2"] + cpu_off,
                 "lattice_beam15": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
                                    "--max-tokens", "262144", "--determinize", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "4",
-                                   "--warmup", "2"],   # (the n-best / determinizer paths allocate their workspaces on first use)
+                                   "--warmup", "2"] + cpu_on,   # (the n-best / determinizer paths allocate their workspaces on first use)
                 # ... and as a service that refills its channels at once would run it: utterance k's lattices determinized beside
                 # utterance k + 1's decode (wfst_decoder_prefetch_determinized_detached), fetched one step later, the last step's
                 # waited for inside the timed region
                 "lattice_beam15_pipelined": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
                                              "--max-tokens", "262144", "--determinize", "--pipeline-determinizer", "--steps", str(max(8, n2)),
-                                             "--cpu-sample", "4", "--warmup", "2"]}
+                                             "--cpu-sample", "4", "--warmup", "2"] + cpu_off}
+        L = out.setdefault("legs", {})
         for name, extra in legs.items():
             t0 = time.time()
+            dpath = "/tmp/wfst_bench_leg_%d_%s.json" % (os.getpid(), name)
+            pr = None
             try:
-                pr = subprocess.run(common + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-                line = pr.stdout.decode().strip().splitlines()[-1]
-                o = json.loads(line)
-                keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "roofline", "postprocess") if k in o}
-                keep["config"] = {k: v for k, v in o["config"].items() if k not in ("divergence_vs_reference_sample",)}
-                keep["wall_s"] = time.time() - t0
-                out[name] = keep
+                pr = subprocess.run(common + extra + ["--detail-out", dpath], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                with open(dpath) as f:   # the child's FULL result (its own stdout line is the summary of it)
+                    o = json.load(f)
+                os.unlink(dpath)
+                o["wall_s"] = time.time() - t0
+                L[name] = o
             except Exception as e:  # a leg that fails is reported, not hidden
-                out[name] = {"error": repr(e), "stderr_tail": pr.stderr.decode()[-600:] if "pr" in dir() else ""}
+                L[name] = {"error": repr(e), "stderr_tail": pr.stderr.decode()[-600:] if pr is not None else ""}
             log("[rank 0] leg %s: %.1fs" % (name, time.time() - t0))
     if rank == 0:
-        def plain(o):  # numpy scalars -> Python numbers
-            if isinstance(o, np.generic):
-                return o.item()
-            raise TypeError("not JSON serialisable: %r" % type(o))
-
-        print(json.dumps(out, default=plain), flush=True)
+        # the full result to bench_detail.json, its summary -- strict JSON under 4 KB, scalars only -- as the ONE stdout line
+        where = write_detail(out, a.detail_out)
+        print(summary_line(out, os.path.basename(where) if where else None), flush=True)
     if dec is not None:
         dec.free()
     for L in list(lm_dev) + list(post_lms or []):

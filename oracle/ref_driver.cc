@@ -830,4 +830,85 @@ long long ref_biglm_timed_loop(void *gp, const RefConfig *rc, void *lm1, void *l
   return frames;
 }
 
+// ref_timed_loop() for the LATTICE pipeline (bench.py --lattice-links ... --determinize, cpu_baseline of BASELINE configs[4]): one
+// decoder object per host thread; per utterance InitDecoding, AdvanceDecoding (forward links + PruneActiveTokens every
+// prune_interval frames), FinalizeDecoding, GetBestPath + LatticeToVector, then the service's GetNbest chain
+// (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:78-105): GetRawLattice, LatticeCheckFormat, DeterminizeLatticeWrapper
+// (newfst/lattice-determinize-api.cc:5-21), NShortestPath(n) (newfst/lattice-to-nbest.cc:15-147), ConvertNbestToVector.
+// with_post = 0: decode + best path only (what part of the time the decoder itself takes).
+// stage_seconds[4] (this thread's own sums) = {decode incl. finalize + best path, GetRawLattice, determinizer, n-best};
+// counts[4] = {lattices determinized, raw states, determinized states, n-best paths}.
+long long ref_lattice_timed_loop(void *gp, const RefConfig *rc, const float *const *mats, const int *T, int n_mats, int stride,
+                                 const int *tid2pdf, int n_tid, int first, int step, double seconds, int with_post, int nbest,
+                                 double *elapsed, double *stage_seconds, long long *counts) {
+  Fst *g = static_cast<Fst *>(gp);
+  LatticeFasterDecoderConfig cfg;
+  cfg._beam = rc->beam;
+  cfg._max_active = rc->max_active;
+  cfg._min_active = rc->min_active;
+  cfg._lattice_beam = rc->lattice_beam;
+  cfg._prune_interval = rc->prune_interval;
+  cfg._beam_delta = rc->beam_delta;
+  cfg._hash_ratio = rc->hash_ratio;
+  cfg._prune_scale = rc->prune_scale;
+  ProbeDecoder dec(g, cfg);
+  long long frames = 0;
+  double st[4] = {0, 0, 0, 0};
+  long long cn[4] = {0, 0, 0, 0};
+  typedef std::chrono::steady_clock clk;
+  const auto t0 = clk::now();
+  double dt = 0.0;
+  for (int i = first % n_mats;; i = (i + step) % n_mats) {
+    auto a = clk::now();
+    MatrixDecodable decodable(mats[i], T[i], stride, tid2pdf, n_tid);
+    dec.InitDecoding();
+    dec.AdvanceDecoding(&decodable);
+    dec.FinalizeDecoding();
+    Lattice best_path;
+    if (dec.GetBestPath(&best_path, true)) {
+      std::vector<int> w, p;
+      float tot = 0, lm = 0;
+      LatticeToVector(best_path, w, p, tot, lm);
+    }
+    auto b = clk::now();
+    st[0] += std::chrono::duration<double>(b - a).count();
+    if (with_post) {
+      Lattice lat, det;
+      if (dec.GetRawLattice(&lat, true) && LatticeCheckFormat(&lat)) {
+        auto c = clk::now();
+        st[1] += std::chrono::duration<double>(c - b).count();
+        DeterminizeLatticeOptions opts;
+        bool debug = false;
+        const bool ok = DeterminizeLatticeWrapper(&lat, &det, opts, &debug);
+        auto d = clk::now();
+        st[2] += std::chrono::duration<double>(d - c).count();
+        if (ok) {
+          cn[0] += 1;
+          cn[1] += lat.NumStates();
+          cn[2] += det.NumStates();
+          Lattice nbest_lat;
+          NShortestPath(det, &nbest_lat, (size_t)nbest);
+          std::vector<Lattice> paths;
+          ConvertNbestToVector(nbest_lat, &paths);
+          for (size_t k = 0; k < paths.size(); ++k) {
+            std::vector<int> w, p;
+            float tot = 0, lm = 0;
+            if (LatticeToVector(paths[k], w, p, tot, lm)) cn[3] += 1;
+          }
+          st[3] += std::chrono::duration<double>(clk::now() - d).count();
+        }
+      }
+    }
+    frames += T[i];
+    dt = std::chrono::duration<double>(clk::now() - t0).count();
+    if (dt >= seconds) break;
+  }
+  if (elapsed) *elapsed = dt;
+  for (int k = 0; k < 4; ++k) {
+    if (stage_seconds) stage_seconds[k] = st[k];
+    if (counts) counts[k] = cn[k];
+  }
+  return frames;
+}
+
 }  // extern "C"
