@@ -877,7 +877,7 @@ void wfst_lm_free(wfst_lm *lm) {
 
 // wfst_options.debug carries, besides the kernel phase timers (32 / 64 / 128) and the lattice decoders' comparison mode (0x1000),
 // A/B switches of timing experiments (0x2000 no two-launch frames, 0x4000 no seed tiles, 0x10000 gathered log-likelihoods, 0x20000
-// the insert launch looks for the best token): honoured only by a library built with -DWFST_AB_SWITCHES (tools/ab_bench.sh),
+// the insert launch looks for the best token, 0x40000 the back-pruning's raw frames on one workgroup per channel): honoured only by a library built with -DWFST_AB_SWITCHES (tools/ab_bench.sh),
 // ignored by the product build.
 #ifdef WFST_AB_SWITCHES
 static constexpr bool kAbSwitches = true;
@@ -986,7 +986,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   A(d->bucket.alloc(B * (size_t)n_part * (size_t)bucket_cap));
   A(d->bucket_cnt.alloc(B * (size_t)n_part));
   A(d->emit_cnt.alloc(B * 32));
-  A(d->prune_par.alloc(B * 32));
+  A(d->prune_par.alloc(B * kPruneParInts));
   A(d->eps_vals.alloc(B * ecap));
   A(d->eps_toki.alloc(B * ecap));
   A(d->eps_occ_list.alloc(B * (size_t)L.max_tokens_per_frame));
@@ -1112,6 +1112,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // (two candidates per thread in registers, rounds of 512) for those decoders; it is gone.  (Timing-experiment bits of
   // wfst_options.debug are honoured by WFST_AB_SWITCHES builds only.)
   const int ab_bits = kAbSwitches ? O.debug : 0;
+  D.prune_raw = (ab_bits & 0x40000) ? 0 : 1;   // (0x40000, A/B: the raw frames of a back-pruning pass on one workgroup per channel, as until round 4)
   D.staged = (D.fused && !big) ? 1 : 0;
   D.st_tile_tokens = O.tile_tokens & ~7;
   // the expansion finds the frame's best token itself (its cheapest candidate): the staged kernel of best_row decoders (0x20000: A/B)

@@ -276,7 +276,8 @@ struct DecoderDev {
   float *cutoff_hist;
   int4 *bucket;
   int32_t *bucket_cnt;
-  int32_t *prune_par;    // [c][32]: lattice mode -- what a running back-pruning pass hands to its compaction launches (wfst_kernels.hip: kPrParInts)
+  int32_t prune_raw;     // lattice mode: a running back-pruning pass prices its raw frames with several workgroups per channel (wfst_kernels.hip: lattice_prune_raw_*)
+  int32_t *prune_par;    // [c][kPruneParInts]: lattice mode -- what a running back-pruning pass hands to its compaction launches (wfst_kernels.hip: kPrParInts)
   int32_t *emit_cnt;     // [c][32] (a line each): lattice mode on the fused rows -- entries of the channel's emitter list (the tokens of the
                          // frame being built that have epsilon arcs out: listed by the insert launch in the channel's worklist space,
                          // read and reset by the closure launch's epsilon_links)
@@ -402,6 +403,8 @@ struct DetCaps;
 }  // namespace wfst
 #include "wfst_determinize.h"
 namespace wfst {
+constexpr int kPruneParInts = 48;   // ints of a channel's block of DecoderDev::prune_par
+
 struct DetDev {
   int32_t *ws;                  // [c][words_per_channel]: the lattice's CSR, then the determinizer's workspace
   int64_t words_per_channel;

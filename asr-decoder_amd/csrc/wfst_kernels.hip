@@ -2616,7 +2616,11 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
 constexpr int kPrLds = 16384;    // {extra, cost} pairs of the walk kept in LDS (128 KB): the frame being priced, and the frame after it where both fit
 constexpr int kPrChunk = 8192;   // items of one compaction sweep (kBT threads x 8)
 constexpr int kPrSlabs = 4;      // workgroups per channel of a compaction's flag sweeps (prune_flags)
-constexpr int kPrParInts = 32;   // a channel's compaction parameters (DecoderDev::prune_par): {run, c_lo, tokens lo / hi, frame-0 bound, links lo / hi, nd, slab counts}
+constexpr int kPrParInts = kPruneParInts;   // a channel's parameter block (DecoderDev::prune_par): [0, 16) the compaction's {run, c_lo, tokens lo / hi, frame-0 bound, links lo / hi, nd, slab counts}; [16, 32) lattice_emit's counters; then:
+constexpr int kPrRawCount = 32;  // ... and of the raw frames' launches: workgroups of the channel that have finished their share of the frame,
+constexpr int kPrRawFlag = 33;   // the pass is due and its raw frames are priced by those launches
+constexpr int kPrRawChg = 34;    // [3]: "an extra moved" of an epsilon round, in rotation
+constexpr int kPrRawJ = 16;      // workgroups per channel and raw frame
 struct ScanShared {
   u64 red[2][kBT / 64];
   int changed, any_changed, cnt, err;
@@ -2651,8 +2655,10 @@ __device__ __forceinline__ int block_exscan(int v, ScanShared &ps, int *total) {
 
 // kFinal: FinalizeDecoding.  Returns with extras valid for every frame, dead tokens and links gone, and
 // ctl->pruned_upto = n_decoded.
+// raw_done (running passes only): the frames never priced before, [pruned_upto, n_decoded), have been priced by the launches of
+// lattice_prune_raw_* (several workgroups per channel and frame, below): the walk starts at frame pruned_upto - 1.
 template <bool kFinal>
-__device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps) {
+__device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShared &ps, bool raw_done = false) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   ChanCtl *ctl = D.ctl + c;
   const int nd = ctl->n_decoded;
@@ -2768,7 +2774,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     }
     __syncthreads();
     relax_eps(lmid[nd], loff[nd + 1]);
-  } else {
+  } else if (!raw_done) {
     for (int i = fn + tid; i < fn1; i += kBT) extra[i] = make_uint2(f2o(0.0f), (uint32_t)tok[i].y);
     __syncthreads();
   }
@@ -2792,7 +2798,21 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
   int have = -1, hb = 0;   // ps.w.e[hb] holds the final pairs of frame `have`
   u64 st_links = 0, st_toks = 0;   // links / tokens priced by this walk (wfst_decoder_get_lattice_stats)
   unsigned long long tw = wall_clock64();
-  for (int k = nd - 1; k >= 0; --k) {
+  int k_first = nd - 1;
+  if (!kFinal && raw_done && n_prev < nd) {
+    // the raw frames are priced; did the oldest of them move (it was created with extra_cost 0, base-inl.h:103)?
+    k_first = n_prev - 1;
+    k_lo = n_prev;
+    if (tid == 0) ps.any_changed = 0;
+    __syncthreads();
+    int ch = 0;
+    for (int i = foff[n_prev] + tid; i < foff[n_prev + 1]; i += kBT) ch |= fabsf(o2f(extra[i].x) - 0.0f) > delta;
+    if (ch) ps.any_changed = 1;
+    __syncthreads();
+    moved = ps.any_changed != 0;
+    __syncthreads();
+  }
+  for (int k = k_first; k >= 0; --k) {
     if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[(k + 1 < n_prev) ? 41 : 40], now - tw); tw = now; }
     const int fk = foff[k], fk1 = foff[k + 1], fk2 = foff[k + 2];
     const int nk = fk1 - fk, n1 = fk2 - fk1;
@@ -3588,19 +3608,205 @@ __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_
 // goes on to decode that frame; then the frame's preparation (prep_frame: the pass has moved the frontier).  Launched by
 // wfst_decoder_advance after the closure launch (do_prep 0) of the steps at which some channel of the group reaches a multiple
 // of prune_interval; one 1024-thread workgroup per channel.
+__device__ __forceinline__ bool prune_due(const DecoderDev &D, int c, const int32_t *target) {
+  const ChanCtl *ctl = D.ctl + c;
+  const int nd = ctl->n_decoded;
+  return nd > 0 && nd % D.prune_interval == 0 && ctl->pruned_upto != nd && nd < target[c] && ctl->error == 0 && !ctl->finalized &&
+         nd < D.max_frames;
+}
 template <bool kBig>
-__global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const int32_t *target, int chan_off, int group, int par) {
+__global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const int32_t *target, int chan_off, int group, int par, int raw) {
   __shared__ PruneShared ps;
   __shared__ BoundaryShared sh;
   const int c = blockIdx.x + chan_off;
-  ChanCtl *ctl = D.ctl + c;
-  const int nd = ctl->n_decoded;
-  if (threadIdx.x == 0) D.prune_par[(size_t)c * kPrParInts] = 0;
+  int32_t *pp = D.prune_par + (size_t)c * kPrParInts;
+  const bool raw_done = raw && pp[kPrRawFlag] != 0;
+  if (threadIdx.x == 0) { pp[0] = 0; pp[kPrRawCount] = 0; }   // (the raw launch's meeting counter: back to 0 for the next pass)
   __syncthreads();
-  if (nd > 0 && nd % D.prune_interval == 0 && ctl->pruned_upto != nd && nd < target[c] && ctl->error == 0 && !ctl->finalized &&
-      nd < D.max_frames)
-    prune_pass<false>(D, c, ps);
+  if (prune_due(D, c, target)) prune_pass<false>(D, c, ps, raw_done);
   (void)sh; (void)group; (void)par;
+}
+
+// ---- the RAW frames of a running pass on several workgroups per channel (round 5) --------------------------------------------
+// A pass prices the prune_interval frames decoded since the pass before for the first time -- nine tenths of the links it touches,
+// a frame at a time, each frame after the one behind it -- and one workgroup per channel streamed them at what ONE compute unit
+// moves (~20 GB/s), the launch as long as its heaviest channel.  lattice_prune_raw_kernel gives a channel kPrRawJ workgroups:
+// each takes its share of a frame's emitting links -- priced against the final {extra, cost} pairs of the frame after it, atomicMin
+// on the sources' extras in HBM -- and of its epsilon links, relaxed round by round to their fixpoint (a "changed" word per round
+// in the channel's parameter block), the dead links marked, as relax_eps does; between the phases the channel's workgroups meet
+// at a counter in that block (the grid is a few hundred workgroups, all resident: nobody waits for a workgroup that cannot
+// start; a workgroup that waits longer than a few seconds gives up and flags the channel).  Everything the workgroups share inside
+// the launch is written by atomics and read by agent-scope loads.  min is order independent and every link_extra is computed as in
+// prune_pass: the extras, and with them which tokens and links die, are those of the single-workgroup walk bit for bit.
+// lattice_prune_kernel then goes on with the frames priced before (its LDS path, the delta stopping rule) from frame pruned_upto - 1.
+constexpr int kPrRawT = 256;
+constexpr int kPrRawU = 4;
+
+// all the workgroups of the channel meet: *seq counts this workgroup's barriers
+__device__ __forceinline__ bool raw_barrier(int32_t *cnt, int J, int *seq, bool release) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores and atomics have been acknowledged
+  __syncthreads();
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    if (release) __threadfence();
+    const int want = (*seq + 1) * J;
+    atomicAdd(cnt, 1);
+    int ok = 1;
+    for (unsigned spin = 0; ld_agent(cnt) < want; ++spin) {
+      __builtin_amdgcn_s_sleep(4);
+      if (spin > (1u << 19)) { ok = 0; break; }   // (~a quarter of a second; never expected: a workgroup of the channel that does not run)
+    }
+    if (release) __threadfence();
+    s_ok = ok;
+  }
+  ++*seq;
+  __syncthreads();
+  return s_ok != 0;
+}
+
+constexpr int kPrRawMaxChan = 256;   // channels of a launch whose workgroups are shared out by their work (more: kPrRawJ each)
+
+__global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D, const int32_t *target, int chan_off, int chan_cnt) {
+  const int tid = threadIdx.x;
+  // The launch's workgroups are shared out over its channels in proportion to the links their passes have to price (a channel's
+  // heaviest frames have ten times the links of the batch's mean: with the same number of workgroups everywhere the launch would
+  // last as long as that channel).  Every workgroup computes the same table from the channels' control blocks.
+  __shared__ int s_base[kPrRawMaxChan + 1];
+  __shared__ unsigned long long s_work[kPrRawMaxChan];
+  int c, j, J;
+  if (chan_cnt <= kPrRawMaxChan) {
+    for (int q = tid; q < chan_cnt; q += kPrRawT) {
+      const int cc = q + chan_off;
+      unsigned long long w = 0;
+      if (prune_due(D, cc, target)) {
+        const ChanCtl *cl = D.ctl + cc;
+        const int32_t *lo = D.link_off + (size_t)cc * (D.max_frames + 3);
+        const int a = cl->pruned_upto < 0 ? 0 : cl->pruned_upto;
+        w = 1ull + (unsigned long long)max(0, lo[cl->n_decoded + 1] - lo[a < cl->n_decoded ? a + 1 : cl->n_decoded]);
+      }
+      s_work[q] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long tot = 0;
+      int n_due = 0;
+      for (int q = 0; q < chan_cnt; ++q) { tot += s_work[q]; n_due += s_work[q] != 0; }
+      const long long spare = (long long)gridDim.x - n_due;
+      int b = 0;
+      for (int q = 0; q < chan_cnt; ++q) {
+        s_base[q] = b;
+        if (s_work[q]) b += 1 + (spare > 0 ? (int)((unsigned long long)spare * s_work[q] / tot) : 0);
+      }
+      s_base[chan_cnt] = b;
+    }
+    __syncthreads();
+    const int w = (int)blockIdx.x;
+    if (w >= s_base[chan_cnt]) {
+      // (a workgroup without a share; the first of them also records the channels that are not due)
+      if (w == s_base[chan_cnt])
+        for (int q = tid; q < chan_cnt; q += kPrRawT)
+          if (!s_work[q]) D.prune_par[(size_t)(q + chan_off) * kPrParInts + kPrRawFlag] = 0;
+      return;
+    }
+    int lo = 0, hi = chan_cnt - 1;   // the channel whose range holds w
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_base[mid] <= w) lo = mid; else hi = mid - 1;
+    }
+    if (!s_work[lo]) return;   // (never: a channel that is not due has the empty range [base, base), and the search takes the LAST channel whose base is <= w)
+    c = lo + chan_off; j = w - s_base[lo]; J = s_base[lo + 1] - s_base[lo];
+  } else {
+    c = (int)blockIdx.x / kPrRawJ + chan_off; j = (int)blockIdx.x % kPrRawJ; J = kPrRawJ;
+  }
+  int32_t *pp = D.prune_par + (size_t)c * kPrParInts;
+  const bool due = prune_due(D, c, target);
+  if (j == 0 && tid == 0) pp[kPrRawFlag] = due ? 1 : 0;   // (read by lattice_prune_kernel, the next launch)
+  if (!due) return;
+  ChanCtl *ctl = D.ctl + c;
+  const int nd = ctl->n_decoded, n_prev = ctl->pruned_upto;
+  const int4 *tok = D.tok + (size_t)c * D.arena_cap;
+  int4 *links = D.links + (size_t)c * D.link_cap;
+  uint2 *extra = D.extra + (size_t)c * D.arena_cap;
+  const int32_t *foff = D.frame_off + (size_t)c * (D.max_frames + 2);
+  const int32_t *loff = D.link_off + (size_t)c * (D.max_frames + 3);
+  const int32_t *lmid = D.link_mid + (size_t)c * (D.max_frames + 3);
+  const float kInf = __builtin_huge_valf();
+  const uint32_t kInfO = f2o(kInf), kZeroO = f2o(0.0f);
+  const float lb = D.lattice_beam;
+  int32_t *cnt = pp + kPrRawCount, *chg = pp + kPrRawChg;
+  int seq = 0;
+  bool ok = true;
+  // ---- the newest frame: extra 0 (PruneActiveTokens); every raw frame: +inf until its links are priced ----
+  {
+    const int lo = foff[n_prev < nd ? n_prev : nd], fn = foff[nd], hi = foff[nd + 1];
+    // (agent-scope stores: the line does not stay behind in this XCD's L2, where a later agent-scope load would find it stale)
+    for (int i = lo + j * kPrRawT + tid; i < hi; i += J * kPrRawT)
+      __hip_atomic_store(reinterpret_cast<u64 *>(&extra[i]), (u64)(i >= fn ? kZeroO : kInfO) | ((u64)(uint32_t)tok[i].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j == 0 && tid < 3) __hip_atomic_store(&chg[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  ok = raw_barrier(cnt, J, &seq, true);   // (plain stores: written back before anybody's atomics and agent loads meet them)
+  // link_extra as prune_pass computes it (base-inl.h:524-526)
+  auto link_extra = [&](const int4 &L, u64 e) -> float {
+    const uint32_t eo = (uint32_t)e;
+    return eo >= kInfO ? kInf : o2f(eo) + (__int_as_float(L.w) - __int_as_float((int)(e >> 32)));
+  };
+  // f(i, L, le) over this workgroup's share of links [lo, hi)
+  auto for_links = [&](int lo, int hi, auto &&f) {
+    for (int i0 = lo + j * (kPrRawT * kPrRawU); i0 < hi; i0 += J * (kPrRawT * kPrRawU)) {
+      int4 L[kPrRawU];
+      u64 e[kPrRawU];
+#pragma unroll
+      for (int u = 0; u < kPrRawU; ++u) {
+        const int i = i0 + u * kPrRawT + tid;
+        L[u] = i < hi ? links[i] : make_int4(-1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < kPrRawU; ++u) e[u] = L[u].x >= 0 ? ld_agent(reinterpret_cast<const u64 *>(&extra[L[u].y])) : 0ull;
+#pragma unroll
+      for (int u = 0; u < kPrRawU; ++u)
+        if (L[u].x >= 0) f(i0 + u * kPrRawT + tid, L[u], link_extra(L[u], e[u]));
+    }
+  };
+  u64 st_links = 0, st_toks = 0;
+  for (int k = nd - 1; k >= n_prev && k >= 0 && ok; --k) {
+    // ---- the emitting links frame k -> k + 1 ----
+    const int m_lo = loff[k + 1], m_hi = lmid[k + 1], e0 = lmid[k], e1 = loff[k + 1];
+    for_links(m_lo, m_hi, [&](int i, const int4 &L, float le) {
+      if (!(le <= lb)) { links[i].x = -1; return; }
+      if (le < 0.0f) le = 0.0f;
+      atomicMin(&extra[L.x].x, f2o(le));
+    });
+    ok = raw_barrier(cnt, J, &seq, false);
+    // ---- the epsilon links inside frame k, to their fixpoint ----
+    if (e0 < e1) {
+      for (int round = 0; round < 4096 && ok; ++round) {
+        int ch = 0;
+        for_links(e0, e1, [&](int, const int4 &L, float le) {
+          if (!(le <= lb)) return;
+          if (le < 0.0f) le = 0.0f;
+          const uint32_t o = f2o(le);
+          if (o < atomicMin(&extra[L.x].x, o)) ch = 1;
+        });
+        const int fl = round % 3;
+        if (__any(ch) && (tid & 63) == 0) atomicOr(&chg[fl], 1);
+        if (j == 0 && tid == 0) __hip_atomic_store(&chg[(fl + 1) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (last read two barriers ago)
+        ok = raw_barrier(cnt, J, &seq, false);
+        if (!ld_agent(&chg[fl])) break;
+      }
+      for_links(e0, e1, [&](int i, const int4 &, float le) {
+        if (!(le <= lb)) links[i].x = -1;
+      });
+      // (the flags of the next frame's rounds: every workgroup has read this frame's last one -- it was 0 -- or will read 0)
+      if (j == 0 && tid < 3) __hip_atomic_store(&chg[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    st_links += (u64)(m_hi - m_lo) + 2ull * (u64)(e1 - e0);
+    st_toks += (u64)(foff[k + 1] - foff[k]);
+  }
+  if (j == 0 && tid == 0) {
+    D.lat_stats[(size_t)c * 4 + 1] += st_links;
+    D.lat_stats[(size_t)c * 4 + 2] += st_toks;
+    if (!ok) atomicOr(&ctl->error, kErrInternal);
+  }
 }
 // the compaction's flag sweeps: kPrSlabs workgroups per channel
 __global__ __launch_bounds__(kBT) void lattice_prune_flags_kernel(DecoderDev D, int chan_off) {
@@ -4242,10 +4448,12 @@ void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32
     hipLaunchKernelGGL((closure_kernel<false, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
 }
 void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int group, int par, hipStream_t s) {
-  // the walk (one workgroup per channel, 130 KB of LDS), the compaction's flag sweeps (kPrSlabs workgroups per channel), its moves +
-  // the next frame's preparation
-  if (D.big) hipLaunchKernelGGL(lattice_prune_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
-  else hipLaunchKernelGGL(lattice_prune_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par);
+  // the raw frames (kPrRawJ workgroups per channel), the walk over the frames priced before (one workgroup per
+  // channel, 130 KB of LDS), the compaction's flag sweeps (kPrSlabs workgroups per channel), its moves + the next frame's preparation
+  const int raw = D.prune_raw ? 1 : 0;
+  if (raw) hipLaunchKernelGGL(lattice_prune_raw_kernel, dim3(kPrRawJ * chan_cnt), dim3(kPrRawT), 0, s, D, target, chan_off, chan_cnt);
+  if (D.big) hipLaunchKernelGGL(lattice_prune_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par, raw);
+  else hipLaunchKernelGGL(lattice_prune_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par, raw);
   hipLaunchKernelGGL(lattice_prune_flags_kernel, dim3(chan_cnt * kPrSlabs), dim3(kBT), 0, s, D, chan_off);
   if (D.big) hipLaunchKernelGGL(lattice_prune_move_kernel<true>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
   else hipLaunchKernelGGL(lattice_prune_move_kernel<false>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
