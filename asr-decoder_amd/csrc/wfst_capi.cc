@@ -39,8 +39,10 @@ struct DevBuf {
   size_t n = 0;
   hipError_t alloc(size_t count) {
     release();
+    const hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; return e; }   // (n stays 0: a failed buffer is never taken for a large enough one)
     n = count;
-    return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+    return e;
   }
   void release() {
     if (p) (void)hipFree(p);
@@ -1587,23 +1589,25 @@ static int read_ctl(wfst_decoder *d) {
   return WFST_OK;
 }
 
+// what a channel's error word says (ChanCtl::error), as the call that finds it reports it
+static constexpr int32_t kDetErrCtl = 0x10000;   // DetLattice::err: the channel's utterance ended in a device error (its error word in the low bits)
+static int fail_ctl_error(int c, int e) {
+  std::string m = "channel " + std::to_string(c) + " exceeded a device capacity:";
+  if (e & kErrTableFull) m += " hash table (max_tokens_per_frame)";
+  if (e & kErrArenaFull) m += " token arena (arena_tokens)";
+  if (e & kErrFrontierFull) m += " frontier (max_tokens_per_frame)";
+  if (e & kErrWorklistFull) m += " epsilon worklist (max_tokens_per_frame)";
+  if (e & kErrFramesFull) m += " frames (max_frames)";
+  if (e & kErrBucketFull) m += " candidate bucket (max_tokens_per_frame)";
+  if (e & kErrLinksFull) m += " forward links (lattice_links)";
+  if (e & kErrPairsFull) m += " LM pair states (lm_pairs)";
+  if (e & kErrInternal) return fail(WFST_E_DEVICE, "channel " + std::to_string(c) + ": internal invariant violated on the device (a forward link without its token, or a backpointer without its predecessor)");
+  return fail(WFST_E_CAPACITY, m);
+}
+
 static int check_ctl_errors(wfst_decoder *d) {
-  for (int c = 0; c < d->n_channels; ++c) {
-    const int e = d->p_ctl[c].error;
-    if (e) {
-      std::string m = "channel " + std::to_string(c) + " exceeded a device capacity:";
-      if (e & kErrTableFull) m += " hash table (max_tokens_per_frame)";
-      if (e & kErrArenaFull) m += " token arena (arena_tokens)";
-      if (e & kErrFrontierFull) m += " frontier (max_tokens_per_frame)";
-      if (e & kErrWorklistFull) m += " epsilon worklist (max_tokens_per_frame)";
-      if (e & kErrFramesFull) m += " frames (max_frames)";
-      if (e & kErrBucketFull) m += " candidate bucket (max_tokens_per_frame)";
-      if (e & kErrLinksFull) m += " forward links (lattice_links)";
-      if (e & kErrPairsFull) m += " LM pair states (lm_pairs)";
-      if (e & kErrInternal) return fail(WFST_E_DEVICE, "channel " + std::to_string(c) + ": internal invariant violated on the device (a forward link without its token, or a backpointer without its predecessor)");
-      return fail(WFST_E_CAPACITY, m);
-    }
-  }
+  for (int c = 0; c < d->n_channels; ++c)
+    if (d->p_ctl[c].error) return fail_ctl_error(c, d->p_ctl[c].error);
   return WFST_OK;
 }
 
@@ -2100,14 +2104,17 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
                                 bool detached = false) {
   DetDev &X = d->det;
   if (!detached) {
-    int rc = read_ctl(d);  // synchronises the stream
-    if (rc != WFST_OK) return rc;
-    rc = check_ctl_errors(d);
+    // A device error of one of THESE channels' utterances is kept with that channel's lattice (DetLattice::err, kDetErrCtl | the error
+    // word) and reported when that lattice is asked for; a harvest never fails for it -- it also runs in front of InitDecoding /
+    // AdvanceDecoding / FinalizeDecoding of other channels (finish_prefetch), which have nothing to do with it -- and the other
+    // channels' lattices of the same launch are kept.
+    const int rc = read_ctl(d);  // synchronises the stream
     if (rc != WFST_OK) return rc;
   } else {
     // (a detached prefetch: the channels may be in the middle of their next utterances -- the errors of the utterances these
     // lattices belong to were reported when their best paths were fetched)
-    if (d->pf_cache.empty()) { d->pf_cache.resize((size_t)d->n_channels); d->pf_have.assign((size_t)d->n_channels, 0); }
+    if (d->pf_cache.empty()) d->pf_cache.resize((size_t)d->n_channels);
+    d->pf_have.assign((size_t)d->n_channels, 0);   // what an EARLIER prefetch left belongs to utterances two steps back: gone, not served as this one's
   }
   // a batch: the lattices packed back to back on the device, two copies for all of them (two per lattice were 256 copy calls for
   // 128 utterances); a single lattice, or a batch beyond the packing buffers: straight from its slot
@@ -2140,6 +2147,7 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
     wfst_decoder::DetLattice &L = detached ? d->pf_cache[(size_t)list[i]] : d->det_cache[(size_t)list[i]];
     L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
     L.err = res[4 * i + 2];   // reported when THIS channel's lattice is asked for
+    if (!detached && d->p_ctl[list[i]].error) L.err = kDetErrCtl | d->p_ctl[list[i]].error;
     if (detached) d->pf_have[(size_t)list[i]] = 1;
     else {
       d->det_cached[(size_t)list[i]] = live ? 0 : 1;
@@ -2171,7 +2179,8 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
       else all_current = false;
     }
   }
-  for (int i = 0; i < (int)list.size(); ++i) all_current = all_current && d->h_state[list[i]] == 2 && res[4 * i + 2] == 0;
+  for (int i = 0; i < (int)list.size(); ++i)
+    all_current = all_current && d->h_state[list[i]] == 2 && res[4 * i + 2] == 0 && (detached || !d->p_ctl[list[i]].error);
   if (all_current) {
     // the workspace slots hold these lattices: a batched second pass / n-best right behind starts from them (postprocess_batch)
     d->post_dev_list = list;
@@ -2245,10 +2254,10 @@ static int prefetch_determinized(wfst_decoder *d, bool detached) {
 
 static int finish_prefetch(wfst_decoder *d) {
   if (!d->pf_pending) return WFST_OK;
-  d->pf_pending = false;
+  HIP_TRY(hipEventSynchronize(d->pf_ev_done));
+  d->pf_pending = false;   // (the launch is over: from here on its lattices are either taken over below or lost with the error returned)
   const bool detached = d->pf_detached;
   d->pf_detached = false;
-  HIP_TRY(hipEventSynchronize(d->pf_ev_done));
   d->pf_res.assign(d->pf_pin + (size_t)d->n_channels * 4, d->pf_pin + (size_t)d->n_channels * 4 + d->pf_list.size() * 4);
   // (a channel initialised or finalized anew since the launch: hooks in front of those calls came here first)
   return harvest_determinized(d, d->pf_list, d->pf_res, false, 1, detached);
@@ -2276,6 +2285,7 @@ int wfst_decoder_get_prefetched_lattice(wfst_decoder *d, int32_t channel, int32_
   *n_arcs = 0;
   if (d->pf_have.empty() || !d->pf_have[(size_t)channel]) return fail(WFST_E_STATE, "no harvested detached prefetch has covered this channel");
   const wfst_decoder::DetLattice &L = d->pf_cache[(size_t)channel];
+  if (L.err & kDetErrCtl) return fail_ctl_error(channel, L.err & ~kDetErrCtl);
   if (L.err == 2) return fail(WFST_E_CAPACITY, "channel " + std::to_string(channel) + ": raw lattice larger than the determinizer takes");
   if (L.err) return fail(WFST_E_CAPACITY, "channel " + std::to_string(channel) + ": the subset construction outgrew its workspace (lattice not determinizable within bounds)");
   *n_states = L.n_states;
@@ -2343,6 +2353,7 @@ int wfst_decoder_get_determinized_lattice(wfst_decoder *d, int32_t channel, int3
     }
   }
   const wfst_decoder::DetLattice &L = d->det_cache[(size_t)channel];
+  if (L.err & kDetErrCtl) return fail_ctl_error(channel, L.err & ~kDetErrCtl);
   if (L.err == 2)
     return fail(WFST_E_CAPACITY, "channel " + std::to_string(channel) + ": raw lattice larger than the determinizer takes (" +
                                      std::to_string(X.raw_states_cap) + " states / " + std::to_string(X.raw_arcs_cap) + " arcs)");
@@ -2551,11 +2562,16 @@ static int postprocess_batch(wfst_decoder *d, const int32_t *channels, int32_t n
     P.ws_ints = 7ll * ns_max + 4ll * nmax + na_max + 16;
     P.list_cap = std::min<int64_t>((int64_t)ns_max * n_paths + 1, 1ll << 24);
     const int64_t out_cap = std::min<int64_t>((int64_t)n_paths * ns_max, 1ll << 22);
-    if ((int64_t)d->np_ws.n < P.ws_ints * cnt) HIP_TRY(d->np_ws.alloc((size_t)(P.ws_ints * cnt)));
-    if ((int64_t)d->np_lists.n < P.list_cap * cnt) HIP_TRY(d->np_lists.alloc((size_t)(P.list_cap * cnt)));
-    if ((int64_t)d->np_arcs.n < out_cap * cnt) HIP_TRY(d->np_arcs.alloc((size_t)(out_cap * cnt)));
-    if ((int64_t)d->np_off.n < (int64_t)(n_paths + 1) * cnt) { HIP_TRY(d->np_off.alloc((size_t)(n_paths + 1) * (size_t)cnt)); HIP_TRY(d->np_tot.alloc((size_t)n_paths * (size_t)cnt)); }
-    if ((int64_t)d->np_out.n < 4ll * cnt) HIP_TRY(d->np_out.alloc((size_t)cnt * 4));
+    // (every buffer grows on its OWN size: the batch call and the single-channel call share them with different shapes.  The path
+    // workspace is the per-lattice worst case times the batch: where the device cannot give that much the call reports a capacity,
+    // not a device error -- GpuBatchDecoder::GetNbests then asks channel by channel, which needs one lattice's worth)
+    auto grow = [&](auto &buf, int64_t need) -> bool { return (int64_t)buf.n >= need || buf.alloc((size_t)need) == hipSuccess; };
+    if (!grow(d->np_ws, P.ws_ints * cnt) || !grow(d->np_lists, P.list_cap * cnt) || !grow(d->np_arcs, out_cap * cnt) ||
+        !grow(d->np_off, (int64_t)(n_paths + 1) * cnt) || !grow(d->np_tot, (int64_t)n_paths * cnt) || !grow(d->np_out, 4ll * cnt)) {
+      (void)hipGetLastError();
+      return fail(WFST_E_CAPACITY, "n-best: no device memory for the path workspace of " + std::to_string(cnt) + " lattices at once (" +
+                                       std::to_string(n_paths) + " paths each): ask channel by channel (wfst_decoder_get_nbest_paths)");
+    }
     P.n = n_paths;
     P.ws = d->np_ws.p; P.lists = d->np_lists.p;
     P.out = d->np_out.p; P.out_off = d->np_off.p; P.out_tot = d->np_tot.p;
@@ -2740,8 +2756,9 @@ int wfst_decoder_get_nbest_paths(wfst_decoder *d, int32_t channel, int32_t n, in
   if ((int64_t)d->np_ws.n < ws_ints) HIP_TRY(d->np_ws.alloc((size_t)ws_ints));
   if ((int64_t)d->np_lists.n < list_cap) HIP_TRY(d->np_lists.alloc((size_t)list_cap));
   if ((int64_t)d->np_arcs.n < out_cap) HIP_TRY(d->np_arcs.alloc((size_t)out_cap));
-  if ((int64_t)d->np_off.n < n + 1) { HIP_TRY(d->np_off.alloc((size_t)n + 1)); HIP_TRY(d->np_tot.alloc((size_t)n)); }
-  if (!d->np_out.p) HIP_TRY(d->np_out.alloc(4));
+  if ((int64_t)d->np_off.n < n + 1) HIP_TRY(d->np_off.alloc((size_t)n + 1));
+  if ((int64_t)d->np_tot.n < n) HIP_TRY(d->np_tot.alloc((size_t)n));   // (its own size: the batch call sizes the two differently)
+  if ((int64_t)d->np_out.n < 4) HIP_TRY(d->np_out.alloc(4));
   P.n = n;
   P.ws = d->np_ws.p; P.ws_ints = (int64_t)d->np_ws.n;
   P.lists = d->np_lists.p; P.list_cap = (int64_t)d->np_lists.n;

@@ -307,6 +307,8 @@ bool GpuLatticeDecoder::Decode(AmInterface *decodable) {
   return GetBestPath(&tmp, true);
 }
 
+static void WarnIfDegraded(wfst_decoder *dec, int channel);
+
 bool GpuLatticeDecoder::GetBestPath(Lattice *ofst, bool use_final_probs) {
   ofst->DeleteStates();
   int cap = 4 * std::max(1, NumFramesDecoded()) + 64;
@@ -319,6 +321,7 @@ bool GpuLatticeDecoder::GetBestPath(Lattice *ofst, bool use_final_probs) {
     if (rc == WFST_E_CAPACITY && n > cap) { cap = n; continue; }
     if (rc == WFST_E_STATE) throw std::runtime_error(wfst_last_error());  // reference: LOG_ERR
     if (rc != WFST_OK) Fatal("GetBestPath");
+    WarnIfDegraded(_dec, 0);
     if (n == 0) { Warn("No final token found."); return false; }
     HopsToLattice(il.data(), ol.data(), g.data(), ac.data(), n, ofst);
     return true;
@@ -629,6 +632,16 @@ void GpuBatchDecoder::FinalizeDecoding(const std::vector<int> &ch) {
 }
 int GpuBatchDecoder::NumFramesDecoded(int channel) const { return wfst_decoder_num_frames_decoded(_dec, channel); }
 
+// A best-path decoder does not fail at wfst_limits.max_tokens_per_frame, it goes on from the limit-th cheapest token (the limit
+// acts as a max_active): the result may then differ from the reference's at the configured beam.  Said once per utterance and
+// channel, where the reference would have said nothing because it has no such limit.
+static void WarnIfDegraded(wfst_decoder *dec, int channel) {
+  int32_t n = 0;
+  if (wfst_decoder_get_degraded_frames(dec, channel, &n) == WFST_OK && n > 0)
+    Warn("channel " + std::to_string(channel) + ": " + std::to_string(n) + " frame(s) held more tokens than max_tokens_per_frame; the search "
+         "went on from the cheapest of them (a max_active): raise wfst_limits.max_tokens_per_frame for the result at the configured beam");
+}
+
 void GpuBatchDecoder::GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts,
                                    std::vector<bool> *ok, bool use_final_probs) {
   const int cnt = channels.empty() ? _n : (int)channels.size();
@@ -649,6 +662,7 @@ void GpuBatchDecoder::GetBestPaths(const std::vector<int> &channels, std::vector
     if (rc == WFST_E_STATE) throw std::runtime_error(wfst_last_error());
     if (rc != WFST_OK) Fatal("GetBestPath");
     for (int i = 0; i < cnt; ++i) {
+      WarnIfDegraded(_dec, channels.empty() ? i : channels[i]);
       if (n[i] == 0) continue;
       HopsToLattice(&il[(size_t)i * cap], &ol[(size_t)i * cap], &g[(size_t)i * cap], &ac[(size_t)i * cap], n[i],
                     &(*ofsts)[i]);

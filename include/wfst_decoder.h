@@ -62,12 +62,20 @@ typedef struct wfst_config {
 } wfst_config;
 
 /* Per-channel device capacities (0 = default).  Exceeding one makes the affected call return
- * WFST_E_CAPACITY; nothing is silently dropped. */
+ * WFST_E_CAPACITY -- with ONE exception, max_tokens_per_frame of a best-path decoder on the fused rows,
+ * which degrades the search instead (below) and says so through wfst_decoder_get_degraded_frames; the
+ * C++ mirror's GetBestPath(s) warn when that count is not 0.  Nothing is dropped without one of the two. */
 typedef struct wfst_limits {
   int32_t max_frames;           /* frames per utterance                     (default 4096)    */
   int32_t max_tokens_per_frame; /* distinct states reached in one frame     (default 65536, or 4 x a finite max_active, at most 262144).
                                    Best-path decoders on the fused rows do not fail at it: it acts as a max_active
-                                   (wfst_decoder_get_degraded_frames); lattice and biglm decoders return WFST_E_CAPACITY */
+                                   (the frame goes on from its limit-th cheapest token; wfst_decoder_get_degraded_frames
+                                   counts such frames).  Such a frame may HOLD several times the limit (the arrivals of
+                                   limit expanded tokens), while the token collection is sized for limit tokens a frame:
+                                   an utterance that stays over the limit frame after frame can still exhaust the arena
+                                   between two collections and then fails loudly with WFST_E_CAPACITY (arena full) --
+                                   size arena_tokens for it or raise the limit.  Lattice and biglm decoders return
+                                   WFST_E_CAPACITY at the limit itself */
   int64_t arena_tokens;         /* token arena of one utterance, 16 bytes a token.  BEST-PATH decoders keep every
                                    token of the utterance for the traceback (there are no link lists to prune
                                    them by): an utterance of T frames with n tokens alive per frame needs about

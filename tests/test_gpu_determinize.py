@@ -292,3 +292,70 @@ def test_detached_prefetch_keeps_the_lattices_of_the_utterance_before(synth, tmp
         dec.prefetch_determinized(detached=True)       # nothing left to do
         dec.free()
     graph.free()
+
+
+def test_a_channels_device_error_stays_with_that_channel(synth, tmp_path):
+    """ADVICE r4: a prefetched determinization is harvested in front of InitDecoding / AdvanceDecoding / FinalizeDecoding of ANY channel;
+    a capacity error of one channel's finished utterance must not make those calls fail for the others, nor lose the other channels'
+    lattices of the same launch -- it is reported when THAT channel's lattice is asked for.  And a detached harvest forgets the
+    lattices of channels it did not cover (they belong to utterances further back)."""
+    import gpu_util as G
+
+    W = G.wfstdec
+    g = synth.make_hclg_like(6000, seed=29, n_tid=2000, n_words=3000)
+    m = synth.default_tid2pdf(2000)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = W.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=5.0)
+    Ts = [110, 8, 110, 8]
+    mats = [synth.make_loglikes(g, T, 1000, m, seed=500 + i, mu=-2.4)[0] for i, T in enumerate(Ts)]
+    lim = dict(max_frames=128, max_tokens_per_frame=32768, arena_tokens=1 << 20)
+
+    def decode(dec, channels=None):
+        dev = G.upload(mats)
+        dec.init()
+        dec.advance([t.data_ptr() for t in dev], Ts, 1000)
+        dec.finalize()
+        return dev
+
+    roomy = W.BatchDecoder(graph, G.gpu_config(cd), len(Ts), lattice_links=1 << 21, **lim)
+    keep = decode(roomy)
+    roomy.sync()
+    links = [roomy.lattice_stats(c)["links_recorded"] for c in range(len(Ts))]
+    want = [roomy.determinized_lattice(c) for c in range(len(Ts))]
+    roomy.free()
+    short, long_ = max(links[1], links[3]), min(links[0], links[2])
+    assert 4 * short < long_, links
+    tight = W.BatchDecoder(graph, G.gpu_config(cd), len(Ts), lattice_links=int(2 * short + 64), **lim)   # the long utterances outgrow it
+    keep2 = decode(tight)
+    tight.prefetch_determinized()           # GetLattice's determinizer, started behind FinalizeDecoding
+    tight.init(channels=[1])                 # harvests it: channel 0 / 2's overflow is not channel 1's business
+    dev1 = G.upload([mats[1]])
+    tight.advance([dev1[0].data_ptr()], [Ts[1]], 1000, channels=[1])
+    tight.finalize(channels=[1])
+    with pytest.raises(W.WfstError) as e:
+        tight.determinized_lattice(0)
+    assert e.value.code == -4 and "forward links" in str(e.value)   # WFST_E_CAPACITY
+    got = tight.determinized_lattice(3)      # the same launch's other lattice was kept
+    assert got is not None and all(np.array_equal(got[k], want[3][k]) for k in got)
+    tight.free()
+
+    # a detached harvest that does not cover a channel forgets what an earlier one left for it
+    dec = W.BatchDecoder(graph, G.gpu_config(cd), len(Ts), lattice_links=1 << 21, **lim)
+    keep3 = decode(dec)
+    dec.prefetch_determinized(detached=True)
+    dec.init()
+    dec.advance([t.data_ptr() for t in keep3], Ts, 1000)
+    dec.finalize(channels=[1])               # only channel 1 finishes its next utterance
+    dec.prefetch_determinized(detached=True)   # harvests the first prefetch (all four), starts channel 1's
+    assert all(dec.prefetched_lattice(c) is not None for c in (0, 2))
+    dec.harvest_prefetched()                 # ... which covered channel 1 alone
+    assert dec.prefetched_lattice(1) is not None
+    for c in (0, 2, 3):
+        with pytest.raises(W.WfstError):
+            dec.prefetched_lattice(c)
+    dec.free()
+    graph.free()
+    del keep, keep2

@@ -192,6 +192,10 @@ def test_batched_postprocessing_equals_the_per_channel_calls(synth, tmp_path):
         A.nbest_paths_batch(n, *lms)
         for c in range(C):
             assert same_paths(A.nbest_paths(c, n, *lms), B.nbest_paths(c, n, *lms)), "n-best %d, channel %d" % (n, c)
+    # the single-channel call right behind a batch: the batch's offset buffer holds (n + 1) x C words, its totals buffer n x C -- a
+    # request alone with n between the two has to grow the totals buffer on its own size (it wrote past it)
+    A.nbest_paths_batch(10)
+    assert same_paths(A.nbest_paths(1, 10 * C + 1), B.nbest_paths(1, 10 * C + 1)), "n between the batch's two buffer sizes"
     # a channel list; a request the batch did not cover is computed alone (and agrees)
     A.nbest_paths_batch(7, L1, L2, channels=[C - 1, 0])
     for c in (0, C - 1, 1):
