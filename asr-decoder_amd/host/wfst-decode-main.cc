@@ -26,6 +26,11 @@
 //                  stream) driven by its own host thread -- the reference service's model of one
 //                  decoder object per thread (v2-asrbin/v2-asr-service.cc:95-105); the GPU overlaps
 //                  independent batches.  Output order is unchanged.
+//   --devices=a,b,...  batch shape only: the node's GPUs: the graph (and the LMs) are uploaded once per listed device, each
+//                  device gets `inflight` GpuBatchDecoders of its own, each driven by its own host thread; batch b goes to device
+//                  b mod n -- utterances share nothing but the read-only graph, so there is no exchange between devices, and the
+//                  results are merged in input order on the host (the reference's model of N worker threads over one shared
+//                  graph, v2-asrbin/v2-asr-service.cc:95-105, with one graph replica per device).  A device may be listed twice.
 //   --nbest=N      also print the N-best word sequences of every utterance (the service's
 //                  GetNbestTxt, kaldi-online-nnet3-my-decoder.cc:139-150) as "KEY-k w1 w2 ..." to
 //                  stdout and "LOG KEY-k tot_score .. lm_score .." to stderr (lattice mode)
@@ -95,6 +100,7 @@ int main(int argc, char **argv) {
     std::string lattice_file, lattice_text;
     long long lattice_links = 1ll << 22;
     int nbest = 0, inflight = 1, chunk = 0;
+    std::vector<int> devices(1, 0);
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
       std::string a = argv[i];
@@ -108,6 +114,15 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 8, "--nbest=") == 0) nbest = atoi(a.c_str() + 8);
       else if (a.compare(0, 11, "--inflight=") == 0) inflight = std::max(1, atoi(a.c_str() + 11));
       else if (a.compare(0, 8, "--chunk=") == 0) chunk = std::max(0, atoi(a.c_str() + 8));
+      else if (a.compare(0, 10, "--devices=") == 0) {
+        devices.clear();
+        for (size_t p0 = 10; p0 <= a.size();) {
+          const size_t p1 = std::min(a.find(',', p0), a.size());
+          if (p1 > p0) devices.push_back(atoi(a.substr(p0, p1 - p0).c_str()));
+          p0 = p1 + 1;
+        }
+        if (devices.empty()) { std::cerr << "--devices needs a list of device ordinals\n"; return 1; }
+      }
       else if (a.compare(0, 9, "--lm-old=") == 0) lm_old_file = a.substr(9);
       else if (a.compare(0, 9, "--lm-new=") == 0) lm_new_file = a.substr(9);
       else if (a.compare(0, 16, "--second-lm-old=") == 0) second_old_file = a.substr(16);
@@ -116,21 +131,27 @@ int main(int argc, char **argv) {
       else pos.push_back(a);
     }
     if (pos.size() < 3) {
-      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream [--chunk=N]] [--inflight=K] [--nbest=N] [--lattice-out=FILE] [--determinize] "
+      std::cerr << "usage: wfst-decode [--tid2pdf=FILE] [--batch=N] [--single-stream [--chunk=N]] [--inflight=K] [--devices=a,b,...] [--nbest=N] [--lattice-out=FILE] [--determinize] "
                    "[--lattice-text=FILE] [--lattice-links=N] [--lm-old=FILE --lm-new=FILE] [--second-lm-old=FILE --second-lm-new=FILE] [--nbest-lattice-out=FILE] CONFIG GRAPH LOGLIKES [WORDS_OUT]\n";
       return 1;
     }
     LatticeFasterDecoderConfig opt;
     opt.ReadConfigFile(pos[0]);
-    Fst fst;
-    if (!fst.ReadFst(pos[1].c_str())) return 1;
+    if (single && devices.size() > 1) { std::cerr << "--devices lists several devices: batch shape only\n"; return 1; }
+    // one graph replica per listed device (fsts[0] also serves --single-stream)
+    std::vector<std::unique_ptr<Fst> > fsts;
+    for (size_t di = 0; di < devices.size(); ++di) {
+      fsts.emplace_back(new Fst());
+      if (!fsts.back()->ReadFst(pos[1].c_str(), devices[di])) return 1;
+    }
+    Fst &fst = *fsts[0];
     if (!tid2pdf_file.empty()) {
       std::ifstream t(tid2pdf_file.c_str(), std::ios::binary | std::ios::ate);
       if (!t) { std::cerr << "cannot open " << tid2pdf_file << "\n"; return 1; }
       std::vector<int32_t> m((size_t)t.tellg() / 4);
       t.seekg(0);
       t.read((char *)m.data(), m.size() * 4);
-      fst.SetTid2Pdf(m);
+      for (auto &f : fsts) f->SetTid2Pdf(m);
     }
     std::ifstream in(pos[2].c_str(), std::ios::binary);
     if (!in) { std::cerr << "cannot open " << pos[2] << "\n"; return 1; }
@@ -160,25 +181,31 @@ int main(int argc, char **argv) {
     };
     // biglm (kaldi-nnet3bin/kaldi-hclg-my-decoder-biglm.cc:55-60,80): both LM files, the old one rescaled by -1
     const bool biglm = !lm_old_file.empty() || !lm_new_file.empty();
-    ArpaLm lm1, lm2;
+    struct LmPair { ArpaLm a, b; };
+    std::vector<std::unique_ptr<LmPair> > lms, slms;   // [device index]: the search's LMs, the second pass's
+    auto load_pairs = [&](const std::string &f_old, const std::string &f_new, std::vector<std::unique_ptr<LmPair> > *v) -> bool {
+      for (size_t di = 0; di < devices.size(); ++di) {
+        v->emplace_back(new LmPair());
+        if (!v->back()->a.Read(f_old.c_str(), devices[di]) || !v->back()->b.Read(f_new.c_str(), devices[di])) return false;
+        v->back()->a.Rescale(-1.0);
+        v->back()->a.Handle();   // both automata go to HBM here, once, before any worker thread asks for them
+        v->back()->b.Handle();
+      }
+      return true;
+    };
     if (biglm) {
       if (lm_old_file.empty() || lm_new_file.empty()) { std::cerr << "--lm-old and --lm-new go together\n"; return 1; }
-      if (!lm1.Read(lm_old_file.c_str()) || !lm2.Read(lm_new_file.c_str())) return 1;
-      lm1.Rescale(-1.0);
-      lm1.Handle();   // both automata go to HBM here, once, before any worker thread asks for them
-      lm2.Handle();
+      if (!load_pairs(lm_old_file, lm_new_file, &lms)) return 1;
     }
+    ArpaLm *lm1p = biglm ? &lms[0]->a : nullptr, *lm2p = biglm ? &lms[0]->b : nullptr;
     // the service's second pass (--use-second, kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:53-78): GetLattice / GetNbest compose the
     // determinized lattice with the old LM (rescaled by -1) and with the new one
     const bool second = !second_old_file.empty() || !second_new_file.empty();
-    ArpaLm slm1, slm2;
     if (second) {
       if (second_old_file.empty() || second_new_file.empty()) { std::cerr << "--second-lm-old and --second-lm-new go together\n"; return 1; }
-      if (!slm1.Read(second_old_file.c_str()) || !slm2.Read(second_new_file.c_str())) return 1;
-      slm1.Rescale(-1.0);
-      slm1.Handle();
-      slm2.Handle();
+      if (!load_pairs(second_old_file, second_new_file, &slms)) return 1;
     }
+    ArpaLm *slm1p = second ? &slms[0]->a : nullptr, *slm2p = second ? &slms[0]->b : nullptr;
     // exact n-best (NShortestPath on the determinized lattice) where its lattices are asked for, a second pass runs or the list is long
     const bool exact_nbest = !nbest_lattice_file.empty() || second || nbest > 16;
     wfst_limits limits = {0, 0, 0, 0, 0};  // zeros = the library defaults
@@ -224,7 +251,7 @@ int main(int argc, char **argv) {
       ++num_success;
     };
     if (single) {  // the reference's shape: one decoder object, one utterance at a time
-      std::unique_ptr<GpuLatticeDecoder> decode_p(biglm ? new OnlineLatticeDecoderMempoolBiglm(&fst, opt, &lm1, &lm2, &limits)
+      std::unique_ptr<GpuLatticeDecoder> decode_p(biglm ? new OnlineLatticeDecoderMempoolBiglm(&fst, opt, lm1p, lm2p, &limits)
                                                         : new GpuLatticeDecoder(&fst, opt, &limits));
       GpuLatticeDecoder &decode = *decode_p;
       for (const Utt &u : utts) {
@@ -266,13 +293,13 @@ int main(int argc, char **argv) {
         emit(u, best, ok);
         if (want_lattice) {
           Lattice lat;
-          bool lok = determinize ? (second ? decode.GetLattice(&lat, &slm1, &slm2) : decode.GetLattice(&lat)) : decode.GetRawLattice(&lat);
+          bool lok = determinize ? (second ? decode.GetLattice(&lat, slm1p, slm2p) : decode.GetLattice(&lat)) : decode.GetRawLattice(&lat);
           emit_lattice(u, lat, lok);
         }
         if (nbest > 0) {
           std::vector<Lattice> paths;
           if (!exact_nbest) decode.GetNbestShortlist(paths, nbest);
-          else if (second) decode.GetNbest(paths, nbest, &slm1, &slm2);
+          else if (second) decode.GetNbest(paths, nbest, slm1p, slm2p);
           else decode.GetNbest(paths, nbest);
           emit_nbest(u, paths);
         }
@@ -286,14 +313,23 @@ int main(int argc, char **argv) {
       const size_t n_batches = (utts.size() + batch - 1) / batch;
       std::vector<BatchOut> outs(n_batches);
       std::atomic<size_t> next(0);
-      std::vector<std::string> errors((size_t)inflight);
+      const int n_dev = (int)devices.size(), n_workers = inflight * n_dev;
+      std::vector<std::string> errors((size_t)n_workers);
+      std::vector<std::atomic<size_t> > next_of_dev((size_t)n_dev);
+      for (auto &x : next_of_dev) x = 0;
       auto worker = [&](int k) {
         try {
-          std::unique_ptr<GpuBatchDecoder> decode_p(biglm ? new GpuBatchDecoder(&fst, opt, &lm1, &lm2, batch, &limits)
-                                                          : new GpuBatchDecoder(&fst, opt, batch, &limits));  // its own stream
+          // worker k drives a decoder on device k mod n_dev, over that device's graph replica (and LMs)
+          const int di = k % n_dev;
+          Fst *wf = fsts[(size_t)di].get();
+          ArpaLm *lm1 = biglm ? &lms[(size_t)di]->a : nullptr, *lm2 = biglm ? &lms[(size_t)di]->b : nullptr;
+          ArpaLm *slm1 = second ? &slms[(size_t)di]->a : nullptr, *slm2 = second ? &slms[(size_t)di]->b : nullptr;
+          std::unique_ptr<GpuBatchDecoder> decode_p(biglm ? new GpuBatchDecoder(wf, opt, lm1, lm2, batch, &limits)
+                                                          : new GpuBatchDecoder(wf, opt, batch, &limits));  // its own stream
           GpuBatchDecoder &decode = *decode_p;
           for (;;) {
-            const size_t b = next.fetch_add(1);
+            // one device: the next batch nobody has taken; several: batch b belongs to device b mod n_dev (its workers share them)
+            const size_t b = n_dev == 1 ? next.fetch_add(1) : (size_t)di + (size_t)n_dev * next_of_dev[(size_t)di].fetch_add(1);
             if (b >= n_batches) return;
             const size_t b0 = b * (size_t)batch;
             const int n = (int)std::min<size_t>(batch, utts.size() - b0);
@@ -315,7 +351,7 @@ int main(int argc, char **argv) {
             if (want_lattice && determinize) {
               o.lats.assign(n, Lattice());
               o.lat_ok.assign(n, false);
-              for (int i = 0; i < n; ++i) o.lat_ok[i] = second ? decode.GetLattice(i, &o.lats[i], &slm1, &slm2) : decode.GetLattice(i, &o.lats[i]);
+              for (int i = 0; i < n; ++i) o.lat_ok[i] = second ? decode.GetLattice(i, &o.lats[i], slm1, slm2) : decode.GetLattice(i, &o.lats[i]);
             } else if (want_lattice) {
               decode.GetRawLattices(ch, &o.lats, &o.lat_ok);
             }
@@ -324,7 +360,7 @@ int main(int argc, char **argv) {
               // (short lists for the whole batch come from one launch on the raw lattices; longer ones are NShortestPath per channel)
               for (int i = 0; i < n; ++i) {
                 if (!exact_nbest) decode.GetNbestShortlist(i, o.nbest[i], nbest);
-                else if (second) decode.GetNbest(i, o.nbest[i], nbest, &slm1, &slm2);
+                else if (second) decode.GetNbest(i, o.nbest[i], nbest, slm1, slm2);
                 else decode.GetNbest(i, o.nbest[i], nbest);
               }
             }
@@ -334,7 +370,7 @@ int main(int argc, char **argv) {
         }
       };
       std::vector<std::thread> threads;
-      for (int k = 1; k < inflight; ++k) threads.emplace_back(worker, k);
+      for (int k = 1; k < n_workers; ++k) threads.emplace_back(worker, k);
       worker(0);
       for (std::thread &t : threads) t.join();
       for (const std::string &e : errors)

@@ -644,6 +644,7 @@ def main():
     tb = {"init": 0.0, "advance_enqueue": 0.0, "finalize": 0.0, "sync": 0.0, "best_paths": 0.0, "n": 0}
 
     gathered = []  # world > 1: every utterance's result in global order, from the last step's gather
+    gathered_lat = []  # world > 1, lattice mode with --determinize: every utterance's determinized lattice (on-disk format), likewise
 
     def make_step(dec, ll_dev, host_rows):
         ptrs = [ll_dev[i].data_ptr() for i in range(B)]
@@ -688,6 +689,10 @@ def main():
             tb["n"] += 1
             if world > 1:  # the path's only collective: gather the final results (RCCL)
                 gathered[:] = shard.gather_results(shard.pack_results(res), device=None if share else dev)
+                if a.lattice_links > 0 and a.determinize and all("det" in r for r in res):
+                    # ... and the final lattices (north_star: "RCCL over xGMI only to gather final lattices"): every utterance's
+                    # determinized lattice as a length-prefixed blob in the reference's on-disk format (Lattice::Write)
+                    gathered_lat[:] = shard.gather_lattices([shard.lattice_to_bytes(r["det"]) for r in res], device=None if share else dev)
             return res
 
         def drain(res):
@@ -879,6 +884,21 @@ def main():
                       and np.float32(o.lm_score).tobytes() == np.float32(r["lm_score"]).tobytes())
         orc.free_graph(h)
         out["config"]["gather_check"] = {"utterances": len(gathered), "bit_exact_vs_oracle": ok}
+        if gathered_lat:
+            # the gathered lattices of ALL ranks against what ONE rank makes of the same utterances: rank 0 decodes every rank's block
+            # itself (its own decoder, after the timed region) and compares the blobs byte for byte
+            same = 0
+            for r in range(world):
+                blk = make_utts(synth, g, m, r * B, B, T, P, sa)
+                tb_ = torch.from_numpy(blk).to(dev)
+                dec.init()
+                dec.advance([tb_[i].data_ptr() for i in range(B)], ready, P)
+                dec.finalize()
+                dec.best_paths(cap=2 * T + 64)
+                for i in range(B):
+                    same += int(shard.lattice_to_bytes(dec.determinized_lattice(i)) == gathered_lat[r * B + i])
+                del tb_
+            out["config"]["lattice_gather_check"] = "%d/%d" % (same, len(gathered_lat))
     if rank == 0:
         N = sum(s["N"] for s in gstats)
         E = sum(s["E"] for s in gstats)

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "asr-decoder_amd", "host", "wfst-decode")
 
 
-@pytest.mark.parametrize("mode", ["batch", "single", "inflight"])
+@pytest.mark.parametrize("mode", ["batch", "single", "inflight", "devices"])
 def test_cli_matches_oracle(mode, synth, oracle, tmp_path):
     subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
     g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
@@ -38,6 +38,8 @@ def test_cli_matches_oracle(mode, synth, oracle, tmp_path):
         args.append("--single-stream")
     if mode == "inflight":   # three 2-utterance batches on two decoder threads, output in input order
         args = args[:-1] + ["--batch=2", "--inflight=2"]
+    if mode == "devices":    # the multi-GPU driver on the one GPU of the box: two graph replicas on device 0, a decoder
+        args = args[:-1] + ["--batch=1", "--devices=0,0"]   # thread per replica, utterance u on replica u mod 2, output in input order
     p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert [l.split()[0] for l in p.stdout.strip().splitlines()] == ["utt%03d" % i for i in range(5)]
@@ -325,3 +327,36 @@ def test_cli_streaming_chunks_with_partial_results(lattice, synth, oracle, tmp_p
     finally:
         oracle.free_graph(h)
     assert n_part == 5 + 2 and (not lattice or len(part_nb) >= n_part)
+
+
+def test_cli_devices_gives_the_single_device_lattices(synth, tmp_path):
+    """wfst-decode --devices=0,0 (one graph replica and one decoder thread per listed device, batch b on device b mod n, results merged
+    in input order -- the shape of an 8-GPU node, exercised with device 0 listed twice): words, scores, determinized lattices and
+    n-best byte for byte what the one-device run prints and writes."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m = synth.default_tid2pdf(600)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=12\n--max-active=1000000\n--min-active=0\n--lattice-beam=5\n")
+    mats = [synth.make_loglikes(g, T, 300, m, seed=700 + i, mu=-2.2)[0] for i, T in enumerate([50, 21, 64, 3, 40, 33, 12])]
+    with open(tmp_path / "ll.bin", "wb") as f:
+        for i, x in enumerate(mats):
+            key = ("utt%03d" % i).encode()
+            f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
+    outs = {}
+    for tag, extra in (("one", []), ("two", ["--devices=0,0"]), ("two_inflight", ["--devices=0,0", "--inflight=2"])):
+        lat = str(tmp_path / ("lat_%s.bin" % tag))
+        p = subprocess.run([CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--batch=2", "--determinize", "--nbest=3", "--lattice-out=" + lat,
+                            "--lattice-links=1000000"] + extra + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        logs = sorted(l for l in p.stderr.splitlines() if l.startswith("LOG utt"))
+        with open(lat, "rb") as f:
+            outs[tag] = (p.stdout, logs, f.read())
+    assert len(outs["one"][0].strip().splitlines()) >= len(mats)
+    for tag in ("two", "two_inflight"):
+        assert outs[tag][0] == outs["one"][0], tag + ": words / n-best"
+        assert outs[tag][1] == outs["one"][1], tag + ": scores"
+        assert outs[tag][2] == outs["one"][2], tag + ": determinized lattices"
