@@ -12,7 +12,7 @@ SRCS = [os.path.join(HERE, "csrc", "wfst_kernels.hip"), os.path.join(HERE, "csrc
         os.path.join(HERE, "csrc", "wfst_determinize.hip"), os.path.join(HERE, "csrc", "wfst_compose.hip"),
         os.path.join(HERE, "csrc", "wfst_capi.cc"),
         os.path.join(HERE, "csrc", "wfst_openfst.cc")]
-HDRS = [os.path.join(HERE, "csrc", "wfst_device.h"), os.path.join(HERE, "csrc", "wfst_determinize.h"), os.path.join(HERE, "csrc", "wfst_openfst.h"),
+HDRS = [os.path.join(HERE, "csrc", "wfst_device.h"), os.path.join(HERE, "csrc", "wfst_determinize.h"), os.path.join(HERE, "csrc", "wfst_determinize_wave.h"), os.path.join(HERE, "csrc", "wfst_openfst.h"),
         os.path.join(HERE, "..", "include", "wfst_decoder.h")]
 LIB = os.path.join(HERE, "lib", "libwfstdec.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -45,9 +45,13 @@ struct DetWs {
   const DetArc *arcs;
   const int32_t *is_final;
   int32_t *osf;                 // [n_states] IsIsymbolOrFinal (:999-1024)
-  // string trie
-  int32_t *tr_parent, *tr_label, *tr_depth, *tr_hash;
-  int32_t tr_n, tr_hcap;
+  int32_t *neps;                // [n_states] leading arcs with input label 0 (the row is sorted: epsilons first)
+  // string trie: one open-addressed table, a node IS its slot -- key {parent (low), label (high)}, depth beside it; slot 0 is the
+  // empty string.  (One probe finds or makes a successor; round 4 kept node arrays beside a table of node ids: two dependent
+  // loads to find one, five memory round trips to make one -- the construction is bound by exactly those.)
+  uint64_t *tr_key;
+  int32_t *tr_depth;
+  int32_t tr_n, tr_hcap;        // nodes in use (the table is kept at most half full), slots in use
   // element pool; output states (minimal subsets) and initial subsets are slices of it
   DetElem *pool;
   int32_t pool_n;
@@ -75,9 +79,8 @@ struct DetWs {
 // int32 words a workspace needs (the caller carves them with det_carve)
 WFST_HD inline int64_t det_words(const DetCaps &c, int32_t n_states) {
   int64_t w = 0;
-  w += n_states;                        // osf
-  w += 3 * (int64_t)c.trie;             // parent, label, depth
-  w += 2 * (int64_t)c.trie;             // tr_hash (>= 2x nodes, rounded to a power of two by det_carve)
+  w += 2 * (int64_t)n_states;           // osf, neps
+  w += 6 * (int64_t)c.trie + 2;         // the trie's table: 2 x trie slots (rounded down to a power of two by det_carve) of key (8 bytes) + depth
   w += 4 * (int64_t)c.pool;             // pool
   w += 3 * (int64_t)c.states + 2 * (int64_t)c.states;  // os_off/len/next + mh_head
   w += 7 * (int64_t)c.initials + 2 * (int64_t)c.initials;
@@ -99,11 +102,11 @@ WFST_HD inline void det_carve(DetWs &W, int32_t *base, const DetCaps &c, int32_t
   W.cap = c;
   W.tb_lo = nullptr; W.tc_lo = nullptr; W.tmp_lo = 0;   // (the caller may set them after det_carve)
   W.osf = p; p += n_states;
-  W.tr_parent = p; p += c.trie;
-  W.tr_label = p; p += c.trie;
-  W.tr_depth = p; p += c.trie;
+  W.neps = p; p += n_states;
   W.tr_hcap = det_pow2_le(2 * (int64_t)c.trie);
-  W.tr_hash = p; p += 2 * (int64_t)c.trie;
+  p += ((uintptr_t)p & 7) ? 1 : 0;      // (8-byte keys)
+  W.tr_key = reinterpret_cast<uint64_t *>(p); p += 4 * (int64_t)c.trie;
+  W.tr_depth = p; p += 2 * (int64_t)c.trie;
   W.pool = reinterpret_cast<DetElem *>(p); p += 4 * (int64_t)c.pool;
   W.os_off = p; p += c.states;
   W.os_len = p; p += c.states;
@@ -163,36 +166,39 @@ WFST_HD inline uint32_t det_hash2(int32_t a, int32_t b) {
   h ^= h >> 15;
   return h * 0x2C1B3C6Du;
 }
+constexpr uint64_t kDetEmptyKey = ~0ull, kDetRootKey = ~0ull - 1;
+WFST_HD inline uint64_t det_key(int32_t parent, int32_t label) { return (uint64_t)(uint32_t)parent | ((uint64_t)(uint32_t)label << 32); }
+WFST_HD inline int32_t det_parent(const DetWs &W, int32_t n) { return (int32_t)(uint32_t)W.tr_key[n]; }
+WFST_HD inline int32_t det_label(const DetWs &W, int32_t n) { return (int32_t)(uint32_t)(W.tr_key[n] >> 32); }
 // Successor (:58-79)
 WFST_HD inline int32_t det_succ(DetWs &W, int32_t parent, int32_t label) {
   const uint32_t mask = (uint32_t)W.tr_hcap - 1u;
+  const uint64_t key = det_key(parent, label);
   uint32_t s = det_hash2(parent, label) & mask;
   for (;;) {
-    const int32_t n = W.tr_hash[s];
-    if (n < 0) break;
-    if (W.tr_parent[n] == parent && W.tr_label[n] == label) return n;
+    const uint64_t k = W.tr_key[s];
+    if (k == key) return (int32_t)s;
+    if (k == kDetEmptyKey) break;
     s = (s + 1) & mask;
   }
   if (W.tr_n >= W.cap.trie || 2 * (int64_t)W.tr_n >= W.tr_hcap) { W.err = 1; return 0; }  // 1: trie
-  const int32_t n = W.tr_n++;
-  W.tr_parent[n] = parent;
-  W.tr_label[n] = label;
-  W.tr_depth[n] = W.tr_depth[parent] + 1;
-  W.tr_hash[s] = n;
-  return n;
+  ++W.tr_n;
+  W.tr_key[s] = key;
+  W.tr_depth[s] = W.tr_depth[parent] + 1;
+  return (int32_t)s;
 }
 // the longest common prefix of two strings = their lowest common ancestor (CommonPrefix / ReduceToCommonPrefix, :95-128)
 WFST_HD inline int32_t det_lca(const DetWs &W, int32_t a, int32_t b) {
-  while (W.tr_depth[a] > W.tr_depth[b]) a = W.tr_parent[a];
-  while (W.tr_depth[b] > W.tr_depth[a]) b = W.tr_parent[b];
-  while (a != b) { a = W.tr_parent[a]; b = W.tr_parent[b]; }
+  while (W.tr_depth[a] > W.tr_depth[b]) a = det_parent(W, a);
+  while (W.tr_depth[b] > W.tr_depth[a]) b = det_parent(W, b);
+  while (a != b) { a = det_parent(W, a); b = det_parent(W, b); }
   return a;
 }
 // the labels of string `s` below depth `from`, in order, into W.labs; returns their number
 WFST_HD inline int32_t det_labels(DetWs &W, int32_t s, int32_t from) {
   const int32_t n = W.tr_depth[s] - from;
   if (n > W.cap.tmp) { W.err = 6; return 0; }
-  for (int32_t i = n - 1; i >= 0; --i) { W.labs[i] = W.tr_label[s]; s = W.tr_parent[s]; }
+  for (int32_t i = n - 1; i >= 0; --i) { const uint64_t k = W.tr_key[s]; W.labs[i] = (int32_t)(uint32_t)(k >> 32); s = (int32_t)(uint32_t)k; }
   return n;
 }
 // RemovePrefix (:131-142)
@@ -222,8 +228,8 @@ WFST_HD inline int det_cmp(const DetWs &W, float a1, float a2, int32_t as, float
   if (al < bl) return 1;
   // equal lengths, different strings: the first position they differ at is just below their lowest common ancestor
   int32_t a = as, b = bs;
-  while (W.tr_parent[a] != W.tr_parent[b]) { a = W.tr_parent[a]; b = W.tr_parent[b]; }
-  return W.tr_label[a] < W.tr_label[b] ? -1 : 1;
+  while (det_parent(W, a) != det_parent(W, b)) { a = det_parent(W, a); b = det_parent(W, b); }
+  return det_label(W, a) < det_label(W, b) ? -1 : 1;
 }
 
 WFST_HD inline void det_sort_by_state(DetElem *e, int32_t n) {  // subsets are small: insertion sort (Shell gaps for the odd large one)
@@ -262,9 +268,9 @@ WFST_HD inline int32_t det_closure(DetWs &W, DetElem *e, int32_t n) {
         const DetElem &c = cur[W.cl_idx[el.state]];
         if (c.str != el.str || c.w1 != el.w1 || c.w2 != el.w2) continue;
       }
-      for (int32_t a = W.off[el.state]; a < W.off[el.state + 1]; ++a) {
+      const int32_t a0 = W.off[el.state], a1 = a0 + W.neps[el.state];   // sorted: the epsilons lead the row
+      for (int32_t a = a0; a < a1; ++a) {
         const DetArc &arc = W.arcs[a];
-        if (arc.ilabel != 0) break;  // sorted: no more epsilons
         if (det_is_zero(arc.w1, arc.w2)) continue;
         DetElem nx;
         nx.state = arc.to;
@@ -477,22 +483,26 @@ WFST_HD inline void det_process_state(DetWs &W, int32_t out) {
 // Table initialisation, shared out over `nthreads` callers (the device calls it workgroup-wide, tid = thread index;
 // the host once with (0, 1)).  A barrier must separate it from det_run.
 WFST_HD inline void det_init(DetWs &W, int32_t tid, int32_t nthreads) {
-  for (int32_t i = tid; i < W.tr_hcap; i += nthreads) W.tr_hash[i] = -1;   // (the slots in use: the device starts with a part of the table)
+  for (int32_t i = tid; i < W.tr_hcap; i += nthreads) W.tr_key[i] = kDetEmptyKey;   // (the slots in use: the device starts with a part of the table)
   for (int32_t i = tid; i < 2 * W.cap.states; i += nthreads) W.mh_head[i] = -1;
   for (int32_t i = tid; i < 2 * W.cap.initials; i += nthreads) W.ih_head[i] = -1;
   for (int32_t s = tid; s < W.n_states; s += nthreads) {
     W.cl_idx[s] = -1;
     int32_t y = W.is_final[s] ? 1 : 0;   // IsIsymbolOrFinal (:999-1024)
-    for (int32_t a = W.off[s]; a < W.off[s + 1] && !y; ++a)
-      if (W.arcs[a].ilabel != 0 && !det_is_zero(W.arcs[a].w1, W.arcs[a].w2)) y = 1;
+    int32_t ne = 0;
+    for (int32_t a = W.off[s]; a < W.off[s + 1]; ++a) {
+      if (W.arcs[a].ilabel == 0) { ++ne; continue; }
+      if (!det_is_zero(W.arcs[a].w1, W.arcs[a].w2)) { y = 1; break; }
+    }
     W.osf[s] = y;
+    W.neps[s] = ne;
   }
 }
 
 // InitializeDeterminization + the main loop (:551-600, 795-838), after det_init.  Returns 0, or which capacity was exceeded.
 WFST_HD inline int det_run(DetWs &W) {
   W.err = 0;
-  W.tr_n = 1; W.tr_parent[0] = 0; W.tr_label[0] = 0; W.tr_depth[0] = 0;
+  W.tr_n = 1; W.tr_key[0] = kDetRootKey; W.tr_depth[0] = 0;   // the empty string: slot 0
   W.pool_n = 0; W.os_n = 0; W.ih_n = 0; W.q_n = 0; W.oa_n = 0;
   if (W.n_states <= 0) return 0;
   {

@@ -14,13 +14,12 @@
 // as plain pointers with a rerun in the workspace's buffers on overflow, are kept: -3 %); walking straight stretches of the raw
 // lattice without queue / index traffic -- 5 % (and it changes the closure's visiting order).  What did pay: the closure's ring
 // buffer without 64-bit modulo (-10 %).  Speeding this up for real needs parallelism INSIDE a lattice.
-#include "wfst_determinize.h"
+#include "wfst_determinize_wave.h"   // (wfst_determinize.h + the one-wave-per-lattice construction)
 #include "wfst_device.h"
 
 namespace wfst {
 
 constexpr int kDetThreads = 256;
-constexpr int kDetLowTmp = 1024;   // elements of the closure's LDS buffers (a closure that outgrows them runs again in the workspace's)
 
 // phase 0: the whole thing.  1: the CSR only -- everything that reads the DECODER's state (the channel's control block, its resolved
 // token / link lists, the arena-index scratch) -- leaving {-, -, status, raw states} in the result words and the CSR in the
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
   }
   // ---- the subset construction: tables cleared by everyone, then one lane ---------------------------------
   __shared__ DetWs W;
-  __shared__ DetElem s_tb[kDetLowTmp], s_tc[kDetLowTmp];
+  __shared__ DwShared S;   // the closure's queue, element list and state index (wfst_determinize_wave.h)
   if (tid == 0) {
     W.n_states = nt;
     W.n_arcs = na;
@@ -134,8 +133,8 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
     W.is_final = fin;
     W.delta = 1.0f / 1024;   // kDelta (DeterminizeLatticeOptions, lattice-determinize-api.h:16-25)
     det_carve(W, rest, X.caps, nt);
-    W.tb_lo = s_tb; W.tc_lo = s_tc; W.tmp_lo = kDetLowTmp;   // the closure's queue and element list in LDS
   }
+  for (int i = tid; i < kDwMap; i += kDetThreads) S.map[i] = 0u;
   __syncthreads();
   // The string trie's hash table is carved for the workspace's full capacity (a million slots, 4 MB); a lattice of a few thousand
   // states makes 1.5-2 nodes per raw state, so the table is first used at 16 slots per raw state (a few hundred KB: its probes
@@ -154,7 +153,10 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
     __syncthreads();
     det_init(W, tid, kDetThreads);
     __syncthreads();
-    if (tid == 0) s_err = det_run(W);
+    {
+      const int e = detw_run(W, S, nullptr);   // wave 0 runs the construction, the other waves go on to the barrier
+      if (tid == 0) s_err = e;
+    }
     __syncthreads();
     if (!(s_err == 1 && W.tr_hcap < hcap_full)) break;   // (1: the trie -- its node array or its hash table -- was outgrown)
   }

@@ -2,19 +2,23 @@
 //
 // The algorithm, its order and its float arithmetic are those of wfst_determinize.h (the reference's LatticeDeterminizer,
 // newfst/lattice-determinize.h:300-1468): output states leave a LIFO queue, an epsilon closure is a FIFO relaxation, subsets
-// are matched within delta.  What changes is who does the work:
+// are matched within delta.  A lattice is ~30 dependent memory round trips per closure element on one lane (rocprofv3 counters on
+// the bench's largest lattice: 8 M instructions in 124 M cycles -- the lane waits); this file cuts the round trips and runs the
+// independent ones side by side:
 //
-//  * EpsilonClosure (:842-936), two thirds of the dependent memory round trips of a lattice: the closure's element list, its FIFO and
-//    its state index live in LDS; the next kDwWin queue entries are PRICED side by side, one lane each -- the entry's row of
-//    epsilon arcs read, the successor strings looked up or created in the trie (lock-free: a node is allocated, written, then published
-//    by a compare-and-swap on its hash slot; two lanes after the same (parent, label) end up with the same node), the offers
-//    (state, weight, string) staged in LDS -- and then COMMITTED in queue order by one lane, which touches LDS only.  A queue entry's
-//    offers depend on nothing but the entry itself (Element copied at push time, :864-865), whether they are made depends on the
-//    entry still being its state's best when its turn comes (:874-875): that test and every comparison against the current best
-//    run at commit time, in the reference's order, so the result is the sequential one bit for bit; what the lanes do ahead of it are
-//    pure look-ups (an entry that turns out stale has at most left trie nodes nobody refers to).
-//  * everything else (ProcessFinal, the transition pairs, NormalizeSubset, the two subset tables) still runs on lane 0 through the
-//    functions of wfst_determinize.h, between the closures.
+//  * EpsilonClosure (:842-936), two thirds of them: the closure's element list, its FIFO and its state index live in LDS; the next
+//    kDwWin queue entries are PRICED side by side, a lane per (entry, epsilon arc) -- the entry's row read in one go (the count of
+//    leading epsilons sits beside the row's offset), the successor string found or made by ONE probe of the trie's table
+//    (wfst_determinize.h: a node is its slot; made by a compare-and-swap on the key, so two lanes after the same (parent, label)
+//    get the same node), the target's place in the state index looked up -- and then COMMITTED in queue order.  A queue entry's
+//    offers depend on nothing but the entry itself (Element copied at push time, :864-865); whether they are made depends on the
+//    entry still being its state's best when its turn comes (:874-875), whether one is taken on the target's best at that moment:
+//    where no two offers of a window meet in one state and none reaches a state that has an entry in the window (checked through
+//    marks in LDS: the rule, not the exception) the order of the commits does not matter and every lane commits its own offer,
+//    queue positions by prefix sum; otherwise one lane commits them in the reference's order.  Bit for bit the sequential result;
+//    what the lanes do ahead of the order are pure look-ups (an entry that turns out stale leaves at most trie nodes behind).
+//  * everything else (ProcessFinal, the transition pairs, NormalizeSubset, the two subset tables) runs between the closures on
+//    lane 0 through the functions of wfst_determinize.h.
 //
 // A closure that outgrows the LDS buffers is run again by det_closure() in the workspace's.
 #ifndef WFST_DETERMINIZE_WAVE_H_
@@ -29,20 +33,22 @@ namespace wfst {
 constexpr int kDwCur = 1024;     // closure elements held in LDS
 constexpr int kDwQueue = 1024;   // FIFO ring
 constexpr int kDwMap = 2048;     // state -> element index, open addressing
-constexpr int kDwWin = 16;       // queue entries priced side by side
-constexpr int kDwArcs = 4;       // epsilon arcs a lane prices for its entry (an entry with more is priced alone, a lane per arc)
-constexpr int kDwOffers = kDwWin * kDwArcs;   // = 64: also what the lane-per-arc path stages per pass
+constexpr int kDwArcs = 4;       // epsilon arcs priced per entry in a window (an entry with more is priced alone, a lane per arc)
+constexpr int kDwWin = 64 / kDwArcs;   // queue entries priced side by side
 
 struct DwShared {
   DetElem cur[kDwCur];
   DetElem queue[kDwQueue];
+  uint16_t qidx[kDwQueue];       // the queue entry's state: its index in cur[]
   uint32_t map[kDwMap];          // 0 = empty, else (state << 11) | (index + 1)
   uint16_t cur_slot[kDwCur];     // where element i sits in map[] (cleared from here when the closure is done)
+  uint16_t mark_idx[kDwCur];     // commit: which lane means to touch cur[i] / map[slot] (two lanes on one: in order, by one lane)
+  uint16_t mark_slot[kDwMap];
   uint32_t sortk[kDwCur];
-  DetElem offer[kDwOffers];
-  int32_t offer_cnt[kDwWin];
+  DetElem offer[64];
+  uint16_t claim[256];           // detw_succ_wave: who takes an empty trie slot
   int32_t bc[16];                // lane 0 -> wave
-  long long tm[8];               // (development timers)
+  long long tm[16];              // (development timers)
 };
 
 __host__ __device__ inline int64_t detw_extra_words(const DetCaps &, int32_t) { return 0; }
@@ -51,9 +57,7 @@ __host__ __device__ inline int64_t detw_extra_words(const DetCaps &, int32_t) { 
 // are issued in order)
 #define DETW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-// Accesses to the workspace go through these: the pointers of DetWs are generic (they are carved at run time), and a generic
-// access is a flat_ instruction -- it counts in BOTH memory counters, so every LDS read behind it waits for it and every wait
-// for it drains the stores too.  Cast to the global address space they become global_load / global_store.
+// global-address-space accesses to the workspace (its pointers are generic: carved at run time)
 #define DW_G(T) __attribute__((address_space(1))) T
 typedef int dw_v4i __attribute__((ext_vector_type(4), aligned(4)));
 __device__ inline int32_t dw_ld(const int32_t *p) { return *(const DW_G(int32_t) *)p; }
@@ -77,34 +81,53 @@ __device__ inline DetArc dw_ld_arc(const DetArc *p) {
   return a;
 }
 
-// Successor (:58-79), callable by any lanes at once.
-__device__ inline int32_t detw_succ(DetWs &W, int32_t parent, int32_t label) {
+// Successor (:58-79) for the whole wave at once (every lane calls it; `need`: this lane has a string to extend): plain loads and
+// stores like the one-lane det_succ() -- the trie's table is read through the L1 everywhere, an L2 atomic in between would leave
+// stale lines there -- with the lanes that find the same empty slot settled through a claim word in LDS: one takes the slot and
+// writes the key, the others look again (and find it, if they were after the same string).
+__device__ inline int32_t detw_succ_wave(DetWs &W, uint16_t *claim /* [256] */, bool need, int32_t parent, int32_t label, int lane) {
   const uint32_t mask = (uint32_t)W.tr_hcap - 1u;
+  const uint64_t key = det_key(parent, label);
   uint32_t s = det_hash2(parent, label) & mask;
-  int32_t mine = -1;
-  for (;;) {
-    const int32_t n = __hip_atomic_load((DW_G(int32_t) *)(W.tr_hash + s), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (n >= 0) {
-      if (dw_ld(W.tr_parent + n) == parent && dw_ld(W.tr_label + n) == label) return n;   // (a node allocated and not published stays unreferenced)
-      s = (s + 1) & mask;
-      continue;
+  int32_t ans = 0;
+  const int32_t pd = need ? dw_ld(W.tr_depth + parent) : 0;
+  bool open = need && !W.err;
+  int made = 0;
+  for (int round = 0; round < (1 << 20); ++round) {
+    if (!__ballot(open)) break;
+    bool want = false;
+    if (open) {
+      const uint64_t k = *(const DW_G(uint64_t) *)(W.tr_key + s);
+      if (k == key) { ans = (int32_t)s; open = false; }
+      else if (k != kDetEmptyKey) s = (s + 1) & mask;
+      else { want = true; claim[s & 255u] = (uint16_t)lane; }
     }
-    if (mine < 0) {
-      mine = atomicAdd(&W.tr_n, 1);
-      if (mine >= W.cap.trie || 2 * (int64_t)mine >= W.tr_hcap) { W.err = 1; return 0; }
-      dw_st(W.tr_parent + mine, parent);
-      dw_st(W.tr_label + mine, label);
-      dw_st(W.tr_depth + mine, dw_ld(W.tr_depth + parent) + 1);
+    DETW_SYNC();
+    if (want && claim[s & 255u] == (uint16_t)lane) {
+      *(DW_G(uint64_t) *)(W.tr_key + s) = key;
+      dw_st(W.tr_depth + s, pd + 1);
+      ans = (int32_t)s;
+      open = false;
+      ++made;
     }
-    int32_t expect = -1;
-    if (__hip_atomic_compare_exchange_strong((DW_G(int32_t) *)(W.tr_hash + s), &expect, mine, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return mine;
-    // (somebody took the slot: look at it again)
+    DETW_SYNC();
   }
+  const unsigned long long mk = __ballot(made != 0);
+  if (mk) {
+    const int n = W.tr_n + __popcll(mk);
+    DETW_SYNC();
+    if (lane == 0) {
+      W.tr_n = n;
+      if (n >= W.cap.trie || 2 * (int64_t)n >= W.tr_hcap) W.err = 1;   // (the table stays at most half full; 1: the trie)
+    }
+    DETW_SYNC();
+  }
+  return ans;
 }
 
 __device__ inline uint32_t detw_mapslot(int32_t state) { return ((uint32_t)state * 2654435761u) >> (32 - 11); }   // kDwMap = 2^11
 
-// index of `state` in cur[], -1
+// index of `state` in cur[], or -1 with the empty slot its probe ended at
 __device__ inline int detw_map_find(const DwShared &S, int32_t state, uint32_t *slot_out) {
   uint32_t h = detw_mapslot(state);
   for (;;) {
@@ -133,6 +156,48 @@ __device__ inline void detw_sort_keys(DwShared &S, int n, int lane) {
     }
 }
 
+__device__ inline int detw_rank(unsigned long long mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
+
+// One lane commits the window's offers in the reference's order (entries in queue order, an entry's arcs in row order).
+// valid: the lanes that hold an offer; lane = entry * arcs_per_entry + arc.  Returns through S.bc {nc, queue length, overflow}.
+__device__ inline void detw_commit_in_order(DetWs &W, DwShared &S, unsigned long long valid, int arcs_per_entry, int n_entries, int qh, int nc, int qn) {
+  bool over = false;
+  int tail = qn;
+  for (int e = 0; e < n_entries && !over; ++e) {
+    const unsigned long long m = (valid >> (e * arcs_per_entry)) & ((arcs_per_entry >= 64) ? ~0ull : ((1ull << arcs_per_entry) - 1ull));
+    if (!m) continue;
+    {  // the entry may have been overtaken by an offer committed since it was priced
+      const DetElem el = S.queue[(qh + e) & (kDwQueue - 1)];
+      const DetElem c = S.cur[S.qidx[(qh + e) & (kDwQueue - 1)]];
+      if (!(c.str == el.str && c.w1 == el.w1 && c.w2 == el.w2)) continue;
+    }
+    for (unsigned long long mk = m; mk; mk &= mk - 1) {
+      const DetElem nx = S.offer[e * arcs_per_entry + __ffsll((long long)mk) - 1];
+      uint32_t slot;
+      int idx = detw_map_find(S, nx.state, &slot);
+      bool push = false;
+      if (idx < 0) {
+        if (nc >= kDwCur) { over = true; break; }
+        idx = nc;
+        S.map[slot] = ((uint32_t)nx.state << 11) | (uint32_t)(nc + 1);
+        S.cur_slot[nc] = (uint16_t)slot;
+        S.cur[nc++] = nx;
+        push = true;
+      } else {
+        const DetElem c = S.cur[idx];
+        if (det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) == 1) { S.cur[idx] = nx; push = true; }
+      }
+      if (push) {
+        if (tail >= kDwQueue) { over = true; break; }
+        S.queue[(qh + tail) & (kDwQueue - 1)] = nx;
+        S.qidx[(qh + tail) & (kDwQueue - 1)] = (uint16_t)idx;
+        ++tail;
+      }
+    }
+  }
+  S.bc[0] = nc; S.bc[1] = tail; S.bc[2] = over ? 1 : 0;
+}
+
 // EpsilonClosure of e[0..n) (global, one element per state) in place, by the wave; returns the new size (sorted by state),
 // -1 when the LDS buffers were outgrown (nothing changed then but the trie: the caller runs det_closure()).
 __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int lane) {
@@ -141,6 +206,7 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
     const DetElem x = dw_ld_elem(e + i);
     S.cur[i] = x;
     S.queue[i] = x;
+    S.qidx[i] = (uint16_t)i;
     uint32_t h = detw_mapslot(x.state);
     for (;;) {
       if (atomicCAS(&S.map[h], 0u, ((uint32_t)x.state << 11) | (uint32_t)(i + 1)) == 0u) break;
@@ -151,159 +217,151 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
   DETW_SYNC();
   int nc = n, qh = 0, qn = n;
   bool over = false;
-  long long tp = 0, tc = 0, iters = 0, ents = 0, tA = clock64();
-  while (qn > 0 && !over) {
+  while (qn > 0 && !over && !W.err) {
     const int win = qn < kDwWin ? qn : kDwWin;
-    ++iters; ents += win;
-    long long c0 = clock64();
-    // ---- price the window: lane i takes queue entry qh + i ---------------------------------------------------
-    bool big = false;
-    long long x0 = clock64(), x1 = x0, x2 = x0, xs = 0;
-    if (lane < win) {
-      const DetElem el = S.queue[(qh + lane) & (kDwQueue - 1)];
-      uint32_t slot;
-      const int idx = detw_map_find(S, el.state, &slot);
-      int cnt = -1;
-      const DetElem c = S.cur[idx];
-      if (c.str == el.str && c.w1 == el.w1 && c.w2 == el.w2) {   // (else: stale already)
-        cnt = 0;
-        x1 = clock64();
-        const int32_t a1 = dw_ld(W.off + el.state + 1);
-        int32_t a = dw_ld(W.off + el.state);
-        if (a1 < 0) big = true;
-        x2 = clock64();
-        for (; a < a1; ++a) {
-          const DetArc arc = dw_ld_arc(W.arcs + a);
-          if (arc.ilabel != 0) break;
-          if (det_is_zero(arc.w1, arc.w2)) continue;
-          if (cnt == kDwArcs) { big = true; break; }
-          DetElem nx;
-          nx.state = arc.to;
-          nx.w1 = el.w1 + arc.w1;
-          nx.w2 = el.w2 + arc.w2;
-          long long y0 = clock64();
-          nx.str = arc.olabel == 0 ? el.str : detw_succ(W, el.str, arc.olabel);
-          xs += clock64() - y0;
-          S.offer[lane * kDwArcs + cnt] = nx;
-          ++cnt;
-        }
-      }
-      S.offer_cnt[lane] = cnt;
+    // ---- price the window: lane = entry * kDwArcs + arc ----------------------------------------------------------
+    const int en = lane / kDwArcs, j = lane % kDwArcs;
+    bool have = false, big = false;
+    DetElem nx;
+    nx.state = 0; nx.str = 0; nx.w1 = 0.0f; nx.w2 = 0.0f;
+    int tgt = 0;
+#ifdef DETW_TIMERS   // (development: tools/det_bench.hip -- the phases of a window, each drained before its clock is read)
+#define DWT(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long now_ = clock64(); if (lane == 0) S.tm[k] += now_ - tq; tq = now_; } while (0)
+    long long tq = clock64();
+#else
+#define DWT(k) do { } while (0)
+#endif
+    DetElem el; el.state = 0; el.str = 0; el.w1 = 0; el.w2 = 0;
+    bool live_e = false;
+    if (en < win) {
+      const int qp = (qh + en) & (kDwQueue - 1);
+      el = S.queue[qp];
+      const DetElem c = S.cur[S.qidx[qp]];
+      live_e = (c.str == el.str && c.w1 == el.w1 && c.w2 == el.w2);
     }
-    if (lane == 0) { S.tm[6] += x1 - x0; S.tm[7] += x2 - x1; S.tm[4] += xs; }
+    DWT(0);
+    int32_t a0 = 0, ne = 0;
+    if (live_e) { a0 = dw_ld(W.off + el.state); ne = dw_ld(W.neps + el.state); }
+    DWT(1);
+    DetArc arc; arc.ilabel = 0; arc.olabel = 0; arc.w1 = 0; arc.w2 = 0; arc.to = 0;
+    big = live_e && ne > kDwArcs;
+    const bool mine = live_e && j < ne && !big;
+    if (mine) arc = dw_ld_arc(W.arcs + a0 + j);
+    DWT(2);
+    if (mine && !det_is_zero(arc.w1, arc.w2)) {
+      have = true;
+      nx.state = arc.to;
+      nx.w1 = el.w1 + arc.w1;
+      nx.w2 = el.w2 + arc.w2;
+      nx.str = el.str;
+    }
+    {
+      const int32_t ns = detw_succ_wave(W, S.claim, have && arc.olabel != 0, el.str, arc.olabel, lane);
+      if (have && arc.olabel != 0) nx.str = ns;
+    }
+    DWT(3);
+    if (have) {
+      uint32_t slot;
+      const int idx = detw_map_find(S, nx.state, &slot);
+      tgt = idx >= 0 ? idx : -1 - (int)slot;
+      S.offer[lane] = nx;
+    }
+    DWT(4);
+#ifdef DETW_TIMERS
+    if (lane == 0) { S.tm[8] += 1; S.tm[9] += win; }
+#endif
     const unsigned long long bigmask = __ballot(big);
-    tp += clock64() - c0; c0 = clock64();
     int use = win;
-    if (bigmask) use = __ffsll((long long)bigmask) - 1;
-    DETW_SYNC();
+    if (bigmask) use = (__ffsll((long long)bigmask) - 1) / kDwArcs;
     if (use == 0) {
-      // ---- the head entry has more epsilon arcs than a lane prices: a lane per arc, 64 at a time -----------------
-      const DetElem el = S.queue[qh & (kDwQueue - 1)];
-      const int32_t a0 = dw_ld(W.off + el.state), a1 = dw_ld(W.off + el.state + 1);
-      bool more;
-      {
-        uint32_t slot;
-        const int idx = detw_map_find(S, el.state, &slot);
-        const DetElem c = S.cur[idx];
-        more = (c.str == el.str && c.w1 == el.w1 && c.w2 == el.w2);   // (else: stale)
-      }
-      for (int32_t base = a0; base < a1 && more && !over; base += 64) {
-        const int32_t a = base + lane;
-        bool live = false, noneps = false;
-        if (a < a1) {
-          const DetArc arc = dw_ld_arc(W.arcs + a);
-          if (arc.ilabel != 0) noneps = true;
-          else if (!det_is_zero(arc.w1, arc.w2)) {
-            live = true;
-            DetElem nx;
-            nx.state = arc.to;
-            nx.w1 = el.w1 + arc.w1;
-            nx.w2 = el.w2 + arc.w2;
-            nx.str = arc.olabel == 0 ? el.str : detw_succ(W, el.str, arc.olabel);
-            S.offer[lane] = nx;
+      // ---- the head entry has more epsilon arcs than a window prices: a lane per arc, 64 at a time, committed in order ----
+      DETW_SYNC();
+      const int qp = qh & (kDwQueue - 1);
+      const DetElem el = S.queue[qp];
+      const int32_t a0 = dw_ld(W.off + el.state), ne = dw_ld(W.neps + el.state);
+      for (int32_t base = 0; base < ne && !over; base += 64) {
+        bool live = false;
+        DetArc arc2; arc2.ilabel = 0; arc2.olabel = 0; arc2.w1 = 0; arc2.w2 = 0; arc2.to = 0;
+        if (base + lane < ne) {
+          arc2 = dw_ld_arc(W.arcs + a0 + base + lane);
+          live = !det_is_zero(arc2.w1, arc2.w2);
+        }
+        {
+          const int32_t ns = detw_succ_wave(W, S.claim, live && arc2.olabel != 0, el.str, arc2.olabel, lane);
+          if (live) {
+            DetElem y;
+            y.state = arc2.to;
+            y.w1 = el.w1 + arc2.w1;
+            y.w2 = el.w2 + arc2.w2;
+            y.str = arc2.olabel != 0 ? ns : el.str;
+            S.offer[lane] = y;
           }
         }
         const unsigned long long livemask = __ballot(live);
-        if (__ballot(noneps)) more = false;   // sorted: the epsilons end in this pass
         DETW_SYNC();
-        if (lane == 0) {
-          for (unsigned long long mk = livemask; mk && !over; mk &= mk - 1) {
-            const DetElem nx = S.offer[__ffsll((long long)mk) - 1];
-            uint32_t slot;
-            const int idx = detw_map_find(S, nx.state, &slot);
-            bool push = false;
-            if (idx < 0) {
-              if (nc >= kDwCur) { over = true; break; }
-              S.map[slot] = ((uint32_t)nx.state << 11) | (uint32_t)(nc + 1);
-              S.cur_slot[nc] = (uint16_t)slot;
-              S.cur[nc++] = nx;
-              push = true;
-            } else {
-              const DetElem c = S.cur[idx];
-              if (det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) == 1) { S.cur[idx] = nx; push = true; }
-            }
-            if (push) {
-              if (qn >= kDwQueue) { over = true; break; }
-              S.queue[(qh + qn) & (kDwQueue - 1)] = nx;
-              ++qn;
-            }
-          }
-          S.bc[0] = nc; S.bc[1] = qn; S.bc[2] = over ? 1 : 0;
-        }
+        if (lane == 0) detw_commit_in_order(W, S, livemask, 64, 1, qh, nc, qn);
         DETW_SYNC();
         nc = S.bc[0]; qn = S.bc[1]; over = S.bc[2] != 0;
         DETW_SYNC();
       }
       qh = (qh + 1) & (kDwQueue - 1);
       --qn;
-      if (W.err) break;
       continue;
     }
-    // ---- commit entries [0, use) in queue order: one lane, LDS only --------------------------------------------
-    if (lane == 0) {
-      int tail = qn;   // entries in the ring counted from qh (the window's are still in it)
-      for (int i = 0; i < use && !over; ++i) {
-        const int cnt = S.offer_cnt[i];
-        if (cnt <= 0) continue;
-        {  // the entry may have been overtaken by an offer committed since it was priced
-          const DetElem el = S.queue[(qh + i) & (kDwQueue - 1)];
-          uint32_t slot;
-          const int idx = detw_map_find(S, el.state, &slot);
-          const DetElem c = S.cur[idx];
-          if (!(c.str == el.str && c.w1 == el.w1 && c.w2 == el.w2)) continue;
-        }
-        for (int j = 0; j < cnt; ++j) {
-          const DetElem nx = S.offer[i * kDwArcs + j];
-          uint32_t slot;
-          const int idx = detw_map_find(S, nx.state, &slot);
-          bool push = false;
-          if (idx < 0) {
-            if (nc >= kDwCur) { over = true; break; }
-            S.map[slot] = ((uint32_t)nx.state << 11) | (uint32_t)(nc + 1);
-            S.cur_slot[nc] = (uint16_t)slot;
-            S.cur[nc++] = nx;
-            push = true;
-          } else {
-            const DetElem c = S.cur[idx];
-            if (det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) == 1) { S.cur[idx] = nx; push = true; }
-          }
-          if (push) {
-            if (tail >= kDwQueue) { over = true; break; }
-            S.queue[(qh + tail) & (kDwQueue - 1)] = nx;
-            ++tail;
-          }
-        }
-      }
-      S.bc[0] = nc; S.bc[1] = tail - use; S.bc[2] = over ? 1 : 0;
+    if (en >= use) have = false;
+    const unsigned long long valid = __ballot(have);
+    // ---- do two offers meet, or does one reach a state that has an entry in this window?  (marks in LDS) ----
+    if (have) {
+      if (tgt >= 0) S.mark_idx[tgt] = (uint16_t)lane;
+      else S.mark_slot[-1 - tgt] = (uint16_t)lane;
     }
     DETW_SYNC();
-    nc = S.bc[0]; qn = S.bc[1]; over = S.bc[2] != 0;
+    if (lane < use) S.mark_idx[S.qidx[(qh + lane) & (kDwQueue - 1)]] = (uint16_t)(64 + lane);   // (behind the offers' marks: an entry's mark wins)
+    DETW_SYNC();
+    bool clash = false;
+    if (have) clash = (tgt >= 0 ? S.mark_idx[tgt] : S.mark_slot[-1 - tgt]) != (uint16_t)lane;
+    if (__ballot(clash)) {
+      DETW_SYNC();
+      if (lane == 0) detw_commit_in_order(W, S, valid, kDwArcs, use, qh, nc, qn);
+      DETW_SYNC();
+      nc = S.bc[0]; qn = S.bc[1] - use; over = S.bc[2] != 0;
+      qh = (qh + use) & (kDwQueue - 1);
+      DETW_SYNC();
+      DWT(6);
+#ifdef DETW_TIMERS
+      if (lane == 0) S.tm[10] += 1;
+#endif
+      continue;
+    }
+    // ---- every lane commits its own offer: new states take cur[] slots, pushes queue positions, in lane order ----
+    const bool is_new = have && tgt < 0;
+    bool push = is_new;
+    if (have && tgt >= 0) {
+      const DetElem c = S.cur[tgt];
+      push = det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) == 1;
+    }
+    const unsigned long long newmask = __ballot(is_new), pushmask = __ballot(push);
+    const int n_new = __popcll(newmask), n_push = __popcll(pushmask);
+    if (nc + n_new > kDwCur || qn + n_push > kDwQueue) { over = true; break; }
+    int idx = tgt;
+    if (is_new) {
+      idx = nc + detw_rank(newmask, lane);
+      const uint32_t slot = (uint32_t)(-1 - tgt);
+      S.map[slot] = ((uint32_t)nx.state << 11) | (uint32_t)(idx + 1);
+      S.cur_slot[idx] = (uint16_t)slot;
+    }
+    if (push) {
+      S.cur[idx] = nx;
+      const int qp = (qh + qn + detw_rank(pushmask, lane)) & (kDwQueue - 1);
+      S.queue[qp] = nx;
+      S.qidx[qp] = (uint16_t)idx;
+    }
+    nc += n_new;
+    qn += n_push - use;
     qh = (qh + use) & (kDwQueue - 1);
     DETW_SYNC();
-    tc += clock64() - c0;
-    if (W.err) break;
+    DWT(5);
   }
-  long long tB = clock64();
   // ---- out: clear the index, sort by state ------------------------------------------------------------------
   for (int i = lane; i < nc; i += 64) {
     S.map[S.cur_slot[i]] = 0u;
@@ -314,7 +372,6 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
   detw_sort_keys(S, nc, lane);
   for (int i = lane; i < nc; i += 64) dw_st_elem(e + i, S.cur[S.sortk[i] & 1023u]);
   DETW_SYNC();
-  if (lane == 0) { S.tm[0] += tp; S.tm[1] += tc; S.tm[2] += iters; S.tm[3] += ents; S.tm[5] += tB - tA; }
   return nc;
 }
 
@@ -345,7 +402,7 @@ __device__ inline int32_t detw_pairs(DetWs &W, int32_t out) {
   int32_t m = 0;
   for (int32_t i = 0; i < n && !W.err; ++i) {
     const DetElem el = W.pool[W.os_off[out] + i];
-    for (int32_t a = W.off[el.state]; a < W.off[el.state + 1]; ++a) {
+    for (int32_t a = W.off[el.state] + W.neps[el.state]; a < W.off[el.state + 1]; ++a) {
       const DetArc &arc = W.arcs[a];
       if (arc.ilabel == 0 || det_is_zero(arc.w1, arc.w2)) continue;
       if (m >= W.cap.tmp) { W.err = 6; break; }
@@ -372,35 +429,20 @@ __device__ inline int32_t detw_pairs(DetWs &W, int32_t out) {
   return m;
 }
 
-// The whole construction for one lattice, called by every thread of a 256-thread workgroup; wave 0 runs it.
-// res {output states, output arcs, error, trie nodes}; timers: clock64 sums (lane 0).
-__device__ inline void detw_run_block(const int32_t *off, const DetArc *arcs, const int32_t *fin, int32_t n_states, int32_t n_arcs,
-                                      int32_t *ws, const DetCaps &caps, DetOutArc *out, int32_t *res, long long *timers, int variant) {
-  __shared__ DetWs W;
-  __shared__ DwShared S;
+// The whole construction for one lattice, called by every thread of a workgroup (W carved, its tables cleared by det_init, a
+// barrier behind both); wave 0 runs it, the other waves return.  timers (may be null): clock64 sums of lane 0.
+__device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
   const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) {
-    W.n_states = n_states; W.n_arcs = n_arcs; W.off = off; W.arcs = arcs; W.is_final = fin; W.delta = 1.0f / 1024;
-    det_carve(W, ws, caps, n_states);
-    int32_t h = 4096;
-    while (h < 16 * n_states && h < W.tr_hcap) h <<= 1;
-    W.tr_hcap = h < W.tr_hcap ? h : W.tr_hcap;
-  }
-  for (int i = tid; i < kDwMap; i += blockDim.x) S.map[i] = 0u;
-  if (tid < 8) S.tm[tid] = 0;
-  __syncthreads();
-  det_init(W, tid, blockDim.x);
-  __syncthreads();
-  if (tid >= 64) return;
+  if (tid >= 64) return 0;
   long long t_clo = 0, t_pairs = 0, t_sub = 0, t_fin = 0, t0 = clock64();
   if (lane == 0) {
     W.err = 0;
-    W.tr_n = 1; W.tr_parent[0] = 0; W.tr_label[0] = 0; W.tr_depth[0] = 0;
+    W.tr_n = 1; W.tr_key[0] = kDetRootKey; W.tr_depth[0] = 0;
     W.pool_n = 0; W.os_n = 0; W.ih_n = 0; W.q_n = 0; W.oa_n = 0;
     W.ta[0].state = 0; W.ta[0].str = 0; W.ta[0].w1 = 0.0f; W.ta[0].w2 = 0.0f;
   }
   DETW_SYNC();
-  if (n_states > 0) {
+  if (W.n_states > 0) {
     int m = detw_closure_any(W, S, W.ta, 1, lane);
     if (lane == 0) {
       m = det_minimal(W, W.ta, m);
@@ -488,10 +530,31 @@ __device__ inline void detw_run_block(const int32_t *off, const DetArc *arcs, co
     }
   }
   DETW_SYNC();
-  if (lane == 0) {
-    res[0] = W.os_n; res[1] = W.oa_n; res[2] = W.err; res[3] = W.tr_n;
-    if (timers) { timers[0] = clock64() - t0; timers[1] = t_clo; timers[2] = t_pairs; timers[3] = t_sub; timers[4] = t_fin; for (int q = 0; q < 8; ++q) timers[5 + q] = S.tm[q]; }
+  if (lane == 0 && timers) { timers[0] = clock64() - t0; timers[1] = t_clo; timers[2] = t_pairs; timers[3] = t_sub; timers[4] = t_fin; for (int q = 0; q < 11; ++q) timers[5 + q] = S.tm[q]; }
+  return W.err;
+}
+
+// (the development harness, tools/det_bench.hip) carve + init + run for one lattice, by a 256-thread workgroup
+__device__ inline void detw_run_block(const int32_t *off, const DetArc *arcs, const int32_t *fin, int32_t n_states, int32_t n_arcs,
+                                      int32_t *ws, const DetCaps &caps, DetOutArc *out, int32_t *res, long long *timers, int variant) {
+  __shared__ DetWs W;
+  __shared__ DwShared S;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) {
+    W.n_states = n_states; W.n_arcs = n_arcs; W.off = off; W.arcs = arcs; W.is_final = fin; W.delta = 1.0f / 1024;
+    det_carve(W, ws, caps, n_states);
+    int32_t h = 4096;
+    while (h < 16 * n_states && h < W.tr_hcap) h <<= 1;
+    W.tr_hcap = h < W.tr_hcap ? h : W.tr_hcap;
   }
+  for (int i = tid; i < kDwMap; i += blockDim.x) S.map[i] = 0u;
+  if (tid < 16) S.tm[tid] = 0;
+  __syncthreads();
+  det_init(W, tid, blockDim.x);
+  __syncthreads();
+  if (tid >= 64) return;
+  detw_run(W, S, timers);
+  if (lane == 0) { res[0] = W.os_n; res[1] = W.oa_n; res[2] = W.err; res[3] = W.tr_n; }
   if (out) {
     const int32_t na = W.oa_n < caps.arcs ? W.oa_n : caps.arcs;
     for (int i = lane; i < na; i += 64) out[i] = W.oarcs[i];

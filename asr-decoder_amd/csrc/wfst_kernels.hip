@@ -2618,7 +2618,6 @@ constexpr int kPrChunk = 8192;   // items of one compaction sweep (kBT threads x
 constexpr int kPrSlabs = 4;      // workgroups per channel of a compaction's flag sweeps (prune_flags)
 constexpr int kPrParInts = kPruneParInts;   // a channel's parameter block (DecoderDev::prune_par): [0, 16) the compaction's {run, c_lo, tokens lo / hi, frame-0 bound, links lo / hi, nd, slab counts}; [16, 32) lattice_emit's counters; then:
 constexpr int kPrRawCount = 32;  // ... and of the raw frames' launches: workgroups of the channel that have finished their share of the frame,
-constexpr int kPrRawFlag = 33;   // the pass is due and its raw frames are priced by those launches
 constexpr int kPrRawChg = 34;    // [3]: "an extra moved" of an epsilon round, in rotation
 constexpr int kPrRawJ = 16;      // workgroups per channel and raw frame
 struct ScanShared {
@@ -3614,13 +3613,28 @@ __device__ __forceinline__ bool prune_due(const DecoderDev &D, int c, const int3
   return nd > 0 && nd % D.prune_interval == 0 && ctl->pruned_upto != nd && nd < target[c] && ctl->error == 0 && !ctl->finalized &&
          nd < D.max_frames;
 }
+// ... and is its share of never-priced links large enough for the several-workgroup path (lattice_prune_raw_kernel) to pay?  Its
+// workgroups meet five times a frame; below a few hundred thousand links the one-workgroup walk in LDS is done sooner
+// (beam 13 of the bench: 12 k links a frame; beam 15: 45 k, 400 k in the heaviest channels).
+constexpr int kPrRawMinLinks = 400000;
+__device__ __forceinline__ int prune_raw_links(const DecoderDev &D, int c) {
+  const ChanCtl *cl = D.ctl + c;
+  const int32_t *lo = D.link_off + (size_t)c * (D.max_frames + 3);
+  const int a = cl->pruned_upto < 0 ? 0 : cl->pruned_upto;
+  return max(0, lo[cl->n_decoded + 1] - lo[a < cl->n_decoded ? a + 1 : cl->n_decoded]);
+}
+__device__ __forceinline__ bool prune_due_raw(const DecoderDev &D, int c, const int32_t *target) {
+  return prune_due(D, c, target) && prune_raw_links(D, c) >= kPrRawMinLinks;
+}
 template <bool kBig>
 __global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const int32_t *target, int chan_off, int group, int par, int raw) {
   __shared__ PruneShared ps;
   __shared__ BoundaryShared sh;
   const int c = blockIdx.x + chan_off;
   int32_t *pp = D.prune_par + (size_t)c * kPrParInts;
-  const bool raw_done = raw && pp[kPrRawFlag] != 0;
+  // (did lattice_prune_raw_kernel, the launch before, price this channel's raw frames?  The same function of the channel's control
+  // block that launch decided by -- no flag to go stale)
+  const bool raw_done = raw && prune_due_raw(D, c, target);
   if (threadIdx.x == 0) { pp[0] = 0; pp[kPrRawCount] = 0; }   // (the raw launch's meeting counter: back to 0 for the next pass)
   __syncthreads();
   if (prune_due(D, c, target)) prune_pass<false>(D, c, ps, raw_done);
@@ -3677,14 +3691,7 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
   if (chan_cnt <= kPrRawMaxChan) {
     for (int q = tid; q < chan_cnt; q += kPrRawT) {
       const int cc = q + chan_off;
-      unsigned long long w = 0;
-      if (prune_due(D, cc, target)) {
-        const ChanCtl *cl = D.ctl + cc;
-        const int32_t *lo = D.link_off + (size_t)cc * (D.max_frames + 3);
-        const int a = cl->pruned_upto < 0 ? 0 : cl->pruned_upto;
-        w = 1ull + (unsigned long long)max(0, lo[cl->n_decoded + 1] - lo[a < cl->n_decoded ? a + 1 : cl->n_decoded]);
-      }
-      s_work[q] = w;
+      s_work[q] = prune_due_raw(D, cc, target) ? 1ull + (unsigned long long)prune_raw_links(D, cc) : 0ull;
     }
     __syncthreads();
     if (tid == 0) {
@@ -3701,13 +3708,7 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
     }
     __syncthreads();
     const int w = (int)blockIdx.x;
-    if (w >= s_base[chan_cnt]) {
-      // (a workgroup without a share; the first of them also records the channels that are not due)
-      if (w == s_base[chan_cnt])
-        for (int q = tid; q < chan_cnt; q += kPrRawT)
-          if (!s_work[q]) D.prune_par[(size_t)(q + chan_off) * kPrParInts + kPrRawFlag] = 0;
-      return;
-    }
+    if (w >= s_base[chan_cnt]) return;   // (a workgroup without a share)
     int lo = 0, hi = chan_cnt - 1;   // the channel whose range holds w
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
@@ -3719,9 +3720,7 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
     c = (int)blockIdx.x / kPrRawJ + chan_off; j = (int)blockIdx.x % kPrRawJ; J = kPrRawJ;
   }
   int32_t *pp = D.prune_par + (size_t)c * kPrParInts;
-  const bool due = prune_due(D, c, target);
-  if (j == 0 && tid == 0) pp[kPrRawFlag] = due ? 1 : 0;   // (read by lattice_prune_kernel, the next launch)
-  if (!due) return;
+  if (!prune_due_raw(D, c, target)) return;
   ChanCtl *ctl = D.ctl + c;
   const int nd = ctl->n_decoded, n_prev = ctl->pruned_upto;
   const int4 *tok = D.tok + (size_t)c * D.arena_cap;

@@ -87,6 +87,8 @@ def parse():
                     "(wfst_decoder_advance_host): the PCIe-inclusive rate; never the headline")
     ap.add_argument("--max-tokens", type=int, default=65536, help="wfst_limits.max_tokens_per_frame (the headline workload peaks at 40 k tokens "
                     "in one frame; the service-point legs, whose frames reach beyond that before max_active cuts them, run with 131072)")
+    ap.add_argument("--default-limits", action="store_true", help="wfst_limits all zero: the LIBRARY's defaults for max_tokens_per_frame (262144 at this "
+                    "max_active) and arena_tokens (4 M), instead of the values this script passes")
     ap.add_argument("--arena-per-frame", type=int, default=0, help="token arena per utterance = frames x this (raise it for wider beams); "
                     "300 x 13900 stays below 2^22 tokens, where a token's backpointer has room for its state's degree code "
                     "(wfst_device.h: the expansion then skips the row-header loads); the heaviest utterance of rank 0's workload needs 3.4 M. "
@@ -361,6 +363,9 @@ def leg_scalars(o):
         if dk in o:
             k["cpu_self_bit_identical"] = "%d/%d" % (o[dk]["bit_identical"], o[dk]["utterances"])
             k["cpu_self_wer"] = o[dk]["wer"]
+    if "spread" in o:
+        k["cpu_self_wer_max"] = o["spread"]["reference_vs_reference_wer_range"][1]
+        k["wer_vs_cpu_max"] = o["spread"]["gpu_vs_reference_wer_range"][1]
     if "degraded_frames" in o:
         k["degraded_frames"] = o["degraded_frames"]
     return {a: _short(v) for a, v in k.items() if v is not None}
@@ -424,8 +429,11 @@ def summary_line(out, detail_path=None):
     def dump():
         return json.dumps(top, default=plain, allow_nan=False, separators=(",", ":"))
 
-    # (a line over the limit loses its optional parts, in this order, rather than its contract keys -- and is printed in any case)
-    core = ("value", "ms_per_step", "steps", "frac", "parity", "cpu_baseline_value", "error")
+    # (a line over the limit loses its optional parts -- strings first, then the legs' scalars from the least telling one up, then
+    # whole legs from the last one -- rather than its contract keys, and is printed in any case)
+    order = ("value", "ms_per_step", "steps", "frac", "parity", "cpu_baseline_value", "error", "utterances_with_path", "bit_identical", "wer_vs_cpu",
+             "cpu_self_wer", "whole_path_frac", "cpu_determinizer_ms_per_lattice", "wer_vs_cpu_max", "cpu_self_wer_max", "lattice_parity",
+             "degraded_frames", "cpu_self_bit_identical", "kernel", "cpu_baseline_cores", "cpu_baseline_kind")
     line = dump()
     if len(line) > LINE_LIMIT:
         for part, key, n in (("cpu_baseline", "sample", 60), ("config", "workload", 120), ("config", "parallelism", 40)):
@@ -433,8 +441,10 @@ def summary_line(out, detail_path=None):
                 top[part][key] = str(top[part][key])[:n]
         top["metric"] = top["metric"][:100]
         line = dump()
-    if len(line) > LINE_LIMIT and "legs" in top:
-        top["legs"] = {name: {k: v for k, v in leg.items() if k in core} for name, leg in top["legs"].items()}
+    for keep in range(len(order) - 1, 5, -1):
+        if len(line) <= LINE_LIMIT or "legs" not in top:
+            break
+        top["legs"] = {name: {k: v for k, v in leg.items() if k in order[:keep]} for name, leg in top["legs"].items()}
         line = dump()
     while len(line) > LINE_LIMIT and top.get("legs"):
         top["legs"].pop(next(reversed(top["legs"])))   # (last added first; bench_detail.json has them all)
@@ -635,8 +645,9 @@ def main():
                           **({"tile_tokens": a.tile_tokens} if a.tile_tokens > 0 else {}))
 
     def new_decoder(cfg_dict, max_tokens=None):
-        return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=T + 2, max_tokens_per_frame=max_tokens or a.max_tokens,
-                                    arena_tokens=int(T * a.arena_per_frame), stream=stream, lattice_links=a.lattice_links,
+        return wfstdec.BatchDecoder(graph, wfstdec.Config(**cfg_dict), B, max_frames=0 if a.default_limits else T + 2,
+                                    max_tokens_per_frame=0 if a.default_limits else (max_tokens or a.max_tokens),
+                                    arena_tokens=0 if a.default_limits else int(T * a.arena_per_frame), stream=stream, lattice_links=a.lattice_links,
                                     options=opt, old_lm=lm_dev[0], new_lm=lm_dev[1], lm_pairs=a.lm_pairs if a.biglm else 0)
 
     dec = new_decoder(cd)
@@ -907,7 +918,7 @@ def main():
         out["config"]["mean_active_tokens_per_frame"] = toks / float(B * (T + 1))
         out["config"]["mean_expanded_tokens_per_frame"] = N / float(B * T)
         out["config"]["peak_tokens_in_a_frame"] = max(s["peak_tokens"] for s in gstats)
-        out["config"]["max_tokens_per_frame_limit"] = a.max_tokens
+        out["config"]["max_tokens_per_frame_limit"] = "library default (262144 at a finite max_active, arena 4 M tokens)" if a.default_limits else a.max_tokens
         out["config"]["max_tokens_per_frame_note"] = ("a best-path decoder does not fail at this limit, it goes on from the limit-th cheapest token "
                                                       "(degraded_frames counts the frames on which it did); the limit also sizes the arena's collection "
                                                       "reserve (a quarter of the arena at most): every gc_stride-th frame (reserve / limit - 1, at most 16) runs the classic three launches")
@@ -1005,7 +1016,7 @@ def main():
             out["config"]["parity"] = "%d/%d sampled utterances bit-exact (words, transition-ids, tot_score) vs the %s CPU decoder" % (
                 dv["bit_identical"], ns, "oracle (biglm, fixed mode)" if a.biglm else "reference" if kind == "reference" else "oracle")
             if a.biglm:
-                oc = {k: sum(r.extra[k] for r in cres) for k in ("N", "E", "Z", "L")}
+                oc = {k: sum(r.extra[k] for r in cres) for k in ("N", "E", "Z", "L", "L_eps")}
                 oc["ties_on_best_path"] = sum(r.extra["ties"] for r in cres)
                 oc["lm_pairs_max"] = max(r.extra["lm_pairs"] for r in cres)
                 n_lm = oc["L"]
@@ -1055,9 +1066,12 @@ def main():
             # biglm: + 96 B per word-labelled arc traversed (8 B pair key; per LM 16 B state record, 4 B x ~4 probes of
             # the word-sorted arcs, 8 B arc {weight, next}; 8 B pair-table slot), + 4 B LM pair id per token and record
             Lb = n_lm * (E / float(max(oc["E"], 1)))   # look-ups of the whole batch, scaled from the sample by the emitting arcs
-            kb["expand"] += 96.0 * Lb + scale * (4.0 * E + 4.0 * N)
+            Leps = oc["L_eps"] * (E / float(max(oc["E"], 1)))   # ... of them on epsilon arcs: made by the closure pass, charged to it
+            kb["expand"] += 96.0 * (Lb - Leps) + scale * (4.0 * E + 4.0 * N)
             kb["insert"] += scale * (4.0 * E + 4.0 * N)
+            kb["closure"] += 96.0 * Leps + 4.0 * Z
             out["config"]["lm_lookups_per_step"] = Lb
+            out["config"]["lm_lookups_on_epsilon_arcs_per_step"] = Leps
         dom = max(("expand", "insert", "closure"), key=lambda k: prof[k + "_ms"])
         k_ms, k_n, k_bytes = prof[dom + "_ms"], prof[dom + "_launches"], kb[dom]
         per_launch_bytes = k_bytes / max(k_n, 1)
@@ -1099,7 +1113,7 @@ def main():
                                                       ("; + lattice terms (builder-defined, DESIGN.md 'Roofline accounting'): 16 B per forward link recorded, "
                                                        "24 B per link and 16 B per token priced by a back-pruning sweep, 12 B per item scanned and 32 B per "
                                                        "survivor moved by a compaction" if a.lattice_links > 0 else "") +
-                                                      ("; + biglm terms (builder-defined): 96 B per LM look-up, 4 B pair id per token and record" if a.biglm else "")),
+                                                      ("; + biglm terms (builder-defined): 96 B per LM look-up (charged to the kernel that makes it: expansion for emitting arcs, closure pass for epsilon arcs), 4 B pair id per token and record" if a.biglm else "")),
                                           "frac_over_kernel_time": (whole_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms > 0 else 0.0,
                                           "frac_over_step_time": whole_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                            "measured": "hipEvent pairs around every launch on the stream it is launched on, one extra step after the timed region"}
@@ -1130,7 +1144,7 @@ def main():
         cd2 = dict(cd, max_active=7000, min_active=200)
         n2 = max(2, a.steps // 4)
 
-        def at_service_point(mats2, ll2):
+        def at_service_point(mats2, ll2, spread=False):
             """decode at 7000/200; with the CPU legs on: GPU result vs the reference decoder's own, and the
             reference against ITSELF with nothing but its hash table size changed (hash_ratio 3 instead of
             2: another visiting order of the same algorithm) -- the yardstick for the first number"""
@@ -1148,8 +1162,28 @@ def main():
                 cres2 = cpu_decode_all(cdec, gpath, cd2, list(mats2), m, affinity_cpus())
                 o["divergence_vs_" + kind] = divergence(res2, cres2)
                 cres3 = cpu_decode_all(cdec, gpath, dict(cd2, hash_ratio=3.0), list(mats2), m, affinity_cpus())
-                o[kind + "_self_divergence_hash_ratio_3_vs_2"] = divergence(
-                    [dict(ok=r.ok, words=r.words, tids=r.tids, tot_score=r.tot_score) for r in cres3], cres2)
+                as_res = lambda rs: [dict(ok=r.ok, words=r.words, tids=r.tids, tot_score=r.tot_score) for r in rs]
+                o[kind + "_self_divergence_hash_ratio_3_vs_2"] = divergence(as_res(cres3), cres2)
+                if spread:
+                    # a third visiting order of the reference (hash_ratio 2.5) and every pair -- the reference's own
+                    # spread, and the GPU (= the order-free restatement, bit for bit) against each of the three
+                    cres25 = cpu_decode_all(cdec, gpath, dict(cd2, hash_ratio=2.5), list(mats2), m, affinity_cpus())
+                    brief = lambda d: {k: d[k] for k in ("bit_identical", "same_words", "wer", "max_rel_cost_gap")}
+                    sp_ = {"reference@2.5 vs reference@2": brief(divergence(as_res(cres25), cres2)),
+                           "reference@3 vs reference@2": brief(o[kind + "_self_divergence_hash_ratio_3_vs_2"]),
+                           "reference@3 vs reference@2.5": brief(divergence(as_res(cres3), cres25)),
+                           "gpu vs reference@2": brief(o["divergence_vs_" + kind]),
+                           "gpu vs reference@2.5": brief(divergence(res2, cres25)),
+                           "gpu vs reference@3": brief(divergence(res2, cres3))}
+                    rr = [v["wer"] for k, v in sp_.items() if not k.startswith("gpu")]
+                    gg = [v["wer"] for k, v in sp_.items() if k.startswith("gpu")]
+                    sp_["reference_vs_reference_wer_range"] = [min(rr), max(rr)]
+                    sp_["gpu_vs_reference_wer_range"] = [min(gg), max(gg)]
+                    sp_["note"] = ("the GPU computes ProcessEmitting's next_cutoff as the minimum over ALL arrivals before admitting any (the reference "
+                                   "tightens it while it walks its hash list, base-inl.h:321-333, so every visiting order admits a superset): it is "
+                                   "the limit point of the reference's orders, further from each of them than they are from each other, with no "
+                                   "bias in path cost (signed_rel_cost_gap); profiles/r05_parity_spread.json, DESIGN.md section 4 deviation 2")
+                    o["spread"] = sp_
             return o
 
         sa = argparse.Namespace(**vars(a))
@@ -1158,7 +1192,7 @@ def main():
         ll2 = torch.from_numpy(mats2).to(dev)
         sp = {"workload": "SURVEY.md 8(d) single-planted-path log-likelihoods (mu -2, sigma 1), same graph and batch, beam=%g, "
                           "max_active=7000, min_active=200 (v1-asrbin/conf/decoder.conf:4-8)" % a.beam}
-        sp.update(at_service_point(mats2, ll2))
+        sp.update(at_service_point(mats2, ll2, spread=True))
         del ll2, mats2
         # third leg: the same generator calibrated as SURVEY 8(d) asks -- mu -2.6 gives ~5.5 k tokens per frame at
         # beam 13, ~4 k of them expanded -- so that max_active 7000 binds on a minority of the frames
@@ -1166,7 +1200,7 @@ def main():
         mats3 = make_utts(synth, g, m, 0, B, T, P, sa)
         ll3 = torch.from_numpy(mats3).to(dev)
         cp = {"workload": "SURVEY.md 8(d) single-planted-path log-likelihoods calibrated to ~5 k tokens per frame (mu -2.6, sigma 1), max_active=7000, min_active=200"}
-        cp.update(at_service_point(mats3, ll3))
+        cp.update(at_service_point(mats3, ll3, spread=True))
         del ll3, mats3
         sp["calibrated_workload_at_7000_200"] = cp
         hp = {"workload": "the headline log-likelihoods at max_active=7000, min_active=200"}
@@ -1224,7 +1258,12 @@ def main():
         # NShortestPath: kaldi-online-nnet3-my-decoder.cc:50-105); the other legs vary the same two configurations and carry none
         cpu_on = ["--cpu-seconds", str(min(a.cpu_seconds, 5.0)), "--cpu-threads", str(min(64, a.cpu_threads or affinity_cpus()))] if (a.cpu_sample > 0 and not a.no_cpu_baseline) else ["--no-cpu-baseline"]
         cpu_off = ["--no-cpu-baseline"]
-        legs = {"biglm": ["--biglm", "--steps", str(max(6, n2)), "--cpu-sample", "8", "--max-tokens", "131072"] + cpu_on,
+        legs = {# the headline with wfst_limits all zero: what a caller who sizes nothing gets
+                "headline_library_default_limits": ["--default-limits", "--steps", str(max(6, n2)), "--cpu-sample", "4"] + cpu_off,
+                "biglm": ["--biglm", "--steps", str(max(6, n2)), "--cpu-sample", "8", "--max-tokens", "131072"] + cpu_on,
+                # ... at lattice_beam 7 the reference's biglm final pruning (biglm.h:186-188) leaves 45 of the 128 utterances a path; at 14,
+                # 121 of them: the same search (the beam is what it costs), a result for nearly every utterance
+                "biglm_lattice_beam14": ["--biglm", "--lattice-beam", "14", "--steps", str(max(6, n2)), "--cpu-sample", "8", "--max-tokens", "131072"] + cpu_off,
                 "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2", "--postprocess"] + cpu_off,
                 "lattice_beam15_no_determinizer": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
                                                    "--max-tokens", "262144", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "2", "--warmup", "2"] + cpu_off,

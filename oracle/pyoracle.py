@@ -508,7 +508,7 @@ def biglm_decode(dec, graph_handle, cfg, lm1, lm2, loglikes, tid2pdf=None, chunk
                pi[:n].copy(), po[:n].copy(), pg[:n].copy(), pa[:n].copy(), fn, fb, None, nt.value, nl.value)
     if not is_ref:
         r.extra = dict(N=int(ex[0]), E=int(ex[1]), Z=int(ex[2]), tokens_created=int(ex[3]), links_created=int(ex[4]),
-                       ties=int(ex[5]), quirk_hops=int(ex[6]), lm_pairs=int(ex[7] & ((1 << 40) - 1)), lm_oob=int(ex[7] >> 40), L=int(ex[8]))
+                       ties=int(ex[5]), quirk_hops=int(ex[6]), lm_pairs=int(ex[7] & ((1 << 40) - 1)), lm_oob=int(ex[7] >> 40), L=int(ex[8]), L_eps=int(ex[9]))
     return r
 
 

@@ -123,6 +123,7 @@ typedef struct {
   /* work counters for the roofline's algorithmic bytes */
   int64_t cnt_N, cnt_E, cnt_Z, cnt_tok_created, cnt_link_created;
   int64_t cnt_L; /* biglm: arcs with an output label traversed (LM look-ups) */
+  int64_t cnt_Leps; /* ... of them on epsilon arcs (ProcessNonemitting) */
 } Decoder;
 
 static void *pool_new(Pool *p) {
@@ -489,7 +490,7 @@ static void process_nonemitting(Decoder *d, float cutoff) {
         int next_lm = 0;
         if (d->dlm) { /* biglm.h:448-451 */
           float lm_score;
-          if (arc->olabel != 0) d->cnt_L++;
+          if (arc->olabel != 0) { d->cnt_L++; d->cnt_Leps++; }
           next_lm = next_lm_state(d->dlm, lm_state, arc->olabel, &lm_score);
           graph_cost = arc->w + lm_score;
         }
@@ -890,7 +891,7 @@ static int decode_impl(void *gp, const Config *rc, DiffLm *dlm, const float *log
   }
   if (extra) { extra[0] = d->cnt_N; extra[1] = d->cnt_E; extra[2] = d->cnt_Z; extra[3] = d->cnt_tok_created; extra[4] = d->cnt_link_created; extra[5] = tie_hops; extra[6] = quirk_hops;
                extra[7] = dlm ? ((int64_t)dlm->n_vec | ((int64_t)dlm->oob << 40)) : 0;
-               if (dlm) extra[8] = d->cnt_L; /* biglm callers pass 10 slots */ }
+               if (dlm) { extra[8] = d->cnt_L; extra[9] = d->cnt_Leps; } /* biglm callers pass 10 slots */ }
 
   /* teardown */
   clear_active_tokens(d);

@@ -460,13 +460,20 @@ def test_service_operating_point_divergence_from_the_reference(big, synth, refde
     # (c) the same generator calibrated as SURVEY 8(d) asks (mu -2.6: ~5.5 k tokens per frame at beam 13, ~4 k expanded), where
     #     max_active 7000 binds on a minority of the frames
     calibrated = [synth.make_loglikes(big["g"], big["T"], 3000, big["m"], seed=u, mu=-2.6, sigma=1.0)[0] for u in range(big["B"])]
-    out = {}
+    out, spread = {}, {}
     for name, mats in (("headline", big["mats"]), ("single", single), ("calibrated", calibrated)):
         res = G.decode_batch(big["graph"], cd, mats, limits=LIM)
         assert all(r.ok and len(r.tids) == big["T"] for r in res)
         r2 = ref_all(mats)
         r3 = ref_all(mats, hash_ratio=3.0)
         out[name] = (divergence(as_gpu(res), r2), divergence(as_gpu(r3), r2))
+        if name != "headline":
+            # the reference's own SPREAD (round 5, tools/parity_spread.py): a third visiting order, every pair
+            r25 = ref_all(mats, hash_ratio=2.5)
+            spread[name] = (max(out[name][1]["wer"], divergence(as_gpu(r25), r2)["wer"], divergence(as_gpu(r3), r25)["wer"]),
+                            max(out[name][0]["wer"], divergence(as_gpu(res), r25)["wer"], divergence(as_gpu(res), r3)["wer"]))
+            with capsys.disabled():
+                print("[7000/200, %s] WER: reference vs reference at most %.4f, GPU vs reference at most %.4f" % ((name,) + spread[name]))
         with capsys.disabled():
             print("\n[7000/200, %s] GPU vs reference: %s\n[7000/200, %s] reference(hash_ratio 3) vs reference: %s" % (name, out[name][0], name, out[name][1]))
     refdec.free_graph(h)
@@ -482,4 +489,11 @@ def test_service_operating_point_divergence_from_the_reference(big, synth, refde
         sg, ss = dv["signed_rel_cost_gap"], self_dv["signed_rel_cost_gap"]
         assert sg["mean"] <= 2.0 * abs(ss["mean"]) + 1e-4, (name, sg, ss)
         assert sg["second_cheaper"] <= 2 * ss["second_cheaper"] + 4, (name, sg, ss)
+    # Round 5: measured against the reference's own spread over THREE visiting orders (hash_ratio 2, 2.5, 3:
+    # WER 0.168-0.193 single, 0.031-0.042 calibrated), the GPU sits just outside it (0.211-0.239, 0.041-0.052): it computes
+    # ProcessEmitting's next_cutoff as the minimum over all arrivals BEFORE admitting any, the limit point of the reference's rule
+    # (which tightens while it walks its hash list: every order admits a superset), so it is further from each order than they are
+    # from each other -- by a factor 1.24 at most here.  The bound is that measurement with a margin, down from 1.5 x one pair.
+    for name, (ref_max, gpu_max) in spread.items():
+        assert gpu_max <= 1.35 * ref_max + 0.005, (name, ref_max, gpu_max)
     assert out["headline"][0]["wer"] <= 0.05, out["headline"]
