@@ -42,7 +42,8 @@ struct DwShared {
   uint16_t qidx[kDwQueue];       // the queue entry's state: its index in cur[]
   uint32_t map[kDwMap];          // 0 = empty, else (state << 11) | (index + 1)
   uint16_t cur_slot[kDwCur];     // where element i sits in map[] (cleared from here when the closure is done)
-  uint16_t mark_idx[kDwCur];     // commit: which lane means to touch cur[i] / map[slot] (two lanes on one: in order, by one lane)
+  uint16_t mark_idx[kDwCur];     // commit: the window's entry that sits on cur[i] (0xFFFF: none)
+  uint16_t mark_best[kDwCur];    // ... the lane whose offer to cur[i] is the best so far; likewise for an empty slot of map[] (a new state)
   uint16_t mark_slot[kDwMap];
   uint32_t sortk[kDwCur];
   DetElem offer[64];
@@ -200,7 +201,8 @@ __device__ inline void detw_commit_in_order(DetWs &W, DwShared &S, unsigned long
 
 // EpsilonClosure of e[0..n) (global, one element per state) in place, by the wave; returns the new size (sorted by state),
 // -1 when the LDS buffers were outgrown (nothing changed then but the trie: the caller runs det_closure()).
-__device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int lane) {
+// minimal: ConvertToMinimal (:940-957) on the way out -- only the elements whose state has a labelled arc or is final are written.
+__device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int lane, bool minimal) {
   if (n > kDwCur || W.n_states >= (1 << 21)) return -1;
   for (int i = lane; i < n; i += 64) {
     const DetElem x = dw_ld_elem(e + i);
@@ -214,6 +216,7 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
     }
     S.cur_slot[i] = (uint16_t)h;
   }
+  for (int i = lane; i < kDwCur; i += 64) S.mark_idx[i] = 0xFFFFu;
   DETW_SYNC();
   int nc = n, qh = 0, qn = n;
   bool over = false;
@@ -309,50 +312,86 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
       continue;
     }
     if (en >= use) have = false;
-    const unsigned long long valid = __ballot(have);
-    // ---- do two offers meet, or does one reach a state that has an entry in this window?  (marks in LDS) ----
-    if (have) {
-      if (tgt >= 0) S.mark_idx[tgt] = (uint16_t)lane;
-      else S.mark_slot[-1 - tgt] = (uint16_t)lane;
+    // ---- commit, every lane its own offer.  What the reference's order decides, and how it is kept:
+    //  (1) an offer counts only if it beats the target's best; the best only improves, so an offer that loses against the best of
+    //      the window's start loses at its turn too: dropped now;
+    //  (2) an entry whose state is improved by an offer of an EARLIER entry of the window is stale at its turn (:874-875): the
+    //      window ends in front of the first such entry (its turn comes next window, where the pricing finds it stale), so every
+    //      entry committed here is alive at its turn whatever the others do;
+    //  (3) offers that meet in one state: the reference takes them in turn and keeps the best; the ones it takes on the way sit in
+    //      the queue as stale entries nobody reads -- only the best (the earliest of equals) is committed, at its own place in the
+    //      queue's order.
+    const int use0 = use;
+    const bool have0 = have;   // (as priced)
+    if (lane < use0) S.mark_idx[S.qidx[(qh + lane) & (kDwQueue - 1)]] = (uint16_t)lane;   // which entry of the window sits on cur[i]
+    DETW_SYNC();
+    int kill = use0;
+    if (have && tgt >= 0) {
+      const DetElem c = S.cur[tgt];
+      if (det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) != 1) have = false;   // (1)
+      else {
+        const int me = S.mark_idx[tgt];
+        if (me < use0 && me > en) kill = me;                                            // (2)
+      }
     }
+    for (int d = 32; d > 0; d >>= 1) kill = min(kill, __shfl_xor(kill, d, 64));
+    use = kill;
+    if (en >= use) have = false;
     DETW_SYNC();
-    if (lane < use) S.mark_idx[S.qidx[(qh + lane) & (kDwQueue - 1)]] = (uint16_t)(64 + lane);   // (behind the offers' marks: an entry's mark wins)
-    DETW_SYNC();
-    bool clash = false;
-    if (have) clash = (tgt >= 0 ? S.mark_idx[tgt] : S.mark_slot[-1 - tgt]) != (uint16_t)lane;
-    if (__ballot(clash)) {
+    if (lane < use0) S.mark_idx[S.qidx[(qh + lane) & (kDwQueue - 1)]] = 0xFFFFu;
+    // (3) the champion of every state that offers meet in
+    bool mixed = false;
+    {
+      bool cand = have;
+      uint16_t *mk = tgt >= 0 ? &S.mark_best[tgt] : &S.mark_slot[-1 - tgt];
+      for (int round = 0; round < 64; ++round) {
+        if (cand) *mk = (uint16_t)lane;
+        DETW_SYNC();
+        const int champ = cand ? (int)*mk : lane;
+        bool beat = false;
+        if (cand && champ != lane) {
+          const DetElem o = S.offer[champ];
+          if (o.state != nx.state) mixed = true;   // (two NEW states after one empty slot of the index: settled in order below)
+          const int cmp = det_cmp(W, nx.w1, nx.w2, nx.str, o.w1, o.w2, o.str);
+          beat = cmp == 1 || (cmp == 0 && lane < champ);
+          if (!beat) cand = false;
+        }
+        DETW_SYNC();
+        if (beat) *mk = (uint16_t)lane;   // (tells the champion it is beaten)
+        DETW_SYNC();
+        if (cand && champ == lane && (int)*mk != lane) cand = false;
+        const bool settled = !cand || (champ == lane && (int)*mk == lane);
+        if (!__ballot(!settled)) break;
+      }
+      have = cand;
+    }
+    const unsigned long long valid = __ballot(have);
+    if (__ballot(mixed)) {
+      // (never seen on a lattice of the bench: two states new to the closure whose probes of the state index end in one slot)
+      const unsigned long long all = __ballot(have0 && en < use);   // the window's offers as priced: the in-order commit judges them itself
       DETW_SYNC();
-      if (lane == 0) detw_commit_in_order(W, S, valid, kDwArcs, use, qh, nc, qn);
+      if (lane == 0) detw_commit_in_order(W, S, all, kDwArcs, use, qh, nc, qn);
       DETW_SYNC();
       nc = S.bc[0]; qn = S.bc[1] - use; over = S.bc[2] != 0;
       qh = (qh + use) & (kDwQueue - 1);
       DETW_SYNC();
       DWT(6);
-#ifdef DETW_TIMERS
-      if (lane == 0) S.tm[10] += 1;
-#endif
       continue;
     }
-    // ---- every lane commits its own offer: new states take cur[] slots, pushes queue positions, in lane order ----
     const bool is_new = have && tgt < 0;
-    bool push = is_new;
-    if (have && tgt >= 0) {
-      const DetElem c = S.cur[tgt];
-      push = det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) == 1;
-    }
-    const unsigned long long newmask = __ballot(is_new), pushmask = __ballot(push);
-    const int n_new = __popcll(newmask), n_push = __popcll(pushmask);
+    const unsigned long long newmask = __ballot(is_new);
+    const int n_new = __popcll(newmask), n_push = __popcll(valid);
     if (nc + n_new > kDwCur || qn + n_push > kDwQueue) { over = true; break; }
-    int idx = tgt;
-    if (is_new) {
-      idx = nc + detw_rank(newmask, lane);
-      const uint32_t slot = (uint32_t)(-1 - tgt);
-      S.map[slot] = ((uint32_t)nx.state << 11) | (uint32_t)(idx + 1);
-      S.cur_slot[idx] = (uint16_t)slot;
-    }
-    if (push) {
+    if (have) {
+      int idx = tgt;
+      if (is_new) {
+        idx = nc + detw_rank(newmask, lane);
+        const uint32_t slot = (uint32_t)(-1 - tgt);
+        S.map[slot] = ((uint32_t)nx.state << 11) | (uint32_t)(idx + 1);
+        S.cur_slot[idx] = (uint16_t)slot;
+      }
       S.cur[idx] = nx;
-      const int qp = (qh + qn + detw_rank(pushmask, lane)) & (kDwQueue - 1);
+      const int qp = (qh + qn + detw_rank(valid, lane)) & (kDwQueue - 1);
       S.queue[qp] = nx;
       S.qidx[qp] = (uint16_t)idx;
     }
@@ -370,16 +409,32 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
   DETW_SYNC();
   if (over || W.err) return -1;
   detw_sort_keys(S, nc, lane);
-  for (int i = lane; i < nc; i += 64) dw_st_elem(e + i, S.cur[S.sortk[i] & 1023u]);
+  int nout = 0;
+  for (int i0 = 0; i0 < nc; i0 += 64) {
+    const int i = i0 + lane;
+    DetElem x;
+    bool keep = false;
+    if (i < nc) {
+      x = S.cur[S.sortk[i] & 1023u];
+      keep = !minimal || dw_ld(W.osf + x.state) != 0;
+    }
+    const unsigned long long km = __ballot(keep);
+    if (keep) dw_st_elem(e + nout + detw_rank(km, lane), x);
+    nout += __popcll(km);
+  }
   DETW_SYNC();
-  return nc;
+  return nout;
 }
 
 // the closure by the wave, or -- when it outgrows LDS -- by lane 0 in the workspace's buffers
-__device__ inline int detw_closure_any(DetWs &W, DwShared &S, DetElem *e, int n, int lane) {
-  int m = detw_closure(W, S, e, n, lane);
+__device__ inline int detw_closure_any(DetWs &W, DwShared &S, DetElem *e, int n, int lane, bool minimal) {
+  int m = detw_closure(W, S, e, n, lane, minimal);
   if (m >= 0) return m;
-  if (lane == 0) S.bc[3] = W.err ? 0 : det_closure(W, e, n);
+  if (lane == 0) {
+    int k = W.err ? 0 : det_closure(W, e, n);
+    if (minimal && !W.err) k = det_minimal(W, e, k);
+    S.bc[3] = k;
+  }
   DETW_SYNC();
   return S.bc[3];
 }
@@ -443,11 +498,8 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
   }
   DETW_SYNC();
   if (W.n_states > 0) {
-    int m = detw_closure_any(W, S, W.ta, 1, lane);
-    if (lane == 0) {
-      m = det_minimal(W, W.ta, m);
-      det_minimal_to_state(W, W.ta, m, false);
-    }
+    const int m = detw_closure_any(W, S, W.ta, 1, lane, true);
+    if (lane == 0) det_minimal_to_state(W, W.ta, m, false);
     DETW_SYNC();
     for (;;) {
       if (W.q_n <= 0 || W.err) break;
@@ -500,13 +552,12 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
         t_sub += clock64() - c0;
         if (found < 0 && !W.err) {
           c0 = clock64();
-          int m2 = detw_closure_any(W, S, W.ta, k, lane);
+          const int m2 = detw_closure_any(W, S, W.ta, k, lane, true);   // (the closure, already minimal)
           t_clo += clock64() - c0;
           c0 = clock64();
           if (lane == 0 && !W.err) {
             // InitialToStateId, second half
             DetElem *s = W.ta;
-            m2 = det_minimal(W, s, m2);
             float w1, w2;
             int32_t str;
             det_normalize(W, s, m2, &w1, &w2, &str);
