@@ -48,6 +48,8 @@ struct DwShared {
   uint32_t sortk[kDwCur];
   DetElem offer[64];
   uint16_t claim[256];           // detw_succ_wave: who takes an empty trie slot
+  DetElem stage[64];             // a closure's (minimal) result of up to 64 elements, beside its copy in the workspace: what lane 0 normalizes,
+  DetElem sub[64];               // hashes and compares next -- and the initial subset it came from -- read at LDS latency
   int32_t bc[16];                // lane 0 -> wave
   long long tm[16];              // (development timers)
 };
@@ -419,7 +421,11 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
       keep = !minimal || dw_ld(W.osf + x.state) != 0;
     }
     const unsigned long long km = __ballot(keep);
-    if (keep) dw_st_elem(e + nout + detw_rank(km, lane), x);
+    if (keep) {
+      const int o = nout + detw_rank(km, lane);
+      dw_st_elem(e + o, x);
+      if (o < 64) S.stage[o] = x;
+    }
     nout += __popcll(km);
   }
   DETW_SYNC();
@@ -433,6 +439,7 @@ __device__ inline int detw_closure_any(DetWs &W, DwShared &S, DetElem *e, int n,
   if (lane == 0) {
     int k = W.err ? 0 : det_closure(W, e, n);
     if (minimal && !W.err) k = det_minimal(W, e, k);
+    for (int i = 0; i < k && i < 64; ++i) S.stage[i] = e[i];   // (as detw_closure leaves it)
     S.bc[3] = k;
   }
   DETW_SYNC();
@@ -517,7 +524,10 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
         c0 = clock64();
         if (lane == 0) {
           const int32_t ilabel = W.ta_label[i];
-          DetElem *sub = W.te;
+          int32_t run = 0;
+          while (i + run < mp && run <= 64 && W.ta_label[i + run] == ilabel) ++run;
+          DetElem *sub = run <= 64 ? S.sub : W.te;   // (a handful of elements as a rule: kept in LDS)
+          S.bc[13] = run <= 64 ? 1 : 0;
           int32_t k = 0;
           while (i < mp && W.ta_label[i] == ilabel) {
             DetElem cur = W.td[i];
@@ -557,7 +567,8 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
           c0 = clock64();
           if (lane == 0 && !W.err) {
             // InitialToStateId, second half
-            DetElem *s = W.ta;
+            DetElem *s = m2 <= 64 ? S.stage : W.ta;   // (the closure left its result in both)
+            DetElem *sub = S.bc[13] ? S.sub : W.te;
             float w1, w2;
             int32_t str;
             det_normalize(W, s, m2, &w1, &w2, &str);
@@ -566,7 +577,7 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
             else {
               const int32_t q = W.ih_n++;
               const uint32_t b = (uint32_t)S.bc[10];
-              W.ih_off[q] = det_store(W, W.te, k);
+              W.ih_off[q] = det_store(W, sub, k);
               W.ih_len[q] = k;
               W.ih_state[q] = ans; W.ih_w1[q] = w1; W.ih_w2[q] = w2; W.ih_str[q] = str;
               W.ih_next[q] = W.ih_head[b];
