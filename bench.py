@@ -134,6 +134,8 @@ def parse():
     ap.add_argument("--lm-new", default="40000,6,100000,3", help="new LM: same four numbers")
     ap.add_argument("--lm-pairs", type=int, default=1 << 20, help="LM pair states per utterance (wfst_limits.lm_pairs)")
     ap.add_argument("--graph-cache", default="/tmp/wfst_bench_graph_%d.bin")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child runs of this script, "
+                    "FETCH_SIZE and WRITE_SIZE, one step each with the kernels enqueued one by one): quote the stored passes of profiles/traffic_latest.json")
     ap.add_argument("--detail-out", default="", help="where the FULL result (every leg, curve, count and note) is written as JSON; default "
                     "bench_detail.json beside this script (and gpurun_out/bench_detail.json when that directory exists).  The final "
                     "stdout line is the compact summary of it (summary_line(): < 4 KB, scalars only)")
@@ -316,6 +318,57 @@ def divergence(gpu_res, cpu_res):
                                     "first_cheaper": int((sg < 0).sum()), "second_cheaper": int((sg > 0).sum()), "equal": int((sg == 0).sum()),
                                     "note": "(tot_first - tot_second) / |tot_second| over utterances with a path on both sides; first = the "
                                             "decoder under test (GPU, or the reference at hash_ratio 3), second = the reference"}}
+
+
+def measure_traffic(a, workload_args):
+    """HBM bytes per launch of each kernel class, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then
+    WRITE_SIZE: separate passes, counters only, no trace domain), one step each, one channel group, kernels enqueued one by one
+    (--no-hip-graph) so that every dispatch is attributed.  Corrected as MI355X_MICROARCH.md's HBM section prescribes for gfx950:
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes (FETCH_SIZE counts 128-byte fabric requests at 64 bytes; both are reported in KB).
+    Returns ({class: bytes per launch}, {class: launches}, seconds) or None."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    t0 = time.time()
+    tmp = tempfile.mkdtemp(prefix="wfst_pmc_", dir="/tmp")
+    klass = lambda k: ("expand" if "expand_kernel" in k else "insert" if "insert_kernel" in k else
+                       "closure" if ("closure_kernel" in k or "lattice_prune" in k) else None)
+    kb = collections.defaultdict(float)
+    launches = collections.defaultdict(int)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1",
+                   "--warmup", "0", "--cpu-sample", "0", "--no-service-point", "--no-legs", "--no-traffic", "--no-hip-graph", "--groups", "1",
+                   "--detail-out", os.path.join(tmp, ctr + ".json")] + workload_args
+            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            fs = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
+            if pr.returncode != 0 or not fs:
+                log("traffic pass %s failed (rc %d): %s" % (ctr, pr.returncode, pr.stderr.decode()[-300:]))
+                return None
+            seen = collections.defaultdict(int)
+            with open(fs[0]) as f:
+                for r in csv.DictReader(f):
+                    c = klass(r["Kernel_Name"])
+                    if c is None or r["Counter_Name"] != ctr:
+                        continue
+                    kb[c] += (2.0 if ctr == "FETCH_SIZE" else 1.0) * float(r["Counter_Value"])
+                    seen[c] += 1
+            for c, n in seen.items():
+                launches[c] = max(launches[c], n)
+    except Exception as e:  # (a measurement that cannot be made is reported as such, it does not take the bench down)
+        log("traffic measurement failed: %r" % (e,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return ({c: kb[c] * 1024.0 / max(launches[c], 1) for c in kb}, dict(launches), time.time() - t0)
 
 
 LINE_LIMIT = 4000   # bytes of the final stdout line (the driver parses it; round 4's 29 KB line was not parsed)
@@ -1097,13 +1150,36 @@ def main():
             try:
                 tjd = json.load(open(tj))
                 traffic = tjd.get(which, {}).get(dom + "_bytes_per_launch")
+                if traffic is not None:   # (stored per whole-batch launch: brought to this run's launch count)
+                    traffic = traffic * tjd[which].get("launches", {}).get(dom, k_n) / float(max(k_n, 1))
                 traffic_src = "NOT measured in this run: profiles/traffic_latest.json [%s] (%s); one channel group, i.e. whole-batch launches" % (which, tjd.get("origin", "stored rocprofv3 --pmc passes"))
             except Exception:
                 traffic = None
+        measured = None
+        if world == 1 and not a.no_traffic and not a.no_hip_graph:
+            wl = ["--batch", str(B), "--frames", str(T), "--states", str(a.states), "--pdfs", str(P), "--beam", str(a.beam), "--max-active", str(a.max_active),
+                  "--min-active", str(a.min_active), "--workload", a.workload, "--paths", str(a.paths), "--mu", str(a.mu), "--sigma", str(a.sigma),
+                  "--max-tokens", str(a.max_tokens), "--arena-per-frame", str(a.arena_per_frame), "--lattice-beam", str(a.lattice_beam),
+                  "--prune-interval", str(a.prune_interval)]
+            if a.biglm:
+                wl += ["--biglm", "--lm-old", a.lm_old, "--lm-new", a.lm_new, "--lm-pairs", str(a.lm_pairs)]
+            if a.lattice_links > 0:
+                wl += ["--lattice-links", str(a.lattice_links), "--nbest", str(a.nbest)] + (["--determinize"] if a.determinize else [])
+            if a.default_limits:
+                wl += ["--default-limits"]
+            measured = measure_traffic(a, wl)
+            if measured is not None:
+                # (the passes run one channel group: a launch there covers the whole batch; per launch of THIS run = the same bytes
+                # over this run's launch count)
+                traffic = measured[0].get(dom, 0.0) * measured[1].get(dom, 0) / float(max(k_n, 1))
+                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this script (one step each, one channel "
+                               "group, kernels enqueued one by one, %.0f s), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch" % measured[2])
         step_ms = 1000.0 * dt / a.steps
         whole_bytes = sum(kb.values())
         out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                           "traffic_measured_in_run": measured is not None,
+                           "traffic_per_class": ({"bytes_per_launch": measured[0], "launches": measured[1]} if measured is not None else None),
                            "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
                            "kernel_ms_per_step": {k: prof[k + "_ms"] for k in ("expand", "insert", "closure")},
                            "all_kernels_achieved_GBs": (whole_bytes / (all_ms * 1e-3) / 1e9) if all_ms > 0 else 0.0,
@@ -1251,7 +1327,7 @@ def main():
         del ll_dev
         torch.cuda.empty_cache()
         n2 = max(2, a.steps // 5)
-        common = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "1", "--no-service-point", "--no-legs",
+        common = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "1", "--no-service-point", "--no-legs", "--no-traffic",
                   "--batch", str(B), "--frames", str(T), "--states", str(a.states), "--pdfs", str(P)]
         # the reference's own CPU path timed beside configs[3] and configs[4] (1 / 32 / all host threads): its biglm decoder
         # (kaldi-hclg-my-decoder-biglm.cc:80-102) and its lattice pipeline (decode, GetRawLattice, DeterminizeLatticeWrapper,

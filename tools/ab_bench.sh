@@ -6,7 +6,7 @@
 R="${GRAFT_REPO_ROOT:-$PWD}"
 cd "$R"
 mkdir -p gpurun_out/ab
-ARGS="${AB_ARGS:---steps 10 --warmup 3 --no-service-point --no-legs --cpu-sample 4 --no-cpu-baseline --max-tokens 65536}"
+ARGS="${AB_ARGS:---steps 10 --warmup 3 --no-service-point --no-traffic --no-legs --cpu-sample 4 --no-cpu-baseline --max-tokens 65536}"
 for rep in 1 2; do
   for v in "$@"; do
     tag="${v:-product}"

@@ -2,7 +2,7 @@
 # A/B on one box: the beam-15 lattice leg (no determinizer) with the raw frames of the back-pruning on several workgroups per
 # channel (default) and on one (debug 0x40000), library variant "ab" (built with -DWFST_AB_SWITCHES).
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R"; mkdir -p gpurun_out/ab
-ARGS="--beam 15 --lattice-beam 8 --lattice-links 25165824 --arena-per-frame 60000 --max-tokens 262144 --steps 4 --cpu-sample 2 --warmup 2 --no-service-point --no-legs --no-cpu-baseline"
+ARGS="--beam 15 --lattice-beam 8 --lattice-links 25165824 --arena-per-frame 60000 --max-tokens 262144 --steps 4 --cpu-sample 2 --warmup 2 --no-service-point --no-traffic --no-legs --no-cpu-baseline"
 for rep in 1 2; do
   for dbg in 0 262144; do
     WFST_LIB_VARIANT=ab timeout 150 python bench.py $ARGS --debug $dbg --detail-out gpurun_out/ab/prune_${dbg}_$rep.json > gpurun_out/ab/prune_${dbg}_$rep.line 2> gpurun_out/ab/prune_${dbg}_$rep.err || tail -3 gpurun_out/ab/prune_${dbg}_$rep.err

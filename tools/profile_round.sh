@@ -13,7 +13,7 @@ O="$R/gpurun_out/prof"
 rm -rf "$O"; mkdir -p "$O"
 export TMPDIR=/tmp
 cd "$R"
-COMMON="--groups 1 --cpu-sample 0 --no-service-point --no-legs"
+COMMON="--groups 1 --cpu-sample 0 --no-service-point --no-traffic --no-legs"
 declare -A CFG
 CFG[headline]=""
 CFG[biglm]="--biglm --max-tokens 131072"
@@ -25,7 +25,7 @@ for name in headline biglm lattice_beam15; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write_$name" -- python3 bench.py $COMMON ${CFG[$name]} --steps 1 --warmup 0 --no-hip-graph > "$O/bench_write_$name.json" 2> "$O/write_$name.err"
 done
 # the DEFAULT (two-group) headline run under the tracer, for the record
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_groups2" -- python3 bench.py --cpu-sample 0 --no-service-point --no-legs --steps 2 --warmup 1 > "$O/bench_kt_groups2.json" 2> "$O/kt_groups2.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_groups2" -- python3 bench.py --cpu-sample 0 --no-service-point --no-traffic --no-legs --steps 2 --warmup 1 > "$O/bench_kt_groups2.json" 2> "$O/kt_groups2.err"
 # reduce the per-dispatch files to per-kernel sums here (the merge-back is limited to 64 MiB)
 python3 - "$O" <<'PY'
 import collections, csv, glob, json, os, sys
