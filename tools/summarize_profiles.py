@@ -24,7 +24,7 @@ def klass(k):
         return "expand"
     if k.startswith("insert_kernel"):
         return "insert"
-    if k.startswith("closure_kernel") or k.startswith("lattice_prune_kernel"):
+    if k.startswith("closure_kernel") or k.startswith("lattice_prune"):
         return "closure"
     return None
 
