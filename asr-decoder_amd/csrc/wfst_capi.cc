@@ -217,6 +217,7 @@ struct wfst_decoder {
   void *det_pack_pin = nullptr;
   size_t det_pack_pin_bytes = 0;
   // wfst_decoder_prefetch_determinized: a determinize launch in flight on a side stream (its channels, its result words)
+  int stagger_us = 0;   // lattice decoders with several channel groups: group g starts its frame chain g x this many microseconds late
   bool pf_pending = false;
   bool pf_detached = false;           // the pending prefetch runs detached (wfst_decoder_prefetch_determinized_detached)
   std::vector<DetLattice> pf_cache;   // detached: the lattices of the last harvested prefetch, whatever the channels have gone on to
@@ -1114,6 +1115,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // (two candidates per thread in registers, rounds of 512) for those decoders; it is gone.  (Timing-experiment bits of
   // wfst_options.debug are honoured by WFST_AB_SWITCHES builds only.)
   const int ab_bits = kAbSwitches ? O.debug : 0;
+  d->stagger_us = (ab_bits & 0x80000) ? ((ab_bits >> 20) & 0xFF) * 100 : 0;   // (0x80000 + a count of 100 us in bits 20..27, A/B)
   D.prune_raw = (ab_bits & 0x40000) ? 0 : 1;   // (0x40000, A/B: the raw frames of a back-pruning pass on one workgroup per channel, as until round 4)
   D.staged = (D.fused && !big) ? 1 : 0;
   D.st_tile_tokens = O.tile_tokens & ~7;
@@ -1466,6 +1468,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
       for (int g = 1; g < G; ++g) {
         if (gsteps[g] == 0) continue;
         if (part == 1) HIP_TRY(hipStreamWaitEvent(d->gstreams[g], d->gevents[0], 0));
+        if (part == 1 && d->stagger_us > 0) launch_delay(g * d->stagger_us, d->gstreams[g]);
         const int rc = run_group(g, d->gstreams[g], part);
         if (rc != WFST_OK) return rc;
         if (part == 2) HIP_TRY(hipEventRecord(d->gevents[1 + g], d->gstreams[g]));

@@ -403,7 +403,7 @@ struct DetCaps;
 }  // namespace wfst
 #include "wfst_determinize.h"
 namespace wfst {
-constexpr int kPruneParInts = 48;   // ints of a channel's block of DecoderDev::prune_par
+constexpr int kPruneParInts = 64;   // ints of a channel's block of DecoderDev::prune_par
 
 struct DetDev {
   int32_t *ws;                  // [c][words_per_channel]: the lattice's CSR, then the determinizer's workspace
@@ -467,6 +467,7 @@ void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32
                     int group, int par, hipStream_t s);
 void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int group, int par, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
+void launch_delay(int microseconds, hipStream_t s);
 void launch_lattice_prune(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_lattice_emit(const DecoderDev &D, const int32_t *chan_list_dev, int n, int use_final, hipStream_t s);
 void launch_best_path(const DecoderDev &D, const int32_t *chan_list_dev, int n, int use_final,

@@ -2615,7 +2615,8 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
 // =========================================================================================
 constexpr int kPrLds = 16384;    // {extra, cost} pairs of the walk kept in LDS (128 KB): the frame being priced, and the frame after it where both fit
 constexpr int kPrChunk = 8192;   // items of one compaction sweep (kBT threads x 8)
-constexpr int kPrSlabs = 4;      // workgroups per channel of a compaction's flag sweeps (prune_flags)
+constexpr int kPrSlabs = 8;      // workgroups per channel of a compaction's flag sweeps (prune_flags; round 5: 4 -> 8)
+constexpr int kPrSlabBase = 40;  // their survivor counts in the channel's parameter block: [40, 40 + 2 x kPrSlabs)
 constexpr int kPrParInts = kPruneParInts;   // a channel's parameter block (DecoderDev::prune_par): [0, 16) the compaction's {run, c_lo, tokens lo / hi, frame-0 bound, links lo / hi, nd, slab counts}; [16, 32) lattice_emit's counters; then:
 constexpr int kPrRawCount = 32;  // ... and of the raw frames' launches: workgroups of the channel that have finished their share of the frame,
 constexpr int kPrRawChg = 34;    // [3]: "an extra moved" of an epsilon round, in rotation
@@ -3191,7 +3192,7 @@ __device__ __forceinline__ void prune_flags(const DecoderDev &D, int c, int g, S
       }
       cnt += tot;
     }
-    if (tid == 0) pp[8 + g] = cnt;
+    if (tid == 0) pp[kPrSlabBase + g] = cnt;
   }
   if (tid == 0 && g == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[44], now - tw); atomicAdd(&D.dbg_t[54], now - tw); tw = now; }
   {  // links of slab g
@@ -3216,7 +3217,7 @@ __device__ __forceinline__ void prune_flags(const DecoderDev &D, int c, int g, S
       }
       cnt += tot;
     }
-    if (tid == 0) pp[8 + kPrSlabs + g] = cnt;
+    if (tid == 0) pp[kPrSlabBase + kPrSlabs + g] = cnt;
   }
   if (tid == 0 && g == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[46], now - tw); atomicAdd(&D.dbg_t[54], now - tw); }
 }
@@ -3244,7 +3245,7 @@ __device__ __forceinline__ void prune_move(const DecoderDev &D, int c, int role,
   int tb[kPrSlabs + 1], lb[kPrSlabs + 1];
   tb[0] = 0; lb[0] = 0;
 #pragma unroll
-  for (int g = 0; g < kPrSlabs; ++g) { tb[g + 1] = tb[g] + pp[8 + g]; lb[g + 1] = lb[g] + pp[8 + kPrSlabs + g]; }
+  for (int g = 0; g < kPrSlabs; ++g) { tb[g + 1] = tb[g] + pp[kPrSlabBase + g]; lb[g + 1] = lb[g] + pp[kPrSlabBase + kPrSlabs + g]; }
   const int tsl = pr_slab_len(end - range_lo), lsl = pr_slab_len(l_end - l_lo);
   const int new_end = range_lo + tb[kPrSlabs], lnew = l_lo + lb[kPrSlabs];
   // new index of token i of the range (negative: dead, ~(survivors below it))
@@ -4456,6 +4457,15 @@ void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, 
   hipLaunchKernelGGL(lattice_prune_flags_kernel, dim3(chan_cnt * kPrSlabs), dim3(kBT), 0, s, D, chan_off);
   if (D.big) hipLaunchKernelGGL(lattice_prune_move_kernel<true>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
   else hipLaunchKernelGGL(lattice_prune_move_kernel<false>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
+}
+// A pause of `us` microseconds on a stream (one wave that sleeps): staggers the channel groups' frame chains against each other
+// (wfst_capi.cc advance_device).
+static __global__ void delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+void launch_delay(int us, hipStream_t s) {
+  if (us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)us * 100ull);   // (the constant 100 MHz clock)
 }
 void launch_set_finalized(const DecoderDev &D, const int32_t *chans, int n, hipStream_t s) {
   hipLaunchKernelGGL(set_finalized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, D, chans, n);

@@ -735,8 +735,11 @@ def main():
                 dec.sync()
             t4 = time.perf_counter()
             res = dec.best_paths(cap=2 * T + 64)
+            t4a = time.perf_counter()
             if a.lattice_links > 0:
                 nb = dec.nbest(a.nbest)
+                tb["nbest"] = tb.get("nbest", 0.0) + time.perf_counter() - t4a
+                tb["best_paths_only"] = tb.get("best_paths_only", 0.0) + t4a - t4
                 for r, paths in zip(res, nb):
                     r["nbest"] = paths
                 if a.determinize and a.pipeline_determinizer:
