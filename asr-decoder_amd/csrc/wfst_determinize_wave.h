@@ -218,7 +218,6 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
     }
     S.cur_slot[i] = (uint16_t)h;
   }
-  for (int i = lane; i < kDwCur; i += 64) S.mark_idx[i] = 0xFFFFu;
   DETW_SYNC();
   int nc = n, qh = 0, qn = n;
   bool over = false;
@@ -325,22 +324,24 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
     //      queue's order.
     const int use0 = use;
     const bool have0 = have;   // (as priced)
-    if (lane < use0) S.mark_idx[S.qidx[(qh + lane) & (kDwQueue - 1)]] = (uint16_t)lane;   // which entry of the window sits on cur[i]
-    DETW_SYNC();
-    int kill = use0;
-    if (have && tgt >= 0) {
-      const DetElem c = S.cur[tgt];
-      if (det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) != 1) have = false;   // (1)
-      else {
-        const int me = S.mark_idx[tgt];
-        if (me < use0 && me > en) kill = me;                                            // (2)
+    if (__ballot(have && tgt >= 0)) {   // (most windows only reach states new to the closure: nothing to look up then)
+      if (lane < use0) S.mark_idx[S.qidx[(qh + lane) & (kDwQueue - 1)]] = (uint16_t)lane;   // which entry of the window sits on cur[i]
+      DETW_SYNC();
+      int kill = use0;
+      if (have && tgt >= 0) {
+        const DetElem c = S.cur[tgt];
+        if (det_cmp(W, nx.w1, nx.w2, nx.str, c.w1, c.w2, c.str) != 1) have = false;   // (1)
+        else {
+          const int me = S.mark_idx[tgt];
+          if (me < use0 && me > en) kill = me;                                            // (2)
+        }
       }
+      for (int d = 32; d > 0; d >>= 1) kill = min(kill, __shfl_xor(kill, d, 64));
+      use = kill;
+      if (en >= use) have = false;
+      DETW_SYNC();
+      if (lane < use0) S.mark_idx[S.qidx[(qh + lane) & (kDwQueue - 1)]] = 0xFFFFu;
     }
-    for (int d = 32; d > 0; d >>= 1) kill = min(kill, __shfl_xor(kill, d, 64));
-    use = kill;
-    if (en >= use) have = false;
-    DETW_SYNC();
-    if (lane < use0) S.mark_idx[S.qidx[(qh + lane) & (kDwQueue - 1)]] = 0xFFFFu;
     // (3) the champion of every state that offers meet in
     bool mixed = false;
     {
@@ -497,6 +498,7 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid >= 64) return 0;
   long long t_clo = 0, t_pairs = 0, t_sub = 0, t_fin = 0, t0 = clock64();
+  for (int i = lane; i < kDwCur; i += 64) S.mark_idx[i] = 0xFFFFu;   // (every window puts its entries' marks back)
   if (lane == 0) {
     W.err = 0;
     W.tr_n = 1; W.tr_key[0] = kDetRootKey; W.tr_depth[0] = 0;

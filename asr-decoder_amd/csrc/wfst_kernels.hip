@@ -3617,7 +3617,8 @@ __device__ __forceinline__ bool prune_due(const DecoderDev &D, int c, const int3
 // ... and is its share of never-priced links large enough for the several-workgroup path (lattice_prune_raw_kernel) to pay?  Its
 // workgroups meet five times a frame; below a few hundred thousand links the one-workgroup walk in LDS is done sooner
 // (beam 13 of the bench: 12 k links a frame; beam 15: 45 k, 400 k in the heaviest channels).
-constexpr int kPrRawMinLinks = 400000;
+constexpr int kPrRawMinLinks = 800000;
+constexpr int kPrRawMaxJ = 32;        // workgroups a channel takes at most (a meeting of a hundred workgroups costs more than their shares save)
 __device__ __forceinline__ int prune_raw_links(const DecoderDev &D, int c) {
   const ChanCtl *cl = D.ctl + c;
   const int32_t *lo = D.link_off + (size_t)c * (D.max_frames + 3);
@@ -3703,7 +3704,7 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
       int b = 0;
       for (int q = 0; q < chan_cnt; ++q) {
         s_base[q] = b;
-        if (s_work[q]) b += 1 + (spare > 0 ? (int)((unsigned long long)spare * s_work[q] / tot) : 0);
+        if (s_work[q]) b += min(kPrRawMaxJ, 1 + (spare > 0 ? (int)((unsigned long long)spare * s_work[q] / tot) : 0));
       }
       s_base[chan_cnt] = b;
     }
