@@ -744,12 +744,12 @@ def main():
                     r["nbest"] = paths
                 if a.determinize and a.pipeline_determinizer:
                     if pipe["primed"]:   # the lattices of the step before (every step decodes the same utterances)
-                        for c, r in enumerate(res):
-                            r["det"] = dec.prefetched_lattice(c)
+                        for r, L in zip(res, dec.prefetched_lattices()):
+                            r["det"] = L
                     pipe["primed"] = True
                 elif a.determinize:
-                    for c, r in enumerate(res):
-                        r["det"] = dec.determinized_lattice(c)
+                    for r, L in zip(res, dec.determinized_lattices()):
+                        r["det"] = L
             t5 = time.perf_counter()
             for k, v in zip(("init", "advance_enqueue", "finalize", "sync", "best_paths"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 tb[k] += v
@@ -766,8 +766,8 @@ def main():
             """pipelined determinizer: the lattices of the LAST step, inside the timed region (K steps = K determinizations)"""
             if a.lattice_links > 0 and a.determinize and a.pipeline_determinizer and res is not None:
                 dec.harvest_prefetched()
-                for c, r in enumerate(res):
-                    r["det"] = dec.prefetched_lattice(c)
+                for r, L in zip(res, dec.prefetched_lattices()):
+                    r["det"] = L
 
         step.drain = drain
         return step

@@ -128,6 +128,12 @@ def test_mid_size_batch_and_refusals(synth, tmp_path):
             dist = nd
         sp = dist[D.st_final == 1].min()
         assert abs(sp - best[c]["tot_score"]) <= 1e-3 * abs(sp), c
+    # the binding's one-sweep fetch hands out the same lattices as the per-channel calls
+    for c, L in enumerate(dec.determinized_lattices()):
+        one = dec.determinized_lattice(c)
+        assert (L is None) == (one is None)
+        if L is not None:
+            assert L["n_states"] == one["n_states"] and all(np.array_equal(L[k], one[k]) for k in one if k != "n_states")
     assert dec.determinized_lattice(0, use_final_probs=False) is None   # finalized && !use_final_probs
     dec.free()
     # not in lattice mode: refused
