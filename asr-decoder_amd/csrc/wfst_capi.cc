@@ -1724,7 +1724,7 @@ int wfst_decoder_get_nbest(wfst_decoder *d, const int32_t *channels, int32_t n_c
     const int64_t budget = (int64_t)(4ll << 30) / ((int64_t)d->n_channels * 16 * (int64_t)sizeof(NbEntry));
     N.tok_cap = (int32_t)std::min<int64_t>(d->D.lat_tok_cap, std::min<int64_t>(262144, std::max<int64_t>(32768, budget)));
     N.arc_cap = (int32_t)std::min<int64_t>(d->D.lat_arc_cap, 4ll * N.tok_cap);
-    N.scratch_ints = 3ll * N.tok_cap + 1 + 3ll * (d->D.max_frames + 2) + N.arc_cap;
+    N.scratch_ints = (3ll * N.tok_cap + 1 + 3ll * (d->D.max_frames + 2) + 4ll * N.arc_cap + 3) & ~3ll;   // (nbest_kernel: in-arc records of 16 bytes first, a multiple of 16 bytes per channel)
     HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(d->nb_list.alloc((size_t)d->n_channels * (size_t)N.tok_cap * 16));
     HIP_TRY(d->nb_scratch.alloc((size_t)d->n_channels * (size_t)N.scratch_ints));

@@ -389,7 +389,7 @@ struct NbestDev {
   NbEntry *list;            // [c][tok_cap][K]
   int32_t *scratch;         // [c][scratch_ints]
   int32_t tok_cap, arc_cap, K;
-  int64_t scratch_ints;     // 3 * tok_cap + 1 + 2 * (max_frames + 2) + arc_cap
+  int64_t scratch_ints;     // 4 * arc_cap (in-arc records) + 3 * tok_cap + 1 + 3 * (max_frames + 2), rounded up to a multiple of 4
   int32_t *out_n;           // [cnt]      paths found, or -1: the lattice exceeds tok_cap / arc_cap
   int32_t *out_nwords;      // [cnt][n]
   int32_t *out_words;       // [cnt][n][max_words]

@@ -104,13 +104,15 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
   int32_t *state_of = D.remap + (size_t)c * D.arena_cap;  // arena index -> lattice state (scratch of the pruning passes, free between them)
   NbEntry *list = N.list + (size_t)c * N.tok_cap * K;
   int32_t *S = N.scratch + (size_t)c * N.scratch_ints;
-  int32_t *off = S;                        // [tok_cap + 1] start of a state's incoming arcs
+  // [arc_cap] the incoming arcs of a state, side by side, each with what the list building needs of it: {source state, word,
+  // graph, acoustic} -- one load where the arc index, the arc and the source token's state were three dependent ones (round 5)
+  int4 *in_rec = reinterpret_cast<int4 *>(S);   // (first in the block, which is a multiple of 16 bytes: aligned)
+  int32_t *off = S + 4 * (size_t)N.arc_cap; // [tok_cap + 1] start of a state's incoming arcs
   int32_t *cur = off + N.tok_cap + 1;      // [tok_cap]     fill cursor
   int32_t *cnt = cur + N.tok_cap;          // [tok_cap]     entries in a state's list
   int32_t *fbeg = cnt + N.tok_cap;         // [max_frames + 2] first state of a frame
   int32_t *fend = fbeg + D.max_frames + 2; // [max_frames + 2]
   int32_t *feps = fend + D.max_frames + 2; // [max_frames + 2] the frame has arcs between its own states (epsilon arcs)
-  int32_t *in_arcs = feps + D.max_frames + 2;  // [arc_cap]
   __shared__ int s_part[kNbThreads];
   __shared__ int s_changed;
   if (tid == 0) N.out_n[slot] = 0;
@@ -155,7 +157,10 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
     if (tid == 0) off[nt] = na;
   }
   __syncthreads();
-  for (int a = tid; a < na; a += kNbThreads) in_arcs[atomicAdd(&cur[state_of[arcs[a].dst_tok]], 1)] = a;
+  for (int a = tid; a < na; a += kNbThreads) {
+    const LatArc A = arcs[a];
+    in_rec[atomicAdd(&cur[state_of[A.dst_tok]], 1)] = make_int4(state_of[A.src_tok], A.olabel, __float_as_int(A.graph), __float_as_int(A.acoustic));
+  }
   __syncthreads();
   // ---- the start state --------------------------------------------------------------------
   const int root = state_of[0];  // the root token is arena entry 0; it survives every pruning
@@ -193,8 +198,7 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
             int wa = ai, we = ej, given = 0;
             // walk the arcs (uniform loop): arc wa contributes cnt[src] - we entries
             while (wa < a1 && given < 64 - K) {
-              const LatArc A = arcs[in_arcs[wa]];
-              const int src = state_of[A.src_tok];
+              const int src = in_rec[wa].x;
               const int have = cnt[src] - we;
               const int take = min(have, 64 - K - given);
               if (want >= given && want < given + take) { my_a = wa; my_e = we + (want - given); }
@@ -204,14 +208,15 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
             ai = wa; ej = we;
             more = wa < a1;
             if (my_a >= 0) {
-              const LatArc A = arcs[in_arcs[my_a]];
-              const int src = state_of[A.src_tok];
+              const int4 R = in_rec[my_a];
+              const int src = R.x;
+              const float a_graph = __int_as_float(R.z), a_ac = __int_as_float(R.w);
               const NbEntry E = list[(size_t)src * K + my_e];
-              cnd.tot = E.tot + (A.graph + A.acoustic);  // LatticeToVector: tot += graph + acoustic
-              cnd.lm = E.lm + A.graph;                   //                  lm  += graph
-              cnd.hash = A.olabel ? mix_word(E.hash, A.olabel) : E.hash;
+              cnd.tot = E.tot + (a_graph + a_ac);        // LatticeToVector: tot += graph + acoustic
+              cnd.lm = E.lm + a_graph;                   //                  lm  += graph
+              cnd.hash = R.y ? mix_word(E.hash, R.y) : E.hash;
               cnd.prev = src * 16 + my_e;
-              cnd.word = A.olabel;
+              cnd.word = R.y;
               cnd.valid = true;
             }
             found = select_distinct(cnd, K, &keep);
