@@ -48,6 +48,8 @@ struct DwShared {
   uint32_t sortk[kDwCur];
   DetElem offer[64];
   uint16_t claim[256];           // detw_succ_wave: who takes an empty trie slot
+  DetElem pair[64], psort[64];   // an output state's transition pairs (element, label) when there are at most 64: as made, then sorted by (label, state)
+  int32_t plabel[64], plsort[64];
   DetElem stage[64];             // a closure's (minimal) result of up to 64 elements, beside its copy in the workspace: what lane 0 normalizes,
   DetElem sub[64];               // hashes and compares next -- and the initial subset it came from -- read at LDS latency
   int32_t bc[16];                // lane 0 -> wave
@@ -492,6 +494,85 @@ __device__ inline int32_t detw_pairs(DetWs &W, int32_t out) {
   return m;
 }
 
+// detw_pairs() by the wave, for an output state of at most 64 elements with at most 64 labelled arcs between them (else lane 0
+// runs detw_pairs()): a lane per element reads its row, the successor strings are made side by side, the pairs land in LDS and are
+// ranked there.  Which of equal (label, state) pairs comes first does not matter: MakeSubsetUnique keeps the better one.
+// Returns the number of pairs; *in_lds: they are in S.psort / S.plsort (else in W.td / W.ta_label).
+__device__ inline int32_t detw_pairs_wave(DetWs &W, DwShared &S, int32_t out, int lane, bool *in_lds) {
+  const int32_t n = dw_ld(W.os_len + out), o0 = dw_ld(W.os_off + out);
+  DetElem el;
+  el.state = 0; el.str = 0; el.w1 = 0.0f; el.w2 = 0.0f;
+  int32_t a_lo = 0, cnt = 0;
+  bool fin = false;
+  if (n <= 64 && lane < n) {
+    el = dw_ld_elem(W.pool + o0 + lane);
+    fin = dw_ld(W.is_final + el.state) != 0;
+    a_lo = dw_ld(W.off + el.state) + dw_ld(W.neps + el.state);
+    cnt = dw_ld(W.off + el.state + 1) - a_lo;
+  }
+  int32_t tot = cnt, mx = cnt;
+  for (int d = 32; d > 0; d >>= 1) { tot += __shfl_xor(tot, d, 64); mx = max(mx, __shfl_xor(mx, d, 64)); }
+  if (n > 64 || tot > 64) {
+    if (lane == 0) S.bc[5] = detw_pairs(W, out);
+    DETW_SYNC();
+    *in_lds = false;
+    return S.bc[5];
+  }
+  // ProcessFinal (:1029-1060): the best final element, the first of equals
+  unsigned long long fm = __ballot(fin);
+  if (fm) {
+    int best = __ffsll((long long)fm) - 1;
+    float f1 = __shfl(el.w1, best, 64), f2 = __shfl(el.w2, best, 64);
+    int32_t fs = __shfl(el.str, best, 64);
+    for (unsigned long long mk = fm & (fm - 1); mk; mk &= mk - 1) {
+      const int k = __ffsll((long long)mk) - 1;
+      const float g1 = __shfl(el.w1, k, 64), g2 = __shfl(el.w2, k, 64);
+      const int32_t gs = __shfl(el.str, k, 64);
+      if (det_cmp(W, g1, g2, gs, f1, f2, fs) == 1) { f1 = g1; f2 = g2; fs = gs; }
+    }
+    if (lane == 0) det_add_arc(W, out, 0, -1, f1, f2);
+  }
+  // the labelled arcs of every element, arc j of each side by side
+  int32_t m = 0;
+  for (int32_t j = 0; j < mx; ++j) {
+    DetArc arc;
+    arc.ilabel = 0; arc.olabel = 0; arc.w1 = 0.0f; arc.w2 = 0.0f; arc.to = 0;
+    bool live = false;
+    if (j < cnt) {
+      arc = dw_ld_arc(W.arcs + a_lo + j);
+      live = arc.ilabel != 0 && !det_is_zero(arc.w1, arc.w2);
+    }
+    const int32_t ns = detw_succ_wave(W, S.claim, live && arc.olabel != 0, el.str, arc.olabel, lane);
+    const unsigned long long lm = __ballot(live);
+    if (live) {
+      DetElem nx;
+      nx.state = arc.to;
+      nx.w1 = el.w1 + arc.w1;
+      nx.w2 = el.w2 + arc.w2;
+      nx.str = arc.olabel != 0 ? ns : el.str;
+      const int pos = m + detw_rank(lm, lane);
+      S.pair[pos] = nx;
+      S.plabel[pos] = arc.ilabel;
+    }
+    m += __popcll(lm);
+  }
+  DETW_SYNC();
+  // rank by (label, state), ties by position
+  if (lane < m) {
+    const int32_t ml = S.plabel[lane], ms = S.pair[lane].state;
+    int r = 0;
+    for (int k = 0; k < m; ++k) {
+      const int32_t kl = S.plabel[k], ks = S.pair[k].state;
+      r += (kl < ml || (kl == ml && (ks < ms || (ks == ms && k < lane)))) ? 1 : 0;
+    }
+    S.psort[r] = S.pair[lane];
+    S.plsort[r] = ml;
+  }
+  DETW_SYNC();
+  *in_lds = true;
+  return m;
+}
+
 // The whole construction for one lattice, called by every thread of a workgroup (W carved, its tables cleared by det_init, a
 // barrier behind both); wave 0 runs it, the other waves return.  timers (may be null): clock64 sums of lane 0.
 __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
@@ -513,29 +594,29 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
     for (;;) {
       if (W.q_n <= 0 || W.err) break;
       long long c0 = clock64();
-      if (lane == 0) {
-        const int32_t o = W.queue[--W.q_n];
-        S.bc[4] = o;
-        S.bc[5] = detw_pairs(W, o);
-      }
+      if (lane == 0) S.bc[4] = W.queue[--W.q_n];
       DETW_SYNC();
-      const int32_t o = S.bc[4], mp = S.bc[5];
+      const int32_t o = S.bc[4];
+      bool pairs_lds = false;
+      const int32_t mp = detw_pairs_wave(W, S, o, lane, &pairs_lds);
+      const DetElem *pel = pairs_lds ? S.psort : W.td;
+      const int32_t *plab = pairs_lds ? S.plsort : W.ta_label;
       t_pairs += clock64() - c0;
       int32_t i = 0;
       while (i < mp && !W.err) {
         c0 = clock64();
         if (lane == 0) {
-          const int32_t ilabel = W.ta_label[i];
+          const int32_t ilabel = plab[i];
           int32_t run = 0;
-          while (i + run < mp && run <= 64 && W.ta_label[i + run] == ilabel) ++run;
+          while (i + run < mp && run <= 64 && plab[i + run] == ilabel) ++run;
           DetElem *sub = run <= 64 ? S.sub : W.te;   // (a handful of elements as a rule: kept in LDS)
           S.bc[13] = run <= 64 ? 1 : 0;
           int32_t k = 0;
-          while (i < mp && W.ta_label[i] == ilabel) {
-            DetElem cur = W.td[i];
+          while (i < mp && plab[i] == ilabel) {
+            DetElem cur = pel[i];
             ++i;
-            while (i < mp && W.ta_label[i] == ilabel && W.td[i].state == cur.state) {
-              const DetElem &x = W.td[i];
+            while (i < mp && plab[i] == ilabel && pel[i].state == cur.state) {
+              const DetElem x = pel[i];
               if (det_cmp(W, x.w1, x.w2, x.str, cur.w1, cur.w2, cur.str) == 1) { cur.w1 = x.w1; cur.w2 = x.w2; cur.str = x.str; }
               ++i;
             }
