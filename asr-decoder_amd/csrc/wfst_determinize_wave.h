@@ -118,14 +118,10 @@ __device__ inline int32_t detw_succ_wave(DetWs &W, uint16_t *claim /* [256] */, 
     DETW_SYNC();
   }
   const unsigned long long mk = __ballot(made != 0);
-  if (mk) {
+  if (mk && lane == 0) {   // (the count is lane 0's: nobody else reads it)
     const int n = W.tr_n + __popcll(mk);
-    DETW_SYNC();
-    if (lane == 0) {
-      W.tr_n = n;
-      if (n >= W.cap.trie || 2 * (int64_t)n >= W.tr_hcap) W.err = 1;   // (the table stays at most half full; 1: the trie)
-    }
-    DETW_SYNC();
+    W.tr_n = n;
+    if (n >= W.cap.trie || 2 * (int64_t)n >= W.tr_hcap) W.err = 1;   // (the table stays at most half full; 1: the trie)
   }
   return ans;
 }
@@ -346,7 +342,7 @@ __device__ inline int detw_closure(DetWs &W, DwShared &S, DetElem *e, int n, int
     }
     // (3) the champion of every state that offers meet in
     bool mixed = false;
-    {
+    if (__popcll(__ballot(have)) > 1) {   // (a single offer meets nobody)
       bool cand = have;
       uint16_t *mk = tgt >= 0 ? &S.mark_best[tgt] : &S.mark_slot[-1 - tgt];
       for (int round = 0; round < 64; ++round) {
@@ -573,6 +569,80 @@ __device__ inline int32_t detw_pairs_wave(DetWs &W, DwShared &S, int32_t out, in
   return m;
 }
 
+// NormalizeSubset (:1219-1252) of e[0..k), k <= 64, by the wave -- a lane per element: the best weight (the first of equals), the
+// longest common prefix of the strings (every lane walks its own string up to the shallowest one's depth, then all walk together
+// until they stand on one node), the weights divided, the prefix taken off every string (its remaining labels collected on the way
+// up, the new string made label by label, all lanes side by side).  The same values as det_normalize(); what was (k - 1) walks one
+// after the other is one walk.  Strings with more than kDwLabs labels left: lane 0 runs det_normalize().
+constexpr int kDwLabs = 128;
+__device__ inline void detw_normalize_wave(DetWs &W, DwShared &S, DetElem *e, int k, int lane, float *t1, float *t2, int32_t *common) {
+  const float inf = __builtin_huge_valf();
+  if (k == 0) { *common = 0; *t1 = inf; *t2 = inf; return; }
+  const bool on = lane < k;
+  DetElem x;
+  x.state = 0; x.str = 0; x.w1 = inf; x.w2 = inf;
+  if (on) x = e[lane];
+  // Plus (:303-308) over the elements in order: the first of the best
+  float b1 = x.w1, b2 = x.w2;
+  int bi = on ? lane : 64;
+  for (int d = 32; d > 0; d >>= 1) {
+    const float o1 = __shfl_xor(b1, d, 64), o2 = __shfl_xor(b2, d, 64);
+    const int oi = __shfl_xor(bi, d, 64);
+    const int c = (bi >= 64) ? -1 : (oi >= 64) ? 1 : det_wcmp(b1, b2, o1, o2);
+    if (c == -1 || (c == 0 && oi < bi)) { b1 = o1; b2 = o2; bi = oi; }
+  }
+  // the strings' lowest common ancestor
+  int32_t node = x.str;
+  const int32_t dep0 = on ? dw_ld(W.tr_depth + node) : 0x7FFFFFFF;
+  int32_t dmin = dep0;
+  for (int d = 32; d > 0; d >>= 1) dmin = min(dmin, __shfl_xor(dmin, d, 64));
+  int32_t dep = dep0;
+  for (;;) {
+    const bool up = on && dep > dmin;
+    if (!__ballot(up)) break;
+    if (up) { node = (int32_t)(uint32_t)(*(const DW_G(uint64_t) *)(W.tr_key + node)); --dep; }
+  }
+  int32_t plen = dmin;
+  for (;;) {
+    const int32_t first = __builtin_amdgcn_readfirstlane(node);   // (lane 0 is on: k >= 1)
+    if (!__ballot(on && node != first)) break;
+    if (on) node = (int32_t)(uint32_t)(*(const DW_G(uint64_t) *)(W.tr_key + node));
+    --plen;
+  }
+  const int32_t pre = __builtin_amdgcn_readfirstlane(node);
+  // the prefix off every string
+  int32_t left = on ? dep0 - plen : 0, mx = left;
+  for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+  if (plen > 0 && mx > kDwLabs) {   // (a string too long for a lane's label buffer: the sequential way, from the untouched elements)
+    if (lane == 0) { det_normalize(W, e, k, t1, t2, common); S.bc[14] = __float_as_int(*t1); S.bc[15] = __float_as_int(*t2); S.bc[3] = *common; }
+    DETW_SYNC();
+    *t1 = __int_as_float(S.bc[14]); *t2 = __int_as_float(S.bc[15]); *common = S.bc[3];
+    return;
+  }
+  if (on) det_divide(x.w1, x.w2, b1, b2);
+  if (plen > 0) {
+    int32_t *labs = W.labs + lane * kDwLabs;
+    int32_t nd = x.str;
+    for (int32_t t = 0; t < mx; ++t)
+      if (t < left) {
+        const uint64_t kk = *(const DW_G(uint64_t) *)(W.tr_key + nd);
+        dw_st(labs + (left - 1 - t), (int32_t)(uint32_t)(kk >> 32));
+        nd = (int32_t)(uint32_t)kk;
+      }
+    int32_t cur = 0;
+    for (int32_t j = 0; j < mx; ++j) {
+      const bool need = on && j < left;
+      const int32_t lab = need ? dw_ld(labs + j) : 0;
+      const int32_t r = detw_succ_wave(W, S.claim, need, cur, lab, lane);
+      if (need) cur = r;
+    }
+    x.str = cur;
+  }
+  if (on) e[lane] = x;
+  DETW_SYNC();
+  *t1 = b1; *t2 = b2; *common = pre;
+}
+
 // The whole construction for one lattice, called by every thread of a workgroup (W carved, its tables cleared by det_init, a
 // barrier behind both); wave 0 runs it, the other waves return.  timers (may be null): clock64 sums of lane 0.
 __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
@@ -612,6 +682,7 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
           DetElem *sub = run <= 64 ? S.sub : W.te;   // (a handful of elements as a rule: kept in LDS)
           S.bc[13] = run <= 64 ? 1 : 0;
           int32_t k = 0;
+          // MakeSubsetUnique (:1184-1216): the elements of one state merged, the better (weight, string) kept
           while (i < mp && plab[i] == ilabel) {
             DetElem cur = pel[i];
             ++i;
@@ -622,22 +693,31 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
             }
             sub[k++] = cur;
           }
+          S.bc[6] = i; S.bc[8] = k; S.bc[9] = ilabel;
+        }
+        DETW_SYNC();
+        {
+          const int32_t k = S.bc[8];
+          DetElem *sub = S.bc[13] ? S.sub : W.te;
           float t1, t2;
           int32_t common;
-          det_normalize(W, sub, k, &t1, &t2, &common);
-          // InitialToStateId, first half: the look-up
-          const uint32_t b = det_subset_hash(sub, k) & ((uint32_t)W.ih_hcap - 1u);
-          int32_t found = -1;
-          for (int32_t q = W.ih_head[b]; q >= 0; q = W.ih_next[q])
-            if (det_subset_equal(sub, k, W.pool + W.ih_off[q], W.ih_len[q], W.delta)) { found = q; break; }
-          if (found >= 0) {
-            det_add_arc(W, o, ilabel, W.ih_state[found], t1 + W.ih_w1[found], t2 + W.ih_w2[found]);
-          } else {
-            if (k > W.cap.tmp) W.err = 6;
-            for (int32_t q = 0; q < k && !W.err; ++q) W.ta[q] = sub[q];
+          if (k <= 64) detw_normalize_wave(W, S, sub, k, lane, &t1, &t2, &common);
+          else if (lane == 0) det_normalize(W, sub, k, &t1, &t2, &common);
+          if (lane == 0) {
+            // InitialToStateId, first half: the look-up
+            const uint32_t b = det_subset_hash(sub, k) & ((uint32_t)W.ih_hcap - 1u);
+            int32_t found = -1;
+            for (int32_t q = W.ih_head[b]; q >= 0; q = W.ih_next[q])
+              if (det_subset_equal(sub, k, W.pool + W.ih_off[q], W.ih_len[q], W.delta)) { found = q; break; }
+            if (found >= 0) {
+              det_add_arc(W, o, S.bc[9], W.ih_state[found], t1 + W.ih_w1[found], t2 + W.ih_w2[found]);
+            } else {
+              if (k > W.cap.tmp) W.err = 6;
+              for (int32_t q = 0; q < k && !W.err; ++q) W.ta[q] = sub[q];
+            }
+            S.bc[7] = found; S.bc[10] = (int32_t)b;
+            S.bc[11] = __float_as_int(t1); S.bc[12] = __float_as_int(t2);
           }
-          S.bc[6] = i; S.bc[7] = found; S.bc[8] = k; S.bc[9] = ilabel; S.bc[10] = (int32_t)b;
-          S.bc[11] = __float_as_int(t1); S.bc[12] = __float_as_int(t2);
         }
         DETW_SYNC();
         i = S.bc[6];
@@ -648,13 +728,16 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
           const int m2 = detw_closure_any(W, S, W.ta, k, lane, true);   // (the closure, already minimal)
           t_clo += clock64() - c0;
           c0 = clock64();
+          DetElem *s = m2 <= 64 ? S.stage : W.ta;   // (the closure left its result in both)
+          float w1 = 0.0f, w2 = 0.0f;
+          int32_t str = 0;
+          if (!W.err) {
+            if (m2 <= 64) detw_normalize_wave(W, S, s, m2, lane, &w1, &w2, &str);
+            else if (lane == 0) det_normalize(W, s, m2, &w1, &w2, &str);
+          }
           if (lane == 0 && !W.err) {
             // InitialToStateId, second half
-            DetElem *s = m2 <= 64 ? S.stage : W.ta;   // (the closure left its result in both)
             DetElem *sub = S.bc[13] ? S.sub : W.te;
-            float w1, w2;
-            int32_t str;
-            det_normalize(W, s, m2, &w1, &w2, &str);
             const int32_t ans = det_minimal_to_state(W, s, m2, true);
             if (W.ih_n >= W.cap.initials) W.err = 4;
             else {
