@@ -30,10 +30,22 @@
 
 namespace wfst {
 
-constexpr int kDwCur = 1024;     // closure elements held in LDS
-constexpr int kDwQueue = 1024;   // FIFO ring
+// (the sizes can be shrunk at compile time -- tests/test_gpu_detwave_stress.py builds the harness with tiny ones so that every
+// fall-back runs on ordinary lattices: closures that outgrow LDS, entries with more arcs than a window prices, strings longer than a
+// lane's label buffer)
+#ifndef DETW_CUR
+#define DETW_CUR 1024
+#endif
+#ifndef DETW_ARCS
+#define DETW_ARCS 4
+#endif
+#ifndef DETW_LABS
+#define DETW_LABS 128
+#endif
+constexpr int kDwCur = DETW_CUR;     // closure elements held in LDS (a power of two, at most 1024: the sort keys carry the index in 10 bits)
+constexpr int kDwQueue = DETW_CUR;   // FIFO ring
 constexpr int kDwMap = 2048;     // state -> element index, open addressing
-constexpr int kDwArcs = 4;       // epsilon arcs priced per entry in a window (an entry with more is priced alone, a lane per arc)
+constexpr int kDwArcs = DETW_ARCS;   // epsilon arcs priced per entry in a window (an entry with more is priced alone, a lane per arc); 1, 2 or 4
 constexpr int kDwWin = 64 / kDwArcs;   // queue entries priced side by side
 
 struct DwShared {
@@ -574,7 +586,7 @@ __device__ inline int32_t detw_pairs_wave(DetWs &W, DwShared &S, int32_t out, in
 // until they stand on one node), the weights divided, the prefix taken off every string (its remaining labels collected on the way
 // up, the new string made label by label, all lanes side by side).  The same values as det_normalize(); what was (k - 1) walks one
 // after the other is one walk.  Strings with more than kDwLabs labels left: lane 0 runs det_normalize().
-constexpr int kDwLabs = 128;
+constexpr int kDwLabs = DETW_LABS;
 __device__ inline void detw_normalize_wave(DetWs &W, DwShared &S, DetElem *e, int k, int lane, float *t1, float *t2, int32_t *common) {
   const float inf = __builtin_huge_valf();
   if (k == 0) { *common = 0; *t1 = inf; *t2 = inf; return; }
@@ -762,26 +774,39 @@ __device__ inline int detw_run(DetWs &W, DwShared &S, long long *timers) {
   return W.err;
 }
 
-// (the development harness, tools/det_bench.hip) carve + init + run for one lattice, by a 256-thread workgroup
+// (the development harness, tools/det_bench.hip) carve + init + run for one lattice, by a 256-thread workgroup -- as determinize_kernel
+// does it: the trie's table first at 16 slots per raw state, the whole table if that is outgrown
 __device__ inline void detw_run_block(const int32_t *off, const DetArc *arcs, const int32_t *fin, int32_t n_states, int32_t n_arcs,
                                       int32_t *ws, const DetCaps &caps, DetOutArc *out, int32_t *res, long long *timers, int variant) {
   __shared__ DetWs W;
   __shared__ DwShared S;
+  __shared__ int s_err;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) {
     W.n_states = n_states; W.n_arcs = n_arcs; W.off = off; W.arcs = arcs; W.is_final = fin; W.delta = 1.0f / 1024;
     det_carve(W, ws, caps, n_states);
-    int32_t h = 4096;
-    while (h < 16 * n_states && h < W.tr_hcap) h <<= 1;
-    W.tr_hcap = h < W.tr_hcap ? h : W.tr_hcap;
   }
   for (int i = tid; i < kDwMap; i += blockDim.x) S.map[i] = 0u;
   if (tid < 16) S.tm[tid] = 0;
   __syncthreads();
-  det_init(W, tid, blockDim.x);
-  __syncthreads();
+  const int32_t hcap_full = W.tr_hcap;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (tid == 0) {
+      int32_t h = hcap_full;
+      if (attempt == 0) { h = 4096; while (h < 16 * n_states && h < hcap_full) h <<= 1; }
+      W.tr_hcap = h < hcap_full ? h : hcap_full;
+    }
+    __syncthreads();
+    det_init(W, tid, blockDim.x);
+    __syncthreads();
+    {
+      const int e = detw_run(W, S, timers);
+      if (tid == 0) s_err = e;
+    }
+    __syncthreads();
+    if (!(s_err == 1 && W.tr_hcap < hcap_full)) break;
+  }
   if (tid >= 64) return;
-  detw_run(W, S, timers);
   if (lane == 0) { res[0] = W.os_n; res[1] = W.oa_n; res[2] = W.err; res[3] = W.tr_n; }
   if (out) {
     const int32_t na = W.oa_n < caps.arcs ? W.oa_n : caps.arcs;
