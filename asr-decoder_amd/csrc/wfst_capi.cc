@@ -1116,6 +1116,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // wfst_options.debug are honoured by WFST_AB_SWITCHES builds only.)
   const int ab_bits = kAbSwitches ? O.debug : 0;
   d->stagger_us = (ab_bits & 0x80000) ? ((ab_bits >> 20) & 0xFF) * 100 : 0;   // (0x80000 + a count of 100 us in bits 20..27, A/B)
+  D.prune_raw_min = (O.debug & 0x800) ? 0 : 800000;   // (below: the one-workgroup walk in LDS is done sooner -- beam 13 of the bench; 0x800: the tests' switch)
   D.prune_raw = (ab_bits & 0x40000) ? 0 : 1;   // (0x40000, A/B: the raw frames of a back-pruning pass on one workgroup per channel, as until round 4)
   D.staged = (D.fused && !big) ? 1 : 0;
   D.st_tile_tokens = O.tile_tokens & ~7;

@@ -276,6 +276,7 @@ struct DecoderDev {
   float *cutoff_hist;
   int4 *bucket;
   int32_t *bucket_cnt;
+  int32_t prune_raw_min; // ... for channels with at least this many never-priced links (wfst_options.debug 0x800: 0, every channel)
   int32_t prune_raw;     // lattice mode: a running back-pruning pass prices its raw frames with several workgroups per channel (wfst_kernels.hip: lattice_prune_raw_*)
   int32_t *prune_par;    // [c][kPruneParInts]: lattice mode -- what a running back-pruning pass hands to its compaction launches (wfst_kernels.hip: kPrParInts)
   int32_t *emit_cnt;     // [c][32] (a line each): lattice mode on the fused rows -- entries of the channel's emitter list (the tokens of the

@@ -3616,8 +3616,7 @@ __device__ __forceinline__ bool prune_due(const DecoderDev &D, int c, const int3
 }
 // ... and is its share of never-priced links large enough for the several-workgroup path (lattice_prune_raw_kernel) to pay?  Its
 // workgroups meet five times a frame; below a few hundred thousand links the one-workgroup walk in LDS is done sooner
-// (beam 13 of the bench: 12 k links a frame; beam 15: 45 k, 400 k in the heaviest channels).
-constexpr int kPrRawMinLinks = 800000;
+// (beam 13 of the bench: 12 k links a frame; beam 15: 45 k, 400 k in the heaviest channels): DecoderDev::prune_raw_min.
 constexpr int kPrRawMaxJ = 32;        // workgroups a channel takes at most (a meeting of a hundred workgroups costs more than their shares save)
 __device__ __forceinline__ int prune_raw_links(const DecoderDev &D, int c) {
   const ChanCtl *cl = D.ctl + c;
@@ -3626,7 +3625,7 @@ __device__ __forceinline__ int prune_raw_links(const DecoderDev &D, int c) {
   return max(0, lo[cl->n_decoded + 1] - lo[a < cl->n_decoded ? a + 1 : cl->n_decoded]);
 }
 __device__ __forceinline__ bool prune_due_raw(const DecoderDev &D, int c, const int32_t *target) {
-  return prune_due(D, c, target) && prune_raw_links(D, c) >= kPrRawMinLinks;
+  return prune_due(D, c, target) && prune_raw_links(D, c) >= D.prune_raw_min;
 }
 template <bool kBig>
 __global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const int32_t *target, int chan_off, int group, int par, int raw) {

@@ -126,6 +126,9 @@ typedef struct wfst_options {
                                   decoder is freed)                                              (0)    */
                                /* (0x1000: lattice decoders run the iterated epsilon-closure pass instead of
                                   the fused rows + flat epsilon-link pass; same results, for comparison.
+                                  0x800: a running back-pruning pass prices the never-priced frames of EVERY
+                                  channel on several workgroups (by default only channels with 800 k such links
+                                  or more: the LDS walk is faster below); same results, for the tests.
                                   Further bits are A/B switches of timing experiments, honoured only by a
                                   library built with -DWFST_AB_SWITCHES) */
 } wfst_options;

@@ -41,8 +41,11 @@ def _same_lattice(L, O, what):
     assert np.array_equal(L.labelled_arcs(), O.labelled_arcs()), what + " arcs"
 
 
+@pytest.mark.parametrize("raw_pass", [False, True])
 @pytest.mark.parametrize("prune_scale", [1e-9, 0.1])
-def test_mid_utterance_raw_lattice(prune_scale, synth, oracle, tmp_path):
+def test_mid_utterance_raw_lattice(prune_scale, raw_pass, synth, oracle, tmp_path):
+    """raw_pass: wfst_options.debug 0x800 -- the never-priced frames of EVERY channel go through lattice_prune_raw_kernel (several
+    workgroups per channel, meetings at a counter), which by default only channels with 800 k such links take; same lattices."""
     from test_gpu_lattice import as_raw
 
     G, g, m, path, graph = _setup(synth, tmp_path)
@@ -50,7 +53,8 @@ def test_mid_utterance_raw_lattice(prune_scale, synth, oracle, tmp_path):
     T = [97, 64, 97, 31]
     mats = [synth.make_loglikes(g, t, 1000, m, seed=40 + i, mu=-2.3)[0] for i, t in enumerate(T)]
     dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), max_frames=128, max_tokens_per_frame=32768,
-                                 arena_tokens=1 << 20, lattice_links=1 << 21)
+                                 arena_tokens=1 << 20, lattice_links=1 << 21,
+                                 options=G.wfstdec.Options(debug=0x800) if raw_pass else None)
     dev = G.upload(mats)
     dec.init()
     h = oracle.load_graph(path)
