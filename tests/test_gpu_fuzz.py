@@ -68,7 +68,10 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         mats = [rng.normal(-1.5, 1.0, size=(T, n_labels + 1)).astype(np.float32) for T in lens]
         # the lattice-mode decoder: fused closures + the flat epsilon-link pass on even cases, the iterated closure pass
         # (wfst_options.debug 0x1000; what graphs without fused rows and the biglm decoder run) on odd ones
-        lat_opt = {} if case % 2 == 0 else {"options": G.wfstdec.Options(debug=0x1000)}
+        # ... and on every third case the back-pruning's several-workgroup pass for every channel (debug 0x800: the raw frames of a
+        # running pass priced by workgroups that meet at a counter -- by default only very heavy channels take it)
+        dbg = (0x1000 if case % 2 else 0) | (0x800 if case % 3 == 0 else 0)
+        lat_opt = {"options": G.wfstdec.Options(debug=dbg)} if dbg else {}
         dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), max_frames=64, max_tokens_per_frame=4096,
                                      arena_tokens=1 << 16, lattice_links=1 << 18, **lat_opt)
         dev = G.upload(mats)
