@@ -1343,7 +1343,7 @@ def main():
                 # ... at lattice_beam 7 the reference's biglm final pruning (biglm.h:186-188) leaves 45 of the 128 utterances a path; at 14,
                 # 121 of them: the same search (the beam is what it costs), a result for nearly every utterance
                 "biglm_lattice_beam14": ["--biglm", "--lattice-beam", "14", "--steps", str(max(6, n2)), "--cpu-sample", "8", "--max-tokens", "131072"] + cpu_off,
-                "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2", "--postprocess"] + cpu_off,
+                "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2", "--postprocess"] + cpu_on,
                 "lattice_beam15_no_determinizer": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
                                                    "--max-tokens", "262144", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "2", "--warmup", "2"] + cpu_off,
                 "lattice_beam15": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
@@ -1370,6 +1370,11 @@ def main():
             except Exception as e:  # a leg that fails is reported, not hidden
                 L[name] = {"error": repr(e), "stderr_tail": pr.stderr.decode()[-600:] if pr is not None else ""}
             log("[rank 0] leg %s: %.1fs" % (name, time.time() - t0))
+        # legs that run the CPU's workload of another leg carry that leg's baseline (the reference decodes the same utterances at the same
+        # beams: it has no pipelining to switch on, and its biglm search does not depend on lattice_beam)
+        for name, sib in (("biglm_lattice_beam14", "biglm"), ("lattice_beam15_no_determinizer", "lattice_beam15"), ("lattice_beam15_pipelined", "lattice_beam15")):
+            if name in L and sib in L and "cpu_baseline" not in L[name] and "cpu_baseline" in L[sib]:
+                L[name]["cpu_baseline"] = dict(L[sib]["cpu_baseline"], measured_in_leg=sib)
     if rank == 0:
         # the full result to bench_detail.json, its summary -- strict JSON under 4 KB, scalars only -- as the ONE stdout line
         where = write_detail(out, a.detail_out)
