@@ -1117,6 +1117,9 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   const int ab_bits = kAbSwitches ? O.debug : 0;
   d->stagger_us = (ab_bits & 0x80000) ? ((ab_bits >> 20) & 0xFF) * 100 : 0;   // (0x80000 + a count of 100 us in bits 20..27, A/B)
   D.prune_raw_min = (O.debug & 0x800) ? 0 : 800000;   // (below: the one-workgroup walk in LDS is done sooner -- beam 13 of the bench; 0x800: the tests' switch)
+  // closure launches of a lattice decoder on the fused rows: workgroups per channel (they share the frame's epsilon links; a heavy
+  // channel's frame is a dozen sweeps for one workgroup).  wfst_options.debug 0x100 / 0x200 / 0x300: 1 / 2 / 8 of them, for the tests
+  { static const int kSlabs[4] = {4, 1, 2, 8}; D.closure_slabs = kSlabs[(O.debug >> 8) & 3]; }
   D.prune_raw = (ab_bits & 0x40000) ? 0 : 1;   // (0x40000, A/B: the raw frames of a back-pruning pass on one workgroup per channel, as until round 4)
   D.staged = (D.fused && !big) ? 1 : 0;
   D.st_tile_tokens = O.tile_tokens & ~7;
@@ -1400,7 +1403,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (s_lo == 0) {
       // GetCutoff + tile list only -- behind PruneActiveTokens where the call before this one stopped at a multiple of prune_interval
       if (prune_step(g, -1)) timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par, st); });
-      else timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st); });
+      else timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st, 0); });
     }
     for (int s = s_lo; s < s_hi; ++s) {
       // two launches per frame where the decoder allows (wfst_device.h two_launch): the insert launch closes the frame and
@@ -1412,7 +1415,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
       // lattice mode: PruneActiveTokens (base-inl.h:660-661) on the steps at which a channel of the group reaches a multiple of
       // prune_interval and goes on decoding -- a launch of its own, which also prepares the next frame
       const bool prune = more && prune_step(g, s);
-      if (classic) timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, more && !prune, g, par ^ 1, st); });
+      if (classic) timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, more && !prune, g, par ^ 1, st, 1); });
       if (prune) timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par ^ 1, st); });
       par ^= 1;
     }

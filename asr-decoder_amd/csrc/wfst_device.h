@@ -277,6 +277,7 @@ struct DecoderDev {
   int4 *bucket;
   int32_t *bucket_cnt;
   int32_t prune_raw_min; // ... for channels with at least this many never-priced links (wfst_options.debug 0x800: 0, every channel)
+  int32_t closure_slabs; // lattice decoders on the fused rows: workgroups per channel of a closure launch (they share the frame's epsilon links)
   int32_t prune_raw;     // lattice mode: a running back-pruning pass prices its raw frames with several workgroups per channel (wfst_kernels.hip: lattice_prune_raw_*)
   int32_t *prune_par;    // [c][kPruneParInts]: lattice mode -- what a running back-pruning pass hands to its compaction launches (wfst_kernels.hip: kPrParInts)
   int32_t *emit_cnt;     // [c][32] (a line each): lattice mode on the fused rows -- entries of the channel's emitter list (the tokens of the
@@ -405,6 +406,7 @@ struct DetCaps;
 #include "wfst_determinize.h"
 namespace wfst {
 constexpr int kPruneParInts = 64;   // ints of a channel's block of DecoderDev::prune_par
+constexpr int kClSlabWord = 60;     // ... of which [60, 62), one 64-bit word: the closure launch's meeting of a channel's workgroups (finalize_frame)
 
 struct DetDev {
   int32_t *ws;                  // [c][words_per_channel]: the lattice's CSR, then the determinizer's workspace
@@ -464,8 +466,9 @@ void launch_expand(const DecoderDev &D, int group, int par, int n_workgroups, hi
 // (two-launch frame); 2 = closes the frame only (last frame of an advance call)
 void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int boundary, int group, int par,
                    int n_workgroups, hipStream_t s);
+// after_insert: the launch closes a frame an insert launch has just built (DecoderDev::closure_slabs workgroups per channel then)
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int do_prep,
-                    int group, int par, hipStream_t s);
+                    int group, int par, hipStream_t s, int after_insert);
 void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int group, int par, hipStream_t s);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_delay(int microseconds, hipStream_t s);

@@ -1678,6 +1678,9 @@ struct BoundaryShared {
   int occ;        // epsilon-table entries touched this frame (continues ChanCtl::eps_occ)
   int nwon;       // tokens won by an epsilon arc this frame
   int nemit;      // lattice mode: tokens of the frame that emit epsilon links
+  int nlinks;     // lattice mode: epsilon links this workgroup appended (epsilon_links)
+  int last;       // closure launches with several workgroups per channel: this one is the last to finish its share
+  int eps_total;  // ... and then: the epsilon links all of them appended
   float redf[kBW];
   u64 red64[kBW];
   u64 best;
@@ -1691,7 +1694,11 @@ struct BoundaryShared {
 // frame has its final cost -- after the closure's fixpoint, or, with fused closures, right after the insert launch.
 // toki[] = the channel's direct-mapped epsilon table: the frame's token on each epsilon-target state.
 template <bool kBig = false>
-__device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, bool listed = false) {
+__device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, BoundaryShared &sh, int base, float cutoff, bool listed = false,
+                                              int slab = 0, int n_slabs = 1) {
+  // slab / n_slabs: the launch runs n_slabs workgroups per channel (closure_kernel on the fused rows of a lattice decoder: a heavy
+  // channel's frame lists ten thousand emitters, a chain of a dozen sweeps on one workgroup while the other channels' are done
+  // after one); this one takes share `slab` of the listed emitters and counts its links into sh.nlinks
   const int tid = threadIdx.x;
   // biglm: a token is (row, LM pair); an epsilon arc with a word label moves the LM (biglm.h:448-456), the link's cost carries
   // the LM difference, and the destination's token is found in the channel's HASHED epsilon table (keys beside toki[])
@@ -1712,6 +1719,9 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
   if (listed && D.emit_cnt[c * 32] <= 8 * D.wl_cap) {
     n_emit = D.emit_cnt[c * 32];
   } else {
+    // (the list overflowed -- never seen --: the sweep below rebuilds it in the channel's worklist space, the work of ONE workgroup)
+    if (slab != 0) return;
+    n_slabs = 1;
     if (tid == 0) sh.nemit = 0;
     __syncthreads();
     for (int i0 = 0; i0 < n_frame; i0 += 4 * kBT) {  // 4 independent loads in flight per thread
@@ -1735,7 +1745,9 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
     __syncthreads();
     n_emit = sh.nemit;
   }
-  for (int j0 = 0; j0 < n_emit; j0 += kBT) {
+  // (equal shares of whole waves, however short the list: one path through the launch for light and heavy channels alike)
+  const int share = ((n_emit + n_slabs - 1) / n_slabs + 63) & ~63, j_lo = min(n_emit, slab * share), j_hi = min(n_emit, j_lo + share);
+  for (int j0 = j_lo; j0 < j_hi; j0 += kBT) {
     const int j = j0 + tid;
     int idx = -1, row = 0, neps = 0, npass = 0;
     float cost = 0.0f;
@@ -1761,7 +1773,7 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
     // two epsilon arcs nearly always): token -> {header, arcs} -> destination tokens -> links, four round trips
     constexpr int kSpec = kBig ? 1 : 3;
     int4 A[kSpec];
-    if (j < n_emit) idx = emit[j];
+    if (j < j_hi) idx = emit[j];
     if (idx >= 0) {
       const int4 T = tok[idx];
       row = T.x;
@@ -1780,7 +1792,7 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
     int ps = wave_incl_scan(npass);
     const int wtot = __builtin_amdgcn_readlane(ps, 63);
     int lb = 0;
-    if ((tid & 63) == 0 && wtot) lb = atomicAdd(&D.ctl[c].link_count, wtot);
+    if ((tid & 63) == 0 && wtot) { lb = atomicAdd(&D.ctl[c].link_count, wtot); atomicAdd(&sh.nlinks, wtot); }
     lb = __shfl(lb, 0, 64);
     int lp = lb + ps - npass;
     for (int e = 0; e < neps && npass; ++e) {
@@ -2082,26 +2094,32 @@ __device__ __forceinline__ void epsilon_closure(const DecoderDev &D, int c, Boun
   if (tid == 0) dbg_phase(D, 3, tq);
 }
 
+// slab / n_slabs (lattice decoders on the fused rows, closure_kernel): n_slabs workgroups per channel share the frame's epsilon
+// links; the one that finishes its share LAST (a 64-bit add on the channel's kClSlabWord: arrivals | links appended << 32) goes
+// on to close the frame -- what the others changed it reads through L2 (the link counter, the error bits) -- and returns true,
+// the others return false and are done.  No workgroup reads what another one stored with plain stores.
 template <bool kLat, bool kBig>
-__device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, BoundaryShared &sh) {
+__device__ __forceinline__ bool finalize_frame(const DecoderDev &D, int c, ChanCtl *ctl, BoundaryShared &sh, int slab = 0, int n_slabs = 1) {
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long tq = wall_clock64();
   const int f = ctl->n_decoded;
   const float cutoff = o2f(ctl->bound);
   const int base = ctl->front_begin + ctl->front_count;
+  const bool shared_out = kLat && !kBig && n_slabs > 1;
   if (tid == 0) {
     sh.nnew = ctl->new_count;
     sh.occ = ctl->eps_occ < D.wl_cap ? ctl->eps_occ : D.wl_cap;
     sh.wl_n[0] = ctl->wl_n < D.wl_cap ? ctl->wl_n : D.wl_cap;
     sh.wl_n[1] = 0;
     sh.err = 0;
+    sh.nlinks = 0;
     // every emitting link into the new frame is recorded (the insert launch is over): the epsilon
-    // links of the frame start here
-    if (kLat && f + 1 <= D.max_frames) D.link_mid[(size_t)c * (D.max_frames + 3) + f + 1] = min(ctl->link_count, (int)D.link_cap);
+    // links of the frame start here  (shared_out: the other workgroups may have appended theirs already -- written below, from the totals)
+    if (kLat && !shared_out && f + 1 <= D.max_frames) D.link_mid[(size_t)c * (D.max_frames + 3) + f + 1] = min(ctl->link_count, (int)D.link_cap);
   }
   // the insert workgroups read all bucket counters of the channel to form their groups, so the
   // counters stay untouched during that launch and are reset here
-  for (int i = tid; i < D.n_part; i += kBT) D.bucket_cnt[(size_t)c * D.n_part + i] = 0;
+  if (slab == 0) for (int i = tid; i < D.n_part; i += kBT) D.bucket_cnt[(size_t)c * D.n_part + i] = 0;
   __syncthreads();
   if (tid == 0) dbg_phase(D, 0, tq);
   u64 nZ = 0;
@@ -2111,8 +2129,26 @@ __device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanC
     if constexpr (kLat) {
       // lattice mode: all that is left of ProcessNonemitting are the epsilon links, one flat pass over the frame
       const bool fits = sh.nnew <= D.max_tok && (int64_t)base + sh.nnew <= D.arena_cap && ctl->error == 0;
-      if (fits) epsilon_links(D, c, sh, base, cutoff, true);
+      if (fits) epsilon_links(D, c, sh, base, cutoff, true, slab, n_slabs);
       __syncthreads();
+      if (tid == 0) dbg_phase(D, 1, tq);   // (the epsilon links of the frame)
+      if (shared_out) {
+        if (tid == 0) {
+          if (sh.err) atomicOr(&ctl->error, sh.err);
+          u64 *word = reinterpret_cast<u64 *>(D.prune_par + (size_t)c * kPruneParInts + kClSlabWord);
+          const u64 old = atomicAdd(word, ((u64)(uint32_t)sh.nlinks << 32) | 1ull);
+          sh.last = (int)(uint32_t)old == n_slabs - 1;
+          sh.eps_total = (int)(old >> 32) + sh.nlinks;
+          if (sh.last) atomicExch(word, 0ull);   // (for the next frame's launch)
+        }
+        __syncthreads();
+        if (!sh.last) return false;
+        if (tid == 0) {
+          const int lend = ld_agent(&ctl->link_count);
+          if (f + 1 <= D.max_frames) D.link_mid[(size_t)c * (D.max_frames + 3) + f + 1] = min(max(lend - sh.eps_total, 0), (int)D.link_cap);
+          sh.err |= ld_agent(&ctl->error);
+        }
+      }
       if (tid == 0) D.emit_cnt[c * 32] = 0;   // (the next frame's insert launch lists afresh)
     }
   } else {
@@ -2134,7 +2170,7 @@ __device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanC
       D.frame_off[(size_t)c * (D.max_frames + 2) + f + 2] = base + nf;
       D.cutoff_hist[(size_t)c * (D.max_frames + 2) + f + 1] = cutoff;
       if (kLat) {
-        const int lend = min(ctl->link_count, (int)D.link_cap);
+        const int lend = min(shared_out ? ld_agent(&ctl->link_count) : ctl->link_count, (int)D.link_cap);
         D.lat_stats[(size_t)c * 4 + 0] += (u64)max(0, lend - D.link_off[(size_t)c * (D.max_frames + 3) + f + 1]);   // links recorded for this frame
         D.link_off[(size_t)c * (D.max_frames + 3) + f + 2] = lend;
       }
@@ -2153,6 +2189,7 @@ __device__ __forceinline__ void finalize_frame(const DecoderDev &D, int c, ChanC
     dbg_phase(D, 4, tq);
   }
   __syncthreads();
+  return true;
 }
 
 // exact k-th smallest (0-based) cost of the frontier: what std::nth_element leaves at
@@ -3580,11 +3617,17 @@ __device__ __forceinline__ void gc_pass(const DecoderDev &D, int c, ScanShared &
 
 template <bool kLat, bool kBig>
 __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_t *target, int do_prep, int chan_off,
-                                                      int group, int par) {
+                                                      int group, int par, int chan_cnt, int n_slabs) {
   __shared__ BoundaryShared sh;
-  const int c = blockIdx.x + chan_off;
+  // n_slabs workgroups per channel (finalize_frame; > 1 only behind an insert launch: no channel idle at the launch's start is
+  // made active by it, so every workgroup of a channel reads the same ChanCtl::active)
+  const int c = (int)blockIdx.x % chan_cnt + chan_off, slab = (int)blockIdx.x / chan_cnt;
   ChanCtl *ctl = D.ctl + c;
-  if (ctl->active) finalize_frame<kLat, kBig>(D, c, ctl, sh);
+  if (ctl->active) {
+    if (!finalize_frame<kLat, kBig>(D, c, ctl, sh, slab, n_slabs)) return;
+  } else if (slab != 0) {
+    return;
+  }
   __syncthreads();
   if constexpr (kLat) {
     // (PruneActiveTokens, every prune_interval-th frame: lattice_prune_kernel, a launch of its own between this one -- which then
@@ -4437,15 +4480,17 @@ void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_
   else hipLaunchKernelGGL(insert_kernel_plain, dim3(n_workgroups), dim3(kInsertThreads), lds, s, D, group, par);
 }
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int do_prep, int group, int par,
-                    hipStream_t s) {
+                    hipStream_t s, int after_insert) {
+  // lattice decoders on the fused rows, behind an insert launch: the frame's epsilon links shared out over kClSlabs workgroups per channel
+  const int ns = (after_insert && D.lattice && !D.big && D.fused && D.closure_slabs > 1) ? D.closure_slabs : 1;
   if (D.big && D.lattice)
-    hipLaunchKernelGGL((closure_kernel<true, true>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+    hipLaunchKernelGGL((closure_kernel<true, true>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par, chan_cnt, 1);
   else if (D.big)
-    hipLaunchKernelGGL((closure_kernel<false, true>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+    hipLaunchKernelGGL((closure_kernel<false, true>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par, chan_cnt, 1);
   else if (D.lattice)
-    hipLaunchKernelGGL((closure_kernel<true, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+    hipLaunchKernelGGL((closure_kernel<true, false>), dim3(chan_cnt * ns), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par, chan_cnt, ns);
   else
-    hipLaunchKernelGGL((closure_kernel<false, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par);
+    hipLaunchKernelGGL((closure_kernel<false, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par, chan_cnt, 1);
 }
 void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int group, int par, hipStream_t s) {
   // the raw frames (kPrRawJ workgroups per channel), the walk over the frames priced before (one workgroup per

@@ -129,6 +129,9 @@ typedef struct wfst_options {
                                   0x800: a running back-pruning pass prices the never-priced frames of EVERY
                                   channel on several workgroups (by default only channels with 800 k such links
                                   or more: the LDS walk is faster below); same results, for the tests.
+                                  0x100 / 0x200 / 0x300: a lattice decoder's closure launches run 1 / 2 / 8
+                                  workgroups per channel instead of 4 (they share the frame's epsilon links);
+                                  same results, for the tests.
                                   Further bits are A/B switches of timing experiments, honoured only by a
                                   library built with -DWFST_AB_SWITCHES) */
 } wfst_options;

@@ -70,7 +70,9 @@ def test_fuzz_against_oracle(block, synth, oracle, tmp_path):
         # (wfst_options.debug 0x1000; what graphs without fused rows and the biglm decoder run) on odd ones
         # ... and on every third case the back-pruning's several-workgroup pass for every channel (debug 0x800: the raw frames of a
         # running pass priced by workgroups that meet at a counter -- by default only very heavy channels take it)
-        dbg = (0x1000 if case % 2 else 0) | (0x800 if case % 3 == 0 else 0)
+        # ... and the closure launches of the fused-row cases with 1 / 4 (the default) / 8 / 2 workgroups per channel sharing a frame's
+        # epsilon links (debug 0x100 / 0 / 0x300 / 0x200)
+        dbg = (0x1000 if case % 2 else 0) | (0x800 if case % 3 == 0 else 0) | (0x100, 0, 0x300, 0, 0x200, 0, 0, 0)[case % 8]
         lat_opt = {"options": G.wfstdec.Options(debug=dbg)} if dbg else {}
         dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), max_frames=64, max_tokens_per_frame=4096,
                                      arena_tokens=1 << 16, lattice_links=1 << 18, **lat_opt)

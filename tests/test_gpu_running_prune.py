@@ -54,7 +54,7 @@ def test_mid_utterance_raw_lattice(prune_scale, raw_pass, synth, oracle, tmp_pat
     mats = [synth.make_loglikes(g, t, 1000, m, seed=40 + i, mu=-2.3)[0] for i, t in enumerate(T)]
     dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), max_frames=128, max_tokens_per_frame=32768,
                                  arena_tokens=1 << 20, lattice_links=1 << 21,
-                                 options=G.wfstdec.Options(debug=0x800) if raw_pass else None)
+                                 options=G.wfstdec.Options(debug=0x800 | 0x300) if raw_pass else None)   # (0x300: and 8 workgroups per channel in the closure launches)
     dev = G.upload(mats)
     dec.init()
     h = oracle.load_graph(path)
