@@ -318,10 +318,10 @@ void wfst_config_default(wfst_config *c) {  // lattice-faster-decoder-conf.h:35-
 void wfst_options_default(wfst_options *o) {
   o->channel_groups = 0;
   o->use_hip_graph = 1;
-  o->log2_partitions = 5;  // 32 partitions: measured best at batch 128 (16: insert slower, 64: more bucket atomics)
+  o->log2_partitions = -1;  // by the decoder's kind (wfst_decoder_create_ex): 5 -- 32 partitions: measured best at batch 128 for best-path decoders (16: insert slower, 64: more bucket atomics) --, 6 for lattice decoders
   o->log2_lds_slots = 12;
   o->joint_max = 1536;
-  o->expand_workgroups = 2048;
+  o->expand_workgroups = 0;   // by the decoder's kind: 2048, lattice decoders 3072
   o->insert_workgroups = 768;
   o->upload_slice_frames = 48;
   o->tile_tokens = 256;
@@ -920,8 +920,8 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   wfst_options O;
   wfst_options_default(&O);
   if (options) O = *options;
-  if (O.channel_groups < 0 || O.channel_groups > 8 || O.log2_partitions < 0 || O.log2_partitions > 6 ||
-      O.log2_lds_slots < 8 || O.log2_lds_slots > 13 || O.joint_max < 1 || O.expand_workgroups < 1 ||
+  if (O.channel_groups < 0 || O.channel_groups > 8 || O.log2_partitions < -1 || O.log2_partitions > 6 ||
+      O.log2_lds_slots < 8 || O.log2_lds_slots > 13 || O.joint_max < 1 || O.expand_workgroups < 0 ||
       O.insert_workgroups < 1 || O.upload_slice_frames < 0 || O.tile_tokens < 64 || O.tile_tokens > 256)
     return fail(WFST_E_ARG, "wfst_options field out of range");
   HIP_TRY(hipSetDevice(g->device));
@@ -946,6 +946,11 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     L.arena_tokens = std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(4194304, (int64_t)L.max_frames * std::max<int64_t>(256, L.max_tokens_per_frame / 64)));
   if (L.arena_tokens > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "arena_tokens must fit int32");
   if (L.lattice_links < 0 || L.lattice_links > 0x7FFFFFF0ll) return fail(WFST_E_ARG, "lattice_links must fit int32");
+  // launch shapes left to the library (wfst_options_default): a lattice decoder's wide beams fill a heavy channel's 32 buckets
+  // beyond an insert workgroup's table (sub-passes over the bucket: the tail of the launch) -- 64 partitions and a larger expansion
+  // grid measured 4 % faster on the beam-15 leg, the same at beam 13; best-path decoders keep 32 / 2048 (bucket atomics)
+  if (O.log2_partitions < 0) O.log2_partitions = (L.lattice_links > 0 && !big) ? 6 : 5;
+  if (O.expand_workgroups == 0) O.expand_workgroups = (L.lattice_links > 0 && !big) ? 3072 : 2048;
   // hash partitions per channel: each insert workgroup owns an LDS table of lds_slots entries;
   // a bucket too full for it is handled in sub-passes, so these are speed knobs, not limits
   const int64_t M = L.max_tokens_per_frame;
@@ -1116,7 +1121,9 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // wfst_options.debug are honoured by WFST_AB_SWITCHES builds only.)
   const int ab_bits = kAbSwitches ? O.debug : 0;
   d->stagger_us = (ab_bits & 0x80000) ? ((ab_bits >> 20) & 0xFF) * 100 : 0;   // (0x80000 + a count of 100 us in bits 20..27, A/B)
-  D.prune_raw_min = (O.debug & 0x800) ? 0 : 800000;   // (below: the one-workgroup walk in LDS is done sooner -- beam 13 of the bench; 0x800: the tests' switch)
+  D.prune_raw_min = (O.debug & 0x800) ? 0 : 800000;
+  if (kAbSwitches) { if (const char *e = getenv("WFST_PRUNE_RAW_MIN")) D.prune_raw_min = atoi(e); }   // (timing experiments)
+   // (below: the one-workgroup walk in LDS is done sooner -- beam 13 of the bench; 0x800: the tests' switch)
   // closure launches of a lattice decoder on the fused rows: workgroups per channel (they share the frame's epsilon links; a heavy
   // channel's frame is a dozen sweeps for one workgroup).  wfst_options.debug 0x100 / 0x200 / 0x300: 1 / 2 / 8 of them, for the tests
   { static const int kSlabs[4] = {4, 1, 2, 8}; D.closure_slabs = kSlabs[(O.debug >> 8) & 3]; }

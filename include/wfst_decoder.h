@@ -114,10 +114,12 @@ typedef struct wfst_options {
   int32_t channel_groups;      /* 1..8: channel groups, each with its own stream and hipGraph; 0 = automatic
                                   (2 groups from 64 channels up, 3 from 96 up, else 1)           (0)    */
   int32_t use_hip_graph;       /* replay the frame loop of an advance call as a hipGraph        (1)    */
-  int32_t log2_partitions;     /* 0..6: hash partitions (candidate buckets) per channel         (5)    */
+  int32_t log2_partitions;     /* 0..6: hash partitions (candidate buckets) per channel; -1 = by the
+                                  decoder's kind: 5, lattice decoders 6                          (-1)   */
   int32_t log2_lds_slots;      /* 8..13: LDS hash slots of one insert workgroup                 (12)   */
   int32_t joint_max;           /* records a group of partitions may hold to share a workgroup   (1536) */
-  int32_t expand_workgroups;   /* grid of the expansion kernel                                  (2048) */
+  int32_t expand_workgroups;   /* grid of the expansion kernel; 0 = by the decoder's kind: 2048,
+                                  lattice decoders 3072                                          (0)    */
   int32_t insert_workgroups;   /* grid of the insert kernel                                     (768)  */
   int32_t upload_slice_frames; /* wfst_decoder_advance_host: frames per upload slice, 0 = copy
                                   everything before decoding                                    (48)   */

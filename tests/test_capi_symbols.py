@@ -153,8 +153,8 @@ def test_header_is_plain_c(tmp_path):
 
 def test_options_defaults_and_range_check(pkg):
     o = pkg.wfstdec.Options()
-    assert (o.channel_groups, o.use_hip_graph, o.log2_partitions, o.log2_lds_slots) == (0, 1, 5, 12)
-    assert (o.joint_max, o.expand_workgroups, o.insert_workgroups, o.upload_slice_frames, o.tile_tokens, o.debug) == (1536, 2048, 768, 48, 256, 0)
+    assert (o.channel_groups, o.use_hip_graph, o.log2_partitions, o.log2_lds_slots) == (0, 1, -1, 12)
+    assert (o.joint_max, o.expand_workgroups, o.insert_workgroups, o.upload_slice_frames, o.tile_tokens, o.debug) == (1536, 0, 768, 48, 256, 0)
     go = pkg.wfstdec.GraphOptions()
     assert (go.row_align_slots, go.flatten_closures) == (8, 1)
     with pytest.raises(TypeError):
