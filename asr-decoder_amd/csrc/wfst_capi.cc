@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/wfst_decoder.h"
@@ -259,6 +260,7 @@ struct wfst_decoder {
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<int, int>> ev_pairs[4];  // [kernel class] -> (start, stop) event indices
+  std::vector<std::array<int, 4>> ev_log;        // the same launches in order: {kind, channel group, start, stop} (WFST_PROFILE_DUMP of a WFST_AB_SWITCHES build)
   size_t ev_used = 0;
   int ev_get() {
     if (ev_used == ev_pool.size()) {
@@ -1384,12 +1386,26 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   std::vector<int> gsteps(G, 0);
   for (int c = 0; c < d->n_channels; ++c)
     gsteps[c / per] = std::max(gsteps[c / per], d->h_target[c] - d->h_decoded[c]);
+  int timed_group = 0, timed_kind = -1;   // (of the launch being enqueued: for the timeline dump)
   auto timed = [&](int cls, hipStream_t st, auto &&launch) {
     if (!d->profiling) { launch(); return; }
     const int a = d->ev_get(), b = d->ev_get();
     if (a >= 0 && b >= 0) (void)hipEventRecord(d->ev_pool[a], st);
     launch();
-    if (a >= 0 && b >= 0) { (void)hipEventRecord(d->ev_pool[b], st); d->ev_pairs[cls].push_back({a, b}); }
+    if (a >= 0 && b >= 0) {
+      (void)hipEventRecord(d->ev_pool[b], st);
+      d->ev_pairs[cls].push_back({a, b});
+      if (kAbSwitches) d->ev_log.push_back({timed_kind >= 0 ? timed_kind : cls, timed_group, a, b});
+    }
+  };
+  // a back-pruning step: four launches (wfst_kernels.hip launch_lattice_prune_step); timed one by one for the timeline dump
+  auto prune_step_launches = [&](int off, int cnt, int g, int par, hipStream_t st) {
+    if (!(kAbSwitches && d->profiling)) { timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par, st, -1); }); return; }
+    for (int stage = 0; stage < 4; ++stage) {
+      timed_kind = 10 + stage;
+      timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par, st, stage); });
+    }
+    timed_kind = -1;
   };
   const std::vector<int> gpar0(d->gpar);  // parity each group starts this call with
   // lattice mode: does step s of group g bring a channel to a multiple of prune_interval, with frames left to decode?
@@ -1406,10 +1422,11 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
   auto enqueue_group = [&](int g, hipStream_t st, int s_lo, int s_hi) {
     const int off = g * per, cnt = std::min(per, d->n_channels - off);
     if (cnt <= 0 || gsteps[g] == 0) return;
+    timed_group = g;
     int par = gpar0[g] ^ (s_lo & 1);
     if (s_lo == 0) {
       // GetCutoff + tile list only -- behind PruneActiveTokens where the call before this one stopped at a multiple of prune_interval
-      if (prune_step(g, -1)) timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par, st); });
+      if (prune_step(g, -1)) prune_step_launches(off, cnt, g, par, st);
       else timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, 1, g, par, st, 0); });
     }
     for (int s = s_lo; s < s_hi; ++s) {
@@ -1423,7 +1440,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
       // prune_interval and goes on decoding -- a launch of its own, which also prepares the next frame
       const bool prune = more && prune_step(g, s);
       if (classic) timed(2, st, [&] { launch_closure(d->D, off, cnt, d->target.p, more && !prune, g, par ^ 1, st, 1); });
-      if (prune) timed(2, st, [&] { launch_lattice_prune_step(d->D, off, cnt, d->target.p, g, par ^ 1, st); });
+      if (prune) prune_step_launches(off, cnt, g, par ^ 1, st);
       par ^= 1;
     }
   };
@@ -1844,6 +1861,7 @@ int wfst_decoder_set_profiling(wfst_decoder *d, int32_t enable) {
   d->profiling = enable != 0;
   d->ev_used = 0;
   for (auto &v : d->ev_pairs) v.clear();
+  d->ev_log.clear();
   return WFST_OK;
 }
 
@@ -1910,6 +1928,19 @@ int wfst_decoder_get_profile_busy(wfst_decoder *d, double busy_ms[3]) {
     }
     if (open) tot += hi - lo;
     busy_ms[k] = tot;
+  }
+  if (kAbSwitches) {   // timing experiments: the profiled step's launches as a timeline (kind, channel group, start ms, stop ms)
+    if (const char *path = getenv("WFST_PROFILE_DUMP")) {
+      if (FILE *f = fopen(path, "w")) {
+        for (auto &e : d->ev_log) {
+          float a = 0, b = 0;
+          (void)hipEventElapsedTime(&a, d->ev_pool[base], d->ev_pool[e[2]]);
+          (void)hipEventElapsedTime(&b, d->ev_pool[base], d->ev_pool[e[3]]);
+          fprintf(f, "%d,%d,%.4f,%.4f\n", e[0], e[1], a, b);
+        }
+        fclose(f);
+      }
+    }
   }
   return WFST_OK;
 }

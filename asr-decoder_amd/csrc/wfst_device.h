@@ -469,7 +469,8 @@ void launch_insert(const DecoderDev &D, int chan_off, int chan_cnt, const int32_
 // after_insert: the launch closes a frame an insert launch has just built (DecoderDev::closure_slabs workgroups per channel then)
 void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int do_prep,
                     int group, int par, hipStream_t s, int after_insert);
-void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int group, int par, hipStream_t s);
+// stage: -1 = the step's four launches; 0..3 = one of them (raw frames, walk, flag sweeps, moves): a profiled step times them one by one
+void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int group, int par, hipStream_t s, int stage);
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_delay(int microseconds, hipStream_t s);
 void launch_lattice_prune(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);

@@ -4492,16 +4492,21 @@ void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32
   else
     hipLaunchKernelGGL((closure_kernel<false, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par, chan_cnt, 1);
 }
-void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int group, int par, hipStream_t s) {
+void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int group, int par, hipStream_t s, int stage) {
   // the raw frames (kPrRawJ workgroups per channel), the walk over the frames priced before (one workgroup per
   // channel, 130 KB of LDS), the compaction's flag sweeps (kPrSlabs workgroups per channel), its moves + the next frame's preparation
   const int raw = D.prune_raw ? 1 : 0;
-  if (raw) hipLaunchKernelGGL(lattice_prune_raw_kernel, dim3(kPrRawJ * chan_cnt), dim3(kPrRawT), 0, s, D, target, chan_off, chan_cnt);
-  if (D.big) hipLaunchKernelGGL(lattice_prune_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par, raw);
-  else hipLaunchKernelGGL(lattice_prune_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par, raw);
-  hipLaunchKernelGGL(lattice_prune_flags_kernel, dim3(chan_cnt * kPrSlabs), dim3(kBT), 0, s, D, chan_off);
-  if (D.big) hipLaunchKernelGGL(lattice_prune_move_kernel<true>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
-  else hipLaunchKernelGGL(lattice_prune_move_kernel<false>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
+  auto on = [&](int k) { return stage < 0 || stage == k; };
+  if (raw && on(0)) hipLaunchKernelGGL(lattice_prune_raw_kernel, dim3(kPrRawJ * chan_cnt), dim3(kPrRawT), 0, s, D, target, chan_off, chan_cnt);
+  if (on(1)) {
+    if (D.big) hipLaunchKernelGGL(lattice_prune_kernel<true>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par, raw);
+    else hipLaunchKernelGGL(lattice_prune_kernel<false>, dim3(chan_cnt), dim3(kBT), 0, s, D, target, chan_off, group, par, raw);
+  }
+  if (on(2)) hipLaunchKernelGGL(lattice_prune_flags_kernel, dim3(chan_cnt * kPrSlabs), dim3(kBT), 0, s, D, chan_off);
+  if (on(3)) {
+    if (D.big) hipLaunchKernelGGL(lattice_prune_move_kernel<true>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
+    else hipLaunchKernelGGL(lattice_prune_move_kernel<false>, dim3(chan_cnt, 2), dim3(kBT), 0, s, D, target, chan_off, group, par);
+  }
 }
 // A pause of `us` microseconds on a stream (one wave that sleeps): staggers the channel groups' frame chains against each other
 // (wfst_capi.cc advance_device).
