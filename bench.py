@@ -120,7 +120,7 @@ def parse():
     ap.add_argument("--tile-tokens", type=int, default=0, help="wfst_options.tile_tokens (0 = library default)")
     ap.add_argument("--row-align", type=int, default=0, help="wfst_graph_options.row_align_slots (0 = library default)")
     ap.add_argument("--no-hip-graph", action="store_true", help="enqueue the frame loop kernel by kernel (rocprofv3 --pmc passes)")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances checked bit for bit against the CPU decoder (0 = skip "
+    ap.add_argument("--cpu-sample", type=int, default=128, help="utterances checked bit for bit against the CPU decoder -- by default the whole batch of rank 0, decoded by the reference on the host threads in a few seconds -- (0 = skip "
                     "the CPU legs: parity sample, cpu_baseline, service_point divergence)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of each timed CPU-baseline leg (1 thread, all cores)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores leg (0 = every CPU this process may run on)")
