@@ -3995,6 +3995,8 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   const int32_t *tok_lm = kBig ? D.tok_lm + (size_t)c * D.arena_cap : nullptr;
   const int fb = ctl->front_begin;
   u64 best_all = ~0ull, best_fin = ~0ull, best_wf = ~0ull;  // best_wf: min cost + LM final cost over ALL tokens (biglm)
+  unsigned long long tb0 = (D.dbg & 32) ? wall_clock64() : 0ull, tb_walk = 0, tb_scan = 0;
+  int n_unres = 0;
   for (int i = tid; i < n; i += kBpThreads) {
     const int4 t = tok[fb + i];
     const u64 v = ((u64)f2o(__int_as_float(t.y)) << 32) | (uint32_t)(fb + i);
@@ -4049,9 +4051,11 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
   // Walk the backpointer chain (last hop first, packed against the end of ch[]).  One thread
   // follows resolved backpointers; a token won by an epsilon arc carries kPrevUnresolved and the
   // whole workgroup scans its frame for the token of the arc's source state.
+  if (tid == 0 && (D.dbg & 32)) { const unsigned long long now = wall_clock64(); atomicAdd(&D.dbg_t[110], now - tb0); tb0 = now; }
   for (;;) {
     __syncthreads();
     if (s_t < 0) break;
+    unsigned long long tw0 = (tid == 0 && (D.dbg & 32)) ? wall_clock64() : 0ull;
     if (tid == 0) {
       // resolved backpointers are followed in one go (a dependent load per hop, nothing else on the chain); the walk stops at a
       // token won by an epsilon arc, whose predecessor the whole workgroup looks for
@@ -4080,9 +4084,11 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
       }
       s_t = t;
       s_len = len;
+      if (D.dbg & 32) { const unsigned long long now = wall_clock64(); tb_walk += now - tw0; tw0 = now; }
     }
     __syncthreads();
     if (s_need >= 0) {
+      ++n_unres;
       const int need = s_need, t = s_t;
       constexpr int kScanU = 4;   // states of the frame in flight per thread
       for (int i0 = s_lo + tid; i0 < s_hi; i0 += kBpThreads * kScanU) {
@@ -4118,7 +4124,13 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
       }
       __syncthreads();
       if (tid == 0) s_t = s_found;  // -1 (never expected) ends the walk
+      if (tid == 0 && (D.dbg & 32)) tb_scan += wall_clock64() - tw0;
     }
+  }
+  if (tid == 0 && (D.dbg & 32)) {
+    atomicAdd(&D.dbg_t[111], tb_walk); atomicAdd(&D.dbg_t[112], tb_scan); atomicAdd(&D.dbg_t[114], (unsigned long long)s_len);
+    atomicAdd(&D.dbg_t[115], (unsigned long long)n_unres); atomicAdd(&D.dbg_t[116], 1ull);
+    tb0 = wall_clock64();
   }
   if (tid == 0) n_hops[bi] = s_len;
   __syncthreads();
@@ -4205,6 +4217,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
     }
     oa[pos] = eps ? 0.f : -llrow[C.x & D.g.col_mask];
   }
+  if (tid == 0 && (D.dbg & 32)) atomicAdd(&D.dbg_t[113], wall_clock64() - tb0);
 }
 
 // GetRawLattice's raw material: every token and link alive right now, resolved to labels and costs, in the
