@@ -355,3 +355,47 @@ def test_zero_frame_utterance_in_lattice_mode(synth, oracle, tmp_path):
     assert len(bp[1]["tids"]) == 0
     dec.free()
     graph.free()
+
+
+def test_closure_launch_workgroups_per_channel_give_one_lattice(oracle, synth, tmp_path):
+    """A lattice decoder's closure launch shares a frame's epsilon links out over 4 workgroups per channel (wfst_options.debug
+    0x100 / 0x200 / 0x300: 1 / 2 / 8); the one that finishes last closes the frame.  Wide frames (a beam that keeps most of a
+    20 000-state graph alive: thousands of emitters a frame, several sweeps per workgroup) must give the SAME lattice whatever the
+    count -- and the oracle's."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(20000, seed=11, n_tid=2000, n_words=3000)
+    m = synth.default_tid2pdf(2000)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=40.0, max_active=1000000, min_active=0, lattice_beam=6.0, prune_interval=10)
+    mats = [synth.make_loglikes_multi(g, T, 1000, m, seed=70 + i)[0] for i, T in enumerate((34, 21))]
+    lim = dict(max_frames=64, max_tokens_per_frame=65536, arena_tokens=1 << 22, lattice_links=1 << 23)
+    got = {}
+    peak = 0
+    for dbg in (0, 0x100, 0x200, 0x300):
+        dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), options=G.wfstdec.Options(debug=dbg) if dbg else None, **lim)
+        dev = G.upload(mats)
+        dec.init()
+        dec.advance([t.data_ptr() for t in dev], [int(x.shape[0]) for x in mats], int(mats[0].shape[1]))
+        dec.finalize()
+        got[dbg] = [as_raw(dec.raw_lattice(c, True)) for c in range(len(mats))]
+        peak = max(peak, max(dec.lattice_stats(c)["links_recorded"] for c in range(len(mats))))
+        dec.free()
+    assert peak > 200000, peak   # (wide frames: the epsilon links alone are thousands a frame)
+    for dbg in (0x100, 0x200, 0x300):
+        for c in range(len(mats)):
+            what = "debug %#x channel %d" % (dbg, c)
+            assert np.array_equal(nodes(got[dbg][c]), nodes(got[0][c])), what + " states"
+            assert np.array_equal(got[dbg][c].labelled_arcs(), got[0][c].labelled_arcs()), what + " arcs"
+    ho = oracle.load_graph(path)
+    try:
+        oracle.set_order_free(True)
+        O = pyoracle.oracle_raw_lattice(oracle, ho, pyoracle.Config(**cd), mats[1], m)
+    finally:
+        oracle.set_order_free(False)
+        oracle.free_graph(ho)
+    assert np.array_equal(nodes(got[0][1]), nodes(O)) and np.array_equal(got[0][1].labelled_arcs(), O.labelled_arcs())
+    graph.free()
