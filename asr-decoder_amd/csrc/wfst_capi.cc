@@ -1259,6 +1259,13 @@ void wfst_decoder_free(wfst_decoder *d) {
         fprintf(stderr, "[wfst dbg] per pass: walk raw frames %.1f us, old frames %.1f us; frames in LDS %.1f, in HBM %.1f; compaction: token flags %.1f us, token move %.1f us, link flags %.1f us, link move %.1f us; raw tokens %.0f, raw links %.0f, survivors %.0f\n",
                 0.01 * t[40] / t[52], 0.01 * t[41] / t[52], (double)t[42] / t[52], (double)t[43] / t[52], 0.01 * t[44] / t[52], 0.01 * t[45] / t[52], 0.01 * t[46] / t[52], 0.01 * t[47] / t[52],
                 (double)t[48] / t[52], (double)t[49] / t[52], (double)t[50] / t[52]);
+      if (t[52]) {
+        fprintf(stderr, "[wfst dbg] walk length per channel and pass, 0.4 ms bins: raw frames priced in the walk");
+        for (int b = 0; b < 11; ++b) fprintf(stderr, " %llu", t[80 + b]);
+        fprintf(stderr, " | behind the raw launch");
+        for (int b = 0; b < 11; ++b) fprintf(stderr, " %llu", t[117 + b]);
+        fprintf(stderr, "\n");
+      }
       if (t[116])
         fprintf(stderr, "[wfst dbg] best path: per channel frontier scan %.1f us, backpointer walk %.1f us (%.1f hops), %.2f epsilon-won tokens resolved by a frame scan %.1f us, hop pass %.1f us\n",
                 0.01 * t[110] / t[116], 0.01 * t[111] / t[116], (double)t[114] / t[116], (double)t[115] / t[116], 0.01 * t[112] / t[116], 0.01 * t[113] / t[116]);
