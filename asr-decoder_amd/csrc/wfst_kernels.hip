@@ -1665,7 +1665,8 @@ __global__ __launch_bounds__(kInsertThreads) void insert_kernel_biglm(DecoderDev
 __global__ __launch_bounds__(kInsertThreads) void insert_kernel_lattice_biglm(DecoderDev D, int group, int par) { insert_body<true, true, false>(D, group, par); }
 
 // =========================================================================================
-// closure_kernel and its pieces.  One 1024-thread workgroup per channel.
+// closure_kernel and its pieces.  One 1024-thread workgroup per channel (lattice decoders on the fused rows: DecoderDev::closure_slabs
+// of them, which share the frame's epsilon links -- finalize_frame).
 // =========================================================================================
 constexpr int kBT = 1024;
 constexpr int kBW = kBT / 64;
