@@ -1094,6 +1094,7 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   // (lattice decoders use the fused rows too: the epsilon arrivals come through the insert launch and the closure kernel
   // only lists the epsilon links; debug 0x1000 keeps the iterated closure pass, for comparison)
   D.fused = (g->fused && !big && (L.lattice_links == 0 || !(O.debug & 0x1000))) ? 1 : 0;
+  D.link_delta = (D.fused && L.lattice_links > 0) ? 1 : 0;
   // degree codes in the tokens (wfst_device.h): fused rows, a packed graph, and an arena whose indices leave 9 bits of a
   // backpointer free (up to 2^22 tokens: the default 4194304)
   D.tok_idx_bits = 31;

@@ -278,6 +278,9 @@ struct DecoderDev {
   int32_t *bucket_cnt;
   int32_t prune_raw_min; // ... for channels with at least this many never-priced links (wfst_options.debug 0x800: 0, every channel)
   int32_t closure_slabs; // lattice decoders on the fused rows: workgroups per channel of a closure launch (they share the frame's epsilon links)
+  int32_t link_delta;    // lattice decoders on the fused rows: a forward link's 4th word is (link cost - cost of its destination token) -- the float the
+                         // back-pruning computes from the two anyway (base-inl.h:524-526), known when the link is recorded: a link is priced from the
+                         // destination's extra alone; elsewhere (iterated closures: a token's cost may still improve) the link cost itself
   int32_t prune_raw;     // lattice mode: a running back-pruning pass prices its raw frames with several workgroups per channel (wfst_kernels.hip: lattice_prune_raw_*)
   int32_t *prune_par;    // [c][kPruneParInts]: lattice mode -- what a running back-pruning pass hands to its compaction launches (wfst_kernels.hip: kPrParInts)
   int32_t *emit_cnt;     // [c][32] (a line each): lattice mode on the fused rows -- entries of the channel's emitter list (the tokens of the

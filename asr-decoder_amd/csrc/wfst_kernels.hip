@@ -274,7 +274,6 @@ __device__ __forceinline__ void dbg_phase(const DecoderDev &D, int k, unsigned l
 }
 
 constexpr int kEmitChunk = 16;   // entries of the channel's emitter list an insert item reserves up front (lattice mode on the fused rows)
-constexpr u64 kClaimedVal = ~0ull - 1;  // LDS hash value of a state whose token has been written (no record packs to it)
 constexpr int kHeavyItem = 900;  // records: insert items above this are handed out first
 
 // Which buckets share a workgroup?  Partitions of a light channel hold a few dozen records each;
@@ -1410,7 +1409,9 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
                 // the record holding the state's minimum writes the token.  With fused closures two
                 // candidates at one state can yield the SAME epsilon arrival (same last arc, costs equal
                 // after rounding): the first to swap the slot's value away is the one
-                winner = vals[slot] == packed && (!kFused || atomicCAS(&vals[slot], packed, kClaimedVal) == packed);
+                // (the claimed value keeps the cost: lattice mode reads it back for the links, pass 3; its low word, arc bits and flags
+                // all ones, is no record's -- row indices stay below kNoArc)
+                winner = vals[slot] == packed && (!kFused || atomicCAS(&vals[slot], packed, packed | 0xFFFFFFFFull) == packed);
                 in_table = true;
                 break;
               }
@@ -1553,7 +1554,9 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
 #pragma unroll
         for (int k = 0; k < kInsertUnroll; ++k) {
           if (lk_slot[k] < 0) continue;
-          if ((int64_t)lp < D.link_cap) links[lp] = make_int4(lk_src[k], tidx[lk_slot[k]], lk_arc[k], lk_cost[k]);
+          // (link_delta: link cost - cost of the token that won the state, the table's minimum)
+          const int lw = D.link_delta ? __float_as_int(__int_as_float(lk_cost[k]) - o2f((uint32_t)(vals[lk_slot[k]] >> 32))) : lk_cost[k];
+          if ((int64_t)lp < D.link_cap) links[lp] = make_int4(lk_src[k], tidx[lk_slot[k]], lk_arc[k], lw);
           else atomicOr(&ctl->error, kErrLinksFull);
           ++lp;
         }
@@ -1565,6 +1568,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
           const int4 r = load_rec(i0 + k * kInsertThreads + tid, &rlm);
           bool live = false;
           int dst = 0;
+          float dcost = 0.0f;
           if (__int_as_float(r.y) < cutoff && !(kFused && ((uint32_t)r.w & kEpsRec))) {
             const uint32_t h = hash_of(r, rlm);
             if (!log2sub || (int)((h >> sub_shift) & ((1u << log2sub) - 1u)) == sub) {
@@ -1572,7 +1576,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
               const KeyT key = key_of(r, rlm);
               for (int q = 0; q < SL; ++q) {
                 const KeyT kk = keys[slot];
-                if (kk == key) { live = true; dst = tidx[slot]; break; }
+                if (kk == key) { live = true; dst = tidx[slot]; dcost = o2f((uint32_t)(vals[slot] >> 32)); break; }
                 if (kk == kNoKey) break;
                 slot = (slot + 1) & mask;
               }
@@ -1585,7 +1589,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
           lb = __shfl(lb, 0, 64);
           if (live) {
             const int lp = lb + lane_rank(lm);
-            if ((int64_t)lp < D.link_cap) links[lp] = make_int4(r.z, dst, (int)((uint32_t)r.w & kArcMask), r.y);
+            if ((int64_t)lp < D.link_cap) links[lp] = make_int4(r.z, dst, (int)((uint32_t)r.w & kArcMask), D.link_delta ? __float_as_int(__int_as_float(r.y) - dcost) : r.y);
             else atomicOr(&ctl->error, kErrLinksFull);
           }
         }
@@ -1819,7 +1823,7 @@ __device__ __forceinline__ void epsilon_links(const DecoderDev &D, int c, Bounda
       // the closure pass); an entry from an older frame would mean that invariant broke: reported, never linked
       const int dst = ord >= 0 ? ld_agent(&toki[ord]) : -1;
       if (dst < base) atomicOr(&sh.err, kErrInternal);
-      else if ((int64_t)lp < D.link_cap) links[lp] = make_int4(idx, dst, a, __float_as_int(tot));
+      else if ((int64_t)lp < D.link_cap) links[lp] = make_int4(idx, dst, a, __float_as_int(D.link_delta ? tot - __int_as_float(tok[dst].y) : tot));
       else atomicOr(&sh.err, kErrLinksFull);
       ++lp;
     }
@@ -2738,7 +2742,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       for (int u = 0; u < kPU; ++u) {
         if (L[u].x < 0) continue;
         const uint32_t eo = (uint32_t)e[u];
-        const float le = eo >= kInfO ? kInf : o2f(eo) + (__int_as_float(L[u].w) - __int_as_float((int)(e[u] >> 32)));
+        const float le = eo >= kInfO ? kInf : o2f(eo) + (D.link_delta ? __int_as_float(L[u].w) : __int_as_float(L[u].w) - __int_as_float((int)(e[u] >> 32)));
         f(i0 + u * kBT + tid, L[u], le);
       }
     }
@@ -2863,28 +2867,40 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       // ---- the frame in LDS ----
       // (WIDE frames, kPrLds < nk <= 2 kPrLds -- the raw frames of a heavy channel at beam 15: only the 4-byte extras live in LDS,
       // 32 768 of them; the costs the epsilon links and the write-back need are read from the tokens)
-      const bool wide = nk > kPrLds;
-      // Placement: the pairs of frame k+1 sit at one end of the buffer (left there by the step before); frame k's go to the
-      // other end.  Where both do not fit, frame k+1's are read from HBM instead (next_lds false).
+      // (DecoderDev::link_delta, xmode: a link carries its cost relative to its destination's, so the 4-byte extras are ALL a frame's
+      // pricing needs -- every frame takes the extras-only form, 32 768 of them fit, and the frame behind stays in LDS beside it)
+      const bool xmode = D.link_delta != 0;
+      const bool wide = xmode || nk > kPrLds;
+      constexpr int kX = 2 * kPrLds;                        // extras the buffer holds
+      uint32_t *Xb = reinterpret_cast<uint32_t *>(ps.w.e);
+      // Placement: the pairs (xmode: extras) of frame k+1 sit at one end of the buffer (left there by the step before); frame k's go
+      // to the other end.  Where both do not fit, frame k+1's are read from HBM instead (next_lds false).
       const bool next_had = have == k + 1;                 // frame k+1's pairs are in LDS (at the `hb` end)
-      const bool next_fits = !wide && n1 + nk <= kPrLds;
+      const bool next_fits = xmode ? n1 + nk <= kX : (!wide && n1 + nk <= kPrLds);
       uint2 *E1 = nullptr;
+      uint32_t *E1x = nullptr;                              // (xmode)
       int cur_end;                                          // 0: frame k at the low end, 1: at the high end
       if (next_had && next_fits) {
-        E1 = hb == 0 ? ps.w.e : ps.w.e + (kPrLds - n1);
+        if (xmode) E1x = hb == 0 ? Xb : Xb + (kX - n1);
+        else E1 = hb == 0 ? ps.w.e : ps.w.e + (kPrLds - n1);
         cur_end = hb ^ 1;
       } else if (next_fits) {                               // fetch them (through L2: the HBM path prices with atomics)
-        E1 = ps.w.e;
-        for (int i = tid; i < n1; i += kBT) {
-          const u64 v = ld_agent(reinterpret_cast<const u64 *>(&extra[fk1 + i]));
-          ps.w.e[i] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+        if (xmode) {
+          E1x = Xb;
+          for (int i = tid; i < n1; i += kBT) Xb[i] = (uint32_t)ld_agent(reinterpret_cast<const u64 *>(&extra[fk1 + i]));
+        } else {
+          E1 = ps.w.e;
+          for (int i = tid; i < n1; i += kBT) {
+            const u64 v = ld_agent(reinterpret_cast<const u64 *>(&extra[fk1 + i]));
+            ps.w.e[i] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+          }
         }
         cur_end = 1;
       } else {
         cur_end = 0;                                        // frame k alone; its successor's pairs come from HBM link by link
       }
       uint2 *E0 = (cur_end == 0 || wide) ? ps.w.e : ps.w.e + (kPrLds - nk);
-      uint32_t *E0x = reinterpret_cast<uint32_t *>(ps.w.e);   // (wide frames)
+      uint32_t *E0x = (xmode && cur_end == 1) ? Xb + (kX - nk) : Xb;   // (wide frames; xmode: every frame)
       // everything a SMALL frame needs from HBM is asked for at once, before the first barrier: the tokens' costs, their
       // extras of the previous pass, its emitting links and epsilon links (a pruned frame: a few hundred tokens, a
       // thousand links); a larger one streams them
@@ -2912,11 +2928,17 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
         const int i = e0 + u * kBT + tid;
         EL[u] = (eps_in_regs && i < e1) ? links[i] : make_int4(-1, 0, 0, 0);
       }
-      if (small) {
+      if (small && !wide) {
 #pragma unroll
         for (int u = 0; u < kTU; ++u) {
           const int i = u * kBT + tid;
           if (i < nk) E0[i] = make_uint2(kInfO, (uint32_t)cy[u]);
+        }
+      } else if (small) {   // (xmode)
+#pragma unroll
+        for (int u = 0; u < kTU; ++u) {
+          const int i = u * kBT + tid;
+          if (i < nk) E0x[i] = kInfO;
         }
       } else {
         if (wide) {
@@ -2937,9 +2959,9 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
       __syncthreads();
       auto price0 = [&](const int4 &X) -> float {   // a link into frame k itself (epsilon links)
         uint2 en;
-        if (wide) { en.x = E0x[X.y - fk]; en.y = en.x >= kInfO ? 0u : (uint32_t)tok[X.y].y; }
+        if (wide) { en.x = E0x[X.y - fk]; en.y = (xmode || en.x >= kInfO) ? 0u : (uint32_t)tok[X.y].y; }
         else en = E0[X.y - fk];
-        return en.x >= kInfO ? kInf : o2f(en.x) + (__int_as_float(X.w) - __uint_as_float(en.y));
+        return en.x >= kInfO ? kInf : o2f(en.x) + (D.link_delta ? __int_as_float(X.w) : __int_as_float(X.w) - __uint_as_float(en.y));
       };
       auto min0 = [&](int i, uint32_t o) -> uint32_t { return wide ? atomicMin(&E0x[i], o) : atomicMin(&E0[i].x, o); };
       // emitting links frame k -> k+1
@@ -2958,6 +2980,9 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
             const uint2 v = ML[u].x >= 0 ? E1[ML[u].y - fk1] : make_uint2(0, 0);
             en[u] = (u64)v.x | ((u64)v.y << 32);
           }
+        } else if (E1x) {
+#pragma unroll
+          for (int u = 0; u < kPU; ++u) en[u] = ML[u].x >= 0 ? (u64)E1x[ML[u].y - fk1] : 0ull;
         } else {
 #pragma unroll
           for (int u = 0; u < kPU; ++u) en[u] = ML[u].x >= 0 ? ld_agent(reinterpret_cast<const u64 *>(&extra[ML[u].y])) : 0ull;
@@ -2966,7 +2991,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
         for (int u = 0; u < kPU; ++u) {
           if (ML[u].x < 0) continue;
           const uint32_t eo = (uint32_t)en[u];
-          float le = eo >= kInfO ? kInf : o2f(eo) + (__int_as_float(ML[u].w) - __int_as_float((int)(en[u] >> 32)));
+          float le = eo >= kInfO ? kInf : o2f(eo) + (D.link_delta ? __int_as_float(ML[u].w) : __int_as_float(ML[u].w) - __int_as_float((int)(en[u] >> 32)));
           if (!(le <= lb)) { links[i0 + u * kBT + tid].x = -1; continue; }
           if (le < 0.0f) le = 0.0f;
           min0(ML[u].x - fk, f2o(le));
@@ -3025,7 +3050,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
         for (int u = 0; u < kTU; ++u) {
           const int i = u * kBT + tid;
           if (i >= nk) continue;
-          const uint2 v = E0[i];
+          const uint2 v = wide ? make_uint2(E0x[i], (uint32_t)cy[u]) : E0[i];
           extra[fk + i] = v;
           if (!kFinal) {
             const float now = o2f(v.x);
@@ -3065,7 +3090,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
         moved = ps.any_changed != 0;
       }
       __syncthreads();   // (the next frame rewrites the other end of the buffer and the flags)
-      have = wide ? -1 : k;   // (a wide frame leaves extras only: its predecessor reads the pairs from HBM)
+      have = (wide && !xmode) ? -1 : k;   // (a wide frame leaves extras only: its predecessor reads the pairs from HBM; xmode: extras are all it needs)
       hb = cur_end;
       if (tid == 0 && (D.dbg & 32)) atomicAdd(&D.dbg_t[42], 1ull);
       continue;
@@ -3794,7 +3819,7 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
   // link_extra as prune_pass computes it (base-inl.h:524-526)
   auto link_extra = [&](const int4 &L, u64 e) -> float {
     const uint32_t eo = (uint32_t)e;
-    return eo >= kInfO ? kInf : o2f(eo) + (__int_as_float(L.w) - __int_as_float((int)(e >> 32)));
+    return eo >= kInfO ? kInf : o2f(eo) + (D.link_delta ? __int_as_float(L.w) : __int_as_float(L.w) - __int_as_float((int)(e >> 32)));
   };
   // f(i, L, le) over this workgroup's share of links [lo, hi)
   auto for_links = [&](int lo, int hi, auto &&f) {
