@@ -2817,7 +2817,8 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
     __syncthreads();
     relax_eps(lmid[nd], loff[nd + 1]);
   } else if (!raw_done) {
-    for (int i = fn + tid; i < fn1; i += kBT) extra[i] = make_uint2(f2o(0.0f), (uint32_t)tok[i].y);
+    // (link_delta: nothing reads a pair's cost half -- it is not fetched from the tokens either, here and below)
+    for (int i = fn + tid; i < fn1; i += kBT) extra[i] = make_uint2(f2o(0.0f), D.link_delta ? 0u : (uint32_t)tok[i].y);
     __syncthreads();
   }
 
@@ -2914,7 +2915,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
 #pragma unroll
       for (int u = 0; u < kTU; ++u) {
         const int i = u * kBT + tid;
-        cy[u] = (small && i < nk) ? tok[fk + i].y : 0;
+        cy[u] = (small && !xmode && i < nk) ? tok[fk + i].y : 0;
         ox[u] = (small && had_old && i < nk) ? extra[fk + i].x : 0u;
       }
 #pragma unroll
@@ -3066,7 +3067,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
           for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * kBT + tid;
             o4[u] = (!kFinal && had_old && i < nk) ? extra[fk + i].x : 0u;
-            c4[u] = (wide && i < nk) ? tok[fk + i].y : 0;
+            c4[u] = (wide && !xmode && i < nk) ? tok[fk + i].y : 0;
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -3104,7 +3105,7 @@ __device__ __forceinline__ void prune_pass(const DecoderDev &D, int c, PruneShar
 #pragma unroll
       for (int u = 0; u < kPU; ++u) {
         const int i = i0 + u * kBT + tid;
-        cy[u] = i < fk1 ? tok[i].y : 0;
+        cy[u] = (i < fk1 && !D.link_delta) ? tok[i].y : 0;
         ox[u] = (had_old && i < fk1) ? extra[i].x : 0u;
       }
 #pragma unroll
@@ -3812,7 +3813,7 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
     const int lo = foff[n_prev < nd ? n_prev : nd], fn = foff[nd], hi = foff[nd + 1];
     // (agent-scope stores: the line does not stay behind in this XCD's L2, where a later agent-scope load would find it stale)
     for (int i = lo + j * kPrRawT + tid; i < hi; i += J * kPrRawT)
-      __hip_atomic_store(reinterpret_cast<u64 *>(&extra[i]), (u64)(i >= fn ? kZeroO : kInfO) | ((u64)(uint32_t)tok[i].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<u64 *>(&extra[i]), (u64)(i >= fn ? kZeroO : kInfO) | (D.link_delta ? 0ull : (u64)(uint32_t)tok[i].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (link_delta: the cost half is read by nobody)
     if (j == 0 && tid < 3) __hip_atomic_store(&chg[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   ok = raw_barrier(cnt, J, &seq, true);   // (plain stores: written back before anybody's atomics and agent loads meet them)
