@@ -2662,7 +2662,10 @@ constexpr int kPrSlabBase = 40;  // their survivor counts in the channel's param
 constexpr int kPrParInts = kPruneParInts;   // a channel's parameter block (DecoderDev::prune_par): [0, 16) the compaction's {run, c_lo, tokens lo / hi, frame-0 bound, links lo / hi, nd, slab counts}; [16, 32) lattice_emit's counters; [60, 62) the closure launch's meeting word (kClSlabWord); then:
 constexpr int kPrRawCount = 32;  // ... and of the raw frames' launches: workgroups of the channel that have finished their share of the frame,
 constexpr int kPrRawChg = 34;    // [3]: "an extra moved" of an epsilon round, in rotation
-constexpr int kPrRawJ = 16;      // workgroups per channel and raw frame
+#ifndef WFST_PR_RAW_J
+#define WFST_PR_RAW_J 16
+#endif
+constexpr int kPrRawJ = WFST_PR_RAW_J;      // workgroups per channel and raw frame
 struct ScanShared {
   u64 red[2][kBT / 64];
   int changed, any_changed, cnt, err;
@@ -3689,7 +3692,10 @@ __device__ __forceinline__ bool prune_due(const DecoderDev &D, int c, const int3
 // ... and is its share of never-priced links large enough for the several-workgroup path (lattice_prune_raw_kernel) to pay?  Its
 // workgroups meet five times a frame; below a few hundred thousand links the one-workgroup walk in LDS is done sooner
 // (beam 13 of the bench: 12 k links a frame; beam 15: 45 k, 400 k in the heaviest channels): DecoderDev::prune_raw_min.
-constexpr int kPrRawMaxJ = 32;        // workgroups a channel takes at most (a meeting of a hundred workgroups costs more than their shares save)
+#ifndef WFST_PR_RAW_MAXJ
+#define WFST_PR_RAW_MAXJ 24
+#endif
+constexpr int kPrRawMaxJ = WFST_PR_RAW_MAXJ;        // workgroups a channel takes at most (a meeting of a hundred workgroups costs more than their shares save; 8 / 12 / 16 / 24 / 32 / 64: 142.1 / 138.9 / 139.1 / 138.5 / 140.5 / 153.0 ms per beam-15 step)
 __device__ __forceinline__ int prune_raw_links(const DecoderDev &D, int c) {
   const ChanCtl *cl = D.ctl + c;
   const int32_t *lo = D.link_off + (size_t)c * (D.max_frames + 3);
@@ -3726,8 +3732,14 @@ __global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const 
 // the launch is written by atomics and read by agent-scope loads.  min is order independent and every link_extra is computed as in
 // prune_pass: the extras, and with them which tokens and links die, are those of the single-workgroup walk bit for bit.
 // lattice_prune_kernel then goes on with the frames priced before (its LDS path, the delta stopping rule) from frame pruned_upto - 1.
-constexpr int kPrRawT = 256;
-constexpr int kPrRawU = 4;
+#ifndef WFST_PR_RAW_T
+#define WFST_PR_RAW_T 256
+#endif
+#ifndef WFST_PR_RAW_U
+#define WFST_PR_RAW_U 4
+#endif
+constexpr int kPrRawT = WFST_PR_RAW_T;
+constexpr int kPrRawU = WFST_PR_RAW_U;
 
 // all the workgroups of the channel meet: *seq counts this workgroup's barriers
 __device__ __forceinline__ bool raw_barrier(int32_t *cnt, int J, int *seq, bool release) {
