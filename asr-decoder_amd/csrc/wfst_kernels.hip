@@ -2657,7 +2657,10 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
 // =========================================================================================
 constexpr int kPrLds = 16384;    // {extra, cost} pairs of the walk kept in LDS (128 KB): the frame being priced, and the frame after it where both fit
 constexpr int kPrChunk = 8192;   // items of one compaction sweep (kBT threads x 8)
-constexpr int kPrSlabs = 8;      // workgroups per channel of a compaction's flag sweeps (prune_flags; round 5: 4 -> 8)
+#ifndef WFST_PR_SLABS
+#define WFST_PR_SLABS 8
+#endif
+constexpr int kPrSlabs = WFST_PR_SLABS;      // workgroups per channel of a compaction's flag sweeps (prune_flags; round 5: 4 -> 8)
 constexpr int kPrSlabBase = 40;  // their survivor counts in the channel's parameter block: [40, 40 + 2 x kPrSlabs)
 constexpr int kPrParInts = kPruneParInts;   // a channel's parameter block (DecoderDev::prune_par): [0, 16) the compaction's {run, c_lo, tokens lo / hi, frame-0 bound, links lo / hi, nd, slab counts}; [16, 32) lattice_emit's counters; [60, 62) the closure launch's meeting word (kClSlabWord); then:
 constexpr int kPrRawCount = 32;  // ... and of the raw frames' launches: workgroups of the channel that have finished their share of the frame,
