@@ -2656,7 +2656,10 @@ __device__ __forceinline__ void frame_boundary_fused(const DecoderDev &D, int c,
 //   raw frames since the last pass -- bounded, whatever the utterance length.
 // =========================================================================================
 constexpr int kPrLds = 16384;    // {extra, cost} pairs of the walk kept in LDS (128 KB): the frame being priced, and the frame after it where both fit
-constexpr int kPrChunk = 8192;   // items of one compaction sweep (kBT threads x 8)
+#ifndef WFST_PR_CHUNK
+#define WFST_PR_CHUNK 8192
+#endif
+constexpr int kPrChunk = WFST_PR_CHUNK;   // items of one compaction sweep (kBT threads x 8)
 #ifndef WFST_PR_SLABS
 #define WFST_PR_SLABS 8
 #endif
