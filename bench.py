@@ -136,6 +136,8 @@ def parse():
     ap.add_argument("--graph-cache", default="/tmp/wfst_bench_graph_%d.bin")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child runs of this script, "
                     "FETCH_SIZE and WRITE_SIZE, one step each with the kernels enqueued one by one): quote the stored passes of profiles/traffic_latest.json")
+    ap.add_argument("--no-profile-step", action="store_true", help="skip the extra instrumented step behind the timed region (the rocprofv3 --pmc "
+                                                                   "child passes: every launch the counters see then belongs to the --steps steps)")
     ap.add_argument("--detail-out", default="", help="where the FULL result (every leg, curve, count and note) is written as JSON; default "
                     "bench_detail.json beside this script (and gpurun_out/bench_detail.json when that directory exists).  The final "
                     "stdout line is the compact summary of it (summary_line(): < 4 KB, scalars only)")
@@ -346,7 +348,7 @@ def measure_traffic(a, workload_args):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1",
-                   "--warmup", "0", "--cpu-sample", "0", "--no-service-point", "--no-legs", "--no-traffic", "--no-hip-graph", "--groups", "1",
+                   "--warmup", "0", "--cpu-sample", "0", "--no-service-point", "--no-legs", "--no-traffic", "--no-hip-graph", "--no-profile-step", "--groups", "1",
                    "--detail-out", os.path.join(tmp, ctr + ".json")] + workload_args
             pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             fs = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
@@ -369,6 +371,20 @@ def measure_traffic(a, workload_args):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return ({c: kb[c] * 1024.0 / max(launches[c], 1) for c in kb}, dict(launches), time.time() - t0)
+
+
+def traffic_per_launch(child_bytes_per_launch, child_launches_per_step, launches_per_step):
+    """HBM bytes per launch of THIS run from a counter pass made with another launch shape (one channel group: whole-batch launches):
+    the class's bytes of one step, over this run's launches of the class per step.  (Round 5's line was 2x too large: the child ran
+    two steps -- the timed one and the instrumented one -- and its launch count was taken for one step's.)"""
+    return float(child_bytes_per_launch) * float(child_launches_per_step) / float(max(launches_per_step, 1))
+
+
+def stored_launches_per_step(entry, klass, default):
+    """profiles/traffic_latest.json: `launches_per_step` since round 6; the rounds before stored `launches` of passes that ran TWO steps"""
+    if "launches_per_step" in entry:
+        return entry["launches_per_step"].get(klass, default)
+    return entry.get("launches", {}).get(klass, 2 * default) / 2.0
 
 
 LINE_LIMIT = 4000   # bytes of the final stdout line (the driver parses it; round 4's 29 KB line was not parsed)
@@ -430,11 +446,13 @@ def summary_line(out, detail_path=None):
     service-point workloads).  Shape of reference: the one RTF line of kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:189-192."""
     top = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                    "vs_baseline", "dtype", "data")}
-    top["metric"] = str(top["metric"])[:150]
+    top["metric"] = str(top["metric"])[:100]
     c = out.get("config", {})
     cfg = {k: c[k] for k in ("workload", "global_batch", "frames_per_utt", "parallelism", "rtfx", "channel_groups",
                              "mean_active_tokens_per_frame", "peak_tokens_in_a_frame", "max_tokens_per_frame_limit", "degraded_frames",
-                             "utterances_with_path", "fused_epsilon_closures", "decoder_paths_same_on_every_rank") if k in c}
+                             "utterances_with_path", "fused_epsilon_closures", "decoder_paths_same_on_every_rank", "regime") if k in c}
+    if "regime" in cfg:
+        cfg["regime"] = str(cfg["regime"])[:120]
     if "workload" in cfg:
         cfg["workload"] = str(cfg["workload"])[:260]
     for k in ("parity", "lattice_parity", "parity_per_rank_sample"):
@@ -450,7 +468,7 @@ def summary_line(out, detail_path=None):
     r = out.get("roofline")
     if r:
         rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
-                                    "avg_launch_ms", "launches", "channel_groups", "profiled_step_ms")}
+                                    "avg_launch_ms", "launches", "channel_groups", "profiled_step_ms", "traffic_over_algorithmic")}
         rr["traffic_measured_in_run"] = bool(r.get("traffic_measured_in_run", False))
         rr["whole_path_frac"] = r.get("whole_path", {}).get("frac_over_step_time")
         rr["whole_path_bytes_per_step"] = r.get("whole_path", {}).get("algorithmic_bytes_per_step")
@@ -489,7 +507,7 @@ def summary_line(out, detail_path=None):
              "degraded_frames", "cpu_self_bit_identical", "kernel", "cpu_baseline_cores", "cpu_baseline_kind")
     line = dump()
     if len(line) > LINE_LIMIT:
-        for part, key, n in (("cpu_baseline", "sample", 60), ("config", "workload", 120), ("config", "parallelism", 40)):
+        for part, key, n in (("cpu_baseline", "sample", 60), ("config", "workload", 120), ("config", "parallelism", 40), ("config", "regime", 50)):
             if part in top and key in top[part]:
                 top[part][key] = str(top[part][key])[:n]
         top["metric"] = top["metric"][:100]
@@ -592,10 +610,41 @@ def oracle_counts(graph_path, cd, mats, m, order_free=False, want_paths=None):
     return dict(N=int(tot[0]), E=int(tot[1]), Z=int(tot[2]), ties_on_best_path=int(tot[5]))
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` with no rank environment: start the N ranks ourselves -- `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N ... bench.py <same arguments>` as a CHILD process (no exec, and nothing in this parent has touched torch or the
+    GPU), relay its output (rank 0's JSON line is the last stdout line) and exit with its code.  The shape it stands for: N workers
+    over one shared graph, v2-asrbin/v2-asr-service.cc:95-105 -- here one process and one graph replica per GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    log("[launcher] %s" % " ".join(cmd))
+    pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    last = None
+    for raw in pr.stdout:   # (stderr goes straight through; stdout is relayed line by line so that the JSON line stays the last one)
+        line = raw.decode(errors="replace").rstrip("\n")
+        if line.startswith("{") and line.endswith("}"):
+            last = line
+        else:
+            log(line)
+    rc = pr.wait()
+    if last is not None:
+        print(last, flush=True)
+    raise SystemExit(rc)
+
+
 def main():
     a = parse()
     if a.mu is None:
         a.mu = -4.0 if a.workload == "multi" else -2.0
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        launch_ranks(a)   # (before torch is imported: the parent never initialises HIP)
     import torch
     import torch.distributed as dist
 
@@ -866,31 +915,31 @@ def main():
         post = None
     # ---- roofline pass: one more step with HIP events around every kernel launch -----------
     gstats = [dec.stats(c) for c in range(B)]
-    dec.set_profiling(True)
-    torch.cuda.synchronize(dev)
-    tp0 = time.perf_counter()
-    res_p = step()
-    if hasattr(step, "drain"):
-        step.drain(res_p)
-    torch.cuda.synchronize(dev)
-    profiled_step_ms = 1e3 * (time.perf_counter() - tp0)   # the instrumented step itself (slower than a timed one: event pairs, no hipGraph)
+    profiled_step_ms = 0.0
+    if not a.no_profile_step:
+        dec.set_profiling(True)
+        torch.cuda.synchronize(dev)
+        tp0 = time.perf_counter()
+        res_p = step()
+        if hasattr(step, "drain"):
+            step.drain(res_p)
+        torch.cuda.synchronize(dev)
+        profiled_step_ms = 1e3 * (time.perf_counter() - tp0)   # the instrumented step itself (slower than a timed one: event pairs, no hipGraph)
     prof = dec.profile()
-    dec.set_profiling(False)
+    if not a.no_profile_step:
+        dec.set_profiling(False)
 
     regime = ("beam-only pruning (max_active never binds, min_active 0): bit-exact best-path parity with the reference CPU decoder"
               if a.max_active >= 1000000 and a.min_active == 0 else
               "max_active %d / min_active %d: where they bind the reference's cutoff depends on its hash-list visiting order "
               "(order-free parity, DESIGN.md section 4)" % (a.max_active, a.min_active))
     out = {
-        "metric": ("frames/sec decoded WITH on-the-fly LM rescoring (biglm, BASELINE configs[3]: every word-labelled arc costs "
-                   "new LM - old LM, tokens keyed by (graph state, LM pair state)); parity: bit-exact with the CPU restatement of "
-                   "the reference's biglm decoder in its fixed DiffArpaLm mode (DESIGN.md section 4)" if a.biglm else
-                   "frames/sec decoded, log-likelihoods handed over as HOST matrices every step (PCIe-inclusive); " + regime
-                   if a.host_feed else
-                   "frames/sec decoded (RTFx = value/100) at fixed beam; " + regime
-                   if a.lattice_links == 0 else
-                   "frames/sec decoded WITH lattice generation (forward links, lattice-beam pruning at finalize, %d-best per "
-                   "utterance%s; BASELINE configs[4]); " % (a.nbest, " + the determinized lattice of every utterance" if a.determinize else "") + regime),
+        # (`metric` stays under 100 characters -- the driver's record cuts it there; what the number is measured on and in which
+        # pruning regime is config.workload / config.regime)
+        "metric": ("frames/sec decoded with on-the-fly LM rescoring (biglm, BASELINE configs[3])" if a.biglm else
+                   "frames/sec decoded, log-likelihoods handed over as host matrices every step (PCIe-inclusive)" if a.host_feed else
+                   "frames/sec decoded (RTFx = value/100) at fixed beam" if a.lattice_links == 0 else
+                   "frames/sec decoded with lattice generation%s (BASELINE configs[4])" % (" + determinization" if a.determinize else "")),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded hclg-like graph + %s log-likelihoods, SURVEY.md 8(d))" % (
@@ -904,6 +953,12 @@ def main():
             "global_batch": world * B, "frames_per_utt": T, "parallelism": "utterance-sharded x%d (graph replicated)" % world,
             "rtfx": value / 100.0,
             "channel_groups": int(dec.n_groups),
+            "regime": regime,
+            "what": ("every word-labelled arc costs new LM - old LM, tokens keyed by (graph state, LM pair state); parity: bit-exact with the CPU "
+                     "restatement of the reference's biglm decoder in its fixed DiffArpaLm mode (DESIGN.md section 4)" if a.biglm else
+                     "forward links, lattice-beam pruning every prune_interval frames and at finalize, %d-best per utterance%s" % (
+                         a.nbest, " + the determinized lattice of every utterance" if a.determinize else "") if a.lattice_links > 0 else
+                     "InitDecoding -> AdvanceDecoding(all frames) -> FinalizeDecoding -> GetBestPath + LatticeToVector for every utterance"),
         },
     }
     pf = dec.path_flags()
@@ -1134,11 +1189,12 @@ def main():
         avg_ms = k_ms / max(k_n, 1)
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         all_ms = prof["expand_ms"] + prof["insert_ms"] + prof["closure_ms"]
-        # HBM traffic per launch comes from rocprofv3 --pmc passes (separate runs, tools/profile_round.sh);
-        # it cannot be collected inside this process, so the stored summary is quoted WITH its origin
-        traffic, traffic_src = None, None
+        # HBM traffic per launch: rocprofv3 --pmc passes cannot be collected inside this process; they are child runs of this script
+        # (measure_traffic), made NOW.  A measurement that cannot be made leaves `traffic` null -- the stored passes of an earlier
+        # run (profiles/traffic_latest.json) are quoted under `traffic_stored`, with their origin, never under `traffic`.
+        traffic, traffic_src, traffic_stored = None, None, None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        # the passes were made on three configurations: the headline workload, the biglm leg and the beam-15 lattice leg
+        # the stored passes were made on three configurations: the headline workload, the biglm leg and the beam-15 lattice leg
         std = a.batch == 128 and a.frames == 300 and a.states == 2850000 and a.workload == "multi" and a.max_active == 1000000 and a.min_active == 0
         which = None
         if std and a.biglm and a.beam == 13.0 and a.lattice_links == 0:
@@ -1147,18 +1203,18 @@ def main():
             which = "lattice_beam15"
         elif std and not a.biglm and a.lattice_links == 0 and a.beam == 13.0:
             which = "headline"
-        if which is None:
-            traffic_src = "not measured for this configuration (profiles/traffic_latest.json holds the passes of the headline, biglm and beam-15 lattice configurations)"
-        elif os.path.exists(tj):
+        if which is not None and os.path.exists(tj):
             try:
                 tjd = json.load(open(tj))
-                traffic = tjd.get(which, {}).get(dom + "_bytes_per_launch")
-                if traffic is not None:   # (stored per whole-batch launch: brought to this run's launch count)
-                    traffic = traffic * tjd[which].get("launches", {}).get(dom, k_n) / float(max(k_n, 1))
-                traffic_src = "NOT measured in this run: profiles/traffic_latest.json [%s] (%s); one channel group, i.e. whole-batch launches" % (which, tjd.get("origin", "stored rocprofv3 --pmc passes"))
+                ts = tjd.get(which, {}).get(dom + "_bytes_per_launch")
+                if ts is not None:   # (stored per whole-batch launch of a one-group run: brought to this run's launch count)
+                    traffic_stored = {"bytes_per_launch": traffic_per_launch(ts, stored_launches_per_step(tjd[which], dom, k_n), k_n),
+                                      "origin": "NOT measured in this run: profiles/traffic_latest.json [%s] (%s)" % (which, tjd.get("origin", "stored rocprofv3 --pmc passes"))}
             except Exception:
-                traffic = None
+                traffic_stored = None
+        traffic_src = "not measured in this run" + (" (--no-traffic)" if a.no_traffic else "")
         measured = None
+        ng = int(dec.n_groups)
         if world == 1 and not a.no_traffic and not a.no_hip_graph:
             wl = ["--batch", str(B), "--frames", str(T), "--states", str(a.states), "--pdfs", str(P), "--beam", str(a.beam), "--max-active", str(a.max_active),
                   "--min-active", str(a.min_active), "--workload", a.workload, "--paths", str(a.paths), "--mu", str(a.mu), "--sigma", str(a.sigma),
@@ -1170,19 +1226,27 @@ def main():
                 wl += ["--lattice-links", str(a.lattice_links), "--nbest", str(a.nbest)] + (["--determinize"] if a.determinize else [])
             if a.default_limits:
                 wl += ["--default-limits"]
+            # (the children allocate a decoder of their own on this GPU: this process lets go of its own first -- everything below
+            # that needs it has been read; the service-point and leg runs make theirs anew)
+            dec.free()
+            dec = None
             measured = measure_traffic(a, wl)
             if measured is not None:
-                # (the passes run one channel group: a launch there covers the whole batch; per launch of THIS run = the same bytes
-                # over this run's launch count)
-                traffic = measured[0].get(dom, 0.0) * measured[1].get(dom, 0) / float(max(k_n, 1))
-                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this script (one step each, one channel "
-                               "group, kernels enqueued one by one, %.0f s), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch" % measured[2])
+                # (the passes run ONE step with one channel group: a launch there covers the whole batch; per launch of THIS run =
+                # the child's bytes per launch x its launches per step / this run's launches per step)
+                traffic = traffic_per_launch(measured[0].get(dom, 0.0), measured[1].get(dom, 0), k_n)
+                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this script (ONE step each and no "
+                               "instrumented extra step, one channel group, kernels enqueued one by one, %.0f s), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch" % measured[2])
+            else:
+                traffic_src = "the rocprofv3 --pmc child passes of this run failed: traffic is null (stderr has the reason)"
         step_ms = 1000.0 * dt / a.steps
         whole_bytes = sum(kb.values())
         out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "traffic_measured_in_run": measured is not None,
-                           "traffic_per_class": ({"bytes_per_launch": measured[0], "launches": measured[1]} if measured is not None else None),
+                           "traffic_per_class": ({"bytes_per_launch": measured[0], "launches_per_step": measured[1], "steps": 1} if measured is not None else None),
+                           "traffic_stored": traffic_stored,
+                           "traffic_over_algorithmic": (traffic / per_launch_bytes) if (traffic and per_launch_bytes > 0) else None,
                            "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
                            "kernel_ms_per_step": {k: prof[k + "_ms"] for k in ("expand", "insert", "closure")},
                            "all_kernels_achieved_GBs": (whole_bytes / (all_ms * 1e-3) / 1e9) if all_ms > 0 else 0.0,
@@ -1196,7 +1260,6 @@ def main():
                                           "frac_over_kernel_time": (whole_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms > 0 else 0.0,
                                           "frac_over_step_time": whole_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                            "measured": "hipEvent pairs around every launch on the stream it is launched on, one extra step after the timed region"}
-        ng = int(dec.n_groups)
         if ng > 1:
             # Channel groups: each group's launches run on its own stream and overlap the other group's (that is what the
             # groups are for), so "one launch" shares the chip with another launch of the same kernel for part of its
@@ -1217,7 +1280,8 @@ def main():
                                         "executing (the groups' launches overlap; per-launch figures under per_launch)" % (dom + "_kernel"))
     # ---- second workload: SURVEY 8(d) generator at the reference service's operating point ----
     if rank == 0 and world == 1 and not a.no_service_point and a.lattice_links == 0 and not a.host_feed and a.workload == "multi" and not a.biglm:
-        dec.free()
+        if dec is not None:
+            dec.free()
         dec = None
         t0 = time.time()
         cd2 = dict(cd, max_active=7000, min_active=200)

@@ -94,3 +94,70 @@ def test_detail_file_is_strict_json(tmp_path):
         d = _strict(f.read())
     assert d["legs"]["biglm"]["roofline"]["kernel"].endswith("_kernel")
     assert d["config"]["mean_active_tokens_per_frame"] is None
+
+
+def test_traffic_is_per_launch_of_this_run():
+    """the line's traffic over its algorithmic bytes per launch must be the counter passes' bytes per whole-batch
+    launch over the algorithmic whole-batch bytes (round 5's was 2x that: the child pass ran two steps, its launches were taken for one
+    step's).  Canned: round 5's own figures -- one-group child, 300 expansion launches of 109.4 MB per step; the run: three channel
+    groups, 900 launches per step, 47.45 MB algorithmic per whole-batch launch."""
+    b = _bench()
+    child_bpl, child_lps, run_lps = 109435074.45, 300, 900
+    alg_whole_batch = 47.45e6
+    alg_per_launch = alg_whole_batch * child_lps / run_lps
+    t = b.traffic_per_launch(child_bpl, child_lps, run_lps)
+    assert abs(t / alg_per_launch - child_bpl / alg_whole_batch) < 1e-9
+    assert abs(t / alg_per_launch - 2.306) < 0.01
+    # the stored passes of the rounds before ran two steps ("launches"); since round 6 they store launches_per_step
+    assert b.stored_launches_per_step({"launches": {"expand": 600}}, "expand", 900) == 300
+    assert b.stored_launches_per_step({"launches_per_step": {"expand": 300}}, "expand", 900) == 300
+    o = _canned()
+    o["roofline"]["traffic"] = t
+    o["roofline"]["algorithmic_bytes_per_launch"] = alg_per_launch
+    o["roofline"]["traffic_over_algorithmic"] = t / alg_per_launch
+    d = _strict(b.summary_line(o, None))
+    assert abs(d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"] - child_bpl / alg_whole_batch) < 1e-3
+    assert abs(d["roofline"]["traffic_over_algorithmic"] - 2.306) < 0.01
+
+
+def test_metric_is_short():
+    b = _bench()
+    o = _canned()
+    o["metric"] = "m" * 300
+    assert len(_strict(b.summary_line(o, None))["metric"]) <= 100
+
+
+def test_gpus_n_launches_its_own_ranks(monkeypatch, capsys):
+    """VERDICT r5 missing #1: `python bench.py --gpus 8` with no rank environment starts torch.distributed.run itself, as a child
+    process, before torch is imported; relays rank 0's JSON line as the last stdout line and exits with the child's code."""
+    import subprocess
+    import sys
+    import types
+
+    b = _bench()
+    seen = {}
+
+    class FakePopen:
+        def __init__(self, cmd, stdout=None, env=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = [b"[rank 0] some log\n", b'{"metric":"m","value":1.0,"n_gpus":8}\n']
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(subprocess, "Popen", FakePopen)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    before = "torch" in sys.modules
+    with pytest.raises(SystemExit) as e:
+        b.main()
+    assert e.value.code == 0
+    assert ("torch" in sys.modules) == before   # the parent did not import torch on the way
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+    out = capsys.readouterr().out.strip().splitlines()
+    assert json.loads(out[-1])["n_gpus"] == 8 and len(out) == 1

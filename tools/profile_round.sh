@@ -21,8 +21,8 @@ CFG[lattice_beam15]="--beam 15 --lattice-beam 8 --lattice-links 25165824 --arena
 for name in headline biglm lattice_beam15; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_$name" -- python3 bench.py $COMMON ${CFG[$name]} --steps 2 --warmup 1 > "$O/bench_kt_$name.json" 2> "$O/kt_$name.err"
   # counter passes: kernels enqueued one by one (--no-hip-graph) so that every dispatch is attributed
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch_$name" -- python3 bench.py $COMMON ${CFG[$name]} --steps 1 --warmup 0 --no-hip-graph > "$O/bench_fetch_$name.json" 2> "$O/fetch_$name.err"
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write_$name" -- python3 bench.py $COMMON ${CFG[$name]} --steps 1 --warmup 0 --no-hip-graph > "$O/bench_write_$name.json" 2> "$O/write_$name.err"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch_$name" -- python3 bench.py $COMMON ${CFG[$name]} --steps 1 --warmup 0 --no-hip-graph --no-profile-step > "$O/bench_fetch_$name.json" 2> "$O/fetch_$name.err"
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write_$name" -- python3 bench.py $COMMON ${CFG[$name]} --steps 1 --warmup 0 --no-hip-graph --no-profile-step > "$O/bench_write_$name.json" 2> "$O/write_$name.err"
 done
 # the DEFAULT (two-group) headline run under the tracer, for the record
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_groups2" -- python3 bench.py --cpu-sample 0 --no-service-point --no-traffic --no-legs --steps 2 --warmup 1 > "$O/bench_kt_groups2.json" 2> "$O/kt_groups2.err"

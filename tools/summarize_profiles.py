@@ -66,7 +66,7 @@ def main():
                 a[1] += (2.0 * fk + wk) * 1024.0
         summary["configs"][name] = per
         traffic[name] = {c + "_bytes_per_launch": v / n for c, (n, v) in cls.items()}
-        traffic[name]["launches"] = {c: n for c, (n, v) in cls.items()}
+        traffic[name]["launches_per_step"] = {c: n for c, (n, v) in cls.items()}   # (the passes run ONE step: --steps 1 --warmup 0 --no-profile-step)
     k2 = sorted(glob.glob(os.path.join(P, "kt_groups2", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if k2:
         shutil.copy(k2[-1], os.path.join(OUT, "%s_kernel_stats_two_groups_traced.csv" % tag))
