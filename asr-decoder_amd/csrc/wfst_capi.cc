@@ -1225,6 +1225,12 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     for (auto &ev : d->gevents) if (ge == hipSuccess) ge = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (ge != hipSuccess) { delete d; return fail(WFST_E_DEVICE, "stream/event creation failed"); }
   }
+  if (d->D.lattice && d->D.prune_raw) {
+    // the raw launch's workgroups wait for each other: taken only where every workgroup of all the groups' launches is resident at
+    // once (a smaller or partitioned part: the one-workgroup walk, always sound)
+    const int per = (n_channels + d->n_groups - 1) / d->n_groups;
+    if ((long long)prune_raw_resident_workgroups(d->device) < (long long)prune_raw_grid(per) * d->n_groups) d->D.prune_raw = 0;
+  }
   d->expand_wgs = O.expand_workgroups;
   d->insert_wgs = O.insert_workgroups;
   d->gpar.assign(8, 0);
@@ -2881,6 +2887,17 @@ int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t sta
   stats[2] = (int64_t)v[2];
   stats[3] = (int64_t)(v[3] & 0xFFFFFFFFull);
   stats[4] = (int64_t)(v[3] >> 32);
+  return WFST_OK;
+}
+
+int wfst_decoder_get_prune_raw_abandoned(wfst_decoder *d, int32_t channel, int32_t *n_passes) {
+  if (!d || !n_passes || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
+  if (!d->D.lattice) return fail(WFST_E_STATE, "lattice statistics need a decoder created with wfst_limits.lattice_links > 0");
+  HIP_TRY(hipSetDevice(d->device));
+  for (hipStream_t st : d->gstreams) if (st) HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipMemcpyAsync(n_passes, d->prune_par.p + (size_t)channel * kPruneParInts + kPrRawAbandonCount, sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  if (!d->D.prune_raw) *n_passes = -1;   // (the several-workgroup raw pass is off on this device: nothing to abandon)
   return WFST_OK;
 }
 

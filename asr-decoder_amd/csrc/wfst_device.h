@@ -409,6 +409,8 @@ struct DetCaps;
 #include "wfst_determinize.h"
 namespace wfst {
 constexpr int kPruneParInts = 64;   // ints of a channel's block of DecoderDev::prune_par
+constexpr int kPrRawAbandon = 37;       // ... [37]: the raw launch gave this pass up (a workgroup of the channel waited too long at a meeting): lattice_prune_kernel prices the raw frames itself
+constexpr int kPrRawAbandonCount = 38;  // ... [38]: how often since InitDecoding (wfst_decoder_get_prune_raw_abandoned)
 constexpr int kClSlabWord = 60;     // ... of which [60, 62), one 64-bit word: the closure launch's meeting of a channel's workgroups (finalize_frame)
 
 struct DetDev {
@@ -474,6 +476,8 @@ void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32
                     int group, int par, hipStream_t s, int after_insert);
 // stage: -1 = the step's four launches; 0..3 = one of them (raw frames, walk, flag sweeps, moves): a profiled step times them one by one
 void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target_dev, int group, int par, hipStream_t s, int stage);
+int prune_raw_resident_workgroups(int device);   // lattice_prune_raw_kernel: workgroups the device holds at once (occupancy x compute units)
+int prune_raw_grid(int chan_cnt);                // ... and the grid of one launch over chan_cnt channels
 void launch_set_finalized(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);
 void launch_delay(int microseconds, hipStream_t s);
 void launch_lattice_prune(const DecoderDev &D, const int32_t *chan_list_dev, int n, hipStream_t s);

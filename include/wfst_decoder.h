@@ -131,6 +131,9 @@ typedef struct wfst_options {
                                   0x800: a running back-pruning pass prices the never-priced frames of EVERY
                                   channel on several workgroups (by default only channels with 800 k such links
                                   or more: the LDS walk is faster below); same results, for the tests.
+                                  0x400: with 0x800, one workgroup of every such channel stays away from the
+                                  first meeting -- the pass is abandoned after its 40 ms time-out and done over
+                                  by the one-workgroup walk; same results, for the tests.
                                   0x100 / 0x200 / 0x300: a lattice decoder's closure launches run 1 / 2 / 8
                                   workgroups per channel instead of 4 (they share the frame's epsilon links);
                                   same results, for the tests.
@@ -469,6 +472,12 @@ int wfst_decoder_channel_groups(wfst_decoder *d);
  * recorded, links priced by the PruneActiveTokens / FinalizeDecoding walks (one per link and sweep), tokens priced by them,
  * tokens + links scanned by the compactions, tokens + links the compactions moved}. */
 int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t stats[5]);
+
+/* Running back-pruning passes (PruneActiveTokens, base-inl.h:439-607) of the channel since its last init whose several-workgroup
+ * pricing of the never-priced frames was ABANDONED -- a workgroup waited 40 ms for its siblings (a chip shared with other
+ * processes) -- and done over by the one-workgroup walk: the same lattice, later; never an error.  -1: the several-workgroup pass is
+ * off on this device (its grid would not be resident at once). */
+int wfst_decoder_get_prune_raw_abandoned(wfst_decoder *d, int32_t channel, int32_t *n_passes);
 
 /* Frames of the channel's utterance (since its last init) on which the per-frame token limit BOUND: best-path decoders on
  * the fused graph rows treat wfst_limits.max_tokens_per_frame as a max_active, not as a capacity -- a frame that reaches
