@@ -31,6 +31,15 @@
 //                  b mod n -- utterances share nothing but the read-only graph, so there is no exchange between devices, and the
 //                  results are merged in input order on the host (the reference's model of N worker threads over one shared
 //                  graph, v2-asrbin/v2-asr-service.cc:95-105, with one graph replica per device).  A device may be listed twice.
+//   --threads=N    the reference SERVICE's shape (v2-asr/v2-asr-work-thread.h:66, v2-asrbin/v2-asr-service.cc:95-105): N worker threads, each
+//                  with its own DecoderItf object, take the utterances in turn -- InitDecoding, AdvanceDecoding in chunks of
+//                  --chunk frames (all at once without it), FinalizeDecoding, GetBestPath.  The objects are GpuLatticeDecoders
+//                  over private 1-channel device decoders, or
+//   --pool=C       over ONE GpuChannelPool of C channels (C >= N): the threads' requests are batched into one device call per
+//                  kind (gpu-asr/v1-gpu-kaldi-worker-pool.h:20-204: the dynamic batcher's shape); --linger-us=U: how long the
+//                  batcher waits for the other leased channels' requests (50)
+//   --pull         the decodable is a plain DecodableInterface: every score goes through LogLikelihood(frame, index) (without it
+//                  the rows are taken in one piece, MatrixDecodable)
 //   --nbest=N      also print the N-best word sequences of every utterance (the service's
 //                  GetNbestTxt, kaldi-online-nnet3-my-decoder.cc:139-150) as "KEY-k w1 w2 ..." to
 //                  stdout and "LOG KEY-k tot_score .. lm_score .." to stderr (lattice mode)
@@ -90,6 +99,20 @@ class HostMatrixDecodable : public MatrixDecodable {
   const Utt &_u;
   int _ready;
 };
+// ... and as the reference's callers see a decodable: LogLikelihood(frame, index) only
+class PullDecodable : public DecodableInterface {
+ public:
+  explicit PullDecodable(const Utt &u) : _u(u), _ready(u.frames) {}
+  float LogLikelihood(int f, int i) override { return _u.m[(size_t)f * _u.cols + i]; }
+  bool IsLastFrame(int f) const override { return f == _u.frames - 1; }
+  int NumFramesReady() const override { return _ready; }
+  void SetFramesReady(int n) { _ready = std::min(n, _u.frames); }
+  int NumIndices() const override { return _u.cols - 1; }
+
+ private:
+  const Utt &_u;
+  int _ready;
+};
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -99,7 +122,8 @@ int main(int argc, char **argv) {
     bool single = false, determinize = false;
     std::string lattice_file, lattice_text;
     long long lattice_links = 1ll << 22;
-    int nbest = 0, inflight = 1, chunk = 0;
+    int nbest = 0, inflight = 1, chunk = 0, n_threads = 0, pool_channels = 0, linger_us = 50;
+    bool pull = false;
     std::vector<int> devices(1, 0);
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -114,6 +138,10 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 8, "--nbest=") == 0) nbest = atoi(a.c_str() + 8);
       else if (a.compare(0, 11, "--inflight=") == 0) inflight = std::max(1, atoi(a.c_str() + 11));
       else if (a.compare(0, 8, "--chunk=") == 0) chunk = std::max(0, atoi(a.c_str() + 8));
+      else if (a.compare(0, 10, "--threads=") == 0) n_threads = std::max(0, atoi(a.c_str() + 10));
+      else if (a.compare(0, 7, "--pool=") == 0) pool_channels = std::max(0, atoi(a.c_str() + 7));
+      else if (a.compare(0, 12, "--linger-us=") == 0) linger_us = std::max(0, atoi(a.c_str() + 12));
+      else if (a == "--pull") pull = true;
       else if (a.compare(0, 10, "--devices=") == 0) {
         devices.clear();
         for (size_t p0 = 10; p0 <= a.size();) {
@@ -250,7 +278,80 @@ int main(int argc, char **argv) {
       frame_count += u.frames;
       ++num_success;
     };
-    if (single) {  // the reference's shape: one decoder object, one utterance at a time
+    if (n_threads > 0) {
+      // the service's shape: N worker threads, one DecoderItf object each, over a pool's channels or private device decoders
+      if (devices.size() > 1) { std::cerr << "--threads: one device\n"; return 1; }
+      if (pool_channels > 0 && pool_channels < n_threads) { std::cerr << "--pool must hold a channel per thread\n"; return 1; }
+      std::unique_ptr<GpuChannelPool> pool;
+      if (pool_channels > 0)
+        pool.reset(biglm ? new GpuChannelPool(&fst, opt, lm1p, lm2p, pool_channels, &limits, linger_us)
+                         : new GpuChannelPool(&fst, opt, pool_channels, &limits, linger_us));
+      struct Res { Lattice best; bool ok = false; Lattice lat; bool lat_ok = false; std::vector<Lattice> nbest; };
+      std::vector<Res> res(utts.size());
+      std::vector<std::string> errors((size_t)n_threads);
+      std::atomic<size_t> next(0);
+      std::atomic<int> ready_threads(0);
+      auto worker = [&](int k) {
+        try {
+          std::unique_ptr<GpuLatticeDecoder> dp(pool ? new GpuLatticeDecoder(pool.get())
+                                                     : biglm ? new OnlineLatticeDecoderMempoolBiglm(&fst, opt, lm1p, lm2p, &limits)
+                                                             : new GpuLatticeDecoder(&fst, opt, &limits));
+          DecoderItf &decode = *dp;   // (the reference's interface is all the loop below uses, results aside)
+          // every thread has its decoder before the first utterance starts (the service creates them at start-up)
+          ready_threads.fetch_add(1);
+          while (ready_threads.load() < n_threads) std::this_thread::yield();
+          for (;;) {
+            const size_t ui = next.fetch_add(1);
+            if (ui >= utts.size()) return;
+            const Utt &u = utts[ui];
+            HostMatrixDecodable md(u);
+            PullDecodable pd(u);
+            AmInterface *am = pull ? (AmInterface *)&pd : (AmInterface *)&md;
+            decode.InitDecoding();
+            if (chunk > 0) {
+              for (int ready = chunk;; ready += chunk) {
+                md.SetFramesReady(ready);
+                pd.SetFramesReady(ready);
+                decode.AdvanceDecoding(am);
+                if (ready >= u.frames) break;
+              }
+            } else {
+              decode.AdvanceDecoding(am);
+            }
+            decode.FinalizeDecoding();
+            Res &r = res[ui];
+            r.ok = decode.GetBestPath(&r.best);
+            if (want_lattice && (!lattice_file.empty() || !lattice_text.empty()))
+              r.lat_ok = determinize ? dp->GetLattice(&r.lat) : decode.GetRawLattice(&r.lat);
+            if (nbest > 0) {
+              if (exact_nbest) dp->GetNbest(r.nbest, nbest);
+              else dp->GetNbestShortlist(r.nbest, nbest);
+            }
+          }
+        } catch (const std::exception &e) {
+          errors[(size_t)k] = e.what();
+          ready_threads.fetch_add(1);   // (a constructor that failed must not leave the others waiting)
+        }
+      };
+      std::vector<std::thread> threads;
+      for (int k = 1; k < n_threads; ++k) threads.emplace_back(worker, k);
+      t0 = std::chrono::steady_clock::now();   // (the decoders' construction is inside: the service pays it once at start-up, a CLI run every time -- reported apart below)
+      worker(0);
+      for (std::thread &t : threads) t.join();
+      for (const std::string &e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+      for (size_t i = 0; i < utts.size(); ++i) {
+        emit(utts[i], res[i].best, res[i].ok);
+        if (want_lattice && (!lattice_file.empty() || !lattice_text.empty())) emit_lattice(utts[i], res[i].lat, res[i].lat_ok);
+        if (nbest > 0) emit_nbest(utts[i], res[i].nbest);
+      }
+      if (pool) {
+        const GpuChannelPool::Stats st = pool->GetStats();
+        std::cerr << "LOG pool: " << pool_channels << " channels, " << n_threads << " threads, " << st.batches << " batcher passes, " << st.requests
+                  << " requests, " << st.advance_calls << " advance calls for " << st.advance_requests << " AdvanceDecoding requests (mean batch "
+                  << (st.advance_calls ? (double)st.advance_requests / st.advance_calls : 0.0) << "), " << st.frames << " frames\n";
+      }
+    } else if (single) {  // the reference's shape: one decoder object, one utterance at a time
       std::unique_ptr<GpuLatticeDecoder> decode_p(biglm ? new OnlineLatticeDecoderMempoolBiglm(&fst, opt, lm1p, lm2p, &limits)
                                                         : new GpuLatticeDecoder(&fst, opt, &limits));
       GpuLatticeDecoder &decode = *decode_p;

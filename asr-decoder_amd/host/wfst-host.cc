@@ -231,26 +231,234 @@ const wfst_lm *ArpaLm::Handle() {
   return _lm;
 }
 
+// ---- channel pool: many decoder objects, one batched device decoder ------------------------------
+GpuChannelPool::GpuChannelPool(Fst *graph, const LatticeFasterDecoderConfig &config, int n_channels, const wfst_limits *limits, int linger_us)
+    : _dec(nullptr), _n(n_channels), _linger_us(linger_us), _n_leased(0), _stop(false), _stats() {
+  config.Check();
+  wfst_config c = config.ToC();
+  if (n_channels < 1) throw std::runtime_error("GpuChannelPool needs at least one channel");
+  if (wfst_decoder_create(graph->Handle(), &c, n_channels, limits, nullptr, &_dec) != WFST_OK) Fatal("wfst_decoder_create");
+  Start(linger_us);
+}
+GpuChannelPool::GpuChannelPool(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm, int n_channels,
+                               const wfst_limits *limits, int linger_us)
+    : _dec(nullptr), _n(n_channels), _linger_us(linger_us), _n_leased(0), _stop(false), _stats() {
+  config.Check();
+  wfst_config c = config.ToC();
+  if (n_channels < 1) throw std::runtime_error("GpuChannelPool needs at least one channel");
+  if (!oldlm || !newlm) throw std::runtime_error("biglm decoder needs both LMs");
+  if (wfst_decoder_create_biglm(graph->Handle(), &c, n_channels, limits, nullptr, oldlm->Handle(), newlm->Handle(), nullptr, &_dec) != WFST_OK)
+    Fatal("wfst_decoder_create_biglm");
+  Start(linger_us);
+}
+void GpuChannelPool::Start(int linger_us) {
+  _linger_us = std::max(0, linger_us);
+  _leased.assign((size_t)_n, 0);
+  _thread = std::thread([this] { Run(); });
+}
+GpuChannelPool::~GpuChannelPool() {
+  {
+    std::lock_guard<std::mutex> lk(_mu);
+    _stop = true;
+  }
+  _cv_work.notify_all();
+  if (_thread.joinable()) _thread.join();
+  wfst_decoder_free(_dec);
+}
+GpuChannelPool::Stats GpuChannelPool::GetStats() {
+  std::lock_guard<std::mutex> lk(_mu);
+  return _stats;
+}
+int GpuChannelPool::Lease() {
+  std::unique_lock<std::mutex> lk(_mu);
+  for (;;) {
+    for (int c = 0; c < _n; ++c)
+      if (!_leased[(size_t)c]) { _leased[(size_t)c] = 1; ++_n_leased; return c; }
+    _cv_free.wait(lk);   // (more decoder objects than channels: this one waits for a destructor)
+  }
+}
+void GpuChannelPool::Release(int c) {
+  {
+    std::lock_guard<std::mutex> lk(_mu);
+    if (c >= 0 && c < _n && _leased[(size_t)c]) { _leased[(size_t)c] = 0; --_n_leased; }
+  }
+  _cv_free.notify_one();
+}
+void GpuChannelPool::Submit(Request *r) {
+  std::unique_lock<std::mutex> lk(_mu);
+  if (_stop) throw std::runtime_error("GpuChannelPool is shutting down");
+  r->done = false;
+  r->error = nullptr;
+  _queue.push_back(r);
+  _cv_work.notify_one();
+  _cv_done.wait(lk, [&] { return r->done; });
+  lk.unlock();
+  if (r->error) std::rethrow_exception(r->error);
+}
+void GpuChannelPool::Run() {
+  std::unique_lock<std::mutex> lk(_mu);
+  for (;;) {
+    _cv_work.wait(lk, [&] { return _stop || !_queue.empty(); });
+    if (_queue.empty()) return;   // (_stop, nothing left to serve)
+    // the other leased channels' requests are on their way more often than not (their threads were released together): a short
+    // wait makes one batch of them instead of two
+    if (_linger_us > 0 && (int)_queue.size() < _n_leased)
+      _cv_work.wait_for(lk, std::chrono::microseconds(_linger_us), [&] { return _stop || (int)_queue.size() >= _n_leased; });
+    std::vector<Request *> batch;
+    batch.swap(_queue);
+    lk.unlock();
+    Execute(batch);
+    lk.lock();
+    _stats.batches += 1;
+    _stats.requests += (long long)batch.size();
+    for (Request *r : batch) r->done = true;
+    _cv_done.notify_all();
+  }
+}
+// One pass over what has arrived.  A channel has at most one request in a batch (its thread waits for it), so the kinds can be
+// served in any order: init, advance, finalize, best path, then the one-off calls.  A batched C-ABI call validates every listed
+// channel before it enqueues anything: when it refuses the batch, the requests are retried one by one and each gets its own verdict.
+void GpuChannelPool::Execute(std::vector<Request *> &batch) {
+  std::vector<Request *> by_kind[kKinds];
+  for (Request *r : batch) by_kind[r->kind].push_back(r);
+  auto listed = [&](std::vector<Request *> &rs, const char *what, auto &&call) {
+    if (rs.empty()) return;
+    std::vector<int32_t> ch;
+    for (Request *r : rs) ch.push_back(r->channel);
+    if (call(ch.data(), (int32_t)ch.size()) == WFST_OK) return;
+    if (rs.size() == 1) { rs[0]->error = std::make_exception_ptr(std::runtime_error(std::string(what) + ": " + wfst_last_error())); return; }
+    for (Request *r : rs) {
+      const int32_t c = r->channel;
+      if (call(&c, 1) != WFST_OK) r->error = std::make_exception_ptr(std::runtime_error(std::string(what) + ": " + wfst_last_error()));
+    }
+  };
+  listed(by_kind[kInit], "InitDecoding", [&](const int32_t *ch, int32_t n) { return wfst_decoder_init(_dec, ch, n); });
+  ExecuteAdvance(by_kind[kAdvance]);
+  listed(by_kind[kFinalize], "FinalizeDecoding", [&](const int32_t *ch, int32_t n) { return wfst_decoder_finalize(_dec, ch, n); });
+  ExecuteBestPath(by_kind[kBestPath]);
+  for (Request *r : by_kind[kCall]) {
+    try {
+      r->call(_dec);
+    } catch (...) {
+      r->error = std::current_exception();
+    }
+  }
+  for (Request *r : batch) r->decoded = wfst_decoder_num_frames_decoded(_dec, r->channel);
+}
+void GpuChannelPool::ExecuteAdvance(std::vector<Request *> &all) {
+  // one call per (stride, max_num_frames): in a service every stream has the same model, i.e. one call
+  while (!all.empty()) {
+    std::vector<Request *> rs, rest;
+    for (Request *r : all) (r->stride == all[0]->stride && r->max_num_frames == all[0]->max_num_frames ? rs : rest).push_back(r);
+    all.swap(rest);
+    auto call = [&](std::vector<Request *> &q) {
+      std::vector<int32_t> ch, ready;
+      std::vector<const float *> rows;
+      for (Request *r : q) { ch.push_back(r->channel); ready.push_back(r->ready); rows.push_back(r->rows); }
+      return wfst_decoder_advance_host(_dec, ch.data(), (int32_t)ch.size(), rows.data(), ready.data(), q[0]->stride, q[0]->max_num_frames);
+    };
+    long long frames = 0;
+    for (Request *r : rs) frames += std::max(0, r->ready - wfst_decoder_num_frames_decoded(_dec, r->channel));
+    {
+      std::lock_guard<std::mutex> lk(_mu);
+      _stats.advance_calls += 1;
+      _stats.advance_requests += (long long)rs.size();
+      _stats.frames += frames;
+    }
+    if (call(rs) == WFST_OK) continue;
+    if (rs.size() == 1) { rs[0]->error = std::make_exception_ptr(std::runtime_error(std::string("AdvanceDecoding: ") + wfst_last_error())); continue; }
+    for (Request *r : rs) {
+      std::vector<Request *> one(1, r);
+      if (call(one) != WFST_OK) r->error = std::make_exception_ptr(std::runtime_error(std::string("AdvanceDecoding: ") + wfst_last_error()));
+    }
+  }
+}
+void GpuChannelPool::ExecuteBestPath(std::vector<Request *> &all) {
+  for (int ufp = 0; ufp < 2; ++ufp) {
+    std::vector<Request *> rs;
+    for (Request *r : all)
+      if ((r->use_final_probs ? 1 : 0) == ufp) rs.push_back(r);
+    if (rs.empty()) continue;
+    const int cnt = (int)rs.size();
+    std::vector<int32_t> ch((size_t)cnt);
+    int maxf = 1;
+    for (int i = 0; i < cnt; ++i) { ch[(size_t)i] = rs[(size_t)i]->channel; maxf = std::max(maxf, wfst_decoder_num_frames_decoded(_dec, ch[(size_t)i])); }
+    int cap = 4 * maxf + 64;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      std::vector<int32_t> il((size_t)cnt * cap), ol((size_t)cnt * cap), n((size_t)cnt, 0);
+      std::vector<float> g((size_t)cnt * cap), ac((size_t)cnt * cap);
+      const int rc = wfst_decoder_get_best_path(_dec, ch.data(), cnt, ufp, cap, il.data(), ol.data(), g.data(), ac.data(), n.data());
+      if (rc == WFST_E_CAPACITY && *std::max_element(n.begin(), n.end()) > cap && attempt == 0) { cap = *std::max_element(n.begin(), n.end()); continue; }
+      if (rc != WFST_OK && cnt > 1 && attempt == 0) {
+        // the batch was refused for one of its channels (GetBestPath before InitDecoding, a channel's device error ...): one by one
+        for (Request *r : rs) { std::vector<Request *> one(1, r); ExecuteBestPath(one); }
+        break;
+      }
+      for (int i = 0; i < cnt; ++i) {
+        Request *r = rs[(size_t)i];
+        if (rc != WFST_OK) { r->error = std::make_exception_ptr(std::runtime_error(std::string("GetBestPath: ") + wfst_last_error())); continue; }
+        r->n_hops = n[(size_t)i];
+        const size_t o = (size_t)i * cap;
+        r->il.assign(il.begin() + (long)o, il.begin() + (long)o + r->n_hops);
+        r->ol.assign(ol.begin() + (long)o, ol.begin() + (long)o + r->n_hops);
+        r->g.assign(g.begin() + (long)o, g.begin() + (long)o + r->n_hops);
+        r->ac.assign(ac.begin() + (long)o, ac.begin() + (long)o + r->n_hops);
+        // (the final result says whether the per-frame token limit bound on the way; partial results do not stop for it)
+        int32_t dg = 0;
+        if (ufp && wfst_decoder_get_degraded_frames(_dec, r->channel, &dg) == WFST_OK) r->degraded = dg;
+      }
+      break;
+    }
+  }
+}
+
 // ---- single-stream decoder --------------------------------------------------------------------
 GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, const wfst_limits *limits)
-    : _dec(nullptr), _stride(0), _rows_ready(0), _inited(false) {
+    : _dec(nullptr), _pool(nullptr), _chan(0), _decoded(0), _stride(0), _rows_ready(0), _inited(false) {
   config.Check();
   wfst_config c = config.ToC();
   if (wfst_decoder_create(graph->Handle(), &c, 1, limits, nullptr, &_dec) != WFST_OK) Fatal("wfst_decoder_create");
 }
 GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm,
                                      const wfst_limits *limits)
-    : _dec(nullptr), _stride(0), _rows_ready(0), _inited(false) {
+    : _dec(nullptr), _pool(nullptr), _chan(0), _decoded(0), _stride(0), _rows_ready(0), _inited(false) {
   config.Check();
   wfst_config c = config.ToC();
   if (!oldlm || !newlm) throw std::runtime_error("biglm decoder needs both LMs");
   if (wfst_decoder_create_biglm(graph->Handle(), &c, 1, limits, nullptr, oldlm->Handle(), newlm->Handle(), nullptr, &_dec) != WFST_OK)
     Fatal("wfst_decoder_create_biglm");
 }
-GpuLatticeDecoder::~GpuLatticeDecoder() { wfst_decoder_free(_dec); }
+GpuLatticeDecoder::GpuLatticeDecoder(GpuChannelPool *pool)
+    : _dec(nullptr), _pool(pool), _chan(0), _decoded(0), _stride(0), _rows_ready(0), _inited(false) {
+  if (!pool) throw std::runtime_error("GpuLatticeDecoder: NULL pool");
+  _dec = pool->_dec;
+  _chan = pool->Lease();
+}
+GpuLatticeDecoder::~GpuLatticeDecoder() {
+  if (_pool) _pool->Release(_chan);
+  else wfst_decoder_free(_dec);
+}
+
+// the C-ABI calls of one decoder are not re-entrant: with a pool they run in its batcher thread, one request after the other
+template <class F>
+void GpuLatticeDecoder::OnDevice(F &&f) {
+  if (!_pool) { f(); return; }
+  GpuChannelPool::Request r;
+  r.kind = GpuChannelPool::kCall;
+  r.channel = _chan;
+  r.call = [&](wfst_decoder *) { f(); };
+  _pool->Submit(&r);
+  _decoded = r.decoded;
+}
 
 void GpuLatticeDecoder::InitDecoding() {
-  if (wfst_decoder_init(_dec, nullptr, 0) != WFST_OK) Fatal("InitDecoding");
+  if (_pool) {
+    GpuChannelPool::Request r;
+    r.kind = GpuChannelPool::kInit;
+    r.channel = _chan;
+    _pool->Submit(&r);
+    _decoded = r.decoded;
+  } else if (wfst_decoder_init(_dec, nullptr, 0) != WFST_OK) Fatal("InitDecoding");
   _rows.clear();
   _rows_ready = 0;
   _stride = 0;
@@ -280,10 +488,19 @@ void GpuLatticeDecoder::Pull(AmInterface *d) {
 
 void GpuLatticeDecoder::AdvanceDecoding(AmInterface *decodable, int32 max_num_frames) {
   if (!_inited) throw std::runtime_error("You must call InitDecoding() before AdvanceDecoding");
-  Pull(decodable);
+  Pull(decodable);   // (in the caller's thread: with a pool, while the device decodes the batch before)
   const float *rows = _rows.data();
   int32_t ready = _rows_ready;
   if (ready == 0) return;
+  if (_pool) {
+    GpuChannelPool::Request r;
+    r.kind = GpuChannelPool::kAdvance;
+    r.channel = _chan;
+    r.rows = rows; r.ready = ready; r.stride = _stride; r.max_num_frames = max_num_frames;
+    _pool->Submit(&r);
+    _decoded = r.decoded;
+    return;
+  }
   if (wfst_decoder_advance_host(_dec, nullptr, 0, &rows, &ready, _stride, max_num_frames) != WFST_OK)
     Fatal("AdvanceDecoding");
 }
@@ -294,10 +511,18 @@ BaseFloat GpuLatticeDecoder::ProcessEmitting(AmInterface *decodable) {
 }
 
 void GpuLatticeDecoder::FinalizeDecoding() {
+  if (_pool) {
+    GpuChannelPool::Request r;
+    r.kind = GpuChannelPool::kFinalize;
+    r.channel = _chan;
+    _pool->Submit(&r);
+    _decoded = r.decoded;
+    return;
+  }
   if (wfst_decoder_finalize(_dec, nullptr, 0) != WFST_OK) Fatal("FinalizeDecoding");
 }
 
-int32 GpuLatticeDecoder::NumFramesDecoded() const { return wfst_decoder_num_frames_decoded(_dec, 0); }
+int32 GpuLatticeDecoder::NumFramesDecoded() const { return _pool ? _decoded : wfst_decoder_num_frames_decoded(_dec, 0); }
 
 bool GpuLatticeDecoder::Decode(AmInterface *decodable) {
   InitDecoding();
@@ -308,9 +533,24 @@ bool GpuLatticeDecoder::Decode(AmInterface *decodable) {
 }
 
 static void WarnIfDegraded(wfst_decoder *dec, int channel);
+static void WarnDegraded(int channel, int n);
 
 bool GpuLatticeDecoder::GetBestPath(Lattice *ofst, bool use_final_probs) {
   ofst->DeleteStates();
+  if (_pool) {
+    // batched with the other channels' requests (one wfst_decoder_get_best_path for all of them); the lattice is built here, in
+    // the caller's thread
+    GpuChannelPool::Request r;
+    r.kind = GpuChannelPool::kBestPath;
+    r.channel = _chan;
+    r.use_final_probs = use_final_probs;
+    _pool->Submit(&r);
+    _decoded = r.decoded;
+    if (r.degraded > 0) WarnDegraded(_chan, r.degraded);
+    if (r.n_hops == 0) { Warn("No final token found."); return false; }
+    HopsToLattice(r.il.data(), r.ol.data(), r.g.data(), r.ac.data(), r.n_hops, ofst);
+    return true;
+  }
   int cap = 4 * std::max(1, NumFramesDecoded()) + 64;
   for (int attempt = 0; attempt < 2; ++attempt) {
     std::vector<int32_t> il(cap), ol(cap);
@@ -471,19 +711,37 @@ static bool NbestOfChannel(wfst_decoder *dec, int channel, std::vector<Lattice> 
   return !out.empty();
 }
 
-bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n) { return NbestOfChannel(_dec, 0, nbest_paths, n, nullptr, nullptr); }
-bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n, ArpaLm *oldlm, ArpaLm *newlm) {
-  return NbestOfChannel(_dec, 0, nbest_paths, n, oldlm, newlm);
+bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n) {
+  bool ok = false;
+  OnDevice([&] { ok = NbestOfChannel(_dec, _chan, nbest_paths, n, nullptr, nullptr); });
+  return ok;
 }
-bool GpuLatticeDecoder::GetNbestShortlist(std::vector<Lattice> &nbest_paths, int n) { return ShortlistOfChannel(_dec, 0, nbest_paths, n); }
+bool GpuLatticeDecoder::GetNbest(std::vector<Lattice> &nbest_paths, int n, ArpaLm *oldlm, ArpaLm *newlm) {
+  bool ok = false;
+  OnDevice([&] { ok = NbestOfChannel(_dec, _chan, nbest_paths, n, oldlm, newlm); });
+  return ok;
+}
+bool GpuLatticeDecoder::GetNbestShortlist(std::vector<Lattice> &nbest_paths, int n) {
+  bool ok = false;
+  OnDevice([&] { ok = ShortlistOfChannel(_dec, _chan, nbest_paths, n); });
+  return ok;
+}
 
-bool GpuLatticeDecoder::GetLattice(Lattice *ofst, bool use_final_probs) { return DetLatticeOfChannel(_dec, 0, ofst, use_final_probs); }
+bool GpuLatticeDecoder::GetLattice(Lattice *ofst, bool use_final_probs) {
+  bool ok = false;
+  OnDevice([&] { ok = DetLatticeOfChannel(_dec, _chan, ofst, use_final_probs); });
+  return ok;
+}
 bool GpuLatticeDecoder::GetLattice(Lattice *ofst, ArpaLm *oldlm, ArpaLm *newlm, bool use_final_probs) {
-  return RescoredLatticeOfChannel(_dec, 0, ofst, oldlm, newlm, use_final_probs);
+  bool ok = false;
+  OnDevice([&] { ok = RescoredLatticeOfChannel(_dec, _chan, ofst, oldlm, newlm, use_final_probs); });
+  return ok;
 }
 
 bool GpuLatticeDecoder::GetRawLattice(Lattice *ofst, bool use_final_probs) {
-  return RawLatticeOfChannel(_dec, 0, ofst, use_final_probs);
+  bool ok = false;
+  OnDevice([&] { ok = RawLatticeOfChannel(_dec, _chan, ofst, use_final_probs); });
+  return ok;
 }
 
 // ---- batch decoder ------------------------------------------------------------------------------
@@ -635,11 +893,13 @@ int GpuBatchDecoder::NumFramesDecoded(int channel) const { return wfst_decoder_n
 // A best-path decoder does not fail at wfst_limits.max_tokens_per_frame, it goes on from the limit-th cheapest token (the limit
 // acts as a max_active): the result may then differ from the reference's at the configured beam.  Said once per utterance and
 // channel, where the reference would have said nothing because it has no such limit.
+static void WarnDegraded(int channel, int n) {
+  Warn("channel " + std::to_string(channel) + ": " + std::to_string(n) + " frame(s) held more tokens than max_tokens_per_frame; the search "
+       "went on from the cheapest of them (a max_active): raise wfst_limits.max_tokens_per_frame for the result at the configured beam");
+}
 static void WarnIfDegraded(wfst_decoder *dec, int channel) {
   int32_t n = 0;
-  if (wfst_decoder_get_degraded_frames(dec, channel, &n) == WFST_OK && n > 0)
-    Warn("channel " + std::to_string(channel) + ": " + std::to_string(n) + " frame(s) held more tokens than max_tokens_per_frame; the search "
-         "went on from the cheapest of them (a max_active): raise wfst_limits.max_tokens_per_frame for the result at the configured beam");
+  if (wfst_decoder_get_degraded_frames(dec, channel, &n) == WFST_OK && n > 0) WarnDegraded(channel, n);
 }
 
 void GpuBatchDecoder::GetBestPaths(const std::vector<int> &channels, std::vector<Lattice> *ofsts,

@@ -17,12 +17,16 @@
 #ifndef WFST_HOST_H_
 #define WFST_HOST_H_
 
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <functional>
 #include <limits>
 #include <stdexcept>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/wfst_decoder.h"
@@ -205,7 +209,81 @@ class DecoderItf {
   virtual bool GetRawLattice(Lattice *ofst, bool use_final_probs = true) = 0;
 };
 
-// One utterance stream on channel 0 of a private 1-channel device decoder.  Scores are pulled
+// ---- many DecoderItf objects over ONE batched device decoder ------------------------------------
+// The reference's service creates one decoder object per worker thread over a shared graph (v2-asr/v2-asr-work-thread.h:66,
+// v2-asrbin/v2-asr-service.cc:95-105); N private 1-channel device decoders would be N latency-bound launch chains.  The pool owns
+// one n_channels-wide device decoder and a batcher thread, the way the GPU service the reference ships batches its streams
+// dynamically (gpu-asr/v1-gpu-kaldi-worker-pool.h:20-204: Push(corr_id, chunk) -> dynamic batcher -> batched pipeline): every
+// GpuLatticeDecoder(pool) leases a channel for its lifetime; its InitDecoding / AdvanceDecoding / FinalizeDecoding / GetBestPath
+// deposit a request and wait; the batcher takes whatever has arrived (plus what arrives within `linger_us`, as long as leased
+// channels are still missing) and issues ONE wfst_decoder_init / _advance_host / _finalize / _get_best_path for all of them --
+// while the device decodes one batch of chunks, the threads pull the next chunks from their decodables and the next batch forms.
+// Everything else a decoder object may ask for (GetRawLattice, GetLattice, GetNbest ...) runs in the batcher thread too, one
+// request after the other: the C ABI's calls on one decoder are not re-entrant.
+// Results are those of the private decoder, bit for bit (a channel's search does not depend on its neighbours).
+// At most n_channels decoder objects can be alive at a time: a further constructor waits for a channel to be released.
+class GpuChannelPool {
+ public:
+  GpuChannelPool(Fst *graph, const LatticeFasterDecoderConfig &config, int n_channels, const wfst_limits *limits = nullptr,
+                 int linger_us = 50);
+  GpuChannelPool(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm, int n_channels,
+                 const wfst_limits *limits = nullptr, int linger_us = 50);   // biglm
+  ~GpuChannelPool();
+  int NumChannels() const { return _n; }
+  struct Stats {
+    long long batches;            // passes of the batcher over its queue
+    long long requests;           // requests served
+    long long advance_calls;      // wfst_decoder_advance_host calls issued ...
+    long long advance_requests;   // ... for this many AdvanceDecoding requests (their ratio = the mean batch)
+    long long frames;             // frames handed to the device
+  };
+  Stats GetStats();
+  wfst_decoder *Handle() { return _dec; }
+
+ private:
+  friend class GpuLatticeDecoder;
+  GpuChannelPool(const GpuChannelPool &);
+  GpuChannelPool &operator=(const GpuChannelPool &);
+  enum Kind { kInit = 0, kAdvance, kFinalize, kBestPath, kCall, kKinds };
+  struct Request {
+    Kind kind;
+    int channel;
+    // kAdvance
+    const float *rows; int ready, stride, max_num_frames;
+    // kBestPath
+    bool use_final_probs;
+    std::vector<int32_t> il, ol; std::vector<float> g, ac; int n_hops, degraded;
+    // kCall
+    std::function<void(wfst_decoder *)> call;
+    // outcome
+    int decoded;                  // NumFramesDecoded of the channel after the request
+    std::exception_ptr error;
+    bool done;
+    Request() : kind(kCall), channel(0), rows(nullptr), ready(0), stride(0), max_num_frames(-1), use_final_probs(true), n_hops(0),
+                degraded(0), decoded(0), done(false) {}
+  };
+  void Start(int linger_us);
+  int Lease();
+  void Release(int channel);
+  void Submit(Request *r);        // enqueue, wait, rethrow what the batcher thread caught
+  void Run();
+  void Execute(std::vector<Request *> &batch);
+  void ExecuteAdvance(std::vector<Request *> &rs);
+  void ExecuteBestPath(std::vector<Request *> &rs);
+  wfst_decoder *_dec;
+  int _n, _linger_us;
+  std::mutex _mu;
+  std::condition_variable _cv_work, _cv_done, _cv_free;
+  std::vector<Request *> _queue;
+  std::vector<char> _leased;
+  int _n_leased;
+  bool _stop;
+  Stats _stats;
+  std::thread _thread;
+};
+
+// One utterance stream on channel 0 of a private 1-channel device decoder -- or, constructed over a GpuChannelPool, on a channel
+// leased from the pool's batched decoder (the shape for a service's worker threads).  Scores are pulled
 // through LogLikelihood(f, i) for the frames that became ready since the last call (or taken in
 // one piece from a MatrixDecodable) and shipped to the GPU; the search runs there.
 // Fatal conditions throw std::runtime_error (the reference's LOG_ERR does, util/log-message.cc:
@@ -216,6 +294,8 @@ class GpuLatticeDecoder : public DecoderItf {
   // OnlineLatticeDecoderMempoolBiglm(fst, config, oldlm, newlm) (biglm.h:21-30): on-the-fly LM rescoring
   GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm,
                     const wfst_limits *limits = nullptr);
+  // a channel of the pool's decoder (graph, config, LMs and limits are the pool's); waits for a free channel
+  explicit GpuLatticeDecoder(GpuChannelPool *pool);
   ~GpuLatticeDecoder() override;
   void InitDecoding() override;
   void AdvanceDecoding(AmInterface *decodable, int32 max_num_frames = -1) override;
@@ -252,7 +332,11 @@ class GpuLatticeDecoder : public DecoderItf {
 
  private:
   void Pull(AmInterface *decodable);
+  template <class F> void OnDevice(F &&f);   // f(): C-ABI calls on (_dec, _chan) -- in the pool's batcher thread where there is a pool
   wfst_decoder *_dec;
+  GpuChannelPool *_pool;     // nullptr: the private decoder
+  int _chan;                 // 0, or the leased channel
+  int _decoded;              // pool: NumFramesDecoded as of the last request
   std::vector<float> _rows;  // host history [frames][stride]
   int _stride, _rows_ready;
   bool _inited;

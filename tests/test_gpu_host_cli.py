@@ -360,3 +360,83 @@ def test_cli_devices_gives_the_single_device_lattices(synth, tmp_path):
         assert outs[tag][0] == outs["one"][0], tag + ": words / n-best"
         assert outs[tag][1] == outs["one"][1], tag + ": scores"
         assert outs[tag][2] == outs["one"][2], tag + ": determinized lattices"
+
+
+def _write_utts(tmp_path, mats):
+    with open(tmp_path / "ll.bin", "wb") as f:
+        for i, x in enumerate(mats):
+            key = ("utt%03d" % i).encode()
+            f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
+
+
+@pytest.mark.parametrize("shape", ["pool_pull", "pool_matrix", "private"])
+def test_service_threads_over_a_channel_pool(shape, synth, oracle, tmp_path):
+    """the reference service's shape -- N worker threads, one DecoderItf object each (v2-asr/v2-asr-work-thread.h:66)
+    -- on the device: 64 host threads x GpuLatticeDecoder(pool) over ONE 64-channel device decoder, every utterance fed in chunks of
+    25 frames through LogLikelihood(frame, index) pulls (pool_pull) or MatrixDecodable rows (pool_matrix), the threads' requests
+    batched by the pool's batcher thread (gpu-asr/v1-gpu-kaldi-worker-pool.h:20-204's shape).  200 ragged utterances, more than
+    channels: every channel serves several.  Words bit-exact and scores equal to the oracle's for every utterance, in input
+    order; `private` = the same threads over private 1-channel decoders (round 5's shape), 8 threads."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m = synth.default_tid2pdf(600)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=12\n--max-active=1000000\n--min-active=0\n--lattice-beam=6\n")
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=6.0)
+    n_utt = 200 if shape != "private" else 24
+    rng = np.random.RandomState(5)
+    lens = [int(x) for x in rng.randint(1, 140, size=n_utt)]
+    lens[:4] = [25, 50, 1, 139]   # (chunk multiples, a one-frame utterance, the longest)
+    mats = [synth.make_loglikes(g, T, 300, m, seed=900 + i, mu=-2.2)[0] for i, T in enumerate(lens)]
+    _write_utts(tmp_path, mats)
+    args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--chunk=25"]
+    args += {"pool_pull": ["--threads=64", "--pool=64", "--pull"], "pool_matrix": ["--threads=64", "--pool=64"], "private": ["--threads=8", "--pull"]}[shape]
+    p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    words = {l.split()[0]: [int(w) for w in l.split()[1:]] for l in lines}
+    scores = {mm.group(1): (float(mm.group(2)), float(mm.group(3))) for mm in re.finditer(r"LOG (utt\d+) tot_score (\S+) lm_score (\S+)", p.stderr)}
+    h = oracle.load_graph(gpath)
+    n_ok = 0
+    for i, x in enumerate(mats):
+        o = oracle.decode(h, pyoracle.Config(**cd), x, m)
+        k = "utt%03d" % i
+        if not o.ok:
+            assert k not in words, k
+            continue
+        assert words[k] == o.words.tolist(), k
+        assert abs(scores[k][0] - o.tot_score) <= 1e-4 * max(1.0, abs(o.tot_score)), k
+        n_ok += 1
+    oracle.free_graph(h)
+    assert [l.split()[0] for l in lines] == sorted(words)   # input order
+    assert n_ok >= n_utt - 5
+    if shape != "private":
+        mm = re.search(r"LOG pool: 64 channels, 64 threads, (\d+) batcher passes, (\d+) requests, (\d+) advance calls for (\d+) AdvanceDecoding requests \(mean batch ([\d.]+)\), (\d+) frames", p.stderr)
+        assert mm, p.stderr[-1500:]
+        assert int(mm.group(6)) == sum(lens)                 # every frame went through the batcher once
+        assert float(mm.group(5)) > 4.0, mm.group(0)          # ... in batches (64 threads in flight: typically 20-60 per call)
+
+
+def test_pool_serves_lattices_and_nbest(synth, oracle, tmp_path):
+    """GetRawLattice and GetNbest of pool-backed decoder objects (they run in the batcher thread, between the batched calls): the same
+    lattices the batch decoder writes for the same utterances, byte for byte."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m = synth.default_tid2pdf(600)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=12\n--max-active=1000000\n--min-active=0\n--lattice-beam=5\n")
+    mats = [synth.make_loglikes(g, T, 300, m, seed=700 + i, mu=-2.2)[0] for i, T in enumerate([50, 21, 3, 77, 64, 30, 90, 12, 45])]
+    _write_utts(tmp_path, mats)
+    outs = {}
+    for tag, extra in (("pool", ["--threads=4", "--pool=4", "--chunk=16", "--pull"]), ("batch", ["--batch=4"])):
+        args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--lattice-out=" + str(tmp_path / (tag + ".lat")), "--lattice-links=1000000",
+                "--nbest=3"] + extra
+        p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[tag] = (p.stdout, open(tmp_path / (tag + ".lat"), "rb").read())
+    assert outs["pool"][0] == outs["batch"][0]     # words and n-best lists, line for line
+    assert outs["pool"][1] == outs["batch"][1] and len(outs["pool"][1]) > 1000   # the raw lattices, byte for byte
