@@ -124,6 +124,8 @@ int main(int argc, char **argv) {
     long long lattice_links = 1ll << 22;
     int nbest = 0, inflight = 1, chunk = 0, n_threads = 0, pool_channels = 0, linger_us = 50;
     bool pull = false;
+    long long max_tokens_per_frame = 0, arena_tokens = 0;
+    int max_frames = 0;
     std::vector<int> devices(1, 0);
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -142,6 +144,9 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 7, "--pool=") == 0) pool_channels = std::max(0, atoi(a.c_str() + 7));
       else if (a.compare(0, 12, "--linger-us=") == 0) linger_us = std::max(0, atoi(a.c_str() + 12));
       else if (a == "--pull") pull = true;
+      else if (a.compare(0, 13, "--max-tokens=") == 0) max_tokens_per_frame = atoll(a.c_str() + 13);
+      else if (a.compare(0, 15, "--arena-tokens=") == 0) arena_tokens = atoll(a.c_str() + 15);
+      else if (a.compare(0, 13, "--max-frames=") == 0) max_frames = atoi(a.c_str() + 13);
       else if (a.compare(0, 10, "--devices=") == 0) {
         devices.clear();
         for (size_t p0 = 10; p0 <= a.size();) {
@@ -238,6 +243,10 @@ int main(int argc, char **argv) {
     const bool exact_nbest = !nbest_lattice_file.empty() || second || nbest > 16;
     wfst_limits limits = {0, 0, 0, 0, 0};  // zeros = the library defaults
     limits.lattice_links = want_lattice ? lattice_links : 0;
+    // (--max-frames / --max-tokens / --arena-tokens: wfst_limits as the caller sizes them; 0 = the library's defaults)
+    limits.max_frames = max_frames;
+    limits.max_tokens_per_frame = (int32_t)max_tokens_per_frame;
+    limits.arena_tokens = arena_tokens;
     auto emit_lattice = [&](const Utt &u, Lattice &lat, bool ok) {
       if (!ok) lat.DeleteStates();
       if (!lattice_file.empty() && !lat.Write(lattice_file)) throw std::runtime_error("cannot write " + lattice_file);
@@ -300,6 +309,7 @@ int main(int argc, char **argv) {
           // every thread has its decoder before the first utterance starts (the service creates them at start-up)
           ready_threads.fetch_add(1);
           while (ready_threads.load() < n_threads) std::this_thread::yield();
+          if (k == 0) t0 = std::chrono::steady_clock::now();   // (the clock starts when every thread holds its decoder)
           for (;;) {
             const size_t ui = next.fetch_add(1);
             if (ui >= utts.size()) return;
@@ -335,7 +345,6 @@ int main(int argc, char **argv) {
       };
       std::vector<std::thread> threads;
       for (int k = 1; k < n_threads; ++k) threads.emplace_back(worker, k);
-      t0 = std::chrono::steady_clock::now();   // (the decoders' construction is inside: the service pays it once at start-up, a CLI run every time -- reported apart below)
       worker(0);
       for (std::thread &t : threads) t.join();
       for (const std::string &e : errors)
