@@ -1561,8 +1561,10 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
       float *np = nullptr;
       HIP_TRY(hipMalloc((void **)&np, ncap * (size_t)stride * 4));
       if (have > 0) {
+        // (on the decoder's own stream, not the legacy one: another decoder of the process may be capturing its frame loop in
+        // another thread -- the service's one-decoder-per-thread shape -- and the legacy stream refuses to work beside a capture)
+        HIP_TRY(hipMemcpyAsync(np, d->hist_dev[c], (size_t)have * stride * 4, hipMemcpyDeviceToDevice, d->stream));
         HIP_TRY(hipStreamSynchronize(d->stream));
-        HIP_TRY(hipMemcpy(np, d->hist_dev[c], (size_t)have * stride * 4, hipMemcpyDeviceToDevice));
       }
       if (d->hist_dev[c]) {
         HIP_TRY(hipStreamSynchronize(d->stream));
@@ -2663,7 +2665,10 @@ static int postprocess_batch(wfst_decoder *d, const int32_t *channels, int32_t n
       if (found) R.off.assign(poff.begin() + (long)i * (n_paths + 1), poff.begin() + (long)i * (n_paths + 1) + found + 1);
       R.tot.assign(ptot.begin() + (long)i * n_paths, ptot.begin() + (long)i * n_paths + found);
       std::vector<int32_t> arcs((size_t)total);
-      if (total) HIP_TRY(hipMemcpy(arcs.data(), P.out_arcs + (size_t)i * (size_t)P.out_cap, (size_t)total * 4, hipMemcpyDeviceToHost));
+      if (total) {
+        HIP_TRY(hipMemcpyAsync(arcs.data(), P.out_arcs + (size_t)i * (size_t)P.out_cap, (size_t)total * 4, hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+      }
       R.olabel.resize((size_t)total); R.graph.resize((size_t)total); R.ac.resize((size_t)total);
       for (int32_t k = 0; k < total; ++k) {
         const size_t aidx = (size_t)arcs[(size_t)k];

@@ -99,18 +99,22 @@ class HostMatrixDecodable : public MatrixDecodable {
   const Utt &_u;
   int _ready;
 };
-// ... and as the reference's callers see a decodable: LogLikelihood(frame, index) only
+// ... and as the reference's callers see a decodable: LogLikelihood(frame, index) only, the index a 1-based TRANSITION-ID.  With
+// --tid2pdf it is Kaldi's DecodableMatrixScaledMapped as the reference CLI builds it (kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:107):
+// LogLikelihood(frame, tid) = M(frame, TransitionIdToPdf(tid)), NumIndices() = the number of transition-ids -- the map belongs to
+// the decodable, the graph reads column ilabel.  Without it: M's columns are the indices themselves.
 class PullDecodable : public DecodableInterface {
  public:
-  explicit PullDecodable(const Utt &u) : _u(u), _ready(u.frames) {}
-  float LogLikelihood(int f, int i) override { return _u.m[(size_t)f * _u.cols + i]; }
+  PullDecodable(const Utt &u, const std::vector<int32_t> *tid2pdf) : _u(u), _map(tid2pdf), _ready(u.frames) {}
+  float LogLikelihood(int f, int i) override { return _u.m[(size_t)f * _u.cols + (_map ? (*_map)[(size_t)i] : i)]; }
   bool IsLastFrame(int f) const override { return f == _u.frames - 1; }
   int NumFramesReady() const override { return _ready; }
   void SetFramesReady(int n) { _ready = std::min(n, _u.frames); }
-  int NumIndices() const override { return _u.cols - 1; }
+  int NumIndices() const override { return _map ? (int)_map->size() - 1 : _u.cols - 1; }
 
  private:
   const Utt &_u;
+  const std::vector<int32_t> *_map;   // entry 0 unused
   int _ready;
 };
 }  // namespace
@@ -178,13 +182,15 @@ int main(int argc, char **argv) {
       if (!fsts.back()->ReadFst(pos[1].c_str(), devices[di])) return 1;
     }
     Fst &fst = *fsts[0];
+    std::vector<int32_t> tid2pdf;
     if (!tid2pdf_file.empty()) {
       std::ifstream t(tid2pdf_file.c_str(), std::ios::binary | std::ios::ate);
       if (!t) { std::cerr << "cannot open " << tid2pdf_file << "\n"; return 1; }
-      std::vector<int32_t> m((size_t)t.tellg() / 4);
+      tid2pdf.resize((size_t)t.tellg() / 4);
       t.seekg(0);
-      t.read((char *)m.data(), m.size() * 4);
-      for (auto &f : fsts) f->SetTid2Pdf(m);
+      t.read((char *)tid2pdf.data(), tid2pdf.size() * 4);
+      if (!pull)   // (--pull: the decodable maps, as the reference's does; otherwise the graph's rows read the pdf columns directly)
+        for (auto &f : fsts) f->SetTid2Pdf(tid2pdf);
     }
     std::ifstream in(pos[2].c_str(), std::ios::binary);
     if (!in) { std::cerr << "cannot open " << pos[2] << "\n"; return 1; }
@@ -287,6 +293,7 @@ int main(int argc, char **argv) {
       frame_count += u.frames;
       ++num_success;
     };
+    if (pull && n_threads == 0) { std::cerr << "--pull goes with --threads\n"; return 1; }
     if (n_threads > 0) {
       // the service's shape: N worker threads, one DecoderItf object each, over a pool's channels or private device decoders
       if (devices.size() > 1) { std::cerr << "--threads: one device\n"; return 1; }
@@ -315,7 +322,7 @@ int main(int argc, char **argv) {
             if (ui >= utts.size()) return;
             const Utt &u = utts[ui];
             HostMatrixDecodable md(u);
-            PullDecodable pd(u);
+            PullDecodable pd(u, tid2pdf.empty() ? nullptr : &tid2pdf);
             AmInterface *am = pull ? (AmInterface *)&pd : (AmInterface *)&md;
             decode.InitDecoding();
             if (chunk > 0) {
