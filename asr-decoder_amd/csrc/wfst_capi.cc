@@ -1605,6 +1605,15 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
   return WFST_OK;
 }
 
+void *wfst_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void wfst_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
   if (!d) return fail(WFST_E_ARG, "NULL decoder");
   HIP_TRY(hipSetDevice(d->device));

@@ -414,14 +414,14 @@ void GpuChannelPool::ExecuteBestPath(std::vector<Request *> &all) {
 
 // ---- single-stream decoder --------------------------------------------------------------------
 GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, const wfst_limits *limits)
-    : _dec(nullptr), _pool(nullptr), _chan(0), _decoded(0), _stride(0), _rows_ready(0), _inited(false) {
+    : _dec(nullptr), _pool(nullptr), _chan(0), _decoded(0), _rows(nullptr), _rows_cap(0), _rows_pinned(false), _stride(0), _rows_ready(0), _inited(false) {
   config.Check();
   wfst_config c = config.ToC();
   if (wfst_decoder_create(graph->Handle(), &c, 1, limits, nullptr, &_dec) != WFST_OK) Fatal("wfst_decoder_create");
 }
 GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm,
                                      const wfst_limits *limits)
-    : _dec(nullptr), _pool(nullptr), _chan(0), _decoded(0), _stride(0), _rows_ready(0), _inited(false) {
+    : _dec(nullptr), _pool(nullptr), _chan(0), _decoded(0), _rows(nullptr), _rows_cap(0), _rows_pinned(false), _stride(0), _rows_ready(0), _inited(false) {
   config.Check();
   wfst_config c = config.ToC();
   if (!oldlm || !newlm) throw std::runtime_error("biglm decoder needs both LMs");
@@ -429,7 +429,7 @@ GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfi
     Fatal("wfst_decoder_create_biglm");
 }
 GpuLatticeDecoder::GpuLatticeDecoder(GpuChannelPool *pool)
-    : _dec(nullptr), _pool(pool), _chan(0), _decoded(0), _stride(0), _rows_ready(0), _inited(false) {
+    : _dec(nullptr), _pool(pool), _chan(0), _decoded(0), _rows(nullptr), _rows_cap(0), _rows_pinned(false), _stride(0), _rows_ready(0), _inited(false) {
   if (!pool) throw std::runtime_error("GpuLatticeDecoder: NULL pool");
   _dec = pool->_dec;
   _chan = pool->Lease();
@@ -437,6 +437,27 @@ GpuLatticeDecoder::GpuLatticeDecoder(GpuChannelPool *pool)
 GpuLatticeDecoder::~GpuLatticeDecoder() {
   if (_pool) _pool->Release(_chan);
   else wfst_decoder_free(_dec);
+  if (_rows_pinned) wfst_host_free(_rows);
+  else free(_rows);
+}
+// the rows pulled from the decodable live in page-locked memory (they are uploaded chunk by chunk, beside the search over the chunk
+// before): grown by doubling, the history kept
+void GpuLatticeDecoder::GrowRows(size_t floats) {
+  if (floats <= _rows_cap) return;
+  const size_t ncap = std::max<size_t>(floats, std::max<size_t>(2 * _rows_cap, (size_t)1 << 16));
+  bool pinned = true;
+  float *np = (float *)wfst_host_alloc(ncap * sizeof(float));
+  if (!np) {
+    pinned = false;
+    np = (float *)malloc(ncap * sizeof(float));
+    if (!np) throw std::bad_alloc();
+  }
+  if (_rows && _rows_ready > 0) memcpy(np, _rows, (size_t)_rows_ready * _stride * sizeof(float));
+  if (_rows_pinned) wfst_host_free(_rows);
+  else free(_rows);
+  _rows = np;
+  _rows_cap = ncap;
+  _rows_pinned = pinned;
 }
 
 // the C-ABI calls of one decoder are not re-entrant: with a pool they run in its batcher thread, one request after the other
@@ -459,8 +480,7 @@ void GpuLatticeDecoder::InitDecoding() {
     _pool->Submit(&r);
     _decoded = r.decoded;
   } else if (wfst_decoder_init(_dec, nullptr, 0) != WFST_OK) Fatal("InitDecoding");
-  _rows.clear();
-  _rows_ready = 0;
+  _rows_ready = 0;   // (the buffer stays: the next utterance's rows go over this one's)
   _stride = 0;
   _inited = true;
 }
@@ -471,7 +491,7 @@ void GpuLatticeDecoder::Pull(AmInterface *d) {
   if (_stride == 0) _stride = stride;
   if (stride != _stride) throw std::runtime_error("decodable changed NumIndices() within an utterance");
   if (ready <= _rows_ready) return;
-  _rows.resize((size_t)ready * _stride);
+  GrowRows((size_t)ready * _stride);
   if (MatrixDecodable *m = dynamic_cast<MatrixDecodable *>(d)) {
     if (m->Stride() != _stride) throw std::runtime_error("MatrixDecodable::Stride() != NumIndices()+1");
     memcpy(&_rows[(size_t)_rows_ready * _stride], m->HostRows() + (size_t)_rows_ready * _stride,
@@ -489,7 +509,7 @@ void GpuLatticeDecoder::Pull(AmInterface *d) {
 void GpuLatticeDecoder::AdvanceDecoding(AmInterface *decodable, int32 max_num_frames) {
   if (!_inited) throw std::runtime_error("You must call InitDecoding() before AdvanceDecoding");
   Pull(decodable);   // (in the caller's thread: with a pool, while the device decodes the batch before)
-  const float *rows = _rows.data();
+  const float *rows = _rows;
   int32_t ready = _rows_ready;
   if (ready == 0) return;
   if (_pool) {

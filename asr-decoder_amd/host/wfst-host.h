@@ -337,7 +337,10 @@ class GpuLatticeDecoder : public DecoderItf {
   GpuChannelPool *_pool;     // nullptr: the private decoder
   int _chan;                 // 0, or the leased channel
   int _decoded;              // pool: NumFramesDecoded as of the last request
-  std::vector<float> _rows;  // host history [frames][stride]
+  float *_rows;              // host history [frames][stride], page-locked (wfst_host_alloc) where the device grants it
+  size_t _rows_cap;          // floats
+  bool _rows_pinned;
+  void GrowRows(size_t floats);
   int _stride, _rows_ready;
   bool _inited;
 };

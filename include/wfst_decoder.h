@@ -20,6 +20,7 @@
 #ifndef WFST_DECODER_H_
 #define WFST_DECODER_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -274,6 +275,12 @@ int wfst_decoder_advance(wfst_decoder *d, const int32_t *channels, int32_t n,
 int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t n,
                               const float *const *loglikes_host, const int32_t *n_frames_ready,
                               int32_t stride, int32_t max_num_frames);
+
+/* Page-locked host memory for the matrices handed to wfst_decoder_advance_host: rows in it go to the device at the link's rate
+ * and without a staging copy (pageable rows work too, at a fraction of it).  NULL when the allocation fails.  The host mirror's
+ * GpuLatticeDecoder keeps the rows it pulls from a DecodableInterface in such a buffer. */
+void *wfst_host_alloc(size_t bytes);
+void wfst_host_free(void *p);
 
 /* FinalizeDecoding() (base-inl.h:829-847): marks the channels finalized (afterwards advance is an
  * error and get_best_path requires use_final_probs != 0, as in the reference). */
