@@ -304,6 +304,8 @@ int main(int argc, char **argv) {
                          : new GpuChannelPool(&fst, opt, pool_channels, &limits, linger_us));
       struct Res { Lattice best; bool ok = false; Lattice lat; bool lat_ok = false; std::vector<Lattice> nbest; };
       std::vector<Res> res(utts.size());
+      int max_utt_frames = 0, max_utt_cols = 0;
+      for (const Utt &u : utts) { max_utt_frames = std::max(max_utt_frames, u.frames); max_utt_cols = std::max(max_utt_cols, u.cols); }
       std::vector<std::string> errors((size_t)n_threads);
       std::atomic<size_t> next(0);
       std::atomic<int> ready_threads(0);
@@ -313,6 +315,7 @@ int main(int argc, char **argv) {
                                                      : biglm ? new OnlineLatticeDecoderMempoolBiglm(&fst, opt, lm1p, lm2p, &limits)
                                                              : new GpuLatticeDecoder(&fst, opt, &limits));
           DecoderItf &decode = *dp;   // (the reference's interface is all the loop below uses, results aside)
+          dp->ReserveRows(max_utt_frames, pull && !tid2pdf.empty() ? (int)tid2pdf.size() - 1 : max_utt_cols - 1);
           // every thread has its decoder before the first utterance starts (the service creates them at start-up)
           ready_threads.fetch_add(1);
           while (ready_threads.load() < n_threads) std::this_thread::yield();

@@ -472,6 +472,10 @@ void GpuLatticeDecoder::OnDevice(F &&f) {
   _decoded = r.decoded;
 }
 
+void GpuLatticeDecoder::ReserveRows(int frames, int num_indices) {
+  if (frames > 0 && num_indices > 0) GrowRows((size_t)frames * (size_t)(num_indices + 1));
+}
+
 void GpuLatticeDecoder::InitDecoding() {
   if (_pool) {
     GpuChannelPool::Request r;

@@ -297,6 +297,10 @@ class GpuLatticeDecoder : public DecoderItf {
   // a channel of the pool's decoder (graph, config, LMs and limits are the pool's); waits for a free channel
   explicit GpuLatticeDecoder(GpuChannelPool *pool);
   ~GpuLatticeDecoder() override;
+  // Page-locked room for `frames` rows of a decodable with `num_indices` indices, allocated NOW: a service calls it when it
+  // creates its decoders (it knows its model and its longest utterance).  Without it the buffer is allocated when the first rows
+  // arrive and grows by doubling -- page-locking memory costs milliseconds and is serialised by the driver.
+  void ReserveRows(int frames, int num_indices);
   void InitDecoding() override;
   void AdvanceDecoding(AmInterface *decodable, int32 max_num_frames = -1) override;
   void FinalizeDecoding() override;
