@@ -1678,6 +1678,15 @@ int wfst_decoder_sync(wfst_decoder *d) {
   return check_ctl_errors(d);
 }
 
+int wfst_decoder_busy(wfst_decoder *d) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  HIP_TRY(hipSetDevice(d->device));
+  const hipError_t e = hipStreamQuery(d->stream);   // (the channel groups' streams join the decoder's own at the end of every advance)
+  if (e == hipSuccess) return 0;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
+  return fail(WFST_E_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+}
+
 int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t channel) {
   if (!d || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad decoder/channel");
   return d->h_decoded[channel];

@@ -302,8 +302,22 @@ void GpuChannelPool::Run() {
     if (_queue.empty()) return;   // (_stop, nothing left to serve)
     // the other leased channels' requests are on their way more often than not (their threads were released together): a short
     // wait makes one batch of them instead of two
-    if (_linger_us > 0 && (int)_queue.size() < _n_leased)
-      _cv_work.wait_for(lk, std::chrono::microseconds(_linger_us), [&] { return _stop || (int)_queue.size() >= _n_leased; });
+    // ... and while the device is still busy with the batch before, the next advance call would only wait for it: what arrives
+    // meanwhile joins this batch (two cohorts of threads that alternate merge into one)
+    if ((int)_queue.size() < _n_leased) {
+      const auto t_first = std::chrono::steady_clock::now();
+      for (;;) {
+        if (_stop || (int)_queue.size() >= _n_leased) break;
+        const bool lingered = std::chrono::steady_clock::now() - t_first >= std::chrono::microseconds(_linger_us);
+        if (lingered) {
+          lk.unlock();
+          const int busy = wfst_decoder_busy(_dec);
+          lk.lock();
+          if (busy != 1) break;
+        }
+        _cv_work.wait_for(lk, std::chrono::microseconds(lingered ? 20 : std::max(1, _linger_us)));
+      }
+    }
     std::vector<Request *> batch;
     batch.swap(_queue);
     lk.unlock();

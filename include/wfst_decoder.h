@@ -290,6 +290,11 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n);
  * channel hit a limit or the device faulted. */
 int wfst_decoder_sync(wfst_decoder *d);
 
+/* 1 while work enqueued on the decoder's stream has not finished, 0 when it is idle (never blocks); < 0: error.  What a batching
+ * host needs to know before it issues the next wfst_decoder_advance: that call waits for the one before it anyway, so requests that
+ * arrive meanwhile can join it (the host mirror's GpuChannelPool). */
+int wfst_decoder_busy(wfst_decoder *d);
+
 /* NumFramesDecoded() (my-decoder/online-decoder-base.h:139). */
 int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t channel);
 
