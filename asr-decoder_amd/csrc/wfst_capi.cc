@@ -1557,7 +1557,10 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
     const int32_t have = d->hist_rows[c], want = n_frames_ready[i];
     if (want < have) return fail(WFST_E_ARG, "NumFramesReady decreased");
     if ((size_t)want > d->hist_rows_cap[c]) {
+      // (a decoder created with a small wfst_limits.max_frames -- a caller that sizes its utterances -- gets the whole history at
+      // once: regrowing costs an allocation, a device copy and a free that waits for the device, per channel)
       size_t ncap = std::max<size_t>((size_t)want, std::max<size_t>(d->hist_rows_cap[c] * 2, 256));
+      if (d->D.max_frames <= 1024) ncap = std::max<size_t>(ncap, (size_t)d->D.max_frames);
       float *np = nullptr;
       HIP_TRY(hipMalloc((void **)&np, ncap * (size_t)stride * 4));
       if (have > 0) {

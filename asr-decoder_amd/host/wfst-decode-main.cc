@@ -38,6 +38,8 @@
 //   --pool=C       over ONE GpuChannelPool of C channels (C >= N): the threads' requests are batched into one device call per
 //                  kind (gpu-asr/v1-gpu-kaldi-worker-pool.h:20-204: the dynamic batcher's shape); --linger-us=U: how long the
 //                  batcher waits for the other leased channels' requests (50)
+//   --repeat=K     --threads only: the utterance list is decoded K times over (a steady-state measurement: the first utterances of a
+//                  run pay the decoder's graph captures and buffer allocations); the output is the first pass's
 //   --pull         the decodable is a plain DecodableInterface: every score goes through LogLikelihood(frame, index) (without it
 //                  the rows are taken in one piece, MatrixDecodable)
 //   --nbest=N      also print the N-best word sequences of every utterance (the service's
@@ -129,7 +131,7 @@ int main(int argc, char **argv) {
     int nbest = 0, inflight = 1, chunk = 0, n_threads = 0, pool_channels = 0, linger_us = 50;
     bool pull = false;
     long long max_tokens_per_frame = 0, arena_tokens = 0;
-    int max_frames = 0;
+    int max_frames = 0, repeat = 1;
     std::vector<int> devices(1, 0);
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -148,6 +150,7 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 7, "--pool=") == 0) pool_channels = std::max(0, atoi(a.c_str() + 7));
       else if (a.compare(0, 12, "--linger-us=") == 0) linger_us = std::max(0, atoi(a.c_str() + 12));
       else if (a == "--pull") pull = true;
+      else if (a.compare(0, 9, "--repeat=") == 0) repeat = std::max(1, atoi(a.c_str() + 9));
       else if (a.compare(0, 13, "--max-tokens=") == 0) max_tokens_per_frame = atoll(a.c_str() + 13);
       else if (a.compare(0, 15, "--arena-tokens=") == 0) arena_tokens = atoll(a.c_str() + 15);
       else if (a.compare(0, 13, "--max-frames=") == 0) max_frames = atoi(a.c_str() + 13);
@@ -274,7 +277,7 @@ int main(int argc, char **argv) {
     std::vector<Utt> utts;
     for (Utt u; ReadUtt(in, &u);) utts.push_back(u);
     int num_success = 0, num_fail = 0;
-    long long frame_count = 0;
+    long long frame_count = 0, repeat_frames = 0;
     double tot_like = 0;
     auto t0 = std::chrono::steady_clock::now();
     auto emit = [&](const Utt &u, Lattice &best, bool ok) {
@@ -309,6 +312,7 @@ int main(int argc, char **argv) {
       std::vector<std::string> errors((size_t)n_threads);
       std::atomic<size_t> next(0);
       std::atomic<int> ready_threads(0);
+      std::atomic<long long> extra_frames(0);   // frames of the repeat passes (--repeat)
       auto worker = [&](int k) {
         try {
           std::unique_ptr<GpuLatticeDecoder> dp(pool ? new GpuLatticeDecoder(pool.get())
@@ -321,8 +325,10 @@ int main(int argc, char **argv) {
           while (ready_threads.load() < n_threads) std::this_thread::yield();
           if (k == 0) t0 = std::chrono::steady_clock::now();   // (the clock starts when every thread holds its decoder)
           for (;;) {
-            const size_t ui = next.fetch_add(1);
-            if (ui >= utts.size()) return;
+            const size_t uj = next.fetch_add(1);
+            if (uj >= utts.size() * (size_t)repeat) return;
+            const size_t ui = uj % utts.size();
+            const bool first_pass = uj < utts.size();
             const Utt &u = utts[ui];
             HostMatrixDecodable md(u);
             PullDecodable pd(u, tid2pdf.empty() ? nullptr : &tid2pdf);
@@ -339,8 +345,10 @@ int main(int argc, char **argv) {
               decode.AdvanceDecoding(am);
             }
             decode.FinalizeDecoding();
-            Res &r = res[ui];
+            Res scratch;
+            Res &r = first_pass ? res[ui] : scratch;
             r.ok = decode.GetBestPath(&r.best);
+            if (!first_pass) { extra_frames.fetch_add(r.ok ? u.frames : 0); continue; }
             if (want_lattice && (!lattice_file.empty() || !lattice_text.empty()))
               r.lat_ok = determinize ? dp->GetLattice(&r.lat) : decode.GetRawLattice(&r.lat);
             if (nbest > 0) {
@@ -364,11 +372,14 @@ int main(int argc, char **argv) {
         if (want_lattice && (!lattice_file.empty() || !lattice_text.empty())) emit_lattice(utts[i], res[i].lat, res[i].lat_ok);
         if (nbest > 0) emit_nbest(utts[i], res[i].nbest);
       }
+      repeat_frames = extra_frames.load();
       if (pool) {
         const GpuChannelPool::Stats st = pool->GetStats();
         std::cerr << "LOG pool: " << pool_channels << " channels, " << n_threads << " threads, " << st.batches << " batcher passes, " << st.requests
                   << " requests, " << st.advance_calls << " advance calls for " << st.advance_requests << " AdvanceDecoding requests (mean batch "
-                  << (st.advance_calls ? (double)st.advance_requests / st.advance_calls : 0.0) << "), " << st.frames << " frames\n";
+                  << (st.advance_calls ? (double)st.advance_requests / st.advance_calls : 0.0) << "), " << st.frames << " frames; batcher ms: init "
+                  << st.ms_by_kind[0] << " advance " << st.ms_by_kind[1] << " finalize " << st.ms_by_kind[2] << " best-path " << st.ms_by_kind[3]
+                  << " calls " << st.ms_by_kind[4] << " waiting " << st.ms_waiting << "\n";
       }
     } else if (single) {  // the reference's shape: one decoder object, one utterance at a time
       std::unique_ptr<GpuLatticeDecoder> decode_p(biglm ? new OnlineLatticeDecoderMempoolBiglm(&fst, opt, lm1p, lm2p, &limits)
@@ -506,7 +517,8 @@ int main(int argc, char **argv) {
     }
     double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cerr << "LOG Time taken " << elapsed << "s: real-time factor assuming 100 frames/sec is "
-              << (frame_count ? elapsed * 100.0 / frame_count : 0.0) << "\n";
+              << (frame_count ? elapsed * 100.0 / (frame_count + repeat_frames) : 0.0) << "\n";
+    if (repeat_frames) std::cerr << "LOG Frames decoded in all passes: " << (frame_count + repeat_frames) << "\n";
     std::cerr << "LOG Done " << num_success << " utterances, failed for " << num_fail << "\n";
     std::cerr << "LOG Overall log-likelihood per frame is " << (frame_count ? tot_like / frame_count : 0.0) << " over "
               << frame_count << " frames.\n";

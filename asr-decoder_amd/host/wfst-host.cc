@@ -298,6 +298,7 @@ void GpuChannelPool::Submit(Request *r) {
 void GpuChannelPool::Run() {
   std::unique_lock<std::mutex> lk(_mu);
   for (;;) {
+    const auto t_wait = std::chrono::steady_clock::now();
     _cv_work.wait(lk, [&] { return _stop || !_queue.empty(); });
     if (_queue.empty()) return;   // (_stop, nothing left to serve)
     // the other leased channels' requests are on their way more often than not (their threads were released together): a short
@@ -320,13 +321,12 @@ void GpuChannelPool::Run() {
     }
     std::vector<Request *> batch;
     batch.swap(_queue);
+    _stats.ms_waiting += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
     lk.unlock();
-    Execute(batch);
+    Execute(batch);   // (releases every kind's requesters as soon as that kind is served: Finish)
     lk.lock();
     _stats.batches += 1;
     _stats.requests += (long long)batch.size();
-    for (Request *r : batch) r->done = true;
-    _cv_done.notify_all();
   }
 }
 // One pass over what has arrived.  A channel has at most one request in a batch (its thread waits for it), so the kinds can be
@@ -346,18 +346,38 @@ void GpuChannelPool::Execute(std::vector<Request *> &batch) {
       if (call(&c, 1) != WFST_OK) r->error = std::make_exception_ptr(std::runtime_error(std::string(what) + ": " + wfst_last_error()));
     }
   };
-  listed(by_kind[kInit], "InitDecoding", [&](const int32_t *ch, int32_t n) { return wfst_decoder_init(_dec, ch, n); });
-  ExecuteAdvance(by_kind[kAdvance]);
-  listed(by_kind[kFinalize], "FinalizeDecoding", [&](const int32_t *ch, int32_t n) { return wfst_decoder_finalize(_dec, ch, n); });
-  ExecuteBestPath(by_kind[kBestPath]);
-  for (Request *r : by_kind[kCall]) {
-    try {
-      r->call(_dec);
-    } catch (...) {
-      r->error = std::current_exception();
+  double ms[kKinds] = {0, 0, 0, 0, 0};
+  // a kind's requesters go on as soon as that kind is served: the threads whose chunks have just been enqueued pull their next
+  // chunks while the batcher fetches other channels' best paths (which waits for the device)
+  auto clocked = [&](int kind, auto &&f) {
+    if (by_kind[kind].empty()) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    f();
+    ms[kind] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (Request *r : by_kind[kind]) r->decoded = wfst_decoder_num_frames_decoded(_dec, r->channel);
+    {
+      std::lock_guard<std::mutex> lk(_mu);
+      for (Request *r : by_kind[kind]) r->done = true;
     }
+    _cv_done.notify_all();
+  };
+  clocked(kInit, [&] { listed(by_kind[kInit], "InitDecoding", [&](const int32_t *ch, int32_t n) { return wfst_decoder_init(_dec, ch, n); }); });
+  clocked(kAdvance, [&] { ExecuteAdvance(by_kind[kAdvance]); });
+  clocked(kFinalize, [&] { listed(by_kind[kFinalize], "FinalizeDecoding", [&](const int32_t *ch, int32_t n) { return wfst_decoder_finalize(_dec, ch, n); }); });
+  clocked(kBestPath, [&] { ExecuteBestPath(by_kind[kBestPath]); });
+  clocked(kCall, [&] {
+    for (Request *r : by_kind[kCall]) {
+      try {
+        r->call(_dec);
+      } catch (...) {
+        r->error = std::current_exception();
+      }
+    }
+  });
+  {
+    std::lock_guard<std::mutex> lk(_mu);
+    for (int k = 0; k < kKinds; ++k) _stats.ms_by_kind[k] += ms[k];
   }
-  for (Request *r : batch) r->decoded = wfst_decoder_num_frames_decoded(_dec, r->channel);
 }
 void GpuChannelPool::ExecuteAdvance(std::vector<Request *> &all) {
   // one call per (stride, max_num_frames): in a service every stream has the same model, i.e. one call

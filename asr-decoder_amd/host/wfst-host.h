@@ -236,6 +236,8 @@ class GpuChannelPool {
     long long advance_calls;      // wfst_decoder_advance_host calls issued ...
     long long advance_requests;   // ... for this many AdvanceDecoding requests (their ratio = the mean batch)
     long long frames;             // frames handed to the device
+    double ms_by_kind[5];         // batcher time in the C-ABI calls: init, advance, finalize, best path, one-off calls
+    double ms_waiting;            // ... and waiting for requests (idle, or letting a batch form)
   };
   Stats GetStats();
   wfst_decoder *Handle() { return _dec; }

@@ -388,7 +388,7 @@ def stored_launches_per_step(entry, klass, default):
     return entry.get("launches", {}).get(klass, 2 * default) / 2.0
 
 
-def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=25):
+def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=25, repeat=4):
     """wfst-decode --threads=64 [--pool=64] --chunk=25 --pull over the batch's utterances: frames/s of the C++ DecoderItf mirror in the
     reference service's shape, and the words of every utterance against the batch decoder's (which the run has checked against the
     reference)."""
@@ -412,11 +412,11 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
                 key = ("utt%04d" % i).encode()
                 f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", T, P))
                 f.write(np.ascontiguousarray(mats[i], "<f4").tobytes())
-        common = [cli, "--tid2pdf=" + os.path.join(tmp, "tid2pdf.bin"), "--chunk=%d" % chunk, "--threads=%d" % threads,
+        common = [cli, "--tid2pdf=" + os.path.join(tmp, "tid2pdf.bin"), "--chunk=%d" % chunk, "--threads=%d" % threads, "--repeat=%d" % repeat,
                   "--max-frames=%d" % (T + 2), "--max-tokens=%d" % a.max_tokens, "--arena-tokens=%d" % int(T * a.arena_per_frame)]
         tail = [os.path.join(tmp, "decoder.conf"), gpath, os.path.join(tmp, "ll.bin")]
         want = {"utt%04d" % i: [int(w) for w in gpu_res[i]["words"]] for i in range(B) if gpu_res[i]["ok"]}
-        o = {"unit": "frames/s", "threads": threads, "chunk_frames": chunk, "utterances": int(B),
+        o = {"unit": "frames/s", "threads": threads, "chunk_frames": chunk, "utterances": int(B) * repeat, "passes_over_the_batch": repeat,
              "what": "wfst-decode --threads=%d --chunk=%d: %d host threads, one DecoderItf object each; pool / private: every score pulled through "
                      "LogLikelihood(frame, transition-id) of a DecodableMatrixScaledMapped-shaped decodable (6000 indices a frame, the graph reads "
                      "column ilabel); pool_matrix: MatrixDecodable rows of 3000 pdf columns taken in one piece (the graph reads tid2pdf[ilabel]); "
