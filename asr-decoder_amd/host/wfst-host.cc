@@ -379,8 +379,9 @@ void GpuChannelPool::Execute(std::vector<Request *> &batch) {
     for (int k = 0; k < kKinds; ++k) _stats.ms_by_kind[k] += ms[k];
   }
 }
-void GpuChannelPool::ExecuteAdvance(std::vector<Request *> &all) {
+void GpuChannelPool::ExecuteAdvance(std::vector<Request *> &requests) {
   // one call per (stride, max_num_frames): in a service every stream has the same model, i.e. one call
+  std::vector<Request *> all(requests);   // (consumed below; the caller's list is what it marks done)
   while (!all.empty()) {
     std::vector<Request *> rs, rest;
     for (Request *r : all) (r->stride == all[0]->stride && r->max_num_frames == all[0]->max_num_frames ? rs : rest).push_back(r);

@@ -22,5 +22,5 @@ with open("/tmp/dp/ll.bin", "wb") as f:
 P
 for args in "$@"; do
   echo "=== $args"
-  asr-decoder_amd/host/wfst-decode --tid2pdf=/tmp/dp/tid2pdf.bin --max-frames=302 --max-tokens=65536 --arena-tokens=4170000 $args /tmp/dp/decoder.conf /tmp/wfst_bench_graph_2850000.bin /tmp/dp/ll.bin 2>&1 >/dev/null | grep -E "LOG pool|LOG Time|ERROR|LOG Done|LOG Frames"
+  timeout 90 asr-decoder_amd/host/wfst-decode --tid2pdf=/tmp/dp/tid2pdf.bin --max-frames=302 --max-tokens=65536 --arena-tokens=4170000 $args /tmp/dp/decoder.conf /tmp/wfst_bench_graph_2850000.bin /tmp/dp/ll.bin 2>&1 >/dev/null | grep -E "LOG pool|LOG Time|ERROR|LOG Done|LOG Frames"
 done
