@@ -206,7 +206,8 @@ struct wfst_decoder {
   // requests right behind the batch of second passes of the same channels starts from those lattices
   std::vector<int32_t> post_dev_list, post_dev_decoded, post_dev_dres, post_dev_cres;
   const wfst_lm *post_dev_o = nullptr, *post_dev_n = nullptr;
-  struct DetLattice { int32_t n_states = 0, n_proper = 0, err = 0; std::vector<int4> a; std::vector<float2> w; };
+  struct DetLattice { int32_t n_states = 0, n_proper = 0, err = 0; std::vector<int4> a; std::vector<float2> w; unsigned long long ticks = 0; };
+  DevBuf<unsigned long long> det_ticks;
   std::vector<DetLattice> det_cache;
   std::vector<char> det_cached;
   std::vector<int32_t> det_live_nd;   // NumFramesDecoded() the cached lattice of a LIVE channel belongs to (-1: none)
@@ -294,7 +295,7 @@ struct wfst_decoder {
     if (pf_pin) (void)hipHostFree(pf_pin);
     if (det_pack_pin) (void)hipHostFree(det_pack_pin);
     pair_keys.release(); pair_list.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
-    det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release(); det_pack_a.release(); det_pack_w.release(); pf_dev.release();
+    det_ws.release(); det_result.release(); det_ticks.release(); det_out_a.release(); det_out_w.release(); det_pack_a.release(); det_pack_w.release(); pf_dev.release();
     cmp_ws.release(); cmp_result.release(); cmp_fin.release(); cmp_out_a.release(); cmp_out_w.release();
     np_ws.release(); np_out.release(); np_off.release(); np_arcs.release(); np_tot.release(); np_lists.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); emit_cnt.release(); prune_par.release();
@@ -2170,6 +2171,8 @@ static int ensure_det_workspace(wfst_decoder *d) {
   HIP_TRY(hipStreamSynchronize(d->stream));
   HIP_TRY(d->det_ws.alloc((size_t)d->det_slots * (size_t)X.words_per_channel));
   HIP_TRY(d->det_result.alloc((size_t)d->det_slots * 4));
+  HIP_TRY(d->det_ticks.alloc((size_t)d->det_slots));
+  X.ticks = d->det_ticks.p;
   HIP_TRY(d->det_out_a.alloc((size_t)d->det_slots * (size_t)X.out_cap));
   HIP_TRY(d->det_out_w.alloc((size_t)d->det_slots * (size_t)X.out_cap));
   X.ws = d->det_ws.p;
@@ -2227,10 +2230,16 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
     HIP_TRY(hipMemcpyAsync((char *)d->det_pack_pin + total * sizeof(int4), d->det_pack_w.p, total * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
   }
+  std::vector<unsigned long long> ticks(list.size(), 0ull);
+  if (X.ticks && !list.empty()) {
+    HIP_TRY(hipMemcpyAsync(ticks.data(), X.ticks, list.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+  }
   size_t off = 0;
   for (int i = 0; i < (int)list.size(); ++i) {
     wfst_decoder::DetLattice &L = detached ? d->pf_cache[(size_t)list[i]] : d->det_cache[(size_t)list[i]];
     L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
+    L.ticks = ticks[(size_t)i];
     L.err = res[4 * i + 2];   // reported when THIS channel's lattice is asked for
     if (!detached && d->p_ctl[list[i]].error) L.err = kDetErrCtl | d->p_ctl[list[i]].error;
     if (detached) d->pf_have[(size_t)list[i]] = 1;
@@ -2913,6 +2922,17 @@ int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t sta
   stats[2] = (int64_t)v[2];
   stats[3] = (int64_t)(v[3] & 0xFFFFFFFFull);
   stats[4] = (int64_t)(v[3] >> 32);
+  return WFST_OK;
+}
+
+int wfst_decoder_get_determinizer_ms(wfst_decoder *d, int32_t channel, float *ms) {
+  if (!d || !ms || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
+  *ms = 0.0f;
+  const wfst_decoder::DetLattice *L = nullptr;
+  if (!d->det_cached.empty() && d->det_cached[(size_t)channel]) L = &d->det_cache[(size_t)channel];
+  else if (!d->pf_have.empty() && d->pf_have[(size_t)channel]) L = &d->pf_cache[(size_t)channel];
+  if (!L) return fail(WFST_E_STATE, "no determinized lattice of this channel is held");
+  *ms = (float)((double)L->ticks / 1e5);   // (100 MHz)
   return WFST_OK;
 }
 

@@ -29,6 +29,8 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
   const int slot = blockIdx.x;
   const int c = chans ? chans[slot] : slot;
   const int tid = threadIdx.x;
+  const unsigned long long t_start = wall_clock64();
+  if (tid == 0 && X.ticks && phase != 2) X.ticks[slot] = 0ull;
   const ChanCtl *ctl = D.ctl + c;
   int32_t *res = X.result + (size_t)slot * 4;   // {states, arcs, status (0 ok, 1 workspace exceeded, 2 lattice too large), -}
   int32_t *base = X.ws + (size_t)slot * X.words_per_channel;   // workspace slots go with the launch's list, not the channel
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
   __syncthreads();
   // the root token (arena entry 0) must be state 0: lat_toks is in arena order, so it is
   if (phase == 1) {
-    if (tid == 0) res[3] = nt;   // (the CSR is complete: off[nt] = na)
+    if (tid == 0) { res[3] = nt; if (X.ticks) X.ticks[slot] = wall_clock64() - t_start; }   // (the CSR is complete: off[nt] = na)
     return;
   }
   }
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(kDetThreads) void determinize_kernel(DecoderDev D, 
     res[1] = no;
     res[2] = (err || over) ? 1 : 0;
     res[3] = W.os_n;   // states below this are the determinized states proper; the rest are the final states
+    if (X.ticks) X.ticks[slot] += wall_clock64() - t_start;   // (phase 2 adds to what phase 1 took)
   }
 }
 

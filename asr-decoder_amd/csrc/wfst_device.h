@@ -422,6 +422,7 @@ struct DetDev {
   int4 *out_a;                  // [cnt][out_cap] {src, dst, word, is-final-arc}
   float2 *out_w;                // [cnt][out_cap] {graph, acoustic}
   int32_t out_cap;
+  unsigned long long *ticks;    // [cnt] how long the slot's workgroup ran, in ticks of the constant 100 MHz clock (wfst_decoder_get_determinizer_ms)
 };
 void launch_determinize(const DecoderDev &D, const DetDev &X, const int32_t *chan_list_dev, int cnt, hipStream_t s, int phase = 0);   // phase: wfst_determinize.hip
 void launch_det_pack(const DetDev &X, int cnt, int4 *pack_a, float2 *pack_w, int64_t pack_cap, hipStream_t s);

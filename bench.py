@@ -486,12 +486,17 @@ def leg_scalars(o):
     r, c, b = o.get("roofline", {}), o.get("config", {}), o.get("cpu_baseline", {})
     k = {"value": o.get("value"), "ms_per_step": o.get("ms_per_step"), "steps": o.get("steps"),
          "kernel": r.get("kernel"), "frac": r.get("frac"), "whole_path_frac": r.get("whole_path", {}).get("frac_over_step_time"),
+         "whole_path_frac_8d": r.get("whole_path", {}).get("frac_8d_formula_over_step_time"),
          "parity": _ratio(c.get("parity")), "utterances_with_path": c.get("utterances_with_path"),
          "cpu_baseline_value": b.get("value"), "cpu_baseline_cores": b.get("cores"), "cpu_baseline_kind": b.get("kind")}
     if "lattice_parity" in c:
         k["lattice_parity"] = _ratio(c["lattice_parity"])
     if "determinizer_ms_per_lattice" in b:
         k["cpu_determinizer_ms_per_lattice"] = b["determinizer_ms_per_lattice"]
+    dl = c.get("determinized_lattices", {})
+    if "gpu_ms_per_lattice_mean" in dl:
+        k["gpu_determinizer_ms_per_lattice_mean"] = dl["gpu_ms_per_lattice_mean"]
+        k["gpu_determinizer_ms_per_lattice_max"] = dl["gpu_ms_per_lattice_max"]
     for dk in ("divergence_vs_reference", "divergence_vs_port"):   # service-point legs: word-level divergence over the whole batch
         if dk in o:
             k["bit_identical"] = "%d/%d" % (o[dk]["bit_identical"], o[dk]["utterances"])
@@ -576,7 +581,7 @@ def summary_line(out, detail_path=None):
     # (a line over the limit loses its optional parts -- strings first, then the legs' scalars from the least telling one up, then
     # whole legs from the last one -- rather than its contract keys, and is printed in any case)
     order = ("value", "ms_per_step", "steps", "frac", "parity", "cpu_baseline_value", "error", "utterances_with_path", "bit_identical", "wer_vs_cpu",
-             "cpu_self_wer", "whole_path_frac", "cpu_determinizer_ms_per_lattice", "wer_vs_cpu_max", "cpu_self_wer_max", "lattice_parity",
+             "cpu_self_wer", "whole_path_frac", "whole_path_frac_8d", "cpu_determinizer_ms_per_lattice", "gpu_determinizer_ms_per_lattice_mean", "gpu_determinizer_ms_per_lattice_max", "wer_vs_cpu_max", "cpu_self_wer_max", "lattice_parity",
              "pool_value", "pool_matrix_value", "private_value", "reference_value",
              "degraded_frames", "cpu_self_bit_identical", "kernel", "cpu_baseline_cores", "cpu_baseline_kind", "reference_threads", "pool_mean_advance_batch",
              "threads", "chunk_frames")
@@ -1116,6 +1121,13 @@ def main():
             out["config"]["determinized_lattices"] = {
                 "utterances": len(dl), "mean_states": float(np.mean([d["n_states"] for d in dl])) if dl else 0.0,
                 "mean_arcs": float(np.mean([len(d["a_src"]) for d in dl])) if dl else 0.0}
+            # the device's own time per lattice (the launch lasts as long as its largest lattice; each lattice's workgroup clocks
+            # itself: wfst_decoder_get_determinizer_ms), beside the reference's DeterminizeLatticeWrapper on a host core (cpu_baseline)
+            dms = [x for x in (dec.determinizer_ms(c) for c in range(B)) if x is not None]
+            if dms:
+                out["config"]["determinized_lattices"]["gpu_ms_per_lattice_mean"] = float(np.mean(dms))
+                out["config"]["determinized_lattices"]["gpu_ms_per_lattice_max"] = float(np.max(dms))
+                out["config"]["determinized_lattices"]["gpu_ms_per_lattice_median"] = float(np.median(dms))
             if a.pipeline_determinizer:
                 out["config"]["determinizer"] = ("pipelined (wfst_decoder_prefetch_determinized_detached): a step's lattices are determinized on a "
                                                  "side stream beside the NEXT step's decode and fetched one step later; the last step's are waited for "
@@ -1187,15 +1199,22 @@ def main():
                 orc = pyoracle.OracleDecoder()
                 orc.set_order_free(True)
                 hh = orc.load_graph(gpath)
-                nl, okl = min(ns, 2), 0
-                for i in range(nl):
-                    O = pyoracle.oracle_raw_lattice(orc, hh, pyoracle.Config(**cd), mats[i], m)
-                    dl = dec.raw_lattice(i)
+                nl, okl = min(ns, 16), 0
+
+                def same_raw(i):
+                    O = pyoracle.oracle_raw_lattice(orc, hh, pyoracle.Config(**cd), mats[i], m)   # (one shared graph, a decode per thread: as cpu_decode_all)
+                    dl = raw_dev[i]
                     if dl is None or O is None:
-                        continue
+                        return 0
                     L = pyoracle.RawLattice(True, dl["n_states"], 0, dl["st_final"], dl["a_src"], dl["a_dst"], dl["a_ilabel"], dl["a_olabel"],
                                             dl["a_graph"], dl["a_acoustic"], dl["st_frame"], dl["st_state"], dl["st_cost"])
-                    okl += int(L.n_states == O.n_states and np.array_equal(L.labelled_arcs(), O.labelled_arcs()))
+                    return int(L.n_states == O.n_states and np.array_equal(L.labelled_arcs(), O.labelled_arcs()))
+
+                raw_dev = [dec.raw_lattice(i) for i in range(nl)]
+                from concurrent.futures import ThreadPoolExecutor
+
+                with ThreadPoolExecutor(max_workers=min(nl, max(1, min(16, cpus)))) as ex:
+                    okl = sum(ex.map(same_raw, range(nl)))
                 orc.set_order_free(False)
                 orc.free_graph(hh)
                 out["config"]["lattice_parity"] = "%d/%d sampled raw lattices arc for arc equal to the CPU restatement's (order-free mode)" % (okl, nl)
@@ -1237,6 +1256,7 @@ def main():
             kb = {"expand": scale * (20.0 * E + 16.0 * N) + 16.0 * Zo, "insert": scale * (8.0 * E + 8.0 * N) + 8.0 * Zo, "closure": 0.0}
         else:
             kb = {"expand": scale * (20.0 * E + 16.0 * N), "insert": scale * (8.0 * E + 8.0 * N), "closure": 24.0 * Z}
+        Z8d = (oc["Z"] * (E / float(max(oc["E"], 1)))) if (fused and do_cpu) else float(Z)   # traversed epsilon arcs of the batch (the CPU restatement's count where the closures are fused)
         out["config"]["fused_epsilon_closures"] = bool(fused)
         if a.lattice_links > 0:
             # lattice mode adds (DESIGN.md "Roofline accounting"): 16 B per forward link recorded (insert launch); per back-pruning
@@ -1333,7 +1353,10 @@ def main():
                                                        "survivor moved by a compaction" if a.lattice_links > 0 else "") +
                                                       ("; + biglm terms (builder-defined): 96 B per LM look-up (charged to the kernel that makes it: expansion for emitting arcs, closure pass for epsilon arcs), 4 B pair id per token and record" if a.biglm else "")),
                                           "frac_over_kernel_time": (whole_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms > 0 else 0.0,
-                                          "frac_over_step_time": whole_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                          "frac_over_step_time": whole_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          # ... and on SURVEY.md 8(d)'s own three terms alone (no builder-defined additions)
+                                          "bytes_8d_formula": scale * (28.0 * E + 24.0 * N) + 24.0 * (Z8d),
+                                          "frac_8d_formula_over_step_time": (scale * (28.0 * E + 24.0 * N) + 24.0 * (Z8d)) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                            "measured": "hipEvent pairs around every launch on the stream it is launched on, one extra step after the timed region"}
         if ng > 1:
             # Channel groups: each group's launches run on its own stream and overlap the other group's (that is what the
@@ -1478,15 +1501,17 @@ def main():
         cpu_off = ["--no-cpu-baseline"]
         legs = {# the headline with wfst_limits all zero: what a caller who sizes nothing gets
                 "headline_library_default_limits": ["--default-limits", "--steps", str(max(6, n2)), "--cpu-sample", "4"] + cpu_off,
-                "biglm": ["--biglm", "--steps", str(max(6, n2)), "--cpu-sample", "8", "--max-tokens", "131072"] + cpu_on,
+                # the headline with the log-likelihoods handed over as HOST matrices inside every step (PCIe-inclusive; never the reported value)
+                "host_feed": ["--host-feed", "--steps", str(max(6, n2)), "--cpu-sample", "4"] + cpu_off,
+                "biglm": ["--biglm", "--steps", str(max(6, n2)), "--cpu-sample", "32", "--max-tokens", "131072"] + cpu_on,
                 # ... at lattice_beam 7 the reference's biglm final pruning (biglm.h:186-188) leaves 45 of the 128 utterances a path; at 14,
                 # 121 of them: the same search (the beam is what it costs), a result for nearly every utterance
                 "biglm_lattice_beam14": ["--biglm", "--lattice-beam", "14", "--steps", str(max(6, n2)), "--cpu-sample", "8", "--max-tokens", "131072"] + cpu_off,
-                "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "4", "--warmup", "2", "--postprocess"] + cpu_on,
+                "lattice_beam13": ["--lattice-links", "25165824", "--steps", str(max(4, n2)), "--cpu-sample", "16", "--warmup", "2", "--postprocess"] + cpu_on,
                 "lattice_beam15_no_determinizer": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
                                                    "--max-tokens", "262144", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "2", "--warmup", "2"] + cpu_off,
                 "lattice_beam15": ["--beam", "15", "--lattice-beam", "8", "--lattice-links", "25165824", "--arena-per-frame", "60000",
-                                   "--max-tokens", "262144", "--determinize", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "4",
+                                   "--max-tokens", "262144", "--determinize", "--steps", str(max(4, n2 // 2)), "--cpu-sample", "16",
                                    "--warmup", "2"] + cpu_on,   # (the n-best / determinizer paths allocate their workspaces on first use)
                 # ... and as a service that refills its channels at once would run it: utterance k's lattices determinized beside
                 # utterance k + 1's decode (wfst_decoder_prefetch_determinized_detached), fetched one step later, the last step's

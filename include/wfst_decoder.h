@@ -485,6 +485,12 @@ int wfst_decoder_channel_groups(wfst_decoder *d);
  * tokens + links scanned by the compactions, tokens + links the compactions moved}. */
 int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t stats[5]);
 
+/* How long the device took to determinize the lattice of `channel` that the decoder holds (the last wfst_decoder_get_determinized_lattice
+ * / prefetch of it), in milliseconds of the device's constant clock: the time of that lattice's own workgroup, not of the launch
+ * (which lasts as long as its largest lattice).  Beside the reference's DeterminizeLatticeWrapper timed on a host core (bench.py).
+ * WFST_E_STATE if no determinized lattice of the channel is held. */
+int wfst_decoder_get_determinizer_ms(wfst_decoder *d, int32_t channel, float *ms);
+
 /* Running back-pruning passes (PruneActiveTokens, base-inl.h:439-607) of the channel since its last init whose several-workgroup
  * pricing of the never-priced frames was ABANDONED -- a workgroup waited 40 ms for its siblings (a chip shared with other
  * processes) -- and done over by the one-workgroup walk: the same lattice, later; never an error.  -1: the several-workgroup pass is
