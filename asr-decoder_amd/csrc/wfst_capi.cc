@@ -226,6 +226,19 @@ struct wfst_decoder {
   std::vector<char> pf_have;
   std::vector<int32_t> fin_epoch, pf_epoch;   // FinalizeDecoding calls per channel; ... as of the pending prefetch
   std::vector<int32_t> pf_list, pf_res;
+  // the n-best of a prefetch (wfst_decoder_prefetch_*_nbest): NShortestPath of every determinized lattice right behind the
+  // determinizer on its stream -- workspaces of their own (the decoder's stream may run a batched n-best of its own meanwhile),
+  // bounded per lattice (kPfNpStates / kPfNpArcs: a determinized lattice of a few seconds of speech has a few hundred of each;
+  // a larger one reports "not computed" and is asked for alone), results landing in pinned memory with the lattices' result words
+  int32_t pf_npaths = 0;              // of the prefetch in flight / last harvested (0: lattices only)
+  DevBuf<int32_t> pf_np_ws, pf_np_arcs, pf_np_off, pf_np_out;
+  DevBuf<NbPathEntry> pf_np_lists;
+  DevBuf<float> pf_np_tot;
+  int32_t pf_np_slots = 0, pf_np_n = 0;
+  void *pf_np_pin = nullptr;
+  size_t pf_np_pin_bytes = 0;
+  std::vector<NbPaths> pf_nbp;        // [channel] detached prefetches: the paths of the utterance the prefetched lattice belongs to
+  std::vector<char> pf_nbp_have;
   int32_t *pf_pin = nullptr;          // [2][n_channels * 4] pinned: the channel list going up, the launch's result words coming down (a copy from or
                                       // to pageable memory would hold the calling thread until the launch is over)
   DevBuf<int32_t> pf_dev;
@@ -293,6 +306,8 @@ struct wfst_decoder {
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
     if (pf_pin) (void)hipHostFree(pf_pin);
+    if (pf_np_pin) (void)hipHostFree(pf_np_pin);
+    pf_np_ws.release(); pf_np_arcs.release(); pf_np_off.release(); pf_np_out.release(); pf_np_lists.release(); pf_np_tot.release();
     if (det_pack_pin) (void)hipHostFree(det_pack_pin);
     pair_keys.release(); pair_list.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
     det_ws.release(); det_result.release(); det_ticks.release(); det_out_a.release(); det_out_w.release(); det_pack_a.release(); det_pack_w.release(); pf_dev.release();
@@ -2291,7 +2306,7 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
 // NOW, on a side stream -- one lane per lattice, a launch as long as its largest lattice, beside which the decoder's own stream
 // serves best paths and n-best lists (both only read the raw lattices; the arena-index -> lattice-state map the n-best search
 // and the determinizer each write is the same map).  The first wfst_decoder_get_determinized_lattice finds the work done or waits.
-static int prefetch_determinized(wfst_decoder *d, bool detached);
+static int prefetch_determinized(wfst_decoder *d, bool detached, int32_t n_paths = 0);
 int wfst_decoder_prefetch_determinized(wfst_decoder *d) { return prefetch_determinized(d, false); }
 // ... DETACHED: the determinizer's first phase -- everything that reads the channels' state: control blocks, resolved lists, the
 // arena-index scratch; a fraction of a millisecond -- runs on the decoder's stream, the subset construction (tens of milliseconds on
@@ -2299,8 +2314,17 @@ int wfst_decoder_prefetch_determinized(wfst_decoder *d) { return prefetch_determ
 // the channels go on to their next utterances beside it.  The lattices are kept per channel (wfst_decoder_get_prefetched_lattice)
 // until the next detached prefetch is harvested.
 int wfst_decoder_prefetch_determinized_detached(wfst_decoder *d) { return prefetch_determinized(d, true); }
+// ... with GetNbest behind GetLattice, as the service runs them (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105: NShortestPath
+// on the lattice DeterminizeLatticeWrapper returned): the n cheapest paths of every lattice of the prefetch, computed right behind
+// the determinizer on its stream
+int wfst_decoder_prefetch_nbest(wfst_decoder *d, int32_t n_paths, int32_t detached) {
+  if (n_paths < 1 || n_paths > 64) return fail(WFST_E_ARG, "1 <= n <= 64 paths with a prefetch (more: wfst_decoder_nbest_paths_batch)");
+  return prefetch_determinized(d, detached != 0, n_paths);
+}
 
-static int prefetch_determinized(wfst_decoder *d, bool detached) {
+static constexpr int32_t kPfNpStates = 4096, kPfNpArcs = 8192;   // the largest determinized lattice a prefetch's n-best takes
+
+static int prefetch_determinized(wfst_decoder *d, bool detached, int32_t n_paths) {
   if (!d) return fail(WFST_E_ARG, "NULL decoder");
   if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice needs a decoder created with wfst_limits.lattice_links > 0");
   HIP_TRY(hipSetDevice(d->device));
@@ -2340,6 +2364,49 @@ static int prefetch_determinized(wfst_decoder *d, bool detached) {
   launch_determinize(d->D, d->det, d->pf_dev.p, (int32_t)list.size(), side, detached ? 2 : 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(pin_res, d->det.result, list.size() * 4 * 4, hipMemcpyDeviceToHost, side));
+  d->pf_npaths = 0;
+  if (n_paths > 0) {
+    const int32_t cnt = (int32_t)list.size();
+    NbPathsDev P = {};
+    P.a = d->det.out_a; P.w = d->det.out_w; P.res = d->det.result; P.fin = nullptr;
+    P.in_stride = d->det.out_cap; P.fin_stride = 0;
+    P.n = n_paths;
+    P.ws_ints = 7ll * kPfNpStates + 4ll * kPfNpArcs + kPfNpArcs + 16;
+    P.list_cap = (int64_t)kPfNpStates * n_paths + 1;
+    P.out_cap = n_paths * 1024;   // arcs on a lattice's n paths together (a path of a determinized lattice: a word or an epsilon per state)
+    if (d->pf_np_slots < cnt || d->pf_np_n < n_paths) {
+      HIP_TRY(hipStreamSynchronize(side));
+      const int32_t slots = std::max(cnt, d->n_channels);
+      HIP_TRY(d->pf_np_ws.alloc((size_t)slots * (size_t)P.ws_ints));
+      HIP_TRY(d->pf_np_lists.alloc((size_t)slots * (size_t)P.list_cap));
+      HIP_TRY(d->pf_np_arcs.alloc((size_t)slots * (size_t)P.out_cap));
+      HIP_TRY(d->pf_np_off.alloc((size_t)slots * (size_t)(n_paths + 1)));
+      HIP_TRY(d->pf_np_tot.alloc((size_t)slots * (size_t)n_paths));
+      HIP_TRY(d->pf_np_out.alloc((size_t)slots * 4));
+      d->pf_np_slots = slots;
+      d->pf_np_n = n_paths;
+    }
+    // (buffers sized for pf_np_n paths serve a request for fewer: the strides below are the request's own)
+    P.ws = d->pf_np_ws.p; P.lists = d->pf_np_lists.p; P.out = d->pf_np_out.p; P.out_off = d->pf_np_off.p; P.out_tot = d->pf_np_tot.p;
+    P.out_arcs = d->pf_np_arcs.p;
+    const size_t b_out = (size_t)cnt * 4 * 4, b_off = (size_t)cnt * (size_t)(n_paths + 1) * 4, b_tot = (size_t)cnt * (size_t)n_paths * 4,
+                 b_arcs = (size_t)cnt * (size_t)P.out_cap * 4;
+    if (d->pf_np_pin_bytes < b_out + b_off + b_tot + b_arcs) {
+      if (d->pf_np_pin) (void)hipHostFree(d->pf_np_pin);
+      d->pf_np_pin = nullptr;
+      d->pf_np_pin_bytes = 0;
+      HIP_TRY(hipHostMalloc(&d->pf_np_pin, b_out + b_off + b_tot + b_arcs, hipHostMallocDefault));
+      d->pf_np_pin_bytes = b_out + b_off + b_tot + b_arcs;
+    }
+    launch_nbest_paths(P, cnt, side);
+    HIP_TRY(hipGetLastError());
+    char *pin = (char *)d->pf_np_pin;
+    HIP_TRY(hipMemcpyAsync(pin, P.out, b_out, hipMemcpyDeviceToHost, side));
+    HIP_TRY(hipMemcpyAsync(pin + b_out, P.out_off, b_off, hipMemcpyDeviceToHost, side));
+    HIP_TRY(hipMemcpyAsync(pin + b_out + b_off, P.out_tot, b_tot, hipMemcpyDeviceToHost, side));
+    HIP_TRY(hipMemcpyAsync(pin + b_out + b_off + b_tot, P.out_arcs, b_arcs, hipMemcpyDeviceToHost, side));
+    d->pf_npaths = n_paths;
+  }
   HIP_TRY(hipEventRecord(d->pf_ev_done, side));
   d->pf_pending = true;
   d->pf_detached = detached;
@@ -2354,7 +2421,68 @@ static int finish_prefetch(wfst_decoder *d) {
   d->pf_detached = false;
   d->pf_res.assign(d->pf_pin + (size_t)d->n_channels * 4, d->pf_pin + (size_t)d->n_channels * 4 + d->pf_list.size() * 4);
   // (a channel initialised or finalized anew since the launch: hooks in front of those calls came here first)
-  return harvest_determinized(d, d->pf_list, d->pf_res, false, 1, detached);
+  const int rc = harvest_determinized(d, d->pf_list, d->pf_res, false, 1, detached);
+  if (rc != WFST_OK || d->pf_npaths <= 0) return rc;
+  // ... and the paths NShortestPath found on those lattices: arc indices -> the labels and costs of the lattices just fetched
+  const int32_t n_paths = d->pf_npaths, cnt = (int32_t)d->pf_list.size(), out_cap = n_paths * 1024;
+  const char *pin = (const char *)d->pf_np_pin;
+  const int32_t *pout = (const int32_t *)pin;
+  const int32_t *poff = (const int32_t *)(pin + (size_t)cnt * 16);
+  const float *ptot = (const float *)(pin + (size_t)cnt * 16 + (size_t)cnt * (size_t)(n_paths + 1) * 4);
+  const int32_t *parcs = (const int32_t *)(pin + (size_t)cnt * 16 + (size_t)cnt * (size_t)(n_paths + 1) * 4 + (size_t)cnt * (size_t)n_paths * 4);
+  if (d->resc_cache.empty()) { d->resc_cache.resize((size_t)d->n_channels); d->nbp_cache.resize((size_t)d->n_channels); }
+  if (detached) { d->pf_nbp.assign((size_t)d->n_channels, wfst_decoder::NbPaths()); d->pf_nbp_have.assign((size_t)d->n_channels, 0); }
+  for (int i = 0; i < cnt; ++i) {
+    const int c = d->pf_list[(size_t)i];
+    const wfst_decoder::DetLattice &L = detached ? d->pf_cache[(size_t)c] : d->det_cache[(size_t)c];
+    const int32_t *o = pout + (size_t)4 * i;
+    if (L.err || o[2] == 1 || o[2] == 3) continue;   // (no lattice, or one beyond the prefetch's n-best bounds: asked for alone, the paths are computed then)
+    wfst_decoder::NbPaths R;
+    R.key.o = nullptr; R.key.n = nullptr; R.key.use_final = 1; R.key.n_paths = n_paths; R.key.decoded = d->h_decoded[c]; R.key.valid = true;
+    const int32_t found = L.n_states > 0 ? o[0] : 0, total = L.n_states > 0 ? o[1] : 0;
+    if (total > out_cap) continue;
+    R.off.assign(1, 0);
+    if (found) R.off.assign(poff + (size_t)i * (size_t)(n_paths + 1), poff + (size_t)i * (size_t)(n_paths + 1) + found + 1);
+    R.tot.assign(ptot + (size_t)i * (size_t)n_paths, ptot + (size_t)i * (size_t)n_paths + found);
+    R.olabel.resize((size_t)total); R.graph.resize((size_t)total); R.ac.resize((size_t)total);
+    bool ok = true;
+    for (int32_t k = 0; k < total && ok; ++k) {
+      const size_t aidx = (size_t)parcs[(size_t)i * (size_t)out_cap + (size_t)k];
+      if (aidx >= L.a.size()) { ok = false; break; }
+      R.olabel[(size_t)k] = L.a[aidx].z;
+      R.graph[(size_t)k] = L.w[aidx].x;
+      R.ac[(size_t)k] = L.w[aidx].y;
+    }
+    if (!ok) continue;
+    if (detached) { d->pf_nbp[(size_t)c] = R; d->pf_nbp_have[(size_t)c] = 1; }
+    // a channel that still holds the very utterance: wfst_decoder_get_nbest_paths(channel, n, 1, NULL, NULL) finds the work done
+    if (d->h_state[c] == 2 && (!detached || (d->det_cached[(size_t)c] && d->pf_epoch[(size_t)i] == d->fin_epoch[(size_t)c]))) d->nbp_cache[(size_t)c] = R;
+  }
+  return WFST_OK;
+}
+
+int wfst_decoder_get_prefetched_nbest_paths(wfst_decoder *d, int32_t channel, int32_t cap_paths, int32_t cap_arcs, int32_t *n_paths, int32_t *total_arcs,
+                                            int32_t *path_off, float *path_tot, int32_t *a_olabel, float *a_graph, float *a_acoustic) {
+  if (!d || channel < 0 || channel >= d->n_channels || !n_paths || !total_arcs) return fail(WFST_E_ARG, "bad argument");
+  *n_paths = 0;
+  *total_arcs = 0;
+  if (d->pf_nbp_have.empty() || !d->pf_nbp_have[(size_t)channel])
+    return fail(WFST_E_STATE, "no harvested detached prefetch with an n-best has covered this channel (or its lattice was beyond the prefetch's bounds)");
+  const wfst_decoder::NbPaths &R = d->pf_nbp[(size_t)channel];
+  const int32_t found = (int32_t)R.tot.size(), total = (int32_t)R.olabel.size();
+  *n_paths = found;
+  *total_arcs = total;
+  if (found > cap_paths || total > cap_arcs) return fail(WFST_E_CAPACITY, "n-best larger than the given capacities");
+  for (int32_t q = 0; q <= found; ++q)
+    if (path_off) path_off[q] = R.off[(size_t)q];
+  for (int32_t q = 0; q < found; ++q)
+    if (path_tot) path_tot[q] = R.tot[(size_t)q];
+  for (int32_t q = 0; q < total; ++q) {
+    if (a_olabel) a_olabel[q] = R.olabel[(size_t)q];
+    if (a_graph) a_graph[q] = R.graph[(size_t)q];
+    if (a_acoustic) a_acoustic[q] = R.ac[(size_t)q];
+  }
+  return WFST_OK;
 }
 
 // Waits for a prefetch in flight and takes its lattices over (what the next prefetch, or any other use of the determinizer, does

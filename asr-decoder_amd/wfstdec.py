@@ -35,7 +35,7 @@ SYMBOLS = [
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
     "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice", "wfst_decoder_get_nbest_paths",
-    "wfst_decoder_get_degraded_frames", "wfst_decoder_get_prune_raw_abandoned", "wfst_host_alloc", "wfst_host_free", "wfst_decoder_busy", "wfst_decoder_get_determinizer_ms", "wfst_decoder_get_path_flags", "wfst_decoder_rescore_lattices", "wfst_decoder_nbest_paths_batch",
+    "wfst_decoder_get_degraded_frames", "wfst_decoder_get_prune_raw_abandoned", "wfst_host_alloc", "wfst_host_free", "wfst_decoder_busy", "wfst_decoder_get_determinizer_ms", "wfst_decoder_prefetch_nbest", "wfst_decoder_get_prefetched_nbest_paths", "wfst_decoder_get_path_flags", "wfst_decoder_rescore_lattices", "wfst_decoder_nbest_paths_batch",
     "wfst_decoder_prefetch_determinized", "wfst_lattice_labels_batch",
     "wfst_decoder_prefetch_determinized_detached", "wfst_decoder_get_prefetched_lattice", "wfst_decoder_harvest_prefetched",
 ]
@@ -417,12 +417,53 @@ class BatchDecoder:
         return dict(n_states=S, st_final=fin, st_frame=fr, st_state=gs, st_cost=co, a_src=src, a_dst=dst, a_ilabel=il,
                     a_olabel=ol, a_graph=gr, a_acoustic=ac)
 
-    def prefetch_determinized(self, detached=False):
+    def prefetch_determinized(self, detached=False, nbest=0):
         """Start the determinization of every finalized channel now, on a side stream (wfst_decoder_prefetch_determinized):
         best_paths() / nbest() run beside it, determinized_lattice(c) finds the work done or waits.  detached=True: init /
         advance / finalize do not wait for it either -- the channels decode their next utterances beside it -- and the lattices
         are fetched with prefetched_lattice(c) (wfst_decoder_prefetch_determinized_detached)."""
+        if nbest > 0:   # GetNbest behind GetLattice on the determinizer's stream (wfst_decoder_prefetch_nbest)
+            _check(lib().wfst_decoder_prefetch_nbest(self.h, int(nbest), int(bool(detached))))
+            return
         _check((lib().wfst_decoder_prefetch_determinized_detached if detached else lib().wfst_decoder_prefetch_determinized)(self.h))
+
+    def _nbest_fetch_all(self, f, extra, n):
+        """f(handle, channel, *extra, cap_paths, cap_arcs, &n_paths, &total_arcs, off, tot, olabel, graph, acoustic) for every channel, over
+        one buffer: per channel a list of dicts {words, olabel, graph, acoustic, tot} in ascending cost (words = the nonzero olabels), or
+        None where the call reports no result."""
+        K, A = int(n), int(n) * 256
+        stride = (K + 1) + K + 3 * A
+        buf = np.zeros((self.n, stride), np.int32)
+        base = buf.ctypes.data
+        npth, na = C.c_int32(0), C.c_int32(0)
+        pn, pa = C.byref(npth), C.byref(na)
+        vp = C.c_void_p
+        out = [None] * self.n
+        fbuf = buf.view(np.float32)
+        for c in range(self.n):
+            p = base + 4 * stride * c
+            rc = f(self.h, c, *extra, K, A, pn, pa, vp(p), vp(p + 4 * (K + 1)), vp(p + 4 * (2 * K + 1)), vp(p + 4 * (2 * K + 1 + A)), vp(p + 4 * (2 * K + 1 + 2 * A)))
+            if rc != WFST_OK:
+                continue
+            k = npth.value
+            off = buf[c, : k + 1]
+            o0 = 2 * K + 1
+            paths = []
+            for i in range(k):
+                a, b = int(off[i]), int(off[i + 1])
+                ol = buf[c, o0 + a:o0 + b]
+                paths.append(dict(olabel=ol, words=ol[ol != 0], graph=fbuf[c, o0 + A + a:o0 + A + b], acoustic=fbuf[c, o0 + 2 * A + a:o0 + 2 * A + b],
+                                  tot=float(fbuf[c, K + 1 + i])))
+            out[c] = paths
+        return out
+
+    def prefetched_nbest(self, n):
+        """The n-best paths a harvested detached prefetch (prefetch_determinized(detached=True, nbest=n)) computed, for every channel."""
+        return self._nbest_fetch_all(lib().wfst_decoder_get_prefetched_nbest_paths, (), n)
+
+    def nbest_paths_all(self, n, use_final_probs=True):
+        """nbest_paths(c, n) for every channel in one sweep (after prefetch_determinized(nbest=n) or nbest_paths_batch(n): no device work)."""
+        return self._nbest_fetch_all(lib().wfst_decoder_get_nbest_paths, (int(n), int(bool(use_final_probs)), None, None), n)
 
     def harvest_prefetched(self):
         """Wait for a prefetch in flight and take its lattices over (wfst_decoder_harvest_prefetched)."""

@@ -101,6 +101,8 @@ def parse():
     ap.add_argument("--prune-interval", type=int, default=25, help="config prune_interval (reference default 25): lattice mode back-prunes and "
                     "compacts every this many frames; >= --frames: once, at FinalizeDecoding (offline batches that have the memory)")
     ap.add_argument("--nbest", type=int, default=5, help="n of the n-best taken per utterance in lattice mode")
+    ap.add_argument("--raw-nbest", action="store_true", help="lattice mode with --determinize: the step's n-best is the short list taken from the RAW "
+                                                              "lattice (round 5's step) instead of NShortestPath on the determinized one")
     ap.add_argument("--postprocess", action="store_true", help="lattice mode: after the timed steps, the service's post-processing of the whole "
                     "batch -- GetLattice with the second LM pass and the 10-best of it -- through the batched calls, next to one channel alone")
     ap.add_argument("--debug", type=int, default=0, help="wfst_options.debug (kernel phase timers 32 closure / 64 insert / 128 expand: "
@@ -853,12 +855,17 @@ def main():
                 dec.advance(ptrs, ready, P)
             t2 = time.perf_counter()
             dec.finalize()
+            # --determinize: the service's order -- GetLattice (GetRawLattice + DeterminizeLatticeWrapper), then GetNbest = NShortestPath
+            # on THAT lattice (kaldi-online-nnet3-my-decoder.cc:97-105) -- both started here, on the determinizer's stream
+            # (wfst_decoder_prefetch_nbest); the short list from the RAW lattice (wfst_decoder_get_nbest) is the step's n-best only
+            # where no determinized lattice is asked for
+            det_nbest = a.lattice_links > 0 and a.determinize and not a.no_prefetch and not a.raw_nbest
             if a.lattice_links > 0 and a.determinize and a.pipeline_determinizer:
                 # (harvests the utterances of the step before, starts these: the subset construction runs on its own stream while
                 # the channels decode the NEXT step's utterances -- wfst_decoder_prefetch_determinized_detached)
-                dec.prefetch_determinized(detached=True)
+                dec.prefetch_determinized(detached=True, nbest=a.nbest if det_nbest else 0)
             elif a.lattice_links > 0 and a.determinize and not a.no_prefetch:
-                dec.prefetch_determinized()   # GetLattice's determinizer starts now, beside the best paths and the n-best lists
+                dec.prefetch_determinized(nbest=a.nbest if det_nbest else 0)   # GetLattice's determinizer starts now, beside the best paths
             t3 = time.perf_counter()
             if os.environ.get("WFST_BENCH_BREAKDOWN"):
                 dec.sync()
@@ -866,19 +873,26 @@ def main():
             res = dec.best_paths(cap=2 * T + 64)
             t4a = time.perf_counter()
             if a.lattice_links > 0:
-                nb = dec.nbest(a.nbest)
+                if not det_nbest:
+                    nb = dec.nbest(a.nbest)
+                    for r, paths in zip(res, nb):
+                        r["nbest"] = paths
                 tb["nbest"] = tb.get("nbest", 0.0) + time.perf_counter() - t4a
                 tb["best_paths_only"] = tb.get("best_paths_only", 0.0) + t4a - t4
-                for r, paths in zip(res, nb):
-                    r["nbest"] = paths
                 if a.determinize and a.pipeline_determinizer:
-                    if pipe["primed"]:   # the lattices of the step before (every step decodes the same utterances)
+                    if pipe["primed"]:   # the lattices (and n-best lists) of the step before (every step decodes the same utterances)
                         for r, L in zip(res, dec.prefetched_lattices()):
                             r["det"] = L
+                        if det_nbest:
+                            for r, paths in zip(res, dec.prefetched_nbest(a.nbest)):
+                                r["nbest"] = paths
                     pipe["primed"] = True
                 elif a.determinize:
                     for r, L in zip(res, dec.determinized_lattices()):
                         r["det"] = L
+                    if det_nbest:
+                        for r, paths in zip(res, dec.nbest_paths_all(a.nbest)):
+                            r["nbest"] = paths
             t5 = time.perf_counter()
             for k, v in zip(("init", "advance_enqueue", "finalize", "sync", "best_paths"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 tb[k] += v
@@ -897,6 +911,9 @@ def main():
                 dec.harvest_prefetched()
                 for r, L in zip(res, dec.prefetched_lattices()):
                     r["det"] = L
+                if not a.no_prefetch and not a.raw_nbest:
+                    for r, paths in zip(res, dec.prefetched_nbest(a.nbest)):
+                        r["nbest"] = paths
 
         step.drain = drain
         return step
@@ -1116,6 +1133,13 @@ def main():
         if a.lattice_links == 0 and not a.biglm:
             out["config"]["degraded_frames"] = int(sum(dec.degraded_frames(c) for c in range(B)))
         out["config"]["utterances_with_path"] = int(sum(1 for r in res if r["ok"]))
+        if a.lattice_links > 0 and any("nbest" in r for r in res):
+            # the 1-best of the step's n-best against the best path: the same word sequence (the determinized lattice keeps, for
+            # every word sequence, its cheapest path)
+            nb_ok = sum(1 for r in res if r["ok"] and r.get("nbest") and np.array_equal(np.asarray(r["nbest"][0]["words"]), np.asarray(r["words"])))
+            out["config"]["nbest_1best_same_words_as_best_path"] = "%d/%d" % (nb_ok, sum(1 for r in res if r["ok"]))
+            out["config"]["nbest_from"] = ("NShortestPath on the DETERMINIZED lattice, behind the determinizer on its stream (wfst_decoder_prefetch_nbest)"
+                                           if (a.determinize and not a.no_prefetch and not a.raw_nbest) else "the k-best search over the raw lattice (wfst_decoder_get_nbest)")
         if a.lattice_links > 0 and a.determinize:
             dl = [r["det"] for r in res if r.get("det") is not None]
             out["config"]["determinized_lattices"] = {

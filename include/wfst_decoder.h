@@ -381,6 +381,17 @@ int wfst_decoder_prefetch_determinized(wfst_decoder *d);
  * four hardware queues it can end up sharing a queue with a channel group's stream, whose launches then wait behind the
  * determinizer -- export GPU_MAX_HW_QUEUES=8 before the process's first HIP call. */
 int wfst_decoder_prefetch_determinized_detached(wfst_decoder *d);
+/* GetLattice AND GetNbest ahead of their requests, as the service runs them one behind the other (kaldi-nnet3/kaldi-online-nnet3-
+ * my-decoder.cc:97-105: NShortestPath on the lattice DeterminizeLatticeWrapper returned): like wfst_decoder_prefetch_determinized
+ * (detached = 0) / _detached (detached != 0), with the n_paths (<= 64) cheapest paths of every lattice computed right behind the
+ * determinizer on its stream.  detached = 0: wfst_decoder_get_nbest_paths(channel, n_paths, 1, NULL, NULL, ...) then finds the work
+ * done; detached: wfst_decoder_get_prefetched_nbest_paths once harvested (same outputs; WFST_E_STATE where the channel's lattice
+ * was not covered or was larger than the prefetch's n-best takes -- 4096 states / 8192 arcs: ask for it alone then). */
+int wfst_decoder_prefetch_nbest(wfst_decoder *d, int32_t n_paths, int32_t detached);
+int wfst_decoder_get_prefetched_nbest_paths(wfst_decoder *d, int32_t channel, int32_t cap_paths, int32_t cap_arcs, int32_t *n_paths,
+                                            int32_t *total_arcs, int32_t *path_off, float *path_tot, int32_t *a_olabel, float *a_graph,
+                                            float *a_acoustic);
+
 /* Waits for a prefetch in flight and takes its lattices over -- what the next prefetch (or any other use of the determinizer)
  * does by itself; for the last utterance of a stream of them.  wfst_decoder_get_prefetched_lattice returns the lattices of the
  * last HARVESTED detached prefetch and never waits: right behind the call that started utterance k's determinization it returns

@@ -365,3 +365,83 @@ def test_a_channels_device_error_stays_with_that_channel(synth, tmp_path):
     dec.free()
     graph.free()
     del keep, keep2
+
+
+def test_prefetch_with_nbest_gives_the_paths_of_the_determinized_lattice(synth, tmp_path):
+    """wfst_decoder_prefetch_nbest: GetNbest behind GetLattice on the determinizer's stream, as the service runs
+    them (kaldi-online-nnet3-my-decoder.cc:97-105).  The paths are those wfst_decoder_get_nbest_paths computes on request -- NShortestPath
+    on the determinized lattice, held to the reference's in tests/test_nbest_paths.py / test_gpu_fullsize.py -- arc for arc: with the
+    plain prefetch (the per-channel call finds the work done) and with the detached one (kept per channel while the channels decode
+    their next utterances, fetched after the harvest); the 1-best carries the best path's words."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(20000, seed=17, n_tid=2000, n_words=3000)
+    m = synth.default_tid2pdf(2000)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=5.0)
+    Ts = [120, 80, 120, 9, 120, 55, 100, 33]
+    mats = [synth.make_loglikes(g, T, 1000, m, seed=160 + i, mu=-2.4)[0] for i, T in enumerate(Ts)]
+    mats2 = [synth.make_loglikes(g, T, 1000, m, seed=460 + i, mu=-2.4)[0] for i, T in enumerate(Ts)]
+    lim = dict(max_frames=128, max_tokens_per_frame=32768, arena_tokens=1 << 20, lattice_links=1 << 21)
+    dev, dev2 = G.upload(mats), G.upload(mats2)
+    n = 5
+
+    def decode(dec, d):
+        dec.init()
+        dec.advance([t.data_ptr() for t in d], Ts, 1000)
+        dec.finalize()
+
+    def same_paths(got, want, what):
+        assert (got is None) == (want is None) or (got is None and not want), what
+        if got is None:
+            return
+        assert len(got) == len(want), what
+        for a, b in zip(got, want):
+            assert np.array_equal(a["olabel"], b["olabel"]) and np.array_equal(a["graph"], b["graph"]) and np.array_equal(a["acoustic"], b["acoustic"]), what
+            assert a["tot"] == b["tot"], what
+
+    # on request: determinize, then NShortestPath, channel by channel
+    plain = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), **lim)
+    decode(plain, dev)
+    want = [plain.nbest_paths(c, n) for c in range(len(mats))]
+    best = plain.best_paths()
+    decode(plain, dev2)
+    want2 = [plain.nbest_paths(c, n) for c in range(len(mats))]
+    plain.free()
+    assert sum(len(w) for w in want) >= 3 * len(mats)
+
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), options=G.wfstdec.Options(channel_groups=2), **lim)
+    # plain prefetch with n-best: the sweep finds everything done
+    decode(dec, dev)
+    dec.prefetch_determinized(nbest=n)
+    bp = dec.best_paths()
+    det = dec.determinized_lattices()
+    got = dec.nbest_paths_all(n)
+    for c in range(len(mats)):
+        same_paths(got[c], want[c], "channel %d (prefetch)" % c)
+        if want[c]:
+            assert np.array_equal(got[c][0]["words"], best[c]["words"]) and np.array_equal(bp[c]["words"], best[c]["words"]), c
+        assert (det[c] is None) == (not want[c]), c
+    # detached: utterance set 1 prefetched, set 2 decoded beside it, set 1's lists fetched after the harvest; then set 2's
+    decode(dec, dev)
+    dec.prefetch_determinized(detached=True, nbest=n)
+    decode(dec, dev2)
+    dec.prefetch_determinized(detached=True, nbest=n)   # (harvests set 1's)
+    got1 = dec.prefetched_nbest(n)
+    dec.harvest_prefetched()
+    got2 = dec.prefetched_nbest(n)
+    for c in range(len(mats)):
+        same_paths(got1[c], want[c], "channel %d (detached, first set)" % c)
+        same_paths(got2[c], want2[c], "channel %d (detached, second set)" % c)
+    # a request for fewer paths than the buffers were sized for
+    decode(dec, dev)
+    dec.prefetch_determinized(nbest=2)
+    dec.determinized_lattices()
+    got = dec.nbest_paths_all(2)
+    for c in range(len(mats)):
+        same_paths(got[c], want[c][:2], "channel %d (two paths)" % c)
+    dec.free()
+    graph.free()
