@@ -4309,6 +4309,7 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
 // 670-720, 924-940): the graph-final tokens of the newest frame if there are any, else all of it.
 constexpr int kEmitFrames = 4096, kEmitU = 8;   // frames whose bounds the emit kernels keep in LDS (longer utterances read them from HBM); items per thread and sweep
 constexpr int kEmitSlabs = 8;                   // workgroups per channel of the emit sweeps
+static_assert(16 + kEmitSlabs + 2 <= kPrRawCount, "prune_par: lattice_emit's slab counts [16, 16 + kEmitSlabs + 2) run into the raw pass's words");
 // GetRawLattice's listing (base-inl.h:869-975) of what is alive in the arena and in the link store -- after FinalizeDecoding, or
 // mid-utterance -- into lat_toks[] (arena order = frame order: the n-best search relies on a frame's states being contiguous) and
 // lat_arcs[] (any order).  Both stores hold their dead as holes (a channel at beam 13: 130-330 k arena entries for 1-2.5 k living

@@ -1300,6 +1300,15 @@ def main():
             kb["expand"] += 96.0 * (Lb - Leps) + scale * (4.0 * E + 4.0 * N)
             kb["insert"] += scale * (4.0 * E + 4.0 * N)
             kb["closure"] += 96.0 * Leps + 4.0 * Z
+            # ... and what the closure PASS of a biglm decoder moves besides its epsilon arcs (the counters read 16x
+            # the 24 Z model): ProcessNonemitting's worklist looks at EVERY token of the frame for epsilon arcs -- the token and its
+            # state's row header, 16 B each (base-inl.h:376-381: `NumInputEpsilons(state) != 0` per element) --, GetCutoff reads every
+            # token's cost once more (16-byte token records, base-inl.h:139-234), and every token the closure creates or improves is a
+            # 16 B record + 4 B pair id written and a 16 B slot of the frame's (state, pair) table probed.  Counts: the frame's tokens
+            # from the device (wfst_decoder_get_stats), the closure's arrivals = Z.
+            kb["closure"] += 32.0 * toks + 16.0 * toks + 36.0 * Z
+            out["config"]["closure_pass_model"] = ("24 Z + 96 L_eps + 4 Z (epsilon arcs, LM look-ups on them, pair ids) + 48 B per frontier token "
+                                                   "(worklist: token + row header; GetCutoff: the token again) + 36 B per epsilon arrival (token record, pair id, table slot)")
             out["config"]["lm_lookups_per_step"] = Lb
             out["config"]["lm_lookups_on_epsilon_arcs_per_step"] = Leps
         dom = max(("expand", "insert", "closure"), key=lambda k: prof[k + "_ms"])
@@ -1375,7 +1384,7 @@ def main():
                                                       ("; + lattice terms (builder-defined, DESIGN.md 'Roofline accounting'): 16 B per forward link recorded, "
                                                        "24 B per link and 16 B per token priced by a back-pruning sweep, 12 B per item scanned and 32 B per "
                                                        "survivor moved by a compaction" if a.lattice_links > 0 else "") +
-                                                      ("; + biglm terms (builder-defined): 96 B per LM look-up (charged to the kernel that makes it: expansion for emitting arcs, closure pass for epsilon arcs), 4 B pair id per token and record" if a.biglm else "")),
+                                                      ("; + biglm terms (builder-defined): 96 B per LM look-up (charged to the kernel that makes it: expansion for emitting arcs, closure pass for epsilon arcs), 4 B pair id per token and record; closure pass: 48 B per frontier token (ProcessNonemitting's worklist scan + GetCutoff) and 36 B per epsilon arrival" if a.biglm else "")),
                                           "frac_over_kernel_time": (whole_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms > 0 else 0.0,
                                           "frac_over_step_time": whole_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                           # ... and on SURVEY.md 8(d)'s own three terms alone (no builder-defined additions)
