@@ -7,7 +7,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $line --output-format csv -d "$O/p$i" -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-service-point --no-traffic --no-hip-graph "$@" > "$O/p$i.json" 2> "$O/p$i.err"
+  timeout 600 rocprofv3 --pmc $line --output-format csv -d "$O/p$i" -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-service-point --no-traffic --no-legs --no-hip-graph --no-profile-step "$@" > "$O/p$i.json" 2> "$O/p$i.err"
   echo "== $line" > "$O/p$i.txt"
   python3 tools/pmc_summary.py "$O/p$i" >> "$O/p$i.txt" 2>&1
   find "$O/p$i" -name "*_counter_collection.csv" -delete
