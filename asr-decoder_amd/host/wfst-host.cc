@@ -316,7 +316,10 @@ void GpuChannelPool::Run() {
           lk.lock();
           if (busy != 1) break;
         }
-        _cv_work.wait_for(lk, std::chrono::microseconds(lingered ? 20 : std::max(1, _linger_us)));
+        // (wait_until on the SYSTEM clock = pthread_cond_timedwait: what ThreadSanitizer's runtime intercepts -- a steady-clock wait is
+        // pthread_cond_clockwait, which gcc 11's does not, and the tool then loses the mutex's hand-over; a jump of the wall clock
+        // costs one short wait at most, the loop looks at its conditions again either way)
+        _cv_work.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(lingered ? 20 : std::max(1, _linger_us)));
       }
     }
     std::vector<Request *> batch;
