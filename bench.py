@@ -443,6 +443,8 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
             mp = re.search(r"mean batch ([\d.]+)", err)
             if mp and tag == "pool":
                 o["pool_mean_advance_batch"] = float(mp.group(1))
+            o[tag + "_log"] = [l for l in err.splitlines() if l.startswith("LOG pool") or l.startswith("LOG Time")]
+            o[tag + "_loadavg_before"] = os.getloadavg()[0]
         o["value"] = o["pool_value"]
         o["ms_per_step"] = 1e3 * B * T / o["pool_value"]
         if cpu_baseline and "threads_to_value" in cpu_baseline:
@@ -532,9 +534,9 @@ def summary_line(out, detail_path=None):
                              "mean_active_tokens_per_frame", "peak_tokens_in_a_frame", "max_tokens_per_frame_limit", "degraded_frames",
                              "utterances_with_path", "fused_epsilon_closures", "decoder_paths_same_on_every_rank", "regime") if k in c}
     if "regime" in cfg:
-        cfg["regime"] = str(cfg["regime"])[:120]
+        cfg["regime"] = str(cfg["regime"])[:60]
     if "workload" in cfg:
-        cfg["workload"] = str(cfg["workload"])[:260]
+        cfg["workload"] = str(cfg["workload"])[:200]
     for k in ("parity", "lattice_parity", "parity_per_rank_sample"):
         if k in c:
             cfg[k] = _ratio(c[k])
@@ -551,8 +553,7 @@ def summary_line(out, detail_path=None):
                                     "avg_launch_ms", "launches", "channel_groups", "profiled_step_ms", "traffic_over_algorithmic")}
         rr["traffic_measured_in_run"] = bool(r.get("traffic_measured_in_run", False))
         rr["whole_path_frac"] = r.get("whole_path", {}).get("frac_over_step_time")
-        rr["whole_path_bytes_per_step"] = r.get("whole_path", {}).get("algorithmic_bytes_per_step")
-        for k in ("expand", "insert", "closure"):
+        for k in ("expand", "insert"):
             rr[k + "_ms_per_step"] = r.get("kernel_ms_per_step", {}).get(k)
             if "kernel_busy_ms_per_step" in r:
                 rr[k + "_busy_ms_per_step"] = r["kernel_busy_ms_per_step"].get(k)
@@ -562,7 +563,7 @@ def summary_line(out, detail_path=None):
     b = out.get("cpu_baseline")
     if b:
         bb = {k: b.get(k) for k in ("value", "unit", "cores", "kind", "single_thread_value", "all_cpus_value", "cpu_model", "affinity_cpus")}
-        bb["sample"] = str(b.get("sample", ""))[:110]
+        bb["sample"] = str(b.get("sample", ""))[:80]
         top["cpu_baseline"] = {k: _short(v) for k, v in bb.items() if v is not None}
     legs = {}
     for name, o in out.get("legs", {}).items():
@@ -582,11 +583,12 @@ def summary_line(out, detail_path=None):
 
     # (a line over the limit loses its optional parts -- strings first, then the legs' scalars from the least telling one up, then
     # whole legs from the last one -- rather than its contract keys, and is printed in any case)
-    order = ("value", "ms_per_step", "steps", "frac", "parity", "cpu_baseline_value", "error", "utterances_with_path", "bit_identical", "wer_vs_cpu",
-             "cpu_self_wer", "whole_path_frac", "whole_path_frac_8d", "cpu_determinizer_ms_per_lattice", "gpu_determinizer_ms_per_lattice_mean", "gpu_determinizer_ms_per_lattice_max", "wer_vs_cpu_max", "cpu_self_wer_max", "lattice_parity",
-             "pool_value", "pool_matrix_value", "private_value", "reference_value",
-             "degraded_frames", "cpu_self_bit_identical", "kernel", "cpu_baseline_cores", "cpu_baseline_kind", "reference_threads", "pool_mean_advance_batch",
-             "threads", "chunk_frames")
+    # (what a leg keeps when the line has to shrink, most telling first)
+    order = ("value", "ms_per_step", "parity", "error", "pool_value", "pool_matrix_value", "private_value", "reference_value", "bit_identical",
+             "wer_vs_cpu", "cpu_self_wer", "cpu_baseline_value", "frac", "whole_path_frac", "lattice_parity", "gpu_determinizer_ms_per_lattice_mean",
+             "gpu_determinizer_ms_per_lattice_max", "cpu_determinizer_ms_per_lattice", "whole_path_frac_8d", "utterances_with_path", "steps",
+             "wer_vs_cpu_max", "cpu_self_wer_max", "pool_mean_advance_batch", "degraded_frames", "cpu_self_bit_identical", "kernel",
+             "cpu_baseline_cores", "cpu_baseline_kind", "reference_threads", "threads", "chunk_frames")
     line = dump()
     if len(line) > LINE_LIMIT:
         for part, key, n in (("cpu_baseline", "sample", 60), ("config", "workload", 120), ("config", "parallelism", 40), ("config", "regime", 50)):
