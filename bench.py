@@ -431,7 +431,7 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
                 if p.returncode != 0:
                     raise RuntimeError("wfst-decode (%s) failed: %s" % (tag, err[-400:]))
                 mt = re.search(r"LOG Time taken (\S+)s", err)
-                mf = re.search(r"per frame is \S+ over (\d+) frames", err)
+                mf = re.search(r"Frames decoded in all passes: (\d+)", err) or re.search(r"per frame is \S+ over (\d+) frames", err)
                 fps = float(mf.group(1)) / float(mt.group(1))
                 if best is None or fps > best[0]:
                     best = (fps, p.stdout.decode(), err)
