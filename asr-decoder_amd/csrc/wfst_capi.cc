@@ -2398,7 +2398,7 @@ static int prefetch_determinized(wfst_decoder *d, bool detached, int32_t n_paths
       HIP_TRY(hipHostMalloc(&d->pf_np_pin, b_out + b_off + b_tot + b_arcs, hipHostMallocDefault));
       d->pf_np_pin_bytes = b_out + b_off + b_tot + b_arcs;
     }
-    launch_nbest_paths(P, cnt, side);
+    launch_nbest_paths(P, cnt, side, /*small=*/1);   // (determinized lattices of utterances: a hundred states each)
     HIP_TRY(hipGetLastError());
     char *pin = (char *)d->pf_np_pin;
     HIP_TRY(hipMemcpyAsync(pin, P.out, b_out, hipMemcpyDeviceToHost, side));
@@ -2798,7 +2798,7 @@ static int postprocess_batch(wfst_decoder *d, const int32_t *channels, int32_t n
     P.ws = d->np_ws.p; P.lists = d->np_lists.p;
     P.out = d->np_out.p; P.out_off = d->np_off.p; P.out_tot = d->np_tot.p;
     P.out_arcs = d->np_arcs.p; P.out_cap = (int32_t)out_cap;
-    launch_nbest_paths(P, cnt, d->stream);
+    launch_nbest_paths(P, cnt, d->stream, /*small=*/(ns_max <= 1024 && n_paths <= 64) ? 1 : 0);
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> pout((size_t)cnt * 4), poff((size_t)cnt * (size_t)(n_paths + 1));
     std::vector<float> ptot((size_t)cnt * (size_t)n_paths);

@@ -447,7 +447,7 @@ struct NbPathsDev {
   int32_t *out_arcs;            // arc indices (into a / w), path after path, front to back
   int32_t out_cap;
 };
-void launch_nbest_paths(const NbPathsDev &P, int n_slots, hipStream_t s);
+void launch_nbest_paths(const NbPathsDev &P, int n_slots, hipStream_t s, int small = 0);   // small: one wave per lattice (lattices of a few hundred states, short lists)
 
 // ---- second-pass LM composition on determinized lattices (wfst_compose.hip) ------------------------------------
 // ComposeLattice (newfst/compose-lat-inl.h:15-130) of the determinized lattice of workspace slot 0 (DetDev::out_a / out_w, as

@@ -321,8 +321,12 @@ __global__ __launch_bounds__(kNbThreads) void nbest_kernel(DecoderDev D, NbestDe
 // to half the sort buffer (4096); paths come out as sequences of arc indices of the input lattice.  One workgroup per lattice:
 // the candidate lists of a state are merged by a bitonic sort in LDS (chunked when they exceed the buffer: the n kept so far
 // plus the next candidates), equal costs in the order (arc, rank).
-constexpr int kNpThreads = 1024, kNpSlots = 8192;
+constexpr int kNpSlots = 8192;
+// kNpThreads: 1024 for lattices of thousands of states (the second-pass lattices of a batch), 64 -- ONE WAVE, whose workgroup
+// barriers cost next to nothing -- for the determinized lattices of a few seconds of speech (a hundred states, a list of a handful
+// of candidates per state: with sixteen waves the ~35 barriers per state were the whole 3 ms of a 128-lattice launch)
 
+template <int kNpThreads>
 __device__ __forceinline__ void np_sort(u64 *key, u64 *pay, int S2) {   // ascending bitonic sort of key[0..S2) (S2 a power of two), pay along
   const int tid = threadIdx.x;
   for (int k = 2; k <= S2; k <<= 1)
@@ -342,6 +346,7 @@ __device__ __forceinline__ void np_sort(u64 *key, u64 *pay, int S2) {   // ascen
     }
 }
 
+template <int kNpThreads>
 __global__ __launch_bounds__(kNpThreads) void nbest_paths_kernel(NbPathsDev P) {
   __shared__ u64 s_key[kNpSlots];
   __shared__ u64 s_pay[kNpSlots];
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(kNpThreads) void nbest_paths_kernel(NbPathsDev P) {
       while (S2 < filled) S2 <<= 1;
       for (int i = filled + tid; i < S2; i += kNpThreads) { s_key[i] = ~0ull; s_pay[i] = 0; }
       __syncthreads();
-      np_sort(s_key, s_pay, S2);
+      np_sort<kNpThreads>(s_key, s_pay, S2);
       kept = min(n, filled);
       qbase += take;
       // (the entries kept keep their keys: their candidate numbers are below every later one's)
@@ -573,7 +578,10 @@ __global__ __launch_bounds__(kNpThreads) void nbest_paths_kernel(NbPathsDev P) {
   }
 }
 
-void launch_nbest_paths(const NbPathsDev &P, int n_slots, hipStream_t s) { hipLaunchKernelGGL(nbest_paths_kernel, dim3(n_slots), dim3(kNpThreads), 0, s, P); }
+void launch_nbest_paths(const NbPathsDev &P, int n_slots, hipStream_t s, int small) {
+  if (small) hipLaunchKernelGGL(nbest_paths_kernel<64>, dim3(n_slots), dim3(64), 0, s, P);
+  else hipLaunchKernelGGL(nbest_paths_kernel<1024>, dim3(n_slots), dim3(1024), 0, s, P);
+}
 
 void launch_nbest(const DecoderDev &D, const NbestDev &N, const int32_t *chans, int cnt, hipStream_t s) {
   hipLaunchKernelGGL(nbest_kernel, dim3(cnt), dim3(kNbThreads), 0, s, D, N, chans);
