@@ -379,6 +379,13 @@ class BatchDecoder:
         _check(lib().wfst_decoder_get_degraded_frames(self.h, int(channel), C.byref(n)))
         return int(n.value)
 
+    def busy(self):
+        """1 while work enqueued on the decoder's stream has not finished, else 0 (wfst_decoder_busy; never blocks)."""
+        rc = lib().wfst_decoder_busy(self.h)
+        if rc < 0:
+            _check(rc)
+        return int(rc)
+
     def determinizer_ms(self, channel):
         """Device time of the channel's own determinization (wfst_decoder_get_determinizer_ms); None if no lattice of it is held."""
         ms = C.c_float(0)

@@ -445,3 +445,37 @@ def test_prefetch_with_nbest_gives_the_paths_of_the_determinized_lattice(synth, 
         same_paths(got[c], want[c][:2], "channel %d (two paths)" % c)
     dec.free()
     graph.free()
+
+
+def test_busy_flag_and_per_lattice_determinizer_time(synth, tmp_path):
+    """wfst_decoder_busy (what the channel pool's batcher asks before it closes a batch) and wfst_decoder_get_determinizer_ms (the
+    device's own time per lattice, reported beside the reference determinizer's in bench.py)."""
+    import gpu_util as G
+
+    g = synth.make_hclg_like(20000, seed=17, n_tid=2000, n_words=3000)
+    m = synth.default_tid2pdf(2000)
+    path = str(tmp_path / "g.bin")
+    g.write(path)
+    graph = G.wfstdec.Graph.load(path)
+    graph.set_tid2pdf(m)
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=5.0)
+    Ts = [120, 9, 100]
+    mats = [synth.make_loglikes(g, T, 1000, m, seed=160 + i, mu=-2.4)[0] for i, T in enumerate(Ts)]
+    dev = G.upload(mats)
+    dec = G.wfstdec.BatchDecoder(graph, G.gpu_config(cd), len(mats), max_frames=128, max_tokens_per_frame=32768, arena_tokens=1 << 20,
+                                 lattice_links=1 << 21)
+    dec.init()
+    dec.sync()
+    assert dec.busy() == 0
+    dec.advance([t.data_ptr() for t in dev], Ts, 1000)
+    seen_busy = dec.busy()          # (120 frames of launches are on the stream: almost certainly still running)
+    dec.sync()
+    assert dec.busy() == 0 and seen_busy in (0, 1)
+    dec.finalize()
+    assert dec.determinizer_ms(0) is None          # nothing determinized yet
+    det = dec.determinized_lattices()
+    ms = [dec.determinizer_ms(c) for c in range(len(mats))]
+    assert all(x is not None and 0.0 < x < 5000.0 for x, L in zip(ms, det) if L is not None), ms
+    assert ms[0] > ms[1] or det[1] is None          # the 120-frame lattice takes longer than the 9-frame one
+    dec.free()
+    graph.free()
