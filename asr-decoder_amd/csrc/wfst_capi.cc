@@ -172,8 +172,16 @@ struct wfst_decoder {
   std::vector<int32_t> h_decoded, h_target, h_state;  // state: 0 = never inited, 1 = decoding, 2 = finalized
   std::vector<const float *> h_ll_base;
   // pinned staging
-  int32_t *p_target = nullptr, *p_chan = nullptr;
+  int32_t *p_target = nullptr, *p_chan = nullptr;   // p_target / p_ll: kStage sets, used in rotation (advance_device)
   const float **p_ll = nullptr;
+  static constexpr int kStage = 4;
+  hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr};   // set k's upload has been consumed
+  int stage_next = 0;
+  hipEvent_t chan_stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr};   // (stage_channels' sets of p_chan)
+  int chan_stage_next = 0;
+  hipEvent_t copy_ev = nullptr;        // advance_host: the rows of page-locked buffers are on their way (the decode stream waits for it, the host does not)
+  std::vector<const float *> hist_src; // [channel] the host buffer of the channel's last hand-over ...
+  std::vector<char> hist_src_pinned;   // ... and whether it is page-locked (asked once per buffer)
   ChanCtl *p_ctl = nullptr;
   // best-path output buffers (device), grown on demand
   DevBuf<int32_t> bp_chain;
@@ -302,6 +310,9 @@ struct wfst_decoder {
     for (hipStream_t st : gstreams) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t ev : gevents) (void)hipEventDestroy(ev);
     if (p_target) (void)hipHostFree(p_target);
+    for (hipEvent_t ev : stage_ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : chan_stage_ev) if (ev) (void)hipEventDestroy(ev);
+    if (copy_ev) (void)hipEventDestroy(copy_ev);
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
@@ -1053,9 +1064,12 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   A(d->target.alloc(B));
   A(d->chan_list.alloc(B));
   A(d->ll_base.alloc(B));
-  A(hipHostMalloc((void **)&d->p_target, B * 4));
-  A(hipHostMalloc((void **)&d->p_chan, B * 4));
-  A(hipHostMalloc((void **)&d->p_ll, B * sizeof(float *)));
+  A(hipHostMalloc((void **)&d->p_target, wfst_decoder::kStage * B * 4));
+  A(hipHostMalloc((void **)&d->p_chan, wfst_decoder::kStage * B * 4));
+  for (int k = 0; k < wfst_decoder::kStage; ++k) A(hipEventCreateWithFlags(&d->chan_stage_ev[k], hipEventDisableTiming));
+  A(hipHostMalloc((void **)&d->p_ll, wfst_decoder::kStage * B * sizeof(float *)));
+  for (int k = 0; k < wfst_decoder::kStage; ++k) A(hipEventCreateWithFlags(&d->stage_ev[k], hipEventDisableTiming));
+  A(hipEventCreateWithFlags(&d->copy_ev, hipEventDisableTiming));
   A(hipHostMalloc((void **)&d->p_ctl, B * sizeof(ChanCtl)));
   if (e == hipSuccess) A(hipMemsetAsync(d->ctl.p, 0, d->ctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->bucket_cnt.p, 0, d->bucket_cnt.bytes(), d->stream));
@@ -1313,9 +1327,15 @@ static int stage_channels(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (seen[channels[i]]) return fail(WFST_E_ARG, "duplicate channel in list");
     seen[channels[i]] = 1;
   }
-  HIP_TRY(hipStreamSynchronize(d->stream));  // staging buffer reuse
-  memcpy(d->p_chan, channels, (size_t)n * 4);
-  HIP_TRY(hipMemcpyAsync(d->chan_list.p, d->p_chan, (size_t)n * 4, hipMemcpyHostToDevice, d->stream));
+  // (page-locked staging sets in rotation, as advance_device's: a list waits for the upload that used its set kStage lists ago, not
+  // for the frames the stream is still decoding)
+  const int stage = d->chan_stage_next;
+  d->chan_stage_next = (d->chan_stage_next + 1) % wfst_decoder::kStage;
+  HIP_TRY(hipEventSynchronize(d->chan_stage_ev[stage]));
+  int32_t *p_chan = d->p_chan + (size_t)stage * d->n_channels;
+  memcpy(p_chan, channels, (size_t)n * 4);
+  HIP_TRY(hipMemcpyAsync(d->chan_list.p, p_chan, (size_t)n * 4, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipEventRecord(d->chan_stage_ev[stage], d->stream));
   *dev = d->chan_list.p;
   *cnt = n;
   return WFST_OK;
@@ -1387,7 +1407,14 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (loglikes[i] && loglikes[i] != d->h_ll_base[c]) moved = true;
   }
   if (steps == 0 && !moved) return WFST_OK;
-  HIP_TRY(hipStreamSynchronize(d->stream));  // pinned staging reuse
+  // The targets and row pointers go up through page-locked staging sets used in rotation: a call waits for the upload that used ITS
+  // set kStage calls ago (long done), not for everything the stream holds -- a host that hands over chunk after chunk (the channel
+  // pool's batcher, a streaming service) enqueues the next chunk's frames while the device still decodes this one's.
+  const int stage = d->stage_next;
+  d->stage_next = (d->stage_next + 1) % wfst_decoder::kStage;
+  HIP_TRY(hipEventSynchronize(d->stage_ev[stage]));   // (never recorded: returns at once)
+  int32_t *p_target = d->p_target + (size_t)stage * d->n_channels;
+  const float **p_ll = d->p_ll + (size_t)stage * d->n_channels;
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     int target = n_frames_ready[i];
@@ -1396,12 +1423,13 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (loglikes[i]) d->h_ll_base[c] = loglikes[i];
   }
   for (int c = 0; c < d->n_channels; ++c) {
-    d->p_target[c] = d->h_target[c];
-    d->p_ll[c] = d->h_ll_base[c];
+    p_target[c] = d->h_target[c];
+    p_ll[c] = d->h_ll_base[c];
   }
-  HIP_TRY(hipMemcpyAsync(d->target.p, d->p_target, (size_t)d->n_channels * 4, hipMemcpyHostToDevice, d->stream));
-  HIP_TRY(hipMemcpyAsync((void *)d->ll_base.p, (const void *)d->p_ll, (size_t)d->n_channels * sizeof(float *),
+  HIP_TRY(hipMemcpyAsync(d->target.p, p_target, (size_t)d->n_channels * 4, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipMemcpyAsync((void *)d->ll_base.p, (const void *)p_ll, (size_t)d->n_channels * sizeof(float *),
                          hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipEventRecord(d->stage_ev[stage], d->stream));
   d->D.stride = stride;
   {
     // expand_kernel_staged_row (wfst_kernels.hip): the frame's log-likelihood row of a tile's channel staged in LDS by 16-byte DMAs
@@ -1578,6 +1606,7 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
       size_t ncap = std::max<size_t>((size_t)want, std::max<size_t>(d->hist_rows_cap[c] * 2, 256));
       if (d->D.max_frames <= 1024) ncap = std::max<size_t>(ncap, (size_t)d->D.max_frames);
       float *np = nullptr;
+      if (d->copy_stream) HIP_TRY(hipStreamSynchronize(d->copy_stream));   // (rows of page-locked buffers may still be on their way into the old history)
       HIP_TRY(hipMalloc((void **)&np, ncap * (size_t)stride * 4));
       if (have > 0) {
         // (on the decoder's own stream, not the legacy one: another decoder of the process may be capturing its frame loop in
@@ -1604,6 +1633,42 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
   for (int i = 0; i < cnt; ++i) longest = std::max(longest, n_frames_ready[i] - d->hist_rows[channels ? channels[i] : i]);
   const bool sliced = max_num_frames < 0 && d->upload_slice > 0 && longest > 2 * kSlice;
   std::vector<int32_t> ready((size_t)cnt);
+  // PAGE-LOCKED rows (wfst_host_alloc, or any memory the caller has registered with HIP): the copies are true DMAs -- the decode
+  // stream waits for them through an event and this call returns when everything is ENQUEUED, like wfst_decoder_advance; the rows
+  // handed over must then stay valid and unchanged until the channel's frames are decoded (any getter, or wfst_decoder_sync), which
+  // a caller that keeps its rows for the utterance -- the contract of the device-pointer call -- does anyway.  Pageable rows: the
+  // copy call returns when the buffer is consumed, and the call waits for the copies before it enqueues the frames (below).
+  bool all_pinned = !sliced;
+  if (all_pinned) {
+    if (d->hist_src.empty()) { d->hist_src.assign((size_t)d->n_channels, nullptr); d->hist_src_pinned.assign((size_t)d->n_channels, 0); }
+    for (int i = 0; i < cnt && all_pinned; ++i) {
+      const int c = channels ? channels[i] : i;
+      if (!loglikes_host[i]) { continue; }
+      if (d->hist_src[(size_t)c] != loglikes_host[i]) {
+        hipPointerAttribute_t at;
+        const hipError_t pe = hipPointerGetAttributes(&at, loglikes_host[i]);
+        if (pe != hipSuccess) (void)hipGetLastError();
+        d->hist_src[(size_t)c] = loglikes_host[i];
+        d->hist_src_pinned[(size_t)c] = (pe == hipSuccess && at.type == hipMemoryTypeHost) ? 1 : 0;
+      }
+      all_pinned = d->hist_src_pinned[(size_t)c] != 0;
+    }
+  }
+  if (all_pinned) {
+    for (int i = 0; i < cnt; ++i) {
+      const int c = channels ? channels[i] : i;
+      const int32_t have = d->hist_rows[c], want = n_frames_ready[i];
+      if (want > have) {
+        HIP_TRY(hipMemcpyAsync(d->hist_dev[c] + (size_t)have * stride, loglikes_host[i] + (size_t)have * stride,
+                               (size_t)(want - have) * stride * 4, hipMemcpyHostToDevice, d->copy_stream));
+        d->hist_rows[c] = want;
+      }
+      ready[i] = d->hist_rows[c];
+    }
+    HIP_TRY(hipEventRecord(d->copy_ev, d->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(d->stream, d->copy_ev, 0));   // the frames' kernels run behind the rows; the host does not wait
+    return advance_device(d, channels, n, dev_ptrs.data(), ready.data(), stride, max_num_frames);
+  }
   for (int done = 0; done < std::max(longest, 1); done += sliced ? kSlice : std::max(longest, 1)) {
     const int upto = sliced ? done + kSlice : longest;
     for (int i = 0; i < cnt; ++i) {

@@ -491,6 +491,9 @@ void GpuLatticeDecoder::GrowRows(size_t floats) {
     if (!np) throw std::bad_alloc();
   }
   if (_rows && _rows_ready > 0) memcpy(np, _rows, (size_t)_rows_ready * _stride * sizeof(float));
+  // (rows of the old page-locked buffer may still be on their way to the device -- wfst_decoder_advance_host returns when they are
+  // enqueued: the device is waited for before the buffer goes)
+  if (_rows_pinned && _rows_ready > 0 && _inited) OnDevice([&] { (void)wfst_decoder_sync(_dec); });
   if (_rows_pinned) wfst_host_free(_rows);
   else free(_rows);
   _rows = np;

@@ -269,9 +269,13 @@ int wfst_decoder_advance(wfst_decoder *d, const int32_t *channels, int32_t n,
                          int32_t stride, int32_t max_num_frames);
 
 /* Same with HOST matrices: rows [NumFramesDecoded, n_frames_ready) are copied into a device
- * history buffer owned by the channel (the shape a DecodableInterface-pulling caller needs).  The
- * caller's buffers are consumed when the call returns.  A long hand-over is uploaded and decoded in
- * slices, so that the copy of one slice overlaps the search over the previous one. */
+ * history buffer owned by the channel (the shape a DecodableInterface-pulling caller needs).
+ * PAGEABLE buffers are consumed when the call returns; a long hand-over is uploaded and decoded in
+ * slices, so that the copy of one slice overlaps the search over the previous one.
+ * PAGE-LOCKED buffers (wfst_host_alloc; every listed channel's): the rows go up by DMA and the call
+ * returns when copies and frames are ENQUEUED, like wfst_decoder_advance -- the rows handed over must
+ * stay valid and unchanged until they are decoded (wfst_decoder_sync or any result getter of the
+ * channel); a host that hands over chunk after chunk keeps enqueueing while the device decodes. */
 int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t n,
                               const float *const *loglikes_host, const int32_t *n_frames_ready,
                               int32_t stride, int32_t max_num_frames);
