@@ -179,6 +179,17 @@ struct wfst_decoder {
   int stage_next = 0;
   hipEvent_t chan_stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr};   // (stage_channels' sets of p_chan)
   int chan_stage_next = 0;
+  // RESULTS beside the search: a best path asked for a LIST of channels (the channel pool's shape: some utterances have ended, the
+  // others go on) runs on a stream of its own behind the listed channels' last enqueued work -- an event recorded on the decoder's
+  // stream by every init / advance / finalize, in a ring; a slot recorded again marks a later point of the stream: still behind the
+  // channel's work -- instead of behind everything the decoder's stream holds (the frames of the other channels enqueued since).
+  static constexpr int kMarkRing = 16;
+  hipEvent_t mark_ev[kMarkRing] = {};
+  int mark_next = 0;
+  std::vector<int> chan_mark;          // [channel] ring slot of the event behind the channel's last enqueued work, -1: none
+  hipStream_t res_stream = nullptr;
+  int32_t *res_chan_pin = nullptr;
+  DevBuf<int32_t> res_chan_list;
   hipEvent_t copy_ev = nullptr;        // advance_host: the rows of page-locked buffers are on their way (the decode stream waits for it, the host does not)
   std::vector<const float *> hist_src; // [channel] the host buffer of the channel's last hand-over ...
   std::vector<char> hist_src_pinned;   // ... and whether it is page-locked (asked once per buffer)
@@ -313,6 +324,10 @@ struct wfst_decoder {
     for (hipEvent_t ev : stage_ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : chan_stage_ev) if (ev) (void)hipEventDestroy(ev);
     if (copy_ev) (void)hipEventDestroy(copy_ev);
+    for (hipEvent_t ev : mark_ev) if (ev) (void)hipEventDestroy(ev);
+    if (res_stream) (void)hipStreamDestroy(res_stream);
+    if (res_chan_pin) (void)hipHostFree(res_chan_pin);
+    res_chan_list.release();
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
@@ -1070,6 +1085,10 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   A(hipHostMalloc((void **)&d->p_ll, wfst_decoder::kStage * B * sizeof(float *)));
   for (int k = 0; k < wfst_decoder::kStage; ++k) A(hipEventCreateWithFlags(&d->stage_ev[k], hipEventDisableTiming));
   A(hipEventCreateWithFlags(&d->copy_ev, hipEventDisableTiming));
+  for (int k = 0; k < wfst_decoder::kMarkRing; ++k) A(hipEventCreateWithFlags(&d->mark_ev[k], hipEventDisableTiming));
+  d->chan_mark.assign(B, -1);
+  A(hipHostMalloc((void **)&d->res_chan_pin, B * 4));
+  A(d->res_chan_list.alloc(B));
   A(hipHostMalloc((void **)&d->p_ctl, B * sizeof(ChanCtl)));
   if (e == hipSuccess) A(hipMemsetAsync(d->ctl.p, 0, d->ctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->bucket_cnt.p, 0, d->bucket_cnt.bytes(), d->stream));
@@ -1313,6 +1332,26 @@ void wfst_decoder_free(wfst_decoder *d) {
   delete d;
 }
 
+// An event behind what has just been enqueued for the listed channels (nullptr: all) on the decoder's stream.
+static int mark_channels(wfst_decoder *d, const int32_t *channels, int32_t cnt) {
+  const int k = d->mark_next;
+  d->mark_next = (k + 1) % wfst_decoder::kMarkRing;
+  HIP_TRY(hipEventRecord(d->mark_ev[k], d->stream));
+  for (int i = 0; i < cnt; ++i) d->chan_mark[(size_t)(channels ? channels[i] : i)] = k;
+  return WFST_OK;
+}
+// The results stream, made to wait for the listed channels' last enqueued work (and nothing newer).
+static int results_stream_behind(wfst_decoder *d, const int32_t *channels, int32_t cnt, hipStream_t *out) {
+  if (!d->res_stream) HIP_TRY(hipStreamCreateWithFlags(&d->res_stream, hipStreamNonBlocking));
+  bool waited[wfst_decoder::kMarkRing] = {};
+  for (int i = 0; i < cnt; ++i) {
+    const int k = d->chan_mark[(size_t)channels[i]];
+    if (k >= 0 && !waited[k]) { HIP_TRY(hipStreamWaitEvent(d->res_stream, d->mark_ev[k], 0)); waited[k] = true; }
+  }
+  *out = d->res_stream;
+  return WFST_OK;
+}
+
 // Resolve a channel list: returns the device pointer to use (nullptr = all channels) and count.
 static int stage_channels(wfst_decoder *d, const int32_t *channels, int32_t n, const int32_t **dev, int32_t *cnt) {
   if (!channels) {
@@ -1353,6 +1392,7 @@ int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n) {
   if (rc != WFST_OK) return rc;
   launch_init(d->D, dev, cnt, d->stream);
   HIP_TRY(hipGetLastError());
+  { const int rcm = mark_channels(d, channels, cnt); if (rcm != WFST_OK) return rcm; }
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     d->h_decoded[c] = 0;
@@ -1569,6 +1609,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
       if (gsteps[g] != 0) HIP_TRY(hipStreamWaitEvent(d->stream, d->gevents[1 + g], 0));
   }
   HIP_TRY(hipGetLastError());
+  { const int rcm = mark_channels(d, channels, cnt); if (rcm != WFST_OK) return rcm; }
   for (int g = 0; g < G; ++g) d->gpar[g] = gpar0[g] ^ (gsteps[g] & 1);
   for (int c = 0; c < d->n_channels; ++c) d->h_decoded[c] = std::max(d->h_decoded[c], d->h_target[c]);
   return WFST_OK;
@@ -1713,6 +1754,7 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
   launch_set_finalized(d->D, dev, cnt, d->stream);
   if (d->D.lattice) launch_lattice_prune(d->D, dev, cnt, d->stream);  // PruneForwardLinksFinal + backward pruning
   HIP_TRY(hipGetLastError());
+  { const int rcm = mark_channels(d, channels, cnt); if (rcm != WFST_OK) return rcm; }
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     d->h_state[c] = 2;
@@ -1784,8 +1826,27 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
   HIP_TRY(hipSetDevice(d->device));
   const int32_t *dev;
   int32_t cnt;
-  int rc = stage_channels(d, channels, n, &dev, &cnt);
-  if (rc != WFST_OK) return rc;
+  int rc;
+  hipStream_t st = d->stream;
+  if (channels) {
+    // a LIST of channels: on the results stream, behind these channels' own work only (see mark_ev)
+    if (n <= 0 || n > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
+    std::vector<char> seen((size_t)d->n_channels, 0);
+    for (int i = 0; i < n; ++i) {
+      if (channels[i] < 0 || channels[i] >= d->n_channels) return fail(WFST_E_ARG, "channel index out of range");
+      if (seen[(size_t)channels[i]]) return fail(WFST_E_ARG, "duplicate channel in list");
+      seen[(size_t)channels[i]] = 1;
+    }
+    rc = results_stream_behind(d, channels, n, &st);
+    if (rc != WFST_OK) return rc;
+    memcpy(d->res_chan_pin, channels, (size_t)n * 4);   // (the stream is idle between these calls: each one waits for it before it returns)
+    HIP_TRY(hipMemcpyAsync(d->res_chan_list.p, d->res_chan_pin, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    dev = d->res_chan_list.p;
+    cnt = n;
+  } else {
+    rc = stage_channels(d, channels, n, &dev, &cnt);
+    if (rc != WFST_OK) return rc;
+  }
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     if (d->h_state[c] == 0) return fail(WFST_E_STATE, "GetBestPath before InitDecoding");
@@ -1798,6 +1859,7 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
   const size_t head = ((size_t)cnt + 3) & ~(size_t)3, words = head + 4 * need;
   if (d->bp_all.n < words || d->bp_chain.n < need) {
     HIP_TRY(hipStreamSynchronize(d->stream));
+    if (d->res_stream) HIP_TRY(hipStreamSynchronize(d->res_stream));
     HIP_TRY(d->bp_all.alloc(words));
     HIP_TRY(d->bp_chain.alloc(need));
   }
@@ -1810,11 +1872,16 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
   }
   int32_t *dn = d->bp_all.p, *dil = dn + head, *dol = dil + need;
   float *dg = reinterpret_cast<float *>(dol + need), *dac = dg + need;
-  launch_best_path(d->D, dev, cnt, use_final_probs ? 1 : 0, cap, dil, dol, dg, dac, dn, d->bp_chain.p, d->stream);
+  launch_best_path(d->D, dev, cnt, use_final_probs ? 1 : 0, cap, dil, dol, dg, dac, dn, d->bp_chain.p, st);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(d->bp_pin, d->bp_all.p, words * 4, hipMemcpyDeviceToHost, d->stream));
-  rc = read_ctl(d);   // synchronises the stream
-  if (rc != WFST_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(d->bp_pin, d->bp_all.p, words * 4, hipMemcpyDeviceToHost, st));
+  if (channels) {   // (the listed channels' control blocks are final behind their marks; the others' are not looked at)
+    HIP_TRY(hipMemcpyAsync(d->p_ctl, d->ctl.p, d->ctl.bytes(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  } else {
+    rc = read_ctl(d);   // synchronises the stream
+    if (rc != WFST_OK) return rc;
+  }
   {
     const int32_t *hp = reinterpret_cast<const int32_t *>(d->bp_pin);
     memcpy(n_hops, hp, (size_t)cnt * 4);
@@ -1823,8 +1890,13 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
     memcpy(graph_cost, hp + head + 2 * need, need * 4);
     memcpy(acoustic_cost, hp + head + 3 * need, need * 4);
   }
-  rc = check_ctl_errors(d);
-  if (rc != WFST_OK) return rc;
+  if (channels) {   // a device error of ANOTHER channel's utterance is that channel's, not this request's
+    for (int i = 0; i < cnt; ++i)
+      if (d->p_ctl[channels[i]].error) return fail_ctl_error(channels[i], d->p_ctl[channels[i]].error);
+  } else {
+    rc = check_ctl_errors(d);
+    if (rc != WFST_OK) return rc;
+  }
   for (int i = 0; i < cnt; ++i)
     if (n_hops[i] > cap) return fail(WFST_E_CAPACITY, "best path longer than cap hops; n_hops holds the needed size");
   return WFST_OK;
@@ -3143,8 +3215,10 @@ int wfst_decoder_get_prune_raw_abandoned(wfst_decoder *d, int32_t channel, int32
 int wfst_decoder_get_degraded_frames(wfst_decoder *d, int32_t channel, int32_t *n_frames) {
   if (!d || !n_frames || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipMemcpyAsync(n_frames, d->degraded.p + channel, sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(hipStreamSynchronize(d->stream));
+  hipStream_t st = d->stream;
+  { const int32_t c = channel; const int rc = results_stream_behind(d, &c, 1, &st); if (rc != WFST_OK) return rc; }   // (behind the channel's own work, not the others')
+  HIP_TRY(hipMemcpyAsync(n_frames, d->degraded.p + channel, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return WFST_OK;
 }
 
