@@ -1679,8 +1679,8 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
   // handed over must then stay valid and unchanged until the channel's frames are decoded (any getter, or wfst_decoder_sync), which
   // a caller that keeps its rows for the utterance -- the contract of the device-pointer call -- does anyway.  Pageable rows: the
   // copy call returns when the buffer is consumed, and the call waits for the copies before it enqueues the frames (below).
-  bool all_pinned = !sliced;
-  if (all_pinned) {
+  bool all_pinned = true;
+  {
     if (d->hist_src.empty()) { d->hist_src.assign((size_t)d->n_channels, nullptr); d->hist_src_pinned.assign((size_t)d->n_channels, 0); }
     for (int i = 0; i < cnt && all_pinned; ++i) {
       const int c = channels ? channels[i] : i;
@@ -1695,21 +1695,8 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
       all_pinned = d->hist_src_pinned[(size_t)c] != 0;
     }
   }
-  if (all_pinned) {
-    for (int i = 0; i < cnt; ++i) {
-      const int c = channels ? channels[i] : i;
-      const int32_t have = d->hist_rows[c], want = n_frames_ready[i];
-      if (want > have) {
-        HIP_TRY(hipMemcpyAsync(d->hist_dev[c] + (size_t)have * stride, loglikes_host[i] + (size_t)have * stride,
-                               (size_t)(want - have) * stride * 4, hipMemcpyHostToDevice, d->copy_stream));
-        d->hist_rows[c] = want;
-      }
-      ready[i] = d->hist_rows[c];
-    }
-    HIP_TRY(hipEventRecord(d->copy_ev, d->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(d->stream, d->copy_ev, 0));   // the frames' kernels run behind the rows; the host does not wait
-    return advance_device(d, channels, n, dev_ptrs.data(), ready.data(), stride, max_num_frames);
-  }
+  // slices (a long hand-over) or everything at once; page-locked rows: every slice's copies and frames are enqueued one behind the
+  // other -- the copy engine is a slice ahead of the search, the host waits for neither
   for (int done = 0; done < std::max(longest, 1); done += sliced ? kSlice : std::max(longest, 1)) {
     const int upto = sliced ? done + kSlice : longest;
     for (int i = 0; i < cnt; ++i) {
@@ -1723,7 +1710,12 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
       }
       ready[i] = d->hist_rows[c];
     }
-    HIP_TRY(hipStreamSynchronize(d->copy_stream));  // rows are in HBM (and the caller's buffers consumed)
+    if (all_pinned) {
+      HIP_TRY(hipEventRecord(d->copy_ev, d->copy_stream));
+      HIP_TRY(hipStreamWaitEvent(d->stream, d->copy_ev, 0));   // the frames' kernels run behind the rows; the host does not wait
+    } else {
+      HIP_TRY(hipStreamSynchronize(d->copy_stream));  // rows are in HBM (and the caller's buffers consumed)
+    }
     const int rc = advance_device(d, channels, n, dev_ptrs.data(), ready.data(), stride, max_num_frames);
     if (rc != WFST_OK) return rc;
   }

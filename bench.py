@@ -85,6 +85,8 @@ def parse():
                     "2 overlaps two half-batches: +7 %% frames/s, but per-launch accounting then covers half a batch")
     ap.add_argument("--host-feed", action="store_true", help="hand the log-likelihoods over as HOST matrices every step "
                     "(wfst_decoder_advance_host): the PCIe-inclusive rate; never the headline")
+    ap.add_argument("--host-pageable", action="store_true", help="--host-feed from PAGEABLE host memory (staged copies, the call waits for every slice's "
+                                                                 "upload) instead of page-locked matrices")
     ap.add_argument("--max-tokens", type=int, default=65536, help="wfst_limits.max_tokens_per_frame (the headline workload peaks at 40 k tokens "
                     "in one frame; the service-point legs, whose frames reach beyond that before max_active cuts them, run with 131072)")
     ap.add_argument("--default-limits", action="store_true", help="wfst_limits all zero: the LIBRARY's defaults for max_tokens_per_frame (262144 at this "
@@ -952,7 +954,13 @@ def main():
             dt = float(tt.item())
         return dt, res
 
-    step = make_step(dec, ll_dev, [mats[i] for i in range(B)])
+    host_rows = [mats[i] for i in range(B)]
+    if a.host_feed and not a.host_pageable:
+        # page-locked host matrices, as a caller that feeds the device keeps them (wfst_host_alloc; here torch's pinned allocator):
+        # wfst_decoder_advance_host then uploads by DMA slice by slice, a slice ahead of the search, and returns when enqueued
+        pinned = [torch.from_numpy(mats[i]).pin_memory() for i in range(B)]
+        host_rows = [t.numpy() for t in pinned]
+    step = make_step(dec, ll_dev, host_rows)
     dt, res = timed(step, a.warmup, a.steps)
     frames_total = world * B * T * a.steps
     value = frames_total / dt
@@ -1036,7 +1044,7 @@ def main():
         # (`metric` stays under 100 characters -- the driver's record cuts it there; what the number is measured on and in which
         # pruning regime is config.workload / config.regime)
         "metric": ("frames/sec decoded with on-the-fly LM rescoring (biglm, BASELINE configs[3])" if a.biglm else
-                   "frames/sec decoded, log-likelihoods handed over as host matrices every step (PCIe-inclusive)" if a.host_feed else
+                   "frames/sec decoded, log-likelihoods handed over as %s host matrices every step (PCIe-inclusive)" % ("pageable" if a.host_pageable else "page-locked") if a.host_feed else
                    "frames/sec decoded (RTFx = value/100) at fixed beam" if a.lattice_links == 0 else
                    "frames/sec decoded with lattice generation%s (BASELINE configs[4])" % (" + determinization" if a.determinize else "")),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
