@@ -333,6 +333,9 @@ int main(int argc, char **argv) {
             HostMatrixDecodable md(u);
             PullDecodable pd(u, tid2pdf.empty() ? nullptr : &tid2pdf);
             AmInterface *am = pull ? (AmInterface *)&pd : (AmInterface *)&md;
+            // an utterance that fails (a capacity limit: the reference's LOG_ERR -> exception) is this utterance's failure, as in the
+            // reference CLI (kaldi-hclg-my-decoder.cc:131-136 counts it and goes on): the thread's decoder takes the next one
+            try {
             decode.InitDecoding();
             if (chunk > 0) {
               for (int ready = chunk;; ready += chunk) {
@@ -354,6 +357,10 @@ int main(int argc, char **argv) {
             if (nbest > 0) {
               if (exact_nbest) dp->GetNbest(r.nbest, nbest);
               else dp->GetNbestShortlist(r.nbest, nbest);
+            }
+            } catch (const std::runtime_error &e) {
+              std::cerr << "WARNING utterance " << u.key << " failed: " << e.what() << "\n";
+              if (first_pass) res[ui].ok = false;
             }
           }
         } catch (const std::exception &e) {

@@ -446,3 +446,39 @@ def test_pool_serves_lattices_and_nbest(synth, oracle, tmp_path):
         assert (x.n_states, x.start, int(x.st_final.sum())) == (y.n_states, y.start, int(y.st_final.sum())), i
         assert np.array_equal(x.arc_multiset(), y.arc_multiset()), i
     assert sum(x.n_states for x in lp) > 100
+
+
+def test_pool_keeps_a_failing_utterance_to_itself(synth, oracle, tmp_path):
+    """Error isolation in the pool: utterances longer than wfst_limits.max_frames are refused by the device decoder (WFST_E_CAPACITY, the
+    reference's LOG_ERR -> exception) -- in a batched call the refusal is retried request by request, so only THAT thread's utterance
+    fails; the other utterances of the same batches decode to the oracle's words, and a best path asked for a list of channels reports
+    the listed channels' errors only."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    g = synth.make_hclg_like(4000, seed=9, n_tid=600, n_words=800)
+    gpath = str(tmp_path / "g.bin")
+    g.write(gpath)
+    m = synth.default_tid2pdf(600)
+    m.astype("<i4").tofile(str(tmp_path / "tid2pdf.bin"))
+    (tmp_path / "decoder.conf").write_text("--beam=12\n--max-active=1000000\n--min-active=0\n--lattice-beam=6\n")
+    cd = dict(beam=12.0, max_active=1000000, min_active=0, lattice_beam=6.0)
+    lens = [40, 90, 30, 75, 20, 120, 55, 64, 10, 100, 33, 48, 70, 61, 25, 88]   # max_frames 64: six of them are too long
+    mats = [synth.make_loglikes(g, T, 300, m, seed=1200 + i, mu=-2.2)[0] for i, T in enumerate(lens)]
+    _write_utts(tmp_path, mats)
+    args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--chunk=25", "--threads=8", "--pool=8", "--pull", "--max-frames=64"]
+    p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    words = {l.split()[0]: [int(w) for w in l.split()[1:]] for l in p.stdout.strip().splitlines()}
+    failed = set(re.findall(r"WARNING utterance (utt\d+) failed", p.stderr))
+    long_ones = {"utt%03d" % i for i, T in enumerate(lens) if T > 64}
+    assert failed == long_ones, (failed, long_ones)
+    assert "max_frames" in p.stderr
+    h = oracle.load_graph(gpath)
+    for i, x in enumerate(mats):
+        k = "utt%03d" % i
+        if k in long_ones:
+            assert k not in words
+            continue
+        o = oracle.decode(h, pyoracle.Config(**cd), x, m)
+        if o.ok:
+            assert words[k] == o.words.tolist(), k
+    oracle.free_graph(h)
