@@ -473,6 +473,14 @@ GpuLatticeDecoder::GpuLatticeDecoder(GpuChannelPool *pool)
   _chan = pool->Lease();
 }
 GpuLatticeDecoder::~GpuLatticeDecoder() {
+  // (rows of an utterance abandoned right behind an AdvanceDecoding may still be on their way to the device from the page-locked
+  // buffer freed below: the device is waited for first; an object that fetched its result, or never decoded, has nothing in flight)
+  if (_rows_pinned && _rows_ready > 0 && _inited) {
+    try {
+      OnDevice([&] { (void)wfst_decoder_sync(_dec); });
+    } catch (...) {
+    }
+  }
   if (_pool) _pool->Release(_chan);
   else wfst_decoder_free(_dec);
   if (_rows_pinned) wfst_host_free(_rows);

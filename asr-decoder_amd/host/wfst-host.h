@@ -222,6 +222,7 @@ class DecoderItf {
 // request after the other: the C ABI's calls on one decoder are not re-entrant.
 // Results are those of the private decoder, bit for bit (a channel's search does not depend on its neighbours).
 // At most n_channels decoder objects can be alive at a time: a further constructor waits for a channel to be released.
+// The pool outlives its decoder objects (destroy them first; the pool's destructor stops the batcher and frees the device decoder).
 class GpuChannelPool {
  public:
   GpuChannelPool(Fst *graph, const LatticeFasterDecoderConfig &config, int n_channels, const wfst_limits *limits = nullptr,
