@@ -104,7 +104,8 @@ class HostMatrixDecodable : public MatrixDecodable {
 // ... and as the reference's callers see a decodable: LogLikelihood(frame, index) only, the index a 1-based TRANSITION-ID.  With
 // --tid2pdf it is Kaldi's DecodableMatrixScaledMapped as the reference CLI builds it (kaldi-nnet3bin/kaldi-hclg-my-decoder.cc:107):
 // LogLikelihood(frame, tid) = M(frame, TransitionIdToPdf(tid)), NumIndices() = the number of transition-ids -- the map belongs to
-// the decodable, the graph reads column ilabel.  Without it: M's columns are the indices themselves.
+// the decodable; the graph carries the same map (Fst::SetTid2Pdf), so the decoder pulls one score per PDF through a representative
+// transition-id.  Without --tid2pdf: M's columns are the indices themselves.
 class PullDecodable : public DecodableInterface {
  public:
   PullDecodable(const Utt &u, const std::vector<int32_t> *tid2pdf) : _u(u), _map(tid2pdf), _ready(u.frames) {}
@@ -192,8 +193,9 @@ int main(int argc, char **argv) {
       tid2pdf.resize((size_t)t.tellg() / 4);
       t.seekg(0);
       t.read((char *)tid2pdf.data(), tid2pdf.size() * 4);
-      if (!pull)   // (--pull: the decodable maps, as the reference's does; otherwise the graph's rows read the pdf columns directly)
-        for (auto &f : fsts) f->SetTid2Pdf(tid2pdf);
+      // the graph's rows read the pdf columns (what DecodableMatrixScaledMapped does with the transition model); --pull: the
+      // decodable ALSO maps, as the reference's does -- the decoder then asks it for one transition-id per pdf (Fst::SetTid2Pdf)
+      for (auto &f : fsts) f->SetTid2Pdf(tid2pdf);
     }
     std::ifstream in(pos[2].c_str(), std::ios::binary);
     if (!in) { std::cerr << "cannot open " << pos[2] << "\n"; return 1; }

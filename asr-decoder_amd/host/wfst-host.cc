@@ -95,6 +95,7 @@ bool Fst::ReadFst(const char *file, int device) {
 void Fst::SetTid2Pdf(const std::vector<int32_t> &m) {
   if (!_graph) throw std::runtime_error("SetTid2Pdf before ReadFst");
   if (wfst_graph_set_tid2pdf(_graph, m.data(), (int32_t)m.size() - 1) != WFST_OK) Fatal("wfst_graph_set_tid2pdf");
+  _tid2pdf = m;
 }
 
 // ---- LatticeToVector --------------------------------------------------------------------------
@@ -233,7 +234,7 @@ const wfst_lm *ArpaLm::Handle() {
 
 // ---- channel pool: many decoder objects, one batched device decoder ------------------------------
 GpuChannelPool::GpuChannelPool(Fst *graph, const LatticeFasterDecoderConfig &config, int n_channels, const wfst_limits *limits, int linger_us)
-    : _dec(nullptr), _n(n_channels), _linger_us(linger_us), _n_leased(0), _stop(false), _stats() {
+    : _dec(nullptr), _graph(graph), _n(n_channels), _linger_us(linger_us), _n_leased(0), _stop(false), _stats() {
   config.Check();
   wfst_config c = config.ToC();
   if (n_channels < 1) throw std::runtime_error("GpuChannelPool needs at least one channel");
@@ -242,7 +243,7 @@ GpuChannelPool::GpuChannelPool(Fst *graph, const LatticeFasterDecoderConfig &con
 }
 GpuChannelPool::GpuChannelPool(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm, int n_channels,
                                const wfst_limits *limits, int linger_us)
-    : _dec(nullptr), _n(n_channels), _linger_us(linger_us), _n_leased(0), _stop(false), _stats() {
+    : _dec(nullptr), _graph(graph), _n(n_channels), _linger_us(linger_us), _n_leased(0), _stop(false), _stats() {
   config.Check();
   wfst_config c = config.ToC();
   if (n_channels < 1) throw std::runtime_error("GpuChannelPool needs at least one channel");
@@ -456,6 +457,7 @@ GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfi
   config.Check();
   wfst_config c = config.ToC();
   if (wfst_decoder_create(graph->Handle(), &c, 1, limits, nullptr, &_dec) != WFST_OK) Fatal("wfst_decoder_create");
+  SetColumns(graph);
 }
 GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm,
                                      const wfst_limits *limits)
@@ -465,12 +467,27 @@ GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfi
   if (!oldlm || !newlm) throw std::runtime_error("biglm decoder needs both LMs");
   if (wfst_decoder_create_biglm(graph->Handle(), &c, 1, limits, nullptr, oldlm->Handle(), newlm->Handle(), nullptr, &_dec) != WFST_OK)
     Fatal("wfst_decoder_create_biglm");
+  SetColumns(graph);
 }
 GpuLatticeDecoder::GpuLatticeDecoder(GpuChannelPool *pool)
     : _dec(nullptr), _pool(pool), _chan(0), _decoded(0), _rows(nullptr), _rows_cap(0), _rows_pinned(false), _stride(0), _rows_ready(0), _inited(false) {
   if (!pool) throw std::runtime_error("GpuLatticeDecoder: NULL pool");
   _dec = pool->_dec;
+  SetColumns(pool->_graph);
   _chan = pool->Lease();
+}
+// the graph reads column tid2pdf[ilabel]: one representative transition-id per pdf is all the decodable is asked for (wfst-host.h,
+// Fst::SetTid2Pdf)
+void GpuLatticeDecoder::SetColumns(const Fst *graph) {
+  _rep.clear();
+  if (!graph) return;
+  const std::vector<int32_t> &m = graph->Tid2Pdf();
+  int32_t n_pdf = 0;
+  for (size_t t = 1; t < m.size(); ++t) n_pdf = std::max(n_pdf, m[t] + 1);
+  if (n_pdf <= 0) return;
+  _rep.assign((size_t)n_pdf, 0);
+  for (size_t t = m.size() - 1; t >= 1; --t)
+    if (m[t] >= 0) _rep[(size_t)m[t]] = (int32_t)t;   // (the lowest transition-id of the pdf)
 }
 GpuLatticeDecoder::~GpuLatticeDecoder() {
   // (rows of an utterance abandoned right behind an AdvanceDecoding may still be on their way to the device from the page-locked
@@ -522,7 +539,8 @@ void GpuLatticeDecoder::OnDevice(F &&f) {
 }
 
 void GpuLatticeDecoder::ReserveRows(int frames, int num_indices) {
-  if (frames > 0 && num_indices > 0) GrowRows((size_t)frames * (size_t)(num_indices + 1));
+  const size_t stride = _rep.empty() ? (size_t)(num_indices + 1) : (((size_t)_rep.size() + 3) & ~(size_t)3);   // (per-pdf rows where the graph maps)
+  if (frames > 0 && num_indices > 0) GrowRows((size_t)frames * stride);
 }
 
 void GpuLatticeDecoder::InitDecoding() {
@@ -540,12 +558,29 @@ void GpuLatticeDecoder::InitDecoding() {
 
 void GpuLatticeDecoder::Pull(AmInterface *d) {
   const int ready = d->NumFramesReady();
+  MatrixDecodable *md = dynamic_cast<MatrixDecodable *>(d);
+  if (!_rep.empty() && !md) {
+    // rows of one column per pdf (padded to a multiple of four columns: the expansion stages such a row in LDS by 16-byte DMAs)
+    const int n_pdf = (int)_rep.size(), stride = (n_pdf + 3) & ~3;
+    if (_stride == 0) _stride = stride;
+    if (stride != _stride) throw std::runtime_error("decodable changed its shape within an utterance");
+    if (d->NumIndices() < *std::max_element(_rep.begin(), _rep.end())) throw std::runtime_error("the decodable has fewer indices than the graph's tid2pdf maps");
+    if (ready <= _rows_ready) return;
+    GrowRows((size_t)ready * _stride);
+    for (int f = _rows_ready; f < ready; ++f) {
+      float *row = &_rows[(size_t)f * _stride];
+      for (int p = 0; p < n_pdf; ++p) row[p] = _rep[(size_t)p] > 0 ? d->LogLikelihood(f, _rep[(size_t)p]) : 0.0f;
+      for (int p = n_pdf; p < _stride; ++p) row[p] = 0.0f;
+    }
+    _rows_ready = ready;
+    return;
+  }
   const int stride = d->NumIndices() + 1;
   if (_stride == 0) _stride = stride;
   if (stride != _stride) throw std::runtime_error("decodable changed NumIndices() within an utterance");
   if (ready <= _rows_ready) return;
   GrowRows((size_t)ready * _stride);
-  if (MatrixDecodable *m = dynamic_cast<MatrixDecodable *>(d)) {
+  if (MatrixDecodable *m = md) {
     if (m->Stride() != _stride) throw std::runtime_error("MatrixDecodable::Stride() != NumIndices()+1");
     memcpy(&_rows[(size_t)_rows_ready * _stride], m->HostRows() + (size_t)_rows_ready * _stride,
            (size_t)(ready - _rows_ready) * _stride * sizeof(float));

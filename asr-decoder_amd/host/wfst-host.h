@@ -97,7 +97,13 @@ class Fst {
   ~Fst();
   bool ReadFst(const char *file, int device = 0);  // false (with a message on stderr) on failure
   bool Init(const char *file, const char *) { return ReadFst(file); }
-  void SetTid2Pdf(const std::vector<int32_t> &tid2pdf);  // entry 0 unused
+  // entry 0 unused.  The graph's rows then read log-likelihood column tid2pdf[ilabel] (what DecodableMatrixScaledMapped does with the
+  // transition model, kaldi-hclg-my-decoder.cc:107), and a GpuLatticeDecoder over this graph pulls ONE score per pdf from its
+  // decodable -- LogLikelihood(frame, a transition-id of that pdf) -- instead of one per transition-id: half the calls, half the
+  // bytes, rows narrow enough for the expansion's LDS row.  For decodables whose score depends on the transition-id's pdf only
+  // (every Kaldi decodable).
+  void SetTid2Pdf(const std::vector<int32_t> &tid2pdf);
+  const std::vector<int32_t> &Tid2Pdf() const { return _tid2pdf; }
   StateId Start() const { return _start; }
   bool IsFinal(StateId id) const { return id == _final; }
   StateId TotState() const { return _states; }
@@ -108,6 +114,7 @@ class Fst {
   Fst(const Fst &);
   Fst &operator=(const Fst &);
   wfst_graph *_graph;
+  std::vector<int32_t> _tid2pdf;
   int32_t _start = 0, _final = 0, _states = 0, _arcs = 0;
 };
 
@@ -274,6 +281,7 @@ class GpuChannelPool {
   void ExecuteAdvance(std::vector<Request *> &rs);
   void ExecuteBestPath(std::vector<Request *> &rs);
   wfst_decoder *_dec;
+  Fst *_graph;
   int _n, _linger_us;
   std::mutex _mu;
   std::condition_variable _cv_work, _cv_done, _cv_free;
@@ -348,6 +356,8 @@ class GpuLatticeDecoder : public DecoderItf {
   size_t _rows_cap;          // floats
   bool _rows_pinned;
   void GrowRows(size_t floats);
+  void SetColumns(const Fst *graph);   // the graph's tid2pdf -> one representative transition-id per pdf (Pull)
+  std::vector<int32_t> _rep;           // [pdf] a transition-id of that pdf; empty: the rows are indexed by the decodable's own indices
   int _stride, _rows_ready;
   bool _inited;
 };
