@@ -59,10 +59,12 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <mutex>
 
 #include "wfst-host.h"
 
@@ -361,7 +363,10 @@ int main(int argc, char **argv) {
               else dp->GetNbestShortlist(r.nbest, nbest);
             }
             } catch (const std::runtime_error &e) {
-              std::cerr << "WARNING utterance " << u.key << " failed: " << e.what() << "\n";
+              {   // (one stdio call per line: the worker threads share stderr)
+                const std::string line = "WARNING utterance " + u.key + " failed: " + e.what() + "\n";
+                fputs(line.c_str(), stderr);
+              }
               if (first_pass) res[ui].ok = false;
             }
           }

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <thread>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -14,7 +15,8 @@ namespace datemoon {
 
 namespace {
 [[noreturn]] void Fatal(const std::string &what) { throw std::runtime_error(what + ": " + wfst_last_error()); }
-void Warn(const std::string &msg) { std::cerr << "WARNING (wfst) " << msg << std::endl; }
+// (one stdio call per line: the worker threads of a service share stderr, and a line put together by several << would interleave)
+void Warn(const std::string &msg) { const std::string line = "WARNING (wfst) " + msg + "\n"; fputs(line.c_str(), stderr); fflush(stderr); }
 
 // hop list (start->final order) -> the linear Lattice the reference's GetBestPath builds
 // (base-inl.h:1080-1091): last state = start, state 0 = final.
