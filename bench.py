@@ -427,7 +427,7 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
                      "host -> device inside the timed region" % (threads, chunk, threads)}
         for tag, extra in (("pool", ["--pool=%d" % threads, "--pull"]), ("pool_matrix", ["--pool=%d" % threads]), ("private", ["--pull"])):
             best = None
-            for rep in range(2):   # (the first run of a shape pays the graph captures: the better of two)
+            for rep in range(3):   # (fresh processes: graph captures, page-locking and thread start-up vary from run to run -- the best of three)
                 p = subprocess.run(common + extra + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
                 err = p.stderr.decode(errors="replace")
                 if p.returncode != 0:
