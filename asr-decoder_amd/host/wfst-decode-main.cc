@@ -40,6 +40,8 @@
 //                  batcher waits for the other leased channels' requests (50)
 //   --repeat=K     --threads only: the utterance list is decoded K times over (a steady-state measurement: the first utterances of a
 //                  run pay the decoder's graph captures and buffer allocations); the output is the first pass's
+//   --share=C      the ONE-LINE drop-in at service scale: GpuLatticeDecoder::ShareDevice(C) once, then every thread constructs its decoder
+//                  the reference's way -- (graph, config) -- and the objects lease channels of shared C-channel device decoders
 //   --pull         the decodable is a plain DecodableInterface: every score goes through LogLikelihood(frame, index) (without it
 //                  the rows are taken in one piece, MatrixDecodable)
 //   --nbest=N      also print the N-best word sequences of every utterance (the service's
@@ -134,7 +136,7 @@ int main(int argc, char **argv) {
     int nbest = 0, inflight = 1, chunk = 0, n_threads = 0, pool_channels = 0, linger_us = 50;
     bool pull = false;
     long long max_tokens_per_frame = 0, arena_tokens = 0;
-    int max_frames = 0, repeat = 1;
+    int max_frames = 0, repeat = 1, share_channels = 0;
     std::vector<int> devices(1, 0);
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -154,6 +156,7 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 12, "--linger-us=") == 0) linger_us = std::max(0, atoi(a.c_str() + 12));
       else if (a == "--pull") pull = true;
       else if (a.compare(0, 9, "--repeat=") == 0) repeat = std::max(1, atoi(a.c_str() + 9));
+      else if (a.compare(0, 8, "--share=") == 0) share_channels = std::max(0, atoi(a.c_str() + 8));
       else if (a.compare(0, 13, "--max-tokens=") == 0) max_tokens_per_frame = atoll(a.c_str() + 13);
       else if (a.compare(0, 15, "--arena-tokens=") == 0) arena_tokens = atoll(a.c_str() + 15);
       else if (a.compare(0, 13, "--max-frames=") == 0) max_frames = atoi(a.c_str() + 13);
@@ -305,6 +308,7 @@ int main(int argc, char **argv) {
       // the service's shape: N worker threads, one DecoderItf object each, over a pool's channels or private device decoders
       if (devices.size() > 1) { std::cerr << "--threads: one device\n"; return 1; }
       if (pool_channels > 0 && pool_channels < n_threads) { std::cerr << "--pool must hold a channel per thread\n"; return 1; }
+      if (share_channels > 0) GpuLatticeDecoder::ShareDevice(share_channels, linger_us);
       std::unique_ptr<GpuChannelPool> pool;
       if (pool_channels > 0)
         pool.reset(biglm ? new GpuChannelPool(&fst, opt, lm1p, lm2p, pool_channels, &limits, linger_us)

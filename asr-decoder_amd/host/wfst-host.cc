@@ -280,6 +280,12 @@ int GpuChannelPool::Lease() {
     _cv_free.wait(lk);   // (more decoder objects than channels: this one waits for a destructor)
   }
 }
+int GpuChannelPool::TryLease() {
+  std::lock_guard<std::mutex> lk(_mu);
+  for (int c = 0; c < _n; ++c)
+    if (!_leased[(size_t)c]) { _leased[(size_t)c] = 1; ++_n_leased; return c; }
+  return -1;
+}
 void GpuChannelPool::Release(int c) {
   {
     std::lock_guard<std::mutex> lk(_mu);
@@ -457,6 +463,8 @@ void GpuChannelPool::ExecuteBestPath(std::vector<Request *> &all) {
 GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfig &config, const wfst_limits *limits)
     : _dec(nullptr), _pool(nullptr), _chan(0), _decoded(0), _rows(nullptr), _rows_cap(0), _rows_pinned(false), _stride(0), _rows_ready(0), _inited(false) {
   config.Check();
+  Share(graph, config, nullptr, nullptr, limits);
+  if (_pool) return;
   wfst_config c = config.ToC();
   if (wfst_decoder_create(graph->Handle(), &c, 1, limits, nullptr, &_dec) != WFST_OK) Fatal("wfst_decoder_create");
   SetColumns(graph);
@@ -465,11 +473,75 @@ GpuLatticeDecoder::GpuLatticeDecoder(Fst *graph, const LatticeFasterDecoderConfi
                                      const wfst_limits *limits)
     : _dec(nullptr), _pool(nullptr), _chan(0), _decoded(0), _rows(nullptr), _rows_cap(0), _rows_pinned(false), _stride(0), _rows_ready(0), _inited(false) {
   config.Check();
-  wfst_config c = config.ToC();
   if (!oldlm || !newlm) throw std::runtime_error("biglm decoder needs both LMs");
+  Share(graph, config, oldlm, newlm, limits);
+  if (_pool) return;
+  wfst_config c = config.ToC();
   if (wfst_decoder_create_biglm(graph->Handle(), &c, 1, limits, nullptr, oldlm->Handle(), newlm->Handle(), nullptr, &_dec) != WFST_OK)
     Fatal("wfst_decoder_create_biglm");
   SetColumns(graph);
+}
+
+// ---- ShareDevice: the reference's constructor shape over shared device decoders ------------------------------------------------
+namespace {
+struct SharedEntry {
+  const wfst_graph *graph;
+  wfst_config cfg;
+  bool has_lim;
+  wfst_limits lim;
+  ArpaLm *oldlm, *newlm;
+  std::shared_ptr<GpuChannelPool> pool;
+};
+struct SharedRegistry {
+  std::mutex mu;
+  int n_channels = 0, linger_us = 50;
+  std::vector<SharedEntry> entries;
+};
+// (never destroyed: worker threads may still hold decoder objects when the process leaves main, and the device runtime's own
+// teardown order is not ours to rely on)
+SharedRegistry &Registry() { static SharedRegistry *r = new SharedRegistry(); return *r; }
+}  // namespace
+
+void GpuLatticeDecoder::ShareDevice(int n_channels, int linger_us) {
+  SharedRegistry &R = Registry();
+  std::lock_guard<std::mutex> lk(R.mu);
+  R.n_channels = std::max(0, n_channels);
+  R.linger_us = linger_us;
+  if (R.n_channels == 0) R.entries.clear();   // (a shared decoder goes when its last object does)
+}
+void GpuLatticeDecoder::Share(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm, const wfst_limits *limits) {
+  SharedRegistry &R = Registry();
+  std::lock_guard<std::mutex> lk(R.mu);
+  if (R.n_channels <= 0) return;
+  const wfst_config c = config.ToC();
+  for (SharedEntry &e : R.entries) {
+    if (e.graph != graph->Handle() || memcmp(&e.cfg, &c, sizeof(c)) != 0 || e.oldlm != oldlm || e.newlm != newlm) continue;
+    if (e.has_lim != (limits != nullptr) || (limits && memcmp(&e.lim, limits, sizeof(*limits)) != 0)) continue;
+    const int ch = e.pool->TryLease();
+    if (ch < 0) continue;   // (full: the next one, or a new one)
+    _shared = e.pool;
+    _pool = _shared.get();
+    _dec = _pool->_dec;
+    _chan = ch;
+    SetColumns(graph);
+    return;
+  }
+  SharedEntry e;
+  e.graph = graph->Handle();
+  e.cfg = c;
+  e.has_lim = limits != nullptr;
+  memset(&e.lim, 0, sizeof(e.lim));
+  if (limits) e.lim = *limits;
+  e.oldlm = oldlm; e.newlm = newlm;
+  e.pool.reset(oldlm ? new GpuChannelPool(graph, config, oldlm, newlm, R.n_channels, limits, R.linger_us)
+                     : new GpuChannelPool(graph, config, R.n_channels, limits, R.linger_us));
+  const int ch = e.pool->TryLease();
+  _shared = e.pool;
+  _pool = _shared.get();
+  _dec = _pool->_dec;
+  _chan = ch;
+  SetColumns(graph);
+  R.entries.push_back(e);
 }
 GpuLatticeDecoder::GpuLatticeDecoder(GpuChannelPool *pool)
     : _dec(nullptr), _pool(pool), _chan(0), _decoded(0), _rows(nullptr), _rows_cap(0), _rows_pinned(false), _stride(0), _rows_ready(0), _inited(false) {
@@ -502,6 +574,7 @@ GpuLatticeDecoder::~GpuLatticeDecoder() {
   }
   if (_pool) _pool->Release(_chan);
   else wfst_decoder_free(_dec);
+  _shared.reset();   // (ShareDevice: the shared decoder goes with its last object once the registry has let go of it)
   if (_rows_pinned) wfst_host_free(_rows);
   else free(_rows);
 }

@@ -23,6 +23,7 @@
 #include <exception>
 #include <functional>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <mutex>
 #include <string>
@@ -274,6 +275,7 @@ class GpuChannelPool {
   };
   void Start(int linger_us);
   int Lease();
+  int TryLease();                 // -1: every channel is leased
   void Release(int channel);
   void Submit(Request *r);        // enqueue, wait, rethrow what the batcher thread caught
   void Run();
@@ -307,6 +309,13 @@ class GpuLatticeDecoder : public DecoderItf {
                     const wfst_limits *limits = nullptr);
   // a channel of the pool's decoder (graph, config, LMs and limits are the pool's); waits for a free channel
   explicit GpuLatticeDecoder(GpuChannelPool *pool);
+  // THE ONE-LINE DROP-IN AT SERVICE SCALE.  After ShareDevice(n), decoder objects constructed the reference's way -- (graph, config
+  // [, oldlm, newlm][, limits]), one per worker thread (v2-asr/v2-asr-work-thread.h:66) -- lease channels of a SHARED n-channel device
+  // decoder per distinct (graph, config, LMs, limits) instead of creating a private 1-channel decoder each: the service's code does not
+  // change, its threads' calls are batched (GpuChannelPool).  An object constructed when all n channels are leased opens a further
+  // shared decoder.  ShareDevice(0): objects constructed from then on are private again (shared decoders live until their last
+  // object is gone).  Call it once at start-up, before the worker threads construct their decoders.
+  static void ShareDevice(int n_channels, int linger_us = 50);
   ~GpuLatticeDecoder() override;
   // Page-locked room for `frames` rows of a decodable with `num_indices` indices, allocated NOW: a service calls it when it
   // creates its decoders (it knows its model and its longest utterance).  Without it the buffer is allocated when the first rows
@@ -349,6 +358,8 @@ class GpuLatticeDecoder : public DecoderItf {
   void Pull(AmInterface *decodable);
   template <class F> void OnDevice(F &&f);   // f(): C-ABI calls on (_dec, _chan) -- in the pool's batcher thread where there is a pool
   wfst_decoder *_dec;
+  void Share(Fst *graph, const LatticeFasterDecoderConfig &config, ArpaLm *oldlm, ArpaLm *newlm, const wfst_limits *limits);
+  std::shared_ptr<GpuChannelPool> _shared;   // ShareDevice: keeps the shared decoder alive
   GpuChannelPool *_pool;     // nullptr: the private decoder
   int _chan;                 // 0, or the leased channel
   int _decoded;              // pool: NumFramesDecoded as of the last request

@@ -425,7 +425,9 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
                      "LogLikelihood(frame, transition-id) of a DecodableMatrixScaledMapped-shaped decodable (6000 indices a frame, the graph reads "
                      "column ilabel); pool_matrix: MatrixDecodable rows of 3000 pdf columns taken in one piece (the graph reads tid2pdf[ilabel]); "
                      "host -> device inside the timed region" % (threads, chunk, threads)}
-        for tag, extra in (("pool", ["--pool=%d" % threads, "--pull"]), ("pool_matrix", ["--pool=%d" % threads]), ("private", ["--pull"])):
+        for tag, extra in (("pool", ["--pool=%d" % threads, "--pull"]), ("pool_matrix", ["--pool=%d" % threads]), ("private", ["--pull"]),
+                           # the one-line drop-in: GpuLatticeDecoder::ShareDevice(64) once, the threads construct (graph, config) decoders as ever
+                           ("shared", ["--share=%d" % threads, "--pull"])):
             best = None
             for rep in range(3):   # (fresh processes: graph captures, page-locking and thread start-up vary from run to run -- the best of three)
                 p = subprocess.run(common + extra + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -516,7 +518,7 @@ def leg_scalars(o):
         k["wer_vs_cpu_max"] = o["spread"]["gpu_vs_reference_wer_range"][1]
     if "degraded_frames" in o:
         k["degraded_frames"] = o["degraded_frames"]
-    for dk in ("pool_value", "pool_matrix_value", "private_value", "reference_value", "reference_threads", "pool_mean_advance_batch", "threads", "chunk_frames"):
+    for dk in ("pool_value", "pool_matrix_value", "shared_value", "private_value", "reference_value", "reference_threads", "pool_mean_advance_batch", "threads", "chunk_frames"):
         if dk in o:
             k[dk] = o[dk]
     if "pool_same_words_as_batch_decoder" in o:
@@ -586,7 +588,7 @@ def summary_line(out, detail_path=None):
     # (a line over the limit loses its optional parts -- strings first, then the legs' scalars from the least telling one up, then
     # whole legs from the last one -- rather than its contract keys, and is printed in any case)
     # (what a leg keeps when the line has to shrink, most telling first)
-    order = ("value", "ms_per_step", "parity", "error", "pool_value", "pool_matrix_value", "private_value", "reference_value", "bit_identical",
+    order = ("value", "ms_per_step", "parity", "error", "pool_value", "shared_value", "private_value", "reference_value", "pool_matrix_value", "bit_identical",
              "wer_vs_cpu", "cpu_self_wer", "cpu_baseline_value", "frac", "whole_path_frac", "lattice_parity", "gpu_determinizer_ms_per_lattice_mean",
              "gpu_determinizer_ms_per_lattice_max", "cpu_determinizer_ms_per_lattice", "whole_path_frac_8d", "utterances_with_path", "steps",
              "wer_vs_cpu_max", "cpu_self_wer_max", "pool_mean_advance_batch", "degraded_frames", "cpu_self_bit_identical", "kernel",

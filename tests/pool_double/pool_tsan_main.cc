@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -49,11 +51,16 @@ int main(int argc, char **argv) {
   }
   LatticeFasterDecoderConfig cfg;
   Fst fst;   // (never read: the test double ignores the graph)
+  // "share": the reference's constructor shape over SHARED decoders -- ShareDevice(half the threads): the objects fill one shared
+  // decoder and open a second
+  const bool share = argc > 3 && std::string(argv[3]) == "share";
+  if (share) GpuLatticeDecoder::ShareDevice(n_threads > 1 ? (n_threads + 1) / 2 : 1, 20);
   GpuChannelPool pool(&fst, cfg, n_threads, nullptr, /*linger_us=*/20);
   std::atomic<size_t> next(0);
   std::atomic<int> bad(0), misuse_caught(0);
   auto worker = [&](int k) {
-    GpuLatticeDecoder dec(&pool);
+    std::unique_ptr<GpuLatticeDecoder> dp(share ? new GpuLatticeDecoder(&fst, cfg) : new GpuLatticeDecoder(&pool));
+    GpuLatticeDecoder &dec = *dp;
     DecoderItf &d = dec;
     if (k == 0) {   // misuse: AdvanceDecoding on a channel whose utterance is finalized -- this thread's exception, nobody else's
       Utt &u = utts[0];
@@ -96,6 +103,11 @@ int main(int argc, char **argv) {
   for (int k = 1; k < n_threads; ++k) th.emplace_back(worker, k);
   worker(0);
   for (std::thread &t : th) t.join();
+  if (share) {   // (the shared decoders' own statistics are not reachable from here: the results above are the check)
+    GpuLatticeDecoder::ShareDevice(0);
+    printf("bad %d misuse_caught %d frames 0/0 advance_calls 0 advance_requests 0 batches 0 fake_advance_calls 0\n", bad.load(), misuse_caught.load());
+    return (bad.load() != 0 || misuse_caught.load() != 1) ? 1 : 0;
+  }
   const GpuChannelPool::Stats st = pool.GetStats();
   long long frames = 0;
   for (const Utt &u : utts) frames += u.frames;

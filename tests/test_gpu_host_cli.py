@@ -369,7 +369,7 @@ def _write_utts(tmp_path, mats):
             f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", x.shape[0], x.shape[1]) + x.tobytes())
 
 
-@pytest.mark.parametrize("shape", ["pool_pull", "pool_matrix", "private"])
+@pytest.mark.parametrize("shape", ["pool_pull", "pool_matrix", "private", "shared"])
 def test_service_threads_over_a_channel_pool(shape, synth, oracle, tmp_path):
     """the reference service's shape -- N worker threads, one DecoderItf object each (v2-asr/v2-asr-work-thread.h:66)
     -- on the device: 64 host threads x GpuLatticeDecoder(pool) over ONE 64-channel device decoder, every utterance fed in chunks of
@@ -392,7 +392,10 @@ def test_service_threads_over_a_channel_pool(shape, synth, oracle, tmp_path):
     mats = [synth.make_loglikes(g, T, 300, m, seed=900 + i, mu=-2.2)[0] for i, T in enumerate(lens)]
     _write_utts(tmp_path, mats)
     args = [CLI, "--tid2pdf=" + str(tmp_path / "tid2pdf.bin"), "--chunk=25"]
-    args += {"pool_pull": ["--threads=64", "--pool=64", "--pull"], "pool_matrix": ["--threads=64", "--pool=64"], "private": ["--threads=8", "--pull"]}[shape]
+    # shared: GpuLatticeDecoder::ShareDevice(24) once, then 64 threads construct their decoders the reference's way -- (graph, config) --:
+    # the objects fill three shared 24-channel device decoders
+    args += {"pool_pull": ["--threads=64", "--pool=64", "--pull"], "pool_matrix": ["--threads=64", "--pool=64"], "private": ["--threads=8", "--pull"],
+             "shared": ["--threads=64", "--share=24", "--pull"]}[shape]
     p = subprocess.run(args + [str(tmp_path / "decoder.conf"), gpath, str(tmp_path / "ll.bin")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = p.stdout.strip().splitlines()
@@ -412,7 +415,7 @@ def test_service_threads_over_a_channel_pool(shape, synth, oracle, tmp_path):
     oracle.free_graph(h)
     assert [l.split()[0] for l in lines] == sorted(words)   # input order
     assert n_ok >= n_utt - 5
-    if shape != "private":
+    if shape in ("pool_pull", "pool_matrix"):
         mm = re.search(r"LOG pool: 64 channels, 64 threads, (\d+) batcher passes, (\d+) requests, (\d+) advance calls for (\d+) AdvanceDecoding requests \(mean batch ([\d.]+)\), (\d+) frames", p.stderr)
         assert mm, p.stderr[-1500:]
         assert int(mm.group(6)) == sum(lens)                 # every frame went through the batcher once

@@ -35,3 +35,14 @@ def test_pool_batches_without_races(pool_tsan, threads, utts):
     assert got == want
     if threads >= 8:
         assert int(out["advance_requests"]) >= 2 * int(out["advance_calls"])
+
+
+def test_shared_device_mode_without_races(pool_tsan):
+    """GpuLatticeDecoder::ShareDevice: decoder objects constructed the reference's way -- (graph, config), one per thread -- lease
+    channels of shared device decoders (16 objects over two 8-channel ones): every utterance's own rows, the misuse to its own
+    thread, nothing for the sanitizer."""
+    p = subprocess.run([pool_tsan, "16", "96", "share"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1"))
+    assert "ThreadSanitizer" not in p.stderr, p.stderr[-3000:]
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr[-1500:])
+    assert "bad 0 misuse_caught 1" in p.stdout
