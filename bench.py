@@ -427,7 +427,8 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
                      "host -> device inside the timed region" % (threads, chunk, threads)}
         for tag, extra in (("pool", ["--pool=%d" % threads, "--pull"]), ("pool_matrix", ["--pool=%d" % threads]), ("private", ["--pull"]),
                            # the one-line drop-in: GpuLatticeDecoder::ShareDevice(64) once, the threads construct (graph, config) decoders as ever
-                           ("shared", ["--share=%d" % threads, "--pull"])):
+                           # (two shared decoders of 32 channels -- each with its own batcher thread -- ran 3-5 % ahead of one of 64; four of 16: behind)
+                           ("shared", ["--share=%d" % (threads // 2), "--pull"])):
             best = None
             for rep in range(3):   # (fresh processes: graph captures, page-locking and thread start-up vary from run to run -- the best of three)
                 p = subprocess.run(common + extra + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
