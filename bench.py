@@ -534,6 +534,7 @@ def summary_line(out, detail_path=None):
     top = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                    "vs_baseline", "dtype", "data")}
     top["metric"] = str(top["metric"])[:100]
+    top["data"] = str(top.get("data", ""))[:64]
     c = out.get("config", {})
     cfg = {k: c[k] for k in ("workload", "global_batch", "frames_per_utt", "parallelism", "rtfx", "channel_groups",
                              "mean_active_tokens_per_frame", "peak_tokens_in_a_frame", "max_tokens_per_frame_limit", "degraded_frames",
@@ -541,7 +542,7 @@ def summary_line(out, detail_path=None):
     if "regime" in cfg:
         cfg["regime"] = str(cfg["regime"])[:60]
     if "workload" in cfg:
-        cfg["workload"] = str(cfg["workload"])[:200]
+        cfg["workload"] = str(cfg["workload"])[:150]
     for k in ("parity", "lattice_parity", "parity_per_rank_sample"):
         if k in c:
             cfg[k] = _ratio(c[k])
@@ -568,7 +569,7 @@ def summary_line(out, detail_path=None):
     b = out.get("cpu_baseline")
     if b:
         bb = {k: b.get(k) for k in ("value", "unit", "cores", "kind", "single_thread_value", "all_cpus_value", "cpu_model", "affinity_cpus")}
-        bb["sample"] = str(b.get("sample", ""))[:80]
+        bb["sample"] = str(b.get("sample", ""))[:48]
         top["cpu_baseline"] = {k: _short(v) for k, v in bb.items() if v is not None}
     legs = {}
     for name, o in out.get("legs", {}).items():
