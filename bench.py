@@ -1053,8 +1053,8 @@ def main():
                    "frames/sec decoded with lattice generation%s (BASELINE configs[4])" % (" + determinization" if a.determinize else "")),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded hclg-like graph + %s log-likelihoods, SURVEY.md 8(d))" % (
-            "%d-live-hypotheses" % a.paths if a.workload == "multi" else "single-planted-path"),
+        "dtype": "f32", "data": "synthetic: seeded hclg-like graph, %s log-likes" % (
+            "%d-hypothesis" % a.paths if a.workload == "multi" else "single-planted-path"),
         "config": {
             "workload": ("BASELINE configs[3] (biglm) on " if a.biglm else "") +
                         "BASELINE configs[1]: batch=%d utterances/GPU x %d frames, %d-arc HCLG, beam=%g, "
@@ -1210,8 +1210,8 @@ def main():
                 best_n = max(curve, key=lambda k: curve[k])   # the CPU's best: more threads than that lose (random access to one shared graph)
                 out["cpu_baseline"] = {"value": curve[best_n], "unit": "frames/s", "cores": int(best_n), "kind": kind,
                                        "single_thread_value": fps1, "all_cpus_value": fps, "cpu_model": cpu_model,
-                                       "sample": "the %d utterances of rank 0, each host thread (one decoder object per thread over one shared "
-                                                 "graph) looping over them; legs of 1, 8, 32 and %d threads (%.1fs wall for the first and the "
+                                       "sample": "rank 0's %d utterances, looped by every thread; each host thread has its decoder object over one shared "
+                                                 "graph; legs of 1, 8, 32 and %d threads (%.1fs wall for the first and the "
                                                  "last: %d and %d frames decoded); value = the best leg" % (B, nth, cdt, fr1, fr),
                                        "threads_to_value": curve,
                                        "affinity_cpus": cpus, "host_cpus": os.cpu_count()}
