@@ -445,24 +445,29 @@ class BatchDecoder:
         npth, na = C.c_int32(0), C.c_int32(0)
         pn, pa = C.byref(npth), C.byref(na)
         vp = C.c_void_p
-        out = [None] * self.n
         fbuf = buf.view(np.float32)
+        found = np.full(self.n, -1, np.int32)
         for c in range(self.n):
             p = base + 4 * stride * c
             rc = f(self.h, c, *extra, K, A, pn, pa, vp(p), vp(p + 4 * (K + 1)), vp(p + 4 * (2 * K + 1)), vp(p + 4 * (2 * K + 1 + A)), vp(p + 4 * (2 * K + 1 + 2 * A)))
-            if rc != WFST_OK:
-                continue
-            k = npth.value
+            if rc == WFST_OK:
+                found[c] = npth.value
+        o0 = 2 * K + 1
+
+        def make(c):   # (the dicts of a channel are put together when the channel is first looked at: _LazyList)
+            k = int(found[c])
+            if k < 0:
+                return None
             off = buf[c, : k + 1]
-            o0 = 2 * K + 1
             paths = []
             for i in range(k):
                 a, b = int(off[i]), int(off[i + 1])
                 ol = buf[c, o0 + a:o0 + b]
                 paths.append(dict(olabel=ol, words=ol[ol != 0], graph=fbuf[c, o0 + A + a:o0 + A + b], acoustic=fbuf[c, o0 + 2 * A + a:o0 + 2 * A + b],
                                   tot=float(fbuf[c, K + 1 + i])))
-            out[c] = paths
-        return out
+            return paths
+
+        return _LazyList(self.n, make)
 
     def prefetched_nbest(self, n):
         """The n-best paths a harvested detached prefetch (prefetch_determinized(detached=True, nbest=n)) computed, for every channel."""

