@@ -188,6 +188,9 @@ struct wfst_decoder {
   int mark_next = 0;
   std::vector<int> chan_mark;          // [channel] ring slot of the event behind the channel's last enqueued work, -1: none
   hipStream_t res_stream = nullptr;
+  std::vector<int32_t> bp_out;         // wfst_decoder_best_path_enqueue: the outstanding request's channels ...
+  int32_t bp_out_n = 0, bp_out_cap = 0;   // ... their number (0: nothing outstanding) and the hop capacity
+  ChanCtl *bp_ctl_pin = nullptr;       // ... and its own page-locked copy of the control blocks (p_ctl is the synchronous getters')
   int32_t *res_chan_pin = nullptr;
   DevBuf<int32_t> res_chan_list;
   hipEvent_t copy_ev = nullptr;        // advance_host: the rows of page-locked buffers are on their way (the decode stream waits for it, the host does not)
@@ -327,6 +330,7 @@ struct wfst_decoder {
     for (hipEvent_t ev : mark_ev) if (ev) (void)hipEventDestroy(ev);
     if (res_stream) (void)hipStreamDestroy(res_stream);
     if (res_chan_pin) (void)hipHostFree(res_chan_pin);
+    if (bp_ctl_pin) (void)hipHostFree(bp_ctl_pin);
     res_chan_list.release();
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
@@ -1810,45 +1814,13 @@ int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t channel) {
   return d->h_decoded[channel];
 }
 
-int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs,
-                               int32_t cap, int32_t *ilabel, int32_t *olabel, float *graph_cost,
-                               float *acoustic_cost, int32_t *n_hops) {
-  if (!d || !ilabel || !olabel || !graph_cost || !acoustic_cost || !n_hops || cap <= 0)
-    return fail(WFST_E_ARG, "NULL output or cap <= 0");
-  HIP_TRY(hipSetDevice(d->device));
-  const int32_t *dev;
-  int32_t cnt;
-  int rc;
-  hipStream_t st = d->stream;
-  if (channels) {
-    // a LIST of channels: on the results stream, behind these channels' own work only (see mark_ev)
-    if (n <= 0 || n > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
-    std::vector<char> seen((size_t)d->n_channels, 0);
-    for (int i = 0; i < n; ++i) {
-      if (channels[i] < 0 || channels[i] >= d->n_channels) return fail(WFST_E_ARG, "channel index out of range");
-      if (seen[(size_t)channels[i]]) return fail(WFST_E_ARG, "duplicate channel in list");
-      seen[(size_t)channels[i]] = 1;
-    }
-    rc = results_stream_behind(d, channels, n, &st);
-    if (rc != WFST_OK) return rc;
-    memcpy(d->res_chan_pin, channels, (size_t)n * 4);   // (the stream is idle between these calls: each one waits for it before it returns)
-    HIP_TRY(hipMemcpyAsync(d->res_chan_list.p, d->res_chan_pin, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    dev = d->res_chan_list.p;
-    cnt = n;
-  } else {
-    rc = stage_channels(d, channels, n, &dev, &cnt);
-    if (rc != WFST_OK) return rc;
-  }
-  for (int i = 0; i < cnt; ++i) {
-    const int c = channels ? channels[i] : i;
-    if (d->h_state[c] == 0) return fail(WFST_E_STATE, "GetBestPath before InitDecoding");
-    if (d->h_state[c] == 2 && !use_final_probs)  // base-inl.h:1100-1102 (LOG_ERR)
-      return fail(WFST_E_STATE, "You cannot call FinalizeDecoding() and then GetBestPath with use_final_probs == false");
-  }
-  const size_t need = (size_t)cnt * (size_t)cap;
-  // one device block {n_hops[cnt] (padded to 4 words) | ilabel | olabel | graph | acoustic} -> one copy into pinned
-  // host memory -> the caller's arrays (five copies into pageable memory cost five staging round trips)
-  const size_t head = ((size_t)cnt + 3) & ~(size_t)3, words = head + 4 * need;
+// ---- GetBestPath of a channel LIST in two halves: enqueue (never waits) / fetch -------------------------------------------------------
+// A host that batches many decoder objects (the channel pool's batcher thread) must not stand still while a finished utterance's best
+// path waits for that utterance's last frames: the kernel and the copies are enqueued on the results stream behind the listed
+// channels' own work, the batcher goes on feeding the device, and the results are taken when they have landed.  One request may be
+// outstanding per decoder; the state it holds (the list, the result block in page-locked memory, a copy of the control blocks of
+// its own) is touched by nothing else meanwhile.
+static int bp_buffers(wfst_decoder *d, size_t words, size_t need) {
   if (d->bp_all.n < words || d->bp_chain.n < need) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     if (d->res_stream) HIP_TRY(hipStreamSynchronize(d->res_stream));
@@ -1862,18 +1834,114 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
     HIP_TRY(hipHostMalloc((void **)&d->bp_pin, words * 4, hipHostMallocDefault));
     d->bp_pin_bytes = words * 4;
   }
+  return WFST_OK;
+}
+
+int wfst_decoder_best_path_enqueue(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs, int32_t cap) {
+  if (!d || !channels || cap <= 0) return fail(WFST_E_ARG, "NULL decoder / channel list, or cap <= 0");
+  if (d->bp_out_n > 0) return fail(WFST_E_STATE, "a best-path request is outstanding (wfst_decoder_best_path_fetch takes it)");
+  HIP_TRY(hipSetDevice(d->device));
+  if (n <= 0 || n > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
+  std::vector<char> seen((size_t)d->n_channels, 0);
+  for (int i = 0; i < n; ++i) {
+    if (channels[i] < 0 || channels[i] >= d->n_channels) return fail(WFST_E_ARG, "channel index out of range");
+    if (seen[(size_t)channels[i]]) return fail(WFST_E_ARG, "duplicate channel in list");
+    seen[(size_t)channels[i]] = 1;
+    const int c = channels[i];
+    if (d->h_state[c] == 0) return fail(WFST_E_STATE, "GetBestPath before InitDecoding");
+    if (d->h_state[c] == 2 && !use_final_probs)  // base-inl.h:1100-1102 (LOG_ERR)
+      return fail(WFST_E_STATE, "You cannot call FinalizeDecoding() and then GetBestPath with use_final_probs == false");
+  }
+  hipStream_t st;
+  int rc = results_stream_behind(d, channels, n, &st);   // behind these channels' own work only (see mark_ev)
+  if (rc != WFST_OK) return rc;
+  const size_t need = (size_t)n * (size_t)cap, head = ((size_t)n + 3) & ~(size_t)3, words = head + 4 * need;
+  rc = bp_buffers(d, words, need);
+  if (rc != WFST_OK) return rc;
+  if (!d->bp_ctl_pin) HIP_TRY(hipHostMalloc((void **)&d->bp_ctl_pin, d->ctl.bytes(), hipHostMallocDefault));
+  memcpy(d->res_chan_pin, channels, (size_t)n * 4);   // (the results stream is idle here: nothing is outstanding)
+  HIP_TRY(hipMemcpyAsync(d->res_chan_list.p, d->res_chan_pin, (size_t)n * 4, hipMemcpyHostToDevice, st));
   int32_t *dn = d->bp_all.p, *dil = dn + head, *dol = dil + need;
   float *dg = reinterpret_cast<float *>(dol + need), *dac = dg + need;
-  launch_best_path(d->D, dev, cnt, use_final_probs ? 1 : 0, cap, dil, dol, dg, dac, dn, d->bp_chain.p, st);
+  launch_best_path(d->D, d->res_chan_list.p, n, use_final_probs ? 1 : 0, cap, dil, dol, dg, dac, dn, d->bp_chain.p, st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(d->bp_pin, d->bp_all.p, words * 4, hipMemcpyDeviceToHost, st));
-  if (channels) {   // (the listed channels' control blocks are final behind their marks; the others' are not looked at)
-    HIP_TRY(hipMemcpyAsync(d->p_ctl, d->ctl.p, d->ctl.bytes(), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-  } else {
-    rc = read_ctl(d);   // synchronises the stream
-    if (rc != WFST_OK) return rc;
+  // (the listed channels' control blocks are final behind their marks; the others' are not looked at)
+  HIP_TRY(hipMemcpyAsync(d->bp_ctl_pin, d->ctl.p, d->ctl.bytes(), hipMemcpyDeviceToHost, st));
+  d->bp_out.assign(channels, channels + n);
+  d->bp_out_n = n;
+  d->bp_out_cap = cap;
+  return WFST_OK;
+}
+
+int wfst_decoder_best_path_ready(wfst_decoder *d) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  if (d->bp_out_n <= 0) return fail(WFST_E_STATE, "no best-path request is outstanding");
+  HIP_TRY(hipSetDevice(d->device));
+  const hipError_t e = hipStreamQuery(d->res_stream);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  return fail(WFST_E_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+}
+
+int wfst_decoder_best_path_fetch(wfst_decoder *d, int32_t *ilabel, int32_t *olabel, float *graph_cost, float *acoustic_cost, int32_t *n_hops) {
+  if (!d || !ilabel || !olabel || !graph_cost || !acoustic_cost || !n_hops) return fail(WFST_E_ARG, "NULL output");
+  if (d->bp_out_n <= 0) return fail(WFST_E_STATE, "no best-path request is outstanding");
+  HIP_TRY(hipSetDevice(d->device));
+  const int32_t cnt = d->bp_out_n, cap = d->bp_out_cap;
+  d->bp_out_n = 0;   // (taken, whatever it turns out to hold)
+  HIP_TRY(hipStreamSynchronize(d->res_stream));
+  const size_t need = (size_t)cnt * (size_t)cap, head = ((size_t)cnt + 3) & ~(size_t)3;
+  const int32_t *hp = reinterpret_cast<const int32_t *>(d->bp_pin);
+  memcpy(n_hops, hp, (size_t)cnt * 4);
+  memcpy(ilabel, hp + head, need * 4);
+  memcpy(olabel, hp + head + need, need * 4);
+  memcpy(graph_cost, hp + head + 2 * need, need * 4);
+  memcpy(acoustic_cost, hp + head + 3 * need, need * 4);
+  // a device error of ANOTHER channel's utterance is that channel's, not this request's
+  for (int i = 0; i < cnt; ++i) {
+    const int c = d->bp_out[(size_t)i];
+    if (d->bp_ctl_pin[c].error) return fail_ctl_error(c, d->bp_ctl_pin[c].error);
   }
+  for (int i = 0; i < cnt; ++i)
+    if (n_hops[i] > cap) return fail(WFST_E_CAPACITY, "best path longer than cap hops; n_hops holds the needed size");
+  return WFST_OK;
+}
+
+int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs,
+                               int32_t cap, int32_t *ilabel, int32_t *olabel, float *graph_cost,
+                               float *acoustic_cost, int32_t *n_hops) {
+  if (!d || !ilabel || !olabel || !graph_cost || !acoustic_cost || !n_hops || cap <= 0)
+    return fail(WFST_E_ARG, "NULL output or cap <= 0");
+  HIP_TRY(hipSetDevice(d->device));
+  if (channels) {   // a LIST of channels: the two halves above, one behind the other
+    const int rc = wfst_decoder_best_path_enqueue(d, channels, n, use_final_probs, cap);
+    if (rc != WFST_OK) return rc;
+    return wfst_decoder_best_path_fetch(d, ilabel, olabel, graph_cost, acoustic_cost, n_hops);
+  }
+  if (d->bp_out_n > 0) return fail(WFST_E_STATE, "a best-path request is outstanding (wfst_decoder_best_path_fetch takes it)");
+  const int32_t *dev;
+  int32_t cnt;
+  int rc = stage_channels(d, channels, n, &dev, &cnt);
+  if (rc != WFST_OK) return rc;
+  for (int c = 0; c < cnt; ++c) {
+    if (d->h_state[c] == 0) return fail(WFST_E_STATE, "GetBestPath before InitDecoding");
+    if (d->h_state[c] == 2 && !use_final_probs)  // base-inl.h:1100-1102 (LOG_ERR)
+      return fail(WFST_E_STATE, "You cannot call FinalizeDecoding() and then GetBestPath with use_final_probs == false");
+  }
+  const size_t need = (size_t)cnt * (size_t)cap;
+  // one device block {n_hops[cnt] (padded to 4 words) | ilabel | olabel | graph | acoustic} -> one copy into pinned
+  // host memory -> the caller's arrays (five copies into pageable memory cost five staging round trips)
+  const size_t head = ((size_t)cnt + 3) & ~(size_t)3, words = head + 4 * need;
+  rc = bp_buffers(d, words, need);
+  if (rc != WFST_OK) return rc;
+  int32_t *dn = d->bp_all.p, *dil = dn + head, *dol = dil + need;
+  float *dg = reinterpret_cast<float *>(dol + need), *dac = dg + need;
+  launch_best_path(d->D, dev, cnt, use_final_probs ? 1 : 0, cap, dil, dol, dg, dac, dn, d->bp_chain.p, d->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(d->bp_pin, d->bp_all.p, words * 4, hipMemcpyDeviceToHost, d->stream));
+  rc = read_ctl(d);   // synchronises the stream
+  if (rc != WFST_OK) return rc;
   {
     const int32_t *hp = reinterpret_cast<const int32_t *>(d->bp_pin);
     memcpy(n_hops, hp, (size_t)cnt * 4);
@@ -1882,13 +1950,8 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
     memcpy(graph_cost, hp + head + 2 * need, need * 4);
     memcpy(acoustic_cost, hp + head + 3 * need, need * 4);
   }
-  if (channels) {   // a device error of ANOTHER channel's utterance is that channel's, not this request's
-    for (int i = 0; i < cnt; ++i)
-      if (d->p_ctl[channels[i]].error) return fail_ctl_error(channels[i], d->p_ctl[channels[i]].error);
-  } else {
-    rc = check_ctl_errors(d);
-    if (rc != WFST_OK) return rc;
-  }
+  rc = check_ctl_errors(d);
+  if (rc != WFST_OK) return rc;
   for (int i = 0; i < cnt; ++i)
     if (n_hops[i] > cap) return fail(WFST_E_CAPACITY, "best path longer than cap hops; n_hops holds the needed size");
   return WFST_OK;

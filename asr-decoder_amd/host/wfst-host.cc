@@ -304,12 +304,32 @@ void GpuChannelPool::Submit(Request *r) {
   lk.unlock();
   if (r->error) std::rethrow_exception(r->error);
 }
+void GpuChannelPool::Finish(std::vector<Request *> &rs) {
+  for (Request *r : rs) r->decoded = wfst_decoder_num_frames_decoded(_dec, r->channel);
+  {
+    std::lock_guard<std::mutex> lk(_mu);
+    for (Request *r : rs) r->done = true;
+  }
+  _cv_done.notify_all();
+}
 void GpuChannelPool::Run() {
   std::unique_lock<std::mutex> lk(_mu);
   for (;;) {
     const auto t_wait = std::chrono::steady_clock::now();
-    _cv_work.wait(lk, [&] { return _stop || !_queue.empty(); });
-    if (_queue.empty()) return;   // (_stop, nothing left to serve)
+    // wait for requests; a best-path list on the device is looked after meanwhile (its results are taken as soon as they have landed)
+    while (!_stop && _queue.empty()) {
+      if (_bp_flight.empty() && _bp_wait.empty()) { _cv_work.wait(lk); continue; }
+      lk.unlock();
+      const bool progressed = PollBestPaths(false);
+      if (!progressed && _bp_flight.empty()) StartBestPaths();
+      lk.lock();
+      if (!progressed && _queue.empty() && !_stop) _cv_work.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(30));
+    }
+    if (_queue.empty()) {   // (_stop: what is on the device is taken, what waits is served, then out)
+      lk.unlock();
+      while (!_bp_flight.empty() || !_bp_wait.empty()) { PollBestPaths(true); StartBestPaths(); }
+      return;
+    }
     // the other leased channels' requests are on their way more often than not (their threads were released together): a short
     // wait makes one batch of them instead of two
     // ... and while the device is still busy with the batch before, the next advance call would only wait for it: what arrives
@@ -322,6 +342,7 @@ void GpuChannelPool::Run() {
         if (lingered) {
           lk.unlock();
           const int busy = wfst_decoder_busy(_dec);
+          if (!_bp_flight.empty()) PollBestPaths(false);
           lk.lock();
           if (busy != 1) break;
         }
@@ -376,7 +397,15 @@ void GpuChannelPool::Execute(std::vector<Request *> &batch) {
   clocked(kInit, [&] { listed(by_kind[kInit], "InitDecoding", [&](const int32_t *ch, int32_t n) { return wfst_decoder_init(_dec, ch, n); }); });
   clocked(kAdvance, [&] { ExecuteAdvance(by_kind[kAdvance]); });
   clocked(kFinalize, [&] { listed(by_kind[kFinalize], "FinalizeDecoding", [&](const int32_t *ch, int32_t n) { return wfst_decoder_finalize(_dec, ch, n); }); });
-  clocked(kBestPath, [&] { ExecuteBestPath(by_kind[kBestPath]); });
+  // best paths: the requests join the waiting list; what is on the device is looked at, the next list is started -- the requesters
+  // are released when THEIR list's results have landed (PollBestPaths), not at the end of this pass
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (Request *r : by_kind[kBestPath]) _bp_wait.push_back(r);
+    PollBestPaths(false);
+    StartBestPaths();
+    ms[kBestPath] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
   clocked(kCall, [&] {
     for (Request *r : by_kind[kCall]) {
       try {
@@ -419,6 +448,55 @@ void GpuChannelPool::ExecuteAdvance(std::vector<Request *> &requests) {
       if (call(one) != WFST_OK) r->error = std::make_exception_ptr(std::runtime_error(std::string("AdvanceDecoding: ") + wfst_last_error()));
     }
   }
+}
+void GpuChannelPool::StartBestPaths() {
+  if (!_bp_flight.empty() || _bp_wait.empty()) return;
+  _bp_ufp = _bp_wait[0]->use_final_probs ? 1 : 0;
+  std::vector<Request *> rest;
+  for (Request *r : _bp_wait) ((r->use_final_probs ? 1 : 0) == _bp_ufp ? _bp_flight : rest).push_back(r);
+  _bp_wait.swap(rest);
+  std::vector<int32_t> ch;
+  int maxf = 1;
+  for (Request *r : _bp_flight) { ch.push_back(r->channel); maxf = std::max(maxf, wfst_decoder_num_frames_decoded(_dec, r->channel)); }
+  _bp_cap = 4 * maxf + 64;
+  if (wfst_decoder_best_path_enqueue(_dec, ch.data(), (int32_t)ch.size(), _bp_ufp, _bp_cap) != WFST_OK) {
+    // refused (one of the channels: GetBestPath before InitDecoding ...): request by request, each its own verdict
+    std::vector<Request *> rs;
+    rs.swap(_bp_flight);
+    ExecuteBestPath(rs);
+    Finish(rs);
+  }
+}
+// true: a list's results were taken (its requesters are released)
+bool GpuChannelPool::PollBestPaths(bool block) {
+  if (_bp_flight.empty()) return false;
+  if (!block && wfst_decoder_best_path_ready(_dec) != 1) return false;
+  const int cnt = (int)_bp_flight.size(), cap = _bp_cap;
+  std::vector<int32_t> il((size_t)cnt * cap), ol((size_t)cnt * cap), n((size_t)cnt, 0);
+  std::vector<float> g((size_t)cnt * cap), ac((size_t)cnt * cap);
+  const int rc = wfst_decoder_best_path_fetch(_dec, il.data(), ol.data(), g.data(), ac.data(), n.data());
+  std::vector<Request *> rs;
+  rs.swap(_bp_flight);
+  if (rc != WFST_OK) {
+    // a path longer than the capacity, or one channel's device error: the synchronous path sorts it out request by request
+    ExecuteBestPath(rs);
+    Finish(rs);
+    return true;
+  }
+  for (int i = 0; i < cnt; ++i) {
+    Request *r = rs[(size_t)i];
+    r->n_hops = n[(size_t)i];
+    const size_t o = (size_t)i * cap;
+    r->il.assign(il.begin() + (long)o, il.begin() + (long)o + r->n_hops);
+    r->ol.assign(ol.begin() + (long)o, ol.begin() + (long)o + r->n_hops);
+    r->g.assign(g.begin() + (long)o, g.begin() + (long)o + r->n_hops);
+    r->ac.assign(ac.begin() + (long)o, ac.begin() + (long)o + r->n_hops);
+    // (the final result says whether the per-frame token limit bound on the way; partial results do not stop for it)
+    int32_t dg = 0;
+    if (_bp_ufp && wfst_decoder_get_degraded_frames(_dec, r->channel, &dg) == WFST_OK) r->degraded = dg;
+  }
+  Finish(rs);
+  return true;
 }
 void GpuChannelPool::ExecuteBestPath(std::vector<Request *> &all) {
   for (int ufp = 0; ufp < 2; ++ufp) {

@@ -281,7 +281,14 @@ class GpuChannelPool {
   void Run();
   void Execute(std::vector<Request *> &batch);
   void ExecuteAdvance(std::vector<Request *> &rs);
-  void ExecuteBestPath(std::vector<Request *> &rs);
+  void ExecuteBestPath(std::vector<Request *> &rs);   // synchronous (the fall-back when a list is refused: request by request)
+  // best paths WITHOUT the batcher standing still: the waiting requests of one kind (with / without final-probs) go to the device as
+  // one list (wfst_decoder_best_path_enqueue), the batcher goes on feeding the device, and takes the results when they have landed
+  void StartBestPaths();
+  bool PollBestPaths(bool block);
+  void Finish(std::vector<Request *> &rs);
+  std::vector<Request *> _bp_wait, _bp_flight;   // (the batcher thread's own)
+  int _bp_cap = 0, _bp_ufp = 1;
   wfst_decoder *_dec;
   Fst *_graph;
   int _n, _linger_us;

@@ -313,6 +313,17 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t
                                int32_t *olabel, float *graph_cost, float *acoustic_cost,
                                int32_t *n_hops);
 
+/* GetBestPath of a channel LIST in two halves, for a host that batches many decoder objects over one decoder (the C++ mirror's
+ * GpuChannelPool): _enqueue puts the traceback and the copies on the decoder's results stream behind the listed channels' own
+ * enqueued work and returns at once; _ready says (never blocks) whether the results have landed; _fetch waits if need be and
+ * writes them out -- same outputs, for the enqueued list and capacity, as wfst_decoder_get_best_path, which for a list is the two
+ * halves one behind the other.  One request may be outstanding per decoder (a second _enqueue: WFST_E_STATE); the listed channels
+ * must not be advanced or initialised in between.  A device error of another channel's utterance does not fail the request. */
+int wfst_decoder_best_path_enqueue(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs, int32_t cap);
+int wfst_decoder_best_path_ready(wfst_decoder *d);
+int wfst_decoder_best_path_fetch(wfst_decoder *d, int32_t *ilabel, int32_t *olabel, float *graph_cost, float *acoustic_cost,
+                                 int32_t *n_hops);
+
 /* LatticeToVector (newfst/lattice-functions.cc:179-217) on one hop list: nonzero olabels ->
  * words, nonzero ilabels -> transition-ids, lm = sum graph, tot = sum (graph + acoustic), float
  * accumulation in forward order.  Host-only helper; returns the counts through n_words/n_tids. */

@@ -22,6 +22,10 @@ struct wfst_decoder {
   std::atomic<int> inside{0};
   std::atomic<long long> busy_until_ns{0};
   long long calls[4] = {0, 0, 0, 0};
+  // the two halves of a list's best path: "on the device" for 120 us
+  std::vector<int32_t> bp_list;
+  int bp_ufp = 1, bp_cap = 0;
+  long long bp_ready_ns = 0;
 };
 
 namespace {
@@ -110,6 +114,29 @@ int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *ch, int32_t n, in
     }
   }
   return rc;
+}
+int wfst_decoder_best_path_enqueue(wfst_decoder *d, const int32_t *ch, int32_t n, int32_t use_final, int32_t cap) {
+  Guard gd(d);
+  if (!d->bp_list.empty()) return fail(WFST_E_STATE, "a best-path request is outstanding");
+  for (int i = 0; i < n; ++i) {
+    if (d->state[ch[i]] == 0) return fail(WFST_E_STATE, "GetBestPath before InitDecoding");
+    if (d->state[ch[i]] == 2 && !use_final) return fail(WFST_E_STATE, "finalized");
+  }
+  d->bp_list.assign(ch, ch + n);
+  d->bp_ufp = use_final; d->bp_cap = cap;
+  d->bp_ready_ns = now_ns() + 120000;
+  return WFST_OK;
+}
+int wfst_decoder_best_path_ready(wfst_decoder *d) {
+  Guard gd(d);
+  if (d->bp_list.empty()) return fail(WFST_E_STATE, "nothing outstanding");
+  return now_ns() >= d->bp_ready_ns ? 1 : 0;
+}
+int wfst_decoder_best_path_fetch(wfst_decoder *d, int32_t *il, int32_t *ol, float *g, float *ac, int32_t *n_hops) {
+  while (now_ns() < d->bp_ready_ns) std::this_thread::sleep_for(std::chrono::microseconds(10));
+  std::vector<int32_t> list;
+  list.swap(d->bp_list);
+  return wfst_decoder_get_best_path(d, list.data(), (int32_t)list.size(), d->bp_ufp, d->bp_cap, il, ol, g, ac, n_hops);
 }
 void wfst_graph_free(wfst_graph *) {}
 void wfst_lm_free(wfst_lm *) {}
