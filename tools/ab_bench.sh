@@ -16,8 +16,9 @@ import json, sys
 tag, rep = sys.argv[1], sys.argv[2]
 try:
     d = json.loads(open("gpurun_out/ab/%s_%s.json" % (tag, rep)).read().strip().splitlines()[-1])
-    k = d["roofline"]["kernel_ms_per_step"]
-    print("AB %-24s rep %s  %.3f ms/step  expand %.2f insert %.2f closure %.2f" % (tag, rep, d["ms_per_step"], k["expand"], k["insert"], k["closure"]), flush=True)
+    k = d["roofline"]
+    print("AB %-24s rep %s  %.3f ms/step  expand %.2f insert %.2f (busy %.2f / %.2f)" % (tag, rep, d["ms_per_step"], k["expand_ms_per_step"], k["insert_ms_per_step"],
+                                                                                       k.get("expand_busy_ms_per_step", 0.0), k.get("insert_busy_ms_per_step", 0.0)), flush=True)
 except Exception as e:
     print("AB %-24s rep %s  FAILED %r" % (tag, rep, e), flush=True)
 PY
