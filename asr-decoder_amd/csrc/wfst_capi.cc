@@ -186,11 +186,16 @@ struct wfst_decoder {
   static constexpr int kMarkRing = 16;
   hipEvent_t mark_ev[kMarkRing] = {};
   int mark_next = 0;
+  long long mark_count = 0;            // marks recorded so far
+  bool mark_frames[kMarkRing] = {};    // the mark stands behind an advance call (frames to decode), not behind an init / finalize
   std::vector<int> chan_mark;          // [channel] ring slot of the event behind the channel's last enqueued work, -1: none
   hipStream_t res_stream = nullptr;
   std::vector<int32_t> bp_out;         // wfst_decoder_best_path_enqueue: the outstanding request's channels ...
   int32_t bp_out_n = 0, bp_out_cap = 0;   // ... their number (0: nothing outstanding) and the hop capacity
   ChanCtl *bp_ctl_pin = nullptr;       // ... and its own page-locked copy of the control blocks (p_ctl is the synchronous getters')
+  int32_t *bp_deg_pin = nullptr;       // ... and of the degraded-frame counts, which a fetch leaves in deg_cache for its channels
+  std::vector<long long> chan_serial, bp_out_serial;   // [channel] calls enqueued for it so far; [list position] ... when the list was enqueued
+  std::vector<int32_t> deg_cache;      // [channel] wfst_decoder_get_degraded_frames without a device round trip; -1: not held (any later init / advance / finalize of the channel)
   int32_t *res_chan_pin = nullptr;
   DevBuf<int32_t> res_chan_list;
   hipEvent_t copy_ev = nullptr;        // advance_host: the rows of page-locked buffers are on their way (the decode stream waits for it, the host does not)
@@ -279,8 +284,11 @@ struct wfst_decoder {
   size_t bp_pin_bytes = 0;
   size_t lat_pin_bytes = 0;
   std::vector<int32_t> lat_cache_nd;
-  std::vector<float *> hist_dev;
-  std::vector<size_t> hist_rows_cap;
+  float *hist_slab = nullptr;          // advance_host's device copy of the rows handed over: ONE allocation, hist_cap rows per channel
+  int32_t hist_slab_stride = 0;        // ... of this many floats
+  size_t hist_cap = 0;                 // (uniform pitch: equally spaced page-locked rows of many channels go up as one 2-D copy)
+  std::vector<float *> hist_dev;       // [channel] = hist_slab + channel * hist_cap * hist_stride
+  std::vector<size_t> hist_rows_cap;   // (= hist_cap)
   std::vector<int32_t> hist_rows;
   int32_t hist_stride = 0;
   int tiles_per_channel = 16;
@@ -317,8 +325,7 @@ struct wfst_decoder {
     if (pf_ev_done) (void)hipEventDestroy(pf_ev_done);
     if (lat_pin) (void)hipHostFree(lat_pin);
     if (bp_pin) (void)hipHostFree(bp_pin);
-    for (float *p : hist_dev)
-      if (p) (void)hipFree(p);
+    if (hist_slab) (void)hipFree(hist_slab);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipStream_t st : gstreams) if (st) (void)hipStreamDestroy(st);
@@ -331,6 +338,7 @@ struct wfst_decoder {
     if (res_stream) (void)hipStreamDestroy(res_stream);
     if (res_chan_pin) (void)hipHostFree(res_chan_pin);
     if (bp_ctl_pin) (void)hipHostFree(bp_ctl_pin);
+    if (bp_deg_pin) (void)hipHostFree(bp_deg_pin);
     res_chan_list.release();
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
@@ -1337,9 +1345,17 @@ void wfst_decoder_free(wfst_decoder *d) {
 }
 
 // An event behind what has just been enqueued for the listed channels (nullptr: all) on the decoder's stream.
-static int mark_channels(wfst_decoder *d, const int32_t *channels, int32_t cnt) {
+static int mark_channels(wfst_decoder *d, const int32_t *channels, int32_t cnt, bool frames = false) {
   const int k = d->mark_next;
+  d->mark_frames[k] = frames;
+  if (d->chan_serial.empty()) d->chan_serial.assign((size_t)d->n_channels, 0);
+  for (int i = 0; i < cnt; ++i) {
+    const size_t c = (size_t)(channels ? channels[i] : i);
+    ++d->chan_serial[c];
+    if (!d->deg_cache.empty()) d->deg_cache[c] = -1;
+  }
   d->mark_next = (k + 1) % wfst_decoder::kMarkRing;
+  ++d->mark_count;
   HIP_TRY(hipEventRecord(d->mark_ev[k], d->stream));
   for (int i = 0; i < cnt; ++i) d->chan_mark[(size_t)(channels ? channels[i] : i)] = k;
   return WFST_OK;
@@ -1613,7 +1629,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
       if (gsteps[g] != 0) HIP_TRY(hipStreamWaitEvent(d->stream, d->gevents[1 + g], 0));
   }
   HIP_TRY(hipGetLastError());
-  { const int rcm = mark_channels(d, channels, cnt); if (rcm != WFST_OK) return rcm; }
+  { const int rcm = mark_channels(d, channels, cnt, true); if (rcm != WFST_OK) return rcm; }
   for (int g = 0; g < G; ++g) d->gpar[g] = gpar0[g] ^ (gsteps[g] & 1);
   for (int c = 0; c < d->n_channels; ++c) d->h_decoded[c] = std::max(d->h_decoded[c], d->h_target[c]);
   return WFST_OK;
@@ -1640,35 +1656,52 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
   }
   d->hist_stride = stride;
   std::vector<const float *> dev_ptrs((size_t)cnt);
+  size_t need_rows = 0;
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     if (c < 0 || c >= d->n_channels) return fail(WFST_E_ARG, "channel index out of range");
     const int32_t have = d->hist_rows[c], want = n_frames_ready[i];
     if (want < have) return fail(WFST_E_ARG, "NumFramesReady decreased");
-    if ((size_t)want > d->hist_rows_cap[c]) {
-      // (a decoder created with a small wfst_limits.max_frames -- a caller that sizes its utterances -- gets the whole history at
-      // once: regrowing costs an allocation, a device copy and a free that waits for the device, per channel)
-      size_t ncap = std::max<size_t>((size_t)want, std::max<size_t>(d->hist_rows_cap[c] * 2, 256));
-      if (d->D.max_frames <= 1024) ncap = std::max<size_t>(ncap, (size_t)d->D.max_frames);
-      float *np = nullptr;
-      if (d->copy_stream) HIP_TRY(hipStreamSynchronize(d->copy_stream));   // (rows of page-locked buffers may still be on their way into the old history)
-      HIP_TRY(hipMalloc((void **)&np, ncap * (size_t)stride * 4));
-      if (have > 0) {
-        // (on the decoder's own stream, not the legacy one: another decoder of the process may be capturing its frame loop in
-        // another thread -- the service's one-decoder-per-thread shape -- and the legacy stream refuses to work beside a capture)
-        HIP_TRY(hipMemcpyAsync(np, d->hist_dev[c], (size_t)have * stride * 4, hipMemcpyDeviceToDevice, d->stream));
-        HIP_TRY(hipStreamSynchronize(d->stream));
-      }
-      if (d->hist_dev[c]) {
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        HIP_TRY(hipFree(d->hist_dev[c]));
-      }
-      d->hist_dev[c] = np;
+    if (want > have && !loglikes_host[i]) return fail(WFST_E_ARG, "NULL log-likelihood matrix");
+    need_rows = std::max(need_rows, (size_t)want);
+  }
+  if (need_rows > d->hist_cap || (d->hist_slab && d->hist_slab_stride != stride)) {
+    // The histories of all channels are one allocation of uniform pitch.  (A decoder created with a small wfst_limits.max_frames --
+    // a caller that sizes its utterances -- gets the whole history at once: regrowing costs an allocation, a device copy and a free
+    // that waits for the device.)
+    size_t ncap = std::max<size_t>(need_rows, std::max<size_t>(d->hist_cap * 2, 256));
+    if (d->D.max_frames <= 1024) ncap = std::max<size_t>(ncap, (size_t)d->D.max_frames);
+    ncap = std::min<size_t>(ncap, std::max<size_t>(need_rows, (size_t)d->D.max_frames));   // (no utterance is longer than max_frames)
+    float *np = nullptr;
+    if (d->copy_stream) HIP_TRY(hipStreamSynchronize(d->copy_stream));   // (rows of page-locked buffers may still be on their way into the old history)
+    HIP_TRY(hipMalloc((void **)&np, (size_t)d->n_channels * ncap * (size_t)stride * 4));
+    size_t keep = 0;
+    for (int c = 0; c < d->n_channels; ++c) keep = std::max(keep, (size_t)d->hist_rows[c]);
+    if (d->hist_slab && keep > 0 && d->hist_slab_stride == stride) {
+      // (on the decoder's own stream, not the legacy one: another decoder of the process may be capturing its frame loop in
+      // another thread -- the service's one-decoder-per-thread shape -- and the legacy stream refuses to work beside a capture)
+      HIP_TRY(hipMemcpy2DAsync(np, ncap * (size_t)stride * 4, d->hist_slab, d->hist_cap * (size_t)stride * 4, keep * (size_t)stride * 4,
+                               (size_t)d->n_channels, hipMemcpyDeviceToDevice, d->stream));
+    }
+    if (d->hist_slab) {
+      HIP_TRY(hipStreamSynchronize(d->stream));
+      // channels that read their rows from the old allocation follow it: the listed ones through advance_device (which sees their
+      // pointers move and uploads ALL row pointers), the others here
+      std::vector<char> listed((size_t)d->n_channels, 0);
+      for (int i = 0; i < cnt; ++i) listed[(size_t)(channels ? channels[i] : i)] = 1;
+      for (int c = 0; c < d->n_channels; ++c)
+        if (!listed[(size_t)c] && d->h_ll_base[c] == d->hist_dev[c] && d->hist_dev[c]) d->h_ll_base[c] = np + (size_t)c * ncap * (size_t)stride;
+      HIP_TRY(hipFree(d->hist_slab));
+    }
+    d->hist_slab = np;
+    d->hist_cap = ncap;
+    d->hist_slab_stride = stride;
+    for (int c = 0; c < d->n_channels; ++c) {
+      d->hist_dev[c] = np + (size_t)c * ncap * (size_t)stride;
       d->hist_rows_cap[c] = ncap;
     }
-    if (want > have && !loglikes_host[i]) return fail(WFST_E_ARG, "NULL log-likelihood matrix");
-    dev_ptrs[i] = d->hist_dev[c];
   }
+  for (int i = 0; i < cnt; ++i) dev_ptrs[i] = d->hist_dev[channels ? channels[i] : i];
   // Upload and decode in slices of kSlice frames: the host copies slice k+1 (pageable memory: the
   // copy call returns when the caller's buffer is consumed) while the GPU decodes slice k, so the
   // PCIe time of a long hand-over hides behind the search instead of preceding it.
@@ -1703,16 +1736,38 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
   // other -- the copy engine is a slice ahead of the search, the host waits for neither
   for (int done = 0; done < std::max(longest, 1); done += sliced ? kSlice : std::max(longest, 1)) {
     const int upto = sliced ? done + kSlice : longest;
-    for (int i = 0; i < cnt; ++i) {
+    // Page-locked rows of CONSECUTIVE channels that lie equally spaced in host memory (one matrix of utterances; the channel pool's
+    // row slab) and cover the same frames go up as ONE 2-D copy -- a copy per channel costs the engine ~7 us each before it moves
+    // a byte: 128 chunks of 300 KB take 2.0 ms one by one, 0.68 ms as one 2-D copy (tools/ubench_h2d.hip).
+    for (int i = 0; i < cnt;) {
       const int c = channels ? channels[i] : i;
       const int32_t have = d->hist_rows[c];
       const int32_t want = std::min<int32_t>(n_frames_ready[i], have + std::max(0, upto - done));
-      if (want > have) {
+      int run = 1;
+      if (want > have && all_pinned) {
+        ptrdiff_t pitch = 0;
+        for (int j = i + 1; j < cnt; ++j) {
+          const int cj = channels ? channels[j] : j;
+          if (cj != c + (j - i) || d->hist_rows[cj] != have) break;
+          if (std::min<int32_t>(n_frames_ready[j], have + std::max(0, upto - done)) != want || !loglikes_host[j]) break;
+          const ptrdiff_t step = loglikes_host[j] - loglikes_host[j - 1];
+          if (j == i + 1) pitch = step;
+          if (step != pitch || pitch < (ptrdiff_t)((size_t)want * stride)) break;   // (equally spaced, one channel's rows not inside the next's)
+          run = j - i + 1;
+        }
+        if (run > 1) {
+          HIP_TRY(hipMemcpy2DAsync(d->hist_dev[c] + (size_t)have * stride, d->hist_cap * (size_t)stride * 4, loglikes_host[i] + (size_t)have * stride,
+                                   (size_t)pitch * 4, (size_t)(want - have) * stride * 4, (size_t)run, hipMemcpyHostToDevice, d->copy_stream));
+          for (int j = i; j < i + run; ++j) d->hist_rows[channels ? channels[j] : j] = want;
+        }
+      }
+      if (want > have && run == 1) {
         HIP_TRY(hipMemcpyAsync(d->hist_dev[c] + (size_t)have * stride, loglikes_host[i] + (size_t)have * stride,
                                (size_t)(want - have) * stride * 4, hipMemcpyHostToDevice, d->copy_stream));
         d->hist_rows[c] = want;
       }
-      ready[i] = d->hist_rows[c];
+      for (int j = i; j < i + run; ++j) ready[j] = d->hist_rows[channels ? channels[j] : j];
+      i += run;
     }
     if (all_pinned) {
       HIP_TRY(hipEventRecord(d->copy_ev, d->copy_stream));
@@ -1809,6 +1864,24 @@ int wfst_decoder_busy(wfst_decoder *d) {
   return fail(WFST_E_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
 }
 
+int wfst_decoder_calls_in_flight(wfst_decoder *d) {
+  if (!d) return fail(WFST_E_ARG, "NULL decoder");
+  HIP_TRY(hipSetDevice(d->device));
+  // the marks behind the enqueued calls, newest first: the stream runs them in order, so the first one that has completed ends
+  // the count; only calls that brought frames count (an init or a finalize between two of them is microseconds of work)
+  const int have = (int)std::min<long long>(d->mark_count, wfst_decoder::kMarkRing);
+  int n = 0;
+  for (int i = 0; i < have; ++i) {
+    const int k = (d->mark_next - 1 - i + 2 * wfst_decoder::kMarkRing) % wfst_decoder::kMarkRing;
+    const hipError_t e = hipEventQuery(d->mark_ev[k]);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) return fail(WFST_E_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(e));
+    (void)hipGetLastError();
+    if (d->mark_frames[k]) ++n;
+  }
+  return n;
+}
+
 int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t channel) {
   if (!d || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad decoder/channel");
   return d->h_decoded[channel];
@@ -1820,7 +1893,14 @@ int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t channel) {
 // channels' own work, the batcher goes on feeding the device, and the results are taken when they have landed.  One request may be
 // outstanding per decoder; the state it holds (the list, the result block in page-locked memory, a copy of the control blocks of
 // its own) is touched by nothing else meanwhile.
-static int bp_buffers(wfst_decoder *d, size_t words, size_t need) {
+static int bp_buffers(wfst_decoder *d, size_t words, size_t need, int32_t cap = 0) {
+  if (cap > 0) {
+    // (list requests: room for EVERY channel at this capacity, once -- lists of growing length would otherwise regrow the buffers
+    // call after call, and a regrowth waits for the device)
+    const size_t all_need = (size_t)d->n_channels * (size_t)cap, all_head = ((size_t)d->n_channels + 3) & ~(size_t)3;
+    need = std::max(need, all_need);
+    words = std::max(words, all_head + 4 * all_need);
+  }
   if (d->bp_all.n < words || d->bp_chain.n < need) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     if (d->res_stream) HIP_TRY(hipStreamSynchronize(d->res_stream));
@@ -1856,7 +1936,7 @@ int wfst_decoder_best_path_enqueue(wfst_decoder *d, const int32_t *channels, int
   int rc = results_stream_behind(d, channels, n, &st);   // behind these channels' own work only (see mark_ev)
   if (rc != WFST_OK) return rc;
   const size_t need = (size_t)n * (size_t)cap, head = ((size_t)n + 3) & ~(size_t)3, words = head + 4 * need;
-  rc = bp_buffers(d, words, need);
+  rc = bp_buffers(d, words, need, cap);
   if (rc != WFST_OK) return rc;
   if (!d->bp_ctl_pin) HIP_TRY(hipHostMalloc((void **)&d->bp_ctl_pin, d->ctl.bytes(), hipHostMallocDefault));
   memcpy(d->res_chan_pin, channels, (size_t)n * 4);   // (the results stream is idle here: nothing is outstanding)
@@ -1868,7 +1948,12 @@ int wfst_decoder_best_path_enqueue(wfst_decoder *d, const int32_t *channels, int
   HIP_TRY(hipMemcpyAsync(d->bp_pin, d->bp_all.p, words * 4, hipMemcpyDeviceToHost, st));
   // (the listed channels' control blocks are final behind their marks; the others' are not looked at)
   HIP_TRY(hipMemcpyAsync(d->bp_ctl_pin, d->ctl.p, d->ctl.bytes(), hipMemcpyDeviceToHost, st));
+  if (!d->bp_deg_pin) HIP_TRY(hipHostMalloc((void **)&d->bp_deg_pin, d->degraded.bytes(), hipHostMallocDefault));
+  HIP_TRY(hipMemcpyAsync(d->bp_deg_pin, d->degraded.p, d->degraded.bytes(), hipMemcpyDeviceToHost, st));
   d->bp_out.assign(channels, channels + n);
+  if (d->chan_serial.empty()) d->chan_serial.assign((size_t)d->n_channels, 0);
+  d->bp_out_serial.resize((size_t)n);
+  for (int i = 0; i < n; ++i) d->bp_out_serial[(size_t)i] = d->chan_serial[(size_t)channels[i]];
   d->bp_out_n = n;
   d->bp_out_cap = cap;
   return WFST_OK;
@@ -1902,6 +1987,12 @@ int wfst_decoder_best_path_fetch(wfst_decoder *d, int32_t *ilabel, int32_t *olab
   for (int i = 0; i < cnt; ++i) {
     const int c = d->bp_out[(size_t)i];
     if (d->bp_ctl_pin[c].error) return fail_ctl_error(c, d->bp_ctl_pin[c].error);
+  }
+  // (the listed channels' counts of frames on which the token limit bound: read behind their own work, like the paths)
+  if (d->deg_cache.empty()) d->deg_cache.assign((size_t)d->n_channels, -1);
+  for (int i = 0; i < cnt; ++i) {
+    const size_t c = (size_t)d->bp_out[(size_t)i];
+    if (d->chan_serial[c] == d->bp_out_serial[(size_t)i]) d->deg_cache[c] = d->bp_deg_pin[c];   // (no call for the channel since the list went up)
   }
   for (int i = 0; i < cnt; ++i)
     if (n_hops[i] > cap) return fail(WFST_E_CAPACITY, "best path longer than cap hops; n_hops holds the needed size");
@@ -3270,6 +3361,7 @@ int wfst_decoder_get_prune_raw_abandoned(wfst_decoder *d, int32_t channel, int32
 int wfst_decoder_get_degraded_frames(wfst_decoder *d, int32_t channel, int32_t *n_frames) {
   if (!d || !n_frames || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(d->device));
+  if (!d->deg_cache.empty() && d->deg_cache[(size_t)channel] >= 0) { *n_frames = d->deg_cache[(size_t)channel]; return WFST_OK; }   // (a list fetch has read it since the channel's last call)
   hipStream_t st = d->stream;
   { const int32_t c = channel; const int rc = results_stream_behind(d, &c, 1, &st); if (rc != WFST_OK) return rc; }   // (behind the channel's own work, not the others')
   HIP_TRY(hipMemcpyAsync(n_frames, d->degraded.p + channel, sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -40,6 +40,9 @@
 //                  batcher waits for the other leased channels' requests (50)
 //   --repeat=K     --threads only: the utterance list is decoded K times over (a steady-state measurement: the first utterances of a
 //                  run pay the decoder's graph captures and buffer allocations); the output is the first pass's
+//   --warm=W       with --repeat: the first W passes over the list run BEFORE the clock (bench.py's warm-up steps, for the service's
+//                  shape): every thread waits until the last warm-up utterance is done, the clock starts there, and the frames
+//                  reported ("LOG Timed passes: ...") are those of the K - W passes behind it
 //   --share=C      the ONE-LINE drop-in at service scale: GpuLatticeDecoder::ShareDevice(C) once, then every thread constructs its decoder
 //                  the reference's way -- (graph, config) -- and the objects lease channels of shared C-channel device decoders
 //   --pull         the decodable is a plain DecodableInterface: every score goes through LogLikelihood(frame, index) (without it
@@ -136,7 +139,7 @@ int main(int argc, char **argv) {
     int nbest = 0, inflight = 1, chunk = 0, n_threads = 0, pool_channels = 0, linger_us = 50;
     bool pull = false;
     long long max_tokens_per_frame = 0, arena_tokens = 0;
-    int max_frames = 0, repeat = 1, share_channels = 0;
+    int max_frames = 0, repeat = 1, share_channels = 0, warm = 0;
     std::vector<int> devices(1, 0);
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -156,6 +159,7 @@ int main(int argc, char **argv) {
       else if (a.compare(0, 12, "--linger-us=") == 0) linger_us = std::max(0, atoi(a.c_str() + 12));
       else if (a == "--pull") pull = true;
       else if (a.compare(0, 9, "--repeat=") == 0) repeat = std::max(1, atoi(a.c_str() + 9));
+      else if (a.compare(0, 7, "--warm=") == 0) warm = std::max(0, atoi(a.c_str() + 7));
       else if (a.compare(0, 8, "--share=") == 0) share_channels = std::max(0, atoi(a.c_str() + 8));
       else if (a.compare(0, 13, "--max-tokens=") == 0) max_tokens_per_frame = atoll(a.c_str() + 13);
       else if (a.compare(0, 15, "--arena-tokens=") == 0) arena_tokens = atoll(a.c_str() + 15);
@@ -284,7 +288,7 @@ int main(int argc, char **argv) {
     std::vector<Utt> utts;
     for (Utt u; ReadUtt(in, &u);) utts.push_back(u);
     int num_success = 0, num_fail = 0;
-    long long frame_count = 0, repeat_frames = 0;
+    long long frame_count = 0, repeat_frames = 0, timed_frames = 0;
     double tot_like = 0;
     auto t0 = std::chrono::steady_clock::now();
     auto emit = [&](const Utt &u, Lattice &best, bool ok) {
@@ -321,6 +325,11 @@ int main(int argc, char **argv) {
       std::atomic<size_t> next(0);
       std::atomic<int> ready_threads(0);
       std::atomic<long long> extra_frames(0);   // frames of the repeat passes (--repeat)
+      if (warm >= repeat) { std::cerr << "--warm must leave a timed pass (--repeat)\n"; return 1; }
+      const size_t warm_n = (size_t)warm * utts.size();   // utterances decoded before the clock
+      std::atomic<size_t> warm_done(0);
+      std::atomic<int> clock_started(warm_n == 0 ? 1 : 0);
+      std::atomic<long long> clocked_frames(0);
       auto worker = [&](int k) {
         try {
           std::unique_ptr<GpuLatticeDecoder> dp(pool ? new GpuLatticeDecoder(pool.get())
@@ -338,6 +347,12 @@ int main(int argc, char **argv) {
             const size_t ui = uj % utts.size();
             const bool first_pass = uj < utts.size();
             const Utt &u = utts[ui];
+            // (--warm: the timed passes start together, behind the last warm-up utterance)
+            if (uj >= warm_n) while (!clock_started.load()) std::this_thread::yield();
+            struct Count {   // whatever way the utterance ends
+              std::atomic<size_t> &done; std::atomic<int> &started; std::chrono::steady_clock::time_point &t0; bool is_warm; size_t n;
+              ~Count() { if (is_warm && done.fetch_add(1) + 1 == n) { t0 = std::chrono::steady_clock::now(); started.store(1); } }
+            } count{warm_done, clock_started, t0, uj < warm_n, warm_n};
             HostMatrixDecodable md(u);
             PullDecodable pd(u, tid2pdf.empty() ? nullptr : &tid2pdf);
             AmInterface *am = pull ? (AmInterface *)&pd : (AmInterface *)&md;
@@ -359,6 +374,7 @@ int main(int argc, char **argv) {
             Res scratch;
             Res &r = first_pass ? res[ui] : scratch;
             r.ok = decode.GetBestPath(&r.best);
+            if (uj >= warm_n && warm_n > 0) clocked_frames.fetch_add(r.ok ? u.frames : 0);
             if (!first_pass) { extra_frames.fetch_add(r.ok ? u.frames : 0); continue; }
             if (want_lattice && (!lattice_file.empty() || !lattice_text.empty()))
               r.lat_ok = determinize ? dp->GetLattice(&r.lat) : decode.GetRawLattice(&r.lat);
@@ -391,6 +407,7 @@ int main(int argc, char **argv) {
         if (nbest > 0) emit_nbest(utts[i], res[i].nbest);
       }
       repeat_frames = extra_frames.load();
+      timed_frames = clocked_frames.load();
       if (pool) {
         const GpuChannelPool::Stats st = pool->GetStats();
         std::cerr << "LOG pool: " << pool_channels << " channels, " << n_threads << " threads, " << st.batches << " batcher passes, " << st.requests
@@ -534,9 +551,14 @@ int main(int argc, char **argv) {
       }
     }
     double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::cerr << "LOG Time taken " << elapsed << "s: real-time factor assuming 100 frames/sec is "
-              << (frame_count ? elapsed * 100.0 / (frame_count + repeat_frames) : 0.0) << "\n";
-    if (repeat_frames) std::cerr << "LOG Frames decoded in all passes: " << (frame_count + repeat_frames) << "\n";
+    if (timed_frames) {   // (--warm: the clock started behind the warm-up passes)
+      std::cerr << "LOG Time taken " << elapsed << "s: real-time factor assuming 100 frames/sec is " << elapsed * 100.0 / timed_frames << "\n";
+      std::cerr << "LOG Timed passes: " << timed_frames << " frames in " << elapsed << " s behind " << warm << " warm-up passes over the list\n";
+    } else {
+      std::cerr << "LOG Time taken " << elapsed << "s: real-time factor assuming 100 frames/sec is "
+                << (frame_count ? elapsed * 100.0 / (frame_count + repeat_frames) : 0.0) << "\n";
+      if (repeat_frames) std::cerr << "LOG Frames decoded in all passes: " << (frame_count + repeat_frames) << "\n";
+    }
     std::cerr << "LOG Done " << num_success << " utterances, failed for " << num_fail << "\n";
     std::cerr << "LOG Overall log-likelihood per frame is " << (frame_count ? tot_like / frame_count : 0.0) << " over "
               << frame_count << " frames.\n";

@@ -257,6 +257,8 @@ GpuChannelPool::GpuChannelPool(Fst *graph, const LatticeFasterDecoderConfig &con
 void GpuChannelPool::Start(int linger_us) {
   _linger_us = std::max(0, linger_us);
   _leased.assign((size_t)_n, 0);
+  if (const char *tf = getenv("WFST_POOL_TRACE")) _trace_file = tf;
+  _t_origin = _t_first = std::chrono::steady_clock::now();
   _thread = std::thread([this] { Run(); });
 }
 GpuChannelPool::~GpuChannelPool() {
@@ -266,7 +268,29 @@ GpuChannelPool::~GpuChannelPool() {
   }
   _cv_work.notify_all();
   if (_thread.joinable()) _thread.join();
-  wfst_decoder_free(_dec);
+  wfst_decoder_free(_dec);   // (waits for the device: no row of the slab is on its way any more)
+  if (_slab) wfst_host_free(_slab);
+  if (!_trace_file.empty()) {
+    if (FILE *f = fopen(_trace_file.c_str(), "w")) {
+      fprintf(f, "# ms since the pool started: first request, batch closed, pass done | requests init advance finalize best-path calls | ms of each | device busy at close\n");
+      for (const TracePass &t : _trace)
+        fprintf(f, "%.3f %.3f %.3f | %d %d %d %d %d | %.3f %.3f %.3f %.3f %.3f | %d\n", t.t_first, t.t_closed, t.t_end, t.n[0], t.n[1], t.n[2], t.n[3], t.n[4],
+                t.ms[0], t.ms[1], t.ms[2], t.ms[3], t.ms[4], t.busy);
+      fclose(f);
+    }
+  }
+}
+float *GpuChannelPool::RowSlot(int channel, size_t floats, size_t *slot_floats) {
+  std::lock_guard<std::mutex> lk(_slab_mu);
+  if (!_slab) {
+    if (_slab_pitch != 0) return nullptr;   // (tried before: no page-locked memory of that size)
+    _slab_pitch = (std::max<size_t>(floats, (size_t)1 << 16) + 1023) & ~(size_t)1023;
+    _slab = (float *)wfst_host_alloc((size_t)_n * _slab_pitch * sizeof(float));
+    if (!_slab) return nullptr;
+  }
+  if (floats > _slab_pitch || channel < 0 || channel >= _n) return nullptr;
+  *slot_floats = _slab_pitch;
+  return _slab + (size_t)channel * _slab_pitch;
 }
 GpuChannelPool::Stats GpuChannelPool::GetStats() {
   std::lock_guard<std::mutex> lk(_mu);
@@ -294,23 +318,31 @@ void GpuChannelPool::Release(int c) {
   _cv_free.notify_one();
 }
 void GpuChannelPool::Submit(Request *r) {
-  std::unique_lock<std::mutex> lk(_mu);
-  if (_stop) throw std::runtime_error("GpuChannelPool is shutting down");
-  r->done = false;
-  r->error = nullptr;
-  _queue.push_back(r);
-  _cv_work.notify_one();
-  _cv_done.wait(lk, [&] { return r->done; });
-  lk.unlock();
+  {
+    std::lock_guard<std::mutex> lk(_mu);
+    if (_stop) throw std::runtime_error("GpuChannelPool is shutting down");
+    r->done = false;
+    r->error = nullptr;
+    if (_queue.empty() && !_trace_file.empty()) _t_first = std::chrono::steady_clock::now();
+    _queue.push_back(r);
+    // (the batcher sleeps without a time-out only on an empty queue; while a batch forms it looks again every few tens of
+    // microseconds -- it is woken for the first request and for the one that completes the batch, not sixty-four times)
+    if (_queue.size() == 1 || (int)_queue.size() + _n_bp_outstanding >= _n_leased) _cv_work.notify_one();
+  }
+  {
+    std::unique_lock<std::mutex> lk(r->m);
+    r->cv.wait(lk, [&] { return r->done; });
+  }
   if (r->error) std::rethrow_exception(r->error);
+}
+void GpuChannelPool::Done(Request *r) {
+  std::lock_guard<std::mutex> lk(r->m);
+  r->done = true;
+  r->cv.notify_one();   // (under the request's mutex: its thread cannot leave Submit -- and destroy the request -- before this returns)
 }
 void GpuChannelPool::Finish(std::vector<Request *> &rs) {
   for (Request *r : rs) r->decoded = wfst_decoder_num_frames_decoded(_dec, r->channel);
-  {
-    std::lock_guard<std::mutex> lk(_mu);
-    for (Request *r : rs) r->done = true;
-  }
-  _cv_done.notify_all();
+  for (Request *r : rs) Done(r);
 }
 void GpuChannelPool::Run() {
   std::unique_lock<std::mutex> lk(_mu);
@@ -331,20 +363,27 @@ void GpuChannelPool::Run() {
       return;
     }
     // the other leased channels' requests are on their way more often than not (their threads were released together): a short
-    // wait makes one batch of them instead of two
-    // ... and while the device is still busy with the batch before, the next advance call would only wait for it: what arrives
-    // meanwhile joins this batch (two cohorts of threads that alternate merge into one)
-    if ((int)_queue.size() < _n_leased) {
+    // wait makes one batch of them instead of two.  Threads that wait for a best path (on the device, or in line for it) are not
+    // coming: they count as arrived.
+    // ... and while the device has a backlog, requests go on joining (two cohorts of threads that alternate merge into one; a
+    // frame of 40 channels takes the device as long as a frame of 64): wfst_decoder_calls_in_flight counts the advance calls not
+    // yet finished -- with three or more outstanding the batch may grow for nothing, below that it goes (the device is a call or
+    // two from running dry, and this batch's rows have to get there first)
+    // ... and with three advance calls outstanding the batch waits in any case: a fourth would stand in wfst_decoder_advance_host
+    // until the device has caught up (its staging sets are used in rotation), and the batcher with it -- finished utterances' best
+    // paths would lie on the device untaken, their threads idle
+    auto arrived = [&] { return (int)(_queue.size() + _bp_wait.size() + _bp_flight.size()); };
+    {
       const auto t_first = std::chrono::steady_clock::now();
       for (;;) {
-        if (_stop || (int)_queue.size() >= _n_leased) break;
+        if (_stop) break;
         const bool lingered = std::chrono::steady_clock::now() - t_first >= std::chrono::microseconds(_linger_us);
-        if (lingered) {
+        if (lingered || arrived() >= _n_leased) {
           lk.unlock();
-          const int busy = wfst_decoder_busy(_dec);
+          const int depth = wfst_decoder_calls_in_flight(_dec);
           if (!_bp_flight.empty()) PollBestPaths(false);
           lk.lock();
-          if (busy != 1) break;
+          if (depth < 3) break;
         }
         // (wait_until on the SYSTEM clock = pthread_cond_timedwait: what ThreadSanitizer's runtime intercepts -- a steady-clock wait is
         // pthread_cond_clockwait, which gcc 11's does not, and the tool then loses the mutex's hand-over; a jump of the wall clock
@@ -355,8 +394,20 @@ void GpuChannelPool::Run() {
     std::vector<Request *> batch;
     batch.swap(_queue);
     _stats.ms_waiting += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
+    const auto t_first = _t_first;
     lk.unlock();
+    if (!_trace_file.empty()) {
+      auto ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(t - _t_origin).count(); };
+      TracePass tp;
+      memset(&tp, 0, sizeof(tp));
+      tp.t_first = ms(t_first);
+      tp.t_closed = ms(std::chrono::steady_clock::now());
+      tp.busy = wfst_decoder_busy(_dec);
+      for (Request *r : batch) tp.n[r->kind] += 1;
+      _trace.push_back(tp);
+    }
     Execute(batch);   // (releases every kind's requesters as soon as that kind is served: Finish)
+    if (!_trace_file.empty()) _trace.back().t_end = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - _t_origin).count();
     lk.lock();
     _stats.batches += 1;
     _stats.requests += (long long)batch.size();
@@ -388,11 +439,7 @@ void GpuChannelPool::Execute(std::vector<Request *> &batch) {
     f();
     ms[kind] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (Request *r : by_kind[kind]) r->decoded = wfst_decoder_num_frames_decoded(_dec, r->channel);
-    {
-      std::lock_guard<std::mutex> lk(_mu);
-      for (Request *r : by_kind[kind]) r->done = true;
-    }
-    _cv_done.notify_all();
+    for (Request *r : by_kind[kind]) Done(r);
   };
   clocked(kInit, [&] { listed(by_kind[kInit], "InitDecoding", [&](const int32_t *ch, int32_t n) { return wfst_decoder_init(_dec, ch, n); }); });
   clocked(kAdvance, [&] { ExecuteAdvance(by_kind[kAdvance]); });
@@ -402,6 +449,7 @@ void GpuChannelPool::Execute(std::vector<Request *> &batch) {
   {
     const auto t0 = std::chrono::steady_clock::now();
     for (Request *r : by_kind[kBestPath]) _bp_wait.push_back(r);
+    CountBestPaths();
     PollBestPaths(false);
     StartBestPaths();
     ms[kBestPath] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -419,6 +467,8 @@ void GpuChannelPool::Execute(std::vector<Request *> &batch) {
     std::lock_guard<std::mutex> lk(_mu);
     for (int k = 0; k < kKinds; ++k) _stats.ms_by_kind[k] += ms[k];
   }
+  if (!_trace_file.empty() && !_trace.empty())
+    for (int k = 0; k < kKinds; ++k) _trace.back().ms[k] = ms[k];
 }
 void GpuChannelPool::ExecuteAdvance(std::vector<Request *> &requests) {
   // one call per (stride, max_num_frames): in a service every stream has the same model, i.e. one call
@@ -427,6 +477,9 @@ void GpuChannelPool::ExecuteAdvance(std::vector<Request *> &requests) {
     std::vector<Request *> rs, rest;
     for (Request *r : all) (r->stride == all[0]->stride && r->max_num_frames == all[0]->max_num_frames ? rs : rest).push_back(r);
     all.swap(rest);
+    // (in channel order: the rows of consecutive channels are equally spaced slots of the pool's slab -- the library uploads such
+    // runs as one 2-D copy each)
+    std::sort(rs.begin(), rs.end(), [](const Request *x, const Request *y) { return x->channel < y->channel; });
     auto call = [&](std::vector<Request *> &q) {
       std::vector<int32_t> ch, ready;
       std::vector<const float *> rows;
@@ -463,6 +516,7 @@ void GpuChannelPool::StartBestPaths() {
     // refused (one of the channels: GetBestPath before InitDecoding ...): request by request, each its own verdict
     std::vector<Request *> rs;
     rs.swap(_bp_flight);
+    CountBestPaths();
     ExecuteBestPath(rs);
     Finish(rs);
   }
@@ -477,6 +531,7 @@ bool GpuChannelPool::PollBestPaths(bool block) {
   const int rc = wfst_decoder_best_path_fetch(_dec, il.data(), ol.data(), g.data(), ac.data(), n.data());
   std::vector<Request *> rs;
   rs.swap(_bp_flight);
+  CountBestPaths();
   if (rc != WFST_OK) {
     // a path longer than the capacity, or one channel's device error: the synchronous path sorts it out request by request
     ExecuteBestPath(rs);
@@ -652,14 +707,26 @@ GpuLatticeDecoder::~GpuLatticeDecoder() {
   }
   if (_pool) _pool->Release(_chan);
   else wfst_decoder_free(_dec);
-  _shared.reset();   // (ShareDevice: the shared decoder goes with its last object once the registry has let go of it)
-  if (_rows_pinned) wfst_host_free(_rows);
+  if (_rows_in_pool) _rows = nullptr;   // (the pool's)
+  else if (_rows_pinned) wfst_host_free(_rows);
   else free(_rows);
+  _shared.reset();   // (ShareDevice: the shared decoder goes with its last object once the registry has let go of it)
 }
 // the rows pulled from the decodable live in page-locked memory (they are uploaded chunk by chunk, beside the search over the chunk
 // before): grown by doubling, the history kept
 void GpuLatticeDecoder::GrowRows(size_t floats) {
   if (floats <= _rows_cap) return;
+  if (_pool && !_rows) {
+    // the channel's slot of the pool's slab, if the rows fit there (they do when the service has reserved its longest utterance)
+    size_t cap = 0;
+    if (float *slot = _pool->RowSlot(_chan, floats, &cap)) {
+      _rows = slot;
+      _rows_cap = cap;
+      _rows_pinned = true;
+      _rows_in_pool = true;
+      return;
+    }
+  }
   const size_t ncap = std::max<size_t>(floats, std::max<size_t>(2 * _rows_cap, (size_t)1 << 16));
   bool pinned = true;
   float *np = (float *)wfst_host_alloc(ncap * sizeof(float));
@@ -670,10 +737,14 @@ void GpuLatticeDecoder::GrowRows(size_t floats) {
   }
   if (_rows && _rows_ready > 0) memcpy(np, _rows, (size_t)_rows_ready * _stride * sizeof(float));
   // (rows of the old page-locked buffer may still be on their way to the device -- wfst_decoder_advance_host returns when they are
-  // enqueued: the device is waited for before the buffer goes)
-  if (_rows_pinned && _rows_ready > 0 && _inited) OnDevice([&] { (void)wfst_decoder_sync(_dec); });
-  if (_rows_pinned) wfst_host_free(_rows);
-  else free(_rows);
+  // enqueued: the device is waited for before the buffer goes; a slot of the pool's slab stays where it is)
+  if (_rows_in_pool) {
+    _rows_in_pool = false;
+  } else {
+    if (_rows_pinned && _rows_ready > 0 && _inited) OnDevice([&] { (void)wfst_decoder_sync(_dec); });
+    if (_rows_pinned) wfst_host_free(_rows);
+    else free(_rows);
+  }
   _rows = np;
   _rows_cap = ncap;
   _rows_pinned = pinned;

@@ -17,6 +17,7 @@
 #ifndef WFST_HOST_H_
 #define WFST_HOST_H_
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -270,6 +271,10 @@ class GpuChannelPool {
     int decoded;                  // NumFramesDecoded of the channel after the request
     std::exception_ptr error;
     bool done;
+    // (every request is waited for on a condition variable of its own: sixty-four threads released together through ONE variable
+    // and the pool's mutex wake up one behind the other -- milliseconds at an utterance boundary)
+    std::mutex m;
+    std::condition_variable cv;
     Request() : kind(kCall), channel(0), rows(nullptr), ready(0), stride(0), max_num_frames(-1), use_final_probs(true), n_hops(0),
                 degraded(0), decoded(0), done(false) {}
   };
@@ -287,18 +292,35 @@ class GpuChannelPool {
   void StartBestPaths();
   bool PollBestPaths(bool block);
   void Finish(std::vector<Request *> &rs);
+  // The decoder objects' row buffers as slots of ONE page-locked allocation, equally spaced: rows of consecutive channels that cover
+  // the same frames then go to the device as one 2-D copy (wfst_decoder_advance_host).  Allocated by the first object that asks, every
+  // slot as large as that request (a service reserves its longest utterance: ReserveRows); nullptr: no room for `floats` in a slot --
+  // the object keeps a buffer of its own.
+  float *RowSlot(int channel, size_t floats, size_t *slot_floats);
+  std::mutex _slab_mu;
+  float *_slab = nullptr;
+  size_t _slab_pitch = 0;   // floats per slot
   std::vector<Request *> _bp_wait, _bp_flight;   // (the batcher thread's own)
   int _bp_cap = 0, _bp_ufp = 1;
+  std::atomic<int> _n_bp_outstanding{0};         // their number, for the submitting threads (which one completes a batch)
+  void CountBestPaths() { _n_bp_outstanding.store((int)(_bp_wait.size() + _bp_flight.size())); }
   wfst_decoder *_dec;
   Fst *_graph;
   int _n, _linger_us;
   std::mutex _mu;
-  std::condition_variable _cv_work, _cv_done, _cv_free;
+  std::condition_variable _cv_work, _cv_free;
+  static void Done(Request *r);   // marks it served and wakes its thread (the request may be gone when this returns)
   std::vector<Request *> _queue;
   std::vector<char> _leased;
   int _n_leased;
   bool _stop;
   Stats _stats;
+  // WFST_POOL_TRACE=<file>: one line per batcher pass (when its first request arrived, when it was closed, what it held, how long each
+  // kind's device calls took, whether the device was still busy when it closed), written when the pool goes
+  struct TracePass { double t_first, t_closed, t_end; int n[5]; double ms[5]; int busy; };
+  std::vector<TracePass> _trace;
+  std::string _trace_file;
+  std::chrono::steady_clock::time_point _t_origin, _t_first;
   std::thread _thread;
 };
 
@@ -373,6 +395,7 @@ class GpuLatticeDecoder : public DecoderItf {
   float *_rows;              // host history [frames][stride], page-locked (wfst_host_alloc) where the device grants it
   size_t _rows_cap;          // floats
   bool _rows_pinned;
+  bool _rows_in_pool = false;   // _rows is the channel's slot of the pool's slab (not this object's to free)
   void GrowRows(size_t floats);
   void SetColumns(const Fst *graph);   // the graph's tid2pdf -> one representative transition-id per pdf (Pull)
   std::vector<int32_t> _rep;           // [pdf] a transition-id of that pdf; empty: the rows are indexed by the decodable's own indices

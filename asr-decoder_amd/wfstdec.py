@@ -35,7 +35,7 @@ SYMBOLS = [
     "wfst_options_default", "wfst_graph_options_default", "wfst_graph_load_ex", "wfst_graph_from_arrays_ex",
     "wfst_decoder_create_ex", "wfst_lm_load", "wfst_lm_from_arrays", "wfst_lm_info", "wfst_lm_free",
     "wfst_decoder_create_biglm", "wfst_decoder_get_determinized_lattice", "wfst_decoder_get_lattice_stats", "wfst_decoder_get_rescored_lattice", "wfst_decoder_get_nbest_paths",
-    "wfst_decoder_get_degraded_frames", "wfst_decoder_get_prune_raw_abandoned", "wfst_host_alloc", "wfst_host_free", "wfst_decoder_busy", "wfst_decoder_get_determinizer_ms", "wfst_decoder_best_path_enqueue", "wfst_decoder_best_path_ready", "wfst_decoder_best_path_fetch", "wfst_decoder_prefetch_nbest", "wfst_decoder_get_prefetched_nbest_paths", "wfst_decoder_get_path_flags", "wfst_decoder_rescore_lattices", "wfst_decoder_nbest_paths_batch",
+    "wfst_decoder_get_degraded_frames", "wfst_decoder_get_prune_raw_abandoned", "wfst_host_alloc", "wfst_host_free", "wfst_decoder_busy", "wfst_decoder_calls_in_flight", "wfst_decoder_get_determinizer_ms", "wfst_decoder_best_path_enqueue", "wfst_decoder_best_path_ready", "wfst_decoder_best_path_fetch", "wfst_decoder_prefetch_nbest", "wfst_decoder_get_prefetched_nbest_paths", "wfst_decoder_get_path_flags", "wfst_decoder_rescore_lattices", "wfst_decoder_nbest_paths_batch",
     "wfst_decoder_prefetch_determinized", "wfst_lattice_labels_batch",
     "wfst_decoder_prefetch_determinized_detached", "wfst_decoder_get_prefetched_lattice", "wfst_decoder_harvest_prefetched",
 ]
@@ -382,6 +382,13 @@ class BatchDecoder:
     def busy(self):
         """1 while work enqueued on the decoder's stream has not finished, else 0 (wfst_decoder_busy; never blocks)."""
         rc = lib().wfst_decoder_busy(self.h)
+        if rc < 0:
+            _check(rc)
+        return int(rc)
+
+    def calls_in_flight(self):
+        """How many enqueued init / advance / finalize calls have not finished (wfst_decoder_calls_in_flight; never blocks)."""
+        rc = lib().wfst_decoder_calls_in_flight(self.h)
         if rc < 0:
             _check(rc)
         return int(rc)

@@ -299,6 +299,12 @@ int wfst_decoder_sync(wfst_decoder *d);
  * arrive meanwhile can join it (the host mirror's GpuChannelPool). */
 int wfst_decoder_busy(wfst_decoder *d);
 
+/* How many of the decoder's enqueued wfst_decoder_init / _advance[_host] / _finalize calls have not finished yet (0 ... 16: the
+ * newest sixteen are looked at; never blocks); < 0: error.  The depth of the device's backlog, for a batching host that hands over
+ * chunk after chunk: with two or more calls outstanding the device has work behind the call it is running, and requests that
+ * arrive meanwhile can still join the next call for nothing; with one or none it is about to run dry. */
+int wfst_decoder_calls_in_flight(wfst_decoder *d);
+
 /* NumFramesDecoded() (my-decoder/online-decoder-base.h:139). */
 int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t channel);
 

@@ -3,6 +3,7 @@
 // row of every utterance reached its own channel exactly once, in order.  It also polices the pool's contract: the C ABI's calls on
 // one decoder are NOT re-entrant, so any two calls that overlap abort the process.  Only the entry points the pool's batched path
 // uses are defined; the test links with --unresolved-symbols=ignore-all.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -76,7 +77,7 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *ch, int32_t n, con
       for (int k = 1; k < stride; ++k) d->sum[c] += (double)rows[i][(size_t)f * stride + k] * (double)((f % 7) + 1);
     d->rows[c] = ready[i];
   }
-  d->busy_until_ns = now_ns() + 150000;   // the "device" is busy for 150 us after an advance
+  d->busy_until_ns = std::max(d->busy_until_ns.load(), now_ns()) + 100000;   // the "device" takes 100 us per advance call, one after the other
   std::this_thread::sleep_for(std::chrono::microseconds(30));
   return WFST_OK;
 }
@@ -89,9 +90,18 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *ch, int32_t n) {
   }
   return WFST_OK;
 }
+int wfst_decoder_sync(wfst_decoder *d) {
+  Guard g(d);
+  return WFST_OK;
+}
 int wfst_decoder_busy(wfst_decoder *d) {
   Guard g(d);
   return now_ns() < d->busy_until_ns.load() ? 1 : 0;
+}
+int wfst_decoder_calls_in_flight(wfst_decoder *d) {
+  Guard g(d);
+  const long long left = d->busy_until_ns.load() - now_ns();
+  return left <= 0 ? 0 : (int)std::min<long long>(4, (left + 99999) / 100000);   // (the double's "device" runs 100 us per call)
 }
 int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t c) { return d->rows[c]; }
 int wfst_decoder_get_degraded_frames(wfst_decoder *d, int32_t, int32_t *n) { Guard g(d); *n = 0; return WFST_OK; }
@@ -140,7 +150,7 @@ int wfst_decoder_best_path_fetch(wfst_decoder *d, int32_t *il, int32_t *ol, floa
 }
 void wfst_graph_free(wfst_graph *) {}
 void wfst_lm_free(wfst_lm *) {}
-void *wfst_host_alloc(size_t) { return nullptr; }   // (no page-locked memory here: GpuLatticeDecoder falls back to malloc)
-void wfst_host_free(void *) {}
+void *wfst_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }   // (plain memory stands in for page-locked: the pool's row slab and the objects' own buffers take the same paths)
+void wfst_host_free(void *p) { free(p); }
 long long fake_calls(wfst_decoder *d, int k) { return d->calls[k]; }
 }

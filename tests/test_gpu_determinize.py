@@ -466,11 +466,13 @@ def test_busy_flag_and_per_lattice_determinizer_time(synth, tmp_path):
                                  lattice_links=1 << 21)
     dec.init()
     dec.sync()
-    assert dec.busy() == 0
+    assert dec.busy() == 0 and dec.calls_in_flight() == 0
+    dec.advance([t.data_ptr() for t in dev], [60, 9, 60], 1000)
     dec.advance([t.data_ptr() for t in dev], Ts, 1000)
-    seen_busy = dec.busy()          # (120 frames of launches are on the stream: almost certainly still running)
+    seen_busy, seen_depth = dec.busy(), dec.calls_in_flight()   # (120 frames of launches are on the stream: almost certainly still running)
     dec.sync()
-    assert dec.busy() == 0 and seen_busy in (0, 1)
+    assert dec.busy() == 0 and seen_busy in (0, 1) and dec.calls_in_flight() == 0
+    assert 0 <= seen_depth <= 2   # (two advance calls behind an init that has finished)
     dec.finalize()
     assert dec.determinizer_ms(0) is None          # nothing determinized yet
     det = dec.determinized_lattices()
