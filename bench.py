@@ -392,7 +392,7 @@ def stored_launches_per_step(entry, klass, default):
     return entry.get("launches", {}).get(klass, 2 * default) / 2.0
 
 
-def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=25, repeat=9, warm=1):
+def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=25, repeat=17, warm=1):
     """wfst-decode --threads=64 [--pool=64] --chunk=25 --pull over the batch's utterances: frames/s of the C++ DecoderItf mirror in the
     reference service's shape, and the words of every utterance against the batch decoder's (which the run has checked against the
     reference).  The list is decoded `repeat` times over, the first `warm` passes before the clock (the headline's warm-up steps for
@@ -418,7 +418,7 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
                 key = ("utt%04d" % i).encode()
                 f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", T, P))
                 f.write(np.ascontiguousarray(mats[i], "<f4").tobytes())
-        common = [cli, "--tid2pdf=" + os.path.join(tmp, "tid2pdf.bin"), "--chunk=%d" % chunk, "--threads=%d" % threads,
+        common = [cli, "--tid2pdf=" + os.path.join(tmp, "tid2pdf.bin"), "--chunk=%d" % chunk,
                   "--max-frames=%d" % (T + 2), "--max-tokens=%d" % a.max_tokens, "--arena-tokens=%d" % int(T * a.arena_per_frame)]
         tail = [os.path.join(tmp, "decoder.conf"), gpath, os.path.join(tmp, "ll.bin")]
         want = {"utt%04d" % i: [int(w) for w in gpu_res[i]["words"]] for i in range(B) if gpu_res[i]["ok"]}
@@ -430,16 +430,20 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
                      "host -> device inside the timed region" % (threads, chunk, threads)}
         for tag, extra in (("pool", ["--pool=%d" % threads, "--pull"]), ("pool_matrix", ["--pool=%d" % threads]), ("private", ["--pull"]),
                            # the one-line drop-in: GpuLatticeDecoder::ShareDevice(64) once, the threads construct (graph, config) decoders as ever
-                           # (two shared decoders of 32 channels -- each with its own batcher thread -- ran 3-5 % ahead of one of 64; four of 16: behind)
-                           ("shared", ["--share=%d" % (threads // 2), "--pull"]),
+                           ("shared", ["--share=%d" % threads, "--pull"]),
+                           # twice the threads over two shared decoders of 64 channels (two batcher threads): the device's frames are
+                           # latency bound -- a call of 64 channels takes it as long as one of 40
+                           ("shared_threads128", ["--threads=128", "--share=64", "--pull"]),
                            # (the process's first utterances inside the clock, four passes: round 6's first way of counting)
                            ("pool_cold_4_passes", ["--pool=%d" % threads, "--pull", "--repeat=4", "--warm=0"])):
             best = None
+            if not any(x.startswith("--threads=") for x in extra):
+                extra = ["--threads=%d" % threads] + extra
             if tag == "private":   # (33 k frames/s: two timed passes are 2.3 s)
                 extra = extra + ["--repeat=%d" % (warm + 2), "--warm=%d" % warm]
             elif "--repeat=4" not in extra:
                 extra = extra + ["--repeat=%d" % repeat, "--warm=%d" % warm]
-            for rep in range(3 if tag not in ("pool_cold_4_passes", "private") else 1):   # (fresh processes: thread start-up and the box's other load vary from run to run -- the best of three)
+            for rep in range(3 if tag == "pool" else 2 if tag not in ("pool_cold_4_passes", "private") else 1):   # (fresh processes: thread start-up and the box's other load vary from run to run -- the best of three)
                 p = subprocess.run(common + extra + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
                 err = p.stderr.decode(errors="replace")
                 if p.returncode != 0:
@@ -532,8 +536,8 @@ def leg_scalars(o):
         k["wer_vs_cpu_max"] = o["spread"]["gpu_vs_reference_wer_range"][1]
     if "degraded_frames" in o:
         k["degraded_frames"] = o["degraded_frames"]
-    for dk in ("pool_value", "pool_matrix_value", "shared_value", "private_value", "reference_value", "reference_threads", "pool_mean_advance_batch", "threads", "chunk_frames",
-               "warm_up_passes", "pool_cold_4_passes_value"):
+    for dk in ("pool_value", "pool_matrix_value", "shared_value", "shared_threads128_value", "private_value", "reference_value", "reference_threads", "pool_mean_advance_batch",
+               "threads", "chunk_frames", "warm_up_passes", "pool_cold_4_passes_value"):
         if dk in o:
             k[dk] = o[dk]
     if "pool_same_words_as_batch_decoder" in o:
@@ -604,7 +608,7 @@ def summary_line(out, detail_path=None):
     # (a line over the limit loses its optional parts -- strings first, then the legs' scalars from the least telling one up, then
     # whole legs from the last one -- rather than its contract keys, and is printed in any case)
     # (what a leg keeps when the line has to shrink, most telling first)
-    order = ("value", "ms_per_step", "parity", "error", "pool_value", "shared_value", "private_value", "reference_value", "pool_matrix_value", "bit_identical",
+    order = ("value", "ms_per_step", "parity", "error", "pool_value", "shared_value", "shared_threads128_value", "private_value", "reference_value", "pool_matrix_value", "bit_identical",
              "wer_vs_cpu", "cpu_self_wer", "cpu_baseline_value", "frac", "whole_path_frac", "lattice_parity", "gpu_determinizer_ms_per_lattice_mean",
              "gpu_determinizer_ms_per_lattice_max", "cpu_determinizer_ms_per_lattice", "whole_path_frac_8d", "utterances_with_path", "steps",
              "wer_vs_cpu_max", "cpu_self_wer_max", "pool_mean_advance_batch", "degraded_frames", "cpu_self_bit_identical", "kernel",

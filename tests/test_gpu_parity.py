@@ -102,6 +102,38 @@ def test_host_fed_matrices_equal_device_resident(setup50k, synth):
                                 [y.tot_score, y.lm_score])
 
 
+def test_page_locked_rows_in_one_block_go_up_as_2d_copies(setup50k, synth):
+    """wfst_decoder_advance_host with PAGE-LOCKED rows that lie equally spaced in host memory (one matrix of utterances; the channel
+    pool's row slab): runs of consecutive channels covering the same frames are uploaded as one 2-D copy each, the call returns when
+    enqueued.  Ragged lengths (runs break where a channel has ended), a channel subset with a gap, a history that has to regrow
+    mid-utterance (max_frames above 1024: it starts at 256 rows): the same paths as from device-resident matrices."""
+    import torch
+
+    s = setup50k
+    G = s["G"]
+    lengths = [300, 300, 300, 41, 300, 280, 300, 7]
+    mats = _utts(synth, s, lengths, 4200)
+    stride = int(mats[0].shape[1])
+    block = torch.zeros((len(mats), max(lengths), stride), dtype=torch.float32).pin_memory()
+    for i, x in enumerate(mats):
+        block[i, : x.shape[0]] = torch.from_numpy(x)
+    rows = [block[i, : lengths[i]].numpy() for i in range(len(mats))]
+    assert all(r.ctypes.data - rows[0].ctypes.data == i * max(lengths) * stride * 4 for i, r in enumerate(rows))
+    want = G.decode_batch(s["graph"], BEAM_ONLY, mats, limits=dict(max_frames=2000, max_tokens_per_frame=32768, arena_tokens=1 << 22))
+    dec = G.wfstdec.BatchDecoder(s["graph"], G.gpu_config(BEAM_ONLY), len(mats), max_frames=2000, max_tokens_per_frame=32768, arena_tokens=1 << 22)
+    for channels in (None, [0, 1, 2, 4, 5, 7]):   # (all channels; a list with gaps: runs 0-2, 4-5, 7)
+        ch = list(range(len(mats))) if channels is None else channels
+        dec.init(channels)
+        for r in (16, 100, 200, 300):   # (256 rows per channel to begin with: the third call regrows the history, rows in flight or not)
+            dec.advance_host([rows[c] for c in ch], [min(r, lengths[c]) for c in ch], channels=channels)
+        dec.finalize(channels)
+        got = [G.GpuResult(d) for d in dec.best_paths(channels)]
+        for c, y in zip(ch, got):
+            x = want[c]
+            G.assert_same_path(y, x.words, x.tids, x.path_ilabel, x.path_olabel, x.path_graph, x.path_ac, [x.tot_score, x.lm_score], "channel %d" % c)
+    dec.free()
+
+
 def test_per_frame_best_cost_and_token_subset(setup50k, synth, oracle):
     """Frame by frame: identical best cost; GPU token set is a subset of the reference's (which
     keeps order-dependent extras) and every GPU token cost equals the oracle's for that state."""
