@@ -443,7 +443,7 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
                 extra = extra + ["--repeat=%d" % (warm + 2), "--warm=%d" % warm]
             elif "--repeat=4" not in extra:
                 extra = extra + ["--repeat=%d" % repeat, "--warm=%d" % warm]
-            for rep in range(3 if tag == "pool" else 2 if tag not in ("pool_cold_4_passes", "private") else 1):   # (fresh processes: thread start-up and the box's other load vary from run to run -- the best of three)
+            for rep in range(2 if tag == "pool" else 1):   # (fresh processes: thread start-up and the box's other load vary from run to run -- the headline shape twice, the better one)
                 p = subprocess.run(common + extra + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
                 err = p.stderr.decode(errors="replace")
                 if p.returncode != 0:
@@ -1511,7 +1511,7 @@ def main():
         mats3 = make_utts(synth, g, m, 0, B, T, P, sa)
         ll3 = torch.from_numpy(mats3).to(dev)
         cp = {"workload": "SURVEY.md 8(d) single-planted-path log-likelihoods calibrated to ~5 k tokens per frame (mu -2.6, sigma 1), max_active=7000, min_active=200"}
-        cp.update(at_service_point(mats3, ll3, spread=True))
+        cp.update(at_service_point(mats3, ll3))   # (the three-order spread on the first workload only: a full pass of the reference over the batch less)
         del ll3, mats3
         sp["calibrated_workload_at_7000_200"] = cp
         hp = {"workload": "the headline log-likelihoods at max_active=7000, min_active=200"}
@@ -1567,7 +1567,7 @@ def main():
         # the reference's own CPU path timed beside configs[3] and configs[4] (1 / 32 / all host threads): its biglm decoder
         # (kaldi-hclg-my-decoder-biglm.cc:80-102) and its lattice pipeline (decode, GetRawLattice, DeterminizeLatticeWrapper,
         # NShortestPath: kaldi-online-nnet3-my-decoder.cc:50-105); the other legs vary the same two configurations and carry none
-        cpu_on = ["--cpu-seconds", str(min(a.cpu_seconds, 5.0)), "--cpu-threads", str(min(64, a.cpu_threads or affinity_cpus()))] if (a.cpu_sample > 0 and not a.no_cpu_baseline) else ["--no-cpu-baseline"]
+        cpu_on = ["--cpu-seconds", str(min(a.cpu_seconds, 4.0)), "--cpu-threads", str(min(64, a.cpu_threads or affinity_cpus()))] if (a.cpu_sample > 0 and not a.no_cpu_baseline) else ["--no-cpu-baseline"]
         cpu_off = ["--no-cpu-baseline"]
         legs = {# the headline with wfst_limits all zero: what a caller who sizes nothing gets
                 "headline_library_default_limits": ["--default-limits", "--steps", str(max(6, n2)), "--cpu-sample", "4"] + cpu_off,

@@ -275,7 +275,10 @@ int wfst_decoder_advance(wfst_decoder *d, const int32_t *channels, int32_t n,
  * PAGE-LOCKED buffers (wfst_host_alloc; every listed channel's): the rows go up by DMA and the call
  * returns when copies and frames are ENQUEUED, like wfst_decoder_advance -- the rows handed over must
  * stay valid and unchanged until they are decoded (wfst_decoder_sync or any result getter of the
- * channel); a host that hands over chunk after chunk keeps enqueueing while the device decodes. */
+ * channel); a host that hands over chunk after chunk keeps enqueueing while the device decodes.
+ * Page-locked matrices of CONSECUTIVE listed channels that lie equally spaced in host memory (one block of utterances; slots of one
+ * allocation) and hand over the same frames go up as ONE 2-D copy per run of such channels: list the channels in ascending order.
+ * (The device histories of all channels are one allocation, n_channels x the longest hand-over so far, at most max_frames rows.) */
 int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t n,
                               const float *const *loglikes_host, const int32_t *n_frames_ready,
                               int32_t stride, int32_t max_num_frames);
