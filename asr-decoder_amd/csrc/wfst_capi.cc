@@ -1734,8 +1734,16 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
   }
   // slices (a long hand-over) or everything at once; page-locked rows: every slice's copies and frames are enqueued one behind the
   // other -- the copy engine is a slice ahead of the search, the host waits for neither
-  for (int done = 0; done < std::max(longest, 1); done += sliced ? kSlice : std::max(longest, 1)) {
-    const int upto = sliced ? done + kSlice : longest;
+  // (the FIRST slice stands in front of the first frame: page-locked rows start with short slices -- a sixth, a third, a half of
+  // kSlice -- and the search starts a sixth of a slice's upload after the call)
+  auto slice_at = [&](int done) {
+    if (!sliced) return std::max(longest, 1);
+    if (!all_pinned || kSlice < 12) return kSlice;
+    if (done >= 2 * kSlice) return 2 * kSlice;   // (... and long ones once the uploads are well ahead: every slice is a call of its own)
+    return done == 0 ? kSlice / 6 : done == kSlice / 6 ? kSlice / 3 : done == kSlice / 6 + kSlice / 3 ? kSlice - kSlice / 6 - kSlice / 3 : kSlice;
+  };
+  for (int done = 0, step = slice_at(0); done < std::max(longest, 1); done += step, step = slice_at(done)) {
+    const int upto = sliced ? done + step : longest;
     // Page-locked rows of CONSECUTIVE channels that lie equally spaced in host memory (one matrix of utterances; the channel pool's
     // row slab) and cover the same frames go up as ONE 2-D copy -- a copy per channel costs the engine ~7 us each before it moves
     // a byte: 128 chunks of 300 KB take 2.0 ms one by one, 0.68 ms as one 2-D copy (tools/ubench_h2d.hip).
