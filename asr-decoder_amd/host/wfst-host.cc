@@ -377,7 +377,12 @@ void GpuChannelPool::Run() {
       const auto t_first = std::chrono::steady_clock::now();
       for (;;) {
         if (_stop) break;
-        const bool lingered = std::chrono::steady_clock::now() - t_first >= std::chrono::microseconds(_linger_us);
+        // (a batch that is at least half full waits ten times as long for the rest: threads released together come back spread over
+        // a few hundred microseconds, and cut in two they stay two cohorts -- a device call of half the channels takes as long as one
+        // of all)
+        const auto waited = std::chrono::steady_clock::now() - t_first;
+        const bool lingered = waited >= std::chrono::microseconds(_linger_us) &&
+                              (2 * arrived() < _n_leased || waited >= std::chrono::microseconds(10 * (long long)_linger_us));
         if (lingered || arrived() >= _n_leased) {
           lk.unlock();
           const int depth = wfst_decoder_calls_in_flight(_dec);

@@ -434,9 +434,9 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
         for tag, extra in (pool_tag, ("pool_matrix", ["--pool=%d" % threads]), ("private", ["--pull"]), pool_tag,
                            # the one-line drop-in: GpuLatticeDecoder::ShareDevice(64) once, the threads construct (graph, config) decoders as ever
                            ("shared", ["--share=%d" % threads, "--pull"]),
-                           # twice the threads over two shared decoders of 64 channels (two batcher threads): the device's frames are
-                           # latency bound -- a call of 64 channels takes it as long as one of 40
-                           ("shared_threads128", ["--threads=128", "--share=64", "--pull"]),
+                           # twice the threads over one shared decoder of 128 channels: the device's frames are latency bound -- a call
+                           # of 128 channels takes it 58 us a frame, one of 64 channels 45
+                           ("shared_threads128", ["--threads=128", "--share=128", "--pull"]),
                            # (the process's first utterances inside the clock, four passes: round 6's first way of counting)
                            ("pool_cold_4_passes", ["--pool=%d" % threads, "--pull", "--repeat=4", "--warm=0"]), pool_tag):
             best = None
