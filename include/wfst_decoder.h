@@ -297,15 +297,15 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n);
  * channel hit a limit or the device faulted. */
 int wfst_decoder_sync(wfst_decoder *d);
 
-/* 1 while work enqueued on the decoder's stream has not finished, 0 when it is idle (never blocks); < 0: error.  What a batching
- * host needs to know before it issues the next wfst_decoder_advance: that call waits for the one before it anyway, so requests that
- * arrive meanwhile can join it (the host mirror's GpuChannelPool). */
+/* 1 while work enqueued on the decoder's stream has not finished, 0 when it is idle (never blocks); < 0: error. */
 int wfst_decoder_busy(wfst_decoder *d);
 
-/* How many of the decoder's enqueued wfst_decoder_init / _advance[_host] / _finalize calls have not finished yet (0 ... 16: the
- * newest sixteen are looked at; never blocks); < 0: error.  The depth of the device's backlog, for a batching host that hands over
- * chunk after chunk: with two or more calls outstanding the device has work behind the call it is running, and requests that
- * arrive meanwhile can still join the next call for nothing; with one or none it is about to run dry. */
+/* How many of the decoder's enqueued wfst_decoder_advance[_host] calls -- calls that brought frames; an init or finalize between two
+ * of them is not counted -- have not finished yet (0 ... 16: the marks of the newest sixteen calls are looked at; never blocks);
+ * < 0: error.  The depth of the device's backlog, for a batching host that hands over chunk after chunk (the host mirror's
+ * GpuChannelPool): with three calls outstanding the next one would wait inside the library for the device (the staging sets of the
+ * targets and row pointers are used in rotation), and while the device has work behind the call it is running, requests that arrive
+ * can still join the next call for nothing; with one or none outstanding it is about to run dry. */
 int wfst_decoder_calls_in_flight(wfst_decoder *d);
 
 /* NumFramesDecoded() (my-decoder/online-decoder-base.h:139). */
