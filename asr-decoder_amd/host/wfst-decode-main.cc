@@ -43,6 +43,9 @@
 //   --warm=W       with --repeat: the first W passes over the list run BEFORE the clock (bench.py's warm-up steps, for the service's
 //                  shape): every thread waits until the last warm-up utterance is done, the clock starts there, and the frames
 //                  reported ("LOG Timed passes: ...") are those of the K - W passes behind it
+//   --ragged=P     the utterances are cut to pseudo-random lengths between P % and 100 % of their frames (a fixed function of their
+//                  position in the list) before anything is decoded: utterance boundaries that do not fall together, as a service
+//                  sees them
 //   --share=C      the ONE-LINE drop-in at service scale: GpuLatticeDecoder::ShareDevice(C) once, then every thread constructs its decoder
 //                  the reference's way -- (graph, config) -- and the objects lease channels of shared C-channel device decoders
 //   --pull         the decodable is a plain DecodableInterface: every score goes through LogLikelihood(frame, index) (without it
@@ -139,7 +142,7 @@ int main(int argc, char **argv) {
     int nbest = 0, inflight = 1, chunk = 0, n_threads = 0, pool_channels = 0, linger_us = 50;
     bool pull = false;
     long long max_tokens_per_frame = 0, arena_tokens = 0;
-    int max_frames = 0, repeat = 1, share_channels = 0, warm = 0;
+    int max_frames = 0, repeat = 1, share_channels = 0, warm = 0, ragged = 0;
     std::vector<int> devices(1, 0);
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -160,6 +163,7 @@ int main(int argc, char **argv) {
       else if (a == "--pull") pull = true;
       else if (a.compare(0, 9, "--repeat=") == 0) repeat = std::max(1, atoi(a.c_str() + 9));
       else if (a.compare(0, 7, "--warm=") == 0) warm = std::max(0, atoi(a.c_str() + 7));
+      else if (a.compare(0, 9, "--ragged=") == 0) ragged = std::min(100, std::max(1, atoi(a.c_str() + 9)));
       else if (a.compare(0, 8, "--share=") == 0) share_channels = std::max(0, atoi(a.c_str() + 8));
       else if (a.compare(0, 13, "--max-tokens=") == 0) max_tokens_per_frame = atoll(a.c_str() + 13);
       else if (a.compare(0, 15, "--arena-tokens=") == 0) arena_tokens = atoll(a.c_str() + 15);
@@ -287,6 +291,13 @@ int main(int argc, char **argv) {
 
     std::vector<Utt> utts;
     for (Utt u; ReadUtt(in, &u);) utts.push_back(u);
+    if (ragged > 0)
+      for (size_t i = 0; i < utts.size(); ++i) {
+        const unsigned h = (unsigned)(i * 2654435761u) >> 8;   // (Knuth's multiplicative hash of the position)
+        const int keep = std::max(1, (int)((long long)utts[i].frames * (ragged + (int)(h % (unsigned)(101 - ragged))) / 100));
+        utts[i].frames = keep;
+        utts[i].m.resize((size_t)keep * utts[i].cols);
+      }
     int num_success = 0, num_fail = 0;
     long long frame_count = 0, repeat_frames = 0, timed_frames = 0;
     double tot_like = 0;

@@ -388,7 +388,7 @@ void GpuChannelPool::Run() {
           const int depth = wfst_decoder_calls_in_flight(_dec);
           if (!_bp_flight.empty()) PollBestPaths(false);
           lk.lock();
-          if (depth < 3) break;
+          if (depth < 3) break;   // (2: the same, measured)
         }
         // (wait_until on the SYSTEM clock = pthread_cond_timedwait: what ThreadSanitizer's runtime intercepts -- a steady-clock wait is
         // pthread_cond_clockwait, which gcc 11's does not, and the tool then loses the mutex's hand-over; a jump of the wall clock
