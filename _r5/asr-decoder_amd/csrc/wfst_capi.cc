@@ -172,35 +172,8 @@ struct wfst_decoder {
   std::vector<int32_t> h_decoded, h_target, h_state;  // state: 0 = never inited, 1 = decoding, 2 = finalized
   std::vector<const float *> h_ll_base;
   // pinned staging
-  int32_t *p_target = nullptr, *p_chan = nullptr;   // p_target / p_ll: kStage sets, used in rotation (advance_device)
+  int32_t *p_target = nullptr, *p_chan = nullptr;
   const float **p_ll = nullptr;
-  static constexpr int kStage = 4;
-  hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr};   // set k's upload has been consumed
-  int stage_next = 0;
-  hipEvent_t chan_stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr};   // (stage_channels' sets of p_chan)
-  int chan_stage_next = 0;
-  // RESULTS beside the search: a best path asked for a LIST of channels (the channel pool's shape: some utterances have ended, the
-  // others go on) runs on a stream of its own behind the listed channels' last enqueued work -- an event recorded on the decoder's
-  // stream by every init / advance / finalize, in a ring; a slot recorded again marks a later point of the stream: still behind the
-  // channel's work -- instead of behind everything the decoder's stream holds (the frames of the other channels enqueued since).
-  static constexpr int kMarkRing = 16;
-  hipEvent_t mark_ev[kMarkRing] = {};
-  int mark_next = 0;
-  long long mark_count = 0;            // marks recorded so far
-  bool mark_frames[kMarkRing] = {};    // the mark stands behind an advance call (frames to decode), not behind an init / finalize
-  std::vector<int> chan_mark;          // [channel] ring slot of the event behind the channel's last enqueued work, -1: none
-  hipStream_t res_stream = nullptr;
-  std::vector<int32_t> bp_out;         // wfst_decoder_best_path_enqueue: the outstanding request's channels ...
-  int32_t bp_out_n = 0, bp_out_cap = 0;   // ... their number (0: nothing outstanding) and the hop capacity
-  ChanCtl *bp_ctl_pin = nullptr;       // ... and its own page-locked copy of the control blocks (p_ctl is the synchronous getters')
-  int32_t *bp_deg_pin = nullptr;       // ... and of the degraded-frame counts, which a fetch leaves in deg_cache for its channels
-  std::vector<long long> chan_serial, bp_out_serial;   // [channel] calls enqueued for it so far; [list position] ... when the list was enqueued
-  std::vector<int32_t> deg_cache;      // [channel] wfst_decoder_get_degraded_frames without a device round trip; -1: not held (any later init / advance / finalize of the channel)
-  int32_t *res_chan_pin = nullptr;
-  DevBuf<int32_t> res_chan_list;
-  hipEvent_t copy_ev = nullptr;        // advance_host: the rows of page-locked buffers are on their way (the decode stream waits for it, the host does not)
-  std::vector<const float *> hist_src; // [channel] the host buffer of the channel's last hand-over ...
-  std::vector<char> hist_src_pinned;   // ... and whether it is page-locked (asked once per buffer)
   ChanCtl *p_ctl = nullptr;
   // best-path output buffers (device), grown on demand
   DevBuf<int32_t> bp_chain;
@@ -233,8 +206,7 @@ struct wfst_decoder {
   // requests right behind the batch of second passes of the same channels starts from those lattices
   std::vector<int32_t> post_dev_list, post_dev_decoded, post_dev_dres, post_dev_cres;
   const wfst_lm *post_dev_o = nullptr, *post_dev_n = nullptr;
-  struct DetLattice { int32_t n_states = 0, n_proper = 0, err = 0; std::vector<int4> a; std::vector<float2> w; unsigned long long ticks = 0; };
-  DevBuf<unsigned long long> det_ticks;
+  struct DetLattice { int32_t n_states = 0, n_proper = 0, err = 0; std::vector<int4> a; std::vector<float2> w; };
   std::vector<DetLattice> det_cache;
   std::vector<char> det_cached;
   std::vector<int32_t> det_live_nd;   // NumFramesDecoded() the cached lattice of a LIVE channel belongs to (-1: none)
@@ -253,19 +225,6 @@ struct wfst_decoder {
   std::vector<char> pf_have;
   std::vector<int32_t> fin_epoch, pf_epoch;   // FinalizeDecoding calls per channel; ... as of the pending prefetch
   std::vector<int32_t> pf_list, pf_res;
-  // the n-best of a prefetch (wfst_decoder_prefetch_*_nbest): NShortestPath of every determinized lattice right behind the
-  // determinizer on its stream -- workspaces of their own (the decoder's stream may run a batched n-best of its own meanwhile),
-  // bounded per lattice (kPfNpStates / kPfNpArcs: a determinized lattice of a few seconds of speech has a few hundred of each;
-  // a larger one reports "not computed" and is asked for alone), results landing in pinned memory with the lattices' result words
-  int32_t pf_npaths = 0;              // of the prefetch in flight / last harvested (0: lattices only)
-  DevBuf<int32_t> pf_np_ws, pf_np_arcs, pf_np_off, pf_np_out;
-  DevBuf<NbPathEntry> pf_np_lists;
-  DevBuf<float> pf_np_tot;
-  int32_t pf_np_slots = 0, pf_np_n = 0;
-  void *pf_np_pin = nullptr;
-  size_t pf_np_pin_bytes = 0;
-  std::vector<NbPaths> pf_nbp;        // [channel] detached prefetches: the paths of the utterance the prefetched lattice belongs to
-  std::vector<char> pf_nbp_have;
   int32_t *pf_pin = nullptr;          // [2][n_channels * 4] pinned: the channel list going up, the launch's result words coming down (a copy from or
                                       // to pageable memory would hold the calling thread until the launch is over)
   DevBuf<int32_t> pf_dev;
@@ -284,11 +243,8 @@ struct wfst_decoder {
   size_t bp_pin_bytes = 0;
   size_t lat_pin_bytes = 0;
   std::vector<int32_t> lat_cache_nd;
-  float *hist_slab = nullptr;          // advance_host's device copy of the rows handed over: ONE allocation, hist_cap rows per channel
-  int32_t hist_slab_stride = 0;        // ... of this many floats
-  size_t hist_cap = 0;                 // (uniform pitch: equally spaced page-locked rows of many channels go up as one 2-D copy)
-  std::vector<float *> hist_dev;       // [channel] = hist_slab + channel * hist_cap * hist_stride
-  std::vector<size_t> hist_rows_cap;   // (= hist_cap)
+  std::vector<float *> hist_dev;
+  std::vector<size_t> hist_rows_cap;
   std::vector<int32_t> hist_rows;
   int32_t hist_stride = 0;
   int tiles_per_channel = 16;
@@ -325,30 +281,20 @@ struct wfst_decoder {
     if (pf_ev_done) (void)hipEventDestroy(pf_ev_done);
     if (lat_pin) (void)hipHostFree(lat_pin);
     if (bp_pin) (void)hipHostFree(bp_pin);
-    if (hist_slab) (void)hipFree(hist_slab);
+    for (float *p : hist_dev)
+      if (p) (void)hipFree(p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipStream_t st : gstreams) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t ev : gevents) (void)hipEventDestroy(ev);
     if (p_target) (void)hipHostFree(p_target);
-    for (hipEvent_t ev : stage_ev) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : chan_stage_ev) if (ev) (void)hipEventDestroy(ev);
-    if (copy_ev) (void)hipEventDestroy(copy_ev);
-    for (hipEvent_t ev : mark_ev) if (ev) (void)hipEventDestroy(ev);
-    if (res_stream) (void)hipStreamDestroy(res_stream);
-    if (res_chan_pin) (void)hipHostFree(res_chan_pin);
-    if (bp_ctl_pin) (void)hipHostFree(bp_ctl_pin);
-    if (bp_deg_pin) (void)hipHostFree(bp_deg_pin);
-    res_chan_list.release();
     if (p_chan) (void)hipHostFree(p_chan);
     if (p_ll) (void)hipHostFree((void *)p_ll);
     if (p_ctl) (void)hipHostFree(p_ctl);
     if (pf_pin) (void)hipHostFree(pf_pin);
-    if (pf_np_pin) (void)hipHostFree(pf_np_pin);
-    pf_np_ws.release(); pf_np_arcs.release(); pf_np_off.release(); pf_np_out.release(); pf_np_lists.release(); pf_np_tot.release();
     if (det_pack_pin) (void)hipHostFree(det_pack_pin);
     pair_keys.release(); pair_list.release(); eps_keys.release(); tok_lm.release(); bucket_lm.release(); remap.release();
-    det_ws.release(); det_result.release(); det_ticks.release(); det_out_a.release(); det_out_w.release(); det_pack_a.release(); det_pack_w.release(); pf_dev.release();
+    det_ws.release(); det_result.release(); det_out_a.release(); det_out_w.release(); det_pack_a.release(); det_pack_w.release(); pf_dev.release();
     cmp_ws.release(); cmp_result.release(); cmp_fin.release(); cmp_out_a.release(); cmp_out_w.release();
     np_ws.release(); np_out.release(); np_off.release(); np_arcs.release(); np_tot.release(); np_lists.release();
     ctl.release(); tok.release(); frame_off.release(); bucket_cnt.release(); emit_cnt.release(); prune_par.release();
@@ -1091,16 +1037,9 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
   A(d->target.alloc(B));
   A(d->chan_list.alloc(B));
   A(d->ll_base.alloc(B));
-  A(hipHostMalloc((void **)&d->p_target, wfst_decoder::kStage * B * 4));
-  A(hipHostMalloc((void **)&d->p_chan, wfst_decoder::kStage * B * 4));
-  for (int k = 0; k < wfst_decoder::kStage; ++k) A(hipEventCreateWithFlags(&d->chan_stage_ev[k], hipEventDisableTiming));
-  A(hipHostMalloc((void **)&d->p_ll, wfst_decoder::kStage * B * sizeof(float *)));
-  for (int k = 0; k < wfst_decoder::kStage; ++k) A(hipEventCreateWithFlags(&d->stage_ev[k], hipEventDisableTiming));
-  A(hipEventCreateWithFlags(&d->copy_ev, hipEventDisableTiming));
-  for (int k = 0; k < wfst_decoder::kMarkRing; ++k) A(hipEventCreateWithFlags(&d->mark_ev[k], hipEventDisableTiming));
-  d->chan_mark.assign(B, -1);
-  A(hipHostMalloc((void **)&d->res_chan_pin, B * 4));
-  A(d->res_chan_list.alloc(B));
+  A(hipHostMalloc((void **)&d->p_target, B * 4));
+  A(hipHostMalloc((void **)&d->p_chan, B * 4));
+  A(hipHostMalloc((void **)&d->p_ll, B * sizeof(float *)));
   A(hipHostMalloc((void **)&d->p_ctl, B * sizeof(ChanCtl)));
   if (e == hipSuccess) A(hipMemsetAsync(d->ctl.p, 0, d->ctl.bytes(), d->stream));
   if (e == hipSuccess) A(hipMemsetAsync(d->bucket_cnt.p, 0, d->bucket_cnt.bytes(), d->stream));
@@ -1286,12 +1225,6 @@ int wfst_decoder_create_biglm(const wfst_graph *g, const wfst_config *cfg, int32
     for (auto &ev : d->gevents) if (ge == hipSuccess) ge = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (ge != hipSuccess) { delete d; return fail(WFST_E_DEVICE, "stream/event creation failed"); }
   }
-  if (d->D.lattice && d->D.prune_raw) {
-    // the raw launch's workgroups wait for each other: taken only where every workgroup of all the groups' launches is resident at
-    // once (a smaller or partitioned part: the one-workgroup walk, always sound)
-    const int per = (n_channels + d->n_groups - 1) / d->n_groups;
-    if ((long long)prune_raw_resident_workgroups(d->device) < (long long)prune_raw_grid(per) * d->n_groups) d->D.prune_raw = 0;
-  }
   d->expand_wgs = O.expand_workgroups;
   d->insert_wgs = O.insert_workgroups;
   d->gpar.assign(8, 0);
@@ -1344,34 +1277,6 @@ void wfst_decoder_free(wfst_decoder *d) {
   delete d;
 }
 
-// An event behind what has just been enqueued for the listed channels (nullptr: all) on the decoder's stream.
-static int mark_channels(wfst_decoder *d, const int32_t *channels, int32_t cnt, bool frames = false) {
-  const int k = d->mark_next;
-  d->mark_frames[k] = frames;
-  if (d->chan_serial.empty()) d->chan_serial.assign((size_t)d->n_channels, 0);
-  for (int i = 0; i < cnt; ++i) {
-    const size_t c = (size_t)(channels ? channels[i] : i);
-    ++d->chan_serial[c];
-    if (!d->deg_cache.empty()) d->deg_cache[c] = -1;
-  }
-  d->mark_next = (k + 1) % wfst_decoder::kMarkRing;
-  ++d->mark_count;
-  HIP_TRY(hipEventRecord(d->mark_ev[k], d->stream));
-  for (int i = 0; i < cnt; ++i) d->chan_mark[(size_t)(channels ? channels[i] : i)] = k;
-  return WFST_OK;
-}
-// The results stream, made to wait for the listed channels' last enqueued work (and nothing newer).
-static int results_stream_behind(wfst_decoder *d, const int32_t *channels, int32_t cnt, hipStream_t *out) {
-  if (!d->res_stream) HIP_TRY(hipStreamCreateWithFlags(&d->res_stream, hipStreamNonBlocking));
-  bool waited[wfst_decoder::kMarkRing] = {};
-  for (int i = 0; i < cnt; ++i) {
-    const int k = d->chan_mark[(size_t)channels[i]];
-    if (k >= 0 && !waited[k]) { HIP_TRY(hipStreamWaitEvent(d->res_stream, d->mark_ev[k], 0)); waited[k] = true; }
-  }
-  *out = d->res_stream;
-  return WFST_OK;
-}
-
 // Resolve a channel list: returns the device pointer to use (nullptr = all channels) and count.
 static int stage_channels(wfst_decoder *d, const int32_t *channels, int32_t n, const int32_t **dev, int32_t *cnt) {
   if (!channels) {
@@ -1386,15 +1291,9 @@ static int stage_channels(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (seen[channels[i]]) return fail(WFST_E_ARG, "duplicate channel in list");
     seen[channels[i]] = 1;
   }
-  // (page-locked staging sets in rotation, as advance_device's: a list waits for the upload that used its set kStage lists ago, not
-  // for the frames the stream is still decoding)
-  const int stage = d->chan_stage_next;
-  d->chan_stage_next = (d->chan_stage_next + 1) % wfst_decoder::kStage;
-  HIP_TRY(hipEventSynchronize(d->chan_stage_ev[stage]));
-  int32_t *p_chan = d->p_chan + (size_t)stage * d->n_channels;
-  memcpy(p_chan, channels, (size_t)n * 4);
-  HIP_TRY(hipMemcpyAsync(d->chan_list.p, p_chan, (size_t)n * 4, hipMemcpyHostToDevice, d->stream));
-  HIP_TRY(hipEventRecord(d->chan_stage_ev[stage], d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));  // staging buffer reuse
+  memcpy(d->p_chan, channels, (size_t)n * 4);
+  HIP_TRY(hipMemcpyAsync(d->chan_list.p, d->p_chan, (size_t)n * 4, hipMemcpyHostToDevice, d->stream));
   *dev = d->chan_list.p;
   *cnt = n;
   return WFST_OK;
@@ -1412,7 +1311,6 @@ int wfst_decoder_init(wfst_decoder *d, const int32_t *channels, int32_t n) {
   if (rc != WFST_OK) return rc;
   launch_init(d->D, dev, cnt, d->stream);
   HIP_TRY(hipGetLastError());
-  { const int rcm = mark_channels(d, channels, cnt); if (rcm != WFST_OK) return rcm; }
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     d->h_decoded[c] = 0;
@@ -1467,14 +1365,7 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (loglikes[i] && loglikes[i] != d->h_ll_base[c]) moved = true;
   }
   if (steps == 0 && !moved) return WFST_OK;
-  // The targets and row pointers go up through page-locked staging sets used in rotation: a call waits for the upload that used ITS
-  // set kStage calls ago (long done), not for everything the stream holds -- a host that hands over chunk after chunk (the channel
-  // pool's batcher, a streaming service) enqueues the next chunk's frames while the device still decodes this one's.
-  const int stage = d->stage_next;
-  d->stage_next = (d->stage_next + 1) % wfst_decoder::kStage;
-  HIP_TRY(hipEventSynchronize(d->stage_ev[stage]));   // (never recorded: returns at once)
-  int32_t *p_target = d->p_target + (size_t)stage * d->n_channels;
-  const float **p_ll = d->p_ll + (size_t)stage * d->n_channels;
+  HIP_TRY(hipStreamSynchronize(d->stream));  // pinned staging reuse
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     int target = n_frames_ready[i];
@@ -1483,13 +1374,12 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
     if (loglikes[i]) d->h_ll_base[c] = loglikes[i];
   }
   for (int c = 0; c < d->n_channels; ++c) {
-    p_target[c] = d->h_target[c];
-    p_ll[c] = d->h_ll_base[c];
+    d->p_target[c] = d->h_target[c];
+    d->p_ll[c] = d->h_ll_base[c];
   }
-  HIP_TRY(hipMemcpyAsync(d->target.p, p_target, (size_t)d->n_channels * 4, hipMemcpyHostToDevice, d->stream));
-  HIP_TRY(hipMemcpyAsync((void *)d->ll_base.p, (const void *)p_ll, (size_t)d->n_channels * sizeof(float *),
+  HIP_TRY(hipMemcpyAsync(d->target.p, d->p_target, (size_t)d->n_channels * 4, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipMemcpyAsync((void *)d->ll_base.p, (const void *)d->p_ll, (size_t)d->n_channels * sizeof(float *),
                          hipMemcpyHostToDevice, d->stream));
-  HIP_TRY(hipEventRecord(d->stage_ev[stage], d->stream));
   d->D.stride = stride;
   {
     // expand_kernel_staged_row (wfst_kernels.hip): the frame's log-likelihood row of a tile's channel staged in LDS by 16-byte DMAs
@@ -1629,7 +1519,6 @@ static int advance_device(wfst_decoder *d, const int32_t *channels, int32_t n, c
       if (gsteps[g] != 0) HIP_TRY(hipStreamWaitEvent(d->stream, d->gevents[1 + g], 0));
   }
   HIP_TRY(hipGetLastError());
-  { const int rcm = mark_channels(d, channels, cnt, true); if (rcm != WFST_OK) return rcm; }
   for (int g = 0; g < G; ++g) d->gpar[g] = gpar0[g] ^ (gsteps[g] & 1);
   for (int c = 0; c < d->n_channels; ++c) d->h_decoded[c] = std::max(d->h_decoded[c], d->h_target[c]);
   return WFST_OK;
@@ -1656,52 +1545,29 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
   }
   d->hist_stride = stride;
   std::vector<const float *> dev_ptrs((size_t)cnt);
-  size_t need_rows = 0;
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     if (c < 0 || c >= d->n_channels) return fail(WFST_E_ARG, "channel index out of range");
     const int32_t have = d->hist_rows[c], want = n_frames_ready[i];
     if (want < have) return fail(WFST_E_ARG, "NumFramesReady decreased");
-    if (want > have && !loglikes_host[i]) return fail(WFST_E_ARG, "NULL log-likelihood matrix");
-    need_rows = std::max(need_rows, (size_t)want);
-  }
-  if (need_rows > d->hist_cap || (d->hist_slab && d->hist_slab_stride != stride)) {
-    // The histories of all channels are one allocation of uniform pitch.  (A decoder created with a small wfst_limits.max_frames --
-    // a caller that sizes its utterances -- gets the whole history at once: regrowing costs an allocation, a device copy and a free
-    // that waits for the device.)
-    size_t ncap = std::max<size_t>(need_rows, std::max<size_t>(d->hist_cap * 2, 256));
-    if (d->D.max_frames <= 1024) ncap = std::max<size_t>(ncap, (size_t)d->D.max_frames);
-    ncap = std::min<size_t>(ncap, std::max<size_t>(need_rows, (size_t)d->D.max_frames));   // (no utterance is longer than max_frames)
-    float *np = nullptr;
-    if (d->copy_stream) HIP_TRY(hipStreamSynchronize(d->copy_stream));   // (rows of page-locked buffers may still be on their way into the old history)
-    HIP_TRY(hipMalloc((void **)&np, (size_t)d->n_channels * ncap * (size_t)stride * 4));
-    size_t keep = 0;
-    for (int c = 0; c < d->n_channels; ++c) keep = std::max(keep, (size_t)d->hist_rows[c]);
-    if (d->hist_slab && keep > 0 && d->hist_slab_stride == stride) {
-      // (on the decoder's own stream, not the legacy one: another decoder of the process may be capturing its frame loop in
-      // another thread -- the service's one-decoder-per-thread shape -- and the legacy stream refuses to work beside a capture)
-      HIP_TRY(hipMemcpy2DAsync(np, ncap * (size_t)stride * 4, d->hist_slab, d->hist_cap * (size_t)stride * 4, keep * (size_t)stride * 4,
-                               (size_t)d->n_channels, hipMemcpyDeviceToDevice, d->stream));
-    }
-    if (d->hist_slab) {
-      HIP_TRY(hipStreamSynchronize(d->stream));
-      // channels that read their rows from the old allocation follow it: the listed ones through advance_device (which sees their
-      // pointers move and uploads ALL row pointers), the others here
-      std::vector<char> listed((size_t)d->n_channels, 0);
-      for (int i = 0; i < cnt; ++i) listed[(size_t)(channels ? channels[i] : i)] = 1;
-      for (int c = 0; c < d->n_channels; ++c)
-        if (!listed[(size_t)c] && d->h_ll_base[c] == d->hist_dev[c] && d->hist_dev[c]) d->h_ll_base[c] = np + (size_t)c * ncap * (size_t)stride;
-      HIP_TRY(hipFree(d->hist_slab));
-    }
-    d->hist_slab = np;
-    d->hist_cap = ncap;
-    d->hist_slab_stride = stride;
-    for (int c = 0; c < d->n_channels; ++c) {
-      d->hist_dev[c] = np + (size_t)c * ncap * (size_t)stride;
+    if ((size_t)want > d->hist_rows_cap[c]) {
+      size_t ncap = std::max<size_t>((size_t)want, std::max<size_t>(d->hist_rows_cap[c] * 2, 256));
+      float *np = nullptr;
+      HIP_TRY(hipMalloc((void **)&np, ncap * (size_t)stride * 4));
+      if (have > 0) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        HIP_TRY(hipMemcpy(np, d->hist_dev[c], (size_t)have * stride * 4, hipMemcpyDeviceToDevice));
+      }
+      if (d->hist_dev[c]) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        HIP_TRY(hipFree(d->hist_dev[c]));
+      }
+      d->hist_dev[c] = np;
       d->hist_rows_cap[c] = ncap;
     }
+    if (want > have && !loglikes_host[i]) return fail(WFST_E_ARG, "NULL log-likelihood matrix");
+    dev_ptrs[i] = d->hist_dev[c];
   }
-  for (int i = 0; i < cnt; ++i) dev_ptrs[i] = d->hist_dev[channels ? channels[i] : i];
   // Upload and decode in slices of kSlice frames: the host copies slice k+1 (pageable memory: the
   // copy call returns when the caller's buffer is consumed) while the GPU decodes slice k, so the
   // PCIe time of a long hand-over hides behind the search instead of preceding it.
@@ -1711,93 +1577,24 @@ int wfst_decoder_advance_host(wfst_decoder *d, const int32_t *channels, int32_t 
   for (int i = 0; i < cnt; ++i) longest = std::max(longest, n_frames_ready[i] - d->hist_rows[channels ? channels[i] : i]);
   const bool sliced = max_num_frames < 0 && d->upload_slice > 0 && longest > 2 * kSlice;
   std::vector<int32_t> ready((size_t)cnt);
-  // PAGE-LOCKED rows (wfst_host_alloc, or any memory the caller has registered with HIP): the copies are true DMAs -- the decode
-  // stream waits for them through an event and this call returns when everything is ENQUEUED, like wfst_decoder_advance; the rows
-  // handed over must then stay valid and unchanged until the channel's frames are decoded (any getter, or wfst_decoder_sync), which
-  // a caller that keeps its rows for the utterance -- the contract of the device-pointer call -- does anyway.  Pageable rows: the
-  // copy call returns when the buffer is consumed, and the call waits for the copies before it enqueues the frames (below).
-  bool all_pinned = true;
-  {
-    if (d->hist_src.empty()) { d->hist_src.assign((size_t)d->n_channels, nullptr); d->hist_src_pinned.assign((size_t)d->n_channels, 0); }
-    for (int i = 0; i < cnt && all_pinned; ++i) {
-      const int c = channels ? channels[i] : i;
-      if (!loglikes_host[i]) { continue; }
-      if (d->hist_src[(size_t)c] != loglikes_host[i]) {
-        hipPointerAttribute_t at;
-        const hipError_t pe = hipPointerGetAttributes(&at, loglikes_host[i]);
-        if (pe != hipSuccess) (void)hipGetLastError();
-        d->hist_src[(size_t)c] = loglikes_host[i];
-        d->hist_src_pinned[(size_t)c] = (pe == hipSuccess && at.type == hipMemoryTypeHost) ? 1 : 0;
-      }
-      all_pinned = d->hist_src_pinned[(size_t)c] != 0;
-    }
-  }
-  // slices (a long hand-over) or everything at once; page-locked rows: every slice's copies and frames are enqueued one behind the
-  // other -- the copy engine is a slice ahead of the search, the host waits for neither
-  // (the FIRST slice stands in front of the first frame: page-locked rows start with short slices -- a sixth, a third, a half of
-  // kSlice -- and the search starts a sixth of a slice's upload after the call)
-  auto slice_at = [&](int done) {
-    if (!sliced) return std::max(longest, 1);
-    if (!all_pinned || kSlice < 12) return kSlice;
-    if (done >= 2 * kSlice) return 2 * kSlice;   // (... and long ones once the uploads are well ahead: every slice is a call of its own)
-    return done == 0 ? kSlice / 6 : done == kSlice / 6 ? kSlice / 3 : done == kSlice / 6 + kSlice / 3 ? kSlice - kSlice / 6 - kSlice / 3 : kSlice;
-  };
-  for (int done = 0, step = slice_at(0); done < std::max(longest, 1); done += step, step = slice_at(done)) {
-    const int upto = sliced ? done + step : longest;
-    // Page-locked rows of CONSECUTIVE channels that lie equally spaced in host memory (one matrix of utterances; the channel pool's
-    // row slab) and cover the same frames go up as ONE 2-D copy -- a copy per channel costs the engine ~7 us each before it moves
-    // a byte: 128 chunks of 300 KB take 2.0 ms one by one, 0.68 ms as one 2-D copy (tools/ubench_h2d.hip).
-    for (int i = 0; i < cnt;) {
+  for (int done = 0; done < std::max(longest, 1); done += sliced ? kSlice : std::max(longest, 1)) {
+    const int upto = sliced ? done + kSlice : longest;
+    for (int i = 0; i < cnt; ++i) {
       const int c = channels ? channels[i] : i;
       const int32_t have = d->hist_rows[c];
       const int32_t want = std::min<int32_t>(n_frames_ready[i], have + std::max(0, upto - done));
-      int run = 1;
-      if (want > have && all_pinned) {
-        ptrdiff_t pitch = 0;
-        for (int j = i + 1; j < cnt; ++j) {
-          const int cj = channels ? channels[j] : j;
-          if (cj != c + (j - i) || d->hist_rows[cj] != have) break;
-          if (std::min<int32_t>(n_frames_ready[j], have + std::max(0, upto - done)) != want || !loglikes_host[j]) break;
-          const intptr_t step_bytes = (intptr_t)(uintptr_t)loglikes_host[j] - (intptr_t)(uintptr_t)loglikes_host[j - 1];   // (maybe unrelated allocations: no pointer arithmetic)
-          if (step_bytes % 4 != 0) break;
-          const ptrdiff_t step = (ptrdiff_t)(step_bytes / 4);
-          if (j == i + 1) pitch = step;
-          if (step != pitch || pitch < (ptrdiff_t)((size_t)want * stride)) break;   // (equally spaced, one channel's rows not inside the next's)
-          run = j - i + 1;
-        }
-        if (run > 1) {
-          HIP_TRY(hipMemcpy2DAsync(d->hist_dev[c] + (size_t)have * stride, d->hist_cap * (size_t)stride * 4, loglikes_host[i] + (size_t)have * stride,
-                                   (size_t)pitch * 4, (size_t)(want - have) * stride * 4, (size_t)run, hipMemcpyHostToDevice, d->copy_stream));
-          for (int j = i; j < i + run; ++j) d->hist_rows[channels ? channels[j] : j] = want;
-        }
-      }
-      if (want > have && run == 1) {
+      if (want > have) {
         HIP_TRY(hipMemcpyAsync(d->hist_dev[c] + (size_t)have * stride, loglikes_host[i] + (size_t)have * stride,
                                (size_t)(want - have) * stride * 4, hipMemcpyHostToDevice, d->copy_stream));
         d->hist_rows[c] = want;
       }
-      for (int j = i; j < i + run; ++j) ready[j] = d->hist_rows[channels ? channels[j] : j];
-      i += run;
+      ready[i] = d->hist_rows[c];
     }
-    if (all_pinned) {
-      HIP_TRY(hipEventRecord(d->copy_ev, d->copy_stream));
-      HIP_TRY(hipStreamWaitEvent(d->stream, d->copy_ev, 0));   // the frames' kernels run behind the rows; the host does not wait
-    } else {
-      HIP_TRY(hipStreamSynchronize(d->copy_stream));  // rows are in HBM (and the caller's buffers consumed)
-    }
+    HIP_TRY(hipStreamSynchronize(d->copy_stream));  // rows are in HBM (and the caller's buffers consumed)
     const int rc = advance_device(d, channels, n, dev_ptrs.data(), ready.data(), stride, max_num_frames);
     if (rc != WFST_OK) return rc;
   }
   return WFST_OK;
-}
-
-void *wfst_host_alloc(size_t bytes) {
-  void *p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  return p;
-}
-void wfst_host_free(void *p) {
-  if (p) (void)hipHostFree(p);
 }
 
 int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
@@ -1815,7 +1612,6 @@ int wfst_decoder_finalize(wfst_decoder *d, const int32_t *channels, int32_t n) {
   launch_set_finalized(d->D, dev, cnt, d->stream);
   if (d->D.lattice) launch_lattice_prune(d->D, dev, cnt, d->stream);  // PruneForwardLinksFinal + backward pruning
   HIP_TRY(hipGetLastError());
-  { const int rcm = mark_channels(d, channels, cnt); if (rcm != WFST_OK) return rcm; }
   for (int i = 0; i < cnt; ++i) {
     const int c = channels ? channels[i] : i;
     d->h_state[c] = 2;
@@ -1865,55 +1661,33 @@ int wfst_decoder_sync(wfst_decoder *d) {
   return check_ctl_errors(d);
 }
 
-int wfst_decoder_busy(wfst_decoder *d) {
-  if (!d) return fail(WFST_E_ARG, "NULL decoder");
-  HIP_TRY(hipSetDevice(d->device));
-  const hipError_t e = hipStreamQuery(d->stream);   // (the channel groups' streams join the decoder's own at the end of every advance)
-  if (e == hipSuccess) return 0;
-  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
-  return fail(WFST_E_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
-}
-
-int wfst_decoder_calls_in_flight(wfst_decoder *d) {
-  if (!d) return fail(WFST_E_ARG, "NULL decoder");
-  HIP_TRY(hipSetDevice(d->device));
-  // the marks behind the enqueued calls, newest first: the stream runs them in order, so the first one that has completed ends
-  // the count; only calls that brought frames count (an init or a finalize between two of them is microseconds of work)
-  const int have = (int)std::min<long long>(d->mark_count, wfst_decoder::kMarkRing);
-  int n = 0;
-  for (int i = 0; i < have; ++i) {
-    const int k = (d->mark_next - 1 - i + 2 * wfst_decoder::kMarkRing) % wfst_decoder::kMarkRing;
-    const hipError_t e = hipEventQuery(d->mark_ev[k]);
-    if (e == hipSuccess) break;
-    if (e != hipErrorNotReady) return fail(WFST_E_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(e));
-    (void)hipGetLastError();
-    if (d->mark_frames[k]) ++n;
-  }
-  return n;
-}
-
 int wfst_decoder_num_frames_decoded(wfst_decoder *d, int32_t channel) {
   if (!d || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad decoder/channel");
   return d->h_decoded[channel];
 }
 
-// ---- GetBestPath of a channel LIST in two halves: enqueue (never waits) / fetch -------------------------------------------------------
-// A host that batches many decoder objects (the channel pool's batcher thread) must not stand still while a finished utterance's best
-// path waits for that utterance's last frames: the kernel and the copies are enqueued on the results stream behind the listed
-// channels' own work, the batcher goes on feeding the device, and the results are taken when they have landed.  One request may be
-// outstanding per decoder; the state it holds (the list, the result block in page-locked memory, a copy of the control blocks of
-// its own) is touched by nothing else meanwhile.
-static int bp_buffers(wfst_decoder *d, size_t words, size_t need, int32_t cap = 0) {
-  if (cap > 0) {
-    // (list requests: room for EVERY channel at this capacity, once -- lists of growing length would otherwise regrow the buffers
-    // call after call, and a regrowth waits for the device)
-    const size_t all_need = (size_t)d->n_channels * (size_t)cap, all_head = ((size_t)d->n_channels + 3) & ~(size_t)3;
-    need = std::max(need, all_need);
-    words = std::max(words, all_head + 4 * all_need);
+int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs,
+                               int32_t cap, int32_t *ilabel, int32_t *olabel, float *graph_cost,
+                               float *acoustic_cost, int32_t *n_hops) {
+  if (!d || !ilabel || !olabel || !graph_cost || !acoustic_cost || !n_hops || cap <= 0)
+    return fail(WFST_E_ARG, "NULL output or cap <= 0");
+  HIP_TRY(hipSetDevice(d->device));
+  const int32_t *dev;
+  int32_t cnt;
+  int rc = stage_channels(d, channels, n, &dev, &cnt);
+  if (rc != WFST_OK) return rc;
+  for (int i = 0; i < cnt; ++i) {
+    const int c = channels ? channels[i] : i;
+    if (d->h_state[c] == 0) return fail(WFST_E_STATE, "GetBestPath before InitDecoding");
+    if (d->h_state[c] == 2 && !use_final_probs)  // base-inl.h:1100-1102 (LOG_ERR)
+      return fail(WFST_E_STATE, "You cannot call FinalizeDecoding() and then GetBestPath with use_final_probs == false");
   }
+  const size_t need = (size_t)cnt * (size_t)cap;
+  // one device block {n_hops[cnt] (padded to 4 words) | ilabel | olabel | graph | acoustic} -> one copy into pinned
+  // host memory -> the caller's arrays (five copies into pageable memory cost five staging round trips)
+  const size_t head = ((size_t)cnt + 3) & ~(size_t)3, words = head + 4 * need;
   if (d->bp_all.n < words || d->bp_chain.n < need) {
     HIP_TRY(hipStreamSynchronize(d->stream));
-    if (d->res_stream) HIP_TRY(hipStreamSynchronize(d->res_stream));
     HIP_TRY(d->bp_all.alloc(words));
     HIP_TRY(d->bp_chain.alloc(need));
   }
@@ -1924,118 +1698,6 @@ static int bp_buffers(wfst_decoder *d, size_t words, size_t need, int32_t cap = 
     HIP_TRY(hipHostMalloc((void **)&d->bp_pin, words * 4, hipHostMallocDefault));
     d->bp_pin_bytes = words * 4;
   }
-  return WFST_OK;
-}
-
-int wfst_decoder_best_path_enqueue(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs, int32_t cap) {
-  if (!d || !channels || cap <= 0) return fail(WFST_E_ARG, "NULL decoder / channel list, or cap <= 0");
-  if (d->bp_out_n > 0) return fail(WFST_E_STATE, "a best-path request is outstanding (wfst_decoder_best_path_fetch takes it)");
-  HIP_TRY(hipSetDevice(d->device));
-  if (n <= 0 || n > d->n_channels) return fail(WFST_E_ARG, "bad channel count");
-  std::vector<char> seen((size_t)d->n_channels, 0);
-  for (int i = 0; i < n; ++i) {
-    if (channels[i] < 0 || channels[i] >= d->n_channels) return fail(WFST_E_ARG, "channel index out of range");
-    if (seen[(size_t)channels[i]]) return fail(WFST_E_ARG, "duplicate channel in list");
-    seen[(size_t)channels[i]] = 1;
-    const int c = channels[i];
-    if (d->h_state[c] == 0) return fail(WFST_E_STATE, "GetBestPath before InitDecoding");
-    if (d->h_state[c] == 2 && !use_final_probs)  // base-inl.h:1100-1102 (LOG_ERR)
-      return fail(WFST_E_STATE, "You cannot call FinalizeDecoding() and then GetBestPath with use_final_probs == false");
-  }
-  hipStream_t st;
-  int rc = results_stream_behind(d, channels, n, &st);   // behind these channels' own work only (see mark_ev)
-  if (rc != WFST_OK) return rc;
-  const size_t need = (size_t)n * (size_t)cap, head = ((size_t)n + 3) & ~(size_t)3, words = head + 4 * need;
-  rc = bp_buffers(d, words, need, cap);
-  if (rc != WFST_OK) return rc;
-  if (!d->bp_ctl_pin) HIP_TRY(hipHostMalloc((void **)&d->bp_ctl_pin, d->ctl.bytes(), hipHostMallocDefault));
-  memcpy(d->res_chan_pin, channels, (size_t)n * 4);   // (the results stream is idle here: nothing is outstanding)
-  HIP_TRY(hipMemcpyAsync(d->res_chan_list.p, d->res_chan_pin, (size_t)n * 4, hipMemcpyHostToDevice, st));
-  int32_t *dn = d->bp_all.p, *dil = dn + head, *dol = dil + need;
-  float *dg = reinterpret_cast<float *>(dol + need), *dac = dg + need;
-  launch_best_path(d->D, d->res_chan_list.p, n, use_final_probs ? 1 : 0, cap, dil, dol, dg, dac, dn, d->bp_chain.p, st);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(d->bp_pin, d->bp_all.p, words * 4, hipMemcpyDeviceToHost, st));
-  // (the listed channels' control blocks are final behind their marks; the others' are not looked at)
-  HIP_TRY(hipMemcpyAsync(d->bp_ctl_pin, d->ctl.p, d->ctl.bytes(), hipMemcpyDeviceToHost, st));
-  if (!d->bp_deg_pin) HIP_TRY(hipHostMalloc((void **)&d->bp_deg_pin, d->degraded.bytes(), hipHostMallocDefault));
-  HIP_TRY(hipMemcpyAsync(d->bp_deg_pin, d->degraded.p, d->degraded.bytes(), hipMemcpyDeviceToHost, st));
-  d->bp_out.assign(channels, channels + n);
-  if (d->chan_serial.empty()) d->chan_serial.assign((size_t)d->n_channels, 0);
-  d->bp_out_serial.resize((size_t)n);
-  for (int i = 0; i < n; ++i) d->bp_out_serial[(size_t)i] = d->chan_serial[(size_t)channels[i]];
-  d->bp_out_n = n;
-  d->bp_out_cap = cap;
-  return WFST_OK;
-}
-
-int wfst_decoder_best_path_ready(wfst_decoder *d) {
-  if (!d) return fail(WFST_E_ARG, "NULL decoder");
-  if (d->bp_out_n <= 0) return fail(WFST_E_STATE, "no best-path request is outstanding");
-  HIP_TRY(hipSetDevice(d->device));
-  const hipError_t e = hipStreamQuery(d->res_stream);
-  if (e == hipSuccess) return 1;
-  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
-  return fail(WFST_E_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
-}
-
-int wfst_decoder_best_path_fetch(wfst_decoder *d, int32_t *ilabel, int32_t *olabel, float *graph_cost, float *acoustic_cost, int32_t *n_hops) {
-  if (!d || !ilabel || !olabel || !graph_cost || !acoustic_cost || !n_hops) return fail(WFST_E_ARG, "NULL output");
-  if (d->bp_out_n <= 0) return fail(WFST_E_STATE, "no best-path request is outstanding");
-  HIP_TRY(hipSetDevice(d->device));
-  const int32_t cnt = d->bp_out_n, cap = d->bp_out_cap;
-  d->bp_out_n = 0;   // (taken, whatever it turns out to hold)
-  HIP_TRY(hipStreamSynchronize(d->res_stream));
-  const size_t need = (size_t)cnt * (size_t)cap, head = ((size_t)cnt + 3) & ~(size_t)3;
-  const int32_t *hp = reinterpret_cast<const int32_t *>(d->bp_pin);
-  memcpy(n_hops, hp, (size_t)cnt * 4);
-  memcpy(ilabel, hp + head, need * 4);
-  memcpy(olabel, hp + head + need, need * 4);
-  memcpy(graph_cost, hp + head + 2 * need, need * 4);
-  memcpy(acoustic_cost, hp + head + 3 * need, need * 4);
-  // a device error of ANOTHER channel's utterance is that channel's, not this request's
-  for (int i = 0; i < cnt; ++i) {
-    const int c = d->bp_out[(size_t)i];
-    if (d->bp_ctl_pin[c].error) return fail_ctl_error(c, d->bp_ctl_pin[c].error);
-  }
-  // (the listed channels' counts of frames on which the token limit bound: read behind their own work, like the paths)
-  if (d->deg_cache.empty()) d->deg_cache.assign((size_t)d->n_channels, -1);
-  for (int i = 0; i < cnt; ++i) {
-    const size_t c = (size_t)d->bp_out[(size_t)i];
-    if (d->chan_serial[c] == d->bp_out_serial[(size_t)i]) d->deg_cache[c] = d->bp_deg_pin[c];   // (no call for the channel since the list went up)
-  }
-  for (int i = 0; i < cnt; ++i)
-    if (n_hops[i] > cap) return fail(WFST_E_CAPACITY, "best path longer than cap hops; n_hops holds the needed size");
-  return WFST_OK;
-}
-
-int wfst_decoder_get_best_path(wfst_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs,
-                               int32_t cap, int32_t *ilabel, int32_t *olabel, float *graph_cost,
-                               float *acoustic_cost, int32_t *n_hops) {
-  if (!d || !ilabel || !olabel || !graph_cost || !acoustic_cost || !n_hops || cap <= 0)
-    return fail(WFST_E_ARG, "NULL output or cap <= 0");
-  HIP_TRY(hipSetDevice(d->device));
-  if (channels) {   // a LIST of channels: the two halves above, one behind the other
-    const int rc = wfst_decoder_best_path_enqueue(d, channels, n, use_final_probs, cap);
-    if (rc != WFST_OK) return rc;
-    return wfst_decoder_best_path_fetch(d, ilabel, olabel, graph_cost, acoustic_cost, n_hops);
-  }
-  if (d->bp_out_n > 0) return fail(WFST_E_STATE, "a best-path request is outstanding (wfst_decoder_best_path_fetch takes it)");
-  const int32_t *dev;
-  int32_t cnt;
-  int rc = stage_channels(d, channels, n, &dev, &cnt);
-  if (rc != WFST_OK) return rc;
-  for (int c = 0; c < cnt; ++c) {
-    if (d->h_state[c] == 0) return fail(WFST_E_STATE, "GetBestPath before InitDecoding");
-    if (d->h_state[c] == 2 && !use_final_probs)  // base-inl.h:1100-1102 (LOG_ERR)
-      return fail(WFST_E_STATE, "You cannot call FinalizeDecoding() and then GetBestPath with use_final_probs == false");
-  }
-  const size_t need = (size_t)cnt * (size_t)cap;
-  // one device block {n_hops[cnt] (padded to 4 words) | ilabel | olabel | graph | acoustic} -> one copy into pinned
-  // host memory -> the caller's arrays (five copies into pageable memory cost five staging round trips)
-  const size_t head = ((size_t)cnt + 3) & ~(size_t)3, words = head + 4 * need;
-  rc = bp_buffers(d, words, need);
-  if (rc != WFST_OK) return rc;
   int32_t *dn = d->bp_all.p, *dil = dn + head, *dol = dil + need;
   float *dg = reinterpret_cast<float *>(dol + need), *dac = dg + need;
   launch_best_path(d->D, dev, cnt, use_final_probs ? 1 : 0, cap, dil, dol, dg, dac, dn, d->bp_chain.p, d->stream);
@@ -2479,8 +2141,6 @@ static int ensure_det_workspace(wfst_decoder *d) {
   HIP_TRY(hipStreamSynchronize(d->stream));
   HIP_TRY(d->det_ws.alloc((size_t)d->det_slots * (size_t)X.words_per_channel));
   HIP_TRY(d->det_result.alloc((size_t)d->det_slots * 4));
-  HIP_TRY(d->det_ticks.alloc((size_t)d->det_slots));
-  X.ticks = d->det_ticks.p;
   HIP_TRY(d->det_out_a.alloc((size_t)d->det_slots * (size_t)X.out_cap));
   HIP_TRY(d->det_out_w.alloc((size_t)d->det_slots * (size_t)X.out_cap));
   X.ws = d->det_ws.p;
@@ -2538,16 +2198,10 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
     HIP_TRY(hipMemcpyAsync((char *)d->det_pack_pin + total * sizeof(int4), d->det_pack_w.p, total * sizeof(float2), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
   }
-  std::vector<unsigned long long> ticks(list.size(), 0ull);
-  if (X.ticks && !list.empty()) {
-    HIP_TRY(hipMemcpyAsync(ticks.data(), X.ticks, list.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-  }
   size_t off = 0;
   for (int i = 0; i < (int)list.size(); ++i) {
     wfst_decoder::DetLattice &L = detached ? d->pf_cache[(size_t)list[i]] : d->det_cache[(size_t)list[i]];
     L.n_states = 0; L.n_proper = 0; L.a.clear(); L.w.clear();
-    L.ticks = ticks[(size_t)i];
     L.err = res[4 * i + 2];   // reported when THIS channel's lattice is asked for
     if (!detached && d->p_ctl[list[i]].error) L.err = kDetErrCtl | d->p_ctl[list[i]].error;
     if (detached) d->pf_have[(size_t)list[i]] = 1;
@@ -2599,7 +2253,7 @@ static int harvest_determinized(wfst_decoder *d, const std::vector<int32_t> &lis
 // NOW, on a side stream -- one lane per lattice, a launch as long as its largest lattice, beside which the decoder's own stream
 // serves best paths and n-best lists (both only read the raw lattices; the arena-index -> lattice-state map the n-best search
 // and the determinizer each write is the same map).  The first wfst_decoder_get_determinized_lattice finds the work done or waits.
-static int prefetch_determinized(wfst_decoder *d, bool detached, int32_t n_paths = 0);
+static int prefetch_determinized(wfst_decoder *d, bool detached);
 int wfst_decoder_prefetch_determinized(wfst_decoder *d) { return prefetch_determinized(d, false); }
 // ... DETACHED: the determinizer's first phase -- everything that reads the channels' state: control blocks, resolved lists, the
 // arena-index scratch; a fraction of a millisecond -- runs on the decoder's stream, the subset construction (tens of milliseconds on
@@ -2607,17 +2261,8 @@ int wfst_decoder_prefetch_determinized(wfst_decoder *d) { return prefetch_determ
 // the channels go on to their next utterances beside it.  The lattices are kept per channel (wfst_decoder_get_prefetched_lattice)
 // until the next detached prefetch is harvested.
 int wfst_decoder_prefetch_determinized_detached(wfst_decoder *d) { return prefetch_determinized(d, true); }
-// ... with GetNbest behind GetLattice, as the service runs them (kaldi-nnet3/kaldi-online-nnet3-my-decoder.cc:97-105: NShortestPath
-// on the lattice DeterminizeLatticeWrapper returned): the n cheapest paths of every lattice of the prefetch, computed right behind
-// the determinizer on its stream
-int wfst_decoder_prefetch_nbest(wfst_decoder *d, int32_t n_paths, int32_t detached) {
-  if (n_paths < 1 || n_paths > 64) return fail(WFST_E_ARG, "1 <= n <= 64 paths with a prefetch (more: wfst_decoder_nbest_paths_batch)");
-  return prefetch_determinized(d, detached != 0, n_paths);
-}
 
-static constexpr int32_t kPfNpStates = 4096, kPfNpArcs = 8192;   // the largest determinized lattice a prefetch's n-best takes
-
-static int prefetch_determinized(wfst_decoder *d, bool detached, int32_t n_paths) {
+static int prefetch_determinized(wfst_decoder *d, bool detached) {
   if (!d) return fail(WFST_E_ARG, "NULL decoder");
   if (!d->D.lattice) return fail(WFST_E_STATE, "GetLattice needs a decoder created with wfst_limits.lattice_links > 0");
   HIP_TRY(hipSetDevice(d->device));
@@ -2657,49 +2302,6 @@ static int prefetch_determinized(wfst_decoder *d, bool detached, int32_t n_paths
   launch_determinize(d->D, d->det, d->pf_dev.p, (int32_t)list.size(), side, detached ? 2 : 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(pin_res, d->det.result, list.size() * 4 * 4, hipMemcpyDeviceToHost, side));
-  d->pf_npaths = 0;
-  if (n_paths > 0) {
-    const int32_t cnt = (int32_t)list.size();
-    NbPathsDev P = {};
-    P.a = d->det.out_a; P.w = d->det.out_w; P.res = d->det.result; P.fin = nullptr;
-    P.in_stride = d->det.out_cap; P.fin_stride = 0;
-    P.n = n_paths;
-    P.ws_ints = 7ll * kPfNpStates + 4ll * kPfNpArcs + kPfNpArcs + 16;
-    P.list_cap = (int64_t)kPfNpStates * n_paths + 1;
-    P.out_cap = n_paths * 1024;   // arcs on a lattice's n paths together (a path of a determinized lattice: a word or an epsilon per state)
-    if (d->pf_np_slots < cnt || d->pf_np_n < n_paths) {
-      HIP_TRY(hipStreamSynchronize(side));
-      const int32_t slots = std::max(cnt, d->n_channels);
-      HIP_TRY(d->pf_np_ws.alloc((size_t)slots * (size_t)P.ws_ints));
-      HIP_TRY(d->pf_np_lists.alloc((size_t)slots * (size_t)P.list_cap));
-      HIP_TRY(d->pf_np_arcs.alloc((size_t)slots * (size_t)P.out_cap));
-      HIP_TRY(d->pf_np_off.alloc((size_t)slots * (size_t)(n_paths + 1)));
-      HIP_TRY(d->pf_np_tot.alloc((size_t)slots * (size_t)n_paths));
-      HIP_TRY(d->pf_np_out.alloc((size_t)slots * 4));
-      d->pf_np_slots = slots;
-      d->pf_np_n = n_paths;
-    }
-    // (buffers sized for pf_np_n paths serve a request for fewer: the strides below are the request's own)
-    P.ws = d->pf_np_ws.p; P.lists = d->pf_np_lists.p; P.out = d->pf_np_out.p; P.out_off = d->pf_np_off.p; P.out_tot = d->pf_np_tot.p;
-    P.out_arcs = d->pf_np_arcs.p;
-    const size_t b_out = (size_t)cnt * 4 * 4, b_off = (size_t)cnt * (size_t)(n_paths + 1) * 4, b_tot = (size_t)cnt * (size_t)n_paths * 4,
-                 b_arcs = (size_t)cnt * (size_t)P.out_cap * 4;
-    if (d->pf_np_pin_bytes < b_out + b_off + b_tot + b_arcs) {
-      if (d->pf_np_pin) (void)hipHostFree(d->pf_np_pin);
-      d->pf_np_pin = nullptr;
-      d->pf_np_pin_bytes = 0;
-      HIP_TRY(hipHostMalloc(&d->pf_np_pin, b_out + b_off + b_tot + b_arcs, hipHostMallocDefault));
-      d->pf_np_pin_bytes = b_out + b_off + b_tot + b_arcs;
-    }
-    launch_nbest_paths(P, cnt, side, /*small=*/1);   // (determinized lattices of utterances: a hundred states each)
-    HIP_TRY(hipGetLastError());
-    char *pin = (char *)d->pf_np_pin;
-    HIP_TRY(hipMemcpyAsync(pin, P.out, b_out, hipMemcpyDeviceToHost, side));
-    HIP_TRY(hipMemcpyAsync(pin + b_out, P.out_off, b_off, hipMemcpyDeviceToHost, side));
-    HIP_TRY(hipMemcpyAsync(pin + b_out + b_off, P.out_tot, b_tot, hipMemcpyDeviceToHost, side));
-    HIP_TRY(hipMemcpyAsync(pin + b_out + b_off + b_tot, P.out_arcs, b_arcs, hipMemcpyDeviceToHost, side));
-    d->pf_npaths = n_paths;
-  }
   HIP_TRY(hipEventRecord(d->pf_ev_done, side));
   d->pf_pending = true;
   d->pf_detached = detached;
@@ -2714,68 +2316,7 @@ static int finish_prefetch(wfst_decoder *d) {
   d->pf_detached = false;
   d->pf_res.assign(d->pf_pin + (size_t)d->n_channels * 4, d->pf_pin + (size_t)d->n_channels * 4 + d->pf_list.size() * 4);
   // (a channel initialised or finalized anew since the launch: hooks in front of those calls came here first)
-  const int rc = harvest_determinized(d, d->pf_list, d->pf_res, false, 1, detached);
-  if (rc != WFST_OK || d->pf_npaths <= 0) return rc;
-  // ... and the paths NShortestPath found on those lattices: arc indices -> the labels and costs of the lattices just fetched
-  const int32_t n_paths = d->pf_npaths, cnt = (int32_t)d->pf_list.size(), out_cap = n_paths * 1024;
-  const char *pin = (const char *)d->pf_np_pin;
-  const int32_t *pout = (const int32_t *)pin;
-  const int32_t *poff = (const int32_t *)(pin + (size_t)cnt * 16);
-  const float *ptot = (const float *)(pin + (size_t)cnt * 16 + (size_t)cnt * (size_t)(n_paths + 1) * 4);
-  const int32_t *parcs = (const int32_t *)(pin + (size_t)cnt * 16 + (size_t)cnt * (size_t)(n_paths + 1) * 4 + (size_t)cnt * (size_t)n_paths * 4);
-  if (d->resc_cache.empty()) { d->resc_cache.resize((size_t)d->n_channels); d->nbp_cache.resize((size_t)d->n_channels); }
-  if (detached) { d->pf_nbp.assign((size_t)d->n_channels, wfst_decoder::NbPaths()); d->pf_nbp_have.assign((size_t)d->n_channels, 0); }
-  for (int i = 0; i < cnt; ++i) {
-    const int c = d->pf_list[(size_t)i];
-    const wfst_decoder::DetLattice &L = detached ? d->pf_cache[(size_t)c] : d->det_cache[(size_t)c];
-    const int32_t *o = pout + (size_t)4 * i;
-    if (L.err || o[2] == 1 || o[2] == 3) continue;   // (no lattice, or one beyond the prefetch's n-best bounds: asked for alone, the paths are computed then)
-    wfst_decoder::NbPaths R;
-    R.key.o = nullptr; R.key.n = nullptr; R.key.use_final = 1; R.key.n_paths = n_paths; R.key.decoded = d->h_decoded[c]; R.key.valid = true;
-    const int32_t found = L.n_states > 0 ? o[0] : 0, total = L.n_states > 0 ? o[1] : 0;
-    if (total > out_cap) continue;
-    R.off.assign(1, 0);
-    if (found) R.off.assign(poff + (size_t)i * (size_t)(n_paths + 1), poff + (size_t)i * (size_t)(n_paths + 1) + found + 1);
-    R.tot.assign(ptot + (size_t)i * (size_t)n_paths, ptot + (size_t)i * (size_t)n_paths + found);
-    R.olabel.resize((size_t)total); R.graph.resize((size_t)total); R.ac.resize((size_t)total);
-    bool ok = true;
-    for (int32_t k = 0; k < total && ok; ++k) {
-      const size_t aidx = (size_t)parcs[(size_t)i * (size_t)out_cap + (size_t)k];
-      if (aidx >= L.a.size()) { ok = false; break; }
-      R.olabel[(size_t)k] = L.a[aidx].z;
-      R.graph[(size_t)k] = L.w[aidx].x;
-      R.ac[(size_t)k] = L.w[aidx].y;
-    }
-    if (!ok) continue;
-    if (detached) { d->pf_nbp[(size_t)c] = R; d->pf_nbp_have[(size_t)c] = 1; }
-    // a channel that still holds the very utterance: wfst_decoder_get_nbest_paths(channel, n, 1, NULL, NULL) finds the work done
-    if (d->h_state[c] == 2 && (!detached || (d->det_cached[(size_t)c] && d->pf_epoch[(size_t)i] == d->fin_epoch[(size_t)c]))) d->nbp_cache[(size_t)c] = R;
-  }
-  return WFST_OK;
-}
-
-int wfst_decoder_get_prefetched_nbest_paths(wfst_decoder *d, int32_t channel, int32_t cap_paths, int32_t cap_arcs, int32_t *n_paths, int32_t *total_arcs,
-                                            int32_t *path_off, float *path_tot, int32_t *a_olabel, float *a_graph, float *a_acoustic) {
-  if (!d || channel < 0 || channel >= d->n_channels || !n_paths || !total_arcs) return fail(WFST_E_ARG, "bad argument");
-  *n_paths = 0;
-  *total_arcs = 0;
-  if (d->pf_nbp_have.empty() || !d->pf_nbp_have[(size_t)channel])
-    return fail(WFST_E_STATE, "no harvested detached prefetch with an n-best has covered this channel (or its lattice was beyond the prefetch's bounds)");
-  const wfst_decoder::NbPaths &R = d->pf_nbp[(size_t)channel];
-  const int32_t found = (int32_t)R.tot.size(), total = (int32_t)R.olabel.size();
-  *n_paths = found;
-  *total_arcs = total;
-  if (found > cap_paths || total > cap_arcs) return fail(WFST_E_CAPACITY, "n-best larger than the given capacities");
-  for (int32_t q = 0; q <= found; ++q)
-    if (path_off) path_off[q] = R.off[(size_t)q];
-  for (int32_t q = 0; q < found; ++q)
-    if (path_tot) path_tot[q] = R.tot[(size_t)q];
-  for (int32_t q = 0; q < total; ++q) {
-    if (a_olabel) a_olabel[q] = R.olabel[(size_t)q];
-    if (a_graph) a_graph[q] = R.graph[(size_t)q];
-    if (a_acoustic) a_acoustic[q] = R.ac[(size_t)q];
-  }
-  return WFST_OK;
+  return harvest_determinized(d, d->pf_list, d->pf_res, false, 1, detached);
 }
 
 // Waits for a prefetch in flight and takes its lattices over (what the next prefetch, or any other use of the determinizer, does
@@ -3091,7 +2632,7 @@ static int postprocess_batch(wfst_decoder *d, const int32_t *channels, int32_t n
     P.ws = d->np_ws.p; P.lists = d->np_lists.p;
     P.out = d->np_out.p; P.out_off = d->np_off.p; P.out_tot = d->np_tot.p;
     P.out_arcs = d->np_arcs.p; P.out_cap = (int32_t)out_cap;
-    launch_nbest_paths(P, cnt, d->stream, /*small=*/(ns_max <= 1024 && n_paths <= 64) ? 1 : 0);
+    launch_nbest_paths(P, cnt, d->stream);
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> pout((size_t)cnt * 4), poff((size_t)cnt * (size_t)(n_paths + 1));
     std::vector<float> ptot((size_t)cnt * (size_t)n_paths);
@@ -3116,10 +2657,7 @@ static int postprocess_batch(wfst_decoder *d, const int32_t *channels, int32_t n
       if (found) R.off.assign(poff.begin() + (long)i * (n_paths + 1), poff.begin() + (long)i * (n_paths + 1) + found + 1);
       R.tot.assign(ptot.begin() + (long)i * n_paths, ptot.begin() + (long)i * n_paths + found);
       std::vector<int32_t> arcs((size_t)total);
-      if (total) {
-        HIP_TRY(hipMemcpyAsync(arcs.data(), P.out_arcs + (size_t)i * (size_t)P.out_cap, (size_t)total * 4, hipMemcpyDeviceToHost, d->stream));
-        HIP_TRY(hipStreamSynchronize(d->stream));
-      }
+      if (total) HIP_TRY(hipMemcpy(arcs.data(), P.out_arcs + (size_t)i * (size_t)P.out_cap, (size_t)total * 4, hipMemcpyDeviceToHost));
       R.olabel.resize((size_t)total); R.graph.resize((size_t)total); R.ac.resize((size_t)total);
       for (int32_t k = 0; k < total; ++k) {
         const size_t aidx = (size_t)arcs[(size_t)k];
@@ -3346,36 +2884,11 @@ int wfst_decoder_get_lattice_stats(wfst_decoder *d, int32_t channel, int64_t sta
   return WFST_OK;
 }
 
-int wfst_decoder_get_determinizer_ms(wfst_decoder *d, int32_t channel, float *ms) {
-  if (!d || !ms || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
-  *ms = 0.0f;
-  const wfst_decoder::DetLattice *L = nullptr;
-  if (!d->det_cached.empty() && d->det_cached[(size_t)channel]) L = &d->det_cache[(size_t)channel];
-  else if (!d->pf_have.empty() && d->pf_have[(size_t)channel]) L = &d->pf_cache[(size_t)channel];
-  if (!L) return fail(WFST_E_STATE, "no determinized lattice of this channel is held");
-  *ms = (float)((double)L->ticks / 1e5);   // (100 MHz)
-  return WFST_OK;
-}
-
-int wfst_decoder_get_prune_raw_abandoned(wfst_decoder *d, int32_t channel, int32_t *n_passes) {
-  if (!d || !n_passes || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
-  if (!d->D.lattice) return fail(WFST_E_STATE, "lattice statistics need a decoder created with wfst_limits.lattice_links > 0");
-  HIP_TRY(hipSetDevice(d->device));
-  for (hipStream_t st : d->gstreams) if (st) HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipMemcpyAsync(n_passes, d->prune_par.p + (size_t)channel * kPruneParInts + kPrRawAbandonCount, sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  if (!d->D.prune_raw) *n_passes = -1;   // (the several-workgroup raw pass is off on this device: nothing to abandon)
-  return WFST_OK;
-}
-
 int wfst_decoder_get_degraded_frames(wfst_decoder *d, int32_t channel, int32_t *n_frames) {
   if (!d || !n_frames || channel < 0 || channel >= d->n_channels) return fail(WFST_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(d->device));
-  if (!d->deg_cache.empty() && d->deg_cache[(size_t)channel] >= 0) { *n_frames = d->deg_cache[(size_t)channel]; return WFST_OK; }   // (a list fetch has read it since the channel's last call)
-  hipStream_t st = d->stream;
-  { const int32_t c = channel; const int rc = results_stream_behind(d, &c, 1, &st); if (rc != WFST_OK) return rc; }   // (behind the channel's own work, not the others')
-  HIP_TRY(hipMemcpyAsync(n_frames, d->degraded.p + channel, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipMemcpyAsync(n_frames, d->degraded.p + channel, sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
   return WFST_OK;
 }
 

@@ -1411,10 +1411,7 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
                 // after rounding): the first to swap the slot's value away is the one
                 // (the claimed value keeps the cost: lattice mode reads it back for the links, pass 3; its low word, arc bits and flags
                 // all ones, is no record's -- row indices stay below kNoArc)
-                // biglm likewise: two tokens of ONE graph state (different LM pairs) whose histories have cost the same take the same
-                // arc into the same LM pair (back-off merges them) at the same cost -- the same packed value twice.  Both "won", the
-                // item wrote one token more than the keys it had counted, over its neighbour's first (found by a fuzz seed, round 6).
-                winner = vals[slot] == packed && (!(kFused || kBig) || atomicCAS(&vals[slot], packed, packed | 0xFFFFFFFFull) == packed);
+                winner = vals[slot] == packed && (!kFused || atomicCAS(&vals[slot], packed, packed | 0xFFFFFFFFull) == packed);
                 in_table = true;
                 break;
               }
@@ -1527,12 +1524,6 @@ __device__ __forceinline__ void insert_body(const DecoderDev &D, int group, int 
           else atomicOr(&ctl->error, kErrWorklistFull);
         }
       }
-    }
-    if constexpr (kBig) {
-      // the invariant the claim above keeps: one winner per key -- an item that wrote more tokens than it had counted would have
-      // written over its neighbour's (loud, not silent: WFST_E_DEVICE)
-      __syncthreads();
-      if (tid == 0 && s_wpos != ns) atomicOr(&ctl->error, kErrInternal);
     }
     // pass 3 (lattice mode): every surviving candidate is a forward link of the lattice
     // (base-inl.h:340-341), source token -> the token that won its next state
@@ -2681,14 +2672,6 @@ constexpr int kPrRawChg = 34;    // [3]: "an extra moved" of an epsilon round, i
 #define WFST_PR_RAW_J 16
 #endif
 constexpr int kPrRawJ = WFST_PR_RAW_J;      // workgroups per channel and raw frame
-// (kPrRawAbandon = 37, kPrRawAbandonCount = 38: wfst_device.h)
-constexpr int kClSlabWordAt = kClSlabWord;   // (wfst_device.h)
-constexpr int kPrRawPoison = 0x40000000;   // set in the meeting counter by the workgroup that gives up: the others leave at once
-// the channel's parameter block is laid out by hand: the ranges must not meet whatever -D overrides a build carries
-static_assert(kPrRawChg + 3 <= kPrRawAbandon && kPrRawAbandonCount < kPrSlabBase, "prune_par: raw-pass words overlap");
-static_assert(kPrSlabBase + 2 * kPrSlabs <= kClSlabWordAt, "prune_par: slab counts run into the closure launch's meeting word (WFST_PR_SLABS too large)");
-static_assert(16 + 10 <= kPrRawCount, "prune_par: lattice_emit's counters [16, 26)");
-static_assert(kClSlabWordAt % 2 == 0 && kClSlabWordAt + 2 <= kPruneParInts, "prune_par: the closure launch's 64-bit meeting word");
 struct ScanShared {
   u64 red[2][kBT / 64];
   int changed, any_changed, cnt, err;
@@ -3682,13 +3665,6 @@ __global__ __launch_bounds__(kBT) void closure_kernel(DecoderDev D, const int32_
     if (!finalize_frame<kLat, kBig>(D, c, ctl, sh, slab, n_slabs)) return;
   } else if (slab != 0) {
     return;
-  } else if (n_slabs > 1) {
-    // The invariant above, enforced: this launch never makes a channel active that was idle at its start (a workgroup of the
-    // channel dispatched later would then read active = 1 and close a frame that is not there).  The host starts every
-    // channel's frames with a one-workgroup launch (wfst_capi.cc advance_device); a channel found idle here that could go on
-    // is a host-side ordering bug and is flagged, not run.
-    if (threadIdx.x == 0 && do_prep && ctl->n_decoded < target[c] && ctl->error == 0 && !ctl->finalized) ctl->error |= kErrInternal;
-    return;
   }
   __syncthreads();
   if constexpr (kLat) {
@@ -3743,17 +3719,8 @@ __global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const 
   int32_t *pp = D.prune_par + (size_t)c * kPrParInts;
   // (did lattice_prune_raw_kernel, the launch before, price this channel's raw frames?  The same function of the channel's control
   // block that launch decided by -- no flag to go stale)
-  // A raw launch that gave the channel up (a workgroup waited too long at a meeting: a chip shared with other processes, a part
-  // with fewer compute units than the grid assumes) has left extras that are not final, and only dead marks that are (it marks
-  // a link behind a COMPLETED meeting only): this walk prices the raw frames itself, from their +inf, on its one-workgroup path --
-  // the same lattice, later.  No error: wfst_decoder_get_prune_raw_abandoned counts it.
-  const bool abandoned = raw && pp[kPrRawAbandon] != 0;
-  const bool raw_done = raw && !abandoned && prune_due_raw(D, c, target);
-  __syncthreads();   // (every thread has read the words lane 0 resets)
-  if (threadIdx.x == 0) {
-    pp[0] = 0; pp[kPrRawCount] = 0;   // (the raw launch's meeting counter: back to 0 for the next pass)
-    if (abandoned) { pp[kPrRawAbandon] = 0; pp[kPrRawAbandonCount] += 1; }
-  }
+  const bool raw_done = raw && prune_due_raw(D, c, target);
+  if (threadIdx.x == 0) { pp[0] = 0; pp[kPrRawCount] = 0; }   // (the raw launch's meeting counter: back to 0 for the next pass)
   __syncthreads();
   if (prune_due(D, c, target)) prune_pass<false>(D, c, ps, raw_done);
   (void)sh; (void)group; (void)par;
@@ -3780,26 +3747,19 @@ __global__ __launch_bounds__(kBT) void lattice_prune_kernel(DecoderDev D, const 
 constexpr int kPrRawT = WFST_PR_RAW_T;
 constexpr int kPrRawU = WFST_PR_RAW_U;
 
-// all the workgroups of the channel meet: *seq counts this workgroup's barriers.  false: the meeting did not complete -- this
-// workgroup waited kPrRawWaitTicks of the constant 100 MHz clock (never expected: a workgroup of the channel that is not
-// resident) or another one did and POISONED the counter (so that nobody else waits its own time-out out); the caller stops.
-constexpr unsigned long long kPrRawWaitTicks = 4000000ull;   // 40 ms
-__device__ __forceinline__ bool raw_barrier(int32_t *cnt, int J, int *seq, bool release, bool skip_arrival = false) {
+// all the workgroups of the channel meet: *seq counts this workgroup's barriers
+__device__ __forceinline__ bool raw_barrier(int32_t *cnt, int J, int *seq, bool release) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores and atomics have been acknowledged
   __syncthreads();
   __shared__ int s_ok;
   if (threadIdx.x == 0) {
     if (release) __threadfence();
     const int want = (*seq + 1) * J;
-    if (!skip_arrival) atomicAdd(cnt, 1);
+    atomicAdd(cnt, 1);
     int ok = 1;
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-      const int v = ld_agent(cnt);
-      if (v & kPrRawPoison) { ok = 0; break; }
-      if (v >= want) break;
+    for (unsigned spin = 0; ld_agent(cnt) < want; ++spin) {
       __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > kPrRawWaitTicks) { atomicOr(cnt, kPrRawPoison); ok = 0; break; }
+      if (spin > (1u << 19)) { ok = 0; break; }   // (~a quarter of a second; never expected: a workgroup of the channel that does not run)
     }
     if (release) __threadfence();
     s_ok = ok;
@@ -3874,9 +3834,7 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
       __hip_atomic_store(reinterpret_cast<u64 *>(&extra[i]), (u64)(i >= fn ? kZeroO : kInfO) | (D.link_delta ? 0ull : (u64)(uint32_t)tok[i].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (link_delta: the cost half is read by nobody)
     if (j == 0 && tid < 3) __hip_atomic_store(&chg[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // (wfst_options.debug 0x400, for the tests: the channel's last workgroup never arrives at the first meeting -- the others time out,
-  // the pass is abandoned and lattice_prune_kernel prices the raw frames)
-  ok = raw_barrier(cnt, J, &seq, true, (D.dbg & 0x400) && J > 1 && j == J - 1);   // (plain stores: written back before anybody's atomics and agent loads meet them)
+  ok = raw_barrier(cnt, J, &seq, true);   // (plain stores: written back before anybody's atomics and agent loads meet them)
   // link_extra as prune_pass computes it (base-inl.h:524-526)
   auto link_extra = [&](const int4 &L, u64 e) -> float {
     const uint32_t eo = (uint32_t)e;
@@ -3910,7 +3868,7 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
     });
     ok = raw_barrier(cnt, J, &seq, false);
     // ---- the epsilon links inside frame k, to their fixpoint ----
-    if (e0 < e1 && ok) {
+    if (e0 < e1) {
       for (int round = 0; round < 4096 && ok; ++round) {
         int ch = 0;
         for_links(e0, e1, [&](int, const int4 &L, float le) {
@@ -3923,10 +3881,9 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
         if (__any(ch) && (tid & 63) == 0) atomicOr(&chg[fl], 1);
         if (j == 0 && tid == 0) __hip_atomic_store(&chg[(fl + 1) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (last read two barriers ago)
         ok = raw_barrier(cnt, J, &seq, false);
-        if (!ok || !ld_agent(&chg[fl])) break;
+        if (!ld_agent(&chg[fl])) break;
       }
-      // (dead marks only behind a completed meeting: the extras they are judged on are final then)
-      if (ok) for_links(e0, e1, [&](int i, const int4 &, float le) {
+      for_links(e0, e1, [&](int i, const int4 &, float le) {
         if (!(le <= lb)) links[i].x = -1;
       });
       // (the flags of the next frame's rounds: every workgroup has read this frame's last one -- it was 0 -- or will read 0)
@@ -3938,10 +3895,8 @@ __global__ __launch_bounds__(kPrRawT) void lattice_prune_raw_kernel(DecoderDev D
   if (j == 0 && tid == 0) {
     D.lat_stats[(size_t)c * 4 + 1] += st_links;
     D.lat_stats[(size_t)c * 4 + 2] += st_toks;
+    if (!ok) atomicOr(&ctl->error, kErrInternal);
   }
-  // Nothing this launch writes is read by its own share-out table (prune_due_raw reads the control block, which stays as it is):
-  // a workgroup dispatched late computes the same (c, j, J) as the others.  The give-up goes to the parameter block.
-  if (!ok && tid == 0) __hip_atomic_store(&pp[kPrRawAbandon], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the compaction's flag sweeps: kPrSlabs workgroups per channel
 __global__ __launch_bounds__(kBT) void lattice_prune_flags_kernel(DecoderDev D, int chan_off) {
@@ -3978,7 +3933,6 @@ __global__ __launch_bounds__(kBT) void init_kernel(DecoderDev D, const int32_t *
   __syncthreads();
   if (tid == 0) {
     if (D.lat_stats) for (int q = 0; q < 4; ++q) D.lat_stats[(size_t)c * 4 + q] = 0;
-    if (D.lattice && D.prune_par) { int32_t *pp = D.prune_par + (size_t)c * kPrParInts; pp[kPrRawCount] = 0; pp[kPrRawAbandon] = 0; pp[kPrRawAbandonCount] = 0; }
     D.emit_cnt[c * 32] = 0;
     D.degraded[c] = 0;
     ChanCtl z;
@@ -4318,7 +4272,6 @@ __global__ __launch_bounds__(kBpThreads) void best_path_kernel(DecoderDev D, con
 // 670-720, 924-940): the graph-final tokens of the newest frame if there are any, else all of it.
 constexpr int kEmitFrames = 4096, kEmitU = 8;   // frames whose bounds the emit kernels keep in LDS (longer utterances read them from HBM); items per thread and sweep
 constexpr int kEmitSlabs = 8;                   // workgroups per channel of the emit sweeps
-static_assert(16 + kEmitSlabs + 2 <= kPrRawCount, "prune_par: lattice_emit's slab counts [16, 16 + kEmitSlabs + 2) run into the raw pass's words");
 // GetRawLattice's listing (base-inl.h:869-975) of what is alive in the arena and in the link store -- after FinalizeDecoding, or
 // mid-utterance -- into lat_toks[] (arena order = frame order: the n-best search relies on a frame's states being contiguous) and
 // lat_arcs[] (any order).  Both stores hold their dead as holes (a channel at beam 13: 130-330 k arena entries for 1-2.5 k living
@@ -4599,17 +4552,6 @@ void launch_closure(const DecoderDev &D, int chan_off, int chan_cnt, const int32
   else
     hipLaunchKernelGGL((closure_kernel<false, false>), dim3(chan_cnt), dim3(kBT), 0, s, D, target, do_prep, chan_off, group, par, chan_cnt, 1);
 }
-// How many workgroups of lattice_prune_raw_kernel the device holds at once.  Its workgroups WAIT for each other inside an ordinary
-// launch: that is only sound while every workgroup of every launch that may run at the same time is resident (wfst_capi.cc enables
-// the several-workgroup raw pass only then; a wait that still runs into its time-out -- a chip shared with other processes -- falls
-// back to the one-workgroup walk, it fails nothing).
-int prune_raw_resident_workgroups(int device) {
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lattice_prune_raw_kernel, kPrRawT, 0) != hipSuccess) return 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-  return per_cu * cus;
-}
-int prune_raw_grid(int chan_cnt) { return kPrRawJ * chan_cnt; }
 void launch_lattice_prune_step(const DecoderDev &D, int chan_off, int chan_cnt, const int32_t *target, int group, int par, hipStream_t s, int stage) {
   // the raw frames (kPrRawJ workgroups per channel), the walk over the frames priced before (one workgroup per
   // channel, 130 KB of LDS), the compaction's flag sweeps (kPrSlabs workgroups per channel), its moves + the next frame's preparation

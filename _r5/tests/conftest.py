@@ -1,0 +1,84 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+# (as bench.py: eight hardware queues for the process's HIP streams, set before anything starts the HIP runtime)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # no test of this suite needs more than a minute; a hang (e.g. a checker that does not terminate)
+    # must not take the whole run with it
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 600
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("asr-decoder_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import pyoracle
+
+    pyoracle.build_oracle()
+    return pyoracle.OracleDecoder()
+
+
+@pytest.fixture(scope="session")
+def refdec():
+    import pyoracle
+
+    if os.path.isdir("/root/reference/src"):
+        pyoracle.build_ref()
+    if not os.path.exists(pyoracle.REF_SO):
+        pytest.skip("oracle/_ref/libref_decoder.so not built (reference tree absent)")
+    return pyoracle.RefDecoder()
+
+
+def _campaign_options():
+    """Hand-run campaigns: WFST_TEST_OPTIONS="log2_partitions=1,joint_max=64" (and WFST_TEST_GRAPH_OPTIONS="row_align_slots=1")
+    make every decoder / graph a test creates WITHOUT options of its own use these wfst_options / wfst_graph_options: the
+    suite then runs under extreme settings of the scheduling knobs (tiny LDS tables, one partition, grids of 3 workgroups,
+    three channel groups, no hipGraph, packed rows ...).  A test-side switch: the library itself reads no environment."""
+    spec, gspec = os.environ.get("WFST_TEST_OPTIONS"), os.environ.get("WFST_TEST_GRAPH_OPTIONS")
+    if not spec and not gspec:
+        return
+    pkg = importlib.import_module("asr-decoder_amd")
+    W = pkg.wfstdec
+    parse = lambda s: {k: int(v) for k, v in (kv.split("=") for kv in s.split(",") if kv)}
+    if spec:
+        kw = parse(spec)
+        init = W.BatchDecoder.__init__
+
+        def patched(self, *a, **k):
+            if k.get("options") is None:
+                k["options"] = W.Options(**kw)
+            init(self, *a, **k)
+
+        W.BatchDecoder.__init__ = patched
+    if gspec:
+        gkw = parse(gspec)
+        for name in ("load", "from_arrays"):
+            orig = getattr(W.Graph, name)
+
+            def make(orig):
+                def f(*a, **k):
+                    if k.get("options") is None:
+                        k["options"] = W.GraphOptions(**gkw)
+                    return orig(*a, **k)
+                return staticmethod(f)
+
+            setattr(W.Graph, name, make(orig.__func__ if hasattr(orig, "__func__") else orig))
+
+
+_campaign_options()
