@@ -19,6 +19,8 @@ The "hclg-like" recipe is SURVEY.md section 8(d).  numpy only; no GPU, no torch.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 ARC_DTYPE = np.dtype([("ilabel", "<i4"), ("olabel", "<i4"), ("w", "<f4"), ("to", "<i4")])
@@ -75,6 +77,10 @@ class Graph:
             raise IOError("truncated graph file: %s" % path)
         return Graph(start, final_state, si, arcs)
 
+
+# (test campaigns only: WFST_SYNTH_SEED_OFFSET shifts every generator seed of this module -- other graphs and log-likelihoods through
+# the same tests; the bench and the default test runs leave it unset)
+_SEED_OFFSET = int(os.environ.get("WFST_SYNTH_SEED_OFFSET", "0") or 0)
 
 def to_openfst_bytes(g, fst_type="vector", aligned=False, flags=0):
     """The flat graph `g` as an OpenFst binary file (StdArc), the input side of the ingestion
@@ -173,7 +179,7 @@ def make_hclg_like(
 
     ~3.5 arcs/state: S=14k -> A~50k (config 1), S=2.85M -> A~10.1M (configs 2/3).
     """
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + _SEED_OFFSET)
     S = int(n_states)
     final_state = S
 
@@ -270,7 +276,7 @@ def make_loglikes(graph, T, n_pdf, tid2pdf, seed, mu=-2.6, sigma=1.0, p_eps_step
     The planted path is a random walk over the graph from the start state; at every frame
     the pdf of the emitting arc it takes is set to U(-1, 0).  Returns (loglikes, planted_tids).
     """
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + _SEED_OFFSET)
     ll = rng.normal(mu, sigma, size=(T, n_pdf)).astype(np.float32)
     off = graph.row_offsets()
     si = graph.state_info
@@ -312,7 +318,7 @@ def make_loglikes_multi(graph, T, n_pdf, tid2pdf, seed, n_paths=256, mu=-4.5, si
     frontier size is proportional to ``n_paths`` and stable from frame to frame.
     Vectorised over paths (one numpy step per frame).  Returns (loglikes, None).
     """
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + _SEED_OFFSET)
     ll = rng.normal(mu, sigma, size=(T, n_pdf)).astype(np.float32)
     key = id(graph)
     if key not in _cache:
