@@ -167,7 +167,9 @@ def test_50k_arc_graph_with_a_100k_ngram_lm_pair(synth, oracle, tmp_path):
             want = [pyoracle.biglm_decode(oracle, h, pyoracle.Config(**cd), o1, o2, x, m, fixed=True) for x in mats]
         finally:
             oracle.set_order_free(False)
-        assert min_ok <= sum(int(o.ok) for o in want) <= max_ok and all(o.extra["lm_oob"] == 0 for o in want)
+        assert all(o.extra["lm_oob"] == 0 for o in want)
+        if __import__("os").environ.get("WFST_SYNTH_SEED_OFFSET", "0") in ("", "0"):   # (how many of the DEFAULT utterances keep a path at this lattice beam)
+            assert min_ok <= sum(int(o.ok) for o in want) <= max_ok
         if lb == 25.0:
             want25 = want
         for chunk in (0, 13):
