@@ -406,7 +406,9 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
     host = os.path.join(ROOT, "asr-decoder_amd", "host")
     subprocess.check_call(["make", "-s", "-C", host])
     cli = os.path.join(host, "wfst-decode")
-    tmp = tempfile.mkdtemp(prefix="wfst_dropin_", dir="/tmp")
+    # (the utterances' file -- 460 MB -- in memory where the box has a tmpfs: on a disk-backed /tmp its write-back ran beside the
+    # leg's first CLI runs, which then came out at half the rate of the later ones)
+    tmp = tempfile.mkdtemp(prefix="wfst_dropin_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp")
     try:
         B, T, P = mats.shape
         np.asarray(m, "<i4").tofile(os.path.join(tmp, "tid2pdf.bin"))
@@ -418,6 +420,7 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
                 key = ("utt%04d" % i).encode()
                 f.write(struct.pack("<i", len(key)) + key + struct.pack("<ii", T, P))
                 f.write(np.ascontiguousarray(mats[i], "<f4").tobytes())
+        os.sync()
         common = [cli, "--tid2pdf=" + os.path.join(tmp, "tid2pdf.bin"), "--chunk=%d" % chunk,
                   "--max-frames=%d" % (T + 2), "--max-tokens=%d" % a.max_tokens, "--arena-tokens=%d" % int(T * a.arena_per_frame)]
         tail = [os.path.join(tmp, "decoder.conf"), gpath, os.path.join(tmp, "ll.bin")]
