@@ -976,8 +976,14 @@ def main():
         gc.collect()
         gc.disable()
         t0 = time.perf_counter()
+        per_step = [] if os.environ.get("WFST_BENCH_PER_STEP") else None   # (experiment: every step's own wall time, to stderr)
         for _ in range(steps):
+            ts = time.perf_counter()
             res = step()
+            if per_step is not None:
+                per_step.append(round(1e3 * (time.perf_counter() - ts), 2))
+        if per_step:
+            log("[rank %d] ms of each timed step: %s" % (rank, per_step))
         if hasattr(step, "drain"):
             step.drain(res)
         fence()
