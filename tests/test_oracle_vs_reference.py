@@ -1,6 +1,8 @@
 """Pin the oracle against the reference decoder itself (oracle/_ref, built from
 /root/reference by oracle/Makefile) on fresh seeded inputs, beyond the committed goldens.
 Skipped where neither the reference tree nor a prebuilt oracle/_ref exists."""
+import os
+
 import numpy as np
 import pytest
 
@@ -54,7 +56,7 @@ def test_oracle_matches_reference_on_random_graphs(block, oracle, refdec, synth,
     the oracle against the reference decoder itself."""
     from test_gpu_fuzz import random_graph
 
-    rng = np.random.default_rng(99 + block)
+    rng = np.random.default_rng(int(os.environ.get("WFST_FUZZ_SEED", "99")) + block)   # WFST_FUZZ_SEED: other campaigns
     n = 0
     for case in range(10):
         n_states = int(rng.integers(4, 70))
