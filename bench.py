@@ -408,7 +408,7 @@ def dropin_leg(a, gpath, mats, m, cd, gpu_res, cpu_baseline, threads=64, chunk=2
     cli = os.path.join(host, "wfst-decode")
     # (the utterances' file -- 460 MB -- in memory where the box has a tmpfs: on a disk-backed /tmp its write-back ran beside the
     # leg's first CLI runs, which then came out at half the rate of the later ones)
-    tmp = tempfile.mkdtemp(prefix="wfst_dropin_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp")
+    tmp = tempfile.mkdtemp(prefix="wfst_dropin_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and __import__("shutil").disk_usage("/dev/shm").free > (2 << 30) else "/tmp")
     try:
         B, T, P = mats.shape
         np.asarray(m, "<i4").tofile(os.path.join(tmp, "tid2pdf.bin"))
